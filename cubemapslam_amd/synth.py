@@ -1,0 +1,229 @@
+"""Deterministic synthetic inputs for the hot path (numpy only; harness code, not the product compute path).
+
+Camera intrinsics are the values of the reference's Config/*.yaml (lafida_cam0_params.yaml, front_cam_params.yaml);
+datasets are not available, so images / masks / BA problems are generated here.
+"""
+import numpy as np
+
+LAFIDA = dict(
+    c=0.999626131079017, d=-0.0034775192597376, e=0.00385134991673147, u0=392.219508388648, v0=243.494438476351,
+    invpol=[293.667187375663, 149.982043337335, -10.448650568161, 28.2295300683376, 7.13365723186292,
+            0.056303218962532, 10.4144677485333, 0.166354960773665, -5.86858687381081, 1.18165998645705,
+            3.1108311354746, 0.810799620714366],
+    pol=[-209.200757992065, 0.0, 0.00213741670953883, -4.2203617319086e-06, 1.77146086919594e-08],
+    Iw=754, Ih=480, fov_deg=190.0, nfeatures=2000)
+
+FRONT = dict(
+    c=0.999896, d=0.000052, e=0.000010, u0=653.580142, v0=359.303805,
+    invpol=[583.462246, 454.202253, 13.957207, -19.762352, 80.087582, 42.643599, -90.924921, -114.523166,
+            -50.405891, -8.090297],
+    pol=[-3.120719e+02, 0.0, 1.007745e-03, -9.430929e-07, 1.348974e-09],
+    Iw=1280, Ih=720, fov_deg=190.0, nfeatures=3000)
+
+
+def camera(name="lafida", face=450, Ih=None):
+    base = dict(LAFIDA if name == "lafida" else FRONT)
+    base["invpol"] = list(base["invpol"])
+    base["face"] = int(face)
+    if Ih is not None and Ih != base["Ih"]:  # config 2: 1280x1024 synthetic variant of front_cam (v0 shifted with the centre)
+        base["v0"] = base["v0"] + (Ih - base["Ih"]) / 2.0
+        base["Ih"] = int(Ih)
+    return base
+
+
+def texture(h, w, seed):
+    """Seeded gray texture with corners at many scales: value-noise octaves + random rectangles."""
+    rs = np.random.RandomState(seed)
+    img = np.zeros((h, w), np.float64)
+    for cell, amp in ((64, 60.0), (24, 45.0), (9, 30.0), (4, 18.0)):
+        gh, gw = h // cell + 2, w // cell + 2
+        g = rs.randint(0, 256, size=(gh, gw)).astype(np.float64) / 255.0 - 0.5
+        yy = (np.arange(h) / cell)
+        xx = (np.arange(w) / cell)
+        y0 = yy.astype(int); x0 = xx.astype(int)
+        fy = (yy - y0)[:, None]; fx = (xx - x0)[None, :]
+        a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+        img += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+    img += 128.0
+    nrect = (h * w) // 1500
+    ys = rs.randint(0, h, nrect); xs = rs.randint(0, w, nrect)
+    hs = rs.randint(3, 40, nrect); ws = rs.randint(3, 40, nrect)
+    vs = rs.randint(-70, 71, nrect)
+    for y, x, hh, ww, v in zip(ys, xs, hs, ws, vs):
+        img[y:y + hh, x:x + ww] += v
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def _horner(coefs, x):
+    r = np.zeros_like(x)
+    for c in coefs[::-1]:
+        r = r * x + c
+    return r
+
+
+def world_to_img(cam, X):
+    """Vectorised CamModelGeneral::WorldToImg (harness use only, not bit-critical)."""
+    x, y, z = X[..., 0], X[..., 1], X[..., 2]
+    n = np.sqrt(x * x + y * y)
+    n = np.where(n == 0, 1e-14, n)
+    theta = np.arctan(-z / n)
+    inv = list(cam["invpol"]) + [0.0] * (12 - len(cam["invpol"]))
+    rho = _horner(inv, theta)
+    uu = x / n * rho
+    vv = y / n * rho
+    return uu * cam["c"] + vv * cam["d"] + cam["u0"], uu * cam["e"] + vv + cam["v0"]
+
+
+_F2R = {0: lambda x, y, z: (x, y, z), 1: lambda x, y, z: (-z, y, x), 2: lambda x, y, z: (z, y, -x),
+        3: lambda x, y, z: (x, -z, y), 4: lambda x, y, z: (x, z, -y)}  # face -> rig (FRONT, LEFT, RIGHT, UPPER, LOWER)
+_FACE_ORIGIN = {0: (1, 1), 1: (0, 1), 2: (2, 1), 3: (1, 0), 4: (1, 2)}  # (col, row) of each face on the 3x3 cross
+
+
+def cubemap_valid_mask(cam, erode=20, band=70):
+    """Model-derived cubemap mask: pixels whose LUT entry lands inside the fisheye image, eroded, outer band zeroed."""
+    from scipy import ndimage
+    F = cam["face"]; W = 3 * F
+    m = np.zeros((W, W), bool)
+    jj, ii = np.meshgrid(np.arange(F, dtype=np.float64), np.arange(F, dtype=np.float64))
+    for f, (cx_, cy_) in _FACE_ORIGIN.items():
+        x = (jj - F / 2.0) / (F / 2.0); y = (ii - F / 2.0) / (F / 2.0); z = np.ones_like(x)
+        rx, ry, rz = _F2R[f](x, y, z)
+        u, v = world_to_img(cam, np.stack([rx, ry, rz], -1))
+        ok = (u >= 0) & (u < cam["Iw"]) & (v >= 0) & (v < cam["Ih"])
+        m[cy_ * F:(cy_ + 1) * F, cx_ * F:(cx_ + 1) * F] = ok
+    if erode > 0:
+        m = ndimage.binary_erosion(m, iterations=erode)
+    if band > 0:
+        m[:band] = False; m[-band:] = False; m[:, :band] = False; m[:, -band:] = False
+    return (m.astype(np.uint8) * 255)
+
+
+def rays_to_cubemap(F, X):
+    """Vectorised TransformRaysToCubemap in float64 (harness use: building synthetic observations)."""
+    x, y, z = X[..., 0], X[..., 1], X[..., 2]
+    face = np.full(x.shape, -1, np.int32)
+    up = np.full(x.shape, -1.0); vp = np.full(x.shape, -1.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        conds = [
+            (0, (z > 0) & (np.abs(x / z) <= 1) & (np.abs(y / z) <= 1), (x, y, z), (1, 1)),
+            (2, (x > 0) & (np.abs(y / x) <= 1) & (np.abs(z / x) <= 1), (-z, y, x), (2, 1)),
+            (1, (x < 0) & (np.abs(y / x) <= 1) & (np.abs(z / x) <= 1), (z, y, -x), (0, 1)),
+            (4, (y > 0) & (np.abs(x / y) <= 1) & (np.abs(z / y) <= 1), (x, -z, y), (1, 2)),
+            (3, (y < 0) & (np.abs(x / y) <= 1) & (np.abs(z / y) <= 1), (x, z, -y), (1, 0)),
+        ]
+        todo = np.ones(x.shape, bool)
+        for fid, c, (lx, ly, lz), (ox, oy) in conds:
+            sel = todo & c
+            u = lx * (F / 2.0) / lz + F / 2.0
+            v = ly * (F / 2.0) / lz + F / 2.0
+            inb = sel & (u >= 0) & (u < F) & (v >= 0) & (v < F)
+            face[inb] = fid; up[inb] = u[inb] + ox * F; vp[inb] = v[inb] + oy * F
+            todo &= ~sel
+    return face, up, vp
+
+
+def face_of_pixel(F, px, py):
+    i = np.floor(px / F).astype(int); j = np.floor(py / F).astype(int)
+    face = np.full(px.shape, -1, np.int32)
+    for f, (cx_, cy_) in _FACE_ORIGIN.items():
+        face[(i == cx_) & (j == cy_)] = f
+    return face
+
+
+def _rot(axis, ang):
+    axis = np.asarray(axis, float); axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def _quat_from_R(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0); w = 0.5 * s; s = 0.5 / s
+        q = [(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w]
+    else:
+        i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (j + 1) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q = [0, 0, 0, 0]; q[i] = 0.5 * s; s = 0.5 / s
+        q[3] = (R[k, j] - R[j, k]) * s; q[j] = (R[j, i] + R[i, j]) * s; q[k] = (R[k, i] + R[i, k]) * s
+    q = np.array(q)
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def ba_problem(K=20, P=20000, obs_per_point=4, F=650, seed=42, outlier_frac=0.05, nlevels=8, scale=1.2):
+    """Config 4 of BASELINE.json: K keyframes on a 2 m arc (KF 0 fixed), P points, obs_per_point views each."""
+    rs = np.random.RandomState(seed)
+    Rt, tt = [], []
+    for k in range(K):
+        a = (k / max(K - 1, 1) - 0.5) * 0.6
+        Rwc = _rot([0, 1, 0], a) @ _rot([1, 0, 0], 0.05 * np.sin(3 * a))
+        cw = np.array([2.0 * np.sin(a) / 0.6, 0.05 * np.cos(5 * a), 0.3 * (1 - np.cos(a))])
+        Rcw = Rwc.T
+        Rt.append(Rcw); tt.append(-Rcw @ cw)
+    Rt = np.array(Rt); tt = np.array(tt)
+    pts = np.stack([rs.uniform(-6, 6, P), rs.uniform(-3, 3, P), rs.uniform(-2, 9, P)], -1)
+    near = np.linalg.norm(pts, axis=1) < 1.5
+    pts[near] += np.array([0, 0, 4.0])
+    sig2 = (np.float32(scale) ** np.arange(nlevels, dtype=np.float32)) ** 2
+    inv_sig2_tab = (np.float32(1.0) / sig2.astype(np.float32)).astype(np.float32)
+    e_pose, e_point, e_obs, e_inv, e_face = [], [], [], [], []
+    for p in range(P):
+        ks = rs.permutation(K)
+        got = 0
+        for k in ks:
+            if got >= obs_per_point:
+                break
+            Xc = Rt[k] @ pts[p] + tt[k]
+            ray = Xc / np.linalg.norm(Xc)
+            if ray[2] < np.cos(np.deg2rad(190.0 / 2)):
+                continue
+            face, up, vp = rays_to_cubemap(F, Xc[None, :])
+            if face[0] < 0:
+                continue
+            octave = rs.randint(0, nlevels)
+            sd = scale ** octave
+            if rs.uniform() < outlier_frac:
+                noise = rs.uniform(-30, 30, 2)
+            else:
+                noise = rs.normal(0, sd, 2)
+            px = np.float32(up[0] + noise[0]); py = np.float32(vp[0] + noise[1])
+            f2 = face_of_pixel(F, np.array([float(px)]), np.array([float(py)]))[0]
+            if f2 < 0:
+                continue
+            u = float(px) - np.floor(float(px) / F) * F
+            v = float(py) - np.floor(float(py) / F) * F
+            e_pose.append(k); e_point.append(p); e_obs.append((u, v)); e_inv.append(float(inv_sig2_tab[octave])); e_face.append(f2)
+            got += 1
+    # perturb the initial estimate (1 deg / 2 cm poses, 2 cm points); inputs are float-representable doubles
+    poses = np.zeros((K, 7))
+    for k in range(K):
+        R = Rt[k]; t = tt[k]
+        if k > 0:
+            ax = rs.normal(size=3)
+            R = _rot(ax, np.deg2rad(1.0) * rs.uniform(0.3, 1.0)) @ R
+            t = t + rs.normal(0, 0.02, 3)
+        R32 = R.astype(np.float32).astype(np.float64)
+        poses[k, :3] = t.astype(np.float32).astype(np.float64)
+        poses[k, 3:] = _quat_from_R(R32)
+    points = (pts + rs.normal(0, 0.02, pts.shape)).astype(np.float32).astype(np.float64)
+    fixed = np.zeros(K, np.uint8); fixed[0] = 1
+    return dict(poses=poses, fixed=fixed, points=points, e_pose=np.array(e_pose, np.int32),
+                e_point=np.array(e_point, np.int32), e_obs=np.array(e_obs, np.float64).reshape(-1, 2),
+                e_invsig2=np.array(e_inv, np.float64), e_face=np.array(e_face, np.int8),
+                fx=F / 2.0, fy=F / 2.0, cx=F / 2.0, cy=F / 2.0)
+
+
+def descriptors(n, seed):
+    return np.random.RandomState(seed).randint(0, 256, size=(n, 32)).astype(np.uint8)
+
+
+def candidate_lists(nq, nt, mean_cand, seed):
+    rs = np.random.RandomState(seed)
+    counts = rs.poisson(mean_cand, nq).astype(np.int64)
+    counts[rs.uniform(size=nq) < 0.05] = 0  # some empty lists
+    off = np.zeros(nq + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    idx = rs.randint(0, nt, size=int(off[-1])).astype(np.int32)
+    return off, idx

@@ -1,0 +1,128 @@
+/*
+ * oracle/orc_api.h -- CPU ORACLE for the CubemapSLAM hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This directory is a plain C++ (no OpenCV / Eigen / g2o) restatement of the reference's
+ * per-frame hot path, used exclusively as the checker by tests/, __graft_entry__.smoke()
+ * and bench.py's `cpu_baseline` leg.  Nothing under cubemapslam_amd/ may include, link or
+ * call it; the product path fails loudly when its HIP library is missing.
+ *
+ * PARITY STATUS: **parity unpinned**.  The reference ships no tests, golden vectors or
+ * fixtures, and it cannot be built in this image: it needs OpenCV
+ * 2.4.11/3.2, Eigen3 and Pangolin, none of which are present, so no
+ * `oracle/_ref` build exists.  Reference-owned logic (the src and include trees, vendored
+ * ThirdParty/g2o) is restated from the cited file:line.  OpenCV primitives (remap, resize,
+ * FAST, GaussianBlur, fastAtan2, cvRound -- third-party, un-vendored; README.md:59 pins
+ * "OpenCV 2.4.11 and 3.2") are restated from the published algorithm of those versions as
+ * summarised in SURVEY.md Appendix C.  What pins the oracle instead:
+ *   - known answers recorded in SURVEY.md section 8c from a run of the reference's own
+ *     CamModelGeneral TU (tests/test_oracle_cam.py),
+ *   - independent brute-force numpy re-implementations of every integer primitive
+ *     (tests/test_oracle_cv.py), finite-difference Jacobians and a dense numpy LM step for
+ *     the bundle adjustment (tests/test_oracle_ba.py).
+ */
+#ifndef ORC_API_H
+#define ORC_API_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Face ids: include/CamModelGeneral.h:55-62 */
+enum { ORC_FACE_UNKNOWN = -1, ORC_FACE_FRONT = 0, ORC_FACE_LEFT = 1, ORC_FACE_RIGHT = 2,
+       ORC_FACE_UPPER = 3, ORC_FACE_LOWER = 4 };
+
+/* Camera parameters as System.cpp:63-89 hands them to CamModelGeneral::SetCamParams. */
+typedef struct {
+  double c, d, e, u0, v0;
+  double invpol[12]; /* zero padded, degree fixed at 12 (System.cpp:70-72, CamModelGeneral.cpp:85-86) */
+  double pol[5];     /* forward polynomial, zero padded to 5 (System.cpp:67-69) */
+  int Iw, Ih;        /* fisheye size */
+  int face;          /* CubeFace.w == CubeFace.h == F ; fx=fy=cx=cy=F/2 (System.cpp:83-84) */
+  double fov_deg;
+} orc_camera;
+
+typedef struct {
+  int nfeatures; float scale_factor; int nlevels; int ini_th_fast; int min_th_fast;
+} orc_orb_params;
+
+/* cv::KeyPoint fields the extractor fills (ORBExtractor.cpp:811-821, 918-919) */
+typedef struct { float x, y, size, angle, response; int octave; } orc_keypoint;
+
+/* ---- camera model (CamModelGeneral.h / .cpp) ---- */
+void orc_world_to_img(const orc_camera* cam, double x, double y, double z, double* u, double* v);
+void orc_img_to_world(const orc_camera* cam, double u, double v, double* x, double* y, double* z);
+void orc_cubemap_to_fisheye(const orc_camera* cam, double up, double vp, double* uf, double* vf);
+int  orc_face_in_cubemap(const orc_camera* cam, float x, float y);
+int  orc_rays_to_cubemap(const orc_camera* cam, float x, float y, float z, float* up, float* vp);
+void orc_rays_to_target_face(const orc_camera* cam, float x, float y, float z, int face, float* up, float* vp);
+int  orc_cubemap_to_rays(const orc_camera* cam, float px, float py, float* ray3);
+float orc_cos_fov_th(const orc_camera* cam);
+/* System::CreateUndistortRectifyMap (System.cpp:301-324): two W x W float maps, W = 3F */
+void orc_build_lut(const orc_camera* cam, float* map1, float* map2);
+
+/* ---- OpenCV primitive restatements ---- */
+int  orc_cv_round(double v);
+float orc_fast_atan2(float y, float x);
+void orc_remap_bilinear(const uint8_t* src, int sw, int sh, int sstride,
+                        const float* map1, const float* map2, int mstride,
+                        uint8_t* dst, int dw, int dh, int dstride);
+/* System::CvtFisheyeToCubeMap_reverseQuery_withInterpolation (System.cpp:327-355) */
+void orc_fisheye_to_cubemap(const orc_camera* cam, const float* map1, const float* map2,
+                            const uint8_t* fisheye, int fstride, uint8_t* cubemap, int cstride);
+void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride,
+                       uint8_t* dst, int dw, int dh, int dstride);
+void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* cv::FAST(img, kps, threshold, nonmaxSuppression=true); out triplets (x, y, score) */
+int  orc_fast(const uint8_t* img, int w, int h, int stride, int threshold, int* out_xys, int cap);
+
+/* ---- ORBextractor (ORBExtractor.cpp) ---- */
+typedef struct orc_orb orc_orb;
+orc_orb* orc_orb_create(const orc_orb_params* p);
+void orc_orb_destroy(orc_orb* o);
+int  orc_orb_nlevels(const orc_orb* o);
+void orc_orb_tables(const orc_orb* o, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int* features_per_level, int* umax16);
+/* operator()(image, mask, keypoints, descriptors)  (ORBExtractor.cpp:838-926). Returns count or <0. */
+int  orc_orb_extract(orc_orb* o, const orc_camera* cam, const uint8_t* image, int w, int h, int stride,
+                     const uint8_t* mask, int mstride, orc_keypoint* kps, uint8_t* desc, int cap);
+/* debug views of the last extract call (for stage-by-stage parity) */
+int  orc_orb_level_size(const orc_orb* o, int level, int* w, int* h);
+void orc_orb_level_copy(const orc_orb* o, int level, uint8_t* dst, int dstride);
+int  orc_orb_level_candidates(const orc_orb* o, int level, int* xys, int cap);      /* vToDistributeKeys, rel. to minBorder */
+int  orc_orb_level_distributed(const orc_orb* o, int level, orc_keypoint* kps, int cap); /* after octree + orientation, pre-cull */
+/* DistributeOctTree stand-alone (ORBExtractor.cpp:511-737); in/out triplets (x,y,response) */
+int  orc_distribute_octree(const int* xys, int n, int min_x, int max_x, int min_y, int max_y, int N, int* out_xys, int cap);
+
+/* ---- ORBMatcher (ORBMatcher.cpp) ---- */
+int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+/* best / second-best over CSR candidate lists, the inner loop of SearchByProjection (ORBMatcher.cpp:84-113) */
+void orc_hamming_best2(const uint8_t* qdesc, int nq, const uint8_t* tdesc, const int* cand_off, const int* cand_idx,
+                       const int* tlevel, int* best_idx, int* best_dist, int* best_level, int* second_dist, int* second_level);
+void orc_hamming_matrix(const uint8_t* a, int na, const uint8_t* b, int nb, uint16_t* out);
+
+/* ---- Local bundle adjustment (Optimizer.cpp:192-451 + g2o slice) ---- */
+typedef struct {
+  int iterations_done[2];
+  double chi2_initial[2], chi2_final[2], lambda_final[2];
+  int n_outliers_mid, n_outliers_final;
+} orc_ba_stats;
+/* poses: K x 7 (tx,ty,tz,qx,qy,qz,qw), world->camera; points P x 3; edges: pose idx, point idx, obs in face (u,v),
+ * invSigma2, face. its = {5,10}. outlier_flags[E]: bit0 set = erased by the final test. */
+int  orc_ba_run(int K, double* poses, const uint8_t* fixed, int P, double* points,
+                int E, const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
+                const int8_t* e_face, double fx, double fy, double cx, double cy,
+                int its_robust, int its_final, const volatile uint8_t* stop,
+                uint8_t* outlier_flags, orc_ba_stats* stats);
+/* one residual + linearisation pass: per-edge error/chi2/Jacobians and the accumulated blocks.
+ * Hpp: K x 36 (row major 6x6), bp: K x 6, Hll: P x 9, bl: P x 3, Hpl: E x 18 (6x3 row major per edge), robust=huber */
+void orc_ba_linearize(int K, const double* poses, const uint8_t* fixed, int P, const double* points,
+                      int E, const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
+                      const int8_t* e_face, double fx, double fy, double cx, double cy, int robust, double huber_delta,
+                      double* err, double* chi2, double* Jpose, double* Jpoint,
+                      double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* robust_chi2_sum);
+void orc_se3_exp_apply(const double* upd6, double* pose7);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,253 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORC_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+
+
+class Camera(C.Structure):
+    _fields_ = [("c", C.c_double), ("d", C.c_double), ("e", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
+                ("invpol", C.c_double * 12), ("pol", C.c_double * 5), ("Iw", C.c_int), ("Ih", C.c_int),
+                ("face", C.c_int), ("fov_deg", C.c_double)]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4")])
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations_done", C.c_int * 2), ("chi2_initial", C.c_double * 2), ("chi2_final", C.c_double * 2),
+                ("lambda_final", C.c_double * 2), ("n_outliers_mid", C.c_int), ("n_outliers_final", C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_ORC_DIR, "liborc.so")
+    srcs = [os.path.join(_ORC_DIR, f) for f in os.listdir(_ORC_DIR) if f.endswith((".cpp", ".h", ".inc"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORC_DIR, "-s"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        L.orc_orb_create.restype = C.c_void_p
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_cos_fov_th.restype = C.c_float
+        L.orc_cv_round.argtypes = [C.c_double]
+        for name in ("orc_world_to_img",):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_img_to_world.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_cubemap_to_fisheye.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_face_in_cubemap.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.orc_rays_to_cubemap.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_rays_to_target_face.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_cubemap_to_rays.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.orc_ba_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ba_linearize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 10
+        L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int]
+        for n in ("orc_orb_destroy", "orc_orb_nlevels"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.orc_orb_tables.argtypes = [C.c_void_p] * 7
+        L.orc_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_orb_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_orb_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_orb_level_distributed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_camera(d):
+    cam = Camera()
+    for k in ("c", "d", "e", "u0", "v0", "Iw", "Ih", "face", "fov_deg"):
+        setattr(cam, k, d[k])
+    for i in range(12):
+        cam.invpol[i] = d["invpol"][i] if i < len(d["invpol"]) else 0.0
+    for i in range(5):
+        cam.pol[i] = d["pol"][i] if i < len(d["pol"]) else 0.0
+    return cam
+
+
+def build_lut(cam):
+    W = 3 * cam.face
+    m1 = np.zeros((W, W), np.float32)
+    m2 = np.zeros((W, W), np.float32)
+    lib().orc_build_lut(C.byref(cam), _p(m1), _p(m2))
+    return m1, m2
+
+
+def fisheye_to_cubemap(cam, m1, m2, fisheye):
+    W = 3 * cam.face
+    out = np.zeros((W, W), np.uint8)
+    fisheye = np.ascontiguousarray(fisheye)
+    lib().orc_fisheye_to_cubemap(C.byref(cam), _p(m1), _p(m2), _p(fisheye), C.c_int(fisheye.strides[0]), _p(out), C.c_int(W))
+    return out
+
+
+def remap(src, m1, m2):
+    src = np.ascontiguousarray(src)
+    m1 = np.ascontiguousarray(m1, np.float32)
+    m2 = np.ascontiguousarray(m2, np.float32)
+    dst = np.zeros(m1.shape, np.uint8)
+    lib().orc_remap_bilinear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(m1), _p(m2), m1.shape[1], _p(dst),
+                             m1.shape[1], m1.shape[0], dst.strides[0])
+    return dst
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def blur7(src):
+    src = np.ascontiguousarray(src)
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast(img, threshold):
+    img = np.ascontiguousarray(img)
+    cap = img.size
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def distribute_octree(xys, min_x, max_x, min_y, max_y, N):
+    xys = np.ascontiguousarray(xys, np.int32)
+    out = np.zeros((max(N + 8, 8), 3), np.int32)
+    n = lib().orc_distribute_octree(_p(xys), len(xys), min_x, max_x, min_y, max_y, N, _p(out), len(out))
+    assert n <= len(out)
+    return out[:n].copy()
+
+
+class Orb:
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.params = OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.h = C.c_void_p(lib().orc_orb_create(C.byref(self.params)))
+        self.nlevels = nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_orb_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        L = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(L, np.float32) for _ in range(4))
+        q = np.zeros(L, np.int32)
+        um = np.zeros(16, np.int32)
+        lib().orc_orb_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(q), _p(um))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, quota=q, umax=um)
+
+    def extract(self, cam, image, mask, cap=None):
+        image = np.ascontiguousarray(image)
+        mask = np.ascontiguousarray(mask)
+        cap = cap or 4 * self.params.nfeatures + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = lib().orc_orb_extract(self.h, C.byref(cam), _p(image), image.shape[1], image.shape[0], image.strides[0],
+                                  _p(mask), mask.strides[0], _p(kps), _p(desc), cap)
+        assert 0 <= n <= cap, n
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, l):
+        w, h = C.c_int(), C.c_int()
+        lib().orc_orb_level_size(self.h, l, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        lib().orc_orb_level_copy(self.h, l, _p(out), w.value)
+        return out
+
+    def candidates(self, l):
+        n = lib().orc_orb_level_candidates(self.h, l, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        lib().orc_orb_level_candidates(self.h, l, _p(out), n)
+        return out[:n]
+
+    def distributed(self, l):
+        n = lib().orc_orb_level_distributed(self.h, l, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        lib().orc_orb_level_distributed(self.h, l, _p(out), n)
+        return out[:n]
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_best2(qdesc, tdesc, cand_off, cand_idx, tlevel=None):
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, np.uint8)
+    cand_off = np.ascontiguousarray(cand_off, np.int32)
+    cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+    nq = len(qdesc)
+    outs = [np.zeros(nq, np.int32) for _ in range(5)]
+    tl = np.ascontiguousarray(tlevel, np.int32) if tlevel is not None else None
+    lib().orc_hamming_best2(_p(qdesc), nq, _p(tdesc), _p(cand_off), _p(cand_idx), _p(tl), *[_p(o) for o in outs])
+    return dict(best_idx=outs[0], best_dist=outs[1], best_level=outs[2], second_dist=outs[3], second_level=outs[4])
+
+
+def hamming_matrix(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.zeros((len(a), len(b)), np.uint16)
+    lib().orc_hamming_matrix(_p(a), len(a), _p(b), len(b), _p(out))
+    return out
+
+
+def ba_run(prob, its=(5, 10), stop=None):
+    poses = np.array(prob["poses"], np.float64, copy=True)
+    pts = np.array(prob["points"], np.float64, copy=True)
+    E = len(prob["e_pose"])
+    flags = np.zeros(E, np.uint8)
+    st = BaStats()
+    stop_arr = np.array([1 if stop else 0], np.uint8)
+    rc = lib().orc_ba_run(len(poses), _p(poses), _p(prob["fixed"]), len(pts), _p(pts), E, _p(prob["e_pose"]),
+                          _p(prob["e_point"]), _p(prob["e_obs"]), _p(prob["e_invsig2"]), _p(prob["e_face"]),
+                          prob["fx"], prob["fy"], prob["cx"], prob["cy"], its[0], its[1], _p(stop_arr), _p(flags), C.byref(st))
+    return dict(rc=rc, poses=poses, points=pts, outliers=flags, stats=st)
+
+
+def ba_linearize(prob, robust=True, delta=np.sqrt(5.991)):
+    K, P, E = len(prob["poses"]), len(prob["points"]), len(prob["e_pose"])
+    poses = np.ascontiguousarray(prob["poses"], np.float64)
+    pts = np.ascontiguousarray(prob["points"], np.float64)
+    o = dict(err=np.zeros((E, 2)), chi2=np.zeros(E), Jpose=np.zeros((E, 2, 6)), Jpoint=np.zeros((E, 2, 3)),
+             Hpp=np.zeros((K, 6, 6)), bp=np.zeros((K, 6)), Hll=np.zeros((P, 3, 3)), bl=np.zeros((P, 3)),
+             Hpl=np.zeros((E, 6, 3)), chi=np.zeros(1))
+    lib().orc_ba_linearize(K, _p(poses), _p(prob["fixed"]), P, _p(pts), E, _p(prob["e_pose"]), _p(prob["e_point"]),
+                           _p(prob["e_obs"]), _p(prob["e_invsig2"]), _p(prob["e_face"]), prob["fx"], prob["fy"],
+                           prob["cx"], prob["cy"], 1 if robust else 0, float(delta), _p(o["err"]), _p(o["chi2"]),
+                           _p(o["Jpose"]), _p(o["Jpoint"]), _p(o["Hpp"]), _p(o["bp"]), _p(o["Hll"]), _p(o["bl"]),
+                           _p(o["Hpl"]), _p(o["chi"]))
+    return o
