@@ -156,3 +156,78 @@ def fast_atan2(y, x):
 
 def popcount_dist(a, b):
     return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def octree_arrayform(xys, W, H, N):
+    """Array-form restatement of DistributeOctTree (the shape the HIP kernel uses): no linked list, no per-node key
+    vectors -- nodes are rectangles + counts, every candidate carries its node id, the list order is rebuilt per pass.
+    xys rows are (x, y, response) in candidate order (order = tie-break priority of the final arg-max)."""
+    n = len(xys)
+    if n == 0:
+        return np.zeros((0, 3), np.int32)
+    X = xys[:, 0].astype(np.int64); Y = xys[:, 1].astype(np.int64); R = xys[:, 2].astype(np.int64)
+    rect = [(0, W, 0, H)]          # x0, x1, y0, y1 per node id
+    cnt = [n]
+    node_of = np.zeros(n, np.int64)
+    order = [0]
+
+    def split(p):
+        x0, x1, y0, y1 = rect[p]
+        hx = int(np.ceil(np.float32(x1 - x0) / 2)); hy = int(np.ceil(np.float32(y1 - y0) / 2))
+        mx, my = x0 + hx, y0 + hy
+        sel = np.nonzero(node_of == p)[0]
+        q = (X[sel] >= mx).astype(np.int64) + 2 * (Y[sel] >= my).astype(np.int64)   # 0:n1 1:n2 2:n3 3:n4
+        rects = [(x0, mx, y0, my), (mx, x1, y0, my), (x0, mx, my, y1), (mx, x1, my, y1)]
+        kids = []
+        for c in range(4):
+            m = int((q == c).sum())
+            if m == 0:
+                continue
+            rect.append(rects[c]); cnt.append(m)
+            node_of[sel[q == c]] = len(rect) - 1
+            kids.append(len(rect) - 1)
+        return kids
+
+    finish = False
+    while not finish:
+        prev = len(order)
+        C = []
+        keep = []
+        for p in order:
+            if cnt[p] == 1:
+                keep.append(p)
+            else:
+                C += split(p)
+        any_split = len(C) > 0
+        order = C[::-1] + keep
+        Ex = [c for c in C if cnt[c] > 1]
+        size = len(order)
+        if size >= N or (size == prev and size >= N // 100):
+            finish = True
+        elif size + 3 * len(Ex) > N:
+            while not finish:
+                prev2 = size
+                srt = sorted(Ex, key=lambda c: (cnt[c], c))   # node id == creation sequence
+                Ex = []
+                C2 = []
+                removed = set()
+                for p in srt[::-1]:
+                    kids = split(p)
+                    C2 += kids
+                    Ex += [c for c in kids if cnt[c] > 1]
+                    removed.add(p)
+                    size += len(kids) - 1
+                    if size >= N:
+                        break
+                order = C2[::-1] + [o for o in order if o not in removed]
+                assert len(order) == size
+                if size >= N or size == prev2:
+                    finish = True
+        elif not any_split:
+            finish = True
+    out = []
+    for p in order:
+        sel = np.nonzero(node_of == p)[0]
+        b = sel[np.argmax(R[sel])]     # first maximum in candidate order
+        out.append((X[b], Y[b], R[b]))
+    return np.array(out, np.int32).reshape(-1, 3)
