@@ -1,0 +1,332 @@
+"""ctypes binding of libcubemapslam_hip.so (the C-ABI in include/cubemapslam_hip.h).
+
+Plumbing only: every call goes straight to the hand-written HIP library.  There is NO CPU fallback: if the shared
+library is missing or no MI355X is visible the calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcubemapslam_hip.so")
+
+
+class CmsError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    _fields_ = [("c", C.c_double), ("d", C.c_double), ("e", C.c_double), ("u0", C.c_double), ("v0", C.c_double),
+                ("invpol", C.c_double * 12), ("pol", C.c_double * 5), ("Iw", C.c_int), ("Ih", C.c_int),
+                ("face", C.c_int), ("fov_deg", C.c_double)]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("W", C.c_int), ("F", C.c_int), ("nlevels", C.c_int), ("kp_cap", C.c_int), ("max_batch", C.c_int),
+                ("level_w", C.c_int * 12), ("level_h", C.c_int * 12), ("level_quota", C.c_int * 12),
+                ("level_cells", C.c_int * 12), ("scale", C.c_float * 12), ("inv_scale", C.c_float * 12),
+                ("sigma2", C.c_float * 12), ("inv_sigma2", C.c_float * 12), ("pyramid_bytes_per_frame", C.c_size_t),
+                ("candidate_entries_per_frame", C.c_size_t), ("fisheye_stride", C.c_int)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations_done", C.c_int * 2), ("chi2_initial", C.c_double * 2), ("chi2_final", C.c_double * 2),
+                ("lambda_final", C.c_double * 2), ("n_outliers_mid", C.c_int), ("n_outliers_final", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4")])
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (python -m cubemapslam_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CmsError("libcubemapslam_hip.so is missing -- build it with `python -m cubemapslam_amd.build` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.cms_last_error.restype = C.c_char_p
+        for n in ("cms_ctx_stream", "cms_frames_input", "cms_ba_stream"):
+            getattr(L, n).restype = C.c_void_p
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.cms_ctx_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.cms_ctx_destroy.argtypes = [C.c_void_p]
+        L.cms_ctx_destroy.restype = None
+        L.cms_ctx_geometry.argtypes = [C.c_void_p, C.c_void_p]
+        L.cms_remap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.cms_set_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.cms_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.cms_remap_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.cms_frames_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]
+        L.cms_frames_process.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cms_frames_sync.argtypes = [C.c_void_p]
+        L.cms_frames_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_frames_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.cms_debug_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_debug_cubemap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.cms_debug_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.cms_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.cms_debug_distributed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.cms_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.cms_profile_get.argtypes = [C.c_void_p, C.c_void_p]
+        L.cms_hamming_best2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+        L.cms_hamming_best2_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10
+        L.cms_hamming_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.cms_ba_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                    C.c_double, C.c_double]
+        L.cms_ba_reset.argtypes = [C.c_void_p]
+        L.cms_ba_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.cms_ba_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_ba_destroy.argtypes = [C.c_void_p]
+        L.cms_ba_destroy.restype = None
+        L.cms_ba_run.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                 C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_ba_linearize.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 7
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, what):
+    if rc < 0:
+        raise CmsError("%s failed (%d): %s" % (what, rc, lib().cms_last_error().decode()))
+    return rc
+
+
+def make_camera(d):
+    cam = Camera()
+    for k in ("c", "d", "e", "u0", "v0", "Iw", "Ih", "face", "fov_deg"):
+        setattr(cam, k, d[k])
+    for i in range(12):
+        cam.invpol[i] = d["invpol"][i] if i < len(d["invpol"]) else 0.0
+    for i in range(5):
+        cam.pol[i] = d["pol"][i] if i < len(d["pol"]) else 0.0
+    return cam
+
+
+class Context:
+    """cms_ctx: remap LUT + extractor tables + device buffers for up to max_batch frames."""
+
+    def __init__(self, cam, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, max_batch=1, device=0):
+        self.cam = make_camera(cam) if isinstance(cam, dict) else cam
+        self.orb = OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.h = C.c_void_p()
+        _chk(lib().cms_ctx_create(C.byref(self.h), device, C.byref(self.cam), C.byref(self.orb), max_batch), "cms_ctx_create")
+        self.geom = Geometry()
+        _chk(lib().cms_ctx_geometry(self.h, C.byref(self.geom)), "cms_ctx_geometry")
+        self.W = self.geom.W
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().cms_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().cms_ctx_stream(self.h)
+
+    def set_mask(self, mask):
+        mask = np.ascontiguousarray(mask, np.uint8)
+        _chk(lib().cms_set_mask(self.h, _p(mask), mask.strides[0]), "cms_set_mask")
+
+    def remap(self, fisheye, cubemap=None):
+        fisheye = np.ascontiguousarray(fisheye, np.uint8)
+        if cubemap is None:
+            cubemap = np.zeros((self.W, self.W), np.uint8)
+        _chk(lib().cms_remap(self.h, _p(fisheye), fisheye.strides[0], _p(cubemap), cubemap.strides[0]), "cms_remap")
+        return cubemap
+
+    def extract(self, cubemap, cap=None):
+        cubemap = np.ascontiguousarray(cubemap, np.uint8)
+        cap = cap or self.geom.kp_cap
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        _chk(lib().cms_extract(self.h, _p(cubemap), cubemap.strides[0], _p(kps), _p(desc), cap, C.byref(n)), "cms_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def remap_extract(self, fisheye, cap=None):
+        fisheye = np.ascontiguousarray(fisheye, np.uint8)
+        cap = cap or self.geom.kp_cap
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        _chk(lib().cms_remap_extract(self.h, _p(fisheye), fisheye.strides[0], _p(kps), _p(desc), cap, C.byref(n)), "cms_remap_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- batched device path
+    def upload(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.ndim == 3
+        _chk(lib().cms_frames_upload(self.h, _p(frames), frames.strides[1], frames.strides[0], frames.shape[0]), "cms_frames_upload")
+
+    def process(self, B, from_fisheye=True):
+        _chk(lib().cms_frames_process(self.h, B, 1 if from_fisheye else 0), "cms_frames_process")
+
+    def sync(self):
+        _chk(lib().cms_frames_sync(self.h), "cms_frames_sync")
+
+    def fetch(self, b):
+        cap = self.geom.kp_cap
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        _chk(lib().cms_frames_fetch(self.h, b, _p(kps), _p(desc), cap, C.byref(n)), "cms_frames_fetch")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def results_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _chk(lib().cms_frames_results(self.h, C.byref(a), C.byref(b), C.byref(c)), "cms_frames_results")
+        return a.value, b.value, c.value
+
+    def input_ptr(self):
+        return lib().cms_frames_input(self.h)
+
+    def profile(self, on=True):
+        lib().cms_profile_enable(self.h, 1 if on else 0)
+
+    def profile_ms(self):
+        ms = np.zeros(7, np.float32)
+        _chk(lib().cms_profile_get(self.h, _p(ms)), "cms_profile_get")
+        return dict(zip(("remap", "pyramid", "fast", "octree", "cull", "describe", "total"), ms.tolist()))
+
+    # ---- debug read-back
+    def debug_lut(self):
+        W = self.W
+        out = np.zeros((W, (W + 3) // 4 * 4), np.uint32)
+        s = C.c_int()
+        _chk(lib().cms_debug_lut(self.h, _p(out), C.byref(s)), "cms_debug_lut")
+        return out[:, :W]
+
+    def debug_level(self, b, l):
+        w, h = self.geom.level_w[l], self.geom.level_h[l]
+        out = np.zeros((h, w), np.uint8)
+        _chk(lib().cms_debug_level(self.h, b, l, _p(out), w), "cms_debug_level")
+        return out
+
+    def debug_candidates(self, b, l):
+        cap = self.geom.level_w[l] * self.geom.level_h[l] // 4 + 4096
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int()
+        _chk(lib().cms_debug_candidates(self.h, b, l, _p(out), cap, C.byref(n)), "cms_debug_candidates")
+        return out[:n.value].copy()
+
+    def debug_distributed(self, b, l):
+        cap = self.geom.level_quota[l] + 8
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int()
+        _chk(lib().cms_debug_distributed(self.h, b, l, _p(out), cap, C.byref(n)), "cms_debug_distributed")
+        return out[:n.value].copy()
+
+    # ---- matching
+    def hamming_best2(self, qdesc, tdesc, cand_off, cand_idx, tlevel=None, texcl=None):
+        qdesc = np.ascontiguousarray(qdesc, np.uint8); tdesc = np.ascontiguousarray(tdesc, np.uint8)
+        cand_off = np.ascontiguousarray(cand_off, np.int32); cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+        tl = np.ascontiguousarray(tlevel, np.int32) if tlevel is not None else None
+        tx = np.ascontiguousarray(texcl, np.uint8) if texcl is not None else None
+        nq = len(qdesc)
+        outs = [np.zeros(max(nq, 1), np.int32) for _ in range(5)]
+        _chk(lib().cms_hamming_best2(self.h, _p(qdesc), nq, _p(tdesc), len(tdesc), _p(cand_off), _p(cand_idx), _p(tl), _p(tx),
+                                     *[_p(o) for o in outs]), "cms_hamming_best2")
+        keys = ("best_idx", "best_dist", "best_level", "second_dist", "second_level")
+        return {k: o[:nq] for k, o in zip(keys, outs)}
+
+    def hamming_matrix(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        out = np.zeros((len(a), len(b)), np.uint16)
+        _chk(lib().cms_hamming_matrix(self.h, _p(a), len(a), _p(b), len(b), _p(out)), "cms_hamming_matrix")
+        return out
+
+
+class BundleAdjuster:
+    """cms_ba: one local-BA window resident on the device."""
+
+    def __init__(self, prob, device=0):
+        self.prob = prob
+        self.K, self.P, self.E = len(prob["poses"]), len(prob["points"]), len(prob["e_pose"])
+        self.h = C.c_void_p()
+        poses = np.ascontiguousarray(prob["poses"], np.float64); pts = np.ascontiguousarray(prob["points"], np.float64)
+        _chk(lib().cms_ba_create(C.byref(self.h), device, self.K, _p(poses), _p(prob["fixed"]), self.P, _p(pts), self.E,
+                                 _p(prob["e_pose"]), _p(prob["e_point"]), _p(np.ascontiguousarray(prob["e_obs"], np.float64)),
+                                 _p(prob["e_invsig2"]), _p(prob["e_face"]), prob["fx"], prob["fy"], prob["cx"], prob["cy"]),
+             "cms_ba_create")
+
+    def reset(self):
+        _chk(lib().cms_ba_reset(self.h), "cms_ba_reset")
+
+    def optimize(self, its=(5, 10), stop=None):
+        st = BaStats()
+        stop_arr = np.array([1 if stop else 0], np.uint8)
+        rc = _chk(lib().cms_ba_optimize(self.h, its[0], its[1], _p(stop_arr), C.byref(st)), "cms_ba_optimize")
+        return rc, st
+
+    def read(self):
+        poses = np.zeros((self.K, 7)); pts = np.zeros((self.P, 3)); flags = np.zeros(self.E, np.uint8)
+        _chk(lib().cms_ba_read(self.h, _p(poses), _p(pts), _p(flags)), "cms_ba_read")
+        return poses, pts, flags
+
+    @property
+    def stream(self):
+        return lib().cms_ba_stream(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().cms_ba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ba_run(prob, its=(5, 10), stop=None, device=0):
+    poses = np.array(prob["poses"], np.float64, copy=True); pts = np.array(prob["points"], np.float64, copy=True)
+    E = len(prob["e_pose"])
+    flags = np.zeros(E, np.uint8)
+    st = BaStats()
+    stop_arr = np.array([1 if stop else 0], np.uint8)
+    rc = _chk(lib().cms_ba_run(device, len(poses), _p(poses), _p(prob["fixed"]), len(pts), _p(pts), E, _p(prob["e_pose"]),
+                               _p(prob["e_point"]), _p(np.ascontiguousarray(prob["e_obs"], np.float64)), _p(prob["e_invsig2"]),
+                               _p(prob["e_face"]), prob["fx"], prob["fy"], prob["cx"], prob["cy"], its[0], its[1], _p(stop_arr),
+                               _p(flags), C.byref(st)), "cms_ba_run")
+    return dict(rc=rc, poses=poses, points=pts, outliers=flags, stats=st)
+
+
+def ba_linearize(prob, robust=True, delta=float(np.sqrt(5.991)), device=0):
+    K, P, E = len(prob["poses"]), len(prob["points"]), len(prob["e_pose"])
+    poses = np.ascontiguousarray(prob["poses"], np.float64); pts = np.ascontiguousarray(prob["points"], np.float64)
+    o = dict(err=np.zeros((E, 2)), Hpp=np.zeros((K, 6, 6)), bp=np.zeros((K, 6)), Hll=np.zeros((P, 3, 3)), bl=np.zeros((P, 3)),
+             Hpl=np.zeros((E, 6, 3)), chi=np.zeros(1))
+    _chk(lib().cms_ba_linearize(device, K, _p(poses), _p(prob["fixed"]), P, _p(pts), E, _p(prob["e_pose"]), _p(prob["e_point"]),
+                                _p(np.ascontiguousarray(prob["e_obs"], np.float64)), _p(prob["e_invsig2"]), _p(prob["e_face"]),
+                                prob["fx"], prob["fy"], prob["cx"], prob["cy"], 1 if robust else 0, float(delta), _p(o["err"]),
+                                _p(o["Hpp"]), _p(o["bp"]), _p(o["Hll"]), _p(o["bl"]), _p(o["Hpl"]), _p(o["chi"])), "cms_ba_linearize")
+    return o

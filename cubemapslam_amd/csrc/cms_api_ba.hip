@@ -1,0 +1,309 @@
+// cms_api_ba.hip -- host driver of the device-resident local bundle adjustment (included by cms_lib.hip).
+// Control flow restated from OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164),
+// SparseOptimizer::optimize (sparse_optimizer.cpp:354-419) and the two-stage schedule of
+// Optimizer::LocalBundleAdjustment (Optimizer.cpp:359-412).  All vectors and matrices live on the device; per
+// Levenberg trial the host reads back three scalars (new chi2, gain denominator, LDL^T status).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <numeric>
+
+struct cms_ba {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int K = 0, P = 0, E = 0, np = 0, nblk_e = 0, nblk_p = 0;
+  std::vector<int> perm;       // sorted position -> caller's edge index
+  BaDev d;
+  // device memory
+  uint8_t* d_fixed = nullptr; int* d_pose_slot = nullptr; int* d_e_pose = nullptr; int* d_e_point = nullptr;
+  double* d_e_obs = nullptr; double* d_e_inv = nullptr; int8_t* d_e_face = nullptr; int* d_pt_off = nullptr;
+  int* d_pose_off = nullptr; int* d_pose_edges = nullptr; uint8_t* d_level = nullptr; double* d_err = nullptr;
+  double* d_poses[2] = {nullptr, nullptr}; double* d_pts[2] = {nullptr, nullptr};
+  double* d_poses0 = nullptr; double* d_pts0 = nullptr;
+  double* d_Hpp = nullptr; double* d_bp = nullptr; double* d_Hll = nullptr; double* d_bl = nullptr; double* d_Hpl = nullptr;
+  double* d_Dinv = nullptr; double* d_Hs = nullptr; double* d_bs = nullptr; double* d_x = nullptr; double* d_Dg = nullptr;
+  double* d_partial = nullptr; double* d_scal = nullptr; int* d_status = nullptr; uint8_t* d_flags = nullptr;
+  int cur = 0;
+  std::vector<void*> allocs;
+};
+
+template <class T> static int ba_alloc(cms_ba* b, T** p, size_t n) {
+  hipError_t e = hipMalloc((void**)p, (n > 0 ? n : 1) * sizeof(T));
+  if (e != hipSuccess) return cms_fail(CMS_ERR_HIP, "hipMalloc (BA)", e);
+  b->allocs.push_back(*p);
+  return CMS_OK;
+}
+
+extern "C" void cms_ba_destroy(cms_ba* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  for (void* p : b->allocs) hipFree(p);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullptr; }
+
+extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P,
+                             const double* points, int E, const int* e_pose, const int* e_point, const double* e_obs,
+                             const double* e_invsig2, const int8_t* e_face, double fx, double fy, double cx, double cy) {
+  if (!out || K < 1 || P < 1 || E < 1 || !poses || !fixed || !points || !e_pose || !e_point || !e_obs || !e_invsig2 || !e_face)
+    return cms_fail(CMS_ERR_ARG, "cms_ba_create: bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return cms_fail(CMS_ERR_NO_DEVICE, "no HIP device: the product path has no CPU fallback");
+  for (int e = 0; e < E; ++e)
+    if (e_pose[e] < 0 || e_pose[e] >= K || e_point[e] < 0 || e_point[e] >= P || e_face[e] < 0 || e_face[e] > 4)
+      return cms_fail(CMS_ERR_ARG, "cms_ba_create: edge index / face out of range (unknown-face edges must be culled by the caller)");
+  HIPCHK(hipSetDevice(device));
+  cms_ba* b = new cms_ba;
+  b->device = device; b->K = K; b->P = P; b->E = E;
+#define BA_TRY(x) do { int _rc = (x); if (_rc) { cms_ba_destroy(b); return _rc; } } while (0)
+#define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
+  BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  // sort edges by (point, pose): CSR by point; per-pose edge lists reference sorted positions
+  b->perm.resize(E);
+  std::iota(b->perm.begin(), b->perm.end(), 0);
+  std::stable_sort(b->perm.begin(), b->perm.end(), [&](int a, int c) {
+    return e_point[a] != e_point[c] ? e_point[a] < e_point[c] : e_pose[a] < e_pose[c];
+  });
+  std::vector<int> s_pose(E), s_point(E), pt_off(P + 1, 0), pose_off(K + 1, 0), pose_edges(E), pose_slot(K, -1);
+  std::vector<double> s_obs(2 * (size_t)E), s_inv(E);
+  std::vector<int8_t> s_face(E);
+  for (int i = 0; i < E; ++i) {
+    const int e = b->perm[i];
+    s_pose[i] = e_pose[e]; s_point[i] = e_point[e]; s_obs[2 * i] = e_obs[2 * e]; s_obs[2 * i + 1] = e_obs[2 * e + 1];
+    s_inv[i] = e_invsig2[e]; s_face[i] = e_face[e];
+    ++pt_off[s_point[i] + 1]; ++pose_off[s_pose[i] + 1];
+  }
+  for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
+  for (int k = 0; k < K; ++k) pose_off[k + 1] += pose_off[k];
+  {
+    std::vector<int> fill(pose_off.begin(), pose_off.end() - 1);
+    for (int i = 0; i < E; ++i) pose_edges[fill[s_pose[i]]++] = i;
+  }
+  int np = 0;
+  for (int k = 0; k < K; ++k) if (!fixed[k]) pose_slot[k] = np++;
+  b->np = np;
+  const int n = 6 * np;
+  b->nblk_e = (E + 255) / 256; b->nblk_p = (P + 127) / 128;
+  BA_TRY(ba_alloc(b, &b->d_fixed, K)); BA_TRY(ba_alloc(b, &b->d_pose_slot, K)); BA_TRY(ba_alloc(b, &b->d_e_pose, E));
+  BA_TRY(ba_alloc(b, &b->d_e_point, E)); BA_TRY(ba_alloc(b, &b->d_e_obs, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_inv, E));
+  BA_TRY(ba_alloc(b, &b->d_e_face, E)); BA_TRY(ba_alloc(b, &b->d_pt_off, P + 1)); BA_TRY(ba_alloc(b, &b->d_pose_off, K + 1));
+  BA_TRY(ba_alloc(b, &b->d_pose_edges, E)); BA_TRY(ba_alloc(b, &b->d_level, E)); BA_TRY(ba_alloc(b, &b->d_err, 2 * (size_t)E));
+  for (int i = 0; i < 2; ++i) { BA_TRY(ba_alloc(b, &b->d_poses[i], 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts[i], 3 * (size_t)P)); }
+  BA_TRY(ba_alloc(b, &b->d_poses0, 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts0, 3 * (size_t)P));
+  BA_TRY(ba_alloc(b, &b->d_Hpp, 36 * (size_t)std::max(np, 1))); BA_TRY(ba_alloc(b, &b->d_bp, 6 * (size_t)std::max(np, 1)));
+  BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
+  BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
+  BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
+  BA_TRY(ba_alloc(b, &b->d_partial, (size_t)std::max(b->nblk_e, b->nblk_p) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 8));
+  BA_TRY(ba_alloc(b, &b->d_status, 2)); BA_TRY(ba_alloc(b, &b->d_flags, E));
+  // normalise quaternions like the SE3Quat constructor (se3quat.h:58-64, 280-285)
+  std::vector<double> p0(poses, poses + 7 * (size_t)K);
+  for (int k = 0; k < K; ++k) {
+    double* q = &p0[7 * k + 3];
+    if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= nn;
+  }
+#define UP(dst, src, bytes) BA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice))
+  UP(b->d_fixed, fixed, K); UP(b->d_pose_slot, pose_slot.data(), K * sizeof(int)); UP(b->d_e_pose, s_pose.data(), E * sizeof(int));
+  UP(b->d_e_point, s_point.data(), E * sizeof(int)); UP(b->d_e_obs, s_obs.data(), 2 * (size_t)E * sizeof(double));
+  UP(b->d_e_inv, s_inv.data(), E * sizeof(double)); UP(b->d_e_face, s_face.data(), E); UP(b->d_pt_off, pt_off.data(), (P + 1) * sizeof(int));
+  UP(b->d_pose_off, pose_off.data(), (K + 1) * sizeof(int)); UP(b->d_pose_edges, pose_edges.data(), E * sizeof(int));
+  UP(b->d_poses0, p0.data(), 7 * (size_t)K * sizeof(double)); UP(b->d_pts0, points, 3 * (size_t)P * sizeof(double));
+#undef UP
+  BaDev& d = b->d;
+  d.K = K; d.P = P; d.E = E; d.np = np; d.fixed = b->d_fixed; d.pose_slot = b->d_pose_slot; d.e_pose = b->d_e_pose;
+  d.e_point = b->d_e_point; d.e_obs = b->d_e_obs; d.e_inv = b->d_e_inv; d.e_face = b->d_e_face; d.pt_off = b->d_pt_off;
+  d.pose_off = b->d_pose_off; d.pose_edges = b->d_pose_edges; d.level = b->d_level; d.err = b->d_err;
+  d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
+  int rc = cms_ba_reset(b);
+  if (rc) { cms_ba_destroy(b); return rc; }
+  *out = b;
+  return CMS_OK;
+}
+
+extern "C" int cms_ba_reset(cms_ba* b) {
+  if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
+  HIPCHK(hipSetDevice(b->device));
+  b->cur = 0;
+  HIPCHK(hipMemcpyAsync(b->d_poses[0], b->d_poses0, 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_pts[0], b->d_pts0, 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_level, 0, b->E, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_err, 0, 2 * (size_t)b->E * sizeof(double), b->stream));
+  HIPCHK(hipMemsetAsync(b->d_flags, 0, b->E, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return CMS_OK;
+}
+
+// chi2 of the active edges at state `which` -> d_scal[slot]; refreshes d_err
+static void ba_errors(cms_ba* b, int which, int robust, double delta, int slot) {
+  hipLaunchKernelGGL(k_ba_errors, dim3(b->nblk_e), dim3(256), 0, b->stream, b->d, (const double*)b->d_poses[which],
+                     (const double*)b->d_pts[which], robust, delta, b->d_partial);
+  hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, b->stream, (const double*)b->d_partial, b->nblk_e, b->d_scal + slot, 0);
+}
+
+// SparseOptimizer::optimize(iterations) with Levenberg; returns iterations done or <0
+static int ba_optimize_stage(cms_ba* b, int iterations, int robust, double delta, const volatile uint8_t* stop,
+                             double* chi_ini, double* chi_fin, double* lam_fin) {
+  hipStream_t s = b->stream;
+  const int n = 6 * b->np;
+  double lambda = -1, ni = 2;
+  int nBad = 0, done = 0;
+  *chi_ini = *chi_fin = *lam_fin = 0;
+  auto stopped = [&]() { return stop && *stop; };
+  for (int it = 0; it < iterations && !stopped(); ++it) {
+    const int cur = b->cur, nxt = cur ^ 1;
+    ba_errors(b, cur, robust, delta, 0);
+    hipLaunchKernelGGL(k_ba_lin_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_poses[cur],
+                       (const double*)b->d_pts[cur], robust, delta, b->d_Hll, b->d_bl, b->d_Hpl);
+    hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K), dim3(256), 0, s, b->d, (const double*)b->d_poses[cur],
+                       (const double*)b->d_pts[cur], robust, delta, b->d_Hpp, b->d_bp);
+    if (it == 0)
+      hipLaunchKernelGGL(k_ba_maxdiag, dim3(1), dim3(256), 0, s, b->np, b->P, (const double*)b->d_Hpp, (const double*)b->d_Hll, b->d_scal + 3);
+    double h[4];
+    HIPCHK(hipMemcpyAsync(h, b->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double currentChi = h[0];
+    const double iniChi = currentChi;
+    if (it == 0) { *chi_ini = iniChi; lambda = 1e-5 * h[3]; ni = 2; nBad = 0; }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      if (n > 0) {
+        hipLaunchKernelGGL(k_ba_schur_init, dim3(std::min((n * n + 255) / 256, 256)), dim3(256), 0, s, b->np, (const double*)b->d_Hpp,
+                           (const double*)b->d_bp, lambda, b->d_Hs, b->d_bs);
+      }
+      hipLaunchKernelGGL(k_ba_schur, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_Hll, (const double*)b->d_bl,
+                         (const double*)b->d_Hpl, lambda, b->d_Dinv, b->d_Hs, b->d_bs);
+      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), 0, s, n, b->d_Hs, b->d_bs, b->d_x, b->d_Dg, b->d_status);
+      hipLaunchKernelGGL(k_ba_backsub, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
+                         (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt], b->d_partial);
+      hipLaunchKernelGGL(k_ba_update_poses, dim3(1), dim3(64), 0, s, b->d, (const double*)b->d_x, (const double*)b->d_bp, lambda,
+                         (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_scal + 2);
+      hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal + 2, 1);
+      ba_errors(b, nxt, robust, delta, 1);
+      double t[3];
+      int ok2 = 0;
+      HIPCHK(hipMemcpyAsync(t, b->d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(&ok2, b->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      double tempChi = t[1];
+      if (!ok2) tempChi = DBL_MAX;
+      rho = (currentChi - tempChi);
+      const double scale = t[2] + 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2; currentChi = tempChi;
+        b->cur = nxt;   // discardTop(): the trial state becomes the estimate
+      } else {
+        lambda *= ni; ni *= 2;   // pop(): keep the old estimate; stored edge errors stay those of the rejected trial (as in g2o)
+      }
+      ++qmax;
+    } while (rho < 0 && qmax < 10 && !stopped());
+    ++done;
+    *chi_fin = currentChi; *lam_fin = lambda;
+    if (qmax == 10 || rho == 0) break;
+    if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
+    if (nBad >= 3) break;
+    // the accepted state is in b->cur; if the last trial was rejected the next iteration re-evaluates from b->cur
+  }
+  HIPCHK(hipGetLastError());
+  return done;
+}
+
+extern "C" int cms_ba_optimize(cms_ba* b, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* st) {
+  if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
+  cms_ba_stats dummy;
+  if (!st) st = &dummy;
+  memset(st, 0, sizeof(*st));
+  HIPCHK(hipSetDevice(b->device));
+  if (stop && *stop) return 1;   // Optimizer.cpp:359-361
+  const double delta = std::sqrt(5.991);
+  int rc = ba_optimize_stage(b, its_robust, 1, delta, stop, &st->chi2_initial[0], &st->chi2_final[0], &st->lambda_final[0]);
+  if (rc < 0) return rc;
+  st->iterations_done[0] = rc;
+  hipStream_t s = b->stream;
+  std::vector<uint8_t> flags(b->E);
+  if (!(stop && *stop)) {
+    hipLaunchKernelGGL(k_ba_classify, dim3(b->nblk_e), dim3(256), 0, s, b->d, (const double*)b->d_poses[b->cur],
+                       (const double*)b->d_pts[b->cur], 5.991, 1, b->d_flags);
+    HIPCHK(hipMemcpyAsync(flags.data(), b->d_flags, b->E, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int e = 0; e < b->E; ++e) st->n_outliers_mid += flags[e];
+    rc = ba_optimize_stage(b, its_final, 0, delta, stop, &st->chi2_initial[1], &st->chi2_final[1], &st->lambda_final[1]);
+    if (rc < 0) return rc;
+    st->iterations_done[1] = rc;
+  }
+  hipLaunchKernelGGL(k_ba_classify, dim3(b->nblk_e), dim3(256), 0, s, b->d, (const double*)b->d_poses[b->cur],
+                     (const double*)b->d_pts[b->cur], 5.991, 0, b->d_flags);
+  HIPCHK(hipMemcpyAsync(flags.data(), b->d_flags, b->E, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int e = 0; e < b->E; ++e) st->n_outliers_final += flags[e];
+  return CMS_OK;
+}
+
+extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* outlier_flags) {
+  if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (poses) HIPCHK(hipMemcpy(poses, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost));
+  if (points) HIPCHK(hipMemcpy(points, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost));
+  if (outlier_flags) {
+    std::vector<uint8_t> f(b->E);
+    HIPCHK(hipMemcpy(f.data(), b->d_flags, b->E, hipMemcpyDeviceToHost));
+    for (int i = 0; i < b->E; ++i) outlier_flags[b->perm[i]] = f[i];
+  }
+  return CMS_OK;
+}
+
+extern "C" int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,
+                          const int* e_point, const double* e_obs, const double* e_invsig2, const int8_t* e_face, double fx,
+                          double fy, double cx, double cy, int its_robust, int its_final, const volatile uint8_t* stop,
+                          uint8_t* outlier_flags, cms_ba_stats* stats) {
+  if (outlier_flags) memset(outlier_flags, 0, E > 0 ? E : 0);
+  if (stop && *stop) { if (stats) memset(stats, 0, sizeof(*stats)); return 1; }
+  cms_ba* b = nullptr;
+  int rc = cms_ba_create(&b, device, K, poses, fixed, P, points, E, e_pose, e_point, e_obs, e_invsig2, e_face, fx, fy, cx, cy);
+  if (rc) return rc;
+  rc = cms_ba_optimize(b, its_robust, its_final, stop, stats);
+  if (rc == CMS_OK) rc = cms_ba_read(b, poses, points, outlier_flags);
+  cms_ba_destroy(b);
+  return rc;
+}
+
+extern "C" int cms_ba_linearize(int device, int K, const double* poses, const uint8_t* fixed, int P, const double* points, int E,
+                                const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
+                                const int8_t* e_face, double fx, double fy, double cx, double cy, int robust, double huber_delta,
+                                double* err, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* robust_chi2_sum) {
+  cms_ba* b = nullptr;
+  int rc = cms_ba_create(&b, device, K, poses, fixed, P, points, E, e_pose, e_point, e_obs, e_invsig2, e_face, fx, fy, cx, cy);
+  if (rc) return rc;
+  hipStream_t s = b->stream;
+  ba_errors(b, 0, robust, huber_delta, 0);
+  hipLaunchKernelGGL(k_ba_lin_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_poses[0], (const double*)b->d_pts[0],
+                     robust, huber_delta, b->d_Hll, b->d_bl, b->d_Hpl);
+  hipMemsetAsync(b->d_Hpp, 0, 36 * (size_t)std::max(b->np, 1) * sizeof(double), s);
+  hipMemsetAsync(b->d_bp, 0, 6 * (size_t)std::max(b->np, 1) * sizeof(double), s);
+  hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K), dim3(256), 0, s, b->d, (const double*)b->d_poses[0], (const double*)b->d_pts[0], robust,
+                     huber_delta, b->d_Hpp, b->d_bp);
+  hipError_t he = hipStreamSynchronize(s);
+  if (he != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, "cms_ba_linearize", he); }
+  std::vector<int> slot(K, -1);
+  { int np = 0; for (int k = 0; k < K; ++k) if (!fixed[k]) slot[k] = np++; }
+  std::vector<double> tmp;
+  auto dl = [&](double* dptr, size_t cnt) { tmp.resize(cnt); hipMemcpy(tmp.data(), dptr, cnt * sizeof(double), hipMemcpyDeviceToHost); };
+  if (err) { dl(b->d_err, 2 * (size_t)E); for (int i = 0; i < E; ++i) { err[2 * b->perm[i]] = tmp[2 * i]; err[2 * b->perm[i] + 1] = tmp[2 * i + 1]; } }
+  if (Hpl) { dl(b->d_Hpl, 18 * (size_t)E); for (int i = 0; i < E; ++i) memcpy(Hpl + 18 * (size_t)b->perm[i], &tmp[18 * (size_t)i], 18 * sizeof(double)); }
+  if (Hll) { dl(b->d_Hll, 9 * (size_t)P); memcpy(Hll, tmp.data(), 9 * (size_t)P * sizeof(double)); }
+  if (bl) { dl(b->d_bl, 3 * (size_t)P); memcpy(bl, tmp.data(), 3 * (size_t)P * sizeof(double)); }
+  if (Hpp) { dl(b->d_Hpp, 36 * (size_t)std::max(b->np, 1)); memset(Hpp, 0, 36 * (size_t)K * sizeof(double)); for (int k = 0; k < K; ++k) if (slot[k] >= 0) memcpy(Hpp + 36 * (size_t)k, &tmp[36 * (size_t)slot[k]], 36 * sizeof(double)); }
+  if (bp) { dl(b->d_bp, 6 * (size_t)std::max(b->np, 1)); memset(bp, 0, 6 * (size_t)K * sizeof(double)); for (int k = 0; k < K; ++k) if (slot[k] >= 0) memcpy(bp + 6 * (size_t)k, &tmp[6 * (size_t)slot[k]], 6 * sizeof(double)); }
+  if (robust_chi2_sum) hipMemcpy(robust_chi2_sum, b->d_scal, sizeof(double), hipMemcpyDeviceToHost);
+  cms_ba_destroy(b);
+  return CMS_OK;
+}

@@ -1,0 +1,433 @@
+// cms_ba_kernels.hip -- FP64 local-bundle-adjustment kernels for gfx950 (Optimizer::LocalBundleAdjustment numeric core).
+//
+// Replaces, for the cubemap multi-pinhole edge (g2o_cubemap_vertices_edges.h:90-134, .cpp:164-233):
+//   computeActiveErrors + activeRobustChi2   (sparse_optimizer.cpp:61-114)                 -> k_ba_errors
+//   linearizeOplus + constructQuadraticForm  (base_binary_edge.hpp:54-120, Huber robust_kernel_impl.cpp:78-91)
+//                                                                  -> k_ba_lin_points (Hll, bl, Hpl) + k_ba_lin_poses (Hpp, bp)
+//   BlockSolver::setLambda / Schur complement / back substitution (block_solver.hpp:367-485, 563-589)
+//                                                                  -> k_ba_schur_init, k_ba_schur, k_ba_solve, k_ba_backsub
+//   vertex oplus (types_six_dof_expmap.h:73-76, types_sba.h:51-55, se3quat.h:217-257) -> k_ba_update_poses / k_ba_backsub
+// Edges are stored sorted by point (CSR) so Hll / bl need no atomics; per-pose blocks are reduced by one workgroup per
+// pose over that pose's edge list; the Schur products are scattered into the small dense reduced system with
+// hardware FP64 atomics.  All state stays on the device across Levenberg-Marquardt trials; the host only reads three
+// scalars per trial (chi2, gain denominator, solver status).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct BaDev {
+  int K, P, E, np;                 // np = number of free poses (reduced system is 6np x 6np)
+  const uint8_t* fixed;
+  const int* pose_slot;            // K: slot among free poses or -1
+  const int* e_pose; const int* e_point;   // E (edges sorted by point)
+  const double* e_obs; const double* e_inv; const int8_t* e_face;
+  const int* pt_off;               // P+1 CSR over the sorted edges
+  const int* pose_off; const int* pose_edges;  // K+1 / E : edge ids per pose
+  uint8_t* level;                  // E: 0 active, 1 excluded
+  double* err;                     // E x 2 (persistent, refreshed only for active edges)
+  double fx, fy, cx, cy;
+};
+
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void face_local(int face, const double* X, double* l) {  // cvtRigToFaces (CamModelGeneral.h:417-443)
+  switch (face) {
+    case 0: l[0] = X[0]; l[1] = X[1]; l[2] = X[2]; break;
+    case 1: l[0] = X[2]; l[1] = X[1]; l[2] = -X[0]; break;
+    case 2: l[0] = -X[2]; l[1] = X[1]; l[2] = X[0]; break;
+    case 3: l[0] = X[0]; l[1] = X[2]; l[2] = -X[1]; break;
+    default: l[0] = X[0]; l[1] = -X[2]; l[2] = X[1]; break;
+  }
+}
+// rows of R_face (g2o_cubemap_vertices_edges.cpp:173-205): l = Rf * X
+__device__ __forceinline__ void face_R(int face, double* Rf) {
+  for (int i = 0; i < 9; ++i) Rf[i] = 0;
+  switch (face) {
+    case 0: Rf[0] = 1; Rf[4] = 1; Rf[8] = 1; break;
+    case 1: Rf[2] = 1; Rf[4] = 1; Rf[6] = -1; break;
+    case 2: Rf[2] = -1; Rf[4] = 1; Rf[6] = 1; break;
+    case 3: Rf[0] = 1; Rf[5] = 1; Rf[7] = -1; break;
+    default: Rf[0] = 1; Rf[5] = -1; Rf[7] = 1; break;
+  }
+}
+__device__ __forceinline__ void cam_point(const double* pose, const double* R, const double* X, double* Xc) {
+  for (int i = 0; i < 3; ++i) Xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + pose[i];
+}
+__device__ __forceinline__ void edge_error(const BaDev& d, int e, const double* Xc, double* r) {
+  // multipinhole_project: the camera-frame point is cast to float first (cv::Vec3f), projection stored in float
+  const double Xf[3] = {(double)(float)Xc[0], (double)(float)Xc[1], (double)(float)Xc[2]};
+  double l[3];
+  face_local(d.e_face[e], Xf, l);
+  const float u = (float)(l[0] * d.fx / l[2] + d.cx);
+  const float v = (float)(l[1] * d.fy / l[2] + d.cy);
+  r[0] = d.e_obs[2 * e] - (double)u;
+  r[1] = d.e_obs[2 * e + 1] - (double)v;
+}
+__device__ __forceinline__ double huber_w(double e2, double delta, double* rho0) {
+  const double dsqr = delta * delta;
+  if (e2 <= dsqr) { *rho0 = e2; return 1.0; }
+  const double s = sqrt(e2);
+  *rho0 = 2 * s * delta - dsqr;
+  return delta / s;
+}
+__device__ __forceinline__ void edge_jac(const BaDev& d, int e, const double* Xc, const double* R, double* Jp, double* Jl) {
+  double Rf[9], l[3];
+  face_R(d.e_face[e], Rf);
+  for (int i = 0; i < 3; ++i) l[i] = Rf[3 * i] * Xc[0] + Rf[3 * i + 1] * Xc[1] + Rf[3 * i + 2] * Xc[2];
+  const double iz = 1.0 / l[2];
+  const double G[6] = {d.fx / l[2], 0, -d.fx * l[0] / (l[2] * l[2]), 0, d.fy / l[2], -d.fy * l[1] / (l[2] * l[2])};
+  (void)iz;
+  double M[6];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j) M[3 * i + j] = -1.0 * (G[3 * i] * Rf[j] + G[3 * i + 1] * Rf[3 + j] + G[3 * i + 2] * Rf[6 + j]);
+  const double S[9] = {0, Xc[2], -Xc[1], -Xc[2], 0, Xc[0], Xc[1], -Xc[0], 0};
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Jp[6 * i + j] = M[3 * i] * S[j] + M[3 * i + 1] * S[3 + j] + M[3 * i + 2] * S[6 + j];
+      Jp[6 * i + 3 + j] = M[3 * i + j];
+      Jl[3 * i + j] = M[3 * i] * R[j] + M[3 * i + 1] * R[3 + j] + M[3 * i + 2] * R[6 + j];
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double s = 0;
+  for (int i = 0; i < nw; ++i) s += sh[i];
+  return s;
+}
+
+// ---- residuals + robust chi2 partial sums (one partial per workgroup, reduced in fixed order by k_ba_reduce)
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_errors(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+            double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double rho0 = 0;
+  if (e < d.E && d.level[e] == 0) {
+    const double* pose = poses + 7 * d.e_pose[e];
+    double R[9], Xc[3], r[2];
+    quat_to_R(pose + 3, R);
+    cam_point(pose, R, pts + 3 * d.e_point[e], Xc);
+    edge_error(d, e, Xc, r);
+    d.err[2 * e] = r[0]; d.err[2 * e + 1] = r[1];
+    const double c2 = d.e_inv[e] * (r[0] * r[0] + r[1] * r[1]);
+    if (robust) huber_w(c2, delta, &rho0); else rho0 = c2;
+  }
+  const double s = block_sum(rho0, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_reduce(const double* __restrict__ partial, int n, double* __restrict__ out, int add) {
+  __shared__ double sh[4];
+  double v = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
+  const double s = block_sum(v, sh);
+  if (threadIdx.x == 0) *out = add ? *out + s : s;
+}
+
+// ---- per-point blocks: Hll (3x3), bl, Hpl per edge (6x3); one thread per point over its (point-sorted) edges
+extern "C" __global__ void __launch_bounds__(128)
+k_ba_lin_points(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+                double* __restrict__ Hll, double* __restrict__ bl, double* __restrict__ Hpl) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.P) return;
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  for (int e = d.pt_off[p]; e < d.pt_off[p + 1]; ++e) {
+    double* B = Hpl + 18 * (size_t)e;
+    if (d.level[e] != 0) { for (int i = 0; i < 18; ++i) B[i] = 0; continue; }
+    const double* pose = poses + 7 * d.e_pose[e];
+    double R[9], Xc[3], Jp[12], Jl[6];
+    quat_to_R(pose + 3, R);
+    cam_point(pose, R, pts + 3 * p, Xc);
+    edge_jac(d, e, Xc, R, Jp, Jl);
+    const double r0 = d.err[2 * e], r1 = d.err[2 * e + 1], om = d.e_inv[e];
+    double w = 1.0, rho0;
+    if (robust) w = huber_w(om * (r0 * r0 + r1 * r1), delta, &rho0);
+    const double ow = w * om;
+    const double o0 = -om * r0 * w, o1 = -om * r1 * w;
+    for (int i = 0; i < 3; ++i) {
+      b[i] += Jl[i] * o0 + Jl[3 + i] * o1;
+      for (int j = 0; j < 3; ++j) H[3 * i + j] += ow * (Jl[i] * Jl[j] + Jl[3 + i] * Jl[3 + j]);
+    }
+    const bool free_pose = d.pose_slot[d.e_pose[e]] >= 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 3; ++j) B[3 * i + j] = free_pose ? ow * (Jp[i] * Jl[j] + Jp[6 + i] * Jl[3 + j]) : 0.0;
+  }
+  for (int i = 0; i < 9; ++i) Hll[9 * (size_t)p + i] = H[i];
+  for (int i = 0; i < 3; ++i) bl[3 * (size_t)p + i] = b[i];
+}
+
+// ---- per-pose blocks: Hpp (6x6) and bp = Gram of [J_pose sqrt(w) | r sqrt(w)] over the pose's edge list
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_lin_poses(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+               double* __restrict__ Hpp, double* __restrict__ bp) {
+  __shared__ double sh[4];
+  const int k = blockIdx.x;
+  const int slot = d.pose_slot[k];
+  if (slot < 0) return;
+  const double* pose = poses + 7 * k;
+  double R[9];
+  quat_to_R(pose + 3, R);
+  double acc[27];
+  for (int i = 0; i < 27; ++i) acc[i] = 0;
+  for (int t = d.pose_off[k] + threadIdx.x; t < d.pose_off[k + 1]; t += blockDim.x) {
+    const int e = d.pose_edges[t];
+    if (d.level[e] != 0) continue;
+    double Xc[3], Jp[12], Jl[6];
+    cam_point(pose, R, pts + 3 * d.e_point[e], Xc);
+    edge_jac(d, e, Xc, R, Jp, Jl);
+    const double r0 = d.err[2 * e], r1 = d.err[2 * e + 1], om = d.e_inv[e];
+    double w = 1.0, rho0;
+    if (robust) w = huber_w(om * (r0 * r0 + r1 * r1), delta, &rho0);
+    const double ow = w * om;
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) acc[c++] += ow * (Jp[i] * Jp[j] + Jp[6 + i] * Jp[6 + j]);
+    for (int i = 0; i < 6; ++i) acc[21 + i] += -ow * (Jp[i] * r0 + Jp[6 + i] * r1);
+  }
+  double tot[27];
+  for (int i = 0; i < 27; ++i) tot[i] = block_sum(acc[i], sh);
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) { Hpp[36 * slot + 6 * i + j] = tot[c]; Hpp[36 * slot + 6 * j + i] = tot[c]; ++c; }
+    for (int i = 0; i < 6; ++i) bp[6 * slot + i] = tot[21 + i];
+  }
+}
+
+// ---- max |diag| of the assembled system (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_maxdiag(int np, int P, const double* __restrict__ Hpp, const double* __restrict__ Hll, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double m = 0;
+  for (int i = threadIdx.x; i < 6 * np; i += blockDim.x) m = fmax(m, fabs(Hpp[36 * (i / 6) + 7 * (i % 6)]));
+  for (int i = threadIdx.x; i < 3 * P; i += blockDim.x) m = fmax(m, fabs(Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// ---- reduced system: Hs = blockdiag(Hpp + lambda I), bs = bp ; then minus the Schur products
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_schur_init(int np, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
+                double* __restrict__ Hs, double* __restrict__ bs) {
+  const int n = 6 * np;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
+    const int r = idx / n, c = idx - r * n;
+    double v = 0;
+    if (r / 6 == c / 6) v = Hpp[36 * (r / 6) + 6 * (r % 6) + (c % 6)] + (r == c ? lambda : 0.0);
+    Hs[idx] = v;
+    if (c == 0) bs[r] = bp[r];
+  }
+}
+__device__ __forceinline__ void inv3(const double* A, double* Ai) {
+  const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], h = A[7], i = A[8];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  const double id = 1.0 / det;
+  Ai[0] = (e * i - f * h) * id; Ai[1] = (c * h - b * i) * id; Ai[2] = (b * f - c * e) * id;
+  Ai[3] = (f * g - d * i) * id; Ai[4] = (a * i - c * g) * id; Ai[5] = (c * d - a * f) * id;
+  Ai[6] = (d * h - e * g) * id; Ai[7] = (b * g - a * h) * id; Ai[8] = (a * e - b * d) * id;
+}
+extern "C" __global__ void __launch_bounds__(128)
+k_ba_schur(BaDev d, const double* __restrict__ Hll, const double* __restrict__ bl, const double* __restrict__ Hpl,
+           double lambda, double* __restrict__ Dinv, double* __restrict__ Hs, double* __restrict__ bs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.P) return;
+  const int n = 6 * d.np;
+  double D[9], Di[9];
+  for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
+  inv3(D, Di);
+  for (int i = 0; i < 9; ++i) Dinv[9 * (size_t)p + i] = Di[i];
+  const double b0 = bl[3 * (size_t)p], b1 = bl[3 * (size_t)p + 1], b2 = bl[3 * (size_t)p + 2];
+  const double db[3] = {Di[0] * b0 + Di[1] * b1 + Di[2] * b2, Di[3] * b0 + Di[4] * b1 + Di[5] * b2, Di[6] * b0 + Di[7] * b1 + Di[8] * b2};
+  const int e0 = d.pt_off[p], e1 = d.pt_off[p + 1];
+  for (int a1 = e0; a1 < e1; ++a1) {
+    const int s1 = d.pose_slot[d.e_pose[a1]];
+    if (s1 < 0 || d.level[a1] != 0) continue;
+    const double* B1 = Hpl + 18 * (size_t)a1;
+    double BD[18];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 3; ++j) BD[3 * i + j] = B1[3 * i] * Di[j] + B1[3 * i + 1] * Di[3 + j] + B1[3 * i + 2] * Di[6 + j];
+    for (int i = 0; i < 6; ++i)
+      unsafeAtomicAdd(&bs[6 * s1 + i], -(B1[3 * i] * db[0] + B1[3 * i + 1] * db[1] + B1[3 * i + 2] * db[2]));
+    for (int a2 = e0; a2 < e1; ++a2) {
+      const int s2 = d.pose_slot[d.e_pose[a2]];
+      if (s2 < 0 || d.level[a2] != 0) continue;
+      const double* B2 = Hpl + 18 * (size_t)a2;
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j)
+          unsafeAtomicAdd(&Hs[(size_t)(6 * s1 + i) * n + 6 * s2 + j],
+                          -(BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2]));
+    }
+  }
+}
+
+// ---- dense LDL^T of the reduced pose system + solve, one workgroup, in place in global memory (n <= a few hundred)
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_solve(int n, double* __restrict__ A, double* __restrict__ b, double* __restrict__ x, double* __restrict__ Dg,
+           int* __restrict__ status) {
+  __shared__ int bad;
+  const int tid = threadIdx.x, T = blockDim.x;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const double dj = A[(size_t)j * n + j];
+    if (tid == 0) { Dg[j] = dj; if (!(isfinite(dj)) || dj == 0.0) bad = 1; }
+    __syncthreads();
+    if (bad) break;
+    // column j of L (stored below the diagonal), keep the unscaled column in the upper triangle for the update
+    for (int i = j + 1 + tid; i < n; i += T) {
+      const double a = A[(size_t)i * n + j];
+      A[(size_t)j * n + i] = a;          // a_ij (unscaled)
+      A[(size_t)i * n + j] = a / dj;     // l_ij
+    }
+    __syncthreads();
+    const int rem = n - j - 1;
+    for (int idx = tid; idx < rem * rem; idx += T) {
+      const int i = j + 1 + idx / rem, k = j + 1 + idx % rem;
+      if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)j * n + k];   // l_ij * a_kj
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (!bad) {
+      for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * x[k]; x[i] = s; }
+      for (int i = 0; i < n; ++i) x[i] /= Dg[i];
+      for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * x[k]; x[i] = s; }
+    } else {
+      for (int i = 0; i < n; ++i) x[i] = 0;
+    }
+    *status = bad ? 0 : 1;
+  }
+}
+
+// ---- landmark back-substitution + point update + gain-denominator partial sums (levenberg.cpp:182-189)
+extern "C" __global__ void __launch_bounds__(128)
+k_ba_backsub(BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+             const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
+             double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double sc = 0;
+  if (p < d.P) {
+    double cl[3] = {bl[3 * (size_t)p], bl[3 * (size_t)p + 1], bl[3 * (size_t)p + 2]};
+    int nact = 0;
+    for (int a = d.pt_off[p]; a < d.pt_off[p + 1]; ++a) {
+      if (d.level[a] != 0) continue;
+      ++nact;
+      const int s = d.pose_slot[d.e_pose[a]];
+      if (s < 0) continue;
+      const double* B = Hpl + 18 * (size_t)a;
+      for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 6; ++i) cl[j] -= B[3 * i + j] * xp[6 * s + i];
+    }
+    const double* Di = Dinv + 9 * (size_t)p;
+    double xl[3] = {0, 0, 0};
+    if (nact > 0)
+      for (int i = 0; i < 3; ++i) xl[i] = Di[3 * i] * cl[0] + Di[3 * i + 1] * cl[1] + Di[3 * i + 2] * cl[2];
+    for (int i = 0; i < 3; ++i) {
+      pts_new[3 * (size_t)p + i] = pts[3 * (size_t)p + i] + xl[i];
+      sc += xl[i] * (lambda * xl[i] + bl[3 * (size_t)p + i]);
+    }
+  }
+  const double s = block_sum(sc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__device__ __forceinline__ void R_to_quat(const double* m, double* q) {  // Eigen::Quaterniond(Matrix3d)
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t; t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+    q[i] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+  }
+}
+__device__ __forceinline__ void normalize_rot(double* q) {
+  if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+// T <- exp(x) * T for the free poses, copy for the fixed ones; adds the pose part of the gain denominator to *scale
+extern "C" __global__ void __launch_bounds__(64)
+k_ba_update_poses(BaDev d, const double* __restrict__ xp, const double* __restrict__ bp, double lambda,
+                  const double* __restrict__ poses, double* __restrict__ poses_new, double* __restrict__ scale_out) {
+  double sc = 0;
+  for (int k = threadIdx.x; k < d.K; k += blockDim.x) {
+    const double* T = poses + 7 * k;
+    double* Tn = poses_new + 7 * k;
+    const int s = d.pose_slot[k];
+    if (s < 0) { for (int i = 0; i < 7; ++i) Tn[i] = T[i]; continue; }
+    const double* u = xp + 6 * s;
+    for (int i = 0; i < 6; ++i) sc += u[i] * (lambda * u[i] + bp[6 * s + i]);
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double Om[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double Om2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Om2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+      for (int i = 0; i < 9; ++i) { R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
+    } else {
+      const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+      for (int i = 0; i < 9; ++i) {
+        const double I = ((i & 3) == 0 ? 1.0 : 0.0);
+        R[i] = I + a * Om[i] + b * Om2[i];
+        V[i] = I + b * Om[i] + c * Om2[i];
+      }
+    }
+    double Eq[4], Et[3], RE[9];
+    R_to_quat(R, Eq);
+    for (int i = 0; i < 3; ++i) Et[i] = V[3 * i] * up[0] + V[3 * i + 1] * up[1] + V[3 * i + 2] * up[2];
+    normalize_rot(Eq);
+    quat_to_R(Eq, RE);
+    for (int i = 0; i < 3; ++i) Tn[i] = Et[i] + RE[3 * i] * T[0] + RE[3 * i + 1] * T[1] + RE[3 * i + 2] * T[2];
+    const double* A = Eq; const double* B = T + 3;
+    double q[4];
+    q[3] = A[3] * B[3] - A[0] * B[0] - A[1] * B[1] - A[2] * B[2];
+    q[0] = A[3] * B[0] + A[0] * B[3] + A[1] * B[2] - A[2] * B[1];
+    q[1] = A[3] * B[1] + A[1] * B[3] + A[2] * B[0] - A[0] * B[2];
+    q[2] = A[3] * B[2] + A[2] * B[3] + A[0] * B[1] - A[1] * B[0];
+    normalize_rot(q);
+    for (int i = 0; i < 4; ++i) Tn[3 + i] = q[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
+  if (threadIdx.x == 0) *scale_out = sc;
+}
+
+// ---- outlier test of Optimizer.cpp:376-382 / 404-410: chi2 of the STORED error > th or depth <= 0
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_classify(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, double chi2_th, int set_level,
+              uint8_t* __restrict__ flags) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.E) return;
+  const double c2 = d.e_inv[e] * (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]);
+  const double* pose = poses + 7 * d.e_pose[e];
+  double R[9], Xc[3];
+  quat_to_R(pose + 3, R);
+  cam_point(pose, R, pts + 3 * d.e_point[e], Xc);
+  const bool out = c2 > chi2_th || !(Xc[2] > 0.0);
+  flags[e] = out ? 1 : 0;
+  if (set_level && out) d.level[e] = 1;
+}

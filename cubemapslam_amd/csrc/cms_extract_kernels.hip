@@ -1,0 +1,410 @@
+// cms_extract_kernels.hip -- gfx950 kernels for the per-frame extraction path, batched over B frames.
+//
+//   k_remap        fisheye -> 3F x 3F cubemap cross   (System::CvtFisheyeToCubeMap_reverseQuery_withInterpolation,
+//                  System.cpp:327-355 == 5 x cv::remap INTER_LINEAR with the LUT of System.cpp:301-324)
+//   k_resize       pyramid level l from level l-1       (ORBextractor::ComputePyramid, ORBExtractor.cpp:928-953)
+//   k_fast_cells   FAST-9/16 score + per-cell NMS + ini/min threshold fallback, one wavefront per ~31x31 cell
+//                  (ComputeKeyPointsOctTree cell loop, ORBExtractor.cpp:764-803, == one cv::FAST call per cell)
+//   k_quadtree     DistributeOctTree (ORBExtractor.cpp:511-737), one workgroup per (frame, level)
+//   k_cull         scale to image coords, face / border / mask cull, ordered compaction (ORBExtractor.cpp:887-904,915-921)
+//   k_describe     IC_Angle (48-75) + GaussianBlur 7x7 (907-908, fused: only the 37x37 neighbourhood the taps can
+//                  reach is blurred) + steered BRIEF (79-118), one wavefront per key point
+//
+// All integer results are bit-exact with the CPU oracle; no host round trip between stages.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cms_types.h"
+#include "cms_detmath.h"
+#include "cms_quadtree_core.h"
+
+#define LANE_PREFIX(mask) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u)))
+
+// ------------------------------------------------------------------------------------------------ remap
+// LUT entry (one u32 per canvas pixel): X[0:11) | Y[11:22) | ax[22:27) | ay[27:32)  -- cv::remap's 5-bit fixed point.
+// One thread = 4 consecutive canvas pixels: one 16-byte LUT load, 16 byte gathers (L2 resident source), one dword store.
+extern "C" __global__ void __launch_bounds__(256)
+k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw, int Ih,
+        const uint32_t* __restrict__ lut, int lut_stride, uint8_t* __restrict__ pyr, size_t pyr_bytes,
+        int W, int stride0, int F) {
+  const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x0 >= W) return;
+  const bool mid_row = (y >= F && y < 2 * F);
+  uint8_t* dst = pyr + (size_t)b * pyr_bytes + (size_t)y * stride0 + x0;
+  if (!mid_row && (x0 + 3 < F || x0 >= 2 * F)) {  // corner block of the cross: kept at 0 (cubemap_lafida.cpp:110-111)
+    *reinterpret_cast<uint32_t*>(dst) = 0u;
+    return;
+  }
+  const uint4 e4 = *reinterpret_cast<const uint4*>(lut + (size_t)y * lut_stride + x0);
+  const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+  const uint8_t* src = fish + (size_t)b * fish_pitch;
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int x = x0 + i;
+    const bool valid = x < W && (mid_row || (x >= F && x < 2 * F));
+    if (!valid) continue;
+    const int X = e[i] & 0x7FF, Y = (e[i] >> 11) & 0x7FF, ax = (e[i] >> 22) & 31, ay = e[i] >> 27;
+    const uint8_t* s = src + (size_t)Y * fstride + X;
+    const bool xin = X + 1 < Iw, yin = Y + 1 < Ih;
+    const int p00 = s[0];
+    const int p01 = xin ? s[1] : 0;
+    const int p10 = yin ? s[fstride] : 0;
+    const int p11 = (xin && yin) ? s[fstride + 1] : 0;
+    const int S = (32 - ay) * ((32 - ax) * p00 + ax * p01) + ay * ((32 - ax) * p10 + ax * p11);
+    out |= (uint32_t)((S + 512) >> 10) << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(dst) = out;   // pixels of a straddling quad that belong to a corner block get 0
+}
+
+// ------------------------------------------------------------------------------------------------ resize
+extern "C" __global__ void __launch_bounds__(256)
+k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst,
+         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby) {
+  const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const int y = blockIdx.y * blockDim.y + threadIdx.y, b = blockIdx.z;
+  if (x0 >= dst.w || y >= dst.h) return;
+  const uint8_t* sbase = pyr + (size_t)b * pyr_bytes + src.off;
+  const CmsResizeTab ty = taby[y];
+  const int sy0 = min(max((int)ty.s, 0), src.h - 1), sy1 = min(max((int)ty.s + 1, 0), src.h - 1);
+  const uint8_t* S0 = sbase + (size_t)sy0 * src.stride;
+  const uint8_t* S1 = sbase + (size_t)sy1 * src.stride;
+  const int b0 = ty.a0, b1 = ty.a1;
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int x = x0 + i;
+    if (x >= dst.w) break;
+    const CmsResizeTab tx = tabx[x];
+    const int sx = tx.s, sx1 = min(sx + 1, src.w - 1);
+    const int r0 = S0[sx] * tx.a0 + S0[sx1] * tx.a1;
+    const int r1 = S1[sx] * tx.a0 + S1[sx1] * tx.a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    out |= (uint32_t)(v & 0xFF) << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(pyr + (size_t)b * pyr_bytes + dst.off + (size_t)y * dst.stride + x0) = out;
+}
+
+// ------------------------------------------------------------------------------------------------ FAST cells
+// Arc score A(p) = max over the 16 contiguous 9-arcs and both polarities of min |v - x|; cornerScore<16> == A - 1.
+// p is a corner at threshold t  <=>  A(p) > t.   Returns A-1 if A > t else 0.
+__device__ __forceinline__ int fast_arc_score(const int d[16], int t) {
+  uint32_t md = 0, mb = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { md |= (d[k] > t ? 1u : 0u) << k; mb |= (-d[k] > t ? 1u : 0u) << k; }
+  auto has9 = [](uint32_t m) -> bool {
+    m |= m << 16;                    // unroll the circle
+    uint32_t r = m & (m >> 1);       // 2 consecutive
+    r &= r >> 2;                     // 4
+    r &= r >> 4;                     // 8
+    r &= m >> 8;                     // 9
+    return (r & 0xFFFFu) != 0;
+  };
+  const bool cd = has9(md), cb = has9(mb);
+  if (!cd && !cb) return 0;
+  int e[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) e[k] = cd ? d[k] : -d[k];
+  int m2[16], m4[16], m8[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m2[k] = min(e[k], e[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+  int A = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) A = max(A, min(m8[k], e[(k + 8) & 15]));
+  return A - 1;
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint32_t* __restrict__ cand,
+             int* __restrict__ cand_cnt, int* __restrict__ overflow) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y;
+  int l = 0;
+  for (int k = 1; k < g.nlevels; ++k) if ((int)blockIdx.x >= g.lv[k].cell0) l = k;
+  const CmsLevel& lv = g.lv[l];
+  const int lc = blockIdx.x - lv.cell0;
+  const int ci = lc / lv.nCols, cj = lc - ci * lv.nCols;
+  const int maxBX = lv.w - CMS_MINB, maxBY = lv.h - CMS_MINB;
+  const int iniY = CMS_MINB + ci * lv.hCell, iniX = CMS_MINB + cj * lv.wCell;
+  if (iniY >= maxBY - 3 || iniX >= maxBX - 6) return;       // ORBExtractor.cpp:769,777
+  const int maxY = min(iniY + lv.hCell + 6, maxBY), maxX = min(iniX + lv.wCell + 6, maxBX);
+  const int ex0 = iniX + 3, ex1 = maxX - 3, ey0 = iniY + 3, ey1 = maxY - 3;   // pixels cv::FAST evaluates in this ROI
+  const int ew = ex1 - ex0, eh = ey1 - ey0;
+  if (ew <= 0 || eh <= 0) return;
+
+  uint8_t* tile = smem;                                             // [tile_h][tile_stride]
+  uint8_t* sc = tile + g.tile_h * g.tile_stride;                     // [sc_h][sc_stride], zero border
+  uint16_t* list = reinterpret_cast<uint16_t*>(sc + g.sc_h * g.sc_stride);
+  const int ts = g.tile_stride, ss = g.sc_stride;
+
+  // ---- stage the ROI in LDS with aligned dword loads
+  const uint8_t* img = pyr + (size_t)b * pyr_bytes + lv.off;
+  const int ax0 = iniX & ~3;
+  const int ndw = (maxX - ax0 + 3) >> 2, th = maxY - iniY;
+  for (int idx = lane; idx < th * ndw; idx += 64) {
+    const int r = idx / ndw, c = idx - r * ndw;
+    reinterpret_cast<uint32_t*>(tile + r * ts)[c] =
+        *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * lv.stride + ax0 + 4 * c);
+  }
+  for (int idx = lane; idx < (g.sc_h * ss) >> 2; idx += 64) reinterpret_cast<uint32_t*>(sc)[idx] = 0u;
+  __syncthreads();
+
+  // ---- phase A: 4-point compass pre-test at minTh, compact the survivors into an LDS list
+  const int t = g.min_th;
+  const int npx = ew * eh;
+  int L = 0;
+  for (int base = 0; base < npx; base += 64) {
+    const int idx = base + lane;
+    bool pass = false;
+    if (idx < npx) {
+      const int py = idx / ew, px = idx - py * ew;
+      const uint8_t* c = tile + (ey0 - iniY + py) * ts + (ex0 - ax0 + px);
+      const int v = c[0];
+      const int d0 = v - c[3 * ts], d4 = v - c[3], d8 = v - c[-3 * ts], d12 = v - c[-3];
+      const bool k0 = d0 > t, k4 = d4 > t, k8 = d8 > t, k12 = d12 > t;
+      const bool b0 = -d0 > t, b4 = -d4 > t, b8 = -d8 > t, b12 = -d12 > t;
+      pass = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+    }
+    const unsigned long long m = __ballot(pass);
+    if (pass) list[L + LANE_PREFIX(m)] = (uint16_t)idx;
+    L += __popcll(m);
+  }
+  __syncthreads();
+
+  // ---- phase B: full 16-pixel ring score for the listed pixels
+  for (int base = 0; base < L; base += 64) {
+    const int k = base + lane;
+    if (k < L) {
+      const int idx = list[k];
+      const int py = idx / ew, px = idx - py * ew;
+      const uint8_t* c = tile + (ey0 - iniY + py) * ts + (ex0 - ax0 + px);
+      const int v = c[0];
+      int d[16];
+      d[0] = v - c[3 * ts];      d[1] = v - c[3 * ts + 1];   d[2] = v - c[2 * ts + 2];   d[3] = v - c[ts + 3];
+      d[4] = v - c[3];           d[5] = v - c[-ts + 3];      d[6] = v - c[-2 * ts + 2];  d[7] = v - c[-3 * ts + 1];
+      d[8] = v - c[-3 * ts];     d[9] = v - c[-3 * ts - 1];  d[10] = v - c[-2 * ts - 2]; d[11] = v - c[-ts - 3];
+      d[12] = v - c[-3];         d[13] = v - c[ts - 3];      d[14] = v - c[2 * ts - 2];  d[15] = v - c[3 * ts - 1];
+      const int S = fast_arc_score(d, t);
+      if (S > 0) sc[(py + 1) * ss + px + 1] = (uint8_t)S;
+      else list[k] = 0xFFFFu;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C: strict 8-neighbour maximum inside this cell, iniTh else minTh, emit
+  int n_all = 0, n_ini = 0;
+  for (int base = 0; base < L; base += 64) {
+    const int k = base + lane;
+    bool keep = false, ini = false;
+    if (k < L && list[k] != 0xFFFFu) {
+      const int idx = list[k];
+      const int py = idx / ew, px = idx - py * ew;
+      const uint8_t* s = sc + (py + 1) * ss + px + 1;
+      const int S = s[0];
+      keep = S > s[-1] && S > s[1] && S > s[-ss - 1] && S > s[-ss] && S > s[-ss + 1] && S > s[ss - 1] && S > s[ss] &&
+             S > s[ss + 1];
+      ini = keep && S >= g.ini_th;
+      if (!keep) list[k] = 0xFFFFu;
+    }
+    n_all += __popcll(__ballot(keep));
+    n_ini += __popcll(__ballot(ini));
+  }
+  const int n_emit = n_ini > 0 ? n_ini : n_all;
+  if (n_emit == 0) return;
+  int basepos = 0;
+  if (lane == 0) basepos = atomicAdd(&cand_cnt[b * g.nlevels + l], n_emit);
+  basepos = __shfl(basepos, 0);
+  uint32_t* out = cand + (size_t)b * g.cand_total + lv.cand_off;
+  const bool use_ini = n_ini > 0;
+  int off = 0;
+  for (int base = 0; base < L; base += 64) {
+    const int k = base + lane;
+    bool emit = false;
+    int idx = 0, S = 0, px = 0, py = 0;
+    if (k < L && list[k] != 0xFFFFu) {
+      idx = list[k];
+      py = idx / ew; px = idx - py * ew;
+      S = sc[(py + 1) * ss + px + 1];
+      emit = use_ini ? (S >= g.ini_th) : true;
+    }
+    const unsigned long long m = __ballot(emit);
+    if (emit) {
+      const int pos = basepos + off + LANE_PREFIX(m);
+      if (pos < lv.cand_cap) out[pos] = (uint32_t)(ex0 + px) | ((uint32_t)(ey0 + py) << 12) | ((uint32_t)S << 24);
+      else *overflow = 1;
+    }
+    off += __popcll(m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ quadtree
+extern "C" __global__ void __launch_bounds__(512)
+k_quadtree(CmsGeom g, const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt, uint16_t* __restrict__ node_of,
+           uint32_t* __restrict__ qt_out, int* __restrict__ qt_cnt) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int l = blockIdx.x, b = blockIdx.y;
+  const CmsLevel& lv = g.lv[l];
+  const int maxn = g.qt_maxn;
+  QtWork w;
+  uint8_t* p = smem;
+  w.maxn = maxn;
+  w.childcnt = reinterpret_cast<uint32_t*>(p); p += 16 * (size_t)maxn;
+  w.rect[0] = reinterpret_cast<QtRect*>(p); p += 8 * (size_t)maxn;
+  w.rect[1] = reinterpret_cast<QtRect*>(p); p += 8 * (size_t)maxn;
+  w.childpos = reinterpret_cast<uint16_t*>(p); p += 8 * (size_t)maxn;
+  w.cnt[0] = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)maxn;
+  w.cnt[1] = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)maxn;
+  w.s0 = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)maxn;
+  w.s1 = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)maxn;
+  w.skey = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)maxn;
+  w.part = reinterpret_cast<uint32_t*>(p); p += 4 * 512;
+  w.sc = reinterpret_cast<int*>(p); p += 64;
+  w.proc = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)maxn;
+  w.flag = p; p += maxn;
+  w.isex = p; p += maxn;
+  QtParams P;
+  P.n = min(cand_cnt[b * g.nlevels + l], lv.cand_cap);
+  P.N = lv.quota;
+  P.width = lv.w - 2 * CMS_MINB; P.height = lv.h - 2 * CMS_MINB;
+  P.minB = CMS_MINB; P.wCell = lv.wCell; P.hCell = lv.hCell; P.nCols = lv.nCols;
+  const uint32_t* c = cand + (size_t)b * g.cand_total + lv.cand_off;
+  uint16_t* no = node_of + (size_t)b * g.cand_total + lv.cand_off;
+  uint32_t* out = qt_out + (size_t)b * g.kp_cap + lv.kp_off;
+  const int S = qt_run(P, c, no, w, out);
+  if (threadIdx.x == 0) qt_cnt[b * g.nlevels + l] = S;
+}
+
+// ------------------------------------------------------------------------------------------------ cull + compaction
+// One workgroup per frame walks the levels in order; survivors keep (level, list) order (ORBExtractor.cpp:875-921).
+extern "C" __global__ void __launch_bounds__(256)
+k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ qt_cnt, const uint8_t* __restrict__ mask,
+       int mstride, CmsKeyPoint* __restrict__ kps, uint32_t* __restrict__ aux, int* __restrict__ kp_cnt) {
+  __shared__ int wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int total = 0;
+  const float Ff = (float)g.F;
+  for (int l = 0; l < g.nlevels; ++l) {
+    const CmsLevel& lv = g.lv[l];
+    const int m = qt_cnt[b * g.nlevels + l];
+    const uint32_t* src = qt_out + (size_t)b * g.kp_cap + lv.kp_off;
+    for (int base = 0; base < m; base += 256) {
+      const int k = base + tid;
+      bool keep = false;
+      float px = 0.f, py = 0.f;
+      uint32_t e = 0;
+      if (k < m) {
+        e = src[k];
+        px = (float)(int)(e & 0xFFF) * lv.scale;           // keypoint.pt * scale (Point2f * float)
+        py = (float)(int)((e >> 12) & 0xFFF) * lv.scale;
+        const float fi = px / Ff, fj = py / Ff;             // FaceInCubemap(Point2f): float / int
+        const bool face = (fi >= 0 && fi < 1 && fj >= 1 && fj < 2) || (fi >= 1 && fi < 2 && fj >= 0 && fj < 3) ||
+                          (fi >= 2 && fi < 3 && fj >= 1 && fj < 2);
+        const int ix = (int)(px + 0.5f), iy = (int)(py + 0.5f);
+        keep = face && !(px < 0 || ix >= g.W || py < 0 || iy >= g.W);
+        if (keep) keep = mask[(size_t)iy * mstride + ix] != 0;
+      }
+      const unsigned long long mk = __ballot(keep);
+      if (lane == 0) wsum[wave] = __popcll(mk);
+      __syncthreads();
+      int off = total;
+      for (int q = 0; q < wave; ++q) off += wsum[q];
+      const int chunk = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (keep) {
+        const int pos = off + LANE_PREFIX(mk);
+        CmsKeyPoint kp;
+        kp.x = px; kp.y = py; kp.size = lv.patch_size; kp.angle = -1.f; kp.response = (float)(e >> 24); kp.octave = l;
+        kps[(size_t)b * g.kp_cap + pos] = kp;
+        aux[(size_t)b * g.kp_cap + pos] = (e & 0xFFFFFFu) | ((uint32_t)l << 24);
+      }
+      total += chunk;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) kp_cnt[b] = total;
+}
+
+// ------------------------------------------------------------------------------------------------ orientation + rBRIEF
+// One wavefront per surviving key point.  A 43x43 raw patch (taps reach +-18, the 7-tap blur +-3 more) is staged in
+// LDS with REFLECT_101 at the level edges, IC_Angle runs on its centre, then a separable fixed-point 7x7 Gaussian
+// ([18,34,49,55,49,34,18], (sum+32768)>>16) produces the 37x37 blurred neighbourhood the 512 steered taps read.
+#define PR 21
+#define PW 43
+#define PS 44
+#define BW 37
+#define BS 40
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+extern "C" __global__ void __launch_bounds__(64)
+k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
+           const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const signed char* __restrict__ pattern,
+           uint8_t* __restrict__ desc) {
+  __shared__ uint8_t raw[PW * PS];
+  __shared__ uint16_t rowp[PW * BW];
+  __shared__ uint8_t blr[BW * BS];
+  const int b = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+  if (k >= kp_cnt[b]) return;
+  const uint32_t a = aux[(size_t)b * g.kp_cap + k];
+  const int cx = a & 0xFFF, cy = (a >> 12) & 0xFFF, l = a >> 24;
+  const CmsLevel& lv = g.lv[l];
+  const uint8_t* img = pyr + (size_t)b * pyr_bytes + lv.off;
+  for (int idx = lane; idx < PW * PW; idx += 64) {
+    const int r = idx / PW, c = idx - r * PW;
+    const int yy = reflect101(cy - PR + r, lv.h), xx = reflect101(cx - PR + c, lv.w);
+    raw[r * PS + c] = img[(size_t)yy * lv.stride + xx];
+  }
+  __syncthreads();
+  // ---- IC_Angle: intensity centroid over the radius-15 disc (umax of ORBExtractor.cpp:426-441)
+  int m10 = 0, m01 = 0;
+  if (lane < 31) {
+    const int v = lane - 15, av = v < 0 ? -v : v;
+    const int umax = av <= 3 ? 15 : av <= 6 ? 14 : av <= 8 ? 13 : av == 9 ? 12 : av == 10 ? 11 : av == 11 ? 10
+                     : av == 12 ? 9 : av == 13 ? 8 : av == 14 ? 6 : 3;
+    const uint8_t* row = raw + (PR + v) * PS + PR;
+    int s = 0;
+    for (int u = -umax; u <= umax; ++u) { const int p = row[u]; m10 += u * p; s += p; }
+    m01 = v * s;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+  const float angle = cms_fast_atan2((float)m01, (float)m10);
+  // ---- separable Gaussian, rows then columns
+  for (int idx = lane; idx < PW * BW; idx += 64) {
+    const int r = idx / BW, c = idx - r * BW;
+    const uint8_t* p = raw + r * PS + c;   // window [c, c+6] is centred on patch column c+3
+    rowp[idx] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+  }
+  __syncthreads();
+  for (int idx = lane; idx < BW * BW; idx += 64) {
+    const int r = idx / BW, c = idx - r * BW;
+    const uint16_t* p = rowp + r * BW + c;
+    const int s = 18 * ((int)p[0] + p[6 * BW]) + 34 * ((int)p[BW] + p[5 * BW]) + 49 * ((int)p[2 * BW] + p[4 * BW]) + 55 * (int)p[3 * BW];
+    const int v = (s + 32768) >> 16;
+    blr[r * BS + c] = (uint8_t)(v > 255 ? 255 : v);
+  }
+  __syncthreads();
+  // ---- steered BRIEF: lane i evaluates tests 4i .. 4i+3
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float sb, ca;
+  cms_sincosf(angle * factorPI, &sb, &ca);
+  const signed char* pt = pattern + 16 * lane;
+  const uint8_t* ctr = blr + 18 * BS + 18;
+  int nib = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float x0 = (float)pt[4 * t], y0 = (float)pt[4 * t + 1], x1 = (float)pt[4 * t + 2], y1 = (float)pt[4 * t + 3];
+    const int v0 = ctr[cms_cv_round(x0 * sb + y0 * ca) * BS + cms_cv_round(x0 * ca - y0 * sb)];
+    const int v1 = ctr[cms_cv_round(x1 * sb + y1 * ca) * BS + cms_cv_round(x1 * ca - y1 * sb)];
+    nib |= (v0 < v1 ? 1 : 0) << t;
+  }
+  const int other = __shfl_xor(nib, 1);
+  if ((lane & 1) == 0) desc[((size_t)b * g.kp_cap + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+  if (lane == 0) kps[(size_t)b * g.kp_cap + k].angle = angle;
+}

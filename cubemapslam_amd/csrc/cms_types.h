@@ -1,0 +1,45 @@
+// cms_types.h -- plain structs shared by the host side of the C-ABI library and the gfx950 kernels.
+#ifndef CMS_TYPES_H
+#define CMS_TYPES_H
+#include <stddef.h>
+#include <stdint.h>
+
+#define CMS_MAX_LEVELS 12
+#define CMS_EDGE 19        /* EDGE_THRESHOLD, ORBExtractor.cpp:45 */
+#define CMS_MINB 16        /* EDGE_THRESHOLD - 3, ORBExtractor.cpp:747 */
+
+struct CmsLevel {
+  int w, h;             // level size: cvRound(W * invScale[l]) (ORBExtractor.cpp:932-933)
+  int stride;           // bytes per row in the device pyramid (multiple of 128)
+  size_t off;           // byte offset of the level inside one frame's pyramid
+  int nCols, nRows, wCell, hCell;  // FAST cell grid (ORBExtractor.cpp:759-762)
+  int cell0;            // index of this level's first cell in the flattened (all levels) cell list
+  int quota;            // mnFeaturesPerLevel
+  int cand_cap;         // capacity of the candidate list of this level
+  size_t cand_off;      // offset (entries) of the level's candidate list inside one frame's candidate buffer
+  int kp_off;           // offset of the level inside one frame's distributed-key-point list
+  float scale;          // mvScaleFactor[l]
+  float patch_size;     // (int)(31 * scale) as float (ORBExtractor.cpp:810)
+  size_t tab_off;       // offset (entries) of this level's resize coefficient table (x then y)
+};
+
+struct CmsGeom {
+  int nlevels, W, F;
+  int ini_th, min_th;
+  int total_cells;
+  int kp_cap;                 // per-frame capacity of the key-point lists: sum(quota + 3)
+  int qt_maxn;                // power of two >= max quota + 3
+  size_t pyr_bytes;           // bytes per frame pyramid
+  size_t cand_total;          // candidate entries per frame
+  int tile_h, tile_stride;    // FAST LDS tile geometry (rows, bytes per row, multiple of 4)
+  int sc_stride, sc_h;        // FAST LDS score tile
+  int list_cap;               // FAST LDS corner list capacity
+  CmsLevel lv[CMS_MAX_LEVELS];
+};
+
+// resize coefficient entry: source index + the two 11-bit weights (cv::resize INTER_LINEAR fixed point)
+struct CmsResizeTab { short s; short a0; short a1; short pad; };
+
+struct CmsKeyPoint { float x, y, size, angle, response; int octave; };
+
+#endif

@@ -168,34 +168,29 @@ def ba_problem(K=20, P=20000, obs_per_point=4, F=650, seed=42, outlier_frac=0.05
     pts[near] += np.array([0, 0, 4.0])
     sig2 = (np.float32(scale) ** np.arange(nlevels, dtype=np.float32)) ** 2
     inv_sig2_tab = (np.float32(1.0) / sig2.astype(np.float32)).astype(np.float32)
-    e_pose, e_point, e_obs, e_inv, e_face = [], [], [], [], []
-    for p in range(P):
-        ks = rs.permutation(K)
-        got = 0
-        for k in ks:
-            if got >= obs_per_point:
-                break
-            Xc = Rt[k] @ pts[p] + tt[k]
-            ray = Xc / np.linalg.norm(Xc)
-            if ray[2] < np.cos(np.deg2rad(190.0 / 2)):
-                continue
-            face, up, vp = rays_to_cubemap(F, Xc[None, :])
-            if face[0] < 0:
-                continue
-            octave = rs.randint(0, nlevels)
-            sd = scale ** octave
-            if rs.uniform() < outlier_frac:
-                noise = rs.uniform(-30, 30, 2)
-            else:
-                noise = rs.normal(0, sd, 2)
-            px = np.float32(up[0] + noise[0]); py = np.float32(vp[0] + noise[1])
-            f2 = face_of_pixel(F, np.array([float(px)]), np.array([float(py)]))[0]
-            if f2 < 0:
-                continue
-            u = float(px) - np.floor(float(px) / F) * F
-            v = float(py) - np.floor(float(py) / F) * F
-            e_pose.append(k); e_point.append(p); e_obs.append((u, v)); e_inv.append(float(inv_sig2_tab[octave])); e_face.append(f2)
-            got += 1
+    # all (point, keyframe) projections at once, then per point the first `obs_per_point` valid views in a random order
+    Xc = np.einsum("kij,pj->pki", Rt, pts) + tt[None, :, :]                   # P x K x 3
+    ray_z = Xc[..., 2] / np.linalg.norm(Xc, axis=-1)
+    face, up, vp = rays_to_cubemap(F, Xc)
+    octave = rs.randint(0, nlevels, size=(P, K))
+    sd = scale ** octave
+    gross = rs.uniform(size=(P, K)) < outlier_frac
+    noise = np.where(gross[..., None], rs.uniform(-30, 30, size=(P, K, 2)), rs.normal(0, 1, size=(P, K, 2)) * sd[..., None])
+    px = (up + noise[..., 0]).astype(np.float32).astype(np.float64)
+    py = (vp + noise[..., 1]).astype(np.float32).astype(np.float64)
+    f2 = face_of_pixel(F, px, py)
+    ok = (face >= 0) & (f2 >= 0) & (ray_z >= np.cos(np.deg2rad(190.0 / 2)))
+    order = np.argsort(rs.uniform(size=(P, K)), axis=1)
+    ok_o = np.take_along_axis(ok, order, 1)
+    take_o = ok_o & (np.cumsum(ok_o, axis=1) <= obs_per_point)
+    pp, jj = np.nonzero(take_o)
+    kk = order[pp, jj]
+    u = px[pp, kk] - np.floor(px[pp, kk] / F) * F
+    v = py[pp, kk] - np.floor(py[pp, kk] / F) * F
+    e_pose, e_point = kk, pp
+    e_obs = np.stack([u, v], 1)
+    e_inv = inv_sig2_tab[octave[pp, kk]].astype(np.float64)
+    e_face = f2[pp, kk]
     # perturb the initial estimate (1 deg / 2 cm poses, 2 cm points); inputs are float-representable doubles
     poses = np.zeros((K, 7))
     for k in range(K):
@@ -210,8 +205,8 @@ def ba_problem(K=20, P=20000, obs_per_point=4, F=650, seed=42, outlier_frac=0.05
     points = (pts + rs.normal(0, 0.02, pts.shape)).astype(np.float32).astype(np.float64)
     fixed = np.zeros(K, np.uint8); fixed[0] = 1
     return dict(poses=poses, fixed=fixed, points=points, e_pose=np.array(e_pose, np.int32),
-                e_point=np.array(e_point, np.int32), e_obs=np.array(e_obs, np.float64).reshape(-1, 2),
-                e_invsig2=np.array(e_inv, np.float64), e_face=np.array(e_face, np.int8),
+                e_point=np.array(e_point, np.int32), e_obs=np.ascontiguousarray(e_obs, np.float64).reshape(-1, 2),
+                e_invsig2=np.ascontiguousarray(e_inv, np.float64), e_face=np.array(e_face, np.int8),
                 fx=F / 2.0, fy=F / 2.0, cx=F / 2.0, cy=F / 2.0)
 
 

@@ -1,0 +1,159 @@
+/*
+ * cubemapslam_hip.h -- C-ABI of libcubemapslam_hip.so: the MI355X (gfx950) implementation of CubemapSLAM's
+ * per-frame data-parallel hot path.  Plain C, caller-owned buffers, int status returns (0 = ok, <0 = error, see
+ * cms_last_error()); nothing throws across this boundary and no torch / OpenCV / Eigen type appears in it.
+ *
+ * The reference has no FFI layer: its "boundary" is four C++ interfaces inside libCubemapSLAM.so.
+ * Each entry point below names the reference interface it stands under; cubemapslam_amd/host/ holds C++ classes with
+ * the reference's own signatures (ORBextractor::operator(), ORBMatcher, Optimizer::LocalBundleAdjustment,
+ * System::CvtFisheyeToCubeMap_reverseQuery_withInterpolation) implemented on top of these calls, and INTEGRATION.md
+ * shows the binding a maintainer of the reference would add.
+ *
+ * Threading contract (reference: Tracking thread extracts/matches, LocalMapping thread runs local BA concurrently,
+ * System.cpp:108-127): a cms_ctx owns one HIP stream for the frame path; every cms_ba handle owns its own stream.
+ * Frame-path calls on one ctx must come from one thread at a time; BA calls on one handle likewise; the two may
+ * overlap freely.
+ */
+#ifndef CUBEMAPSLAM_HIP_H
+#define CUBEMAPSLAM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMS_OK 0
+#define CMS_ERR_ARG (-1)
+#define CMS_ERR_HIP (-2)
+#define CMS_ERR_UNSUPPORTED (-3)
+#define CMS_ERR_OVERFLOW (-4)
+#define CMS_ERR_NO_DEVICE (-5)
+
+/* Face ids, include/CamModelGeneral.h:55-62 */
+enum { CMS_FACE_UNKNOWN = -1, CMS_FACE_FRONT = 0, CMS_FACE_LEFT = 1, CMS_FACE_RIGHT = 2, CMS_FACE_UPPER = 3, CMS_FACE_LOWER = 4 };
+
+/* What System::System reads from the YAML and hands to CamModelGeneral::SetCamParams (System.cpp:63-89). */
+typedef struct {
+  double c, d, e, u0, v0;  /* Camera.c/d/e/u0/v0 */
+  double invpol[12];       /* Camera.pol0..11, zero padded (System.cpp:70-72) */
+  double pol[5];           /* Camera.a0..4 */
+  int Iw, Ih;              /* Camera.Iw / Ih */
+  int face;                /* CubeFace.w == CubeFace.h; fx = fy = cx = cy = face/2 (System.cpp:83-84) */
+  double fov_deg;          /* Camera.fov */
+} cms_camera;
+
+/* ORBextractor ctor arguments (include/ORBExtractor.h:55-56, Tracking.cpp:88-96) */
+typedef struct { int nfeatures; float scale_factor; int nlevels; int ini_th_fast; int min_th_fast; } cms_orb_params;
+
+/* The cv::KeyPoint fields the extractor fills (ORBExtractor.cpp:811-821, 918-919) */
+typedef struct { float x, y, size, angle, response; int octave; } cms_keypoint;
+
+typedef struct {
+  int W, F, nlevels, kp_cap, max_batch;
+  int level_w[12], level_h[12], level_quota[12], level_cells[12];
+  float scale[12], inv_scale[12], sigma2[12], inv_sigma2[12];  /* ORBextractor::GetScaleFactors() etc. (ORBExtractor.h:67-87) */
+  size_t pyramid_bytes_per_frame, candidate_entries_per_frame;
+  int fisheye_stride;      /* row stride (bytes) of the device fisheye staging buffer */
+} cms_geometry;
+
+typedef struct cms_ctx cms_ctx;
+
+const char* cms_last_error(void);
+int cms_device_count(void);
+
+/* ---- context: builds the remap LUT (System::CreateUndistortRectifyMap, System.cpp:301-324) and the extractor
+ *      tables (ORBextractor::ORBextractor, ORBExtractor.cpp:381-442) once, allocates device buffers for max_batch frames. */
+int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, const cms_orb_params* orb, int max_batch);
+void cms_ctx_destroy(cms_ctx* ctx);
+int cms_ctx_geometry(const cms_ctx* ctx, cms_geometry* out);
+void* cms_ctx_stream(cms_ctx* ctx);  /* hipStream_t of the frame path (for event timing / interop) */
+
+/* ---- single-frame, host-buffer calls (the literal drop-in boundary)
+ * cms_remap        : System::CvtFisheyeToCubeMap_reverseQuery_withInterpolation (include/System.h:106-107, System.cpp:327-355).
+ *                    Writes the five face rectangles of the caller's 3F x 3F canvas; corner blocks are left untouched.
+ * cms_set_mask     : the `mask` argument of ORBextractor::operator() (ORBExtractor.cpp:846-848), kept on the device.
+ * cms_extract      : ORBextractor::operator()(image, mask, keypoints, descriptors) (include/ORBExtractor.h:63-65,
+ *                    ORBExtractor.cpp:838-926).  *n receives the key-point count; returns CMS_ERR_OVERFLOW if cap is too small. */
+int cms_remap(cms_ctx* ctx, const uint8_t* fisheye, int fstride, uint8_t* cubemap, int cstride);
+int cms_set_mask(cms_ctx* ctx, const uint8_t* mask, int mstride);
+int cms_extract(cms_ctx* ctx, const uint8_t* cubemap, int cstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n);
+int cms_remap_extract(cms_ctx* ctx, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n);
+
+/* ---- batched, device-resident frame path (many frames / streams per launch; inputs already in HBM)
+ * cms_frames_input()   : device pointer of the fisheye staging buffer, [max_batch][Ih][fisheye_stride] bytes.
+ * cms_frames_upload()  : convenience host->device copy of B fisheye frames into that buffer.
+ * cms_frames_process() : enqueue remap + pyramid + FAST + octree + cull + orientation + rBRIEF for frames [0,B) on the
+ *                        ctx stream (asynchronous).  from_fisheye = 0 skips the remap (level 0 was uploaded by cms_extract).
+ * cms_frames_results() : device pointers of the outputs: kps [max_batch][kp_cap] cms_keypoint, desc [max_batch][kp_cap][32],
+ *                        counts [max_batch] int.
+ */
+void* cms_frames_input(cms_ctx* ctx);
+int cms_frames_upload(cms_ctx* ctx, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B);
+int cms_frames_process(cms_ctx* ctx, int B, int from_fisheye);
+int cms_frames_sync(cms_ctx* ctx);
+int cms_frames_results(cms_ctx* ctx, void** d_kps, void** d_desc, void** d_counts);
+int cms_frames_fetch(cms_ctx* ctx, int b, cms_keypoint* kps, uint8_t* desc, int cap, int* n);
+
+/* ---- stage-by-stage read-back for the parity tests */
+int cms_debug_lut(cms_ctx* ctx, uint32_t* out, int* stride);
+int cms_debug_cubemap(cms_ctx* ctx, int b, uint8_t* dst, int dstride);
+int cms_debug_level(cms_ctx* ctx, int b, int level, uint8_t* dst, int dstride);
+int cms_debug_candidates(cms_ctx* ctx, int b, int level, int* xys, int cap, int* n);   /* (x, y, score) rel. to minBorder, unordered */
+int cms_debug_distributed(cms_ctx* ctx, int b, int level, int* xys, int cap, int* n);  /* octree output, list order, level coords */
+
+/* ---- in-library stage timing with HIP events on the ctx stream (ms of the last cms_frames_process call)
+ *      stages: 0 remap, 1 pyramid, 2 fast, 3 octree, 4 cull, 5 describe, 6 total */
+int cms_profile_enable(cms_ctx* ctx, int on);
+int cms_profile_get(cms_ctx* ctx, float* ms7);
+
+/* ---- matching: ORBMatcher::DescriptorDistance (ORBMatcher.cpp:951-967) evaluated over the candidate list of every query
+ *      (the inner loops of ORBMatcher::SearchByProjection, ORBMatcher.cpp:84-113 / 186-205).  Candidates are a CSR:
+ *      query q scans cand_idx[cand_off[q] .. cand_off[q+1]).  t_excluded (optional) marks target key points that already
+ *      hold a map point (ORBMatcher.cpp:91-95).  Outputs follow the sequential scan exactly (first minimum wins).
+ *      The *_device variant takes device pointers and is asynchronous on the ctx stream. */
+int cms_hamming_best2(cms_ctx* ctx, const uint8_t* qdesc, int nq, const uint8_t* tdesc, int nt, const int* cand_off,
+                      const int* cand_idx, const int* t_level, const uint8_t* t_excluded, int* best_idx, int* best_dist,
+                      int* best_level, int* second_dist, int* second_level);
+int cms_hamming_best2_device(cms_ctx* ctx, const void* qdesc, int nq, const void* tdesc, const void* cand_off,
+                             const void* cand_idx, const void* t_level, const void* t_excluded, void* best_idx,
+                             void* best_dist, void* best_level, void* second_dist, void* second_level);
+int cms_hamming_matrix(cms_ctx* ctx, const uint8_t* a, int na, const uint8_t* b, int nb, uint16_t* out);
+
+/* ---- local bundle adjustment: numeric core of Optimizer::LocalBundleAdjustment (include/Optimizer.h:50,
+ *      src/Optimizer.cpp:192-451) with EdgeSE3ProjectXYZMultiPinhole (include/g2o_cubemap_vertices_edges.h:90-134).
+ *      The caller (the Optimizer mirror in cubemapslam_amd/host/) assembles the window exactly like Optimizer.cpp:194-357:
+ *      poses K x 7 (tx,ty,tz,qx,qy,qz,qw; world->camera), fixed[K], points P x 3, and per observation: pose index,
+ *      point index, measurement in the face, invSigma2 of the octave, face id.
+ *      cms_ba_optimize runs optimize(its_robust) with Huber(sqrt(5.991)) -> chi2/depth classification ->
+ *      optimize(its_final) on the inliers without kernel -> final classification (outlier_flags[e] = 1 to erase);
+ *      *stop is polled between iterations like g2o's forceStopFlag (Optimizer.cpp:256-257). */
+typedef struct cms_ba cms_ba;
+typedef struct {
+  int iterations_done[2];
+  double chi2_initial[2], chi2_final[2], lambda_final[2];
+  int n_outliers_mid, n_outliers_final;
+} cms_ba_stats;
+int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P, const double* points,
+                  int E, const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
+                  const int8_t* e_face, double fx, double fy, double cx, double cy);
+int cms_ba_reset(cms_ba* ba);  /* restore the initial estimate on the device (benchmark loops) */
+int cms_ba_optimize(cms_ba* ba, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats);
+int cms_ba_read(cms_ba* ba, double* poses, double* points, uint8_t* outlier_flags);
+void* cms_ba_stream(cms_ba* ba);
+void cms_ba_destroy(cms_ba* ba);
+/* one-shot convenience: create + optimize + read + destroy */
+int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,
+               const int* e_point, const double* e_obs, const double* e_invsig2, const int8_t* e_face, double fx, double fy,
+               double cx, double cy, int its_robust, int its_final, const volatile uint8_t* stop, uint8_t* outlier_flags,
+               cms_ba_stats* stats);
+/* one linearisation at the given estimate (parity of the J^T J / J^T r build): Hpp K x 36, bp K x 6, Hll P x 9, bl P x 3,
+ * Hpl E x 18 (caller's edge order), err E x 2, robust chi2 sum */
+int cms_ba_linearize(int device, int K, const double* poses, const uint8_t* fixed, int P, const double* points, int E,
+                     const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
+                     const int8_t* e_face, double fx, double fy, double cx, double cy, int robust, double huber_delta,
+                     double* err, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* robust_chi2_sum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

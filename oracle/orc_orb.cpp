@@ -324,7 +324,10 @@ int orc_orb_extract(orc_orb* o, const orc_camera* cam, const uint8_t* image, int
     for (size_t i = 0; i < kept.size(); ++i) {
       const KP& k = kept[i];
       const float angle = (float)k.angle * factorPI;
-      const float a = (float)cosf(angle), b = (float)sinf(angle);
+      // reference: a = (float)cos(angle), b = (float)sin(angle) on floats (ORBExtractor.cpp:84) -> the platform's cosf/sinf.
+      // libm float results differ between glibc versions in the last ulp (2.6 % of angles vs this image's glibc); the
+      // oracle fixes the CORRECTLY ROUNDED value (what glibc >= 2.41 / CORE-MATH returns), evaluated via long double.
+      const float a = (float)cosl((long double)angle), b = (float)sinl((long double)angle);
       const int cy = orc_cv_round(k.y), cx = orc_cv_round(k.x);
       uint8_t d32[32];
       const signed char* pat = kOrcPattern;
