@@ -46,11 +46,12 @@ k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw
     if (!valid) continue;
     const int X = e[i] & 0x7FF, Y = (e[i] >> 11) & 0x7FF, ax = (e[i] >> 22) & 31, ay = e[i] >> 27;
     const uint8_t* s = src + (size_t)Y * fstride + X;
-    const bool xin = X + 1 < Iw, yin = Y + 1 < Ih;
-    const int p00 = s[0];
-    const int p01 = xin ? s[1] : 0;
-    const int p10 = yin ? s[fstride] : 0;
-    const int p11 = (xin && yin) ? s[fstride + 1] : 0;
+    // BORDER_CONSTANT(0) per tap: a valid map value just below Iw / Ih can round up to X == Iw / Y == Ih
+    const bool x0in = X < Iw, y0in = Y < Ih, x1in = X + 1 < Iw, y1in = Y + 1 < Ih;
+    const int p00 = (x0in && y0in) ? s[0] : 0;
+    const int p01 = (x1in && y0in) ? s[1] : 0;
+    const int p10 = (x0in && y1in) ? s[fstride] : 0;
+    const int p11 = (x1in && y1in) ? s[fstride + 1] : 0;
     const int S = (32 - ay) * ((32 - ax) * p00 + ax * p01) + ay * ((32 - ax) * p10 + ax * p11);
     out |= (uint32_t)((S + 512) >> 10) << (8 * i);
   }
