@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the CubemapSLAM hot path (remap + ORB extract + Hamming match + local BA) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json: "frames/sec (extract+match+localBA) on Lafida cam0", configs[2] geometry): synthetic Lafida cam0
+stream, 754x480 fisheye, cube face F=550 (1650^2 cross), nFeatures 2000 / 8 levels / 1.2 / FAST 20-7.
+One step = one batch of B consecutive frames, inputs resident in HBM:
+    remap -> pyramid -> FAST cells -> octree -> cull -> orientation + rBRIEF     (ORBextractor::operator(), all B frames per launch)
+    Hamming best/second-best of every key point of frame b-1 against its window candidates in frame b
+        (the inner loops of ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15); candidate windows built once
+         on the host from the real key points -- GetFeaturesInArea is a "next" row)
+    one local BA window (K=20 key frames, ~80k cubemap edges, BASELINE.json configs[3]) per `--ba-every` frames, on its own
+        stream / host thread like the reference's LocalMapping thread.
+Weak scaling over GPUs: every rank runs its own stream(s); the only exchange is an RCCL gather of the per-frame trajectory
+records [ts, t(3), q(4)] (System.cpp:261-262 order) to rank 0.
+
+Prints ONE JSON line (rank 0) incl. `roofline` for the dominant kernel (HIP-event timing on the library's stream) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores, single thread, on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def make_frames(camd, B, seed):
+    """B consecutive frames of one synthetic stream: a large seeded texture drifting 3 px / frame under the fisheye."""
+    from cubemapslam_amd import synth
+    Ih, Iw = camd["Ih"], camd["Iw"]
+    big = synth.texture(Ih + 4 * B + 8, Iw + 4 * B + 8, seed)
+    return np.stack([big[2 * b:2 * b + Ih, 3 * b:3 * b + Iw] for b in range(B)]).copy()
+
+
+def build_match_lists(kps_per_frame, scales, kp_cap, th=15.0):
+    """SearchByProjection(Cur, Last) candidate windows (ORBMatcher.cpp:176-181): radius th*scale[octave], octave +-1."""
+    from scipy.spatial import cKDTree
+    B = len(kps_per_frame)
+    q_row, off, idx = [], [0], []
+    for b in range(B):
+        last, cur = kps_per_frame[(b - 1) % B], kps_per_frame[b]
+        if len(cur) == 0:
+            continue
+        tree = cKDTree(np.stack([cur["x"], cur["y"]], 1))
+        for i in range(len(last)):
+            r = th * scales[last["octave"][i]]
+            cand = tree.query_ball_point([last["x"][i], last["y"][i]], r, p=np.inf)
+            cand = [c for c in sorted(cand) if abs(int(cur["octave"][c]) - int(last["octave"][i])) <= 1]
+            q_row.append(((b - 1) % B) * kp_cap + i)
+            idx.extend(b * kp_cap + c for c in cand)
+            off.append(len(idx))
+    return np.array(q_row, np.int32), np.array(off, np.int32), np.array(idx, np.int32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--face", type=int, default=550)
+    ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from cubemapslam_amd import api, build, synth
+    build.build(verbose=False)
+
+    B, F = args.batch, args.face
+    camd = synth.camera("lafida", F)
+    nfeat = camd["nfeatures"]
+    ctx = api.Context(camd, nfeatures=nfeat, max_batch=B, device=local_rank)
+    mask = synth.cubemap_valid_mask(camd)
+    ctx.set_mask(mask)
+    frames = make_frames(camd, B, seed=100 + rank)
+    ctx.upload(frames)          # inputs resident in HBM before the timed region
+    ctx.process(B, True)
+    ctx.sync()
+    kps = [ctx.fetch(b)[0] for b in range(B)]
+    g = ctx.geom
+    kp_cap = g.kp_cap
+    scales = [g.scale[l] for l in range(g.nlevels)]
+    q_row, c_off, c_idx = build_match_lists(kps, scales, kp_cap)
+    nq = len(q_row)
+    t_level = np.zeros(B * kp_cap, np.int32)
+    for b in range(B):
+        t_level[b * kp_cap:b * kp_cap + len(kps[b])] = kps[b]["octave"]
+    dev = torch.device("cuda", local_rank)
+    d_qrow = torch.from_numpy(q_row).to(dev); d_off = torch.from_numpy(c_off).to(dev); d_idx = torch.from_numpy(c_idx).to(dev)
+    d_lvl = torch.from_numpy(t_level).to(dev)
+    d_out = [torch.zeros(max(nq, 1), dtype=torch.int32, device=dev) for _ in range(5)]
+    _, d_desc, _ = ctx.results_ptrs()
+
+    n_ba = max(1, B // args.ba_every)
+    prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + rank)
+    # one LocalMapping-like host thread + BA handle (own HIP stream) per window, all concurrent with the frame path
+    bas = [api.BundleAdjuster(prob, device=local_rank) for _ in range(n_ba)]
+    ba_err = []
+
+    def ba_worker(ba):
+        try:
+            ba.reset()
+            ba.optimize((5, 10))
+        except Exception as e:  # surfaced after join
+            ba_err.append(e)
+
+    traj = torch.zeros((B, 8), dtype=torch.float64, device=dev)
+
+    def step(i):
+        ths = [threading.Thread(target=ba_worker, args=(ba,)) for ba in bas]
+        for th in ths:
+            th.start()
+        ctx.process(B, True)
+        ctx.hamming_best2_device(d_desc, d_qrow.data_ptr(), nq, d_desc, d_off.data_ptr(), d_idx.data_ptr(), d_lvl.data_ptr(), None,
+                                 [o.data_ptr() for o in d_out])
+        ctx.sync()
+        for th in ths:
+            th.join()
+        if ba_err:
+            raise ba_err[0]
+        if world > 1:   # trajectory assembly on rank 0 (tiny payload, latency only)
+            poses, _, _ = bas[0].read()
+            rec = np.zeros((B, 8)); rec[:, 0] = i * B + np.arange(B); rec[:, 1:] = poses[np.arange(B) % len(poses)]
+            traj.copy_(torch.from_numpy(rec))
+            import torch.distributed as dist
+            out = [torch.empty_like(traj) for _ in range(world)] if rank == 0 else None
+            dist.gather(traj, out, dst=0)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.profile(True)
+    for i in range(args.warmup):
+        step(i)
+    stage_ms = {}
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        for k, v in ctx.profile_ms().items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    for k in stage_ms:
+        stage_ms[k] /= max(args.steps, 1)
+
+    # ---- roofline of the dominant extraction kernel (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
+    sumP = sum(g.level_w[l] * g.level_h[l] for l in range(g.nlevels))
+    P = [g.level_w[l] * g.level_h[l] for l in range(g.nlevels)]
+    nkp = float(np.mean([len(k) for k in kps]))
+    alg = {
+        "remap": camd["Iw"] * camd["Ih"] + 5 * F * F * (1 + 4),                     # source + dest + one packed u32 LUT entry / px
+        "pyramid": sum(P[l - 1] + P[l] for l in range(1, g.nlevels)),               # read level l-1, write level l
+        "fast": sumP,                                                                # every pyramid pixel read once
+        "describe": nkp * (43 * 43 + 32 + 24),                                       # raw patch + descriptor + key-point record
+    }
+    dom = max(("remap", "pyramid", "fast", "describe", "octree", "cull"), key=lambda k: stage_ms.get(k, 0.0))
+    peak = 8000.0
+    roof = None
+    if dom in alg and stage_ms.get(dom, 0) > 0:
+        launches = 7 if dom == "pyramid" else 1
+        ach = alg[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        roof = {"kernel": {"remap": "k_remap", "pyramid": "k_resize (7 launches)", "fast": "k_fast_cells", "describe": "k_describe"}[dom],
+                "bound": "hbm", "achieved": round(ach, 1), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4),
+                "traffic": None, "ms_per_launch": round(stage_ms[dom] / launches, 4),
+                "algorithmic_bytes_per_launch": int(alg[dom] * B / launches)}
+    else:
+        roof = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": peak, "unit": "GB/s", "frac": None, "traffic": None,
+                "ms_per_launch": round(stage_ms.get(dom, 0.0), 4)}
+    fast_gbs = alg["fast"] * B / (stage_ms["fast"] * 1e-3) / 1e9 if stage_ms.get("fast", 0) > 0 else None
+
+    # ---- CPU baseline: the oracle, single thread, on a bounded sample of the same workload (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        import orc
+        ocam = orc.make_camera(camd)
+        m1, m2 = orc.build_lut(ocam)
+        o = orc.Orb(nfeatures=nfeat)
+        n = min(args.cpu_frames, B)
+        t1 = time.perf_counter()
+        descs = []
+        for b in range(n):
+            cube = orc.fisheye_to_cubemap(ocam, m1, m2, frames[b])
+            k, d = o.extract(ocam, cube, mask)
+            descs.append(d)
+        t_ext = time.perf_counter() - t1
+        # matching on the same candidate lists (queries of the first n frame pairs)
+        sel = np.nonzero((q_row // kp_cap) < n - 1)[0] if n > 1 else np.zeros(0, int)
+        t1 = time.perf_counter()
+        if len(sel):
+            alld = np.zeros((B * kp_cap, 32), np.uint8)
+            for b in range(n):
+                alld[b * kp_cap:b * kp_cap + len(descs[b])] = descs[b]
+            # queries whose targets are inside the sample
+            ok = np.array([c_idx[c_off[q]:c_off[q + 1]].max(initial=0) < n * kp_cap for q in sel])
+            sel = sel[ok]
+            cnt = (c_off[sel + 1] - c_off[sel]).astype(np.int64)
+            off2 = np.zeros(len(sel) + 1, np.int32); off2[1:] = np.cumsum(cnt)
+            idx2 = np.concatenate([c_idx[c_off[q]:c_off[q + 1]] for q in sel]) if len(sel) else np.zeros(0, np.int32)
+            t1 = time.perf_counter()
+            orc.hamming_best2(alld[q_row[sel]], alld, off2, idx2, t_level)
+        t_match = time.perf_counter() - t1
+        pairs = max(len(sel), 1) / max(nq / B, 1.0)      # frame pairs' worth of queries matched
+        t1 = time.perf_counter()
+        n_cpu_ba = 3
+        for _ in range(n_cpu_ba):
+            orc.ba_run(prob)
+        t_ba = (time.perf_counter() - t1) / n_cpu_ba
+        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_ba / args.ba_every
+        cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d frames remap+extract (%.1f ms/frame), Hamming over %.1f frame pairs (%.2f ms/frame), %d local-BA windows "
+                         "(%.1f ms each, 1 per %d frames); oracle/liborc.so, single thread" %
+                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), n_cpu_ba, 1e3 * t_ba, args.ba_every),
+               "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        total_frames = B * args.steps * world
+        out = {
+            "metric": "frames/sec (extract+match+localBA) on Lafida cam0",
+            "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (extract/match), f64 (BA)", "data": "synthetic",
+            "config": {"workload": "Lafida cam0 synthetic stream, 754x480 fisheye, face=%d (%dx%d cross), nFeatures %d; per step %d frames: "
+                                   "remap+ORB extract, Hamming best-2 (%d queries, %d candidate pairs), %d local-BA windows (K=20, E=%d)"
+                                   % (F, 3 * F, 3 * F, nfeat, B, nq, len(c_idx), n_ba, len(prob["e_pose"])),
+                       "frames_per_step_per_gpu": B, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
+                       "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+                       "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

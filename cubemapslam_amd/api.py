@@ -78,7 +78,7 @@ def lib():
         L.cms_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.cms_profile_get.argtypes = [C.c_void_p, C.c_void_p]
         L.cms_hamming_best2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 9
-        L.cms_hamming_best2_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10
+        L.cms_hamming_best2_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10
         L.cms_hamming_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.cms_ba_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
@@ -256,6 +256,11 @@ class Context:
                                      *[_p(o) for o in outs]), "cms_hamming_best2")
         keys = ("best_idx", "best_dist", "best_level", "second_dist", "second_level")
         return {k: o[:nq] for k, o in zip(keys, outs)}
+
+    def hamming_best2_device(self, qdesc, q_row, nq, tdesc, cand_off, cand_idx, t_level, t_excl, outs):
+        """all arguments are raw device pointers (ints); asynchronous on the ctx stream"""
+        _chk(lib().cms_hamming_best2_device(self.h, _p(qdesc), _p(q_row), nq, _p(tdesc), _p(cand_off), _p(cand_idx), _p(t_level),
+                                            _p(t_excl), *[_p(o) for o in outs]), "cms_hamming_best2_device")
 
     def hamming_matrix(self, a, b):
         a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)

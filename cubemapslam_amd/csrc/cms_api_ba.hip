@@ -23,7 +23,12 @@ struct cms_ba {
   double* d_Hpp = nullptr; double* d_bp = nullptr; double* d_Hll = nullptr; double* d_bl = nullptr; double* d_Hpl = nullptr;
   double* d_Dinv = nullptr; double* d_Hs = nullptr; double* d_bs = nullptr; double* d_x = nullptr; double* d_Dg = nullptr;
   double* d_partial = nullptr; double* d_scal = nullptr; int* d_status = nullptr; uint8_t* d_flags = nullptr;
+  double* d_pose_partial = nullptr; double* d_db = nullptr;
+  int* d_pair_s1 = nullptr; int* d_pair_s2 = nullptr; int* d_pair_off = nullptr; int2* d_tup = nullptr;
+  int* d_pair_chunk_off = nullptr; int2* d_chunk_range = nullptr; double* d_chunk_sum = nullptr;
+  int npairs = 0, nchunks = 0; size_t solve_lds = 0; bool solve_in_lds = false;
   int cur = 0;
+  double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   std::vector<void*> allocs;
 };
 
@@ -38,6 +43,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (!b) return;
   hipSetDevice(b->device);
   for (void* p : b->allocs) hipFree(p);
+  if (b->h_pin) hipHostFree(b->h_pin);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -97,7 +103,56 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
   BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
   BA_TRY(ba_alloc(b, &b->d_partial, (size_t)std::max(b->nblk_e, b->nblk_p) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 8));
-  BA_TRY(ba_alloc(b, &b->d_status, 2)); BA_TRY(ba_alloc(b, &b->d_flags, E));
+  BA_TRY(ba_alloc(b, &b->d_flags, E));
+  b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
+  BA_HIP(hipHostMalloc((void**)&b->h_pin, 8 * sizeof(double)));
+  BA_TRY(ba_alloc(b, &b->d_pose_partial, (size_t)std::max(np, 1) * BA_POSE_CHUNKS * 27)); BA_TRY(ba_alloc(b, &b->d_db, 3 * (size_t)P));
+  // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2
+  {
+    struct Tup { int pair, a1, a2; };
+    std::vector<Tup> tups;
+    for (int p = 0; p < P; ++p)
+      for (int a1 = pt_off[p]; a1 < pt_off[p + 1]; ++a1) {
+        const int s1 = pose_slot[s_pose[a1]];
+        if (s1 < 0) continue;
+        for (int a2 = pt_off[p]; a2 < pt_off[p + 1]; ++a2) {
+          const int s2 = pose_slot[s_pose[a2]];
+          if (s2 < 0 || s2 < s1) continue;
+          tups.push_back({s1 * np + s2, a1, a2});
+        }
+      }
+    std::stable_sort(tups.begin(), tups.end(), [](const Tup& x, const Tup& y) { return x.pair < y.pair; });
+    std::vector<int> ps1, ps2, poff;
+    std::vector<int2> tt(tups.size());
+    for (size_t i = 0; i < tups.size(); ++i) {
+      if (i == 0 || tups[i].pair != tups[i - 1].pair) { ps1.push_back(tups[i].pair / np); ps2.push_back(tups[i].pair % np); poff.push_back((int)i); }
+      tt[i] = make_int2(tups[i].a1, tups[i].a2);
+    }
+    poff.push_back((int)tups.size());
+    b->npairs = (int)ps1.size();
+    std::vector<int> pcoff(1, 0);
+    std::vector<int2> crange;
+    for (size_t pr = 0; pr + 1 < poff.size(); ++pr) {
+      for (int t0 = poff[pr]; t0 < poff[pr + 1]; t0 += BA_TUP_CHUNK) crange.push_back(make_int2(t0, std::min(poff[pr + 1], t0 + BA_TUP_CHUNK)));
+      pcoff.push_back((int)crange.size());
+    }
+    b->nchunks = (int)crange.size();
+    BA_TRY(ba_alloc(b, &b->d_pair_chunk_off, pcoff.size())); BA_TRY(ba_alloc(b, &b->d_chunk_range, crange.size()));
+    BA_TRY(ba_alloc(b, &b->d_chunk_sum, crange.size() * 42));
+    BA_HIP(hipMemcpy(b->d_pair_chunk_off, pcoff.data(), pcoff.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!crange.empty()) BA_HIP(hipMemcpy(b->d_chunk_range, crange.data(), crange.size() * sizeof(int2), hipMemcpyHostToDevice));
+    BA_TRY(ba_alloc(b, &b->d_pair_s1, ps1.size())); BA_TRY(ba_alloc(b, &b->d_pair_s2, ps2.size()));
+    BA_TRY(ba_alloc(b, &b->d_pair_off, poff.size())); BA_TRY(ba_alloc(b, &b->d_tup, tt.size()));
+    if (!ps1.empty()) {
+      BA_HIP(hipMemcpy(b->d_pair_s1, ps1.data(), ps1.size() * sizeof(int), hipMemcpyHostToDevice));
+      BA_HIP(hipMemcpy(b->d_pair_s2, ps2.data(), ps2.size() * sizeof(int), hipMemcpyHostToDevice));
+      BA_HIP(hipMemcpy(b->d_tup, tt.data(), tt.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
+    BA_HIP(hipMemcpy(b->d_pair_off, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  b->solve_lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double) + 64;
+  b->solve_in_lds = b->solve_lds <= 160 * 1024 - 256;
+  if (b->solve_in_lds) BA_HIP(hipFuncSetAttribute((const void*)k_ba_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->solve_lds));
   // normalise quaternions like the SE3Quat constructor (se3quat.h:58-64, 280-285)
   std::vector<double> p0(poses, poses + 7 * (size_t)K);
   for (int k = 0; k < K; ++k) {
@@ -158,11 +213,15 @@ static int ba_optimize_stage(cms_ba* b, int iterations, int robust, double delta
     ba_errors(b, cur, robust, delta, 0);
     hipLaunchKernelGGL(k_ba_lin_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_poses[cur],
                        (const double*)b->d_pts[cur], robust, delta, b->d_Hll, b->d_bl, b->d_Hpl);
-    hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K), dim3(256), 0, s, b->d, (const double*)b->d_poses[cur],
-                       (const double*)b->d_pts[cur], robust, delta, b->d_Hpp, b->d_bp);
-    if (it == 0)
-      hipLaunchKernelGGL(k_ba_maxdiag, dim3(1), dim3(256), 0, s, b->np, b->P, (const double*)b->d_Hpp, (const double*)b->d_Hll, b->d_scal + 3);
-    double h[4];
+    hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K, BA_POSE_CHUNKS), dim3(256), 0, s, b->d, (const double*)b->d_poses[cur],
+                       (const double*)b->d_pts[cur], robust, delta, b->d_pose_partial);
+    if (b->np > 0)
+      hipLaunchKernelGGL(k_ba_pose_finish, dim3(b->np), dim3(64), 0, s, b->np, (const double*)b->d_pose_partial, b->d_Hpp, b->d_bp);
+    if (it == 0) {
+      HIPCHK(hipMemsetAsync(b->d_scal + 3, 0, sizeof(double), s));
+      hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, s, b->np, b->P, (const double*)b->d_Hpp, (const double*)b->d_Hll, b->d_scal + 3);
+    }
+    double* h = b->h_pin;
     HIPCHK(hipMemcpyAsync(h, b->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     double currentChi = h[0];
@@ -175,20 +234,29 @@ static int ba_optimize_stage(cms_ba* b, int iterations, int robust, double delta
         hipLaunchKernelGGL(k_ba_schur_init, dim3(std::min((n * n + 255) / 256, 256)), dim3(256), 0, s, b->np, (const double*)b->d_Hpp,
                            (const double*)b->d_bp, lambda, b->d_Hs, b->d_bs);
       }
-      hipLaunchKernelGGL(k_ba_schur, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_Hll, (const double*)b->d_bl,
-                         (const double*)b->d_Hpl, lambda, b->d_Dinv, b->d_Hs, b->d_bs);
-      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), 0, s, n, b->d_Hs, b->d_bs, b->d_x, b->d_Dg, b->d_status);
+      hipLaunchKernelGGL(k_ba_dinv, dim3((b->P + 255) / 256), dim3(256), 0, s, b->P, (const double*)b->d_Hll, (const double*)b->d_bl, lambda,
+                         b->d_Dinv, b->d_db);
+      if (b->npairs > 0) {
+        hipLaunchKernelGGL(k_ba_schur_chunks, dim3(b->nchunks), dim3(256), 0, s, b->d, (const int2*)b->d_chunk_range, (const int2*)b->d_tup,
+                           (const double*)b->d_Hpl, (const double*)b->d_Dinv, (const double*)b->d_db, b->d_chunk_sum);
+        hipLaunchKernelGGL(k_ba_schur_finish, dim3(b->npairs), dim3(64), 0, s, b->np, (const int*)b->d_pair_s1, (const int*)b->d_pair_s2,
+                           (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum, b->d_Hs, b->d_bs);
+      }
+      if (b->solve_in_lds)
+        hipLaunchKernelGGL(k_ba_solve_lds, dim3(1), dim3(512), b->solve_lds, s, n, (const double*)b->d_Hs, (const double*)b->d_bs, b->d_x, b->d_status);
+      else
+        hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), 0, s, n, b->d_Hs, b->d_bs, b->d_x, b->d_Dg, b->d_status);
       hipLaunchKernelGGL(k_ba_backsub, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
                          (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt], b->d_partial);
       hipLaunchKernelGGL(k_ba_update_poses, dim3(1), dim3(64), 0, s, b->d, (const double*)b->d_x, (const double*)b->d_bp, lambda,
                          (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_scal + 2);
       hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal + 2, 1);
       ba_errors(b, nxt, robust, delta, 1);
-      double t[3];
-      int ok2 = 0;
-      HIPCHK(hipMemcpyAsync(t, b->d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(&ok2, b->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+      double* t = b->h_pin;
+      HIPCHK(hipMemcpyAsync(t, b->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
+      int ok2 = 0;
+      memcpy(&ok2, &t[4], sizeof(int));
       double tempChi = t[1];
       if (!ok2) tempChi = DBL_MAX;
       rho = (currentChi - tempChi);
@@ -289,8 +357,10 @@ extern "C" int cms_ba_linearize(int device, int K, const double* poses, const ui
                      robust, huber_delta, b->d_Hll, b->d_bl, b->d_Hpl);
   hipMemsetAsync(b->d_Hpp, 0, 36 * (size_t)std::max(b->np, 1) * sizeof(double), s);
   hipMemsetAsync(b->d_bp, 0, 6 * (size_t)std::max(b->np, 1) * sizeof(double), s);
-  hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K), dim3(256), 0, s, b->d, (const double*)b->d_poses[0], (const double*)b->d_pts[0], robust,
-                     huber_delta, b->d_Hpp, b->d_bp);
+  hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K, BA_POSE_CHUNKS), dim3(256), 0, s, b->d, (const double*)b->d_poses[0], (const double*)b->d_pts[0], robust,
+                     huber_delta, b->d_pose_partial);
+  if (b->np > 0)
+    hipLaunchKernelGGL(k_ba_pose_finish, dim3(b->np), dim3(64), 0, s, b->np, (const double*)b->d_pose_partial, b->d_Hpp, b->d_bp);
   hipError_t he = hipStreamSynchronize(s);
   if (he != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, "cms_ba_linearize", he); }
   std::vector<int> slot(K, -1);

@@ -475,13 +475,13 @@ extern "C" int cms_profile_get(cms_ctx* c, float* ms7) {
 }
 
 // ---- matching
-extern "C" int cms_hamming_best2_device(cms_ctx* c, const void* qdesc, int nq, const void* tdesc, const void* cand_off,
+extern "C" int cms_hamming_best2_device(cms_ctx* c, const void* qdesc, const void* q_row, int nq, const void* tdesc, const void* cand_off,
                                         const void* cand_idx, const void* t_level, const void* t_excluded, void* best_idx,
                                         void* best_dist, void* best_level, void* second_dist, void* second_level) {
   if (!c || nq < 0) return cms_fail(CMS_ERR_ARG, "cms_hamming_best2_device: bad argument");
   if (nq == 0) return CMS_OK;
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_hamming_best2, dim3((nq + 3) / 4), dim3(256), 0, c->stream, (const uint4*)qdesc, nq, (const uint4*)tdesc,
+  hipLaunchKernelGGL(k_hamming_best2, dim3((nq + 3) / 4), dim3(256), 0, c->stream, (const uint4*)qdesc, (const int*)q_row, nq, (const uint4*)tdesc,
                      (const int*)cand_off, (const int*)cand_idx, (const int*)t_level, (const uint8_t*)t_excluded, (int*)best_idx,
                      (int*)best_dist, (int*)best_level, (int*)second_dist, (int*)second_level);
   HIPCHK(hipGetLastError());
@@ -520,7 +520,7 @@ extern "C" int cms_hamming_best2(cms_ctx* c, const uint8_t* qdesc, int nq, const
   if (t_level && nt > 0) HIPCHK(hipMemcpyAsync(base + olv, t_level, (size_t)nt * 4, hipMemcpyHostToDevice, s));
   if (t_excluded && nt > 0) HIPCHK(hipMemcpyAsync(base + oex, t_excluded, (size_t)nt, hipMemcpyHostToDevice, s));
   int* dout = (int*)(base + oout);
-  rc = cms_hamming_best2_device(c, base + oq, nq, base + ot, base + ooff, base + oidx, t_level ? base + olv : nullptr,
+  rc = cms_hamming_best2_device(c, base + oq, nullptr, nq, base + ot, base + ooff, base + oidx, t_level ? base + olv : nullptr,
                                 t_excluded ? base + oex : nullptr, dout, dout + nq, dout + 2 * nq, dout + 3 * nq, dout + 4 * nq);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(best_idx, dout, (size_t)nq * 4, hipMemcpyDeviceToHost, s));

@@ -5,11 +5,12 @@
 //   linearizeOplus + constructQuadraticForm  (base_binary_edge.hpp:54-120, Huber robust_kernel_impl.cpp:78-91)
 //                                                                  -> k_ba_lin_points (Hll, bl, Hpl) + k_ba_lin_poses (Hpp, bp)
 //   BlockSolver::setLambda / Schur complement / back substitution (block_solver.hpp:367-485, 563-589)
-//                                                                  -> k_ba_schur_init, k_ba_schur, k_ba_solve, k_ba_backsub
+//                                            -> k_ba_dinv, k_ba_schur_init, k_ba_schur_pairs, k_ba_solve_lds, k_ba_backsub
 //   vertex oplus (types_six_dof_expmap.h:73-76, types_sba.h:51-55, se3quat.h:217-257) -> k_ba_update_poses / k_ba_backsub
-// Edges are stored sorted by point (CSR) so Hll / bl need no atomics; per-pose blocks are reduced by one workgroup per
-// pose over that pose's edge list; the Schur products are scattered into the small dense reduced system with
-// hardware FP64 atomics.  All state stays on the device across Levenberg-Marquardt trials; the host only reads three
+// Edges are stored sorted by point (CSR) so Hll / bl need no atomics; per-pose blocks are reduced by workgroups over
+// slices of that pose's edge list; every 6x6 block of the reduced (Schur) system is owned by one workgroup that sums
+// over the host-built co-visibility tuple list of its pose pair (deterministic, no atomics); the reduced system is
+// factorised in LDS.  All state stays on the device across Levenberg-Marquardt trials; the host only reads three
 // scalars per trial (chi2, gain denominator, solver status).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -167,12 +168,15 @@ k_ba_lin_points(BaDev d, const double* __restrict__ poses, const double* __restr
   for (int i = 0; i < 3; ++i) bl[3 * (size_t)p + i] = b[i];
 }
 
-// ---- per-pose blocks: Hpp (6x6) and bp = Gram of [J_pose sqrt(w) | r sqrt(w)] over the pose's edge list
+// ---- per-pose blocks: Hpp (6x6) and bp = Gram of [J_pose sqrt(w) | r sqrt(w)] over the pose's edge list.
+// grid (K, BA_POSE_CHUNKS): every workgroup reduces one slice of the list into 27 partial sums (21 unique Hpp + 6 bp),
+// k_ba_pose_finish adds the slices in fixed order (deterministic, no atomics).
+#define BA_POSE_CHUNKS 8
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_lin_poses(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
-               double* __restrict__ Hpp, double* __restrict__ bp) {
-  __shared__ double sh[4];
-  const int k = blockIdx.x;
+               double* __restrict__ pose_partial) {
+  __shared__ double sh[4][27];
+  const int k = blockIdx.x, ch = blockIdx.y;
   const int slot = d.pose_slot[k];
   if (slot < 0) return;
   const double* pose = poses + 7 * k;
@@ -180,7 +184,10 @@ k_ba_lin_poses(BaDev d, const double* __restrict__ poses, const double* __restri
   quat_to_R(pose + 3, R);
   double acc[27];
   for (int i = 0; i < 27; ++i) acc[i] = 0;
-  for (int t = d.pose_off[k] + threadIdx.x; t < d.pose_off[k + 1]; t += blockDim.x) {
+  const int e0 = d.pose_off[k], e1 = d.pose_off[k + 1];
+  const int per = (e1 - e0 + BA_POSE_CHUNKS - 1) / BA_POSE_CHUNKS;
+  const int t0 = e0 + ch * per, t1 = min(e1, t0 + per);
+  for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
     const int e = d.pose_edges[t];
     if (d.level[e] != 0) continue;
     double Xc[3], Jp[12], Jl[6];
@@ -195,27 +202,42 @@ k_ba_lin_poses(BaDev d, const double* __restrict__ poses, const double* __restri
       for (int j = i; j < 6; ++j) acc[c++] += ow * (Jp[i] * Jp[j] + Jp[6 + i] * Jp[6 + j]);
     for (int i = 0; i < 6; ++i) acc[21 + i] += -ow * (Jp[i] * r0 + Jp[6 + i] * r1);
   }
-  double tot[27];
-  for (int i = 0; i < 27; ++i) tot[i] = block_sum(acc[i], sh);
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int i = 0; i < 6; ++i)
-      for (int j = i; j < 6; ++j) { Hpp[36 * slot + 6 * i + j] = tot[c]; Hpp[36 * slot + 6 * j + i] = tot[c]; ++c; }
-    for (int i = 0; i < 6; ++i) bp[6 * slot + i] = tot[21 + i];
+  for (int i = 0; i < 27; ++i) {
+    double v = acc[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27)
+    pose_partial[((size_t)slot * BA_POSE_CHUNKS + ch) * 27 + threadIdx.x] =
+        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+extern "C" __global__ void __launch_bounds__(64)
+k_ba_pose_finish(int np, const double* __restrict__ pose_partial, double* __restrict__ Hpp, double* __restrict__ bp) {
+  const int slot = blockIdx.x, t = threadIdx.x;
+  if (slot >= np || t >= 27) return;
+  double s = 0;
+  for (int ch = 0; ch < BA_POSE_CHUNKS; ++ch) s += pose_partial[((size_t)slot * BA_POSE_CHUNKS + ch) * 27 + t];
+  if (t < 21) {
+    int i = 0, rem = t;
+    while (rem >= 6 - i) { rem -= 6 - i; ++i; }
+    const int j = i + rem;
+    Hpp[36 * slot + 6 * i + j] = s; Hpp[36 * slot + 6 * j + i] = s;
+  } else {
+    bp[6 * slot + (t - 21)] = s;
   }
 }
 
-// ---- max |diag| of the assembled system (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
+// ---- max |diag| of the assembled system (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180).
+// Non-negative doubles order like their bit patterns, so the cross-workgroup maximum is one u64 atomicMax (*out zeroed first).
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_maxdiag(int np, int P, const double* __restrict__ Hpp, const double* __restrict__ Hll, double* __restrict__ out) {
-  __shared__ double sh[4];
   double m = 0;
-  for (int i = threadIdx.x; i < 6 * np; i += blockDim.x) m = fmax(m, fabs(Hpp[36 * (i / 6) + 7 * (i % 6)]));
-  for (int i = threadIdx.x; i < 3 * P; i += blockDim.x) m = fmax(m, fabs(Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+  for (int i = gid; i < 6 * np; i += gs) m = fmax(m, fabs(Hpp[36 * (i / 6) + 7 * (i % 6)]));
+  for (int i = gid; i < 3 * P; i += gs) m = fmax(m, fabs(Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) *out = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(m));
 }
 
 // ---- reduced system: Hs = blockdiag(Hpp + lambda I), bs = bp ; then minus the Schur products
@@ -239,41 +261,128 @@ __device__ __forceinline__ void inv3(const double* A, double* Ai) {
   Ai[3] = (f * g - d * i) * id; Ai[4] = (a * i - c * g) * id; Ai[5] = (c * d - a * f) * id;
   Ai[6] = (d * h - e * g) * id; Ai[7] = (b * g - a * h) * id; Ai[8] = (a * e - b * d) * id;
 }
-extern "C" __global__ void __launch_bounds__(128)
-k_ba_schur(BaDev d, const double* __restrict__ Hll, const double* __restrict__ bl, const double* __restrict__ Hpl,
-           double lambda, double* __restrict__ Dinv, double* __restrict__ Hs, double* __restrict__ bs) {
+// per point: Dinv = (Hll + lambda I)^-1 and db = Dinv * bl
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_dinv(int P, const double* __restrict__ Hll, const double* __restrict__ bl, double lambda, double* __restrict__ Dinv,
+          double* __restrict__ db) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.P) return;
-  const int n = 6 * d.np;
+  if (p >= P) return;
   double D[9], Di[9];
   for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
   inv3(D, Di);
   for (int i = 0; i < 9; ++i) Dinv[9 * (size_t)p + i] = Di[i];
   const double b0 = bl[3 * (size_t)p], b1 = bl[3 * (size_t)p + 1], b2 = bl[3 * (size_t)p + 2];
-  const double db[3] = {Di[0] * b0 + Di[1] * b1 + Di[2] * b2, Di[3] * b0 + Di[4] * b1 + Di[5] * b2, Di[6] * b0 + Di[7] * b1 + Di[8] * b2};
-  const int e0 = d.pt_off[p], e1 = d.pt_off[p + 1];
-  for (int a1 = e0; a1 < e1; ++a1) {
-    const int s1 = d.pose_slot[d.e_pose[a1]];
-    if (s1 < 0 || d.level[a1] != 0) continue;
-    const double* B1 = Hpl + 18 * (size_t)a1;
+  db[3 * (size_t)p] = Di[0] * b0 + Di[1] * b1 + Di[2] * b2;
+  db[3 * (size_t)p + 1] = Di[3] * b0 + Di[4] * b1 + Di[5] * b2;
+  db[3 * (size_t)p + 2] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
+}
+// Schur complement without atomics: the host lists, per co-visible pose pair (s1 <= s2), the (edge, edge) tuples of the
+// points both poses observe, cut into chunks of <= BA_TUP_CHUNK tuples.  One workgroup sums B1 Dinv B2^T (and, on the
+// diagonal pairs, B1 Dinv bl) over one chunk; k_ba_schur_finish adds the chunk sums of a pair in fixed order and
+// subtracts them from its 6x6 block of Hs (and the mirrored block) / bs.  Deterministic.
+#define BA_TUP_CHUNK 1024
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_schur_chunks(BaDev d, const int2* __restrict__ chunk_range, const int2* __restrict__ tup, const double* __restrict__ Hpl,
+                  const double* __restrict__ Dinv, const double* __restrict__ db, double* __restrict__ chunk_sum) {
+  __shared__ double sh[4][42];
+  const int2 rg = chunk_range[blockIdx.x];
+  double acc[42];
+  for (int i = 0; i < 42; ++i) acc[i] = 0;
+  for (int t = rg.x + threadIdx.x; t < rg.y; t += blockDim.x) {
+    const int2 aa = tup[t];
+    if (d.level[aa.x] != 0 || d.level[aa.y] != 0) continue;
+    const int p = d.e_point[aa.x];
+    const double* Di = Dinv + 9 * (size_t)p;
+    const double* B1 = Hpl + 18 * (size_t)aa.x;
+    const double* B2 = Hpl + 18 * (size_t)aa.y;
     double BD[18];
     for (int i = 0; i < 6; ++i)
       for (int j = 0; j < 3; ++j) BD[3 * i + j] = B1[3 * i] * Di[j] + B1[3 * i + 1] * Di[3 + j] + B1[3 * i + 2] * Di[6 + j];
     for (int i = 0; i < 6; ++i)
-      unsafeAtomicAdd(&bs[6 * s1 + i], -(B1[3 * i] * db[0] + B1[3 * i + 1] * db[1] + B1[3 * i + 2] * db[2]));
-    for (int a2 = e0; a2 < e1; ++a2) {
-      const int s2 = d.pose_slot[d.e_pose[a2]];
-      if (s2 < 0 || d.level[a2] != 0) continue;
-      const double* B2 = Hpl + 18 * (size_t)a2;
-      for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j)
-          unsafeAtomicAdd(&Hs[(size_t)(6 * s1 + i) * n + 6 * s2 + j],
-                          -(BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2]));
+      for (int j = 0; j < 6; ++j) acc[6 * i + j] += BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2];
+    if (aa.x == aa.y) {
+      const double* dbp = db + 3 * (size_t)p;
+      for (int i = 0; i < 6; ++i) acc[36 + i] += B1[3 * i] * dbp[0] + B1[3 * i + 1] * dbp[1] + B1[3 * i + 2] * dbp[2];
     }
+  }
+  for (int i = 0; i < 42; ++i) {
+    double v = acc[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 42) {
+    const int t = threadIdx.x;
+    chunk_sum[(size_t)blockIdx.x * 42 + t] = sh[0][t] + sh[1][t] + sh[2][t] + sh[3][t];
+  }
+}
+extern "C" __global__ void __launch_bounds__(64)
+k_ba_schur_finish(int np, const int* __restrict__ pair_s1, const int* __restrict__ pair_s2, const int* __restrict__ pair_chunk_off,
+                  const double* __restrict__ chunk_sum, double* __restrict__ Hs, double* __restrict__ bs) {
+  const int pr = blockIdx.x, t = threadIdx.x;
+  if (t >= 42) return;
+  const int s1 = pair_s1[pr], s2 = pair_s2[pr], n = 6 * np;
+  double v = 0;
+  for (int c = pair_chunk_off[pr]; c < pair_chunk_off[pr + 1]; ++c) v += chunk_sum[(size_t)c * 42 + t];
+  if (t < 36) {
+    const int i = t / 6, j = t % 6;
+    Hs[(size_t)(6 * s1 + i) * n + 6 * s2 + j] -= v;
+    if (s1 != s2) Hs[(size_t)(6 * s2 + j) * n + 6 * s1 + i] -= v;
+  } else if (s1 == s2) {
+    bs[6 * s1 + (t - 36)] -= v;
   }
 }
 
-// ---- dense LDL^T of the reduced pose system + solve, one workgroup, in place in global memory (n <= a few hundred)
+// ---- dense LDL^T of the reduced pose system in LDS (packed lower triangle), one workgroup of 512 threads.
+// Right-looking, one barrier per column: the pivot column is kept unscaled (updates use a_ij * a_kj / d_j), the forward
+// substitution rides along as an extra column, then one pass scales L and a single wavefront runs the back substitution
+// without barriers (LDS operations of one wave are processed in order).
+extern "C" __global__ void __launch_bounds__(512)
+k_ba_solve_lds(int n, const double* __restrict__ A, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ status) {
+  extern __shared__ __align__(16) double sm[];
+  double* Lp = sm;
+  double* y = Lp + (size_t)n * (n + 1) / 2;
+  double* idg = y + n;
+  const int tid = threadIdx.x, T = blockDim.x, tx = tid & 31, ty = tid >> 5;
+  for (int e = tid; e < n * n; e += T) {
+    const int i = e / n, j = e - i * n;
+    if (j <= i) Lp[i * (i + 1) / 2 + j] = A[e];
+  }
+  for (int i = tid; i < n; i += T) y[i] = b[i];
+  bool bad = false;
+  for (int j = 0; j < n; ++j) {
+    __syncthreads();
+    const double dj = Lp[j * (j + 1) / 2 + j];
+    if (!(isfinite(dj)) || dj == 0.0) { bad = true; break; }   // same value in every thread: uniform exit
+    const double idj = 1.0 / dj;
+    const double yj = y[j];
+    if (tid == 0) idg[j] = idj;
+    for (int i = j + 1 + ty; i < n; i += 16) {
+      const double lij = Lp[i * (i + 1) / 2 + j] * idj;
+      for (int k = j + 1 + tx; k <= i; k += 32) Lp[i * (i + 1) / 2 + k] -= lij * Lp[k * (k + 1) / 2 + j];
+      if (tx == 31) y[i] -= lij * yj;
+    }
+  }
+  __syncthreads();
+  if (!bad) {
+    for (int i = ty; i < n; i += 16)                       // scale the columns: l_ij = a_ij / d_j ; w = D^-1 y
+      for (int k = tx; k < i; k += 32) Lp[i * (i + 1) / 2 + k] *= idg[k];
+    for (int i = tid; i < n; i += T) y[i] *= idg[i];
+    __syncthreads();
+    if (tid < 64) {
+      for (int j = n - 1; j > 0; --j) {                     // L^T x = w, column oriented, one wavefront
+        const double xj = y[j];
+        const double* row = Lp + (size_t)j * (j + 1) / 2;
+        for (int i = tid; i < j; i += 64) y[i] -= row[i] * xj;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += T) x[i] = bad ? 0.0 : y[i];
+  if (tid == 0) *status = bad ? 0 : 1;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_solve(int n, double* __restrict__ A, double* __restrict__ b, double* __restrict__ x, double* __restrict__ Dg,
            int* __restrict__ status) {

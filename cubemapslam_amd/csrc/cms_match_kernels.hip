@@ -15,14 +15,15 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-k_hamming_best2(const uint4* __restrict__ qdesc, int nq, const uint4* __restrict__ tdesc,
+k_hamming_best2(const uint4* __restrict__ qdesc, const int* __restrict__ q_row, int nq, const uint4* __restrict__ tdesc,
                 const int* __restrict__ cand_off, const int* __restrict__ cand_idx, const int* __restrict__ tlevel,
                 const uint8_t* __restrict__ texcl, int* __restrict__ best_idx, int* __restrict__ best_dist,
                 int* __restrict__ best_level, int* __restrict__ second_dist, int* __restrict__ second_level) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= nq) return;
-  const uint4 q0 = qdesc[2 * (size_t)q], q1 = qdesc[2 * (size_t)q + 1];
+  const size_t qr = q_row ? (size_t)q_row[q] : (size_t)q;   // optional gather: query q lives in row q_row[q]
+  const uint4 q0 = qdesc[2 * qr], q1 = qdesc[2 * qr + 1];
   const int start = cand_off[q], end = cand_off[q + 1];
   uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
   for (int c = start + lane; c < end; c += 64) {

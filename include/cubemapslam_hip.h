@@ -110,11 +110,13 @@ int cms_profile_get(cms_ctx* ctx, float* ms7);
  *      (the inner loops of ORBMatcher::SearchByProjection, ORBMatcher.cpp:84-113 / 186-205).  Candidates are a CSR:
  *      query q scans cand_idx[cand_off[q] .. cand_off[q+1]).  t_excluded (optional) marks target key points that already
  *      hold a map point (ORBMatcher.cpp:91-95).  Outputs follow the sequential scan exactly (first minimum wins).
- *      The *_device variant takes device pointers and is asynchronous on the ctx stream. */
+ *      The *_device variant takes device pointers and is asynchronous on the ctx stream; q_row (optional int[nq])
+ *      gathers query q from row q_row[q] of qdesc, so one launch can match many frame pairs straight out of the
+ *      extractor's descriptor buffer. */
 int cms_hamming_best2(cms_ctx* ctx, const uint8_t* qdesc, int nq, const uint8_t* tdesc, int nt, const int* cand_off,
                       const int* cand_idx, const int* t_level, const uint8_t* t_excluded, int* best_idx, int* best_dist,
                       int* best_level, int* second_dist, int* second_level);
-int cms_hamming_best2_device(cms_ctx* ctx, const void* qdesc, int nq, const void* tdesc, const void* cand_off,
+int cms_hamming_best2_device(cms_ctx* ctx, const void* qdesc, const void* q_row, int nq, const void* tdesc, const void* cand_off,
                              const void* cand_idx, const void* t_level, const void* t_excluded, void* best_idx,
                              void* best_dist, void* best_level, void* second_dist, void* second_level);
 int cms_hamming_matrix(cms_ctx* ctx, const uint8_t* a, int na, const uint8_t* b, int nb, uint16_t* out);
