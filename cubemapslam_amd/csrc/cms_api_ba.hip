@@ -26,7 +26,7 @@ struct cms_ba {
   double* d_pose_partial = nullptr; double* d_db = nullptr;
   int* d_pair_s1 = nullptr; int* d_pair_s2 = nullptr; int* d_pair_off = nullptr; int2* d_tup = nullptr;
   int* d_pair_chunk_off = nullptr; int2* d_chunk_range = nullptr; double* d_chunk_sum = nullptr;
-  int npairs = 0, nchunks = 0; size_t solve_lds = 0; bool solve_in_lds = false;
+  int npairs = 0, nchunks = 0; size_t solve_lds = 0, blk_lds = 0; bool solve_in_lds = false, solve_blk = false;
   int cur = 0;
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   std::vector<void*> allocs;
@@ -150,9 +150,15 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     }
     BA_HIP(hipMemcpy(b->d_pair_off, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
   }
-  b->solve_lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double) + 64;
-  b->solve_in_lds = b->solve_lds <= 160 * 1024 - 256;
-  if (b->solve_in_lds) BA_HIP(hipFuncSetAttribute((const void*)k_ba_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->solve_lds));
+  b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
+  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= 160 * 1024 - 512;
+  if (b->solve_blk) BA_HIP(hipFuncSetAttribute((const void*)k_ba_solve_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds));
+  {
+    const int NP = 192;
+    b->solve_lds = ((size_t)n * (n + 1) / 2 + 4 * (size_t)NP + 8) * sizeof(double);
+    b->solve_in_lds = n <= 192 && b->solve_lds <= 160 * 1024 - 512;
+    if (b->solve_in_lds) BA_HIP(hipFuncSetAttribute((const void*)k_ba_solve_r192, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->solve_lds));
+  }
   // normalise quaternions like the SE3Quat constructor (se3quat.h:58-64, 280-285)
   std::vector<double> p0(poses, poses + 7 * (size_t)K);
   for (int k = 0; k < K; ++k) {
@@ -242,8 +248,10 @@ static int ba_optimize_stage(cms_ba* b, int iterations, int robust, double delta
         hipLaunchKernelGGL(k_ba_schur_finish, dim3(b->npairs), dim3(64), 0, s, b->np, (const int*)b->d_pair_s1, (const int*)b->d_pair_s2,
                            (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum, b->d_Hs, b->d_bs);
       }
-      if (b->solve_in_lds)
-        hipLaunchKernelGGL(k_ba_solve_lds, dim3(1), dim3(512), b->solve_lds, s, n, (const double*)b->d_Hs, (const double*)b->d_bs, b->d_x, b->d_status);
+      if (b->solve_blk)
+        hipLaunchKernelGGL(k_ba_solve_blk, dim3(1), dim3(384), b->blk_lds, s, b->np, (const double*)b->d_Hs, (const double*)b->d_bs, b->d_x, b->d_status);
+      else if (b->solve_in_lds)
+        hipLaunchKernelGGL(k_ba_solve_r192, dim3(1), dim3(512), b->solve_lds, s, n, (const double*)b->d_Hs, (const double*)b->d_bs, b->d_x, b->d_status);
       else
         hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), 0, s, n, b->d_Hs, b->d_bs, b->d_x, b->d_Dg, b->d_status);
       hipLaunchKernelGGL(k_ba_backsub, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,

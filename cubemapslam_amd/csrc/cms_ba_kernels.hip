@@ -5,12 +5,12 @@
 //   linearizeOplus + constructQuadraticForm  (base_binary_edge.hpp:54-120, Huber robust_kernel_impl.cpp:78-91)
 //                                                                  -> k_ba_lin_points (Hll, bl, Hpl) + k_ba_lin_poses (Hpp, bp)
 //   BlockSolver::setLambda / Schur complement / back substitution (block_solver.hpp:367-485, 563-589)
-//                                            -> k_ba_dinv, k_ba_schur_init, k_ba_schur_pairs, k_ba_solve_lds, k_ba_backsub
+//                                            -> k_ba_dinv, k_ba_schur_init, k_ba_schur_chunks/_finish, k_ba_solve_blk (k_ba_solve_r192 / k_ba_solve for larger windows), k_ba_backsub
 //   vertex oplus (types_six_dof_expmap.h:73-76, types_sba.h:51-55, se3quat.h:217-257) -> k_ba_update_poses / k_ba_backsub
 // Edges are stored sorted by point (CSR) so Hll / bl need no atomics; per-pose blocks are reduced by workgroups over
 // slices of that pose's edge list; every 6x6 block of the reduced (Schur) system is owned by one workgroup that sums
 // over the host-built co-visibility tuple list of its pose pair (deterministic, no atomics); the reduced system is
-// factorised in LDS.  All state stays on the device across Levenberg-Marquardt trials; the host only reads three
+// factorised by one workgroup with the trailing matrix in registers.  All state stays on the device across Levenberg-Marquardt trials; the host only reads three
 // scalars per trial (chi2, gain denominator, solver status).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -277,43 +277,75 @@ k_ba_dinv(int P, const double* __restrict__ Hll, const double* __restrict__ bl, 
   db[3 * (size_t)p + 2] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
 }
 // Schur complement without atomics: the host lists, per co-visible pose pair (s1 <= s2), the (edge, edge) tuples of the
-// points both poses observe, cut into chunks of <= BA_TUP_CHUNK tuples.  One workgroup sums B1 Dinv B2^T (and, on the
-// diagonal pairs, B1 Dinv bl) over one chunk; k_ba_schur_finish adds the chunk sums of a pair in fixed order and
-// subtracts them from its 6x6 block of Hs (and the mirrored block) / bs.  Deterministic.
-#define BA_TUP_CHUNK 1024
+// points both poses observe, cut into chunks of <= BA_TUP_CHUNK tuples.  One thread evaluates one tuple (all of its 45
+// operand loads are independent, so a wave has thousands of loads in flight), the 42 partial values per thread (36 for
+// B1 Dinv B2^T + 6 for B1 Dinv bl on diagonal pairs) are folded across the wavefront with a reduce-scatter butterfly
+// (44 shuffles instead of 42 x 6), the four wave results are added in LDS.  k_ba_schur_finish adds the chunk sums of a
+// pair in fixed order and subtracts them from its 6x6 block of Hs (and the mirrored block) / bs.  Deterministic.
+#define BA_TUP_CHUNK 256
+template <int N, int H>
+__device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, int off) {
+  // lanes with the bit clear keep in[0..H), lanes with it set keep in[H..N) (zero padded to H); partner's copy is added
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const double upper = (H + i < N) ? in[H + i] : 0.0;
+    const double send = hi ? in[i] : upper;
+    const double keep = hi ? upper : in[i];
+    out[i] = keep + __shfl_xor(send, off);
+  }
+}
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_schur_chunks(BaDev d, const int2* __restrict__ chunk_range, const int2* __restrict__ tup, const double* __restrict__ Hpl,
                   const double* __restrict__ Dinv, const double* __restrict__ db, double* __restrict__ chunk_sum) {
   __shared__ double sh[4][42];
   const int2 rg = chunk_range[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc[42];
+#pragma unroll
   for (int i = 0; i < 42; ++i) acc[i] = 0;
-  for (int t = rg.x + threadIdx.x; t < rg.y; t += blockDim.x) {
+  const int t = rg.x + threadIdx.x;
+  if (t < rg.y) {
     const int2 aa = tup[t];
-    if (d.level[aa.x] != 0 || d.level[aa.y] != 0) continue;
-    const int p = d.e_point[aa.x];
-    const double* Di = Dinv + 9 * (size_t)p;
-    const double* B1 = Hpl + 18 * (size_t)aa.x;
-    const double* B2 = Hpl + 18 * (size_t)aa.y;
-    double BD[18];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 3; ++j) BD[3 * i + j] = B1[3 * i] * Di[j] + B1[3 * i + 1] * Di[3 + j] + B1[3 * i + 2] * Di[6 + j];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) acc[6 * i + j] += BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2];
-    if (aa.x == aa.y) {
-      const double* dbp = db + 3 * (size_t)p;
-      for (int i = 0; i < 6; ++i) acc[36 + i] += B1[3 * i] * dbp[0] + B1[3 * i + 1] * dbp[1] + B1[3 * i + 2] * dbp[2];
+    if (d.level[aa.x] == 0 && d.level[aa.y] == 0) {
+      const int p = d.e_point[aa.x];
+      const double* Di = Dinv + 9 * (size_t)p;
+      const double* B1 = Hpl + 18 * (size_t)aa.x;
+      const double* B2 = Hpl + 18 * (size_t)aa.y;
+      double BD[18];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) BD[3 * i + j] = B1[3 * i] * Di[j] + B1[3 * i + 1] * Di[3 + j] + B1[3 * i + 2] * Di[6 + j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[6 * i + j] = BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2];
+      if (aa.x == aa.y) {
+        const double* dbp = db + 3 * (size_t)p;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[36 + i] = B1[3 * i] * dbp[0] + B1[3 * i + 1] * dbp[1] + B1[3 * i + 2] * dbp[2];
+      }
     }
   }
-  for (int i = 0; i < 42; ++i) {
-    double v = acc[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = v;
-  }
+  double v21[21], v11[11], v6[6], v3[3], v2[2], v1[1];
+  rs_step<42, 21>(acc, v21, (lane & 32) != 0, 32);
+  rs_step<21, 11>(v21, v11, (lane & 16) != 0, 16);
+  rs_step<11, 6>(v11, v6, (lane & 8) != 0, 8);
+  rs_step<6, 3>(v6, v3, (lane & 4) != 0, 4);
+  rs_step<3, 2>(v3, v2, (lane & 2) != 0, 2);
+  rs_step<2, 1>(v2, v1, (lane & 1) != 0, 1);
+  // which of the 42 sums this lane ended up with (nested split sizes; padded slots are invalid)
+  int s = 21, idx = (lane & 32) ? 21 : 0;
+  { const bool h = lane & 16; idx += h ? 11 : 0; s = h ? max(0, s - 11) : min(11, s); }
+  { const bool h = lane & 8; idx += h ? 6 : 0; s = h ? max(0, s - 6) : min(6, s); }
+  { const bool h = lane & 4; idx += h ? 3 : 0; s = h ? max(0, s - 3) : min(3, s); }
+  { const bool h = lane & 2; idx += h ? 2 : 0; s = h ? max(0, s - 2) : min(2, s); }
+  { const bool h = lane & 1; idx += h ? 1 : 0; s = h ? max(0, s - 1) : min(1, s); }
+  if (s > 0) sh[wave][idx] = v1[0];
   __syncthreads();
   if (threadIdx.x < 42) {
-    const int t = threadIdx.x;
-    chunk_sum[(size_t)blockIdx.x * 42 + t] = sh[0][t] + sh[1][t] + sh[2][t] + sh[3][t];
+    const int k = threadIdx.x;
+    chunk_sum[(size_t)blockIdx.x * 42 + k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
   }
 }
 extern "C" __global__ void __launch_bounds__(64)
@@ -333,54 +365,247 @@ k_ba_schur_finish(int np, const int* __restrict__ pair_s1, const int* __restrict
   }
 }
 
-// ---- dense LDL^T of the reduced pose system in LDS (packed lower triangle), one workgroup of 512 threads.
-// Right-looking, one barrier per column: the pivot column is kept unscaled (updates use a_ij * a_kj / d_j), the forward
-// substitution rides along as an extra column, then one pass scales L and a single wavefront runs the back substitution
-// without barriers (LDS operations of one wave are processed in order).
-extern "C" __global__ void __launch_bounds__(512)
-k_ba_solve_lds(int n, const double* __restrict__ A, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ status) {
+// ---- blocked LDL^T of the reduced pose system (6x6 pose blocks), one workgroup, one thread per lower block, the block
+// held in registers for the whole factorisation.  Per block column J: (a) the owner of (J,J) factorises its 6x6 block and
+// forward-substitutes y_J, (b) the owners of (I,J) solve W_IJ = A_IJ L_JJ^-T, L_IJ = W_IJ D_J^-1 and update y_I,
+// (c) every owner of (I,K), K > J, subtracts W_IJ L_KJ^T.  Two barriers per block column (19 columns for 20 key frames
+// instead of 114 scalar columns); one wavefront then runs the block back substitution out of LDS.
+extern "C" __global__ void __launch_bounds__(384)
+k_ba_solve_blk(int nb, const double* __restrict__ A, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ status) {
   extern __shared__ __align__(16) double sm[];
-  double* Lp = sm;
-  double* y = Lp + (size_t)n * (n + 1) / 2;
-  double* idg = y + n;
-  const int tid = threadIdx.x, T = blockDim.x, tx = tid & 31, ty = tid >> 5;
-  for (int e = tid; e < n * n; e += T) {
-    const int i = e / n, j = e - i * n;
-    if (j <= i) Lp[i * (i + 1) / 2 + j] = A[e];
+  const int n = 6 * nb, nblk = nb * (nb + 1) / 2;
+  double* Lblk = sm;                          // [nblk][36] final L blocks (diagonal blocks: unit lower)
+  double* Wbuf = Lblk + 36 * (size_t)nblk;    // [2][nb][36]
+  double* ybuf = Wbuf + 72 * (size_t)nb;      // [n] running right-hand side / z / w / x
+  double* idg = ybuf + n;                     // [n] 1 / d
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  int I = 0, K = 0;
+  const bool have = tid < nblk;
+  if (have) {
+    I = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= tid) ++I;
+    while (I * (I + 1) / 2 > tid) --I;
+    K = tid - I * (I + 1) / 2;
   }
-  for (int i = tid; i < n; i += T) y[i] = b[i];
-  bool bad = false;
-  for (int j = 0; j < n; ++j) {
+  double a[36];
+  if (have) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a[6 * r + c] = A[(size_t)(6 * I + r) * n + 6 * K + c];
+  }
+  if (tid == 0) bad = 0;
+  for (int i = tid; i < n; i += blockDim.x) ybuf[i] = b[i];
+  __syncthreads();
+  for (int J = 0; J < nb; ++J) {
+    double* W = Wbuf + (J & 1) * 36 * (size_t)nb;
+    if (have && I == J && K == J) {                  // (a)
+      double idl[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double dc = a[7 * c];
+        if (!(isfinite(dc)) || dc == 0.0) bad = 1;
+        idl[c] = 1.0 / dc;
+        double lc[6];
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) lc[r] = a[6 * r + c] * idl[c];
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+#pragma unroll
+          for (int q = c + 1; q <= r; ++q) a[6 * r + q] -= lc[r] * lc[q] * dc;
+          a[6 * r + c] = lc[r];
+        }
+      }
+      double* Ld = Lblk + 36 * (size_t)tid;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Ld[6 * r + c] = c < r ? a[6 * r + c] : (c == r ? 1.0 : 0.0);
+      double z[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        z[r] = ybuf[6 * J + r];
+#pragma unroll
+        for (int c = 0; c < r; ++c) z[r] -= a[6 * r + c] * z[c];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { ybuf[6 * J + r] = z[r]; idg[6 * J + r] = idl[r]; }
+    }
     __syncthreads();
-    const double dj = Lp[j * (j + 1) / 2 + j];
-    if (!(isfinite(dj)) || dj == 0.0) { bad = true; break; }   // same value in every thread: uniform exit
-    const double idj = 1.0 / dj;
-    const double yj = y[j];
-    if (tid == 0) idg[j] = idj;
-    for (int i = j + 1 + ty; i < n; i += 16) {
-      const double lij = Lp[i * (i + 1) / 2 + j] * idj;
-      for (int k = j + 1 + tx; k <= i; k += 32) Lp[i * (i + 1) / 2 + k] -= lij * Lp[k * (k + 1) / 2 + j];
-      if (tx == 31) y[i] -= lij * yj;
+    if (bad) break;
+    if (have && K == J && I > J) {                   // (b)
+      const double* Ld = Lblk + 36 * (size_t)(J * (J + 1) / 2 + J);
+      double w[36];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = a[6 * r + c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) v -= w[6 * r + q] * Ld[6 * c + q];
+          w[6 * r + c] = v;
+        }
+      double* Wd = W + 36 * (size_t)I;
+      double* Lo = Lblk + 36 * (size_t)tid;
+      double yi[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) yi[r] = ybuf[6 * I + r];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double l = w[6 * r + c] * idg[6 * J + c];
+          Wd[6 * r + c] = w[6 * r + c];
+          Lo[6 * r + c] = l;
+          yi[r] -= l * ybuf[6 * J + c];
+        }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) ybuf[6 * I + r] = yi[r];
+    }
+    __syncthreads();
+    if (have && K > J) {                             // (c)  (I >= K > J)
+      const double* Wi = W + 36 * (size_t)I;
+      const double* Lk = Lblk + 36 * (size_t)(K * (K + 1) / 2 + J);
+      double lk[36];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) lk[q] = Lk[q];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double wr[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) wr[c] = Wi[6 * r + c];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          double v = a[6 * r + q];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v -= wr[c] * lk[6 * q + c];
+          a[6 * r + q] = v;
+        }
+      }
     }
   }
   __syncthreads();
-  if (!bad) {
-    for (int i = ty; i < n; i += 16)                       // scale the columns: l_ij = a_ij / d_j ; w = D^-1 y
-      for (int k = tx; k < i; k += 32) Lp[i * (i + 1) / 2 + k] *= idg[k];
-    for (int i = tid; i < n; i += T) y[i] *= idg[i];
-    __syncthreads();
-    if (tid < 64) {
-      for (int j = n - 1; j > 0; --j) {                     // L^T x = w, column oriented, one wavefront
-        const double xj = y[j];
-        const double* row = Lp + (size_t)j * (j + 1) / 2;
-        for (int i = tid; i < j; i += 64) y[i] -= row[i] * xj;
-        __builtin_amdgcn_wave_barrier();
+  const bool isbad = bad != 0;
+  if (!isbad && tid < 64) {
+    for (int i = tid; i < n; i += 64) ybuf[i] *= idg[i];      // w = D^-1 z
+    __builtin_amdgcn_wave_barrier();
+    for (int J = nb - 1; J >= 0; --J) {
+      const double* Ld = Lblk + 36 * (size_t)(J * (J + 1) / 2 + J);
+      double xj[6];
+#pragma unroll
+      for (int r = 5; r >= 0; --r) {                          // L_JJ^T x_J = w_J (unit upper)
+        xj[r] = ybuf[6 * J + r];
+#pragma unroll
+        for (int q = r + 1; q < 6; ++q) xj[r] -= Ld[6 * q + r] * xj[q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (tid < 6) ybuf[6 * J + tid] = xj[tid];
+      for (int o = tid; o < 6 * J; o += 64) {                 // w_K -= L_JK^T x_J for K < J
+        const int Kq = o / 6, c = o - 6 * Kq;
+        const double* Ljk = Lblk + 36 * (size_t)(J * (J + 1) / 2 + Kq);
+        double v = ybuf[o];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) v -= Ljk[6 * r + c] * xj[r];
+        ybuf[o] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) x[i] = isbad ? 0.0 : ybuf[i];
+  if (tid == 0) *status = isbad ? 0 : 1;
+}
+
+// ---- dense LDL^T of the reduced pose system, one workgroup of 16 x 32 threads, trailing matrix held in REGISTERS
+// (2-D cyclic: thread (tx, ty) owns entries (i, k), i = ty + 16 r, k = tx + 32 c, k <= i).  Per column: the owners publish
+// column j through a double-buffered LDS vector, one barrier, then every thread updates its tile with the rank-1 term
+// a_ij a_kj / d_j.  The forward substitution rides along in the tx == 0 threads, the finished column l_ij = a_ij / d_j is
+// stored to a packed LDS triangle, and a single wavefront runs the back substitution (LDS ops of one wave are in order).
+template <int NR, int NC>
+__device__ __forceinline__ void ba_solve_reg(int n, const double* __restrict__ A, const double* __restrict__ b,
+                                             double* __restrict__ x, int* __restrict__ status, double* sm) {
+  constexpr int NP = 16 * NR;
+  double* Lp = sm;
+  double* colbuf = Lp + (size_t)n * (n + 1) / 2;
+  double* y = colbuf + 2 * NP;
+  double* idg = y + NP;
+  double* yjb = idg + NP;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  double a[NR][NC], yreg[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = ty + 16 * r;
+    yreg[r] = (tx == 0 && i < n) ? b[i] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int k = tx + 32 * c;
+      a[r][c] = (i < n && k <= i) ? A[(size_t)i * n + k] : 0.0;
+    }
+  }
+  bool bad = false;
+  for (int j = 0; j < n; ++j) {
+    double* buf = colbuf + (j & 1) * NP;
+    if (tx == (j & 31)) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = ty + 16 * r;
+        if (i >= j && i < n) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) if (c == (j >> 5)) buf[i] = a[r][c];
+        }
       }
     }
+    if (tx == 0 && ty == (j & 15)) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) if (r == (j >> 4)) yjb[j & 1] = yreg[r];
+    }
     __syncthreads();
+    const double dj = buf[j];
+    if (!(isfinite(dj)) || dj == 0.0) { bad = true; break; }   // same value in every thread: uniform exit
+    const double idj = 1.0 / dj, yj = yjb[j & 1];
+    if (tid == 0) idg[j] = idj;
+    double li[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = ty + 16 * r;
+      li[r] = (i > j && i < n) ? buf[i] * idj : 0.0;
+      if (tx == 0) {
+        if (i > j && i < n) Lp[(size_t)i * (i + 1) / 2 + j] = li[r];
+        yreg[r] -= li[r] * yj;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int k = tx + 32 * c;
+      const double ak = (k > j && k < n) ? buf[k] : 0.0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) a[r][c] -= li[r] * ak;
+    }
   }
-  for (int i = tid; i < n; i += T) x[i] = bad ? 0.0 : y[i];
+  if (tx == 0) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { const int i = ty + 16 * r; if (i < n) y[i] = yreg[r]; }
+  }
+  __syncthreads();
+  if (!bad && tid < 64) {
+    for (int i = tid; i < n; i += 64) y[i] *= idg[i];           // w = D^-1 (L^-1 b)
+    __builtin_amdgcn_wave_barrier();
+    for (int j = n - 1; j > 0; --j) {                           // L^T x = w, column oriented
+      const double xj = y[j];
+      const double* row = Lp + (size_t)j * (j + 1) / 2;
+      for (int i = tid; i < j; i += 64) y[i] -= row[i] * xj;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 512) x[i] = bad ? 0.0 : y[i];
   if (tid == 0) *status = bad ? 0 : 1;
+}
+extern "C" __global__ void __launch_bounds__(512)
+k_ba_solve_r192(int n, const double* __restrict__ A, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ status) {
+  extern __shared__ __align__(16) double sm[];
+  ba_solve_reg<12, 6>(n, A, b, x, status, sm);
 }
 
 extern "C" __global__ void __launch_bounds__(256)

@@ -221,6 +221,14 @@ def test_ba_run_small_window():
     assert out["rc"] == 1 and np.array_equal(out["points"], prob["points"])
 
 
+def test_ba_run_larger_windows_all_solver_paths():
+    """reduced system of 24 pose blocks (blocked LDL^T), 6*29 = 174 (register-tiled scalar LDL^T) and 6*39 = 234
+    (global-memory fallback)."""
+    _ba_compare(synth.ba_problem(K=25, P=1500, obs_per_point=5, F=550, seed=3))
+    _ba_compare(synth.ba_problem(K=30, P=2000, obs_per_point=5, F=550, seed=5))
+    _ba_compare(synth.ba_problem(K=40, P=2500, obs_per_point=6, F=550, seed=4))
+
+
 def test_ba_run_config4_full_size():
     """BASELINE.json configs[3]: 20 keyframes x 4000 edges (E = 80 000, P = 20 000), 1e-4 vs the CPU path."""
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=650, seed=42)
