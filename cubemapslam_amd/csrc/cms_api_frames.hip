@@ -212,7 +212,8 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   g.sc_h = hCellMax + 2;
   g.sc_stride = (int)align_up((size_t)wCellMax + 2, 4);
   g.list_cap = wCellMax * hCellMax;
-  if (g.list_cap > 4095) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 4095 pixels"); }
+  if (wCellMax > 60 || hCellMax > 60) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 60 pixels"); }
+  if (orb->scale_factor < 1.01f || orb->scale_factor > 1.9f) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "scaleFactor must be in [1.01, 1.9]"); }
   c->fast_lds = (size_t)g.tile_h * g.tile_stride + (size_t)g.sc_h * g.sc_stride + 2 * (size_t)g.list_cap + 16;
   c->qt_lds = 64 * (size_t)g.qt_maxn + 4 * 512 + 64;
 
@@ -319,9 +320,12 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   for (int l = 1; l < L; ++l) {
     const CmsLevel& d = g.lv[l];
     dim3 block(64, 4);
-    dim3 grid((d.w + 255) / 256, (d.h + 3) / 4, B);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, s, c->d_pyr, g.pyr_bytes, g.lv[l - 1], d, (const CmsResizeTab*)(c->d_tab + d.tab_off),
-                       (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w));
+    dim3 grid((d.w + 255) / 256, (d.h + 7) / 8, B);
+    const double ratio = (double)g.lv[l - 1].w / d.w;
+    const int ls = (int)align_up((size_t)ceil(256 * ratio) + 12, 4);     // LDS row stride of the staged source rectangle
+    const int lrows = (int)ceil(8 * ratio) + 3;
+    hipLaunchKernelGGL(k_resize, grid, block, (size_t)ls * lrows, s, c->d_pyr, g.pyr_bytes, g.lv[l - 1], d,
+                       (const CmsResizeTab*)(c->d_tab + d.tab_off), (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w), ls);
   }
   if (c->prof) hipEventRecord(c->ev[2], s);
   HIPCHK(hipMemsetAsync(c->d_cand_cnt, 0, (size_t)B * L * sizeof(int), s));

@@ -59,31 +59,59 @@ k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw
 }
 
 // ------------------------------------------------------------------------------------------------ resize
+// One workgroup (64 x 4 threads) produces a 256 x 8 destination tile.  The source rectangle it needs (about 310 x 12
+// pixels at scale 1.2) is staged in LDS with coalesced dword loads; the 2 x 2 taps of every destination pixel are then
+// byte reads from LDS (a byte gather straight from global memory is bound by the texture-address path, not by HBM).
+// `ls` = LDS row stride in bytes (multiple of 4, <= 512).
 extern "C" __global__ void __launch_bounds__(256)
 k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst,
-         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby) {
-  const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-  const int y = blockIdx.y * blockDim.y + threadIdx.y, b = blockIdx.z;
-  if (x0 >= dst.w || y >= dst.h) return;
-  const uint8_t* sbase = pyr + (size_t)b * pyr_bytes + src.off;
-  const CmsResizeTab ty = taby[y];
-  const int sy0 = min(max((int)ty.s, 0), src.h - 1), sy1 = min(max((int)ty.s + 1, 0), src.h - 1);
-  const uint8_t* S0 = sbase + (size_t)sy0 * src.stride;
-  const uint8_t* S1 = sbase + (size_t)sy1 * src.stride;
-  const int b0 = ty.a0, b1 = ty.a1;
-  uint32_t out = 0;
+         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby, int ls) {
+  extern __shared__ __align__(16) uint8_t rtile[];
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int xb = blockIdx.x * 256, yb = blockIdx.y * 8, b = blockIdx.z;
+  const int xl = min(xb + 255, dst.w - 1), yl = min(yb + 7, dst.h - 1);
+  const int c0 = (int)tabx[xb].s & ~3;
+  const int c1 = min((int)tabx[xl].s + 1, src.w - 1);
+  const int r0 = min(max((int)taby[yb].s, 0), src.h - 1);
+  const int r1 = min(max((int)taby[yl].s + 1, 0), src.h - 1);
+  const int ndw = ((c1 - c0) >> 2) + 1, nr = r1 - r0 + 1;
+  const uint8_t* simg = pyr + (size_t)b * pyr_bytes + src.off;
+  {
+    const int c = tid & 127;
+    if (c < ndw)
+      for (int r = tid >> 7; r < nr; r += 2)
+        reinterpret_cast<uint32_t*>(rtile + r * ls)[c] =
+            *reinterpret_cast<const uint32_t*>(simg + (size_t)(r0 + r) * src.stride + c0 + 4 * c);
+  }
+  __syncthreads();
+  const int x0 = xb + 4 * tx;
+  if (x0 >= dst.w) return;
+  int ca[4], cb[4], a0[4], a1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int x = x0 + i;
-    if (x >= dst.w) break;
-    const CmsResizeTab tx = tabx[x];
-    const int sx = tx.s, sx1 = min(sx + 1, src.w - 1);
-    const int r0 = S0[sx] * tx.a0 + S0[sx1] * tx.a1;
-    const int r1 = S1[sx] * tx.a0 + S1[sx1] * tx.a1;
-    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-    out |= (uint32_t)(v & 0xFF) << (8 * i);
+    const CmsResizeTab t = tabx[min(x0 + i, dst.w - 1)];
+    ca[i] = (int)t.s - c0;
+    cb[i] = min((int)t.s + 1, src.w - 1) - c0;
+    a0[i] = t.a0; a1[i] = t.a1;
   }
-  *reinterpret_cast<uint32_t*>(pyr + (size_t)b * pyr_bytes + dst.off + (size_t)y * dst.stride + x0) = out;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int y = yb + ty + 4 * rr;
+    if (y >= dst.h) break;
+    const CmsResizeTab tyy = taby[y];
+    const uint8_t* S0 = rtile + (min(max((int)tyy.s, 0), src.h - 1) - r0) * ls;
+    const uint8_t* S1 = rtile + (min(max((int)tyy.s + 1, 0), src.h - 1) - r0) * ls;
+    const int b0 = tyy.a0, b1 = tyy.a1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h0 = S0[ca[i]] * a0[i] + S0[cb[i]] * a1[i];
+      const int h1 = S1[ca[i]] * a0[i] + S1[cb[i]] * a1[i];
+      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xFF) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(pyr + (size_t)b * pyr_bytes + dst.off + (size_t)y * dst.stride + x0) = out;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ FAST cells
@@ -143,37 +171,56 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   uint16_t* list = reinterpret_cast<uint16_t*>(sc + g.sc_h * g.sc_stride);
   const int ts = g.tile_stride, ss = g.sc_stride;
 
-  // ---- stage the ROI in LDS with aligned dword loads
+  // ---- stage the ROI in LDS with aligned dword loads (lane -> (row, dword) fixed, rows advance by 64 / ndw)
   const uint8_t* img = pyr + (size_t)b * pyr_bytes + lv.off;
   const int ax0 = iniX & ~3;
   const int ndw = (maxX - ax0 + 3) >> 2, th = maxY - iniY;
-  for (int idx = lane; idx < th * ndw; idx += 64) {
-    const int r = idx / ndw, c = idx - r * ndw;
-    reinterpret_cast<uint32_t*>(tile + r * ts)[c] =
-        *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * lv.stride + ax0 + 4 * c);
+  {
+    const int lr = lane / ndw, lc2 = lane - lr * ndw, rstep = 64 / ndw;
+    if (lr < rstep)
+      for (int r = lr; r < th; r += rstep)
+        reinterpret_cast<uint32_t*>(tile + r * ts)[lc2] =
+            *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * lv.stride + ax0 + 4 * lc2);
   }
   for (int idx = lane; idx < (g.sc_h * ss) >> 2; idx += 64) reinterpret_cast<uint32_t*>(sc)[idx] = 0u;
   __syncthreads();
 
-  // ---- phase A: 4-point compass pre-test at minTh, compact the survivors into an LDS list
+  // ---- phase A: 4-point compass pre-test at minTh on 4 pixels per lane (5 dword LDS reads per quad instead of 20 byte
+  // reads), survivors are compacted into an LDS list of (py << 6 | px) codes
   const int t = g.min_th;
-  const int npx = ew * eh;
+  const int lx0 = ex0 - ax0, lx1 = ex1 - ax0;           // evaluated LDS columns [lx0, lx1)
+  const int q0 = lx0 >> 2, nq = ((lx1 - 1) >> 2) - q0 + 1;
+  const int qr = lane / nq, qc = lane - qr * nq, qrows = 64 / nq;
   int L = 0;
-  for (int base = 0; base < npx; base += 64) {
-    const int idx = base + lane;
-    bool pass = false;
-    if (idx < npx) {
-      const int py = idx / ew, px = idx - py * ew;
-      const uint8_t* c = tile + (ey0 - iniY + py) * ts + (ex0 - ax0 + px);
-      const int v = c[0];
-      const int d0 = v - c[3 * ts], d4 = v - c[3], d8 = v - c[-3 * ts], d12 = v - c[-3];
+  for (int rb = 0; rb < eh; rb += qrows) {
+    const int py = rb + qr;
+    const bool rowok = qr < qrows && py < eh;
+    uint32_t cm = 0, cc = 0, cp = 0, up = 0, dn = 0;
+    const int q = q0 + qc;
+    if (rowok) {
+      const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py) * ts);
+      cm = row[q - 1]; cc = row[q]; cp = row[q + 1];
+      up = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py - 3) * ts)[q];
+      dn = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py + 3) * ts)[q];
+    }
+    const unsigned long long wide = ((unsigned long long)cp << 32) | cc;       // bytes lx .. lx+7
+    const unsigned long long wlow = ((unsigned long long)cc << 32) | cm;       // bytes lx-4 .. lx+3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lx = 4 * q + i;
+      const int v = (cc >> (8 * i)) & 0xFF;
+      const int p4 = (int)((wide >> (8 * (i + 3))) & 0xFF);     // x + 3
+      const int p12 = (int)((wlow >> (8 * (i + 1))) & 0xFF);    // x - 3
+      const int p0 = (dn >> (8 * i)) & 0xFF, p8 = (up >> (8 * i)) & 0xFF;
+      const int d0 = v - p0, d4 = v - p4, d8 = v - p8, d12 = v - p12;
       const bool k0 = d0 > t, k4 = d4 > t, k8 = d8 > t, k12 = d12 > t;
       const bool b0 = -d0 > t, b4 = -d4 > t, b8 = -d8 > t, b12 = -d12 > t;
-      pass = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+      const bool pass = rowok && lx >= lx0 && lx < lx1 &&
+                        ((k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0));
+      const unsigned long long m = __ballot(pass);
+      if (pass) list[L + LANE_PREFIX(m)] = (uint16_t)((py << 6) | (lx - lx0));
+      L += __popcll(m);
     }
-    const unsigned long long m = __ballot(pass);
-    if (pass) list[L + LANE_PREFIX(m)] = (uint16_t)idx;
-    L += __popcll(m);
   }
   __syncthreads();
 
@@ -181,9 +228,9 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   for (int base = 0; base < L; base += 64) {
     const int k = base + lane;
     if (k < L) {
-      const int idx = list[k];
-      const int py = idx / ew, px = idx - py * ew;
-      const uint8_t* c = tile + (ey0 - iniY + py) * ts + (ex0 - ax0 + px);
+      const int code = list[k];
+      const int py = code >> 6, px = code & 63;
+      const uint8_t* c = tile + (ey0 - iniY + py) * ts + (lx0 + px);
       const int v = c[0];
       int d[16];
       d[0] = v - c[3 * ts];      d[1] = v - c[3 * ts + 1];   d[2] = v - c[2 * ts + 2];   d[3] = v - c[ts + 3];
@@ -203,8 +250,8 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
     const int k = base + lane;
     bool keep = false, ini = false;
     if (k < L && list[k] != 0xFFFFu) {
-      const int idx = list[k];
-      const int py = idx / ew, px = idx - py * ew;
+      const int code = list[k];
+      const int py = code >> 6, px = code & 63;
       const uint8_t* s = sc + (py + 1) * ss + px + 1;
       const int S = s[0];
       keep = S > s[-1] && S > s[1] && S > s[-ss - 1] && S > s[-ss] && S > s[-ss + 1] && S > s[ss - 1] && S > s[ss] &&
@@ -226,10 +273,10 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   for (int base = 0; base < L; base += 64) {
     const int k = base + lane;
     bool emit = false;
-    int idx = 0, S = 0, px = 0, py = 0;
+    int S = 0, px = 0, py = 0;
     if (k < L && list[k] != 0xFFFFu) {
-      idx = list[k];
-      py = idx / ew; px = idx - py * ew;
+      const int code = list[k];
+      py = code >> 6; px = code & 63;
       S = sc[(py + 1) * ss + px + 1];
       emit = use_ini ? (S >= g.ini_th) : true;
     }
