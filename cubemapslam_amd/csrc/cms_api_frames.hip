@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -212,6 +213,7 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   g.sc_h = hCellMax + 2;
   g.sc_stride = (int)align_up((size_t)wCellMax + 2, 4);
   g.list_cap = wCellMax * hCellMax;
+  g.dbg_stop = getenv("CMS_DBG_FAST_STOP") ? atoi(getenv("CMS_DBG_FAST_STOP")) : 0;
   if (wCellMax > 60 || hCellMax > 60) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 60 pixels"); }
   if (orb->scale_factor < 1.01f || orb->scale_factor > 1.9f) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "scaleFactor must be in [1.01, 1.9]"); }
   c->fast_lds = (size_t)g.tile_h * g.tile_stride + (size_t)g.sc_h * g.sc_stride + 2 * (size_t)g.list_cap + 16;
@@ -294,6 +296,7 @@ extern "C" int cms_frames_upload(cms_ctx* c, const uint8_t* fisheye, int fstride
   for (int b = 0; b < B; ++b)
     HIPCHK(hipMemcpy2DAsync(c->d_fish + (size_t)b * c->fish_pitch, c->fstride, fisheye + (size_t)b * frame_pitch, fstride,
                             c->cam.Iw, c->cam.Ih, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // the caller may free / reuse its host buffer as soon as we return
   return CMS_OK;
 }
 

@@ -165,6 +165,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   const int ex0 = iniX + 3, ex1 = maxX - 3, ey0 = iniY + 3, ey1 = maxY - 3;   // pixels cv::FAST evaluates in this ROI
   const int ew = ex1 - ex0, eh = ey1 - ey0;
   if (ew <= 0 || eh <= 0) return;
+  if (g.dbg_stop == 9) return;
 
   uint8_t* tile = smem;                                             // [tile_h][tile_stride]
   uint8_t* sc = tile + g.tile_h * g.tile_stride;                     // [sc_h][sc_stride], zero border
@@ -176,14 +177,26 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   const int ax0 = iniX & ~3;
   const int ndw = (maxX - ax0 + 3) >> 2, th = maxY - iniY;
   {
+    // all loads of a lane are issued before the first LDS store: one memory latency per cell instead of one per row group
     const int lr = lane / ndw, lc2 = lane - lr * ndw, rstep = 64 / ndw;
-    if (lr < rstep)
-      for (int r = lr; r < th; r += rstep)
-        reinterpret_cast<uint32_t*>(tile + r * ts)[lc2] =
-            *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * lv.stride + ax0 + 4 * lc2);
+    const uint8_t* gp = img + (size_t)iniY * lv.stride + ax0 + 4 * lc2;
+    for (int rbase = 0; rbase < th; rbase += 12 * rstep) {
+      uint32_t tmp[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int r = rbase + lr + k * rstep;
+        tmp[k] = (lr < rstep && r < th) ? *reinterpret_cast<const uint32_t*>(gp + (size_t)r * lv.stride) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int r = rbase + lr + k * rstep;
+        if (lr < rstep && r < th) reinterpret_cast<uint32_t*>(tile + r * ts)[lc2] = tmp[k];
+      }
+    }
   }
   for (int idx = lane; idx < (g.sc_h * ss) >> 2; idx += 64) reinterpret_cast<uint32_t*>(sc)[idx] = 0u;
   __syncthreads();
+  if (g.dbg_stop == 1) return;
 
   // ---- phase A: 4-point compass pre-test at minTh on 4 pixels per lane (5 dword LDS reads per quad instead of 20 byte
   // reads), survivors are compacted into an LDS list of (py << 6 | px) codes
@@ -223,6 +236,40 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
     }
   }
   __syncthreads();
+  if (g.dbg_stop == 2) return;
+
+  // ---- phase A2: 8-point refinement on the list.  Nine contiguous ring pixels always cover four consecutive even ring
+  // positions (0,2,..,14), so a corner needs 4 cyclically consecutive "darker" (or "brighter") bits among those eight.
+  if (L > 0) {
+    int L2 = 0;
+    for (int base = 0; base < L; base += 64) {
+      const int k = base + lane;
+      bool pass = false;
+      int code = 0;
+      if (k < L) {
+        code = list[k];
+        const int py = code >> 6, px = code & 63;
+        const uint8_t* c = tile + (ey0 - iniY + py) * ts + (lx0 + px);
+        const int v = c[0];
+        const int e[8] = {v - c[3 * ts], v - c[2 * ts + 2], v - c[3], v - c[-2 * ts + 2],
+                          v - c[-3 * ts], v - c[-2 * ts - 2], v - c[-3], v - c[2 * ts - 2]};
+        uint32_t md = 0, mb = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { md |= (e[i] > t ? 1u : 0u) << i; mb |= (-e[i] > t ? 1u : 0u) << i; }
+        md |= md << 8; mb |= mb << 8;
+        uint32_t rd = md & (md >> 1); rd &= rd >> 2;
+        uint32_t rbm = mb & (mb >> 1); rbm &= rbm >> 2;
+        pass = ((rd | rbm) & 0xFFu) != 0;
+      }
+      __syncthreads();                         // every lane has read its entry before the compacted list is written
+      const unsigned long long m = __ballot(pass);
+      if (pass) list[L2 + LANE_PREFIX(m)] = (uint16_t)code;
+      L2 += __popcll(m);
+    }
+    L = L2;
+  }
+  __syncthreads();
+  if (g.dbg_stop == 3) return;
 
   // ---- phase B: full 16-pixel ring score for the listed pixels
   for (int base = 0; base < L; base += 64) {
@@ -243,6 +290,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
     }
   }
   __syncthreads();
+  if (g.dbg_stop == 4) return;
 
   // ---- phase C: strict 8-neighbour maximum inside this cell, iniTh else minTh, emit
   int n_all = 0, n_ini = 0;
