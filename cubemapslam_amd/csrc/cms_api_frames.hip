@@ -49,6 +49,7 @@ struct cms_ctx {
   CmsResizeTab* d_tab = nullptr; signed char* d_pattern = nullptr;
   uint32_t* d_cand = nullptr; uint16_t* d_node = nullptr; int* d_cand_cnt = nullptr; int* d_overflow = nullptr;
   uint32_t* d_qt_out = nullptr; int* d_qt_cnt = nullptr;
+  uint32_t* d_cell_cand = nullptr; int* d_cell_cnt = nullptr;
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
   // match scratch
   void* d_match = nullptr; size_t match_bytes = 0;
@@ -143,7 +144,8 @@ static void cms_ctx_free(cms_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_fish, c->d_lut, c->d_pyr, c->d_mask, c->d_tab, c->d_pattern, c->d_cand, c->d_node, c->d_cand_cnt,
-                  c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_desc, c->d_kp_cnt, c->d_match};
+                  c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_desc, c->d_kp_cnt, c->d_match, c->d_cell_cand,
+                  c->d_cell_cnt};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < 8; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -213,6 +215,7 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   g.sc_h = hCellMax + 2;
   g.sc_stride = (int)align_up((size_t)wCellMax + 2, 4);
   g.list_cap = wCellMax * hCellMax;
+  g.cell_cap = (int)align_up((size_t)((wCellMax + 1) / 2) * ((hCellMax + 1) / 2), 8);   // strict 3x3 maxima cannot be 8-adjacent
   g.dbg_stop = getenv("CMS_DBG_FAST_STOP") ? atoi(getenv("CMS_DBG_FAST_STOP")) : 0;
   if (wCellMax > 60 || hCellMax > 60) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 60 pixels"); }
   if (orb->scale_factor < 1.01f || orb->scale_factor > 1.9f) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "scaleFactor must be in [1.01, 1.9]"); }
@@ -238,6 +241,8 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   ALLOC(c->d_node, B * g.cand_total * 2);
   ALLOC(c->d_cand_cnt, B * L * sizeof(int));
   ALLOC(c->d_overflow, sizeof(int));
+  ALLOC(c->d_cell_cand, B * g.total_cells * g.cell_cap * 4);
+  ALLOC(c->d_cell_cnt, B * g.total_cells * sizeof(int));
   ALLOC(c->d_qt_out, B * g.kp_cap * 4);
   ALLOC(c->d_qt_cnt, B * L * sizeof(int));
   ALLOC(c->d_kps, B * g.kp_cap * sizeof(CmsKeyPoint));
@@ -331,11 +336,12 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
                        (const CmsResizeTab*)(c->d_tab + d.tab_off), (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w), ls);
   }
   if (c->prof) hipEventRecord(c->ev[2], s);
-  HIPCHK(hipMemsetAsync(c->d_cand_cnt, 0, (size_t)B * L * sizeof(int), s));
+  HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, (size_t)B * g.total_cells * sizeof(int), s));
   hipLaunchKernelGGL(k_fast_cells, dim3(g.total_cells, B), dim3(64), c->fast_lds, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g,
-                     c->d_cand, c->d_cand_cnt, c->d_overflow);
+                     c->d_cell_cand, c->d_cell_cnt, c->d_overflow);
   if (c->prof) hipEventRecord(c->ev[3], s);
-  hipLaunchKernelGGL(k_quadtree, dim3(L, B), dim3(512), c->qt_lds, s, g, (const uint32_t*)c->d_cand, (const int*)c->d_cand_cnt,
+  hipLaunchKernelGGL(k_quadtree, dim3(L, B), dim3(512), c->qt_lds, s, g, (const uint32_t*)c->d_cell_cand, (const int*)c->d_cell_cnt,
+                     c->d_cand, c->d_cand_cnt, c->d_overflow,
                      c->d_node, c->d_qt_out, c->d_qt_cnt);
   if (c->prof) hipEventRecord(c->ev[4], s);
   hipLaunchKernelGGL(k_cull, dim3(B), dim3(256), 0, s, g, (const uint32_t*)c->d_qt_out, (const int*)c->d_qt_cnt,

@@ -148,8 +148,8 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int t) {
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint32_t* __restrict__ cand,
-             int* __restrict__ cand_cnt, int* __restrict__ overflow) {
+k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint32_t* __restrict__ cell_cand,
+             int* __restrict__ cell_cnt, int* __restrict__ overflow) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int lane = threadIdx.x;
   const int b = blockIdx.y;
@@ -311,11 +311,12 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
     n_ini += __popcll(__ballot(ini));
   }
   const int n_emit = n_ini > 0 ? n_ini : n_all;
-  if (n_emit == 0) return;
-  int basepos = 0;
-  if (lane == 0) basepos = atomicAdd(&cand_cnt[b * g.nlevels + l], n_emit);
-  basepos = __shfl(basepos, 0);
-  uint32_t* out = cand + (size_t)b * g.cand_total + lv.cand_off;
+  if (n_emit == 0) return;            // cell_cnt was zeroed before the launch
+  // every cell owns a fixed slot: no atomics, no wait on a returning atomic; k_quadtree compacts the slots of its level
+  const size_t cell = (size_t)b * g.total_cells + blockIdx.x;
+  if (lane == 0) cell_cnt[cell] = min(n_emit, g.cell_cap);
+  uint32_t* out = cell_cand + cell * g.cell_cap;
+  const int basepos = 0;
   const bool use_ini = n_ini > 0;
   int off = 0;
   for (int base = 0; base < L; base += 64) {
@@ -331,7 +332,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
     const unsigned long long m = __ballot(emit);
     if (emit) {
       const int pos = basepos + off + LANE_PREFIX(m);
-      if (pos < lv.cand_cap) out[pos] = (uint32_t)(ex0 + px) | ((uint32_t)(ey0 + py) << 12) | ((uint32_t)S << 24);
+      if (pos < g.cell_cap) out[pos] = (uint32_t)(ex0 + px) | ((uint32_t)(ey0 + py) << 12) | ((uint32_t)S << 24);
       else *overflow = 1;
     }
     off += __popcll(m);
@@ -340,7 +341,8 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
 
 // ------------------------------------------------------------------------------------------------ quadtree
 extern "C" __global__ void __launch_bounds__(512)
-k_quadtree(CmsGeom g, const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt, uint16_t* __restrict__ node_of,
+k_quadtree(CmsGeom g, const uint32_t* __restrict__ cell_cand, const int* __restrict__ cell_cnt, uint32_t* __restrict__ cand,
+           int* __restrict__ cand_cnt, int* __restrict__ overflow, uint16_t* __restrict__ node_of,
            uint32_t* __restrict__ qt_out, int* __restrict__ qt_cnt) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int l = blockIdx.x, b = blockIdx.y;
@@ -364,7 +366,37 @@ k_quadtree(CmsGeom g, const uint32_t* __restrict__ cand, const int* __restrict__
   w.flag = p; p += maxn;
   w.isex = p; p += maxn;
   QtParams P;
-  P.n = min(cand_cnt[b * g.nlevels + l], lv.cand_cap);
+  // ---- gather this level's per-cell candidate slots into one contiguous list (cell-major order), no atomics:
+  // chunks of 512 cells, block-wide exclusive scan of the cell counts, every thread copies its cell's entries.
+  uint32_t* cwr = cand + (size_t)b * g.cand_total + lv.cand_off;
+  {
+    const int ncells = lv.nCols * lv.nRows;
+    const int* cc = cell_cnt + (size_t)b * g.total_cells + lv.cell0;
+    const uint32_t* cs = cell_cand + ((size_t)b * g.total_cells + lv.cell0) * g.cell_cap;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int running = 0;
+    for (int c0 = 0; c0 < ncells; c0 += 512) {
+      const int cell = c0 + (int)threadIdx.x;
+      const int cnt = cell < ncells ? cc[cell] : 0;
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      if (lane == 63) w.part[wv] = (uint32_t)incl;
+      __syncthreads();
+      int wbase = 0, total = 0;
+      for (int q = 0; q < 8; ++q) { const int v = (int)w.part[q]; if (q < wv) wbase += v; total += v; }
+      const int off = running + wbase + incl - cnt;
+      for (int i = 0; i < cnt; ++i) {
+        if (off + i < lv.cand_cap) cwr[off + i] = cs[(size_t)cell * g.cell_cap + i];
+        else *overflow = 1;
+      }
+      running += total;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) cand_cnt[b * g.nlevels + l] = min(running, lv.cand_cap);
+    P.n = min(running, lv.cand_cap);
+  }
+  __syncthreads();
   P.N = lv.quota;
   P.width = lv.w - 2 * CMS_MINB; P.height = lv.h - 2 * CMS_MINB;
   P.minB = CMS_MINB; P.wCell = lv.wCell; P.hCell = lv.hCell; P.nCols = lv.nCols;

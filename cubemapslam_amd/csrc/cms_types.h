@@ -34,6 +34,7 @@ struct CmsGeom {
   int tile_h, tile_stride;    // FAST LDS tile geometry (rows, bytes per row, multiple of 4)
   int sc_stride, sc_h;        // FAST LDS score tile
   int list_cap;               // FAST LDS corner list capacity
+  int cell_cap;               // capacity of one FAST cell's candidate slot
   int dbg_stop;               // developer switch (env CMS_DBG_FAST_STOP): cut k_fast_cells short after phase N, 0 = off
   CmsLevel lv[CMS_MAX_LEVELS];
 };
