@@ -1,0 +1,289 @@
+// cubemap_hot_path.cpp -- host-side mirror of the reference interfaces over the C-ABI (see cubemap_hot_path.h).
+#include "cubemap_hot_path.h"
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+
+namespace CubemapSLAM {
+
+// ------------------------------------------------------------------------------------------------ camera singleton
+CamModelGeneral* CamModelGeneral::GetCamera() {
+  static CamModelGeneral* cam = new CamModelGeneral();   // CamModelGeneral.cpp:31-38
+  return cam;
+}
+void CamModelGeneral::SetCamParams(const double cdeu0v0[5], const std::vector<double>& poly, const std::vector<double>& invpoly,
+                                   double Iw, double Ih, double, double, double, double, double width, double height, double camFov) {
+  std::memset(&cam_, 0, sizeof(cam_));
+  cam_.c = cdeu0v0[0]; cam_.d = cdeu0v0[1]; cam_.e = cdeu0v0[2]; cam_.u0 = cdeu0v0[3]; cam_.v0 = cdeu0v0[4];
+  for (size_t i = 0; i < invpoly.size() && i < 12; ++i) cam_.invpol[i] = invpoly[i];
+  for (size_t i = 0; i < poly.size() && i < 5; ++i) cam_.pol[i] = poly[i];
+  cam_.Iw = (int)Iw; cam_.Ih = (int)Ih;
+  if ((int)width != (int)height) throw std::runtime_error("CubeFace.w must equal CubeFace.h");
+  cam_.face = (int)width;
+  cam_.fov_deg = camFov;
+  const float fov = (float)camFov;
+  cosFovTh_ = cosf(fov / 2 * (3.1415926535897932384626f / 180));   // CamModelGeneral.h:224-229
+  configured_ = true;
+}
+CamModelGeneral::eFace CamModelGeneral::FaceInCubemap(const cv::Point2f& pixel) const {
+  const double i = pixel.x / (float)cam_.face, j = pixel.y / (float)cam_.face;
+  if (i >= 0 && i < 1 && j >= 1 && j < 2) return LEFT_FACE;
+  if (i >= 1 && i < 2 && j >= 0 && j < 1) return UPPER_FACE;
+  if (i >= 1 && i < 2 && j >= 1 && j < 2) return FRONT_FACE;
+  if (i >= 1 && i < 2 && j >= 2 && j < 3) return LOWER_FACE;
+  if (i >= 2 && i < 3 && j >= 1 && j < 2) return RIGHT_FACE;
+  return UNKNOWN_FACE;
+}
+void CamModelGeneral::GetPosInFace(double& u, double& v, double uCubemap, double vCubemap) const {
+  const int i = (int)std::floor(uCubemap / cam_.face), j = (int)std::floor(vCubemap / cam_.face);
+  u = uCubemap - i * cam_.face; v = vCubemap - j * cam_.face;
+}
+
+// ------------------------------------------------------------------------------------------------ shared device context
+static std::mutex g_ctx_mutex;
+static cms_ctx* g_ctx = nullptr;
+static cms_orb_params g_ctx_orb{};
+cms_ctx* SharedContext(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) {
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  cms_orb_params orb{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
+  if (g_ctx && std::memcmp(&orb, &g_ctx_orb, sizeof(orb)) == 0) return g_ctx;
+  if (!CamModelGeneral::GetCamera()->configured()) throw std::runtime_error("CamModelGeneral::SetCamParams was not called");
+  if (g_ctx) { cms_ctx_destroy(g_ctx); g_ctx = nullptr; }
+  const int rc = cms_ctx_create(&g_ctx, 0, &CamModelGeneral::GetCamera()->params(), &orb, 1);
+  if (rc != CMS_OK) throw std::runtime_error(std::string("cms_ctx_create: ") + cms_last_error());
+  g_ctx_orb = orb;
+  return g_ctx;
+}
+
+// ------------------------------------------------------------------------------------------------ remap
+void System::CreateUndistortRectifyMap() { SharedContext(2000, 1.2f, 8, 20, 7); }
+void System::CvtFisheyeToCubeMap_reverseQuery_withInterpolation(cv::Mat& cubemapImg, const cv::Mat& fisheyeImg, int interpolation,
+                                                                int borderType, const cv::Scalar&) {
+  if (interpolation != cv::INTER_LINEAR || borderType != cv::BORDER_CONSTANT)
+    throw std::runtime_error("only INTER_LINEAR / BORDER_CONSTANT(0) -- the mode the reference's examples use (cubemap_lafida.cpp:143)");
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  if (!g_ctx) throw std::runtime_error("CreateUndistortRectifyMap was not called");
+  if (cms_remap(g_ctx, fisheyeImg.data, (int)fisheyeImg.step, cubemapImg.data, (int)cubemapImg.step) != CMS_OK)
+    throw std::runtime_error(std::string("cms_remap: ") + cms_last_error());
+}
+
+// ------------------------------------------------------------------------------------------------ extractor
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
+  ctx_ = SharedContext(nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST);
+  cms_geometry g;
+  cms_ctx_geometry(ctx_, &g);
+  for (int l = 0; l < nlevels; ++l) {
+    mvScaleFactor.push_back(g.scale[l]); mvInvScaleFactor.push_back(g.inv_scale[l]);
+    mvLevelSigma2.push_back(g.sigma2[l]); mvInvLevelSigma2.push_back(g.inv_sigma2[l]);
+  }
+}
+void ORBextractor::operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints,
+                              cv::OutputArray descriptors) {
+  if (image.empty()) return;                                        // ORBExtractor.cpp:841
+  assert(image.type() == cv::CV_8UC1);                              // :845
+  assert(mask.type() == cv::CV_8UC1 && !mask.empty());              // :848
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  cms_geometry g;
+  cms_ctx_geometry(ctx_, &g);
+  if (image.cols != g.W || image.rows != g.W || mask.cols != g.W || mask.rows != g.W)
+    throw std::runtime_error("ORBextractor: image / mask must be the 3F x 3F cubemap canvas");
+  if (mask.data != last_mask_) {   // the mask is constant per sequence: upload once per distinct buffer
+    if (cms_set_mask(ctx_, mask.data, (int)mask.step) != CMS_OK) throw std::runtime_error(cms_last_error());
+    last_mask_ = mask.data;
+  }
+  std::vector<cms_keypoint> kps(g.kp_cap);
+  std::vector<uint8_t> desc((size_t)g.kp_cap * 32);
+  int n = 0;
+  if (cms_extract(ctx_, image.data, (int)image.step, kps.data(), desc.data(), g.kp_cap, &n) != CMS_OK)
+    throw std::runtime_error(std::string("cms_extract: ") + cms_last_error());
+  keypoints.clear();
+  keypoints.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    cv::KeyPoint kp;
+    kp.pt = cv::Point2f(kps[i].x, kps[i].y); kp.size = kps[i].size; kp.angle = kps[i].angle; kp.response = kps[i].response;
+    kp.octave = kps[i].octave;
+    keypoints.push_back(kp);
+  }
+  if (n == 0) { descriptors.release(); return; }                    // ORBExtractor.cpp:863-864
+  descriptors.create(n, 32, cv::CV_8U);
+  for (int i = 0; i < n; ++i) std::memcpy(descriptors.ptr<uint8_t>(i), &desc[(size_t)i * 32], 32);
+}
+
+// ------------------------------------------------------------------------------------------------ matcher
+int ORBMatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
+  const uint32_t* pa = a.ptr<uint32_t>();
+  const uint32_t* pb = b.ptr<uint32_t>();
+  int dist = 0;
+  for (int i = 0; i < 8; ++i) dist += __builtin_popcount(pa[i] ^ pb[i]);
+  return dist;
+}
+
+int ORBMatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, float th, bool) {
+  const int F = CamModelGeneral::GetCamera()->GetCubeFaceWidth();
+  const int W = 3 * F, GR = 150;                      // 3 x 50 grid columns over the cross (Frame.h:43-45: 50 x 50 per face)
+  const float cell = (float)W / GR;
+  const int N2 = (int)Cur.mvKeys.size();
+  std::vector<std::vector<int>> grid((size_t)GR * GR);
+  for (int i = 0; i < N2; ++i) {
+    const int gx = std::min(GR - 1, std::max(0, (int)(Cur.mvKeys[i].pt.x / cell)));
+    const int gy = std::min(GR - 1, std::max(0, (int)(Cur.mvKeys[i].pt.y / cell)));
+    grid[(size_t)gx * GR + gy].push_back(i);
+  }
+  // candidate windows (Frame::GetFeaturesInArea semantics within one face: |dx| < r, |dy| < r, level gate; cell-major order)
+  std::vector<int> qidx, off(1, 0), cand;
+  for (int i = 0; i < (int)Last.mvKeys.size(); ++i) {
+    if (Last.mvpMapPoints[i] < 0 || (i < (int)Last.mvbOutlier.size() && Last.mvbOutlier[i])) continue;
+    const cv::Point2f p = Last.projInCurrent[i];
+    if (p.x < 0 || p.y < 0) continue;
+    const int oct = Last.mvKeys[i].octave;
+    const float r = th * Cur.mvScaleFactors[oct];
+    const int x0 = std::max(0, (int)std::floor((p.x - r) / cell)), x1 = std::min(GR - 1, (int)std::ceil((p.x + r) / cell));
+    const int y0 = std::max(0, (int)std::floor((p.y - r) / cell)), y1 = std::min(GR - 1, (int)std::ceil((p.y + r) / cell));
+    for (int ix = x0; ix <= x1; ++ix)
+      for (int iy = y0; iy <= y1; ++iy)
+        for (int j : grid[(size_t)ix * GR + iy]) {
+          const cv::KeyPoint& k = Cur.mvKeys[j];
+          if (k.octave < oct - 1 || k.octave > oct + 1) continue;
+          if (std::fabs(k.pt.x - p.x) < r && std::fabs(k.pt.y - p.y) < r) cand.push_back(j);
+        }
+    if ((int)cand.size() == off.back()) continue;     // vIndices2.empty()
+    qidx.push_back(i);
+    off.push_back((int)cand.size());
+  }
+  const int nq = (int)qidx.size();
+  if (nq == 0) return 0;
+  std::vector<uint8_t> qdesc((size_t)nq * 32), excl(N2, 0);
+  for (int q = 0; q < nq; ++q) std::memcpy(&qdesc[(size_t)q * 32], Last.mDescriptors.ptr<uint8_t>(qidx[q]), 32);
+  for (int j = 0; j < N2; ++j) excl[j] = Cur.mvpMapPoints[j] >= 0;
+  std::vector<uint8_t> tdesc((size_t)N2 * 32);
+  for (int j = 0; j < N2; ++j) std::memcpy(&tdesc[(size_t)j * 32], Cur.mDescriptors.ptr<uint8_t>(j), 32);
+  std::vector<int> bi(nq), bd(nq), sd(nq);
+  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (cms_hamming_best2(ctx, qdesc.data(), nq, tdesc.data(), N2, off.data(), cand.data(), nullptr, excl.data(), bi.data(), bd.data(),
+                          nullptr, sd.data(), nullptr) != CMS_OK)
+      throw std::runtime_error(std::string("cms_hamming_best2: ") + cms_last_error());
+  }
+  // greedy replay in the reference's order (ORBMatcher.cpp:150-222)
+  const int nBins = (int)std::ceil(360.0f / HISTO_LENGTH);
+  std::vector<std::vector<int>> rotHist(nBins);
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  for (int q = 0; q < nq; ++q) {
+    int bestIdx = bi[q], bestDist = bd[q];
+    if (bestIdx >= 0 && Cur.mvpMapPoints[bestIdx] >= 0 && !excl[bestIdx]) {   // taken earlier in THIS call: rescan on the host
+      bestDist = 256; bestIdx = -1;
+      for (int c = off[q]; c < off[q + 1]; ++c) {
+        const int j = cand[c];
+        if (Cur.mvpMapPoints[j] >= 0) continue;
+        const int d = DescriptorDistance(Last.mDescriptors.row(qidx[q]), Cur.mDescriptors.row(j));
+        if (d < bestDist) { bestDist = d; bestIdx = j; }
+      }
+    }
+    if (bestIdx < 0 || bestDist > TH_HIGH) continue;
+    Cur.mvpMapPoints[bestIdx] = Last.mvpMapPoints[qidx[q]];
+    ++nmatches;
+    if (mbCheckOrientation) {
+      float rot = Last.mvKeys[qidx[q]].angle - Cur.mvKeys[bestIdx].angle;
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)std::round(rot * factor);
+      if (bin == nBins) bin = 0;
+      rotHist[bin].push_back(bestIdx);
+    }
+  }
+  if (mbCheckOrientation) {   // ComputeThreeMaxima (ORBMatcher.cpp:905-946)
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < nBins; ++i) {
+      const int s = (int)rotHist[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+    for (int i = 0; i < nBins; ++i)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int j : rotHist[i]) { Cur.mvpMapPoints[j] = -1; --nmatches; }
+  }
+  return nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------ local BA
+static void R_to_quat(const double m[9], double* q) {  // Eigen::Quaterniond(Matrix3d), as Converter::toSE3Quat uses it
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t; q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+  }
+}
+void Optimizer::LocalBundleAdjustment(LocalBAWindow* win, bool* pbStopFlag) {
+  CamModelGeneral* cam = CamModelGeneral::GetCamera();
+  const int K = (int)win->keyframes.size(), P = (int)win->mappoints.size();
+  win->toErase.clear();
+  if (K == 0 || P == 0) return;
+  std::vector<double> poses((size_t)K * 7), points((size_t)P * 3);
+  std::vector<uint8_t> fixed(K);
+  for (int k = 0; k < K; ++k) {   // Converter::toSE3Quat (Converter.cpp:41-51): float Tcw -> double R, t -> quaternion
+    const cv::Mat& T = win->keyframes[k].Tcw;
+    double R[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = T.at<float>(r, c);
+    for (int r = 0; r < 3; ++r) poses[7 * k + r] = T.at<float>(r, 3);
+    R_to_quat(R, &poses[7 * k + 3]);
+    fixed[k] = (win->keyframes[k].mnId == 0) || win->keyframes[k].fixed;   // Optimizer.cpp:268, 281
+  }
+  std::vector<int> e_pose, e_point;
+  std::vector<double> e_obs, e_inv;
+  std::vector<int8_t> e_face;
+  std::vector<std::pair<int, int>> e_src;
+  for (int p = 0; p < P; ++p) {
+    const LocalBAWindow::MP& mp = win->mappoints[p];
+    for (int i = 0; i < 3; ++i) points[3 * p + i] = mp.Xw.at<float>(i, 0);   // Converter::toVector3d
+    for (const LocalBAWindow::Obs& ob : mp.observations) {
+      if (ob.ray(2) < cam->GetCosFovTh()) continue;                            // Optimizer.cpp:323-325
+      const int face = cam->FaceInCubemap(ob.kp.pt);                           // :335
+      if (face == CamModelGeneral::UNKNOWN_FACE) continue;                     // would exit() inside g2o (edge h:103-108)
+      double u, v;
+      cam->GetPosInFace(u, v, (double)ob.kp.pt.x, (double)ob.kp.pt.y);          // :336-338
+      e_pose.push_back(ob.kf); e_point.push_back(p); e_obs.push_back(u); e_obs.push_back(v);
+      e_inv.push_back((double)win->keyframes[ob.kf].mvInvLevelSigma2[ob.kp.octave]);   // :339-340
+      e_face.push_back((int8_t)face);
+      e_src.push_back(std::make_pair(ob.kf, p));
+    }
+  }
+  const int E = (int)e_pose.size();
+  if (E == 0) return;
+  if (pbStopFlag && *pbStopFlag) return;                                       // :359-361
+  std::vector<uint8_t> flags(E);
+  const double f = cam->Get_fx();
+  const int rc = cms_ba_run(0, K, poses.data(), fixed.data(), P, points.data(), E, e_pose.data(), e_point.data(), e_obs.data(), e_inv.data(),
+                            e_face.data(), f, f, f, f, 5, 10, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), flags.data(), nullptr);
+  if (rc < 0) throw std::runtime_error(std::string("cms_ba_run: ") + cms_last_error());
+  if (rc == 1) return;
+  for (int e = 0; e < E; ++e) if (flags[e]) win->toErase.push_back(e_src[e]);  // :399-412
+  for (int k = 0; k < K; ++k) {   // Converter::toCvMat(SE3Quat) -> float 4x4 (Converter.cpp:53-104)
+    if (fixed[k]) continue;       // the reference rewrites local key frames only (:432-438); fixed ones are unchanged anyway
+    const double* q = &poses[7 * k + 3];
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                         2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    cv::Mat& T = win->keyframes[k].Tcw;
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T.at<float>(r, c) = (float)R[3 * r + c]; T.at<float>(r, 3) = (float)poses[7 * k + r]; }
+  }
+  for (int p = 0; p < P; ++p)
+    for (int i = 0; i < 3; ++i) win->mappoints[p].Xw.at<float>(i, 0) = (float)points[3 * p + i];
+}
+
+}  // namespace CubemapSLAM

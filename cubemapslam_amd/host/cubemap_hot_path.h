@@ -1,0 +1,129 @@
+// cubemap_hot_path.h -- host-side C++ mirror of the reference interfaces on the hot path, implemented on top of the
+// C-ABI of libcubemapslam_hip.so (include/cubemapslam_hip.h).  Same class / method names, argument meaning and error
+// behaviour as the reference so Tracking / LocalMapping style call sites read unchanged:
+//
+//   CamModelGeneral::GetCamera()->SetCamParams(...)                 include/CamModelGeneral.h:100-108, src/System.cpp:63-89
+//   System::CreateUndistortRectifyMap / CvtFisheyeToCubeMap_reverseQuery_withInterpolation
+//                                                                   include/System.h:104-107, src/System.cpp:301-355
+//   ORBextractor(int,float,int,int,int) / operator()(image, mask, keypoints, descriptors) / Get* accessors
+//                                                                   include/ORBExtractor.h:55-90, src/ORBExtractor.cpp:838-926
+//   ORBMatcher(nnratio, checkOri) / DescriptorDistance / SearchByProjection(CurrentFrame, LastFrame, th, mono)
+//                                                                   include/ORBMatcher.h:46-84, src/ORBMatcher.cpp:130-251,951-967
+//   Optimizer::LocalBundleAdjustment(...)                           include/Optimizer.h:50, src/Optimizer.cpp:192-451
+//
+// The pointer-graph types the reference passes around (Frame, KeyFrame, MapPoint, Map) are out of scope (SURVEY.md
+// section 2); the two methods that take them receive plain views instead (FrameView, LocalBAWindow) holding exactly the
+// fields those methods read.
+#ifndef CMS_CUBEMAP_HOT_PATH_H
+#define CMS_CUBEMAP_HOT_PATH_H
+#include <string>
+#include <vector>
+#include "cubemapslam_hip.h"
+#include "mini_cv.h"
+
+namespace CubemapSLAM {
+
+class CamModelGeneral {
+ public:
+  enum eFace { UNKNOWN_FACE = -1, FRONT_FACE = 0, LEFT_FACE = 1, RIGHT_FACE = 2, UPPER_FACE = 3, LOWER_FACE = 4 };
+  static CamModelGeneral* GetCamera();
+  // same argument order as the reference overload used by System (CamModelGeneral.h:105-108); poly / invpoly zero padded
+  void SetCamParams(const double cdeu0v0[5], const std::vector<double>& poly, const std::vector<double>& invpoly, double Iw,
+                    double Ih, double fx, double fy, double cx, double cy, double width, double height, double camFov);
+  int GetCubeFaceWidth() const { return cam_.face; }
+  int GetCubeFaceHeight() const { return cam_.face; }
+  int GetFisheyeWidth() const { return cam_.Iw; }
+  int GetFisheyeHeight() const { return cam_.Ih; }
+  double Get_fx() const { return cam_.face / 2.0; }
+  float GetCosFovTh() const { return cosFovTh_; }
+  eFace FaceInCubemap(const cv::Point2f& pixel) const;                          // CamModelGeneral.h:445-456
+  void GetPosInFace(double& u, double& v, double uCubemap, double vCubemap) const;  // CamModelGeneral.h:204-209
+  const cms_camera& params() const { return cam_; }
+  bool configured() const { return configured_; }
+
+ private:
+  cms_camera cam_{};
+  float cosFovTh_ = 0;
+  bool configured_ = false;
+};
+
+// Owner of the device context shared by the remap entry point and the extractor (one per process, like the reference's
+// camera singleton + System instance).  Throws std::runtime_error when the HIP library cannot create a context.
+cms_ctx* SharedContext(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+
+class System {
+ public:
+  void CreateUndistortRectifyMap();  // builds the LUT on the device (inside the shared context)
+  void CvtFisheyeToCubeMap_reverseQuery_withInterpolation(cv::Mat& cubemapImg, const cv::Mat& fisheyeImg, int interpolation,
+                                                          int borderType = cv::BORDER_CONSTANT,
+                                                          const cv::Scalar& borderValue = cv::Scalar());
+};
+
+class ORBextractor {
+ public:
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+  // image: CV_8UC1 3F x 3F cubemap; mask: CV_8UC1 non-empty (assert in the reference, ORBExtractor.cpp:845-848);
+  // empty image -> silent return (ORBExtractor.cpp:841).
+  void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
+  int GetLevels() const { return nlevels; }
+  float GetScaleFactor() const { return (float)scaleFactor; }
+  std::vector<float> GetScaleFactors() const { return mvScaleFactor; }
+  std::vector<float> GetInverseScaleFactors() const { return mvInvScaleFactor; }
+  std::vector<float> GetScaleSigmaSquares() const { return mvLevelSigma2; }
+  std::vector<float> GetInverseScaleSigmaSquares() const { return mvInvLevelSigma2; }
+
+ protected:
+  int nfeatures; double scaleFactor; int nlevels, iniThFAST, minThFAST;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+  cms_ctx* ctx_ = nullptr;
+  const uint8_t* last_mask_ = nullptr;
+};
+
+// What ORBMatcher::SearchByProjection(Frame&, const Frame&, th, mono) reads from a Frame (Frame.h): key points,
+// descriptors, the map-point slot per key point (>=0 = id of the assigned map point) and, for the last frame, the
+// projection of each of its map points into the current frame (u, v in cubemap pixels, <0 = not visible).
+struct FrameView {
+  std::vector<cv::KeyPoint> mvKeys;
+  cv::Mat mDescriptors;                 // N x 32 CV_8U
+  std::vector<long> mvpMapPoints;       // -1 = none
+  std::vector<uint8_t> mvbOutlier;
+  std::vector<cv::Point2f> projInCurrent;  // last frame only: where map point i projects in the current frame
+  std::vector<float> mvScaleFactors;
+};
+
+class ORBMatcher {
+ public:
+  ORBMatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+  static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);   // ORBMatcher.cpp:951-967 (single pair, host)
+  // ORBMatcher.cpp:130-251: windows of radius th*scale[octave] around the projections, octave +-1, best Hamming <= TH_HIGH,
+  // rotation-histogram consistency.  Distances / arg-min run on the GPU (cms_hamming_best2); the greedy acceptance is
+  // replayed on the host in the reference's order.  Returns the number of matches, fills CurrentFrame.mvpMapPoints.
+  int SearchByProjection(FrameView& CurrentFrame, const FrameView& LastFrame, float th, bool bMono);
+  static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 12;
+
+ protected:
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+
+// The window Optimizer::LocalBundleAdjustment assembles from pKF's covisibility graph (Optimizer.cpp:194-357), as data.
+struct LocalBAWindow {
+  struct KF { long mnId; cv::Mat Tcw; bool fixed; std::vector<float> mvInvLevelSigma2; };   // Tcw: 4x4 CV_32F
+  struct Obs { int kf; cv::KeyPoint kp; cv::Vec3f ray; };                                   // kf = index into keyframes
+  struct MP { long mnId; cv::Mat Xw; std::vector<Obs> observations; };                      // Xw: 3x1 CV_32F
+  std::vector<KF> keyframes;
+  std::vector<MP> mappoints;
+  std::vector<std::pair<int, int>> toErase;   // out: (keyframe index, map point index) observations to erase
+};
+
+class Optimizer {
+ public:
+  // Optimizer.cpp:192-451 with the graph already collected: builds the edge list exactly like :246-357 (fixed = mnId==0 or
+  // fixed KF, rays with z < cosFovTh skipped, face + in-face measurement from the key point, invSigma2 of the octave),
+  // runs optimize(5) / classify / optimize(10) on the GPU, writes poses and points back through float (Converter.cpp:53-104)
+  // and lists the observations to erase.  *pbStopFlag is polled like g2o's forceStopFlag.
+  static void LocalBundleAdjustment(LocalBAWindow* window, bool* pbStopFlag);
+};
+
+}  // namespace CubemapSLAM
+#endif

@@ -1,0 +1,97 @@
+// host_capi.cpp -- flat C entry points around the C++ mirror classes (cubemap_hot_path.h) so the Python test-suite can
+// drive them exactly the way a C++ caller (Tracking / LocalMapping) would.  Test plumbing, not part of the boundary.
+#include <cstring>
+#include <stdexcept>
+#include "cubemap_hot_path.h"
+using namespace CubemapSLAM;
+
+static thread_local std::string g_err;
+extern "C" const char* hm_last_error() { return g_err.c_str(); }
+#define HM_TRY(...) try { __VA_ARGS__ } catch (const std::exception& e) { g_err = e.what(); return -1; }
+
+extern "C" int hm_set_camera(const cms_camera* c) {
+  HM_TRY(
+    const double cde[5] = {c->c, c->d, c->e, c->u0, c->v0};
+    std::vector<double> pol(c->pol, c->pol + 5), inv(c->invpol, c->invpol + 12);
+    const double h = c->face / 2.0;
+    CamModelGeneral::GetCamera()->SetCamParams(cde, pol, inv, c->Iw, c->Ih, h, h, h, h, c->face, c->face, c->fov_deg);
+    return 0;)
+}
+extern "C" int hm_remap(const uint8_t* fish, int fstride, uint8_t* cube, int cstride) {
+  HM_TRY(
+    CamModelGeneral* cam = CamModelGeneral::GetCamera();
+    System sys;
+    sys.CreateUndistortRectifyMap();
+    cv::Mat f(cam->GetFisheyeHeight(), cam->GetFisheyeWidth(), cv::CV_8U, (void*)fish, (size_t)fstride);
+    const int W = 3 * cam->GetCubeFaceWidth();
+    cv::Mat c(W, W, cv::CV_8U, cube, (size_t)cstride);
+    sys.CvtFisheyeToCubeMap_reverseQuery_withInterpolation(c, f, cv::INTER_LINEAR);
+    return 0;)
+}
+extern "C" int hm_extract(int nfeatures, float scale, int nlevels, int ini_th, int min_th, const uint8_t* img, int stride,
+                          const uint8_t* mask, int mstride, cms_keypoint* kps, uint8_t* desc, int cap) {
+  HM_TRY(
+    const int W = 3 * CamModelGeneral::GetCamera()->GetCubeFaceWidth();
+    ORBextractor ex(nfeatures, scale, nlevels, ini_th, min_th);
+    cv::Mat image(W, W, cv::CV_8U, (void*)img, (size_t)stride), m(W, W, cv::CV_8U, (void*)mask, (size_t)mstride), d;
+    std::vector<cv::KeyPoint> keys;
+    ex(image, m, keys, d);
+    const int n = (int)keys.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+      kps[i] = cms_keypoint{keys[i].pt.x, keys[i].pt.y, keys[i].size, keys[i].angle, keys[i].response, keys[i].octave};
+      std::memcpy(desc + (size_t)i * 32, d.ptr<uint8_t>(i), 32);
+    }
+    return n;)
+}
+// frame-to-frame SearchByProjection: returns matches; cur_mp[j] receives the matched map-point id or -1
+extern "C" int hm_search_by_projection(int ncur, const cms_keypoint* cur_k, const uint8_t* cur_d, long* cur_mp, int nlast,
+                                       const cms_keypoint* last_k, const uint8_t* last_d, const long* last_mp, const float* proj_xy,
+                                       const float* scale_factors, int nlevels, float th, float nnratio, int check_ori) {
+  HM_TRY(
+    FrameView cur, last;
+    auto fill = [](FrameView& f, int n, const cms_keypoint* k, const uint8_t* d) {
+      f.mvKeys.resize(n);
+      f.mDescriptors.create(n > 0 ? n : 1, 32, cv::CV_8U);
+      for (int i = 0; i < n; ++i) {
+        f.mvKeys[i].pt = cv::Point2f(k[i].x, k[i].y); f.mvKeys[i].angle = k[i].angle; f.mvKeys[i].octave = k[i].octave;
+        std::memcpy(f.mDescriptors.ptr<uint8_t>(i), d + (size_t)i * 32, 32);
+      }
+    };
+    fill(cur, ncur, cur_k, cur_d); fill(last, nlast, last_k, last_d);
+    cur.mvpMapPoints.assign(cur_mp, cur_mp + ncur);
+    last.mvpMapPoints.assign(last_mp, last_mp + nlast);
+    last.mvbOutlier.assign(nlast, 0);
+    last.projInCurrent.resize(nlast);
+    for (int i = 0; i < nlast; ++i) last.projInCurrent[i] = cv::Point2f(proj_xy[2 * i], proj_xy[2 * i + 1]);
+    cur.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+    ORBMatcher matcher(nnratio, check_ori != 0);
+    const int n = matcher.SearchByProjection(cur, last, th, true);
+    for (int j = 0; j < ncur; ++j) cur_mp[j] = cur.mvpMapPoints[j];
+    return n;)
+}
+// local BA through the Optimizer mirror.  Tcw: K x 16 float (row major 4x4), Xw: P x 3 float, observations flat.
+extern "C" int hm_local_ba(int K, float* Tcw, const long* kf_id, const uint8_t* kf_fixed, const float* inv_sigma2, int nlevels, int P,
+                           float* Xw, int nobs, const int* obs_kf, const int* obs_mp, const cms_keypoint* obs_kp, const float* obs_ray,
+                           uint8_t* stop, int* erase_pairs, int erase_cap) {
+  HM_TRY(
+    LocalBAWindow w;
+    w.keyframes.resize(K);
+    for (int k = 0; k < K; ++k) {
+      w.keyframes[k].mnId = kf_id[k]; w.keyframes[k].fixed = kf_fixed[k] != 0;
+      w.keyframes[k].Tcw = cv::Mat(4, 4, cv::CV_32F, Tcw + 16 * (size_t)k, 16);
+      w.keyframes[k].mvInvLevelSigma2.assign(inv_sigma2, inv_sigma2 + nlevels);
+    }
+    w.mappoints.resize(P);
+    for (int p = 0; p < P; ++p) { w.mappoints[p].mnId = p; w.mappoints[p].Xw = cv::Mat(3, 1, cv::CV_32F, Xw + 3 * (size_t)p, 4); }
+    for (int o = 0; o < nobs; ++o) {
+      LocalBAWindow::Obs ob;
+      ob.kf = obs_kf[o];
+      ob.kp.pt = cv::Point2f(obs_kp[o].x, obs_kp[o].y); ob.kp.octave = obs_kp[o].octave;
+      ob.ray.v[0] = obs_ray[3 * o]; ob.ray.v[1] = obs_ray[3 * o + 1]; ob.ray.v[2] = obs_ray[3 * o + 2];
+      w.mappoints[obs_mp[o]].observations.push_back(ob);
+    }
+    Optimizer::LocalBundleAdjustment(&w, reinterpret_cast<bool*>(stop));
+    const int n = (int)w.toErase.size();
+    for (int i = 0; i < n && i < erase_cap; ++i) { erase_pairs[2 * i] = w.toErase[i].first; erase_pairs[2 * i + 1] = w.toErase[i].second; }
+    return n;)
+}

@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: two gloo processes shard 8 streams, run the (host-side) per-stream bookkeeping and gather the
+trajectory on rank 0 -- the only exchange step of the multi-GPU design."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_streams, frames, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from cubemapslam_amd import dist as cdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = cdist.streams_of_rank(n_streams, world, rank)
+    recs = []
+    for s in mine:
+        n = frames + s            # ragged: streams have different lengths
+        ts = np.arange(n) / 30.0
+        poses = np.zeros((n, 7)); poses[:, 0] = s; poses[:, 1] = np.arange(n); poses[:, 6] = 1.0
+        recs.append(cdist.make_records(s, ts, poses))
+    local = np.concatenate(recs, 0) if recs else np.zeros((0, cdist.RECORD))
+    traj = cdist.gather_trajectory(local)
+    dist.barrier()
+    if rank == 0:
+        q.put(traj)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_streams", [(2, 8), (2, 3)])
+def test_stream_sharding_and_trajectory_gather(world, n_streams):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    traj = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = sum(5 + s for s in range(n_streams))
+    assert traj.shape == (want, 9)
+    # sorted by (stream, ts), every stream complete and untouched
+    for s in range(n_streams):
+        rows = traj[traj[:, 0] == s]
+        assert len(rows) == 5 + s
+        assert np.allclose(rows[:, 1], np.arange(5 + s) / 30.0) and np.all(rows[:, 2] == s) and np.all(rows[:, 8] == 1.0)
+    assert np.all(np.diff(traj[:, 0]) >= 0)
+
+
+def test_partition_covers_all_streams():
+    from cubemapslam_amd import dist as cdist
+    for world in (1, 2, 4, 8):
+        got = sorted(s for r in range(world) for s in cdist.streams_of_rank(8, world, r))
+        assert got == list(range(8))
+        assert max(len(cdist.streams_of_rank(8, world, r)) for r in range(world)) == 8 // world
+    rec = cdist.make_records(3, [0.0, 1.0], np.ones((2, 7)))
+    assert rec.shape == (2, 9) and np.all(rec[:, 0] == 3)
+    one = cdist.gather_trajectory(rec)           # world size 1: local sort only
+    assert one.shape == (2, 9)
