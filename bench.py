@@ -83,7 +83,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from cubemapslam_amd import api, build, synth
-    build.build(verbose=False)
+    from cubemapslam_amd import dist as cdist
+    if rank == 0:
+        build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
 
     B, F = args.batch, args.face
     camd = synth.camera("lafida", F)
@@ -123,8 +127,6 @@ def main():
         except Exception as e:  # surfaced after join
             ba_err.append(e)
 
-    traj = torch.zeros((B, 8), dtype=torch.float64, device=dev)
-
     def step(i):
         ths = [threading.Thread(target=ba_worker, args=(ba,)) for ba in bas]
         for th in ths:
@@ -137,13 +139,10 @@ def main():
             th.join()
         if ba_err:
             raise ba_err[0]
-        if world > 1:   # trajectory assembly on rank 0 (tiny payload, latency only)
+        if world > 1:   # trajectory assembly on rank 0 over RCCL (64 B / frame, latency only)
             poses, _, _ = bas[0].read()
-            rec = np.zeros((B, 8)); rec[:, 0] = i * B + np.arange(B); rec[:, 1:] = poses[np.arange(B) % len(poses)]
-            traj.copy_(torch.from_numpy(rec))
-            import torch.distributed as dist
-            out = [torch.empty_like(traj) for _ in range(world)] if rank == 0 else None
-            dist.gather(traj, out, dst=0)
+            rec = cdist.make_records(rank, i * B + np.arange(B), poses[np.arange(B) % len(poses)])
+            cdist.gather_trajectory(rec, device=dev, dst=0)
 
     def barrier():
         if world > 1:

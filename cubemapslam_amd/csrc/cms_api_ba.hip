@@ -25,7 +25,7 @@ struct cms_ba {
   double* d_partial = nullptr; double* d_scal = nullptr; int* d_status = nullptr; uint8_t* d_flags = nullptr;
   double* d_pose_partial = nullptr; double* d_db = nullptr;
   int* d_pair_s1 = nullptr; int* d_pair_s2 = nullptr; int* d_pair_off = nullptr; int2* d_tup = nullptr;
-  int* d_pair_chunk_off = nullptr; int2* d_chunk_range = nullptr; double* d_chunk_sum = nullptr;
+  int* d_pair_chunk_off = nullptr; int2* d_chunk_range = nullptr; double* d_chunk_sum = nullptr; int* d_pair_of_block = nullptr;
   int npairs = 0, nchunks = 0; size_t solve_lds = 0, blk_lds = 0; bool solve_in_lds = false, solve_blk = false;
   int cur = 0;
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
@@ -102,7 +102,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
   BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
-  BA_TRY(ba_alloc(b, &b->d_partial, (size_t)std::max(b->nblk_e, b->nblk_p) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 8));
+  BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(b->nblk_e, b->nblk_p) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 8));
   BA_TRY(ba_alloc(b, &b->d_flags, E));
   b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
   BA_HIP(hipHostMalloc((void**)&b->h_pin, 8 * sizeof(double)));
@@ -130,6 +130,12 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     }
     poff.push_back((int)tups.size());
     b->npairs = (int)ps1.size();
+    {   // lower block (I, K) of the reduced system -> index of the pose pair (s1 = K, s2 = I) or -1 (not co-visible)
+      std::vector<int> pob((size_t)std::max(np * (np + 1) / 2, 1), -1);
+      for (size_t pr = 0; pr < ps1.size(); ++pr) pob[(size_t)ps2[pr] * (ps2[pr] + 1) / 2 + ps1[pr]] = (int)pr;
+      BA_TRY(ba_alloc(b, &b->d_pair_of_block, pob.size()));
+      BA_HIP(hipMemcpy(b->d_pair_of_block, pob.data(), pob.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     std::vector<int> pcoff(1, 0);
     std::vector<int2> crange;
     for (size_t pr = 0; pr + 1 < poff.size(); ++pr) {
@@ -152,7 +158,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   }
   b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
   b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= 160 * 1024 - 512;
-  if (b->solve_blk) BA_HIP(hipFuncSetAttribute((const void*)k_ba_solve_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds));
+  if (b->solve_blk) BA_HIP(hipFuncSetAttribute((const void*)k_ba_trial_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds));
   {
     const int NP = 192;
     b->solve_lds = ((size_t)n * (n + 1) / 2 + 4 * (size_t)NP + 8) * sizeof(double);
@@ -236,6 +242,21 @@ static int ba_optimize_stage(cms_ba* b, int iterations, int robust, double delta
     double rho = 0;
     int qmax = 0;
     do {
+      if (b->solve_blk) {
+        // fused trial (cms_ba_fused.hip): 5 launches, no reduced matrix in memory
+        hipLaunchKernelGGL(k_ba_dinv, dim3((b->P + 255) / 256), dim3(256), 0, s, b->P, (const double*)b->d_Hll, (const double*)b->d_bl, lambda,
+                           b->d_Dinv, b->d_db);
+        if (b->npairs > 0)
+          hipLaunchKernelGGL(k_ba_schur_chunks, dim3(b->nchunks), dim3(256), 0, s, b->d, (const int2*)b->d_chunk_range, (const int2*)b->d_tup,
+                             (const double*)b->d_Hpl, (const double*)b->d_Dinv, (const double*)b->d_db, b->d_chunk_sum);
+        hipLaunchKernelGGL(k_ba_trial_solve, dim3(1), dim3(384), b->blk_lds, s, b->d, (const double*)b->d_Hpp, (const double*)b->d_bp, lambda,
+                           (const int*)b->d_pair_of_block, (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum,
+                           (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_x, b->d_scal);
+        hipLaunchKernelGGL(k_ba_trial_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
+                           (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt],
+                           (const double*)b->d_poses[nxt], robust, delta, b->d_partial);
+        hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal);
+      } else {
       if (n > 0) {
         hipLaunchKernelGGL(k_ba_schur_init, dim3(std::min((n * n + 255) / 256, 256)), dim3(256), 0, s, b->np, (const double*)b->d_Hpp,
                            (const double*)b->d_bp, lambda, b->d_Hs, b->d_bs);
@@ -260,6 +281,7 @@ static int ba_optimize_stage(cms_ba* b, int iterations, int robust, double delta
                          (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_scal + 2);
       hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal + 2, 1);
       ba_errors(b, nxt, robust, delta, 1);
+      }
       double* t = b->h_pin;
       HIPCHK(hipMemcpyAsync(t, b->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));

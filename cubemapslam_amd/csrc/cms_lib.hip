@@ -3,5 +3,6 @@
 #include "cms_extract_kernels.hip"
 #include "cms_match_kernels.hip"
 #include "cms_ba_kernels.hip"
+#include "cms_ba_fused.hip"
 #include "cms_api_frames.hip"
 #include "cms_api_ba.hip"
