@@ -116,7 +116,7 @@ def main():
 
     n_ba = max(1, B // args.ba_every)
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + rank)
-    # one LocalMapping-like host thread + BA handle (own HIP stream) per window, all concurrent with the frame path
+    # one BA handle (own HIP stream) + one LocalMapping-like host thread per window, concurrent with the frame path
     bas = [api.BundleAdjuster(prob, device=local_rank) for _ in range(n_ba)]
     ba_err = []
 

@@ -312,6 +312,17 @@ class BundleAdjuster:
             pass
 
 
+def ba_optimize_many(bas, its=(5, 10), stop=None):
+    """cms_ba_optimize_many: advance several BundleAdjuster windows in lock-step from one host thread."""
+    n = len(bas)
+    handles = (C.c_void_p * n)(*[b.h for b in bas])
+    stats = (BaStats * n)()
+    stop_arr = np.array([1 if stop else 0], np.uint8)
+    lib().cms_ba_optimize_many.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rc = _chk(lib().cms_ba_optimize_many(handles, n, its[0], its[1], _p(stop_arr), stats), "cms_ba_optimize_many")
+    return rc, list(stats)
+
+
 def ba_run(prob, its=(5, 10), stop=None, device=0):
     poses = np.array(prob["poses"], np.float64, copy=True); pts = np.array(prob["points"], np.float64, copy=True)
     E = len(prob["e_pose"])

@@ -211,139 +211,8 @@ static void ba_errors(cms_ba* b, int which, int robust, double delta, int slot) 
   hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, b->stream, (const double*)b->d_partial, b->nblk_e, b->d_scal + slot, 0);
 }
 
-// SparseOptimizer::optimize(iterations) with Levenberg; returns iterations done or <0
-static int ba_optimize_stage(cms_ba* b, int iterations, int robust, double delta, const volatile uint8_t* stop,
-                             double* chi_ini, double* chi_fin, double* lam_fin) {
-  hipStream_t s = b->stream;
-  const int n = 6 * b->np;
-  double lambda = -1, ni = 2;
-  int nBad = 0, done = 0;
-  *chi_ini = *chi_fin = *lam_fin = 0;
-  auto stopped = [&]() { return stop && *stop; };
-  for (int it = 0; it < iterations && !stopped(); ++it) {
-    const int cur = b->cur, nxt = cur ^ 1;
-    ba_errors(b, cur, robust, delta, 0);
-    hipLaunchKernelGGL(k_ba_lin_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_poses[cur],
-                       (const double*)b->d_pts[cur], robust, delta, b->d_Hll, b->d_bl, b->d_Hpl);
-    hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K, BA_POSE_CHUNKS), dim3(256), 0, s, b->d, (const double*)b->d_poses[cur],
-                       (const double*)b->d_pts[cur], robust, delta, b->d_pose_partial);
-    if (b->np > 0)
-      hipLaunchKernelGGL(k_ba_pose_finish, dim3(b->np), dim3(64), 0, s, b->np, (const double*)b->d_pose_partial, b->d_Hpp, b->d_bp);
-    if (it == 0) {
-      HIPCHK(hipMemsetAsync(b->d_scal + 3, 0, sizeof(double), s));
-      hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, s, b->np, b->P, (const double*)b->d_Hpp, (const double*)b->d_Hll, b->d_scal + 3);
-    }
-    double* h = b->h_pin;
-    HIPCHK(hipMemcpyAsync(h, b->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    double currentChi = h[0];
-    const double iniChi = currentChi;
-    if (it == 0) { *chi_ini = iniChi; lambda = 1e-5 * h[3]; ni = 2; nBad = 0; }
-    double rho = 0;
-    int qmax = 0;
-    do {
-      if (b->solve_blk) {
-        // fused trial (cms_ba_fused.hip): 5 launches, no reduced matrix in memory
-        hipLaunchKernelGGL(k_ba_dinv, dim3((b->P + 255) / 256), dim3(256), 0, s, b->P, (const double*)b->d_Hll, (const double*)b->d_bl, lambda,
-                           b->d_Dinv, b->d_db);
-        if (b->npairs > 0)
-          hipLaunchKernelGGL(k_ba_schur_chunks, dim3(b->nchunks), dim3(256), 0, s, b->d, (const int2*)b->d_chunk_range, (const int2*)b->d_tup,
-                             (const double*)b->d_Hpl, (const double*)b->d_Dinv, (const double*)b->d_db, b->d_chunk_sum);
-        hipLaunchKernelGGL(k_ba_trial_solve, dim3(1), dim3(384), b->blk_lds, s, b->d, (const double*)b->d_Hpp, (const double*)b->d_bp, lambda,
-                           (const int*)b->d_pair_of_block, (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum,
-                           (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_x, b->d_scal);
-        hipLaunchKernelGGL(k_ba_trial_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
-                           (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt],
-                           (const double*)b->d_poses[nxt], robust, delta, b->d_partial);
-        hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal);
-      } else {
-      if (n > 0) {
-        hipLaunchKernelGGL(k_ba_schur_init, dim3(std::min((n * n + 255) / 256, 256)), dim3(256), 0, s, b->np, (const double*)b->d_Hpp,
-                           (const double*)b->d_bp, lambda, b->d_Hs, b->d_bs);
-      }
-      hipLaunchKernelGGL(k_ba_dinv, dim3((b->P + 255) / 256), dim3(256), 0, s, b->P, (const double*)b->d_Hll, (const double*)b->d_bl, lambda,
-                         b->d_Dinv, b->d_db);
-      if (b->npairs > 0) {
-        hipLaunchKernelGGL(k_ba_schur_chunks, dim3(b->nchunks), dim3(256), 0, s, b->d, (const int2*)b->d_chunk_range, (const int2*)b->d_tup,
-                           (const double*)b->d_Hpl, (const double*)b->d_Dinv, (const double*)b->d_db, b->d_chunk_sum);
-        hipLaunchKernelGGL(k_ba_schur_finish, dim3(b->npairs), dim3(64), 0, s, b->np, (const int*)b->d_pair_s1, (const int*)b->d_pair_s2,
-                           (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum, b->d_Hs, b->d_bs);
-      }
-      if (b->solve_blk)
-        hipLaunchKernelGGL(k_ba_solve_blk, dim3(1), dim3(384), b->blk_lds, s, b->np, (const double*)b->d_Hs, (const double*)b->d_bs, b->d_x, b->d_status);
-      else if (b->solve_in_lds)
-        hipLaunchKernelGGL(k_ba_solve_r192, dim3(1), dim3(512), b->solve_lds, s, n, (const double*)b->d_Hs, (const double*)b->d_bs, b->d_x, b->d_status);
-      else
-        hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), 0, s, n, b->d_Hs, b->d_bs, b->d_x, b->d_Dg, b->d_status);
-      hipLaunchKernelGGL(k_ba_backsub, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
-                         (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt], b->d_partial);
-      hipLaunchKernelGGL(k_ba_update_poses, dim3(1), dim3(64), 0, s, b->d, (const double*)b->d_x, (const double*)b->d_bp, lambda,
-                         (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_scal + 2);
-      hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal + 2, 1);
-      ba_errors(b, nxt, robust, delta, 1);
-      }
-      double* t = b->h_pin;
-      HIPCHK(hipMemcpyAsync(t, b->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      int ok2 = 0;
-      memcpy(&ok2, &t[4], sizeof(int));
-      double tempChi = t[1];
-      if (!ok2) tempChi = DBL_MAX;
-      rho = (currentChi - tempChi);
-      const double scale = t[2] + 1e-3;
-      rho /= scale;
-      if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
-        alpha = std::min(alpha, 2. / 3.);
-        lambda *= std::max(1. / 3., alpha);
-        ni = 2; currentChi = tempChi;
-        b->cur = nxt;   // discardTop(): the trial state becomes the estimate
-      } else {
-        lambda *= ni; ni *= 2;   // pop(): keep the old estimate; stored edge errors stay those of the rejected trial (as in g2o)
-      }
-      ++qmax;
-    } while (rho < 0 && qmax < 10 && !stopped());
-    ++done;
-    *chi_fin = currentChi; *lam_fin = lambda;
-    if (qmax == 10 || rho == 0) break;
-    if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
-    if (nBad >= 3) break;
-    // the accepted state is in b->cur; if the last trial was rejected the next iteration re-evaluates from b->cur
-  }
-  HIPCHK(hipGetLastError());
-  return done;
-}
-
-extern "C" int cms_ba_optimize(cms_ba* b, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* st) {
-  if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
-  cms_ba_stats dummy;
-  if (!st) st = &dummy;
-  memset(st, 0, sizeof(*st));
-  HIPCHK(hipSetDevice(b->device));
-  if (stop && *stop) return 1;   // Optimizer.cpp:359-361
-  const double delta = std::sqrt(5.991);
-  int rc = ba_optimize_stage(b, its_robust, 1, delta, stop, &st->chi2_initial[0], &st->chi2_final[0], &st->lambda_final[0]);
-  if (rc < 0) return rc;
-  st->iterations_done[0] = rc;
-  hipStream_t s = b->stream;
-  std::vector<uint8_t> flags(b->E);
-  if (!(stop && *stop)) {
-    hipLaunchKernelGGL(k_ba_classify, dim3(b->nblk_e), dim3(256), 0, s, b->d, (const double*)b->d_poses[b->cur],
-                       (const double*)b->d_pts[b->cur], 5.991, 1, b->d_flags);
-    HIPCHK(hipMemcpyAsync(flags.data(), b->d_flags, b->E, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    for (int e = 0; e < b->E; ++e) st->n_outliers_mid += flags[e];
-    rc = ba_optimize_stage(b, its_final, 0, delta, stop, &st->chi2_initial[1], &st->chi2_final[1], &st->lambda_final[1]);
-    if (rc < 0) return rc;
-    st->iterations_done[1] = rc;
-  }
-  hipLaunchKernelGGL(k_ba_classify, dim3(b->nblk_e), dim3(256), 0, s, b->d, (const double*)b->d_poses[b->cur],
-                     (const double*)b->d_pts[b->cur], 5.991, 0, b->d_flags);
-  HIPCHK(hipMemcpyAsync(flags.data(), b->d_flags, b->E, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  for (int e = 0; e < b->E; ++e) st->n_outliers_final += flags[e];
-  return CMS_OK;
-}
+// Levenberg-Marquardt driver (lock-step over one or many windows)
+#include "cms_api_ba_lm.hip"
 
 extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* outlier_flags) {
   if (!b) return cms_fail(CMS_ERR_ARG, "null ba");

@@ -1,0 +1,200 @@
+// cms_api_ba_lm.hip -- Levenberg-Marquardt driver of the device-resident local BA, included by cms_api_ba.hip.
+//
+// Control flow restated from OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164),
+// SparseOptimizer::optimize (sparse_optimizer.cpp:354-419) and the two-stage schedule of
+// Optimizer::LocalBundleAdjustment (Optimizer.cpp:359-412), as a resumable per-window state machine: one host thread
+// advances any number of windows in lock-step (every round it enqueues the next step of every unfinished window on
+// that window's own HIP stream, then collects the few scalars each step returns).  Windows of different streams thus
+// overlap on the device without competing host threads; a single window is just the n = 1 case.
+
+struct BaLm {
+  int iterations = 0, robust = 0;
+  double delta = 0;
+  int it = 0, qmax = 0, nBad = 0, done = 0, next = 0;   // next: 0 = start an iteration, 1 = one more trial, 2 = finished
+  double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, rho = 0;
+  double chi_ini = 0, chi_fin = 0, lam_fin = 0;
+};
+
+static bool ba_stopped(const volatile uint8_t* stop) { return stop && *stop; }
+
+// computeActiveErrors + activeRobustChi2 + buildSystem (+ computeLambdaInit on the first iteration); scalars -> h_pin
+static int ba_enqueue_iter_start(cms_ba* b, const BaLm& st) {
+  hipStream_t s = b->stream;
+  const int cur = b->cur;
+  ba_errors(b, cur, st.robust, st.delta, 0);
+  hipLaunchKernelGGL(k_ba_lin_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_poses[cur],
+                     (const double*)b->d_pts[cur], st.robust, st.delta, b->d_Hll, b->d_bl, b->d_Hpl);
+  hipLaunchKernelGGL(k_ba_lin_poses, dim3(b->K, BA_POSE_CHUNKS), dim3(256), 0, s, b->d, (const double*)b->d_poses[cur],
+                     (const double*)b->d_pts[cur], st.robust, st.delta, b->d_pose_partial);
+  if (b->np > 0)
+    hipLaunchKernelGGL(k_ba_pose_finish, dim3(b->np), dim3(64), 0, s, b->np, (const double*)b->d_pose_partial, b->d_Hpp, b->d_bp);
+  if (st.it == 0) {
+    HIPCHK(hipMemsetAsync(b->d_scal + 3, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_ba_maxdiag, dim3(64), dim3(256), 0, s, b->np, b->P, (const double*)b->d_Hpp, (const double*)b->d_Hll, b->d_scal + 3);
+  }
+  HIPCHK(hipMemcpyAsync(b->h_pin, b->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  return CMS_OK;
+}
+static void ba_finish_iter_start(cms_ba* b, BaLm& st) {
+  st.currentChi = b->h_pin[0];
+  st.iniChi = st.currentChi;
+  if (st.it == 0) { st.chi_ini = st.iniChi; st.lambda = 1e-5 * b->h_pin[3]; st.ni = 2; st.nBad = 0; }
+  st.rho = 0; st.qmax = 0;
+  st.next = 1;
+}
+
+// one Levenberg trial: setLambda + Schur solve + update + computeActiveErrors at the trial state; scalars -> h_pin
+static int ba_enqueue_trial(cms_ba* b, const BaLm& st) {
+  hipStream_t s = b->stream;
+  const int cur = b->cur, nxt = cur ^ 1, n = 6 * b->np;
+  const double lambda = st.lambda;
+  if (b->solve_blk) {
+    // fused trial (cms_ba_fused.hip): 5 launches, no reduced matrix in memory
+    hipLaunchKernelGGL(k_ba_dinv, dim3((b->P + 255) / 256), dim3(256), 0, s, b->P, (const double*)b->d_Hll, (const double*)b->d_bl, lambda,
+                       b->d_Dinv, b->d_db);
+    if (b->npairs > 0)
+      hipLaunchKernelGGL(k_ba_schur_chunks, dim3(b->nchunks), dim3(256), 0, s, b->d, (const int2*)b->d_chunk_range, (const int2*)b->d_tup,
+                         (const double*)b->d_Hpl, (const double*)b->d_Dinv, (const double*)b->d_db, b->d_chunk_sum);
+    hipLaunchKernelGGL(k_ba_trial_solve, dim3(1), dim3(384), b->blk_lds, s, b->d, (const double*)b->d_Hpp, (const double*)b->d_bp, lambda,
+                       (const int*)b->d_pair_of_block, (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum,
+                       (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_x, b->d_scal);
+    hipLaunchKernelGGL(k_ba_trial_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
+                       (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt],
+                       (const double*)b->d_poses[nxt], st.robust, st.delta, b->d_partial);
+    hipLaunchKernelGGL(k_ba_reduce2, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal);
+  } else {
+    // larger windows: reduced matrix in global memory, scalar LDL^T
+    if (n > 0)
+      hipLaunchKernelGGL(k_ba_schur_init, dim3(std::min((n * n + 255) / 256, 256)), dim3(256), 0, s, b->np, (const double*)b->d_Hpp,
+                         (const double*)b->d_bp, lambda, b->d_Hs, b->d_bs);
+    hipLaunchKernelGGL(k_ba_dinv, dim3((b->P + 255) / 256), dim3(256), 0, s, b->P, (const double*)b->d_Hll, (const double*)b->d_bl, lambda,
+                       b->d_Dinv, b->d_db);
+    if (b->npairs > 0) {
+      hipLaunchKernelGGL(k_ba_schur_chunks, dim3(b->nchunks), dim3(256), 0, s, b->d, (const int2*)b->d_chunk_range, (const int2*)b->d_tup,
+                         (const double*)b->d_Hpl, (const double*)b->d_Dinv, (const double*)b->d_db, b->d_chunk_sum);
+      hipLaunchKernelGGL(k_ba_schur_finish, dim3(b->npairs), dim3(64), 0, s, b->np, (const int*)b->d_pair_s1, (const int*)b->d_pair_s2,
+                         (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum, b->d_Hs, b->d_bs);
+    }
+    if (b->solve_in_lds)
+      hipLaunchKernelGGL(k_ba_solve_r192, dim3(1), dim3(512), b->solve_lds, s, n, (const double*)b->d_Hs, (const double*)b->d_bs, b->d_x, b->d_status);
+    else
+      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(256), 0, s, n, b->d_Hs, b->d_bs, b->d_x, b->d_Dg, b->d_status);
+    hipLaunchKernelGGL(k_ba_backsub, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
+                       (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt], b->d_partial);
+    hipLaunchKernelGGL(k_ba_update_poses, dim3(1), dim3(64), 0, s, b->d, (const double*)b->d_x, (const double*)b->d_bp, lambda,
+                       (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_scal + 2);
+    hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, (const double*)b->d_partial, b->nblk_p, b->d_scal + 2, 1);
+    ba_errors(b, nxt, st.robust, st.delta, 1);
+  }
+  HIPCHK(hipMemcpyAsync(b->h_pin, b->d_scal, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+  return CMS_OK;
+}
+static void ba_finish_trial(cms_ba* b, BaLm& st, const volatile uint8_t* stop) {
+  const double* t = b->h_pin;
+  int ok2 = 0;
+  memcpy(&ok2, &t[4], sizeof(int));
+  double tempChi = t[1];
+  if (!ok2) tempChi = DBL_MAX;
+  st.rho = (st.currentChi - tempChi);
+  const double scale = t[2] + 1e-3;
+  st.rho /= scale;
+  if (st.rho > 0 && std::isfinite(tempChi)) {
+    double alpha = 1. - std::pow((2 * st.rho - 1), 3);
+    alpha = std::min(alpha, 2. / 3.);
+    st.lambda *= std::max(1. / 3., alpha);
+    st.ni = 2; st.currentChi = tempChi;
+    b->cur ^= 1;   // discardTop(): the trial state becomes the estimate
+  } else {
+    st.lambda *= st.ni; st.ni *= 2;   // pop(): old estimate kept; stored edge errors stay those of the rejected trial (as in g2o)
+  }
+  ++st.qmax;
+  if (st.rho < 0 && st.qmax < 10 && !ba_stopped(stop)) { st.next = 1; return; }   // do { } while (rho<0 && qmax<max && !terminate())
+  ++st.done;
+  st.chi_fin = st.currentChi; st.lam_fin = st.lambda;
+  bool terminate = (st.qmax == 10 || st.rho == 0);
+  if (!terminate) {
+    if ((st.iniChi - st.currentChi) * 1e3 < st.iniChi) ++st.nBad; else st.nBad = 0;
+    if (st.nBad >= 3) terminate = true;
+  }
+  ++st.it;
+  st.next = (terminate || st.it >= st.iterations || ba_stopped(stop)) ? 2 : 0;
+}
+
+// SparseOptimizer::optimize(iterations) for every window, in lock-step
+static int ba_optimize_stage_many(cms_ba** bas, int n, std::vector<BaLm>& st, const volatile uint8_t* stop) {
+  std::vector<int> stepped(n);
+  for (;;) {
+    int nact = 0;
+    for (int w = 0; w < n; ++w) {
+      stepped[w] = -1;
+      if (st[w].next == 2) continue;
+      if (st[w].next == 0 && (st[w].it >= st[w].iterations || ba_stopped(stop))) { st[w].next = 2; continue; }
+      HIPCHK(hipSetDevice(bas[w]->device));
+      const int rc = st[w].next == 0 ? ba_enqueue_iter_start(bas[w], st[w]) : ba_enqueue_trial(bas[w], st[w]);
+      if (rc) return rc;
+      stepped[w] = st[w].next;
+      ++nact;
+    }
+    if (nact == 0) break;
+    for (int w = 0; w < n; ++w) {
+      if (stepped[w] < 0) continue;
+      HIPCHK(hipStreamSynchronize(bas[w]->stream));
+      if (stepped[w] == 0) ba_finish_iter_start(bas[w], st[w]);
+      else ba_finish_trial(bas[w], st[w], stop);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+
+extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats) {
+  if (!bas || n < 1) return cms_fail(CMS_ERR_ARG, "cms_ba_optimize_many: bad argument");
+  for (int w = 0; w < n; ++w) if (!bas[w]) return cms_fail(CMS_ERR_ARG, "null ba");
+  std::vector<cms_ba_stats> local(n);
+  for (int w = 0; w < n; ++w) memset(&local[w], 0, sizeof(cms_ba_stats));
+  if (ba_stopped(stop)) { if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats)); return 1; }   // Optimizer.cpp:359-361
+  const double delta = std::sqrt(5.991);
+  std::vector<BaLm> st(n);
+  for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_robust; st[w].robust = 1; st[w].delta = delta; }
+  int rc = ba_optimize_stage_many(bas, n, st, stop);
+  if (rc) return rc;
+  for (int w = 0; w < n; ++w) {
+    local[w].iterations_done[0] = st[w].done; local[w].chi2_initial[0] = st[w].chi_ini; local[w].chi2_final[0] = st[w].chi_fin;
+    local[w].lambda_final[0] = st[w].lam_fin;
+  }
+  std::vector<std::vector<uint8_t>> flags(n);
+  auto classify = [&](int set_level) -> int {
+    for (int w = 0; w < n; ++w) {
+      cms_ba* b = bas[w];
+      HIPCHK(hipSetDevice(b->device));
+      flags[w].resize(b->E);
+      hipLaunchKernelGGL(k_ba_classify, dim3(b->nblk_e), dim3(256), 0, b->stream, b->d, (const double*)b->d_poses[b->cur],
+                         (const double*)b->d_pts[b->cur], 5.991, set_level, b->d_flags);
+      HIPCHK(hipMemcpyAsync(flags[w].data(), b->d_flags, b->E, hipMemcpyDeviceToHost, b->stream));
+    }
+    for (int w = 0; w < n; ++w) HIPCHK(hipStreamSynchronize(bas[w]->stream));
+    return CMS_OK;
+  };
+  if (!ba_stopped(stop)) {   // Optimizer.cpp:366-397: exclude outliers, drop the kernel, optimize(10)
+    rc = classify(1);
+    if (rc) return rc;
+    for (int w = 0; w < n; ++w) for (int e = 0; e < bas[w]->E; ++e) local[w].n_outliers_mid += flags[w][e];
+    for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_final; st[w].robust = 0; st[w].delta = delta; }
+    rc = ba_optimize_stage_many(bas, n, st, stop);
+    if (rc) return rc;
+    for (int w = 0; w < n; ++w) {
+      local[w].iterations_done[1] = st[w].done; local[w].chi2_initial[1] = st[w].chi_ini; local[w].chi2_final[1] = st[w].chi_fin;
+      local[w].lambda_final[1] = st[w].lam_fin;
+    }
+  }
+  rc = classify(0);          // Optimizer.cpp:399-412
+  if (rc) return rc;
+  for (int w = 0; w < n; ++w) for (int e = 0; e < bas[w]->E; ++e) local[w].n_outliers_final += flags[w][e];
+  if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats));
+  return CMS_OK;
+}
+
+extern "C" int cms_ba_optimize(cms_ba* b, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* st) {
+  if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
+  return cms_ba_optimize_many(&b, 1, its_robust, its_final, stop, st);
+}

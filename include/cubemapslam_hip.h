@@ -140,6 +140,9 @@ int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const ui
                   const int8_t* e_face, double fx, double fy, double cx, double cy);
 int cms_ba_reset(cms_ba* ba);  /* restore the initial estimate on the device (benchmark loops) */
 int cms_ba_optimize(cms_ba* ba, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats);
+/* n independent windows (e.g. the LocalMapping threads of n camera streams) advanced in lock-step by ONE host thread, each on
+ * its own stream: same results as n cms_ba_optimize calls, without n host threads competing for the HIP runtime. stats[n]. */
+int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats);
 int cms_ba_read(cms_ba* ba, double* poses, double* points, uint8_t* outlier_flags);
 void* cms_ba_stream(cms_ba* ba);
 void cms_ba_destroy(cms_ba* ba);

@@ -229,6 +229,21 @@ def test_ba_run_larger_windows_all_solver_paths():
     _ba_compare(synth.ba_problem(K=40, P=2500, obs_per_point=6, F=550, seed=4))
 
 
+def test_ba_optimize_many_lockstep_equals_individual_runs():
+    """cms_ba_optimize_many: two different windows advanced in lock-step give what two separate runs give."""
+    probs = [synth.ba_problem(K=6, P=400, obs_per_point=4, F=650, seed=9), synth.ba_problem(K=9, P=700, obs_per_point=5, F=550, seed=13)]
+    bas = [api.BundleAdjuster(p) for p in probs]
+    rc, stats = api.ba_optimize_many(bas)
+    assert rc == 0
+    for ba, p, st in zip(bas, probs, stats):
+        poses, pts, flags = ba.read()
+        w = orc.ba_run(p)
+        assert list(st.iterations_done) == list(w["stats"].iterations_done)
+        assert np.abs((pts - p["points"]) - (w["points"] - p["points"])).max() <= 1e-4 * np.abs(w["points"] - p["points"]).max()
+        assert np.array_equal(flags, w["outliers"])
+        ba.close()
+
+
 def test_ba_run_config4_full_size():
     """BASELINE.json configs[3]: 20 keyframes x 4000 edges (E = 80 000, P = 20 000), 1e-4 vs the CPU path."""
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=650, seed=42)
