@@ -180,19 +180,26 @@ def main():
         "fast": sumP,                                                                # every pyramid pixel read once
         "describe": nkp * (43 * 43 + 32 + 24),                                       # raw patch + descriptor + key-point record
     }
-    dom = max(("remap", "pyramid", "fast", "describe", "octree", "cull"), key=lambda k: stage_ms.get(k, 0.0))
+    # dominant kernel of the extraction path = the one with the longest average launch (k_resize is 7 short launches)
+    nl = {"pyramid": g.nlevels - 1}
+    per_launch = {k: stage_ms.get(k, 0.0) / nl.get(k, 1) for k in ("remap", "pyramid", "fast", "describe")}
+    dom = max(per_launch, key=per_launch.get)
+    kname = {"remap": "k_remap", "pyramid": "k_resize", "fast": "k_fast_cells", "describe": "k_describe"}[dom]
     peak = 8000.0
-    roof = None
-    if dom in alg and stage_ms.get(dom, 0) > 0:
-        launches = 7 if dom == "pyramid" else 1
-        ach = alg[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
-        roof = {"kernel": {"remap": "k_remap", "pyramid": "k_resize (7 launches)", "fast": "k_fast_cells", "describe": "k_describe"}[dom],
-                "bound": "hbm", "achieved": round(ach, 1), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4),
-                "traffic": None, "ms_per_launch": round(stage_ms[dom] / launches, 4),
-                "algorithmic_bytes_per_launch": int(alg[dom] * B / launches)}
-    else:
-        roof = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": peak, "unit": "GB/s", "frac": None, "traffic": None,
-                "ms_per_launch": round(stage_ms.get(dom, 0.0), 4)}
+    launches = nl.get(dom, 1)
+    ach = alg[dom] * B / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms.get(dom, 0) > 0 else None
+    # measured HBM traffic of that kernel: committed rocprofv3 PMC pass (FETCH_SIZE and WRITE_SIZE collected in separate runs,
+    # tools/run_profiles.sh), valid for the default workload only (B = 32, F = 550)
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if os.path.exists(pj) and B == 32 and F == 550:
+        kk = json.load(open(pj))["kernels"].get(kname)
+        if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
+            traffic = int((kk["FETCH_SIZE"]["per_dispatch"] + kk["WRITE_SIZE"]["per_dispatch"]) * 1024)
+    roof = {"kernel": kname, "bound": "hbm", "achieved": None if ach is None else round(ach, 1), "peak": peak, "unit": "GB/s",
+            "frac": None if ach is None else round(ach / peak, 4), "traffic": traffic,
+            "ms_per_launch": round(stage_ms.get(dom, 0.0) / launches, 4), "algorithmic_bytes_per_launch": int(alg[dom] * B / launches),
+            "all_stages_GBps": {k: round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in alg if stage_ms.get(k, 0) > 0}}
     fast_gbs = alg["fast"] * B / (stage_ms["fast"] * 1e-3) / 1e9 if stage_ms.get("fast", 0) > 0 else None
 
     # ---- CPU baseline: the oracle, single thread, on a bounded sample of the same workload (rank 0, N=1 only)

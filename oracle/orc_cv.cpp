@@ -154,19 +154,26 @@ void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* 
     sum = 1. / sum;
     for (int i = 0; i < 7; ++i) k[i] = orc_cv_round((double)((float)(cf[i] * sum)) * 256.0);
   }
+  // row pass into an int buffer (source row copied once into a REFLECT_101-padded line so the inner loop is branch free
+  // and vectorisable -- the CPU baseline should not be slower than it has to be), then the column pass over row pointers
   std::vector<int> tmp((size_t)w * h);
-  for (int y = 0; y < h; ++y)
+  std::vector<uint8_t> line((size_t)w + 6);
+  for (int y = 0; y < h; ++y) {
+    for (int x = -3; x < w + 3; ++x) line[x + 3] = src[(size_t)y * sstride + reflect101(x, w)];
+    int* trow = &tmp[(size_t)y * w];
+    const uint8_t* p = line.data();
+    for (int x = 0; x < w; ++x)
+      trow[x] = k[0] * p[x] + k[1] * p[x + 1] + k[2] * p[x + 2] + k[3] * p[x + 3] + k[4] * p[x + 4] + k[5] * p[x + 5] + k[6] * p[x + 6];
+  }
+  for (int y = 0; y < h; ++y) {
+    const int* r[7];
+    for (int t = -3; t <= 3; ++t) r[t + 3] = &tmp[(size_t)reflect101(y + t, h) * w];
+    uint8_t* drow = dst + (size_t)y * dstride;
     for (int x = 0; x < w; ++x) {
-      int s = 0;
-      for (int t = -3; t <= 3; ++t) s += k[t + 3] * src[(size_t)y * sstride + reflect101(x + t, w)];
-      tmp[(size_t)y * w + x] = s;
+      const int s = k[0] * r[0][x] + k[1] * r[1][x] + k[2] * r[2][x] + k[3] * r[3][x] + k[4] * r[4][x] + k[5] * r[5][x] + k[6] * r[6][x];
+      drow[x] = sat_u8((s + 32768) >> 16);
     }
-  for (int y = 0; y < h; ++y)
-    for (int x = 0; x < w; ++x) {
-      int s = 0;
-      for (int t = -3; t <= 3; ++t) s += k[t + 3] * tmp[(size_t)reflect101(y + t, h) * w + x];
-      dst[(size_t)y * dstride + x] = sat_u8((s + 32768) >> 16);
-    }
+  }
 }
 
 // cv::FAST(img, kps, threshold, true) == FAST_t<16>: literal restatement incl. the 3-row score ring buffer
@@ -215,8 +222,10 @@ int orc_fast(const uint8_t* img, int w, int h, int stride, int threshold, int* o
   threshold = std::min(std::max(threshold, 0), 255);
   uint8_t tab[512];
   for (int i = -255; i <= 255; ++i) tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
-  std::vector<uint8_t> sbuf((size_t)3 * w, 0);
-  std::vector<int> cbuf((size_t)3 * (w + 1), 0);
+  static thread_local std::vector<uint8_t> sbuf;   // reused across the thousands of per-cell calls of one frame
+  static thread_local std::vector<int> cbuf;
+  sbuf.assign((size_t)3 * w, 0);
+  cbuf.assign((size_t)3 * (w + 1), 0);
   uint8_t* buf[3] = {sbuf.data(), sbuf.data() + w, sbuf.data() + 2 * w};
   int* cpbuf[3] = {cbuf.data() + 1, cbuf.data() + (w + 1) + 1, cbuf.data() + 2 * (w + 1) + 1};
   int n = 0;
