@@ -27,6 +27,11 @@ import time
 
 import numpy as np
 
+# The frame path and every local-BA window run on their own HIP stream; the ROCm runtime multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), which serialises the BA windows behind each other.  Must be set before the
+# HIP runtime initialises (measured: 4 -> 8 queues = +28 % frames/s with 4 concurrent windows).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -116,19 +121,21 @@ def main():
 
     n_ba = max(1, B // args.ba_every)
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + rank)
-    # one BA handle (own HIP stream) + one LocalMapping-like host thread per window, concurrent with the frame path
+    # the local-BA windows of this step are independent LM problems: one host thread (LocalMapping-like) drives them as a batch,
+    # concurrent with the frame path on its own stream
     bas = [api.BundleAdjuster(prob, device=local_rank) for _ in range(n_ba)]
     ba_err = []
 
-    def ba_worker(ba):
+    def ba_worker():
         try:
-            ba.reset()
-            ba.optimize((5, 10))
+            for ba in bas:
+                ba.reset()
+            api.ba_optimize_many(bas, (5, 10))   # all windows share every launch (kb_ba_* kernels, one window per blockIdx.z)
         except Exception as e:  # surfaced after join
             ba_err.append(e)
 
     def step(i):
-        ths = [threading.Thread(target=ba_worker, args=(ba,)) for ba in bas]
+        ths = [threading.Thread(target=ba_worker)]
         for th in ths:
             th.start()
         ctx.process(B, True)

@@ -29,6 +29,9 @@ struct cms_ba {
   int npairs = 0, nchunks = 0; size_t solve_lds = 0, blk_lds = 0; bool solve_in_lds = false, solve_blk = false;
   int cur = 0;
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
+  // group resources (owned by the first window of a cms_ba_optimize_many call, grown on demand)
+  void* grp_items_dev = nullptr; void* grp_items_host = nullptr; double* grp_scal_dev = nullptr; double* grp_scal_host = nullptr;
+  int grp_cap = 0;
   std::vector<void*> allocs;
 };
 
@@ -44,6 +47,10 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   hipSetDevice(b->device);
   for (void* p : b->allocs) hipFree(p);
   if (b->h_pin) hipHostFree(b->h_pin);
+  if (b->grp_items_dev) hipFree(b->grp_items_dev);
+  if (b->grp_scal_dev) hipFree(b->grp_scal_dev);
+  if (b->grp_items_host) hipHostFree(b->grp_items_host);
+  if (b->grp_scal_host) hipHostFree(b->grp_scal_host);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }

@@ -47,8 +47,7 @@ __device__ __forceinline__ void ba_factor_diag(double* a, int J, int tid_blk, do
   for (int r = 0; r < 6; ++r) { ybuf[6 * J + r] = z[r]; idg[6 * J + r] = idl[r]; }
 }
 
-extern "C" __global__ void __launch_bounds__(384)
-k_ba_trial_solve(BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
+__device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
                  double* __restrict__ xp_out, double* __restrict__ scal) {
@@ -251,12 +250,11 @@ k_ba_trial_solve(BaDev d, const double* __restrict__ Hpp, const double* __restri
 
 // per point: x_l = Dinv (b_l - sum B^T x_p), X_new = X + x_l, gain-denominator partial; then residuals + robust chi2 of the
 // point's edges at the trial state.  partial[blk] = chi2 sum, partial[nblk + blk] = denominator sum.
-extern "C" __global__ void __launch_bounds__(128)
-k_ba_trial_points(BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+__device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                   const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
                   const double* __restrict__ poses_new, int robust, double delta, double* __restrict__ partial) {
   __shared__ double sh[4];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = BX * blockDim.x + threadIdx.x;
   double sc = 0, chi = 0;
   if (p < d.P) {
     const int e0 = d.pt_off[p], e1 = d.pt_off[p + 1];
@@ -293,12 +291,11 @@ k_ba_trial_points(BaDev d, const double* __restrict__ bl, const double* __restri
   }
   const double s1 = block_sum(chi, sh);
   const double s2 = block_sum(sc, sh);
-  if (threadIdx.x == 0) { partial[blockIdx.x] = s1; partial[gridDim.x + blockIdx.x] = s2; }
+  if (threadIdx.x == 0) { partial[BX] = s1; partial[GX + BX] = s2; }
 }
 
 // scal[1] = sum(partial[0..n)), scal[2] = sum(partial[n..2n)) + scal[5]
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_reduce2(const double* __restrict__ partial, int n, double* __restrict__ scal) {
+__device__ __forceinline__ void ba_reduce2_body(int BX, int GX, const double* __restrict__ partial, int n, double* __restrict__ scal) {
   __shared__ double sh[4];
   double v1 = 0, v2 = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) { v1 += partial[i]; v2 += partial[n + i]; }

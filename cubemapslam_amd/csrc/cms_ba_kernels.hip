@@ -108,11 +108,10 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 }
 
 // ---- residuals + robust chi2 partial sums (one partial per workgroup, reduced in fixed order by k_ba_reduce)
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_errors(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+__device__ __forceinline__ void ba_errors_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
             double* __restrict__ partial) {
   __shared__ double sh[4];
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = BX * blockDim.x + threadIdx.x;
   double rho0 = 0;
   if (e < d.E && d.level[e] == 0) {
     const double* pose = poses + 7 * d.e_pose[e];
@@ -125,10 +124,9 @@ k_ba_errors(BaDev d, const double* __restrict__ poses, const double* __restrict_
     if (robust) huber_w(c2, delta, &rho0); else rho0 = c2;
   }
   const double s = block_sum(rho0, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) partial[BX] = s;
 }
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_reduce(const double* __restrict__ partial, int n, double* __restrict__ out, int add) {
+__device__ __forceinline__ void ba_reduce_body(int BX, int GX, const double* __restrict__ partial, int n, double* __restrict__ out, int add) {
   __shared__ double sh[4];
   double v = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
@@ -137,10 +135,9 @@ k_ba_reduce(const double* __restrict__ partial, int n, double* __restrict__ out,
 }
 
 // ---- per-point blocks: Hll (3x3), bl, Hpl per edge (6x3); one thread per point over its (point-sorted) edges
-extern "C" __global__ void __launch_bounds__(128)
-k_ba_lin_points(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+__device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
                 double* __restrict__ Hll, double* __restrict__ bl, double* __restrict__ Hpl) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = BX * blockDim.x + threadIdx.x;
   if (p >= d.P) return;
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   for (int e = d.pt_off[p]; e < d.pt_off[p + 1]; ++e) {
@@ -172,11 +169,10 @@ k_ba_lin_points(BaDev d, const double* __restrict__ poses, const double* __restr
 // grid (K, BA_POSE_CHUNKS): every workgroup reduces one slice of the list into 27 partial sums (21 unique Hpp + 6 bp),
 // k_ba_pose_finish adds the slices in fixed order (deterministic, no atomics).
 #define BA_POSE_CHUNKS 8
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_lin_poses(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+__device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
                double* __restrict__ pose_partial) {
   __shared__ double sh[4][27];
-  const int k = blockIdx.x, ch = blockIdx.y;
+  const int k = BX, ch = blockIdx.y;
   const int slot = d.pose_slot[k];
   if (slot < 0) return;
   const double* pose = poses + 7 * k;
@@ -212,9 +208,8 @@ k_ba_lin_poses(BaDev d, const double* __restrict__ poses, const double* __restri
     pose_partial[((size_t)slot * BA_POSE_CHUNKS + ch) * 27 + threadIdx.x] =
         sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
-extern "C" __global__ void __launch_bounds__(64)
-k_ba_pose_finish(int np, const double* __restrict__ pose_partial, double* __restrict__ Hpp, double* __restrict__ bp) {
-  const int slot = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void ba_pose_finish_body(int BX, int GX, int np, const double* __restrict__ pose_partial, double* __restrict__ Hpp, double* __restrict__ bp) {
+  const int slot = BX, t = threadIdx.x;
   if (slot >= np || t >= 27) return;
   double s = 0;
   for (int ch = 0; ch < BA_POSE_CHUNKS; ++ch) s += pose_partial[((size_t)slot * BA_POSE_CHUNKS + ch) * 27 + t];
@@ -230,10 +225,9 @@ k_ba_pose_finish(int np, const double* __restrict__ pose_partial, double* __rest
 
 // ---- max |diag| of the assembled system (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180).
 // Non-negative doubles order like their bit patterns, so the cross-workgroup maximum is one u64 atomicMax (*out zeroed first).
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_maxdiag(int np, int P, const double* __restrict__ Hpp, const double* __restrict__ Hll, double* __restrict__ out) {
+__device__ __forceinline__ void ba_maxdiag_body(int BX, int GX, int np, int P, const double* __restrict__ Hpp, const double* __restrict__ Hll, double* __restrict__ out) {
   double m = 0;
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+  const int gid = BX * blockDim.x + threadIdx.x, gs = GX * blockDim.x;
   for (int i = gid; i < 6 * np; i += gs) m = fmax(m, fabs(Hpp[36 * (i / 6) + 7 * (i % 6)]));
   for (int i = gid; i < 3 * P; i += gs) m = fmax(m, fabs(Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
@@ -262,10 +256,9 @@ __device__ __forceinline__ void inv3(const double* A, double* Ai) {
   Ai[6] = (d * h - e * g) * id; Ai[7] = (b * g - a * h) * id; Ai[8] = (a * e - b * d) * id;
 }
 // per point: Dinv = (Hll + lambda I)^-1 and db = Dinv * bl
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_dinv(int P, const double* __restrict__ Hll, const double* __restrict__ bl, double lambda, double* __restrict__ Dinv,
+__device__ __forceinline__ void ba_dinv_body(int BX, int GX, int P, const double* __restrict__ Hll, const double* __restrict__ bl, double lambda, double* __restrict__ Dinv,
           double* __restrict__ db) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = BX * blockDim.x + threadIdx.x;
   if (p >= P) return;
   double D[9], Di[9];
   for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
@@ -294,11 +287,10 @@ __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, 
     out[i] = keep + __shfl_xor(send, off);
   }
 }
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_schur_chunks(BaDev d, const int2* __restrict__ chunk_range, const int2* __restrict__ tup, const double* __restrict__ Hpl,
+__device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDev d, const int2* __restrict__ chunk_range, const int2* __restrict__ tup, const double* __restrict__ Hpl,
                   const double* __restrict__ Dinv, const double* __restrict__ db, double* __restrict__ chunk_sum) {
   __shared__ double sh[4][42];
-  const int2 rg = chunk_range[blockIdx.x];
+  const int2 rg = chunk_range[BX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc[42];
 #pragma unroll
@@ -345,7 +337,7 @@ k_ba_schur_chunks(BaDev d, const int2* __restrict__ chunk_range, const int2* __r
   __syncthreads();
   if (threadIdx.x < 42) {
     const int k = threadIdx.x;
-    chunk_sum[(size_t)blockIdx.x * 42 + k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
+    chunk_sum[(size_t)BX * 42 + k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
   }
 }
 extern "C" __global__ void __launch_bounds__(64)
@@ -751,10 +743,9 @@ k_ba_update_poses(BaDev d, const double* __restrict__ xp, const double* __restri
 }
 
 // ---- outlier test of Optimizer.cpp:376-382 / 404-410: chi2 of the STORED error > th or depth <= 0
-extern "C" __global__ void __launch_bounds__(256)
-k_ba_classify(BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, double chi2_th, int set_level,
+__device__ __forceinline__ void ba_classify_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, double chi2_th, int set_level,
               uint8_t* __restrict__ flags) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = BX * blockDim.x + threadIdx.x;
   if (e >= d.E) return;
   const double c2 = d.e_inv[e] * (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]);
   const double* pose = poses + 7 * d.e_pose[e];

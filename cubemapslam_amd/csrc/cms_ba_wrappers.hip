@@ -1,0 +1,127 @@
+// cms_ba_wrappers.hip -- __global__ entry points of the local-BA kernels.
+//
+// Every kernel body lives in cms_ba_kernels.hip / cms_ba_fused.hip as a __device__ function taking its block index (BX)
+// and grid size (GX).  Two thin entry points exist per body:
+//   k_ba_*   one window per launch (explicit arguments)
+//   kb_ba_*  MANY windows per launch: blockIdx.z selects a BaItem (one per window) holding that window's pointers,
+//            lambda and phase; a window whose phase differs from the launch's phase, or whose own grid is smaller than
+//            the launch grid, exits at once.  n independent Levenberg-Marquardt problems then cost the launches (and
+//            host synchronisations) of one, and their small kernels fill the chip together.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct BaItem {
+  BaDev d;
+  const double* poses_cur; const double* pts_cur; double* poses_nxt; double* pts_nxt;
+  double* Hll; double* bl; double* Hpl; double* Hpp; double* bp; double* pose_partial; double* Dinv; double* db;
+  double* chunk_sum; double* x; double* partial; double* scal;
+  const int2* chunk_range; const int2* tup; const int* pair_of_block; const int* pair_chunk_off;
+  uint8_t* flags;
+  int nblk_e, nblk_p, nchunks, first_iter;
+  int robust, phase, set_level, pad;
+  double lambda, delta, chi2_th;
+};
+enum { BA_PHASE_IDLE = 0, BA_PHASE_ITER = 1, BA_PHASE_TRIAL = 2, BA_PHASE_CLASSIFY = 3 };
+
+// ------------------------------------------------------------------------------------------------ one window per launch
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_errors(BaDev d, const double* poses, const double* pts, int robust, double delta, double* partial) {
+  ba_errors_body(blockIdx.x, gridDim.x, d, poses, pts, robust, delta, partial);
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_reduce(const double* partial, int n, double* out, int add) { ba_reduce_body(blockIdx.x, gridDim.x, partial, n, out, add); }
+extern "C" __global__ void __launch_bounds__(128)
+k_ba_lin_points(BaDev d, const double* poses, const double* pts, int robust, double delta, double* Hll, double* bl, double* Hpl) {
+  ba_lin_points_body(blockIdx.x, gridDim.x, d, poses, pts, robust, delta, Hll, bl, Hpl);
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_lin_poses(BaDev d, const double* poses, const double* pts, int robust, double delta, double* pose_partial) {
+  ba_lin_poses_body(blockIdx.x, gridDim.x, d, poses, pts, robust, delta, pose_partial);
+}
+extern "C" __global__ void __launch_bounds__(64)
+k_ba_pose_finish(int np, const double* pose_partial, double* Hpp, double* bp) { ba_pose_finish_body(blockIdx.x, gridDim.x, np, pose_partial, Hpp, bp); }
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_maxdiag(int np, int P, const double* Hpp, const double* Hll, double* out) { ba_maxdiag_body(blockIdx.x, gridDim.x, np, P, Hpp, Hll, out); }
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_dinv(int P, const double* Hll, const double* bl, double lambda, double* Dinv, double* db) {
+  ba_dinv_body(blockIdx.x, gridDim.x, P, Hll, bl, lambda, Dinv, db);
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_schur_chunks(BaDev d, const int2* chunk_range, const int2* tup, const double* Hpl, const double* Dinv, const double* db, double* chunk_sum) {
+  ba_schur_chunks_body(blockIdx.x, gridDim.x, d, chunk_range, tup, Hpl, Dinv, db, chunk_sum);
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_classify(BaDev d, const double* poses, const double* pts, double chi2_th, int set_level, uint8_t* flags) {
+  ba_classify_body(blockIdx.x, gridDim.x, d, poses, pts, chi2_th, set_level, flags);
+}
+extern "C" __global__ void __launch_bounds__(384)
+k_ba_trial_solve(BaDev d, const double* Hpp, const double* bp, double lambda, const int* pair_of_block, const int* pair_chunk_off,
+                 const double* chunk_sum, const double* poses, double* poses_new, double* xp_out, double* scal) {
+  ba_trial_solve_body(blockIdx.x, gridDim.x, d, Hpp, bp, lambda, pair_of_block, pair_chunk_off, chunk_sum, poses, poses_new, xp_out, scal);
+}
+extern "C" __global__ void __launch_bounds__(128)
+k_ba_trial_points(BaDev d, const double* bl, const double* Hpl, const double* Dinv, const double* xp, double lambda, const double* pts,
+                  double* pts_new, const double* poses_new, int robust, double delta, double* partial) {
+  ba_trial_points_body(blockIdx.x, gridDim.x, d, bl, Hpl, Dinv, xp, lambda, pts, pts_new, poses_new, robust, delta, partial);
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_reduce2(const double* partial, int n, double* scal) { ba_reduce2_body(blockIdx.x, gridDim.x, partial, n, scal); }
+
+// ------------------------------------------------------------------------------------------------ many windows per launch
+#define BA_ITEM(PHASE, NBLK)                       \
+  const BaItem& it = items[blockIdx.z];            \
+  if (it.phase != (PHASE) || (int)blockIdx.x >= (NBLK)) return;
+
+extern "C" __global__ void __launch_bounds__(256) kb_ba_errors(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, it.nblk_e)
+  ba_errors_body(blockIdx.x, it.nblk_e, it.d, it.poses_cur, it.pts_cur, it.robust, it.delta, it.partial);
+}
+// chi2 of the current estimate -> scal[0]; also clears the max-diagonal slot before kb_ba_maxdiag accumulates into it
+extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, 1)
+  ba_reduce_body(0, 1, it.partial, it.nblk_e, it.scal, 0);
+  if (threadIdx.x == 0 && it.first_iter) it.scal[3] = 0.0;
+}
+extern "C" __global__ void __launch_bounds__(128) kb_ba_lin_points(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, it.nblk_p)
+  ba_lin_points_body(blockIdx.x, it.nblk_p, it.d, it.poses_cur, it.pts_cur, it.robust, it.delta, it.Hll, it.bl, it.Hpl);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_lin_poses(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, it.d.K)        // blockIdx.y = slice of the pose's edge list
+  ba_lin_poses_body(blockIdx.x, it.d.K, it.d, it.poses_cur, it.pts_cur, it.robust, it.delta, it.pose_partial);
+}
+extern "C" __global__ void __launch_bounds__(64) kb_ba_pose_finish(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, it.d.np)
+  ba_pose_finish_body(blockIdx.x, it.d.np, it.d.np, it.pose_partial, it.Hpp, it.bp);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_maxdiag(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, (int)gridDim.x)
+  if (!it.first_iter) return;
+  ba_maxdiag_body(blockIdx.x, gridDim.x, it.d.np, it.d.P, it.Hpp, it.Hll, it.scal + 3);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_dinv(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, (it.d.P + 255) / 256)
+  ba_dinv_body(blockIdx.x, 0, it.d.P, it.Hll, it.bl, it.lambda, it.Dinv, it.db);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, it.nchunks)
+  ba_schur_chunks_body(blockIdx.x, it.nchunks, it.d, it.chunk_range, it.tup, it.Hpl, it.Dinv, it.db, it.chunk_sum);
+}
+extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, 1)
+  ba_trial_solve_body(0, 1, it.d, it.Hpp, it.bp, it.lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses_cur, it.poses_nxt,
+                      it.x, it.scal);
+}
+extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, it.nblk_p)
+  ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, it.lambda, it.pts_cur, it.pts_nxt, it.poses_nxt, it.robust,
+                       it.delta, it.partial);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, 1)
+  ba_reduce2_body(0, 1, it.partial, it.nblk_p, it.scal);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* __restrict__ items, int phase) {
+  BA_ITEM(phase, it.nblk_e)
+  ba_classify_body(blockIdx.x, it.nblk_e, it.d, it.poses_cur, it.pts_cur, it.chi2_th, it.set_level, it.flags);
+}

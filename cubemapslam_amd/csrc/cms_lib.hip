@@ -4,5 +4,6 @@
 #include "cms_match_kernels.hip"
 #include "cms_ba_kernels.hip"
 #include "cms_ba_fused.hip"
+#include "cms_ba_wrappers.hip"
 #include "cms_api_frames.hip"
 #include "cms_api_ba.hip"
