@@ -204,6 +204,8 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   const int lx0 = ex0 - ax0, lx1 = ex1 - ax0;           // evaluated LDS columns [lx0, lx1)
   const int q0 = lx0 >> 2, nq = ((lx1 - 1) >> 2) - q0 + 1;
   const int qr = lane / nq, qc = lane - qr * nq, qrows = 64 / nq;
+  int colmask = 0;                                      // which of this lane's 4 columns are evaluated (row independent)
+  for (int i = 0; i < 4; ++i) { const int lxi = 4 * (q0 + qc) + i; colmask |= (lxi >= lx0 && lxi < lx1 ? 1 : 0) << i; }
   int L = 0;
   for (int rb = 0; rb < eh; rb += qrows) {
     const int py = rb + qr;
@@ -225,10 +227,10 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
       const int p4 = (int)((wide >> (8 * (i + 3))) & 0xFF);     // x + 3
       const int p12 = (int)((wlow >> (8 * (i + 1))) & 0xFF);    // x - 3
       const int p0 = (dn >> (8 * i)) & 0xFF, p8 = (up >> (8 * i)) & 0xFF;
-      const int d0 = v - p0, d4 = v - p4, d8 = v - p8, d12 = v - p12;
-      const bool k0 = d0 > t, k4 = d4 > t, k8 = d8 > t, k12 = d12 > t;
-      const bool b0 = -d0 > t, b4 = -d4 > t, b8 = -d8 > t, b12 = -d12 > t;
-      const bool pass = rowok && lx >= lx0 && lx < lx1 &&
+      const int lo = v - t, hi = v + t;                         // darker: p < v - t ; brighter: p > v + t
+      const bool k0 = p0 < lo, k4 = p4 < lo, k8 = p8 < lo, k12 = p12 < lo;
+      const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+      const bool pass = rowok && ((colmask >> i) & 1) &&
                         ((k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0));
       const unsigned long long m = __ballot(pass);
       if (pass) list[L + LANE_PREFIX(m)] = (uint16_t)((py << 6) | (lx - lx0));

@@ -75,21 +75,23 @@ QT_DEV void qt_exclusive_scan(uint32_t* a, int n, const QtWork& w, int* total) {
   for (int i = 0; i < n; ++i) { uint32_t v = a[i]; a[i] = acc; acc += v; }
   *total = (int)acc;
 #else
-  const int T = QT_NT, t = QT_TID;
+  // thread t owns a[t*per .. t*per+per); wave-level inclusive scan of the per-thread sums with shuffles, then the (at
+  // most 16) wave totals are combined through LDS -- no serial pass over the elements
+  const int T = QT_NT, t = QT_TID, lane = t & 63, wv = t >> 6, nw = T >> 6;
   const int per = (n + T - 1) / T;
   const int b = t * per, e = (b + per < n) ? b + per : n;
   uint32_t s = 0;
   for (int i = b; i < e; ++i) s += a[i];
-  w.part[t] = s;
+  uint32_t incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+  if (lane == 63) w.part[wv] = incl;
   __syncthreads();
-  if (t == 0) {
-    uint32_t acc = 0;
-    for (int i = 0; i < T; ++i) { uint32_t v = w.part[i]; w.part[i] = acc; acc += v; }
-    *total = (int)acc;
-  }
-  __syncthreads();
-  uint32_t acc = w.part[t];
-  for (int i = b; i < e; ++i) { uint32_t v = a[i]; a[i] = acc; acc += v; }
+  uint32_t wbase = 0, tot = 0;
+  for (int q = 0; q < nw; ++q) { const uint32_t v = w.part[q]; if (q < wv) wbase += v; tot += v; }
+  uint32_t acc = wbase + incl - s;
+  for (int i = b; i < e; ++i) { const uint32_t v = a[i]; a[i] = acc; acc += v; }
+  if (t == 0) *total = (int)tot;
   __syncthreads();
 #endif
 }
