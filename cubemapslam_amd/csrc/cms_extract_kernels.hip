@@ -76,20 +76,37 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
   const int r1 = min(max((int)taby[yl].s + 1, 0), src.h - 1);
   const int ndw = ((c1 - c0) >> 2) + 1, nr = r1 - r0 + 1;
   const uint8_t* simg = pyr + (size_t)b * pyr_bytes + src.off;
+  const int x0 = xb + 4 * tx;
+  // every global load of this thread (coefficient entries, then its share of the source rectangle) is issued before the
+  // first dependent use, so the workgroup pays one memory latency, not one per row
+  CmsResizeTab t4[4], tyr[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t4[i] = tabx[min(x0 + i, dst.w - 1)];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) tyr[rr] = taby[min(yb + ty + 4 * rr, dst.h - 1)];
   {
-    const int c = tid & 127;
-    if (c < ndw)
-      for (int r = tid >> 7; r < nr; r += 2)
-        reinterpret_cast<uint32_t*>(rtile + r * ls)[c] =
-            *reinterpret_cast<const uint32_t*>(simg + (size_t)(r0 + r) * src.stride + c0 + 4 * c);
+    const int c = tid & 127, rs = tid >> 7;
+    const uint8_t* gp = simg + (size_t)r0 * src.stride + c0 + 4 * c;
+    for (int rbase = 0; rbase < nr; rbase += 16) {
+      uint32_t tmp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = rbase + rs + 2 * k;
+        tmp[k] = (c < ndw && r < nr) ? *reinterpret_cast<const uint32_t*>(gp + (size_t)r * src.stride) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = rbase + rs + 2 * k;
+        if (c < ndw && r < nr) reinterpret_cast<uint32_t*>(rtile + r * ls)[c] = tmp[k];
+      }
+    }
   }
   __syncthreads();
-  const int x0 = xb + 4 * tx;
   if (x0 >= dst.w) return;
   int ca[4], cb[4], a0[4], a1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const CmsResizeTab t = tabx[min(x0 + i, dst.w - 1)];
+    const CmsResizeTab t = t4[i];
     ca[i] = (int)t.s - c0;
     cb[i] = min((int)t.s + 1, src.w - 1) - c0;
     a0[i] = t.a0; a1[i] = t.a1;
@@ -98,7 +115,7 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
   for (int rr = 0; rr < 2; ++rr) {
     const int y = yb + ty + 4 * rr;
     if (y >= dst.h) break;
-    const CmsResizeTab tyy = taby[y];
+    const CmsResizeTab tyy = tyr[rr];
     const uint8_t* S0 = rtile + (min(max((int)tyy.s, 0), src.h - 1) - r0) * ls;
     const uint8_t* S1 = rtile + (min(max((int)tyy.s + 1, 0), src.h - 1) - r0) * ls;
     const int b0 = tyy.a0, b1 = tyy.a1;
@@ -464,7 +481,7 @@ k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ q
 // ([18,34,49,55,49,34,18], (sum+32768)>>16) produces the 37x37 blurred neighbourhood the 512 steered taps read.
 #define PR 21
 #define PW 43
-#define PS 44
+#define PS 48
 #define BW 37
 #define BS 40
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -476,7 +493,7 @@ extern "C" __global__ void __launch_bounds__(64)
 k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
            const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const signed char* __restrict__ pattern,
            uint8_t* __restrict__ desc) {
-  __shared__ uint8_t raw[PW * PS];
+  __shared__ __align__(16) uint8_t raw[PW * PS + 16];
   __shared__ uint16_t rowp[PW * BW];
   __shared__ uint8_t blr[BW * BS];
   const int b = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
@@ -485,11 +502,31 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
   const int cx = a & 0xFFF, cy = (a >> 12) & 0xFFF, l = a >> 24;
   const CmsLevel& lv = g.lv[l];
   const uint8_t* img = pyr + (size_t)b * pyr_bytes + lv.off;
-  for (int idx = lane; idx < PW * PW; idx += 64) {
-    const int r = idx / PW, c = idx - r * PW;
-    const int yy = reflect101(cy - PR + r, lv.h), xx = reflect101(cx - PR + c, lv.w);
-    raw[r * PS + c] = img[(size_t)yy * lv.stride + xx];
+  int off = 0;                       // patch column c lives at raw[r * PS + off + c]
+  if (cx - PR >= 0 && cx + PR < lv.w && cy - PR >= 0 && cy + PR < lv.h) {
+    // interior (the normal case): 43 rows x 12 aligned dwords, all 9 loads of a lane in flight before the first LDS store
+    const int ax = (cx - PR) & ~3;
+    off = cx - PR - ax;
+    const uint8_t* gp = img + (size_t)(cy - PR) * lv.stride + ax;
+    uint32_t tmp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int idx = lane + 64 * k, r = idx / 12, c = idx - r * 12;
+      tmp[k] = idx < PW * 12 ? *reinterpret_cast<const uint32_t*>(gp + (size_t)r * lv.stride + 4 * c) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int idx = lane + 64 * k;
+      if (idx < PW * 12) reinterpret_cast<uint32_t*>(raw)[idx] = tmp[k];     // PS == 48 == 12 dwords per row
+    }
+  } else {
+    for (int idx = lane; idx < PW * PW; idx += 64) {   // patch crosses the level edge: REFLECT_101, byte by byte
+      const int r = idx / PW, c = idx - r * PW;
+      const int yy = reflect101(cy - PR + r, lv.h), xx = reflect101(cx - PR + c, lv.w);
+      raw[r * PS + c] = img[(size_t)yy * lv.stride + xx];
+    }
   }
+  const uint8_t* rawp = raw + off;
   __syncthreads();
   // ---- IC_Angle: intensity centroid over the radius-15 disc (umax of ORBExtractor.cpp:426-441)
   int m10 = 0, m01 = 0;
@@ -497,7 +534,7 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
     const int v = lane - 15, av = v < 0 ? -v : v;
     const int umax = av <= 3 ? 15 : av <= 6 ? 14 : av <= 8 ? 13 : av == 9 ? 12 : av == 10 ? 11 : av == 11 ? 10
                      : av == 12 ? 9 : av == 13 ? 8 : av == 14 ? 6 : 3;
-    const uint8_t* row = raw + (PR + v) * PS + PR;
+    const uint8_t* row = rawp + (PR + v) * PS + PR;
     int s = 0;
     for (int u = -umax; u <= umax; ++u) { const int p = row[u]; m10 += u * p; s += p; }
     m01 = v * s;
@@ -508,7 +545,7 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
   // ---- separable Gaussian, rows then columns
   for (int idx = lane; idx < PW * BW; idx += 64) {
     const int r = idx / BW, c = idx - r * BW;
-    const uint8_t* p = raw + r * PS + c;   // window [c, c+6] is centred on patch column c+3
+    const uint8_t* p = rawp + r * PS + c;   // window [c, c+6] is centred on patch column c+3
     rowp[idx] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
   }
   __syncthreads();
