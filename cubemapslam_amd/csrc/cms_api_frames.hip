@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "../../include/cubemapslam_hip.h"
@@ -265,6 +266,18 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
       cms_resize_table(g.lv[l - 1].w, g.lv[l].w, true, &tab[g.lv[l].tab_off]);
       cms_resize_table(g.lv[l - 1].h, g.lv[l].h, false, &tab[g.lv[l].tab_off + g.lv[l].w]);
     }
+    // extent of the exactly-zero corner regions per level (exact, from the very tables k_resize uses): a destination
+    // pixel is zero when both source taps sx, sx+1 lie inside the previous level's zero region (w == h, x and y tables agree
+    // on the index part)
+    g.lv[0].zlo = F; g.lv[0].zhi = F;
+    for (int l = 1; l < L; ++l) {
+      const CmsResizeTab* tx = &tab[g.lv[l].tab_off];
+      const int sw = g.lv[l - 1].w, dw = g.lv[l].w;
+      int lo = 0, hi = 0;
+      while (lo < dw && std::min((int)tx[lo].s + 1, sw - 1) < g.lv[l - 1].zlo) ++lo;
+      while (hi < dw && (int)tx[dw - 1 - hi].s >= sw - g.lv[l - 1].zhi) ++hi;
+      g.lv[l].zlo = lo; g.lv[l].zhi = hi;
+    }
     hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(CmsResizeTab), hipMemcpyHostToDevice);
     hipMemcpy(c->d_pattern, kOrbPattern, 1024, hipMemcpyHostToDevice);
   }
@@ -315,6 +328,7 @@ extern "C" int cms_set_mask(cms_ctx* c, const uint8_t* mask, int mstride) {
 }
 
 static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
+  c->g.skip_zero_cells = from_fisheye ? 1 : 0;   // a caller-supplied canvas (cms_extract) may hold anything in its corner blocks
   const CmsGeom& g = c->g;
   const int L = g.nlevels;
   hipStream_t s = c->stream;

@@ -182,6 +182,9 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   const int ex0 = iniX + 3, ex1 = maxX - 3, ey0 = iniY + 3, ey1 = maxY - 3;   // pixels cv::FAST evaluates in this ROI
   const int ew = ex1 - ex0, eh = ey1 - ey0;
   if (ew <= 0 || eh <= 0) return;
+  // 4/9 of the cross are corner blocks that k_remap keeps at 0: a cell whose whole ROI lies in that constant region (at this
+  // level: [0, zlo) or [w - zhi, w) in both directions) has no corner by definition -- identical result, no work
+  if (g.skip_zero_cells && (maxX <= lv.zlo || iniX >= lv.w - lv.zhi) && (maxY <= lv.zlo || iniY >= lv.h - lv.zhi)) return;
   if (g.dbg_stop == 9) return;
 
   uint8_t* tile = smem;                                             // [tile_h][tile_stride]

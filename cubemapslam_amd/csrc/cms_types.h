@@ -21,6 +21,8 @@ struct CmsLevel {
   float scale;          // mvScaleFactor[l]
   float patch_size;     // (int)(31 * scale) as float (ORBExtractor.cpp:810)
   size_t tab_off;       // offset (entries) of this level's resize coefficient table (x then y)
+  int zlo, zhi;         // pixels [0, zlo) and [w - zhi, w) (rows and columns alike) depend only on the corner blocks of the
+                        // cross, i.e. are exactly 0 at this level whenever the canvas came from k_remap
 };
 
 struct CmsGeom {
@@ -35,6 +37,7 @@ struct CmsGeom {
   int sc_stride, sc_h;        // FAST LDS score tile
   int list_cap;               // FAST LDS corner list capacity
   int cell_cap;               // capacity of one FAST cell's candidate slot
+  int skip_zero_cells;        // set per launch: the canvas was produced by k_remap, FAST cells inside the zero corners are skipped
   int dbg_stop;               // developer switch (env CMS_DBG_FAST_STOP): cut k_fast_cells short after phase N, 0 = off
   CmsLevel lv[CMS_MAX_LEVELS];
 };
