@@ -55,6 +55,10 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   delete b;
 }
 extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullptr; }
+extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
+  if (!b || !out8) return CMS_ERR_ARG;
+  return hipMemcpy(out8, b->d_scal + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
+}
 
 extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P,
                              const double* points, int E, const int* e_pose, const int* e_point, const double* e_obs,
@@ -109,7 +113,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
   BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
-  BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(b->nblk_e, b->nblk_p) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 8));
+  BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(b->nblk_e, b->nblk_p) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 24));   // [8..16): developer clocks of k_ba_trial_solve
   BA_TRY(ba_alloc(b, &b->d_flags, E));
   b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
   BA_HIP(hipHostMalloc((void**)&b->h_pin, 8 * sizeof(double)));

@@ -45,6 +45,7 @@ struct cms_ctx {
   size_t fish_pitch = 0;      // bytes per fisheye frame
   int lut_stride = 0, mstride = 0;
   bool have_mask = false;
+  int dirty_frames = 0;       // leading frames whose corner blocks may be non-zero (a caller-supplied canvas went through them)
   // device buffers
   uint8_t* d_fish = nullptr; uint32_t* d_lut = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_mask = nullptr;
   CmsResizeTab* d_tab = nullptr; signed char* d_pattern = nullptr;
@@ -329,6 +330,11 @@ extern "C" int cms_set_mask(cms_ctx* c, const uint8_t* mask, int mstride) {
 
 static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   c->g.skip_zero_cells = from_fisheye ? 1 : 0;   // a caller-supplied canvas (cms_extract) may hold anything in its corner blocks
+  // the corner blocks of every level are 0 from cms_ctx_create on and k_remap never writes there; only a caller-supplied canvas
+  // can dirty them, in which case the next remapped launch rewrites the zeros in full
+  const int clean = (from_fisheye && c->dirty_frames == 0) ? 1 : 0;
+  if (!from_fisheye) c->dirty_frames = std::max(c->dirty_frames, B);
+  else if (B >= c->dirty_frames) c->dirty_frames = 0;
   const CmsGeom& g = c->g;
   const int L = g.nlevels;
   hipStream_t s = c->stream;
@@ -336,7 +342,7 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   if (from_fisheye) {
     dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, B);
     hipLaunchKernelGGL(k_remap, grid, dim3(256), 0, s, (const uint8_t*)c->d_fish, c->fish_pitch, c->fstride, c->cam.Iw,
-                       c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F);
+                       c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, clean ? 0 : 1);
   }
   if (c->prof) hipEventRecord(c->ev[1], s);
   for (int l = 1; l < L; ++l) {
@@ -347,7 +353,7 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
     const int ls = (int)align_up((size_t)ceil(256 * ratio) + 12, 4);     // LDS row stride of the staged source rectangle
     const int lrows = (int)ceil(8 * ratio) + 3;
     hipLaunchKernelGGL(k_resize, grid, block, (size_t)ls * lrows, s, c->d_pyr, g.pyr_bytes, g.lv[l - 1], d,
-                       (const CmsResizeTab*)(c->d_tab + d.tab_off), (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w), ls);
+                       (const CmsResizeTab*)(c->d_tab + d.tab_off), (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w), ls, clean);
   }
   if (c->prof) hipEventRecord(c->ev[2], s);
   HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, (size_t)B * g.total_cells * sizeof(int), s));
@@ -411,7 +417,7 @@ extern "C" int cms_remap(cms_ctx* c, const uint8_t* fisheye, int fstride, uint8_
   const CmsGeom& g = c->g;
   dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, 1);
   hipLaunchKernelGGL(k_remap, grid, dim3(256), 0, c->stream, (const uint8_t*)c->d_fish, c->fish_pitch, c->fstride, c->cam.Iw,
-                     c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F);
+                     c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, 1);
   const int F = g.F;
   const int fx0[5] = {F, 0, 2 * F, F, F}, fy0[5] = {F, F, F, 0, 2 * F};
   for (int f = 0; f < 5; ++f)

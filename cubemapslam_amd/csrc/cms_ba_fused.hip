@@ -14,35 +14,41 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-__device__ __forceinline__ void ba_factor_diag(double* a, int J, int tid_blk, double* Lblk, double* ybuf, double* idg, int* bad) {
+__device__ __forceinline__ void ba_factor_diag(double* a, int J, double* Ld, double* ybuf, double* idg, int* bad) {
+  // The solver is outside the bit-exact part of the path (BA parity bar: 1e-4 relative), so the serial chains use explicit
+  // fused multiply-adds and a Newton reciprocal (hardware estimate + two steps, <= 1 ulp) instead of the IEEE division sequence.
   double idl[6];
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     const double dc = a[7 * c];
     if (!(isfinite(dc)) || dc == 0.0) *bad = 1;
-    idl[c] = 1.0 / dc;
+    double x = __builtin_amdgcn_rcp(dc);
+    x = __builtin_fma(__builtin_fma(-dc, x, 1.0), x, x);
+    x = __builtin_fma(__builtin_fma(-dc, x, 1.0), x, x);
+    idl[c] = x;
     double lc[6];
 #pragma unroll
-    for (int r = c + 1; r < 6; ++r) lc[r] = a[6 * r + c] * idl[c];
+    for (int r = c + 1; r < 6; ++r) lc[r] = a[6 * r + c] * x;
 #pragma unroll
     for (int r = c + 1; r < 6; ++r) {
 #pragma unroll
-      for (int q = c + 1; q <= r; ++q) a[6 * r + q] -= lc[r] * lc[q] * dc;
-      a[6 * r + c] = lc[r];
+      for (int q = c + 1; q <= r; ++q) a[6 * r + q] = __builtin_fma(-lc[r], a[6 * q + c], a[6 * r + q]);   // a[q][c] still unscaled
     }
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) a[6 * r + c] = lc[r];
   }
-  double* Ld = Lblk + 36 * (size_t)tid_blk;
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) Ld[6 * r + c] = c < r ? a[6 * r + c] : (c == r ? 1.0 : 0.0);
   double z[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    z[r] = ybuf[6 * J + r];
+  for (int r = 0; r < 6; ++r) z[r] = ybuf[6 * J + r];     // loads before the stores below (same shared array)
 #pragma unroll
-    for (int c = 0; c < r; ++c) z[r] -= a[6 * r + c] * z[c];
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c < r; ++c) z[r] = __builtin_fma(-a[6 * r + c], z[c], z[r]);
   }
+#pragma unroll
+  for (int r = 1; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < r; ++c) Ld[6 * r + c] = a[6 * r + c];      // strictly lower part is all anybody reads
 #pragma unroll
   for (int r = 0; r < 6; ++r) { ybuf[6 * J + r] = z[r]; idg[6 * J + r] = idl[r]; }
 }
@@ -50,25 +56,35 @@ __device__ __forceinline__ void ba_factor_diag(double* a, int J, int tid_blk, do
 __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
-                 double* __restrict__ xp_out, double* __restrict__ scal) {
+                 double* __restrict__ xp_out, double* __restrict__ scal, long long* __restrict__ clk = nullptr) {
   extern __shared__ __align__(16) double sm[];
+#define BA_CLK(i) do { if (clk && threadIdx.x == 0) clk[i] = (long long)wall_clock64(); } while (0)
+  BA_CLK(0);
   const int nb = d.np, n = 6 * nb, nblk = nb * (nb + 1) / 2;
-  double* Lblk = sm;
-  double* Wbuf = Lblk + 36 * (size_t)nblk;
+  // LDS (doubles): panels of L | diagonal factors | W double buffer | y | 1/D            = 36 nblk + 84 nb
+  // A panel (column J, rows I = J+1 .. nb-1, m = nb-J-1) is stored "pair-interleaved transposed": element q of row i sits at
+  // ((q >> 1) * m + i) * 2 + (q & 1), so that the lanes of a wave (consecutive i) move consecutive 16-byte words -- the
+  // row-major block layout cost 3-5 way bank conflicts on every one of the 72 stores of the panel step.
+  double* Lp = sm;
+  double* Ldg = Lp + 36 * (size_t)(nb * (nb - 1) / 2);
+  double* Wbuf = Ldg + 36 * (size_t)nb;
   double* ybuf = Wbuf + 72 * (size_t)nb;
   double* idg = ybuf + n;
   __shared__ int bad;
   const int tid = threadIdx.x;
+  // thread <-> block (I, K), I >= K, COLUMN-major: the blocks of one column are consecutive lanes, so the panel of a column
+  // lives in one or two waves and the trailing blocks K > J are a dense tail of the thread range
   int I = 0, K = 0;
   const bool have = tid < nblk;
   if (have) {
-    I = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
-    while ((I + 1) * (I + 2) / 2 <= tid) ++I;
-    while (I * (I + 1) / 2 > tid) --I;
-    K = tid - I * (I + 1) / 2;
+    int off = 0;
+    while (off + (nb - K) <= tid) { off += nb - K; ++K; }
+    I = K + (tid - off);
   }
   if (tid == 0) bad = 0;
-  // ---- assemble this thread's block of  blockdiag(Hpp + lambda I) - sum_chunks(B1 Dinv B2^T)  and the reduced rhs
+  // ---- assemble this thread's block of  blockdiag(Hpp + lambda I) - sum_chunks(B1 Dinv B2^T)  and the reduced rhs.
+  // A pair has at most ceil(tuples / BA_TUP_CHUNK) chunk sums (<= 5 for a diagonal pair of an 80k-edge window); two chunks
+  // (84 loads) are in flight per round trip.
   double a[36];
   if (have) {
 #pragma unroll
@@ -79,19 +95,25 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 #pragma unroll
       for (int r = 0; r < 6; ++r) a[7 * r] += lambda;
     }
-    const int pr = pair_of_block[tid];
+    const int pr = pair_of_block[I * (I + 1) / 2 + K];       // the host table is row-major over the lower triangle
     double yb[6] = {0, 0, 0, 0, 0, 0};
     if (pr >= 0) {
-      for (int c = pair_chunk_off[pr]; c < pair_chunk_off[pr + 1]; ++c) {
-        const double* cs = chunk_sum + (size_t)c * 42;
+      const int c0 = pair_chunk_off[pr], c1 = pair_chunk_off[pr + 1];
+      for (int c = c0; c < c1; c += 2) {
+        const double* cs0 = chunk_sum + (size_t)c * 42;
+        const bool two = c + 1 < c1;
+        const double* cs1 = two ? cs0 + 42 : cs0;
+        double u[42], v[42];
+#pragma unroll
+        for (int q = 0; q < 42; ++q) { u[q] = cs0[q]; v[q] = cs1[q]; }
         // chunk sums are stored for the pair (s1 = K) <= (s2 = I), i.e. for block (K, I): transpose into (I, K)
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-          for (int q = 0; q < 6; ++q) a[6 * r + q] -= cs[6 * q + r];
+          for (int q = 0; q < 6; ++q) a[6 * r + q] -= two ? (u[6 * q + r] + v[6 * q + r]) : u[6 * q + r];
         if (I == K) {
 #pragma unroll
-          for (int r = 0; r < 6; ++r) yb[r] += cs[36 + r];
+          for (int r = 0; r < 6; ++r) yb[r] += two ? (u[36 + r] + v[36 + r]) : u[36 + r];
         }
       }
     }
@@ -101,69 +123,85 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
     }
   }
   __syncthreads();
-  if (have && I == 0 && K == 0) ba_factor_diag(a, 0, tid, Lblk, ybuf, idg, &bad);
+  BA_CLK(1);
+  if (have && I == 0 && K == 0) ba_factor_diag(a, 0, Ldg, ybuf, idg, &bad);
   __syncthreads();
   for (int J = 0; J < nb && !bad; ++J) {
-    double* W = Wbuf + (J & 1) * 36 * (size_t)nb;
+    const int m = nb - J - 1;                                            // rows below the diagonal of column J
+    double2* W2 = reinterpret_cast<double2*>(Wbuf + (J & 1) * 36 * (size_t)nb);
+    double2* L2 = reinterpret_cast<double2*>(Lp + 36 * (size_t)(J * nb - J * (J + 1) / 2));
     if (have && K == J && I > J) {                   // panel: W_IJ = A_IJ L_JJ^-T, L_IJ = W_IJ D_J^-1, y_I -= L_IJ z_J
-      const double* Ld = Lblk + 36 * (size_t)(J * (J + 1) / 2 + J);
-      double w[36];
+      const double* Ld = Ldg + 36 * (size_t)J;
+      // every LDS operand is read into registers first and all results are stored at the end: stores into the shared array
+      // between the loads would force the compiler to re-read (it cannot prove the destinations do not alias idg / ybuf)
+      double ld[15], idj[6], zj[6], yi[6];
+#pragma unroll
+      for (int c = 1; c < 6; ++c)
+#pragma unroll
+        for (int q = 0; q < c; ++q) ld[c * (c - 1) / 2 + q] = Ld[6 * c + q];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { idj[c] = idg[6 * J + c]; zj[c] = ybuf[6 * J + c]; yi[c] = ybuf[6 * I + c]; }
+      double w[36], lo[36];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           double v = a[6 * r + c];
 #pragma unroll
-          for (int q = 0; q < c; ++q) v -= w[6 * r + q] * Ld[6 * c + q];
+          for (int q = 0; q < c; ++q) v = __builtin_fma(-w[6 * r + q], ld[c * (c - 1) / 2 + q], v);
           w[6 * r + c] = v;
         }
-      double* Wd = W + 36 * (size_t)I;
-      double* Lo = Lblk + 36 * (size_t)tid;
-      double yi[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) yi[r] = ybuf[6 * I + r];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          const double l = w[6 * r + c] * idg[6 * J + c];
-          Wd[6 * r + c] = w[6 * r + c];
-          Lo[6 * r + c] = l;
-          yi[r] -= l * ybuf[6 * J + c];
+          const double l = w[6 * r + c] * idj[c];
+          lo[6 * r + c] = l;
+          yi[r] = __builtin_fma(-l, zj[c], yi[r]);
         }
+      const int i = I - J - 1;
+#pragma unroll
+      for (int qp = 0; qp < 18; ++qp) {
+        W2[qp * m + i] = make_double2(w[2 * qp], w[2 * qp + 1]);
+        L2[qp * m + i] = make_double2(lo[2 * qp], lo[2 * qp + 1]);
+      }
 #pragma unroll
       for (int r = 0; r < 6; ++r) ybuf[6 * I + r] = yi[r];
     }
     __syncthreads();
+    if (J == 0) BA_CLK(5);
     if (have && K > J) {                             // trailing update, then look-ahead factorisation of the next diagonal
-      const double* Wi = W + 36 * (size_t)I;
-      const double* Lk = Lblk + 36 * (size_t)(K * (K + 1) / 2 + J);
-      double lk[36];
+      const int iw = I - J - 1, ik = K - J - 1;
+      double wv[36], lk[36];
 #pragma unroll
-      for (int q = 0; q < 36; ++q) lk[q] = Lk[q];
+      for (int qp = 0; qp < 18; ++qp) {
+        const double2 x = W2[qp * m + iw], y = L2[qp * m + ik];
+        wv[2 * qp] = x.x; wv[2 * qp + 1] = x.y; lk[2 * qp] = y.x; lk[2 * qp + 1] = y.y;
+      }
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        double wr[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) wr[c] = Wi[6 * r + c];
+      for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
           double v = a[6 * r + q];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) v -= wr[c] * lk[6 * q + c];
+          for (int c = 0; c < 6; ++c) v = __builtin_fma(-wv[6 * r + c], lk[6 * q + c], v);
           a[6 * r + q] = v;
         }
+      if (I == J + 1 && K == J + 1) {
+        if (clk && J == 0) clk[6] = (long long)wall_clock64();
+        ba_factor_diag(a, J + 1, Ldg + 36 * (size_t)(J + 1), ybuf, idg, &bad);
+        if (clk && J == 0) clk[7] = (long long)wall_clock64();
       }
-      if (I == J + 1 && K == J + 1) ba_factor_diag(a, J + 1, tid, Lblk, ybuf, idg, &bad);
     }
     __syncthreads();
   }
   const bool isbad = bad != 0;
+  BA_CLK(2);
   if (!isbad && tid < 64) {
     for (int i = tid; i < n; i += 64) ybuf[i] *= idg[i];
     __builtin_amdgcn_wave_barrier();
     for (int J = nb - 1; J >= 0; --J) {
-      const double* Ld = Lblk + 36 * (size_t)(J * (J + 1) / 2 + J);
+      const double* Ld = Ldg + 36 * (size_t)J;
       double xj[6];
 #pragma unroll
       for (int r = 5; r >= 0; --r) {
@@ -178,10 +216,12 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
       }
       for (int o = tid; o < 6 * J; o += 64) {
         const int Kq = o / 6, c = o - 6 * Kq;
-        const double* Ljk = Lblk + 36 * (size_t)(J * (J + 1) / 2 + Kq);
+        // L_{J,Kq}: row i = J-Kq-1 of the panel of column Kq
+        const int mq = nb - Kq - 1, iq = J - Kq - 1;
+        const double* Lq = Lp + 36 * (size_t)(Kq * nb - Kq * (Kq + 1) / 2);
         double v = ybuf[o];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) v -= Ljk[6 * r + c] * xj[r];
+        for (int r = 0; r < 6; ++r) { const int q = 6 * r + c; v -= Lq[((q >> 1) * mq + iq) * 2 + (q & 1)] * xj[r]; }
         ybuf[o] = v;
       }
       __builtin_amdgcn_wave_barrier();
@@ -190,6 +230,7 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
   __syncthreads();
   if (isbad) for (int i = tid; i < n; i += blockDim.x) ybuf[i] = 0.0;
   __syncthreads();
+  BA_CLK(3);
   for (int i = tid; i < n; i += blockDim.x) xp_out[i] = ybuf[i];
   // ---- T <- exp(x) T for the free poses (types_six_dof_expmap.h:73-76), plain copy for the fixed ones
   double sc = 0;
@@ -246,6 +287,8 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
     memcpy(&stv, &st, sizeof(int));
     scal[4] = stv;
   }
+  BA_CLK(4);
+#undef BA_CLK
 }
 
 // per point: x_l = Dinv (b_l - sum B^T x_p), X_new = X + x_l, gain-denominator partial; then residuals + robust chi2 of the

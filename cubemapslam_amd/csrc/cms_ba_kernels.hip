@@ -275,7 +275,7 @@ __device__ __forceinline__ void ba_dinv_body(int BX, int GX, int P, const double
 // B1 Dinv B2^T + 6 for B1 Dinv bl on diagonal pairs) are folded across the wavefront with a reduce-scatter butterfly
 // (44 shuffles instead of 42 x 6), the four wave results are added in LDS.  k_ba_schur_finish adds the chunk sums of a
 // pair in fixed order and subtracts them from its 6x6 block of Hs (and the mirrored block) / bs.  Deterministic.
-#define BA_TUP_CHUNK 256
+#define BA_TUP_CHUNK 1024    /* tuples per chunk = per workgroup of 256 threads */
 template <int N, int H>
 __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, int off) {
   // lanes with the bit clear keep in[0..H), lanes with it set keep in[H..N) (zero padded to H); partner's copy is added
@@ -295,8 +295,7 @@ __device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDev d, co
   double acc[42];
 #pragma unroll
   for (int i = 0; i < 42; ++i) acc[i] = 0;
-  const int t = rg.x + threadIdx.x;
-  if (t < rg.y) {
+  for (int t = rg.x + threadIdx.x; t < rg.y; t += 256) {
     const int2 aa = tup[t];
     if (d.level[aa.x] == 0 && d.level[aa.y] == 0) {
       const int p = d.e_point[aa.x];
@@ -311,11 +310,11 @@ __device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDev d, co
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[6 * i + j] = BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2];
+        for (int j = 0; j < 6; ++j) acc[6 * i + j] += BD[3 * i] * B2[3 * j] + BD[3 * i + 1] * B2[3 * j + 1] + BD[3 * i + 2] * B2[3 * j + 2];
       if (aa.x == aa.y) {
         const double* dbp = db + 3 * (size_t)p;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[36 + i] = B1[3 * i] * dbp[0] + B1[3 * i + 1] * dbp[1] + B1[3 * i + 2] * dbp[2];
+        for (int i = 0; i < 6; ++i) acc[36 + i] += B1[3 * i] * dbp[0] + B1[3 * i + 1] * dbp[1] + B1[3 * i + 2] * dbp[2];
       }
     }
   }

@@ -57,7 +57,8 @@ k_ba_classify(BaDev d, const double* poses, const double* pts, double chi2_th, i
 extern "C" __global__ void __launch_bounds__(384)
 k_ba_trial_solve(BaDev d, const double* Hpp, const double* bp, double lambda, const int* pair_of_block, const int* pair_chunk_off,
                  const double* chunk_sum, const double* poses, double* poses_new, double* xp_out, double* scal) {
-  ba_trial_solve_body(blockIdx.x, gridDim.x, d, Hpp, bp, lambda, pair_of_block, pair_chunk_off, chunk_sum, poses, poses_new, xp_out, scal);
+  ba_trial_solve_body(blockIdx.x, gridDim.x, d, Hpp, bp, lambda, pair_of_block, pair_chunk_off, chunk_sum, poses, poses_new, xp_out, scal,
+                      reinterpret_cast<long long*>(scal + 8));
 }
 extern "C" __global__ void __launch_bounds__(128)
 k_ba_trial_points(BaDev d, const double* bl, const double* Hpl, const double* Dinv, const double* xp, double lambda, const double* pts,

@@ -25,14 +25,14 @@
 extern "C" __global__ void __launch_bounds__(256)
 k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw, int Ih,
         const uint32_t* __restrict__ lut, int lut_stride, uint8_t* __restrict__ pyr, size_t pyr_bytes,
-        int W, int stride0, int F) {
+        int W, int stride0, int F, int write_corners) {
   const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
   const int y = blockIdx.y, b = blockIdx.z;
   if (x0 >= W) return;
   const bool mid_row = (y >= F && y < 2 * F);
   uint8_t* dst = pyr + (size_t)b * pyr_bytes + (size_t)y * stride0 + x0;
   if (!mid_row && (x0 + 3 < F || x0 >= 2 * F)) {  // corner block of the cross: kept at 0 (cubemap_lafida.cpp:110-111)
-    *reinterpret_cast<uint32_t*>(dst) = 0u;
+    if (write_corners) *reinterpret_cast<uint32_t*>(dst) = 0u;   // already 0 unless a caller-supplied canvas was here before
     return;
   }
   const uint4 e4 = *reinterpret_cast<const uint4*>(lut + (size_t)y * lut_stride + x0);
@@ -65,11 +65,13 @@ k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw
 // `ls` = LDS row stride in bytes (multiple of 4, <= 512).
 extern "C" __global__ void __launch_bounds__(256)
 k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst,
-         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby, int ls) {
+         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby, int ls, int skip_zero) {
   extern __shared__ __align__(16) uint8_t rtile[];
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int xb = blockIdx.x * 256, yb = blockIdx.y * 8, b = blockIdx.z;
   const int xl = min(xb + 255, dst.w - 1), yl = min(yb + 7, dst.h - 1);
+  // tile inside the constant-zero corner region of a remapped cross (see CmsLevel::zlo): source and destination are 0 already
+  if (skip_zero && (xl < dst.zlo || xb >= dst.w - dst.zhi) && (yl < dst.zlo || yb >= dst.h - dst.zhi)) return;
   const int c0 = (int)tabx[xb].s & ~3;
   const int c1 = min((int)tabx[xl].s + 1, src.w - 1);
   const int r0 = min(max((int)taby[yb].s, 0), src.h - 1);

@@ -145,6 +145,8 @@ int cms_ba_optimize(cms_ba* ba, int its_robust, int its_final, const volatile ui
 int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats);
 int cms_ba_read(cms_ba* ba, double* poses, double* points, uint8_t* outlier_flags);
 void* cms_ba_stream(cms_ba* ba);
+/* developer aid: 100 MHz wall-clock stamps of the last single-window solve kernel (start, assembled, factorised, solved, end) */
+int cms_ba_debug_clocks(cms_ba* ba, long long* out16);
 void cms_ba_destroy(cms_ba* ba);
 /* one-shot convenience: create + optimize + read + destroy */
 int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,

@@ -113,6 +113,14 @@ def test_extract_host_api_and_dense_texture():
     cube = orc.fisheye_to_cubemap(ocam, m1, m2, fish)
     k2, d2 = o.extract(ocam, cube, mask)
     assert np.array_equal(k1.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d1, d2)
+    _compare_frame(ctx, 0, o, ocam, cube, mask, "remap after a caller canvas (corner blocks rewritten)")
+    # third call: the corner blocks are known to be 0 now, remap / resize / FAST skip them -- same results, every level
+    fish = synth.texture(camd["Ih"], camd["Iw"], 10)
+    k1, d1 = ctx.remap_extract(fish)
+    cube = orc.fisheye_to_cubemap(ocam, m1, m2, fish)
+    k2, d2 = o.extract(ocam, cube, mask)
+    assert np.array_equal(k1.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d1, d2)
+    _compare_frame(ctx, 0, o, ocam, cube, mask, "remap with corner skipping")
     ctx.close()
 
 
