@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcubemapslam_hip.so")
+LIB_PATH = os.environ.get("CMS_HIP_LIB") or os.path.join(_HERE, "lib", "libcubemapslam_hip.so")   # override: developer A/B builds (tools/ab_build.sh)
 
 
 class CmsError(RuntimeError):

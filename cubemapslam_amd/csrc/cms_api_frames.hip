@@ -52,6 +52,7 @@ struct cms_ctx {
   uint32_t* d_cand = nullptr; uint16_t* d_node = nullptr; int* d_cand_cnt = nullptr; int* d_overflow = nullptr;
   uint32_t* d_qt_out = nullptr; int* d_qt_cnt = nullptr;
   uint32_t* d_cell_cand = nullptr; int* d_cell_cnt = nullptr;
+  int* d_cells_all = nullptr; int* d_cells_nz = nullptr; int n_cells_all = 0, n_cells_nz = 0;   // FAST work lists
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
   // match scratch
   void* d_match = nullptr; size_t match_bytes = 0;
@@ -147,7 +148,7 @@ static void cms_ctx_free(cms_ctx* c) {
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_fish, c->d_lut, c->d_pyr, c->d_mask, c->d_tab, c->d_pattern, c->d_cand, c->d_node, c->d_cand_cnt,
                   c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_desc, c->d_kp_cnt, c->d_match, c->d_cell_cand,
-                  c->d_cell_cnt};
+                  c->d_cell_cnt, c->d_cells_all, c->d_cells_nz};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < 8; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -221,7 +222,8 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   g.dbg_stop = getenv("CMS_DBG_FAST_STOP") ? atoi(getenv("CMS_DBG_FAST_STOP")) : 0;
   if (wCellMax > 60 || hCellMax > 60) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 60 pixels"); }
   if (orb->scale_factor < 1.01f || orb->scale_factor > 1.9f) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "scaleFactor must be in [1.01, 1.9]"); }
-  c->fast_lds = (size_t)g.tile_h * g.tile_stride + (size_t)g.sc_h * g.sc_stride + 2 * (size_t)g.list_cap + 16;
+  g.fast_cell_lds = (int)align_up((size_t)g.tile_h * g.tile_stride + (size_t)g.sc_h * g.sc_stride + 2 * (size_t)g.list_cap + 16, 16);
+  c->fast_lds = CMS_FAST_WPB * (size_t)g.fast_cell_lds;
   c->qt_lds = 64 * (size_t)g.qt_maxn + 4 * 512 + 64;
 
   c->fstride = (int)align_up((size_t)cam->Iw, 64);
@@ -280,6 +282,31 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
       g.lv[l].zlo = lo; g.lv[l].zhi = hi;
     }
     hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(CmsResizeTab), hipMemcpyHostToDevice);
+    // FAST work lists: every cell the reference loop visits (ORBExtractor.cpp:764-781), and the subset that does not lie
+    // wholly inside the zero corner regions of a remapped cross (same tests as in k_fast_cells)
+    std::vector<int> all, nz;
+    for (int l = 0; l < L; ++l) {
+      const CmsLevel& lv = g.lv[l];
+      const int maxBX = lv.w - CMS_MINB, maxBY = lv.h - CMS_MINB;
+      for (int ci = 0; ci < lv.nRows; ++ci)
+        for (int cj = 0; cj < lv.nCols; ++cj) {
+          const int iniY = CMS_MINB + ci * lv.hCell, iniX = CMS_MINB + cj * lv.wCell;
+          if (iniY >= maxBY - 3 || iniX >= maxBX - 6) continue;
+          const int maxY = std::min(iniY + lv.hCell + 6, maxBY), maxX = std::min(iniX + lv.wCell + 6, maxBX);
+          if (maxX - iniX - 6 <= 0 || maxY - iniY - 6 <= 0) continue;
+          const int id = lv.cell0 + ci * lv.nCols + cj;
+          all.push_back(id);
+          const bool zero = (maxX <= lv.zlo || iniX >= lv.w - lv.zhi) && (maxY <= lv.zlo || iniY >= lv.h - lv.zhi);
+          if (!zero) nz.push_back(id);
+        }
+    }
+    c->n_cells_all = (int)all.size(); c->n_cells_nz = (int)nz.size();
+    if (hipMalloc((void**)&c->d_cells_all, std::max<size_t>(all.size(), 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_cells_nz, std::max<size_t>(nz.size(), 1) * 4) != hipSuccess) {
+      cms_ctx_free(c); return cms_fail(CMS_ERR_HIP, "hipMalloc cell lists");
+    }
+    hipMemcpy(c->d_cells_all, all.data(), all.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(c->d_cells_nz, nz.data(), nz.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(c->d_pattern, kOrbPattern, 1024, hipMemcpyHostToDevice);
   }
   e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->qt_lds);
@@ -340,9 +367,9 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   hipStream_t s = c->stream;
   if (c->prof) hipEventRecord(c->ev[0], s);
   if (from_fisheye) {
-    dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, B);
+    dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, (B + CMS_REMAP_FPT - 1) / CMS_REMAP_FPT);
     hipLaunchKernelGGL(k_remap, grid, dim3(256), 0, s, (const uint8_t*)c->d_fish, c->fish_pitch, c->fstride, c->cam.Iw,
-                       c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, clean ? 0 : 1);
+                       c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, clean ? 0 : 1, B);
   }
   if (c->prof) hipEventRecord(c->ev[1], s);
   for (int l = 1; l < L; ++l) {
@@ -357,8 +384,18 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   }
   if (c->prof) hipEventRecord(c->ev[2], s);
   HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, (size_t)B * g.total_cells * sizeof(int), s));
-  hipLaunchKernelGGL(k_fast_cells, dim3(g.total_cells, B), dim3(64), c->fast_lds, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g,
-                     c->d_cell_cand, c->d_cell_cnt, c->d_overflow);
+  {
+#if CMS_FAST_LIST
+    const int* list = from_fisheye ? c->d_cells_nz : c->d_cells_all;
+    const int nlist = from_fisheye ? c->n_cells_nz : c->n_cells_all;
+#else
+    const int* list = nullptr;
+    const int nlist = g.total_cells;
+#endif
+    if (nlist > 0)
+      hipLaunchKernelGGL(k_fast_cells, dim3((nlist + CMS_FAST_WPB - 1) / CMS_FAST_WPB, B), dim3(64 * CMS_FAST_WPB), c->fast_lds, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g,
+                         list, nlist, c->d_cell_cand, c->d_cell_cnt, c->d_overflow);
+  }
   if (c->prof) hipEventRecord(c->ev[3], s);
   hipLaunchKernelGGL(k_quadtree, dim3(L, B), dim3(512), c->qt_lds, s, g, (const uint32_t*)c->d_cell_cand, (const int*)c->d_cell_cnt,
                      c->d_cand, c->d_cand_cnt, c->d_overflow,
@@ -367,7 +404,7 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   hipLaunchKernelGGL(k_cull, dim3(B), dim3(256), 0, s, g, (const uint32_t*)c->d_qt_out, (const int*)c->d_qt_cnt,
                      (const uint8_t*)c->d_mask, c->mstride, c->d_kps, c->d_aux, c->d_kp_cnt);
   if (c->prof) hipEventRecord(c->ev[5], s);
-  hipLaunchKernelGGL(k_describe, dim3(g.kp_cap, B), dim3(64), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
+  hipLaunchKernelGGL(k_describe, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
                      (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const signed char*)c->d_pattern, c->d_desc);
   if (c->prof) hipEventRecord(c->ev[6], s);
   HIPCHK(hipGetLastError());
@@ -417,7 +454,7 @@ extern "C" int cms_remap(cms_ctx* c, const uint8_t* fisheye, int fstride, uint8_
   const CmsGeom& g = c->g;
   dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, 1);
   hipLaunchKernelGGL(k_remap, grid, dim3(256), 0, c->stream, (const uint8_t*)c->d_fish, c->fish_pitch, c->fstride, c->cam.Iw,
-                     c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, 1);
+                     c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, 1, 1);
   const int F = g.F;
   const int fx0[5] = {F, 0, 2 * F, F, F}, fy0[5] = {F, F, F, 0, 2 * F};
   for (int f = 0; f < 5; ++f)

@@ -21,41 +21,65 @@
 
 // ------------------------------------------------------------------------------------------------ remap
 // LUT entry (one u32 per canvas pixel): X[0:11) | Y[11:22) | ax[22:27) | ay[27:32)  -- cv::remap's 5-bit fixed point.
-// One thread = 4 consecutive canvas pixels: one 16-byte LUT load, 16 byte gathers (L2 resident source), one dword store.
+// One thread = 4 consecutive canvas pixels of CMS_REMAP_FPT frames of the batch: one 16-byte LUT load and one decode serve all
+// of them (the LUT is the largest stream of this kernel), then per frame 8 unaligned 16-bit gathers (the source image is cache
+// resident) and one dword store.
+#ifndef CMS_REMAP_FPT
+#define CMS_REMAP_FPT 4
+#endif
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 extern "C" __global__ void __launch_bounds__(256)
 k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw, int Ih,
         const uint32_t* __restrict__ lut, int lut_stride, uint8_t* __restrict__ pyr, size_t pyr_bytes,
-        int W, int stride0, int F, int write_corners) {
+        int W, int stride0, int F, int write_corners, int B) {
   const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-  const int y = blockIdx.y, b = blockIdx.z;
+  const int y = blockIdx.y, b0 = blockIdx.z * CMS_REMAP_FPT;
   if (x0 >= W) return;
+  const int nb = min(CMS_REMAP_FPT, B - b0);
   const bool mid_row = (y >= F && y < 2 * F);
-  uint8_t* dst = pyr + (size_t)b * pyr_bytes + (size_t)y * stride0 + x0;
+  uint8_t* dst = pyr + (size_t)b0 * pyr_bytes + (size_t)y * stride0 + x0;
   if (!mid_row && (x0 + 3 < F || x0 >= 2 * F)) {  // corner block of the cross: kept at 0 (cubemap_lafida.cpp:110-111)
-    if (write_corners) *reinterpret_cast<uint32_t*>(dst) = 0u;   // already 0 unless a caller-supplied canvas was here before
+    if (write_corners)                              // already 0 unless a caller-supplied canvas was here before
+      for (int f = 0; f < nb; ++f) *reinterpret_cast<uint32_t*>(dst + (size_t)f * pyr_bytes) = 0u;
     return;
   }
   const uint4 e4 = *reinterpret_cast<const uint4*>(lut + (size_t)y * lut_stride + x0);
   const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
-  const uint8_t* src = fish + (size_t)b * fish_pitch;
-  uint32_t out = 0;
+  // BORDER_CONSTANT(0) per tap: a valid map value just below Iw / Ih can round up to X == Iw / Y == Ih.
+  // The two taps of a row come from ONE unaligned 16-bit load (the gather is bound by the number of address requests, not by
+  // bytes); the byte after the last pixel of a row is readable (row padding / next row / 256-byte slack) and masked out.
+  int soff[4], w00[4], w01[4], w10[4], w11[4];
+  bool ld0[4], ld1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int x = x0 + i;
-    const bool valid = x < W && (mid_row || (x >= F && x < 2 * F));
-    if (!valid) continue;
+    const bool valid = x < W && (mid_row || (x >= F && x < 2 * F));   // pixels of a straddling quad inside a corner block get 0
     const int X = e[i] & 0x7FF, Y = (e[i] >> 11) & 0x7FF, ax = (e[i] >> 22) & 31, ay = e[i] >> 27;
-    const uint8_t* s = src + (size_t)Y * fstride + X;
-    // BORDER_CONSTANT(0) per tap: a valid map value just below Iw / Ih can round up to X == Iw / Y == Ih
     const bool x0in = X < Iw, y0in = Y < Ih, x1in = X + 1 < Iw, y1in = Y + 1 < Ih;
-    const int p00 = (x0in && y0in) ? s[0] : 0;
-    const int p01 = (x1in && y0in) ? s[1] : 0;
-    const int p10 = (x0in && y1in) ? s[fstride] : 0;
-    const int p11 = (x1in && y1in) ? s[fstride + 1] : 0;
-    const int S = (32 - ay) * ((32 - ax) * p00 + ax * p01) + ay * ((32 - ax) * p10 + ax * p11);
-    out |= (uint32_t)((S + 512) >> 10) << (8 * i);
+    soff[i] = Y * fstride + X;
+    ld0[i] = valid && y0in; ld1[i] = valid && y1in;
+    w00[i] = x0in ? (32 - ay) * (32 - ax) : 0; w01[i] = x1in ? (32 - ay) * ax : 0;
+    w10[i] = x0in ? ay * (32 - ax) : 0;        w11[i] = x1in ? ay * ax : 0;
   }
-  *reinterpret_cast<uint32_t*>(dst) = out;   // pixels of a straddling quad that belong to a corner block get 0
+#pragma unroll
+  for (int f = 0; f < CMS_REMAP_FPT; ++f) {
+    if (f >= nb) break;
+    const uint8_t* src = fish + (size_t)(b0 + f) * fish_pitch;
+    uint32_t r0[4], r1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r0[i] = ld0[i] ? (uint32_t)*reinterpret_cast<const u16_unaligned*>(src + soff[i]) : 0u;
+      r1[i] = ld1[i] ? (uint32_t)*reinterpret_cast<const u16_unaligned*>(src + soff[i] + fstride) : 0u;
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // (32-ay)((32-ax) p00 + ax p01) + ay((32-ax) p10 + ax p11): integer arithmetic, any association gives the same value
+      const int S = w00[i] * (int)(r0[i] & 0xFF) + w01[i] * (int)(r0[i] >> 8) + w10[i] * (int)(r1[i] & 0xFF) + w11[i] * (int)(r1[i] >> 8);
+      out |= (uint32_t)((S + 512) >> 10) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)f * pyr_bytes) = out;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ resize
@@ -166,16 +190,46 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int t) {
   return A - 1;
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint32_t* __restrict__ cell_cand,
-             int* __restrict__ cell_cnt, int* __restrict__ overflow) {
-  extern __shared__ __align__(16) uint8_t smem[];
-  const int lane = threadIdx.x;
+// The wavefronts of a workgroup work on different cells and never exchange data: all synchronisation is inside a
+// wavefront (LDS operations of one wave complete in order; the fence only pins the compiler's order).
+#ifndef CMS_FAST_LIST
+#define CMS_FAST_LIST 1     /* launch only the host-listed cells that can hold a corner (0.342 -> 0.329 ms per 32 frames) */
+#endif
+#ifndef CMS_FAST_SYNC_WG
+#define CMS_FAST_SYNC_WG 0
+#endif
+#if CMS_FAST_SYNC_WG
+#define WAVE_SYNC() __syncthreads()
+#else
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
+#ifndef CMS_FAST_WPB
+#define CMS_FAST_WPB 1      /* cells (wavefronts) per workgroup; measured: 1 -> 0.34 ms, 4 -> 0.38 ms per 32 frames */
+#endif
+extern "C" __global__ void __launch_bounds__(64 * CMS_FAST_WPB)
+k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const int* __restrict__ cell_list, int n_list,
+             uint32_t* __restrict__ cell_cand, int* __restrict__ cell_cnt, int* __restrict__ overflow) {
+  extern __shared__ __align__(16) uint8_t smem_all[];
+#if CMS_FAST_WPB == 1
+  const int lane = threadIdx.x, wave = 0;           // compile-time LDS base: addresses fold into the instruction offsets
+#else
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#endif
+  const int slot = blockIdx.x * CMS_FAST_WPB + wave;
+#if CMS_FAST_LIST
+  if (slot >= n_list) return;
+  const int cid = cell_list[slot];          // host-built list of the cells that can hold a corner (see cms_ctx_create)
+#else
+  if (slot >= g.total_cells) return;
+  const int cid = slot;
+#endif
+  uint8_t* smem = smem_all + (size_t)wave * g.fast_cell_lds;
   const int b = blockIdx.y;
   int l = 0;
-  for (int k = 1; k < g.nlevels; ++k) if ((int)blockIdx.x >= g.lv[k].cell0) l = k;
+  for (int k = 1; k < g.nlevels; ++k) if (cid >= g.lv[k].cell0) l = k;
   const CmsLevel& lv = g.lv[l];
-  const int lc = blockIdx.x - lv.cell0;
+  const int lc = cid - lv.cell0;
   const int ci = lc / lv.nCols, cj = lc - ci * lv.nCols;
   const int maxBX = lv.w - CMS_MINB, maxBY = lv.h - CMS_MINB;
   const int iniY = CMS_MINB + ci * lv.hCell, iniX = CMS_MINB + cj * lv.wCell;
@@ -217,7 +271,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
     }
   }
   for (int idx = lane; idx < (g.sc_h * ss) >> 2; idx += 64) reinterpret_cast<uint32_t*>(sc)[idx] = 0u;
-  __syncthreads();
+  WAVE_SYNC();
   if (g.dbg_stop == 1) return;
 
   // ---- phase A: 4-point compass pre-test at minTh on 4 pixels per lane (5 dword LDS reads per quad instead of 20 byte
@@ -259,7 +313,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
       L += __popcll(m);
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   if (g.dbg_stop == 2) return;
 
   // ---- phase A2: 8-point refinement on the list.  Nine contiguous ring pixels always cover four consecutive even ring
@@ -285,14 +339,14 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
         uint32_t rbm = mb & (mb >> 1); rbm &= rbm >> 2;
         pass = ((rd | rbm) & 0xFFu) != 0;
       }
-      __syncthreads();                         // every lane has read its entry before the compacted list is written
+      WAVE_SYNC();                         // every lane has read its entry before the compacted list is written
       const unsigned long long m = __ballot(pass);
       if (pass) list[L2 + LANE_PREFIX(m)] = (uint16_t)code;
       L2 += __popcll(m);
     }
     L = L2;
   }
-  __syncthreads();
+  WAVE_SYNC();
   if (g.dbg_stop == 3) return;
 
   // ---- phase B: full 16-pixel ring score for the listed pixels
@@ -313,7 +367,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
       else list[k] = 0xFFFFu;
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   if (g.dbg_stop == 4) return;
 
   // ---- phase C: strict 8-neighbour maximum inside this cell, iniTh else minTh, emit
@@ -337,7 +391,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, uint3
   const int n_emit = n_ini > 0 ? n_ini : n_all;
   if (n_emit == 0) return;            // cell_cnt was zeroed before the launch
   // every cell owns a fixed slot: no atomics, no wait on a returning atomic; k_quadtree compacts the slots of its level
-  const size_t cell = (size_t)b * g.total_cells + blockIdx.x;
+  const size_t cell = (size_t)b * g.total_cells + cid;
   if (lane == 0) cell_cnt[cell] = min(n_emit, g.cell_cap);
   uint32_t* out = cell_cand + cell * g.cell_cap;
   const int basepos = 0;
@@ -494,14 +548,24 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   if (i >= n) i = 2 * n - 2 - i;
   return i;
 }
-extern "C" __global__ void __launch_bounds__(64)
+#ifndef CMS_DESC_WPB
+#define CMS_DESC_WPB 1
+#endif
+extern "C" __global__ void __launch_bounds__(64 * CMS_DESC_WPB)
 k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
            const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const signed char* __restrict__ pattern,
            uint8_t* __restrict__ desc) {
-  __shared__ __align__(16) uint8_t raw[PW * PS + 16];
-  __shared__ uint16_t rowp[PW * BW];
-  __shared__ uint8_t blr[BW * BS];
-  const int b = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+  // CMS_DESC_WPB key points per workgroup, one per wavefront, no data shared between them (wave-level synchronisation only)
+  __shared__ __align__(16) uint8_t raw4[CMS_DESC_WPB][PW * PS + 16];
+  __shared__ uint16_t rowp4[CMS_DESC_WPB][PW * BW];
+  __shared__ uint8_t blr4[CMS_DESC_WPB][BW * BS];
+#if CMS_DESC_WPB == 1
+  const int wave = 0, lane = threadIdx.x;
+#else
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#endif
+  uint8_t* raw = raw4[wave]; uint16_t* rowp = rowp4[wave]; uint8_t* blr = blr4[wave];
+  const int b = blockIdx.y, k = blockIdx.x * CMS_DESC_WPB + wave;
   if (k >= kp_cnt[b]) return;
   const uint32_t a = aux[(size_t)b * g.kp_cap + k];
   const int cx = a & 0xFFF, cy = (a >> 12) & 0xFFF, l = a >> 24;
@@ -532,7 +596,7 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
     }
   }
   const uint8_t* rawp = raw + off;
-  __syncthreads();
+  WAVE_SYNC();
   // ---- IC_Angle: intensity centroid over the radius-15 disc (umax of ORBExtractor.cpp:426-441)
   int m10 = 0, m01 = 0;
   if (lane < 31) {
@@ -553,7 +617,7 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
     const uint8_t* p = rawp + r * PS + c;   // window [c, c+6] is centred on patch column c+3
     rowp[idx] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
   }
-  __syncthreads();
+  WAVE_SYNC();
   for (int idx = lane; idx < BW * BW; idx += 64) {
     const int r = idx / BW, c = idx - r * BW;
     const uint16_t* p = rowp + r * BW + c;
@@ -561,7 +625,7 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
     const int v = (s + 32768) >> 16;
     blr[r * BS + c] = (uint8_t)(v > 255 ? 255 : v);
   }
-  __syncthreads();
+  WAVE_SYNC();
   // ---- steered BRIEF: lane i evaluates tests 4i .. 4i+3
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float sb, ca;

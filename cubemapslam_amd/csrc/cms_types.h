@@ -37,6 +37,7 @@ struct CmsGeom {
   int sc_stride, sc_h;        // FAST LDS score tile
   int list_cap;               // FAST LDS corner list capacity
   int cell_cap;               // capacity of one FAST cell's candidate slot
+  int fast_cell_lds;          // LDS bytes of one FAST cell (one wavefront); a workgroup holds CMS_FAST_WPB of them
   int skip_zero_cells;        // set per launch: the canvas was produced by k_remap, FAST cells inside the zero corners are skipped
   int dbg_stop;               // developer switch (env CMS_DBG_FAST_STOP): cut k_fast_cells short after phase N, 0 = off
   CmsLevel lv[CMS_MAX_LEVELS];
