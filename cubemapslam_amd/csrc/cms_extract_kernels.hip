@@ -83,33 +83,38 @@ k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw
 }
 
 // ------------------------------------------------------------------------------------------------ resize
-// One workgroup (64 x 4 threads) produces a 256 x 8 destination tile.  The source rectangle it needs (about 310 x 12
+// One workgroup (64 x 4 threads) produces a 256 x CMS_RZ_ROWS destination tile.  The source rectangle it needs (about 310 x 12
 // pixels at scale 1.2) is staged in LDS with coalesced dword loads; the 2 x 2 taps of every destination pixel are then
 // byte reads from LDS (a byte gather straight from global memory is bound by the texture-address path, not by HBM).
 // `ls` = LDS row stride in bytes (multiple of 4, <= 512).
+#ifndef CMS_RZ_ROWS
+#define CMS_RZ_ROWS 16
+#endif
 extern "C" __global__ void __launch_bounds__(256)
 k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst,
-         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby, int ls, int skip_zero) {
+         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby, int ls, int skip_zero, double scale) {
   extern __shared__ __align__(16) uint8_t rtile[];
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-  const int xb = blockIdx.x * 256, yb = blockIdx.y * 8, b = blockIdx.z;
-  const int xl = min(xb + 255, dst.w - 1), yl = min(yb + 7, dst.h - 1);
+  const int xb = blockIdx.x * 256, yb = blockIdx.y * CMS_RZ_ROWS, b = blockIdx.z;
+  const int xl = min(xb + 255, dst.w - 1), yl = min(yb + CMS_RZ_ROWS - 1, dst.h - 1);
   // tile inside the constant-zero corner region of a remapped cross (see CmsLevel::zlo): source and destination are 0 already
   if (skip_zero && (xl < dst.zlo || xb >= dst.w - dst.zhi) && (yl < dst.zlo || yb >= dst.h - dst.zhi)) return;
-  const int c0 = (int)tabx[xb].s & ~3;
-  const int c1 = min((int)tabx[xl].s + 1, src.w - 1);
-  const int r0 = min(max((int)taby[yb].s, 0), src.h - 1);
-  const int r1 = min(max((int)taby[yl].s + 1, 0), src.h - 1);
+  // staged source rectangle: a conservative superset computed arithmetically (tap index s(d) = floor((d + 0.5) scale - 0.5)
+  // lies in [floor(d scale) - 1, floor((d + 1) scale)]), so the pixel loads do not wait for the coefficient-table loads
+  const int c0 = max((int)floor(xb * scale) - 1, 0) & ~3;
+  const int c1 = min((int)floor((xl + 1) * scale) + 1, src.w - 1);
+  const int r0 = min(max((int)floor(yb * scale) - 1, 0), src.h - 1);
+  const int r1 = min((int)floor((yl + 1) * scale) + 1, src.h - 1);
   const int ndw = ((c1 - c0) >> 2) + 1, nr = r1 - r0 + 1;
   const uint8_t* simg = pyr + (size_t)b * pyr_bytes + src.off;
   const int x0 = xb + 4 * tx;
   // every global load of this thread (coefficient entries, then its share of the source rectangle) is issued before the
   // first dependent use, so the workgroup pays one memory latency, not one per row
-  CmsResizeTab t4[4], tyr[2];
+  CmsResizeTab t4[4], tyr[CMS_RZ_ROWS / 4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) t4[i] = tabx[min(x0 + i, dst.w - 1)];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) tyr[rr] = taby[min(yb + ty + 4 * rr, dst.h - 1)];
+  for (int rr = 0; rr < CMS_RZ_ROWS / 4; ++rr) tyr[rr] = taby[min(yb + ty + 4 * rr, dst.h - 1)];
   {
     const int c = tid & 127, rs = tid >> 7;
     const uint8_t* gp = simg + (size_t)r0 * src.stride + c0 + 4 * c;
@@ -138,7 +143,7 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
     a0[i] = t.a0; a1[i] = t.a1;
   }
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
+  for (int rr = 0; rr < CMS_RZ_ROWS / 4; ++rr) {
     const int y = yb + ty + 4 * rr;
     if (y >= dst.h) break;
     const CmsResizeTab tyy = tyr[rr];
