@@ -299,20 +299,22 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
       up = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py - 3) * ts)[q];
       dn = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py + 3) * ts)[q];
     }
-    const unsigned long long wide = ((unsigned long long)cp << 32) | cc;       // bytes lx .. lx+7
-    const unsigned long long wlow = ((unsigned long long)cc << 32) | cm;       // bytes lx-4 .. lx+3
+    // the four compass points are the four (vertical, horizontal) combinations of {p0, p8} x {p4, p12}, so
+    //   "some adjacent pair is darker than v - t"   <=>  max(min(p0, p8), min(p4, p12)) < v - t
+    //   "some adjacent pair is brighter than v + t" <=>  min(max(p0, p8), max(p4, p12)) > v + t
+    // -- six min/max and two compares per pixel, all on byte i of five dwords (x+3 and x-3 are brought into the lane's byte
+    // positions by two byte-align operations per quad).
+    const uint32_t e4 = __builtin_amdgcn_alignbyte(cp, cc, 3);     // bytes lx+3 .. lx+6
+    const uint32_t w4 = __builtin_amdgcn_alignbyte(cc, cm, 1);     // bytes lx-3 .. lx
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int lx = 4 * q + i;
       const int v = (cc >> (8 * i)) & 0xFF;
-      const int p4 = (int)((wide >> (8 * (i + 3))) & 0xFF);     // x + 3
-      const int p12 = (int)((wlow >> (8 * (i + 1))) & 0xFF);    // x - 3
+      const int p4 = (e4 >> (8 * i)) & 0xFF, p12 = (w4 >> (8 * i)) & 0xFF;
       const int p0 = (dn >> (8 * i)) & 0xFF, p8 = (up >> (8 * i)) & 0xFF;
-      const int lo = v - t, hi = v + t;                         // darker: p < v - t ; brighter: p > v + t
-      const bool k0 = p0 < lo, k4 = p4 < lo, k8 = p8 < lo, k12 = p12 < lo;
-      const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
-      const bool pass = rowok && ((colmask >> i) & 1) &&
-                        ((k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0));
+      const int dmax = max(min(p0, p8), min(p4, p12));
+      const int bmin = min(max(p0, p8), max(p4, p12));
+      const bool pass = rowok && ((colmask >> i) & 1) && ((dmax < v - t) | (bmin > v + t));
       const unsigned long long m = __ballot(pass);
       if (pass) list[L + LANE_PREFIX(m)] = (uint16_t)((py << 6) | (lx - lx0));
       L += __popcll(m);
