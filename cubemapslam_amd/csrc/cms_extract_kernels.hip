@@ -209,6 +209,9 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int t) {
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
+#ifndef CMS_FAST_LD
+#define CMS_FAST_LD 8       /* row loads in flight per lane while staging the ROI */
+#endif
 #ifndef CMS_FAST_WPB
 #define CMS_FAST_WPB 1      /* cells (wavefronts) per workgroup; measured: 1 -> 0.34 ms, 4 -> 0.38 ms per 32 frames */
 #endif
@@ -261,15 +264,15 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
     // all loads of a lane are issued before the first LDS store: one memory latency per cell instead of one per row group
     const int lr = lane / ndw, lc2 = lane - lr * ndw, rstep = 64 / ndw;
     const uint8_t* gp = img + (size_t)iniY * lv.stride + ax0 + 4 * lc2;
-    for (int rbase = 0; rbase < th; rbase += 12 * rstep) {
-      uint32_t tmp[12];
+    for (int rbase = 0; rbase < th; rbase += CMS_FAST_LD * rstep) {      // one pass for the usual ~37-row ROI
+      uint32_t tmp[CMS_FAST_LD];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
+      for (int k = 0; k < CMS_FAST_LD; ++k) {
         const int r = rbase + lr + k * rstep;
         tmp[k] = (lr < rstep && r < th) ? *reinterpret_cast<const uint32_t*>(gp + (size_t)r * lv.stride) : 0u;
       }
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
+      for (int k = 0; k < CMS_FAST_LD; ++k) {
         const int r = rbase + lr + k * rstep;
         if (lr < rstep && r < th) reinterpret_cast<uint32_t*>(tile + r * ts)[lc2] = tmp[k];
       }
@@ -314,7 +317,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
       const int p0 = (dn >> (8 * i)) & 0xFF, p8 = (up >> (8 * i)) & 0xFF;
       const int dmax = max(min(p0, p8), min(p4, p12));
       const int bmin = min(max(p0, p8), max(p4, p12));
-      const bool pass = rowok && ((colmask >> i) & 1) && ((dmax < v - t) | (bmin > v + t));
+      const bool pass = (bool)((int)rowok & ((colmask >> i) & 1) & ((int)(dmax < v - t) | (int)(bmin > v + t)));   // no short circuit: branch-free
       const unsigned long long m = __ballot(pass);
       if (pass) list[L + LANE_PREFIX(m)] = (uint16_t)((py << 6) | (lx - lx0));
       L += __popcll(m);
