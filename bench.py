@@ -5,7 +5,8 @@
 
 Workload (BASELINE.json: "frames/sec (extract+match+localBA) on Lafida cam0", configs[2] geometry): synthetic Lafida cam0
 stream, 754x480 fisheye, cube face F=550 (1650^2 cross), nFeatures 2000 / 8 levels / 1.2 / FAST 20-7.
-One step = one batch of B consecutive frames, inputs resident in HBM:
+One step = one batch of B frames (default 64 = 8 camera streams x 8 consecutive frames, cf. BASELINE.json configs[4]), inputs
+resident in HBM:
     remap -> pyramid -> FAST cells -> octree -> cull -> orientation + rBRIEF     (ORBextractor::operator(), all B frames per launch)
     Hamming best/second-best of every key point of frame b-1 against its window candidates in frame b
         (the inner loops of ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15); candidate windows built once
@@ -70,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (default: 8 streams x 8 consecutive frames)")
     ap.add_argument("--face", type=int, default=550)
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
@@ -126,13 +127,17 @@ def main():
     bas = [api.BundleAdjuster(prob, device=local_rank) for _ in range(n_ba)]
     ba_err = []
 
+    ba_ms = [0.0, 0]
+
     def ba_worker():
+        t_ba0 = time.perf_counter()
         try:
             for ba in bas:
                 ba.reset()
             api.ba_optimize_many(bas, (5, 10))   # all windows share every launch (kb_ba_* kernels, one window per blockIdx.z)
         except Exception as e:  # surfaced after join
             ba_err.append(e)
+        ba_ms[0] += 1e3 * (time.perf_counter() - t_ba0); ba_ms[1] += 1
 
     def step(i):
         ths = [threading.Thread(target=ba_worker)]
@@ -162,6 +167,7 @@ def main():
         step(i)
     stage_ms = {}
     barrier()
+    ba_ms[0], ba_ms[1] = 0.0, 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -196,10 +202,10 @@ def main():
     launches = nl.get(dom, 1)
     ach = alg[dom] * B / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms.get(dom, 0) > 0 else None
     # measured HBM traffic of that kernel: committed rocprofv3 PMC pass (FETCH_SIZE and WRITE_SIZE collected in separate runs,
-    # tools/run_profiles.sh), valid for the default workload only (B = 32, F = 550)
+    # tools/run_profiles.sh), valid for the default workload only (B = 64, F = 550)
     traffic = None
     pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pj) and B == 32 and F == 550:
+    if os.path.exists(pj) and B == 64 and F == 550:
         kk = json.load(open(pj))["kernels"].get(kname)
         if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
             traffic = int((kk["FETCH_SIZE"]["per_dispatch"] + kk["WRITE_SIZE"]["per_dispatch"]) * 1024)
@@ -208,6 +214,15 @@ def main():
             "ms_per_launch": round(stage_ms.get(dom, 0.0) / launches, 4), "algorithmic_bytes_per_launch": int(alg[dom] * B / launches),
             "all_stages_GBps": {k: round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in alg if stage_ms.get(k, 0) > 0}}
     fast_gbs = alg["fast"] * B / (stage_ms["fast"] * 1e-3) / 1e9 if stage_ms.get("fast", 0) > 0 else None
+    # whole ORBextractor::operator() against SURVEY.md 8(d)'s compulsory traffic at the reference's stage granularity
+    # (B_pyr + B_fast + B_blur + B_kp; the full-level blur pass is counted although the product never runs it)
+    b_extract = (2 * P[0] + sum(P[l - 1] + P[l] for l in range(1, g.nlevels))) + sumP + 2 * sumP + nkp * (709 + 961 + 32 + 28)
+    ext_ms = sum(stage_ms.get(k, 0.0) for k in ("pyramid", "fast", "octree", "cull", "describe"))
+    extractor = None
+    if ext_ms > 0:
+        ext_gbs = b_extract * B / (ext_ms * 1e-3) / 1e9
+        extractor = {"survey_bytes_per_frame": int(b_extract), "us_per_frame": round(1e3 * ext_ms / B, 2), "GBps": round(ext_gbs, 1),
+                     "frac_of_8TBps": round(ext_gbs / peak, 4)}
 
     # ---- CPU baseline: the oracle, single thread, on a bounded sample of the same workload (rank 0, N=1 only)
     cpu = None
@@ -265,7 +280,9 @@ def main():
                                    % (F, 3 * F, 3 * F, nfeat, B, nq, len(c_idx), n_ba, len(prob["e_pose"])),
                        "frames_per_step_per_gpu": B, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-                       "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1)},
+                       "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
+                       "extractor_vs_survey_bytes": extractor,
+                       "ba_windows_per_step": n_ba, "ba_ms_per_step": round(ba_ms[0] / max(ba_ms[1], 1), 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -150,7 +150,7 @@ static int ba_optimize_stage_many(cms_ba** bas, int n, std::vector<BaLm>& st, co
 // ---- batched variant: the windows share every launch (kb_ba_* kernels, blockIdx.z = window) and every synchronisation.
 // Used when all windows fit the fused trial path and live on one device; results are identical to the per-window path.
 static bool ba_can_batch(cms_ba** bas, int n) {
-  if (n < 2) return false;
+  if (n < 2 || n > BA_MAX_GROUP) return false;
   for (int w = 0; w < n; ++w) if (!bas[w]->solve_blk || bas[w]->device != bas[0]->device) return false;
   return true;
 }
@@ -164,29 +164,32 @@ static int ba_group_reserve(cms_ba* owner, int n) {
   HIPCHK(hipMalloc(&owner->grp_items_dev, (size_t)n * sizeof(BaItem)));
   HIPCHK(hipMalloc((void**)&owner->grp_scal_dev, (size_t)n * 8 * sizeof(double)));
   HIPCHK(hipHostMalloc(&owner->grp_items_host, (size_t)n * sizeof(BaItem)));
-  HIPCHK(hipHostMalloc((void**)&owner->grp_scal_host, (size_t)n * 8 * sizeof(double)));
-  size_t lds = 0;
+  HIPCHK(hipHostMalloc((void**)&owner->grp_scal_host, (size_t)n * 8 * sizeof(double)));   // device-visible: kernels publish into it
   owner->grp_cap = n;
-  (void)lds;
   return CMS_OK;
 }
-static void ba_fill_item(cms_ba* b, BaItem& it, double* scal, int phase, const BaLm* st, int set_level) {
-  it.d = b->d;
-  it.poses_cur = b->d_poses[b->cur]; it.pts_cur = b->d_pts[b->cur];
-  it.poses_nxt = b->d_poses[b->cur ^ 1]; it.pts_nxt = b->d_pts[b->cur ^ 1];
-  it.Hll = b->d_Hll; it.bl = b->d_bl; it.Hpl = b->d_Hpl; it.Hpp = b->d_Hpp; it.bp = b->d_bp; it.pose_partial = b->d_pose_partial;
-  it.Dinv = b->d_Dinv; it.db = b->d_db; it.chunk_sum = b->d_chunk_sum; it.x = b->d_x; it.partial = b->d_partial; it.scal = scal;
-  it.chunk_range = b->d_chunk_range; it.tup = b->d_tup; it.pair_of_block = b->d_pair_of_block; it.pair_chunk_off = b->d_pair_chunk_off;
-  it.flags = b->d_flags;
-  it.nblk_e = b->nblk_e; it.nblk_p = b->nblk_p; it.nchunks = b->nchunks;
-  it.first_iter = st ? (st->it == 0) : 0;
-  it.robust = st ? st->robust : 0; it.phase = phase; it.set_level = set_level; it.pad = 0;
-  it.lambda = st ? st->lambda : 0.0; it.delta = st ? st->delta : 0.0; it.chi2_th = 5.991;
+// static part of the windows' descriptions -> device, once per stage
+static int ba_upload_items(cms_ba** bas, int n) {
+  cms_ba* g = bas[0];
+  BaItem* items = reinterpret_cast<BaItem*>(g->grp_items_host);
+  for (int w = 0; w < n; ++w) {
+    cms_ba* b = bas[w];
+    BaItem& it = items[w];
+    it.d = b->d;
+    it.poses[0] = b->d_poses[0]; it.poses[1] = b->d_poses[1]; it.pts[0] = b->d_pts[0]; it.pts[1] = b->d_pts[1];
+    it.Hll = b->d_Hll; it.bl = b->d_bl; it.Hpl = b->d_Hpl; it.Hpp = b->d_Hpp; it.bp = b->d_bp; it.pose_partial = b->d_pose_partial;
+    it.Dinv = b->d_Dinv; it.db = b->d_db; it.chunk_sum = b->d_chunk_sum; it.x = b->d_x; it.partial = b->d_partial;
+    it.scal = g->grp_scal_dev + 8 * w; it.hscal = g->grp_scal_host + 8 * w;
+    it.chunk_range = b->d_chunk_range; it.tup = b->d_tup; it.pair_of_block = b->d_pair_of_block; it.pair_chunk_off = b->d_pair_chunk_off;
+    it.flags = b->d_flags;
+    it.nblk_e = b->nblk_e; it.nblk_p = b->nblk_p; it.nchunks = b->nchunks; it.pad = 0;
+  }
+  HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
+  return CMS_OK;
 }
 static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st, const volatile uint8_t* stop) {
   cms_ba* g = bas[0];
   hipStream_t s = g->stream;
-  BaItem* items = reinterpret_cast<BaItem*>(g->grp_items_host);
   const BaItem* ditems = reinterpret_cast<const BaItem*>(g->grp_items_dev);
   int max_e = 0, max_p = 0, max_K = 0, max_np = 0, max_chunks = 0, max_P = 0;
   size_t lds = 0;
@@ -196,39 +199,41 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
     lds = std::max(lds, bas[w]->blk_lds);
   }
   HIPCHK(hipFuncSetAttribute((const void*)kb_ba_trial_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  std::vector<int> phase(n);
+  int rc = ba_upload_items(bas, n);
+  if (rc) return rc;
+  BaDyn dyn;
+  memset(&dyn, 0, sizeof(dyn));
+  dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0;
   for (;;) {
     int n_iter = 0, n_trial = 0;
     for (int w = 0; w < n; ++w) {
-      phase[w] = BA_PHASE_IDLE;
+      dyn.phase[w] = BA_PHASE_IDLE;
       if (st[w].next == 0 && (st[w].it >= st[w].iterations || ba_stopped(stop))) st[w].next = 2;
-      if (st[w].next == 0) { phase[w] = BA_PHASE_ITER; ++n_iter; }
-      else if (st[w].next == 1) { phase[w] = BA_PHASE_TRIAL; ++n_trial; }
-      ba_fill_item(bas[w], items[w], g->grp_scal_dev + 8 * w, phase[w], &st[w], 0);
+      if (st[w].next == 0) { dyn.phase[w] = BA_PHASE_ITER; ++n_iter; }
+      else if (st[w].next == 1) { dyn.phase[w] = BA_PHASE_TRIAL; ++n_trial; }
+      dyn.cur[w] = (uint8_t)bas[w]->cur; dyn.first_iter[w] = st[w].it == 0; dyn.lambda[w] = st[w].lambda;
     }
     if (n_iter + n_trial == 0) break;
-    HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, s));
     if (n_iter) {
-      hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_lin_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_lin_poses, dim3(max_K, BA_POSE_CHUNKS, n), dim3(256), 0, s, ditems, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_pose_finish, dim3(std::max(max_np, 1), 1, n), dim3(64), 0, s, ditems, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(64, 1, n), dim3(256), 0, s, ditems, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_lin_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_lin_poses, dim3(max_K, BA_POSE_CHUNKS, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_pose_finish, dim3(std::max(max_np, 1), 1, n), dim3(64), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
     }
     if (n_trial) {
-      hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, (int)BA_PHASE_TRIAL);
-      if (max_chunks > 0) hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, (int)BA_PHASE_TRIAL);
-      hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, (int)BA_PHASE_TRIAL);
-      hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, (int)BA_PHASE_TRIAL);
-      hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, (int)BA_PHASE_TRIAL);
+      hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (max_chunks > 0) hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
     }
-    HIPCHK(hipMemcpyAsync(g->grp_scal_host, g->grp_scal_dev, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipStreamSynchronize(s));          // the last kernel of each phase wrote the scalars into the pinned mirror
     for (int w = 0; w < n; ++w) {
-      if (phase[w] == BA_PHASE_IDLE) continue;
+      if (dyn.phase[w] == BA_PHASE_IDLE) continue;
       memcpy(bas[w]->h_pin, g->grp_scal_host + 8 * w, 8 * sizeof(double));
-      if (phase[w] == BA_PHASE_ITER) ba_finish_iter_start(bas[w], st[w]);
+      if (dyn.phase[w] == BA_PHASE_ITER) ba_finish_iter_start(bas[w], st[w]);
       else ba_finish_trial(bas[w], st[w], stop);
     }
   }
@@ -238,15 +243,18 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
 static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<std::vector<uint8_t>>& flags) {
   cms_ba* g = bas[0];
   hipStream_t s = g->stream;
-  BaItem* items = reinterpret_cast<BaItem*>(g->grp_items_host);
+  int rc = ba_upload_items(bas, n);
+  if (rc) return rc;
+  BaDyn dyn;
+  memset(&dyn, 0, sizeof(dyn));
+  dyn.chi2_th = 5.991; dyn.set_level = set_level;
   int max_e = 0;
   for (int w = 0; w < n; ++w) {
-    ba_fill_item(bas[w], items[w], g->grp_scal_dev + 8 * w, BA_PHASE_CLASSIFY, nullptr, set_level);
+    dyn.phase[w] = BA_PHASE_CLASSIFY; dyn.cur[w] = (uint8_t)bas[w]->cur;
     max_e = std::max(max_e, bas[w]->nblk_e);
     flags[w].resize(bas[w]->E);
   }
-  HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(kb_ba_classify, dim3(max_e, 1, n), dim3(256), 0, s, reinterpret_cast<const BaItem*>(g->grp_items_dev), (int)BA_PHASE_CLASSIFY);
+  hipLaunchKernelGGL(kb_ba_classify, dim3(max_e, 1, n), dim3(256), 0, s, reinterpret_cast<const BaItem*>(g->grp_items_dev), dyn, (int)BA_PHASE_CLASSIFY);
   for (int w = 0; w < n; ++w) HIPCHK(hipMemcpyAsync(flags[w].data(), bas[w]->d_flags, bas[w]->E, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return CMS_OK;

@@ -338,11 +338,16 @@ __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, co
 }
 
 // scal[1] = sum(partial[0..n)), scal[2] = sum(partial[n..2n)) + scal[5]
-__device__ __forceinline__ void ba_reduce2_body(int BX, int GX, const double* __restrict__ partial, int n, double* __restrict__ scal) {
+__device__ __forceinline__ void ba_reduce2_body(int BX, int GX, const double* __restrict__ partial, int n, double* __restrict__ scal,
+                                                double* __restrict__ hscal = nullptr) {
   __shared__ double sh[4];
   double v1 = 0, v2 = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) { v1 += partial[i]; v2 += partial[n + i]; }
   const double s1 = block_sum(v1, sh);
   const double s2 = block_sum(v2, sh);
-  if (threadIdx.x == 0) { scal[1] = s1; scal[2] = s2 + scal[5]; }
+  if (threadIdx.x == 0) {
+    const double den = s2 + scal[5];
+    scal[1] = s1; scal[2] = den;
+    if (hscal) { hscal[1] = s1; hscal[2] = den; hscal[4] = scal[4]; }   // pinned host mirror (batched driver)
+  }
 }

@@ -10,16 +10,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define BA_MAX_GROUP 64
+// static description of one window (device resident, uploaded once per optimisation stage) ...
 struct BaItem {
   BaDev d;
-  const double* poses_cur; const double* pts_cur; double* poses_nxt; double* pts_nxt;
+  double* poses[2]; double* pts[2];          // estimate double buffer; BaDyn::cur says which one is current
   double* Hll; double* bl; double* Hpl; double* Hpp; double* bp; double* pose_partial; double* Dinv; double* db;
   double* chunk_sum; double* x; double* partial; double* scal;
+  double* hscal;                             // pinned host mirror of scal[0..6), written by the last kernel of a phase
   const int2* chunk_range; const int2* tup; const int* pair_of_block; const int* pair_chunk_off;
   uint8_t* flags;
-  int nblk_e, nblk_p, nchunks, first_iter;
-  int robust, phase, set_level, pad;
-  double lambda, delta, chi2_th;
+  int nblk_e, nblk_p, nchunks, pad;
+};
+// ... and what changes from launch to launch, passed BY VALUE as a kernel argument: no host->device copy per Levenberg step
+struct BaDyn {
+  double lambda[BA_MAX_GROUP];
+  uint8_t phase[BA_MAX_GROUP], cur[BA_MAX_GROUP], first_iter[BA_MAX_GROUP];
+  int robust, set_level;
+  double delta, chi2_th;
 };
 enum { BA_PHASE_IDLE = 0, BA_PHASE_ITER = 1, BA_PHASE_TRIAL = 2, BA_PHASE_CLASSIFY = 3 };
 
@@ -69,60 +77,74 @@ extern "C" __global__ void __launch_bounds__(256)
 k_ba_reduce2(const double* partial, int n, double* scal) { ba_reduce2_body(blockIdx.x, gridDim.x, partial, n, scal); }
 
 // ------------------------------------------------------------------------------------------------ many windows per launch
-#define BA_ITEM(PHASE, NBLK)                       \
-  const BaItem& it = items[blockIdx.z];            \
-  if (it.phase != (PHASE) || (int)blockIdx.x >= (NBLK)) return;
+#define BA_ITEM(PHASE, NBLK)                                               \
+  const int z = blockIdx.z;                                                \
+  const BaItem& it = items[z];                                             \
+  if (dyn.phase[z] != (PHASE) || (int)blockIdx.x >= (NBLK)) return;        \
+  const int cur = dyn.cur[z], nxt = cur ^ 1;                               \
+  (void)nxt;
 
-extern "C" __global__ void __launch_bounds__(256) kb_ba_errors(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(256) kb_ba_errors(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_e)
-  ba_errors_body(blockIdx.x, it.nblk_e, it.d, it.poses_cur, it.pts_cur, it.robust, it.delta, it.partial);
+  ba_errors_body(blockIdx.x, it.nblk_e, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.partial);
 }
-// chi2 of the current estimate -> scal[0]; also clears the max-diagonal slot before kb_ba_maxdiag accumulates into it
-extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce(const BaItem* __restrict__ items, int phase) {
+// chi2 of the current estimate -> scal[0]
+extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
   ba_reduce_body(0, 1, it.partial, it.nblk_e, it.scal, 0);
-  if (threadIdx.x == 0 && it.first_iter) it.scal[3] = 0.0;
 }
-extern "C" __global__ void __launch_bounds__(128) kb_ba_lin_points(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(128) kb_ba_lin_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
-  ba_lin_points_body(blockIdx.x, it.nblk_p, it.d, it.poses_cur, it.pts_cur, it.robust, it.delta, it.Hll, it.bl, it.Hpl);
+  ba_lin_points_body(blockIdx.x, it.nblk_p, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.Hll, it.bl, it.Hpl);
 }
-extern "C" __global__ void __launch_bounds__(256) kb_ba_lin_poses(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(256) kb_ba_lin_poses(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.d.K)        // blockIdx.y = slice of the pose's edge list
-  ba_lin_poses_body(blockIdx.x, it.d.K, it.d, it.poses_cur, it.pts_cur, it.robust, it.delta, it.pose_partial);
+  ba_lin_poses_body(blockIdx.x, it.d.K, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.pose_partial);
 }
-extern "C" __global__ void __launch_bounds__(64) kb_ba_pose_finish(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(64) kb_ba_pose_finish(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.d.np)
   ba_pose_finish_body(blockIdx.x, it.d.np, it.d.np, it.pose_partial, it.Hpp, it.bp);
 }
-extern "C" __global__ void __launch_bounds__(256) kb_ba_maxdiag(const BaItem* __restrict__ items, int phase) {
-  BA_ITEM(phase, (int)gridDim.x)
-  if (!it.first_iter) return;
-  ba_maxdiag_body(blockIdx.x, gridDim.x, it.d.np, it.d.P, it.Hpp, it.Hll, it.scal + 3);
+// last kernel of the ITER phase, one workgroup per window: computeLambdaInit's max diagonal on the first iteration, then the
+// phase's scalars are published to the pinned host mirror (the host only has to wait for the stream, no D2H copy)
+extern "C" __global__ void __launch_bounds__(256) kb_ba_maxdiag(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, 1)
+  __shared__ double shm[4];
+  if (dyn.first_iter[z]) {
+    double m = 0;
+    for (int i = threadIdx.x; i < 6 * it.d.np; i += 256) m = fmax(m, fabs(it.Hpp[36 * (i / 6) + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < 3 * it.d.P; i += 256) m = fmax(m, fabs(it.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { const double mx = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3])); it.scal[3] = mx; it.hscal[3] = mx; }
+  }
+  if (threadIdx.x == 0) it.hscal[0] = it.scal[0];
 }
-extern "C" __global__ void __launch_bounds__(256) kb_ba_dinv(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(256) kb_ba_dinv(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, (it.d.P + 255) / 256)
-  ba_dinv_body(blockIdx.x, 0, it.d.P, it.Hll, it.bl, it.lambda, it.Dinv, it.db);
+  ba_dinv_body(blockIdx.x, 0, it.d.P, it.Hll, it.bl, dyn.lambda[z], it.Dinv, it.db);
 }
-extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nchunks)
   ba_schur_chunks_body(blockIdx.x, it.nchunks, it.d, it.chunk_range, it.tup, it.Hpl, it.Dinv, it.db, it.chunk_sum);
 }
-extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
-  ba_trial_solve_body(0, 1, it.d, it.Hpp, it.bp, it.lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses_cur, it.poses_nxt,
+  ba_trial_solve_body(0, 1, it.d, it.Hpp, it.bp, dyn.lambda[z], it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt],
                       it.x, it.scal);
 }
-extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
-  ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, it.lambda, it.pts_cur, it.pts_nxt, it.poses_nxt, it.robust,
-                       it.delta, it.partial);
+  ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, dyn.lambda[z], it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
+                       dyn.delta, it.partial);
 }
-extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, int phase) {
+// last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
+extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
-  ba_reduce2_body(0, 1, it.partial, it.nblk_p, it.scal);
+  ba_reduce2_body(0, 1, it.partial, it.nblk_p, it.scal, it.hscal);
 }
-extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* __restrict__ items, int phase) {
+extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_e)
-  ba_classify_body(blockIdx.x, it.nblk_e, it.d, it.poses_cur, it.pts_cur, it.chi2_th, it.set_level, it.flags);
+  ba_classify_body(blockIdx.x, it.nblk_e, it.d, it.poses[cur], it.pts[cur], dyn.chi2_th, dyn.set_level, it.flags);
 }
