@@ -94,6 +94,17 @@ def lib():
         L.cms_ba_linearize.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                        C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 7
+        L.cms_pose_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.cms_pose_destroy.argtypes = [C.c_void_p]
+        L.cms_pose_destroy.restype = None
+        L.cms_pose_stream.argtypes = [C.c_void_p]
+        L.cms_pose_stream.restype = C.c_void_p
+        _edge = [C.c_void_p] * 5 + [C.c_double] * 4
+        L.cms_pose_upload.argtypes = [C.c_void_p, C.c_int] + _edge + [C.c_void_p]
+        L.cms_pose_launch.argtypes = [C.c_void_p]
+        L.cms_pose_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_pose_optimize_batch.argtypes = [C.c_void_p, C.c_int] + _edge + [C.c_void_p] * 4
+        L.cms_pose_optimize.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_double] * 4 + [C.c_void_p] * 4
         _lib = L
     return _lib
 
@@ -346,3 +357,68 @@ def ba_linearize(prob, robust=True, delta=float(np.sqrt(5.991)), device=0):
                                 prob["fx"], prob["fy"], prob["cx"], prob["cy"], 1 if robust else 0, float(delta), _p(o["err"]),
                                 _p(o["Hpp"]), _p(o["bp"]), _p(o["Hll"]), _p(o["bl"]), _p(o["Hpl"]), _p(o["chi"])), "cms_ba_linearize")
     return o
+
+
+class PoseStats(C.Structure):
+    _fields_ = [("rounds", C.c_int), ("n_bad", C.c_int), ("iterations_done", C.c_int * 4)]
+
+
+class PoseOptimizer:
+    """Optimizer::PoseOptimization for a batch of frames (cms_pose_*): problems are dicts like synth.pose_problem()."""
+
+    def __init__(self, max_frames, max_edges, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().cms_pose_create(C.byref(self.h), device, max_frames, max_edges), "cms_pose_create")
+        self.nf = 0
+
+    def close(self):
+        if self.h:
+            lib().cms_pose_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self):
+        return lib().cms_pose_stream(self.h)
+
+    def upload(self, probs):
+        self.nf = len(probs)
+        cnt = [len(p["Xw"]) for p in probs]
+        self.off = np.zeros(self.nf + 1, np.int32); self.off[1:] = np.cumsum(cnt)
+        cat = lambda k, dt, w: (np.ascontiguousarray(np.concatenate([np.asarray(p[k], dt).reshape(-1, w) for p in probs]), dt)
+                                if self.off[-1] else np.zeros((0, w), dt))
+        Xw, obs, inv, face = cat("Xw", np.float64, 3), cat("obs", np.float64, 2), cat("invsig2", np.float64, 1), cat("face", np.int8, 1)
+        poses = np.ascontiguousarray(np.stack([p["pose0"] for p in probs]), np.float64)
+        p0 = probs[0]
+        _chk(lib().cms_pose_upload(self.h, self.nf, _p(self.off), _p(Xw), _p(obs), _p(inv), _p(face), p0["fx"], p0["fy"], p0["cx"],
+                                   p0["cy"], _p(poses)), "cms_pose_upload")
+
+    def launch(self):
+        _chk(lib().cms_pose_launch(self.h), "cms_pose_launch")
+
+    def fetch(self):
+        poses = np.zeros((self.nf, 7)); out = np.zeros(max(int(self.off[-1]), 1), np.uint8)
+        ninl = np.zeros(self.nf, np.int32); st = (PoseStats * self.nf)()
+        _chk(lib().cms_pose_fetch(self.h, _p(poses), _p(out), _p(ninl), C.byref(st)), "cms_pose_fetch")
+        outs = [out[self.off[f]:self.off[f + 1]].copy() for f in range(self.nf)]
+        return ninl, poses, outs, list(st)
+
+    def optimize(self, probs):
+        self.upload(probs); self.launch()
+        return self.fetch()
+
+
+def pose_optimize(prob, n=None, device=0):
+    """One frame through the one-shot entry point cms_pose_optimize; returns (n_inliers, pose7, outlier flags, stats)."""
+    n = len(prob["Xw"]) if n is None else n
+    pose = np.array(prob["pose0"], np.float64, copy=True)
+    out = np.zeros(max(n, 1), np.uint8); ninl = np.zeros(1, np.int32); st = PoseStats()
+    Xw = np.ascontiguousarray(prob["Xw"][:n], np.float64); obs = np.ascontiguousarray(prob["obs"][:n], np.float64)
+    inv = np.ascontiguousarray(prob["invsig2"][:n], np.float64); face = np.ascontiguousarray(prob["face"][:n], np.int8)
+    _chk(lib().cms_pose_optimize(device, n, _p(Xw), _p(obs), _p(inv), _p(face), prob["fx"], prob["fy"], prob["cx"], prob["cy"],
+                                 _p(pose), _p(out), _p(ninl), C.byref(st)), "cms_pose_optimize")
+    return int(ninl[0]), pose, out[:n], st

@@ -1,0 +1,118 @@
+// cms_api_pose.hip -- host side of the pose-only optimisation (Optimizer::PoseOptimization, Optimizer.cpp:48-190).
+// Persistent device buffers + one stream per handle; a batch of frames is one launch of k_pose_optimize (cms_pose_opt.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "../../include/cubemapslam_hip.h"
+
+struct cms_pose {
+  int device = 0, cap_f = 0, cap_e = 0, nf = 0, ne = 0;
+  hipStream_t stream = nullptr;
+  int* d_off = nullptr; double* d_Xw = nullptr; double* d_obs = nullptr; double* d_inv = nullptr; int8_t* d_face = nullptr;
+  uint8_t* d_out = nullptr; double* d_err = nullptr; double* d_poses = nullptr; double* d_poses0 = nullptr; int* d_res = nullptr;
+  double fx = 0, fy = 0, cx = 0, cy = 0;
+};
+
+static void cms_pose_free(cms_pose* p) {
+  if (!p) return;
+  hipSetDevice(p->device);
+  void* ptrs[] = {p->d_off, p->d_Xw, p->d_obs, p->d_inv, p->d_face, p->d_out, p->d_err, p->d_poses, p->d_poses0, p->d_res};
+  for (void* q : ptrs) if (q) hipFree(q);
+  if (p->stream) hipStreamDestroy(p->stream);
+  delete p;
+}
+
+extern "C" int cms_pose_create(cms_pose** out, int device, int max_frames, int max_edges) {
+  if (!out || max_frames < 1 || max_edges < 1) return cms_fail(CMS_ERR_ARG, "cms_pose_create: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+    return cms_fail(CMS_ERR_NO_DEVICE, "cms_pose_create: no HIP device (the pose optimisation has no CPU fallback)");
+  HIPCHK(hipSetDevice(device));
+  cms_pose* p = new cms_pose();
+  p->device = device; p->cap_f = max_frames; p->cap_e = max_edges;
+#define PALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { cms_pose_free(p); return cms_fail(CMS_ERR_HIP, "hipMalloc " #ptr); } } while (0)
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { cms_pose_free(p); return cms_fail(CMS_ERR_HIP, "hipStreamCreate"); }
+  PALLOC(p->d_off, ((size_t)max_frames + 1) * sizeof(int));
+  PALLOC(p->d_Xw, (size_t)max_edges * 3 * sizeof(double)); PALLOC(p->d_obs, (size_t)max_edges * 2 * sizeof(double));
+  PALLOC(p->d_inv, (size_t)max_edges * sizeof(double)); PALLOC(p->d_face, (size_t)max_edges);
+  PALLOC(p->d_out, (size_t)max_edges); PALLOC(p->d_err, (size_t)max_edges * 2 * sizeof(double));
+  PALLOC(p->d_poses, (size_t)max_frames * 7 * sizeof(double)); PALLOC(p->d_poses0, (size_t)max_frames * 7 * sizeof(double));
+  PALLOC(p->d_res, (size_t)max_frames * 8 * sizeof(int));
+#undef PALLOC
+  *out = p;
+  return CMS_OK;
+}
+extern "C" void cms_pose_destroy(cms_pose* p) { cms_pose_free(p); }
+extern "C" void* cms_pose_stream(cms_pose* p) { return p ? (void*)p->stream : nullptr; }
+
+extern "C" int cms_pose_upload(cms_pose* p, int nf, const int* edge_off, const double* Xw, const double* obs_uv, const double* inv_sigma2,
+                               const int8_t* face, double fx, double fy, double cx, double cy, const double* poses7) {
+  if (!p || nf < 1 || nf > p->cap_f || !edge_off || !poses7) return cms_fail(CMS_ERR_ARG, "cms_pose_upload: bad argument");
+  const int ne = edge_off[nf];
+  if (edge_off[0] != 0 || ne < 0 || ne > p->cap_e) return cms_fail(CMS_ERR_ARG, "cms_pose_upload: edge count exceeds the handle's capacity");
+  for (int f = 0; f < nf; ++f) if (edge_off[f + 1] < edge_off[f]) return cms_fail(CMS_ERR_ARG, "cms_pose_upload: edge_off must not decrease");
+  if (ne > 0 && (!Xw || !obs_uv || !inv_sigma2 || !face)) return cms_fail(CMS_ERR_ARG, "cms_pose_upload: null edge array");
+  for (int e = 0; e < ne; ++e) if (face[e] < 0 || face[e] > 4) return cms_fail(CMS_ERR_ARG, "cms_pose_upload: edge on an unknown face");   // the reference exits
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  HIPCHK(hipMemcpyAsync(p->d_off, edge_off, ((size_t)nf + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  if (ne > 0) {
+    HIPCHK(hipMemcpyAsync(p->d_Xw, Xw, (size_t)ne * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p->d_obs, obs_uv, (size_t)ne * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p->d_inv, inv_sigma2, (size_t)ne * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p->d_face, face, (size_t)ne, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(hipMemcpyAsync(p->d_poses0, poses7, (size_t)nf * 7 * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));       // the caller's arrays may be temporaries
+  p->nf = nf; p->ne = ne; p->fx = fx; p->fy = fy; p->cx = cx; p->cy = cy;
+  return CMS_OK;
+}
+extern "C" int cms_pose_launch(cms_pose* p) {
+  if (!p || p->nf < 1) return cms_fail(CMS_ERR_ARG, "cms_pose_launch: nothing uploaded");
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  HIPCHK(hipMemcpyAsync(p->d_poses, p->d_poses0, (size_t)p->nf * 7 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  PoseDev d;
+  d.nf = p->nf; d.off = p->d_off; d.Xw = p->d_Xw; d.obs = p->d_obs; d.inv = p->d_inv; d.face = p->d_face; d.outlier = p->d_out;
+  d.err = p->d_err; d.poses = p->d_poses; d.result = p->d_res; d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy;
+  hipLaunchKernelGGL(k_pose_optimize, dim3(p->nf), dim3(256), 0, s, d);
+  HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+extern "C" int cms_pose_fetch(cms_pose* p, double* poses7, uint8_t* outlier, int* n_inliers, cms_pose_stats* stats) {
+  if (!p || p->nf < 1) return cms_fail(CMS_ERR_ARG, "cms_pose_fetch: nothing launched");
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  std::vector<int> res((size_t)p->nf * 8);
+  HIPCHK(hipMemcpyAsync(res.data(), p->d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (poses7) HIPCHK(hipMemcpyAsync(poses7, p->d_poses, (size_t)p->nf * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (outlier && p->ne > 0) HIPCHK(hipMemcpyAsync(outlier, p->d_out, (size_t)p->ne, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int f = 0; f < p->nf; ++f) {
+    if (n_inliers) n_inliers[f] = res[8 * f];
+    if (stats) { stats[f].n_bad = res[8 * f + 1]; stats[f].rounds = res[8 * f + 2]; for (int i = 0; i < 4; ++i) stats[f].iterations_done[i] = res[8 * f + 4 + i]; }
+  }
+  return CMS_OK;
+}
+extern "C" int cms_pose_optimize_batch(cms_pose* p, int nf, const int* edge_off, const double* Xw, const double* obs_uv, const double* inv_sigma2,
+                                       const int8_t* face, double fx, double fy, double cx, double cy, double* poses7, uint8_t* outlier,
+                                       int* n_inliers, cms_pose_stats* stats) {
+  int rc = cms_pose_upload(p, nf, edge_off, Xw, obs_uv, inv_sigma2, face, fx, fy, cx, cy, poses7);
+  if (rc) return rc;
+  rc = cms_pose_launch(p);
+  if (rc) return rc;
+  return cms_pose_fetch(p, poses7, outlier, n_inliers, stats);
+}
+extern "C" int cms_pose_optimize(int device, int n, const double* Xw, const double* obs_uv, const double* inv_sigma2, const int8_t* face,
+                                 double fx, double fy, double cx, double cy, double* pose7, uint8_t* outlier, int* n_inliers,
+                                 cms_pose_stats* stats) {
+  if (n < 0 || !pose7) return cms_fail(CMS_ERR_ARG, "cms_pose_optimize: bad argument");
+  cms_pose* p = nullptr;
+  int rc = cms_pose_create(&p, device, 1, n > 0 ? n : 1);
+  if (rc) return rc;
+  const int off[2] = {0, n};
+  rc = cms_pose_optimize_batch(p, 1, off, Xw, obs_uv, inv_sigma2, face, fx, fy, cx, cy, pose7, outlier, n_inliers, stats);
+  cms_pose_free(p);
+  return rc;
+}

@@ -5,5 +5,7 @@
 #include "cms_ba_kernels.hip"
 #include "cms_ba_fused.hip"
 #include "cms_ba_wrappers.hip"
+#include "cms_pose_opt.hip"
 #include "cms_api_frames.hip"
 #include "cms_api_ba.hip"
+#include "cms_api_pose.hip"

@@ -229,6 +229,49 @@ static void R_to_quat(const double m[9], double* q) {  // Eigen::Quaterniond(Mat
     q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t; q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
   }
 }
+int Optimizer::PoseOptimization(PoseFrame* fr) {
+  CamModelGeneral* cam = CamModelGeneral::GetCamera();
+  const int N = fr->N;
+  fr->mvbOutlier.resize(N);
+  std::vector<double> Xw, obs, inv;
+  std::vector<int8_t> face;
+  std::vector<int> index;
+  int nInitialCorrespondences = 0;
+  for (int i = 0; i < N; ++i) {
+    if (fr->mvKeyRays[i](2) < cam->GetCosFovTh()) continue;                      // Optimizer.cpp:83-85
+    if (!fr->mvbHasMapPoint[i]) continue;
+    ++nInitialCorrespondences;
+    fr->mvbOutlier[i] = false;
+    const cv::KeyPoint& kp = fr->mvKeys[i];
+    const int f = cam->FaceInCubemap(kp.pt);                                      // :103
+    if (f == CamModelGeneral::UNKNOWN_FACE) throw std::runtime_error("PoseOptimization: key point on an unknown face");   // the reference exits
+    double u, v;
+    cam->GetPosInFace(u, v, (double)kp.pt.x, (double)kp.pt.y);                     // :104-106
+    obs.push_back(u); obs.push_back(v);
+    inv.push_back((double)fr->mvInvLevelSigma2[kp.octave]);                        // :107-108
+    face.push_back((int8_t)f);
+    for (int k = 0; k < 3; ++k) Xw.push_back((double)fr->mvMapPointPos[i](k));     // :118-121
+    index.push_back(i);
+  }
+  if (nInitialCorrespondences < 3) return 0;                                       // :131-132
+  double pose[7], R[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = fr->mTcw.at<float>(r, c);   // Converter::toSE3Quat
+  for (int r = 0; r < 3; ++r) pose[r] = fr->mTcw.at<float>(r, 3);
+  R_to_quat(R, pose + 3);
+  const int n = (int)index.size();
+  std::vector<uint8_t> out(n);
+  int ninl = 0;
+  const double f = cam->Get_fx();
+  const int rc = cms_pose_optimize(0, n, Xw.data(), obs.data(), inv.data(), face.data(), f, f, f, f, pose, out.data(), &ninl, nullptr);
+  if (rc < 0) throw std::runtime_error(std::string("cms_pose_optimize: ") + cms_last_error());
+  for (int e = 0; e < n; ++e) fr->mvbOutlier[index[e]] = out[e] != 0;
+  const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];                  // Converter::toCvMat(SE3Quat) -> float 4x4
+  const double Ro[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) fr->mTcw.at<float>(r, c) = (float)Ro[3 * r + c]; fr->mTcw.at<float>(r, 3) = (float)pose[r]; }
+  return ninl;
+}
+
 void Optimizer::LocalBundleAdjustment(LocalBAWindow* win, bool* pbStopFlag) {
   CamModelGeneral* cam = CamModelGeneral::GetCamera();
   const int K = (int)win->keyframes.size(), P = (int)win->mappoints.size();

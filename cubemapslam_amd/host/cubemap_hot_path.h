@@ -116,8 +116,26 @@ struct LocalBAWindow {
   std::vector<std::pair<int, int>> toErase;   // out: (keyframe index, map point index) observations to erase
 };
 
+// The members of Frame that Optimizer::PoseOptimization reads and writes (Frame.h: mTcw, N, mvKeys, mvKeyRays, mvpMapPoints,
+// mvbOutlier, mvInvLevelSigma2); a map point is represented by its world position (MapPoint::GetWorldPos()).
+struct PoseFrame {
+  cv::Mat mTcw;                                 // 4x4 CV_32F, in/out (Frame::SetPose)
+  int N = 0;
+  std::vector<cv::KeyPoint> mvKeys;
+  std::vector<cv::Vec3f> mvKeyRays;
+  std::vector<bool> mvbHasMapPoint;             // mvpMapPoints[i] != NULL
+  std::vector<cv::Vec3f> mvMapPointPos;         // pMP->GetWorldPos() where mvbHasMapPoint[i]
+  std::vector<bool> mvbOutlier;                 // out
+  std::vector<float> mvInvLevelSigma2;
+};
+
 class Optimizer {
  public:
+  // Optimizer.cpp:48-190: edges collected exactly like :80-127 (rays with z < cosFovTh skipped, face + in-face measurement of
+  // the key point, invSigma2 of its octave, map point through float), the four optimisation rounds run in one GPU kernel
+  // (cms_pose_optimize), the pose is written back through float (Converter::toCvMat).  Returns nInitialCorrespondences - nBad.
+  static int PoseOptimization(PoseFrame* pFrame);
+
   // Optimizer.cpp:192-451 with the graph already collected: builds the edge list exactly like :246-357 (fixed = mnId==0 or
   // fixed KF, rays with z < cosFovTh skipped, face + in-face measurement from the key point, invSigma2 of the octave),
   // runs optimize(5) / classify / optimize(10) on the GPU, writes poses and points back through float (Converter.cpp:53-104)

@@ -95,3 +95,23 @@ extern "C" int hm_local_ba(int K, float* Tcw, const long* kf_id, const uint8_t* 
     for (int i = 0; i < n && i < erase_cap; ++i) { erase_pairs[2 * i] = w.toErase[i].first; erase_pairs[2 * i + 1] = w.toErase[i].second; }
     return n;)
 }
+
+// Optimizer::PoseOptimization on a Frame given as flat arrays: Tcw 4x4 float in/out, N key points (x, y, octave), rays N x 3,
+// has_mp N, Xw N x 3 (float), inv_sigma2[nlevels]; outlier N out.  Returns the reference's return value.
+extern "C" int hm_pose_optimization(float* Tcw, int N, const cms_keypoint* kps, const float* rays, const uint8_t* has_mp, const float* Xw,
+                                    const float* inv_sigma2, int nlevels, uint8_t* outlier) {
+  HM_TRY(
+    PoseFrame fr;
+    fr.mTcw = cv::Mat(4, 4, cv::CV_32F, Tcw, 16);
+    fr.N = N;
+    fr.mvKeys.resize(N); fr.mvKeyRays.resize(N); fr.mvbHasMapPoint.resize(N); fr.mvMapPointPos.resize(N);
+    for (int i = 0; i < N; ++i) {
+      fr.mvKeys[i].pt = cv::Point2f(kps[i].x, kps[i].y); fr.mvKeys[i].octave = kps[i].octave;
+      for (int k = 0; k < 3; ++k) { fr.mvKeyRays[i].v[k] = rays[3 * i + k]; fr.mvMapPointPos[i].v[k] = Xw[3 * i + k]; }
+      fr.mvbHasMapPoint[i] = has_mp[i] != 0;
+    }
+    fr.mvInvLevelSigma2.assign(inv_sigma2, inv_sigma2 + nlevels);
+    const int r = Optimizer::PoseOptimization(&fr);
+    for (int i = 0; i < N; ++i) outlier[i] = (i < (int)fr.mvbOutlier.size() && fr.mvbOutlier[i]) ? 1 : 0;
+    return r;)
+}

@@ -210,6 +210,41 @@ def ba_problem(K=20, P=20000, obs_per_point=4, F=650, seed=42, outlier_frac=0.05
                 fx=F / 2.0, fy=F / 2.0, cx=F / 2.0, cy=F / 2.0)
 
 
+def pose_problem(N=600, F=550, seed=7, outlier_frac=0.1, nlevels=8, scale=1.2, rot_deg=1.5, trans=0.05):
+    """One frame of Optimizer::PoseOptimization (SURVEY.md 8f-1): N map points seen on the five faces, pixel noise growing
+    with the octave, `outlier_frac` gross mismatches, initial pose = ground truth perturbed by rot_deg / trans.
+    Returns the edge arrays the C-ABI takes plus the ground-truth pose."""
+    rs = np.random.RandomState(seed)
+    a = 0.3 * rs.uniform(-1, 1)
+    Rcw = (_rot([0, 1, 0], a) @ _rot([1, 0, 0], 0.1 * rs.uniform(-1, 1))).T
+    tcw = -Rcw @ np.array([0.4 * rs.uniform(-1, 1), 0.1 * rs.uniform(-1, 1), 0.3 * rs.uniform(-1, 1)])
+    M = 4 * N + 64
+    pts = np.stack([rs.uniform(-6, 6, M), rs.uniform(-3, 3, M), rs.uniform(-2, 9, M)], -1)
+    pts = pts.astype(np.float32).astype(np.float64)           # map points are float cv::Mat in the reference
+    Xc = pts @ Rcw.T + tcw
+    ray_z = Xc[:, 2] / np.linalg.norm(Xc, axis=1)
+    face, up, vp = rays_to_cubemap(F, Xc)
+    octave = rs.randint(0, nlevels, size=M)
+    gross = rs.uniform(size=M) < outlier_frac
+    noise = np.where(gross[:, None], rs.uniform(-40, 40, size=(M, 2)), rs.normal(0, 1, size=(M, 2)) * (scale ** octave)[:, None])
+    px = (up + noise[:, 0]).astype(np.float32).astype(np.float64)
+    py = (vp + noise[:, 1]).astype(np.float32).astype(np.float64)
+    f2 = face_of_pixel(F, px, py)
+    ok = (face >= 0) & (f2 >= 0) & (ray_z >= np.cos(np.deg2rad(190.0 / 2))) & (np.linalg.norm(Xc, axis=1) > 1.0)
+    sel = np.nonzero(ok)[0][:N]
+    sig2 = (np.float32(scale) ** np.arange(nlevels, dtype=np.float32)) ** 2
+    inv_tab = (np.float32(1.0) / sig2).astype(np.float32)
+    u = px[sel] - np.floor(px[sel] / F) * F
+    v = py[sel] - np.floor(py[sel] / F) * F
+    R0 = _rot(rs.normal(size=3), np.deg2rad(rot_deg) * rs.uniform(0.5, 1.0)) @ Rcw
+    t0 = tcw + rs.normal(0, trans, 3)
+    pose0 = np.concatenate([t0.astype(np.float32).astype(np.float64), _quat_from_R(R0.astype(np.float32).astype(np.float64))])
+    pose_gt = np.concatenate([tcw, _quat_from_R(Rcw)])
+    return dict(Xw=np.ascontiguousarray(pts[sel]), obs=np.ascontiguousarray(np.stack([u, v], 1)),
+                invsig2=inv_tab[octave[sel]].astype(np.float64), face=f2[sel].astype(np.int8), gross=gross[sel],
+                pose0=pose0, pose_gt=pose_gt, fx=F / 2.0, fy=F / 2.0, cx=F / 2.0, cy=F / 2.0)
+
+
 def descriptors(n, seed):
     return np.random.RandomState(seed).randint(0, 256, size=(n, 32)).astype(np.uint8)
 

@@ -160,6 +160,33 @@ int cms_ba_linearize(int device, int K, const double* poses, const uint8_t* fixe
                      const int8_t* e_face, double fx, double fy, double cx, double cy, int robust, double huber_delta,
                      double* err, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* robust_chi2_sum);
 
+/* ---- pose-only optimisation: Optimizer::PoseOptimization(Frame*) (src/Optimizer.cpp:48-190), the per-frame solver Tracking calls
+ * 1-3 times per frame (Tracking.cpp:585,647,688).  Edge = EdgeSE3ProjectXYZMultiPinholeOnlyPose
+ * (include/g2o_cubemap_vertices_edges.h:42-88, src/g2o_cubemap_vertices_edges.cpp:61-134).  One workgroup per frame runs all four
+ * rounds (10 Levenberg iterations each, chi2 > 5.991 re-classification in between, Huber dropped for the last round) on the device;
+ * a batch of nf frames (camera streams) is ONE launch.  The caller prepares, exactly as Optimizer.cpp:80-127 does per matched
+ * map point whose key ray passes the FoV test: Xw (world point), obs_uv = GetPosInFace(kp.pt), face = FaceInCubemap(kp.pt),
+ * inv_sigma2 = mvInvLevelSigma2[kp.octave]; edge_off[f]..edge_off[f+1] are frame f's edges.  poses7: nf x (tx,ty,tz,qx,qy,qz,qw),
+ * world->camera, in/out.  outlier: one byte per edge (pFrame->mvbOutlier).  n_inliers[f] = nInitialCorrespondences - nBad, or 0
+ * and an untouched pose when the frame has fewer than 3 edges. */
+typedef struct cms_pose cms_pose;
+typedef struct { int rounds, n_bad; int iterations_done[4]; } cms_pose_stats;
+int cms_pose_create(cms_pose** out, int device, int max_frames, int max_edges);
+void cms_pose_destroy(cms_pose* p);
+void* cms_pose_stream(cms_pose* p);
+int cms_pose_optimize_batch(cms_pose* p, int nf, const int* edge_off, const double* Xw, const double* obs_uv, const double* inv_sigma2,
+                            const int8_t* face, double fx, double fy, double cx, double cy, double* poses7, uint8_t* outlier,
+                            int* n_inliers, cms_pose_stats* stats);
+/* the same in three steps, for callers that keep the problem resident: upload once, launch (asynchronous, restarts from the
+ * uploaded poses every time), fetch (synchronises) */
+int cms_pose_upload(cms_pose* p, int nf, const int* edge_off, const double* Xw, const double* obs_uv, const double* inv_sigma2,
+                    const int8_t* face, double fx, double fy, double cx, double cy, const double* poses7);
+int cms_pose_launch(cms_pose* p);
+int cms_pose_fetch(cms_pose* p, double* poses7, uint8_t* outlier, int* n_inliers, cms_pose_stats* stats);
+/* one frame, one shot (create + optimize + destroy) */
+int cms_pose_optimize(int device, int n, const double* Xw, const double* obs_uv, const double* inv_sigma2, const int8_t* face,
+                      double fx, double fy, double cx, double cy, double* pose7, uint8_t* outlier, int* n_inliers, cms_pose_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

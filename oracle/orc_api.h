@@ -122,6 +122,13 @@ void orc_ba_linearize(int K, const double* poses, const uint8_t* fixed, int P, c
                       double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* robust_chi2_sum);
 void orc_se3_exp_apply(const double* upd6, double* pose7);
 
+/* ---- Optimizer::PoseOptimization (Optimizer.cpp:48-190): pose-only LM over n unary multi-pinhole edges, 4 rounds x 10
+ * iterations with outlier re-classification.  Xw n x 3 (world), obs_uv n x 2 (measurement in its face), face ids, pose7 in/out.
+ * Returns the number of inliers (nInitialCorrespondences - nBad), 0 if n < 3 (pose untouched). */
+typedef struct { int rounds, n_bad; int iterations_done[4]; double chi2_final[4]; } orc_pose_stats;
+int  orc_pose_optimize(int n, const double* Xw, const double* obs_uv, const double* inv_sigma2, const int8_t* face,
+                       double fx, double fy, double cx, double cy, double* pose7, uint8_t* outlier, orc_pose_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

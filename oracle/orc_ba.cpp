@@ -433,6 +433,125 @@ int orc_ba_run(int K, double* poses, const uint8_t* fixed, int P, double* points
   return 0;
 }
 
+// ---- Optimizer::PoseOptimization (src/Optimizer.cpp:48-190): one free SE3 vertex, N unary multi-pinhole edges
+// (EdgeSE3ProjectXYZMultiPinholeOnlyPose: include/g2o_cubemap_vertices_edges.h:42-88, src/g2o_cubemap_vertices_edges.cpp:61-134;
+// quadratic form ThirdParty/g2o/g2o/core/base_unary_edge.hpp:43-72), BlockSolver_6_3 without Schur (no marginalised vertex:
+// block_solver.hpp:354-365) + LinearSolverDense (solvers/linear_solver_dense.h:64-118), Levenberg as in optimize() above.
+// Four rounds of optimize(10) from the SAME initial pose; after each round every edge is re-classified with chi2 > 5.991
+// (Optimizer.cpp:138-176), edges that were outliers get their error recomputed first (:147-150), active ones keep the
+// error of the last computeActiveErrors (the rejected trial's if the last trial was rejected); the Huber kernel is dropped
+// after the third round (:171-172); the loop stops early when the graph holds fewer than 10 edges (:175-176).
+int orc_pose_optimize(int n, const double* Xw, const double* obs_uv, const double* inv_sigma2, const int8_t* face, double fx,
+                      double fy, double cx, double cy, double* pose7, uint8_t* outlier, orc_pose_stats* st) {
+  orc_pose_stats dummy;
+  if (!st) st = &dummy;
+  memset(st, 0, sizeof(*st));
+  if (outlier) memset(outlier, 0, n);
+  if (n < 3) return 0;                                   // Optimizer.cpp:131-132
+  // reuse the edge arithmetic of the binary edge: one pose, n "points" that never move
+  Problem pb;
+  std::vector<int> e_pose(n, 0), e_point(n);
+  for (int i = 0; i < n; ++i) e_point[i] = i;
+  const uint8_t fixed0 = 0;
+  load(pb, 1, pose7, &fixed0, n, Xw, n, e_pose.data(), e_point.data(), obs_uv, inv_sigma2, face, fx, fy, cx, cy);
+  pb.delta = std::sqrt(5.991);
+  const Pose T0 = pb.poses[0];
+  std::vector<uint8_t> isout(n, 0);
+  int nBad = 0;
+  for (int round = 0; round < 4; ++round) {
+    pb.robust = round < 3;
+    pb.poses[0] = T0;                                    // vSE3->setEstimate(toSE3Quat(pFrame->mTcw)) every round
+    std::vector<int> act;
+    for (int e = 0; e < n; ++e) if (pb.level[e] == 0) act.push_back(e);
+    int done = 0;
+    double chi_fin = 0;
+    if (!act.empty()) {                                  // no active edge -> no active vertex -> optimize() returns at once
+      double H[36], b[6], lambda = -1, ni = 2;
+      int nBadIt = 0;
+      for (int it = 0; it < 10; ++it) {
+        double currentChi = 0;
+        for (int e : act) edge_error(pb, e, &pb.err[2 * e]);
+        auto chi_of = [&]() {
+          double c = 0;
+          for (int e : act) {
+            const double c2 = pb.e_invsig2[e] * (pb.err[2 * e] * pb.err[2 * e] + pb.err[2 * e + 1] * pb.err[2 * e + 1]);
+            if (pb.robust) { double rho[3]; huber(c2, pb.delta, rho); c += rho[0]; } else c += c2;
+          }
+          return c;
+        };
+        currentChi = chi_of();
+        double tempChi = currentChi;
+        const double iniChi = currentChi;
+        for (int i = 0; i < 36; ++i) H[i] = 0;
+        for (int i = 0; i < 6; ++i) b[i] = 0;
+        for (int e : act) {
+          double Jp[12], Jl[6];
+          edge_jacobians(pb, e, Jp, Jl);
+          const double* r = &pb.err[2 * e];
+          const double om = pb.e_invsig2[e];
+          double w = 1.0;
+          if (pb.robust) { double rho[3]; huber(om * (r[0] * r[0] + r[1] * r[1]), pb.delta, rho); w = rho[1]; }
+          for (int i = 0; i < 6; ++i) {
+            b[i] -= w * om * (Jp[i] * r[0] + Jp[6 + i] * r[1]);
+            for (int j = 0; j < 6; ++j) H[6 * i + j] += w * om * (Jp[i] * Jp[j] + Jp[6 + i] * Jp[6 + j]);
+          }
+        }
+        if (it == 0) {
+          double maxDiag = 0;
+          for (int j = 0; j < 6; ++j) maxDiag = std::max(std::fabs(H[7 * j]), maxDiag);
+          lambda = 1e-5 * maxDiag; ni = 2; nBadIt = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+          const Pose bak = pb.poses[0];
+          std::vector<double> A(H, H + 36), x(b, b + 6);
+          for (int j = 0; j < 6; ++j) A[7 * j] += lambda;
+          const bool ok2 = ldlt_solve(A, 6, x);
+          if (!ok2) std::fill(x.begin(), x.end(), 0.0);
+          se3_exp_mul(x.data(), pb.poses[0]);
+          for (int e : act) edge_error(pb, e, &pb.err[2 * e]);
+          tempChi = chi_of();
+          if (!ok2) tempChi = DBL_MAX;
+          rho = currentChi - tempChi;
+          double scale = 0;
+          for (int j = 0; j < 6; ++j) scale += x[j] * (lambda * x[j] + b[j]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && std::isfinite(tempChi)) {
+            double alpha = 1. - std::pow((2 * rho - 1), 3);
+            alpha = std::min(alpha, 2. / 3.);
+            lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+          } else {
+            lambda *= ni; ni *= 2;
+            pb.poses[0] = bak;
+          }
+          ++qmax;
+        } while (rho < 0 && qmax < 10);
+        ++done;
+        chi_fin = currentChi;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) ++nBadIt; else nBadIt = 0;
+        if (nBadIt >= 3) break;
+      }
+    }
+    st->iterations_done[round] = done; st->chi2_final[round] = chi_fin;
+    nBad = 0;
+    for (int e = 0; e < n; ++e) {
+      if (isout[e]) edge_error(pb, e, &pb.err[2 * e]);
+      const float chi2 = (float)(pb.e_invsig2[e] * (pb.err[2 * e] * pb.err[2 * e] + pb.err[2 * e + 1] * pb.err[2 * e + 1]));  // const float chi2 = e->chi2()
+      if (chi2 > 5.991f) { isout[e] = 1; pb.level[e] = 1; ++nBad; } else { isout[e] = 0; pb.level[e] = 0; }
+    }
+    st->rounds = round + 1;
+    if (n < 10) break;
+  }
+  for (int i = 0; i < 3; ++i) pose7[i] = pb.poses[0].t[i];
+  for (int i = 0; i < 4; ++i) pose7[3 + i] = pb.poses[0].q[i];
+  if (outlier) memcpy(outlier, isout.data(), n);
+  st->n_bad = nBad;
+  return n - nBad;
+}
+
 void orc_ba_linearize(int K, const double* poses, const uint8_t* fixed, int P, const double* points, int E,
                       const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
                       const int8_t* e_face, double fx, double fy, double cx, double cy, int robust, double huber_delta,

@@ -66,6 +66,8 @@ def lib():
         L.orc_ba_linearize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                        C.c_double, C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 10
+        L.orc_pose_optimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_int]
         for n in ("orc_orb_destroy", "orc_orb_nlevels"):
@@ -236,6 +238,23 @@ def ba_run(prob, its=(5, 10), stop=None):
                           _p(prob["e_point"]), _p(prob["e_obs"]), _p(prob["e_invsig2"]), _p(prob["e_face"]),
                           prob["fx"], prob["fy"], prob["cx"], prob["cy"], its[0], its[1], _p(stop_arr), _p(flags), C.byref(st))
     return dict(rc=rc, poses=poses, points=pts, outliers=flags, stats=st)
+
+
+class PoseStats(C.Structure):
+    _fields_ = [("rounds", C.c_int), ("n_bad", C.c_int), ("iterations_done", C.c_int * 4), ("chi2_final", C.c_double * 4)]
+
+
+def pose_optimize(prob, n=None):
+    """Optimizer::PoseOptimization on synth.pose_problem-style arrays; returns (n_inliers, pose7, outlier flags, stats)."""
+    n = len(prob["Xw"]) if n is None else n
+    pose = np.array(prob["pose0"], np.float64, copy=True)
+    out = np.zeros(max(n, 1), np.uint8)
+    st = PoseStats()
+    Xw = np.ascontiguousarray(prob["Xw"][:n], np.float64); obs = np.ascontiguousarray(prob["obs"][:n], np.float64)
+    inv = np.ascontiguousarray(prob["invsig2"][:n], np.float64); face = np.ascontiguousarray(prob["face"][:n], np.int8)
+    r = lib().orc_pose_optimize(n, _p(Xw), _p(obs), _p(inv), _p(face), prob["fx"], prob["fy"], prob["cx"], prob["cy"],
+                                _p(pose), _p(out), C.byref(st))
+    return r, pose, out[:n], st
 
 
 def ba_linearize(prob, robust=True, delta=np.sqrt(5.991)):

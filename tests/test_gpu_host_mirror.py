@@ -22,6 +22,7 @@ def _host():
     L.hm_search_by_projection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]
     L.hm_local_ba.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int]
+    L.hm_pose_optimization.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
     return L
 
 
@@ -176,3 +177,51 @@ def test_mirror_local_bundle_adjustment():
     assert np.array_equal(Tcw[0], T_in[0])                                  # key frame 0 is fixed (mnId == 0)
     assert np.abs(Xw - w["points"].astype(np.float32)).max() < 2e-4
     assert np.abs(Tcw[1:, :3, 3] - w["poses"][1:, :3].astype(np.float32)).max() < 2e-4
+
+
+def test_mirror_pose_optimization():
+    """Optimizer::PoseOptimization(Frame*) drop-in: a Frame with matched and unmatched key points, one key ray outside the FoV
+    (skipped like Optimizer.cpp:83-85); the mirror must return what the oracle returns on the edges the reference would build."""
+    L = _host()
+    F = 550
+    camd = synth.camera("lafida", F)
+    cam = api.make_camera(camd)
+    assert L.hm_set_camera(C.byref(cam)) == 0
+    pr = synth.pose_problem(N=500, F=F, seed=31, outlier_frac=0.12)
+    n = len(pr["Xw"])
+    origin = {0: (1, 1), 1: (0, 1), 2: (2, 1), 3: (1, 0), 4: (1, 2)}
+    inv_tab = (np.float32(1.0) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    N = n + 40                                              # 40 extra key points without a map point
+    kps = np.zeros(N, KP); rays = np.tile(np.array([0, 0, 1], np.float32), (N, 1)); has = np.zeros(N, np.uint8)
+    Xw = np.zeros((N, 3), np.float32)
+    slot = np.sort(np.random.RandomState(1).permutation(N)[:n])
+    for e, i in enumerate(slot):
+        ox, oy = origin[int(pr["face"][e])]
+        kps["x"][i] = pr["obs"][e, 0] + ox * F; kps["y"][i] = pr["obs"][e, 1] + oy * F
+        kps["octave"][i] = int(np.argmin(np.abs(inv_tab.astype(np.float64) - pr["invsig2"][e])))
+        has[i] = 1; Xw[i] = pr["Xw"][e]
+    dropped = slot[7]; rays[dropped] = (0.0, 0.5, -0.9)     # behind the 190 deg field of view: no edge for this one
+    x, y, z, w = pr["pose0"][3:]
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[:3, :3] = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    Tcw[:3, 3] = pr["pose0"][:3]
+    T_in = Tcw.copy()
+    out = np.zeros(N, np.uint8)
+    got = L.hm_pose_optimization(_p(Tcw), N, _p(kps), _p(rays), _p(has), _p(Xw), _p(inv_tab), 8, _p(out))
+    assert got >= 0, L.hm_last_error()
+    # oracle on the edges the reference builds from this Frame (float key points / map points / Tcw)
+    keep = [e for e, i in enumerate(slot) if i != dropped]
+    ks = slot[keep]
+    pr2 = dict(pr)
+    pr2["Xw"] = Xw[ks].astype(np.float64)
+    kx = kps["x"][ks].astype(np.float64); ky = kps["y"][ks].astype(np.float64)
+    pr2["obs"] = np.stack([kx - np.floor(kx / F) * F, ky - np.floor(ky / F) * F], 1)
+    pr2["invsig2"] = inv_tab[kps["octave"][ks]].astype(np.float64)
+    pr2["face"] = pr["face"][keep]
+    pr2["pose0"] = np.concatenate([T_in[:3, 3].astype(np.float64), synth._quat_from_R(T_in[:3, :3].astype(np.float64))])
+    w_n, w_pose, w_out, _ = orc.pose_optimize(pr2)
+    assert got == w_n and got > 300
+    assert np.array_equal(out[ks], w_out) and out[dropped] == 0 and out[has == 0].sum() == 0
+    assert np.abs(Tcw[:3, 3] - w_pose[:3].astype(np.float32)).max() < 1e-5
+    assert np.array_equal(Tcw[3], T_in[3])

@@ -258,3 +258,39 @@ def test_ba_run_config4_full_size():
     assert 78000 < len(prob["e_pose"]) < 82000
     g, w = _ba_compare(prob)
     assert 0.05 < g["outliers"].mean() < 0.20      # 5 % gross outliers + the 5 % chi2 tail of the inliers + unobservable ones
+
+
+def _pose_close(got, want, ref0, tol=1e-4):
+    """pose UPDATE within tol relative (north_star): compare the change from the initial pose"""
+    du = np.linalg.norm(np.concatenate([want[:3] - ref0[:3], want[3:] - ref0[3:]]))
+    err = np.linalg.norm(np.concatenate([got[:3] - want[:3], got[3:] - want[3:]]))
+    return err <= tol * max(du, 1e-12), (err, du)
+
+
+def test_pose_optimization_matches_oracle():
+    """Optimizer::PoseOptimization (SURVEY.md 8f-1): four-round pose-only LM in one kernel vs the CPU oracle -- same inlier
+    count, identical outlier flags and per-round iteration counts, pose update within 1e-4 relative."""
+    from cubemapslam_amd import synth as sy
+    probs = [sy.pose_problem(N=n, seed=s, outlier_frac=o) for n, s, o in
+             ((600, 1, 0.1), (150, 2, 0.3), (1500, 3, 0.05), (40, 4, 0.0), (9, 5, 0.0), (2, 6, 0.0), (300, 7, 0.5))]
+    po = api.PoseOptimizer(len(probs), sum(len(p["Xw"]) for p in probs))
+    ninl, poses, outs, stats = po.optimize(probs)
+    for f, pr in enumerate(probs):
+        w_n, w_pose, w_out, w_st = orc.pose_optimize(pr)
+        assert ninl[f] == w_n, (f, ninl[f], w_n)
+        assert np.array_equal(outs[f], w_out), (f, int((outs[f] != w_out).sum()))
+        assert stats[f].rounds == w_st.rounds and list(stats[f].iterations_done) == list(w_st.iterations_done), \
+            (f, list(stats[f].iterations_done), list(w_st.iterations_done))
+        if len(pr["Xw"]) >= 3:
+            ok, info = _pose_close(poses[f], w_pose, pr["pose0"] / np.concatenate([[1, 1, 1], [np.linalg.norm(pr["pose0"][3:])] * 4]))
+            assert ok, (f, info)
+        else:
+            assert np.array_equal(poses[f], pr["pose0"])
+    # launching again restarts from the uploaded poses: same answer (resident-problem path used by bench.py)
+    po.launch()
+    ninl2, poses2, outs2, _ = po.fetch()
+    assert np.array_equal(ninl, ninl2) and np.array_equal(poses, poses2)
+    po.close()
+    # one-shot entry point
+    n1, pose1, out1, st1 = api.pose_optimize(probs[0])
+    assert n1 == ninl[0] and np.array_equal(out1, outs[0]) and np.array_equal(pose1, poses[0])
