@@ -11,6 +11,7 @@ resident in HBM:
     Hamming best/second-best of every key point of frame b-1 against its window candidates in frame b
         (the inner loops of ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15); candidate windows built once
          on the host from the real key points -- GetFeaturesInArea is a "next" row)
+    Optimizer::PoseOptimization of every frame (one launch for the batch, own stream)
     one local BA window (K=20 key frames, ~80k cubemap edges, BASELINE.json configs[3]) per `--ba-every` frames, on its own
         stream / host thread like the reference's LocalMapping thread.
 Weak scaling over GPUs: every rank runs its own stream(s); the only exchange is an RCCL gather of the per-frame trajectory
@@ -74,6 +75,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (default: 8 streams x 8 consecutive frames)")
     ap.add_argument("--face", type=int, default=550)
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
+    ap.add_argument("--pose-edges", type=int, default=600, help="matched map points per frame for the pose-only optimisation")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -125,6 +127,11 @@ def main():
     # the local-BA windows of this step are independent LM problems: one host thread (LocalMapping-like) drives them as a batch,
     # concurrent with the frame path on its own stream
     bas = [api.BundleAdjuster(prob, device=local_rank) for _ in range(n_ba)]
+    # tracking's pose-only optimisation (Optimizer::PoseOptimization, once per frame here; the reference calls it 1-3 times):
+    # one problem per frame, ~600 matched map points with 10 % mismatches, resident on the device, one launch per step
+    pose_probs = [synth.pose_problem(N=args.pose_edges, F=F, seed=1000 * rank + b, outlier_frac=0.1) for b in range(B)]
+    po = api.PoseOptimizer(B, sum(len(p["Xw"]) for p in pose_probs), device=local_rank)
+    po.upload(pose_probs)
     ba_err = []
 
     ba_ms = [0.0, 0]
@@ -143,10 +150,12 @@ def main():
         ths = [threading.Thread(target=ba_worker)]
         for th in ths:
             th.start()
+        po.launch()                 # own stream, overlaps the frame path
         ctx.process(B, True)
         ctx.hamming_best2_device(d_desc, d_qrow.data_ptr(), nq, d_desc, d_off.data_ptr(), d_idx.data_ptr(), d_lvl.data_ptr(), None,
                                  [o.data_ptr() for o in d_out])
         ctx.sync()
+        po.fetch()
         for th in ths:
             th.join()
         if ba_err:
@@ -261,11 +270,15 @@ def main():
         for _ in range(n_cpu_ba):
             orc.ba_run(prob)
         t_ba = (time.perf_counter() - t1) / n_cpu_ba
-        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_ba / args.ba_every
+        t1 = time.perf_counter()
+        for b in range(min(n, 8)):
+            orc.pose_optimize(pose_probs[b])
+        t_pose = (time.perf_counter() - t1) / min(n, 8)
+        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_pose + t_ba / args.ba_every
         cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "%d frames remap+extract (%.1f ms/frame), Hamming over %.1f frame pairs (%.2f ms/frame), %d local-BA windows "
-                         "(%.1f ms each, 1 per %d frames); oracle/liborc.so, single thread" %
-                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), n_cpu_ba, 1e3 * t_ba, args.ba_every),
+               "sample": "%d frames remap+extract (%.1f ms/frame), Hamming over %.1f frame pairs (%.2f ms/frame), pose-only optimisation "
+                         "(%.2f ms/frame), %d local-BA windows (%.1f ms each, 1 per %d frames); oracle/liborc.so, single thread" %
+                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_pose, n_cpu_ba, 1e3 * t_ba, args.ba_every),
                "host_cores_available": os.cpu_count()}
 
     if rank == 0:
@@ -276,8 +289,9 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract/match), f64 (BA)", "data": "synthetic",
             "config": {"workload": "Lafida cam0 synthetic stream, 754x480 fisheye, face=%d (%dx%d cross), nFeatures %d; per step %d frames: "
-                                   "remap+ORB extract, Hamming best-2 (%d queries, %d candidate pairs), %d local-BA windows (K=20, E=%d)"
-                                   % (F, 3 * F, 3 * F, nfeat, B, nq, len(c_idx), n_ba, len(prob["e_pose"])),
+                                   "remap+ORB extract, Hamming best-2 (%d queries, %d candidate pairs), pose-only optimisation (%d edges/frame), "
+                                   "%d local-BA windows (K=20, E=%d)"
+                                   % (F, 3 * F, 3 * F, nfeat, B, nq, len(c_idx), args.pose_edges, n_ba, len(prob["e_pose"])),
                        "frames_per_step_per_gpu": B, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
