@@ -132,6 +132,7 @@ extern "C" __global__ void __launch_bounds__(256) k_pose_optimize(PoseDev P) {
   const int f = blockIdx.x, tid = threadIdx.x;
   const int e0 = P.off[f], e1 = P.off[f + 1], n = e1 - e0;
   int* res = P.result + 8 * f;
+  for (int e = e0 + tid; e < e1; e += 256) P.outlier[e] = 0;   // pFrame->mvbOutlier[i] = false (Optimizer.cpp:91)
   if (n < 3) {                          // Optimizer.cpp:131-132: pose untouched, 0 returned
     if (tid < 8) res[tid] = 0;
     return;
@@ -145,7 +146,6 @@ extern "C" __global__ void __launch_bounds__(256) k_pose_optimize(PoseDev P) {
     for (int i = 0; i < 7; ++i) pose0[i] = p[i];
     normalize_rot(pose0 + 3);           // SE3Quat constructor (se3quat.h:58-64)
   }
-  for (int e = e0 + tid; e < e1; e += 256) P.outlier[e] = 0;
   int nBad = 0, rounds = 0;
   int its[4] = {0, 0, 0, 0};
   for (int round = 0; round < 4; ++round) {
