@@ -27,6 +27,11 @@ struct cms_ba {
   int* d_pair_s1 = nullptr; int* d_pair_s2 = nullptr; int* d_pair_off = nullptr; int2* d_tup = nullptr;
   int* d_pair_chunk_off = nullptr; int2* d_chunk_range = nullptr; double* d_chunk_sum = nullptr; int* d_pair_of_block = nullptr;
   int npairs = 0, nchunks = 0; size_t solve_lds = 0, blk_lds = 0; bool solve_in_lds = false, solve_blk = false;
+  // per-point Schur work lists (sp.R == 0: not available for this window, the tuple-chunk kernel is used)
+  BaSp sp = {};
+  int* d_sp_bat_e0 = nullptr; uint32_t* d_sp_off = nullptr; uint32_t* d_sp_list = nullptr; int* d_sp_slot_pair = nullptr; int* d_sp_tup_base = nullptr;
+  int* d_sp_pair_slots = nullptr; double* d_sp_partial = nullptr; double* d_sp_sum = nullptr; int* d_sp_chunk_off = nullptr;
+  int sp_threads = 0; size_t sp_lds = 0;
   int cur = 0;
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   // group resources (owned by the first window of a cms_ba_optimize_many call, grown on demand)
@@ -146,6 +151,113 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
       for (size_t pr = 0; pr < ps1.size(); ++pr) pob[(size_t)ps2[pr] * (ps2[pr] + 1) / 2 + ps1[pr]] = (int)pr;
       BA_TRY(ba_alloc(b, &b->d_pair_of_block, pob.size()));
       BA_HIP(hipMemcpy(b->d_pair_of_block, pob.data(), pob.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // ---- work lists of the per-point Schur kernel (cms_ba_schur_points.hip): batches of consecutive points whose edges fit
+    // LDS, ranges of consecutive batches (one workgroup each), one owner slot per co-visible pair (several helper slots for
+    // the diagonal pairs, which get one tuple per edge), per (batch, slot) the tuples as 16-bit local edge ids
+    {
+      const int npairs = b->npairs;
+      std::vector<int> pair_idx((size_t)std::max(np * np, 1), -1);
+      int ndiag = 0;
+      for (int pr = 0; pr < npairs; ++pr) { pair_idx[(size_t)ps1[pr] * np + ps2[pr]] = pr; ndiag += ps1[pr] == ps2[pr]; }
+      bool ok = npairs > 0 && getenv("CMS_BA_SCHUR_CHUNKS") == nullptr;
+      std::vector<int> bat_e0(1, 0), bat_of_point(P, 0);
+      for (int p = 0, cur = 0, curt = 0; p < P && ok; ++p) {
+        const int ne = pt_off[p + 1] - pt_off[p];
+        int nfree = 0;
+        for (int a = pt_off[p]; a < pt_off[p + 1]; ++a) nfree += pose_slot[s_pose[a]] >= 0;
+        const int nt = nfree * (nfree + 1) / 2;                    // tuples of this point
+        if (ne > BA_SP_MAXE || nt > BA_SP_MAXT) { ok = false; break; }
+        if (cur + ne > BA_SP_MAXE || curt + nt > BA_SP_MAXT) { bat_e0.push_back(pt_off[p]); cur = 0; curt = 0; }
+        cur += ne; curt += nt;
+        bat_of_point[p] = (int)bat_e0.size() - 1;
+      }
+      bat_e0.push_back(E);
+      const int nbat = (int)bat_e0.size() - 1;
+      int nhd = 1;
+      if (ok) {
+        nhd = ndiag > 0 ? std::min(8, std::min(BA_SP_MAXE / ndiag, (BA_SP_MAX_THREADS - (npairs - ndiag)) / ndiag)) : 1;
+        if (nhd < 1 || ndiag * nhd + (npairs - ndiag) > BA_SP_MAX_THREADS) ok = false;
+      }
+      if (ok) {
+        // slots: helpers of the diagonal pairs first, then one slot per off-diagonal pair
+        std::vector<int> slot_pair;
+        std::vector<int> order;
+        for (int pr = 0; pr < npairs; ++pr) if (ps1[pr] == ps2[pr]) order.push_back(pr);
+        const int nd_slots = ndiag * nhd;
+        for (int pr = 0; pr < npairs; ++pr) if (ps1[pr] != ps2[pr]) order.push_back(pr);
+        std::vector<int> slot0_of(npairs, 0);
+        for (int pr : order) { slot0_of[pr] = (int)slot_pair.size(); for (int h = 0; h < (ps1[pr] == ps2[pr] ? nhd : 1); ++h) slot_pair.push_back(pr); }
+        const int nslots = (int)slot_pair.size();
+        // helpers of a pair are consecutive slots: [first, end) per pair id
+        std::vector<int> slot_first(npairs), slot_end(npairs);
+        for (int pr = 0; pr < npairs; ++pr) { slot_first[pr] = slot0_of[pr]; slot_end[pr] = slot0_of[pr] + (ps1[pr] == ps2[pr] ? nhd : 1); }
+        const int bpw = std::max(1, (nbat + BA_SP_RANGES - 1) / BA_SP_RANGES);
+        const int R = (nbat + bpw - 1) / bpw;
+        // per batch: tuples grouped by slot (point order inside a slot), 16-bit words a1 | a2 << 8, two per u32; and the
+        // nslots + 1 offsets of the slots inside the batch's tuples, 16 bit each
+        const int off_stride = (nslots + 2) / 2;
+        std::vector<int> rr((size_t)nbat * std::max(npairs, 1), 0);
+        auto slot_of = [&](int bt, int pr) {
+          if (ps1[pr] != ps2[pr]) return slot_first[pr];
+          const int h = rr[(size_t)bt * npairs + pr]++ % nhd;     // round robin over the helpers, per batch
+          return slot_first[pr] + h;
+        };
+        std::vector<std::vector<std::pair<int, uint16_t>>> per_batch(nbat);
+        for (int p = 0; p < P; ++p) {
+          const int bt = bat_of_point[p], e0 = bat_e0[bt];
+          for (int a1 = pt_off[p]; a1 < pt_off[p + 1]; ++a1) {
+            const int s1 = pose_slot[s_pose[a1]];
+            if (s1 < 0) continue;
+            for (int a2 = pt_off[p]; a2 < pt_off[p + 1]; ++a2) {
+              const int s2 = pose_slot[s_pose[a2]];
+              if (s2 < 0 || s2 < s1) continue;
+              const int sl = slot_of(bt, pair_idx[(size_t)s1 * np + s2]);
+              per_batch[bt].push_back(std::make_pair(sl, (uint16_t)((a1 - e0) | ((a2 - e0) << 8))));
+            }
+          }
+        }
+        std::vector<int> tup_base(nbat + 1, 0);
+        std::vector<uint16_t> tup16, off16((size_t)nbat * off_stride * 2, 0);
+        for (int bt = 0; bt < nbat; ++bt) {
+          auto& v = per_batch[bt];
+          std::stable_sort(v.begin(), v.end(), [](const std::pair<int, uint16_t>& x, const std::pair<int, uint16_t>& y) { return x.first < y.first; });
+          uint16_t* off = &off16[(size_t)bt * off_stride * 2];
+          size_t i = 0;
+          for (int sl = 0; sl <= nslots; ++sl) {
+            while (i < v.size() && v[i].first < sl) ++i;
+            off[sl] = (uint16_t)i;
+          }
+          tup_base[bt] = (int)(tup16.size() / 2);
+          for (const auto& x : v) tup16.push_back(x.second);
+          if (tup16.size() & 1) tup16.push_back(0);
+        }
+        tup_base[nbat] = (int)(tup16.size() / 2);
+        std::vector<int> ps0(2 * (size_t)npairs);
+        for (int pr = 0; pr < npairs; ++pr) { ps0[2 * pr] = slot_first[pr]; ps0[2 * pr + 1] = slot_end[pr]; }
+        BA_TRY(ba_alloc(b, &b->d_sp_bat_e0, bat_e0.size())); BA_TRY(ba_alloc(b, &b->d_sp_off, off16.size() / 2));
+        BA_TRY(ba_alloc(b, &b->d_sp_list, tup16.size() / 2)); BA_TRY(ba_alloc(b, &b->d_sp_tup_base, tup_base.size())); BA_TRY(ba_alloc(b, &b->d_sp_slot_pair, slot_pair.size()));
+        BA_TRY(ba_alloc(b, &b->d_sp_pair_slots, ps0.size())); BA_TRY(ba_alloc(b, &b->d_sp_partial, (size_t)R * npairs * 42));
+        BA_TRY(ba_alloc(b, &b->d_sp_sum, (size_t)npairs * 42)); BA_TRY(ba_alloc(b, &b->d_sp_chunk_off, (size_t)npairs + 1));
+        BA_HIP(hipMemcpy(b->d_sp_bat_e0, bat_e0.data(), bat_e0.size() * sizeof(int), hipMemcpyHostToDevice));
+        BA_HIP(hipMemcpy(b->d_sp_off, off16.data(), off16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if (!tup16.empty()) BA_HIP(hipMemcpy(b->d_sp_list, tup16.data(), tup16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        BA_HIP(hipMemcpy(b->d_sp_tup_base, tup_base.data(), tup_base.size() * sizeof(int), hipMemcpyHostToDevice));
+        BA_HIP(hipMemcpy(b->d_sp_slot_pair, slot_pair.data(), slot_pair.size() * sizeof(int), hipMemcpyHostToDevice));
+        BA_HIP(hipMemcpy(b->d_sp_pair_slots, ps0.data(), ps0.size() * sizeof(int), hipMemcpyHostToDevice));
+        std::vector<int> ident(npairs + 1);
+        for (int i = 0; i <= npairs; ++i) ident[i] = i;          // "one chunk per pair" for the solve kernel's assembly
+        BA_HIP(hipMemcpy(b->d_sp_chunk_off, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        BaSp& sp = b->sp;
+        sp.nbat = nbat; sp.bpw = bpw; sp.nslots = nslots; sp.npairs = npairs; sp.R = R; sp.nd_slots = nd_slots;
+        sp.bat_e0 = b->d_sp_bat_e0; sp.off32 = b->d_sp_off; sp.tup32 = b->d_sp_list; sp.tup_base = b->d_sp_tup_base; sp.off_stride = off_stride;
+        sp.slot_pair = b->d_sp_slot_pair;
+        sp.pair_slots = b->d_sp_pair_slots; sp.partial = b->d_sp_partial;
+        b->sp_threads = std::max((nslots + 63) / 64 * 64, (BA_SP_MAXE + 63) / 64 * 64);   // >= BA_SP_MAXE: one staged edge per thread
+        b->sp_lds = (size_t)BA_SP_MAXE * BA_SP_ROW * sizeof(double) + BA_SP_MAXT * 2 + (BA_SP_MAX_THREADS + 4) * 2;
+        BA_HIP(hipFuncSetAttribute((const void*)k_ba_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->sp_lds));
+        BA_HIP(hipFuncSetAttribute((const void*)kb_ba_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->sp_lds));
+      }
     }
     std::vector<int> pcoff(1, 0);
     std::vector<int2> crange;

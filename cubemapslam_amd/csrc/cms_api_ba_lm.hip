@@ -52,12 +52,21 @@ static int ba_enqueue_trial(cms_ba* b, const BaLm& st) {
     // fused trial (cms_ba_fused.hip): 5 launches, no reduced matrix in memory
     hipLaunchKernelGGL(k_ba_dinv, dim3((b->P + 255) / 256), dim3(256), 0, s, b->P, (const double*)b->d_Hll, (const double*)b->d_bl, lambda,
                        b->d_Dinv, b->d_db);
-    if (b->npairs > 0)
+    // A window on its own is a latency problem: the tuple-chunk kernel (hundreds of short workgroups, 13 us) beats the
+    // per-point kernel (64 workgroups walking 6 batches each, 40 us).  The per-point kernel pays off when several windows
+    // share the launches and the chunk kernel becomes bandwidth bound -- the batched driver below uses it.
+    const bool sp = b->sp.R > 0 && getenv("CMS_BA_SCHUR_POINTS") != nullptr;
+    if (sp) {
+      hipLaunchKernelGGL(k_ba_schur_points, dim3(b->sp.R), dim3(b->sp_threads), b->sp_lds, s, b->d, b->sp, (const double*)b->d_Hpl,
+                         (const double*)b->d_Dinv, (const double*)b->d_db);
+      hipLaunchKernelGGL(k_ba_schur_reduce, dim3(b->npairs), dim3(256), 0, s, b->sp, b->d_sp_sum);
+    } else if (b->npairs > 0) {
       hipLaunchKernelGGL(k_ba_schur_chunks, dim3(b->nchunks), dim3(256), 0, s, b->d, (const int2*)b->d_chunk_range, (const int2*)b->d_tup,
                          (const double*)b->d_Hpl, (const double*)b->d_Dinv, (const double*)b->d_db, b->d_chunk_sum);
+    }
     hipLaunchKernelGGL(k_ba_trial_solve, dim3(1), dim3(384), b->blk_lds, s, b->d, (const double*)b->d_Hpp, (const double*)b->d_bp, lambda,
-                       (const int*)b->d_pair_of_block, (const int*)b->d_pair_chunk_off, (const double*)b->d_chunk_sum,
-                       (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_x, b->d_scal);
+                       (const int*)b->d_pair_of_block, (const int*)(sp ? b->d_sp_chunk_off : b->d_pair_chunk_off),
+                       (const double*)(sp ? b->d_sp_sum : b->d_chunk_sum), (const double*)b->d_poses[cur], b->d_poses[nxt], b->d_x, b->d_scal);
     hipLaunchKernelGGL(k_ba_trial_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_bl, (const double*)b->d_Hpl,
                        (const double*)b->d_Dinv, (const double*)b->d_x, lambda, (const double*)b->d_pts[cur], b->d_pts[nxt],
                        (const double*)b->d_poses[nxt], st.robust, st.delta, b->d_partial);
@@ -169,9 +178,14 @@ static int ba_group_reserve(cms_ba* owner, int n) {
   return CMS_OK;
 }
 // static part of the windows' descriptions -> device, once per stage
+static bool ba_all_sp(cms_ba** bas, int n) {
+  for (int w = 0; w < n; ++w) if (bas[w]->sp.R <= 0) return false;
+  return true;
+}
 static int ba_upload_items(cms_ba** bas, int n) {
   cms_ba* g = bas[0];
   BaItem* items = reinterpret_cast<BaItem*>(g->grp_items_host);
+  const bool all_sp = ba_all_sp(bas, n);
   for (int w = 0; w < n; ++w) {
     cms_ba* b = bas[w];
     BaItem& it = items[w];
@@ -183,6 +197,9 @@ static int ba_upload_items(cms_ba** bas, int n) {
     it.chunk_range = b->d_chunk_range; it.tup = b->d_tup; it.pair_of_block = b->d_pair_of_block; it.pair_chunk_off = b->d_pair_chunk_off;
     it.flags = b->d_flags;
     it.nblk_e = b->nblk_e; it.nblk_p = b->nblk_p; it.nchunks = b->nchunks; it.pad = 0;
+    it.sp = b->sp;
+    if (!all_sp) it.sp.R = 0;                       // one launch sequence for the whole group: per-point Schur only if every window has it
+    if (all_sp) { it.chunk_sum = b->d_sp_sum; it.pair_chunk_off = b->d_sp_chunk_off; }
   }
   HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
   return CMS_OK;
@@ -191,9 +208,12 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
   cms_ba* g = bas[0];
   hipStream_t s = g->stream;
   const BaItem* ditems = reinterpret_cast<const BaItem*>(g->grp_items_dev);
-  int max_e = 0, max_p = 0, max_K = 0, max_np = 0, max_chunks = 0, max_P = 0;
-  size_t lds = 0;
+  int max_e = 0, max_p = 0, max_K = 0, max_np = 0, max_chunks = 0, max_P = 0, max_R = 0, max_spt = 64, max_pairs = 0;
+  size_t lds = 0, sp_lds = 0;
+  const bool all_sp = ba_all_sp(bas, n);
   for (int w = 0; w < n; ++w) {
+    max_R = std::max(max_R, bas[w]->sp.R); max_spt = std::max(max_spt, bas[w]->sp_threads); max_pairs = std::max(max_pairs, bas[w]->npairs);
+    sp_lds = std::max(sp_lds, bas[w]->sp_lds);
     max_e = std::max(max_e, bas[w]->nblk_e); max_p = std::max(max_p, bas[w]->nblk_p); max_K = std::max(max_K, bas[w]->K);
     max_np = std::max(max_np, bas[w]->np); max_chunks = std::max(max_chunks, bas[w]->nchunks); max_P = std::max(max_P, bas[w]->P);
     lds = std::max(lds, bas[w]->blk_lds);
@@ -224,7 +244,12 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
     }
     if (n_trial) {
       hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
-      if (max_chunks > 0) hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (all_sp) {
+        hipLaunchKernelGGL(kb_ba_schur_points, dim3(max_R, 1, n), dim3(max_spt), sp_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        hipLaunchKernelGGL(kb_ba_schur_reduce, dim3(max_pairs, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      } else if (max_chunks > 0) {
+        hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      }
       hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);

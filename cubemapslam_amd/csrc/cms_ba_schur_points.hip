@@ -1,0 +1,149 @@
+// cms_ba_schur_points.hip -- Schur complement of the local BA with every Hpl block read ONCE per Levenberg trial.
+//
+// k_ba_schur_chunks (cms_ba_kernels.hip) walks the co-visibility tuples pair by pair: deterministic and atomic-free, but each
+// tuple re-reads its two 6x3 blocks and the point's Dinv from memory -- 360 B per tuple, 5.5x the unique bytes of a window
+// (a point seen by k key frames has k(k+1)/2 tuples over k blocks).  With several windows in flight that kernel is the
+// largest of the whole BA and bandwidth bound.  Here the work is point-major:
+//
+//   * the host cuts the (point-sorted) edge list into BATCHES of consecutive points whose edges fit LDS, and consecutive batches
+//     into RANGES, one workgroup each;
+//   * a workgroup stages a batch once -- B = Hpl[e], BD = B * Dinv[point], rb = B * (Dinv bl) per edge -- into LDS;
+//   * every co-visible pose pair has one owner thread ("slot"; diagonal pairs, which get one tuple per edge, have several
+//     helper slots) that walks ITS tuples of the batch (host-built list per (batch, slot), 16-bit local edge ids) and
+//     accumulates BD[a1] B[a2]^T in registers across all batches of the range -- no atomics, fixed order;
+//   * the helpers of a pair are added in LDS, the range writes one 42-vector per pair, k_ba_schur_reduce adds the ranges in
+//     order into the "one chunk per pair" array the solve kernel already consumes.
+//
+// Global traffic per trial: Hpl + Dinv + db once (14 MB at E = 80k) + R x npairs x 336 B of partials, instead of 66 MB.
+// (block_solver.hpp:367-437: Hschur -= Bi Dinv Bj^T, bschur -= Bi Dinv bl.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BA_SP_MAXE 208            /* edges per batch (< 256: 8-bit local ids): 208 x (18 + 18 + 6) doubles = 68 KB of LDS */
+#define BA_SP_MAXT 512            /* tuples per batch: their 16-bit words (1 KB) and the per-slot offsets are staged in LDS too */
+#define BA_SP_ROW 42              /* doubles per staged edge: B (18) | BD (18) | rb (6) */
+#define BA_SP_MAX_THREADS 512
+#ifndef BA_SP_RANGES
+#define BA_SP_RANGES 64           /* workgroups per window (each walks nbat / 64 batches) */
+#endif
+
+struct BaSp {                      // device view of the host-built work lists (cms_api_ba.hip)
+  int nbat, bpw, nslots, npairs, R;
+  int nd_slots;                   // slots [0, nd_slots) are the helper slots of the diagonal pairs (summed in LDS), the rest own a pair alone
+  const int* bat_e0;              // nbat + 1: first edge of every batch
+  int off_stride;                 // u32 words per batch in `off32`: ceil((nslots + 1) / 2)
+  const int* tup_base;            // nbat + 1: first u32 word of every batch in `tup32` (two 16-bit tuples a1 | a2 << 8 per word)
+  const uint32_t* tup32;          // tuples of a batch, grouped by slot
+  const uint32_t* off32;          // per batch nslots + 1 16-bit offsets into the batch's tuples
+  const int* slot_pair;           // nslots: pair id of a slot
+  const int* pair_slots;          // 2 x npairs: [first, end) slot of every pair (its helpers are consecutive)
+  double* partial;                // R x npairs x 42
+};
+
+__device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+                                                     const double* __restrict__ db) {
+  extern __shared__ __align__(16) double sp_lds[];      // [BA_SP_MAXE][42], reused at the end for the helper sums
+  const int tid = threadIdx.x;
+  const bool have = tid < sp.nslots;
+  double acc[42];
+#pragma unroll
+  for (int i = 0; i < 42; ++i) acc[i] = 0;
+  const int b0 = BX * sp.bpw, b1 = min(sp.nbat, b0 + sp.bpw);
+  // staging is software pipelined: blockDim >= BA_SP_MAXE, so a thread stages at most ONE edge per batch; the global loads of
+  // batch b + 1 are issued right after batch b went to LDS and travel while the tuples of batch b are multiplied
+  double Bv[18], Dv[9], dv[3];
+  uint32_t tw = 0, ow = 0;
+  bool mine = false;
+  uint16_t* ltup = reinterpret_cast<uint16_t*>(sp_lds + (size_t)BA_SP_MAXE * BA_SP_ROW);
+  uint16_t* loff = ltup + BA_SP_MAXT;
+  auto fetch = [&](int bb) {
+    const int tb = sp.tup_base[bb], ntw = sp.tup_base[bb + 1] - tb;
+    tw = tid < ntw ? sp.tup32[tb + tid] : 0u;
+    ow = tid < sp.off_stride ? sp.off32[(size_t)bb * sp.off_stride + tid] : 0u;
+    const int e0 = sp.bat_e0[bb], ne = sp.bat_e0[bb + 1] - e0;
+    mine = tid < ne;
+    if (mine) {
+      const int e = e0 + tid, p = d.e_point[e];
+      const double* B = Hpl + 18 * (size_t)e;
+      const double* Di = Dinv + 9 * (size_t)p;
+      const double* dbp = db + 3 * (size_t)p;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Bv[i] = B[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Dv[i] = Di[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dv[i] = dbp[i];
+    }
+  };
+  if (b0 < b1) fetch(b0);
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();                                     // readers of the previous batch are done
+    if (tid < BA_SP_MAXT / 2) reinterpret_cast<uint32_t*>(ltup)[tid] = tw;
+    if (tid < sp.off_stride) reinterpret_cast<uint32_t*>(loff)[tid] = ow;
+    if (mine) {
+      double* row = sp_lds + (size_t)tid * BA_SP_ROW;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) row[i] = Bv[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          row[18 + 3 * i + j] = __builtin_fma(Bv[3 * i + 2], Dv[6 + j], __builtin_fma(Bv[3 * i + 1], Dv[3 + j], Bv[3 * i] * Dv[j]));
+        row[36 + i] = __builtin_fma(Bv[3 * i + 2], dv[2], __builtin_fma(Bv[3 * i + 1], dv[1], Bv[3 * i] * dv[0]));
+      }
+    }
+    __syncthreads();
+    if (b + 1 < b1) fetch(b + 1);
+    const int l0 = have ? loff[tid] : 0, l1 = have ? loff[tid + 1] : 0;
+    for (int t = l0; t < l1; ++t) {
+      const int w = ltup[t];
+      const int a1 = w & 0xFF, a2 = w >> 8;
+      const double* r1 = sp_lds + (size_t)a1 * BA_SP_ROW + 18;     // BD of the first edge
+      const double* r2 = sp_lds + (size_t)a2 * BA_SP_ROW;          // B of the second
+      double bd[18], b2[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) { bd[i] = r1[i]; b2[i] = r2[i]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          acc[6 * i + j] = __builtin_fma(bd[3 * i + 2], b2[3 * j + 2], __builtin_fma(bd[3 * i + 1], b2[3 * j + 1], __builtin_fma(bd[3 * i], b2[3 * j], acc[6 * i + j])));
+      if (a1 == a2) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[36 + i] += r1[18 + i];     // rb sits right behind BD
+      }
+    }
+  }
+  // ---- this range's slice of `partial`: an off-diagonal pair has a single owner which writes its vector directly; the helper
+  // slots of the diagonal pairs are added in LDS first (fixed order)
+  __syncthreads();
+  if (have && tid < sp.nd_slots) {
+#pragma unroll
+    for (int i = 0; i < 42; ++i) sp_lds[(size_t)tid * 42 + i] = acc[i];
+  } else if (have) {
+    double* out = sp.partial + ((size_t)BX * sp.npairs + sp.slot_pair[tid]) * 42;
+#pragma unroll
+    for (int i = 0; i < 42; ++i) out[i] = acc[i];
+  }
+  __syncthreads();
+  for (int o = tid; o < sp.npairs * 42; o += blockDim.x) {
+    const int pr = o / 42, k = o - 42 * pr;
+    const int s0 = sp.pair_slots[2 * pr], s1 = sp.pair_slots[2 * pr + 1];
+    if (s0 >= sp.nd_slots) continue;
+    double v = 0;
+    for (int s = s0; s < s1; ++s) v += sp_lds[(size_t)s * 42 + k];
+    sp.partial[((size_t)BX * sp.npairs + pr) * 42 + k] = v;
+  }
+}
+
+// sum over the ranges, in order: one workgroup per pair; 4 x 64 threads = 4 interleaved range sub-sums x 42 values
+__device__ __forceinline__ void ba_schur_reduce_body(int BX, BaSp sp, double* __restrict__ pair_sum) {
+  __shared__ double sh[4][42];
+  const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double v = 0;
+  if (k < 42)
+    for (int r = g; r < sp.R; r += 4) v += sp.partial[((size_t)r * sp.npairs + BX) * 42 + k];
+  if (k < 42) sh[g][k] = v;
+  __syncthreads();
+  if (threadIdx.x < 42) pair_sum[(size_t)BX * 42 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}

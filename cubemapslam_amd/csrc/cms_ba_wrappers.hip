@@ -21,6 +21,7 @@ struct BaItem {
   const int2* chunk_range; const int2* tup; const int* pair_of_block; const int* pair_chunk_off;
   uint8_t* flags;
   int nblk_e, nblk_p, nchunks, pad;
+  BaSp sp;                                   // per-point Schur work lists (sp.R == 0: window uses the tuple-chunk kernel)
 };
 // ... and what changes from launch to launch, passed BY VALUE as a kernel argument: no host->device copy per Levenberg step
 struct BaDyn {
@@ -58,6 +59,10 @@ extern "C" __global__ void __launch_bounds__(256)
 k_ba_schur_chunks(BaDev d, const int2* chunk_range, const int2* tup, const double* Hpl, const double* Dinv, const double* db, double* chunk_sum) {
   ba_schur_chunks_body(blockIdx.x, gridDim.x, d, chunk_range, tup, Hpl, Dinv, db, chunk_sum);
 }
+extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS)
+k_ba_schur_points(BaDev d, BaSp sp, const double* Hpl, const double* Dinv, const double* db) { ba_schur_points_body(blockIdx.x, d, sp, Hpl, Dinv, db); }
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_schur_reduce(BaSp sp, double* pair_sum) { ba_schur_reduce_body(blockIdx.x, sp, pair_sum); }
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_classify(BaDev d, const double* poses, const double* pts, double chi2_th, int set_level, uint8_t* flags) {
   ba_classify_body(blockIdx.x, gridDim.x, d, poses, pts, chi2_th, set_level, flags);
@@ -128,6 +133,14 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_dinv(const BaItem* __res
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nchunks)
   ba_schur_chunks_body(blockIdx.x, it.nchunks, it.d, it.chunk_range, it.tup, it.Hpl, it.Dinv, it.db, it.chunk_sum);
+}
+extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS) kb_ba_schur_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.sp.R)
+  ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.sp.R > 0 ? it.sp.npairs : 0)
+  ba_schur_reduce_body(blockIdx.x, it.sp, it.chunk_sum);
 }
 extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)

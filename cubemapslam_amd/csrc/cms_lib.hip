@@ -4,6 +4,7 @@
 #include "cms_match_kernels.hip"
 #include "cms_ba_kernels.hip"
 #include "cms_ba_fused.hip"
+#include "cms_ba_schur_points.hip"
 #include "cms_ba_wrappers.hip"
 #include "cms_pose_opt.hip"
 #include "cms_api_frames.hip"
