@@ -240,7 +240,7 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
       hipLaunchKernelGGL(kb_ba_lin_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
       hipLaunchKernelGGL(kb_ba_lin_poses, dim3(max_K, BA_POSE_CHUNKS, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
       hipLaunchKernelGGL(kb_ba_pose_finish, dim3(std::max(max_np, 1), 1, n), dim3(64), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
     }
     if (n_trial) {
       hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);

@@ -169,6 +169,7 @@ __device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, cons
 // grid (K, BA_POSE_CHUNKS): every workgroup reduces one slice of the list into 27 partial sums (21 unique Hpp + 6 bp),
 // k_ba_pose_finish adds the slices in fixed order (deterministic, no atomics).
 #define BA_POSE_CHUNKS 8
+template <int N, int H> __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, int off);   // defined below
 __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
                double* __restrict__ pose_partial) {
   __shared__ double sh[4][27];
@@ -178,8 +179,8 @@ __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const
   const double* pose = poses + 7 * k;
   double R[9];
   quat_to_R(pose + 3, R);
-  double acc[27];
-  for (int i = 0; i < 27; ++i) acc[i] = 0;
+  double acc[28];
+  for (int i = 0; i < 28; ++i) acc[i] = 0;
   const int e0 = d.pose_off[k], e1 = d.pose_off[k + 1];
   const int per = (e1 - e0 + BA_POSE_CHUNKS - 1) / BA_POSE_CHUNKS;
   const int t0 = e0 + ch * per, t1 = min(e1, t0 + per);
@@ -198,10 +199,24 @@ __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const
       for (int j = i; j < 6; ++j) acc[c++] += ow * (Jp[i] * Jp[j] + Jp[6 + i] * Jp[6 + j]);
     for (int i = 0; i < 6; ++i) acc[21 + i] += -ow * (Jp[i] * r0 + Jp[6 + i] * r1);
   }
-  for (int i = 0; i < 27; ++i) {
-    double v = acc[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = v;
+  // 28 -> 1 value per lane with a reduce-scatter butterfly (29 double shuffles instead of 27 x 6), then the four waves in LDS
+  {
+    const int lane = threadIdx.x & 63;
+    double v14[14], v7[7], v4[4], v2[2], v1[1], v0[1];
+    rs_step<28, 14>(acc, v14, (lane & 32) != 0, 32);
+    rs_step<14, 7>(v14, v7, (lane & 16) != 0, 16);
+    rs_step<7, 4>(v7, v4, (lane & 8) != 0, 8);
+    rs_step<4, 2>(v4, v2, (lane & 4) != 0, 4);
+    rs_step<2, 1>(v2, v1, (lane & 2) != 0, 2);
+    rs_step<1, 1>(v1, v0, (lane & 1) != 0, 1);
+    int idx = 0, sz = 28;
+    { const bool h = lane & 32; idx += h ? 14 : 0; sz = h ? max(0, sz - 14) : min(14, sz); }
+    { const bool h = lane & 16; idx += h ? 7 : 0; sz = h ? max(0, sz - 7) : min(7, sz); }
+    { const bool h = lane & 8; idx += h ? 4 : 0; sz = h ? max(0, sz - 4) : min(4, sz); }
+    { const bool h = lane & 4; idx += h ? 2 : 0; sz = h ? max(0, sz - 2) : min(2, sz); }
+    { const bool h = lane & 2; idx += h ? 1 : 0; sz = h ? max(0, sz - 1) : min(1, sz); }
+    { const bool h = lane & 1; idx += h ? 1 : 0; sz = h ? max(0, sz - 1) : min(1, sz); }
+    if (sz > 0 && idx < 27) sh[threadIdx.x >> 6][idx] = v0[0];
   }
   __syncthreads();
   if (threadIdx.x < 27)

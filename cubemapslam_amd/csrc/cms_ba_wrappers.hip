@@ -112,17 +112,21 @@ extern "C" __global__ void __launch_bounds__(64) kb_ba_pose_finish(const BaItem*
 }
 // last kernel of the ITER phase, one workgroup per window: computeLambdaInit's max diagonal on the first iteration, then the
 // phase's scalars are published to the pinned host mirror (the host only has to wait for the stream, no D2H copy)
-extern "C" __global__ void __launch_bounds__(256) kb_ba_maxdiag(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+extern "C" __global__ void __launch_bounds__(1024) kb_ba_maxdiag(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
-  __shared__ double shm[4];
+  __shared__ double shm[16];
   if (dyn.first_iter[z]) {
     double m = 0;
-    for (int i = threadIdx.x; i < 6 * it.d.np; i += 256) m = fmax(m, fabs(it.Hpp[36 * (i / 6) + 7 * (i % 6)]));
-    for (int i = threadIdx.x; i < 3 * it.d.P; i += 256) m = fmax(m, fabs(it.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+    for (int i = threadIdx.x; i < 6 * it.d.np; i += blockDim.x) m = fmax(m, fabs(it.Hpp[36 * (i / 6) + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < 3 * it.d.P; i += blockDim.x) m = fmax(m, fabs(it.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) { const double mx = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3])); it.scal[3] = mx; it.hscal[3] = mx; }
+    if (threadIdx.x == 0) {
+      double mx = 0;
+      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) mx = fmax(mx, shm[i]);
+      it.scal[3] = mx; it.hscal[3] = mx;
+    }
   }
   if (threadIdx.x == 0) it.hscal[0] = it.scal[0];
 }
