@@ -553,6 +553,8 @@ k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ q
 #define PS 48
 #define BW 37
 #define BS 40
+#define RW 40            /* row-sum stride (16-bit entries): 10 quads per row */
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (i < 0) i = -i;
   if (i >= n) i = 2 * n - 2 - i;
@@ -567,8 +569,8 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
            uint8_t* __restrict__ desc) {
   // CMS_DESC_WPB key points per workgroup, one per wavefront, no data shared between them (wave-level synchronisation only)
   __shared__ __align__(16) uint8_t raw4[CMS_DESC_WPB][PW * PS + 16];
-  __shared__ uint16_t rowp4[CMS_DESC_WPB][PW * BW];
-  __shared__ uint8_t blr4[CMS_DESC_WPB][BW * BS];
+  __shared__ __align__(16) uint16_t rowp4[CMS_DESC_WPB][PW * RW];
+  __shared__ __align__(4) uint8_t blr4[CMS_DESC_WPB][BW * BS];
 #if CMS_DESC_WPB == 1
   const int wave = 0, lane = threadIdx.x;
 #else
@@ -622,18 +624,43 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
   for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
   const float angle = cms_fast_atan2((float)m01, (float)m10);
   // ---- separable Gaussian, rows then columns
-  for (int idx = lane; idx < PW * BW; idx += 64) {
-    const int r = idx / BW, c = idx - r * BW;
-    const uint8_t* p = rawp + r * PS + c;   // window [c, c+6] is centred on patch column c+3
-    rowp[idx] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+  // Row pass, four outputs per lane and step: 12 patch bytes come in as four aligned dwords (funnel-shifted by the patch's
+  // byte offset), the seven taps of two neighbouring outputs are evaluated at once on packed 16-bit lanes -- the row sum is at
+  // most 255 * 257 = 65535, so it is exact in 16 bits.  Outputs c = 37..39 of a row are computed from bytes that exist and
+  // are never read.
+  {
+    const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(raw);
+    for (int task = lane; task < PW * (RW / 4); task += 64) {
+      const int r = task / (RW / 4), q = task - r * (RW / 4);
+      const uint32_t* dp = raw32 + r * (PS / 4) + q;
+      const uint32_t d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
+      const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off), w1 = __builtin_amdgcn_alignbyte(d2, d1, off),
+                     w2 = __builtin_amdgcn_alignbyte(d3, d2, off);                        // patch bytes 4q .. 4q+11
+#define PK(hi, lo, k) __builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi, lo, (uint32_t)(k) | 0x0c00u | ((uint32_t)((k) + 1) << 16) | 0x0c000000u))
+      const us2_t P0 = PK(w1, w0, 0), P1 = PK(w1, w0, 1), P2 = PK(w1, w0, 2), P3 = PK(w1, w0, 3), P4 = PK(w1, w0, 4),
+                  P5 = PK(w1, w0, 5), P6 = PK(w1, w0, 6), P7 = PK(w2, w1, 3), P8 = PK(w2, w1, 4);   // P_k = (b_k, b_k+1)
+#undef PK
+      const us2_t c18 = {18, 18}, c34 = {34, 34}, c49 = {49, 49}, c55 = {55, 55};
+      const us2_t o01 = (P0 + P6) * c18 + (P1 + P5) * c34 + (P2 + P4) * c49 + P3 * c55;   // outputs 4q, 4q+1
+      const us2_t o23 = (P2 + P8) * c18 + (P3 + P7) * c34 + (P4 + P6) * c49 + P5 * c55;   // outputs 4q+2, 4q+3
+      uint2 out;
+      out.x = __builtin_bit_cast(uint32_t, o01); out.y = __builtin_bit_cast(uint32_t, o23);
+      *reinterpret_cast<uint2*>(rowp + r * RW + 4 * q) = out;
+    }
   }
   WAVE_SYNC();
-  for (int idx = lane; idx < BW * BW; idx += 64) {
-    const int r = idx / BW, c = idx - r * BW;
-    const uint16_t* p = rowp + r * BW + c;
-    const int s = 18 * ((int)p[0] + p[6 * BW]) + 34 * ((int)p[BW] + p[5 * BW]) + 49 * ((int)p[2 * BW] + p[4 * BW]) + 55 * (int)p[3 * BW];
-    const int v = (s + 32768) >> 16;
-    blr[r * BS + c] = (uint8_t)(v > 255 ? 255 : v);
+  // Column pass, two neighbouring columns per lane and step (one dword = two 16-bit row sums)
+  for (int task = lane; task < BW * (RW / 2); task += 64) {
+    const int r = task / (RW / 2), cp = task - r * (RW / 2);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + r * RW) + cp;
+    const uint32_t e0 = p[0], e1 = p[RW / 2], e2 = p[2 * (RW / 2)], e3 = p[3 * (RW / 2)], e4 = p[4 * (RW / 2)], e5 = p[5 * (RW / 2)],
+                   e6 = p[6 * (RW / 2)];
+    const int sl = 18 * (int)((e0 & 0xFFFF) + (e6 & 0xFFFF)) + 34 * (int)((e1 & 0xFFFF) + (e5 & 0xFFFF)) +
+                   49 * (int)((e2 & 0xFFFF) + (e4 & 0xFFFF)) + 55 * (int)(e3 & 0xFFFF);
+    const int sh = 18 * (int)((e0 >> 16) + (e6 >> 16)) + 34 * (int)((e1 >> 16) + (e5 >> 16)) + 49 * (int)((e2 >> 16) + (e4 >> 16)) +
+                   55 * (int)(e3 >> 16);
+    const int vl = min((sl + 32768) >> 16, 255), vh = min((sh + 32768) >> 16, 255);
+    *reinterpret_cast<uint16_t*>(blr + r * BS + 2 * cp) = (uint16_t)(vl | (vh << 8));
   }
   WAVE_SYNC();
   // ---- steered BRIEF: lane i evaluates tests 4i .. 4i+3
