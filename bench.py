@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
     ap.add_argument("--ba-groups", type=int, default=2, help="host threads / streams the local-BA windows of a step are split over")
     ap.add_argument("--pose-edges", type=int, default=600, help="matched map points per frame for the pose-only optimisation")
+    ap.add_argument("--force-gather", action="store_true", help="run the trajectory gather code path even with one rank (self-test)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -161,14 +162,13 @@ def main():
         ctx.hamming_best2_device(d_desc, d_qrow.data_ptr(), nq, d_desc, d_off.data_ptr(), d_idx.data_ptr(), d_lvl.data_ptr(), None,
                                  [o.data_ptr() for o in d_out])
         ctx.sync()
-        po.fetch()
+        _, frame_poses, _, _ = po.fetch()
         for th in ths:
             th.join()
         if ba_err:
             raise ba_err[0]
-        if world > 1:   # trajectory assembly on rank 0 over RCCL (64 B / frame, latency only)
-            poses, _, _ = bas[0].read()
-            rec = cdist.make_records(rank, i * B + np.arange(B), poses[np.arange(B) % len(poses)])
+        if world > 1 or args.force_gather:   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
+            rec = cdist.make_records(rank, i * B + np.arange(B), frame_poses)   # the frames' optimised poses, TUM order
             cdist.gather_trajectory(rec, device=dev, dst=0)
 
     def barrier():
