@@ -377,7 +377,7 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
     dim3 block(64, 4);
     dim3 grid((d.w + 255) / 256, (d.h + CMS_RZ_ROWS - 1) / CMS_RZ_ROWS, B);
     const double ratio = (double)g.lv[l - 1].w / d.w;
-    const int ls = (int)align_up((size_t)ceil(256 * ratio) + 12, 4);     // LDS row stride of the staged source rectangle
+    const int ls = (int)align_up((size_t)ceil(256 * ratio) + 34, 16);    // LDS row stride of the staged source rectangle (16-byte columns)
     const int lrows = (int)ceil(CMS_RZ_ROWS * ratio) + 5;
     hipLaunchKernelGGL(k_resize, grid, block, (size_t)ls * lrows, s, c->d_pyr, g.pyr_bytes, g.lv[l - 1], d,
                        (const CmsResizeTab*)(c->d_tab + d.tab_off), (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w), ls, clean, ratio);

@@ -101,35 +101,34 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
   if (skip_zero && (xl < dst.zlo || xb >= dst.w - dst.zhi) && (yl < dst.zlo || yb >= dst.h - dst.zhi)) return;
   // staged source rectangle: a conservative superset computed arithmetically (tap index s(d) = floor((d + 0.5) scale - 0.5)
   // lies in [floor(d scale) - 1, floor((d + 1) scale)]), so the pixel loads do not wait for the coefficient-table loads
-  const int c0 = max((int)floor(xb * scale) - 1, 0) & ~3;
+  const int c0 = max((int)floor(xb * scale) - 1, 0) & ~15;
   const int c1 = min((int)floor((xl + 1) * scale) + 1, src.w - 1);
   const int r0 = min(max((int)floor(yb * scale) - 1, 0), src.h - 1);
   const int r1 = min((int)floor((yl + 1) * scale) + 1, src.h - 1);
-  const int ndw = ((c1 - c0) >> 2) + 1, nr = r1 - r0 + 1;
+  const int nq = ((c1 - c0) >> 4) + 1, nr = r1 - r0 + 1;          // 16-byte columns (<= 32), rows
   const uint8_t* simg = pyr + (size_t)b * pyr_bytes + src.off;
   const int x0 = xb + 4 * tx;
-  // every global load of this thread (coefficient entries, then its share of the source rectangle) is issued before the
-  // first dependent use, so the workgroup pays one memory latency, not one per row
+  // every global load of this thread (coefficient entries, then its share of the source rectangle, 16 bytes per load: level
+  // rows are 128-byte aligned) is issued before the first dependent use, so the workgroup pays one memory latency, not one per row
   CmsResizeTab t4[4], tyr[CMS_RZ_ROWS / 4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) t4[i] = tabx[min(x0 + i, dst.w - 1)];
 #pragma unroll
   for (int rr = 0; rr < CMS_RZ_ROWS / 4; ++rr) tyr[rr] = taby[min(yb + ty + 4 * rr, dst.h - 1)];
   {
-    const int c = tid & 127, rs = tid >> 7;
-    const uint8_t* gp = simg + (size_t)r0 * src.stride + c0 + 4 * c;
-    for (int rbase = 0; rbase < nr; rbase += 16) {
-      uint32_t tmp[8];
+    const int c = tid & 31, rs = tid >> 5;
+    const uint8_t* gp = simg + (size_t)r0 * src.stride + c0 + 16 * c;
+    constexpr int NLD = (CMS_RZ_ROWS * 2 + 5 + 7) / 8;               // rows staged <= 1.9 * CMS_RZ_ROWS + 5
+    uint4 tmp[NLD];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int r = rbase + rs + 2 * k;
-        tmp[k] = (c < ndw && r < nr) ? *reinterpret_cast<const uint32_t*>(gp + (size_t)r * src.stride) : 0u;
-      }
+    for (int k = 0; k < NLD; ++k) {
+      const int r = rs + 8 * k;
+      tmp[k] = (c < nq && r < nr) ? *reinterpret_cast<const uint4*>(gp + (size_t)r * src.stride) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int r = rbase + rs + 2 * k;
-        if (c < ndw && r < nr) reinterpret_cast<uint32_t*>(rtile + r * ls)[c] = tmp[k];
-      }
+    for (int k = 0; k < NLD; ++k) {
+      const int r = rs + 8 * k;
+      if (c < nq && r < nr) reinterpret_cast<uint4*>(rtile + r * ls)[c] = tmp[k];
     }
   }
   __syncthreads();
@@ -210,7 +209,7 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int t) {
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
 #ifndef CMS_FAST_LD
-#define CMS_FAST_LD 8       /* row loads in flight per lane while staging the ROI */
+#define CMS_FAST_LD 8       /* row loads in flight per lane while staging the ROI (16-byte loads were measured slower here) */
 #endif
 #ifndef CMS_FAST_WPB
 #define CMS_FAST_WPB 1      /* cells (wavefronts) per workgroup; measured: 1 -> 0.34 ms, 4 -> 0.38 ms per 32 frames */
