@@ -252,6 +252,24 @@ def test_ba_optimize_many_lockstep_equals_individual_runs():
         ba.close()
 
 
+def test_ba_optimize_many_mixed_sizes_point_major_schur():
+    """The batched driver with the point-major Schur kernel on windows of very different shape: 19 / 24 / 11 free key frames
+    (171 / 276 / 55 off-diagonal pose pairs -> different owner-thread layouts in one launch), 3 to 6 observations per point."""
+    probs = [synth.ba_problem(K=20, P=3000, obs_per_point=4, F=550, seed=21), synth.ba_problem(K=25, P=1500, obs_per_point=6, F=550, seed=22),
+             synth.ba_problem(K=12, P=900, obs_per_point=3, F=650, seed=23), synth.ba_problem(K=20, P=3000, obs_per_point=4, F=550, seed=24)]
+    bas = [api.BundleAdjuster(p) for p in probs]
+    rc, stats = api.ba_optimize_many(bas)
+    assert rc == 0
+    for ba, p, st in zip(bas, probs, stats):
+        poses, pts, flags = ba.read()
+        w = orc.ba_run(p)
+        assert list(st.iterations_done) == list(w["stats"].iterations_done)
+        assert np.abs((pts - p["points"]) - (w["points"] - p["points"])).max() <= 1e-4 * np.abs(w["points"] - p["points"]).max()
+        assert np.abs((poses - p["poses"]) - (w["poses"] - p["poses"])).max() <= 1e-4 * np.abs(w["poses"] - p["poses"]).max()
+        assert np.array_equal(flags, w["outliers"])
+        ba.close()
+
+
 def test_ba_run_config4_full_size():
     """BASELINE.json configs[3]: 20 keyframes x 4000 edges (E = 80 000, P = 20 000), 1e-4 vs the CPU path."""
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=650, seed=42)
