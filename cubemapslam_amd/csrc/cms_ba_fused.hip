@@ -274,7 +274,7 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
     for (int i = 0; i < 4; ++i) Tn[3 + i] = q[i];
   }
   // pose part of the gain denominator + solver status (status travels as a double next to the other scalars)
-  __shared__ double shs[8];
+  __shared__ double shs[16];
   for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
   if ((tid & 63) == 0) shs[tid >> 6] = sc;
   __syncthreads();
@@ -296,7 +296,7 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                   const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
                   const double* __restrict__ poses_new, int robust, double delta, double* __restrict__ partial) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   const int p = BX * blockDim.x + threadIdx.x;
   double sc = 0, chi = 0;
   if (p < d.P) {
@@ -340,7 +340,7 @@ __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, co
 // scal[1] = sum(partial[0..n)), scal[2] = sum(partial[n..2n)) + scal[5]
 __device__ __forceinline__ void ba_reduce2_body(int BX, int GX, const double* __restrict__ partial, int n, double* __restrict__ scal,
                                                 double* __restrict__ hscal = nullptr) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   double v1 = 0, v2 = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) { v1 += partial[i]; v2 += partial[n + i]; }
   const double s1 = block_sum(v1, sh);

@@ -110,7 +110,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 // ---- residuals + robust chi2 partial sums (one partial per workgroup, reduced in fixed order by k_ba_reduce)
 __device__ __forceinline__ void ba_errors_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
             double* __restrict__ partial) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   const int e = BX * blockDim.x + threadIdx.x;
   double rho0 = 0;
   if (e < d.E && d.level[e] == 0) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void ba_errors_body(int BX, int GX, BaDev d, const do
   if (threadIdx.x == 0) partial[BX] = s;
 }
 __device__ __forceinline__ void ba_reduce_body(int BX, int GX, const double* __restrict__ partial, int n, double* __restrict__ out, int add) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   double v = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
   const double s = block_sum(v, sh);
@@ -171,9 +171,10 @@ __device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, cons
 #define BA_POSE_CHUNKS 8
 template <int N, int H> __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, int off);   // defined below
 __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
-               double* __restrict__ pose_partial) {
-  __shared__ double sh[4][27];
-  const int k = BX, ch = blockIdx.y;
+               double* __restrict__ pose_partial, int ch_arg = -1) {
+  __shared__ double sh[16][27];
+  const int k = BX, ch = ch_arg >= 0 ? ch_arg : (int)blockIdx.y;
+  __syncthreads();                                  // a previous virtual block of the same workgroup may still read sh
   const int slot = d.pose_slot[k];
   if (slot < 0) return;
   const double* pose = poses + 7 * k;
@@ -219,9 +220,11 @@ __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const
     if (sz > 0 && idx < 27) sh[threadIdx.x >> 6][idx] = v0[0];
   }
   __syncthreads();
-  if (threadIdx.x < 27)
-    pose_partial[((size_t)slot * BA_POSE_CHUNKS + ch) * 27 + threadIdx.x] =
-        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (threadIdx.x < 27) {
+    double v = 0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) v += sh[wv][threadIdx.x];
+    pose_partial[((size_t)slot * BA_POSE_CHUNKS + ch) * 27 + threadIdx.x] = v;
+  }
 }
 __device__ __forceinline__ void ba_pose_finish_body(int BX, int GX, int np, const double* __restrict__ pose_partial, double* __restrict__ Hpp, double* __restrict__ bp) {
   const int slot = BX, t = threadIdx.x;
@@ -304,13 +307,14 @@ __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, 
 }
 __device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDev d, const int2* __restrict__ chunk_range, const int2* __restrict__ tup, const double* __restrict__ Hpl,
                   const double* __restrict__ Dinv, const double* __restrict__ db, double* __restrict__ chunk_sum) {
-  __shared__ double sh[4][42];
+  __shared__ double sh[16][42];
   const int2 rg = chunk_range[BX];
+  __syncthreads();                                  // a previous virtual block of the same workgroup may still read sh
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc[42];
 #pragma unroll
   for (int i = 0; i < 42; ++i) acc[i] = 0;
-  for (int t = rg.x + threadIdx.x; t < rg.y; t += 256) {
+  for (int t = rg.x + threadIdx.x; t < rg.y; t += blockDim.x) {
     const int2 aa = tup[t];
     if (d.level[aa.x] == 0 && d.level[aa.y] == 0) {
       const int p = d.e_point[aa.x];
@@ -351,7 +355,9 @@ __device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDev d, co
   __syncthreads();
   if (threadIdx.x < 42) {
     const int k = threadIdx.x;
-    chunk_sum[(size_t)BX * 42 + k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
+    double v = 0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) v += sh[wv][k];
+    chunk_sum[(size_t)BX * 42 + k] = v;
   }
 }
 extern "C" __global__ void __launch_bounds__(64)
@@ -657,7 +663,7 @@ extern "C" __global__ void __launch_bounds__(128)
 k_ba_backsub(BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
              const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
              double* __restrict__ partial) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   double sc = 0;
   if (p < d.P) {
