@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
     ap.add_argument("--ba-groups", type=int, default=2, help="host threads / streams the local-BA windows of a step are split over")
     ap.add_argument("--pose-edges", type=int, default=600, help="matched map points per frame for the pose-only optimisation")
+    ap.add_argument("--save-trajectory", default="", help="rank 0 writes the gathered trajectory of the last step here (TUM format)")
     ap.add_argument("--force-gather", action="store_true", help="run the trajectory gather code path even with one rank (self-test)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -153,6 +154,8 @@ def main():
             ba_err.append(e)
         ba_ms[0] += 1e3 * (time.perf_counter() - t_ba0) / n_grp; ba_ms[1] += 1.0 / n_grp
 
+    last_traj = [None]
+
     def step(i):
         ths = [threading.Thread(target=ba_worker, args=(grp,)) for grp in groups]
         for th in ths:
@@ -169,7 +172,9 @@ def main():
             raise ba_err[0]
         if world > 1 or args.force_gather:   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
             rec = cdist.make_records(rank, i * B + np.arange(B), frame_poses)   # the frames' optimised poses, TUM order
-            cdist.gather_trajectory(rec, device=dev, dst=0)
+            traj = cdist.gather_trajectory(rec, device=dev, dst=0)
+            if traj is not None:
+                last_traj[0] = traj
 
     def barrier():
         if world > 1:
@@ -287,6 +292,17 @@ def main():
                          (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_pose, n_cpu_ba, 1e3 * t_ba, args.ba_every),
                "host_cores_available": os.cpu_count()}
 
+    if rank == 0 and args.save_trajectory and last_traj[0] is not None:
+        # rank 0's assembled trajectory of the last step in the reference's TUM format (System.cpp:238-268)
+        tr = last_traj[0]
+        q = tr[:, 5:9]
+        x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        Tcw = np.zeros((len(tr), 4, 4), np.float32)
+        Tcw[:, 0, 0] = 1 - 2 * (y * y + z * z); Tcw[:, 0, 1] = 2 * (x * y - z * w); Tcw[:, 0, 2] = 2 * (x * z + y * w)
+        Tcw[:, 1, 0] = 2 * (x * y + z * w); Tcw[:, 1, 1] = 1 - 2 * (x * x + z * z); Tcw[:, 1, 2] = 2 * (y * z - x * w)
+        Tcw[:, 2, 0] = 2 * (x * z - y * w); Tcw[:, 2, 1] = 2 * (y * z + x * w); Tcw[:, 2, 2] = 1 - 2 * (x * x + y * y)
+        Tcw[:, :3, 3] = tr[:, 2:5]; Tcw[:, 3, 3] = 1
+        cdist.write_trajectory_tum(args.save_trajectory, tr[:, 1], Tcw)
     if rank == 0:
         total_frames = B * args.steps * world
         out = {

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <fstream>
+#include <iomanip>
 #include <stdexcept>
 
 namespace CubemapSLAM {
@@ -229,6 +231,26 @@ static void R_to_quat(const double m[9], double* q) {  // Eigen::Quaterniond(Mat
     q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t; q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
   }
 }
+void System::SaveKeyFrameTrajectoryTUM(const std::string& filename, const std::vector<TrajectoryKeyFrame>& vpKFs) {
+  std::ofstream f(filename.c_str());
+  f << std::fixed;
+  for (const TrajectoryKeyFrame& kf : vpKFs) {
+    if (kf.bad) continue;
+    double Rt[9];                                           // R^T = GetRotation().t(), through Converter::toMatrix3d (float -> double)
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rt[3 * r + c] = kf.Tcw.at<float>(c, r);
+    double q[4];
+    R_to_quat(Rt, q);                                       // Eigen::Quaterniond(Matrix3d), stored as float (Converter.cpp:141-153)
+    float t[3];                                             // KeyFrame::GetCameraCenter() = -R^T t in float arithmetic (KeyFrame.cpp SetPose)
+    for (int r = 0; r < 3; ++r) {
+      float acc = 0.f;
+      for (int c = 0; c < 3; ++c) acc += kf.Tcw.at<float>(c, r) * kf.Tcw.at<float>(c, 3);
+      t[r] = -acc;
+    }
+    f << std::setprecision(6) << kf.mTimeStamp << std::setprecision(7) << " " << t[0] << " " << t[1] << " " << t[2] << " " << (float)q[0] << " "
+      << (float)q[1] << " " << (float)q[2] << " " << (float)q[3] << std::endl;
+  }
+}
+
 int Optimizer::PoseOptimization(PoseFrame* fr) {
   CamModelGeneral* cam = CamModelGeneral::GetCamera();
   const int N = fr->N;

@@ -51,8 +51,15 @@ class CamModelGeneral {
 // camera singleton + System instance).  Throws std::runtime_error when the HIP library cannot create a context.
 cms_ctx* SharedContext(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
 
+// one key frame of the trajectory output: KeyFrame::mTimeStamp and its world->camera pose (KeyFrame::GetPose(), 4x4 CV_32F)
+struct TrajectoryKeyFrame { double mTimeStamp; cv::Mat Tcw; bool bad = false; };
+
 class System {
  public:
+  // System.cpp:238-268: one line per (non-bad) key frame, "ts tx ty tz qx qy qz qw" with the camera centre -R^T t and the
+  // quaternion of R^T through float, fixed notation, 6 digits for the time stamp and 7 for the rest.  The caller passes
+  // the key frames already sorted by id (the reference sorts with KeyFrame::lId).
+  static void SaveKeyFrameTrajectoryTUM(const std::string& filename, const std::vector<TrajectoryKeyFrame>& vpKFs);
   void CreateUndistortRectifyMap();  // builds the LUT on the device (inside the shared context)
   void CvtFisheyeToCubeMap_reverseQuery_withInterpolation(cv::Mat& cubemapImg, const cv::Mat& fisheyeImg, int interpolation,
                                                           int borderType = cv::BORDER_CONSTANT,

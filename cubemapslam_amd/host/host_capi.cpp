@@ -115,3 +115,12 @@ extern "C" int hm_pose_optimization(float* Tcw, int N, const cms_keypoint* kps, 
     for (int i = 0; i < N; ++i) outlier[i] = (i < (int)fr.mvbOutlier.size() && fr.mvbOutlier[i]) ? 1 : 0;
     return r;)
 }
+
+// System::SaveKeyFrameTrajectoryTUM on n key frames given as time stamps + 4x4 float Tcw
+extern "C" int hm_save_trajectory_tum(const char* path, int n, const double* ts, float* Tcw) {
+  HM_TRY(
+    std::vector<TrajectoryKeyFrame> v(n);
+    for (int i = 0; i < n; ++i) { v[i].mTimeStamp = ts[i]; v[i].Tcw = cv::Mat(4, 4, cv::CV_32F, Tcw + 16 * (size_t)i, 16); }
+    System::SaveKeyFrameTrajectoryTUM(path, v);
+    return n;)
+}
