@@ -314,17 +314,29 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   return CMS_OK;
 }
 
+// restore the initial estimate and clear the per-edge state: one launch (five copies / memsets cost more in dispatch than in work)
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_reset(int K, int P, int E, const double* __restrict__ poses0, const double* __restrict__ pts0, double* __restrict__ poses,
+           double* __restrict__ pts, uint8_t* __restrict__ level, double* __restrict__ err, uint8_t* __restrict__ flags) {
+  const int gs = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * E; i += gs) {
+    err[i] = 0.0;
+    if (i < E) { level[i] = 0; flags[i] = 0; }
+    if (i < 7 * K) poses[i] = poses0[i];
+    if (i < 3 * P) pts[i] = pts0[i];
+  }
+  for (int i = 2 * E + blockIdx.x * blockDim.x + threadIdx.x; i < 3 * P; i += gs) pts[i] = pts0[i];      // P large relative to E
+  for (int i = 2 * E + blockIdx.x * blockDim.x + threadIdx.x; i < 7 * K; i += gs) poses[i] = poses0[i];
+}
 extern "C" int cms_ba_reset(cms_ba* b) {
   if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
   HIPCHK(hipSetDevice(b->device));
   b->cur = 0;
-  HIPCHK(hipMemcpyAsync(b->d_poses[0], b->d_poses0, 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_pts[0], b->d_pts0, 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-  HIPCHK(hipMemsetAsync(b->d_level, 0, b->E, b->stream));
-  HIPCHK(hipMemsetAsync(b->d_err, 0, 2 * (size_t)b->E * sizeof(double), b->stream));
-  HIPCHK(hipMemsetAsync(b->d_flags, 0, b->E, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
-  return CMS_OK;
+  const int n = std::max(2 * b->E, std::max(3 * b->P, 7 * b->K));
+  hipLaunchKernelGGL(k_ba_reset, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, b->stream, b->K, b->P, b->E, (const double*)b->d_poses0,
+                     (const double*)b->d_pts0, b->d_poses[0], b->d_pts[0], b->d_level, b->d_err, b->d_flags);
+  HIPCHK(hipGetLastError());
+  return CMS_OK;       // asynchronous on the window's stream: every consumer (optimize, read) orders itself behind it
 }
 
 // chi2 of the active edges at state `which` -> d_scal[slot]; refreshes d_err
