@@ -461,25 +461,36 @@ k_quadtree(CmsGeom g, const uint32_t* __restrict__ cell_cand, const int* __restr
     const int* cc = cell_cnt + (size_t)b * g.total_cells + lv.cell0;
     const uint32_t* cs = cell_cand + ((size_t)b * g.total_cells + lv.cell0) * g.cell_cap;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int running = 0;
-    for (int c0 = 0; c0 < ncells; c0 += 512) {
-      const int cell = c0 + (int)threadIdx.x;
-      const int cnt = cell < ncells ? cc[cell] : 0;
-      int incl = cnt;
+    // thread t owns the cells [t * per, (t + 1) * per): one block-wide scan for the whole level (not one per 512 cells), all
+    // count loads in flight together, then every thread copies its cells' entries with four loads in flight
+    const int per = (ncells + 511) / 512;
+    const int cb = (int)threadIdx.x * per, ce = min(cb + per, ncells);
+    int mine = 0;
+    for (int cell = cb; cell < ce; ++cell) mine += cc[cell];
+    int incl = mine;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-      if (lane == 63) w.part[wv] = (uint32_t)incl;
-      __syncthreads();
-      int wbase = 0, total = 0;
-      for (int q = 0; q < 8; ++q) { const int v = (int)w.part[q]; if (q < wv) wbase += v; total += v; }
-      const int off = running + wbase + incl - cnt;
-      for (int i = 0; i < cnt; ++i) {
-        if (off + i < lv.cand_cap) cwr[off + i] = cs[(size_t)cell * g.cell_cap + i];
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) w.part[wv] = (uint32_t)incl;
+    __syncthreads();
+    int wbase = 0, running = 0;
+    for (int q = 0; q < 8; ++q) { const int v = (int)w.part[q]; if (q < wv) wbase += v; running += v; }
+    int off = wbase + incl - mine;
+    for (int cell = cb; cell < ce; ++cell) {
+      const int cnt = cc[cell];
+      const uint32_t* src = cs + (size_t)cell * g.cell_cap;
+      int i = 0;
+      for (; i + 3 < cnt; i += 4) {
+        const uint32_t v0 = src[i], v1 = src[i + 1], v2 = src[i + 2], v3 = src[i + 3];
+        if (off + i + 3 < lv.cand_cap) { cwr[off + i] = v0; cwr[off + i + 1] = v1; cwr[off + i + 2] = v2; cwr[off + i + 3] = v3; }
         else *overflow = 1;
       }
-      running += total;
-      __syncthreads();
+      for (; i < cnt; ++i) {
+        if (off + i < lv.cand_cap) cwr[off + i] = src[i];
+        else *overflow = 1;
+      }
+      off += cnt;
     }
+    __syncthreads();
     if (threadIdx.x == 0) cand_cnt[b * g.nlevels + l] = min(running, lv.cand_cap);
     P.n = min(running, lv.cand_cap);
   }
@@ -490,7 +501,8 @@ k_quadtree(CmsGeom g, const uint32_t* __restrict__ cell_cand, const int* __restr
   const uint32_t* c = cand + (size_t)b * g.cand_total + lv.cand_off;
   uint16_t* no = node_of + (size_t)b * g.cand_total + lv.cand_off;
   uint32_t* out = qt_out + (size_t)b * g.kp_cap + lv.kp_off;
-  const int S = qt_run(P, c, no, w, out);
+  if (g.dbg_stop == 30) { if (threadIdx.x == 0) qt_cnt[b * g.nlevels + l] = 0; return; }      // developer switch: gather only
+  const int S = qt_run(P, c, no, w, out, g.dbg_stop >= 31 ? g.dbg_stop - 30 : 0);
   if (threadIdx.x == 0) qt_cnt[b * g.nlevels + l] = S;
 }
 

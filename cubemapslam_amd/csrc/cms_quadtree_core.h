@@ -101,23 +101,18 @@ QT_DEV void qt_sort_desc(uint32_t* keys, int n, const QtWork& w) {
 #ifdef CMS_QT_HOST_EMU
   std::sort(keys, keys + n, [](uint32_t a, uint32_t b) { return a > b; });
 #else
-  int np2 = 1;
-  while (np2 < n) np2 <<= 1;
-  QT_PARFOR(i, np2) if (i >= n) keys[i] = 0u;
-  __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      QT_PARFOR(i, np2) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const uint32_t a = keys[i], b = keys[ixj];
-          const bool desc = ((i & k) == 0);
-          if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
+  // keys are unique (count << 12 | creation sequence), so the position of a key in descending order is the number of keys
+  // greater than it: one pass of n broadcast LDS reads per thread and two barriers, instead of the ~45 barrier-separated
+  // compare-exchange steps of a bitonic network on 512 keys.  w.s1 is free at this point and serves as the output buffer.
+  QT_PARFOR(i, n) {
+    const uint32_t k = keys[i];
+    int r = 0;
+    for (int q = 0; q < n; ++q) r += keys[q] > k ? 1 : 0;
+    w.s1[r] = k;
   }
+  __syncthreads();
+  QT_PARFOR(i, n) keys[i] = w.s1[i];
+  __syncthreads();
 #endif
 }
 
@@ -187,15 +182,17 @@ QT_DEV void qt_apply_round(const QtParams& P, const uint32_t* cand, uint16_t* no
     }
   }
   QT_SYNC();
+  // the child counters of this round are consumed; clear them for the NEW list, then re-label every candidate and let it vote
+  // its quadrant inside its new node in the same pass (one walk over the candidates per round instead of two)
+  QT_PARFOR(k, 4 * (totC + nkeep)) w.childcnt[k] = 0u;
+  QT_SYNC();
   QT_PARFOR(i, P.n) {
     const int p = node_of[i];
-    if (w.flag[p]) {
-      const uint32_t c = cand[i];
-      const int q = qt_quadrant(rc[p], QT_CX(c) - P.minB, QT_CY(c) - P.minB);
-      node_of[i] = w.childpos[4 * p + q];
-    } else {
-      node_of[i] = w.childpos[4 * p];
-    }
+    const uint32_t c = cand[i];
+    const int x = QT_CX(c) - P.minB, y = QT_CY(c) - P.minB;
+    const int np_ = w.flag[p] ? w.childpos[4 * p + qt_quadrant(rc[p], x, y)] : w.childpos[4 * p];
+    node_of[i] = (uint16_t)np_;
+    qt_atomic_add(&w.childcnt[4 * np_ + qt_quadrant(rn[np_], x, y)], 1u);
   }
   QT_SYNC();
   QT_SINGLE { w.sc[QT_CUR] = nxt; w.sc[QT_S] = totC + nkeep; w.sc[QT_PREVTOTC] = totC; }
@@ -219,7 +216,7 @@ QT_DEV void qt_vote(const QtParams& P, const uint32_t* cand, const uint16_t* nod
 }
 
 // Returns the number of surviving key points; out[pos] = packed (x | y<<12 | response<<24) in list order.
-QT_DEV int qt_run(const QtParams& P, const uint32_t* cand, uint16_t* node_of, const QtWork& w, uint32_t* out) {
+QT_DEV int qt_run(const QtParams& P, const uint32_t* cand, uint16_t* node_of, const QtWork& w, uint32_t* out, int dbg = 0) {
   if (P.n <= 0) return 0;
   QT_SINGLE {
     w.sc[QT_CUR] = 0; w.sc[QT_S] = 1; w.sc[QT_NEX] = 0; w.sc[QT_FIN] = 0; w.sc[QT_PREVTOTC] = 0;
@@ -227,8 +224,11 @@ QT_DEV int qt_run(const QtParams& P, const uint32_t* cand, uint16_t* node_of, co
     w.rect[0][0] = r; w.cnt[0][0] = (uint32_t)P.n; w.isex[0] = 0;
   }
   QT_PARFOR(i, P.n) node_of[i] = 0;
+  QT_SINGLE { w.flag[0] = 1; }
   QT_SYNC();
-  for (int guard = 0; guard < 64 && !w.sc[QT_FIN]; ++guard) {
+  qt_vote(P, cand, node_of, w);                  // root: every later vote happens inside qt_apply_round's re-labelling pass
+  if (dbg == 1) return 0;                        // developer switch (CMS_DBG_FAST_STOP=31): timing of the phases
+  for (int guard = 0; guard < 64 && !w.sc[QT_FIN] && !(dbg >= 10 && guard >= dbg - 10); ++guard) {
     // ---- main pass: split every node that holds more than one key point (ORBExtractor.cpp:565-636)
     const int prevS = w.sc[QT_S];
     {
@@ -241,8 +241,7 @@ QT_DEV int qt_run(const QtParams& P, const uint32_t* cand, uint16_t* node_of, co
       QT_SYNC();
     }
     const int m = w.sc[QT_M];
-    qt_vote(P, cand, node_of, w);
-    qt_apply_round(P, cand, node_of, w, m);
+    qt_apply_round(P, cand, node_of, w, m);     // the votes were cast while the previous round re-labelled (or by the initial vote)
     int S = w.sc[QT_S];
     const int nEx = w.sc[QT_NEX];
     QT_SYNC();
@@ -267,7 +266,6 @@ QT_DEV int qt_run(const QtParams& P, const uint32_t* cand, uint16_t* node_of, co
         QT_SYNC();
         qt_sort_desc(w.skey, mall, w);
         QT_SYNC();
-        qt_vote(P, cand, node_of, w);
         // size after each split, in processing order; cut at the first that reaches N
         QT_PARFOR(j, mall) {
           const int p = totCprev - 1 - (int)(w.skey[j] & 0xFFFu);
@@ -309,6 +307,7 @@ QT_DEV int qt_run(const QtParams& P, const uint32_t* cand, uint16_t* node_of, co
     }
     QT_SYNC();
   }
+  if (dbg == 2 || dbg >= 10) return 0;
   // ---- retain the best point of every node (ORBExtractor.cpp:713-734): max response, first in candidate order
   const int S = w.sc[QT_S];
   unsigned long long* best = (unsigned long long*)w.childcnt;
