@@ -24,6 +24,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(api.Camera) == 5 * 8 + 12 * 8 + 5 * 8 + 3 * 4 + 4 + 8
     assert C.sizeof(api.OrbParams) == 20 and api.KP_DTYPE.itemsize == 24
     assert C.sizeof(api.BaStats) == 8 + 6 * 8 + 8
+    assert C.sizeof(api.PoseStats) == 6 * 4
 
 
 def test_no_cpu_fallback():
@@ -35,6 +36,10 @@ def test_no_cpu_fallback():
     assert "no HIP device" in str(ei.value) or "failed" in str(ei.value)
     with pytest.raises(api.CmsError):
         api.ba_run(synth.ba_problem(K=3, P=10, obs_per_point=2, seed=1))
+    with pytest.raises(api.CmsError):
+        api.PoseOptimizer(1, 16)
+    with pytest.raises(api.CmsError):
+        api.pose_optimize(synth.pose_problem(N=20, seed=1))
 
 
 def test_product_sources_do_not_touch_the_oracle():

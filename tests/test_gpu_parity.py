@@ -312,3 +312,40 @@ def test_pose_optimization_matches_oracle():
     # one-shot entry point
     n1, pose1, out1, st1 = api.pose_optimize(probs[0])
     assert n1 == ninl[0] and np.array_equal(out1, outs[0]) and np.array_equal(pose1, poses[0])
+
+
+def test_c_abi_error_paths():
+    """the C-ABI reports misuse with a status code and a message instead of crashing or silently truncating"""
+    import ctypes as C
+    L = api.lib()
+    camd = synth.camera("lafida", 150)
+    ctx = api.Context(camd, nfeatures=800, max_batch=2)
+    ctx.set_mask(np.full((450, 450), 255, np.uint8))
+    fish = synth.texture(camd["Ih"], camd["Iw"], 3)
+    k, d = ctx.remap_extract(fish)
+    assert len(k) > 50
+    # caller capacity too small -> CMS_ERR_OVERFLOW (-4), count still reported
+    kp = np.zeros(8, api.KP_DTYPE); ds = np.zeros((8, 32), np.uint8); n = C.c_int(0)
+    rc = L.cms_frames_fetch(ctx.h, 0, kp.ctypes.data_as(C.c_void_p), ds.ctypes.data_as(C.c_void_p), 8, C.byref(n))
+    assert rc == -4 and n.value == len(k) and b"capacity" in L.cms_last_error()
+    # batch larger than the context was created for / bad frame index -> CMS_ERR_ARG (-1)
+    assert L.cms_frames_process(ctx.h, 3, 1) == -1
+    assert L.cms_frames_fetch(ctx.h, 5, None, None, 0, C.byref(n)) == -1
+    ctx.close()
+    # BA: edge referring to a key frame that does not exist, face id out of range
+    prob = synth.ba_problem(K=4, P=50, obs_per_point=3, F=550, seed=2)
+    bad = dict(prob); bad["e_pose"] = prob["e_pose"].copy(); bad["e_pose"][0] = 99
+    with pytest.raises(api.CmsError):
+        api.BundleAdjuster(bad)
+    bad = dict(prob); bad["e_face"] = prob["e_face"].copy(); bad["e_face"][3] = 5
+    with pytest.raises(api.CmsError):
+        api.BundleAdjuster(bad)
+    # pose optimisation: more edges than the handle holds, unknown face (the reference exits the process there)
+    pp = synth.pose_problem(N=100, seed=3)
+    po = api.PoseOptimizer(1, 50)
+    with pytest.raises(api.CmsError):
+        po.upload([pp])
+    po.close()
+    bad = dict(pp); bad["face"] = pp["face"].copy(); bad["face"][0] = 7
+    with pytest.raises(api.CmsError):
+        api.pose_optimize(bad)
