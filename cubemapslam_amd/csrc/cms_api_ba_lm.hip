@@ -243,7 +243,8 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
       hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
     }
     if (n_trial) {
-      hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (!all_sp)    // the point-major Schur kernel and the trial-points kernel invert Hll + lambda I themselves
+        hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       if (all_sp) {
         hipLaunchKernelGGL(kb_ba_schur_points, dim3(max_R, 1, n), dim3(max_spt), sp_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         hipLaunchKernelGGL(kb_ba_schur_reduce, dim3(max_pairs, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);

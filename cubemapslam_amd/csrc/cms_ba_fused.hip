@@ -295,7 +295,10 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 // point's edges at the trial state.  partial[blk] = chi2 sum, partial[nblk + blk] = denominator sum.
 __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                   const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
-                  const double* __restrict__ poses_new, int robust, double delta, double* __restrict__ partial) {
+                  const double* __restrict__ poses_new, int robust, double delta, double* __restrict__ partial,
+                  const double* __restrict__ Hll = nullptr) {
+  // Hll != nullptr: (Hll + lambda I)^-1 is evaluated here (same arithmetic as k_ba_dinv) and `Dinv` is not read -- the batched
+  // driver then needs no separate inversion kernel
   __shared__ double sh[16];
   const int p = BX * blockDim.x + threadIdx.x;
   double sc = 0, chi = 0;
@@ -312,7 +315,13 @@ __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, co
       for (int j = 0; j < 3; ++j)
         for (int i = 0; i < 6; ++i) cl[j] -= B[3 * i + j] * xp[6 * s + i];
     }
-    const double* Di = Dinv + 9 * (size_t)p;
+    double Dl[9];
+    if (Hll) {
+      double D[9];
+      for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
+      inv3(D, Dl);
+    }
+    const double* Di = Hll ? Dl : Dinv + 9 * (size_t)p;
     double X[3];
     for (int i = 0; i < 3; ++i) {
       const double xl = nact > 0 ? Di[3 * i] * cl[0] + Di[3 * i + 1] * cl[1] + Di[3 * i + 2] * cl[2] : 0.0;

@@ -41,7 +41,10 @@ struct BaSp {                      // device view of the host-built work lists (
 };
 
 __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
-                                                     const double* __restrict__ db) {
+                                                     const double* __restrict__ db, const double* __restrict__ Hll = nullptr,
+                                                     const double* __restrict__ bl = nullptr, double lambda = 0.0) {
+  // Hll != nullptr: the staging thread inverts (Hll + lambda I) of its edge's point itself (same arithmetic as k_ba_dinv; a
+  // point's k edges repeat it, which is cheaper than a separate kernel) and Dinv / db are not read
   extern __shared__ __align__(16) double sp_lds[];      // [BA_SP_MAXE][42], reused at the end for the helper sums
   const int tid = threadIdx.x;
   const bool have = tid < sp.nslots;
@@ -65,14 +68,25 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
     if (mine) {
       const int e = e0 + tid, p = d.e_point[e];
       const double* B = Hpl + 18 * (size_t)e;
-      const double* Di = Dinv + 9 * (size_t)p;
-      const double* dbp = db + 3 * (size_t)p;
 #pragma unroll
       for (int i = 0; i < 18; ++i) Bv[i] = B[i];
+      if (Hll) {
+        double D[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) Dv[i] = Di[i];
+        for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
+        const double b0 = bl[3 * (size_t)p], b1 = bl[3 * (size_t)p + 1], b2 = bl[3 * (size_t)p + 2];
+        inv3(D, Dv);
+        dv[0] = Dv[0] * b0 + Dv[1] * b1 + Dv[2] * b2;
+        dv[1] = Dv[3] * b0 + Dv[4] * b1 + Dv[5] * b2;
+        dv[2] = Dv[6] * b0 + Dv[7] * b1 + Dv[8] * b2;
+      } else {
+        const double* Di = Dinv + 9 * (size_t)p;
+        const double* dbp = db + 3 * (size_t)p;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) dv[i] = dbp[i];
+        for (int i = 0; i < 9; ++i) Dv[i] = Di[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dv[i] = dbp[i];
+      }
     }
   };
   if (b0 < b1) fetch(b0);

@@ -140,7 +140,7 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaIte
 }
 extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS) kb_ba_schur_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R)
-  ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db);
+  ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db, it.Hll, it.bl, dyn.lambda[z]);   // inverts Hll + lambda I itself
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R > 0 ? it.sp.npairs : 0)
@@ -154,7 +154,7 @@ extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
   ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, dyn.lambda[z], it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
-                       dyn.delta, it.partial);
+                       dyn.delta, it.partial, it.sp.R > 0 ? it.Hll : nullptr);
 }
 // last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
 extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
