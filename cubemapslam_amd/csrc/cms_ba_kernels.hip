@@ -5,7 +5,7 @@
 //   linearizeOplus + constructQuadraticForm  (base_binary_edge.hpp:54-120, Huber robust_kernel_impl.cpp:78-91)
 //                                                                  -> k_ba_lin_points (Hll, bl, Hpl) + k_ba_lin_poses (Hpp, bp)
 //   BlockSolver::setLambda / Schur complement / back substitution (block_solver.hpp:367-485, 563-589)
-//                                            -> k_ba_dinv, k_ba_schur_init, k_ba_schur_chunks/_finish, k_ba_solve_blk (k_ba_solve_r192 / k_ba_solve for larger windows), k_ba_backsub
+//                                            -> k_ba_dinv, k_ba_schur_init, k_ba_schur_chunks/_finish, k_ba_solve_r192 / k_ba_solve (windows beyond the fused trial of cms_ba_fused.hip), k_ba_backsub
 //   vertex oplus (types_six_dof_expmap.h:73-76, types_sba.h:51-55, se3quat.h:217-257) -> k_ba_update_poses / k_ba_backsub
 // Edges are stored sorted by point (CSR) so Hll / bl need no atomics; per-pose blocks are reduced by workgroups over
 // slices of that pose's edge list; every 6x6 block of the reduced (Schur) system is owned by one workgroup that sums
@@ -375,158 +375,6 @@ k_ba_schur_finish(int np, const int* __restrict__ pair_s1, const int* __restrict
   } else if (s1 == s2) {
     bs[6 * s1 + (t - 36)] -= v;
   }
-}
-
-// ---- blocked LDL^T of the reduced pose system (6x6 pose blocks), one workgroup, one thread per lower block, the block
-// held in registers for the whole factorisation.  Per block column J: (a) the owner of (J,J) factorises its 6x6 block and
-// forward-substitutes y_J, (b) the owners of (I,J) solve W_IJ = A_IJ L_JJ^-T, L_IJ = W_IJ D_J^-1 and update y_I,
-// (c) every owner of (I,K), K > J, subtracts W_IJ L_KJ^T.  Two barriers per block column (19 columns for 20 key frames
-// instead of 114 scalar columns); one wavefront then runs the block back substitution out of LDS.
-extern "C" __global__ void __launch_bounds__(384)
-k_ba_solve_blk(int nb, const double* __restrict__ A, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ status) {
-  extern __shared__ __align__(16) double sm[];
-  const int n = 6 * nb, nblk = nb * (nb + 1) / 2;
-  double* Lblk = sm;                          // [nblk][36] final L blocks (diagonal blocks: unit lower)
-  double* Wbuf = Lblk + 36 * (size_t)nblk;    // [2][nb][36]
-  double* ybuf = Wbuf + 72 * (size_t)nb;      // [n] running right-hand side / z / w / x
-  double* idg = ybuf + n;                     // [n] 1 / d
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  int I = 0, K = 0;
-  const bool have = tid < nblk;
-  if (have) {
-    I = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
-    while ((I + 1) * (I + 2) / 2 <= tid) ++I;
-    while (I * (I + 1) / 2 > tid) --I;
-    K = tid - I * (I + 1) / 2;
-  }
-  double a[36];
-  if (have) {
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) a[6 * r + c] = A[(size_t)(6 * I + r) * n + 6 * K + c];
-  }
-  if (tid == 0) bad = 0;
-  for (int i = tid; i < n; i += blockDim.x) ybuf[i] = b[i];
-  __syncthreads();
-  for (int J = 0; J < nb; ++J) {
-    double* W = Wbuf + (J & 1) * 36 * (size_t)nb;
-    if (have && I == J && K == J) {                  // (a)
-      double idl[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double dc = a[7 * c];
-        if (!(isfinite(dc)) || dc == 0.0) bad = 1;
-        idl[c] = 1.0 / dc;
-        double lc[6];
-#pragma unroll
-        for (int r = c + 1; r < 6; ++r) lc[r] = a[6 * r + c] * idl[c];
-#pragma unroll
-        for (int r = c + 1; r < 6; ++r) {
-#pragma unroll
-          for (int q = c + 1; q <= r; ++q) a[6 * r + q] -= lc[r] * lc[q] * dc;
-          a[6 * r + c] = lc[r];
-        }
-      }
-      double* Ld = Lblk + 36 * (size_t)tid;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) Ld[6 * r + c] = c < r ? a[6 * r + c] : (c == r ? 1.0 : 0.0);
-      double z[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        z[r] = ybuf[6 * J + r];
-#pragma unroll
-        for (int c = 0; c < r; ++c) z[r] -= a[6 * r + c] * z[c];
-      }
-#pragma unroll
-      for (int r = 0; r < 6; ++r) { ybuf[6 * J + r] = z[r]; idg[6 * J + r] = idl[r]; }
-    }
-    __syncthreads();
-    if (bad) break;
-    if (have && K == J && I > J) {                   // (b)
-      const double* Ld = Lblk + 36 * (size_t)(J * (J + 1) / 2 + J);
-      double w[36];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          double v = a[6 * r + c];
-#pragma unroll
-          for (int q = 0; q < c; ++q) v -= w[6 * r + q] * Ld[6 * c + q];
-          w[6 * r + c] = v;
-        }
-      double* Wd = W + 36 * (size_t)I;
-      double* Lo = Lblk + 36 * (size_t)tid;
-      double yi[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) yi[r] = ybuf[6 * I + r];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const double l = w[6 * r + c] * idg[6 * J + c];
-          Wd[6 * r + c] = w[6 * r + c];
-          Lo[6 * r + c] = l;
-          yi[r] -= l * ybuf[6 * J + c];
-        }
-#pragma unroll
-      for (int r = 0; r < 6; ++r) ybuf[6 * I + r] = yi[r];
-    }
-    __syncthreads();
-    if (have && K > J) {                             // (c)  (I >= K > J)
-      const double* Wi = W + 36 * (size_t)I;
-      const double* Lk = Lblk + 36 * (size_t)(K * (K + 1) / 2 + J);
-      double lk[36];
-#pragma unroll
-      for (int q = 0; q < 36; ++q) lk[q] = Lk[q];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        double wr[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) wr[c] = Wi[6 * r + c];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          double v = a[6 * r + q];
-#pragma unroll
-          for (int c = 0; c < 6; ++c) v -= wr[c] * lk[6 * q + c];
-          a[6 * r + q] = v;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const bool isbad = bad != 0;
-  if (!isbad && tid < 64) {
-    for (int i = tid; i < n; i += 64) ybuf[i] *= idg[i];      // w = D^-1 z
-    __builtin_amdgcn_wave_barrier();
-    for (int J = nb - 1; J >= 0; --J) {
-      const double* Ld = Lblk + 36 * (size_t)(J * (J + 1) / 2 + J);
-      double xj[6];
-#pragma unroll
-      for (int r = 5; r >= 0; --r) {                          // L_JJ^T x_J = w_J (unit upper)
-        xj[r] = ybuf[6 * J + r];
-#pragma unroll
-        for (int q = r + 1; q < 6; ++q) xj[r] -= Ld[6 * q + r] * xj[q];
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (tid < 6) ybuf[6 * J + tid] = xj[tid];
-      for (int o = tid; o < 6 * J; o += 64) {                 // w_K -= L_JK^T x_J for K < J
-        const int Kq = o / 6, c = o - 6 * Kq;
-        const double* Ljk = Lblk + 36 * (size_t)(J * (J + 1) / 2 + Kq);
-        double v = ybuf[o];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) v -= Ljk[6 * r + c] * xj[r];
-        ybuf[o] = v;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += blockDim.x) x[i] = isbad ? 0.0 : ybuf[i];
-  if (tid == 0) *status = isbad ? 0 : 1;
 }
 
 // ---- dense LDL^T of the reduced pose system, one workgroup of 16 x 32 threads, trailing matrix held in REGISTERS
