@@ -194,6 +194,33 @@ __device__ __forceinline__ int fast_arc_score(const int d[16], int t) {
   return A - 1;
 }
 
+// Same score on packed 16-bit lanes, both polarities at once: lane pair e[k] = (v - p_k, p_k - v); a 9-arc of one polarity
+// always overlaps any 9-arc of the other (9 + 9 > 16), so at most one of the two arc scores exceeds t and max(dark, bright)
+// is the score of the polarity that makes p a corner.  111 packed operations instead of ~200 scalar ones.
+typedef short s2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int fast_arc_score_pk(const uint8_t* c, int ts, int v, int t) {
+  const int off[16] = {3 * ts, 3 * ts + 1, 2 * ts + 2, ts + 3, 3, -ts + 3, -2 * ts + 2, -3 * ts + 1,
+                       -3 * ts, -3 * ts - 1, -2 * ts - 2, -ts - 3, -3, ts - 3, 2 * ts - 2, 3 * ts - 1};
+  s2_t e[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const s2_t x = __builtin_bit_cast(s2_t, (uint32_t)v | ((uint32_t)c[off[k]] << 16));     // (v, p_k)
+    e[k] = x - __builtin_shufflevector(x, x, 1, 0);                                           // (v - p_k, p_k - v)
+  }
+  s2_t m2[16], m4[16], m8[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+  s2_t a = __builtin_elementwise_min(m8[0], e[8]);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) a = __builtin_elementwise_max(a, __builtin_elementwise_min(m8[k], e[(k + 8) & 15]));
+  const int A = max((int)a.x, (int)a.y);
+  return A > t ? A - 1 : 0;
+}
+
 // The wavefronts of a workgroup work on different cells and never exchange data: all synchronisation is inside a
 // wavefront (LDS operations of one wave complete in order; the fence only pins the compiler's order).
 #ifndef CMS_FAST_LIST
@@ -366,12 +393,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
       const int py = code >> 6, px = code & 63;
       const uint8_t* c = tile + (ey0 - iniY + py) * ts + (lx0 + px);
       const int v = c[0];
-      int d[16];
-      d[0] = v - c[3 * ts];      d[1] = v - c[3 * ts + 1];   d[2] = v - c[2 * ts + 2];   d[3] = v - c[ts + 3];
-      d[4] = v - c[3];           d[5] = v - c[-ts + 3];      d[6] = v - c[-2 * ts + 2];  d[7] = v - c[-3 * ts + 1];
-      d[8] = v - c[-3 * ts];     d[9] = v - c[-3 * ts - 1];  d[10] = v - c[-2 * ts - 2]; d[11] = v - c[-ts - 3];
-      d[12] = v - c[-3];         d[13] = v - c[ts - 3];      d[14] = v - c[2 * ts - 2];  d[15] = v - c[3 * ts - 1];
-      const int S = fast_arc_score(d, t);
+      const int S = fast_arc_score_pk(c, ts, v, t);
       if (S > 0) sc[(py + 1) * ss + px + 1] = (uint8_t)S;
       else list[k] = 0xFFFFu;
     }
