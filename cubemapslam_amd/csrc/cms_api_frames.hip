@@ -380,7 +380,7 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   hipStream_t s = c->stream;
   if (c->prof) hipEventRecord(c->ev[0], s);
   if (from_fisheye) {
-    dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, (B + CMS_REMAP_FPT - 1) / CMS_REMAP_FPT);
+    dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, std::min((B + CMS_REMAP_FPT - 1) / CMS_REMAP_FPT, CMS_REMAP_ZSPLIT));
     hipLaunchKernelGGL(k_remap, grid, dim3(256), 0, s, (const uint8_t*)c->d_fish, c->fish_pitch, c->fstride, c->cam.Iw,
                        c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, clean ? 0 : 1, B);
   }
