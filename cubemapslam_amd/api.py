@@ -94,6 +94,10 @@ def lib():
         L.cms_ba_linearize.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                        C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 7
+        L.cms_area_set_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.cms_area_grid.argtypes = [C.c_void_p, C.c_int]
+        L.cms_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
+        L.cms_features_in_area_device.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]
         L.cms_pose_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cms_pose_destroy.argtypes = [C.c_void_p]
         L.cms_pose_destroy.restype = None
@@ -267,6 +271,31 @@ class Context:
                                      *[_p(o) for o in outs]), "cms_hamming_best2")
         keys = ("best_idx", "best_dist", "best_level", "second_dist", "second_level")
         return {k: o[:nq] for k, o in zip(keys, outs)}
+
+    def area_set_keypoints(self, b, kps):
+        """put caller key points into frame slot b (tests / callers that extracted elsewhere)"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        _chk(lib().cms_area_set_keypoints(self.h, b, len(kps), _p(kps)), "cms_area_set_keypoints")
+
+    def area_grid(self, B):
+        """Frame::AssignFeaturesToGrid for frames 0..B-1 (device-resident key points)"""
+        _chk(lib().cms_area_grid(self.h, B), "cms_area_grid")
+
+    def features_in_area(self, b, qx, qy, qr, qmin, qmax, cap=None):
+        """Frame::GetFeaturesInArea for a batch of queries against frame b -> (off[nq+1], idx[total]) in the reference's order"""
+        qx = np.ascontiguousarray(qx, np.float32); qy = np.ascontiguousarray(qy, np.float32); qr = np.ascontiguousarray(qr, np.float32)
+        qmin = np.ascontiguousarray(qmin, np.int32); qmax = np.ascontiguousarray(qmax, np.int32)
+        nq = len(qx)
+        cap = cap or max(1, 64 * nq + 1024)
+        off = np.zeros(nq + 1, np.int32); idx = np.zeros(cap, np.int32); tot = C.c_int(0)
+        _chk(lib().cms_features_in_area(self.h, b, nq, _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax), _p(off), _p(idx), cap, C.byref(tot)),
+             "cms_features_in_area")
+        return off, idx[:tot.value]
+
+    def features_in_area_device(self, b, nq, d_q5, d_cnt, d_off, d_idx, cap, idx_base, d_total):
+        """device-pointer variant: d_q5 = (qx, qy, qr, qmin, qmax) device addresses"""
+        _chk(lib().cms_features_in_area_device(self.h, b, nq, *[C.c_void_p(int(a)) for a in d_q5], C.c_void_p(int(d_cnt)), C.c_void_p(int(d_off)),
+                                               C.c_void_p(int(d_idx)), cap, idx_base, C.c_void_p(int(d_total))), "cms_features_in_area_device")
 
     def hamming_best2_device(self, qdesc, q_row, nq, tdesc, cand_off, cand_idx, t_level, t_excl, outs):
         """all arguments are raw device pointers (ints); asynchronous on the ctx stream"""

@@ -160,6 +160,23 @@ int cms_ba_linearize(int device, int K, const double* poses, const uint8_t* fixe
                      const int8_t* e_face, double fx, double fy, double cx, double cy, int robust, double huber_delta,
                      double* err, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* robust_chi2_sum);
 
+/* ---- frame grid + window query: Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cpp:158-176, 728-744) and
+ * Frame::GetFeaturesInArea with AddCells (src/Frame.cpp:36-72, 251-716), the step in front of every Hamming scan of
+ * ORBMatcher::SearchByProjection / SearchForInitialization.  The reference's 41 window-unfolding cases (90 AddCells calls) are
+ * reproduced literally (cubemapslam_amd/csrc/cms_area_table.h), so the candidate ORDER -- which decides Hamming ties -- is the
+ * reference's.  cms_area_grid builds the 5 x 50 x 50 cell lists of frames 0..B-1 from the key points the last
+ * cms_frames_process left on the device (or cms_area_set_keypoints put there); a query is (x, y, r, minLevel, maxLevel) in canvas
+ * pixels; the result is a CSR list cand_off[nq+1] / cand_idx[] of key-point indices of frame b.  The _device variant takes and
+ * returns device pointers (cnt_scratch: nq ints) and adds idx_base to every index, so the lists feed cms_hamming_best2_device
+ * without touching the host. */
+int cms_area_set_keypoints(cms_ctx* ctx, int b, int n, const cms_keypoint* kps);
+int cms_area_grid(cms_ctx* ctx, int B);
+int cms_features_in_area(cms_ctx* ctx, int b, int nq, const float* qx, const float* qy, const float* qr, const int* min_level,
+                         const int* max_level, int* cand_off, int* cand_idx, int cap, int* total);
+int cms_features_in_area_device(cms_ctx* ctx, int b, int nq, const void* d_qx, const void* d_qy, const void* d_qr, const void* d_min_level,
+                                const void* d_max_level, void* d_cnt_scratch, void* d_cand_off, void* d_cand_idx, int cap, int idx_base,
+                                void* d_total);
+
 /* ---- pose-only optimisation: Optimizer::PoseOptimization(Frame*) (src/Optimizer.cpp:48-190), the per-frame solver Tracking calls
  * 1-3 times per frame (Tracking.cpp:585,647,688).  Edge = EdgeSE3ProjectXYZMultiPinholeOnlyPose
  * (include/g2o_cubemap_vertices_edges.h:42-88, src/g2o_cubemap_vertices_edges.cpp:61-134).  One workgroup per frame runs all four

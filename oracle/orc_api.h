@@ -93,6 +93,13 @@ int  orc_orb_level_distributed(const orc_orb* o, int level, orc_keypoint* kps, i
 /* DistributeOctTree stand-alone (ORBExtractor.cpp:511-737); in/out triplets (x,y,response) */
 int  orc_distribute_octree(const int* xys, int n, int min_x, int max_x, int min_y, int max_y, int N, int* out_xys, int cap);
 
+/* ---- Frame grid + window query (Frame.cpp:36-72 AddCells, 158-176 AssignFeaturesToGrid, 251-716 GetFeaturesInArea, 728-744 PosInGrid):
+ * nq queries (x, y, r, minLevel, maxLevel) against the n key points of one frame; candidate indices in the reference's order as
+ * a CSR list (off[nq+1], idx[cap]).  Returns the total number of candidates (may exceed cap: then only cap were written). */
+int  orc_features_in_area(const orc_camera* cam, int n, const float* kx, const float* ky, const int* koct, int nq,
+                          const float* qx, const float* qy, const float* qr, const int* qmin, const int* qmax,
+                          int* off, int* idx, int cap);
+
 /* ---- ORBMatcher (ORBMatcher.cpp) ---- */
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
 /* best / second-best over CSR candidate lists, the inner loop of SearchByProjection (ORBMatcher.cpp:84-113) */

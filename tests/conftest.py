@@ -9,3 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """torch brings its own HIP runtime; it must initialise BEFORE libcubemapslam_hip.so pulls in the system one, or a later
+    torch.cuda call in the same process finds no device (bench.py has the same order).  No-op without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass

@@ -66,6 +66,7 @@ def lib():
         L.orc_ba_linearize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                        C.c_double, C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 10
+        L.orc_features_in_area.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int]
         L.orc_pose_optimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -270,3 +271,17 @@ def ba_linearize(prob, robust=True, delta=np.sqrt(5.991)):
                            _p(o["Jpose"]), _p(o["Jpoint"]), _p(o["Hpp"]), _p(o["bp"]), _p(o["Hll"]), _p(o["bl"]),
                            _p(o["Hpl"]), _p(o["chi"]))
     return o
+
+
+def features_in_area(cam, kx, ky, koct, qx, qy, qr, qmin, qmax, cap=None):
+    """Frame::GetFeaturesInArea for a batch of queries; returns (off[nq+1], idx[total]) in the reference's candidate order."""
+    kx = np.ascontiguousarray(kx, np.float32); ky = np.ascontiguousarray(ky, np.float32); koct = np.ascontiguousarray(koct, np.int32)
+    qx = np.ascontiguousarray(qx, np.float32); qy = np.ascontiguousarray(qy, np.float32); qr = np.ascontiguousarray(qr, np.float32)
+    qmin = np.ascontiguousarray(qmin, np.int32); qmax = np.ascontiguousarray(qmax, np.int32)
+    nq = len(qx)
+    cap = cap or max(1, 64 * nq + 1024)
+    off = np.zeros(nq + 1, np.int32); idx = np.zeros(cap, np.int32)
+    tot = lib().orc_features_in_area(C.byref(cam), len(kx), _p(kx), _p(ky), _p(koct), nq, _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax),
+                                     _p(off), _p(idx), cap)
+    assert tot <= cap, (tot, cap)
+    return off, idx[:tot]

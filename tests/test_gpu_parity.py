@@ -349,3 +349,76 @@ def test_c_abi_error_paths():
     bad = dict(pp); bad["face"] = pp["face"].copy(); bad["face"][0] = 7
     with pytest.raises(api.CmsError):
         api.pose_optimize(bad)
+
+
+def test_features_in_area_matches_oracle():
+    """Frame::AssignFeaturesToGrid + GetFeaturesInArea (SURVEY.md 8f-2) on the device: identical candidate lists, order included,
+    for queries biased to face edges and corners (all 41 unfolding cases), with level filters; host and device-pointer entry."""
+    import test_area_emu as te
+    for F, seed in ((550, 21), (150, 22)):
+        camd = synth.camera("lafida", F)
+        ocam = orc.make_camera(camd)
+        ctx = api.Context(camd, nfeatures=2000, max_batch=2)
+        kx, ky, ko = te._keypoints(F, 2000, seed)
+        kps = np.zeros(len(kx), api.KP_DTYPE); kps["x"] = kx; kps["y"] = ky; kps["octave"] = ko
+        ctx.area_set_keypoints(1, kps)
+        ctx.area_set_keypoints(0, kps[:7])
+        ctx.area_grid(2)
+        qx, qy, qr, lo, hi, _ = te._queries(F, 5000, 30 + seed)
+        want_off, want_idx = orc.features_in_area(ocam, kx, ky, ko, qx, qy, qr, lo, hi)
+        got_off, got_idx = ctx.features_in_area(1, qx, qy, qr, lo, hi)
+        assert np.array_equal(got_off, want_off) and np.array_equal(got_idx, want_idx), (F, len(got_idx), len(want_idx))
+        assert len(want_idx) > 2000
+        # the other frame slot has its own (tiny) grid
+        w0, i0 = orc.features_in_area(ocam, kx[:7], ky[:7], ko[:7], qx, qy, qr, lo, hi)
+        g0, j0 = ctx.features_in_area(0, qx, qy, qr, lo, hi)
+        assert np.array_equal(g0, w0) and np.array_equal(j0, i0)
+        # capacity too small -> CMS_ERR_OVERFLOW
+        with pytest.raises(api.CmsError):
+            ctx.features_in_area(1, qx, qy, qr, lo, hi, cap=10)
+        ctx.close()
+
+
+def test_features_in_area_on_extracted_frames_feeds_the_matcher():
+    """extract two frames, build their grids on the device, generate the SearchByProjection windows of frame 0's key points in
+    frame 1 on the device and match -- no candidate list ever built on the host; equals oracle lists + oracle Hamming scan."""
+    import torch
+    camd = synth.camera("lafida", 250)
+    ocam = orc.make_camera(camd)
+    ctx = api.Context(camd, nfeatures=1000, max_batch=2)
+    mask = synth.cubemap_valid_mask(camd, erode=5, band=30)
+    ctx.set_mask(mask)
+    big = synth.texture(camd["Ih"] + 16, camd["Iw"] + 16, 4)
+    frames = np.stack([big[:camd["Ih"], :camd["Iw"]], big[2:2 + camd["Ih"], 3:3 + camd["Iw"]]]).copy()
+    ctx.upload(frames); ctx.process(2, True); ctx.sync()
+    (k0, d0), (k1, d1) = ctx.fetch(0), ctx.fetch(1)
+    assert len(k0) > 200 and len(k1) > 200
+    ctx.area_grid(2)
+    scales = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    qx = k0["x"].copy(); qy = k0["y"].copy(); qr = (np.float32(15.0) * scales[k0["octave"]]).astype(np.float32)
+    lo = (k0["octave"] - 1).astype(np.int32); hi = (k0["octave"] + 1).astype(np.int32)
+    want_off, want_idx = orc.features_in_area(ocam, k1["x"], k1["y"], k1["octave"], qx, qy, qr, lo, hi)
+    nq, cap, kp_cap = len(qx), len(want_idx) + 64, ctx.geom.kp_cap
+    dev = torch.device("cuda", 0)
+    dq = [torch.from_numpy(a).to(dev) for a in (qx, qy, qr, lo, hi)]
+    d_cnt = torch.zeros(nq, dtype=torch.int32, device=dev); d_off = torch.zeros(nq + 1, dtype=torch.int32, device=dev)
+    d_idx = torch.zeros(cap, dtype=torch.int32, device=dev); d_tot = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.features_in_area_device(1, nq, [t.data_ptr() for t in dq], d_cnt.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), cap, kp_cap, d_tot.data_ptr())
+    ctx.sync()
+    assert int(d_tot.item()) == len(want_idx)
+    assert np.array_equal(d_off.cpu().numpy(), want_off) and np.array_equal(d_idx.cpu().numpy()[:len(want_idx)], want_idx + kp_cap)
+    # ... and straight into the Hamming scan on the device (rows of frame 0 are the queries, candidates are rows of frame 1)
+    _, d_desc, _ = ctx.results_ptrs()
+    d_qrow = torch.arange(nq, dtype=torch.int32, device=dev)
+    d_lvl = torch.zeros(2 * kp_cap, dtype=torch.int32, device=dev)
+    d_lvl[kp_cap:kp_cap + len(k1)] = torch.from_numpy(k1["octave"].astype(np.int32)).to(dev)
+    outs = [torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(5)]
+    ctx.hamming_best2_device(d_desc, d_qrow.data_ptr(), nq, d_desc, d_off.data_ptr(), d_idx.data_ptr(), d_lvl.data_ptr(), None, [o.data_ptr() for o in outs])
+    ctx.sync()
+    alld = np.zeros((2 * kp_cap, 32), np.uint8); alld[:len(d0)] = d0; alld[kp_cap:kp_cap + len(d1)] = d1
+    lvl = np.zeros(2 * kp_cap, np.int32); lvl[kp_cap:kp_cap + len(k1)] = k1["octave"]
+    want = orc.hamming_best2(alld[:nq], alld, want_off, (want_idx + kp_cap).astype(np.int32), lvl)
+    assert np.array_equal(outs[0].cpu().numpy(), want["best_idx"]) and np.array_equal(outs[1].cpu().numpy(), want["best_dist"])
+    assert np.array_equal(outs[3].cpu().numpy(), want["second_dist"])
+    assert (want["best_idx"] >= 0).sum() > 100
+    ctx.close()
