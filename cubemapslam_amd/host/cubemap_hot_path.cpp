@@ -126,36 +126,48 @@ int ORBMatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
 }
 
 int ORBMatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, float th, bool) {
-  const int F = CamModelGeneral::GetCamera()->GetCubeFaceWidth();
-  const int W = 3 * F, GR = 150;                      // 3 x 50 grid columns over the cross (Frame.h:43-45: 50 x 50 per face)
-  const float cell = (float)W / GR;
   const int N2 = (int)Cur.mvKeys.size();
-  std::vector<std::vector<int>> grid((size_t)GR * GR);
-  for (int i = 0; i < N2; ++i) {
-    const int gx = std::min(GR - 1, std::max(0, (int)(Cur.mvKeys[i].pt.x / cell)));
-    const int gy = std::min(GR - 1, std::max(0, (int)(Cur.mvKeys[i].pt.y / cell)));
-    grid[(size_t)gx * GR + gy].push_back(i);
-  }
-  // candidate windows (Frame::GetFeaturesInArea semantics within one face: |dx| < r, |dy| < r, level gate; cell-major order)
-  std::vector<int> qidx, off(1, 0), cand;
+  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+  // candidate windows: CurrentFrame.GetFeaturesInArea(u, v, th * scale[octave], octave - 1, octave + 1) (ORBMatcher.cpp:176-181) for
+  // every projected map point of the last frame, answered on the device by the frame grid of the current frame's key points --
+  // same unfolding cases, same candidate order as Frame.cpp:251-716
+  std::vector<int> qall;
+  std::vector<float> qx, qy, qr;
+  std::vector<int> qlo, qhi;
   for (int i = 0; i < (int)Last.mvKeys.size(); ++i) {
     if (Last.mvpMapPoints[i] < 0 || (i < (int)Last.mvbOutlier.size() && Last.mvbOutlier[i])) continue;
     const cv::Point2f p = Last.projInCurrent[i];
     if (p.x < 0 || p.y < 0) continue;
     const int oct = Last.mvKeys[i].octave;
-    const float r = th * Cur.mvScaleFactors[oct];
-    const int x0 = std::max(0, (int)std::floor((p.x - r) / cell)), x1 = std::min(GR - 1, (int)std::ceil((p.x + r) / cell));
-    const int y0 = std::max(0, (int)std::floor((p.y - r) / cell)), y1 = std::min(GR - 1, (int)std::ceil((p.y + r) / cell));
-    for (int ix = x0; ix <= x1; ++ix)
-      for (int iy = y0; iy <= y1; ++iy)
-        for (int j : grid[(size_t)ix * GR + iy]) {
-          const cv::KeyPoint& k = Cur.mvKeys[j];
-          if (k.octave < oct - 1 || k.octave > oct + 1) continue;
-          if (std::fabs(k.pt.x - p.x) < r && std::fabs(k.pt.y - p.y) < r) cand.push_back(j);
-        }
-    if ((int)cand.size() == off.back()) continue;     // vIndices2.empty()
-    qidx.push_back(i);
-    off.push_back((int)cand.size());
+    qall.push_back(i); qx.push_back(p.x); qy.push_back(p.y); qr.push_back(th * Cur.mvScaleFactors[oct]);
+    qlo.push_back(oct - 1); qhi.push_back(oct + 1);
+  }
+  std::vector<int> qidx, off(1, 0), cand;
+  if (!qall.empty()) {
+    std::vector<cms_keypoint> kps(N2);
+    for (int j = 0; j < N2; ++j) {
+      const cv::KeyPoint& k = Cur.mvKeys[j];
+      kps[j].x = k.pt.x; kps[j].y = k.pt.y; kps[j].size = k.size; kps[j].angle = k.angle; kps[j].response = k.response; kps[j].octave = k.octave;
+    }
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    std::vector<int> aoff(qall.size() + 1), aidx(64 * qall.size() + 1024);
+    int total = 0;
+    int rc = cms_area_set_keypoints(ctx, 0, N2, kps.data());
+    if (rc == CMS_OK) rc = cms_area_grid(ctx, 1);
+    if (rc == CMS_OK) rc = cms_features_in_area(ctx, 0, (int)qall.size(), qx.data(), qy.data(), qr.data(), qlo.data(), qhi.data(), aoff.data(),
+                                                aidx.data(), (int)aidx.size(), &total);
+    if (rc == CMS_ERR_OVERFLOW) {               // denser than 64 candidates per window: retry with the exact size
+      aidx.resize((size_t)total + 1);
+      rc = cms_features_in_area(ctx, 0, (int)qall.size(), qx.data(), qy.data(), qr.data(), qlo.data(), qhi.data(), aoff.data(), aidx.data(),
+                                (int)aidx.size(), &total);
+    }
+    if (rc != CMS_OK) throw std::runtime_error(std::string("cms_features_in_area: ") + cms_last_error());
+    for (size_t q = 0; q < qall.size(); ++q) {
+      if (aoff[q + 1] == aoff[q]) continue;     // vIndices2.empty()
+      qidx.push_back(qall[q]);
+      cand.insert(cand.end(), aidx.begin() + aoff[q], aidx.begin() + aoff[q + 1]);
+      off.push_back((int)cand.size());
+    }
   }
   const int nq = (int)qidx.size();
   if (nq == 0) return 0;
@@ -165,7 +177,6 @@ int ORBMatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, float 
   std::vector<uint8_t> tdesc((size_t)N2 * 32);
   for (int j = 0; j < N2; ++j) std::memcpy(&tdesc[(size_t)j * 32], Cur.mDescriptors.ptr<uint8_t>(j), 32);
   std::vector<int> bi(nq), bd(nq), sd(nq);
-  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
   {
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     if (cms_hamming_best2(ctx, qdesc.data(), nq, tdesc.data(), N2, off.data(), cand.data(), nullptr, excl.data(), bi.data(), bd.data(),

@@ -31,37 +31,25 @@ def _p(a):
 
 
 def _search_by_projection_ref(cur_k, cur_d, cur_mp, last_k, last_d, last_mp, proj, scales, th, F):
-    """literal replay of ORBMatcher.cpp:150-251 (frame-to-frame), candidate order = grid cell-major like GetFeaturesInArea"""
-    W, GR = 3 * F, 150
-    cell = np.float32(W) / np.float32(GR)
-    grid = {}
-    for j in range(len(cur_k)):
-        gx = min(GR - 1, max(0, int(np.float32(cur_k["x"][j]) / cell))); gy = min(GR - 1, max(0, int(np.float32(cur_k["y"][j]) / cell)))
-        grid.setdefault((gx, gy), []).append(j)
+    """literal replay of ORBMatcher.cpp:150-251 (frame-to-frame); the candidate windows come from the oracle's
+    Frame::GetFeaturesInArea (oracle/orc_area.cpp), in the reference's order"""
     cur_mp = cur_mp.copy()
     nb = 30
     hist = [[] for _ in range(nb)]
     n = 0
-    for i in range(len(last_k)):
-        if last_mp[i] < 0 or proj[i, 0] < 0 or proj[i, 1] < 0:
-            continue
-        o = int(last_k["octave"][i]); r = np.float32(th) * np.float32(scales[o])
-        px, py = np.float32(proj[i, 0]), np.float32(proj[i, 1])
-        x0 = max(0, int(np.floor((px - r) / cell))); x1 = min(GR - 1, int(np.ceil((px + r) / cell)))
-        y0 = max(0, int(np.floor((py - r) / cell))); y1 = min(GR - 1, int(np.ceil((py + r) / cell)))
+    sel = [i for i in range(len(last_k)) if not (last_mp[i] < 0 or proj[i, 0] < 0 or proj[i, 1] < 0)]
+    octs = last_k["octave"][sel].astype(np.int32)
+    rad = (np.float32(th) * np.asarray(scales, np.float32)[octs]).astype(np.float32)
+    ocam = orc.make_camera(synth.camera("lafida", F))
+    off, idx = orc.features_in_area(ocam, cur_k["x"], cur_k["y"], cur_k["octave"], proj[sel, 0], proj[sel, 1], rad, octs - 1, octs + 1)
+    for q, i in enumerate(sel):
         best, bidx = 256, -1
-        for ix in range(x0, x1 + 1):
-            for iy in range(y0, y1 + 1):
-                for j in grid.get((ix, iy), ()):
-                    if not (o - 1 <= cur_k["octave"][j] <= o + 1):
-                        continue
-                    if not (abs(np.float32(cur_k["x"][j]) - px) < r and abs(np.float32(cur_k["y"][j]) - py) < r):
-                        continue
-                    if cur_mp[j] >= 0:
-                        continue
-                    d = int(np.unpackbits(last_d[i] ^ cur_d[j]).sum())
-                    if d < best:
-                        best, bidx = d, j
+        for j in idx[off[q]:off[q + 1]]:
+            if cur_mp[j] >= 0:
+                continue
+            d = int(np.unpackbits(last_d[i] ^ cur_d[j]).sum())
+            if d < best:
+                best, bidx = d, j
         if bidx >= 0 and best <= 100:
             cur_mp[bidx] = last_mp[i]; n += 1
             rot = np.float32(last_k["angle"][i]) - np.float32(cur_k["angle"][bidx])
