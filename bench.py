@@ -8,9 +8,8 @@ stream, 754x480 fisheye, cube face F=550 (1650^2 cross), nFeatures 2000 / 8 leve
 One step = one batch of B frames (default 64 = 8 camera streams x 8 consecutive frames, cf. BASELINE.json configs[4]), inputs
 resident in HBM:
     remap -> pyramid -> FAST cells -> octree -> cull -> orientation + rBRIEF     (ORBextractor::operator(), all B frames per launch)
-    Hamming best/second-best of every key point of frame b-1 against its window candidates in frame b
-        (the inner loops of ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15); candidate windows built once
-         on the host from the real key points -- GetFeaturesInArea is a "next" row)
+    Frame::AssignFeaturesToGrid + GetFeaturesInArea windows + Hamming best/second-best of every key point of frame b-1 in
+        frame b (ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15)), all on the device, every step
     Optimizer::PoseOptimization of every frame (one launch for the batch, own stream)
     one local BA window (K=20 key frames, ~80k cubemap edges, BASELINE.json configs[3]) per `--ba-every` frames, on its own
         stream / host thread like the reference's LocalMapping thread.
@@ -47,24 +46,23 @@ def make_frames(camd, B, seed):
     return np.stack([big[2 * b:2 * b + Ih, 3 * b:3 * b + Iw] for b in range(B)]).copy()
 
 
-def build_match_lists(kps_per_frame, scales, kp_cap, th=15.0):
-    """SearchByProjection(Cur, Last) candidate windows (ORBMatcher.cpp:176-181): radius th*scale[octave], octave +-1."""
-    from scipy.spatial import cKDTree
+def build_match_queries(kps_per_frame, scales, kp_cap, th=15.0):
+    """The windows of ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15) (ORBMatcher.cpp:176-181) for every key point of
+    frame b-1 searched in frame b: centre = its own position (the synthetic stream drifts by a few pixels), radius th*scale[octave],
+    octave +-1.  Only the QUERIES are prepared here; the candidate lists are generated on the device in every step
+    (Frame::GetFeaturesInArea, cms_features_in_area_batch_device)."""
     B = len(kps_per_frame)
-    q_row, off, idx = [], [0], []
+    q_row, q_frame, qx, qy, qr, lo, hi = [], [], [], [], [], [], []
+    sc = np.asarray(scales, np.float32)
     for b in range(B):
-        last, cur = kps_per_frame[(b - 1) % B], kps_per_frame[b]
-        if len(cur) == 0:
-            continue
-        tree = cKDTree(np.stack([cur["x"], cur["y"]], 1))
-        for i in range(len(last)):
-            r = th * scales[last["octave"][i]]
-            cand = tree.query_ball_point([last["x"][i], last["y"][i]], r, p=np.inf)
-            cand = [c for c in sorted(cand) if abs(int(cur["octave"][c]) - int(last["octave"][i])) <= 1]
-            q_row.append(((b - 1) % B) * kp_cap + i)
-            idx.extend(b * kp_cap + c for c in cand)
-            off.append(len(idx))
-    return np.array(q_row, np.int32), np.array(off, np.int32), np.array(idx, np.int32)
+        last = kps_per_frame[(b - 1) % B]
+        n = len(last)
+        q_row.append(((b - 1) % B) * kp_cap + np.arange(n)); q_frame.append(np.full(n, b))
+        qx.append(last["x"]); qy.append(last["y"]); qr.append(np.float32(th) * sc[last["octave"]])
+        lo.append(last["octave"] - 1); hi.append(last["octave"] + 1)
+    cat = lambda v, dt: np.ascontiguousarray(np.concatenate(v), dt)
+    return (cat(q_row, np.int32), cat(q_frame, np.int32), cat(qx, np.float32), cat(qy, np.float32), cat(qr, np.float32),
+            cat(lo, np.int32), cat(hi, np.int32))
 
 
 def main():
@@ -114,16 +112,28 @@ def main():
     g = ctx.geom
     kp_cap = g.kp_cap
     scales = [g.scale[l] for l in range(g.nlevels)]
-    q_row, c_off, c_idx = build_match_lists(kps, scales, kp_cap)
+    q_row, q_frame, q_x, q_y, q_r, q_lo, q_hi = build_match_queries(kps, scales, kp_cap)
     nq = len(q_row)
     t_level = np.zeros(B * kp_cap, np.int32)
     for b in range(B):
         t_level[b * kp_cap:b * kp_cap + len(kps[b])] = kps[b]["octave"]
     dev = torch.device("cuda", local_rank)
-    d_qrow = torch.from_numpy(q_row).to(dev); d_off = torch.from_numpy(c_off).to(dev); d_idx = torch.from_numpy(c_idx).to(dev)
+    d_qrow = torch.from_numpy(q_row).to(dev); d_qframe = torch.from_numpy(q_frame).to(dev)
+    d_q5 = [torch.from_numpy(a).to(dev) for a in (q_x, q_y, q_r, q_lo, q_hi)]
+    d_cnt = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev); d_off = torch.zeros(nq + 1, dtype=torch.int32, device=dev)
+    d_tot = torch.zeros(1, dtype=torch.int32, device=dev)
     d_lvl = torch.from_numpy(t_level).to(dev)
     d_out = [torch.zeros(max(nq, 1), dtype=torch.int32, device=dev) for _ in range(5)]
     _, d_desc, _ = ctx.results_ptrs()
+    # size the candidate buffer with one dry run (the lists are rebuilt on the device in every step)
+    ctx.area_grid(B)
+    d_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.features_in_area_batch_device(nq, d_qframe.data_ptr(), [t.data_ptr() for t in d_q5], d_cnt.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), 0,
+                                      d_tot.data_ptr())
+    ctx.sync()
+    n_pairs = int(d_tot.item())
+    cand_cap = n_pairs + 4096
+    d_idx = torch.zeros(cand_cap, dtype=torch.int32, device=dev)
 
     n_ba = max(1, B // args.ba_every)
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + rank)
@@ -162,6 +172,9 @@ def main():
             th.start()
         po.launch()                 # own stream, overlaps the frame path
         ctx.process(B, True)
+        ctx.area_grid(B)            # Frame::AssignFeaturesToGrid of the B frames, then every SearchByProjection window, on the device
+        ctx.features_in_area_batch_device(nq, d_qframe.data_ptr(), [t.data_ptr() for t in d_q5], d_cnt.data_ptr(), d_off.data_ptr(),
+                                          d_idx.data_ptr(), cand_cap, d_tot.data_ptr())
         ctx.hamming_best2_device(d_desc, d_qrow.data_ptr(), nq, d_desc, d_off.data_ptr(), d_idx.data_ptr(), d_lvl.data_ptr(), None,
                                  [o.data_ptr() for o in d_out])
         ctx.sync()
@@ -254,29 +267,25 @@ def main():
         o = orc.Orb(nfeatures=nfeat)
         n = min(args.cpu_frames, B)
         t1 = time.perf_counter()
-        descs = []
+        descs, cpu_kps = [], []
         for b in range(n):
             cube = orc.fisheye_to_cubemap(ocam, m1, m2, frames[b])
             k, d = o.extract(ocam, cube, mask)
-            descs.append(d)
+            descs.append(d); cpu_kps.append(k)
         t_ext = time.perf_counter() - t1
-        # matching on the same candidate lists (queries of the first n frame pairs)
-        sel = np.nonzero((q_row // kp_cap) < n - 1)[0] if n > 1 else np.zeros(0, int)
+        # candidate windows (Frame::GetFeaturesInArea) + Hamming scan for the first n - 1 frame pairs, like the GPU leg does per step
         t1 = time.perf_counter()
-        if len(sel):
-            alld = np.zeros((B * kp_cap, 32), np.uint8)
-            for b in range(n):
-                alld[b * kp_cap:b * kp_cap + len(descs[b])] = descs[b]
-            # queries whose targets are inside the sample
-            ok = np.array([c_idx[c_off[q]:c_off[q + 1]].max(initial=0) < n * kp_cap for q in sel])
-            sel = sel[ok]
-            cnt = (c_off[sel + 1] - c_off[sel]).astype(np.int64)
-            off2 = np.zeros(len(sel) + 1, np.int32); off2[1:] = np.cumsum(cnt)
-            idx2 = np.concatenate([c_idx[c_off[q]:c_off[q + 1]] for q in sel]) if len(sel) else np.zeros(0, np.int32)
-            t1 = time.perf_counter()
-            orc.hamming_best2(alld[q_row[sel]], alld, off2, idx2, t_level)
+        pairs = 0
+        sc32 = np.asarray(scales, np.float32)
+        for b in range(1, n):
+            last, cur = cpu_kps[b - 1], cpu_kps[b]
+            if len(last) == 0 or len(cur) == 0:
+                continue
+            off2, idx2 = orc.features_in_area(ocam, cur["x"], cur["y"], cur["octave"], last["x"], last["y"], np.float32(15.0) * sc32[last["octave"]],
+                                              last["octave"] - 1, last["octave"] + 1)
+            orc.hamming_best2(descs[b - 1], descs[b], off2, idx2, cur["octave"].astype(np.int32))
+            pairs += 1
         t_match = time.perf_counter() - t1
-        pairs = max(len(sel), 1) / max(nq / B, 1.0)      # frame pairs' worth of queries matched
         t1 = time.perf_counter()
         n_cpu_ba = 3
         for _ in range(n_cpu_ba):
@@ -312,9 +321,9 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract/match), f64 (BA)", "data": "synthetic",
             "config": {"workload": "Lafida cam0 synthetic stream, 754x480 fisheye, face=%d (%dx%d cross), nFeatures %d; per step %d frames: "
-                                   "remap+ORB extract, Hamming best-2 (%d queries, %d candidate pairs), pose-only optimisation (%d edges/frame), "
+                                   "remap+ORB extract, frame grids + GetFeaturesInArea windows + Hamming best-2 (%d queries, %d candidate pairs), pose-only optimisation (%d edges/frame), "
                                    "%d local-BA windows (K=20, E=%d)"
-                                   % (F, 3 * F, 3 * F, nfeat, B, nq, len(c_idx), args.pose_edges, n_ba, len(prob["e_pose"])),
+                                   % (F, 3 * F, 3 * F, nfeat, B, nq, n_pairs, args.pose_edges, n_ba, len(prob["e_pose"])),
                        "frames_per_step_per_gpu": B, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),

@@ -98,6 +98,7 @@ def lib():
         L.cms_area_grid.argtypes = [C.c_void_p, C.c_int]
         L.cms_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
         L.cms_features_in_area_device.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]
+        L.cms_features_in_area_batch_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p]
         L.cms_pose_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cms_pose_destroy.argtypes = [C.c_void_p]
         L.cms_pose_destroy.restype = None
@@ -296,6 +297,12 @@ class Context:
         """device-pointer variant: d_q5 = (qx, qy, qr, qmin, qmax) device addresses"""
         _chk(lib().cms_features_in_area_device(self.h, b, nq, *[C.c_void_p(int(a)) for a in d_q5], C.c_void_p(int(d_cnt)), C.c_void_p(int(d_off)),
                                                C.c_void_p(int(d_idx)), cap, idx_base, C.c_void_p(int(d_total))), "cms_features_in_area_device")
+
+    def features_in_area_batch_device(self, nq, d_qframe, d_q5, d_cnt, d_off, d_idx, cap, d_total):
+        """all frames of the batch in one launch sequence; d_qframe[q] = frame searched by query q; indices are batch rows"""
+        _chk(lib().cms_features_in_area_batch_device(self.h, nq, C.c_void_p(int(d_qframe)), *[C.c_void_p(int(a)) for a in d_q5], C.c_void_p(int(d_cnt)),
+                                                     C.c_void_p(int(d_off)), C.c_void_p(int(d_idx)), cap, C.c_void_p(int(d_total))),
+             "cms_features_in_area_batch_device")
 
     def hamming_best2_device(self, qdesc, q_row, nq, tdesc, cand_off, cand_idx, t_level, t_excl, outs):
         """all arguments are raw device pointers (ints); asynchronous on the ctx stream"""

@@ -12,6 +12,15 @@ static int cms_area_reserve(cms_ctx* c) {
   return CMS_OK;
 }
 
+static int cms_area_bsum_reserve(cms_ctx* c, int nblk) {
+  if (nblk <= c->area_bsum_cap) return CMS_OK;
+  if (c->d_area_bsum) hipFree(c->d_area_bsum);
+  c->d_area_bsum = nullptr; c->area_bsum_cap = 0;
+  HIPCHK(hipMalloc((void**)&c->d_area_bsum, (size_t)(nblk + 64) * sizeof(int)));
+  c->area_bsum_cap = nblk + 64;
+  return CMS_OK;
+}
+
 extern "C" int cms_area_set_keypoints(cms_ctx* c, int b, int n, const cms_keypoint* kps) {
   if (!c || b < 0 || b >= c->max_batch || n < 0 || n > c->g.kp_cap || (n > 0 && !kps)) return cms_fail(CMS_ERR_ARG, "cms_area_set_keypoints: bad argument");
   HIPCHK(hipSetDevice(c->device));
@@ -45,12 +54,46 @@ extern "C" int cms_features_in_area_device(cms_ctx* c, int b, int nq, const void
   a.sorted_idx = c->d_area_sorted + (size_t)b * c->g.kp_cap;
   a.cell_start = c->d_area_cell_start + (size_t)b * (CMS_AREA_CELLS + 1);
   a.qx = (const float*)d_qx; a.qy = (const float*)d_qy; a.qr = (const float*)d_qr; a.qmin = (const int*)d_qmin; a.qmax = (const int*)d_qmax;
+  a.q_frame = nullptr; a.kp_cap = c->g.kp_cap;
   a.nq = nq; a.F = c->g.F; a.inv = (float)(3 * CMS_AREA_G) / (float)c->g.W;
   a.cnt = (int*)d_cnt_scratch; a.off = (const int*)d_cand_off; a.idx = (int*)d_cand_idx; a.cap = cap; a.idx_base = idx_base;
   hipStream_t s = c->stream;
-  hipLaunchKernelGGL(k_area_query, dim3((nq + 63) / 64), dim3(64), 0, s, a, 0);
-  hipLaunchKernelGGL(k_area_scan, dim3(1), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, (int*)d_cand_off, (int*)d_total);
-  hipLaunchKernelGGL(k_area_query, dim3((nq + 63) / 64), dim3(64), 0, s, a, 1);
+  {
+    const int nblk = (nq + 1023) / 1024, qgrid = (nq * CMS_AREA_QL + 255) / 256;
+    int rcb = cms_area_bsum_reserve(c, nblk);
+    if (rcb) return rcb;
+    hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 0);
+    hipLaunchKernelGGL(k_area_blocksum, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, c->d_area_bsum);
+    hipLaunchKernelGGL(k_area_scan, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, (const int*)c->d_area_bsum, (int*)d_cand_off, (int*)d_total);
+    hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 1);
+  }
+  HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+
+// every query names the frame of the batch it searches (d_qframe); candidate indices are rows of the batch (frame * kp_cap + i)
+extern "C" int cms_features_in_area_batch_device(cms_ctx* c, int nq, const void* d_qframe, const void* d_qx, const void* d_qy, const void* d_qr,
+                                                 const void* d_qmin, const void* d_qmax, void* d_cnt_scratch, void* d_cand_off, void* d_cand_idx,
+                                                 int cap, void* d_total) {
+  if (!c || nq < 0 || cap < 0 || c->area_frames < 1 || !d_qframe) return cms_fail(CMS_ERR_ARG, "cms_features_in_area_batch_device: bad argument (cms_area_grid first)");
+  if (nq == 0) return CMS_OK;
+  HIPCHK(hipSetDevice(c->device));
+  CmsAreaArgs a;
+  a.kp = (const CmsKeyPoint*)c->d_kps; a.sorted_idx = c->d_area_sorted; a.cell_start = c->d_area_cell_start;
+  a.qx = (const float*)d_qx; a.qy = (const float*)d_qy; a.qr = (const float*)d_qr; a.qmin = (const int*)d_qmin; a.qmax = (const int*)d_qmax;
+  a.q_frame = (const int*)d_qframe; a.kp_cap = c->g.kp_cap;
+  a.nq = nq; a.F = c->g.F; a.inv = (float)(3 * CMS_AREA_G) / (float)c->g.W;
+  a.cnt = (int*)d_cnt_scratch; a.off = (const int*)d_cand_off; a.idx = (int*)d_cand_idx; a.cap = cap; a.idx_base = 0;
+  hipStream_t s = c->stream;
+  {
+    const int nblk = (nq + 1023) / 1024, qgrid = (nq * CMS_AREA_QL + 255) / 256;
+    int rcb = cms_area_bsum_reserve(c, nblk);
+    if (rcb) return rcb;
+    hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 0);
+    hipLaunchKernelGGL(k_area_blocksum, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, c->d_area_bsum);
+    hipLaunchKernelGGL(k_area_scan, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, (const int*)c->d_area_bsum, (int*)d_cand_off, (int*)d_total);
+    hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 1);
+  }
   HIPCHK(hipGetLastError());
   return CMS_OK;
 }

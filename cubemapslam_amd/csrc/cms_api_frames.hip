@@ -55,6 +55,7 @@ struct cms_ctx {
   int* d_cells_all = nullptr; int* d_cells_nz = nullptr; int n_cells_all = 0, n_cells_nz = 0;   // FAST work lists
   // frame grid (Frame::AssignFeaturesToGrid), allocated on first use
   uint16_t* d_area_sorted = nullptr; int* d_area_cell_start = nullptr; int* d_area_nvalid = nullptr; int area_frames = 0;
+  int* d_area_bsum = nullptr; int area_bsum_cap = 0;
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
   // match scratch
   void* d_match = nullptr; size_t match_bytes = 0;
@@ -150,7 +151,7 @@ static void cms_ctx_free(cms_ctx* c) {
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_fish, c->d_lut, c->d_pyr, c->d_mask, c->d_tab, c->d_pattern, c->d_cand, c->d_node, c->d_cand_cnt,
                   c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_desc, c->d_kp_cnt, c->d_match, c->d_cell_cand,
-                  c->d_cell_cnt, c->d_cells_all, c->d_cells_nz, c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid};
+                  c->d_cell_cnt, c->d_cells_all, c->d_cells_nz, c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid, c->d_area_bsum};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < 8; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
   if (c->stream) hipStreamDestroy(c->stream);

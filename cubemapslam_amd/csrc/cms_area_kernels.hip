@@ -71,67 +71,130 @@ struct CmsAreaArgs {
   const uint16_t* sorted_idx;   // cell-major index list of the frame
   const int* cell_start;        // CMS_AREA_CELLS + 1 offsets into sorted_idx
   const float* qx; const float* qy; const float* qr; const int* qmin; const int* qmax;
+  const int* q_frame;           // optional: frame of the batch a query addresses (nullptr: all queries address `kp`'s frame)
+  int kp_cap;                   // frame stride of kp / sorted_idx (cell_start: CMS_AREA_CELLS + 1) when q_frame is given
   int nq, F; float inv;
   int* cnt;                     // pass 0: candidates per query
   const int* off;               // pass 1: CSR offsets
   int* idx; int cap; int idx_base;
 };
 
-extern "C" __global__ void __launch_bounds__(64) k_area_query(CmsAreaArgs a, int pass) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= a.nq) return;
-  const float x = a.qx[q], y = a.qy[q], r = a.qr[q];
-  const int minLevel = a.qmin[q], maxLevel = a.qmax[q];
+// Eight lanes per query (eight queries per wavefront): the lanes of a group take the cell columns ix of a rectangle in turn, so the
+// dependent loads of a query (cell offsets -> index list -> key point) run eight wide; a group-wide prefix sum of the per-column
+// hit counts keeps the output in AddCells' order (ix outer, iy inner, index order inside a cell).
+#define CMS_AREA_QL 8
+extern "C" __global__ void __launch_bounds__(256) k_area_query(CmsAreaArgs a, int pass) {
+  const int gl = threadIdx.x & (CMS_AREA_QL - 1);
+  const int q = (blockIdx.x * blockDim.x + threadIdx.x) / CMS_AREA_QL;
+  const bool live = q < a.nq;
+  const int qq = live ? q : 0;
+  const float x = a.qx[qq], y = a.qy[qq], r = a.qr[qq];
+  const int minLevel = a.qmin[qq], maxLevel = a.qmax[qq];
   const bool check = (minLevel > 0) || (maxLevel >= 0);
   CmsAreaRectI rc[3];
-  const int nr = cms_area_rects(x, y, r, a.F, a.inv, rc);
-  int n = 0;
-  const int base = pass ? a.off[q] : 0;
-  for (int k = 0; k < nr; ++k) {
-    const int x0 = max(0, rc[k].x0), x1 = min(CMS_AREA_G - 1, rc[k].x1), y0 = max(0, rc[k].y0), y1 = min(CMS_AREA_G - 1, rc[k].y1);   // AddCells' clamp
-    for (int ix = x0; ix <= x1; ++ix) {
-      if (y0 > y1) break;
-      // the cells (ix, y0 .. y1) of a face are consecutive in the cell-major list: one range per ix
-      const int c0 = (rc[k].face * CMS_AREA_G + ix) * CMS_AREA_G + y0;
-      const int s0 = a.cell_start[c0], s1 = a.cell_start[c0 + (y1 - y0) + 1];
+  const int nr = live ? cms_area_rects(x, y, r, a.F, a.inv, rc) : 0;
+  int n = 0;                                               // hits of the whole query so far (same in all lanes of the group)
+  const int base = (pass && live) ? a.off[qq] : 0;
+  const int fr = a.q_frame ? a.q_frame[qq] : 0;
+  const CmsKeyPoint* kp = a.kp + (size_t)fr * a.kp_cap;
+  const uint16_t* sorted_idx = a.sorted_idx + (size_t)fr * a.kp_cap;
+  const int* cell_start = a.cell_start + (size_t)fr * (CMS_AREA_CELLS + 1);
+  const int idx_base = a.idx_base + (a.q_frame ? fr * a.kp_cap : 0);
+  // the groups of a wavefront walk different rectangle shapes: loop bounds are made group-uniform via shuffles inside the group
+  for (int k = 0; k < 3; ++k) {
+    const bool has = k < nr;
+    const int x0 = has ? max(0, rc[k].x0) : 0, x1 = has ? min(CMS_AREA_G - 1, rc[k].x1) : -1;
+    const int y0 = has ? max(0, rc[k].y0) : 0, y1 = has ? min(CMS_AREA_G - 1, rc[k].y1) : -1;        // AddCells' clamp
+    const int face = has ? rc[k].face : 0;
+    const int ncol = (x1 >= x0 && y1 >= y0) ? x1 - x0 + 1 : 0;
+    // every group of the wave iterates max-over-wave column chunks; idle groups just carry zeros through the shuffles
+    int maxcol = ncol;
+    for (int o = 32; o > 0; o >>= 1) maxcol = max(maxcol, __shfl_xor(maxcol, o));
+    for (int cb = 0; cb < maxcol; cb += CMS_AREA_QL) {
+      const int ix = x0 + cb + gl;
+      const bool col = cb + gl < ncol;
+      int s0 = 0, s1 = 0;
+      if (col) {
+        const int c0 = (face * CMS_AREA_G + ix) * CMS_AREA_G + y0;      // cells (ix, y0 .. y1) are consecutive in the list
+        s0 = cell_start[c0]; s1 = cell_start[c0 + (y1 - y0) + 1];
+      }
+      // this lane's hits in its column; the first four are kept (a column rarely holds more)
+      int h0 = 0, h1 = 0, h2 = 0, h3 = 0;                  // registers, not an indexed array (that would live in scratch)
+      int nh = 0;
       for (int s = s0; s < s1; ++s) {
-        const int j = a.sorted_idx[s];
-        const CmsKeyPoint p = a.kp[j];
+        const int j = sorted_idx[s];
+        const CmsKeyPoint p = kp[j];
         if (check) {
           if (p.octave < minLevel) continue;
           if (maxLevel >= 0 && p.octave > maxLevel) continue;
         }
         if (fabsf(p.x - x) < r && fabsf(p.y - y) < r) {
-          if (pass && base + n < a.cap) a.idx[base + n] = a.idx_base + j;
-          ++n;
+          if (nh == 0) h0 = j; else if (nh == 1) h1 = j; else if (nh == 2) h2 = j; else if (nh == 3) h3 = j;
+          ++nh;
         }
       }
+      // exclusive prefix of nh over the 8 lanes of the group
+      int incl = nh;
+#pragma unroll
+      for (int o = 1; o < CMS_AREA_QL; o <<= 1) { const int t = __shfl_up(incl, o, CMS_AREA_QL); if (gl >= o) incl += t; }
+      const int tot = __shfl(incl, CMS_AREA_QL - 1, CMS_AREA_QL);
+      if (pass && nh > 0) {
+        int w = base + n + incl - nh;
+        if (nh <= 4) {
+          if (w < a.cap) a.idx[w] = idx_base + h0;
+          if (nh > 1 && w + 1 < a.cap) a.idx[w + 1] = idx_base + h1;
+          if (nh > 2 && w + 2 < a.cap) a.idx[w + 2] = idx_base + h2;
+          if (nh > 3 && w + 3 < a.cap) a.idx[w + 3] = idx_base + h3;
+        } else {                                            // crowded column: walk it again instead of a bigger local list
+          for (int s = s0; s < s1; ++s) {
+            const int j = sorted_idx[s];
+            const CmsKeyPoint p = kp[j];
+            if (check && (p.octave < minLevel || (maxLevel >= 0 && p.octave > maxLevel))) continue;
+            if (fabsf(p.x - x) < r && fabsf(p.y - y) < r) { if (w < a.cap) a.idx[w] = idx_base + j; ++w; }
+          }
+        }
+      }
+      n += tot;
     }
   }
-  if (!pass) a.cnt[q] = n;
+  if (!pass && live && gl == 0) a.cnt[q] = n;
 }
 
-// off[0] = 0, off[q + 1] = sum cnt[0..q]; *total = off[nq]
-extern "C" __global__ void __launch_bounds__(1024) k_area_scan(const int* __restrict__ cnt, int nq, int* __restrict__ off, int* __restrict__ total) {
+// CSR offsets: off[0] = 0, off[q + 1] = sum cnt[0..q], *total = off[nq].  Two launches: per-1024 block sums, then every block adds
+// the sums of the blocks before it (a few hundred values at most) to its own scan.
+extern "C" __global__ void __launch_bounds__(1024) k_area_blocksum(const int* __restrict__ cnt, int nq, int* __restrict__ bsum) {
   __shared__ int part[16];
-  __shared__ int carry;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { carry = 0; off[0] = 0; }
+  const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int v = i < nq ? cnt[i] : 0;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) part[wv] = v;
   __syncthreads();
-  for (int base = 0; base < nq; base += 1024) {
-    const int i = base + tid;
-    const int v = i < nq ? cnt[i] : 0;
-    int incl = v;
+  if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += part[w]; bsum[blockIdx.x] = t; }
+}
+extern "C" __global__ void __launch_bounds__(1024) k_area_scan(const int* __restrict__ cnt, int nq, const int* __restrict__ bsum,
+                                                                int* __restrict__ off, int* __restrict__ total) {
+  __shared__ int part[16];
+  __shared__ int s_before;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int before = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += 1024) before += bsum[b];
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) part[wv] = before;
+  __syncthreads();
+  if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += part[w]; s_before = t; }
+  __syncthreads();
+  const int i = blockIdx.x * 1024 + tid;
+  const int v = i < nq ? cnt[i] : 0;
+  int incl = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) part[wv] = incl;
-    __syncthreads();
-    int wbase = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) { const int pv = part[w]; if (w < wv) wbase += pv; tot += pv; }
-    if (i < nq) off[i + 1] = carry + wbase + incl;
-    __syncthreads();
-    if (tid == 0) carry += tot;
-    __syncthreads();
-  }
-  if (tid == 0 && total) *total = carry;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  __syncthreads();
+  if (lane == 63) part[wv] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < wv; ++w) wbase += part[w];
+  const int mine = s_before + wbase + incl;
+  if (i < nq) off[i + 1] = mine;
+  if (i == 0) off[0] = 0;
+  if (i == nq - 1 && total) *total = mine;
 }

@@ -176,6 +176,10 @@ int cms_features_in_area(cms_ctx* ctx, int b, int nq, const float* qx, const flo
 int cms_features_in_area_device(cms_ctx* ctx, int b, int nq, const void* d_qx, const void* d_qy, const void* d_qr, const void* d_min_level,
                                 const void* d_max_level, void* d_cnt_scratch, void* d_cand_off, void* d_cand_idx, int cap, int idx_base,
                                 void* d_total);
+/* one launch sequence for a whole batch: d_qframe[q] names the frame (0 .. B-1 of cms_area_grid) query q searches; indices are batch rows */
+int cms_features_in_area_batch_device(cms_ctx* ctx, int nq, const void* d_qframe, const void* d_qx, const void* d_qy, const void* d_qr,
+                                      const void* d_min_level, const void* d_max_level, void* d_cnt_scratch, void* d_cand_off,
+                                      void* d_cand_idx, int cap, void* d_total);
 
 /* ---- pose-only optimisation: Optimizer::PoseOptimization(Frame*) (src/Optimizer.cpp:48-190), the per-frame solver Tracking calls
  * 1-3 times per frame (Tracking.cpp:585,647,688).  Edge = EdgeSE3ProjectXYZMultiPinholeOnlyPose
