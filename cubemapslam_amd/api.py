@@ -99,6 +99,11 @@ def lib():
         L.cms_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
         L.cms_features_in_area_device.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]
         L.cms_features_in_area_batch_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p]
+        L.cms_area_set_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.cms_search_local_points.argtypes = ([C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_int, C.c_int] +
+                                              [C.c_void_p] * 9)
+        L.cms_is_in_frustum_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float] + [C.c_void_p] * 8
+        L.cms_search_local_points_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 3
         L.cms_pose_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cms_pose_destroy.argtypes = [C.c_void_p]
         L.cms_pose_destroy.restype = None
@@ -303,6 +308,40 @@ class Context:
         _chk(lib().cms_features_in_area_batch_device(self.h, nq, C.c_void_p(int(d_qframe)), *[C.c_void_p(int(a)) for a in d_q5], C.c_void_p(int(d_cnt)),
                                                      C.c_void_p(int(d_off)), C.c_void_p(int(d_idx)), cap, C.c_void_p(int(d_total))),
              "cms_features_in_area_batch_device")
+
+    def area_set_descriptors(self, b, desc):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        _chk(lib().cms_area_set_descriptors(self.h, b, len(desc), _p(desc)), "cms_area_set_descriptors")
+
+    def search_local_points(self, b, pose15, pos, normal, min_dist, max_dist, mp_desc, kp_mp, viewing_cos_limit=0.5, th=1.0, nnratio=0.8,
+                            th_high=100):
+        """Frame::isInFrustum + ORBMatcher::SearchByProjection(F, vpMapPoints, th) for frame b (area_grid first).  kp_mp: int32 per key
+        point (>= 0 = taken), updated in place.  Returns dict(in_view, proj_x, proj_y, level, view_cos, match, n_matches, rounds)."""
+        pose15 = np.ascontiguousarray(pose15, np.float32).reshape(15)
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3); normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        n = len(pos)
+        min_dist = np.ascontiguousarray(min_dist, np.float32); max_dist = np.ascontiguousarray(max_dist, np.float32)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(n, 32)
+        assert kp_mp.dtype == np.int32 and kp_mp.flags.c_contiguous
+        vis = np.zeros(n, np.uint8); px = np.zeros(n, np.float32); py = np.zeros(n, np.float32); lvl = np.zeros(n, np.int32)
+        vc = np.zeros(n, np.float32); match = np.full(n, -1, np.int32)
+        nm = C.c_int(0); rounds = C.c_int(0)
+        _chk(lib().cms_search_local_points(self.h, b, _p(pose15), n, _p(pos), _p(normal), _p(min_dist), _p(max_dist), _p(mp_desc),
+                                           viewing_cos_limit, th, nnratio, th_high, len(kp_mp), _p(kp_mp), _p(vis), _p(px), _p(py), _p(lvl),
+                                           _p(vc), _p(match), C.addressof(nm), C.addressof(rounds)), "cms_search_local_points")
+        return dict(in_view=vis, proj_x=px, proj_y=py, level=lvl, view_cos=vc, match=match, n_matches=nm.value, rounds=rounds.value)
+
+    def is_in_frustum_device(self, nmp, d_mp_frame, d_pose15, d_pos, d_normal, d_min, d_max, viewing_cos_limit, th, d_outs5, d_q3):
+        """d_outs5 = (in_view u8, proj_x, proj_y, level, view_cos); d_q3 = (qr, qmin, qmax) or (0, 0, 0); raw device pointers"""
+        v = lambda a: C.c_void_p(int(a)) if a else None
+        _chk(lib().cms_is_in_frustum_device(self.h, nmp, v(d_mp_frame), v(d_pose15), v(d_pos), v(d_normal), v(d_min), v(d_max),
+                                            viewing_cos_limit, th, *[v(a) for a in d_outs5], *[v(a) for a in d_q3]), "cms_is_in_frustum_device")
+
+    def search_local_points_device(self, B, d_mp_off, d_mp_desc, d_cand_off, d_cand_idx, d_pair_dist, nnratio, th_high, d_kp_mp, d_mp_match,
+                                   d_rounds=0):
+        v = lambda a: C.c_void_p(int(a)) if a else None
+        _chk(lib().cms_search_local_points_device(self.h, B, v(d_mp_off), v(d_mp_desc), v(d_cand_off), v(d_cand_idx), v(d_pair_dist), nnratio,
+                                                  th_high, v(d_kp_mp), v(d_mp_match), v(d_rounds)), "cms_search_local_points_device")
 
     def hamming_best2_device(self, qdesc, q_row, nq, tdesc, cand_off, cand_idx, t_level, t_excl, outs):
         """all arguments are raw device pointers (ints); asynchronous on the ctx stream"""

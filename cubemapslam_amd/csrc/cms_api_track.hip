@@ -1,0 +1,140 @@
+// cms_api_track.hip -- host side of the "track local map" step (Frame::isInFrustum + ORBMatcher::SearchByProjection over the local
+// map points, Tracking::SearchLocalPoints), included by cms_lib.hip after cms_api_area.hip.
+#include <cmath>
+#include <vector>
+
+extern "C" int cms_area_set_descriptors(cms_ctx* c, int b, int n, const uint8_t* desc) {
+  if (!c || b < 0 || b >= c->max_batch || n < 0 || n > c->g.kp_cap || (n > 0 && !desc)) return cms_fail(CMS_ERR_ARG, "cms_area_set_descriptors: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (n > 0) HIPCHK(hipMemcpyAsync(c->d_desc + (size_t)b * c->g.kp_cap * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return CMS_OK;
+}
+
+extern "C" int cms_is_in_frustum_device(cms_ctx* c, int nmp, const void* d_mp_frame, const void* d_pose15, const void* d_pos, const void* d_normal,
+                                        const void* d_min_dist, const void* d_max_dist, float viewing_cos_limit, float th, void* d_in_view,
+                                        void* d_proj_x, void* d_proj_y, void* d_level, void* d_view_cos, void* d_qr, void* d_qmin, void* d_qmax) {
+  if (!c || nmp < 0 || (nmp > 0 && (!d_pose15 || !d_pos || !d_normal || !d_min_dist || !d_max_dist || !d_in_view || !d_proj_x || !d_proj_y ||
+                                    !d_level || !d_view_cos)) || (d_qr && (!d_qmin || !d_qmax)))
+    return cms_fail(CMS_ERR_ARG, "cms_is_in_frustum_device: bad argument");
+  if (nmp == 0) return CMS_OK;
+  if (c->g.nlevels > 16) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_is_in_frustum_device: more than 16 pyramid levels");
+  HIPCHK(hipSetDevice(c->device));
+  CmsFrustumArgs a;
+  a.pose15 = (const float*)d_pose15; a.mp_frame = (const int*)d_mp_frame; a.n = nmp;
+  a.P = (const float*)d_pos; a.normal = (const float*)d_normal; a.min_dist = (const float*)d_min_dist; a.max_dist = (const float*)d_max_dist;
+  a.viewing_cos_limit = viewing_cos_limit; a.th = th;
+  a.log_scale = std::log(c->g.nlevels > 1 ? c->scale[1] : 1.2f);          // mfLogScaleFactor = log(mfScaleFactor), float (Frame.cpp:113)
+  a.nlevels = c->g.nlevels; a.F = c->g.F;
+  for (int l = 0; l < 16; ++l) a.sf[l] = l < c->g.nlevels ? c->scale[l] : 0.0f;
+  a.in_view = (uint8_t*)d_in_view; a.proj_x = (float*)d_proj_x; a.proj_y = (float*)d_proj_y; a.level = (int*)d_level; a.view_cos = (float*)d_view_cos;
+  a.qr = (float*)d_qr; a.qmin = (int*)d_qmin; a.qmax = (int*)d_qmax;
+  hipLaunchKernelGGL(k_in_frustum, dim3((nmp + 255) / 256), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+
+#define CMS_TRACK_MAX_MP_PER_FRAME (32 * 1024)
+extern "C" int cms_search_local_points_device(cms_ctx* c, int B, const void* d_mp_off, const void* d_mp_desc, const void* d_cand_off,
+                                              const void* d_cand_idx, void* d_pair_dist, float nnratio, int th_high, void* d_kp_mp,
+                                              void* d_mp_match, void* d_rounds) {
+  if (!c || B < 1 || B > c->area_frames || !d_mp_off || !d_mp_desc || !d_cand_off || !d_cand_idx || !d_pair_dist || !d_kp_mp || !d_mp_match)
+    return cms_fail(CMS_ERR_ARG, "cms_search_local_points_device: bad argument (cms_area_grid first)");
+  if (c->g.kp_cap > CMS_TRACK_KPMAX) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points_device: more than 4096 key points per frame");
+  HIPCHK(hipSetDevice(c->device));
+  CmsSearchLocalArgs a;
+  a.mp_off = (const int*)d_mp_off; a.mp_desc = (const uint4*)d_mp_desc; a.cand_off = (const int*)d_cand_off; a.cand_idx = (const int*)d_cand_idx;
+  a.t_desc = (const uint4*)c->d_desc; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_cap = c->g.kp_cap;
+  a.pair_dist = (uint16_t*)d_pair_dist; a.kp_mp = (int*)d_kp_mp; a.mp_match = (int*)d_mp_match; a.rounds = (int*)d_rounds;
+  a.nnratio = nnratio; a.th_high = th_high; a.frame0 = 0;
+  hipLaunchKernelGGL(k_search_local, dim3(B), dim3(1024), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+
+// One frame, host buffers: isInFrustum for the n map points, window query against frame b's grid, greedy search.  kp_mp: one int per
+// key point of frame b, in/out (>= 0 on entry = key point already holds a map point with observations; matches are written as the
+// index of the map point in this list).
+extern "C" int cms_search_local_points(cms_ctx* c, int b, const float* pose15, int nmp, const float* pos, const float* normal,
+                                       const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float viewing_cos_limit, float th,
+                                       float nnratio, int th_high, int nkp, int* kp_mp, uint8_t* in_view, float* proj_x, float* proj_y,
+                                       int* level, float* view_cos, int* mp_match, int* n_matches, int* rounds) {
+  if (!c || !pose15 || nmp < 0 || nkp < 0 || nkp > (c ? c->g.kp_cap : 0) || (nmp > 0 && (!pos || !normal || !min_dist || !max_dist || !mp_desc || !mp_match)) ||
+      (nkp > 0 && !kp_mp))
+    return cms_fail(CMS_ERR_ARG, "cms_search_local_points: bad argument");
+  if (b < 0 || b >= c->area_frames) return cms_fail(CMS_ERR_ARG, "cms_search_local_points: no grid for this frame (cms_area_grid first)");
+  if (nmp > CMS_TRACK_MAX_MP_PER_FRAME) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points: more than 32768 map points per frame");
+  if (n_matches) *n_matches = 0;
+  if (rounds) *rounds = 0;
+  if (nmp == 0) return CMS_OK;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t n4 = (size_t)nmp * 4, rows = (size_t)c->g.kp_cap * (size_t)c->max_batch;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  // arena: pose | pos | normal | min | max | desc | in_view | px | py | level | vcos | qr | qmin | qmax | cnt | off | total | mp_off | match | rounds | kp_mp(all rows)
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
+  const size_t o_pose = take(64), o_pos = take(3 * n4), o_nrm = take(3 * n4), o_min = take(n4), o_max = take(n4), o_desc = take((size_t)nmp * 32),
+               o_vis = take(nmp), o_px = take(n4), o_py = take(n4), o_lvl = take(n4), o_vc = take(n4), o_qr = take(n4), o_qmin = take(n4),
+               o_qmax = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16), o_mpoff = take(16), o_match = take(n4),
+               o_rounds = take(16), o_kpmp = take(rows * 4), o_qf = take(n4);
+  const size_t fixed = o;
+  int cap = 64 * nmp + 1024;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
+    int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
+    if (rc) return rc;
+    uint8_t* p = (uint8_t*)c->d_match;
+    HIPCHK(hipMemcpyAsync(p + o_pose, pose15, 60, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_pos, pos, 3 * n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_nrm, normal, 3 * n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_min, min_dist, n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_max, max_dist, n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(p + o_kpmp, 0xFF, rows * 4, s));
+    if (nkp > 0) HIPCHK(hipMemcpyAsync(p + o_kpmp + (size_t)b * c->g.kp_cap * 4, kp_mp, (size_t)nkp * 4, hipMemcpyHostToDevice, s));
+    const std::vector<int> qf((size_t)nmp, b);
+    HIPCHK(hipMemcpyAsync(p + o_qf, qf.data(), n4, hipMemcpyHostToDevice, s));
+    rc = cms_is_in_frustum_device(c, nmp, nullptr, p + o_pose, p + o_pos, p + o_nrm, p + o_min, p + o_max, viewing_cos_limit, th, p + o_vis,
+                                  p + o_px, p + o_py, p + o_lvl, p + o_vc, p + o_qr, p + o_qmin, p + o_qmax);
+    if (rc) return rc;
+    rc = cms_features_in_area_batch_device(c, nmp, p + o_qf, p + o_px, p + o_py, p + o_qr, p + o_qmin, p + o_qmax, p + o_cnt, p + o_off, p + o_idx,
+                                           cap, p + o_tot);
+    if (rc) return rc;
+    int tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (tot > cap) { cap = tot + 64; continue; }               // denser than 64 candidates per window: once more with the exact size
+    const int mpoff[2] = {0, nmp};                               // one workgroup: frame b (frame0 shifts the key-point rows)
+    HIPCHK(hipMemcpyAsync(p + o_mpoff, mpoff, sizeof(mpoff), hipMemcpyHostToDevice, s));
+    CmsSearchLocalArgs a;
+    a.mp_off = (const int*)(p + o_mpoff); a.mp_desc = (const uint4*)(p + o_desc); a.cand_off = (const int*)(p + o_off); a.cand_idx = (const int*)(p + o_idx);
+    a.t_desc = (const uint4*)c->d_desc; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_cap = c->g.kp_cap;
+    a.pair_dist = (uint16_t*)(p + o_pd); a.kp_mp = (int*)(p + o_kpmp); a.mp_match = (int*)(p + o_match); a.rounds = (int*)(p + o_rounds);
+    a.nnratio = nnratio; a.th_high = th_high; a.frame0 = b;
+    if (c->g.kp_cap > CMS_TRACK_KPMAX) { return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points: more than 4096 key points per frame"); }
+    hipLaunchKernelGGL(k_search_local, dim3(1), dim3(1024), 0, s, a);
+    HIPCHK(hipGetLastError());
+    std::vector<int> match((size_t)nmp);
+    HIPCHK(hipMemcpyAsync(match.data(), p + o_match, n4, hipMemcpyDeviceToHost, s));
+    if (nkp > 0) HIPCHK(hipMemcpyAsync(kp_mp, p + o_kpmp + (size_t)b * c->g.kp_cap * 4, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
+    if (in_view) HIPCHK(hipMemcpyAsync(in_view, p + o_vis, nmp, hipMemcpyDeviceToHost, s));
+    if (proj_x) HIPCHK(hipMemcpyAsync(proj_x, p + o_px, n4, hipMemcpyDeviceToHost, s));
+    if (proj_y) HIPCHK(hipMemcpyAsync(proj_y, p + o_py, n4, hipMemcpyDeviceToHost, s));
+    if (level) HIPCHK(hipMemcpyAsync(level, p + o_lvl, n4, hipMemcpyDeviceToHost, s));
+    if (view_cos) HIPCHK(hipMemcpyAsync(view_cos, p + o_vc, n4, hipMemcpyDeviceToHost, s));
+    int r = 0;
+    HIPCHK(hipMemcpyAsync(&r, p + o_rounds, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    int nm = 0;
+    for (int i = 0; i < nmp; ++i) {
+      const int m = match[(size_t)i];
+      mp_match[i] = m >= 0 ? m - b * c->g.kp_cap : -1;         // batch row -> key point index of frame b
+      nm += m >= 0;
+    }
+    if (n_matches) *n_matches = nm;
+    if (rounds) *rounds = r;
+    return CMS_OK;
+  }
+  return cms_fail(CMS_ERR_OVERFLOW, "cms_search_local_points: candidate lists kept growing");
+}

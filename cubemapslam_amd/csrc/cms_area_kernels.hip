@@ -86,9 +86,9 @@ struct CmsAreaArgs {
 extern "C" __global__ void __launch_bounds__(256) k_area_query(CmsAreaArgs a, int pass) {
   const int gl = threadIdx.x & (CMS_AREA_QL - 1);
   const int q = (blockIdx.x * blockDim.x + threadIdx.x) / CMS_AREA_QL;
-  const bool live = q < a.nq;
-  const int qq = live ? q : 0;
+  const int qq = q < a.nq ? q : 0;
   const float x = a.qx[qq], y = a.qy[qq], r = a.qr[qq];
+  const bool live = q < a.nq && !(r < 0.0f);            // r < 0: "no window" (a map point outside the frustum), empty list
   const int minLevel = a.qmin[qq], maxLevel = a.qmax[qq];
   const bool check = (minLevel > 0) || (maxLevel >= 0);
   CmsAreaRectI rc[3];
@@ -157,7 +157,7 @@ extern "C" __global__ void __launch_bounds__(256) k_area_query(CmsAreaArgs a, in
       n += tot;
     }
   }
-  if (!pass && live && gl == 0) a.cnt[q] = n;
+  if (!pass && q < a.nq && gl == 0) a.cnt[q] = n;             // 0 for a "no window" query
 }
 
 // CSR offsets: off[0] = 0, off[q + 1] = sum cnt[0..q], *total = off[nq].  Two launches: per-1024 block sums, then every block adds

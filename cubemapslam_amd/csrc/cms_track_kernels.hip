@@ -1,0 +1,185 @@
+// cms_track_kernels.hip -- "track local map" on the device: Frame::isInFrustum (src/Frame.cpp:197-249) for every local map point
+// and ORBMatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBMatcher.cpp:50-128), the pair
+// Tracking::SearchLocalPoints runs once per frame (src/Tracking.cpp:794-846).
+//
+//   k_in_frustum       one thread per map point: project with the frame's float pose, the five visibility tests, PredictScale;
+//                      it also writes the GetFeaturesInArea query of the point (x, y, r, level-1, level; r < 0 = not in view), so the
+//                      window query (cms_area_kernels.hip) follows without a host round trip
+//   k_search_local     one workgroup per frame.  The reference's loop is a sequential greedy: a key point taken by map point i is
+//                      skipped by every later map point (ORBMatcher.cpp:91-93, :121).  The same result is reached in parallel
+//                      rounds: a map point is decided in the round in which it is the LOWEST undecided point among all undecided
+//                      points sharing any of its still-free candidates -- then every earlier point that could take one of its
+//                      candidates has already spoken.  Points decided in one round have disjoint free candidates, so their claims
+//                      cannot collide; the lowest undecided point always qualifies, so the loop ends.  Hamming distances of all
+//                      (point, candidate) pairs are computed once, before the rounds.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct CmsFrustumArgs {
+  const float* pose15;      // per frame: Rcw (9, row major) | tcw (3) | Ow (3), the float members Frame::UpdatePoseMatrices leaves
+  const int* mp_frame;      // frame of every map point (nullptr: all frame 0)
+  int n;
+  const float* P; const float* normal; const float* min_dist; const float* max_dist;   // mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance
+  float viewing_cos_limit, log_scale, th;
+  int nlevels, F;
+  float sf[16];             // mvScaleFactors
+  uint8_t* in_view; float* proj_x; float* proj_y; int* level; float* view_cos;            // mbTrackInView, mTrackProjX/Y, mnTrackScaleLevel, mTrackViewCos
+  float* qr; int* qmin; int* qmax;                                                      // window of SearchByProjection (ORBMatcher.cpp:69-75)
+};
+
+// CamModelGeneral::TransformRaysToCubemap (src/CamModelGeneral.cpp:95-154): face choice on float ratios, pixel through the double
+// intrinsics (fx = fy = cx = cy = F / 2 are double members, so `_x * fx / _z + cx` is evaluated in double and narrowed on assignment)
+__device__ __forceinline__ int track_rays_to_cubemap(int F, float x, float y, float z, float& up, float& vp) {
+  const double f = F / 2.0;
+  float lx, ly, lz, ox, oy;
+  int face;
+  if (z > 0 && x / z <= 1 && x / z >= -1 && y / z <= 1 && y / z >= -1) { face = 0; lx = x; ly = y; lz = z; ox = (float)F; oy = (float)F; }
+  else if (x > 0 && y / x <= 1 && y / x >= -1 && z / x <= 1 && z / x >= -1) { face = 2; lx = -z; ly = y; lz = x; ox = (float)(2 * F); oy = (float)F; }
+  else if (x < 0 && y / (-x) <= 1 && y / (-x) >= -1 && z / (-x) <= 1 && z / (-x) >= -1) { face = 1; lx = z; ly = y; lz = -x; ox = 0.0f; oy = (float)F; }
+  else if (y > 0 && x / y <= 1 && x / y >= -1 && z / y <= 1 && z / y >= -1) { face = 4; lx = x; ly = -z; lz = y; ox = (float)F; oy = (float)(2 * F); }
+  else if (y < 0 && x / (-y) <= 1 && x / (-y) >= -1 && z / (-y) <= 1 && z / (-y) >= -1) { face = 3; lx = x; ly = z; lz = -y; ox = (float)F; oy = 0.0f; }
+  else { up = -1.0f; vp = -1.0f; return -1; }
+  up = (float)((double)lx * f / (double)lz + f);
+  vp = (float)((double)ly * f / (double)lz + f);
+  if (up < 0 || up >= F || vp < 0 || vp >= F) return -1;
+  if (ox != 0.0f) up += ox;          // the reference adds nothing on the first column / row of faces
+  if (oy != 0.0f) vp += oy;
+  return face;
+}
+
+extern "C" __global__ void __launch_bounds__(256) k_in_frustum(CmsFrustumArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float* ps = a.pose15 + 15 * (size_t)(a.mp_frame ? a.mp_frame[i] : 0);
+  uint8_t vis = 0; float u = -1.0f, v = -1.0f, vc = 0.0f; int lvl = -1;
+  const float px = a.P[3 * (size_t)i], py = a.P[3 * (size_t)i + 1], pz = a.P[3 * (size_t)i + 2];
+  float Pc[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {      // mRcw*P+mtcw: float products and sums left to right, + tcw through double (cv::gemm's small path)
+    float t = __fmul_rn(ps[3 * r], px);
+    t = __fadd_rn(t, __fmul_rn(ps[3 * r + 1], py));
+    t = __fadd_rn(t, __fmul_rn(ps[3 * r + 2], pz));
+    Pc[r] = (float)((double)t * 1.0 + (double)ps[9 + r] * 1.0);
+  }
+  const float mnMax = (float)(3 * a.F);
+  do {
+    const int face = track_rays_to_cubemap(a.F, Pc[0], Pc[1], Pc[2], u, v);
+    if (face < 0) break;
+    if (u < 0.0f || u > mnMax || v < 0.0f || v > mnMax) break;
+    const float maxd = a.max_dist[i];
+    const float maxDistance = __fmul_rn(1.2f, maxd), minDistance = __fmul_rn(0.8f, a.min_dist[i]);
+    const float PO[3] = {__fsub_rn(px, ps[12]), __fsub_rn(py, ps[13]), __fsub_rn(pz, ps[14])};
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s = __dadd_rn(s, __dmul_rn((double)PO[k], (double)PO[k]));
+    const float dist = (float)sqrt(s);
+    if (dist < minDistance || dist > maxDistance) break;
+    double d = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d = __dadd_rn(d, __dmul_rn((double)PO[k], (double)a.normal[3 * (size_t)i + k]));
+    vc = (float)(d / (double)dist);
+    if (vc < a.viewing_cos_limit) break;
+    // MapPoint::PredictScale (MapPoint.cpp:404-419): ceil(logf(ratio) / mfLogScaleFactor); the float log is taken as the rounded
+    // double log (glibc's logf is within 0.82 ulp of it; the two can only part where the quotient sits within an ulp of an integer)
+    const float ratio = maxd / dist;
+    const float lg = (float)log((double)ratio);
+    int ns = (int)ceilf(lg / a.log_scale);
+    if (ns < 0) ns = 0; else if (ns >= a.nlevels) ns = a.nlevels - 1;
+    lvl = ns; vis = 1;
+  } while (false);
+  if (!vis) { u = -1.0f; v = -1.0f; vc = 0.0f; }
+  a.in_view[i] = vis; a.proj_x[i] = u; a.proj_y[i] = v; a.level[i] = lvl; a.view_cos[i] = vc;
+  if (a.qr) {
+    float r = (double)vc > 0.998 ? 2.5f : 4.0f;                    // ORBMatcher::RadiusByViewingCos (ORBMatcher.cpp:380-386)
+    if (a.th != 1.0f) r = __fmul_rn(r, a.th);
+    a.qr[i] = vis ? __fmul_rn(r, a.sf[lvl]) : -1.0f;
+    a.qmin[i] = lvl - 1; a.qmax[i] = lvl;
+  }
+}
+
+struct CmsSearchLocalArgs {
+  const int* mp_off;          // B + 1: map points [mp_off[f], mp_off[f+1]) belong to frame f, in the reference's list order
+  const uint4* mp_desc;       // 32 B per map point (MapPoint::GetDescriptor)
+  const int* cand_off; const int* cand_idx;   // CSR from the window query; indices are batch rows (frame * kp_cap + key point)
+  const uint4* t_desc; const CmsKeyPoint* kp; int kp_cap;
+  uint16_t* pair_dist;        // one entry per candidate pair (scratch)
+  int* kp_mp;                 // per batch row, in/out: >= 0 = holds a map point with observations (skipped), new matches get the point's index
+  int* mp_match;              // per map point: matched batch row or -1
+  int* rounds;                // per frame (optional): rounds the greedy needed
+  float nnratio; int th_high;
+  int frame0;                 // key-point rows of workgroup w are those of frame frame0 + w (single-frame entry point)
+};
+
+__device__ __forceinline__ int track_hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+#define CMS_TRACK_KPMAX 4096
+extern "C" __global__ void __launch_bounds__(1024) k_search_local(CmsSearchLocalArgs a) {
+  __shared__ int min_open[CMS_TRACK_KPMAX];           // lowest undecided map point that still wants key point k
+  const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int m0 = a.mp_off[f], m1 = a.mp_off[f + 1];
+  const int row0 = (f + a.frame0) * a.kp_cap;
+  // ---- distances of all pairs of this frame, 4 lanes per map point
+  {
+    const int sub = tid & 3;
+    for (int i = m0 + (tid >> 2); i < m1; i += nt >> 2) {
+      const int c0 = a.cand_off[i], c1 = a.cand_off[i + 1];
+      if (c0 == c1) continue;
+      const uint4 q0 = a.mp_desc[2 * (size_t)i], q1 = a.mp_desc[2 * (size_t)i + 1];
+      for (int c = c0 + sub; c < c1; c += 4) {
+        const size_t row = (size_t)a.cand_idx[c];
+        a.pair_dist[c] = (uint16_t)track_hamming256(q0, q1, a.t_desc[2 * row], a.t_desc[2 * row + 1]);
+      }
+    }
+  }
+  for (int i = m0 + tid; i < m1; i += nt) a.mp_match[i] = a.cand_off[i] == a.cand_off[i + 1] ? -1 : -2;   // -2 = undecided
+  __syncthreads();
+  int round = 0;
+  for (;;) {
+    for (int k = tid; k < a.kp_cap; k += nt) min_open[k] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int i = m0 + tid; i < m1; i += nt) {
+      if (a.mp_match[i] != -2) continue;
+      for (int c = a.cand_off[i]; c < a.cand_off[i + 1]; ++c) {
+        const int row = a.cand_idx[c];
+        if (a.kp_mp[row] < 0) atomicMin(&min_open[row - row0], i);
+      }
+    }
+    __syncthreads();
+    // which of my points are the lowest claimant of every free candidate they have?  (decided before anybody writes a claim)
+    unsigned ready = 0;
+    int open = 0, slot = 0;
+    for (int i = m0 + tid; i < m1; i += nt, ++slot) {
+      if (a.mp_match[i] != -2) continue;
+      bool ok = true;
+      for (int c = a.cand_off[i]; c < a.cand_off[i + 1] && ok; ++c) {
+        const int row = a.cand_idx[c];
+        ok = a.kp_mp[row] >= 0 || min_open[row - row0] == i;
+      }
+      if (ok && slot < 32) ready |= 1u << slot; else ++open;
+    }
+    __syncthreads();
+    slot = 0;
+    for (int i = m0 + tid; i < m1; i += nt, ++slot) {
+      if (slot >= 32 || !((ready >> slot) & 1u)) continue;
+      // the reference's scan (ORBMatcher.cpp:84-113) over the candidates in GetFeaturesInArea's order
+      int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestRow = -1;
+      for (int c = a.cand_off[i]; c < a.cand_off[i + 1]; ++c) {
+        const int row = a.cand_idx[c];
+        if (a.kp_mp[row] >= 0) continue;
+        const int dist = a.pair_dist[c];
+        if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = a.kp[row].octave; bestRow = row; }
+        else if (dist < bestDist2) { bestLevel2 = a.kp[row].octave; bestDist2 = dist; }
+      }
+      int m = -1;
+      if (bestDist <= a.th_high && !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2))) m = bestRow;
+      if (m >= 0) a.kp_mp[m] = i;
+      a.mp_match[i] = m;
+    }
+    ++round;
+    if (__syncthreads_count(open > 0) == 0) break;
+  }
+  if (a.rounds && tid == 0) a.rounds[f] = round;
+}

@@ -245,6 +245,68 @@ def pose_problem(N=600, F=550, seed=7, outlier_frac=0.1, nlevels=8, scale=1.2, r
                 pose0=pose0, pose_gt=pose_gt, fx=F / 2.0, fy=F / 2.0, cx=F / 2.0, cy=F / 2.0)
 
 
+def pixel_to_ray(F, px, py):
+    """rig-frame ray (z_local = 1) through canvas pixel (px, py): inverse of rays_to_cubemap on the five faces (harness use)."""
+    px = np.asarray(px, np.float64); py = np.asarray(py, np.float64)
+    face = face_of_pixel(F, px, py)
+    lx = (px - np.floor(px / F) * F - F / 2.0) / (F / 2.0); ly = (py - np.floor(py / F) * F - F / 2.0) / (F / 2.0); lz = np.ones_like(lx)
+    X = np.zeros(px.shape + (3,))
+    for fid, (rx, ry, rz) in {0: (lx, ly, lz), 1: (-lz, ly, lx), 2: (lz, ly, -lx), 4: (lx, lz, -ly), 3: (lx, -lz, ly)}.items():
+        m = face == fid
+        X[m, 0] = rx[m]; X[m, 1] = ry[m]; X[m, 2] = rz[m]
+    return face, X
+
+
+def local_map_problem(F, kx, ky, koct, kdesc, seed=3, nlevels=8, scale=1.2, extra=0.6, dup=0.25, order="random"):
+    """A local map seen from one frame (Tracking::SearchLocalPoints' inputs): float pose (Rcw | tcw | Ow), map points behind a share of
+    the frame's key points (position noise of a few pixels, descriptor = key point's with a few flipped bits, scale range around the key
+    point's level), `dup` of them doubled (two map points competing for one key point), plus `extra` x as many that are out of view,
+    too near / far, or seen from behind.  order: "random" or "spatial" (map points sorted along the image -- long claim chains)."""
+    rng = np.random.default_rng(seed)
+    kx = np.asarray(kx, np.float32); ky = np.asarray(ky, np.float32); koct = np.asarray(koct, np.int32)
+    n = len(kx)
+    ang = rng.normal(0, 0.3, 3)
+    R = (_rot((1, 0, 0), ang[0]) @ _rot((0, 1, 0), ang[1]) @ _rot((0, 0, 1), ang[2])).astype(np.float32)
+    t = rng.normal(0, 1.0, 3).astype(np.float32)
+    Ow = (-(R.T.astype(np.float32) @ t)).astype(np.float32)
+    sf = np.float32(scale) ** np.arange(nlevels, dtype=np.float32)
+    pick = np.flatnonzero(rng.random(n) < 0.7)
+    pick = np.concatenate([pick, rng.choice(pick, int(dup * len(pick)), replace=False)]) if len(pick) else pick
+    fc, ray = pixel_to_ray(F, kx[pick] + rng.normal(0, 1.5, len(pick)), ky[pick] + rng.normal(0, 1.5, len(pick)))
+    ray[fc < 0] = (0.0, 0.0, 1.0)                                       # jittered into a corner block of the cross
+    ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+    depth = rng.uniform(2.0, 12.0, len(pick))
+    Xc = ray * depth[:, None]
+    Xw = (Xc - t.astype(np.float64)) @ R.astype(np.float64)           # R^T (Xc - t)
+    lvl = np.clip(koct[pick] + rng.integers(-1, 2, len(pick)), 0, nlevels - 1)
+    max_d = depth * sf[lvl] * rng.uniform(0.97, 1.03, len(pick))
+    min_d = max_d / sf[nlevels - 1]
+    nrm = (Xw - Ow.astype(np.float64)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm += rng.normal(0, 0.25, nrm.shape); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    desc = np.asarray(kdesc, np.uint8)[pick].copy()
+    flips = rng.integers(0, 256, (len(pick), 12))
+    nflip = rng.integers(0, 13, len(pick))
+    for j in range(12):
+        m = nflip > j
+        desc[m, flips[m, j] >> 3] ^= (1 << (flips[m, j] & 7)).astype(np.uint8)
+    ne = int(extra * len(pick))
+    Xe = rng.normal(0, 8.0, (ne, 3)) + Ow
+    ne_n = rng.normal(0, 1, (ne, 3)); ne_n /= np.linalg.norm(ne_n, axis=1, keepdims=True)
+    de = np.linalg.norm(Xe - Ow, axis=1)
+    max_e = de * rng.uniform(0.3, 3.0, ne); min_e = max_e / sf[nlevels - 1]
+    P = np.concatenate([Xw, Xe]).astype(np.float32); N = np.concatenate([nrm, ne_n]).astype(np.float32)
+    mind = np.concatenate([min_d, min_e]).astype(np.float32); maxd = np.concatenate([max_d, max_e]).astype(np.float32)
+    D = np.concatenate([desc, rng.integers(0, 256, (ne, 32), dtype=np.uint8)])
+    if order == "spatial":
+        key = np.concatenate([ky[pick] * 4096.0 + kx[pick], rng.uniform(0, 4096.0 * 3 * F, ne)])
+        perm = np.argsort(key, kind="stable")
+    else:
+        perm = rng.permutation(len(P))
+    pose15 = np.concatenate([R.reshape(-1), t, Ow]).astype(np.float32)
+    return dict(pose15=pose15, pos=np.ascontiguousarray(P[perm]), normal=np.ascontiguousarray(N[perm]), min_dist=mind[perm].copy(),
+                max_dist=maxd[perm].copy(), desc=np.ascontiguousarray(D[perm]), scale_factors=sf)
+
+
 def descriptors(n, seed):
     return np.random.RandomState(seed).randint(0, 256, size=(n, 32)).astype(np.uint8)
 

@@ -181,6 +181,34 @@ int cms_features_in_area_batch_device(cms_ctx* ctx, int nq, const void* d_qframe
                                       const void* d_min_level, const void* d_max_level, void* d_cnt_scratch, void* d_cand_off,
                                       void* d_cand_idx, int cap, void* d_total);
 
+/* ---- track local map: Frame::isInFrustum (src/Frame.cpp:197-249, with MapPoint::PredictScale, src/MapPoint.cpp:404-419, and
+ * Get{Min,Max}DistanceInvariance :375-385) for every local map point, then ORBMatcher::SearchByProjection(Frame&, const
+ * vector<MapPoint*>&, th) (src/ORBMatcher.cpp:50-128, RadiusByViewingCos :380-386) -- the pair Tracking::SearchLocalPoints
+ * (src/Tracking.cpp:794-846) runs per frame with viewingCosLimit 0.5, ORBMatcher(0.8), th 1 (5 after a relocalisation).
+ *   pose15      Rcw (9 floats, row major) | tcw (3) | Ow (3): Frame::mRcw / mtcw / mOw as Frame::UpdatePoseMatrices leaves them
+ *   pos, normal MapPoint::mWorldPos / mNormalVector (3 floats each); min_dist / max_dist = mfMinDistance / mfMaxDistance
+ *   outputs     in_view = mbTrackInView, proj_x/y = mTrackProjX/Y (-1 when not in view), level = mnTrackScaleLevel, view_cos
+ * The reference's matching loop is sequential -- a key point taken by one map point is skipped by all later ones -- and the
+ * device reproduces exactly that result (cms_track_kernels.hip explains how).  kp_mp holds one int per key point: >= 0 on entry
+ * means "already holds a map point with observations" (ORBMatcher.cpp:91-93); a new match stores the map point's list index.
+ * cms_search_local_points is the one-frame entry with host buffers: frame b's key points/descriptors are the ones the last
+ * cms_frames_process left on the device, or cms_area_set_keypoints + cms_area_set_descriptors put there (cms_area_grid first).
+ * The _device entries take device pointers, work on all frames of a batch at once and are asynchronous on the ctx stream:
+ * cms_is_in_frustum_device also writes the window of every point (qr < 0: not in view) for cms_features_in_area_batch_device;
+ * cms_search_local_points_device takes that CSR (indices = batch rows), mp_off[B+1] (map points grouped by frame, list order
+ * inside a frame), scratch pair_dist (2 bytes per candidate) and kp_mp over all batch rows; mp_match = batch row or -1. */
+int cms_area_set_descriptors(cms_ctx* ctx, int b, int n, const uint8_t* desc);
+int cms_search_local_points(cms_ctx* ctx, int b, const float* pose15, int nmp, const float* pos, const float* normal,
+                            const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float viewing_cos_limit, float th,
+                            float nnratio, int th_high, int nkp, int* kp_mp, uint8_t* in_view, float* proj_x, float* proj_y, int* level,
+                            float* view_cos, int* mp_match, int* n_matches, int* rounds);
+int cms_is_in_frustum_device(cms_ctx* ctx, int nmp, const void* d_mp_frame, const void* d_pose15, const void* d_pos, const void* d_normal,
+                             const void* d_min_dist, const void* d_max_dist, float viewing_cos_limit, float th, void* d_in_view,
+                             void* d_proj_x, void* d_proj_y, void* d_level, void* d_view_cos, void* d_qr, void* d_qmin, void* d_qmax);
+int cms_search_local_points_device(cms_ctx* ctx, int B, const void* d_mp_off, const void* d_mp_desc, const void* d_cand_off,
+                                   const void* d_cand_idx, void* d_pair_dist, float nnratio, int th_high, void* d_kp_mp, void* d_mp_match,
+                                   void* d_rounds);
+
 /* ---- pose-only optimisation: Optimizer::PoseOptimization(Frame*) (src/Optimizer.cpp:48-190), the per-frame solver Tracking calls
  * 1-3 times per frame (Tracking.cpp:585,647,688).  Edge = EdgeSE3ProjectXYZMultiPinholeOnlyPose
  * (include/g2o_cubemap_vertices_edges.h:42-88, src/g2o_cubemap_vertices_edges.cpp:61-134).  One workgroup per frame runs all four

@@ -100,6 +100,18 @@ int  orc_features_in_area(const orc_camera* cam, int n, const float* kx, const f
                           const float* qx, const float* qy, const float* qr, const int* qmin, const int* qmax,
                           int* off, int* idx, int cap);
 
+/* ---- track local map: Frame::isInFrustum (Frame.cpp:197-249) + ORBMatcher::SearchByProjection(F, vpMapPoints, th)
+ * (ORBMatcher.cpp:50-128); orc_track.cpp.  Rcw (row major), tcw, Ow: the float members Frame::UpdatePoseMatrices leaves;
+ * min_dist / max_dist: MapPoint::mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors are applied inside). */
+int  orc_is_in_frustum(const orc_camera* cam, const float* Rcw, const float* tcw, const float* Ow, int n, const float* P,
+                       const float* normal, const float* min_dist, const float* max_dist, float viewing_cos_limit,
+                       float scale_factor, int nlevels, uint8_t* in_view, float* proj_x, float* proj_y, int* level,
+                       float* view_cos);
+int  orc_search_local_points(const orc_camera* cam, int nkp, const float* kx, const float* ky, const int* koct,
+                             const uint8_t* kdesc, const float* scale_factors, int nmp, const uint8_t* in_view,
+                             const float* proj_x, const float* proj_y, const int* level, const float* view_cos,
+                             const uint8_t* mp_desc, float th, float nnratio, int th_high, int* kp_mp, int* mp_match);
+
 /* ---- ORBMatcher (ORBMatcher.cpp) ---- */
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
 /* best / second-best over CSR candidate lists, the inner loop of SearchByProjection (ORBMatcher.cpp:84-113) */

@@ -1,0 +1,95 @@
+// oracle/orc_track.cpp -- CPU ORACLE (test infrastructure only, see orc_api.h) for the "track local map" projection + search:
+//   Frame::isInFrustum                      src/Frame.cpp:197-249
+//   MapPoint::PredictScale(dist, Frame*)    src/MapPoint.cpp:404-419, Get{Min,Max}DistanceInvariance :375-385
+//   ORBMatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)   src/ORBMatcher.cpp:50-128, RadiusByViewingCos :380-386
+// as Tracking::SearchLocalPoints drives them (src/Tracking.cpp:794-846: isInFrustum(pMP, 0.5), ORBMatcher(0.8), th = 1 or 5).
+//
+// cv::Mat arithmetic the reference leans on (OpenCV is not vendored; "parity unpinned") is taken as:
+//   mRcw*P+mtcw   3x3 * 3x1 + 3x1 in CV_32F = cv::gemm's small-matrix path: t = a0*b0 + a1*b1 + a2*b2 in float (left to right, no
+//                 contraction), result (float)((double)t * 1.0 + (double)c * 1.0)
+//   P-mOw         float subtraction
+//   cv::norm      sqrt of the double sum of double squares, then narrowed by `const float dist = ...`
+//   PO.dot(Pn)    double sum of double products; `/dist` is double / float, narrowed by `const float viewCos = ...`
+//   log(ratio)    <cmath>'s float overload (logf), divided by the float mfLogScaleFactor = logf(mfScaleFactor) (Frame.cpp:113)
+#include "orc_api.h"
+#include <cmath>
+#include <vector>
+
+extern "C" int orc_is_in_frustum(const orc_camera* cam, const float* Rcw, const float* tcw, const float* Ow, int n, const float* P,
+                                 const float* normal, const float* min_dist, const float* max_dist, float viewing_cos_limit,
+                                 float scale_factor, int nlevels, uint8_t* in_view, float* proj_x, float* proj_y, int* level,
+                                 float* view_cos) {
+  const float mnMinX = 0.0f, mnMinY = 0.0f, mnMaxX = (float)(3 * cam->face), mnMaxY = (float)(3 * cam->face);   // Frame.cpp:144-147
+  const float logScale = std::log(scale_factor);                                                              // Frame.cpp:113
+  int nin = 0;
+  for (int i = 0; i < n; ++i) {
+    in_view[i] = 0; proj_x[i] = -1.0f; proj_y[i] = -1.0f; level[i] = -1; view_cos[i] = 0.0f;                       // mbTrackInView = false
+    const float* p = P + 3 * i;
+    float Pc[3];
+    for (int r = 0; r < 3; ++r) {
+      float t = Rcw[3 * r] * p[0];
+      t = t + Rcw[3 * r + 1] * p[1];
+      t = t + Rcw[3 * r + 2] * p[2];
+      Pc[r] = (float)((double)t * 1.0 + (double)tcw[r] * 1.0);
+    }
+    float u, v;
+    const int face = orc_rays_to_cubemap(cam, Pc[0], Pc[1], Pc[2], &u, &v);
+    if (face == ORC_FACE_UNKNOWN) continue;
+    if (u < mnMinX || u > mnMaxX) continue;
+    if (v < mnMinY || v > mnMaxY) continue;
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    const float PO[3] = {p[0] - Ow[0], p[1] - Ow[1], p[2] - Ow[2]};
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (double)PO[k] * (double)PO[k];
+    const float dist = (float)std::sqrt(s);
+    if (dist < minDistance || dist > maxDistance) continue;
+    double d = 0;
+    for (int k = 0; k < 3; ++k) d += (double)PO[k] * (double)normal[3 * i + k];
+    const float viewCos = (float)(d / dist);
+    if (viewCos < viewing_cos_limit) continue;
+    const float ratio = max_dist[i] / dist;                                                                     // MapPoint.cpp:409
+    int nScale = (int)std::ceil(std::log(ratio) / logScale);                                                    // float log, float divide
+    if (nScale < 0) nScale = 0; else if (nScale >= nlevels) nScale = nlevels - 1;
+    in_view[i] = 1; proj_x[i] = u; proj_y[i] = v; level[i] = nScale; view_cos[i] = viewCos;
+    ++nin;
+  }
+  return nin;
+}
+
+// SearchByProjection(F, vpMapPoints, th) over the map points isInFrustum marked; returns nmatches.  kp_mp (in/out, one int per
+// key point of F): < 0 = key point free, otherwise the index of the map point it holds (entries the caller passes >= 0 stand for
+// "mvpMapPoints[idx] with Observations() > 0"; new matches are written as the map point's index in the list).
+extern "C" int orc_search_local_points(const orc_camera* cam, int nkp, const float* kx, const float* ky, const int* koct,
+                                       const uint8_t* kdesc, const float* scale_factors, int nmp, const uint8_t* in_view,
+                                       const float* proj_x, const float* proj_y, const int* level, const float* view_cos,
+                                       const uint8_t* mp_desc, float th, float nnratio, int th_high, int* kp_mp, int* mp_match) {
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  std::vector<int> off(2), idx(nkp > 0 ? nkp : 1);
+  for (int i = 0; i < nmp; ++i) {
+    mp_match[i] = -1;
+    if (!in_view[i]) continue;
+    const int nPredictedLevel = level[i];
+    float r = view_cos[i] > 0.998 ? 2.5f : 4.0f;                     // RadiusByViewingCos: float vs the double literal 0.998
+    if (bFactor) r *= th;
+    const float qx = proj_x[i], qy = proj_y[i], qr = r * scale_factors[nPredictedLevel];
+    const int lo = nPredictedLevel - 1, hi = nPredictedLevel;
+    const int nc = orc_features_in_area(cam, nkp, kx, ky, koct, 1, &qx, &qy, &qr, &lo, &hi, off.data(), idx.data(), nkp);
+    if (nc == 0) continue;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int c = 0; c < nc; ++c) {
+      const int k = idx[c];
+      if (kp_mp[k] >= 0) continue;
+      const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, kdesc + 32 * (size_t)k);
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = koct[k]; bestIdx = k; }
+      else if (dist < bestDist2) { bestLevel2 = koct[k]; bestDist2 = dist; }
+    }
+    if (bestDist <= th_high) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      kp_mp[bestIdx] = i;
+      mp_match[i] = bestIdx;
+      ++nmatches;
+    }
+  }
+  return nmatches;
+}

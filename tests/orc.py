@@ -285,3 +285,34 @@ def features_in_area(cam, kx, ky, koct, qx, qy, qr, qmin, qmax, cap=None):
                                      _p(off), _p(idx), cap)
     assert tot <= cap, (tot, cap)
     return off, idx[:tot]
+
+
+def is_in_frustum(cam, pose15, pos, normal, min_dist, max_dist, viewing_cos_limit=0.5, scale_factor=1.2, nlevels=8):
+    """Frame::isInFrustum over a list of map points -> dict(in_view, proj_x, proj_y, level, view_cos)"""
+    L = lib()
+    L.orc_is_in_frustum.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 5
+    pose15 = np.ascontiguousarray(pose15, np.float32).reshape(15)
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3); normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+    min_dist = np.ascontiguousarray(min_dist, np.float32); max_dist = np.ascontiguousarray(max_dist, np.float32)
+    n = len(pos)
+    vis = np.zeros(n, np.uint8); px = np.zeros(n, np.float32); py = np.zeros(n, np.float32); lvl = np.zeros(n, np.int32); vc = np.zeros(n, np.float32)
+    R, t, O = pose15[:9].copy(), pose15[9:12].copy(), pose15[12:15].copy()
+    L.orc_is_in_frustum(C.byref(cam), _p(R), _p(t), _p(O), n, _p(pos), _p(normal), _p(min_dist), _p(max_dist), viewing_cos_limit,
+                        scale_factor, nlevels, _p(vis), _p(px), _p(py), _p(lvl), _p(vc))
+    return dict(in_view=vis, proj_x=px, proj_y=py, level=lvl, view_cos=vc)
+
+
+def search_local_points(cam, kx, ky, koct, kdesc, scale_factors, fr, mp_desc, kp_mp, th=1.0, nnratio=0.8, th_high=100):
+    """ORBMatcher::SearchByProjection(F, vpMapPoints, th); fr = is_in_frustum's dict; kp_mp int32 in/out.  Returns (match, nmatches)."""
+    L = lib()
+    L.orc_search_local_points.argtypes = ([C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_int] +
+                                          [C.c_void_p] * 2)
+    kx = np.ascontiguousarray(kx, np.float32); ky = np.ascontiguousarray(ky, np.float32); koct = np.ascontiguousarray(koct, np.int32)
+    kdesc = np.ascontiguousarray(kdesc, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    n = len(fr["in_view"])
+    assert kp_mp.dtype == np.int32 and len(kp_mp) == len(kx)
+    match = np.full(n, -1, np.int32)
+    nm = L.orc_search_local_points(C.byref(cam), len(kx), _p(kx), _p(ky), _p(koct), _p(kdesc), _p(sf), n, _p(fr["in_view"]), _p(fr["proj_x"]),
+                                   _p(fr["proj_y"]), _p(fr["level"]), _p(fr["view_cos"]), _p(mp_desc), th, nnratio, th_high, _p(kp_mp), _p(match))
+    return match, nm

@@ -422,3 +422,41 @@ def test_features_in_area_on_extracted_frames_feeds_the_matcher():
     assert np.array_equal(outs[3].cpu().numpy(), want["second_dist"])
     assert (want["best_idx"] >= 0).sum() > 100
     ctx.close()
+
+
+def _local_map_case(F, n, seed, order):
+    import test_area_emu as te
+    kx, ky, ko = te._keypoints(F, n, seed)
+    kd = synth.descriptors(len(kx), seed + 1)
+    pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=seed + 2, order=order)
+    return kx, ky, ko, kd, pr
+
+
+def test_search_local_points_matches_oracle():
+    """Tracking::SearchLocalPoints on the device (SURVEY.md 8f-2): Frame::isInFrustum for every map point, the windows, and the
+    sequential greedy of ORBMatcher::SearchByProjection(F, vpMapPoints, th) reproduced by parallel rounds -- identical in-view flags,
+    projections, predicted levels, matches and key-point ownership, for random and for spatially sorted (long claim chains) lists."""
+    for F, n, seed, order, th in ((550, 2000, 41, "random", 1.0), (550, 2000, 42, "spatial", 5.0), (150, 600, 43, "random", 5.0)):
+        camd = synth.camera("lafida", F)
+        ocam = orc.make_camera(camd)
+        kx, ky, ko, kd, pr = _local_map_case(F, n, seed, order)
+        ctx = api.Context(camd, nfeatures=2000, max_batch=2)
+        kps = np.zeros(len(kx), api.KP_DTYPE); kps["x"] = kx; kps["y"] = ky; kps["octave"] = ko
+        ctx.area_set_keypoints(1, kps); ctx.area_set_descriptors(1, kd)
+        ctx.area_set_keypoints(0, kps[:5]); ctx.area_set_descriptors(0, kd[:5])
+        ctx.area_grid(2)
+        fr = orc.is_in_frustum(ocam, pr["pose15"], pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"])
+        taken = np.full(len(kx), -1, np.int32); taken[::9] = 10**6
+        want_kp = taken.copy()
+        want, nm = orc.search_local_points(ocam, kx, ky, ko, kd, pr["scale_factors"], fr, pr["desc"], want_kp, th=th)
+        got_kp = taken.copy()
+        got = ctx.search_local_points(1, pr["pose15"], pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], got_kp, th=th)
+        assert np.array_equal(got["in_view"], fr["in_view"]), (F, order)
+        for k in ("proj_x", "proj_y", "view_cos"):
+            assert np.array_equal(got[k], fr[k]), (F, order, k)
+        assert np.array_equal(got["level"], fr["level"])
+        assert np.array_equal(got["match"], want) and got["n_matches"] == nm, (F, order, got["n_matches"], nm)
+        assert np.array_equal(got_kp, want_kp)
+        assert nm > 100 and 1 <= got["rounds"] <= len(want)
+        # conflicts really occurred: some map point lost its best key point to an earlier one
+        ctx.close()

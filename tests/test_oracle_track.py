@@ -1,0 +1,75 @@
+"""CPU checks of the oracle's track-local-map restatement (oracle/orc_track.cpp): isInFrustum against a float64 numpy re-derivation,
+SearchByProjection(F, vpMapPoints, th) against a literal Python loop over the oracle's own GetFeaturesInArea lists."""
+import numpy as np
+import orc
+from cubemapslam_amd import synth
+import test_area_emu as te
+
+
+def _frame(F, n, seed):
+    kx, ky, ko = te._keypoints(F, n, seed)
+    kd = synth.descriptors(len(kx), seed + 1)
+    return kx, ky, ko, kd
+
+
+def test_is_in_frustum_against_numpy():
+    F = 350
+    cam = orc.make_camera(synth.camera("lafida", F))
+    kx, ky, ko, kd = _frame(F, 1500, 5)
+    pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=11)
+    fr = orc.is_in_frustum(cam, pr["pose15"], pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"])
+    R = pr["pose15"][:9].reshape(3, 3).astype(np.float64); t = pr["pose15"][9:12].astype(np.float64); Ow = pr["pose15"][12:].astype(np.float64)
+    Pc = pr["pos"].astype(np.float64) @ R.T + t
+    face, up, vp = synth.rays_to_cubemap(F, Pc)
+    PO = pr["pos"].astype(np.float64) - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    vc = (PO * pr["normal"]).sum(1) / dist
+    want = (face >= 0) & (dist >= 0.8 * pr["min_dist"]) & (dist <= 1.2 * pr["max_dist"]) & (vc >= 0.5)
+    # float vs double: only points sitting on a threshold may differ
+    margin = (np.abs(dist - 0.8 * pr["min_dist"]) < 1e-4) | (np.abs(dist - 1.2 * pr["max_dist"]) < 1e-4) | (np.abs(vc - 0.5) < 1e-5)
+    got = fr["in_view"].astype(bool)
+    assert ((got == want) | margin | (face < 0)).all()
+    assert 0.3 < got.mean() < 0.9 and (~got).sum() > 100
+    v = got & want
+    assert np.abs(fr["proj_x"][v] - up[v]).max() < 2e-2 and np.abs(fr["proj_y"][v] - vp[v]).max() < 2e-2
+    assert np.abs(fr["view_cos"][v] - vc[v]).max() < 1e-5
+    lvl = np.clip(np.ceil(np.log(pr["max_dist"][v] / dist[v]) / np.log(1.2)), 0, 7)
+    assert (fr["level"][v] != lvl).mean() < 0.002                      # boundary ties only
+    assert (fr["proj_x"][~got] == -1).all() and (fr["level"][~got] == -1).all()
+
+
+def test_search_local_points_against_python_loop():
+    F = 350
+    cam = orc.make_camera(synth.camera("lafida", F))
+    kx, ky, ko, kd = _frame(F, 1500, 6)
+    for order, th in (("random", 1.0), ("spatial", 5.0)):
+        pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=12, order=order)
+        fr = orc.is_in_frustum(cam, pr["pose15"], pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"])
+        taken = np.full(len(kx), -1, np.int32); taken[::7] = 10**6
+        kp_mp = taken.copy()
+        match, nm = orc.search_local_points(cam, kx, ky, ko, kd, pr["scale_factors"], fr, pr["desc"], kp_mp, th=th)
+        # literal loop (ORBMatcher.cpp:50-128)
+        sf = pr["scale_factors"]
+        r = np.where(fr["view_cos"].astype(np.float64) > 0.998, np.float32(2.5), np.float32(4.0)).astype(np.float32)
+        if th != 1.0:
+            r = (r * np.float32(th)).astype(np.float32)
+        lv = np.maximum(fr["level"], 0)
+        qr = (r * sf[lv]).astype(np.float32)
+        vis = fr["in_view"].astype(bool)
+        off, idx = orc.features_in_area(cam, kx, ky, ko, fr["proj_x"][vis], fr["proj_y"][vis], qr[vis], fr["level"][vis] - 1, fr["level"][vis])
+        cur = taken.copy(); want = np.full(len(vis), -1, np.int32)
+        for q, i in enumerate(np.flatnonzero(vis)):
+            best = (256, -1, -1); second = (256, -1)
+            for k in idx[off[q]:off[q + 1]]:
+                if cur[k] >= 0:
+                    continue
+                d = int(np.unpackbits(pr["desc"][i] ^ kd[k]).sum())
+                if d < best[0]:
+                    second = (best[0], best[1]); best = (d, ko[k], k)
+                elif d < second[0]:
+                    second = (d, ko[k])
+            if best[0] <= 100 and not (best[1] == second[1] and best[0] > np.float32(0.8) * np.float32(second[0])):
+                cur[best[2]] = i; want[i] = best[2]
+        assert np.array_equal(match, want) and nm == (want >= 0).sum()
+        assert np.array_equal(kp_mp, cur)
+        assert nm > 300
