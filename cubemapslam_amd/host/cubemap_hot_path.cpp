@@ -125,6 +125,61 @@ int ORBMatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
   return dist;
 }
 
+int Tracking::SearchLocalPoints(FrameView& F, std::vector<MapPointView>& mps, float th, float nnratio, float viewingCosLimit) {
+  const int N = (int)F.mvKeys.size(), M = (int)mps.size();
+  if (M == 0) return 0;
+  if (F.mTcw.rows != 4 || F.mTcw.cols != 4 || F.mTcw.type() != cv::CV_32F) throw std::runtime_error("SearchLocalPoints: mTcw must be 4x4 CV_32F");
+  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+  // Frame::UpdatePoseMatrices (Frame.cpp:189-195): mRcw, mtcw and mOw = -mRcw.t()*mtcw (cv::gemm with a transposed operand:
+  // double accumulation, one rounding to float)
+  float pose15[15];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) pose15[3 * r + c] = F.mTcw.at<float>(r, c);
+    pose15[9 + r] = F.mTcw.at<float>(r, 3);
+  }
+  for (int r = 0; r < 3; ++r) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (double)F.mTcw.at<float>(k, r) * (double)F.mTcw.at<float>(k, 3);
+    pose15[12 + r] = (float)(-1.0 * s);
+  }
+  std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M);
+  std::vector<uint8_t> desc(32 * (size_t)M);
+  for (int i = 0; i < M; ++i) {
+    for (int k = 0; k < 3; ++k) { pos[3 * (size_t)i + k] = mps[i].mWorldPos.at<float>(k, 0); nrm[3 * (size_t)i + k] = mps[i].mNormalVector.at<float>(k, 0); }
+    dmin[i] = mps[i].mfMinDistance; dmax[i] = mps[i].mfMaxDistance;
+    std::memcpy(&desc[32 * (size_t)i], mps[i].mDescriptor.ptr<uint8_t>(0), 32);
+  }
+  std::vector<cms_keypoint> kps(N);
+  std::vector<uint8_t> tdesc(32 * (size_t)N);
+  std::vector<int> kp_mp(N, -1);
+  for (int j = 0; j < N; ++j) {
+    const cv::KeyPoint& k = F.mvKeys[j];
+    kps[j].x = k.pt.x; kps[j].y = k.pt.y; kps[j].size = k.size; kps[j].angle = k.angle; kps[j].response = k.response; kps[j].octave = k.octave;
+    std::memcpy(&tdesc[32 * (size_t)j], F.mDescriptors.ptr<uint8_t>(j), 32);
+    if (F.mvpMapPoints[j] >= 0) kp_mp[j] = 0x40000000;           // holds a map point already (ORBMatcher.cpp:91-93)
+  }
+  std::vector<uint8_t> vis(M);
+  std::vector<float> px(M), py(M), vc(M);
+  std::vector<int> lvl(M), match(M);
+  int nm = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    int rc = cms_area_set_keypoints(ctx, 0, N, kps.data());
+    if (rc == CMS_OK) rc = cms_area_set_descriptors(ctx, 0, N, tdesc.data());
+    if (rc == CMS_OK) rc = cms_area_grid(ctx, 1);
+    if (rc == CMS_OK) rc = cms_search_local_points(ctx, 0, pose15, M, pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(), viewingCosLimit, th,
+                                                   nnratio, ORBMatcher::TH_HIGH, N, kp_mp.data(), vis.data(), px.data(), py.data(), lvl.data(), vc.data(),
+                                                   match.data(), &nm, nullptr);
+    if (rc != CMS_OK) throw std::runtime_error(std::string("cms_search_local_points: ") + cms_last_error());
+  }
+  for (int i = 0; i < M; ++i) {
+    mps[i].mbTrackInView = vis[i] != 0; mps[i].mTrackProjX = px[i]; mps[i].mTrackProjY = py[i];
+    mps[i].mnTrackScaleLevel = lvl[i]; mps[i].mTrackViewCos = vc[i];
+    if (match[i] >= 0) F.mvpMapPoints[match[i]] = mps[i].mnId;
+  }
+  return nm;
+}
+
 int ORBMatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, float th, bool) {
   const int N2 = (int)Cur.mvKeys.size();
   cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);

@@ -96,6 +96,7 @@ struct FrameView {
   std::vector<uint8_t> mvbOutlier;
   std::vector<cv::Point2f> projInCurrent;  // last frame only: where map point i projects in the current frame
   std::vector<float> mvScaleFactors;
+  cv::Mat mTcw;                         // 4x4 CV_32F (Tracking::SearchLocalPoints only)
 };
 
 class ORBMatcher {
@@ -111,6 +112,28 @@ class ORBMatcher {
  protected:
   float mfNNratio;
   bool mbCheckOrientation;
+};
+
+// What Frame::isInFrustum and ORBMatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) read and write on a MapPoint
+// (include/MapPoint.h): position, mean viewing direction, scale-invariance distances, representative descriptor, and the
+// mbTrackInView / mTrackProj* / mnTrackScaleLevel / mTrackViewCos fields Tracking uses afterwards.
+struct MapPointView {
+  long mnId = -1;
+  cv::Mat mWorldPos, mNormalVector;     // 3x1 CV_32F
+  float mfMinDistance = 0, mfMaxDistance = 0;
+  cv::Mat mDescriptor;                  // 1x32 CV_8U
+  bool mbTrackInView = false;
+  float mTrackProjX = -1, mTrackProjY = -1, mTrackViewCos = 0;
+  int mnTrackScaleLevel = -1;
+};
+
+// Tracking::SearchLocalPoints (src/Tracking.cpp:794-846): Frame::isInFrustum(pMP, 0.5) for every local map point, then
+// ORBMatcher(0.8).SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th).  Both halves run on the device in one call
+// (cms_search_local_points); F.mTcw is the 4x4 CV_32F pose (Frame::SetPose), F.mvpMapPoints gets the id of the matched point.
+class Tracking {
+ public:
+  static int SearchLocalPoints(FrameView& F, std::vector<MapPointView>& vpLocalMapPoints, float th = 1.0f, float nnratio = 0.8f,
+                               float viewingCosLimit = 0.5f);
 };
 
 // The window Optimizer::LocalBundleAdjustment assembles from pKF's covisibility graph (Optimizer.cpp:194-357), as data.

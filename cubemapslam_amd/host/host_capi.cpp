@@ -69,6 +69,38 @@ extern "C" int hm_search_by_projection(int ncur, const cms_keypoint* cur_k, cons
     for (int j = 0; j < ncur; ++j) cur_mp[j] = cur.mvpMapPoints[j];
     return n;)
 }
+// Tracking::SearchLocalPoints: Tcw 16 floats (row major 4x4); map points as flat arrays; outputs per map point + cur_mp[j] updated
+extern "C" int hm_search_local_points(int ncur, const cms_keypoint* cur_k, const uint8_t* cur_d, long* cur_mp, const float* scale_factors, int nlevels,
+                                      float* Tcw, int nmp, const long* mp_id, const float* pos, const float* normal, const float* min_dist,
+                                      const float* max_dist, const uint8_t* mp_desc, float th, float nnratio, uint8_t* in_view, float* proj_xy,
+                                      int* level, float* view_cos) {
+  HM_TRY(
+    FrameView cur;
+    cur.mvKeys.resize(ncur);
+    cur.mDescriptors.create(ncur > 0 ? ncur : 1, 32, cv::CV_8U);
+    for (int i = 0; i < ncur; ++i) {
+      cur.mvKeys[i].pt = cv::Point2f(cur_k[i].x, cur_k[i].y); cur.mvKeys[i].angle = cur_k[i].angle; cur.mvKeys[i].octave = cur_k[i].octave;
+      std::memcpy(cur.mDescriptors.ptr<uint8_t>(i), cur_d + (size_t)i * 32, 32);
+    }
+    cur.mvpMapPoints.assign(cur_mp, cur_mp + ncur);
+    cur.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+    cur.mTcw = cv::Mat(4, 4, cv::CV_32F, Tcw, 16);
+    std::vector<MapPointView> mps(nmp);
+    for (int i = 0; i < nmp; ++i) {
+      mps[i].mnId = mp_id[i];
+      mps[i].mWorldPos = cv::Mat(3, 1, cv::CV_32F, const_cast<float*>(pos) + 3 * (size_t)i, 4);
+      mps[i].mNormalVector = cv::Mat(3, 1, cv::CV_32F, const_cast<float*>(normal) + 3 * (size_t)i, 4);
+      mps[i].mfMinDistance = min_dist[i]; mps[i].mfMaxDistance = max_dist[i];
+      mps[i].mDescriptor = cv::Mat(1, 32, cv::CV_8U, const_cast<uint8_t*>(mp_desc) + 32 * (size_t)i, 32);
+    }
+    const int n = Tracking::SearchLocalPoints(cur, mps, th, nnratio);
+    for (int j = 0; j < ncur; ++j) cur_mp[j] = cur.mvpMapPoints[j];
+    for (int i = 0; i < nmp; ++i) {
+      in_view[i] = mps[i].mbTrackInView; proj_xy[2 * i] = mps[i].mTrackProjX; proj_xy[2 * i + 1] = mps[i].mTrackProjY;
+      level[i] = mps[i].mnTrackScaleLevel; view_cos[i] = mps[i].mTrackViewCos;
+    }
+    return n;)
+}
 // local BA through the Optimizer mirror.  Tcw: K x 16 float (row major 4x4), Xw: P x 3 float, observations flat.
 extern "C" int hm_local_ba(int K, float* Tcw, const long* kf_id, const uint8_t* kf_fixed, const float* inv_sigma2, int nlevels, int P,
                            float* Xw, int nobs, const int* obs_kf, const int* obs_mp, const cms_keypoint* obs_kp, const float* obs_ray,

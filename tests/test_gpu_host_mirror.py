@@ -213,3 +213,45 @@ def test_mirror_pose_optimization():
     assert np.array_equal(out[ks], w_out) and out[dropped] == 0 and out[has == 0].sum() == 0
     assert np.abs(Tcw[:3, 3] - w_pose[:3].astype(np.float32)).max() < 1e-5
     assert np.array_equal(Tcw[3], T_in[3])
+
+
+def test_mirror_search_local_points():
+    """Tracking::SearchLocalPoints through the C++ mirror == oracle isInFrustum + SearchByProjection(F, vpMapPoints, th)"""
+    import test_area_emu as te
+    L = _host()
+    L.hm_search_local_points.argtypes = ([C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float] +
+                                         [C.c_void_p] * 4)
+    F = 450
+    camd = synth.camera("lafida", F)
+    cam = api.make_camera(camd)
+    assert L.hm_set_camera(C.byref(cam)) == 0
+    ocam = orc.make_camera(camd)
+    # a Frame always comes from an ORBextractor: constructing one (2000 features) sizes the shared device context
+    W = 3 * F
+    img = np.ascontiguousarray(synth.texture(W, W, 70)); msk = np.full((W, W), 255, np.uint8)
+    k0 = np.zeros(3000, KP); d0 = np.zeros((3000, 32), np.uint8)
+    assert L.hm_extract(2000, 1.2, 8, 20, 7, _p(img), W, _p(msk), W, _p(k0), _p(d0), 3000) > 0, L.hm_last_error()
+    kx, ky, ko = te._keypoints(F, 1800, 71)
+    kd = synth.descriptors(len(kx), 72)
+    pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=73)
+    ck = np.zeros(len(kx), KP); ck["x"] = kx; ck["y"] = ky; ck["octave"] = ko
+    Tcw = np.eye(4, dtype=np.float32); Tcw[:3, :3] = pr["pose15"][:9].reshape(3, 3); Tcw[:3, 3] = pr["pose15"][9:12]
+    # Frame::UpdatePoseMatrices: mOw = -mRcw.t()*mtcw (double accumulation, one rounding)
+    Ow = (-(Tcw[:3, :3].astype(np.float64).T @ Tcw[:3, 3].astype(np.float64))).astype(np.float32)
+    pose15 = np.concatenate([pr["pose15"][:12], Ow]).astype(np.float32)
+    th = 5.0
+    fr = orc.is_in_frustum(ocam, pose15, pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"])
+    taken = np.full(len(kx), -1, np.int32); taken[::10] = 10**6
+    want_kp = taken.copy()
+    want, nm = orc.search_local_points(ocam, kx, ky, ko, kd, pr["scale_factors"], fr, pr["desc"], want_kp, th=th)
+    n = len(pr["pos"])
+    ids = (np.arange(n, dtype=np.int64) + 5000)
+    cur_mp = np.where(taken >= 0, 10**6, -1).astype(np.int64)
+    vis = np.zeros(n, np.uint8); pxy = np.zeros((n, 2), np.float32); lvl = np.zeros(n, np.int32); vc = np.zeros(n, np.float32)
+    got_n = L.hm_search_local_points(len(ck), _p(ck), _p(kd), _p(cur_mp), _p(pr["scale_factors"]), 8, _p(Tcw), n, _p(ids), _p(pr["pos"]), _p(pr["normal"]),
+                                     _p(pr["min_dist"]), _p(pr["max_dist"]), _p(pr["desc"]), th, 0.8, _p(vis), _p(pxy), _p(lvl), _p(vc))
+    assert got_n == nm and nm > 300, (got_n, nm, L.hm_last_error())
+    assert np.array_equal(vis, fr["in_view"]) and np.array_equal(pxy[:, 0], fr["proj_x"]) and np.array_equal(pxy[:, 1], fr["proj_y"])
+    assert np.array_equal(lvl, fr["level"]) and np.array_equal(vc, fr["view_cos"])
+    want_mp = np.where(want_kp >= 0, np.where(want_kp == 10**6, 10**6, want_kp + 5000), -1)
+    assert np.array_equal(cur_mp, want_mp)

@@ -460,3 +460,68 @@ def test_search_local_points_matches_oracle():
         assert nm > 100 and 1 <= got["rounds"] <= len(want)
         # conflicts really occurred: some map point lost its best key point to an earlier one
         ctx.close()
+
+
+def test_search_local_points_batch_on_extracted_frames():
+    """the device-pointer entries over a whole batch: three extracted frames, each with its own pose and local map; projection, windows
+    and greedy search run back to back on the ctx stream without a host round trip; every frame equals the oracle run on its own."""
+    import torch
+    camd = synth.camera("lafida", 250)
+    ocam = orc.make_camera(camd)
+    B = 3
+    ctx = api.Context(camd, nfeatures=1000, max_batch=B)
+    ctx.set_mask(synth.cubemap_valid_mask(camd, erode=5, band=30))
+    big = synth.texture(camd["Ih"] + 16, camd["Iw"] + 16, 9)
+    frames = np.stack([big[dy:dy + camd["Ih"], dx:dx + camd["Iw"]] for dy, dx in ((0, 0), (3, 5), (7, 2))]).copy()
+    ctx.upload(frames); ctx.process(B, True); ctx.sync()
+    fetched = [ctx.fetch(b) for b in range(B)]
+    ctx.area_grid(B)
+    kp_cap = ctx.geom.kp_cap
+    probs = [synth.local_map_problem(250, k["x"], k["y"], k["octave"], d, seed=60 + b, order=("spatial" if b == 1 else "random"))
+             for b, (k, d) in enumerate(fetched)]
+    mp_off = np.concatenate([[0], np.cumsum([len(p["pos"]) for p in probs])]).astype(np.int32)
+    nmp = int(mp_off[-1])
+    dev = torch.device("cuda", 0)
+    cat = lambda key, dt: torch.from_numpy(np.concatenate([p[key] for p in probs]).astype(dt)).to(dev)
+    d_pose = torch.from_numpy(np.stack([p["pose15"] for p in probs])).to(dev)
+    d_frame = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), np.diff(mp_off))).to(dev)
+    d_pos, d_nrm, d_min, d_max, d_desc = cat("pos", np.float32), cat("normal", np.float32), cat("min_dist", np.float32), cat("max_dist", np.float32), cat("desc", np.uint8)
+    d_vis = torch.zeros(nmp, dtype=torch.uint8, device=dev)
+    d_px, d_py, d_vc, d_qr = (torch.zeros(nmp, dtype=torch.float32, device=dev) for _ in range(4))
+    d_lvl, d_qmin, d_qmax, d_cnt, d_match = (torch.zeros(nmp, dtype=torch.int32, device=dev) for _ in range(5))
+    d_off = torch.zeros(nmp + 1, dtype=torch.int32, device=dev); d_tot = torch.zeros(1, dtype=torch.int32, device=dev)
+    cap = 64 * nmp
+    d_idx = torch.zeros(cap, dtype=torch.int32, device=dev); d_pd = torch.zeros(cap, dtype=torch.int16, device=dev)
+    taken = [np.full(kp_cap, -1, np.int32) for _ in range(B)]
+    for b in range(B):
+        taken[b][:len(fetched[b][0]):11] = 10**6
+    d_kpmp = torch.from_numpy(np.concatenate(taken)).to(dev)
+    d_mpoff = torch.from_numpy(mp_off).to(dev); d_rounds = torch.zeros(B, dtype=torch.int32, device=dev)
+    th = 5.0
+    ctx.is_in_frustum_device(nmp, d_frame.data_ptr(), d_pose.data_ptr(), d_pos.data_ptr(), d_nrm.data_ptr(), d_min.data_ptr(), d_max.data_ptr(), 0.5, th,
+                             [t.data_ptr() for t in (d_vis, d_px, d_py, d_lvl, d_vc)], [t.data_ptr() for t in (d_qr, d_qmin, d_qmax)])
+    ctx.features_in_area_batch_device(nmp, d_frame.data_ptr(), [t.data_ptr() for t in (d_px, d_py, d_qr, d_qmin, d_qmax)], d_cnt.data_ptr(),
+                                      d_off.data_ptr(), d_idx.data_ptr(), cap, d_tot.data_ptr())
+    ctx.search_local_points_device(B, d_mpoff.data_ptr(), d_desc.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), d_pd.data_ptr(), 0.8, 100,
+                                   d_kpmp.data_ptr(), d_match.data_ptr(), d_rounds.data_ptr())
+    ctx.sync()
+    assert int(d_tot.item()) <= cap
+    match = d_match.cpu().numpy(); kpmp = d_kpmp.cpu().numpy(); vis = d_vis.cpu().numpy()
+    total = 0
+    for b in range(B):
+        k, d = fetched[b]; p = probs[b]
+        fr = orc.is_in_frustum(ocam, p["pose15"], p["pos"], p["normal"], p["min_dist"], p["max_dist"])
+        want_kp = taken[b][:len(k)].copy()
+        want, nm = orc.search_local_points(ocam, k["x"], k["y"], k["octave"], d, p["scale_factors"], fr, p["desc"], want_kp, th=th)
+        sl = slice(mp_off[b], mp_off[b + 1])
+        assert np.array_equal(vis[sl], fr["in_view"])
+        assert np.array_equal(d_px.cpu().numpy()[sl], fr["proj_x"]) and np.array_equal(d_lvl.cpu().numpy()[sl], fr["level"])
+        got = match[sl]
+        assert np.array_equal(np.where(got >= 0, got - b * kp_cap, -1), want), b
+        # ownership is written with the global map-point index
+        got_kp = kpmp[b * kp_cap: b * kp_cap + len(k)]
+        assert np.array_equal(np.where((got_kp >= 0) & (got_kp < 10**6), got_kp - mp_off[b], got_kp), want_kp), b
+        total += nm
+    assert total > 300
+    assert (d_rounds.cpu().numpy() >= 1).all()
+    ctx.close()
