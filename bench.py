@@ -108,7 +108,8 @@ def main():
     ctx.upload(frames)          # inputs resident in HBM before the timed region
     ctx.process(B, True)
     ctx.sync()
-    kps = [ctx.fetch(b)[0] for b in range(B)]
+    fetched = [ctx.fetch(b) for b in range(B)]
+    kps = [f[0] for f in fetched]
     g = ctx.geom
     kp_cap = g.kp_cap
     scales = [g.scale[l] for l in range(g.nlevels)]
@@ -134,6 +135,38 @@ def main():
     n_pairs = int(d_tot.item())
     cand_cap = n_pairs + 4096
     d_idx = torch.zeros(cand_cap, dtype=torch.int32, device=dev)
+
+    # ---- track local map (Tracking::SearchLocalPoints): every frame has its own pose and local map (~2000 points, about two thirds in
+    # view, a quarter competing for a key point); projection, windows and the greedy search run on the device every step
+    lm = [synth.local_map_problem(F, k["x"], k["y"], k["octave"], d, seed=7000 + 100 * rank + b) for b, (k, d) in enumerate(fetched)]
+    lm_off = np.concatenate([[0], np.cumsum([len(p["pos"]) for p in lm])]).astype(np.int32)
+    n_mp = int(lm_off[-1])
+    lcat = lambda key, dt: torch.from_numpy(np.concatenate([p[key] for p in lm]).astype(dt)).to(dev)
+    d_lm_pose = torch.from_numpy(np.stack([p["pose15"] for p in lm])).to(dev)
+    d_lm_frame = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), np.diff(lm_off))).to(dev)
+    d_lm_in = [lcat("pos", np.float32), lcat("normal", np.float32), lcat("min_dist", np.float32), lcat("max_dist", np.float32)]
+    d_lm_desc = lcat("desc", np.uint8)
+    d_lm_vis = torch.zeros(n_mp, dtype=torch.uint8, device=dev)
+    d_lm_f = [torch.zeros(n_mp, dtype=torch.float32, device=dev) for _ in range(4)]          # proj_x, proj_y, view_cos, qr
+    d_lm_i = [torch.zeros(n_mp, dtype=torch.int32, device=dev) for _ in range(5)]            # level, qmin, qmax, cnt, match
+    d_lm_off = torch.zeros(n_mp + 1, dtype=torch.int32, device=dev); d_lm_tot = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_lm_mpoff = torch.from_numpy(lm_off).to(dev)
+    d_kpmp0 = torch.full((B * kp_cap,), -1, dtype=torch.int32, device=dev); d_kpmp = d_kpmp0.clone()
+    ext_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+
+    def lm_windows(d_idx_buf, cap):
+        ctx.is_in_frustum_device(n_mp, d_lm_frame.data_ptr(), d_lm_pose.data_ptr(), *[t.data_ptr() for t in d_lm_in], 0.5, 1.0,
+                                 [d_lm_vis.data_ptr(), d_lm_f[0].data_ptr(), d_lm_f[1].data_ptr(), d_lm_i[0].data_ptr(), d_lm_f[2].data_ptr()],
+                                 [d_lm_f[3].data_ptr(), d_lm_i[1].data_ptr(), d_lm_i[2].data_ptr()])
+        ctx.features_in_area_batch_device(n_mp, d_lm_frame.data_ptr(), [d_lm_f[0].data_ptr(), d_lm_f[1].data_ptr(), d_lm_f[3].data_ptr(),
+                                                                        d_lm_i[1].data_ptr(), d_lm_i[2].data_ptr()],
+                                          d_lm_i[3].data_ptr(), d_lm_off.data_ptr(), d_idx_buf.data_ptr(), cap, d_lm_tot.data_ptr())
+
+    lm_windows(torch.zeros(1, dtype=torch.int32, device=dev), 0)       # dry run: size the candidate buffer
+    ctx.sync()
+    lm_pairs = int(d_lm_tot.item())
+    lm_cap = lm_pairs + 4096
+    d_lm_idx = torch.zeros(lm_cap, dtype=torch.int32, device=dev); d_lm_pd = torch.zeros(lm_cap, dtype=torch.int16, device=dev)
 
     n_ba = max(1, B // args.ba_every)
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + rank)
@@ -177,6 +210,11 @@ def main():
                                           d_idx.data_ptr(), cand_cap, d_tot.data_ptr())
         ctx.hamming_best2_device(d_desc, d_qrow.data_ptr(), nq, d_desc, d_off.data_ptr(), d_idx.data_ptr(), d_lvl.data_ptr(), None,
                                  [o.data_ptr() for o in d_out])
+        with torch.cuda.stream(ext_stream):
+            d_kpmp.copy_(d_kpmp0)
+        lm_windows(d_lm_idx, lm_cap)
+        ctx.search_local_points_device(B, d_lm_mpoff.data_ptr(), d_lm_desc.data_ptr(), d_lm_off.data_ptr(), d_lm_idx.data_ptr(), d_lm_pd.data_ptr(),
+                                       0.8, 100, d_kpmp.data_ptr(), d_lm_i[4].data_ptr())
         ctx.sync()
         _, frame_poses, _, _ = po.fetch()
         for th in ths:
@@ -287,6 +325,13 @@ def main():
             pairs += 1
         t_match = time.perf_counter() - t1
         t1 = time.perf_counter()
+        for b in range(n):          # Tracking::SearchLocalPoints on the same local maps (key points of the GPU leg's frames)
+            kb, db = fetched[b]
+            fr = orc.is_in_frustum(ocam, lm[b]["pose15"], lm[b]["pos"], lm[b]["normal"], lm[b]["min_dist"], lm[b]["max_dist"])
+            orc.search_local_points(ocam, kb["x"], kb["y"], kb["octave"], db, lm[b]["scale_factors"], fr, lm[b]["desc"],
+                                    np.full(len(kb), -1, np.int32))
+        t_local = (time.perf_counter() - t1) / n
+        t1 = time.perf_counter()
         n_cpu_ba = 3
         for _ in range(n_cpu_ba):
             orc.ba_run(prob)
@@ -295,11 +340,13 @@ def main():
         for b in range(min(n, 8)):
             orc.pose_optimize(pose_probs[b])
         t_pose = (time.perf_counter() - t1) / min(n, 8)
-        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_pose + t_ba / args.ba_every
+        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_local + t_pose + t_ba / args.ba_every
         cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "%d frames remap+extract (%.1f ms/frame), Hamming over %.1f frame pairs (%.2f ms/frame), pose-only optimisation "
-                         "(%.2f ms/frame), %d local-BA windows (%.1f ms each, 1 per %d frames); oracle/liborc.so, single thread" %
-                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_pose, n_cpu_ba, 1e3 * t_ba, args.ba_every),
+               "sample": "%d frames remap+extract (%.1f ms/frame), windows + Hamming over %.1f frame pairs (%.2f ms/frame), local-map search "
+                         "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
+                         "oracle/liborc.so, single thread" %
+                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_local, 1e3 * t_pose, n_cpu_ba, 1e3 * t_ba,
+                          args.ba_every),
                "host_cores_available": os.cpu_count()}
 
     if rank == 0 and args.save_trajectory and last_traj[0] is not None:
@@ -321,9 +368,10 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract/match), f64 (BA)", "data": "synthetic",
             "config": {"workload": "Lafida cam0 synthetic stream, 754x480 fisheye, face=%d (%dx%d cross), nFeatures %d; per step %d frames: "
-                                   "remap+ORB extract, frame grids + GetFeaturesInArea windows + Hamming best-2 (%d queries, %d candidate pairs), pose-only optimisation (%d edges/frame), "
+                                   "remap+ORB extract, frame grids + GetFeaturesInArea windows + Hamming best-2 (%d queries, %d candidate pairs), "
+                                   "local-map search (isInFrustum + SearchByProjection, %d map points, %d candidate pairs), pose-only optimisation (%d edges/frame), "
                                    "%d local-BA windows (K=20, E=%d)"
-                                   % (F, 3 * F, 3 * F, nfeat, B, nq, n_pairs, args.pose_edges, n_ba, len(prob["e_pose"])),
+                                   % (F, 3 * F, 3 * F, nfeat, B, nq, n_pairs, n_mp, lm_pairs, args.pose_edges, n_ba, len(prob["e_pose"])),
                        "frames_per_step_per_gpu": B, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),

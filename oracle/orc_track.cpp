@@ -65,20 +65,34 @@ extern "C" int orc_search_local_points(const orc_camera* cam, int nkp, const flo
                                        const uint8_t* mp_desc, float th, float nnratio, int th_high, int* kp_mp, int* mp_match) {
   int nmatches = 0;
   const bool bFactor = th != 1.0;
-  std::vector<int> off(2), idx(nkp > 0 ? nkp : 1);
+  // the windows do not depend on the matching state: all GetFeaturesInArea calls first (the frame grid is built once, as
+  // Frame::AssignFeaturesToGrid does), then the reference's loop over the map points
+  std::vector<float> qx, qy, qr;
+  std::vector<int> lo, hi, qi;
   for (int i = 0; i < nmp; ++i) {
     mp_match[i] = -1;
     if (!in_view[i]) continue;
     const int nPredictedLevel = level[i];
     float r = view_cos[i] > 0.998 ? 2.5f : 4.0f;                     // RadiusByViewingCos: float vs the double literal 0.998
     if (bFactor) r *= th;
-    const float qx = proj_x[i], qy = proj_y[i], qr = r * scale_factors[nPredictedLevel];
-    const int lo = nPredictedLevel - 1, hi = nPredictedLevel;
-    const int nc = orc_features_in_area(cam, nkp, kx, ky, koct, 1, &qx, &qy, &qr, &lo, &hi, off.data(), idx.data(), nkp);
+    qx.push_back(proj_x[i]); qy.push_back(proj_y[i]); qr.push_back(r * scale_factors[nPredictedLevel]);
+    lo.push_back(nPredictedLevel - 1); hi.push_back(nPredictedLevel); qi.push_back(i);
+  }
+  const int nq = (int)qi.size();
+  std::vector<int> off((size_t)nq + 1, 0), idx((size_t)64 * nq + 1024);
+  int tot = orc_features_in_area(cam, nkp, kx, ky, koct, nq, qx.data(), qy.data(), qr.data(), lo.data(), hi.data(), off.data(), idx.data(), (int)idx.size());
+  if (tot > (int)idx.size()) {
+    idx.resize((size_t)tot);
+    orc_features_in_area(cam, nkp, kx, ky, koct, nq, qx.data(), qy.data(), qr.data(), lo.data(), hi.data(), off.data(), idx.data(), (int)idx.size());
+  }
+  for (int q = 0; q < nq; ++q) {
+    const int i = qi[q];
+    const int* cand = idx.data() + off[q];
+    const int nc = off[q + 1] - off[q];
     if (nc == 0) continue;
     int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
     for (int c = 0; c < nc; ++c) {
-      const int k = idx[c];
+      const int k = cand[c];
       if (kp_mp[k] >= 0) continue;
       const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, kdesc + 32 * (size_t)k);
       if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = koct[k]; bestIdx = k; }
