@@ -104,6 +104,8 @@ def lib():
                                               [C.c_void_p] * 9)
         L.cms_is_in_frustum_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float] + [C.c_void_p] * 8
         L.cms_search_local_points_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 3
+        L.cms_create_new_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.cms_fuse_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
         L.cms_pose_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cms_pose_destroy.argtypes = [C.c_void_p]
         L.cms_pose_destroy.restype = None
@@ -353,6 +355,55 @@ class Context:
         out = np.zeros((len(a), len(b)), np.uint16)
         _chk(lib().cms_hamming_matrix(self.h, _p(a), len(a), _p(b), len(b), _p(out)), "cms_hamming_matrix")
         return out
+
+
+class Keyframe(C.Structure):
+    """cms_keyframe (include/cubemapslam_hip.h)"""
+    _fields_ = [("n", C.c_int), ("kps", C.c_void_p), ("desc", C.c_void_p), ("rays", C.c_void_p), ("mp", C.c_void_p),
+                ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3),
+                ("nnodes", C.c_int), ("node_id", C.c_void_p), ("node_off", C.c_void_p), ("node_feat", C.c_void_p), ("median_depth", C.c_float)]
+
+
+def make_keyframe(kf):
+    """kf: dict with x, y, octave, angle, desc, rays, mp, R, t, Ow, node_id, node_off, node_feat, median_depth (synth.keyframe_set entries
+    plus 'rays').  Returns (Keyframe, keep-alive list)."""
+    n = len(kf["x"])
+    kps = np.zeros(n, KP_DTYPE); kps["x"] = kf["x"]; kps["y"] = kf["y"]; kps["octave"] = kf["octave"]; kps["angle"] = kf["angle"]
+    keep = [kps, np.ascontiguousarray(kf["desc"], np.uint8), np.ascontiguousarray(kf["rays"], np.float32), np.ascontiguousarray(kf["mp"], np.int32),
+            np.ascontiguousarray(kf["node_id"], np.int32), np.ascontiguousarray(kf["node_off"], np.int32), np.ascontiguousarray(kf["node_feat"], np.int32)]
+    K = Keyframe()
+    K.n = n; K.kps = keep[0].ctypes.data; K.desc = keep[1].ctypes.data; K.rays = keep[2].ctypes.data; K.mp = keep[3].ctypes.data
+    K.Rcw[:] = [float(v) for v in np.asarray(kf["R"], np.float32).reshape(9)]
+    K.tcw[:] = [float(v) for v in kf["t"]]; K.Ow[:] = [float(v) for v in kf["Ow"]]
+    K.nnodes = len(keep[4]); K.node_id = keep[4].ctypes.data; K.node_off = keep[5].ctypes.data; K.node_feat = keep[6].ctypes.data
+    K.median_depth = float(kf["median_depth"])
+    return K, keep
+
+
+def create_new_map_points(ctx, jobs, check_orientation=False, cap=None):
+    """jobs: list of (current Keyframe, [neighbour Keyframes in covisibility order]).  Returns per job (neigh, idx1, idx2, x3d)."""
+    nj = len(jobs)
+    cur = (Keyframe * max(nj, 1))(*[j[0] for j in jobs])
+    flat = [k for j in jobs for k in j[1]]
+    neigh = (Keyframe * max(len(flat), 1))(*flat)
+    off = np.concatenate([[0], np.cumsum([len(j[1]) for j in jobs])]).astype(np.int32)
+    cap = cap if cap is not None else max([j[0].n for j in jobs] + [1])
+    n_new = np.zeros(max(nj, 1), np.int32)
+    on = np.zeros((max(nj, 1), cap), np.int32); o1 = np.zeros_like(on); o2 = np.zeros_like(on); ox = np.zeros((max(nj, 1), cap, 3), np.float32)
+    _chk(lib().cms_create_new_map_points(ctx.h, nj, C.addressof(cur), _p(off), C.addressof(neigh), int(check_orientation), cap, _p(n_new), _p(on), _p(o1),
+                                         _p(o2), _p(ox)), "cms_create_new_map_points")
+    return [(on[j, :n_new[j]].copy(), o1[j, :n_new[j]].copy(), o2[j, :n_new[j]].copy(), ox[j, :n_new[j]].copy()) for j in range(nj)]
+
+
+def fuse_search(ctx, b, pose15, skip, pos, normal, min_dist, max_dist, desc, th):
+    """search half of ORBMatcher::Fuse against key-frame slot b -> (best_idx, best_dist)"""
+    n = len(pos)
+    a = [np.ascontiguousarray(pose15, np.float32), np.ascontiguousarray(skip, np.uint8), np.ascontiguousarray(pos, np.float32),
+         np.ascontiguousarray(normal, np.float32), np.ascontiguousarray(min_dist, np.float32), np.ascontiguousarray(max_dist, np.float32),
+         np.ascontiguousarray(desc, np.uint8)]
+    bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32)
+    _chk(lib().cms_fuse_search(ctx.h, b, _p(a[0]), n, *[_p(v) for v in a[1:]], th, _p(bi), _p(bd)), "cms_fuse_search")
+    return bi, bd
 
 
 class BundleAdjuster:

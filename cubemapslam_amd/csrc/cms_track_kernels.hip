@@ -29,7 +29,7 @@ struct CmsFrustumArgs {
 
 // CamModelGeneral::TransformRaysToCubemap (src/CamModelGeneral.cpp:95-154): face choice on float ratios, pixel through the double
 // intrinsics (fx = fy = cx = cy = F / 2 are double members, so `_x * fx / _z + cx` is evaluated in double and narrowed on assignment)
-__device__ __forceinline__ int track_rays_to_cubemap(int F, float x, float y, float z, float& up, float& vp) {
+__host__ __device__ __forceinline__ int track_rays_to_cubemap(int F, float x, float y, float z, float& up, float& vp) {
   const double f = F / 2.0;
   float lx, ly, lz, ox, oy;
   int face;

@@ -307,6 +307,50 @@ def local_map_problem(F, kx, ky, koct, kdesc, seed=3, nlevels=8, scale=1.2, extr
                 max_dist=maxd[perm].copy(), desc=np.ascontiguousarray(D[perm]), scale_factors=sf)
 
 
+def keyframe_set(F, n_kf=4, n_pts=1600, seed=5, nlevels=8, scale=1.2, node_size=6, with_mp=0.45):
+    """A current key frame (index 0) and n_kf - 1 covisible neighbours looking at one random scene (LocalMapping::CreateNewMapPoints'
+    inputs): per key frame float pose (Rcw, tcw, Ow), key points (projection + noise, random level), descriptors (the scene point's +
+    a few flipped bits), `mp` (>= 0 where the feature already holds a map point) and a DBoW2-style FeatureVector: node id ->
+    feature indices (scene points are binned into nodes of ~node_size; 8 % of the features land in a wrong node)."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(0, 1, (n_pts, 3)); X *= (rng.uniform(3.0, 9.0, n_pts) / np.linalg.norm(X, axis=1))[:, None]
+    pdesc = rng.integers(0, 256, (n_pts, 32), dtype=np.uint8)
+    pnode = (rng.permutation(n_pts) // node_size).astype(np.int32)
+    has_mp = rng.random(n_pts) < with_mp
+    sf = np.float32(scale) ** np.arange(nlevels, dtype=np.float32)
+    kfs = []
+    for k in range(n_kf):
+        ang = rng.normal(0, 0.15, 3)
+        R = (_rot((1, 0, 0), ang[0]) @ _rot((0, 1, 0), ang[1]) @ _rot((0, 0, 1), ang[2])).astype(np.float32)
+        t = (rng.normal(0, 0.35, 3) if k else np.zeros(3)).astype(np.float32)
+        Ow = (-(R.astype(np.float64).T @ t.astype(np.float64))).astype(np.float32)
+        Xc = X @ R.astype(np.float64).T + t
+        face, up, vp = rays_to_cubemap(F, Xc)
+        vis = np.flatnonzero((face >= 0) & (rng.random(n_pts) < 0.85))
+        u = (up[vis] + rng.normal(0, 0.4, len(vis))).astype(np.float32); v = (vp[vis] + rng.normal(0, 0.4, len(vis))).astype(np.float32)
+        ok = face_of_pixel(F, u.astype(np.float64), v.astype(np.float64)) == face[vis]
+        vis, u, v = vis[ok], u[ok], v[ok]
+        perm = rng.permutation(len(vis)); vis, u, v = vis[perm], u[perm], v[perm]
+        n = len(vis)
+        depth = np.linalg.norm(Xc[vis], axis=1)
+        octave = np.clip(np.round(np.log(6.0 / depth) / np.log(scale) + 3 + rng.normal(0, 0.4, n)), 0, nlevels - 1).astype(np.int32)
+        d = pdesc[vis].copy()
+        flips = rng.integers(0, 256, (n, 10)); nflip = rng.integers(0, 11, n)
+        for j in range(10):
+            m = nflip > j
+            d[m, flips[m, j] >> 3] ^= (1 << (flips[m, j] & 7)).astype(np.uint8)
+        node = pnode[vis].copy()
+        wrong = rng.random(n) < 0.08
+        node[wrong] = rng.integers(0, pnode.max() + 1, wrong.sum())
+        order = np.lexsort((np.arange(n), node))
+        ids, starts = np.unique(node[order], return_index=True)
+        mp = np.where(has_mp[vis] & (rng.random(n) < 0.9), vis, -1).astype(np.int32)
+        kfs.append(dict(R=R, t=t, Ow=Ow, x=u, y=v, octave=octave, angle=rng.uniform(0, 360, n).astype(np.float32), desc=d, point=vis, mp=mp,
+                        node_id=ids.astype(np.int32), node_off=np.concatenate([starts, [n]]).astype(np.int32), node_feat=order.astype(np.int32),
+                        median_depth=np.float32(np.median(Xc[vis, 2]) if n else 1.0)))
+    return dict(kfs=kfs, X=X, scale_factors=sf, level_sigma2=(sf * sf).astype(np.float32), inv_level_sigma2=(np.float32(1.0) / (sf * sf)).astype(np.float32))
+
+
 def descriptors(n, seed):
     return np.random.RandomState(seed).randint(0, 256, size=(n, 32)).astype(np.uint8)
 

@@ -209,6 +209,36 @@ int cms_search_local_points_device(cms_ctx* ctx, int B, const void* d_mp_off, co
                                    const void* d_cand_idx, void* d_pair_dist, float nnratio, int th_high, void* d_kp_mp, void* d_mp_match,
                                    void* d_rounds);
 
+/* ---- mapping thread, either side of the local BA.
+ * cms_create_new_map_points: numeric core of LocalMapping::CreateNewMapPoints (src/LocalMapping.cpp:209-386, bearing-vector version):
+ * for every neighbour of a current key frame, in the order given (GetBestCovisibilityKeyFrames), the baseline test (:238-247),
+ * ComputeE12 (:469-482), ORBMatcher::SearchForTriangulation (src/ORBMatcher.cpp:971-1125; CheckDistEpipolarLine :388-407,
+ * CamModelGeneral::GetVectorSigma src/CamModelGeneral.cpp:307-333) and the triangulation of every match on its key rays with all of
+ * the reference's tests (:266-357).  A feature triangulated with one neighbour is taken for the following ones, as
+ * KeyFrame::AddMapPoint makes it.  njobs current key frames (independent maps / streams) are ONE launch.
+ *   cms_keyframe   what these functions read of a KeyFrame: mvKeys, mDescriptors, mvKeyRays, mp[i] >= 0 <=> GetMapPoint(i) != NULL,
+ *                  GetRotation / GetTranslation / GetCameraCenter (float), mFeatVec as CSR (node ids ascending; DBoW2 is only
+ *                  needed to produce it), ComputeSceneMedianDepth(2)
+ *   neigh_off      njobs + 1 offsets into neigh[]
+ *   outputs        n_new[j]; records j * cap_per_job + k, k < n_new[j], in creation order: neighbour index (within job j),
+ *                  idx1, idx2, x3D.  check_orientation = ORBMatcher's mbCheckOrientation (false at this call site, :217).
+ * cms_fuse_search: search half of ORBMatcher::Fuse(pKF, vpMapPoints, th) (src/ORBMatcher.cpp:1127-1226) against key-frame slot b
+ * (cms_area_set_keypoints + cms_area_set_descriptors + cms_area_grid first): projection, image / distance / viewing-angle tests,
+ * PredictScale, KeyFrame::GetFeaturesInArea(u, v, th * scale), level and reprojection gates, Hamming minimum <= TH_LOW.
+ * skip[i] != 0 <=> !pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF).  best_idx[i] = key point to fuse with or -1; the Replace /
+ * AddObservation bookkeeping (:1216-1241) stays with the caller, in list order. */
+typedef struct {
+  int n; const cms_keypoint* kps; const uint8_t* desc; const float* rays; const int* mp;
+  float Rcw[9], tcw[3], Ow[3];
+  int nnodes; const int* node_id; const int* node_off; const int* node_feat;
+  float median_depth;
+} cms_keyframe;
+int cms_create_new_map_points(cms_ctx* ctx, int njobs, const cms_keyframe* cur, const int* neigh_off, const cms_keyframe* neigh,
+                              int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
+                              float* out_x3d);
+int cms_fuse_search(cms_ctx* ctx, int b, const float* pose15, int nmp, const uint8_t* skip, const float* pos, const float* normal,
+                    const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, int* best_idx, int* best_dist);
+
 /* ---- pose-only optimisation: Optimizer::PoseOptimization(Frame*) (src/Optimizer.cpp:48-190), the per-frame solver Tracking calls
  * 1-3 times per frame (Tracking.cpp:585,647,688).  Edge = EdgeSE3ProjectXYZMultiPinholeOnlyPose
  * (include/g2o_cubemap_vertices_edges.h:42-88, src/g2o_cubemap_vertices_edges.cpp:61-134).  One workgroup per frame runs all four

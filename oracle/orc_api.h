@@ -112,6 +112,27 @@ int  orc_search_local_points(const orc_camera* cam, int nkp, const float* kx, co
                              const float* proj_x, const float* proj_y, const int* level, const float* view_cos,
                              const uint8_t* mp_desc, float th, float nnratio, int th_high, int* kp_mp, int* mp_match);
 
+/* ---- mapping thread, either side of the local BA (orc_tri.cpp): LocalMapping::CreateNewMapPoints (LocalMapping.cpp:209-386),
+ * ORBMatcher::SearchForTriangulation (ORBMatcher.cpp:971-1125), search half of ORBMatcher::Fuse (ORBMatcher.cpp:1127-1226).
+ * A key frame as these functions see it; node_* is its DBoW2::FeatureVector (node ids ascending, CSR of feature indices). */
+typedef struct {
+  int n; const orc_keypoint* kps; const uint8_t* desc; const float* rays; const int* mp;   /* mp[i] < 0: no map point */
+  float Rcw[9], tcw[3], Ow[3];
+  int nnodes; const int* node_id; const int* node_off; const int* node_feat;
+  float median_depth;                                                                      /* KeyFrame::ComputeSceneMedianDepth(2) */
+} orc_keyframe;
+void orc_compute_e12(const float* R1w, const float* t1w, const float* R2w, const float* t2w, float* E12);
+int  orc_search_for_triangulation(const orc_camera* cam, const orc_keyframe* kf1, const orc_keyframe* kf2, const float* E12,
+                                  const float* scale_factors, const float* level_sigma2, int check_orientation, int* matches12);
+int  orc_triangulate_match(const orc_camera* cam, const orc_keyframe* kf1, const orc_keyframe* kf2, int idx1, int idx2,
+                           const float* scale_factors, const float* level_sigma2, float ratio_factor, float* x3d_out);
+int  orc_create_new_map_points(const orc_camera* cam, const orc_keyframe* cur, int nneigh, const orc_keyframe* neigh,
+                               const float* scale_factors, const float* level_sigma2, int* cur_mp_inout, int* out_neigh,
+                               int* out_idx1, int* out_idx2, float* out_x3d, int cap);
+void orc_fuse_search(const orc_camera* cam, const orc_keyframe* kf, int nmp, const uint8_t* skip, const float* P, const float* normal,
+                     const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, const float* scale_factors,
+                     const float* inv_level_sigma2, int nlevels, int* best_idx, int* best_dist);
+
 /* ---- ORBMatcher (ORBMatcher.cpp) ---- */
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
 /* best / second-best over CSR candidate lists, the inner loop of SearchByProjection (ORBMatcher.cpp:84-113) */

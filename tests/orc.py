@@ -316,3 +316,75 @@ def search_local_points(cam, kx, ky, koct, kdesc, scale_factors, fr, mp_desc, kp
     nm = L.orc_search_local_points(C.byref(cam), len(kx), _p(kx), _p(ky), _p(koct), _p(kdesc), _p(sf), n, _p(fr["in_view"]), _p(fr["proj_x"]),
                                    _p(fr["proj_y"]), _p(fr["level"]), _p(fr["view_cos"]), _p(mp_desc), th, nnratio, th_high, _p(kp_mp), _p(match))
     return match, nm
+
+
+class Keyframe(C.Structure):
+    _fields_ = [("n", C.c_int), ("kps", C.c_void_p), ("desc", C.c_void_p), ("rays", C.c_void_p), ("mp", C.c_void_p),
+                ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3),
+                ("nnodes", C.c_int), ("node_id", C.c_void_p), ("node_off", C.c_void_p), ("node_feat", C.c_void_p), ("median_depth", C.c_float)]
+
+
+def keyframe_rays(cam, x, y):
+    """mvKeyRays: CamModelGeneral::TransformCubemapToRays of every key point"""
+    L = lib()
+    L.orc_cubemap_to_rays.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    out = np.zeros((len(x), 3), np.float32); r = (C.c_float * 3)()
+    for i in range(len(x)):
+        L.orc_cubemap_to_rays(C.byref(cam), float(x[i]), float(y[i]), r)
+        out[i] = r[:]
+    return out
+
+
+def make_keyframe(cam, kf):
+    """kf: one entry of synth.keyframe_set(...)['kfs']; returns (Keyframe struct, keep-alive list)"""
+    n = len(kf["x"])
+    kps = np.zeros(n, KP_DTYPE); kps["x"] = kf["x"]; kps["y"] = kf["y"]; kps["octave"] = kf["octave"]; kps["angle"] = kf["angle"]
+    if "rays" not in kf:
+        kf["rays"] = keyframe_rays(cam, kf["x"], kf["y"])
+    keep = [kps, np.ascontiguousarray(kf["desc"]), np.ascontiguousarray(kf["rays"], np.float32), np.ascontiguousarray(kf["mp"], np.int32),
+            np.ascontiguousarray(kf["node_id"], np.int32), np.ascontiguousarray(kf["node_off"], np.int32), np.ascontiguousarray(kf["node_feat"], np.int32)]
+    K = Keyframe()
+    K.n = n; K.kps = keep[0].ctypes.data; K.desc = keep[1].ctypes.data; K.rays = keep[2].ctypes.data; K.mp = keep[3].ctypes.data
+    K.Rcw[:] = [float(v) for v in np.asarray(kf["R"], np.float32).reshape(9)]; K.tcw[:] = [float(v) for v in kf["t"]]; K.Ow[:] = [float(v) for v in kf["Ow"]]
+    K.nnodes = len(keep[4]); K.node_id = keep[4].ctypes.data; K.node_off = keep[5].ctypes.data; K.node_feat = keep[6].ctypes.data
+    K.median_depth = float(kf["median_depth"])
+    return K, keep
+
+
+def compute_e12(k1, k2):
+    L = lib()
+    E = np.zeros(9, np.float32)
+    a = [np.ascontiguousarray(v, np.float32) for v in (k1["R"], k1["t"], k2["R"], k2["t"])]
+    L.orc_compute_e12.argtypes = [C.c_void_p] * 5
+    L.orc_compute_e12(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(E))
+    return E
+
+
+def search_for_triangulation(cam, K1, K2, E12, sf, sigma2, check_ori=False):
+    L = lib()
+    L.orc_search_for_triangulation.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    m = np.full(K1.n, -1, np.int32)
+    n = L.orc_search_for_triangulation(C.byref(cam), C.byref(K1), C.byref(K2), _p(E12), _p(sf), _p(sigma2), int(check_ori), _p(m))
+    return m, n
+
+
+def create_new_map_points(cam, K1, Kn, sf, sigma2, cur_mp):
+    """Kn: list of Keyframe structs (neighbours, covisibility order); cur_mp int32 in/out -> (neigh, idx1, idx2, x3d)"""
+    L = lib()
+    L.orc_create_new_map_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int]
+    arr = (Keyframe * len(Kn))(*Kn)
+    cap = K1.n * max(len(Kn), 1) + 1
+    on = np.zeros(cap, np.int32); o1 = np.zeros(cap, np.int32); o2 = np.zeros(cap, np.int32); ox = np.zeros((cap, 3), np.float32)
+    n = L.orc_create_new_map_points(C.byref(cam), C.byref(K1), len(Kn), arr, _p(sf), _p(sigma2), _p(cur_mp), _p(on), _p(o1), _p(o2), _p(ox), cap)
+    return on[:n], o1[:n], o2[:n], ox[:n]
+
+
+def fuse_search(cam, K, skip, pos, normal, min_dist, max_dist, desc, th, sf, inv_sigma2):
+    L = lib()
+    L.orc_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    n = len(pos)
+    bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32)
+    a = [np.ascontiguousarray(skip, np.uint8), np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(normal, np.float32),
+         np.ascontiguousarray(min_dist, np.float32), np.ascontiguousarray(max_dist, np.float32), np.ascontiguousarray(desc, np.uint8)]
+    L.orc_fuse_search(C.byref(cam), C.byref(K), n, *[_p(v) for v in a], th, _p(sf), _p(inv_sigma2), len(sf), _p(bi), _p(bd))
+    return bi, bd

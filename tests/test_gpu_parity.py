@@ -525,3 +525,73 @@ def test_search_local_points_batch_on_extracted_frames():
     assert total > 300
     assert (d_rounds.cpu().numpy() >= 1).all()
     ctx.close()
+
+
+def _keyframes(F, n_kf, n_pts, seed):
+    ocam = orc.make_camera(synth.camera("lafida", F))
+    S = synth.keyframe_set(F, n_kf=n_kf, n_pts=n_pts, seed=seed)
+    oks = [orc.make_keyframe(ocam, k) for k in S["kfs"]]          # fills k["rays"] too
+    gks = [api.make_keyframe(k) for k in S["kfs"]]
+    return ocam, S, oks, gks
+
+
+def test_create_new_map_points_matches_oracle():
+    """LocalMapping::CreateNewMapPoints on the device (SURVEY.md 8f-3): SearchForTriangulation over the FeatureVectors with the
+    epipolar gate, ray triangulation (4x4 Jacobi SVD in float) and all acceptance tests, neighbours in sequence; two independent
+    jobs in one launch.  Same new points in the same order, coordinates bit-identical."""
+    F = 550
+    camd = synth.camera("lafida", F)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=1)
+    jobs_g, want = [], []
+    keep = []
+    for seed, n_kf in ((5, 5), (6, 3)):
+        ocam, S, oks, gks = _keyframes(F, n_kf, 2400, seed)
+        keep.append((S, oks, gks))
+        cur_mp = S["kfs"][0]["mp"].copy()
+        want.append(orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], S["scale_factors"], S["level_sigma2"], cur_mp))
+        jobs_g.append((gks[0][0], [k for k, _ in gks[1:]]))
+    got = api.create_new_map_points(ctx, jobs_g)
+    for j in range(2):
+        wn, w1, w2, wx = want[j]
+        gn, g1, g2, gx = got[j]
+        assert len(wn) > 200, len(wn)
+        assert np.array_equal(gn, wn) and np.array_equal(g1, w1) and np.array_equal(g2, w2), (j, len(gn), len(wn))
+        assert np.array_equal(gx.view(np.uint32), wx.view(np.uint32)), (j, np.abs(gx - wx).max())
+        assert len(np.unique(wn)) >= 2                                # several neighbours contributed
+    # orientation check on (ORBMatcher(.., true)) only changes the search: compare the pair search through a one-neighbour job
+    S, oks, gks = keep[0]
+    E = orc.compute_e12(S["kfs"][0], S["kfs"][1])
+    m, _ = orc.search_for_triangulation(ocam, oks[0][0], oks[1][0], E, S["scale_factors"], S["level_sigma2"], check_ori=True)
+    got1 = api.create_new_map_points(ctx, [(gks[0][0], [gks[1][0]])], check_orientation=True)[0]
+    assert set(got1[1]) <= set(np.flatnonzero(m >= 0)) and len(got1[1]) > 50
+    assert np.array_equal(got1[2], m[got1[1]])
+    # capacity too small
+    with pytest.raises(api.CmsError):
+        api.create_new_map_points(ctx, jobs_g, cap=10)
+    ctx.close()
+
+
+def test_fuse_search_matches_oracle():
+    """search half of ORBMatcher::Fuse: the key point every map point would be fused with"""
+    import test_area_emu as te
+    F = 550
+    camd = synth.camera("lafida", F)
+    ocam = orc.make_camera(camd)
+    kx, ky, ko = te._keypoints(F, 2000, 81)
+    kd = synth.descriptors(len(kx), 82)
+    pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=83)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=1)
+    kps = np.zeros(len(kx), api.KP_DTYPE); kps["x"] = kx; kps["y"] = ky; kps["octave"] = ko
+    ctx.area_set_keypoints(0, kps); ctx.area_set_descriptors(0, kd); ctx.area_grid(1)
+    kf = dict(x=kx, y=ky, octave=ko, angle=np.zeros(len(kx), np.float32), desc=kd, mp=np.full(len(kx), -1, np.int32),
+              R=pr["pose15"][:9], t=pr["pose15"][9:12], Ow=pr["pose15"][12:], node_id=np.zeros(0, np.int32), node_off=np.zeros(1, np.int32),
+              node_feat=np.zeros(0, np.int32), median_depth=1.0, rays=np.zeros((len(kx), 3), np.float32))
+    K, _keep = orc.make_keyframe(ocam, kf)
+    skip = (np.arange(len(pr["pos"])) % 13 == 0).astype(np.uint8)
+    sf = pr["scale_factors"]; inv_s2 = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    for th in (3.0, 8.0):
+        wi, wd = orc.fuse_search(ocam, K, skip, pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], th, sf, inv_s2)
+        gi, gd = api.fuse_search(ctx, 0, pr["pose15"], skip, pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], th)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd), (th, (gi != wi).sum())
+        assert (wi >= 0).sum() > 300 and (wi[skip > 0] == -1).all()
+    ctx.close()

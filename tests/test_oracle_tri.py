@@ -1,0 +1,145 @@
+"""CPU checks of oracle/orc_tri.cpp against independent numpy derivations: essential matrix, the search against a literal Python loop
+with a float64 epipolar distance, triangulated points against numpy's SVD and the generating scene, Fuse against a brute-force scan."""
+import numpy as np
+import orc
+from cubemapslam_amd import synth
+
+F = 450
+
+
+def _set(seed, n_kf=3):
+    cam = orc.make_camera(synth.camera("lafida", F))
+    S = synth.keyframe_set(F, n_kf=n_kf, n_pts=2000, seed=seed)
+    Ks = [orc.make_keyframe(cam, k) for k in S["kfs"]]
+    return cam, S, Ks
+
+
+def test_e12_is_the_essential_matrix():
+    cam, S, Ks = _set(31)
+    k1, k2 = S["kfs"][0], S["kfs"][1]
+    E = orc.compute_e12(k1, k2).reshape(3, 3).astype(np.float64)
+    R1, R2 = k1["R"].astype(np.float64), k2["R"].astype(np.float64)
+    R12 = R1 @ R2.T; t12 = -R12 @ k2["t"] + k1["t"]
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    assert np.abs(E - tx @ R12).max() < 1e-6
+    # epipolar constraint on the noise-free rays of shared scene points: x1' E x2 = 0
+    common = np.intersect1d(k1["point"], k2["point"])[:200]
+    X = S["X"][common]
+    x1 = X @ R1.T + k1["t"]; x2 = X @ R2.T + k2["t"]
+    res = np.einsum("ij,jk,ik->i", x1, E, x2) / (np.linalg.norm(x1, axis=1) * np.linalg.norm(x2, axis=1))
+    assert np.abs(res).max() < 1e-5
+
+
+def test_search_for_triangulation_against_python_loop():
+    cam, S, Ks = _set(32)
+    k1, k2 = S["kfs"][0], S["kfs"][1]
+    E = orc.compute_e12(k1, k2)
+    sf, s2 = S["scale_factors"], S["level_sigma2"]
+    m, n = orc.search_for_triangulation(cam, Ks[0][0], Ks[1][0], E, sf, s2)
+    assert n == (m >= 0).sum() and n > 300
+    # matches pair features of the same scene point almost always, never touch features that hold a map point
+    right = np.mean(k1["point"][m >= 0] == k2["point"][m[m >= 0]])
+    assert right > 0.97
+    assert (k1["mp"][m >= 0] < 0).all() and (k2["mp"][m[m >= 0]] < 0).all()
+    # literal loop with a float64 gate: identical except where the float gate sits within rounding of 3.84
+    E64 = E.reshape(3, 3).astype(np.float64)
+    r1, r2 = k1["rays"].astype(np.float64), k2["rays"].astype(np.float64)
+    nodes2 = {int(nid): k2["node_feat"][k2["node_off"][e]:k2["node_off"][e + 1]] for e, nid in enumerate(k2["node_id"])}
+    C2 = k2["R"].astype(np.float64) @ k1["Ow"].astype(np.float64) + k2["t"]
+    _, eu, ev = synth.rays_to_cubemap(F, C2[None])
+    diff = 0
+    for e, nid in enumerate(k1["node_id"]):
+        if int(nid) not in nodes2:
+            continue
+        for i1 in k1["node_feat"][k1["node_off"][e]:k1["node_off"][e + 1]]:
+            if k1["mp"][i1] >= 0:
+                continue
+            best, bidx = 50, -1
+            for i2 in nodes2[int(nid)]:
+                if k2["mp"][i2] >= 0:
+                    continue
+                d = int(np.unpackbits(k1["desc"][i1] ^ k2["desc"][i2]).sum())
+                if d > 50 or d > best:
+                    continue
+                if (eu[0] - k2["x"][i2]) ** 2 + (ev[0] - k2["y"][i2]) ** 2 < 100 * sf[k2["octave"][i2]]:
+                    continue
+                l = r1[i1] @ E64
+                num = l @ r2[i2]; den = l @ l
+                # GetVectorSigma in float64
+                face = synth.face_of_pixel(F, np.array([float(k2["x"][i2])]), np.array([float(k2["y"][i2])]))[0]
+                nc = {0: (l[0], l[1]), 1: (l[2], l[1]), 2: (-l[2], l[1]), 4: (l[0], -l[2]), 3: (l[0], l[2])}[int(face)]
+                u = k2["x"][i2] % F - F / 2.0; v = k2["y"][i2] % F - F / 2.0
+                nn = np.hypot(*nc)
+                OO1 = abs(u * nc[1] - v * nc[0]) / nn; CO1 = np.sqrt(OO1 ** 2 + (F / 2.0) ** 2); PO1 = abs(u * nc[0] + v * nc[1]) / nn
+                t1, t2 = PO1 / CO1, (PO1 + 1) / CO1
+                t3 = (t2 - t1) / (1 + t1 * t2)
+                sig = 1 / np.sqrt(1 / t3 ** 2 + 1)
+                if num * num / (den * sig * sig * s2[k2["octave"][i2]]) < 3.84:
+                    best, bidx = d, i2
+            diff += int(bidx != m[i1])
+    assert diff <= 2, diff
+
+
+def test_triangulation_against_numpy_svd_and_the_scene():
+    cam, S, Ks = _set(33, n_kf=4)
+    sf, s2 = S["scale_factors"], S["level_sigma2"]
+    cur_mp = S["kfs"][0]["mp"].copy()
+    on, o1, o2, ox = orc.create_new_map_points(cam, Ks[0][0], [k for k, _ in Ks[1:]], sf, s2, cur_mp)
+    assert len(on) > 300 and len(np.unique(on)) >= 2
+    assert len(np.unique(o1)) == len(o1)                       # a feature is triangulated once (later neighbours skip it)
+    assert (cur_mp[o1] >= 0).all()
+    k1 = S["kfs"][0]
+    worst = 0.0
+    for j in range(0, len(on), 7):
+        k2 = S["kfs"][1 + on[j]]
+        r1, r2 = k1["rays"][o1[j]].astype(np.float64), k2["rays"][o2[j]].astype(np.float64)
+        T1 = np.hstack([k1["R"].astype(np.float64), k1["t"][:, None]]); T2 = np.hstack([k2["R"].astype(np.float64), k2["t"][:, None]])
+        A = np.stack([r1[0] * (T1[1] + T1[2]) - (r1[1] + r1[2]) * T1[0], r1[1] * (T1[0] + T1[2]) - (r1[0] + r1[2]) * T1[1],
+                      r2[0] * (T2[1] + T2[2]) - (r2[1] + r2[2]) * T2[0], r2[1] * (T2[0] + T2[2]) - (r2[0] + r2[2]) * T2[1]])
+        v = np.linalg.svd(A)[2][3]
+        x = v[:3] / v[3]
+        worst = max(worst, np.linalg.norm(x - ox[j]) / np.linalg.norm(x))
+    assert worst < 2e-3, worst                                   # float Jacobi vs float64 LAPACK on a noisy two-ray system
+    same = k1["point"][o1] == np.array([S["kfs"][1 + n]["point"][i2] for n, i2 in zip(on, o2)])
+    err = np.linalg.norm(ox[same] - S["X"][k1["point"][o1[same]]], axis=1)
+    assert same.mean() > 0.97 and np.median(err) < 0.3
+
+
+def test_fuse_search_against_brute_force():
+    import test_area_emu as te
+    cam = orc.make_camera(synth.camera("lafida", F))
+    kx, ky, ko = te._keypoints(F, 1500, 34)
+    kd = synth.descriptors(len(kx), 35)
+    pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=36)
+    kf = dict(x=kx, y=ky, octave=ko, angle=np.zeros(len(kx), np.float32), desc=kd, mp=np.full(len(kx), -1, np.int32), R=pr["pose15"][:9],
+              t=pr["pose15"][9:12], Ow=pr["pose15"][12:], node_id=np.zeros(0, np.int32), node_off=np.zeros(1, np.int32), node_feat=np.zeros(0, np.int32),
+              median_depth=1.0, rays=np.zeros((len(kx), 3), np.float32))
+    K, _keep = orc.make_keyframe(cam, kf)
+    sf = pr["scale_factors"]; inv = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    skip = np.zeros(len(pr["pos"]), np.uint8)
+    th = 3.0
+    bi, bd = orc.fuse_search(cam, K, skip, pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], th, sf, inv)
+    assert (bi >= 0).sum() > 300
+    # brute force over ALL key points (no grid): same gates, float64 geometry
+    R = pr["pose15"][:9].reshape(3, 3).astype(np.float64); t = pr["pose15"][9:12].astype(np.float64); Ow = pr["pose15"][12:].astype(np.float64)
+    Pc = pr["pos"].astype(np.float64) @ R.T + t
+    face, up, vp = synth.rays_to_cubemap(F, Pc)
+    PO = pr["pos"] - Ow; dist = np.linalg.norm(PO, axis=1)
+    ok = (face >= 0) & (dist >= 0.8 * pr["min_dist"]) & (dist <= 1.2 * pr["max_dist"]) & ((PO * pr["normal"]).sum(1) >= 0.5 * dist)
+    lvl = np.clip(np.ceil(np.log(pr["max_dist"] / dist) / np.log(1.2)), 0, 7).astype(int)
+    bad = 0
+    for i in np.flatnonzero(ok)[::5]:
+        r = th * sf[lvl[i]]
+        near = (np.abs(kx - up[i]) < r) & (np.abs(ky - vp[i]) < r) & (ko >= lvl[i] - 1) & (ko <= lvl[i])
+        e2 = (kx - up[i]) ** 2 + (ky - vp[i]) ** 2
+        near &= e2 * inv[ko] <= 5.99
+        # windows that unfold over a face edge can reach further than the canvas box; restrict the check to interior windows
+        fx, fy = up[i] % F, vp[i] % F
+        if min(fx, fy, F - fx, F - fy) < r + 1:
+            continue
+        cand = np.flatnonzero(near)
+        d = np.array([np.unpackbits(pr["desc"][i] ^ kd[k]).sum() for k in cand]) if len(cand) else np.array([256])
+        want = int(d.min()) if len(cand) else 256
+        got = bd[i]
+        bad += int((want if want <= 50 else 256) != got)
+    assert bad <= 2, bad
