@@ -5,7 +5,7 @@
 #include <vector>
 
 namespace {
-// cv::gemm semantics used by ComputeE12 (LocalMapping.cpp:469-482) and the epipole (ORBMatcher.cpp:976-982); see oracle/orc_tri.cpp
+// cv::gemm semantics used by ComputeE12 (LocalMapping.cpp:469-482) and the epipole (ORBMatcher.cpp:976-982); cv::gemm semantics as listed in DESIGN.md section 2
 inline float tri_h_small(const float* a, const float* b, int bs) {
   float t = a[0] * b[0];
   t = t + a[1] * b[bs];

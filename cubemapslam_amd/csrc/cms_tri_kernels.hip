@@ -10,7 +10,10 @@
 //   k_fuse_project + k_fuse_scan   search half of ORBMatcher::Fuse(pKF, vpMapPoints, th) (src/ORBMatcher.cpp:1127-1226): projection and
 //                             visibility tests per map point, window query (cms_area_kernels.hip, no level filter), then the
 //                             level / reprojection-gated Hamming minimum.  The map surgery (Replace / AddObservation) stays on the host.
-// Float arithmetic follows the cv::Mat / cv::Matx semantics spelled out in oracle/orc_tri.cpp, operation for operation.
+// Float arithmetic follows cv::Mat / cv::Matx, operation for operation (DESIGN.md section 2 lists the assumptions): 3x3 products
+// without transposed operands = cv::gemm's small path (float products summed left to right, + C through double); Mat::dot and
+// cv::norm accumulate in double, Matx::dot in float; `a*row + b*row` = cv::addWeighted in float; cv::SVD = one-sided Jacobi with
+// double dot products and float rotations.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

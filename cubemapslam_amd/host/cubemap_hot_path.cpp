@@ -125,6 +125,117 @@ int ORBMatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
   return dist;
 }
 
+namespace {
+struct KfPack {                                            // flat buffers behind one cms_keyframe
+  std::vector<cms_keypoint> kps; std::vector<uint8_t> desc; std::vector<float> rays; std::vector<int> mp, node_id, node_off, node_feat;
+};
+void pose15_from_Tcw(const cv::Mat& Tcw, float* R, float* t, float* Ow) {
+  // KeyFrame::SetPose (KeyFrame.cpp): Rcw, tcw, Ow = -Rcw.t()*tcw (transposed operand: double accumulation, one rounding)
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = Tcw.at<float>(r, c); t[r] = Tcw.at<float>(r, 3); }
+  for (int r = 0; r < 3; ++r) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (double)Tcw.at<float>(k, r) * (double)Tcw.at<float>(k, 3);
+    Ow[r] = (float)(-1.0 * s);
+  }
+}
+cms_keyframe pack_keyframe(const KeyFrameView& kf, KfPack& b) {
+  const int N = (int)kf.mvKeys.size();
+  b.kps.resize(N + 1); b.desc.resize(32 * (size_t)N + 32); b.rays.resize(3 * (size_t)N + 3); b.mp.resize(N + 1);
+  for (int i = 0; i < N; ++i) {
+    const cv::KeyPoint& k = kf.mvKeys[i];
+    b.kps[i].x = k.pt.x; b.kps[i].y = k.pt.y; b.kps[i].size = k.size; b.kps[i].angle = k.angle; b.kps[i].response = k.response; b.kps[i].octave = k.octave;
+    std::memcpy(&b.desc[32 * (size_t)i], kf.mDescriptors.ptr<uint8_t>(i), 32);
+    for (int c = 0; c < 3; ++c) b.rays[3 * (size_t)i + c] = kf.mvKeyRays[i].v[c];
+    b.mp[i] = kf.mvpMapPoints[i] >= 0 ? 1 : -1;
+  }
+  b.node_off.assign(1, 0);
+  for (const auto& e : kf.mFeatVec) {
+    b.node_id.push_back((int)e.first);
+    for (unsigned f : e.second) b.node_feat.push_back((int)f);
+    b.node_off.push_back((int)b.node_feat.size());
+  }
+  if (b.node_feat.empty()) b.node_feat.push_back(0);
+  if (b.node_id.empty()) b.node_id.push_back(0);
+  cms_keyframe k{};
+  k.n = N; k.kps = b.kps.data(); k.desc = b.desc.data(); k.rays = b.rays.data(); k.mp = b.mp.data();
+  pose15_from_Tcw(kf.Tcw, k.Rcw, k.tcw, k.Ow);
+  k.nnodes = (int)kf.mFeatVec.size(); k.node_id = b.node_id.data(); k.node_off = b.node_off.data(); k.node_feat = b.node_feat.data();
+  k.median_depth = kf.medianDepth;
+  return k;
+}
+}  // namespace
+
+std::vector<NewMapPoint> LocalMapping::CreateNewMapPoints(const KeyFrameView& cur, const std::vector<const KeyFrameView*>& neigh) {
+  std::vector<NewMapPoint> out;
+  if (neigh.empty() || cur.mvKeys.empty()) return out;
+  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+  KfPack pc;
+  std::vector<KfPack> pn(neigh.size());
+  const cms_keyframe kc = pack_keyframe(cur, pc);
+  std::vector<cms_keyframe> kn(neigh.size());
+  for (size_t i = 0; i < neigh.size(); ++i) kn[i] = pack_keyframe(*neigh[i], pn[i]);
+  const int off[2] = {0, (int)neigh.size()};
+  const int cap = (int)cur.mvKeys.size();
+  std::vector<int> on(cap), o1(cap), o2(cap);
+  std::vector<float> ox(3 * (size_t)cap);
+  int n_new = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (cms_create_new_map_points(ctx, 1, &kc, off, kn.data(), 0 /* ORBMatcher matcher(0.6,false) */, cap, &n_new, on.data(), o1.data(), o2.data(),
+                                  ox.data()) != CMS_OK)
+      throw std::runtime_error(std::string("cms_create_new_map_points: ") + cms_last_error());
+  }
+  out.resize(n_new);
+  for (int k = 0; k < n_new; ++k) {
+    out[k].neighbour = on[k]; out[k].idx1 = o1[k]; out[k].idx2 = o2[k];
+    for (int c = 0; c < 3; ++c) out[k].x3D.v[c] = ox[3 * (size_t)k + c];
+  }
+  return out;
+}
+
+int ORBMatcher::Fuse(KeyFrameView& kf, const std::vector<MapPointView>& mps, const std::vector<uint8_t>& skip, float th, std::vector<int>& fused) {
+  const int N = (int)kf.mvKeys.size(), M = (int)mps.size();
+  fused.assign(M, -1);
+  if (M == 0 || N == 0) return 0;
+  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+  float pose15[15];
+  pose15_from_Tcw(kf.Tcw, pose15, pose15 + 9, pose15 + 12);
+  std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M);
+  std::vector<uint8_t> desc(32 * (size_t)M);
+  for (int i = 0; i < M; ++i) {
+    for (int k = 0; k < 3; ++k) { pos[3 * (size_t)i + k] = mps[i].mWorldPos.at<float>(k, 0); nrm[3 * (size_t)i + k] = mps[i].mNormalVector.at<float>(k, 0); }
+    dmin[i] = mps[i].mfMinDistance; dmax[i] = mps[i].mfMaxDistance;
+    std::memcpy(&desc[32 * (size_t)i], mps[i].mDescriptor.ptr<uint8_t>(0), 32);
+  }
+  std::vector<cms_keypoint> kps(N);
+  std::vector<uint8_t> tdesc(32 * (size_t)N);
+  for (int j = 0; j < N; ++j) {
+    const cv::KeyPoint& k = kf.mvKeys[j];
+    kps[j].x = k.pt.x; kps[j].y = k.pt.y; kps[j].size = k.size; kps[j].angle = k.angle; kps[j].response = k.response; kps[j].octave = k.octave;
+    std::memcpy(&tdesc[32 * (size_t)j], kf.mDescriptors.ptr<uint8_t>(j), 32);
+  }
+  std::vector<int> bi(M), bd(M);
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    int rc = cms_area_set_keypoints(ctx, 0, N, kps.data());
+    if (rc == CMS_OK) rc = cms_area_set_descriptors(ctx, 0, N, tdesc.data());
+    if (rc == CMS_OK) rc = cms_area_grid(ctx, 1);
+    if (rc == CMS_OK) rc = cms_fuse_search(ctx, 0, pose15, M, skip.empty() ? nullptr : skip.data(), pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(),
+                                           th, bi.data(), bd.data());
+    if (rc != CMS_OK) throw std::runtime_error(std::string("cms_fuse_search: ") + cms_last_error());
+  }
+  // ORBMatcher.cpp:1216-1241 in list order.  A key point that already holds a point means Replace (which of the two survives is the
+  // caller's Observations() comparison); a free one receives the observation -- and then holds a point for the rest of the list.
+  int nFused = 0;
+  for (int i = 0; i < M; ++i) {
+    if (bi[i] < 0) continue;
+    fused[i] = bi[i];
+    if (kf.mvpMapPoints[bi[i]] < 0) kf.mvpMapPoints[bi[i]] = mps[i].mnId;
+    ++nFused;
+  }
+  return nFused;
+}
+
 int Tracking::SearchLocalPoints(FrameView& F, std::vector<MapPointView>& mps, float th, float nnratio, float viewingCosLimit) {
   const int N = (int)F.mvKeys.size(), M = (int)mps.size();
   if (M == 0) return 0;

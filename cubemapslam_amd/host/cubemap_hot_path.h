@@ -99,6 +99,9 @@ struct FrameView {
   cv::Mat mTcw;                         // 4x4 CV_32F (Tracking::SearchLocalPoints only)
 };
 
+struct KeyFrameView;
+struct MapPointView;
+
 class ORBMatcher {
  public:
   ORBMatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
@@ -107,6 +110,9 @@ class ORBMatcher {
   // rotation-histogram consistency.  Distances / arg-min run on the GPU (cms_hamming_best2); the greedy acceptance is
   // replayed on the host in the reference's order.  Returns the number of matches, fills CurrentFrame.mvpMapPoints.
   int SearchByProjection(FrameView& CurrentFrame, const FrameView& LastFrame, float th, bool bMono);
+  // ORBMatcher.cpp:1127-1226: search on the device (cms_fuse_search), then the reference's Replace / AddObservation decisions in list
+  // order: fused[i] = key point map point i is fused with (or -1); returns nFused.  mvpMapPoints of pKF is updated for additions.
+  int Fuse(KeyFrameView& pKF, const std::vector<MapPointView>& vpMapPoints, const std::vector<uint8_t>& skip, float th, std::vector<int>& fused);
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 12;
 
  protected:
@@ -157,6 +163,28 @@ struct PoseFrame {
   std::vector<cv::Vec3f> mvMapPointPos;         // pMP->GetWorldPos() where mvbHasMapPoint[i]
   std::vector<bool> mvbOutlier;                 // out
   std::vector<float> mvInvLevelSigma2;
+};
+
+// What LocalMapping::CreateNewMapPoints, ORBMatcher::SearchForTriangulation and ORBMatcher::Fuse read of a KeyFrame
+// (include/KeyFrame.h): key points, descriptors, key rays, the map-point slot per key point (>= 0 = id), pose, mFeatVec
+// (DBoW2::FeatureVector: node id -> feature indices, std::map order) and ComputeSceneMedianDepth(2).
+struct KeyFrameView {
+  long mnId = -1;
+  std::vector<cv::KeyPoint> mvKeys;
+  cv::Mat mDescriptors;                                  // N x 32 CV_8U
+  std::vector<cv::Vec3f> mvKeyRays;
+  std::vector<long> mvpMapPoints;                        // -1 = none
+  cv::Mat Tcw;                                           // 4x4 CV_32F
+  std::vector<std::pair<unsigned, std::vector<unsigned>>> mFeatVec;   // ascending node id
+  float medianDepth = 1.0f;                              // ComputeSceneMedianDepth(2)
+};
+struct NewMapPoint { int neighbour; int idx1, idx2; cv::Vec3f x3D; };
+
+class LocalMapping {
+ public:
+  // LocalMapping.cpp:209-386 with the covisible neighbours already collected (GetBestCovisibilityKeyFrames(20)): returns the points
+  // the reference would create, in creation order; the MapPoint bookkeeping (:359-381) stays with the caller.
+  static std::vector<NewMapPoint> CreateNewMapPoints(const KeyFrameView& current, const std::vector<const KeyFrameView*>& vpNeighKFs);
 };
 
 class Optimizer {

@@ -101,6 +101,44 @@ extern "C" int hm_search_local_points(int ncur, const cms_keypoint* cur_k, const
     }
     return n;)
 }
+// LocalMapping::CreateNewMapPoints through the mirror: key frame 0 is the current one, 1..nkf-1 its neighbours.  Flat inputs:
+// feat_off[nkf+1]; per feature kps/desc/rays/mp; Tcw nkf x 16; FeatureVector per key frame as node_off2[nkf+1] into (node_id, node_cnt)
+// and the features of the nodes concatenated in node_feat; median_depth[nkf].  Outputs up to cap records.
+extern "C" int hm_create_new_map_points(int nkf, const int* feat_off, const cms_keypoint* kps, const uint8_t* desc, const float* rays, const long* mp,
+                                        float* Tcw, const int* node_off2, const int* node_id, const int* node_cnt, const int* node_feat,
+                                        const float* median_depth, int cap, int* out_neigh, int* out_idx1, int* out_idx2, float* out_x3d) {
+  HM_TRY(
+    std::vector<KeyFrameView> kfs(nkf);
+    size_t nf_cursor = 0;
+    for (int k = 0; k < nkf; ++k) {
+      KeyFrameView& v = kfs[k];
+      const int f0 = feat_off[k], n = feat_off[k + 1] - f0;
+      v.mnId = k; v.mvKeys.resize(n); v.mvKeyRays.resize(n); v.mvpMapPoints.assign(mp + f0, mp + f0 + n);
+      v.mDescriptors.create(n > 0 ? n : 1, 32, cv::CV_8U);
+      for (int i = 0; i < n; ++i) {
+        const cms_keypoint& s = kps[f0 + i];
+        v.mvKeys[i].pt = cv::Point2f(s.x, s.y); v.mvKeys[i].angle = s.angle; v.mvKeys[i].octave = s.octave;
+        std::memcpy(v.mDescriptors.ptr<uint8_t>(i), desc + 32 * (size_t)(f0 + i), 32);
+        for (int c = 0; c < 3; ++c) v.mvKeyRays[i].v[c] = rays[3 * (size_t)(f0 + i) + c];
+      }
+      v.Tcw = cv::Mat(4, 4, cv::CV_32F, Tcw + 16 * (size_t)k, 16);
+      for (int e = node_off2[k]; e < node_off2[k + 1]; ++e) {
+        std::vector<unsigned> fl(node_feat + nf_cursor, node_feat + nf_cursor + node_cnt[e]);
+        nf_cursor += (size_t)node_cnt[e];
+        v.mFeatVec.emplace_back((unsigned)node_id[e], std::move(fl));
+      }
+      v.medianDepth = median_depth[k];
+    }
+    std::vector<const KeyFrameView*> neigh;
+    for (int k = 1; k < nkf; ++k) neigh.push_back(&kfs[k]);
+    const std::vector<NewMapPoint> pts = LocalMapping::CreateNewMapPoints(kfs[0], neigh);
+    const int n = (int)pts.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+      out_neigh[i] = pts[i].neighbour; out_idx1[i] = pts[i].idx1; out_idx2[i] = pts[i].idx2;
+      for (int c = 0; c < 3; ++c) out_x3d[3 * (size_t)i + c] = pts[i].x3D.v[c];
+    }
+    return n;)
+}
 // local BA through the Optimizer mirror.  Tcw: K x 16 float (row major 4x4), Xw: P x 3 float, observations flat.
 extern "C" int hm_local_ba(int K, float* Tcw, const long* kf_id, const uint8_t* kf_fixed, const float* inv_sigma2, int nlevels, int P,
                            float* Xw, int nobs, const int* obs_kf, const int* obs_mp, const cms_keypoint* obs_kp, const float* obs_ray,

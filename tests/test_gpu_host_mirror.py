@@ -255,3 +255,49 @@ def test_mirror_search_local_points():
     assert np.array_equal(lvl, fr["level"]) and np.array_equal(vc, fr["view_cos"])
     want_mp = np.where(want_kp >= 0, np.where(want_kp == 10**6, 10**6, want_kp + 5000), -1)
     assert np.array_equal(cur_mp, want_mp)
+
+
+def test_mirror_create_new_map_points():
+    """LocalMapping::CreateNewMapPoints through the C++ mirror (KeyFrameView with a std::map-ordered FeatureVector) == oracle"""
+    L = _host()
+    L.hm_create_new_map_points.argtypes = [C.c_int] + [C.c_void_p] * 11 + [C.c_int] + [C.c_void_p] * 4
+    F = 450
+    camd = synth.camera("lafida", F)
+    cam = api.make_camera(camd)
+    assert L.hm_set_camera(C.byref(cam)) == 0
+    ocam = orc.make_camera(camd)
+    W = 3 * F
+    img = np.ascontiguousarray(synth.texture(W, W, 90)); msk = np.full((W, W), 255, np.uint8)
+    k0 = np.zeros(3000, KP); d0 = np.zeros((3000, 32), np.uint8)
+    assert L.hm_extract(2000, 1.2, 8, 20, 7, _p(img), W, _p(msk), W, _p(k0), _p(d0), 3000) > 0, L.hm_last_error()   # sizes the shared context
+    S = synth.keyframe_set(F, n_kf=4, n_pts=2200, seed=91)
+    kfs = S["kfs"]
+    # the mirror derives Ow from Tcw like KeyFrame::SetPose does: feed the oracle the same value
+    for k in kfs:
+        k["Ow"] = (-(k["R"].astype(np.float64).T @ k["t"].astype(np.float64))).astype(np.float32)
+    oks = [orc.make_keyframe(ocam, k) for k in kfs]
+    cur_mp = kfs[0]["mp"].copy()
+    wn, w1, w2, wx = orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], S["scale_factors"], S["level_sigma2"], cur_mp)
+    nk = len(kfs)
+    feat_off = np.concatenate([[0], np.cumsum([len(k["x"]) for k in kfs])]).astype(np.int32)
+    kps = np.zeros(feat_off[-1], KP)
+    for i, k in enumerate(kfs):
+        sl = slice(feat_off[i], feat_off[i + 1])
+        kps["x"][sl] = k["x"]; kps["y"][sl] = k["y"]; kps["octave"][sl] = k["octave"]; kps["angle"][sl] = k["angle"]
+    desc = np.concatenate([k["desc"] for k in kfs]); rays = np.concatenate([k["rays"] for k in kfs]).astype(np.float32)
+    mp = np.concatenate([k["mp"] for k in kfs]).astype(np.int64)
+    Tcw = np.zeros((nk, 4, 4), np.float32)
+    for i, k in enumerate(kfs):
+        Tcw[i, :3, :3] = k["R"]; Tcw[i, :3, 3] = k["t"]; Tcw[i, 3, 3] = 1
+    node_off2 = np.concatenate([[0], np.cumsum([len(k["node_id"]) for k in kfs])]).astype(np.int32)
+    node_id = np.concatenate([k["node_id"] for k in kfs]).astype(np.int32)
+    node_cnt = np.concatenate([np.diff(k["node_off"]) for k in kfs]).astype(np.int32)
+    node_feat = np.concatenate([k["node_feat"] for k in kfs]).astype(np.int32)
+    med = np.array([k["median_depth"] for k in kfs], np.float32)
+    cap = len(kfs[0]["x"])
+    on = np.zeros(cap, np.int32); o1 = np.zeros(cap, np.int32); o2 = np.zeros(cap, np.int32); ox = np.zeros((cap, 3), np.float32)
+    n = L.hm_create_new_map_points(nk, _p(feat_off), _p(kps), _p(desc), _p(rays), _p(mp), _p(Tcw), _p(node_off2), _p(node_id), _p(node_cnt), _p(node_feat),
+                                   _p(med), cap, _p(on), _p(o1), _p(o2), _p(ox))
+    assert n == len(wn) and n > 200, (n, len(wn), L.hm_last_error())
+    assert np.array_equal(on[:n], wn) and np.array_equal(o1[:n], w1) and np.array_equal(o2[:n], w2)
+    assert np.array_equal(ox[:n].view(np.uint32), wx.view(np.uint32))
