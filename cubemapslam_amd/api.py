@@ -105,6 +105,12 @@ def lib():
         L.cms_is_in_frustum_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float] + [C.c_void_p] * 8
         L.cms_search_local_points_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 3
         L.cms_create_new_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.cms_kfstore_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.cms_kfstore_destroy.argtypes = [C.c_void_p]
+        L.cms_kfstore_destroy.restype = None
+        L.cms_kfstore_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.cms_kfstore_update.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.cms_kfstore_create_new_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.cms_fuse_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
         L.cms_pose_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cms_pose_destroy.argtypes = [C.c_void_p]
@@ -393,6 +399,45 @@ def create_new_map_points(ctx, jobs, check_orientation=False, cap=None):
     _chk(lib().cms_create_new_map_points(ctx.h, nj, C.addressof(cur), _p(off), C.addressof(neigh), int(check_orientation), cap, _p(n_new), _p(on), _p(o1),
                                          _p(o2), _p(ox)), "cms_create_new_map_points")
     return [(on[j, :n_new[j]].copy(), o1[j, :n_new[j]].copy(), o2[j, :n_new[j]].copy(), ox[j, :n_new[j]].copy()) for j in range(nj)]
+
+
+class KeyframeStore:
+    """cms_kfstore: key frames resident on the device in slots"""
+
+    def __init__(self, ctx, max_keyframes, max_features=2048, max_nodes=2048):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _chk(lib().cms_kfstore_create(C.byref(self.h), ctx.h, max_keyframes, max_features, max_nodes), "cms_kfstore_create")
+
+    def close(self):
+        if self.h:
+            lib().cms_kfstore_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def put(self, slot, K):
+        _chk(lib().cms_kfstore_put(self.h, slot, C.byref(K)), "cms_kfstore_put")
+
+    def update(self, slot, R=None, t=None, Ow=None, median_depth=None, mp=None):
+        f = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        a = [f(R, np.float32), f(t, np.float32), f(Ow, np.float32), None if median_depth is None else np.array([median_depth], np.float32), f(mp, np.int32)]
+        _chk(lib().cms_kfstore_update(self.h, slot, *[_p(v) for v in a]), "cms_kfstore_update")
+
+    def create_new_map_points(self, jobs, check_orientation=False, cap=2048):
+        """jobs: list of (current slot, [neighbour slots in covisibility order]) -> per job (neigh, idx1, idx2, x3d)"""
+        nj = len(jobs)
+        cur = np.array([j[0] for j in jobs], np.int32)
+        neigh = np.array([s for j in jobs for s in j[1]] + [0], np.int32)
+        off = np.concatenate([[0], np.cumsum([len(j[1]) for j in jobs])]).astype(np.int32)
+        n_new = np.zeros(max(nj, 1), np.int32)
+        on = np.zeros((max(nj, 1), cap), np.int32); o1 = np.zeros_like(on); o2 = np.zeros_like(on); ox = np.zeros((max(nj, 1), cap, 3), np.float32)
+        _chk(lib().cms_kfstore_create_new_map_points(self.h, nj, _p(cur), _p(off), _p(neigh), int(check_orientation), cap, _p(n_new), _p(on), _p(o1), _p(o2),
+                                                     _p(ox)), "cms_kfstore_create_new_map_points")
+        return [(on[j, :n_new[j]].copy(), o1[j, :n_new[j]].copy(), o2[j, :n_new[j]].copy(), ox[j, :n_new[j]].copy()) for j in range(nj)]
 
 
 def fuse_search(ctx, b, pose15, skip, pos, normal, min_dist, max_dist, desc, th):

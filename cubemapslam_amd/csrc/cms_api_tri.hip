@@ -1,6 +1,8 @@
 // cms_api_tri.hip -- host side of LocalMapping::CreateNewMapPoints and of the search half of ORBMatcher::Fuse, included by
 // cms_lib.hip after cms_api_track.hip.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -28,6 +30,116 @@ void tri_h_e12(const float* R1w, const float* t1w, const float* R2w, const float
 }
 }  // namespace
 
+namespace {
+struct TriDev {                                           // device views of the key-frame data (flattened per call, or a resident store)
+  const CmsTriKF* kf; const CmsKeyPoint* kp; const uint4* desc; const float* rays; const int* mp; const int* feat_node;
+  const int* node_id; const int* node_off; const int* node_feat;
+};
+inline size_t tri_al(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t tri_work_bytes(int njobs, int nneigh, int max_n1, int cap) {
+  const size_t nb = (size_t)njobs * (size_t)cap;
+  return tri_al((size_t)nneigh * sizeof(CmsTriPair) + 16) + tri_al((size_t)njobs * sizeof(CmsTriJob) + 16) + tri_al((size_t)nneigh * 4 + 16) +
+         tri_al((size_t)njobs * 4 + 16) + 3 * tri_al(nb * 4 + 16) + tri_al(nb * 12 + 16) + tri_al((size_t)nneigh * (size_t)max_n1 * sizeof(CmsTriCand) + 16);
+}
+int tri_check_keyframe(const cms_keyframe& k, const char* who) {
+  if (k.n < 0 || k.n > CMS_TRI_MAXF || k.nnodes < 0 || (k.n > 0 && (!k.kps || !k.desc || !k.rays || !k.mp)) ||
+      (k.nnodes > 0 && (!k.node_id || !k.node_off || !k.node_feat)))
+    return cms_fail(CMS_ERR_ARG, who);
+  for (int e = 0; e < k.nnodes; ++e) {
+    if (e > 0 && k.node_id[e] <= k.node_id[e - 1]) return cms_fail(CMS_ERR_ARG, "FeatureVector node ids must ascend");
+    if (k.node_off[e + 1] < k.node_off[e]) return cms_fail(CMS_ERR_ARG, "FeatureVector offsets must ascend");
+    for (int q = k.node_off[e]; q < k.node_off[e + 1]; ++q)
+      if (k.node_feat[q] < 0 || k.node_feat[q] >= k.n) return cms_fail(CMS_ERR_ARG, "FeatureVector index out of range");
+  }
+  return CMS_OK;
+}
+void tri_feat_node(const cms_keyframe& k, int* feat_node /* k.n entries */) {
+  for (int i = 0; i < k.n; ++i) feat_node[i] = -1;
+  for (int e = 0; e < k.nnodes; ++e)
+    for (int q = k.node_off[e]; q < k.node_off[e + 1]; ++q) feat_node[k.node_feat[q]] = e;
+}
+
+// pairs (baseline test, essential matrix, epipole: host, the reference's float arithmetic), launch, fetch.  hkf / hmedian: host copies of
+// the key frames' CmsTriKF records and median depths, indexed like the device array; cur_idx / neigh_idx index them.
+int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hmedian, int njobs, const int* cur_idx, const int* neigh_off,
+            const int* neigh_idx, int check_orientation, int cap, uint8_t* work, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2, float* out_x3d) {
+  const int nneigh = neigh_off[njobs];
+  std::vector<CmsTriPair> pairs((size_t)nneigh + 1);
+  std::vector<CmsTriJob> jobs((size_t)njobs);
+  std::vector<int> pair_job((size_t)nneigh + 1, 0);
+  const int F = c->g.F;
+  int max_n1 = 1, max_pairs = 0;
+  for (int j = 0; j < njobs; ++j) {
+    jobs[(size_t)j].kf1 = cur_idx[j]; jobs[(size_t)j].pair0 = neigh_off[j]; jobs[(size_t)j].npairs = neigh_off[j + 1] - neigh_off[j];
+    if (jobs[(size_t)j].npairs < 0) return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: neigh_off must ascend");
+    const CmsTriKF& k1 = hkf[cur_idx[j]];
+    max_n1 = std::max(max_n1, k1.n); max_pairs = std::max(max_pairs, jobs[(size_t)j].npairs);
+    for (int q = neigh_off[j]; q < neigh_off[j + 1]; ++q) {
+      const CmsTriKF& k2 = hkf[neigh_idx[q]];
+      CmsTriPair& pr = pairs[(size_t)q];
+      pair_job[(size_t)q] = j;
+      pr.kf2 = neigh_idx[q];
+      double s = 0;
+      for (int k = 0; k < 3; ++k) { const float v = k2.Ow[k] - k1.Ow[k]; s += (double)v * (double)v; }
+      const float baseline = (float)std::sqrt(s);
+      const float ratioBaselineDepth = baseline / hmedian[neigh_idx[q]];
+      pr.skip = ratioBaselineDepth < 0.01;                             // LocalMapping.cpp:243-247
+      tri_h_e12(k1.Rcw, k1.tcw, k2.Rcw, k2.tcw, pr.E12);
+      float C2[3];
+      for (int r = 0; r < 3; ++r) C2[r] = (float)((double)tri_h_small(k2.Rcw + 3 * r, k1.Ow, 1) * 1.0 + (double)k2.tcw[r] * 1.0);
+      track_rays_to_cubemap(F, C2[0], C2[1], C2[2], pr.ex, pr.ey);
+    }
+  }
+  const size_t nb = (size_t)njobs * (size_t)cap;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += tri_al(bytes + 16); return at; };
+  const size_t o_pair = take((size_t)nneigh * sizeof(CmsTriPair)), o_job = take((size_t)njobs * sizeof(CmsTriJob)), o_pjob = take((size_t)nneigh * 4),
+               o_nnew = take((size_t)njobs * 4), o_on = take(nb * 4), o_o1 = take(nb * 4), o_o2 = take(nb * 4), o_ox = take(nb * 12),
+               o_cand = take((size_t)nneigh * (size_t)max_n1 * sizeof(CmsTriCand));
+  (void)o_cand;
+  hipStream_t s = c->stream;
+  uint8_t* p = work;
+  if (nneigh > 0) {
+    HIPCHK(hipMemcpyAsync(p + o_pair, pairs.data(), (size_t)nneigh * sizeof(CmsTriPair), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_pjob, pair_job.data(), (size_t)nneigh * 4, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(hipMemcpyAsync(p + o_job, jobs.data(), (size_t)njobs * sizeof(CmsTriJob), hipMemcpyHostToDevice, s));
+  CmsTriArgs a;
+  a.kf = dev.kf; a.pair = (const CmsTriPair*)(p + o_pair); a.job = (const CmsTriJob*)(p + o_job);
+  a.kp = dev.kp; a.desc = dev.desc; a.rays = dev.rays; a.mp = dev.mp; a.feat_node = dev.feat_node;
+  a.node_id = dev.node_id; a.node_off = dev.node_off; a.node_feat = dev.node_feat;
+  a.F = F;
+  {                                                                    // CamModelGeneral::SetCosFovTh (CamModelGeneral.h:224-229), float
+    const float fov = (float)c->cam.fov_deg;
+    const float pif = 3.1415926535897932384626f;
+    a.cos_fov = std::cos(fov / 2 * (pif / 180));
+  }
+  a.ratio_factor = 1.5f * c->scale[1];                                // 1.5f * mpCurrentKeyFrame->mfScaleFactor
+  a.check_orientation = check_orientation;
+  for (int l = 0; l < 16; ++l) { a.sf[l] = l < c->g.nlevels ? c->scale[l] : 1.0f; a.sigma2[l] = l < c->g.nlevels ? c->sigma2[l] : 1.0f; }
+  a.cap = cap;
+  a.n_new = (int*)(p + o_nnew); a.out_neigh = (int*)(p + o_on); a.out_idx1 = (int*)(p + o_o1); a.out_idx2 = (int*)(p + o_o2); a.out_x3d = (float*)(p + o_ox);
+  if (check_orientation || max_pairs > 64 || nneigh == 0 || getenv("CMS_TRI_SEQUENTIAL")) {
+    hipLaunchKernelGGL(k_create_new_map_points, dim3(njobs), dim3(512), 0, s, a);      // neighbour after neighbour (the rotation histogram of a
+  } else {                                                                            // neighbour depends on which features are still free)
+    hipLaunchKernelGGL(k_tri_candidates, dim3((max_n1 + 255) / 256, nneigh), dim3(256), 0, s, a, (const int*)(p + o_pjob), (CmsTriCand*)(p + o_cand), max_n1);
+    hipLaunchKernelGGL(k_tri_resolve, dim3(njobs), dim3(1024), 0, s, a, (const CmsTriCand*)(p + o_cand), max_n1);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(n_new, p + o_nnew, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
+  if (cap > 0) {
+    HIPCHK(hipMemcpyAsync(out_neigh, p + o_on, nb * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_idx1, p + o_o1, nb * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_idx2, p + o_o2, nb * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_x3d, p + o_ox, nb * 12, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  for (int j = 0; j < njobs; ++j)
+    if (n_new[j] > cap) return cms_fail(CMS_ERR_OVERFLOW, "cms_create_new_map_points: more new points than cap_per_job (n_new holds the counts)");
+  return CMS_OK;
+}
+}  // namespace
+
 extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyframe* cur, const int* neigh_off, const cms_keyframe* neigh,
                                          int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
                                          float* out_x3d) {
@@ -41,19 +153,20 @@ extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyfra
   // ---- flatten: key frames = the njobs current ones, then all neighbours
   const int nkf = njobs + nneigh;
   std::vector<CmsTriKF> kfs((size_t)nkf);
-  std::vector<CmsTriPair> pairs((size_t)nneigh);
-  std::vector<CmsTriJob> jobs((size_t)njobs);
+  std::vector<float> median((size_t)nkf);
   size_t nf = 0, nn = 0, nno = 0, nnf = 0;
+  int max_n1 = 1;
   auto kf_at = [&](int i) -> const cms_keyframe& { return i < njobs ? cur[i] : neigh[i - njobs]; };
   for (int i = 0; i < nkf; ++i) {
     const cms_keyframe& k = kf_at(i);
-    if (k.n < 0 || k.n > CMS_TRI_MAXF || k.nnodes < 0 || (k.n > 0 && (!k.kps || !k.desc || !k.rays || !k.mp)) ||
-        (k.nnodes > 0 && (!k.node_id || !k.node_off || !k.node_feat)))
-      return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: bad key frame (at most 4096 features)");
+    const int rc = tri_check_keyframe(k, "cms_create_new_map_points: bad key frame (at most 4096 features)");
+    if (rc) return rc;
     CmsTriKF& d = kfs[(size_t)i];
     d.f0 = (int)nf; d.n = k.n; d.node0 = (int)nn; d.nnodes = k.nnodes; d.noff0 = (int)nno; d.nfeat0 = (int)nnf;
     std::memcpy(d.Rcw, k.Rcw, sizeof(d.Rcw)); std::memcpy(d.tcw, k.tcw, sizeof(d.tcw)); std::memcpy(d.Ow, k.Ow, sizeof(d.Ow));
+    median[(size_t)i] = k.median_depth;
     nf += (size_t)k.n; nn += (size_t)k.nnodes; nno += (size_t)k.nnodes + 1; nnf += k.nnodes > 0 ? (size_t)k.node_off[k.nnodes] : 0;
+    if (i < njobs) max_n1 = std::max(max_n1, k.n);
   }
   std::vector<CmsKeyPoint> kp(nf + 1);
   std::vector<uint8_t> desc(32 * nf + 32);
@@ -67,63 +180,29 @@ extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyfra
       std::memcpy(&desc[32 * (size_t)d.f0], k.desc, 32 * (size_t)k.n);
       std::memcpy(&rays[3 * (size_t)d.f0], k.rays, 12 * (size_t)k.n);
       std::memcpy(&mp[(size_t)d.f0], k.mp, 4 * (size_t)k.n);
+      tri_feat_node(k, &feat_node[(size_t)d.f0]);
     }
     if (k.nnodes > 0) {
       std::memcpy(&node_id[(size_t)d.node0], k.node_id, 4 * (size_t)k.nnodes);
       std::memcpy(&node_off[(size_t)d.noff0], k.node_off, 4 * ((size_t)k.nnodes + 1));
-      const int tot = k.node_off[k.nnodes];
-      std::memcpy(&node_feat[(size_t)d.nfeat0], k.node_feat, 4 * (size_t)tot);
-      for (int e = 0; e < k.nnodes; ++e) {
-        if (e > 0 && k.node_id[e] <= k.node_id[e - 1]) return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: FeatureVector node ids must ascend");
-        for (int q = k.node_off[e]; q < k.node_off[e + 1]; ++q) {
-          const int f = k.node_feat[q];
-          if (f < 0 || f >= k.n) return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: FeatureVector index out of range");
-          feat_node[(size_t)d.f0 + f] = e;
-        }
-      }
+      std::memcpy(&node_feat[(size_t)d.nfeat0], k.node_feat, 4 * (size_t)k.node_off[k.nnodes]);
     } else {
       node_off[(size_t)d.noff0] = 0;
     }
   }
-  // ---- per pair: baseline test, essential matrix, epipole (host, the reference's float arithmetic)
-  const int F = c->g.F;
-  for (int j = 0; j < njobs; ++j) {
-    jobs[(size_t)j].kf1 = j; jobs[(size_t)j].pair0 = neigh_off[j]; jobs[(size_t)j].npairs = neigh_off[j + 1] - neigh_off[j];
-    if (jobs[(size_t)j].npairs < 0) return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: neigh_off must ascend");
-    const cms_keyframe& k1 = cur[j];
-    for (int p = neigh_off[j]; p < neigh_off[j + 1]; ++p) {
-      const cms_keyframe& k2 = neigh[p];
-      CmsTriPair& pr = pairs[(size_t)p];
-      pr.kf2 = njobs + p;
-      double s = 0;
-      for (int k = 0; k < 3; ++k) { const float v = k2.Ow[k] - k1.Ow[k]; s += (double)v * (double)v; }
-      const float baseline = (float)std::sqrt(s);
-      const float ratioBaselineDepth = baseline / k2.median_depth;
-      pr.skip = ratioBaselineDepth < 0.01;                             // LocalMapping.cpp:243-247
-      tri_h_e12(k1.Rcw, k1.tcw, k2.Rcw, k2.tcw, pr.E12);
-      float C2[3];
-      for (int r = 0; r < 3; ++r) C2[r] = (float)((double)tri_h_small(k2.Rcw + 3 * r, k1.Ow, 1) * 1.0 + (double)k2.tcw[r] * 1.0);
-      track_rays_to_cubemap(F, C2[0], C2[1], C2[2], pr.ex, pr.ey);
-    }
-  }
-  // ---- device arena
   HIPCHK(hipSetDevice(c->device));
-  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = 0;
-  auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes + 16); return at; };
-  const size_t o_kf = take(kfs.size() * sizeof(CmsTriKF)), o_pair = take(pairs.size() * sizeof(CmsTriPair)), o_job = take(jobs.size() * sizeof(CmsTriJob)),
-               o_kp = take(kp.size() * sizeof(CmsKeyPoint)), o_desc = take(desc.size()), o_rays = take(rays.size() * 4), o_mp = take(mp.size() * 4),
-               o_fn = take(feat_node.size() * 4), o_nid = take(node_id.size() * 4), o_noff = take(node_off.size() * 4), o_nfeat = take(node_feat.size() * 4),
-               o_nnew = take((size_t)njobs * 4), o_on = take((size_t)njobs * cap_per_job * 4), o_o1 = take((size_t)njobs * cap_per_job * 4),
-               o_o2 = take((size_t)njobs * cap_per_job * 4), o_ox = take((size_t)njobs * cap_per_job * 12);
-  int rc = cms_scratch(c, o);
+  auto take = [&](size_t bytes) { const size_t at = o; o += tri_al(bytes + 16); return at; };
+  const size_t o_kf = take(kfs.size() * sizeof(CmsTriKF)), o_kp = take(kp.size() * sizeof(CmsKeyPoint)), o_desc = take(desc.size()), o_rays = take(rays.size() * 4),
+               o_mp = take(mp.size() * 4), o_fn = take(feat_node.size() * 4), o_nid = take(node_id.size() * 4), o_noff = take(node_off.size() * 4),
+               o_nfeat = take(node_feat.size() * 4);
+  const size_t o_work = o;
+  int rc = cms_scratch(c, o_work + tri_work_bytes(njobs, nneigh, max_n1, cap_per_job));
   if (rc) return rc;
   uint8_t* p = (uint8_t*)c->d_match;
   hipStream_t s = c->stream;
   auto up = [&](size_t at, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(p + at, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
   HIPCHK(up(o_kf, kfs.data(), kfs.size() * sizeof(CmsTriKF)));
-  HIPCHK(up(o_pair, pairs.data(), pairs.size() * sizeof(CmsTriPair)));
-  HIPCHK(up(o_job, jobs.data(), jobs.size() * sizeof(CmsTriJob)));
   HIPCHK(up(o_kp, kp.data(), kp.size() * sizeof(CmsKeyPoint)));
   HIPCHK(up(o_desc, desc.data(), desc.size()));
   HIPCHK(up(o_rays, rays.data(), rays.size() * 4));
@@ -132,35 +211,139 @@ extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyfra
   HIPCHK(up(o_nid, node_id.data(), node_id.size() * 4));
   HIPCHK(up(o_noff, node_off.data(), node_off.size() * 4));
   HIPCHK(up(o_nfeat, node_feat.data(), node_feat.size() * 4));
-  CmsTriArgs a;
-  a.kf = (const CmsTriKF*)(p + o_kf); a.pair = (const CmsTriPair*)(p + o_pair); a.job = (const CmsTriJob*)(p + o_job);
-  a.kp = (const CmsKeyPoint*)(p + o_kp); a.desc = (const uint4*)(p + o_desc); a.rays = (const float*)(p + o_rays); a.mp = (const int*)(p + o_mp);
-  a.feat_node = (const int*)(p + o_fn); a.node_id = (const int*)(p + o_nid); a.node_off = (const int*)(p + o_noff); a.node_feat = (const int*)(p + o_nfeat);
-  a.F = F;
-  {                                                                    // CamModelGeneral::SetCosFovTh (CamModelGeneral.h:224-229), float
-    const float fov = (float)c->cam.fov_deg;
-    const float pif = 3.1415926535897932384626f;
-    a.cos_fov = std::cos(fov / 2 * (pif / 180));
-  }
-  a.ratio_factor = 1.5f * c->scale[1];                                // 1.5f * mpCurrentKeyFrame->mfScaleFactor
-  a.check_orientation = check_orientation;
-  for (int l = 0; l < 16; ++l) { a.sf[l] = l < c->g.nlevels ? c->scale[l] : 1.0f; a.sigma2[l] = l < c->g.nlevels ? c->sigma2[l] : 1.0f; }
-  a.cap = cap_per_job;
-  a.n_new = (int*)(p + o_nnew); a.out_neigh = (int*)(p + o_on); a.out_idx1 = (int*)(p + o_o1); a.out_idx2 = (int*)(p + o_o2); a.out_x3d = (float*)(p + o_ox);
-  hipLaunchKernelGGL(k_create_new_map_points, dim3(njobs), dim3(512), 0, s, a);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(n_new, p + o_nnew, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
-  if (cap_per_job > 0) {
-    const size_t nb = (size_t)njobs * cap_per_job;
-    HIPCHK(hipMemcpyAsync(out_neigh, p + o_on, nb * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out_idx1, p + o_o1, nb * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out_idx2, p + o_o2, nb * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out_x3d, p + o_ox, nb * 12, hipMemcpyDeviceToHost, s));
-  }
-  HIPCHK(hipStreamSynchronize(s));
-  for (int j = 0; j < njobs; ++j)
-    if (n_new[j] > cap_per_job) return cms_fail(CMS_ERR_OVERFLOW, "cms_create_new_map_points: more new points than cap_per_job (n_new holds the counts)");
+  TriDev dev;
+  dev.kf = (const CmsTriKF*)(p + o_kf); dev.kp = (const CmsKeyPoint*)(p + o_kp); dev.desc = (const uint4*)(p + o_desc); dev.rays = (const float*)(p + o_rays);
+  dev.mp = (const int*)(p + o_mp); dev.feat_node = (const int*)(p + o_fn); dev.node_id = (const int*)(p + o_nid); dev.node_off = (const int*)(p + o_noff);
+  dev.node_feat = (const int*)(p + o_nfeat);
+  std::vector<int> cur_idx((size_t)njobs), neigh_idx((size_t)nneigh + 1);
+  for (int j = 0; j < njobs; ++j) cur_idx[(size_t)j] = j;
+  for (int q = 0; q < nneigh; ++q) neigh_idx[(size_t)q] = njobs + q;
+  return tri_run(c, dev, kfs.data(), median.data(), njobs, cur_idx.data(), neigh_off, neigh_idx.data(), check_orientation, cap_per_job, p + o_work, n_new,
+                 out_neigh, out_idx1, out_idx2, out_x3d);
+}
+
+// ---- resident key frames: the map's key frames live on the device in fixed-size slots (features, FeatureVector, pose); a call names
+// slots, so nothing but ~100 bytes per (current, neighbour) pair travels to the device per CreateNewMapPoints.
+struct cms_kfstore {
+  cms_ctx* c = nullptr;
+  int maxkf = 0, maxf = 0, maxn = 0;
+  CmsTriKF* d_kf = nullptr; CmsKeyPoint* d_kp = nullptr; uint8_t* d_desc = nullptr; float* d_rays = nullptr; int* d_mp = nullptr; int* d_fn = nullptr;
+  int* d_nid = nullptr; int* d_noff = nullptr; int* d_nfeat = nullptr;
+  uint8_t* d_work = nullptr; size_t work_bytes = 0;
+  std::vector<CmsTriKF> h_kf; std::vector<float> h_median; std::vector<uint8_t> used;
+};
+
+extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
+  if (!st) return;
+  if (st->c) (void)hipSetDevice(st->c->device);
+  void* bufs[] = {st->d_kf, st->d_kp, st->d_desc, st->d_rays, st->d_mp, st->d_fn, st->d_nid, st->d_noff, st->d_nfeat, st->d_work};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  delete st;
+}
+
+extern "C" int cms_kfstore_create(cms_kfstore** out, cms_ctx* c, int max_keyframes, int max_features, int max_nodes) {
+  if (!out || !c || max_keyframes < 1 || max_features < 1 || max_features > CMS_TRI_MAXF || max_nodes < 1)
+    return cms_fail(CMS_ERR_ARG, "cms_kfstore_create: bad argument (at most 4096 features per key frame)");
+  HIPCHK(hipSetDevice(c->device));
+  cms_kfstore* st = new cms_kfstore();
+  st->c = c; st->maxkf = max_keyframes; st->maxf = max_features; st->maxn = max_nodes;
+  const size_t K = (size_t)max_keyframes, Fq = (size_t)max_features, Nq = (size_t)max_nodes;
+#define KF_ALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { cms_kfstore_destroy(st); return cms_fail(CMS_ERR_HIP, "cms_kfstore_create: out of device memory"); } } while (0)
+  KF_ALLOC(st->d_kf, K * sizeof(CmsTriKF));
+  KF_ALLOC(st->d_kp, K * Fq * sizeof(CmsKeyPoint));
+  KF_ALLOC(st->d_desc, K * Fq * 32);
+  KF_ALLOC(st->d_rays, K * Fq * 12);
+  KF_ALLOC(st->d_mp, K * Fq * 4);
+  KF_ALLOC(st->d_fn, K * Fq * 4);
+  KF_ALLOC(st->d_nid, K * Nq * 4);
+  KF_ALLOC(st->d_noff, K * (Nq + 1) * 4);
+  KF_ALLOC(st->d_nfeat, K * Fq * 4);
+#undef KF_ALLOC
+  st->h_kf.assign(K, CmsTriKF{}); st->h_median.assign(K, 1.0f); st->used.assign(K, 0);
+  *out = st;
   return CMS_OK;
+}
+
+// upload / replace the key frame in `slot`
+extern "C" int cms_kfstore_put(cms_kfstore* st, int slot, const cms_keyframe* kf) {
+  if (!st || !kf || slot < 0 || slot >= st->maxkf) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put: bad argument");
+  int rc = tri_check_keyframe(*kf, "cms_kfstore_put: bad key frame");
+  if (rc) return rc;
+  if (kf->n > st->maxf || kf->nnodes > st->maxn) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put: key frame larger than the store's slots");
+  cms_ctx* c = st->c;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t f0 = (size_t)slot * st->maxf, n0 = (size_t)slot * st->maxn, o0 = (size_t)slot * (st->maxn + 1);
+  CmsTriKF d;
+  d.f0 = (int)f0; d.n = kf->n; d.node0 = (int)n0; d.nnodes = kf->nnodes; d.noff0 = (int)o0; d.nfeat0 = (int)f0;
+  std::memcpy(d.Rcw, kf->Rcw, sizeof(d.Rcw)); std::memcpy(d.tcw, kf->tcw, sizeof(d.tcw)); std::memcpy(d.Ow, kf->Ow, sizeof(d.Ow));
+  std::vector<int> fn((size_t)kf->n + 1, -1);
+  tri_feat_node(*kf, fn.data());
+  const int zero = 0;
+  if (kf->n > 0) {
+    HIPCHK(hipMemcpyAsync(st->d_kp + f0, kf->kps, (size_t)kf->n * sizeof(CmsKeyPoint), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->d_desc + 32 * f0, kf->desc, 32 * (size_t)kf->n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->d_rays + 3 * f0, kf->rays, 12 * (size_t)kf->n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->d_mp + f0, kf->mp, 4 * (size_t)kf->n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->d_fn + f0, fn.data(), 4 * (size_t)kf->n, hipMemcpyHostToDevice, s));
+  }
+  if (kf->nnodes > 0) {
+    HIPCHK(hipMemcpyAsync(st->d_nid + n0, kf->node_id, 4 * (size_t)kf->nnodes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->d_noff + o0, kf->node_off, 4 * ((size_t)kf->nnodes + 1), hipMemcpyHostToDevice, s));
+    if (kf->node_off[kf->nnodes] > 0) HIPCHK(hipMemcpyAsync(st->d_nfeat + f0, kf->node_feat, 4 * (size_t)kf->node_off[kf->nnodes], hipMemcpyHostToDevice, s));
+  } else {
+    HIPCHK(hipMemcpyAsync(st->d_noff + o0, &zero, 4, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(hipMemcpyAsync(st->d_kf + slot, &d, sizeof(d), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  st->h_kf[(size_t)slot] = d; st->h_median[(size_t)slot] = kf->median_depth; st->used[(size_t)slot] = 1;
+  return CMS_OK;
+}
+
+// what changes on a key frame between CreateNewMapPoints calls: pose (local BA), median depth, map-point slots (any may be NULL: unchanged)
+extern "C" int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, const float* tcw, const float* Ow, const float* median_depth, const int* mp) {
+  if (!st || slot < 0 || slot >= st->maxkf || !st->used[(size_t)slot]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_update: bad slot");
+  cms_ctx* c = st->c;
+  HIPCHK(hipSetDevice(c->device));
+  CmsTriKF& d = st->h_kf[(size_t)slot];
+  if (Rcw) std::memcpy(d.Rcw, Rcw, sizeof(d.Rcw));
+  if (tcw) std::memcpy(d.tcw, tcw, sizeof(d.tcw));
+  if (Ow) std::memcpy(d.Ow, Ow, sizeof(d.Ow));
+  if (median_depth) st->h_median[(size_t)slot] = *median_depth;
+  if (Rcw || tcw || Ow) HIPCHK(hipMemcpyAsync(st->d_kf + slot, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+  if (mp && d.n > 0) HIPCHK(hipMemcpyAsync(st->d_mp + (size_t)d.f0, mp, 4 * (size_t)d.n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return CMS_OK;
+}
+
+extern "C" int cms_kfstore_create_new_map_points(cms_kfstore* st, int njobs, const int* cur_slot, const int* neigh_off, const int* neigh_slot,
+                                                 int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
+                                                 float* out_x3d) {
+  if (!st || njobs < 0 || cap_per_job < 0 || (njobs > 0 && (!cur_slot || !neigh_off || !n_new)) ||
+      (njobs > 0 && cap_per_job > 0 && (!out_neigh || !out_idx1 || !out_idx2 || !out_x3d)))
+    return cms_fail(CMS_ERR_ARG, "cms_kfstore_create_new_map_points: bad argument");
+  if (njobs == 0) return CMS_OK;
+  cms_ctx* c = st->c;
+  if (c->g.nlevels > 16 || c->g.nlevels < 2) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_kfstore_create_new_map_points: 2..16 pyramid levels");
+  const int nneigh = neigh_off[njobs];
+  if (nneigh < 0 || (nneigh > 0 && !neigh_slot)) return cms_fail(CMS_ERR_ARG, "cms_kfstore_create_new_map_points: bad neighbour list");
+  for (int j = 0; j < njobs; ++j)
+    if (cur_slot[j] < 0 || cur_slot[j] >= st->maxkf || !st->used[(size_t)cur_slot[j]]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_create_new_map_points: empty slot");
+  for (int q = 0; q < nneigh; ++q)
+    if (neigh_slot[q] < 0 || neigh_slot[q] >= st->maxkf || !st->used[(size_t)neigh_slot[q]]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_create_new_map_points: empty slot");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t need = tri_work_bytes(njobs, nneigh, st->maxf, cap_per_job);
+  if (need > st->work_bytes) {
+    if (st->d_work) HIPCHK(hipFree(st->d_work));
+    st->d_work = nullptr; st->work_bytes = 0;
+    HIPCHK(hipMalloc((void**)&st->d_work, need + need / 4));
+    st->work_bytes = need + need / 4;
+  }
+  TriDev dev;
+  dev.kf = st->d_kf; dev.kp = st->d_kp; dev.desc = (const uint4*)st->d_desc; dev.rays = st->d_rays; dev.mp = st->d_mp; dev.feat_node = st->d_fn;
+  dev.node_id = st->d_nid; dev.node_off = st->d_noff; dev.node_feat = st->d_nfeat;
+  return tri_run(c, dev, st->h_kf.data(), st->h_median.data(), njobs, cur_slot, neigh_off, neigh_slot, check_orientation, cap_per_job, st->d_work, n_new,
+                 out_neigh, out_idx1, out_idx2, out_x3d);
 }
 
 // search half of ORBMatcher::Fuse(pKF, vpMapPoints, th) for key frame slot b (cms_area_set_keypoints / _descriptors + cms_area_grid first)

@@ -244,6 +244,46 @@ __device__ bool tri_triangulate(const CmsTriArgs& a, const CmsTriKF& k1, const C
   return true;
 }
 
+// ORBMatcher::SearchForTriangulation for ONE feature of the current key frame (ORBMatcher.cpp:1009-1058): the key point of the
+// neighbour it pairs with, or -1.  The caller has checked that the feature holds no map point.
+__device__ int tri_search_feature(const CmsTriArgs& a, const CmsTriKF& k1, const CmsTriKF& k2, const CmsTriPair& pr, int idx1) {
+  int best2 = -1;
+  const int e1 = a.feat_node[k1.f0 + idx1];
+  if (e1 >= 0) {
+    const int node = a.node_id[k1.node0 + e1];
+    int lo = 0, hi = k2.nnodes;                  // lower_bound in the neighbour's node list
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.node_id[k2.node0 + mid] < node) lo = mid + 1; else hi = mid; }
+    if (lo < k2.nnodes && a.node_id[k2.node0 + lo] == node) {
+      const uint4 d0 = a.desc[2 * (size_t)(k1.f0 + idx1)], d1 = a.desc[2 * (size_t)(k1.f0 + idx1) + 1];
+      const float* ray1 = a.rays + 3 * (size_t)(k1.f0 + idx1);
+      // epipolar plane normal of this feature in the neighbour's frame: l = ray1' E12 (CheckDistEpipolarLine)
+      const float la = __fadd_rn(__fadd_rn(__fmul_rn(ray1[0], pr.E12[0]), __fmul_rn(ray1[1], pr.E12[3])), __fmul_rn(ray1[2], pr.E12[6]));
+      const float lb = __fadd_rn(__fadd_rn(__fmul_rn(ray1[0], pr.E12[1]), __fmul_rn(ray1[1], pr.E12[4])), __fmul_rn(ray1[2], pr.E12[7]));
+      const float lc = __fadd_rn(__fadd_rn(__fmul_rn(ray1[0], pr.E12[2]), __fmul_rn(ray1[1], pr.E12[5])), __fmul_rn(ray1[2], pr.E12[8]));
+      const float den = __fadd_rn(__fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb)), __fmul_rn(lc, lc));
+      int bestDist = 50;                         // TH_LOW
+      const int nb0 = a.node_off[k2.noff0 + lo], nb1 = a.node_off[k2.noff0 + lo + 1];
+      for (int b = nb0; b < nb1; ++b) {
+        const int idx2 = a.node_feat[k2.nfeat0 + b];
+        const size_t g2 = (size_t)(k2.f0 + idx2);
+        if (a.mp[g2] >= 0) continue;
+        const int dist = tri_hamming256(d0, d1, a.desc[2 * g2], a.desc[2 * g2 + 1]);
+        if (dist > 50 || dist > bestDist) continue;
+        const CmsKeyPoint kp2 = a.kp[g2];
+        const float dex = __fsub_rn(pr.ex, kp2.x), dey = __fsub_rn(pr.ey, kp2.y);
+        if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.0f, a.sf[kp2.octave])) continue;
+        if (den == 0) continue;
+        const float* ray2 = a.rays + 3 * g2;
+        const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, ray2[0]), __fmul_rn(lb, ray2[1])), __fmul_rn(lc, ray2[2]));
+        const float sigma = tri_vector_sigma(a.F, kp2.x, kp2.y, la, lb, lc);
+        const float dsqr = __fmul_rn(num, num) / __fmul_rn(__fmul_rn(den, __fmul_rn(sigma, sigma)), a.sigma2[kp2.octave]);
+        if ((double)dsqr < 3.84) { best2 = idx2; bestDist = dist; }
+      }
+    }
+  }
+  return best2;
+}
+
 extern "C" __global__ void __launch_bounds__(512) k_create_new_map_points(CmsTriArgs a) {
   __shared__ uint8_t s_taken[CMS_TRI_MAXF];        // KeyFrame::GetMapPoint(idx1) != NULL for the current key frame, updated as points are created
   __shared__ int s_match[CMS_TRI_MAXF];
@@ -265,40 +305,7 @@ extern "C" __global__ void __launch_bounds__(512) k_create_new_map_points(CmsTri
     __syncthreads();
     // ---- SearchForTriangulation: one thread per feature of the current key frame
     for (int idx1 = tid; idx1 < k1.n; idx1 += nt) {
-      int best2 = -1;
-      const int e1 = a.feat_node[k1.f0 + idx1];
-      if (e1 >= 0 && !s_taken[idx1]) {
-        const int node = a.node_id[k1.node0 + e1];
-        int lo = 0, hi = k2.nnodes;                  // lower_bound in the neighbour's node list
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.node_id[k2.node0 + mid] < node) lo = mid + 1; else hi = mid; }
-        if (lo < k2.nnodes && a.node_id[k2.node0 + lo] == node) {
-          const uint4 d0 = a.desc[2 * (size_t)(k1.f0 + idx1)], d1 = a.desc[2 * (size_t)(k1.f0 + idx1) + 1];
-          const float* ray1 = a.rays + 3 * (size_t)(k1.f0 + idx1);
-          // epipolar plane normal of this feature in the neighbour's frame: l = ray1' E12 (CheckDistEpipolarLine)
-          const float la = __fadd_rn(__fadd_rn(__fmul_rn(ray1[0], pr.E12[0]), __fmul_rn(ray1[1], pr.E12[3])), __fmul_rn(ray1[2], pr.E12[6]));
-          const float lb = __fadd_rn(__fadd_rn(__fmul_rn(ray1[0], pr.E12[1]), __fmul_rn(ray1[1], pr.E12[4])), __fmul_rn(ray1[2], pr.E12[7]));
-          const float lc = __fadd_rn(__fadd_rn(__fmul_rn(ray1[0], pr.E12[2]), __fmul_rn(ray1[1], pr.E12[5])), __fmul_rn(ray1[2], pr.E12[8]));
-          const float den = __fadd_rn(__fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb)), __fmul_rn(lc, lc));
-          int bestDist = 50;                         // TH_LOW
-          const int nb0 = a.node_off[k2.noff0 + lo], nb1 = a.node_off[k2.noff0 + lo + 1];
-          for (int b = nb0; b < nb1; ++b) {
-            const int idx2 = a.node_feat[k2.nfeat0 + b];
-            const size_t g2 = (size_t)(k2.f0 + idx2);
-            if (a.mp[g2] >= 0) continue;
-            const int dist = tri_hamming256(d0, d1, a.desc[2 * g2], a.desc[2 * g2 + 1]);
-            if (dist > 50 || dist > bestDist) continue;
-            const CmsKeyPoint kp2 = a.kp[g2];
-            const float dex = __fsub_rn(pr.ex, kp2.x), dey = __fsub_rn(pr.ey, kp2.y);
-            if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.0f, a.sf[kp2.octave])) continue;
-            if (den == 0) continue;
-            const float* ray2 = a.rays + 3 * g2;
-            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, ray2[0]), __fmul_rn(lb, ray2[1])), __fmul_rn(lc, ray2[2]));
-            const float sigma = tri_vector_sigma(a.F, kp2.x, kp2.y, la, lb, lc);
-            const float dsqr = __fmul_rn(num, num) / __fmul_rn(__fmul_rn(den, __fmul_rn(sigma, sigma)), a.sigma2[kp2.octave]);
-            if ((double)dsqr < 3.84) { best2 = idx2; bestDist = dist; }
-          }
-        }
-      }
+      const int best2 = s_taken[idx1] ? -1 : tri_search_feature(a, k1, k2, pr, idx1);
       s_match[idx1] = best2;
       if (best2 >= 0 && a.check_orientation) {
         float rot = __fsub_rn(a.kp[k1.f0 + idx1].angle, a.kp[k2.f0 + best2].angle);
@@ -364,6 +371,71 @@ extern "C" __global__ void __launch_bounds__(512) k_create_new_map_points(CmsTri
     }
   }
   if (tid == 0) a.n_new[blockIdx.x] = s_base;
+}
+
+// ---- the same result without walking the neighbours one after the other (check_orientation == 0, the reference's call site).
+// Neither the search nor the triangulation of (feature, neighbour) looks at what other features did; the only coupling is "a feature
+// that got its point from an earlier neighbour is skipped by the later ones".  So every (neighbour, feature) pair is evaluated at once
+// (k_tri_candidates, one thread each), and k_tri_resolve keeps for every feature the FIRST neighbour whose candidate survived, then
+// writes the records in the reference's creation order (neighbour ascending, feature ascending inside a neighbour).
+struct CmsTriCand { int idx2; float x, y, z; };       // idx2 < 0: no surviving candidate
+extern "C" __global__ void __launch_bounds__(256) k_tri_candidates(CmsTriArgs a, const int* __restrict__ pair_job, CmsTriCand* __restrict__ cand, int maxf) {
+  const int pg = blockIdx.y;                           // global pair index
+  const CmsTriPair pr = a.pair[pg];
+  const CmsTriKF k1 = a.kf[a.job[pair_job[pg]].kf1];
+  const int idx1 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx1 >= k1.n) return;
+  CmsTriCand c; c.idx2 = -1; c.x = 0; c.y = 0; c.z = 0;
+  if (!pr.skip && a.mp[k1.f0 + idx1] < 0) {
+    const CmsTriKF k2 = a.kf[pr.kf2];
+    const int idx2 = tri_search_feature(a, k1, k2, pr, idx1);
+    if (idx2 >= 0) {
+      float x3D[3];
+      if (tri_triangulate(a, k1, k2, a.kp[k1.f0 + idx1], a.kp[k2.f0 + idx2], a.rays + 3 * (size_t)(k1.f0 + idx1), a.rays + 3 * (size_t)(k2.f0 + idx2), x3D)) {
+        c.idx2 = idx2; c.x = x3D[0]; c.y = x3D[1]; c.z = x3D[2];
+      }
+    }
+  }
+  cand[(size_t)pg * maxf + idx1] = c;
+}
+
+extern "C" __global__ void __launch_bounds__(1024) k_tri_resolve(CmsTriArgs a, const CmsTriCand* __restrict__ cand, int maxf) {
+  __shared__ short s_win[CMS_TRI_MAXF];                // neighbour that creates the point of feature i, -1 = none
+  __shared__ int s_cnt[64], s_base[65];
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  const CmsTriJob jb = a.job[blockIdx.x];
+  const CmsTriKF k1 = a.kf[jb.kf1];
+  for (int p = tid; p < 64; p += nt) s_cnt[p] = 0;
+  __syncthreads();
+  for (int i = tid; i < k1.n; i += nt) {
+    int w = -1;
+    for (int p = 0; p < jb.npairs; ++p)
+      if (cand[(size_t)(jb.pair0 + p) * maxf + i].idx2 >= 0) { w = p; break; }
+    s_win[i] = (short)w;
+    if (w >= 0) atomicAdd(&s_cnt[w & 63], 1);          // (npairs <= 64, checked on the host)
+  }
+  __syncthreads();
+  if (tid == 0) { int t = 0; for (int p = 0; p < 64; ++p) { s_base[p] = t; t += s_cnt[p]; } s_base[64] = t; a.n_new[blockIdx.x] = t; }
+  __syncthreads();
+  // one wavefront per neighbour: its features in ascending order
+  for (int p = wv; p < jb.npairs; p += nw) {
+    int pos = s_base[p];
+    for (int i0 = 0; i0 < k1.n; i0 += 64) {
+      const int i = i0 + lane;
+      const bool mine = i < k1.n && s_win[i] == p;
+      const unsigned long long bal = __ballot(mine);
+      if (mine) {
+        const int o = pos + __popcll(bal & ((1ull << lane) - 1ull));
+        if (o < a.cap) {
+          const CmsTriCand c = cand[(size_t)(jb.pair0 + p) * maxf + i];
+          const size_t r = (size_t)blockIdx.x * a.cap + o;
+          a.out_neigh[r] = p; a.out_idx1[r] = i; a.out_idx2[r] = c.idx2;
+          a.out_x3d[3 * r] = c.x; a.out_x3d[3 * r + 1] = c.y; a.out_x3d[3 * r + 2] = c.z;
+        }
+      }
+      pos += __popcll(bal);
+    }
+  }
 }
 
 // ---- Fuse: projection half.  Writes the window (qx, qy, qr; qr < 0 = rejected) and the predicted level per map point.

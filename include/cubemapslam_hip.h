@@ -236,6 +236,17 @@ typedef struct {
 int cms_create_new_map_points(cms_ctx* ctx, int njobs, const cms_keyframe* cur, const int* neigh_off, const cms_keyframe* neigh,
                               int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
                               float* out_x3d);
+/* Resident key frames: the map's key frames stay on the device in fixed-size slots, a CreateNewMapPoints call names slots and only
+ * ~100 bytes per (current, neighbour) pair travel.  cms_kfstore_put uploads / replaces a key frame; cms_kfstore_update refreshes what
+ * changes between calls (pose after a local BA, median depth, map-point slots; NULL = unchanged).  Results as above. */
+typedef struct cms_kfstore cms_kfstore;
+int cms_kfstore_create(cms_kfstore** out, cms_ctx* ctx, int max_keyframes, int max_features, int max_nodes);
+void cms_kfstore_destroy(cms_kfstore* st);
+int cms_kfstore_put(cms_kfstore* st, int slot, const cms_keyframe* kf);
+int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, const float* tcw, const float* Ow, const float* median_depth, const int* mp);
+int cms_kfstore_create_new_map_points(cms_kfstore* st, int njobs, const int* cur_slot, const int* neigh_off, const int* neigh_slot,
+                                      int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
+                                      float* out_x3d);
 int cms_fuse_search(cms_ctx* ctx, int b, const float* pose15, int nmp, const uint8_t* skip, const float* pos, const float* normal,
                     const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, int* best_idx, int* best_dist);
 

@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle, stage by stage and end to end.
 Integer / index / byte results must be bit-exact; BA within 1e-4 relative (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 import orc
@@ -558,6 +560,15 @@ def test_create_new_map_points_matches_oracle():
         assert np.array_equal(gn, wn) and np.array_equal(g1, w1) and np.array_equal(g2, w2), (j, len(gn), len(wn))
         assert np.array_equal(gx.view(np.uint32), wx.view(np.uint32)), (j, np.abs(gx - wx).max())
         assert len(np.unique(wn)) >= 2                                # several neighbours contributed
+    # the neighbour-after-neighbour kernel (used when the rotation histogram is on) gives the same records
+    os.environ["CMS_TRI_SEQUENTIAL"] = "1"
+    try:
+        got_seq = api.create_new_map_points(ctx, jobs_g)
+    finally:
+        del os.environ["CMS_TRI_SEQUENTIAL"]
+    for j in range(2):
+        for x, y in zip(got_seq[j], got[j]):
+            assert np.array_equal(x, y)
     # orientation check on (ORBMatcher(.., true)) only changes the search: compare the pair search through a one-neighbour job
     S, oks, gks = keep[0]
     E = orc.compute_e12(S["kfs"][0], S["kfs"][1])
@@ -568,6 +579,34 @@ def test_create_new_map_points_matches_oracle():
     # capacity too small
     with pytest.raises(api.CmsError):
         api.create_new_map_points(ctx, jobs_g, cap=10)
+    # resident key frames: same records from slots; then a pose / map-point update changes the outcome like the oracle says
+    store = api.KeyframeStore(ctx, max_keyframes=16, max_features=2048, max_nodes=1024)
+    slot = 0
+    slot_jobs = []
+    for S, oks, gks in keep:
+        ids = []
+        for K, _ in gks:
+            store.put(slot, K); ids.append(slot); slot += 1
+        slot_jobs.append((ids[0], ids[1:]))
+    got_res = store.create_new_map_points(slot_jobs)
+    for j in range(2):
+        for x, y in zip(got_res[j], got[j]):
+            assert np.array_equal(x, y)
+    S, oks, gks = keep[1]
+    new_mp = S["kfs"][0]["mp"].copy(); new_mp[::3] = 7
+    k1 = dict(S["kfs"][0]); k1["mp"] = new_mp
+    t2 = (S["kfs"][1]["t"] * np.float32(1.5)).astype(np.float32)
+    k2 = dict(S["kfs"][1]); k2["t"] = t2; k2["Ow"] = (-(k2["R"].astype(np.float64).T @ t2.astype(np.float64))).astype(np.float32)
+    store.update(slot_jobs[1][0], mp=new_mp)
+    store.update(slot_jobs[1][1][0], t=t2, Ow=k2["Ow"])
+    O1, _k1 = orc.make_keyframe(ocam, k1); O2, _k2 = orc.make_keyframe(ocam, k2)
+    cur_mp = new_mp.copy()
+    w = orc.create_new_map_points(ocam, O1, [O2] + [k for k, _ in oks[2:]], S["scale_factors"], S["level_sigma2"], cur_mp)
+    g = store.create_new_map_points([slot_jobs[1]])[0]
+    assert len(w[0]) > 50 and all(np.array_equal(x, y) for x, y in zip(g[:3], w[:3])) and np.array_equal(g[3].view(np.uint32), w[3].view(np.uint32))
+    with pytest.raises(api.CmsError):
+        store.create_new_map_points([(15, [0])])            # empty slot
+    store.close()
     ctx.close()
 
 
