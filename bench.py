@@ -187,9 +187,34 @@ def main():
     n_grp = max(1, min(args.ba_groups, n_ba))
     groups = [bas[g::n_grp] for g in range(n_grp)]
 
-    def ba_worker(grp):
+    # LocalMapping::CreateNewMapPoints in front of every window's BA: the window's key frame against its 20 best covisible neighbours
+    # (~1650 features each, FeatureVectors of ~400 nodes), key frames resident on the device; one store + context (stream) per group
+    tri_nn = 20
+    tri_sets = [synth.keyframe_set(F, n_kf=tri_nn + 1, n_pts=2400, seed=300 + 10 * rank + w) for w in range(min(n_ba, 2))]
+    for S in tri_sets:
+        for k in S["kfs"]:           # mvKeyRays: the pixel's ray with unit depth on its face (CamModelGeneral::TransformCubemapToRays)
+            _, r = synth.pixel_to_ray(F, k["x"].astype(np.float64), k["y"].astype(np.float64))
+            k["rays"] = r.astype(np.float32)
+    tri_ctx, tri_store, tri_jobs = [], [], []
+    for gi, grp in enumerate(groups):
+        cg = api.Context(camd, nfeatures=nfeat, max_batch=1, device=local_rank)
+        st = api.KeyframeStore(cg, max_keyframes=len(grp) * (tri_nn + 1), max_features=2048, max_nodes=1024)
+        jobs_g = []
+        for wi in range(len(grp)):
+            S = tri_sets[(gi + wi) % len(tri_sets)]
+            base = wi * (tri_nn + 1)
+            for i, k in enumerate(S["kfs"]):
+                K, keep = api.make_keyframe(k)
+                st.put(base + i, K)
+            jobs_g.append((base, list(range(base + 1, base + tri_nn + 1))))
+        tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g)
+    tri_new = [0]
+
+    def ba_worker(grp, gi):
         t_ba0 = time.perf_counter()
         try:
+            res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+            tri_new[0] = sum(len(r[0]) for r in res)
             for ba in grp:
                 ba.reset()
             api.ba_optimize_many(grp, (5, 10))   # the group's windows share every launch (kb_ba_* kernels, one window per blockIdx.z)
@@ -200,7 +225,7 @@ def main():
     last_traj = [None]
 
     def step(i):
-        ths = [threading.Thread(target=ba_worker, args=(grp,)) for grp in groups]
+        ths = [threading.Thread(target=ba_worker, args=(grp, gi)) for gi, grp in enumerate(groups)]
         for th in ths:
             th.start()
         po.launch()                 # own stream, overlaps the frame path
@@ -332,6 +357,12 @@ def main():
                                     np.full(len(kb), -1, np.int32))
         t_local = (time.perf_counter() - t1) / n
         t1 = time.perf_counter()
+        S0 = tri_sets[0]
+        oks = [orc.make_keyframe(ocam, k) for k in S0["kfs"]]
+        for _ in range(2):
+            orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], S0["scale_factors"], S0["level_sigma2"], S0["kfs"][0]["mp"].copy())
+        t_tri = (time.perf_counter() - t1) / 2
+        t1 = time.perf_counter()
         n_cpu_ba = 3
         for _ in range(n_cpu_ba):
             orc.ba_run(prob)
@@ -340,12 +371,12 @@ def main():
         for b in range(min(n, 8)):
             orc.pose_optimize(pose_probs[b])
         t_pose = (time.perf_counter() - t1) / min(n, 8)
-        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_local + t_pose + t_ba / args.ba_every
+        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_local + t_pose + (t_ba + t_tri) / args.ba_every
         cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames remap+extract (%.1f ms/frame), windows + Hamming over %.1f frame pairs (%.2f ms/frame), local-map search "
-                         "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
+                         "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), CreateNewMapPoints (%.1f ms per key frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
                          "oracle/liborc.so, single thread" %
-                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_local, 1e3 * t_pose, n_cpu_ba, 1e3 * t_ba,
+                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, n_cpu_ba, 1e3 * t_ba,
                           args.ba_every),
                "host_cores_available": os.cpu_count()}
 
@@ -370,7 +401,7 @@ def main():
             "config": {"workload": "Lafida cam0 synthetic stream, 754x480 fisheye, face=%d (%dx%d cross), nFeatures %d; per step %d frames: "
                                    "remap+ORB extract, frame grids + GetFeaturesInArea windows + Hamming best-2 (%d queries, %d candidate pairs), "
                                    "local-map search (isInFrustum + SearchByProjection, %d map points, %d candidate pairs), pose-only optimisation (%d edges/frame), "
-                                   "%d local-BA windows (K=20, E=%d)"
+                                   "%d key frames x (CreateNewMapPoints against 20 neighbours + local BA window K=20, E=%d)"
                                    % (F, 3 * F, 3 * F, nfeat, B, nq, n_pairs, n_mp, lm_pairs, args.pose_edges, n_ba, len(prob["e_pose"])),
                        "frames_per_step_per_gpu": B, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
