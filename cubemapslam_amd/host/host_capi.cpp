@@ -3,6 +3,7 @@
 #include <cstring>
 #include <stdexcept>
 #include "cubemap_hot_path.h"
+#include "io_formats.h"
 using namespace CubemapSLAM;
 
 static thread_local std::string g_err;
@@ -193,4 +194,37 @@ extern "C" int hm_save_trajectory_tum(const char* path, int n, const double* ts,
     for (int i = 0; i < n; ++i) { v[i].mTimeStamp = ts[i]; v[i].Tcw = cv::Mat(4, 4, cv::CV_32F, Tcw + 16 * (size_t)i, 16); }
     System::SaveKeyFrameTrajectoryTUM(path, v);
     return n;)
+}
+
+// ---- file formats (io_formats.h); host only, usable without a GPU
+extern "C" int hm_settings_load(const char* path, cms_camera* cam, cms_orb_params* orb, float* fps, int* with_mask, int* rgb) {
+  HM_TRY(
+    Settings st;
+    if (!st.Load(path)) throw std::runtime_error(std::string("Failed to open settings file at: ") + path);
+    if (cam) *cam = st.Camera();
+    if (orb) *orb = st.Orb();
+    if (fps) *fps = st.Fps();
+    if (with_mask) *with_mask = st.WithFisheyeMask();
+    if (rgb) *rgb = st.RGB() ? 1 : 0;
+    return 0;)
+}
+// kind 0 = Lafida list, 1 = Fangshan list.  names: cap x name_len chars (NUL terminated).  Returns the number of entries.
+extern "C" int hm_load_image_list(const char* path, int kind, int cap, int name_len, char* names, double* timestamps) {
+  HM_TRY(
+    const ImageList l = kind == 0 ? LoadImageListLafida(path) : LoadImageListFangshan(path);
+    const int n = (int)l.names.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+      std::strncpy(names + (size_t)i * name_len, l.names[i].c_str(), name_len - 1);
+      names[(size_t)i * name_len + name_len - 1] = 0;
+      timestamps[i] = l.timestamps[i];
+    }
+    return n;)
+}
+extern "C" int hm_write_tracking_summary(const char* path, float* times, int n, int frame_counter, char* console, int console_len) {
+  HM_TRY(
+    std::vector<float> v(times, times + n);
+    const std::string text = WriteTrackingSummary(path ? path : "", v, frame_counter);
+    std::copy(v.begin(), v.end(), times);
+    if (console && console_len > 0) { std::strncpy(console, text.c_str(), console_len - 1); console[console_len - 1] = 0; }
+    return 0;)
 }
