@@ -634,3 +634,72 @@ def test_fuse_search_matches_oracle():
         assert np.array_equal(gi, wi) and np.array_equal(gd, wd), (th, (gi != wi).sum())
         assert (wi >= 0).sum() > 300 and (wi[skip > 0] == -1).all()
     ctx.close()
+
+
+def test_tracking_and_mapping_edge_cases():
+    """empty and degenerate inputs of the local-map search, CreateNewMapPoints and Fuse entries behave like the reference's loops:
+    nothing to do -> nothing returned, no error."""
+    import test_area_emu as te
+    F = 250
+    camd = synth.camera("lafida", F)
+    ocam = orc.make_camera(camd)
+    ctx = api.Context(camd, nfeatures=1000, max_batch=1)
+    kx, ky, ko = te._keypoints(F, 500, 5)
+    kd = synth.descriptors(len(kx), 6)
+    kps = np.zeros(len(kx), api.KP_DTYPE); kps["x"] = kx; kps["y"] = ky; kps["octave"] = ko
+    pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=7)
+    # no map points
+    ctx.area_set_keypoints(0, kps); ctx.area_set_descriptors(0, kd); ctx.area_grid(1)
+    kp_mp = np.full(len(kx), -1, np.int32)
+    r = ctx.search_local_points(0, pr["pose15"], np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32),
+                                np.zeros((0, 32), np.uint8), kp_mp)
+    assert r["n_matches"] == 0 and len(r["match"]) == 0
+    # every key point already taken -> no match, ownership untouched
+    taken = np.full(len(kx), 99, np.int32)
+    r = ctx.search_local_points(0, pr["pose15"], pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], taken)
+    assert r["n_matches"] == 0 and (r["match"] == -1).all() and (taken == 99).all() and r["in_view"].sum() > 50
+    # all map points behind / out of range -> nothing in view
+    far = pr["max_dist"] * np.float32(1e-3)
+    r = ctx.search_local_points(0, pr["pose15"], pr["pos"], pr["normal"], far * np.float32(0.5), far, pr["desc"], kp_mp)
+    fr = orc.is_in_frustum(ocam, pr["pose15"], pr["pos"], pr["normal"], far * np.float32(0.5), far)
+    assert np.array_equal(r["in_view"], fr["in_view"]) and r["n_matches"] == 0
+    # a frame without key points
+    ctx.area_set_keypoints(0, kps[:0]); ctx.area_grid(1)
+    r = ctx.search_local_points(0, pr["pose15"], pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], np.zeros(0, np.int32))
+    fr = orc.is_in_frustum(ocam, pr["pose15"], pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"])
+    assert r["n_matches"] == 0 and np.array_equal(r["in_view"], fr["in_view"])
+    bi, bd = api.fuse_search(ctx, 0, pr["pose15"], np.zeros(len(pr["pos"]), np.uint8), pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], 3.0)
+    assert (bi == -1).all() and (bd == 256).all()
+    # Fuse with everything skipped
+    ctx.area_set_keypoints(0, kps); ctx.area_set_descriptors(0, kd); ctx.area_grid(1)
+    bi, bd = api.fuse_search(ctx, 0, pr["pose15"], np.ones(len(pr["pos"]), np.uint8), pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], 3.0)
+    assert (bi == -1).all()
+    # CreateNewMapPoints: no neighbours; a neighbour without features / without a FeatureVector; every feature already mapped; baseline too short
+    S = synth.keyframe_set(F, n_kf=3, n_pts=900, seed=8)
+    for k in S["kfs"]:
+        k["rays"] = orc.keyframe_rays(ocam, k["x"], k["y"])
+    g = [api.make_keyframe(k) for k in S["kfs"]]
+    assert len(api.create_new_map_points(ctx, [(g[0][0], [])])[0][0]) == 0
+    empty = dict(S["kfs"][1]); n0 = 0
+    for key in ("x", "y", "octave", "angle", "desc", "rays", "mp"):
+        empty[key] = empty[key][:n0]
+    empty["node_id"] = np.zeros(0, np.int32); empty["node_off"] = np.zeros(1, np.int32); empty["node_feat"] = np.zeros(0, np.int32)
+    ge = api.make_keyframe(empty)
+    nofv = dict(S["kfs"][2]); nofv["node_id"] = np.zeros(0, np.int32); nofv["node_off"] = np.zeros(1, np.int32); nofv["node_feat"] = np.zeros(0, np.int32)
+    gn = api.make_keyframe(nofv)
+    res = api.create_new_map_points(ctx, [(g[0][0], [ge[0], gn[0], g[1][0]])])[0]
+    oks = [orc.make_keyframe(ocam, k) for k in (S["kfs"][0], empty, nofv, S["kfs"][1])]
+    w = orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], S["scale_factors"], S["level_sigma2"], S["kfs"][0]["mp"].copy())
+    assert len(w[0]) > 20 and (w[0] == 2).all() and all(np.array_equal(a, b) for a, b in zip(res[:3], w[:3]))
+    full = dict(S["kfs"][0]); full["mp"] = np.zeros(len(full["x"]), np.int32)
+    gf = api.make_keyframe(full)
+    assert len(api.create_new_map_points(ctx, [(gf[0], [g[1][0], g[2][0]])])[0][0]) == 0
+    near = dict(S["kfs"][1]); near["median_depth"] = np.float32(1e4)          # baseline / depth < 0.01 -> neighbour skipped
+    gnr = api.make_keyframe(near)
+    assert len(api.create_new_map_points(ctx, [(g[0][0], [gnr[0]])])[0][0]) == 0
+    # malformed FeatureVector is refused, not read out of bounds
+    bad = dict(S["kfs"][1]); bad["node_feat"] = bad["node_feat"].copy(); bad["node_feat"][0] = 10**6
+    gb = api.make_keyframe(bad)
+    with pytest.raises(api.CmsError):
+        api.create_new_map_points(ctx, [(g[0][0], [gb[0]])])
+    ctx.close()
