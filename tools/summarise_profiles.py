@@ -19,6 +19,20 @@ if os.path.exists(stats):
         line = [l for l in open(bj) if l.startswith("{")]
         if line:
             open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w").write(line[-1])
+for extra, cmd in (("mapping", "python tools/prof_tri.py 8 20 5"), ("ba8", "python tools/prof_ba_many.py 8")):
+    st = os.path.join(src, "%s_%s_kernel_stats.csv" % (tag, extra))
+    if os.path.exists(st):
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, extra)), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- %s   (MI355X, 1 GPU)\n" % cmd)
+            lg = os.path.join(src, "%s_%s.log" % (tag, extra))
+            if os.path.exists(lg):
+                for l in open(lg):
+                    if "ms" in l and not l.startswith(("W2", "E2", "I2")):
+                        f.write("# " + l.strip() + "\n")
+            f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+            for r in csv.DictReader(open(st)):
+                f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
+                                  "%.2f" % float(r["Percentage"]), r["MinNs"], r["MaxNs"]]) + "\n")
 pmc = {}
 for kind in ("fetch", "write"):
     p = os.path.join(src, "%s_pmc_%s_counter_collection.csv" % (tag, kind))
