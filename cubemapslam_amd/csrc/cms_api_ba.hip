@@ -36,6 +36,7 @@ struct cms_ba {
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   // group resources (owned by the first window of a cms_ba_optimize_many call, grown on demand)
   void* grp_items_dev = nullptr; void* grp_items_host = nullptr; double* grp_scal_dev = nullptr; double* grp_scal_host = nullptr;
+  void* grp_lm_dev = nullptr; void* grp_lm_host = nullptr;   // BaLmDev per window (device-side Levenberg state) and its pinned mirror
   int grp_cap = 0;
   std::vector<void*> allocs;
 };
@@ -56,6 +57,8 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->grp_scal_dev) hipFree(b->grp_scal_dev);
   if (b->grp_items_host) hipHostFree(b->grp_items_host);
   if (b->grp_scal_host) hipHostFree(b->grp_scal_host);
+  if (b->grp_lm_dev) hipFree(b->grp_lm_dev);
+  if (b->grp_lm_host) hipHostFree(b->grp_lm_host);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }

@@ -169,11 +169,16 @@ static int ba_group_reserve(cms_ba* owner, int n) {
   if (owner->grp_scal_dev) hipFree(owner->grp_scal_dev);
   if (owner->grp_items_host) hipHostFree(owner->grp_items_host);
   if (owner->grp_scal_host) hipHostFree(owner->grp_scal_host);
+  if (owner->grp_lm_dev) hipFree(owner->grp_lm_dev);
+  if (owner->grp_lm_host) hipHostFree(owner->grp_lm_host);
+  owner->grp_lm_dev = nullptr; owner->grp_lm_host = nullptr;
   owner->grp_cap = 0;
   HIPCHK(hipMalloc(&owner->grp_items_dev, (size_t)n * sizeof(BaItem)));
   HIPCHK(hipMalloc((void**)&owner->grp_scal_dev, (size_t)n * 8 * sizeof(double)));
   HIPCHK(hipHostMalloc(&owner->grp_items_host, (size_t)n * sizeof(BaItem)));
   HIPCHK(hipHostMalloc((void**)&owner->grp_scal_host, (size_t)n * 8 * sizeof(double)));   // device-visible: kernels publish into it
+  HIPCHK(hipMalloc(&owner->grp_lm_dev, (size_t)n * sizeof(BaLmDev)));
+  HIPCHK(hipHostMalloc(&owner->grp_lm_host, (size_t)n * sizeof(BaLmDev)));
   owner->grp_cap = n;
   return CMS_OK;
 }
@@ -198,6 +203,7 @@ static int ba_upload_items(cms_ba** bas, int n) {
     it.flags = b->d_flags;
     it.nblk_e = b->nblk_e; it.nblk_p = b->nblk_p; it.nchunks = b->nchunks; it.pad = 0;
     it.sp = b->sp;
+    it.lm = reinterpret_cast<BaLmDev*>(g->grp_lm_dev) + w; it.hlm = reinterpret_cast<BaLmDev*>(g->grp_lm_host) + w;
     if (!all_sp) it.sp.R = 0;                       // one launch sequence for the whole group: per-point Schur only if every window has it
     if (all_sp) { it.chunk_sum = b->d_sp_sum; it.pair_chunk_off = b->d_sp_chunk_off; }
   }
@@ -266,6 +272,80 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
   HIPCHK(hipGetLastError());
   return CMS_OK;
 }
+// ---- the same stage with the Levenberg logic on the device: every kernel reads the window's BaLmDev to know whether it has work, the
+// last kernel of a phase updates it, and the host enqueues whole iterations back to back -- one synchronisation per batch of
+// iterations instead of two per iteration.  With a stop flag the batches are one iteration long so that the flag is polled as often
+// as g2o polls forceStopFlag.  Env CMS_BA_HOST_LM=1 selects the host-driven variant above (A/B, debugging).
+static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>& st, const volatile uint8_t* stop) {
+  cms_ba* g = bas[0];
+  hipStream_t s = g->stream;
+  const BaItem* ditems = reinterpret_cast<const BaItem*>(g->grp_items_dev);
+  int max_e = 0, max_p = 0, max_K = 0, max_np = 0, max_chunks = 0, max_P = 0, max_R = 0, max_spt = 64, max_pairs = 0, max_it = 0;
+  size_t lds = 0, sp_lds = 0;
+  const bool all_sp = ba_all_sp(bas, n);
+  for (int w = 0; w < n; ++w) {
+    max_R = std::max(max_R, bas[w]->sp.R); max_spt = std::max(max_spt, bas[w]->sp_threads); max_pairs = std::max(max_pairs, bas[w]->npairs);
+    sp_lds = std::max(sp_lds, bas[w]->sp_lds);
+    max_e = std::max(max_e, bas[w]->nblk_e); max_p = std::max(max_p, bas[w]->nblk_p); max_K = std::max(max_K, bas[w]->K);
+    max_np = std::max(max_np, bas[w]->np); max_chunks = std::max(max_chunks, bas[w]->nchunks); max_P = std::max(max_P, bas[w]->P);
+    lds = std::max(lds, bas[w]->blk_lds);
+    max_it = std::max(max_it, st[w].iterations);
+  }
+  HIPCHK(hipFuncSetAttribute((const void*)kb_ba_trial_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int rc = ba_upload_items(bas, n);
+  if (rc) return rc;
+  BaLmDev* hlm = reinterpret_cast<BaLmDev*>(g->grp_lm_host);
+  for (int w = 0; w < n; ++w) {
+    BaLmDev& L = hlm[w];
+    memset(&L, 0, sizeof(L));
+    L.lambda = st[w].lambda; L.ni = st[w].ni; L.it = st[w].it; L.iterations = st[w].iterations; L.nBad = st[w].nBad; L.done = st[w].done;
+    L.cur = bas[w]->cur;
+    L.next = (st[w].it >= st[w].iterations || ba_stopped(stop)) ? 2 : 0;
+  }
+  HIPCHK(hipMemcpyAsync(g->grp_lm_dev, hlm, (size_t)n * sizeof(BaLmDev), hipMemcpyHostToDevice, s));
+  BaDyn dyn;
+  memset(&dyn, 0, sizeof(dyn));
+  dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1;
+  bool first_batch = true;
+  for (;;) {
+    bool any = false;
+    for (int w = 0; w < n; ++w) any = any || hlm[w].next != 2;
+    if (!any || (!first_batch && ba_stopped(stop))) break;
+    const int rounds = stop ? 1 : (first_batch ? std::max(max_it, 1) : 2);
+    first_batch = false;
+    for (int r = 0; r < rounds; ++r) {
+      hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_lin_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_lin_poses, dim3(max_K, BA_POSE_CHUNKS, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_pose_finish, dim3(std::max(max_np, 1), 1, n), dim3(64), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      if (!all_sp)
+        hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (all_sp) {
+        hipLaunchKernelGGL(kb_ba_schur_points, dim3(max_R, 1, n), dim3(max_spt), sp_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        hipLaunchKernelGGL(kb_ba_schur_reduce, dim3(max_pairs, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      } else if (max_chunks > 0) {
+        hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      }
+      hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+    }
+    HIPCHK(hipStreamSynchronize(s));            // the kernels mirrored every window's state into hlm (pinned)
+  }
+  HIPCHK(hipGetLastError());
+  for (int w = 0; w < n; ++w) {
+    const BaLmDev& L = hlm[w];
+    BaLm& t = st[w];
+    t.lambda = L.lambda; t.ni = L.ni; t.currentChi = L.currentChi; t.iniChi = L.iniChi; t.rho = L.rho; t.it = L.it; t.qmax = L.qmax;
+    t.nBad = L.nBad; t.done = L.done; t.next = 2;
+    if (L.done > 0 || L.it > 0) { t.chi_ini = L.chi_ini; t.chi_fin = L.chi_fin; t.lam_fin = L.lam_fin; }
+    bas[w]->cur = L.cur;
+  }
+  return CMS_OK;
+}
+
 static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<std::vector<uint8_t>>& flags) {
   cms_ba* g = bas[0];
   hipStream_t s = g->stream;
@@ -302,7 +382,8 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
   const double delta = std::sqrt(5.991);
   std::vector<BaLm> st(n);
   for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_robust; st[w].robust = 1; st[w].delta = delta; }
-  int rc = batched ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_many(bas, n, st, stop);
+  const bool host_lm = getenv("CMS_BA_HOST_LM") != nullptr;
+  int rc = batched ? (host_lm ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_batched_dev(bas, n, st, stop)) : ba_optimize_stage_many(bas, n, st, stop);
   if (rc) return rc;
   for (int w = 0; w < n; ++w) {
     local[w].iterations_done[0] = st[w].done; local[w].chi2_initial[0] = st[w].chi_ini; local[w].chi2_final[0] = st[w].chi_fin;
@@ -327,7 +408,7 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
     if (rc) return rc;
     for (int w = 0; w < n; ++w) for (int e = 0; e < bas[w]->E; ++e) local[w].n_outliers_mid += flags[w][e];
     for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_final; st[w].robust = 0; st[w].delta = delta; }
-    rc = batched ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_many(bas, n, st, stop);
+    rc = batched ? (host_lm ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_batched_dev(bas, n, st, stop)) : ba_optimize_stage_many(bas, n, st, stop);
     if (rc) return rc;
     for (int w = 0; w < n; ++w) {
       local[w].iterations_done[1] = st[w].done; local[w].chi2_initial[1] = st[w].chi_ini; local[w].chi2_final[1] = st[w].chi_fin;

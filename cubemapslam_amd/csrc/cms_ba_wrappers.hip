@@ -11,6 +11,14 @@
 #include <stdint.h>
 
 #define BA_MAX_GROUP 64
+// Levenberg-Marquardt state of one window when the accept / reject logic runs on the device (batched driver): what
+// OptimizationAlgorithmLevenberg::solve keeps between trials (optimization_algorithm_levenberg.cpp:61-164).  The last kernel of a phase
+// updates it (ba_lm_after_iter / ba_lm_after_trial) and mirrors it into pinned host memory; every kernel of the following launches
+// reads `next` to know whether it has work: the host can enqueue several iterations back to back without waiting.
+struct BaLmDev {
+  double lambda, ni, currentChi, iniChi, rho, chi_ini, chi_fin, lam_fin;
+  int it, iterations, qmax, nBad, done, next, cur, pad;     // next: 0 = start an iteration, 1 = one more trial, 2 = finished
+};
 // static description of one window (device resident, uploaded once per optimisation stage) ...
 struct BaItem {
   BaDev d;
@@ -22,6 +30,7 @@ struct BaItem {
   uint8_t* flags;
   int nblk_e, nblk_p, nchunks, pad;
   BaSp sp;                                   // per-point Schur work lists (sp.R == 0: window uses the tuple-chunk kernel)
+  BaLmDev* lm; BaLmDev* hlm;                 // device-side LM state and its pinned host mirror (dyn.dev_lm)
 };
 // ... and what changes from launch to launch, passed BY VALUE as a kernel argument: no host->device copy per Levenberg step
 struct BaDyn {
@@ -29,6 +38,7 @@ struct BaDyn {
   uint8_t phase[BA_MAX_GROUP], cur[BA_MAX_GROUP], first_iter[BA_MAX_GROUP];
   int robust, set_level;
   double delta, chi2_th;
+  int dev_lm, pad;                           // 1: phase / cur / lambda / first_iter come from BaItem::lm instead of the arrays above
 };
 enum { BA_PHASE_IDLE = 0, BA_PHASE_ITER = 1, BA_PHASE_TRIAL = 2, BA_PHASE_CLASSIFY = 3 };
 
@@ -82,12 +92,55 @@ extern "C" __global__ void __launch_bounds__(256)
 k_ba_reduce2(const double* partial, int n, double* scal) { ba_reduce2_body(blockIdx.x, gridDim.x, partial, n, scal); }
 
 // ------------------------------------------------------------------------------------------------ many windows per launch
-#define BA_ITEM(PHASE, NBLK)                                               \
-  const int z = blockIdx.z;                                                \
-  const BaItem& it = items[z];                                             \
-  if (dyn.phase[z] != (PHASE) || (int)blockIdx.x >= (NBLK)) return;        \
-  const int cur = dyn.cur[z], nxt = cur ^ 1;                               \
-  (void)nxt;
+#define BA_ITEM(PHASE, NBLK)                                                                              \
+  const int z = blockIdx.z;                                                                               \
+  const BaItem& it = items[z];                                                                            \
+  int ba_ph = dyn.phase[z], cur = dyn.cur[z];                                                             \
+  double ba_lambda = dyn.lambda[z];                                                                       \
+  bool ba_first = dyn.first_iter[z] != 0;                                                                 \
+  if (dyn.dev_lm && (PHASE) != BA_PHASE_CLASSIFY) {                                                       \
+    const int nx = it.lm->next;                                                                           \
+    ba_ph = nx == 0 ? BA_PHASE_ITER : nx == 1 ? BA_PHASE_TRIAL : BA_PHASE_IDLE;                           \
+    cur = it.lm->cur; ba_lambda = it.lm->lambda; ba_first = it.lm->it == 0;                               \
+  }                                                                                                       \
+  if (ba_ph != (PHASE) || (int)blockIdx.x >= (NBLK)) return;                                              \
+  const int nxt = cur ^ 1;                                                                                \
+  (void)nxt; (void)ba_lambda; (void)ba_first;
+
+// end of the ITER phase (computeActiveErrors + buildSystem done): what the host driver's ba_finish_iter_start does
+__device__ __forceinline__ void ba_lm_after_iter(BaLmDev* L, BaLmDev* H, double chi, double maxdiag) {
+  L->currentChi = chi; L->iniChi = chi;
+  if (L->it == 0) { L->chi_ini = chi; L->lambda = 1e-5 * maxdiag; L->ni = 2; L->nBad = 0; }
+  L->rho = 0; L->qmax = 0; L->next = 1;
+  *H = *L;
+}
+// end of a TRIAL: accept / reject, lambda update, the 10-trial rule and the termination tests (ba_finish_trial)
+__device__ __forceinline__ void ba_lm_after_trial(BaLmDev* L, BaLmDev* H, double tempChi, double den, int ok2) {
+  if (!ok2) tempChi = 1.7976931348623157e308;
+  double rho = (L->currentChi - tempChi) / (den + 1e-3);
+  L->rho = rho;
+  if (rho > 0 && isfinite(tempChi)) {
+    double alpha = 1. - pow(2 * rho - 1, 3.0);
+    alpha = fmin(alpha, 2. / 3.);
+    L->lambda *= fmax(1. / 3., alpha);
+    L->ni = 2; L->currentChi = tempChi;
+    L->cur ^= 1;
+  } else {
+    L->lambda *= L->ni; L->ni *= 2;
+  }
+  ++L->qmax;
+  if (rho < 0 && L->qmax < 10) { L->next = 1; *H = *L; return; }
+  ++L->done;
+  L->chi_fin = L->currentChi; L->lam_fin = L->lambda;
+  bool terminate = (L->qmax == 10 || rho == 0);
+  if (!terminate) {
+    if ((L->iniChi - L->currentChi) * 1e3 < L->iniChi) ++L->nBad; else L->nBad = 0;
+    if (L->nBad >= 3) terminate = true;
+  }
+  ++L->it;
+  L->next = (terminate || L->it >= L->iterations) ? 2 : 0;
+  *H = *L;
+}
 
 extern "C" __global__ void __launch_bounds__(256) kb_ba_errors(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_e)
@@ -115,7 +168,8 @@ extern "C" __global__ void __launch_bounds__(64) kb_ba_pose_finish(const BaItem*
 extern "C" __global__ void __launch_bounds__(1024) kb_ba_maxdiag(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
   __shared__ double shm[16];
-  if (dyn.first_iter[z]) {
+  double mx_all = it.scal[3];
+  if (ba_first) {
     double m = 0;
     for (int i = threadIdx.x; i < 6 * it.d.np; i += blockDim.x) m = fmax(m, fabs(it.Hpp[36 * (i / 6) + 7 * (i % 6)]));
     for (int i = threadIdx.x; i < 3 * it.d.P; i += blockDim.x) m = fmax(m, fabs(it.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
@@ -125,14 +179,17 @@ extern "C" __global__ void __launch_bounds__(1024) kb_ba_maxdiag(const BaItem* _
     if (threadIdx.x == 0) {
       double mx = 0;
       for (int i = 0; i < (int)(blockDim.x >> 6); ++i) mx = fmax(mx, shm[i]);
-      it.scal[3] = mx; it.hscal[3] = mx;
+      it.scal[3] = mx; it.hscal[3] = mx; mx_all = mx;
     }
   }
-  if (threadIdx.x == 0) it.hscal[0] = it.scal[0];
+  if (threadIdx.x == 0) {
+    it.hscal[0] = it.scal[0];
+    if (dyn.dev_lm) ba_lm_after_iter(it.lm, it.hlm, it.scal[0], mx_all);
+  }
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_dinv(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, (it.d.P + 255) / 256)
-  ba_dinv_body(blockIdx.x, 0, it.d.P, it.Hll, it.bl, dyn.lambda[z], it.Dinv, it.db);
+  ba_dinv_body(blockIdx.x, 0, it.d.P, it.Hll, it.bl, ba_lambda, it.Dinv, it.db);
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nchunks)
@@ -140,7 +197,7 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaIte
 }
 extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS) kb_ba_schur_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R)
-  ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db, it.Hll, it.bl, dyn.lambda[z]);   // inverts Hll + lambda I itself
+  ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db, it.Hll, it.bl, ba_lambda);   // inverts Hll + lambda I itself
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R > 0 ? it.sp.npairs : 0)
@@ -148,18 +205,23 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_reduce(const BaIte
 }
 extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
-  ba_trial_solve_body(0, 1, it.d, it.Hpp, it.bp, dyn.lambda[z], it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt],
+  ba_trial_solve_body(0, 1, it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt],
                       it.x, it.scal);
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
-  ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, dyn.lambda[z], it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
+  ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
                        dyn.delta, it.partial, it.sp.R > 0 ? it.Hll : nullptr);
 }
 // last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
 extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
   ba_reduce2_body(0, 1, it.partial, it.nblk_p, it.scal, it.hscal);
+  if (dyn.dev_lm && threadIdx.x == 0) {
+    int ok2;
+    memcpy(&ok2, &it.scal[4], sizeof(int));
+    ba_lm_after_trial(it.lm, it.hlm, it.scal[1], it.scal[2], ok2);
+  }
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_e)
