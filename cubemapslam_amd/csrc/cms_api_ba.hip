@@ -17,7 +17,7 @@ struct cms_ba {
   // device memory
   uint8_t* d_fixed = nullptr; int* d_pose_slot = nullptr; int* d_e_pose = nullptr; int* d_e_point = nullptr;
   double* d_e_obs = nullptr; double* d_e_inv = nullptr; int8_t* d_e_face = nullptr; int* d_pt_off = nullptr;
-  int* d_pose_off = nullptr; int* d_pose_edges = nullptr; uint8_t* d_level = nullptr; double* d_err = nullptr;
+  int* d_pose_off = nullptr; int* d_pose_edges = nullptr; uint8_t* d_level = nullptr; double* d_err = nullptr; double* d_ow = nullptr;
   double* d_poses[2] = {nullptr, nullptr}; double* d_pts[2] = {nullptr, nullptr};
   double* d_poses0 = nullptr; double* d_pts0 = nullptr;
   double* d_Hpp = nullptr; double* d_bp = nullptr; double* d_Hll = nullptr; double* d_bl = nullptr; double* d_Hpl = nullptr;
@@ -114,7 +114,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_TRY(ba_alloc(b, &b->d_fixed, K)); BA_TRY(ba_alloc(b, &b->d_pose_slot, K)); BA_TRY(ba_alloc(b, &b->d_e_pose, E));
   BA_TRY(ba_alloc(b, &b->d_e_point, E)); BA_TRY(ba_alloc(b, &b->d_e_obs, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_inv, E));
   BA_TRY(ba_alloc(b, &b->d_e_face, E)); BA_TRY(ba_alloc(b, &b->d_pt_off, P + 1)); BA_TRY(ba_alloc(b, &b->d_pose_off, K + 1));
-  BA_TRY(ba_alloc(b, &b->d_pose_edges, E)); BA_TRY(ba_alloc(b, &b->d_level, E)); BA_TRY(ba_alloc(b, &b->d_err, 2 * (size_t)E));
+  BA_TRY(ba_alloc(b, &b->d_pose_edges, E)); BA_TRY(ba_alloc(b, &b->d_level, E)); BA_TRY(ba_alloc(b, &b->d_err, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_ow, (size_t)E));
   for (int i = 0; i < 2; ++i) { BA_TRY(ba_alloc(b, &b->d_poses[i], 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts[i], 3 * (size_t)P)); }
   BA_TRY(ba_alloc(b, &b->d_poses0, 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts0, 3 * (size_t)P));
   BA_TRY(ba_alloc(b, &b->d_Hpp, 36 * (size_t)std::max(np, 1))); BA_TRY(ba_alloc(b, &b->d_bp, 6 * (size_t)std::max(np, 1)));
@@ -309,7 +309,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BaDev& d = b->d;
   d.K = K; d.P = P; d.E = E; d.np = np; d.fixed = b->d_fixed; d.pose_slot = b->d_pose_slot; d.e_pose = b->d_e_pose;
   d.e_point = b->d_e_point; d.e_obs = b->d_e_obs; d.e_inv = b->d_e_inv; d.e_face = b->d_e_face; d.pt_off = b->d_pt_off;
-  d.pose_off = b->d_pose_off; d.pose_edges = b->d_pose_edges; d.level = b->d_level; d.err = b->d_err;
+  d.pose_off = b->d_pose_off; d.pose_edges = b->d_pose_edges; d.level = b->d_level; d.err = b->d_err; d.ow = b->d_ow;
   d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
   int rc = cms_ba_reset(b);
   if (rc) { cms_ba_destroy(b); return rc; }

@@ -296,7 +296,9 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                   const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
                   const double* __restrict__ poses_new, int robust, double delta, double* __restrict__ partial,
-                  const double* __restrict__ Hll = nullptr) {
+                  const double* __restrict__ Hll = nullptr, const double* __restrict__ poses_cur = nullptr) {
+  // poses_cur != nullptr: B^T xp of an edge is evaluated from its Jacobians at the linearisation point and the stored weight
+  // (Jl^T ow (Jp xp)) instead of reading the 6x3 block
   // Hll != nullptr: (Hll + lambda I)^-1 is evaluated here (same arithmetic as k_ba_dinv) and `Dinv` is not read -- the batched
   // driver then needs no separate inversion kernel
   __shared__ double sh[16];
@@ -311,18 +313,39 @@ __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, co
       ++nact;
       const int s = d.pose_slot[d.e_pose[a]];
       if (s < 0) continue;
-      const double* B = Hpl + 18 * (size_t)a;
-      for (int j = 0; j < 3; ++j)
-        for (int i = 0; i < 6; ++i) cl[j] -= B[3 * i + j] * xp[6 * s + i];
+      if (poses_cur) {
+        const double* pose = poses_cur + 7 * d.e_pose[a];
+        double R[9], Xc[3], Jp[12], Jl[6];
+        quat_to_R(pose + 3, R);
+        cam_point(pose, R, pts + 3 * (size_t)p, Xc);
+        edge_jac(d, a, Xc, R, Jp, Jl);
+        double t0 = 0, t1 = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { t0 += Jp[i] * xp[6 * s + i]; t1 += Jp[6 + i] * xp[6 * s + i]; }
+        const double ow = d.ow[a];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cl[j] -= ow * (Jl[j] * t0 + Jl[3 + j] * t1);
+      } else {
+        const double2* q = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)a);   // nine 16-byte loads (see ba_lin_points_body)
+        double B[18];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const double2 u = q[i]; B[2 * i] = u.x; B[2 * i + 1] = u.y; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) cl[j] -= B[3 * i + j] * xp[6 * s + i];
+      }
     }
     double Dl[9];
     if (Hll) {
       double D[9];
+#pragma unroll
       for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
       inv3(D, Dl);
     }
     const double* Di = Hll ? Dl : Dinv + 9 * (size_t)p;
     double X[3];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       const double xl = nact > 0 ? Di[3 * i] * cl[0] + Di[3 * i + 1] * cl[1] + Di[3 * i + 2] * cl[2] : 0.0;
       X[i] = pts[3 * (size_t)p + i] + xl;
@@ -336,7 +359,7 @@ __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, co
       quat_to_R(pose + 3, R);
       cam_point(pose, R, X, Xc);
       edge_error(d, e, Xc, r);
-      d.err[2 * e] = r[0]; d.err[2 * e + 1] = r[1];
+      reinterpret_cast<double2*>(d.err)[e] = make_double2(r[0], r[1]);
       const double c2 = d.e_inv[e] * (r[0] * r[0] + r[1] * r[1]);
       if (robust) { huber_w(c2, delta, &rho0); chi += rho0; } else chi += c2;
     }

@@ -25,6 +25,8 @@ struct BaDev {
   const int* pose_off; const int* pose_edges;  // K+1 / E : edge ids per pose
   uint8_t* level;                  // E: 0 active, 1 excluded
   double* err;                     // E x 2 (persistent, refreshed only for active edges)
+  double* ow;                      // E: robust weight x information of the last linearisation (0 for excluded edges): with it the 6x3
+                                   // pose-point block of an edge can be rebuilt from the estimate instead of being stored (144 B / edge)
   double fx, fy, cx, cy;
 };
 
@@ -77,23 +79,60 @@ __device__ __forceinline__ double huber_w(double e2, double delta, double* rho0)
   *rho0 = 2 * s * delta - dsqr;
   return delta / s;
 }
-__device__ __forceinline__ void edge_jac(const BaDev& d, int e, const double* Xc, const double* R, double* Jp, double* Jl) {
-  double Rf[9], l[3];
-  face_R(d.e_face[e], Rf);
-  for (int i = 0; i < 3; ++i) l[i] = Rf[3 * i] * Xc[0] + Rf[3 * i + 1] * Xc[1] + Rf[3 * i + 2] * Xc[2];
+// Jacobians of the multi-pinhole reprojection (g2o_cubemap_vertices_edges.cpp:164-233): Jp (2x6, [rotation | translation]) and
+// Jl (2x3).  The reference multiplies dense 3x3 matrices; R_face is a signed permutation, so its products are picked apart here, the
+// four divisions by z share one reciprocal and mul+add pairs may contract to FMAs.  The linearisation is outside the bit-exact part
+// (updates within 1e-4); the residual (edge_error) is not touched by any of this.
+__device__ __forceinline__ void edge_jac_face(const BaDev& d, int face, const double* Xc, const double* R, double* Jp, double* Jl) {
+#pragma clang fp contract(fast)
+  double l[3];
+  face_local(face, Xc, l);
   const double iz = 1.0 / l[2];
-  const double G[6] = {d.fx / l[2], 0, -d.fx * l[0] / (l[2] * l[2]), 0, d.fy / l[2], -d.fy * l[1] / (l[2] * l[2])};
-  (void)iz;
+  const double g00 = d.fx * iz, g11 = d.fy * iz, g02 = -(g00 * l[0]) * iz, g12 = -(g11 * l[1]) * iz;   // G = [g00 0 g02; 0 g11 g12]
+  // M = -(G * R_face): the face-frame gradient carried back to the camera frame
   double M[6];
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 3; ++j) M[3 * i + j] = -1.0 * (G[3 * i] * Rf[j] + G[3 * i + 1] * Rf[3 + j] + G[3 * i + 2] * Rf[6 + j]);
-  const double S[9] = {0, Xc[2], -Xc[1], -Xc[2], 0, Xc[0], Xc[1], -Xc[0], 0};
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 3; ++j) {
-      Jp[6 * i + j] = M[3 * i] * S[j] + M[3 * i + 1] * S[3 + j] + M[3 * i + 2] * S[6 + j];
-      Jp[6 * i + 3 + j] = M[3 * i + j];
-      Jl[3 * i + j] = M[3 * i] * R[j] + M[3 * i + 1] * R[3 + j] + M[3 * i + 2] * R[6 + j];
-    }
+  switch (face) {
+    case 0: M[0] = -g00; M[1] = 0.0; M[2] = -g02; M[3] = 0.0; M[4] = -g11; M[5] = -g12; break;
+    case 1: M[0] = g02; M[1] = 0.0; M[2] = -g00; M[3] = g12; M[4] = -g11; M[5] = 0.0; break;
+    case 2: M[0] = -g02; M[1] = 0.0; M[2] = g00; M[3] = -g12; M[4] = -g11; M[5] = 0.0; break;
+    case 3: M[0] = -g00; M[1] = g02; M[2] = 0.0; M[3] = 0.0; M[4] = g12; M[5] = -g11; break;
+    default: M[0] = -g00; M[1] = -g02; M[2] = 0.0; M[3] = 0.0; M[4] = -g12; M[5] = g11; break;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double m0 = M[3 * i], m1 = M[3 * i + 1], m2 = M[3 * i + 2];
+    Jp[6 * i] = m2 * Xc[1] - m1 * Xc[2];            // M * [Xc]x, the skew matrix written out
+    Jp[6 * i + 1] = m0 * Xc[2] - m2 * Xc[0];
+    Jp[6 * i + 2] = m1 * Xc[0] - m0 * Xc[1];
+    Jp[6 * i + 3] = m0; Jp[6 * i + 4] = m1; Jp[6 * i + 5] = m2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Jl[3 * i + j] = m0 * R[j] + m1 * R[3 + j] + m2 * R[6 + j];
+  }
+}
+
+__device__ __forceinline__ void edge_jac(const BaDev& d, int e, const double* Xc, const double* R, double* Jp, double* Jl) {
+  edge_jac_face(d, d.e_face[e], Xc, R, Jp, Jl);
+}
+// Hpl block of edge e (6x3, row major) rebuilt from the estimate the system was linearised at and the stored weight ow[e]:
+// B = ow * Jp^T Jl.  Zero for excluded edges and fixed poses, like the stored block.
+__device__ __forceinline__ void edge_block(const BaDev& d, int e, const double* __restrict__ poses, const double* __restrict__ pts, double* Bv) {
+#pragma clang fp contract(fast)
+  const int k = d.e_pose[e];
+  const double ow = d.ow[e];
+  if (d.pose_slot[k] < 0 || ow == 0.0) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) Bv[i] = 0.0;
+    return;
+  }
+  const double* pose = poses + 7 * k;
+  double R[9], Xc[3], Jp[12], Jl[6];
+  quat_to_R(pose + 3, R);
+  cam_point(pose, R, pts + 3 * (size_t)d.e_point[e], Xc);
+  edge_jac(d, e, Xc, R, Jp, Jl);
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Bv[3 * i + j] = ow * (Jp[i] * Jl[j] + Jp[6 + i] * Jl[3 + j]);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -119,7 +158,7 @@ __device__ __forceinline__ void ba_errors_body(int BX, int GX, BaDev d, const do
     quat_to_R(pose + 3, R);
     cam_point(pose, R, pts + 3 * d.e_point[e], Xc);
     edge_error(d, e, Xc, r);
-    d.err[2 * e] = r[0]; d.err[2 * e + 1] = r[1];
+    reinterpret_cast<double2*>(d.err)[e] = make_double2(r[0], r[1]);
     const double c2 = d.e_inv[e] * (r[0] * r[0] + r[1] * r[1]);
     if (robust) huber_w(c2, delta, &rho0); else rho0 = c2;
   }
@@ -137,18 +176,26 @@ __device__ __forceinline__ void ba_reduce_body(int BX, int GX, const double* __r
 // ---- per-point blocks: Hll (3x3), bl, Hpl per edge (6x3); one thread per point over its (point-sorted) edges
 __device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
                 double* __restrict__ Hll, double* __restrict__ bl, double* __restrict__ Hpl) {
+#pragma clang fp contract(fast)                       // block accumulation: FMAs allowed (not part of the bit-exact surface)
   const int p = BX * blockDim.x + threadIdx.x;
   if (p >= d.P) return;
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   for (int e = d.pt_off[p]; e < d.pt_off[p + 1]; ++e) {
-    double* B = Hpl + 18 * (size_t)e;
-    if (d.level[e] != 0) { for (int i = 0; i < 18; ++i) B[i] = 0; continue; }
+    // the 6x3 block leaves as nine 16-byte stores: a lane's blocks are 144 B apart from its neighbour's, so the request count, not the
+    // byte count, bounds these kernels (8-byte accesses doubled it)
+    double2* B2v = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+    if (d.level[e] != 0) {
+      d.ow[e] = 0.0;
+      if (Hpl) for (int i = 0; i < 9; ++i) B2v[i] = make_double2(0.0, 0.0);
+      continue;
+    }
     const double* pose = poses + 7 * d.e_pose[e];
     double R[9], Xc[3], Jp[12], Jl[6];
     quat_to_R(pose + 3, R);
     cam_point(pose, R, pts + 3 * p, Xc);
     edge_jac(d, e, Xc, R, Jp, Jl);
-    const double r0 = d.err[2 * e], r1 = d.err[2 * e + 1], om = d.e_inv[e];
+    const double2 rr = reinterpret_cast<const double2*>(d.err)[e];
+    const double r0 = rr.x, r1 = rr.y, om = d.e_inv[e];
     double w = 1.0, rho0;
     if (robust) w = huber_w(om * (r0 * r0 + r1 * r1), delta, &rho0);
     const double ow = w * om;
@@ -157,9 +204,14 @@ __device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, cons
       b[i] += Jl[i] * o0 + Jl[3 + i] * o1;
       for (int j = 0; j < 3; ++j) H[3 * i + j] += ow * (Jl[i] * Jl[j] + Jl[3 + i] * Jl[3 + j]);
     }
-    const bool free_pose = d.pose_slot[d.e_pose[e]] >= 0;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 3; ++j) B[3 * i + j] = free_pose ? ow * (Jp[i] * Jl[j] + Jp[6 + i] * Jl[3 + j]) : 0.0;
+    d.ow[e] = ow;
+    if (Hpl) {                                    // Hpl == nullptr: the trial kernels rebuild the block from ow and the estimate instead of reading it
+      const bool free_pose = d.pose_slot[d.e_pose[e]] >= 0;
+      double Bv[18];
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 3; ++j) Bv[3 * i + j] = free_pose ? ow * (Jp[i] * Jl[j] + Jp[6 + i] * Jl[3 + j]) : 0.0;
+      for (int i = 0; i < 9; ++i) B2v[i] = make_double2(Bv[2 * i], Bv[2 * i + 1]);
+    }
   }
   for (int i = 0; i < 9; ++i) Hll[9 * (size_t)p + i] = H[i];
   for (int i = 0; i < 3; ++i) bl[3 * (size_t)p + i] = b[i];
@@ -172,6 +224,7 @@ __device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, cons
 template <int N, int H> __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, int off);   // defined below
 __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
                double* __restrict__ pose_partial, int ch_arg = -1) {
+#pragma clang fp contract(fast)
   __shared__ double sh[16][27];
   const int k = BX, ch = ch_arg >= 0 ? ch_arg : (int)blockIdx.y;
   __syncthreads();                                  // a previous virtual block of the same workgroup may still read sh
@@ -191,7 +244,8 @@ __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const
     double Xc[3], Jp[12], Jl[6];
     cam_point(pose, R, pts + 3 * d.e_point[e], Xc);
     edge_jac(d, e, Xc, R, Jp, Jl);
-    const double r0 = d.err[2 * e], r1 = d.err[2 * e + 1], om = d.e_inv[e];
+    const double2 rr = reinterpret_cast<const double2*>(d.err)[e];
+    const double r0 = rr.x, r1 = rr.y, om = d.e_inv[e];
     double w = 1.0, rho0;
     if (robust) w = huber_w(om * (r0 * r0 + r1 * r1), delta, &rho0);
     const double ow = w * om;
@@ -319,8 +373,13 @@ __device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDev d, co
     if (d.level[aa.x] == 0 && d.level[aa.y] == 0) {
       const int p = d.e_point[aa.x];
       const double* Di = Dinv + 9 * (size_t)p;
-      const double* B1 = Hpl + 18 * (size_t)aa.x;
-      const double* B2 = Hpl + 18 * (size_t)aa.y;
+      double B1[18], B2[18];
+      {
+        const double2* q1 = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)aa.x);
+        const double2* q2 = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)aa.y);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const double2 u = q1[i], v = q2[i]; B1[2 * i] = u.x; B1[2 * i + 1] = u.y; B2[2 * i] = v.x; B2[2 * i + 1] = v.y; }
+      }
       double BD[18];
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -522,7 +581,11 @@ k_ba_backsub(BaDev d, const double* __restrict__ bl, const double* __restrict__ 
       ++nact;
       const int s = d.pose_slot[d.e_pose[a]];
       if (s < 0) continue;
-      const double* B = Hpl + 18 * (size_t)a;
+      double B[18];
+      {
+        const double2* q = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)a);
+        for (int i = 0; i < 9; ++i) { const double2 u = q[i]; B[2 * i] = u.x; B[2 * i + 1] = u.y; }
+      }
       for (int j = 0; j < 3; ++j)
         for (int i = 0; i < 6; ++i) cl[j] -= B[3 * i + j] * xp[6 * s + i];
     }

@@ -19,8 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef BA_SP_MAXE
 #define BA_SP_MAXE 208            /* edges per batch (< 256: 8-bit local ids): 208 x (18 + 18 + 6) doubles = 68 KB of LDS */
 #define BA_SP_MAXT 512            /* tuples per batch: their 16-bit words (1 KB) and the per-slot offsets are staged in LDS too */
+#endif
 #define BA_SP_ROW 42              /* doubles per staged edge: B (18) | BD (18) | rb (6) */
 #define BA_SP_MAX_THREADS 512
 #ifndef BA_SP_RANGES
@@ -42,7 +44,9 @@ struct BaSp {                      // device view of the host-built work lists (
 
 __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                      const double* __restrict__ db, const double* __restrict__ Hll = nullptr,
-                                                     const double* __restrict__ bl = nullptr, double lambda = 0.0) {
+                                                     const double* __restrict__ bl = nullptr, double lambda = 0.0,
+                                                     const double* __restrict__ poses = nullptr, const double* __restrict__ pts = nullptr) {
+  // poses != nullptr: the 6x3 block of an edge is rebuilt from the estimate and the stored weight (edge_block) instead of being read
   // Hll != nullptr: the staging thread inverts (Hll + lambda I) of its edge's point itself (same arithmetic as k_ba_dinv; a
   // point's k edges repeat it, which is cheaper than a separate kernel) and Dinv / db are not read
   extern __shared__ __align__(16) double sp_lds[];      // [BA_SP_MAXE][42], reused at the end for the helper sums
@@ -67,9 +71,13 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
     mine = tid < ne;
     if (mine) {
       const int e = e0 + tid, p = d.e_point[e];
-      const double* B = Hpl + 18 * (size_t)e;
+      if (poses) {
+        edge_block(d, e, poses, pts, Bv);
+      } else {
+        const double2* B = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)e);   // nine 16-byte loads
 #pragma unroll
-      for (int i = 0; i < 18; ++i) Bv[i] = B[i];
+        for (int i = 0; i < 9; ++i) { const double2 u = B[i]; Bv[2 * i] = u.x; Bv[2 * i + 1] = u.y; }
+      }
       if (Hll) {
         double D[9];
 #pragma unroll
@@ -89,9 +97,17 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
       }
     }
   };
+#ifdef BA_SP_CLK
+  long long ck[6] = {0, 0, 0, 0, 0, 0}; long long c0 = wall_clock64(), c1;
+#define SPCK(i) { c1 = wall_clock64(); ck[i] += c1 - c0; c0 = c1; }
+#else
+#define SPCK(i)
+#endif
   if (b0 < b1) fetch(b0);
+  SPCK(0)
   for (int b = b0; b < b1; ++b) {
     __syncthreads();                                     // readers of the previous batch are done
+    SPCK(1)
     if (tid < BA_SP_MAXT / 2) reinterpret_cast<uint32_t*>(ltup)[tid] = tw;
     if (tid < sp.off_stride) reinterpret_cast<uint32_t*>(loff)[tid] = ow;
     if (mine) {
@@ -107,7 +123,9 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
       }
     }
     __syncthreads();
+    SPCK(2)
     if (b + 1 < b1) fetch(b + 1);
+    SPCK(3)
     const int l0 = have ? loff[tid] : 0, l1 = have ? loff[tid + 1] : 0;
     for (int t = l0; t < l1; ++t) {
       const int w = ltup[t];
@@ -128,6 +146,10 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
       }
     }
   }
+  SPCK(4)
+#ifdef BA_SP_CLK
+  if (BX == 0 && tid == 0 && blockIdx.z == 0) printf("SPCLK fetch0 %lld sync %lld stage %lld fetch %lld tuples %lld (x10ns) batches %d nslots %d\n", ck[0], ck[1], ck[2], ck[3], ck[4], b1 - b0, sp.nslots);
+#endif
   // ---- this range's slice of `partial`: an off-diagonal pair has a single owner which writes its vector directly; the helper
   // slots of the diagonal pairs are added in LDS first (fixed order)
   __syncthreads();

@@ -153,7 +153,8 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce(const BaItem* __r
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_lin_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
-  ba_lin_points_body(blockIdx.x, it.nblk_p, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.Hll, it.bl, it.Hpl);
+  ba_lin_points_body(blockIdx.x, it.nblk_p, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.Hll, it.bl,
+                     it.sp.R > 0 ? nullptr : it.Hpl);   // per-point Schur path: blocks are rebuilt on the fly, only the weights are stored
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_lin_poses(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.d.K)        // blockIdx.y = slice of the pose's edge list
@@ -197,7 +198,7 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaIte
 }
 extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS) kb_ba_schur_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R)
-  ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db, it.Hll, it.bl, ba_lambda);   // inverts Hll + lambda I itself
+  ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur]);   // inverts Hll + lambda I itself
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R > 0 ? it.sp.npairs : 0)
@@ -211,7 +212,7 @@ extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
   ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
-                       dyn.delta, it.partial, it.sp.R > 0 ? it.Hll : nullptr);
+                       dyn.delta, it.partial, it.sp.R > 0 ? it.Hll : nullptr, it.sp.R > 0 ? it.poses[cur] : nullptr);
 }
 // last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
 extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
