@@ -256,7 +256,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
         sp.bat_e0 = b->d_sp_bat_e0; sp.off32 = b->d_sp_off; sp.tup32 = b->d_sp_list; sp.tup_base = b->d_sp_tup_base; sp.off_stride = off_stride;
         sp.slot_pair = b->d_sp_slot_pair;
         sp.pair_slots = b->d_sp_pair_slots; sp.partial = b->d_sp_partial;
-        b->sp_threads = std::max((nslots + 63) / 64 * 64, (BA_SP_MAXE + 63) / 64 * 64);   // >= BA_SP_MAXE: one staged edge per thread
+        b->sp_threads = (nslots + 63) / 64 * 64 + BA_SP_STAGERS;   // owner wavefronts + the staging team
         b->sp_lds = (size_t)BA_SP_MAXE * BA_SP_ROW * sizeof(double) + BA_SP_MAXT * 2 + (BA_SP_MAX_THREADS + 4) * 2;
         BA_HIP(hipFuncSetAttribute((const void*)k_ba_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->sp_lds));
         BA_HIP(hipFuncSetAttribute((const void*)kb_ba_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->sp_lds));

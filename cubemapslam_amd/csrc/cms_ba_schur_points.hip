@@ -24,7 +24,8 @@
 #define BA_SP_MAXT 512            /* tuples per batch: their 16-bit words (1 KB) and the per-slot offsets are staged in LDS too */
 #endif
 #define BA_SP_ROW 42              /* doubles per staged edge: B (18) | BD (18) | rb (6) */
-#define BA_SP_MAX_THREADS 512
+#define BA_SP_MAX_THREADS 512     /* owner threads (slots) at most */
+#define BA_SP_STAGERS 256         /* + four wavefronts that only stage the next batch (>= BA_SP_MAXE: one edge per thread) */
 #ifndef BA_SP_RANGES
 #define BA_SP_RANGES 64           /* workgroups per window (each walks nbat / 64 batches) */
 #endif
@@ -50,14 +51,19 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
   // Hll != nullptr: the staging thread inverts (Hll + lambda I) of its edge's point itself (same arithmetic as k_ba_dinv; a
   // point's k edges repeat it, which is cheaper than a separate kernel) and Dinv / db are not read
   extern __shared__ __align__(16) double sp_lds[];      // [BA_SP_MAXE][42], reused at the end for the helper sums
+  // Two kinds of wavefronts: the first blockDim - BA_SP_STAGERS threads own pose pairs and multiply tuples; the last BA_SP_STAGERS
+  // threads do nothing but fetch / rebuild the edges of the NEXT batch (their loads and Jacobians run while the owners multiply) and
+  // copy them into LDS between the two barriers.
   const int tid = threadIdx.x;
+  const int sid = tid - ((int)blockDim.x - BA_SP_STAGERS);     // >= 0: stager, lane sid of the staging team
+  const bool stager = sid >= 0;
   const bool have = tid < sp.nslots;
   double acc[42];
 #pragma unroll
   for (int i = 0; i < 42; ++i) acc[i] = 0;
   const int b0 = BX * sp.bpw, b1 = min(sp.nbat, b0 + sp.bpw);
-  // staging is software pipelined: blockDim >= BA_SP_MAXE, so a thread stages at most ONE edge per batch; the global loads of
-  // batch b + 1 are issued right after batch b went to LDS and travel while the tuples of batch b are multiplied
+  // staging is software pipelined: BA_SP_STAGERS >= BA_SP_MAXE, so a stager handles at most ONE edge per batch; batch b + 1 is fetched
+  // (rebuilt) by the stagers while the owners multiply the tuples of batch b
   double Bv[18], Dv[9], dv[3];
   uint32_t tw = 0, ow = 0;
   bool mine = false;
@@ -65,12 +71,12 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
   uint16_t* loff = ltup + BA_SP_MAXT;
   auto fetch = [&](int bb) {
     const int tb = sp.tup_base[bb], ntw = sp.tup_base[bb + 1] - tb;
-    tw = tid < ntw ? sp.tup32[tb + tid] : 0u;
-    ow = tid < sp.off_stride ? sp.off32[(size_t)bb * sp.off_stride + tid] : 0u;
+    tw = sid < ntw ? sp.tup32[tb + sid] : 0u;
+    ow = sid < sp.off_stride ? sp.off32[(size_t)bb * sp.off_stride + sid] : 0u;
     const int e0 = sp.bat_e0[bb], ne = sp.bat_e0[bb + 1] - e0;
-    mine = tid < ne;
+    mine = sid < ne;
     if (mine) {
-      const int e = e0 + tid, p = d.e_point[e];
+      const int e = e0 + sid, p = d.e_point[e];
       if (poses) {
         edge_block(d, e, poses, pts, Bv);
       } else {
@@ -97,59 +103,56 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
       }
     }
   };
-#ifdef BA_SP_CLK
-  long long ck[6] = {0, 0, 0, 0, 0, 0}; long long c0 = wall_clock64(), c1;
-#define SPCK(i) { c1 = wall_clock64(); ck[i] += c1 - c0; c0 = c1; }
-#else
-#define SPCK(i)
-#endif
-  if (b0 < b1) fetch(b0);
-  SPCK(0)
-  for (int b = b0; b < b1; ++b) {
-    __syncthreads();                                     // readers of the previous batch are done
-    SPCK(1)
-    if (tid < BA_SP_MAXT / 2) reinterpret_cast<uint32_t*>(ltup)[tid] = tw;
-    if (tid < sp.off_stride) reinterpret_cast<uint32_t*>(loff)[tid] = ow;
-    if (mine) {
-      double* row = sp_lds + (size_t)tid * BA_SP_ROW;
+  // The two teams run their own loops (the register allocator then sees each role on its own: the owners' 42 accumulators and the
+  // stagers' rebuilt blocks never have to be live together).  Both execute exactly two barriers per batch:
+  //   A  the owners have finished the tuples of the previous batch     -> the stagers may overwrite the rows
+  //   B  the rows, tuple words and offsets of this batch are in LDS     -> the owners may read them
+  if (stager) {
+    if (b0 < b1) fetch(b0);
+    for (int b = b0; b < b1; ++b) {
+      __syncthreads();                                   // A
+      if (sid < BA_SP_MAXT / 2) reinterpret_cast<uint32_t*>(ltup)[sid] = tw;
+      if (sid < sp.off_stride) reinterpret_cast<uint32_t*>(loff)[sid] = ow;
+      if (mine) {
+        double* row = sp_lds + (size_t)sid * BA_SP_ROW;
 #pragma unroll
-      for (int i = 0; i < 18; ++i) row[i] = Bv[i];
+        for (int i = 0; i < 18; ++i) row[i] = Bv[i];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          row[18 + 3 * i + j] = __builtin_fma(Bv[3 * i + 2], Dv[6 + j], __builtin_fma(Bv[3 * i + 1], Dv[3 + j], Bv[3 * i] * Dv[j]));
-        row[36 + i] = __builtin_fma(Bv[3 * i + 2], dv[2], __builtin_fma(Bv[3 * i + 1], dv[1], Bv[3 * i] * dv[0]));
+          for (int j = 0; j < 3; ++j)
+            row[18 + 3 * i + j] = __builtin_fma(Bv[3 * i + 2], Dv[6 + j], __builtin_fma(Bv[3 * i + 1], Dv[3 + j], Bv[3 * i] * Dv[j]));
+          row[36 + i] = __builtin_fma(Bv[3 * i + 2], dv[2], __builtin_fma(Bv[3 * i + 1], dv[1], Bv[3 * i] * dv[0]));
+        }
       }
+      __syncthreads();                                   // B
+      if (b + 1 < b1) fetch(b + 1);                      // travels / is rebuilt while the owners multiply batch b
     }
-    __syncthreads();
-    SPCK(2)
-    if (b + 1 < b1) fetch(b + 1);
-    SPCK(3)
-    const int l0 = have ? loff[tid] : 0, l1 = have ? loff[tid + 1] : 0;
-    for (int t = l0; t < l1; ++t) {
-      const int w = ltup[t];
-      const int a1 = w & 0xFF, a2 = w >> 8;
-      const double* r1 = sp_lds + (size_t)a1 * BA_SP_ROW + 18;     // BD of the first edge
-      const double* r2 = sp_lds + (size_t)a2 * BA_SP_ROW;          // B of the second
-      double bd[18], b2[18];
+  } else {
+    for (int b = b0; b < b1; ++b) {
+      __syncthreads();                                   // A
+      __syncthreads();                                   // B
+      const int l0 = have ? loff[tid] : 0, l1 = have ? loff[tid + 1] : 0;
+      for (int t = l0; t < l1; ++t) {
+        const int w = ltup[t];
+        const int a1 = w & 0xFF, a2 = w >> 8;
+        const double* r1 = sp_lds + (size_t)a1 * BA_SP_ROW + 18;     // BD of the first edge
+        const double* r2 = sp_lds + (size_t)a2 * BA_SP_ROW;          // B of the second
+        double bd[18], b2[18];
 #pragma unroll
-      for (int i = 0; i < 18; ++i) { bd[i] = r1[i]; b2[i] = r2[i]; }
+        for (int i = 0; i < 18; ++i) { bd[i] = r1[i]; b2[i] = r2[i]; }
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          acc[6 * i + j] = __builtin_fma(bd[3 * i + 2], b2[3 * j + 2], __builtin_fma(bd[3 * i + 1], b2[3 * j + 1], __builtin_fma(bd[3 * i], b2[3 * j], acc[6 * i + j])));
-      if (a1 == a2) {
+          for (int j = 0; j < 6; ++j)
+            acc[6 * i + j] = __builtin_fma(bd[3 * i + 2], b2[3 * j + 2], __builtin_fma(bd[3 * i + 1], b2[3 * j + 1], __builtin_fma(bd[3 * i], b2[3 * j], acc[6 * i + j])));
+        if (a1 == a2) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[36 + i] += r1[18 + i];     // rb sits right behind BD
+          for (int i = 0; i < 6; ++i) acc[36 + i] += r1[18 + i];     // rb sits right behind BD
+        }
       }
     }
   }
-  SPCK(4)
-#ifdef BA_SP_CLK
-  if (BX == 0 && tid == 0 && blockIdx.z == 0) printf("SPCLK fetch0 %lld sync %lld stage %lld fetch %lld tuples %lld (x10ns) batches %d nslots %d\n", ck[0], ck[1], ck[2], ck[3], ck[4], b1 - b0, sp.nslots);
-#endif
   // ---- this range's slice of `partial`: an off-diagonal pair has a single owner which writes its vector directly; the helper
   // slots of the diagonal pairs are added in LDS first (fixed order)
   __syncthreads();

@@ -69,7 +69,7 @@ extern "C" __global__ void __launch_bounds__(256)
 k_ba_schur_chunks(BaDev d, const int2* chunk_range, const int2* tup, const double* Hpl, const double* Dinv, const double* db, double* chunk_sum) {
   ba_schur_chunks_body(blockIdx.x, gridDim.x, d, chunk_range, tup, Hpl, Dinv, db, chunk_sum);
 }
-extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS)
+extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS + BA_SP_STAGERS) __attribute__((amdgpu_waves_per_eu(1, 3)))
 k_ba_schur_points(BaDev d, BaSp sp, const double* Hpl, const double* Dinv, const double* db) { ba_schur_points_body(blockIdx.x, d, sp, Hpl, Dinv, db); }
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_schur_reduce(BaSp sp, double* pair_sum) { ba_schur_reduce_body(blockIdx.x, sp, pair_sum); }
@@ -196,7 +196,7 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_chunks(const BaIte
   BA_ITEM(phase, it.nchunks)
   ba_schur_chunks_body(blockIdx.x, it.nchunks, it.d, it.chunk_range, it.tup, it.Hpl, it.Dinv, it.db, it.chunk_sum);
 }
-extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS) kb_ba_schur_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS + BA_SP_STAGERS) __attribute__((amdgpu_waves_per_eu(1, 3))) kb_ba_schur_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R)
   ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur]);   // inverts Hll + lambda I itself
 }
