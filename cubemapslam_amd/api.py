@@ -111,6 +111,8 @@ def lib():
         L.cms_kfstore_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cms_kfstore_update.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.cms_kfstore_create_new_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.cms_distinctive_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_update_normal_and_depth.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         L.cms_fuse_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
         L.cms_pose_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cms_pose_destroy.argtypes = [C.c_void_p]
@@ -438,6 +440,20 @@ class KeyframeStore:
         _chk(lib().cms_kfstore_create_new_map_points(self.h, nj, _p(cur), _p(off), _p(neigh), int(check_orientation), cap, _p(n_new), _p(on), _p(o1), _p(o2),
                                                      _p(ox)), "cms_kfstore_create_new_map_points")
         return [(on[j, :n_new[j]].copy(), o1[j, :n_new[j]].copy(), o2[j, :n_new[j]].copy(), ox[j, :n_new[j]].copy()) for j in range(nj)]
+
+
+def distinctive_descriptors(ctx, obs_off, desc):
+    obs_off = np.ascontiguousarray(obs_off, np.int32); desc = np.ascontiguousarray(desc, np.uint8)
+    out = np.zeros(len(obs_off) - 1, np.int32)
+    _chk(lib().cms_distinctive_descriptors(ctx.h, len(out), _p(obs_off), _p(desc), _p(out)), "cms_distinctive_descriptors")
+    return out
+
+
+def update_normal_and_depth(ctx, obs_off, pos, obs_Ow, ref_Ow, ref_level, normal, min_dist, max_dist):
+    """normal / min_dist / max_dist: float32 arrays updated in place"""
+    a = [np.ascontiguousarray(obs_off, np.int32), np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(obs_Ow, np.float32),
+         np.ascontiguousarray(ref_Ow, np.float32), np.ascontiguousarray(ref_level, np.int32)]
+    _chk(lib().cms_update_normal_and_depth(ctx.h, len(a[0]) - 1, *[_p(v) for v in a], _p(normal), _p(min_dist), _p(max_dist)), "cms_update_normal_and_depth")
 
 
 def fuse_search(ctx, b, pose15, skip, pos, normal, min_dist, max_dist, desc, th):

@@ -411,3 +411,73 @@ extern "C" int cms_fuse_search(cms_ctx* c, int b, const float* pose15, int nmp, 
   }
   return cms_fail(CMS_ERR_OVERFLOW, "cms_fuse_search: candidate lists kept growing");
 }
+
+// MapPoint::ComputeDistinctiveDescriptors for a batch of map points (host buffers)
+extern "C" int cms_distinctive_descriptors(cms_ctx* c, int npts, const int* obs_off, const uint8_t* desc, int* best_idx) {
+  if (!c || npts < 0 || (npts > 0 && (!obs_off || !best_idx))) return cms_fail(CMS_ERR_ARG, "cms_distinctive_descriptors: bad argument");
+  if (npts == 0) return CMS_OK;
+  const int nobs = obs_off[npts];
+  if (nobs < 0 || (nobs > 0 && !desc)) return cms_fail(CMS_ERR_ARG, "cms_distinctive_descriptors: bad observation list");
+  for (int p = 0; p < npts; ++p) {
+    if (obs_off[p + 1] < obs_off[p]) return cms_fail(CMS_ERR_ARG, "cms_distinctive_descriptors: obs_off must ascend");
+    if (obs_off[p + 1] - obs_off[p] > 65535) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_distinctive_descriptors: more than 65535 observations of one point");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  const size_t o_off = 0, o_desc = tri_al((size_t)(npts + 1) * 4), o_out = o_desc + tri_al((size_t)nobs * 32 + 32);
+  int rc = cms_scratch(c, o_out + tri_al((size_t)npts * 4));
+  if (rc) return rc;
+  uint8_t* p = (uint8_t*)c->d_match;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(p + o_off, obs_off, (size_t)(npts + 1) * 4, hipMemcpyHostToDevice, s));
+  if (nobs > 0) HIPCHK(hipMemcpyAsync(p + o_desc, desc, (size_t)nobs * 32, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_distinctive, dim3((npts + 3) / 4), dim3(256), 0, s, npts, (const int*)(p + o_off), (const uint4*)(p + o_desc), (int*)(p + o_out));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(best_idx, p + o_out, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CMS_OK;
+}
+
+// MapPoint::UpdateNormalAndDepth for a batch of map points (host buffers); points without observations keep their outputs untouched
+extern "C" int cms_update_normal_and_depth(cms_ctx* c, int npts, const int* obs_off, const float* pos, const float* obs_Ow, const float* ref_Ow,
+                                           const int* ref_level, float* normal, float* min_dist, float* max_dist) {
+  if (!c || npts < 0 || (npts > 0 && (!obs_off || !pos || !ref_Ow || !ref_level || !normal || !min_dist || !max_dist)))
+    return cms_fail(CMS_ERR_ARG, "cms_update_normal_and_depth: bad argument");
+  if (npts == 0) return CMS_OK;
+  const int nobs = obs_off[npts];
+  if (nobs < 0 || (nobs > 0 && !obs_Ow)) return cms_fail(CMS_ERR_ARG, "cms_update_normal_and_depth: bad observation list");
+  for (int p = 0; p < npts; ++p) {
+    if (obs_off[p + 1] < obs_off[p]) return cms_fail(CMS_ERR_ARG, "cms_update_normal_and_depth: obs_off must ascend");
+    if (ref_level[p] < 0 || ref_level[p] >= c->g.nlevels) return cms_fail(CMS_ERR_ARG, "cms_update_normal_and_depth: reference level out of range");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n4 = (size_t)npts * 4;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += tri_al(bytes + 16); return at; };
+  const size_t o_off = take(n4 + 4), o_pos = take(3 * n4), o_ow = take((size_t)nobs * 12), o_ref = take(3 * n4), o_lvl = take(n4), o_sf = take(64),
+               o_nrm = take(3 * n4), o_min = take(n4), o_max = take(n4);
+  int rc = cms_scratch(c, o);
+  if (rc) return rc;
+  uint8_t* p = (uint8_t*)c->d_match;
+  hipStream_t s = c->stream;
+  float sf[16];
+  for (int l = 0; l < 16; ++l) sf[l] = l < c->g.nlevels ? c->scale[l] : 1.0f;
+  HIPCHK(hipMemcpyAsync(p + o_off, obs_off, n4 + 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p + o_pos, pos, 3 * n4, hipMemcpyHostToDevice, s));
+  if (nobs > 0) HIPCHK(hipMemcpyAsync(p + o_ow, obs_Ow, (size_t)nobs * 12, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p + o_ref, ref_Ow, 3 * n4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p + o_lvl, ref_level, n4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p + o_sf, sf, sizeof(sf), hipMemcpyHostToDevice, s));
+  // outputs start from the caller's values so that points without observations come back unchanged
+  HIPCHK(hipMemcpyAsync(p + o_nrm, normal, 3 * n4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p + o_min, min_dist, n4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p + o_max, max_dist, n4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_update_normal_depth, dim3((npts + 255) / 256), dim3(256), 0, s, npts, (const int*)(p + o_off), (const float*)(p + o_pos),
+                     (const float*)(p + o_ow), (const float*)(p + o_ref), (const int*)(p + o_lvl), (const float*)(p + o_sf), c->g.nlevels,
+                     (float*)(p + o_nrm), (float*)(p + o_min), (float*)(p + o_max));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(normal, p + o_nrm, 3 * n4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(min_dist, p + o_min, n4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(max_dist, p + o_max, n4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CMS_OK;
+}

@@ -513,3 +513,61 @@ extern "C" __global__ void __launch_bounds__(256) k_fuse_scan(CmsFuseScanArgs a)
     best_dist[i] = hit ? d : 256;
   }
 }
+
+// ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cpp:243-308), one wavefront per map point.  Lane i owns observation i:
+// the median of its row of the distance matrix is found by bisection on the value (distances are integers in [0, 256]; the smallest v
+// with #(d <= v) > idx is sorted[idx]), each probe recomputing the row's Hamming distances from the descriptors (L1 resident);
+// then the wave keeps the smallest (median, i) -- "first one on ties", as `median < BestMedian` does.
+extern "C" __global__ void __launch_bounds__(256) k_distinctive(int npts, const int* __restrict__ obs_off, const uint4* __restrict__ desc,
+                                                                int* __restrict__ best_idx) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= npts) return;
+  const int o0 = obs_off[p], N = obs_off[p + 1] - o0;
+  if (N <= 0) { if (lane == 0) best_idx[p] = -1; return; }
+  const int idx = (int)(0.5 * (N - 1));
+  uint32_t best = 0xFFFFFFFFu;
+  for (int i = lane; i < N; i += 64) {
+    const uint4 a0 = desc[2 * (size_t)(o0 + i)], a1 = desc[2 * (size_t)(o0 + i) + 1];
+    int lo = 0, hi = 256;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      int cnt = 0;
+      for (int k = 0; k < N; ++k) {
+        const int d = k == i ? 0 : tri_hamming256(a0, a1, desc[2 * (size_t)(o0 + k)], desc[2 * (size_t)(o0 + k) + 1]);
+        cnt += d <= mid;
+      }
+      if (cnt > idx) hi = mid; else lo = mid + 1;
+    }
+    best = min(best, ((uint32_t)lo << 16) | (uint32_t)i);
+  }
+  for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+  if (lane == 0) best_idx[p] = (int)(best & 0xFFFFu);
+}
+
+// ---- MapPoint::UpdateNormalAndDepth (src/MapPoint.cpp:332-373), one thread per map point, observations in the caller's (std::map) order
+extern "C" __global__ void __launch_bounds__(256)
+k_update_normal_depth(int npts, const int* __restrict__ obs_off, const float* __restrict__ pos, const float* __restrict__ obs_Ow,
+                      const float* __restrict__ ref_Ow, const int* __restrict__ ref_level, const float* __restrict__ sf16, int nlevels,
+                      float* __restrict__ normal, float* __restrict__ min_dist, float* __restrict__ max_dist) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npts) return;
+  const int o0 = obs_off[p], o1 = obs_off[p + 1];
+  if (o1 <= o0) return;
+  const float P[3] = {pos[3 * (size_t)p], pos[3 * (size_t)p + 1], pos[3 * (size_t)p + 2]};
+  float nrm[3] = {0.0f, 0.0f, 0.0f};
+  for (int o = o0; o < o1; ++o) {
+    const float ni[3] = {__fsub_rn(P[0], obs_Ow[3 * (size_t)o]), __fsub_rn(P[1], obs_Ow[3 * (size_t)o + 1]), __fsub_rn(P[2], obs_Ow[3 * (size_t)o + 2])};
+    const float beta = (float)(1.0 / tri_dnorm3(ni));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nrm[k] = __fadd_rn(__fmul_rn(nrm[k], 1.0f), __fmul_rn(ni[k], beta));   // cv::addWeighted(normal, 1, normali, 1/norm)
+  }
+  const float PC[3] = {__fsub_rn(P[0], ref_Ow[3 * (size_t)p]), __fsub_rn(P[1], ref_Ow[3 * (size_t)p + 1]), __fsub_rn(P[2], ref_Ow[3 * (size_t)p + 2])};
+  const float dist = (float)tri_dnorm3(PC);
+  const float mx = __fmul_rn(dist, sf16[ref_level[p]]);
+  max_dist[p] = mx;
+  min_dist[p] = mx / sf16[nlevels - 1];
+  const float inv_n = (float)(1.0 / (double)(o1 - o0));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) normal[3 * (size_t)p + k] = __fmul_rn(nrm[k], inv_n);
+}

@@ -247,6 +247,15 @@ int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, const float*
 int cms_kfstore_create_new_map_points(cms_kfstore* st, int njobs, const int* cur_slot, const int* neigh_off, const int* neigh_slot,
                                       int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
                                       float* out_x3d);
+/* Per-map-point bookkeeping the mapping thread runs over the points it created, fused or optimised, batched:
+ * MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cpp:243-308): obs_off[npts+1] into the concatenated descriptors of each
+ * point's non-bad observations (std::map order); best_idx[p] = the observation whose descriptor has the least median distance to the
+ * rest (first on ties), -1 without observations.  MapPoint::UpdateNormalAndDepth (:332-373): obs_Ow = camera centres of the observing
+ * key frames (same order), ref_Ow / ref_level = centre of mpRefKF and octave of its observation; normal / min_dist / max_dist are
+ * in/out (points without observations stay untouched). */
+int cms_distinctive_descriptors(cms_ctx* ctx, int npts, const int* obs_off, const uint8_t* desc, int* best_idx);
+int cms_update_normal_and_depth(cms_ctx* ctx, int npts, const int* obs_off, const float* pos, const float* obs_Ow, const float* ref_Ow,
+                                const int* ref_level, float* normal, float* min_dist, float* max_dist);
 int cms_fuse_search(cms_ctx* ctx, int b, const float* pose15, int nmp, const uint8_t* skip, const float* pos, const float* normal,
                     const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, int* best_idx, int* best_dist);
 

@@ -133,6 +133,12 @@ void orc_fuse_search(const orc_camera* cam, const orc_keyframe* kf, int nmp, con
                      const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, const float* scale_factors,
                      const float* inv_level_sigma2, int nlevels, int* best_idx, int* best_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cpp:243-308) and MapPoint::UpdateNormalAndDepth (:332-373), batched over map points */
+void orc_distinctive_descriptors(int npts, const int* obs_off, const uint8_t* desc, int* best_idx);
+void orc_update_normal_and_depth(int npts, const int* obs_off, const float* pos, const float* obs_Ow, const float* ref_Ow,
+                                 const int* ref_level, const float* scale_factors, int nlevels, float* normal, float* min_dist,
+                                 float* max_dist);
+
 /* ---- ORBMatcher (ORBMatcher.cpp) ---- */
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
 /* best / second-best over CSR candidate lists, the inner loop of SearchByProjection (ORBMatcher.cpp:84-113) */

@@ -396,3 +396,57 @@ extern "C" void orc_fuse_search(const orc_camera* cam, const orc_keyframe* kf, i
     if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; best_dist[i] = bestDist; }
   }
 }
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cpp:243-308) for a batch of map points: obs_off[npts+1] into the concatenated
+// descriptors of each point's (non-bad) observations, in the std::map order the caller walked them; best_idx[p] = index inside the
+// point's list of the descriptor with the least median distance to the rest (first one on ties), -1 for a point without observations.
+extern "C" void orc_distinctive_descriptors(int npts, const int* obs_off, const uint8_t* desc, int* best_idx) {
+  for (int p = 0; p < npts; ++p) {
+    const int N = obs_off[p + 1] - obs_off[p];
+    best_idx[p] = -1;
+    if (N <= 0) continue;
+    const uint8_t* D = desc + 32 * (size_t)obs_off[p];
+    std::vector<float> dist((size_t)N * N);
+    for (int i = 0; i < N; ++i) {
+      dist[(size_t)i * N + i] = 0;
+      for (int j = i + 1; j < N; ++j) {
+        const int d = orc_descriptor_distance(D + 32 * (size_t)i, D + 32 * (size_t)j);
+        dist[(size_t)i * N + j] = (float)d; dist[(size_t)j * N + i] = (float)d;
+      }
+    }
+    int BestMedian = 0x7fffffff, BestIdx = 0;
+    for (int i = 0; i < N; ++i) {
+      std::vector<int> v(dist.begin() + (size_t)i * N, dist.begin() + (size_t)(i + 1) * N);
+      std::sort(v.begin(), v.end());
+      const int median = v[(size_t)(0.5 * (N - 1))];
+      if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    best_idx[p] = BestIdx;
+  }
+}
+
+// MapPoint::UpdateNormalAndDepth (src/MapPoint.cpp:332-373): normal = mean of the unit vectors from the observing key frames' centres
+// (cv::Mat float arithmetic: addWeighted(normal, 1, normali, 1/norm) per observation, then scale by (float)(1/n)), dist to the
+// reference key frame, mfMaxDistance = dist * scaleFactor[level of the reference observation], mfMinDistance = max / scaleFactor[nLevels-1].
+extern "C" void orc_update_normal_and_depth(int npts, const int* obs_off, const float* pos, const float* obs_Ow, const float* ref_Ow,
+                                            const int* ref_level, const float* scale_factors, int nlevels, float* normal, float* min_dist,
+                                            float* max_dist) {
+  for (int p = 0; p < npts; ++p) {
+    const int N = obs_off[p + 1] - obs_off[p];
+    if (N <= 0) continue;                                             // observations.empty(): nothing is touched
+    const float* P = pos + 3 * (size_t)p;
+    float nrm[3] = {0, 0, 0};
+    for (int o = obs_off[p]; o < obs_off[p + 1]; ++o) {
+      const float ni[3] = {P[0] - obs_Ow[3 * (size_t)o], P[1] - obs_Ow[3 * (size_t)o + 1], P[2] - obs_Ow[3 * (size_t)o + 2]};
+      const float beta = (float)(1.0 / dnorm3(ni));
+      for (int k = 0; k < 3; ++k) nrm[k] = nrm[k] * 1.0f + ni[k] * beta;
+    }
+    const float PC[3] = {P[0] - ref_Ow[3 * (size_t)p], P[1] - ref_Ow[3 * (size_t)p + 1], P[2] - ref_Ow[3 * (size_t)p + 2]};
+    const float dist = (float)dnorm3(PC);
+    const float mx = dist * scale_factors[ref_level[p]];
+    max_dist[p] = mx;
+    min_dist[p] = mx / scale_factors[nlevels - 1];
+    const float inv_n = (float)(1.0 / (double)N);
+    for (int k = 0; k < 3; ++k) normal[3 * (size_t)p + k] = nrm[k] * inv_n;
+  }
+}

@@ -388,3 +388,23 @@ def fuse_search(cam, K, skip, pos, normal, min_dist, max_dist, desc, th, sf, inv
          np.ascontiguousarray(min_dist, np.float32), np.ascontiguousarray(max_dist, np.float32), np.ascontiguousarray(desc, np.uint8)]
     L.orc_fuse_search(C.byref(cam), C.byref(K), n, *[_p(v) for v in a], th, _p(sf), _p(inv_sigma2), len(sf), _p(bi), _p(bd))
     return bi, bd
+
+
+def distinctive_descriptors(obs_off, desc):
+    L = lib()
+    L.orc_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    obs_off = np.ascontiguousarray(obs_off, np.int32); desc = np.ascontiguousarray(desc, np.uint8)
+    out = np.zeros(len(obs_off) - 1, np.int32)
+    L.orc_distinctive_descriptors(len(out), _p(obs_off), _p(desc), _p(out))
+    return out
+
+
+def update_normal_and_depth(obs_off, pos, obs_Ow, ref_Ow, ref_level, sf):
+    L = lib()
+    L.orc_update_normal_and_depth.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3
+    a = [np.ascontiguousarray(obs_off, np.int32), np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(obs_Ow, np.float32),
+         np.ascontiguousarray(ref_Ow, np.float32), np.ascontiguousarray(ref_level, np.int32), np.ascontiguousarray(sf, np.float32)]
+    n = len(a[0]) - 1
+    nrm = np.zeros((n, 3), np.float32); mn = np.zeros(n, np.float32); mx = np.zeros(n, np.float32)
+    L.orc_update_normal_and_depth(n, *[_p(v) for v in a], len(a[5]), _p(nrm), _p(mn), _p(mx))
+    return nrm, mn, mx

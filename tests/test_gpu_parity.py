@@ -703,3 +703,26 @@ def test_tracking_and_mapping_edge_cases():
     with pytest.raises(api.CmsError):
         api.create_new_map_points(ctx, [(g[0][0], [gb[0]])])
     ctx.close()
+
+
+def test_map_point_bookkeeping_matches_oracle():
+    """MapPoint::ComputeDistinctiveDescriptors and MapPoint::UpdateNormalAndDepth, batched over map points with 0 .. 70 observations:
+    same chosen observation (first on ties) and bit-identical normal / distance range."""
+    from test_oracle_tri import _map_point_batch
+    camd = synth.camera("lafida", 250)
+    ctx = api.Context(camd, nfeatures=500, max_batch=1)
+    off, desc, pos, obs_Ow, ref_Ow, ref_level = _map_point_batch(51, npts=3000)
+    want = orc.distinctive_descriptors(off, desc)
+    got = api.distinctive_descriptors(ctx, off, desc)
+    assert np.array_equal(got, want) and (want >= 0).sum() > 2000 and (want > 0).sum() > 500
+    sf = np.array([ctx.geom.scale[l] for l in range(8)], np.float32)
+    wn, wmn, wmx = orc.update_normal_and_depth(off, pos, obs_Ow, ref_Ow, ref_level, sf)
+    gn = np.zeros((len(pos), 3), np.float32); gmn = np.zeros(len(pos), np.float32); gmx = np.zeros(len(pos), np.float32)
+    api.update_normal_and_depth(ctx, off, pos, obs_Ow, ref_Ow, ref_level, gn, gmn, gmx)
+    assert np.array_equal(gn.view(np.uint32), wn.view(np.uint32)) and np.array_equal(gmn.view(np.uint32), wmn.view(np.uint32))
+    assert np.array_equal(gmx.view(np.uint32), wmx.view(np.uint32))
+    # nothing to do / bad lists
+    assert len(api.distinctive_descriptors(ctx, np.zeros(1, np.int32), np.zeros((0, 32), np.uint8))) == 0
+    with pytest.raises(api.CmsError):
+        api.distinctive_descriptors(ctx, np.array([0, 5, 3], np.int32), desc[:5])
+    ctx.close()

@@ -143,3 +143,45 @@ def test_fuse_search_against_brute_force():
         got = bd[i]
         bad += int((want if want <= 50 else 256) != got)
     assert bad <= 2, bad
+
+
+def _map_point_batch(seed, npts=400, max_obs=70):
+    rng = np.random.default_rng(seed)
+    n = np.minimum(rng.geometric(0.18, npts), max_obs).astype(np.int32); n[::17] = 0; n[3] = max_obs; n[4] = 1; n[5] = 2
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+    base = rng.integers(0, 256, (npts, 32), dtype=np.uint8)
+    desc = np.repeat(base, n, axis=0)
+    flips = rng.integers(0, 256, (len(desc), 30)); nf = rng.integers(0, 31, len(desc))
+    for j in range(30):
+        m = nf > j
+        desc[m, flips[m, j] >> 3] ^= (1 << (flips[m, j] & 7)).astype(np.uint8)
+    pos = rng.normal(0, 5, (npts, 3)).astype(np.float32)
+    obs_Ow = (np.repeat(pos, n, axis=0) + rng.normal(0, 3, (len(desc), 3))).astype(np.float32)
+    ref_Ow = (pos + rng.normal(0, 3, (npts, 3))).astype(np.float32)
+    ref_level = rng.integers(0, 8, npts).astype(np.int32)
+    return off, desc, pos, obs_Ow, ref_Ow, ref_level
+
+
+def test_distinctive_descriptors_and_normal_depth_against_numpy():
+    off, desc, pos, obs_Ow, ref_Ow, ref_level = _map_point_batch(41)
+    best = orc.distinctive_descriptors(off, desc)
+    for p in range(len(off) - 1):
+        D = desc[off[p]:off[p + 1]]
+        if len(D) == 0:
+            assert best[p] == -1
+            continue
+        dm = np.unpackbits(D[:, None, :] ^ D[None, :, :], axis=-1).sum(-1)
+        med = np.sort(dm, axis=1)[:, int(0.5 * (len(D) - 1))]
+        assert best[p] == int(np.argmin(med)), p                      # np.argmin: first minimum, like `median < BestMedian`
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    nrm, mn, mx = orc.update_normal_and_depth(off, pos, obs_Ow, ref_Ow, ref_level, sf)
+    for p in range(0, len(off) - 1, 7):
+        o = slice(off[p], off[p + 1])
+        if off[p + 1] == off[p]:
+            assert (nrm[p] == 0).all() and mn[p] == 0 and mx[p] == 0   # untouched
+            continue
+        v = pos[p].astype(np.float64) - obs_Ow[o].astype(np.float64)
+        want = (v / np.linalg.norm(v, axis=1, keepdims=True)).mean(0)
+        assert np.abs(nrm[p] - want).max() < 1e-5
+        d = np.linalg.norm(pos[p].astype(np.float64) - ref_Ow[p])
+        assert abs(mx[p] - d * sf[ref_level[p]]) < 1e-4 * mx[p] and abs(mn[p] - mx[p] / sf[7]) < 1e-6 * mx[p]
