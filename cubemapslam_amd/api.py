@@ -102,6 +102,10 @@ def lib():
         L.cms_area_set_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cms_search_local_points.argtypes = ([C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_int, C.c_int] +
                                               [C.c_void_p] * 9)
+        L.cms_search_by_projection.argtypes = ([C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] +
+                                               [C.c_void_p] * 3)
+        L.cms_project_last_frame_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 5
+        L.cms_rotation_filter_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
         L.cms_is_in_frustum_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_float] + [C.c_void_p] * 8
         L.cms_search_local_points_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 3
         L.cms_create_new_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
@@ -340,6 +344,17 @@ class Context:
                                            viewing_cos_limit, th, nnratio, th_high, len(kp_mp), _p(kp_mp), _p(vis), _p(px), _p(py), _p(lvl),
                                            _p(vc), _p(match), C.addressof(nm), C.addressof(rounds)), "cms_search_local_points")
         return dict(in_view=vis, proj_x=px, proj_y=py, level=lvl, view_cos=vc, match=match, n_matches=nm.value, rounds=rounds.value)
+
+    def search_by_projection(self, b, pose12, valid, Xw, octave, angle, mp_desc, kp_mp, th=15.0, check_ori=True, th_high=100):
+        """ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) against frame slot b -> (match, n_matches); kp_mp in/out"""
+        a = [np.ascontiguousarray(pose12, np.float32), np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(Xw, np.float32),
+             np.ascontiguousarray(octave, np.int32), np.ascontiguousarray(angle, np.float32), np.ascontiguousarray(mp_desc, np.uint8)]
+        n = len(a[1])
+        match = np.full(n, -1, np.int32); nm = C.c_int(0)
+        assert kp_mp.dtype == np.int32
+        _chk(lib().cms_search_by_projection(self.h, b, _p(a[0]), n, *[_p(v) for v in a[1:]], th, int(check_ori), th_high, len(kp_mp), _p(kp_mp), _p(match),
+                                            C.addressof(nm)), "cms_search_by_projection")
+        return match, nm.value
 
     def is_in_frustum_device(self, nmp, d_mp_frame, d_pose15, d_pos, d_normal, d_min, d_max, viewing_cos_limit, th, d_outs5, d_q3):
         """d_outs5 = (in_view u8, proj_x, proj_y, level, view_cos); d_q3 = (qr, qmin, qmax) or (0, 0, 0); raw device pointers"""

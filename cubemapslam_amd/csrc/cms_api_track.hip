@@ -138,3 +138,113 @@ extern "C" int cms_search_local_points(cms_ctx* c, int b, const float* pose15, i
   }
   return cms_fail(CMS_ERR_OVERFLOW, "cms_search_local_points: candidate lists kept growing");
 }
+
+
+// ---- ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono): device-pointer pieces (asynchronous on the ctx stream) ...
+extern "C" int cms_project_last_frame_device(cms_ctx* c, int n, const void* d_qframe, const void* d_pose12, const void* d_valid, const void* d_Xw,
+                                             const void* d_oct, float th, void* d_qx, void* d_qy, void* d_qr, void* d_qmin, void* d_qmax) {
+  if (!c || n < 0 || (n > 0 && (!d_pose12 || !d_valid || !d_Xw || !d_oct || !d_qx || !d_qy || !d_qr || !d_qmin || !d_qmax)))
+    return cms_fail(CMS_ERR_ARG, "cms_project_last_frame_device: bad argument");
+  if (n == 0) return CMS_OK;
+  HIPCHK(hipSetDevice(c->device));
+  CmsProjectLastArgs a;
+  a.pose12 = (const float*)d_pose12; a.q_frame = (const int*)d_qframe; a.n = n; a.valid = (const uint8_t*)d_valid; a.Xw = (const float*)d_Xw;
+  a.oct = (const int*)d_oct; a.th = th; a.F = c->g.F;
+  {
+    const float fov = (float)c->cam.fov_deg;
+    const float pif = 3.1415926535897932384626f;
+    a.cos_fov = std::cos(fov / 2 * (pif / 180));                      // CamModelGeneral::SetCosFovTh
+  }
+  for (int l = 0; l < 16; ++l) a.sf[l] = l < c->g.nlevels ? c->scale[l] : 0.0f;
+  a.qx = (float*)d_qx; a.qy = (float*)d_qy; a.qr = (float*)d_qr; a.qmin = (int*)d_qmin; a.qmax = (int*)d_qmax;
+  hipLaunchKernelGGL(k_project_last, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+extern "C" int cms_rotation_filter_device(cms_ctx* c, int B, const void* d_mp_off, const void* d_last_angle, void* d_kp_mp, void* d_mp_match,
+                                          void* d_n_matches, int check_orientation) {
+  if (!c || B < 1 || !d_mp_off || !d_last_angle || !d_kp_mp || !d_mp_match) return cms_fail(CMS_ERR_ARG, "cms_rotation_filter_device: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  CmsRotFilterArgs a;
+  a.mp_off = (const int*)d_mp_off; a.last_angle = (const float*)d_last_angle; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_mp = (int*)d_kp_mp;
+  a.mp_match = (int*)d_mp_match; a.n_matches = (int*)d_n_matches; a.check_orientation = check_orientation;
+  hipLaunchKernelGGL(k_rot_filter, dim3(B), dim3(1024), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+
+// ... and the one-frame entry with host buffers: frame b's key points / descriptors are the current frame (cms_area_grid first).
+// pose12 = Rcw | tcw of CurrentFrame.mTcw.  Per key point i of the last frame: valid[i] (holds a map point, not an outlier), Xw, octave,
+// angle, mp_desc (MapPoint::GetDescriptor).  kp_mp in/out like cms_search_local_points; match[i] = key point of the current frame or -1.
+extern "C" int cms_search_by_projection(cms_ctx* c, int b, const float* pose12, int nlast, const uint8_t* valid, const float* Xw, const int* octave,
+                                        const float* angle, const uint8_t* mp_desc, float th, int check_orientation, int th_high, int nkp, int* kp_mp,
+                                        int* match, int* n_matches) {
+  if (!c || !pose12 || nlast < 0 || nkp < 0 || nkp > (c ? c->g.kp_cap : 0) || (nlast > 0 && (!valid || !Xw || !octave || !angle || !mp_desc || !match)) ||
+      (nkp > 0 && !kp_mp))
+    return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: bad argument");
+  if (b < 0 || b >= c->area_frames) return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: no grid for this frame (cms_area_grid first)");
+  if (nlast > CMS_TRACK_MAX_MP_PER_FRAME) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_by_projection: more than 32768 queries");
+  if (n_matches) *n_matches = 0;
+  if (nlast == 0) return CMS_OK;
+  for (int i = 0; i < nlast; ++i)
+    if (valid[i] && (octave[i] < 0 || octave[i] >= c->g.nlevels)) return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: octave out of range");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t n4 = (size_t)nlast * 4, rows = (size_t)c->g.kp_cap * (size_t)c->max_batch;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
+  const size_t o_pose = take(64), o_valid = take(nlast), o_xw = take(3 * n4), o_oct = take(n4), o_ang = take(n4), o_desc = take((size_t)nlast * 32),
+               o_qx = take(n4), o_qy = take(n4), o_qr = take(n4), o_qmin = take(n4), o_qmax = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16),
+               o_mpoff = take(16), o_match = take(n4), o_nm = take(16), o_kpmp = take(rows * 4), o_qf = take(n4);
+  const size_t fixed = o;
+  int cap = 64 * nlast + 1024;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
+    int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
+    if (rc) return rc;
+    uint8_t* p = (uint8_t*)c->d_match;
+    HIPCHK(hipMemcpyAsync(p + o_pose, pose12, 48, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_valid, valid, nlast, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_xw, Xw, 3 * n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_oct, octave, n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_ang, angle, n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nlast * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(p + o_kpmp, 0xFF, rows * 4, s));
+    if (nkp > 0) HIPCHK(hipMemcpyAsync(p + o_kpmp + (size_t)b * c->g.kp_cap * 4, kp_mp, (size_t)nkp * 4, hipMemcpyHostToDevice, s));
+    const std::vector<int> qf((size_t)nlast, b);
+    HIPCHK(hipMemcpyAsync(p + o_qf, qf.data(), n4, hipMemcpyHostToDevice, s));
+    rc = cms_project_last_frame_device(c, nlast, nullptr, p + o_pose, p + o_valid, p + o_xw, p + o_oct, th, p + o_qx, p + o_qy, p + o_qr, p + o_qmin, p + o_qmax);
+    if (rc) return rc;
+    rc = cms_features_in_area_batch_device(c, nlast, p + o_qf, p + o_qx, p + o_qy, p + o_qr, p + o_qmin, p + o_qmax, p + o_cnt, p + o_off, p + o_idx, cap, p + o_tot);
+    if (rc) return rc;
+    int tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (tot > cap) { cap = tot + 64; continue; }
+    const int mpoff[2] = {0, nlast};
+    HIPCHK(hipMemcpyAsync(p + o_mpoff, mpoff, sizeof(mpoff), hipMemcpyHostToDevice, s));
+    if (c->g.kp_cap > CMS_TRACK_KPMAX) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_by_projection: more than 4096 key points per frame");
+    CmsSearchLocalArgs a;
+    a.mp_off = (const int*)(p + o_mpoff); a.mp_desc = (const uint4*)(p + o_desc); a.cand_off = (const int*)(p + o_off); a.cand_idx = (const int*)(p + o_idx);
+    a.t_desc = (const uint4*)c->d_desc; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_cap = c->g.kp_cap;
+    a.pair_dist = (uint16_t*)(p + o_pd); a.kp_mp = (int*)(p + o_kpmp); a.mp_match = (int*)(p + o_match); a.rounds = nullptr;
+    a.nnratio = -1.0f; a.th_high = th_high; a.frame0 = b;
+    hipLaunchKernelGGL(k_search_local, dim3(1), dim3(1024), 0, s, a);
+    CmsRotFilterArgs r;
+    r.mp_off = (const int*)(p + o_mpoff); r.last_angle = (const float*)(p + o_ang); r.kp = (const CmsKeyPoint*)c->d_kps; r.kp_mp = (int*)(p + o_kpmp);
+    r.mp_match = (int*)(p + o_match); r.n_matches = (int*)(p + o_nm); r.check_orientation = check_orientation;
+    hipLaunchKernelGGL(k_rot_filter, dim3(1), dim3(1024), 0, s, r);
+    HIPCHK(hipGetLastError());
+    std::vector<int> m((size_t)nlast);
+    int nm = 0;
+    HIPCHK(hipMemcpyAsync(m.data(), p + o_match, n4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, p + o_nm, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (nkp > 0) HIPCHK(hipMemcpyAsync(kp_mp, p + o_kpmp + (size_t)b * c->g.kp_cap * 4, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < nlast; ++i) match[i] = m[(size_t)i] >= 0 ? m[(size_t)i] - b * c->g.kp_cap : -1;
+    if (n_matches) *n_matches = nm;
+    return CMS_OK;
+  }
+  return cms_fail(CMS_ERR_OVERFLOW, "cms_search_by_projection: candidate lists kept growing");
+}

@@ -174,7 +174,9 @@ extern "C" __global__ void __launch_bounds__(1024) k_search_local(CmsSearchLocal
         else if (dist < bestDist2) { bestLevel2 = a.kp[row].octave; bestDist2 = dist; }
       }
       int m = -1;
-      if (bestDist <= a.th_high && !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2))) m = bestRow;
+      // nnratio < 0: no second-best test (the frame-to-frame SearchByProjection, ORBMatcher.cpp:207)
+      const bool ratio_ok = a.nnratio < 0.0f || !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2));
+      if (bestDist <= a.th_high && ratio_ok) m = bestRow;
       if (m >= 0) a.kp_mp[m] = i;
       a.mp_match[i] = m;
     }
@@ -182,4 +184,86 @@ extern "C" __global__ void __launch_bounds__(1024) k_search_local(CmsSearchLocal
     if (__syncthreads_count(open > 0) == 0) break;
   }
   if (a.rounds && tid == 0) a.rounds[f] = round;
+}
+
+
+// ---- ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBMatcher.cpp:130-251), the matcher of TrackWithMotionModel:
+// k_project_last projects the last frame's map points with the current pose and writes their windows; the window query and k_search_local
+// (nnratio < 0: best distance only) follow; k_rot_filter applies the rotation-consistency histogram (ComputeThreeMaxima, :905-946).
+struct CmsProjectLastArgs {
+  const float* pose12;        // per current frame: Rcw (9, row major) | tcw (3)
+  const int* q_frame;         // current frame searched by every query (nullptr: 0)
+  int n; const uint8_t* valid; const float* Xw; const int* oct;
+  float th, cos_fov; int F; float sf[16];
+  float* qx; float* qy; float* qr; int* qmin; int* qmax;
+};
+extern "C" __global__ void __launch_bounds__(256) k_project_last(CmsProjectLastArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  float u = -1.0f, v = -1.0f, r = -1.0f;
+  const int o = a.oct[i];
+  if (a.valid[i]) {
+    const float* ps = a.pose12 + 12 * (size_t)(a.q_frame ? a.q_frame[i] : 0);
+    const float p0 = a.Xw[3 * (size_t)i], p1 = a.Xw[3 * (size_t)i + 1], p2 = a.Xw[3 * (size_t)i + 2];
+    float xc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float t = __fmul_rn(ps[3 * k], p0);
+      t = __fadd_rn(t, __fmul_rn(ps[3 * k + 1], p1));
+      t = __fadd_rn(t, __fmul_rn(ps[3 * k + 2], p2));
+      xc[k] = (float)((double)t * 1.0 + (double)ps[9 + k] * 1.0);
+    }
+    if (!(xc[2] < a.cos_fov) && track_rays_to_cubemap(a.F, xc[0], xc[1], xc[2], u, v) >= 0) r = __fmul_rn(a.th, a.sf[o & 15]);
+  }
+  a.qx[i] = u; a.qy[i] = v; a.qr[i] = r; a.qmin[i] = o - 1; a.qmax[i] = o + 1;
+}
+
+struct CmsRotFilterArgs {
+  const int* mp_off; const float* last_angle; const CmsKeyPoint* kp; int* kp_mp; int* mp_match; int* n_matches; int check_orientation;
+};
+extern "C" __global__ void __launch_bounds__(1024) k_rot_filter(CmsRotFilterArgs a) {
+  __shared__ int hist[32];
+  __shared__ int keep[3];
+  __shared__ int s_n;
+  const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int m0 = a.mp_off[f], m1 = a.mp_off[f + 1];
+  if (tid < 32) hist[tid] = 0;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  auto bin_of = [&](int i, int row) {
+    float rot = __fsub_rn(a.last_angle[i], a.kp[row].angle);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / 12));
+    return bin == 30 ? 0 : bin;
+  };
+  for (int i = m0 + tid; i < m1; i += nt) {
+    const int row = a.mp_match[i];
+    if (row >= 0 && a.check_orientation) atomicAdd(&hist[bin_of(i, row)], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    for (int b = 0; b < 30; ++b) {
+      const int s = hist[b];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = b; }
+      else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = b; }
+      else if (s > max3) { max3 = s; i3 = b; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) i3 = -1;
+    keep[0] = i1; keep[1] = i2; keep[2] = i3;
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int i = m0 + tid; i < m1; i += nt) {
+    const int row = a.mp_match[i];
+    if (row < 0) continue;
+    if (a.check_orientation) {
+      const int b = bin_of(i, row);
+      if (b != keep[0] && b != keep[1] && b != keep[2]) { a.kp_mp[row] = -1; a.mp_match[i] = -1; continue; }
+    }
+    ++mine;
+  }
+  atomicAdd(&s_n, mine);
+  __syncthreads();
+  if (tid == 0 && a.n_matches) a.n_matches[f] = s_n;
 }

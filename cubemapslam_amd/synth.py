@@ -307,6 +307,43 @@ def local_map_problem(F, kx, ky, koct, kdesc, seed=3, nlevels=8, scale=1.2, extr
                 max_dist=maxd[perm].copy(), desc=np.ascontiguousarray(D[perm]), scale_factors=sf)
 
 
+def motion_model_problem(F, kx, ky, koct, kangle, kdesc, seed=3, nlevels=8, scale=1.2, dup=0.2):
+    """Inputs of ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono): the current frame's float pose (Rcw | tcw) and, per
+    key point of a synthetic last frame, whether it holds a usable map point (`valid`), that point's world position (behind a current
+    key point, a few pixels of noise; some behind the camera), descriptor (the current key point's + flipped bits), the last key point's
+    octave (current +-1) and angle (current + a common rotation + noise; 12 % random, so the rotation histogram has something to reject).
+    `dup` of the points are doubled (two map points competing for one key point)."""
+    rng = np.random.default_rng(seed)
+    kx = np.asarray(kx, np.float32); ky = np.asarray(ky, np.float32); koct = np.asarray(koct, np.int32); kangle = np.asarray(kangle, np.float32)
+    n = len(kx)
+    ang = rng.normal(0, 0.3, 3)
+    R = (_rot((1, 0, 0), ang[0]) @ _rot((0, 1, 0), ang[1]) @ _rot((0, 0, 1), ang[2])).astype(np.float32)
+    t = rng.normal(0, 1.0, 3).astype(np.float32)
+    pick = np.flatnonzero(rng.random(n) < 0.75)
+    pick = np.concatenate([pick, rng.choice(pick, int(dup * len(pick)), replace=False)])
+    pick = pick[rng.permutation(len(pick))]
+    m = len(pick)
+    fc, ray = pixel_to_ray(F, kx[pick] + rng.normal(0, 2.0, m), ky[pick] + rng.normal(0, 2.0, m))
+    ray[fc < 0] = (0.0, 0.0, 1.0)
+    ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+    depth = rng.uniform(2.0, 12.0, m)
+    depth[rng.random(m) < 0.05] *= -1.0                                   # behind the camera
+    Xw = ((ray * depth[:, None]) - t.astype(np.float64)) @ R.astype(np.float64)
+    desc = np.asarray(kdesc, np.uint8)[pick].copy()
+    flips = rng.integers(0, 256, (m, 14)); nflip = rng.integers(0, 15, m)
+    for j in range(14):
+        sel = nflip > j
+        desc[sel, flips[sel, j] >> 3] ^= (1 << (flips[sel, j] & 7)).astype(np.uint8)
+    octave = np.clip(koct[pick] + rng.integers(-1, 2, m), 0, nlevels - 1).astype(np.int32)
+    angle = (kangle[pick] + np.float32(17.0) + rng.normal(0, 4.0, m)).astype(np.float32) % np.float32(360.0)
+    wild = rng.random(m) < 0.12
+    angle[wild] = rng.uniform(0, 360, wild.sum()).astype(np.float32)
+    valid = (rng.random(m) < 0.85).astype(np.uint8)
+    sf = np.float32(scale) ** np.arange(nlevels, dtype=np.float32)
+    return dict(pose12=np.concatenate([R.reshape(-1), t]).astype(np.float32), valid=valid, Xw=Xw.astype(np.float32), octave=octave, angle=angle.astype(np.float32),
+                desc=desc, scale_factors=sf)
+
+
 def keyframe_set(F, n_kf=4, n_pts=1600, seed=5, nlevels=8, scale=1.2, node_size=6, with_mp=0.45):
     """A current key frame (index 0) and n_kf - 1 covisible neighbours looking at one random scene (LocalMapping::CreateNewMapPoints'
     inputs): per key frame float pose (Rcw, tcw, Ow), key points (projection + noise, random level), descriptors (the scene point's +

@@ -198,6 +198,21 @@ int cms_features_in_area_batch_device(cms_ctx* ctx, int nq, const void* d_qframe
  * cms_search_local_points_device takes that CSR (indices = batch rows), mp_off[B+1] (map points grouped by frame, list order
  * inside a frame), scratch pair_dist (2 bytes per candidate) and kp_mp over all batch rows; mp_match = batch row or -1. */
 int cms_area_set_descriptors(cms_ctx* ctx, int b, int n, const uint8_t* desc);
+/* ORBMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBMatcher.cpp:130-251), the matcher of
+ * Tracking::TrackWithMotionModel, whole on the device: the last frame's map points are projected with the current pose (Rcw | tcw of
+ * CurrentFrame.mTcw; z < cosFovTh and UNKNOWN_FACE are dropped), windows th * scale[octave] over octave -1 .. +1, greedy best match
+ * <= TH_HIGH (a key point taken by one map point is skipped by the later ones), then the rotation-consistency histogram
+ * (ComputeThreeMaxima, :905-946).  valid[i]: key point i of the last frame holds a map point and is not an outlier.  kp_mp as in
+ * cms_search_local_points.  The _device entries are the batched pieces: cms_project_last_frame_device writes the windows of all
+ * queries (q_frame = current frame each one searches), cms_features_in_area_batch_device and cms_search_local_points_device
+ * (nnratio < 0: no second-best test) follow, cms_rotation_filter_device applies the histogram per frame and counts the matches. */
+int cms_search_by_projection(cms_ctx* ctx, int b, const float* pose12, int nlast, const uint8_t* valid, const float* Xw, const int* octave,
+                             const float* angle, const uint8_t* mp_desc, float th, int check_orientation, int th_high, int nkp, int* kp_mp,
+                             int* match, int* n_matches);
+int cms_project_last_frame_device(cms_ctx* ctx, int n, const void* d_qframe, const void* d_pose12, const void* d_valid, const void* d_Xw,
+                                  const void* d_oct, float th, void* d_qx, void* d_qy, void* d_qr, void* d_qmin, void* d_qmax);
+int cms_rotation_filter_device(cms_ctx* ctx, int B, const void* d_mp_off, const void* d_last_angle, void* d_kp_mp, void* d_mp_match,
+                               void* d_n_matches, int check_orientation);
 int cms_search_local_points(cms_ctx* ctx, int b, const float* pose15, int nmp, const float* pos, const float* normal,
                             const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float viewing_cos_limit, float th,
                             float nnratio, int th_high, int nkp, int* kp_mp, uint8_t* in_view, float* proj_x, float* proj_y, int* level,

@@ -139,6 +139,13 @@ void orc_update_normal_and_depth(int npts, const int* obs_off, const float* pos,
                                  const int* ref_level, const float* scale_factors, int nlevels, float* normal, float* min_dist,
                                  float* max_dist);
 
+/* ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBMatcher.cpp:130-251): projection of the last frame's map points with
+ * the current pose, windows, greedy best match, rotation-consistency filter; orc_track.cpp */
+int  orc_search_by_projection_frames(const orc_camera* cam, const float* Rcw, const float* tcw, int nkp, const float* kx, const float* ky,
+                                     const int* koct, const float* kangle, const uint8_t* kdesc, const float* scale_factors, int nlast,
+                                     const uint8_t* valid, const float* Xw, const int* loct, const float* langle, const uint8_t* mp_desc,
+                                     float th, int check_orientation, int th_high, int* kp_mp, int* match);
+
 /* ---- ORBMatcher (ORBMatcher.cpp) ---- */
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
 /* best / second-best over CSR candidate lists, the inner loop of SearchByProjection (ORBMatcher.cpp:84-113) */

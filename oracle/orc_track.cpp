@@ -107,3 +107,81 @@ extern "C" int orc_search_local_points(const orc_camera* cam, int nkp, const flo
   }
   return nmatches;
 }
+
+// ORBMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBMatcher.cpp:130-251), the matcher of
+// Tracking::TrackWithMotionModel.  Rcw / tcw: CurrentFrame.mTcw (float).  Per key point i of the last frame: valid[i] = it holds a map
+// point and is not an outlier, Xw = that point's world position, mp_desc = its descriptor (MapPoint::GetDescriptor), oct / angle = the
+// last frame's key point.  kp_mp (in/out, per key point of the current frame): >= 0 = taken; new matches store i.  Returns nmatches
+// (after the rotation-consistency filter when check_orientation).
+extern "C" int orc_search_by_projection_frames(const orc_camera* cam, const float* Rcw, const float* tcw, int nkp, const float* kx, const float* ky,
+                                               const int* koct, const float* kangle, const uint8_t* kdesc, const float* scale_factors, int nlast,
+                                               const uint8_t* valid, const float* Xw, const int* loct, const float* langle, const uint8_t* mp_desc,
+                                               float th, int check_orientation, int th_high, int* kp_mp, int* match) {
+  const int HISTO_LENGTH = 12;
+  const int nBins = (int)std::ceil(360.0f / HISTO_LENGTH);
+  const float factor = 1.0f / HISTO_LENGTH;
+  const float cosFov = orc_cos_fov_th(cam);
+  std::vector<std::vector<int>> rotHist(nBins);
+  std::vector<float> qx, qy, qr;
+  std::vector<int> lo, hi, qi;
+  for (int i = 0; i < nlast; ++i) {
+    match[i] = -1;
+    if (!valid[i]) continue;
+    const float* p = Xw + 3 * (size_t)i;
+    float xc[3];
+    for (int r = 0; r < 3; ++r) {
+      float t = Rcw[3 * r] * p[0];
+      t = t + Rcw[3 * r + 1] * p[1];
+      t = t + Rcw[3 * r + 2] * p[2];
+      xc[r] = (float)((double)t * 1.0 + (double)tcw[r] * 1.0);
+    }
+    if (xc[2] < cosFov) continue;
+    float u, v;
+    if (orc_rays_to_cubemap(cam, xc[0], xc[1], xc[2], &u, &v) == ORC_FACE_UNKNOWN) continue;
+    const int o = loct[i];
+    qx.push_back(u); qy.push_back(v); qr.push_back(th * scale_factors[o]); lo.push_back(o - 1); hi.push_back(o + 1); qi.push_back(i);
+  }
+  const int nq = (int)qi.size();
+  std::vector<int> off((size_t)nq + 1, 0), idx((size_t)64 * nq + 1024);
+  const int tot = orc_features_in_area(cam, nkp, kx, ky, koct, nq, qx.data(), qy.data(), qr.data(), lo.data(), hi.data(), off.data(), idx.data(), (int)idx.size());
+  if (tot > (int)idx.size()) {
+    idx.resize((size_t)tot);
+    orc_features_in_area(cam, nkp, kx, ky, koct, nq, qx.data(), qy.data(), qr.data(), lo.data(), hi.data(), off.data(), idx.data(), (int)idx.size());
+  }
+  int nmatches = 0;
+  for (int q = 0; q < nq; ++q) {
+    const int i = qi[q];
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = off[q]; c < off[q + 1]; ++c) {
+      const int i2 = idx[c];
+      if (kp_mp[i2] >= 0) continue;
+      const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, kdesc + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= th_high) {
+      kp_mp[bestIdx2] = i; match[i] = bestIdx2; ++nmatches;
+      if (check_orientation) {
+        float rot = langle[i] - kangle[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == nBins) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_orientation) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < nBins; ++i) {
+      const int s = (int)rotHist[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; } else if (max3 < 0.1f * (float)max1) ind3 = -1;
+    for (int i = 0; i < nBins; ++i) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int i2 : rotHist[i]) { match[kp_mp[i2]] = -1; kp_mp[i2] = -1; --nmatches; }   // CurrentFrame.mvpMapPoints[...] = NULL
+    }
+  }
+  return nmatches;
+}

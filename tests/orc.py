@@ -408,3 +408,17 @@ def update_normal_and_depth(obs_off, pos, obs_Ow, ref_Ow, ref_level, sf):
     nrm = np.zeros((n, 3), np.float32); mn = np.zeros(n, np.float32); mx = np.zeros(n, np.float32)
     L.orc_update_normal_and_depth(n, *[_p(v) for v in a], len(a[5]), _p(nrm), _p(mn), _p(mx))
     return nrm, mn, mx
+
+
+def search_by_projection_frames(cam, Rcw, tcw, kx, ky, koct, kangle, kdesc, sf, valid, Xw, loct, langle, mp_desc, kp_mp, th=15.0, check_ori=True, th_high=100):
+    L = lib()
+    L.orc_search_by_projection_frames.argtypes = ([C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int] +
+                                                  [C.c_void_p] * 2)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32); i32 = lambda a: np.ascontiguousarray(a, np.int32); u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+    a = [f32(Rcw), f32(tcw)]; k = [f32(kx), f32(ky), i32(koct), f32(kangle), u8(kdesc), f32(sf)]
+    l = [u8(valid), f32(Xw), i32(loct), f32(langle), u8(mp_desc)]
+    match = np.full(len(l[0]), -1, np.int32)
+    assert kp_mp.dtype == np.int32
+    n = L.orc_search_by_projection_frames(C.byref(cam), _p(a[0]), _p(a[1]), len(k[0]), *[_p(v) for v in k], len(l[0]), *[_p(v) for v in l], th, int(check_ori),
+                                          th_high, _p(kp_mp), _p(match))
+    return match, n

@@ -726,3 +726,32 @@ def test_map_point_bookkeeping_matches_oracle():
     with pytest.raises(api.CmsError):
         api.distinctive_descriptors(ctx, np.array([0, 5, 3], np.int32), desc[:5])
     ctx.close()
+
+
+def test_search_by_projection_frames_matches_oracle():
+    """ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) whole on the device: projection with the current pose, windows,
+    greedy best match (parallel rounds), rotation histogram -- identical matches and key-point ownership, histogram on and off."""
+    import test_area_emu as te
+    for F, n, seed in ((550, 2000, 91), (250, 800, 92)):
+        camd = synth.camera("lafida", F)
+        ocam = orc.make_camera(camd)
+        kx, ky, ko = te._keypoints(F, n, seed)
+        kd = synth.descriptors(len(kx), seed + 1)
+        ka = np.random.default_rng(seed + 2).uniform(0, 360, len(kx)).astype(np.float32)
+        pr = synth.motion_model_problem(F, kx, ky, ko, ka, kd, seed=seed + 3)
+        ctx = api.Context(camd, nfeatures=2000, max_batch=2)
+        kps = np.zeros(len(kx), api.KP_DTYPE); kps["x"] = kx; kps["y"] = ky; kps["octave"] = ko; kps["angle"] = ka
+        ctx.area_set_keypoints(1, kps); ctx.area_set_descriptors(1, kd)
+        ctx.area_set_keypoints(0, kps[:3]); ctx.area_set_descriptors(0, kd[:3])
+        ctx.area_grid(2)
+        for check, th in ((True, 15.0), (False, 7.0)):
+            taken = np.full(len(kx), -1, np.int32); taken[::8] = 10**6
+            want_kp = taken.copy()
+            want, nm = orc.search_by_projection_frames(ocam, pr["pose12"][:9], pr["pose12"][9:], kx, ky, ko, ka, kd, pr["scale_factors"], pr["valid"], pr["Xw"],
+                                                       pr["octave"], pr["angle"], pr["desc"], want_kp, th=th, check_ori=check)
+            got_kp = taken.copy()
+            got, gn = ctx.search_by_projection(1, pr["pose12"], pr["valid"], pr["Xw"], pr["octave"], pr["angle"], pr["desc"], got_kp, th=th, check_ori=check)
+            assert np.array_equal(got, want) and gn == nm, (F, check, (got != want).sum(), gn, nm)
+            assert np.array_equal(got_kp, want_kp)
+            assert nm > 100
+        ctx.close()

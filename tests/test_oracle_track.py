@@ -73,3 +73,60 @@ def test_search_local_points_against_python_loop():
         assert np.array_equal(match, want) and nm == (want >= 0).sum()
         assert np.array_equal(kp_mp, cur)
         assert nm > 300
+
+
+def test_search_by_projection_frames_against_python_loop():
+    """ORBMatcher::SearchByProjection(CurrentFrame, LastFrame): oracle vs a literal Python replay over the oracle's own windows"""
+    F = 350
+    cam = orc.make_camera(synth.camera("lafida", F))
+    kx, ky, ko = te._keypoints(F, 1500, 8)
+    kd = synth.descriptors(len(kx), 9)
+    ka = np.random.default_rng(10).uniform(0, 360, len(kx)).astype(np.float32)
+    pr = synth.motion_model_problem(F, kx, ky, ko, ka, kd, seed=13)
+    for check in (True, False):
+        taken = np.full(len(kx), -1, np.int32); taken[::8] = 10**6
+        kp = taken.copy()
+        match, nm = orc.search_by_projection_frames(cam, pr["pose12"][:9], pr["pose12"][9:], kx, ky, ko, ka, kd, pr["scale_factors"], pr["valid"], pr["Xw"],
+                                                    pr["octave"], pr["angle"], pr["desc"], kp, th=15.0, check_ori=check)
+        R = pr["pose12"][:9].reshape(3, 3).astype(np.float64); t = pr["pose12"][9:].astype(np.float64)
+        Xc = pr["Xw"].astype(np.float64) @ R.T + t
+        face, up, vp = synth.rays_to_cubemap(F, Xc)
+        cosfov = np.cos(np.float32(190.0) / 2 * (np.float32(np.pi) / 180))
+        ok = (pr["valid"] > 0) & (Xc[:, 2] >= cosfov) & (face >= 0)
+        sel = np.flatnonzero(ok)
+        rad = (np.float32(15.0) * pr["scale_factors"][pr["octave"][sel]]).astype(np.float32)
+        off, idx = orc.features_in_area(cam, kx, ky, ko, up[sel].astype(np.float32), vp[sel].astype(np.float32), rad, pr["octave"][sel] - 1, pr["octave"][sel] + 1)
+        cur = taken.copy(); want = np.full(len(ok), -1, np.int32); hist = [[] for _ in range(30)]
+        for q, i in enumerate(sel):
+            best, bi = 256, -1
+            for k in idx[off[q]:off[q + 1]]:
+                if cur[k] >= 0:
+                    continue
+                d = int(np.unpackbits(pr["desc"][i] ^ kd[k]).sum())
+                if d < best:
+                    best, bi = d, k
+            if best <= 100:
+                cur[bi] = i; want[i] = bi
+                rot = np.float32(pr["angle"][i]) - np.float32(ka[bi])
+                if rot < 0:
+                    rot += np.float32(360)
+                b = int(np.floor(float(rot * np.float32(1.0 / 12)) + 0.5))
+                hist[0 if b == 30 else b].append(bi)
+        if check:
+            sizes = [len(h) for h in hist]
+            order = sorted(range(30), key=lambda b: (-sizes[b], b))
+            m1, m2, m3 = sizes[order[0]], sizes[order[1]], sizes[order[2]]
+            keep = {order[0]}
+            if m2 >= 0.1 * m1:
+                keep.add(order[1])
+                if m3 >= 0.1 * m1:
+                    keep.add(order[2])
+            for b in range(30):
+                if b not in keep:
+                    for k in hist[b]:
+                        want[cur[k]] = -1; cur[k] = -1
+        # projections computed in float64 here: the few points whose window moves by a float rounding may differ
+        assert (match != want).sum() <= 3, (check, (match != want).sum())
+        assert nm == (match >= 0).sum() and nm > 300
+        if check:
+            assert nm < (want >= 0).sum() + 10
