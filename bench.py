@@ -46,25 +46,6 @@ def make_frames(camd, B, seed):
     return np.stack([big[2 * b:2 * b + Ih, 3 * b:3 * b + Iw] for b in range(B)]).copy()
 
 
-def build_match_queries(kps_per_frame, scales, kp_cap, th=15.0):
-    """The windows of ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15) (ORBMatcher.cpp:176-181) for every key point of
-    frame b-1 searched in frame b: centre = its own position (the synthetic stream drifts by a few pixels), radius th*scale[octave],
-    octave +-1.  Only the QUERIES are prepared here; the candidate lists are generated on the device in every step
-    (Frame::GetFeaturesInArea, cms_features_in_area_batch_device)."""
-    B = len(kps_per_frame)
-    q_row, q_frame, qx, qy, qr, lo, hi = [], [], [], [], [], [], []
-    sc = np.asarray(scales, np.float32)
-    for b in range(B):
-        last = kps_per_frame[(b - 1) % B]
-        n = len(last)
-        q_row.append(((b - 1) % B) * kp_cap + np.arange(n)); q_frame.append(np.full(n, b))
-        qx.append(last["x"]); qy.append(last["y"]); qr.append(np.float32(th) * sc[last["octave"]])
-        lo.append(last["octave"] - 1); hi.append(last["octave"] + 1)
-    cat = lambda v, dt: np.ascontiguousarray(np.concatenate(v), dt)
-    return (cat(q_row, np.int32), cat(q_frame, np.int32), cat(qx, np.float32), cat(qy, np.float32), cat(qr, np.float32),
-            cat(lo, np.int32), cat(hi, np.int32))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,28 +94,35 @@ def main():
     g = ctx.geom
     kp_cap = g.kp_cap
     scales = [g.scale[l] for l in range(g.nlevels)]
-    q_row, q_frame, q_x, q_y, q_r, q_lo, q_hi = build_match_queries(kps, scales, kp_cap)
-    nq = len(q_row)
-    t_level = np.zeros(B * kp_cap, np.int32)
-    for b in range(B):
-        t_level[b * kp_cap:b * kp_cap + len(kps[b])] = kps[b]["octave"]
     dev = torch.device("cuda", local_rank)
-    d_qrow = torch.from_numpy(q_row).to(dev); d_qframe = torch.from_numpy(q_frame).to(dev)
-    d_q5 = [torch.from_numpy(a).to(dev) for a in (q_x, q_y, q_r, q_lo, q_hi)]
+    # ---- frame-to-frame matching (ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th = 15), Tracking::TrackWithMotionModel): per
+    # frame a predicted pose and the ~1400 map points its last frame holds; projection, windows, greedy best match and the rotation
+    # histogram run on the device every step (the key points the windows are answered from are the ones this step extracts)
+    ctx.area_grid(B)
+    mm = [synth.motion_model_problem(F, k["x"], k["y"], k["octave"], k["angle"], d, seed=5000 + 100 * rank + b) for b, (k, d) in enumerate(fetched)]
+    mm_off = np.concatenate([[0], np.cumsum([len(p["valid"]) for p in mm])]).astype(np.int32)
+    nq = int(mm_off[-1])
+    mcat = lambda key, dt: torch.from_numpy(np.concatenate([p[key] for p in mm]).astype(dt)).to(dev)
+    d_mm_pose = torch.from_numpy(np.stack([p["pose12"] for p in mm])).to(dev)
+    d_mm_frame = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), np.diff(mm_off))).to(dev)
+    d_mm_valid, d_mm_xw, d_mm_oct, d_mm_ang, d_mm_desc = mcat("valid", np.uint8), mcat("Xw", np.float32), mcat("octave", np.int32), mcat("angle", np.float32), mcat("desc", np.uint8)
+    d_mm_q = [torch.zeros(nq, dtype=torch.float32, device=dev) for _ in range(3)] + [torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(2)]
     d_cnt = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev); d_off = torch.zeros(nq + 1, dtype=torch.int32, device=dev)
     d_tot = torch.zeros(1, dtype=torch.int32, device=dev)
-    d_lvl = torch.from_numpy(t_level).to(dev)
-    d_out = [torch.zeros(max(nq, 1), dtype=torch.int32, device=dev) for _ in range(5)]
-    _, d_desc, _ = ctx.results_ptrs()
-    # size the candidate buffer with one dry run (the lists are rebuilt on the device in every step)
-    ctx.area_grid(B)
-    d_idx = torch.zeros(1, dtype=torch.int32, device=dev)
-    ctx.features_in_area_batch_device(nq, d_qframe.data_ptr(), [t.data_ptr() for t in d_q5], d_cnt.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), 0,
-                                      d_tot.data_ptr())
+    d_mm_match = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev); d_mm_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_mm_mpoff = torch.from_numpy(mm_off).to(dev)
+
+    def mm_windows(d_idx_buf, cap):
+        ctx.project_last_frame_device(nq, d_mm_frame.data_ptr(), d_mm_pose.data_ptr(), d_mm_valid.data_ptr(), d_mm_xw.data_ptr(), d_mm_oct.data_ptr(), 15.0,
+                                      [t.data_ptr() for t in d_mm_q])
+        ctx.features_in_area_batch_device(nq, d_mm_frame.data_ptr(), [t.data_ptr() for t in d_mm_q], d_cnt.data_ptr(), d_off.data_ptr(),
+                                          d_idx_buf.data_ptr(), cap, d_tot.data_ptr())
+
+    mm_windows(torch.zeros(1, dtype=torch.int32, device=dev), 0)       # dry run: size the candidate buffer
     ctx.sync()
     n_pairs = int(d_tot.item())
     cand_cap = n_pairs + 4096
-    d_idx = torch.zeros(cand_cap, dtype=torch.int32, device=dev)
+    d_idx = torch.zeros(cand_cap, dtype=torch.int32, device=dev); d_mm_pd = torch.zeros(cand_cap, dtype=torch.int16, device=dev)
 
     # ---- track local map (Tracking::SearchLocalPoints): every frame has its own pose and local map (~2000 points, about two thirds in
     # view, a quarter competing for a key point); projection, windows and the greedy search run on the device every step
@@ -230,13 +218,15 @@ def main():
             th.start()
         po.launch()                 # own stream, overlaps the frame path
         ctx.process(B, True)
-        ctx.area_grid(B)            # Frame::AssignFeaturesToGrid of the B frames, then every SearchByProjection window, on the device
-        ctx.features_in_area_batch_device(nq, d_qframe.data_ptr(), [t.data_ptr() for t in d_q5], d_cnt.data_ptr(), d_off.data_ptr(),
-                                          d_idx.data_ptr(), cand_cap, d_tot.data_ptr())
-        ctx.hamming_best2_device(d_desc, d_qrow.data_ptr(), nq, d_desc, d_off.data_ptr(), d_idx.data_ptr(), d_lvl.data_ptr(), None,
-                                 [o.data_ptr() for o in d_out])
+        ctx.area_grid(B)            # Frame::AssignFeaturesToGrid of the B frames
         with torch.cuda.stream(ext_stream):
             d_kpmp.copy_(d_kpmp0)
+        # TrackWithMotionModel's matcher: projection + windows + greedy best match (Hamming inside) + rotation histogram ...
+        mm_windows(d_idx, cand_cap)
+        ctx.search_local_points_device(B, d_mm_mpoff.data_ptr(), d_mm_desc.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), d_mm_pd.data_ptr(),
+                                       -1.0, 100, d_kpmp.data_ptr(), d_mm_match.data_ptr())
+        ctx.rotation_filter_device(B, d_mm_mpoff.data_ptr(), d_mm_ang.data_ptr(), d_kpmp.data_ptr(), d_mm_match.data_ptr(), d_mm_n.data_ptr(), True)
+        # ... then TrackLocalMap's search over the key points that are still free
         lm_windows(d_lm_idx, lm_cap)
         ctx.search_local_points_device(B, d_lm_mpoff.data_ptr(), d_lm_desc.data_ptr(), d_lm_off.data_ptr(), d_lm_idx.data_ptr(), d_lm_pd.data_ptr(),
                                        0.8, 100, d_kpmp.data_ptr(), d_lm_i[4].data_ptr())
@@ -336,25 +326,22 @@ def main():
             k, d = o.extract(ocam, cube, mask)
             descs.append(d); cpu_kps.append(k)
         t_ext = time.perf_counter() - t1
-        # candidate windows (Frame::GetFeaturesInArea) + Hamming scan for the first n - 1 frame pairs, like the GPU leg does per step
+        # TrackWithMotionModel's SearchByProjection, then TrackLocalMap's SearchLocalPoints on what is left, per frame like the GPU leg
         t1 = time.perf_counter()
-        pairs = 0
-        sc32 = np.asarray(scales, np.float32)
-        for b in range(1, n):
-            last, cur = cpu_kps[b - 1], cpu_kps[b]
-            if len(last) == 0 or len(cur) == 0:
-                continue
-            off2, idx2 = orc.features_in_area(ocam, cur["x"], cur["y"], cur["octave"], last["x"], last["y"], np.float32(15.0) * sc32[last["octave"]],
-                                              last["octave"] - 1, last["octave"] + 1)
-            orc.hamming_best2(descs[b - 1], descs[b], off2, idx2, cur["octave"].astype(np.int32))
-            pairs += 1
+        kp_after = []
+        for b in range(n):
+            kb, db = fetched[b]
+            kpm = np.full(len(kb), -1, np.int32)
+            orc.search_by_projection_frames(ocam, mm[b]["pose12"][:9], mm[b]["pose12"][9:], kb["x"], kb["y"], kb["octave"], kb["angle"], db, mm[b]["scale_factors"],
+                                            mm[b]["valid"], mm[b]["Xw"], mm[b]["octave"], mm[b]["angle"], mm[b]["desc"], kpm, th=15.0, check_ori=True)
+            kp_after.append(kpm)
         t_match = time.perf_counter() - t1
+        pairs = n
         t1 = time.perf_counter()
-        for b in range(n):          # Tracking::SearchLocalPoints on the same local maps (key points of the GPU leg's frames)
+        for b in range(n):
             kb, db = fetched[b]
             fr = orc.is_in_frustum(ocam, lm[b]["pose15"], lm[b]["pos"], lm[b]["normal"], lm[b]["min_dist"], lm[b]["max_dist"])
-            orc.search_local_points(ocam, kb["x"], kb["y"], kb["octave"], db, lm[b]["scale_factors"], fr, lm[b]["desc"],
-                                    np.full(len(kb), -1, np.int32))
+            orc.search_local_points(ocam, kb["x"], kb["y"], kb["octave"], db, lm[b]["scale_factors"], fr, lm[b]["desc"], kp_after[b])
         t_local = (time.perf_counter() - t1) / n
         t1 = time.perf_counter()
         S0 = tri_sets[0]
@@ -373,7 +360,7 @@ def main():
         t_pose = (time.perf_counter() - t1) / min(n, 8)
         per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_local + t_pose + (t_ba + t_tri) / args.ba_every
         cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "%d frames remap+extract (%.1f ms/frame), windows + Hamming over %.1f frame pairs (%.2f ms/frame), local-map search "
+               "sample": "%d frames remap+extract (%.1f ms/frame), frame-to-frame SearchByProjection over %.1f frames (%.2f ms/frame), local-map search "
                          "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), CreateNewMapPoints (%.1f ms per key frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
                          "oracle/liborc.so, single thread" %
                          (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, n_cpu_ba, 1e3 * t_ba,
@@ -399,7 +386,8 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (extract/match), f64 (BA)", "data": "synthetic",
             "config": {"workload": "Lafida cam0 synthetic stream, 754x480 fisheye, face=%d (%dx%d cross), nFeatures %d; per step %d frames: "
-                                   "remap+ORB extract, frame grids + GetFeaturesInArea windows + Hamming best-2 (%d queries, %d candidate pairs), "
+                                   "remap+ORB extract, frame grids, frame-to-frame SearchByProjection (projection + GetFeaturesInArea windows + greedy Hamming match + rotation histogram: "
+                                   "%d map points, %d candidate pairs), "
                                    "local-map search (isInFrustum + SearchByProjection, %d map points, %d candidate pairs), pose-only optimisation (%d edges/frame), "
                                    "%d key frames x (CreateNewMapPoints against 20 neighbours + local BA window K=20, E=%d)"
                                    % (F, 3 * F, 3 * F, nfeat, B, nq, n_pairs, n_mp, lm_pairs, args.pose_edges, n_ba, len(prob["e_pose"])),

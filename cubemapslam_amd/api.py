@@ -356,6 +356,17 @@ class Context:
                                             C.addressof(nm)), "cms_search_by_projection")
         return match, nm.value
 
+    def project_last_frame_device(self, n, d_qframe, d_pose12, d_valid, d_Xw, d_oct, th, d_q5):
+        """d_q5 = (qx, qy, qr, qmin, qmax) raw device pointers"""
+        v = lambda a: C.c_void_p(int(a)) if a else None
+        _chk(lib().cms_project_last_frame_device(self.h, n, v(d_qframe), v(d_pose12), v(d_valid), v(d_Xw), v(d_oct), th, *[v(a) for a in d_q5]),
+             "cms_project_last_frame_device")
+
+    def rotation_filter_device(self, B, d_mp_off, d_last_angle, d_kp_mp, d_mp_match, d_n_matches, check_orientation=True):
+        v = lambda a: C.c_void_p(int(a)) if a else None
+        _chk(lib().cms_rotation_filter_device(self.h, B, v(d_mp_off), v(d_last_angle), v(d_kp_mp), v(d_mp_match), v(d_n_matches), int(check_orientation)),
+             "cms_rotation_filter_device")
+
     def is_in_frustum_device(self, nmp, d_mp_frame, d_pose15, d_pos, d_normal, d_min, d_max, viewing_cos_limit, th, d_outs5, d_q3):
         """d_outs5 = (in_view u8, proj_x, proj_y, level, view_cos); d_q3 = (qr, qmin, qmax) or (0, 0, 0); raw device pointers"""
         v = lambda a: C.c_void_p(int(a)) if a else None

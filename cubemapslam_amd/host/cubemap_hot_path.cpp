@@ -293,6 +293,41 @@ int Tracking::SearchLocalPoints(FrameView& F, std::vector<MapPointView>& mps, fl
 
 int ORBMatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, float th, bool) {
   const int N2 = (int)Cur.mvKeys.size();
+  if (!Last.mvMapPointPos.empty() && Cur.mTcw.rows == 4 && Cur.mTcw.cols == 4 && N2 > 0) {
+    // the whole function on the device (cms_search_by_projection)
+    const int NL = (int)Last.mvKeys.size();
+    cms_ctx* dctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+    float pose12[12];
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) pose12[3 * r + c] = Cur.mTcw.at<float>(r, c); pose12[9 + r] = Cur.mTcw.at<float>(r, 3); }
+    std::vector<uint8_t> valid(NL), mpd(32 * (size_t)NL), tdesc(32 * (size_t)N2);
+    std::vector<float> Xw(3 * (size_t)NL), ang(NL);
+    std::vector<int> oct(NL), kp_mp(N2, -1), match(NL, -1);
+    for (int i = 0; i < NL; ++i) {
+      valid[i] = Last.mvpMapPoints[i] >= 0 && !(i < (int)Last.mvbOutlier.size() && Last.mvbOutlier[i]);
+      for (int c = 0; c < 3; ++c) Xw[3 * (size_t)i + c] = Last.mvMapPointPos[i].v[c];
+      oct[i] = Last.mvKeys[i].octave; ang[i] = Last.mvKeys[i].angle;
+      std::memcpy(&mpd[32 * (size_t)i], Last.mMapPointDescriptors.ptr<uint8_t>(i), 32);
+    }
+    std::vector<cms_keypoint> kps(N2);
+    for (int j = 0; j < N2; ++j) {
+      const cv::KeyPoint& k = Cur.mvKeys[j];
+      kps[j].x = k.pt.x; kps[j].y = k.pt.y; kps[j].size = k.size; kps[j].angle = k.angle; kps[j].response = k.response; kps[j].octave = k.octave;
+      std::memcpy(&tdesc[32 * (size_t)j], Cur.mDescriptors.ptr<uint8_t>(j), 32);
+      if (Cur.mvpMapPoints[j] >= 0) kp_mp[j] = 0x40000000;
+    }
+    int nm = 0;
+    {
+      std::lock_guard<std::mutex> lock(g_ctx_mutex);
+      int rc = cms_area_set_keypoints(dctx, 0, N2, kps.data());
+      if (rc == CMS_OK) rc = cms_area_set_descriptors(dctx, 0, N2, tdesc.data());
+      if (rc == CMS_OK) rc = cms_area_grid(dctx, 1);
+      if (rc == CMS_OK) rc = cms_search_by_projection(dctx, 0, pose12, NL, valid.data(), Xw.data(), oct.data(), ang.data(), mpd.data(), th, mbCheckOrientation ? 1 : 0,
+                                                     TH_HIGH, N2, kp_mp.data(), match.data(), &nm);
+      if (rc != CMS_OK) throw std::runtime_error(std::string("cms_search_by_projection: ") + cms_last_error());
+    }
+    for (int i = 0; i < NL; ++i) if (match[i] >= 0) Cur.mvpMapPoints[match[i]] = Last.mvpMapPoints[i];
+    return nm;
+  }
   cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
   // candidate windows: CurrentFrame.GetFeaturesInArea(u, v, th * scale[octave], octave - 1, octave + 1) (ORBMatcher.cpp:176-181) for
   // every projected map point of the last frame, answered on the device by the frame grid of the current frame's key points --

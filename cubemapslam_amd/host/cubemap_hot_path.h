@@ -96,7 +96,11 @@ struct FrameView {
   std::vector<uint8_t> mvbOutlier;
   std::vector<cv::Point2f> projInCurrent;  // last frame only: where map point i projects in the current frame
   std::vector<float> mvScaleFactors;
-  cv::Mat mTcw;                         // 4x4 CV_32F (Tracking::SearchLocalPoints only)
+  cv::Mat mTcw;                         // 4x4 CV_32F (Frame::SetPose): SearchLocalPoints, and SearchByProjection's device path
+  // last frame only, optional: world position and descriptor of the map point behind key point i (MapPoint::GetWorldPos / GetDescriptor).
+  // When given (and CurrentFrame.mTcw is set) SearchByProjection projects on the device instead of reading projInCurrent.
+  std::vector<cv::Vec3f> mvMapPointPos;
+  cv::Mat mMapPointDescriptors;         // N x 32 CV_8U
 };
 
 struct KeyFrameView;
@@ -107,8 +111,10 @@ class ORBMatcher {
   ORBMatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
   static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);   // ORBMatcher.cpp:951-967 (single pair, host)
   // ORBMatcher.cpp:130-251: windows of radius th*scale[octave] around the projections, octave +-1, best Hamming <= TH_HIGH,
-  // rotation-histogram consistency.  Distances / arg-min run on the GPU (cms_hamming_best2); the greedy acceptance is
-  // replayed on the host in the reference's order.  Returns the number of matches, fills CurrentFrame.mvpMapPoints.
+  // rotation-histogram consistency.  With LastFrame.mvMapPointPos + CurrentFrame.mTcw the whole function runs on the device
+  // (cms_search_by_projection: projection, windows, greedy, histogram).  Otherwise the projections are read from projInCurrent,
+  // distances / arg-min run on the GPU (cms_hamming_best2) and the greedy acceptance is replayed on the host in the reference's
+  // order.  Returns the number of matches, fills CurrentFrame.mvpMapPoints.
   int SearchByProjection(FrameView& CurrentFrame, const FrameView& LastFrame, float th, bool bMono);
   // ORBMatcher.cpp:1127-1226: search on the device (cms_fuse_search), then the reference's Replace / AddObservation decisions in list
   // order: fused[i] = key point map point i is fused with (or -1); returns nFused.  mvpMapPoints of pKF is updated for additions.

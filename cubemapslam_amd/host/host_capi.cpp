@@ -70,6 +70,32 @@ extern "C" int hm_search_by_projection(int ncur, const cms_keypoint* cur_k, cons
     for (int j = 0; j < ncur; ++j) cur_mp[j] = cur.mvpMapPoints[j];
     return n;)
 }
+// frame-to-frame SearchByProjection, device path: the last frame's map points come with position + descriptor, the current frame with its pose
+extern "C" int hm_search_by_projection_pose(int ncur, const cms_keypoint* cur_k, const uint8_t* cur_d, long* cur_mp, float* Tcw, int nlast,
+                                            const cms_keypoint* last_k, const long* last_mp, const uint8_t* last_outlier, const float* mp_pos,
+                                            const uint8_t* mp_desc, float th, int check_ori) {
+  HM_TRY(
+    FrameView cur, last;
+    cur.mvKeys.resize(ncur); cur.mDescriptors.create(ncur > 0 ? ncur : 1, 32, cv::CV_8U);
+    for (int i = 0; i < ncur; ++i) {
+      cur.mvKeys[i].pt = cv::Point2f(cur_k[i].x, cur_k[i].y); cur.mvKeys[i].angle = cur_k[i].angle; cur.mvKeys[i].octave = cur_k[i].octave;
+      std::memcpy(cur.mDescriptors.ptr<uint8_t>(i), cur_d + (size_t)i * 32, 32);
+    }
+    cur.mvpMapPoints.assign(cur_mp, cur_mp + ncur);
+    cur.mTcw = cv::Mat(4, 4, cv::CV_32F, Tcw, 16);
+    last.mvKeys.resize(nlast); last.mvMapPointPos.resize(nlast); last.mMapPointDescriptors.create(nlast > 0 ? nlast : 1, 32, cv::CV_8U);
+    for (int i = 0; i < nlast; ++i) {
+      last.mvKeys[i].pt = cv::Point2f(last_k[i].x, last_k[i].y); last.mvKeys[i].angle = last_k[i].angle; last.mvKeys[i].octave = last_k[i].octave;
+      for (int c = 0; c < 3; ++c) last.mvMapPointPos[i].v[c] = mp_pos[3 * (size_t)i + c];
+      std::memcpy(last.mMapPointDescriptors.ptr<uint8_t>(i), mp_desc + (size_t)i * 32, 32);
+    }
+    last.mvpMapPoints.assign(last_mp, last_mp + nlast);
+    last.mvbOutlier.assign(last_outlier, last_outlier + nlast);
+    ORBMatcher matcher(0.9f, check_ori != 0);
+    const int n = matcher.SearchByProjection(cur, last, th, true);
+    for (int j = 0; j < ncur; ++j) cur_mp[j] = cur.mvpMapPoints[j];
+    return n;)
+}
 // Tracking::SearchLocalPoints: Tcw 16 floats (row major 4x4); map points as flat arrays; outputs per map point + cur_mp[j] updated
 extern "C" int hm_search_local_points(int ncur, const cms_keypoint* cur_k, const uint8_t* cur_d, long* cur_mp, const float* scale_factors, int nlevels,
                                       float* Tcw, int nmp, const long* mp_id, const float* pos, const float* normal, const float* min_dist,

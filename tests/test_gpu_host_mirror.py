@@ -301,3 +301,38 @@ def test_mirror_create_new_map_points():
     assert n == len(wn) and n > 200, (n, len(wn), L.hm_last_error())
     assert np.array_equal(on[:n], wn) and np.array_equal(o1[:n], w1) and np.array_equal(o2[:n], w2)
     assert np.array_equal(ox[:n].view(np.uint32), wx.view(np.uint32))
+
+
+def test_mirror_search_by_projection_device_path():
+    """ORBMatcher::SearchByProjection(CurrentFrame, LastFrame) through the mirror's device path (pose + map points given) == oracle"""
+    import test_area_emu as te
+    L = _host()
+    L.hm_search_by_projection_pose.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int]
+    F = 450
+    camd = synth.camera("lafida", F)
+    cam = api.make_camera(camd)
+    assert L.hm_set_camera(C.byref(cam)) == 0
+    ocam = orc.make_camera(camd)
+    W = 3 * F
+    img = np.ascontiguousarray(synth.texture(W, W, 95)); msk = np.full((W, W), 255, np.uint8)
+    k0 = np.zeros(3000, KP); d0 = np.zeros((3000, 32), np.uint8)
+    assert L.hm_extract(2000, 1.2, 8, 20, 7, _p(img), W, _p(msk), W, _p(k0), _p(d0), 3000) > 0, L.hm_last_error()
+    kx, ky, ko = te._keypoints(F, 1700, 96)
+    kd = synth.descriptors(len(kx), 97)
+    ka = np.random.default_rng(98).uniform(0, 360, len(kx)).astype(np.float32)
+    pr = synth.motion_model_problem(F, kx, ky, ko, ka, kd, seed=99)
+    taken = np.full(len(kx), -1, np.int32); taken[::9] = 10**6
+    want_kp = taken.copy()
+    want, nm = orc.search_by_projection_frames(ocam, pr["pose12"][:9], pr["pose12"][9:], kx, ky, ko, ka, kd, pr["scale_factors"], pr["valid"], pr["Xw"],
+                                               pr["octave"], pr["angle"], pr["desc"], want_kp, th=15.0, check_ori=True)
+    ck = np.zeros(len(kx), KP); ck["x"] = kx; ck["y"] = ky; ck["octave"] = ko; ck["angle"] = ka
+    nl = len(pr["valid"])
+    lk = np.zeros(nl, KP); lk["octave"] = pr["octave"]; lk["angle"] = pr["angle"]
+    last_mp = np.where(pr["valid"] > 0, np.arange(nl) + 7000, -1).astype(np.int64)
+    cur_mp = np.where(taken >= 0, 10**6, -1).astype(np.int64)
+    Tcw = np.eye(4, dtype=np.float32); Tcw[:3, :3] = pr["pose12"][:9].reshape(3, 3); Tcw[:3, 3] = pr["pose12"][9:]
+    n = L.hm_search_by_projection_pose(len(ck), _p(ck), _p(kd), _p(cur_mp), _p(Tcw), nl, _p(lk), _p(last_mp), _p(np.zeros(nl, np.uint8)), _p(pr["Xw"]),
+                                       _p(pr["desc"]), 15.0, 1)
+    assert n == nm and nm > 300, (n, nm, L.hm_last_error())
+    want_mp = np.where(want_kp >= 0, np.where(want_kp == 10**6, 10**6, want_kp + 7000), -1)
+    assert np.array_equal(cur_mp, want_mp)
