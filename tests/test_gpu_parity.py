@@ -755,3 +755,43 @@ def test_search_by_projection_frames_matches_oracle():
             assert np.array_equal(got_kp, want_kp)
             assert nm > 100
         ctx.close()
+
+
+def test_product_reproduces_golden_vectors():
+    """the HIP path against the committed regression vectors (tests/golden/oracle_v1.npz) directly -- no live oracle in between"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    import test_area_emu as te
+    want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_v1.npz"))
+    F = 150
+    camd = synth.camera("lafida", F)
+    ctx = api.Context(camd, nfeatures=800, max_batch=1)
+    ctx.set_mask(synth.cubemap_valid_mask(camd, erode=5, band=30))
+    fish = synth.texture(camd["Ih"], camd["Iw"], 3)
+    k, d = ctx.remap_extract(fish)
+    assert len(k) == int(want["kp_count"][0]) and np.array_equal(mg.h(k.view(np.uint8)), want["kp_hash"]) and np.array_equal(mg.h(d), want["desc_hash"])
+    kx, ky, ko = te._keypoints(F, 600, 1)
+    kd = synth.descriptors(len(kx), 3)
+    ka = np.random.default_rng(5).uniform(0, 360, len(kx)).astype(np.float32)
+    kps = np.zeros(len(kx), api.KP_DTYPE); kps["x"] = kx; kps["y"] = ky; kps["octave"] = ko; kps["angle"] = ka
+    ctx.area_set_keypoints(0, kps); ctx.area_set_descriptors(0, kd); ctx.area_grid(1)
+    qx, qy, qr, lo, hi, _ = te._queries(F, 800, 2)
+    off, idx = ctx.features_in_area(0, qx, qy, qr, lo, hi)
+    assert np.array_equal(mg.h(off), want["area_off_hash"]) and np.array_equal(mg.h(idx), want["area_idx_hash"])
+    lm = synth.local_map_problem(F, kx, ky, ko, kd, seed=4)
+    r = ctx.search_local_points(0, lm["pose15"], lm["pos"], lm["normal"], lm["min_dist"], lm["max_dist"], lm["desc"], np.full(len(kx), -1, np.int32), th=5.0)
+    fr_hash = mg.h(np.concatenate([r["in_view"].astype(np.float32), r["proj_x"], r["proj_y"], r["level"].astype(np.float32), r["view_cos"]]))
+    assert np.array_equal(fr_hash, want["frustum_hash"]) and np.array_equal(r["match"], want["local_match"])
+    mm = synth.motion_model_problem(F, kx, ky, ko, ka, kd, seed=6)
+    m2, n2 = ctx.search_by_projection(0, mm["pose12"], mm["valid"], mm["Xw"], mm["octave"], mm["angle"], mm["desc"], np.full(len(kx), -1, np.int32))
+    assert np.array_equal(m2, want["frame_match"]) and n2 == int(want["frame_nm"][0])
+    S = synth.keyframe_set(F, n_kf=4, n_pts=900, seed=7)
+    ocam = orc.make_camera(camd)
+    for q in S["kfs"]:
+        q["rays"] = orc.keyframe_rays(ocam, q["x"], q["y"])            # mvKeyRays (an input of the step)
+    g = [api.make_keyframe(q) for q in S["kfs"]]
+    on, o1, o2, ox = api.create_new_map_points(ctx, [(g[0][0], [q for q, _ in g[1:]])])[0]
+    assert np.array_equal(on, want["tri_neigh"]) and np.array_equal(o1, want["tri_idx1"]) and np.array_equal(o2, want["tri_idx2"])
+    assert np.array_equal(ox.view(np.uint32), want["tri_x3d"].view(np.uint32))
+    ctx.close()
