@@ -142,13 +142,18 @@ __device__ __forceinline__ void ba_lm_after_trial(BaLmDev* L, BaLmDev* H, double
   *H = *L;
 }
 
+// Device-side Levenberg state: from the second iteration of a stage on, the estimate an iteration starts from is the trial the previous
+// iteration accepted -- its residuals are already in d.err and its chi2 is currentChi (kb_ba_trial_points / kb_ba_reduce2 produced
+// both), so computeActiveErrors + activeRobustChi2 would only recompute them: these two kernels have work on a stage's first iteration only.
 extern "C" __global__ void __launch_bounds__(256) kb_ba_errors(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_e)
+  if (dyn.dev_lm && !ba_first) return;
   ba_errors_body(blockIdx.x, it.nblk_e, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.partial);
 }
 // chi2 of the current estimate -> scal[0]
 extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
+  if (dyn.dev_lm && !ba_first) return;
   ba_reduce_body(0, 1, it.partial, it.nblk_e, it.scal, 0);
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_lin_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
@@ -185,7 +190,7 @@ extern "C" __global__ void __launch_bounds__(1024) kb_ba_maxdiag(const BaItem* _
   }
   if (threadIdx.x == 0) {
     it.hscal[0] = it.scal[0];
-    if (dyn.dev_lm) ba_lm_after_iter(it.lm, it.hlm, it.scal[0], mx_all);
+    if (dyn.dev_lm) ba_lm_after_iter(it.lm, it.hlm, ba_first ? it.scal[0] : it.lm->currentChi, mx_all);
   }
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_dinv(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
