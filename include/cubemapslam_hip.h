@@ -12,7 +12,9 @@
  * Threading contract (reference: Tracking thread extracts/matches, LocalMapping thread runs local BA concurrently,
  * System.cpp:108-127): a cms_ctx owns one HIP stream for the frame path; every cms_ba handle owns its own stream.
  * Frame-path calls on one ctx must come from one thread at a time; BA calls on one handle likewise; the two may
- * overlap freely.
+ * overlap freely.  The window-query, projection-search, mapping (cms_create_new_map_points, cms_kfstore_*, cms_fuse_search) and
+ * map-point entries use the stream and the scratch arena of the ctx they are given: a mapping thread that runs next to a tracking
+ * thread creates its own cms_ctx (bench.py does).
  */
 #ifndef CUBEMAPSLAM_HIP_H
 #define CUBEMAPSLAM_HIP_H
