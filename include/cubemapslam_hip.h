@@ -198,7 +198,9 @@ int cms_features_in_area_batch_device(cms_ctx* ctx, int nq, const void* d_qframe
  * The _device entries take device pointers, work on all frames of a batch at once and are asynchronous on the ctx stream:
  * cms_is_in_frustum_device also writes the window of every point (qr < 0: not in view) for cms_features_in_area_batch_device;
  * cms_search_local_points_device takes that CSR (indices = batch rows), mp_off[B+1] (map points grouped by frame, list order
- * inside a frame), scratch pair_dist (2 bytes per candidate) and kp_mp over all batch rows; mp_match = batch row or -1. */
+ * inside a frame), scratch pair_dist (2 bytes per candidate) and kp_mp over all batch rows; mp_match = batch row or -1.
+ * Limits: at most 32768 map points per frame and 4096 key points per frame (CMS_ERR_UNSUPPORTED from the host entries; the device
+ * entries trust mp_off). */
 int cms_area_set_descriptors(cms_ctx* ctx, int b, int n, const uint8_t* desc);
 /* ORBMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBMatcher.cpp:130-251), the matcher of
  * Tracking::TrackWithMotionModel, whole on the device: the last frame's map points are projected with the current pose (Rcw | tcw of
