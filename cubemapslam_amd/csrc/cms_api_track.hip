@@ -46,7 +46,7 @@ extern "C" int cms_search_local_points_device(cms_ctx* c, int B, const void* d_m
   a.mp_off = (const int*)d_mp_off; a.mp_desc = (const uint4*)d_mp_desc; a.cand_off = (const int*)d_cand_off; a.cand_idx = (const int*)d_cand_idx;
   a.t_desc = (const uint4*)c->d_desc; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_cap = c->g.kp_cap;
   a.pair_dist = (uint16_t*)d_pair_dist; a.kp_mp = (int*)d_kp_mp; a.mp_match = (int*)d_mp_match; a.rounds = (int*)d_rounds;
-  a.nnratio = nnratio; a.th_high = th_high; a.frame0 = 0;
+  a.nnratio = nnratio; a.th_high = th_high; a.frame0 = 0; a.total = nullptr; a.cap = 0;
   hipLaunchKernelGGL(k_search_local, dim3(B), dim3(1024), 0, c->stream, a);
   HIPCHK(hipGetLastError());
   return CMS_OK;
@@ -64,81 +64,79 @@ extern "C" int cms_search_local_points(cms_ctx* c, int b, const float* pose15, i
     return cms_fail(CMS_ERR_ARG, "cms_search_local_points: bad argument");
   if (b < 0 || b >= c->area_frames) return cms_fail(CMS_ERR_ARG, "cms_search_local_points: no grid for this frame (cms_area_grid first)");
   if (nmp > CMS_TRACK_MAX_MP_PER_FRAME) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points: more than 32768 map points per frame");
+  if (c->g.kp_cap > CMS_TRACK_KPMAX) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points: more than 4096 key points per frame");
   if (n_matches) *n_matches = 0;
   if (rounds) *rounds = 0;
   if (nmp == 0) return CMS_OK;
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const size_t n4 = (size_t)nmp * 4, rows = (size_t)c->g.kp_cap * (size_t)c->max_batch;
+  const size_t n4 = (size_t)nmp * 4, kp4 = (size_t)c->g.kp_cap * 4;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  // arena: pose | pos | normal | min | max | desc | in_view | px | py | level | vcos | qr | qmin | qmax | cnt | off | total | mp_off | match | rounds | kp_mp(all rows)
+  // one block in (pose .. mp_off), one block out (kp_mp .. rounds): one pinned copy each way, no synchronisation in between
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
   const size_t o_pose = take(64), o_pos = take(3 * n4), o_nrm = take(3 * n4), o_min = take(n4), o_max = take(n4), o_desc = take((size_t)nmp * 32),
-               o_vis = take(nmp), o_px = take(n4), o_py = take(n4), o_lvl = take(n4), o_vc = take(n4), o_qr = take(n4), o_qmin = take(n4),
-               o_qmax = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16), o_mpoff = take(16), o_match = take(n4),
-               o_rounds = take(16), o_kpmp = take(rows * 4), o_qf = take(n4);
+               o_qf = take(n4), o_mpoff = take(16), o_kpmp = take(kp4);
+  const size_t in_bytes = o;
+  const size_t o_vis = take(nmp), o_px = take(n4), o_py = take(n4), o_lvl = take(n4), o_vc = take(n4), o_match = take(n4), o_tot = take(16), o_rounds = take(16);
+  const size_t out_begin = o_kpmp, out_bytes = o - o_kpmp;
+  const size_t o_qr = take(n4), o_qmin = take(n4), o_qmax = take(n4), o_cnt = take(n4), o_off = take(n4 + 4);
   const size_t fixed = o;
   int cap = 64 * nmp + 1024;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
     int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
     if (rc) return rc;
+    rc = cms_hstage(c, std::max(in_bytes, out_bytes));
+    if (rc) return rc;
     uint8_t* p = (uint8_t*)c->d_match;
-    HIPCHK(hipMemcpyAsync(p + o_pose, pose15, 60, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_pos, pos, 3 * n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_nrm, normal, 3 * n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_min, min_dist, n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_max, max_dist, n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(p + o_kpmp, 0xFF, rows * 4, s));
-    if (nkp > 0) HIPCHK(hipMemcpyAsync(p + o_kpmp + (size_t)b * c->g.kp_cap * 4, kp_mp, (size_t)nkp * 4, hipMemcpyHostToDevice, s));
-    const std::vector<int> qf((size_t)nmp, b);
-    HIPCHK(hipMemcpyAsync(p + o_qf, qf.data(), n4, hipMemcpyHostToDevice, s));
+    uint8_t* h = c->h_stage;
+    memcpy(h + o_pose, pose15, 60);
+    memcpy(h + o_pos, pos, 3 * n4); memcpy(h + o_nrm, normal, 3 * n4); memcpy(h + o_min, min_dist, n4); memcpy(h + o_max, max_dist, n4);
+    memcpy(h + o_desc, mp_desc, (size_t)nmp * 32);
+    { int* qf = reinterpret_cast<int*>(h + o_qf); for (int i = 0; i < nmp; ++i) qf[i] = b; }
+    { int* mo = reinterpret_cast<int*>(h + o_mpoff); mo[0] = 0; mo[1] = nmp; }
+    { int* km = reinterpret_cast<int*>(h + o_kpmp); for (int k = 0; k < c->g.kp_cap; ++k) km[k] = k < nkp ? kp_mp[k] : -1; }
+    HIPCHK(hipMemcpyAsync(p, h, in_bytes, hipMemcpyHostToDevice, s));
     rc = cms_is_in_frustum_device(c, nmp, nullptr, p + o_pose, p + o_pos, p + o_nrm, p + o_min, p + o_max, viewing_cos_limit, th, p + o_vis,
                                   p + o_px, p + o_py, p + o_lvl, p + o_vc, p + o_qr, p + o_qmin, p + o_qmax);
     if (rc) return rc;
     rc = cms_features_in_area_batch_device(c, nmp, p + o_qf, p + o_px, p + o_py, p + o_qr, p + o_qmin, p + o_qmax, p + o_cnt, p + o_off, p + o_idx,
                                            cap, p + o_tot);
     if (rc) return rc;
-    int tot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (tot > cap) { cap = tot + 64; continue; }               // denser than 64 candidates per window: once more with the exact size
-    const int mpoff[2] = {0, nmp};                               // one workgroup: frame b (frame0 shifts the key-point rows)
-    HIPCHK(hipMemcpyAsync(p + o_mpoff, mpoff, sizeof(mpoff), hipMemcpyHostToDevice, s));
     CmsSearchLocalArgs a;
     a.mp_off = (const int*)(p + o_mpoff); a.mp_desc = (const uint4*)(p + o_desc); a.cand_off = (const int*)(p + o_off); a.cand_idx = (const int*)(p + o_idx);
     a.t_desc = (const uint4*)c->d_desc; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_cap = c->g.kp_cap;
-    a.pair_dist = (uint16_t*)(p + o_pd); a.kp_mp = (int*)(p + o_kpmp); a.mp_match = (int*)(p + o_match); a.rounds = (int*)(p + o_rounds);
-    a.nnratio = nnratio; a.th_high = th_high; a.frame0 = b;
-    if (c->g.kp_cap > CMS_TRACK_KPMAX) { return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points: more than 4096 key points per frame"); }
+    a.pair_dist = (uint16_t*)(p + o_pd);
+    a.kp_mp = (int*)(p + o_kpmp) - (size_t)b * c->g.kp_cap;          // indexed by batch row: only frame b's rows are ever touched
+    a.mp_match = (int*)(p + o_match); a.rounds = (int*)(p + o_rounds);
+    a.nnratio = nnratio; a.th_high = th_high; a.frame0 = b; a.total = (const int*)(p + o_tot); a.cap = cap;
+    // (window lists longer than `cap` are cut by the query kernel; the search kernel then sees *total > cap and does nothing)
     hipLaunchKernelGGL(k_search_local, dim3(1), dim3(1024), 0, s, a);
     HIPCHK(hipGetLastError());
-    std::vector<int> match((size_t)nmp);
-    HIPCHK(hipMemcpyAsync(match.data(), p + o_match, n4, hipMemcpyDeviceToHost, s));
-    if (nkp > 0) HIPCHK(hipMemcpyAsync(kp_mp, p + o_kpmp + (size_t)b * c->g.kp_cap * 4, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
-    if (in_view) HIPCHK(hipMemcpyAsync(in_view, p + o_vis, nmp, hipMemcpyDeviceToHost, s));
-    if (proj_x) HIPCHK(hipMemcpyAsync(proj_x, p + o_px, n4, hipMemcpyDeviceToHost, s));
-    if (proj_y) HIPCHK(hipMemcpyAsync(proj_y, p + o_py, n4, hipMemcpyDeviceToHost, s));
-    if (level) HIPCHK(hipMemcpyAsync(level, p + o_lvl, n4, hipMemcpyDeviceToHost, s));
-    if (view_cos) HIPCHK(hipMemcpyAsync(view_cos, p + o_vc, n4, hipMemcpyDeviceToHost, s));
-    int r = 0;
-    HIPCHK(hipMemcpyAsync(&r, p + o_rounds, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + out_begin, p + out_begin, out_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    const int tot = *reinterpret_cast<const int*>(h + o_tot);
+    if (tot > cap) { cap = tot + 64; continue; }               // denser than 64 candidates per window: once more with the exact size
+    const int* match = reinterpret_cast<const int*>(h + o_match);
+    if (nkp > 0) memcpy(kp_mp, h + o_kpmp, (size_t)nkp * 4);
+    if (in_view) memcpy(in_view, h + o_vis, nmp);
+    if (proj_x) memcpy(proj_x, h + o_px, n4);
+    if (proj_y) memcpy(proj_y, h + o_py, n4);
+    if (level) memcpy(level, h + o_lvl, n4);
+    if (view_cos) memcpy(view_cos, h + o_vc, n4);
     int nm = 0;
     for (int i = 0; i < nmp; ++i) {
-      const int m = match[(size_t)i];
+      const int m = match[i];
       mp_match[i] = m >= 0 ? m - b * c->g.kp_cap : -1;         // batch row -> key point index of frame b
       nm += m >= 0;
     }
     if (n_matches) *n_matches = nm;
-    if (rounds) *rounds = r;
+    if (rounds) *rounds = *reinterpret_cast<const int*>(h + o_rounds);
     return CMS_OK;
   }
   return cms_fail(CMS_ERR_OVERFLOW, "cms_search_local_points: candidate lists kept growing");
 }
-
 
 // ---- ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono): device-pointer pieces (asynchronous on the ctx stream) ...
 extern "C" int cms_project_last_frame_device(cms_ctx* c, int n, const void* d_qframe, const void* d_pose12, const void* d_valid, const void* d_Xw,
@@ -167,7 +165,7 @@ extern "C" int cms_rotation_filter_device(cms_ctx* c, int B, const void* d_mp_of
   HIPCHK(hipSetDevice(c->device));
   CmsRotFilterArgs a;
   a.mp_off = (const int*)d_mp_off; a.last_angle = (const float*)d_last_angle; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_mp = (int*)d_kp_mp;
-  a.mp_match = (int*)d_mp_match; a.n_matches = (int*)d_n_matches; a.check_orientation = check_orientation;
+  a.mp_match = (int*)d_mp_match; a.n_matches = (int*)d_n_matches; a.check_orientation = check_orientation; a.total = nullptr; a.cap = 0;
   hipLaunchKernelGGL(k_rot_filter, dim3(B), dim3(1024), 0, c->stream, a);
   HIPCHK(hipGetLastError());
   return CMS_OK;
@@ -184,66 +182,63 @@ extern "C" int cms_search_by_projection(cms_ctx* c, int b, const float* pose12, 
     return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: bad argument");
   if (b < 0 || b >= c->area_frames) return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: no grid for this frame (cms_area_grid first)");
   if (nlast > CMS_TRACK_MAX_MP_PER_FRAME) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_by_projection: more than 32768 queries");
+  if (c->g.kp_cap > CMS_TRACK_KPMAX) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_by_projection: more than 4096 key points per frame");
   if (n_matches) *n_matches = 0;
   if (nlast == 0) return CMS_OK;
   for (int i = 0; i < nlast; ++i)
     if (valid[i] && (octave[i] < 0 || octave[i] >= c->g.nlevels)) return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: octave out of range");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const size_t n4 = (size_t)nlast * 4, rows = (size_t)c->g.kp_cap * (size_t)c->max_batch;
+  const size_t n4 = (size_t)nlast * 4, kp4 = (size_t)c->g.kp_cap * 4;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
   const size_t o_pose = take(64), o_valid = take(nlast), o_xw = take(3 * n4), o_oct = take(n4), o_ang = take(n4), o_desc = take((size_t)nlast * 32),
-               o_qx = take(n4), o_qy = take(n4), o_qr = take(n4), o_qmin = take(n4), o_qmax = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16),
-               o_mpoff = take(16), o_match = take(n4), o_nm = take(16), o_kpmp = take(rows * 4), o_qf = take(n4);
+               o_qf = take(n4), o_mpoff = take(16), o_kpmp = take(kp4);
+  const size_t in_bytes = o;
+  const size_t o_match = take(n4), o_nm = take(16), o_tot = take(16);
+  const size_t out_begin = o_kpmp, out_bytes = o - o_kpmp;
+  const size_t o_qx = take(n4), o_qy = take(n4), o_qr = take(n4), o_qmin = take(n4), o_qmax = take(n4), o_cnt = take(n4), o_off = take(n4 + 4);
   const size_t fixed = o;
   int cap = 64 * nlast + 1024;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
     int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
     if (rc) return rc;
+    rc = cms_hstage(c, std::max(in_bytes, out_bytes));
+    if (rc) return rc;
     uint8_t* p = (uint8_t*)c->d_match;
-    HIPCHK(hipMemcpyAsync(p + o_pose, pose12, 48, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_valid, valid, nlast, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_xw, Xw, 3 * n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_oct, octave, n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_ang, angle, n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nlast * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(p + o_kpmp, 0xFF, rows * 4, s));
-    if (nkp > 0) HIPCHK(hipMemcpyAsync(p + o_kpmp + (size_t)b * c->g.kp_cap * 4, kp_mp, (size_t)nkp * 4, hipMemcpyHostToDevice, s));
-    const std::vector<int> qf((size_t)nlast, b);
-    HIPCHK(hipMemcpyAsync(p + o_qf, qf.data(), n4, hipMemcpyHostToDevice, s));
+    uint8_t* h = c->h_stage;
+    memcpy(h + o_pose, pose12, 48);
+    memcpy(h + o_valid, valid, nlast); memcpy(h + o_xw, Xw, 3 * n4); memcpy(h + o_oct, octave, n4); memcpy(h + o_ang, angle, n4);
+    memcpy(h + o_desc, mp_desc, (size_t)nlast * 32);
+    { int* qf = reinterpret_cast<int*>(h + o_qf); for (int i = 0; i < nlast; ++i) qf[i] = b; }
+    { int* mo = reinterpret_cast<int*>(h + o_mpoff); mo[0] = 0; mo[1] = nlast; }
+    { int* km = reinterpret_cast<int*>(h + o_kpmp); for (int k = 0; k < c->g.kp_cap; ++k) km[k] = k < nkp ? kp_mp[k] : -1; }
+    HIPCHK(hipMemcpyAsync(p, h, in_bytes, hipMemcpyHostToDevice, s));
     rc = cms_project_last_frame_device(c, nlast, nullptr, p + o_pose, p + o_valid, p + o_xw, p + o_oct, th, p + o_qx, p + o_qy, p + o_qr, p + o_qmin, p + o_qmax);
     if (rc) return rc;
     rc = cms_features_in_area_batch_device(c, nlast, p + o_qf, p + o_qx, p + o_qy, p + o_qr, p + o_qmin, p + o_qmax, p + o_cnt, p + o_off, p + o_idx, cap, p + o_tot);
     if (rc) return rc;
-    int tot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (tot > cap) { cap = tot + 64; continue; }
-    const int mpoff[2] = {0, nlast};
-    HIPCHK(hipMemcpyAsync(p + o_mpoff, mpoff, sizeof(mpoff), hipMemcpyHostToDevice, s));
-    if (c->g.kp_cap > CMS_TRACK_KPMAX) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_by_projection: more than 4096 key points per frame");
     CmsSearchLocalArgs a;
     a.mp_off = (const int*)(p + o_mpoff); a.mp_desc = (const uint4*)(p + o_desc); a.cand_off = (const int*)(p + o_off); a.cand_idx = (const int*)(p + o_idx);
     a.t_desc = (const uint4*)c->d_desc; a.kp = (const CmsKeyPoint*)c->d_kps; a.kp_cap = c->g.kp_cap;
-    a.pair_dist = (uint16_t*)(p + o_pd); a.kp_mp = (int*)(p + o_kpmp); a.mp_match = (int*)(p + o_match); a.rounds = nullptr;
-    a.nnratio = -1.0f; a.th_high = th_high; a.frame0 = b;
+    a.pair_dist = (uint16_t*)(p + o_pd); a.kp_mp = (int*)(p + o_kpmp) - (size_t)b * c->g.kp_cap; a.mp_match = (int*)(p + o_match); a.rounds = nullptr;
+    a.nnratio = -1.0f; a.th_high = th_high; a.frame0 = b; a.total = (const int*)(p + o_tot); a.cap = cap;
     hipLaunchKernelGGL(k_search_local, dim3(1), dim3(1024), 0, s, a);
     CmsRotFilterArgs r;
-    r.mp_off = (const int*)(p + o_mpoff); r.last_angle = (const float*)(p + o_ang); r.kp = (const CmsKeyPoint*)c->d_kps; r.kp_mp = (int*)(p + o_kpmp);
-    r.mp_match = (int*)(p + o_match); r.n_matches = (int*)(p + o_nm); r.check_orientation = check_orientation;
+    r.mp_off = (const int*)(p + o_mpoff); r.last_angle = (const float*)(p + o_ang); r.kp = (const CmsKeyPoint*)c->d_kps; r.kp_mp = a.kp_mp;
+    r.mp_match = (int*)(p + o_match); r.n_matches = (int*)(p + o_nm); r.check_orientation = check_orientation; r.total = a.total; r.cap = cap;
     hipLaunchKernelGGL(k_rot_filter, dim3(1), dim3(1024), 0, s, r);
     HIPCHK(hipGetLastError());
-    std::vector<int> m((size_t)nlast);
-    int nm = 0;
-    HIPCHK(hipMemcpyAsync(m.data(), p + o_match, n4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&nm, p + o_nm, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (nkp > 0) HIPCHK(hipMemcpyAsync(kp_mp, p + o_kpmp + (size_t)b * c->g.kp_cap * 4, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + out_begin, p + out_begin, out_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    for (int i = 0; i < nlast; ++i) match[i] = m[(size_t)i] >= 0 ? m[(size_t)i] - b * c->g.kp_cap : -1;
-    if (n_matches) *n_matches = nm;
+    const int tot = *reinterpret_cast<const int*>(h + o_tot);
+    if (tot > cap) { cap = tot + 64; continue; }
+    const int* m = reinterpret_cast<const int*>(h + o_match);
+    if (nkp > 0) memcpy(kp_mp, h + o_kpmp, (size_t)nkp * 4);
+    for (int i = 0; i < nlast; ++i) match[i] = m[i] >= 0 ? m[i] - b * c->g.kp_cap : -1;
+    if (n_matches) *n_matches = *reinterpret_cast<const int*>(h + o_nm);
     return CMS_OK;
   }
   return cms_fail(CMS_ERR_OVERFLOW, "cms_search_by_projection: candidate lists kept growing");

@@ -108,6 +108,7 @@ struct CmsSearchLocalArgs {
   int* rounds;                // per frame (optional): rounds the greedy needed
   float nnratio; int th_high;
   int frame0;                 // key-point rows of workgroup w are those of frame frame0 + w (single-frame entry point)
+  const int* total; int cap;  // optional: *total > cap means the candidate lists were cut short -- do nothing, the host repeats the query
 };
 
 __device__ __forceinline__ int track_hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
@@ -119,6 +120,7 @@ __device__ __forceinline__ int track_hamming256(const uint4& a0, const uint4& a1
 extern "C" __global__ void __launch_bounds__(1024) k_search_local(CmsSearchLocalArgs a) {
   __shared__ int min_open[CMS_TRACK_KPMAX];           // lowest undecided map point that still wants key point k
   const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  if (a.total && *a.total > a.cap) return;
   const int m0 = a.mp_off[f], m1 = a.mp_off[f + 1];
   const int row0 = (f + a.frame0) * a.kp_cap;
   // ---- distances of all pairs of this frame, 4 lanes per map point
@@ -220,12 +222,14 @@ extern "C" __global__ void __launch_bounds__(256) k_project_last(CmsProjectLastA
 
 struct CmsRotFilterArgs {
   const int* mp_off; const float* last_angle; const CmsKeyPoint* kp; int* kp_mp; int* mp_match; int* n_matches; int check_orientation;
+  const int* total; int cap;  // as in CmsSearchLocalArgs
 };
 extern "C" __global__ void __launch_bounds__(1024) k_rot_filter(CmsRotFilterArgs a) {
   __shared__ int hist[32];
   __shared__ int keep[3];
   __shared__ int s_n;
   const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  if (a.total && *a.total > a.cap) return;
   const int m0 = a.mp_off[f], m1 = a.mp_off[f + 1];
   if (tid < 32) hist[tid] = 0;
   if (tid == 0) s_n = 0;
