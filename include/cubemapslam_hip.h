@@ -14,7 +14,7 @@
  * Frame-path calls on one ctx must come from one thread at a time; BA calls on one handle likewise; the two may
  * overlap freely.  The window-query, projection-search, mapping (cms_create_new_map_points, cms_kfstore_*, cms_fuse_search) and
  * map-point entries use the stream and the scratch arena of the ctx they are given: a mapping thread that runs next to a tracking
- * thread creates its own cms_ctx (bench.py does).
+ * thread creates a context of its own (bench.py does).
  */
 #ifndef CUBEMAPSLAM_HIP_H
 #define CUBEMAPSLAM_HIP_H
