@@ -296,9 +296,17 @@ def main():
         if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
             # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section) -> doubled; unit KB
             traffic = int((2.0 * kk["FETCH_SIZE"]["per_dispatch"] + kk["WRITE_SIZE"]["per_dispatch"]) * 1024)
+    # vector-ALU issue time of the same kernel from the committed SQ-counter pass (VALU instructions x 4 cycles per wave64 instruction /
+    # (256 CUs x 4 SIMDs x 2.4 GHz)): how much of the launch is spent just issuing its vector instructions
+    valu_us = None
+    pm = os.path.join(ROOT, "profiles", "r01_pmc_instruction_mix.json")
+    if os.path.exists(pm) and B == 64 and F == 550:
+        kk = json.load(open(pm))["kernels"].get(kname)
+        if kk:
+            valu_us = kk["valu_issue_bound_us"]
     roof = {"kernel": kname, "bound": "hbm", "achieved": None if ach is None else round(ach, 1), "peak": peak, "unit": "GB/s",
             "frac": None if ach is None else round(ach / peak, 4), "traffic": traffic,
-            "ms_per_launch": round(stage_ms.get(dom, 0.0) / launches, 4), "algorithmic_bytes_per_launch": int(alg[dom] * B / launches),
+            "ms_per_launch": round(stage_ms.get(dom, 0.0) / launches, 4), "valu_issue_bound_ms": None if valu_us is None else round(valu_us / 1e3, 4), "algorithmic_bytes_per_launch": int(alg[dom] * B / launches),
             "all_stages_GBps": {k: round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in alg if stage_ms.get(k, 0) > 0}}
     fast_gbs = alg["fast"] * B / (stage_ms["fast"] * 1e-3) / 1e9 if stage_ms.get("fast", 0) > 0 else None
     # whole ORBextractor::operator() against SURVEY.md 8(d)'s compulsory traffic at the reference's stage granularity
