@@ -114,6 +114,7 @@ def lib():
         L.cms_kfstore_destroy.restype = None
         L.cms_kfstore_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cms_kfstore_update.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.cms_kfstore_fuse_search.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_void_p, C.c_void_p]
         L.cms_kfstore_create_new_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.cms_distinctive_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cms_update_normal_and_depth.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
@@ -454,6 +455,18 @@ class KeyframeStore:
         f = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
         a = [f(R, np.float32), f(t, np.float32), f(Ow, np.float32), None if median_depth is None else np.array([median_depth], np.float32), f(mp, np.int32)]
         _chk(lib().cms_kfstore_update(self.h, slot, *[_p(v) for v in a]), "cms_kfstore_update")
+
+    def fuse_search(self, jobs, th=3.0):
+        """jobs: list of (slot, dict(skip, pos, normal, min_dist, max_dist, desc)) -> per job (best_idx, best_dist)"""
+        nj = len(jobs)
+        slots = np.array([j[0] for j in jobs], np.int32)
+        off = np.concatenate([[0], np.cumsum([len(j[1]["pos"]) for j in jobs])]).astype(np.int32)
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(j[1][k]) for j in jobs]), dt)
+        a = [cat("skip", np.uint8), cat("pos", np.float32), cat("normal", np.float32), cat("min_dist", np.float32), cat("max_dist", np.float32), cat("desc", np.uint8)]
+        n = int(off[-1])
+        bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32)
+        _chk(lib().cms_kfstore_fuse_search(self.h, nj, _p(slots), _p(off), *[_p(v) for v in a], th, _p(bi), _p(bd)), "cms_kfstore_fuse_search")
+        return [(bi[off[j]:off[j + 1]].copy(), bd[off[j]:off[j + 1]].copy()) for j in range(nj)]
 
     def create_new_map_points(self, jobs, check_orientation=False, cap=2048):
         """jobs: list of (current slot, [neighbour slots in covisibility order]) -> per job (neigh, idx1, idx2, x3d)"""

@@ -230,20 +230,23 @@ struct cms_kfstore {
   CmsTriKF* d_kf = nullptr; CmsKeyPoint* d_kp = nullptr; uint8_t* d_desc = nullptr; float* d_rays = nullptr; int* d_mp = nullptr; int* d_fn = nullptr;
   int* d_nid = nullptr; int* d_noff = nullptr; int* d_nfeat = nullptr;
   uint8_t* d_work = nullptr; size_t work_bytes = 0;
+  // frame grid of every slot (KeyFrame::AssignFeaturesToGrid), built by cms_kfstore_put: the Fuse search runs on resident key frames too
+  uint16_t* d_sorted = nullptr; int* d_cell_start = nullptr; int* d_nvalid = nullptr; int* d_kp_cnt = nullptr;
   std::vector<CmsTriKF> h_kf; std::vector<float> h_median; std::vector<uint8_t> used;
 };
 
 extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
   if (!st) return;
   if (st->c) (void)hipSetDevice(st->c->device);
-  void* bufs[] = {st->d_kf, st->d_kp, st->d_desc, st->d_rays, st->d_mp, st->d_fn, st->d_nid, st->d_noff, st->d_nfeat, st->d_work};
+  void* bufs[] = {st->d_kf, st->d_kp, st->d_desc, st->d_rays, st->d_mp, st->d_fn, st->d_nid, st->d_noff, st->d_nfeat, st->d_work,
+                  st->d_sorted, st->d_cell_start, st->d_nvalid, st->d_kp_cnt};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete st;
 }
 
 extern "C" int cms_kfstore_create(cms_kfstore** out, cms_ctx* c, int max_keyframes, int max_features, int max_nodes) {
-  if (!out || !c || max_keyframes < 1 || max_features < 1 || max_features > CMS_TRI_MAXF || max_nodes < 1)
-    return cms_fail(CMS_ERR_ARG, "cms_kfstore_create: bad argument (at most 4096 features per key frame)");
+  if (!out || !c || max_keyframes < 1 || max_features < 1 || max_features > CMS_AREA_MAXKP || max_nodes < 1)
+    return cms_fail(CMS_ERR_ARG, "cms_kfstore_create: bad argument (at most 4095 features per key frame)");
   HIPCHK(hipSetDevice(c->device));
   cms_kfstore* st = new cms_kfstore();
   st->c = c; st->maxkf = max_keyframes; st->maxf = max_features; st->maxn = max_nodes;
@@ -258,6 +261,10 @@ extern "C" int cms_kfstore_create(cms_kfstore** out, cms_ctx* c, int max_keyfram
   KF_ALLOC(st->d_nid, K * Nq * 4);
   KF_ALLOC(st->d_noff, K * (Nq + 1) * 4);
   KF_ALLOC(st->d_nfeat, K * Fq * 4);
+  KF_ALLOC(st->d_sorted, K * Fq * sizeof(uint16_t));
+  KF_ALLOC(st->d_cell_start, K * (CMS_AREA_CELLS + 1) * sizeof(int));
+  KF_ALLOC(st->d_nvalid, K * sizeof(int));
+  KF_ALLOC(st->d_kp_cnt, K * sizeof(int));
 #undef KF_ALLOC
   st->h_kf.assign(K, CmsTriKF{}); st->h_median.assign(K, 1.0f); st->used.assign(K, 0);
   *out = st;
@@ -295,6 +302,13 @@ extern "C" int cms_kfstore_put(cms_kfstore* st, int slot, const cms_keyframe* kf
     HIPCHK(hipMemcpyAsync(st->d_noff + o0, &zero, 4, hipMemcpyHostToDevice, s));
   }
   HIPCHK(hipMemcpyAsync(st->d_kf + slot, &d, sizeof(d), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(st->d_kp_cnt + slot, &kf->n, sizeof(int), hipMemcpyHostToDevice, s));
+  {
+    const float inv = (float)(3 * CMS_AREA_G) / (float)c->g.W;          // mfGridElementLengthInv (Frame.cpp:149)
+    hipLaunchKernelGGL(k_area_grid, dim3(1), dim3(1024), 0, s, (const CmsKeyPoint*)(st->d_kp + f0), (const int*)(st->d_kp_cnt + slot), st->maxf, c->g.F, inv,
+                       st->d_sorted + f0, st->d_cell_start + (size_t)slot * (CMS_AREA_CELLS + 1), st->d_nvalid + slot);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(s));
   st->h_kf[(size_t)slot] = d; st->h_median[(size_t)slot] = kf->median_depth; st->used[(size_t)slot] = 1;
   return CMS_OK;
@@ -480,4 +494,97 @@ extern "C" int cms_update_normal_and_depth(cms_ctx* c, int npts, const int* obs_
   HIPCHK(hipMemcpyAsync(max_dist, p + o_max, n4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return CMS_OK;
+}
+
+
+// SearchInNeighbors' Fuse calls on resident key frames, all in one launch sequence: job j searches the map points [mp_off[j], mp_off[j+1])
+// (host arrays, concatenated) in the key frame of slot job_slot[j].  best_idx[i] = key point of that key frame or -1.
+extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const uint8_t* skip, const float* pos,
+                                       const float* normal, const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th,
+                                       int* best_idx, int* best_dist) {
+  if (!st || njobs < 0 || (njobs > 0 && (!job_slot || !mp_off))) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search: bad argument");
+  if (njobs == 0) return CMS_OK;
+  const int nmp = mp_off[njobs];
+  if (nmp < 0 || (nmp > 0 && (!pos || !normal || !min_dist || !max_dist || !mp_desc || !best_idx || !best_dist)))
+    return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search: bad map-point arrays");
+  if (nmp == 0) return CMS_OK;
+  cms_ctx* c = st->c;
+  if (c->g.nlevels > 16) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_kfstore_fuse_search: more than 16 pyramid levels");
+  std::vector<float> pose((size_t)njobs * 15);
+  std::vector<int> mp_job((size_t)nmp), mp_slot((size_t)nmp);
+  for (int j = 0; j < njobs; ++j) {
+    const int sl = job_slot[j];
+    if (sl < 0 || sl >= st->maxkf || !st->used[(size_t)sl] || mp_off[j + 1] < mp_off[j]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search: bad job");
+    const CmsTriKF& k = st->h_kf[(size_t)sl];
+    memcpy(&pose[15 * (size_t)j], k.Rcw, 36); memcpy(&pose[15 * (size_t)j + 9], k.tcw, 12); memcpy(&pose[15 * (size_t)j + 12], k.Ow, 12);
+    for (int i = mp_off[j]; i < mp_off[j + 1]; ++i) { mp_job[(size_t)i] = j; mp_slot[(size_t)i] = sl; }
+  }
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t n4 = (size_t)nmp * 4;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
+  const size_t o_pose = take(pose.size() * 4), o_job = take(n4), o_slot = take(n4), o_skip = take(nmp), o_pos = take(3 * n4), o_nrm = take(3 * n4), o_min = take(n4),
+               o_max = take(n4), o_desc = take((size_t)nmp * 32), o_qx = take(n4), o_qy = take(n4), o_qr = take(n4), o_qmin = take(n4), o_qmax = take(n4),
+               o_lvl = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16), o_bi = take(n4), o_bd = take(n4);
+  const size_t fixed = o;
+  int cap = 64 * nmp + 1024;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    int rc = cms_scratch(c, fixed + al((size_t)cap * 4));
+    if (rc) return rc;
+    uint8_t* p = (uint8_t*)c->d_match;
+    const size_t o_idx = fixed;
+    HIPCHK(hipMemcpyAsync(p + o_pose, pose.data(), pose.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_job, mp_job.data(), n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_slot, mp_slot.data(), n4, hipMemcpyHostToDevice, s));
+    if (skip) HIPCHK(hipMemcpyAsync(p + o_skip, skip, nmp, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_pos, pos, 3 * n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_nrm, normal, 3 * n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_min, min_dist, n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_max, max_dist, n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice, s));
+    CmsFuseArgs fa;
+    fa.pose15 = (const float*)(p + o_pose); fa.mp_frame = (const int*)(p + o_job); fa.n = nmp; fa.skip = skip ? p + o_skip : nullptr;
+    fa.P = (const float*)(p + o_pos); fa.normal = (const float*)(p + o_nrm); fa.min_dist = (const float*)(p + o_min); fa.max_dist = (const float*)(p + o_max);
+    fa.th = th; fa.log_scale = std::log(c->scale[1]); fa.nlevels = c->g.nlevels; fa.F = c->g.F;
+    for (int l = 0; l < 16; ++l) fa.sf[l] = l < c->g.nlevels ? c->scale[l] : 0.0f;
+    fa.qx = (float*)(p + o_qx); fa.qy = (float*)(p + o_qy); fa.qr = (float*)(p + o_qr); fa.qmin = (int*)(p + o_qmin); fa.qmax = (int*)(p + o_qmax);
+    fa.level = (int*)(p + o_lvl);
+    hipLaunchKernelGGL(k_fuse_project, dim3((nmp + 255) / 256), dim3(256), 0, s, fa);
+    // window query against the grids of the store's slots
+    CmsAreaArgs a;
+    a.kp = (const CmsKeyPoint*)st->d_kp; a.sorted_idx = st->d_sorted; a.cell_start = st->d_cell_start;
+    a.qx = fa.qx; a.qy = fa.qy; a.qr = fa.qr; a.qmin = fa.qmin; a.qmax = fa.qmax;
+    a.q_frame = (const int*)(p + o_slot); a.kp_cap = st->maxf;
+    a.nq = nmp; a.F = c->g.F; a.inv = (float)(3 * CMS_AREA_G) / (float)c->g.W;
+    a.cnt = (int*)(p + o_cnt); a.off = (const int*)(p + o_off); a.idx = (int*)(p + o_idx); a.cap = cap; a.idx_base = 0;
+    {
+      const int nblk = (nmp + 1023) / 1024, qgrid = (nmp * CMS_AREA_QL + 255) / 256;
+      rc = cms_area_bsum_reserve(c, nblk);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 0);
+      hipLaunchKernelGGL(k_area_blocksum, dim3(nblk), dim3(1024), 0, s, (const int*)(p + o_cnt), nmp, c->d_area_bsum);
+      hipLaunchKernelGGL(k_area_scan, dim3(nblk), dim3(1024), 0, s, (const int*)(p + o_cnt), nmp, (const int*)c->d_area_bsum, (int*)(p + o_off), (int*)(p + o_tot));
+      hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 1);
+    }
+    HIPCHK(hipGetLastError());
+    int tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (tot > cap) { cap = tot + 64; continue; }
+    CmsFuseScanArgs sa;
+    sa.n = nmp; sa.qx = fa.qx; sa.qy = fa.qy; sa.level = fa.level; sa.mp_desc = (const uint4*)(p + o_desc);
+    sa.cand_off = (const int*)(p + o_off); sa.cand_idx = (const int*)(p + o_idx); sa.kp = (const CmsKeyPoint*)st->d_kp; sa.t_desc = (const uint4*)st->d_desc;
+    for (int l = 0; l < 16; ++l) sa.inv_sigma2[l] = l < c->g.nlevels ? c->inv_sigma2[l] : 0.0f;
+    sa.best_idx = (int*)(p + o_bi); sa.best_dist = (int*)(p + o_bd);
+    hipLaunchKernelGGL(k_fuse_scan, dim3((nmp * 8 + 255) / 256), dim3(256), 0, s, sa);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(best_idx, p + o_bi, n4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(best_dist, p + o_bd, n4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < nmp; ++i) if (best_idx[i] >= 0) best_idx[i] -= mp_slot[(size_t)i] * st->maxf;     // store row -> key point index
+    return CMS_OK;
+  }
+  return cms_fail(CMS_ERR_OVERFLOW, "cms_kfstore_fuse_search: candidate lists kept growing");
 }

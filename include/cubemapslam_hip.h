@@ -263,6 +263,11 @@ int cms_kfstore_create(cms_kfstore** out, cms_ctx* ctx, int max_keyframes, int m
 void cms_kfstore_destroy(cms_kfstore* st);
 int cms_kfstore_put(cms_kfstore* st, int slot, const cms_keyframe* kf);
 int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, const float* tcw, const float* Ow, const float* median_depth, const int* mp);
+/* SearchInNeighbors' Fuse calls (src/LocalMapping.cpp:388-467) on resident key frames in one launch sequence: job j searches the map points
+ * [mp_off[j], mp_off[j+1]) of the concatenated host arrays in the key frame of slot job_slot[j]; arguments and results as cms_fuse_search. */
+int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const uint8_t* skip, const float* pos,
+                            const float* normal, const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, int* best_idx,
+                            int* best_dist);
 int cms_kfstore_create_new_map_points(cms_kfstore* st, int njobs, const int* cur_slot, const int* neigh_off, const int* neigh_slot,
                                       int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
                                       float* out_x3d);

@@ -796,3 +796,38 @@ def test_product_reproduces_golden_vectors():
     assert np.array_equal(on, want["tri_neigh"]) and np.array_equal(o1, want["tri_idx1"]) and np.array_equal(o2, want["tri_idx2"])
     assert np.array_equal(ox.view(np.uint32), want["tri_x3d"].view(np.uint32))
     ctx.close()
+
+
+def test_kfstore_fuse_search_matches_oracle():
+    """SearchInNeighbors' Fuse calls on resident key frames: three key frames in a store, four jobs (one slot used twice) in one call"""
+    import test_area_emu as te
+    F = 550
+    camd = synth.camera("lafida", F)
+    ocam = orc.make_camera(camd)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=1)
+    store = api.KeyframeStore(ctx, max_keyframes=4, max_features=2048, max_nodes=16)
+    kfs, prs, oks = [], [], []
+    for s in range(3):
+        kx, ky, ko = te._keypoints(F, 1500 + 200 * s, 100 + s)
+        kd = synth.descriptors(len(kx), 110 + s)
+        pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=120 + s)
+        kf = dict(x=kx, y=ky, octave=ko, angle=np.zeros(len(kx), np.float32), desc=kd, mp=np.full(len(kx), -1, np.int32), R=pr["pose15"][:9], t=pr["pose15"][9:12],
+                  Ow=pr["pose15"][12:], node_id=np.zeros(0, np.int32), node_off=np.zeros(1, np.int32), node_feat=np.zeros(0, np.int32), median_depth=1.0,
+                  rays=np.zeros((len(kx), 3), np.float32))
+        K, keep = api.make_keyframe(kf)
+        store.put(s + 1, K)                                     # slots 1..3 (slot 0 stays empty)
+        kfs.append(kf); prs.append(pr); oks.append(orc.make_keyframe(ocam, kf))
+    sf = prs[0]["scale_factors"]; inv_s2 = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    jobs, want = [], []
+    for slot_i, src in ((0, 0), (1, 1), (2, 2), (0, 1)):      # the last job searches key frame 0 with the map points made for key frame 1
+        pr = prs[src]
+        skip = (np.arange(len(pr["pos"])) % 11 == 0).astype(np.uint8)
+        jobs.append((slot_i + 1, dict(skip=skip, pos=pr["pos"], normal=pr["normal"], min_dist=pr["min_dist"], max_dist=pr["max_dist"], desc=pr["desc"])))
+        want.append(orc.fuse_search(ocam, oks[slot_i][0], skip, pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], 3.0, sf, inv_s2))
+    got = store.fuse_search(jobs, th=3.0)
+    for j in range(4):
+        assert np.array_equal(got[j][0], want[j][0]) and np.array_equal(got[j][1], want[j][1]), j
+    assert sum((w[0] >= 0).sum() for w in want[:3]) > 900
+    with pytest.raises(api.CmsError):
+        store.fuse_search([(0, jobs[0][1])])                    # empty slot
+    store.close(); ctx.close()
