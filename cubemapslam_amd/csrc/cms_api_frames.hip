@@ -293,6 +293,7 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
     // wholly inside the zero corner regions of a remapped cross (same tests as in k_fast_cells)
     std::vector<int> all, nz;
     for (int l = 0; l < L; ++l) {
+      if (g.lv[l].nRows > 255 || g.lv[l].nCols > 255) { cms_ctx_free(c); return cms_fail(CMS_ERR_UNSUPPORTED, "cms_ctx_create: more than 255 FAST cells per row"); }
       const CmsLevel& lv = g.lv[l];
       const int maxBX = lv.w - CMS_MINB, maxBY = lv.h - CMS_MINB;
       for (int ci = 0; ci < lv.nRows; ++ci)
@@ -301,7 +302,8 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
           if (iniY >= maxBY - 3 || iniX >= maxBX - 6) continue;
           const int maxY = std::min(iniY + lv.hCell + 6, maxBY), maxX = std::min(iniX + lv.wCell + 6, maxBX);
           if (maxX - iniX - 6 <= 0 || maxY - iniY - 6 <= 0) continue;
-          const int id = lv.cell0 + ci * lv.nCols + cj;
+          // list entry: level (4 bits) | row (8) | column (8): the kernel needs no division to find its cell
+          const int id = l | (ci << 4) | (cj << 12);
           all.push_back(id);
           const bool zero = (maxX <= lv.zlo || iniX >= lv.w - lv.zhi) && (maxY <= lv.zlo || iniY >= lv.h - lv.zhi);
           if (!zero) nz.push_back(id);

@@ -246,6 +246,8 @@ __device__ __forceinline__ int fast_arc_score_pk(const uint8_t* c, int ts, int v
 #ifndef CMS_FAST_LD
 #define CMS_FAST_LD 8       /* row loads in flight per lane while staging the ROI (16-byte loads were measured slower here) */
 #endif
+__device__ const int k_fast_recip[32] = {0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097,
+                                         3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115};
 #ifndef CMS_FAST_WPB
 #define CMS_FAST_WPB 1      /* cells (wavefronts) per workgroup; measured: 1 -> 0.34 ms, 4 -> 0.38 ms per 32 frames */
 #endif
@@ -261,18 +263,22 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
   const int slot = blockIdx.x * CMS_FAST_WPB + wave;
 #if CMS_FAST_LIST
   if (slot >= n_list) return;
-  const int cid = cell_list[slot];          // host-built list of the cells that can hold a corner (see cms_ctx_create)
+  // host-built list of the cells that can hold a corner (see cms_ctx_create); an entry carries level | row | column
+  const int entry = cell_list[slot];
+  const int l = entry & 15, ci = (entry >> 4) & 255, cj = (entry >> 12) & 255;
+  const CmsLevel& lv = g.lv[l];
+  const int cid = lv.cell0 + ci * lv.nCols + cj;
 #else
   if (slot >= g.total_cells) return;
   const int cid = slot;
-#endif
-  uint8_t* smem = smem_all + (size_t)wave * g.fast_cell_lds;
-  const int b = blockIdx.y;
   int l = 0;
   for (int k = 1; k < g.nlevels; ++k) if (cid >= g.lv[k].cell0) l = k;
   const CmsLevel& lv = g.lv[l];
   const int lc = cid - lv.cell0;
   const int ci = lc / lv.nCols, cj = lc - ci * lv.nCols;
+#endif
+  uint8_t* smem = smem_all + (size_t)wave * g.fast_cell_lds;
+  const int b = blockIdx.y;
   const int maxBX = lv.w - CMS_MINB, maxBY = lv.h - CMS_MINB;
   const int iniY = CMS_MINB + ci * lv.hCell, iniX = CMS_MINB + cj * lv.wCell;
   if (iniY >= maxBY - 3 || iniX >= maxBX - 6) return;       // ORBExtractor.cpp:769,777
@@ -296,19 +302,21 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
   const int ndw = (maxX - ax0 + 3) >> 2, th = maxY - iniY;
   {
     // all loads of a lane are issued before the first LDS store: one memory latency per cell instead of one per row group
-    const int lr = lane / ndw, lc2 = lane - lr * ndw, rstep = 64 / ndw;
+    // lane / ndw and 64 / ndw without integer division (ndw <= 16, lane < 64: floor(x / n) == (x * (65536 / n + 1)) >> 16)
+    const int rcp = k_fast_recip[ndw & 31];
+    const int lr = __mul24(lane, rcp) >> 16, lc2 = lane - __mul24(lr, ndw), rstep = (64 * rcp) >> 16;
     const uint8_t* gp = img + (size_t)iniY * lv.stride + ax0 + 4 * lc2;
     for (int rbase = 0; rbase < th; rbase += CMS_FAST_LD * rstep) {      // one pass for the usual ~37-row ROI
       uint32_t tmp[CMS_FAST_LD];
 #pragma unroll
       for (int k = 0; k < CMS_FAST_LD; ++k) {
         const int r = rbase + lr + k * rstep;
-        tmp[k] = (lr < rstep && r < th) ? *reinterpret_cast<const uint32_t*>(gp + (size_t)r * lv.stride) : 0u;
+        tmp[k] = (lr < rstep && r < th) ? *reinterpret_cast<const uint32_t*>(gp + (uint32_t)__mul24(r, lv.stride)) : 0u;
       }
 #pragma unroll
       for (int k = 0; k < CMS_FAST_LD; ++k) {
         const int r = rbase + lr + k * rstep;
-        if (lr < rstep && r < th) reinterpret_cast<uint32_t*>(tile + r * ts)[lc2] = tmp[k];
+        if (lr < rstep && r < th) reinterpret_cast<uint32_t*>(tile + __mul24(r, ts))[lc2] = tmp[k];
       }
     }
   }
@@ -321,7 +329,8 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
   const int t = g.min_th;
   const int lx0 = ex0 - ax0, lx1 = ex1 - ax0;           // evaluated LDS columns [lx0, lx1)
   const int q0 = lx0 >> 2, nq = ((lx1 - 1) >> 2) - q0 + 1;
-  const int qr = lane / nq, qc = lane - qr * nq, qrows = 64 / nq;
+  const int qrcp = k_fast_recip[nq & 31];                      // (32-bit integer multiplies and divisions are quarter rate: 24-bit forms throughout)
+  const int qr = __mul24(lane, qrcp) >> 16, qc = lane - __mul24(qr, nq), qrows = (64 * qrcp) >> 16;
   int colmask = 0;                                      // which of this lane's 4 columns are evaluated (row independent)
   for (int i = 0; i < 4; ++i) { const int lxi = 4 * (q0 + qc) + i; colmask |= (lxi >= lx0 && lxi < lx1 ? 1 : 0) << i; }
   int L = 0;
@@ -331,10 +340,10 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
     uint32_t cm = 0, cc = 0, cp = 0, up = 0, dn = 0;
     const int q = q0 + qc;
     if (rowok) {
-      const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py) * ts);
+      const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + __mul24(ey0 - iniY + py, ts));
       cm = row[q - 1]; cc = row[q]; cp = row[q + 1];
-      up = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py - 3) * ts)[q];
-      dn = reinterpret_cast<const uint32_t*>(tile + (ey0 - iniY + py + 3) * ts)[q];
+      up = reinterpret_cast<const uint32_t*>(tile + __mul24(ey0 - iniY + py - 3, ts))[q];
+      dn = reinterpret_cast<const uint32_t*>(tile + __mul24(ey0 - iniY + py + 3, ts))[q];
     }
     // the four compass points are the four (vertical, horizontal) combinations of {p0, p8} x {p4, p12}, so
     //   "some adjacent pair is darker than v - t"   <=>  max(min(p0, p8), min(p4, p12)) < v - t
@@ -371,7 +380,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
       if (k < L) {
         code = list[k];
         const int py = code >> 6, px = code & 63;
-        const uint8_t* c = tile + (ey0 - iniY + py) * ts + (lx0 + px);
+        const uint8_t* c = tile + __mul24(ey0 - iniY + py, ts) + (lx0 + px);
         const int v = c[0];
         const int e[8] = {v - c[3 * ts], v - c[2 * ts + 2], v - c[3], v - c[-2 * ts + 2],
                           v - c[-3 * ts], v - c[-2 * ts - 2], v - c[-3], v - c[2 * ts - 2]};
@@ -399,10 +408,10 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
     if (k < L) {
       const int code = list[k];
       const int py = code >> 6, px = code & 63;
-      const uint8_t* c = tile + (ey0 - iniY + py) * ts + (lx0 + px);
+      const uint8_t* c = tile + __mul24(ey0 - iniY + py, ts) + (lx0 + px);
       const int v = c[0];
       const int S = fast_arc_score_pk(c, ts, v, t);
-      if (S > 0) sc[(py + 1) * ss + px + 1] = (uint8_t)S;
+      if (S > 0) sc[__mul24(py + 1, ss) + px + 1] = (uint8_t)S;
       else list[k] = 0xFFFFu;
     }
   }
@@ -417,7 +426,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
     if (k < L && list[k] != 0xFFFFu) {
       const int code = list[k];
       const int py = code >> 6, px = code & 63;
-      const uint8_t* s = sc + (py + 1) * ss + px + 1;
+      const uint8_t* s = sc + __mul24(py + 1, ss) + px + 1;
       const int S = s[0];
       keep = S > s[-1] && S > s[1] && S > s[-ss - 1] && S > s[-ss] && S > s[-ss + 1] && S > s[ss - 1] && S > s[ss] &&
              S > s[ss + 1];
@@ -443,7 +452,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
     if (k < L && list[k] != 0xFFFFu) {
       const int code = list[k];
       py = code >> 6; px = code & 63;
-      S = sc[(py + 1) * ss + px + 1];
+      S = sc[__mul24(py + 1, ss) + px + 1];
       emit = use_ini ? (S >= g.ini_th) : true;
     }
     const unsigned long long m = __ballot(emit);
