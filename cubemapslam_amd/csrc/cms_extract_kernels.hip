@@ -131,12 +131,12 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int r = rs + 8 * k;
-      tmp[k] = (c < nq && r < nr) ? *reinterpret_cast<const uint4*>(gp + (size_t)r * src.stride) : make_uint4(0, 0, 0, 0);
+      tmp[k] = (c < nq && r < nr) ? *reinterpret_cast<const uint4*>(gp + (uint32_t)__mul24(r, src.stride)) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int r = rs + 8 * k;
-      if (c < nq && r < nr) reinterpret_cast<uint4*>(rtile + r * ls)[c] = tmp[k];
+      if (c < nq && r < nr) reinterpret_cast<uint4*>(rtile + __mul24(r, ls))[c] = tmp[k];
     }
   }
   __syncthreads();
@@ -154,15 +154,16 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
     const int y = yb + ty + 4 * rr;
     if (y >= dst.h) break;
     const CmsResizeTab tyy = tyr[rr];
-    const uint8_t* S0 = rtile + (min(max((int)tyy.s, 0), src.h - 1) - r0) * ls;
-    const uint8_t* S1 = rtile + (min(max((int)tyy.s + 1, 0), src.h - 1) - r0) * ls;
+    const uint8_t* S0 = rtile + __mul24(min(max((int)tyy.s, 0), src.h - 1) - r0, ls);
+    const uint8_t* S1 = rtile + __mul24(min(max((int)tyy.s + 1, 0), src.h - 1) - r0, ls);
     const int b0 = tyy.a0, b1 = tyy.a1;
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int h0 = S0[ca[i]] * a0[i] + S0[cb[i]] * a1[i];
-      const int h1 = S1[ca[i]] * a0[i] + S1[cb[i]] * a1[i];
-      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      // 8-bit pixels x 11-bit weights: 24-bit multiplies (full rate; the 32-bit integer multiply is not)
+      const int h0 = __mul24(S0[ca[i]], a0[i]) + __mul24(S0[cb[i]], a1[i]);
+      const int h1 = __mul24(S1[ca[i]], a0[i]) + __mul24(S1[cb[i]], a1[i]);
+      const int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
       out |= (uint32_t)(v & 0xFF) << (8 * i);
     }
     *reinterpret_cast<uint32_t*>(pyr + (size_t)b * pyr_bytes + dst.off + (size_t)y * dst.stride + x0) = out;
