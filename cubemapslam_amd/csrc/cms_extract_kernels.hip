@@ -643,8 +643,9 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
     uint32_t tmp[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const int idx = lane + 64 * k, r = idx / 12, c = idx - r * 12;
-      tmp[k] = idx < PW * 12 ? *reinterpret_cast<const uint32_t*>(gp + (size_t)r * lv.stride + 4 * c) : 0u;
+      // idx / 12 as a 24-bit multiply by the reciprocal (exact for idx < 580); row offset as a 24-bit multiply, 32-bit offset
+      const int idx = lane + 64 * k, r = __mul24(idx, 5462) >> 16, c = idx - r * 12;
+      tmp[k] = idx < PW * 12 ? *reinterpret_cast<const uint32_t*>(gp + (uint32_t)(__mul24(r, lv.stride) + 4 * c)) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -682,7 +683,8 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
   {
     const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(raw);
     for (int task = lane; task < PW * (RW / 4); task += 64) {
-      const int r = task / (RW / 4), q = task - r * (RW / 4);
+      static_assert(RW == 40, "reciprocals below are for RW / 4 == 10 and RW / 2 == 20");
+      const int r = __mul24(task, 6554) >> 16, q = task - r * (RW / 4);           // task / 10, exact for task < 494
       const uint32_t* dp = raw32 + r * (PS / 4) + q;
       const uint32_t d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
       const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, off), w1 = __builtin_amdgcn_alignbyte(d2, d1, off),
@@ -702,7 +704,7 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
   WAVE_SYNC();
   // Column pass, two neighbouring columns per lane and step (one dword = two 16-bit row sums)
   for (int task = lane; task < BW * (RW / 2); task += 64) {
-    const int r = task / (RW / 2), cp = task - r * (RW / 2);
+    const int r = __mul24(task, 3277) >> 16, cp = task - r * (RW / 2);            // task / 20, exact for task < 804
     const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + r * RW) + cp;
     const uint32_t e0 = p[0], e1 = p[RW / 2], e2 = p[2 * (RW / 2)], e3 = p[3 * (RW / 2)], e4 = p[4 * (RW / 2)], e5 = p[5 * (RW / 2)],
                    e6 = p[6 * (RW / 2)];
