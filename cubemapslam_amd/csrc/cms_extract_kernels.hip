@@ -708,10 +708,11 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
     const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + r * RW) + cp;
     const uint32_t e0 = p[0], e1 = p[RW / 2], e2 = p[2 * (RW / 2)], e3 = p[3 * (RW / 2)], e4 = p[4 * (RW / 2)], e5 = p[5 * (RW / 2)],
                    e6 = p[6 * (RW / 2)];
-    const int sl = 18 * (int)((e0 & 0xFFFF) + (e6 & 0xFFFF)) + 34 * (int)((e1 & 0xFFFF) + (e5 & 0xFFFF)) +
-                   49 * (int)((e2 & 0xFFFF) + (e4 & 0xFFFF)) + 55 * (int)(e3 & 0xFFFF);
-    const int sh = 18 * (int)((e0 >> 16) + (e6 >> 16)) + 34 * (int)((e1 >> 16) + (e5 >> 16)) + 49 * (int)((e2 >> 16) + (e4 >> 16)) +
-                   55 * (int)(e3 >> 16);
+    // (row sums are < 2^17: 24-bit multiplies)
+    const int sl = __mul24(18, (int)((e0 & 0xFFFF) + (e6 & 0xFFFF))) + __mul24(34, (int)((e1 & 0xFFFF) + (e5 & 0xFFFF))) +
+                   __mul24(49, (int)((e2 & 0xFFFF) + (e4 & 0xFFFF))) + __mul24(55, (int)(e3 & 0xFFFF));
+    const int sh = __mul24(18, (int)((e0 >> 16) + (e6 >> 16))) + __mul24(34, (int)((e1 >> 16) + (e5 >> 16))) +
+                   __mul24(49, (int)((e2 >> 16) + (e4 >> 16))) + __mul24(55, (int)(e3 >> 16));
     const int vl = min((sl + 32768) >> 16, 255), vh = min((sh + 32768) >> 16, 255);
     *reinterpret_cast<uint16_t*>(blr + r * BS + 2 * cp) = (uint16_t)(vl | (vh << 8));
   }
