@@ -163,7 +163,9 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
       // 8-bit pixels x 11-bit weights: 24-bit multiplies (full rate; the 32-bit integer multiply is not)
       const int h0 = __mul24(S0[ca[i]], a0[i]) + __mul24(S0[cb[i]], a1[i]);
       const int h1 = __mul24(S1[ca[i]], a0[i]) + __mul24(S1[cb[i]], a1[i]);
-      const int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+      // weights are in [0, 2048], h >> 4 < 2^16: the masks tell the compiler so and it picks the 24-bit multiply
+      const int v = (int)((((uint32_t)b0 & 0xFFFu) * (((uint32_t)h0 >> 4) & 0xFFFFu) >> 16) +
+                          (((uint32_t)b1 & 0xFFFu) * (((uint32_t)h1 >> 4) & 0xFFFFu) >> 16) + 2) >> 2;
       out |= (uint32_t)(v & 0xFF) << (8 * i);
     }
     *reinterpret_cast<uint32_t*>(pyr + (size_t)b * pyr_bytes + dst.off + (size_t)y * dst.stride + x0) = out;
