@@ -1,13 +1,14 @@
 // cms_api_pose.hip -- host side of the pose-only optimisation (Optimizer::PoseOptimization, Optimizer.cpp:48-190).
 // Persistent device buffers + one stream per handle; a batch of frames is one launch of k_pose_optimize (cms_pose_opt.hip).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <string.h>
 #include <vector>
 #include "../../include/cubemapslam_hip.h"
 
 struct cms_pose {
-  int device = 0, cap_f = 0, cap_e = 0, nf = 0, ne = 0;
+  int device = 0, cap_f = 0, cap_e = 0, nf = 0, ne = 0, max_n = 0;   // max_n: most edges of one uploaded frame
   hipStream_t stream = nullptr;
   int* d_off = nullptr; double* d_Xw = nullptr; double* d_obs = nullptr; double* d_inv = nullptr; int8_t* d_face = nullptr;
   uint8_t* d_out = nullptr; double* d_err = nullptr; double* d_poses = nullptr; double* d_poses0 = nullptr; int* d_res = nullptr;
@@ -66,6 +67,8 @@ extern "C" int cms_pose_upload(cms_pose* p, int nf, const int* edge_off, const d
   HIPCHK(hipMemcpyAsync(p->d_poses0, poses7, (size_t)nf * 7 * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));       // the caller's arrays may be temporaries
   p->nf = nf; p->ne = ne; p->fx = fx; p->fy = fy; p->cx = cx; p->cy = cy;
+  p->max_n = 0;
+  for (int f = 0; f < nf; ++f) p->max_n = std::max(p->max_n, edge_off[f + 1] - edge_off[f]);
   return CMS_OK;
 }
 extern "C" int cms_pose_launch(cms_pose* p) {
@@ -76,7 +79,9 @@ extern "C" int cms_pose_launch(cms_pose* p) {
   PoseDev d;
   d.nf = p->nf; d.off = p->d_off; d.Xw = p->d_Xw; d.obs = p->d_obs; d.inv = p->d_inv; d.face = p->d_face; d.outlier = p->d_out;
   d.err = p->d_err; d.poses = p->d_poses; d.result = p->d_res; d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy;
-  hipLaunchKernelGGL(k_pose_optimize, dim3(p->nf), dim3(256), 0, s, d);
+  // edges of a frame in registers when they fit (256 threads x PO_MAXJ edges), otherwise the variant that walks them in memory
+  if (p->max_n <= 256 * PO_MAXJ && !getenv("CMS_POSE_GLOBAL")) hipLaunchKernelGGL(k_pose_optimize, dim3(p->nf), dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(k_pose_optimize_g, dim3(p->nf), dim3(256), 0, s, d);
   HIPCHK(hipGetLastError());
   return CMS_OK;
 }

@@ -62,15 +62,18 @@ __device__ __forceinline__ void face_R(int face, double* Rf) {
 __device__ __forceinline__ void cam_point(const double* pose, const double* R, const double* X, double* Xc) {
   for (int i = 0; i < 3; ++i) Xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + pose[i];
 }
-__device__ __forceinline__ void edge_error(const BaDev& d, int e, const double* Xc, double* r) {
+__device__ __forceinline__ void edge_error_v(const BaDev& d, int face, double o0, double o1, const double* Xc, double* r) {
   // multipinhole_project: the camera-frame point is cast to float first (cv::Vec3f), projection stored in float
   const double Xf[3] = {(double)(float)Xc[0], (double)(float)Xc[1], (double)(float)Xc[2]};
   double l[3];
-  face_local(d.e_face[e], Xf, l);
+  face_local(face, Xf, l);
   const float u = (float)(l[0] * d.fx / l[2] + d.cx);
   const float v = (float)(l[1] * d.fy / l[2] + d.cy);
-  r[0] = d.e_obs[2 * e] - (double)u;
-  r[1] = d.e_obs[2 * e + 1] - (double)v;
+  r[0] = o0 - (double)u;
+  r[1] = o1 - (double)v;
+}
+__device__ __forceinline__ void edge_error(const BaDev& d, int e, const double* Xc, double* r) {
+  edge_error_v(d, d.e_face[e], d.e_obs[2 * e], d.e_obs[2 * e + 1], Xc, r);
 }
 __device__ __forceinline__ double huber_w(double e2, double delta, double* rho0) {
   const double dsqr = delta * delta;

@@ -124,7 +124,8 @@ __device__ __forceinline__ void pose_block_sum28(const double* acc, double (*sh)
   __syncthreads();
 }
 
-extern "C" __global__ void __launch_bounds__(256) k_pose_optimize(PoseDev P) {
+// (generic variant: edges stay in global memory; used for frames with more than 256 x PO_MAXJ edges)
+extern "C" __global__ void __launch_bounds__(256) k_pose_optimize_g(PoseDev P) {
   __shared__ double sh28[4][28];
   __shared__ double sum[28];            // [0..21) upper triangle of H row by row, [21..27) b, [27] chi2
   __shared__ double s_pose[7], s_trial[7];
@@ -295,6 +296,207 @@ extern "C" __global__ void __launch_bounds__(256) k_pose_optimize(PoseDev P) {
     rounds = round + 1;
     if (n < 10) break;                                           // optimizer.edges().size() < 10
   }
+  if (tid < 7) P.poses[7 * f + tid] = s_pose[tid];
+  if (tid == 0) {
+    res[0] = n - nBad; res[1] = nBad; res[2] = rounds; res[3] = 0;
+    for (int i = 0; i < 4; ++i) res[4 + i] = its[i];
+  }
+}
+
+// The same procedure with a frame's edges held in REGISTERS: thread t owns edges t, t + 256, ... (PO_MAXJ of them, i.e. frames of up to
+// 256 x PO_MAXJ edges); world point, measurement, information, face, the persistent error and the outlier flag never go back to memory
+// during the ~80 dependent passes of the four rounds -- the global-memory latency of every pass was most of the kernel's time.
+// Arithmetic and order of operations are those of k_pose_optimize_g above.
+#define PO_MAXJ 4
+extern "C" __global__ void __launch_bounds__(256) k_pose_optimize(PoseDev P) {
+  __shared__ double sh28[4][28];
+  __shared__ double sum[28];            // [0..21) upper triangle of H row by row, [21..27) b, [27] chi2
+  __shared__ double s_pose[7], s_trial[7];
+  __shared__ int s_ctl[2];              // [0] another trial, [1] another iteration
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int e0 = P.off[f], e1 = P.off[f + 1], n = e1 - e0;
+  int* res = P.result + 8 * f;
+  for (int e = e0 + tid; e < e1; e += 256) P.outlier[e] = 0;   // pFrame->mvbOutlier[i] = false (Optimizer.cpp:91)
+  bool has[PO_MAXJ]; int cf[PO_MAXJ], cout_[PO_MAXJ];
+  double cX[PO_MAXJ][3], co[PO_MAXJ][2], ci[PO_MAXJ], cer[PO_MAXJ][2];
+#pragma unroll
+  for (int j = 0; j < PO_MAXJ; ++j) {
+    const int e = e0 + tid + 256 * j;
+    has[j] = e < e1; cf[j] = 0; cout_[j] = 0; ci[j] = 0; cer[j][0] = 0; cer[j][1] = 0;
+    cX[j][0] = cX[j][1] = cX[j][2] = 0; co[j][0] = co[j][1] = 0;
+    if (has[j]) {
+      cX[j][0] = P.Xw[3 * (size_t)e]; cX[j][1] = P.Xw[3 * (size_t)e + 1]; cX[j][2] = P.Xw[3 * (size_t)e + 2];
+      co[j][0] = P.obs[2 * (size_t)e]; co[j][1] = P.obs[2 * (size_t)e + 1]; ci[j] = P.inv[e]; cf[j] = P.face[e];
+    }
+  }
+  if (n < 3) {                          // Optimizer.cpp:131-132: pose untouched, 0 returned
+    if (tid < 8) res[tid] = 0;
+    return;
+  }
+  BaDev d;                              // the edge arithmetic of the local BA (cms_ba_kernels.hip) on this frame's arrays
+  d.e_face = P.face; d.e_obs = P.obs; d.e_inv = P.inv; d.fx = P.fx; d.fy = P.fy; d.cx = P.cx; d.cy = P.cy;
+  const double delta = sqrt(5.991);
+  double pose0[7];
+  {
+    const double* p = P.poses + 7 * f;
+    for (int i = 0; i < 7; ++i) pose0[i] = p[i];
+    normalize_rot(pose0 + 3);           // SE3Quat constructor (se3quat.h:58-64)
+  }
+  int nBad = 0, rounds = 0;
+  int its[4] = {0, 0, 0, 0};
+  for (int round = 0; round < 4; ++round) {
+    const int robust = round < 3;
+    if (tid < 7) s_pose[tid] = pose0[tid];                      // setEstimate(pFrame->mTcw) before every round
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < PO_MAXJ; ++j) mine += (has[j] && cout_[j] == 0) ? 1 : 0;
+    const int nact = __syncthreads_count(mine > 0);             // also publishes s_pose
+    int done = 0;
+    if (nact > 0) {                                             // no level-0 edge -> no active vertex -> optimize() returns at once
+      double lambda = -1, ni = 2, currentChi = 0, iniChi = 0, rho = 0;
+      int nBadIt = 0;
+      for (int it = 0; it < 10; ++it) {
+        // ---- computeActiveErrors + activeRobustChi2 + buildSystem at s_pose
+        double acc[28];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) acc[i] = 0;
+        {
+          double R[9];
+          quat_to_R(s_pose + 3, R);
+#pragma unroll
+          for (int j = 0; j < PO_MAXJ; ++j) {
+            if (!has[j] || cout_[j]) continue;
+            double Xc[3], r[2], Jp[12], Jl[6];
+            cam_point(s_pose, R, cX[j], Xc);
+            edge_error_v(d, cf[j], co[j][0], co[j][1], Xc, r);
+            cer[j][0] = r[0]; cer[j][1] = r[1];
+            const double om = ci[j], c2 = om * (r[0] * r[0] + r[1] * r[1]);
+            double w = 1.0, rho0 = c2;
+            if (robust) w = huber_w(c2, delta, &rho0);
+            edge_jac_face(d, cf[j], Xc, R, Jp, Jl);
+            const double ow = w * om;
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+              for (int jj = i; jj < 6; ++jj) acc[k++] += ow * (Jp[i] * Jp[jj] + Jp[6 + i] * Jp[6 + jj]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[21 + i] -= ow * (Jp[i] * r[0] + Jp[6 + i] * r[1]);
+            acc[27] += rho0;
+          }
+        }
+        pose_block_sum28(acc, sh28, sum);
+        double H[36], b[6];
+        if (tid == 0) {
+          int k = 0;
+          for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) { H[6 * i + j] = sum[k]; H[6 * j + i] = sum[k]; ++k; }
+          for (int i = 0; i < 6; ++i) b[i] = sum[21 + i];
+          currentChi = sum[27]; iniChi = currentChi;
+          if (it == 0) {
+            double md = 0;
+            for (int j = 0; j < 6; ++j) md = fmax(fabs(H[7 * j]), md);
+            lambda = 1e-5 * md; ni = 2; nBadIt = 0;
+          }
+          rho = 0;
+        }
+        int qmax = 0;
+        for (;;) {   // do { } while (rho < 0 && qmax < 10)
+          double scale = 0;
+          bool ok2 = true;
+          if (tid == 0) {
+            double x[6];
+            ok2 = pose_solve6(H, b, lambda, x);
+            if (!ok2) for (int i = 0; i < 6; ++i) x[i] = 0;
+            double Tn[7];
+            pose_exp_mul(x, s_pose, Tn);
+            for (int i = 0; i < 7; ++i) s_trial[i] = Tn[i];
+            for (int j = 0; j < 6; ++j) scale += x[j] * (lambda * x[j] + b[j]);
+          }
+          __syncthreads();
+          // ---- computeActiveErrors at the trial pose: the stored errors ARE the trial's from here on (kept on rejection, g2o)
+          double chi = 0;
+          {
+            double R[9];
+            quat_to_R(s_trial + 3, R);
+#pragma unroll
+            for (int j = 0; j < PO_MAXJ; ++j) {
+              if (!has[j] || cout_[j]) continue;
+              double Xc[3], r[2];
+              cam_point(s_trial, R, cX[j], Xc);
+              edge_error_v(d, cf[j], co[j][0], co[j][1], Xc, r);
+              cer[j][0] = r[0]; cer[j][1] = r[1];
+              const double c2 = ci[j] * (r[0] * r[0] + r[1] * r[1]);
+              double rho0 = c2;
+              if (robust) huber_w(c2, delta, &rho0);
+              chi += rho0;
+            }
+          }
+          const double tempChi0 = block_sum(chi, &sh28[0][0]);
+          if (tid == 0) {
+            double tempChi = ok2 ? tempChi0 : 1.7976931348623157e308;
+            rho = (currentChi - tempChi) / (scale + 1e-3);
+            if (rho > 0 && isfinite(tempChi)) {
+              double alpha = 1. - pow((2 * rho - 1), 3.0);
+              alpha = fmin(alpha, 2. / 3.);
+              lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+              for (int i = 0; i < 7; ++i) s_pose[i] = s_trial[i];
+            } else {
+              lambda *= ni; ni *= 2;
+            }
+            ++qmax;
+            s_ctl[0] = (rho < 0 && qmax < 10) ? 1 : 0;
+          }
+          __syncthreads();
+          if (!s_ctl[0]) break;
+        }
+        ++done;
+        if (tid == 0) {
+          bool stop = (qmax == 10 || rho == 0);
+          if (!stop) {
+            if ((iniChi - currentChi) * 1e3 < iniChi) ++nBadIt; else nBadIt = 0;
+            if (nBadIt >= 3) stop = true;
+          }
+          s_ctl[1] = stop ? 0 : 1;
+        }
+        __syncthreads();
+        if (!s_ctl[1]) break;
+      }
+    }
+    its[round] = done;
+    // ---- re-classification (Optimizer.cpp:142-173): former outliers get a fresh error at the round's final pose
+    int bad = 0;
+    {
+      double R[9];
+      quat_to_R(s_pose + 3, R);
+#pragma unroll
+      for (int j = 0; j < PO_MAXJ; ++j) {
+        if (!has[j]) continue;
+        if (cout_[j]) {
+          double Xc[3], r[2];
+          cam_point(s_pose, R, cX[j], Xc);
+          edge_error_v(d, cf[j], co[j][0], co[j][1], Xc, r);
+          cer[j][0] = r[0]; cer[j][1] = r[1];
+        }
+        const double r0 = cer[j][0], r1 = cer[j][1];
+        const float chi2 = (float)(ci[j] * (r0 * r0 + r1 * r1));        // const float chi2 = e->chi2()
+        const int o = chi2 > 5.991f ? 1 : 0;
+        cout_[j] = o;
+        bad += o;
+      }
+    }
+    // nBad of this round (integer sum over the workgroup)
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    __shared__ int s_bad[4];
+    __syncthreads();
+    if ((tid & 63) == 0) s_bad[tid >> 6] = bad;
+    __syncthreads();
+    nBad = s_bad[0] + s_bad[1] + s_bad[2] + s_bad[3];
+    rounds = round + 1;
+    if (n < 10) break;                                           // optimizer.edges().size() < 10
+  }
+#pragma unroll
+  for (int j = 0; j < PO_MAXJ; ++j) if (has[j]) P.outlier[e0 + tid + 256 * j] = (uint8_t)cout_[j];
   if (tid < 7) P.poses[7 * f + tid] = s_pose[tid];
   if (tid == 0) {
     res[0] = n - nBad; res[1] = nBad; res[2] = rounds; res[3] = 0;
