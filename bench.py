@@ -212,10 +212,16 @@ def main():
 
     last_traj = [None]
 
+    part = os.environ.get("CMS_BENCH_PART", "")      # developer knob: "ba" / "frames" times one half of the step alone (not a bench line)
+
     def step(i):
-        ths = [threading.Thread(target=ba_worker, args=(grp, gi)) for gi, grp in enumerate(groups)]
+        ths = [threading.Thread(target=ba_worker, args=(grp, gi)) for gi, grp in enumerate(groups)] if part != "frames" else []
         for th in ths:
             th.start()
+        if part == "ba":
+            for th in ths:
+                th.join()
+            return
         po.launch()                 # own stream, overlaps the frame path
         ctx.process(B, True)
         ctx.area_grid(B)            # Frame::AssignFeaturesToGrid of the B frames
@@ -257,7 +263,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        for k, v in ctx.profile_ms().items():
+        for k, v in (ctx.profile_ms().items() if part != "ba" else ()):
             stage_ms[k] = stage_ms.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
@@ -268,6 +274,10 @@ def main():
         dt = float(tt.item())
     for k in stage_ms:
         stage_ms[k] /= max(args.steps, 1)
+    if part:
+        if rank == 0:
+            print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms[0] / max(ba_ms[1], 1), 3), "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
+        return
 
     # ---- roofline of the dominant extraction kernel (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
     sumP = sum(g.level_w[l] * g.level_h[l] for l in range(g.nlevels))

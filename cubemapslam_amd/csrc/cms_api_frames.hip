@@ -415,9 +415,10 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
     dim3 grid((d.w + 255) / 256, (d.h + CMS_RZ_ROWS - 1) / CMS_RZ_ROWS, B);
     const double ratio = (double)g.lv[l - 1].w / d.w;
     const int ls = (int)align_up((size_t)ceil(256 * ratio) + 34, 16);    // LDS row stride of the staged source rectangle (16-byte columns)
-    const int lrows = (int)ceil(CMS_RZ_ROWS * ratio) + 5;
+    const int lrows = (int)ceil(CMS_RZ_ROWS * ratio) + 7;               // the kernel's integer bounds can be one row wider on either side
     hipLaunchKernelGGL(k_resize, grid, block, (size_t)ls * lrows, s, c->d_pyr, g.pyr_bytes, g.lv[l - 1], d,
-                       (const CmsResizeTab*)(c->d_tab + d.tab_off), (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w), ls, clean, ratio);
+                       (const CmsResizeTab*)(c->d_tab + d.tab_off), (const CmsResizeTab*)(c->d_tab + d.tab_off + d.w), ls, clean,
+                       (int)floor(ratio * 65536.0), (int)ceil(ratio * 65536.0));
   }
   if (c->prof) hipEventRecord(c->ev[2], s);
   HIPCHK(hipMemsetAsync(c->d_cell_cnt, 0, (size_t)B * g.total_cells * sizeof(int), s));

@@ -17,6 +17,8 @@
 #include "cms_detmath.h"
 #include "cms_quadtree_core.h"
 
+// ballot of a boolean: the builtin takes the i1 as it is (HIP's __ballot goes through an int and costs a select + compare per use)
+#define CMS_BALLOT(p) ((unsigned long long)__builtin_amdgcn_ballot_w64((bool)(p)))
 #define LANE_PREFIX(mask) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u)))
 
 // ------------------------------------------------------------------------------------------------ remap
@@ -100,7 +102,7 @@ k_remap(const uint8_t* __restrict__ fish, size_t fish_pitch, int fstride, int Iw
 #endif
 extern "C" __global__ void __launch_bounds__(256)
 k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst,
-         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby, int ls, int skip_zero, double scale) {
+         const CmsResizeTab* __restrict__ tabx, const CmsResizeTab* __restrict__ taby, int ls, int skip_zero, int scale_lo, int scale_hi) {
   extern __shared__ __align__(16) uint8_t rtile[];
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int xb = blockIdx.x * 256, yb = blockIdx.y * CMS_RZ_ROWS, b = blockIdx.z;
@@ -108,11 +110,14 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
   // tile inside the constant-zero corner region of a remapped cross (see CmsLevel::zlo): source and destination are 0 already
   if (skip_zero && (xl < dst.zlo || xb >= dst.w - dst.zhi) && (yl < dst.zlo || yb >= dst.h - dst.zhi)) return;
   // staged source rectangle: a conservative superset computed arithmetically (tap index s(d) = floor((d + 0.5) scale - 0.5)
-  // lies in [floor(d scale) - 1, floor((d + 1) scale)]), so the pixel loads do not wait for the coefficient-table loads
-  const int c0 = max((int)floor(xb * scale) - 1, 0) & ~15;
-  const int c1 = min((int)floor((xl + 1) * scale) + 1, src.w - 1);
-  const int r0 = min(max((int)floor(yb * scale) - 1, 0), src.h - 1);
-  const int r1 = min((int)floor((yl + 1) * scale) + 1, src.h - 1);
+  // lies in [floor(d scale) - 1, floor((d + 1) scale)]), so the pixel loads do not wait for the coefficient-table loads.
+  // scale_lo / scale_hi = the ratio rounded down / up to 16 fractional bits: (d scale_lo) >> 16 <= floor(d scale) <=
+  // (d scale_hi + 65535) >> 16, all of it wave-uniform integer arithmetic on the scalar unit (the double-precision floor this
+  // replaces ran on the vector unit at half rate, 16 instructions per wave)
+  const int c0 = max(((xb * scale_lo) >> 16) - 1, 0) & ~15;
+  const int c1 = min((((xl + 1) * scale_hi + 65535) >> 16) + 1, src.w - 1);
+  const int r0 = min(max(((yb * scale_lo) >> 16) - 1, 0), src.h - 1);
+  const int r1 = min((((yl + 1) * scale_hi + 65535) >> 16) + 1, src.h - 1);
   const int nq = ((c1 - c0) >> 4) + 1, nr = r1 - r0 + 1;          // 16-byte columns (<= 32), rows
   const uint8_t* simg = pyr + (size_t)b * pyr_bytes + src.off;
   const int x0 = xb + 4 * tx;
@@ -161,6 +166,8 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // 8-bit pixels x 11-bit weights: 24-bit multiplies (full rate; the 32-bit integer multiply is not)
+      // (the right tap keeps its own address: written as left + 1 the two byte reads are fused into one unaligned 16-bit LDS read,
+      // which runs 4x slower)
       const int h0 = __mul24(S0[ca[i]], a0[i]) + __mul24(S0[cb[i]], a1[i]);
       const int h1 = __mul24(S1[ca[i]], a0[i]) + __mul24(S1[cb[i]], a1[i]);
       // weights are in [0, 2048], h >> 4 < 2^16: the masks tell the compiler so and it picks the 24-bit multiply
@@ -218,16 +225,28 @@ __device__ __forceinline__ int fast_arc_score_pk(const uint8_t* c, int ts, int v
     const s2_t x = __builtin_bit_cast(s2_t, (uint32_t)v | ((uint32_t)c[off[k]] << 16));     // (v, p_k)
     e[k] = x - __builtin_shufflevector(x, x, 1, 0);                                           // (v - p_k, p_k - v)
   }
-  s2_t m2[16], m4[16], m8[16];
+  // minima of the sixteen cyclic 9-windows [k, k+8] by block prefix / suffix minima over the unrolled ring x[j] = e[j & 15], blocks
+  // [0,8] [9,17] [18,23]: 29 + 14 minima instead of 64 for the doubling scheme
+#define EX(j) e[(j) & 15]
+  s2_t S0[9], P1[9], S1[9], P2[6];
+  S0[8] = EX(8);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 15]);
+  for (int j = 7; j >= 0; --j) S0[j] = __builtin_elementwise_min(EX(j), S0[j + 1]);            // min x[j..8]
+  P1[0] = EX(9);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+  for (int j = 1; j < 9; ++j) P1[j] = __builtin_elementwise_min(P1[j - 1], EX(9 + j));          // min x[9..9+j]
+  S1[8] = EX(17);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-  s2_t a = __builtin_elementwise_min(m8[0], e[8]);
+  for (int j = 7; j >= 0; --j) S1[j] = __builtin_elementwise_min(EX(9 + j), S1[j + 1]);        // min x[9+j..17]
+  P2[0] = EX(18);
 #pragma unroll
-  for (int k = 1; k < 16; ++k) a = __builtin_elementwise_max(a, __builtin_elementwise_min(m8[k], e[(k + 8) & 15]));
+  for (int j = 1; j < 6; ++j) P2[j] = __builtin_elementwise_min(P2[j - 1], EX(18 + j));         // min x[18..18+j]
+#undef EX
+  s2_t a = __builtin_elementwise_max(S0[0], S1[0]);                                             // windows 0 and 9
+#pragma unroll
+  for (int k = 1; k <= 8; ++k) a = __builtin_elementwise_max(a, __builtin_elementwise_min(S0[k], P1[k - 1]));     // [k,8] + [9,k+8]
+#pragma unroll
+  for (int k = 10; k <= 15; ++k) a = __builtin_elementwise_max(a, __builtin_elementwise_min(S1[k - 9], P2[k - 10]));   // [k,17] + [18,k+8]
   const int A = max((int)a.x, (int)a.y);
   return A > t ? A - 1 : 0;
 }
@@ -334,20 +353,27 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
   const int q0 = lx0 >> 2, nq = ((lx1 - 1) >> 2) - q0 + 1;
   const int qrcp = k_fast_recip[nq & 31];                      // (32-bit integer multiplies and divisions are quarter rate: 24-bit forms throughout)
   const int qr = __mul24(lane, qrcp) >> 16, qc = lane - __mul24(qr, nq), qrows = (64 * qrcp) >> 16;
-  int colmask = 0;                                      // which of this lane's 4 columns are evaluated (row independent)
-  for (int i = 0; i < 4; ++i) { const int lxi = 4 * (q0 + qc) + i; colmask |= (lxi >= lx0 && lxi < lx1 ? 1 : 0) << i; }
+  // which of this lane's 4 columns are evaluated (row independent): kept as wave masks, so that the per-pixel survivor mask below
+  // is scalar arithmetic on compare results (a ballot of a combined boolean costs a select + compare per use)
+  bool colok[4];
+  unsigned long long colm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int lxi = 4 * (q0 + qc) + i; colok[i] = lxi >= lx0 && lxi < lx1; colm[i] = CMS_BALLOT(colok[i]); }
   int L = 0;
-  for (int rb = 0; rb < eh; rb += qrows) {
+  // the lane's quad in its first row; rows advance by `qrows`: one pointer increment per round instead of five row products
+  const uint8_t* prow = tile + __mul24(ey0 - iniY + qr, ts) + 4 * (q0 + qc);
+  const uint8_t* prow0 = tile + __mul24(ey0 - iniY, ts) + 4 * q0;         // row 0, first quad: valid for every lane
+  const int rstride = __mul24(qrows, ts), ts3 = 3 * ts;
+  const int q = q0 + qc;
+  const unsigned long long qrm = CMS_BALLOT(qr < qrows);
+  for (int rb = 0; rb < eh; rb += qrows, prow += rstride) {
     const int py = rb + qr;
     const bool rowok = qr < qrows && py < eh;
-    uint32_t cm = 0, cc = 0, cp = 0, up = 0, dn = 0;
-    const int q = q0 + qc;
-    if (rowok) {
-      const uint32_t* row = reinterpret_cast<const uint32_t*>(tile + __mul24(ey0 - iniY + py, ts));
-      cm = row[q - 1]; cc = row[q]; cp = row[q + 1];
-      up = reinterpret_cast<const uint32_t*>(tile + __mul24(ey0 - iniY + py - 3, ts))[q];
-      dn = reinterpret_cast<const uint32_t*>(tile + __mul24(ey0 - iniY + py + 3, ts))[q];
-    }
+    const unsigned long long rowm = CMS_BALLOT(py < eh) & qrm;      // == ballot(rowok), from plain compare masks
+    // a lane outside the rows reads its first-row quad again (always staged) and is masked out of the result below
+    const uint8_t* pr = rowok ? prow : prow0;
+    const uint32_t cm = *reinterpret_cast<const uint32_t*>(pr - 4), cc = *reinterpret_cast<const uint32_t*>(pr), cp = *reinterpret_cast<const uint32_t*>(pr + 4);
+    const uint32_t up = *reinterpret_cast<const uint32_t*>(pr - ts3), dn = *reinterpret_cast<const uint32_t*>(pr + ts3);
     // the four compass points are the four (vertical, horizontal) combinations of {p0, p8} x {p4, p12}, so
     //   "some adjacent pair is darker than v - t"   <=>  max(min(p0, p8), min(p4, p12)) < v - t
     //   "some adjacent pair is brighter than v + t" <=>  min(max(p0, p8), max(p4, p12)) > v + t
@@ -363,8 +389,8 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
       const int p0 = (dn >> (8 * i)) & 0xFF, p8 = (up >> (8 * i)) & 0xFF;
       const int dmax = max(min(p0, p8), min(p4, p12));
       const int bmin = min(max(p0, p8), max(p4, p12));
-      const bool pass = (bool)((int)rowok & ((colmask >> i) & 1) & ((int)(dmax < v - t) | (int)(bmin > v + t)));   // no short circuit: branch-free
-      const unsigned long long m = __ballot(pass);
+      const unsigned long long m = (CMS_BALLOT(dmax < v - t) | CMS_BALLOT(bmin > v + t)) & colm[i] & rowm;
+      const bool pass = __builtin_amdgcn_inverse_ballot_w64(m);
       if (pass) list[L + LANE_PREFIX(m)] = (uint16_t)((py << 6) | (lx - lx0));
       L += __popcll(m);
     }
@@ -377,27 +403,26 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
   if (L > 0) {
     int L2 = 0;
     for (int base = 0; base < L; base += 64) {
+      // every lane runs the test (lanes past the end on entry 0, masked out of the result): the sixteen compare results are wave
+      // masks and the run test is scalar and/or on them -- building per-lane bit fields cost a select and an or per bit
       const int k = base + lane;
-      bool pass = false;
-      int code = 0;
-      if (k < L) {
-        code = list[k];
-        const int py = code >> 6, px = code & 63;
-        const uint8_t* c = tile + __mul24(ey0 - iniY + py, ts) + (lx0 + px);
-        const int v = c[0];
-        const int e[8] = {v - c[3 * ts], v - c[2 * ts + 2], v - c[3], v - c[-2 * ts + 2],
-                          v - c[-3 * ts], v - c[-2 * ts - 2], v - c[-3], v - c[2 * ts - 2]};
-        uint32_t md = 0, mb = 0;
+      const int code = list[k < L ? k : 0];
+      const int py = code >> 6, px = code & 63;
+      const uint8_t* c = tile + __mul24(ey0 - iniY + py, ts) + (lx0 + px);
+      const int v = c[0];
+      const int e[8] = {v - c[3 * ts], v - c[2 * ts + 2], v - c[3], v - c[-2 * ts + 2],
+                        v - c[-3 * ts], v - c[-2 * ts - 2], v - c[-3], v - c[2 * ts - 2]};
+      unsigned long long dk[8], br[8], d2[8], b2[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { md |= (e[i] > t ? 1u : 0u) << i; mb |= (-e[i] > t ? 1u : 0u) << i; }
-        md |= md << 8; mb |= mb << 8;
-        uint32_t rd = md & (md >> 1); rd &= rd >> 2;
-        uint32_t rbm = mb & (mb >> 1); rbm &= rbm >> 2;
-        pass = ((rd | rbm) & 0xFFu) != 0;
-      }
+      for (int i = 0; i < 8; ++i) { dk[i] = CMS_BALLOT(e[i] > t); br[i] = CMS_BALLOT(e[i] < -t); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { d2[i] = dk[i] & dk[(i + 1) & 7]; b2[i] = br[i] & br[(i + 1) & 7]; }
+      unsigned long long m = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m |= (d2[i] & d2[(i + 2) & 7]) | (b2[i] & b2[(i + 2) & 7]);
+      m &= CMS_BALLOT(k < L);
       WAVE_SYNC();                         // every lane has read its entry before the compacted list is written
-      const unsigned long long m = __ballot(pass);
-      if (pass) list[L2 + LANE_PREFIX(m)] = (uint16_t)code;
+      if (__builtin_amdgcn_inverse_ballot_w64(m)) list[L2 + LANE_PREFIX(m)] = (uint16_t)code;
       L2 += __popcll(m);
     }
     L = L2;
@@ -424,20 +449,21 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
   // ---- phase C: strict 8-neighbour maximum inside this cell, iniTh else minTh, emit
   int n_all = 0, n_ini = 0;
   for (int base = 0; base < L; base += 64) {
+    // all nine scores are read at once (a short-circuit chain waits for eight LDS round trips in a row) by every lane -- dead
+    // entries and lanes past the end look at pixel (0, 0) and are masked out; the comparisons meet as wave masks
     const int k = base + lane;
-    bool keep = false, ini = false;
-    if (k < L && list[k] != 0xFFFFu) {
-      const int code = list[k];
-      const int py = code >> 6, px = code & 63;
-      const uint8_t* s = sc + __mul24(py + 1, ss) + px + 1;
-      const int S = s[0];
-      keep = S > s[-1] && S > s[1] && S > s[-ss - 1] && S > s[-ss] && S > s[-ss + 1] && S > s[ss - 1] && S > s[ss] &&
-             S > s[ss + 1];
-      ini = keep && S >= g.ini_th;
-      if (!keep) list[k] = 0xFFFFu;
-    }
-    n_all += __popcll(__ballot(keep));
-    n_ini += __popcll(__ballot(ini));
+    const int code = list[k < L ? k : 0];
+    const unsigned long long livem = CMS_BALLOT(k < L) & CMS_BALLOT(code != 0xFFFF);
+    const int cd = code != 0xFFFF ? code : 0;
+    const int py = cd >> 6, px = cd & 63;
+    const uint8_t* s = sc + __mul24(py + 1, ss) + px + 1;
+    const int S = s[0];
+    const int n0 = s[-1], n1 = s[1], n2 = s[-ss - 1], n3 = s[-ss], n4 = s[-ss + 1], n5 = s[ss - 1], n6 = s[ss], n7 = s[ss + 1];
+    const unsigned long long keepm = livem & CMS_BALLOT(S > n0) & CMS_BALLOT(S > n1) & CMS_BALLOT(S > n2) & CMS_BALLOT(S > n3) &
+                                     CMS_BALLOT(S > n4) & CMS_BALLOT(S > n5) & CMS_BALLOT(S > n6) & CMS_BALLOT(S > n7);
+    if (__builtin_amdgcn_inverse_ballot_w64(livem & ~keepm)) list[k] = 0xFFFFu;
+    n_all += __popcll(keepm);
+    n_ini += __popcll(keepm & CMS_BALLOT(S >= g.ini_th));
   }
   const int n_emit = n_ini > 0 ? n_ini : n_all;
   if (n_emit == 0) return;            // cell_cnt was zeroed before the launch
@@ -458,7 +484,7 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
       S = sc[__mul24(py + 1, ss) + px + 1];
       emit = use_ini ? (S >= g.ini_th) : true;
     }
-    const unsigned long long m = __ballot(emit);
+    const unsigned long long m = CMS_BALLOT(emit);
     if (emit) {
       const int pos = basepos + off + LANE_PREFIX(m);
       if (pos < g.cell_cap) out[pos] = (uint32_t)(ex0 + px) | ((uint32_t)(ey0 + py) << 12) | ((uint32_t)S << 24);
@@ -577,7 +603,7 @@ k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ q
         keep = face && !(px < 0 || ix >= g.W || py < 0 || iy >= g.W);
         if (keep) keep = mask[(size_t)iy * mstride + ix] != 0;
       }
-      const unsigned long long mk = __ballot(keep);
+      const unsigned long long mk = CMS_BALLOT(keep);
       if (lane == 0) wsum[wave] = __popcll(mk);
       __syncthreads();
       int off = total;
