@@ -306,7 +306,8 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   BaDyn dyn;
   memset(&dyn, 0, sizeof(dyn));
   dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1;
-  bool first_batch = true;
+  bool first_batch = true, first_round = false;
+  for (int w = 0; w < n; ++w) first_round = first_round || st[w].it == 0;
   for (;;) {
     bool any = false;
     for (int w = 0; w < n; ++w) any = any || hlm[w].next != 2;
@@ -314,10 +315,15 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     const int rounds = stop ? 1 : (first_batch ? std::max(max_it, 1) : 2);
     first_batch = false;
     for (int r = 0; r < rounds; ++r) {
-      hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_lin_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_lin_poses, dim3(max_K, BA_POSE_CHUNKS, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      if (first_round) {     // residuals of the stage's starting estimate: later iterations carry the accepted trial's over (every window starts at it == 0)
+        hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+        hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      }
+      first_round = false;
+      {
+        const int npb = (max_P + 255) / 256;
+        hipLaunchKernelGGL(kb_ba_lin, dim3(npb + max_K * BA_POSE_CHUNKS, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER, npb);
+      }
       hipLaunchKernelGGL(kb_ba_pose_finish, dim3(std::max(max_np, 1), 1, n), dim3(64), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
       hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
       if (!all_sp)

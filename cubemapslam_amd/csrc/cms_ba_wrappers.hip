@@ -165,6 +165,20 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_lin_poses(const BaItem* 
   BA_ITEM(phase, it.d.K)        // blockIdx.y = slice of the pose's edge list
   ba_lin_poses_body(blockIdx.x, it.d.K, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.pose_partial);
 }
+// Both linearisation passes in one launch: the per-point and the per-pose accumulation read the same estimate and residuals and write
+// disjoint outputs, and neither fills the chip on its own (one after the other they cost 19 + 28 us per iteration of a four-window
+// group).  Workgroups [0, npb) take 256 points each, the rest take one (pose, slice) pair each.
+extern "C" __global__ void __launch_bounds__(256) kb_ba_lin(const BaItem* __restrict__ items, BaDyn dyn, int phase, int npb) {
+  BA_ITEM(phase, 1 << 30)
+  if ((int)blockIdx.x < npb) {
+    if ((int)blockIdx.x * 256 >= it.d.P) return;
+    ba_lin_points_body(blockIdx.x, npb, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.Hll, it.bl, it.sp.R > 0 ? nullptr : it.Hpl);
+  } else {
+    const int j = (int)blockIdx.x - npb, k = j / BA_POSE_CHUNKS, ch = j - k * BA_POSE_CHUNKS;
+    if (k >= it.d.K) return;
+    ba_lin_poses_body(k, it.d.K, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.pose_partial, ch);
+  }
+}
 extern "C" __global__ void __launch_bounds__(64) kb_ba_pose_finish(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.d.np)
   ba_pose_finish_body(blockIdx.x, it.d.np, it.d.np, it.pose_partial, it.Hpp, it.bp);
