@@ -305,7 +305,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   HIPCHK(hipMemcpyAsync(g->grp_lm_dev, hlm, (size_t)n * sizeof(BaLmDev), hipMemcpyHostToDevice, s));
   BaDyn dyn;
   memset(&dyn, 0, sizeof(dyn));
-  dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1;
+  dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1; dyn.fold_finish = 1;
   bool first_batch = true, first_round = false;
   for (int w = 0; w < n; ++w) first_round = first_round || st[w].it == 0;
   for (;;) {
@@ -324,8 +324,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         const int npb = (max_P + 255) / 256;
         hipLaunchKernelGGL(kb_ba_lin, dim3(npb + max_K * BA_POSE_CHUNKS, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER, npb);
       }
-      hipLaunchKernelGGL(kb_ba_pose_finish, dim3(std::max(max_np, 1), 1, n), dim3(64), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
-      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
+      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);      // + the pose slice sums (fold_finish)
       if (!all_sp)
         hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       if (all_sp) {
