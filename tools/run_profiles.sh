@@ -15,4 +15,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ${TAG}_
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o ${TAG}_pmc_write -- python $R/tools/prof_frames.py 64 550 3 > $OUT/${TAG}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_mapping -- python $R/tools/prof_tri.py 8 20 5 > $OUT/${TAG}_mapping.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_ba8 -- python $R/tools/prof_ba_many.py 8 > $OUT/${TAG}_ba8.log 2>&1
+# 4. SQ instruction mix of the frame-path kernels (three --pmc passes, kernel trace only)                 -> gpurun_out/pmc/
+bash $R/tools/pmc_mix.sh > $OUT/${TAG}_pmc_mix.log 2>&1
 ls $OUT

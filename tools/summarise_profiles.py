@@ -52,4 +52,29 @@ if pmc:
                            "calibration on this path: k_fast_cells with the XCD-striped cell list reports 183 MB against >= 300 MB of "
                            "non-zero cell bytes it must read (x2 = 366 MB incl. the 3-px halos); the plain row-major list reported 854 MB",
                    "kernels": {k: v for k, v in pmc.items() if k.startswith("k_")}}, f, indent=1)
+# ---- SQ instruction mix (tools/pmc_mix.sh): per kernel, counters per wave and the vector-ALU issue bound
+import glob
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "gpurun_out", "pmc", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+mix = {}
+for k, cs in sorted(acc.items()):
+    if not k.startswith("k_") or "SQ_WAVES" not in cs:
+        continue
+    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    w = m["SQ_WAVES"] or 1.0
+    per = lambda c: round(m.get(c, 0.0) / w, 1)
+    mix[k] = {"waves_per_dispatch": int(w),
+              "per_wave": {"valu": per("SQ_INSTS_VALU"), "salu": per("SQ_INSTS_SALU"), "lds": per("SQ_INSTS_LDS"), "smem": per("SQ_INSTS_SMEM"),
+                           "wave_quad_cycles": per("SQ_WAVE_CYCLES"), "wait_inst_any_quad_cycles": per("SQ_WAIT_INST_ANY")},
+              "valu_issue_bound_us": round(m.get("SQ_INSTS_VALU", 0.0) * 4 / (256 * 4 * 2.4e9) * 1e6, 1)}
+if mix:
+    with open(os.path.join(dst, tag + "_pmc_instruction_mix.json"), "w") as f:
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass, 3 passes> -- python tools/prof_frames.py 64 550 2   (tools/pmc_mix.sh; MI355X; "
+                              "one dispatch = 64 frames; k_resize = average of its 7 per-level dispatches)",
+                   "note": "valu_issue_bound_us = VALU instructions x 4 cycles (a wave64 VALU instruction occupies its SIMD16 for 4 cycles) / (256 CUs x 4 SIMDs x "
+                           "2.4 GHz): the time the kernel would need if it did nothing but issue its vector ALU instructions.  SQ_WAVE_CYCLES / "
+                           "SQ_WAIT_INST_ANY are in quad-cycles.",
+                   "kernels": mix}, f, indent=1)
 print("profiles/:", sorted(os.listdir(dst)))
