@@ -48,7 +48,7 @@ struct cms_ctx {
   int dirty_frames = 0;       // leading frames whose corner blocks may be non-zero (a caller-supplied canvas went through them)
   // device buffers
   uint8_t* d_fish = nullptr; uint32_t* d_lut = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_mask = nullptr;
-  CmsResizeTab* d_tab = nullptr; signed char* d_pattern = nullptr;
+  CmsResizeTab* d_tab = nullptr; float* d_pattern = nullptr;     // the 256 x 4 test coordinates as floats (what the kernel multiplies)
   uint32_t* d_cand = nullptr; uint16_t* d_node = nullptr; int* d_cand_cnt = nullptr; int* d_overflow = nullptr;
   uint32_t* d_qt_out = nullptr; int* d_qt_cnt = nullptr;
   uint32_t* d_cell_cand = nullptr; int* d_cell_cnt = nullptr;
@@ -247,7 +247,7 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   ALLOC(c->d_pyr, B * g.pyr_bytes + 256);
   ALLOC(c->d_mask, (size_t)W * c->mstride);
   ALLOC(c->d_tab, tab_off * sizeof(CmsResizeTab));
-  ALLOC(c->d_pattern, 1024);
+  ALLOC(c->d_pattern, 1024 * sizeof(float));
   ALLOC(c->d_cand, B * g.cand_total * 4);
   ALLOC(c->d_node, B * g.cand_total * 2);
   ALLOC(c->d_cand_cnt, B * L * sizeof(int));
@@ -329,7 +329,9 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
     }
     hipMemcpy(c->d_cells_all, all.data(), all.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(c->d_cells_nz, nz.data(), nz.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(c->d_pattern, kOrbPattern, 1024, hipMemcpyHostToDevice);
+    float patf[1024];
+    for (int i = 0; i < 1024; ++i) patf[i] = (float)kOrbPattern[i];
+    hipMemcpy(c->d_pattern, patf, sizeof(patf), hipMemcpyHostToDevice);
   }
   e = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->qt_lds);
   if (e != hipSuccess) { cms_ctx_free(c); return cms_fail(CMS_ERR_HIP, "hipFuncSetAttribute(k_quadtree)", e); }
@@ -443,7 +445,7 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
                      (const uint8_t*)c->d_mask, c->mstride, c->d_kps, c->d_aux, c->d_kp_cnt);
   if (c->prof) hipEventRecord(c->ev[5], s);
   hipLaunchKernelGGL(k_describe, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
-                     (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const signed char*)c->d_pattern, c->d_desc);
+                     (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc);
   if (c->prof) hipEventRecord(c->ev[6], s);
   HIPCHK(hipGetLastError());
   return CMS_OK;
