@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <numeric>
+#include <thread>
 
 struct cms_ba {
   int device = 0;

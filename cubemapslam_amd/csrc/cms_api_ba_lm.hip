@@ -306,15 +306,18 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   BaDyn dyn;
   memset(&dyn, 0, sizeof(dyn));
   dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1; dyn.fold_finish = 1;
-  bool first_batch = true, first_round = false;
+  bool first_round = false;
   for (int w = 0; w < n; ++w) first_round = first_round || st[w].it == 0;
-  for (;;) {
-    bool any = false;
-    for (int w = 0; w < n; ++w) any = any || hlm[w].next != 2;
-    if (!any || (!first_batch && ba_stopped(stop))) break;
-    const int rounds = stop ? 1 : (first_batch ? std::max(max_it, 1) : 2);
-    first_batch = false;
-    for (int r = 0; r < rounds; ++r) {
+  // One "round" = the launches of one Levenberg trial (plus the linearisation in front of it for the windows that start an iteration).
+  // The host never synchronises the stream inside a stage: a synchronisation -- or an event -- after a round makes the chip publish
+  // its caches before the next kernel starts, 19 us of idle time per round, 0.4 ms per window group.  Instead the last kernel of a
+  // round bumps a counter in pinned host memory (next to the windows' Levenberg state, which the kernels mirror there too) and the
+  // host keeps at most two rounds in the queue: the one that is running and the one behind it.  It looks at the mirrored state and
+  // at the caller's stop flag before every round it adds; the price is at most two rounds of idle launches after the last window
+  // finished, and a stop request that takes effect up to two trials later (it is asynchronous in the reference too: Optimizer.cpp:
+  // 359-361 hands g2o a flag another thread sets).
+  int k = 0;
+  auto enqueue_round = [&]() {
       if (first_round) {     // residuals of the stage's starting estimate: later iterations carry the accepted trial's over (every window starts at it == 0)
         hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
         hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
@@ -336,9 +339,24 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
       hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      ++k;
+  };
+  const volatile BaLmDev* vh = reinterpret_cast<const volatile BaLmDev*>(hlm);
+  hipError_t werr = hipSuccess;
+  for (long spins = 0;;) {
+    bool any = false;
+    for (int w = 0; w < n; ++w) any = any || vh[w].next != 2;
+    if (!any || (k > 0 && ba_stopped(stop))) break;
+    if (k - vh[0].rounds < 2) { enqueue_round(); spins = 0; continue; }
+    std::this_thread::yield();
+    if ((++spins & 0xFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) {      // the stream drained (or failed) without the counter moving
+      werr = hipStreamSynchronize(s);
+      if (werr != hipSuccess || k - vh[0].rounds >= 2) { if (werr == hipSuccess) werr = hipErrorUnknown; break; }
     }
-    HIPCHK(hipStreamSynchronize(s));            // the kernels mirrored every window's state into hlm (pinned)
   }
+  const hipError_t serr = hipStreamSynchronize(s);                  // final state of every window: mirrored into hlm by the kernels
+  HIPCHK(werr);
+  HIPCHK(serr);
   HIPCHK(hipGetLastError());
   for (int w = 0; w < n; ++w) {
     const BaLmDev& L = hlm[w];

@@ -17,7 +17,7 @@
 // reads `next` to know whether it has work: the host can enqueue several iterations back to back without waiting.
 struct BaLmDev {
   double lambda, ni, currentChi, iniChi, rho, chi_ini, chi_fin, lam_fin;
-  int it, iterations, qmax, nBad, done, next, cur, pad;     // next: 0 = start an iteration, 1 = one more trial, 2 = finished
+  int it, iterations, qmax, nBad, done, next, cur, rounds;   // next: 0 = start an iteration, 1 = one more trial, 2 = finished
 };
 // static description of one window (device resident, uploaded once per optimisation stage) ...
 struct BaItem {
@@ -251,6 +251,14 @@ extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaIte
 }
 // last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
 extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) {
+    // round counter of the group, mirrored into pinned host memory: the host driver paces its launches on it without ever
+    // synchronising the stream (see ba_optimize_stage_batched_dev)
+    BaLmDev* L0 = items[0].lm;
+    const int r = L0->rounds + 1;
+    L0->rounds = r;
+    *reinterpret_cast<volatile int*>(&items[0].hlm->rounds) = r;
+  }
   BA_ITEM(phase, 1)
   ba_reduce2_body(0, 1, it.partial, it.nblk_p, it.scal, it.hscal);
   if (dyn.dev_lm && threadIdx.x == 0) {
