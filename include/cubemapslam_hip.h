@@ -130,7 +130,10 @@ int cms_hamming_matrix(cms_ctx* ctx, const uint8_t* a, int na, const uint8_t* b,
  *      point index, measurement in the face, invSigma2 of the octave, face id.
  *      cms_ba_optimize runs optimize(its_robust) with Huber(sqrt(5.991)) -> chi2/depth classification ->
  *      optimize(its_final) on the inliers without kernel -> final classification (outlier_flags[e] = 1 to erase);
- *      *stop is polled between iterations like g2o's forceStopFlag (Optimizer.cpp:256-257). */
+ *      *stop is polled between iterations like g2o's forceStopFlag (Optimizer.cpp:256-257): before anything is launched, then
+ *      before every Levenberg trial the host enqueues.  Windows advanced as a group (optimize_many) keep up to two trials queued
+ *      on the device, so a request raised mid-way takes effect at most two trials later; the estimate left behind is the last
+ *      accepted one, as with g2o. */
 typedef struct cms_ba cms_ba;
 typedef struct {
   int iterations_done[2];
