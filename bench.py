@@ -5,7 +5,7 @@
 
 Workload (BASELINE.json: "frames/sec (extract+match+localBA) on Lafida cam0", configs[2] geometry): synthetic Lafida cam0
 stream, 754x480 fisheye, cube face F=550 (1650^2 cross), nFeatures 2000 / 8 levels / 1.2 / FAST 20-7.
-One step = one batch of B frames (default 64 = 8 camera streams x 8 consecutive frames, cf. BASELINE.json configs[4]), inputs
+One step = one batch of B frames (default 128 = 16 camera streams x 8 consecutive frames, cf. BASELINE.json configs[4]), inputs
 resident in HBM:
     remap -> pyramid -> FAST cells -> octree -> cull -> orientation + rBRIEF     (ORBextractor::operator(), all B frames per launch)
     Frame::AssignFeaturesToGrid + GetFeaturesInArea windows + Hamming best/second-best of every key point of frame b-1 in
@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (default: 8 streams x 8 consecutive frames)")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU (default: 16 streams x 8 consecutive frames)")
     ap.add_argument("--face", type=int, default=550)
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
     ap.add_argument("--ba-groups", type=int, default=2, help="host threads / streams the local-BA windows of a step are split over")
@@ -298,10 +298,10 @@ def main():
     launches = nl.get(dom, 1)
     ach = alg[dom] * B / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms.get(dom, 0) > 0 else None
     # measured HBM traffic of that kernel: committed rocprofv3 PMC pass (FETCH_SIZE and WRITE_SIZE collected in separate runs,
-    # tools/run_profiles.sh), valid for the default workload only (B = 64, F = 550)
+    # tools/run_profiles.sh), valid for the batch size the passes were taken at (the default, F = 550)
     traffic = None
     pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pj) and B == 64 and F == 550:
+    if os.path.exists(pj) and F == 550 and json.load(open(pj)).get("frames_per_dispatch", 64) == B:
         kk = json.load(open(pj))["kernels"].get(kname)
         if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
             # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section) -> doubled; unit KB
@@ -310,7 +310,7 @@ def main():
     # (256 CUs x 4 SIMDs x 2.4 GHz)): how much of the launch is spent just issuing its vector instructions
     valu_us = None
     pm = os.path.join(ROOT, "profiles", "r01_pmc_instruction_mix.json")
-    if os.path.exists(pm) and B == 64 and F == 550:
+    if os.path.exists(pm) and F == 550 and json.load(open(pm)).get("frames_per_dispatch", 64) == B:
         kk = json.load(open(pm))["kernels"].get(kname)
         if kk:
             valu_us = kk["valu_issue_bound_us"]

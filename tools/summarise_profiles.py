@@ -2,6 +2,7 @@
 """Condense gpurun_out/prof/<tag>_* (rocprofv3 csv output) into the small, tracked summaries under profiles/."""
 import collections, csv, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+PB = int(os.environ.get("PROF_B", "128"))      # frames per dispatch of the PMC passes (tools/run_profiles.sh)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof"); dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -46,7 +47,7 @@ for kind in ("fetch", "write"):
         pmc.setdefault(k, {})[c] = {"sum": v, "dispatches": n, "per_dispatch": v / n}
 if pmc:
     with open(os.path.join(dst, tag + "_pmc_hbm_traffic.json"), "w") as f:
-        json.dump({"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/prof_frames.py 64 550 3",
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/prof_frames.py %d 550 3" % PB, "frames_per_dispatch": PB,
                    "note": "counter unit: KB (rocprofv3 derived metric); separate passes for FETCH_SIZE and WRITE_SIZE; "
                            "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section): bench.py doubles it; "
                            "calibration on this path: k_fast_cells with the XCD-striped cell list reports 183 MB against >= 300 MB of "
@@ -71,8 +72,8 @@ for k, cs in sorted(acc.items()):
               "valu_issue_bound_us": round(m.get("SQ_INSTS_VALU", 0.0) * 4 / (256 * 4 * 2.4e9) * 1e6, 1)}
 if mix:
     with open(os.path.join(dst, tag + "_pmc_instruction_mix.json"), "w") as f:
-        json.dump({"command": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass, 3 passes> -- python tools/prof_frames.py 64 550 2   (tools/pmc_mix.sh; MI355X; "
-                              "one dispatch = 64 frames; k_resize = average of its 7 per-level dispatches)",
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass, 3 passes> -- python tools/prof_frames.py %d 550 2   (tools/pmc_mix.sh; MI355X; "
+                              "one dispatch = %d frames; k_resize = average of its 7 per-level dispatches)" % (PB, PB), "frames_per_dispatch": PB,
                    "note": "valu_issue_bound_us = VALU instructions x 4 cycles (a wave64 VALU instruction occupies its SIMD16 for 4 cycles) / (256 CUs x 4 SIMDs x "
                            "2.4 GHz): the time the kernel would need if it did nothing but issue its vector ALU instructions.  SQ_WAVE_CYCLES / "
                            "SQ_WAIT_INST_ANY are in quad-cycles.",
