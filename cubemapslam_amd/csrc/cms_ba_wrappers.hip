@@ -250,21 +250,25 @@ extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaIte
                        dyn.delta, it.partial, it.sp.R > 0 ? it.Hll : nullptr, it.sp.R > 0 ? it.poses[cur] : nullptr);
 }
 // last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
-extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
-  if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) {
-    // round counter of the group, mirrored into pinned host memory: the host driver paces its launches on it without ever
-    // synchronising the stream (see ba_optimize_stage_batched_dev)
-    BaLmDev* L0 = items[0].lm;
-    const int r = L0->rounds + 1;
-    L0->rounds = r;
-    *reinterpret_cast<volatile int*>(&items[0].hlm->rounds) = r;
-  }
+__device__ __forceinline__ void kb_ba_reduce2_window(const BaItem* __restrict__ items, const BaDyn& dyn, int phase) {
   BA_ITEM(phase, 1)
   ba_reduce2_body(0, 1, it.partial, it.nblk_p, it.scal, it.hscal);
   if (dyn.dev_lm && threadIdx.x == 0) {
     int ok2;
     memcpy(&ok2, &it.scal[4], sizeof(int));
     ba_lm_after_trial(it.lm, it.hlm, it.scal[1], it.scal[2], ok2);
+  }
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  kb_ba_reduce2_window(items, dyn, phase);
+  if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) {
+    // round counter of the group, mirrored into pinned host memory AFTER this window's state: the host driver paces its launches on
+    // it without ever synchronising the stream (see ba_optimize_stage_batched_dev); bumped first, the host saw the round end before
+    // the windows' "finished" flags and queued idle rounds (5 per window group and call instead of 2)
+    BaLmDev* L0 = items[0].lm;
+    const int r = L0->rounds + 1;
+    L0->rounds = r;
+    *reinterpret_cast<volatile int*>(&items[0].hlm->rounds) = r;
   }
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
