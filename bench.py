@@ -214,13 +214,14 @@ def main():
 
     part = os.environ.get("CMS_BENCH_PART", "")      # developer knob: "ba" / "frames" times one half of the step alone (not a bench line)
 
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=n_grp)       # one standing host thread per window group (LocalMapping-like)
+
     def step(i):
-        ths = [threading.Thread(target=ba_worker, args=(grp, gi)) for gi, grp in enumerate(groups)] if part != "frames" else []
-        for th in ths:
-            th.start()
+        ths = [pool.submit(ba_worker, grp, gi) for gi, grp in enumerate(groups)] if part != "frames" else []   # the groups' standing host threads
         if part == "ba":
             for th in ths:
-                th.join()
+                th.result()
             return
         po.launch()                 # own stream, overlaps the frame path
         ctx.process(B, True)
@@ -239,7 +240,7 @@ def main():
         ctx.sync()
         _, frame_poses, _, _ = po.fetch()
         for th in ths:
-            th.join()
+            th.result()
         if ba_err:
             raise ba_err[0]
         if world > 1 or args.force_gather:   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
@@ -267,6 +268,7 @@ def main():
             stage_ms[k] = stage_ms.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
+    pool.shutdown()
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
