@@ -5,7 +5,7 @@
 
 Workload (BASELINE.json: "frames/sec (extract+match+localBA) on Lafida cam0", configs[2] geometry): synthetic Lafida cam0
 stream, 754x480 fisheye, cube face F=550 (1650^2 cross), nFeatures 2000 / 8 levels / 1.2 / FAST 20-7.
-One step = one batch of B frames (default 128 = 16 camera streams x 8 consecutive frames, cf. BASELINE.json configs[4]), inputs
+One step = one batch of B frames (default 256 = 32 camera streams x 8 consecutive frames, cf. BASELINE.json configs[4]), inputs
 resident in HBM:
     remap -> pyramid -> FAST cells -> octree -> cull -> orientation + rBRIEF     (ORBextractor::operator(), all B frames per launch)
     Frame::AssignFeaturesToGrid + GetFeaturesInArea windows + Hamming best/second-best of every key point of frame b-1 in
@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU (default: 16 streams x 8 consecutive frames)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (default: 32 streams x 8 consecutive frames)")
     ap.add_argument("--face", type=int, default=550)
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
     ap.add_argument("--ba-groups", type=int, default=2, help="host threads / streams the local-BA windows of a step are split over")

@@ -6,7 +6,7 @@
 # Summaries are then copied into profiles/ by tools/summarise_profiles.py.
 set -u
 TAG=${1:-r01}
-PB=${PROF_B:-128}          # frames per dispatch of the PMC passes = bench.py's default --batch
+PB=${PROF_B:-256}          # frames per dispatch of the PMC passes = bench.py's default --batch
 export PROF_B=$PB
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof

@@ -2,7 +2,7 @@
 """Condense gpurun_out/prof/<tag>_* (rocprofv3 csv output) into the small, tracked summaries under profiles/."""
 import collections, csv, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-PB = int(os.environ.get("PROF_B", "128"))      # frames per dispatch of the PMC passes (tools/run_profiles.sh)
+PB = int(os.environ.get("PROF_B", "256"))      # frames per dispatch of the PMC passes (tools/run_profiles.sh)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof"); dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
