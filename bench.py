@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (default: 32 streams x 8 consecutive frames)")
     ap.add_argument("--face", type=int, default=550)
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
-    ap.add_argument("--ba-groups", type=int, default=2, help="host threads / streams the local-BA windows of a step are split over")
+    ap.add_argument("--ba-groups", type=int, default=4, help="host threads / streams the local-BA windows of a step are split over")
     ap.add_argument("--pose-edges", type=int, default=600, help="matched map points per frame for the pose-only optimisation")
     ap.add_argument("--save-trajectory", default="", help="rank 0 writes the gathered trajectory of the last step here (TUM format)")
     ap.add_argument("--force-gather", action="store_true", help="run the trajectory gather code path even with one rank (self-test)")
