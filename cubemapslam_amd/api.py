@@ -549,12 +549,13 @@ class BundleAdjuster:
             pass
 
 
-def ba_optimize_many(bas, its=(5, 10), stop=None):
-    """cms_ba_optimize_many: advance several BundleAdjuster windows in lock-step from one host thread."""
+def ba_optimize_many(bas, its=(5, 10), stop=None, stop_array=None):
+    """cms_ba_optimize_many: advance several BundleAdjuster windows in lock-step from one host thread.  stop_array: a uint8[1] array
+    another thread may set while the call runs (Optimizer::LocalBundleAdjustment's pbStopFlag); None = no flag."""
     n = len(bas)
     handles = (C.c_void_p * n)(*[b.h for b in bas])
     stats = (BaStats * n)()
-    stop_arr = np.array([1 if stop else 0], np.uint8)
+    stop_arr = stop_array if stop_array is not None else (np.array([1], np.uint8) if stop else None)
     lib().cms_ba_optimize_many.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     rc = _chk(lib().cms_ba_optimize_many(handles, n, its[0], its[1], _p(stop_arr), stats), "cms_ba_optimize_many")
     return rc, list(stats)

@@ -5,7 +5,9 @@
 // Levenberg trial the host reads back three scalars (new chi2, gain denominator, LDL^T status).
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -41,6 +43,24 @@ struct cms_ba {
   int grp_cap = 0;
   std::vector<void*> allocs;
 };
+
+// Dynamic-LDS ceilings of the BA kernels: hipFuncAttributeMaxDynamicSharedMemorySize is a per-function (per device) global, so it is
+// raised ONCE to the largest size any window can ask for and never lowered per handle (another window / host thread may be launching).
+#define BA_LDS_CEILING (160 * 1024 - 512)
+static int ba_lds_attrs_once(int device) {
+  static std::mutex mu;
+  static bool done[64] = {false};
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= 64 || done[device]) return CMS_OK;
+  const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)k_ba_trial_solve,
+                       (const void*)kb_ba_trial_solve, (const void*)k_ba_solve_r192};
+  for (const void* f : fns) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);
+    if (e != hipSuccess) return cms_fail(CMS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+  }
+  done[device] = true;
+  return CMS_OK;
+}
 
 template <class T> static int ba_alloc(cms_ba* b, T** p, size_t n) {
   hipError_t e = hipMalloc((void**)p, (n > 0 ? n : 1) * sizeof(T));
@@ -85,6 +105,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   b->device = device; b->K = K; b->P = P; b->E = E;
 #define BA_TRY(x) do { int _rc = (x); if (_rc) { cms_ba_destroy(b); return _rc; } } while (0)
 #define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
+  BA_TRY(ba_lds_attrs_once(device));
   BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   // sort edges by (point, pose): CSR by point; per-pose edge lists reference sorted positions
   b->perm.resize(E);
@@ -259,8 +280,6 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
         sp.pair_slots = b->d_sp_pair_slots; sp.partial = b->d_sp_partial;
         b->sp_threads = (nslots + 63) / 64 * 64 + BA_SP_STAGERS;   // owner wavefronts + the staging team
         b->sp_lds = (size_t)BA_SP_MAXE * BA_SP_ROW * sizeof(double) + BA_SP_MAXT * 2 + (BA_SP_MAX_THREADS + 4) * 2;
-        BA_HIP(hipFuncSetAttribute((const void*)k_ba_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->sp_lds));
-        BA_HIP(hipFuncSetAttribute((const void*)kb_ba_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->sp_lds));
       }
     }
     std::vector<int> pcoff(1, 0);
@@ -284,13 +303,11 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     BA_HIP(hipMemcpy(b->d_pair_off, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
-  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= 160 * 1024 - 512;
-  if (b->solve_blk) BA_HIP(hipFuncSetAttribute((const void*)k_ba_trial_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds));
+  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
   {
     const int NP = 192;
     b->solve_lds = ((size_t)n * (n + 1) / 2 + 4 * (size_t)NP + 8) * sizeof(double);
-    b->solve_in_lds = n <= 192 && b->solve_lds <= 160 * 1024 - 512;
-    if (b->solve_in_lds) BA_HIP(hipFuncSetAttribute((const void*)k_ba_solve_r192, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->solve_lds));
+    b->solve_in_lds = n <= 192 && b->solve_lds <= BA_LDS_CEILING;
   }
   // normalise quaternions like the SE3Quat constructor (se3quat.h:58-64, 280-285)
   std::vector<double> p0(poses, poses + 7 * (size_t)K);

@@ -176,9 +176,11 @@ static int ba_group_reserve(cms_ba* owner, int n) {
   HIPCHK(hipMalloc(&owner->grp_items_dev, (size_t)n * sizeof(BaItem)));
   HIPCHK(hipMalloc((void**)&owner->grp_scal_dev, (size_t)n * 8 * sizeof(double)));
   HIPCHK(hipHostMalloc(&owner->grp_items_host, (size_t)n * sizeof(BaItem)));
-  HIPCHK(hipHostMalloc((void**)&owner->grp_scal_host, (size_t)n * 8 * sizeof(double)));   // device-visible: kernels publish into it
+  // device-visible and explicitly coherent (fine-grained, uncached on the device side): kernels publish the windows' state and the round
+  // counter into these while they run, so visibility must not depend on HIP_HOST_COHERENT's default
+  HIPCHK(hipHostMalloc((void**)&owner->grp_scal_host, (size_t)n * 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   HIPCHK(hipMalloc(&owner->grp_lm_dev, (size_t)n * sizeof(BaLmDev)));
-  HIPCHK(hipHostMalloc(&owner->grp_lm_host, (size_t)n * sizeof(BaLmDev)));
+  HIPCHK(hipHostMalloc(&owner->grp_lm_host, (size_t)n * sizeof(BaLmDev), hipHostMallocMapped | hipHostMallocCoherent));
   owner->grp_cap = n;
   return CMS_OK;
 }
@@ -224,7 +226,6 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
     max_np = std::max(max_np, bas[w]->np); max_chunks = std::max(max_chunks, bas[w]->nchunks); max_P = std::max(max_P, bas[w]->P);
     lds = std::max(lds, bas[w]->blk_lds);
   }
-  HIPCHK(hipFuncSetAttribute((const void*)kb_ba_trial_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int rc = ba_upload_items(bas, n);
   if (rc) return rc;
   BaDyn dyn;
@@ -273,9 +274,10 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
   return CMS_OK;
 }
 // ---- the same stage with the Levenberg logic on the device: every kernel reads the window's BaLmDev to know whether it has work, the
-// last kernel of a phase updates it, and the host enqueues whole iterations back to back -- one synchronisation per batch of
-// iterations instead of two per iteration.  With a stop flag the batches are one iteration long so that the flag is polled as often
-// as g2o polls forceStopFlag.  Env CMS_BA_HOST_LM=1 selects the host-driven variant above (A/B, debugging).
+// last kernel of a phase updates it, and the host enqueues whole rounds (one Levenberg trial of every window) back to back without ever
+// synchronising the stream inside a stage.  Without a stop flag two rounds are kept in the queue; with one, a round is only added once
+// the previous one has finished and the flag has been looked at -- the abort point is then the trial boundary g2o's terminate() polls
+// (optimization_algorithm_levenberg.cpp:127, sparse_optimizer.cpp:376).  Env CMS_BA_HOST_LM=1 selects the host-driven variant above (A/B).
 static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>& st, const volatile uint8_t* stop) {
   cms_ba* g = bas[0];
   hipStream_t s = g->stream;
@@ -291,7 +293,6 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     lds = std::max(lds, bas[w]->blk_lds);
     max_it = std::max(max_it, st[w].iterations);
   }
-  HIPCHK(hipFuncSetAttribute((const void*)kb_ba_trial_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int rc = ba_upload_items(bas, n);
   if (rc) return rc;
   BaLmDev* hlm = reinterpret_cast<BaLmDev*>(g->grp_lm_host);
@@ -312,10 +313,9 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // The host never synchronises the stream inside a stage: a synchronisation -- or an event -- after a round makes the chip publish
   // its caches before the next kernel starts, 19 us of idle time per round, 0.4 ms per window group.  Instead the last kernel of a
   // round bumps a counter in pinned host memory (next to the windows' Levenberg state, which the kernels mirror there too) and the
-  // host keeps at most two rounds in the queue: the one that is running and the one behind it.  It looks at the mirrored state and
-  // at the caller's stop flag before every round it adds; the price is at most two rounds of idle launches after the last window
-  // finished, and a stop request that takes effect up to two trials later (it is asynchronous in the reference too: Optimizer.cpp:
-  // 359-361 hands g2o a flag another thread sets).
+  // host keeps at most two rounds in the queue: the one that is running and the one behind it (one, if the caller passed a stop flag:
+  // the flag is then honoured at the very next trial boundary).  It looks at the mirrored state and at the caller's stop flag before
+  // every round it adds; the price is at most two rounds of idle launches after the last window finished.
   int k = 0;
   auto enqueue_round = [&]() {
       if (first_round) {     // residuals of the stage's starting estimate: later iterations carry the accepted trial's over (every window starts at it == 0)
@@ -347,8 +347,9 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     bool any = false;
     for (int w = 0; w < n; ++w) any = any || vh[w].next != 2;
     if (!any || (k > 0 && ba_stopped(stop))) break;
-    if (k - vh[0].rounds < 2) { enqueue_round(); spins = 0; continue; }
-    std::this_thread::yield();
+    if (k - vh[0].rounds < (stop ? 1 : 2)) { enqueue_round(); spins = 0; continue; }
+    if (spins < 256) std::this_thread::yield();                         // a round takes 100-250 us: spin briefly, then back off so that
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));    // several groups' host threads do not burn a core each
     if ((++spins & 0xFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) {      // the stream drained (or failed) without the counter moving
       werr = hipStreamSynchronize(s);
       if (werr != hipSuccess || k - vh[0].rounds >= 2) { if (werr == hipSuccess) werr = hipErrorUnknown; break; }
@@ -364,6 +365,9 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     t.lambda = L.lambda; t.ni = L.ni; t.currentChi = L.currentChi; t.iniChi = L.iniChi; t.rho = L.rho; t.it = L.it; t.qmax = L.qmax;
     t.nBad = L.nBad; t.done = L.done; t.next = 2;
     if (L.done > 0 || L.it > 0) { t.chi_ini = L.chi_ini; t.chi_fin = L.chi_fin; t.lam_fin = L.lam_fin; }
+    if (L.next == 1 && L.qmax > 0 && ba_stopped(stop)) {   // stopped inside an iteration's trial loop (after a rejected trial): g2o leaves the
+      ++t.done; t.chi_ini = L.chi_ini; t.chi_fin = L.currentChi; t.lam_fin = L.lambda;   // do-while, counts the iteration and keeps the old estimate
+    }
     bas[w]->cur = L.cur;
   }
   return CMS_OK;

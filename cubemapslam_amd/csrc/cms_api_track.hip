@@ -34,7 +34,6 @@ extern "C" int cms_is_in_frustum_device(cms_ctx* c, int nmp, const void* d_mp_fr
   return CMS_OK;
 }
 
-#define CMS_TRACK_MAX_MP_PER_FRAME (32 * 1024)
 extern "C" int cms_search_local_points_device(cms_ctx* c, int B, const void* d_mp_off, const void* d_mp_desc, const void* d_cand_off,
                                               const void* d_cand_idx, void* d_pair_dist, float nnratio, int th_high, void* d_kp_mp,
                                               void* d_mp_match, void* d_rounds) {
@@ -63,7 +62,6 @@ extern "C" int cms_search_local_points(cms_ctx* c, int b, const float* pose15, i
       (nkp > 0 && !kp_mp))
     return cms_fail(CMS_ERR_ARG, "cms_search_local_points: bad argument");
   if (b < 0 || b >= c->area_frames) return cms_fail(CMS_ERR_ARG, "cms_search_local_points: no grid for this frame (cms_area_grid first)");
-  if (nmp > CMS_TRACK_MAX_MP_PER_FRAME) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points: more than 32768 map points per frame");
   if (c->g.kp_cap > CMS_TRACK_KPMAX) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_local_points: more than 4096 key points per frame");
   if (n_matches) *n_matches = 0;
   if (rounds) *rounds = 0;
@@ -181,7 +179,6 @@ extern "C" int cms_search_by_projection(cms_ctx* c, int b, const float* pose12, 
       (nkp > 0 && !kp_mp))
     return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: bad argument");
   if (b < 0 || b >= c->area_frames) return cms_fail(CMS_ERR_ARG, "cms_search_by_projection: no grid for this frame (cms_area_grid first)");
-  if (nlast > CMS_TRACK_MAX_MP_PER_FRAME) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_by_projection: more than 32768 queries");
   if (c->g.kp_cap > CMS_TRACK_KPMAX) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_by_projection: more than 4096 key points per frame");
   if (n_matches) *n_matches = 0;
   if (nlast == 0) return CMS_OK;

@@ -264,7 +264,11 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __
   if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) {
     // round counter of the group, mirrored into pinned host memory AFTER this window's state: the host driver paces its launches on
     // it without ever synchronising the stream (see ba_optimize_stage_batched_dev); bumped first, the host saw the round end before
-    // the windows' "finished" flags and queued idle rounds (5 per window group and call instead of 2)
+    // the windows' "finished" flags and queued idle rounds (5 per window group and call instead of 2).  The mirror is fine-grained
+    // coherent host memory (uncached on the device, hipHostMallocCoherent): stores of one thread arrive in order, no fence -- a
+    // system-scope release would write back this XCD's whole L2, the 19 us the pacing scheme exists to avoid.  The other windows'
+    // blocks are not ordered against this counter; the host only uses the mirrored state to decide whether to queue another round
+    // (an early counter costs at most one idle round) and reads the final state after synchronising the stream.
     BaLmDev* L0 = items[0].lm;
     const int r = L0->rounds + 1;
     L0->rounds = r;

@@ -150,22 +150,21 @@ extern "C" __global__ void __launch_bounds__(1024) k_search_local(CmsSearchLocal
       }
     }
     __syncthreads();
-    // which of my points are the lowest claimant of every free candidate they have?  (decided before anybody writes a claim)
-    unsigned ready = 0;
-    int open = 0, slot = 0;
-    for (int i = m0 + tid; i < m1; i += nt, ++slot) {
+    // which of my points are the lowest claimant of every free candidate they have?  (decided before anybody writes a claim; a ready
+    // point is marked -3 in its own mp_match entry -- only its owner thread reads that entry -- so a thread may own any number of points)
+    int open = 0;
+    for (int i = m0 + tid; i < m1; i += nt) {
       if (a.mp_match[i] != -2) continue;
       bool ok = true;
       for (int c = a.cand_off[i]; c < a.cand_off[i + 1] && ok; ++c) {
         const int row = a.cand_idx[c];
         ok = a.kp_mp[row] >= 0 || min_open[row - row0] == i;
       }
-      if (ok && slot < 32) ready |= 1u << slot; else ++open;
+      if (ok) a.mp_match[i] = -3; else ++open;
     }
     __syncthreads();
-    slot = 0;
-    for (int i = m0 + tid; i < m1; i += nt, ++slot) {
-      if (slot >= 32 || !((ready >> slot) & 1u)) continue;
+    for (int i = m0 + tid; i < m1; i += nt) {
+      if (a.mp_match[i] != -3) continue;
       // the reference's scan (ORBMatcher.cpp:84-113) over the candidates in GetFeaturesInArea's order
       int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestRow = -1;
       for (int c = a.cand_off[i]; c < a.cand_off[i + 1]; ++c) {

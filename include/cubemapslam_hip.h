@@ -131,9 +131,9 @@ int cms_hamming_matrix(cms_ctx* ctx, const uint8_t* a, int na, const uint8_t* b,
  *      cms_ba_optimize runs optimize(its_robust) with Huber(sqrt(5.991)) -> chi2/depth classification ->
  *      optimize(its_final) on the inliers without kernel -> final classification (outlier_flags[e] = 1 to erase);
  *      *stop is polled between iterations like g2o's forceStopFlag (Optimizer.cpp:256-257): before anything is launched, then
- *      before every Levenberg trial the host enqueues.  Windows advanced as a group (optimize_many) keep up to two trials queued
- *      on the device, so a request raised mid-way takes effect at most two trials later; the estimate left behind is the last
- *      accepted one, as with g2o. */
+ *      before every Levenberg trial the host enqueues.  With a stop pointer the grouped driver (optimize_many) queues a trial only
+ *      after the previous one has finished, so a request raised mid-way takes effect at the next trial boundary -- where g2o's
+ *      terminate() polls -- and the estimate left behind is the last accepted one, as with g2o. */
 typedef struct cms_ba cms_ba;
 typedef struct {
   int iterations_done[2];
@@ -202,8 +202,8 @@ int cms_features_in_area_batch_device(cms_ctx* ctx, int nq, const void* d_qframe
  * cms_is_in_frustum_device also writes the window of every point (qr < 0: not in view) for cms_features_in_area_batch_device;
  * cms_search_local_points_device takes that CSR (indices = batch rows), mp_off[B+1] (map points grouped by frame, list order
  * inside a frame), scratch pair_dist (2 bytes per candidate) and kp_mp over all batch rows; mp_match = batch row or -1.
- * Limits: at most 32768 map points per frame and 4096 key points per frame (CMS_ERR_UNSUPPORTED from the host entries; the device
- * entries trust mp_off). */
+ * Limit: at most 4096 key points per frame (CMS_ERR_UNSUPPORTED); any number of map points per frame (a thread of the greedy kernel
+ * takes every 1024th point of its frame). */
 int cms_area_set_descriptors(cms_ctx* ctx, int b, int n, const uint8_t* desc);
 /* ORBMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBMatcher.cpp:130-251), the matcher of
  * Tracking::TrackWithMotionModel, whole on the device: the last frame's map points are projected with the current pose (Rcw | tcw of

@@ -166,6 +166,12 @@ int  orc_ba_run(int K, double* poses, const uint8_t* fixed, int P, double* point
                 const int8_t* e_face, double fx, double fy, double cx, double cy,
                 int its_robust, int its_final, const volatile uint8_t* stop,
                 uint8_t* outlier_flags, orc_ba_stats* stats);
+/* test hook: the stop flag is raised while trial number stop_after_trials (1-based, over both stages) runs */
+int  orc_ba_run_stop_after(int K, double* poses, const uint8_t* fixed, int P, double* points,
+                int E, const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
+                const int8_t* e_face, double fx, double fy, double cx, double cy,
+                int its_robust, int its_final, int stop_after_trials,
+                uint8_t* outlier_flags, orc_ba_stats* stats);
 /* one residual + linearisation pass: per-edge error/chi2/Jacobians and the accumulated blocks.
  * Hpp: K x 36 (row major 6x6), bp: K x 6, Hll: P x 9, bl: P x 3, Hpl: E x 18 (6x3 row major per edge), robust=huber */
 void orc_ba_linearize(int K, const double* poses, const uint8_t* fixed, int P, const double* points,

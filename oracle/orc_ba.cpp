@@ -303,6 +303,12 @@ bool schur_solve(const Problem& pb, System& s, double lambda) {
   return true;
 }
 
+// Test hook for the stop flag (Optimizer.cpp:256-257 hands g2o a bool another thread sets; g2o polls it in terminate(), i.e. at every
+// trial boundary -- optimization_algorithm_levenberg.cpp:127 -- and at every iteration -- sparse_optimizer.cpp:376): a trial budget makes
+// "the flag was raised while trial number n was running" reproducible.  -1 = no budget.
+static thread_local int g_trial_budget = -1, g_trials = 0;
+static bool budget_spent() { return g_trial_budget >= 0 && g_trials >= g_trial_budget; }
+
 // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg + BlockSolver_6_3 (Schur)
 int optimize(Problem& pb, int iterations, const volatile uint8_t* stop, double* chi_ini, double* chi_fin, double* lam_fin) {
   System s;
@@ -318,7 +324,7 @@ int optimize(Problem& pb, int iterations, const volatile uint8_t* stop, double* 
   s.Hpl.resize((size_t)18 * s.act.size()); s.x.resize((size_t)6 * s.np + 3 * s.nl);
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
-  auto stopped = [&]() { return stop && *stop; };
+  auto stopped = [&]() { return (stop && *stop) || budget_spent(); };
   for (int it = 0; it < iterations && !stopped(); ++it) {
     compute_active_errors(pb, s);
     double currentChi = active_robust_chi2(pb, s);
@@ -361,6 +367,7 @@ int optimize(Problem& pb, int iterations, const volatile uint8_t* stop, double* 
         pb.poses = poses_bak; pb.pts = pts_bak;  // pop(); edge errors stay those of the rejected trial, as in g2o
       }
       ++qmax;
+      ++g_trials;
     } while (rho < 0 && qmax < 10 && !stopped());
     ++done;
     *chi_fin = currentChi; *lam_fin = lambda;
@@ -418,7 +425,7 @@ int orc_ba_run(int K, double* poses, const uint8_t* fixed, int P, double* points
     map_point(pb.poses[pb.e_pose[e]], &pb.pts[3 * pb.e_point[e]], Xc);
     return c2 > 5.991 || !(Xc[2] > 0.0);
   };
-  if (!(stop && *stop)) {  // Optimizer.cpp:366-397
+  if (!(stop && *stop) && !budget_spent()) {  // Optimizer.cpp:366-397
     for (int e = 0; e < E; ++e) if (is_outlier(e)) { pb.level[e] = 1; ++st->n_outliers_mid; }
     pb.robust = false;
     st->iterations_done[1] = optimize(pb, its_final, stop, &st->chi2_initial[1], &st->chi2_final[1], &st->lambda_final[1]);
@@ -431,6 +438,19 @@ int orc_ba_run(int K, double* poses, const uint8_t* fixed, int P, double* points
   }
   memcpy(points, pb.pts.data(), sizeof(double) * 3 * (size_t)P);
   return 0;
+}
+
+// orc_ba_run with the stop flag raised by "another thread" while trial number stop_after_trials (counted over both stages, from 1) was
+// running: that trial completes, then every terminate() poll sees the flag.
+int orc_ba_run_stop_after(int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,
+                          const int* e_point, const double* e_obs, const double* e_invsig2, const int8_t* e_face, double fx,
+                          double fy, double cx, double cy, int its_robust, int its_final, int stop_after_trials,
+                          uint8_t* outlier_flags, orc_ba_stats* st) {
+  g_trial_budget = stop_after_trials; g_trials = 0;
+  const int rc = orc_ba_run(K, poses, fixed, P, points, E, e_pose, e_point, e_obs, e_invsig2, e_face, fx, fy, cx, cy, its_robust, its_final,
+                            nullptr, outlier_flags, st);
+  g_trial_budget = -1; g_trials = 0;
+  return rc;
 }
 
 // ---- Optimizer::PoseOptimization (src/Optimizer.cpp:48-190): one free SE3 vertex, N unary multi-pinhole edges

@@ -241,6 +241,21 @@ def ba_run(prob, its=(5, 10), stop=None):
     return dict(rc=rc, poses=poses, points=pts, outliers=flags, stats=st)
 
 
+def ba_run_stop_after(prob, stop_after_trials, its=(5, 10)):
+    """ba_run with the stop flag raised while trial number `stop_after_trials` (1-based, counted over both stages) is running"""
+    poses = np.array(prob["poses"], np.float64, copy=True)
+    pts = np.array(prob["points"], np.float64, copy=True)
+    E = len(prob["e_pose"])
+    flags = np.zeros(E, np.uint8)
+    st = BaStats()
+    f = lib().orc_ba_run_stop_after
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 4 + [C.c_int] * 3 + [C.c_void_p] * 2
+    rc = f(len(poses), _p(poses), _p(prob["fixed"]), len(pts), _p(pts), E, _p(prob["e_pose"]), _p(prob["e_point"]), _p(prob["e_obs"]),
+           _p(prob["e_invsig2"]), _p(prob["e_face"]), prob["fx"], prob["fy"], prob["cx"], prob["cy"], its[0], its[1], int(stop_after_trials),
+           _p(flags), C.byref(st))
+    return dict(rc=rc, poses=poses, points=pts, outliers=flags, stats=st)
+
+
 class PoseStats(C.Structure):
     _fields_ = [("rounds", C.c_int), ("n_bad", C.c_int), ("iterations_done", C.c_int * 4), ("chi2_final", C.c_double * 4)]
 
