@@ -1,35 +1,49 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/sec of the CubemapSLAM hot path (remap + ORB extract + Hamming match + local BA) on MI355X.
+"""bench.py -- frames/sec of the CubemapSLAM hot path (remap + ORB extract + matching + pose optimisation + local BA) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json: "frames/sec (extract+match+localBA) on Lafida cam0", configs[2] geometry): synthetic Lafida cam0
-stream, 754x480 fisheye, cube face F=550 (1650^2 cross), nFeatures 2000 / 8 levels / 1.2 / FAST 20-7.
-One step = one batch of B frames (default 256 = 32 camera streams x 8 consecutive frames, cf. BASELINE.json configs[4]), inputs
-resident in HBM:
-    remap -> pyramid -> FAST cells -> octree -> cull -> orientation + rBRIEF     (ORBextractor::operator(), all B frames per launch)
-    Frame::AssignFeaturesToGrid + GetFeaturesInArea windows + Hamming best/second-best of every key point of frame b-1 in
-        frame b (ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th=15)), all on the device, every step
+N > 1: bench.py starts its N ranks itself (one process per GPU through torch.distributed.run, rendezvous on 127.0.0.1) unless it
+already runs under a launcher (RANK / WORLD_SIZE in the environment, e.g. the driver's own torch.distributed.run line); it fails if
+the world it ends up in is not --gpus.
+
+Workloads
+  default (BASELINE.json metric, configs[2] geometry): synthetic Lafida cam0 streams, 754x480 fisheye, cube face F = 550 (1650^2
+      cross), nFeatures 2000 / 8 levels / 1.2 / FAST 20-7.  Per GPU 32 camera streams x 8 consecutive frames = 256 frames per step.
+      Weak scaling: every rank owns its own 32 streams.
+  --camera front (configs[4]): 8 independent front_cam streams (1280x720, F = 650, nFeatures 3000), stream s -> GPU s mod G,
+      --frames-per-stream consecutive frames per step.  Strong scaling: the 8 streams are split over the ranks.
+
+One step = one batch of frames through, all on the device:
+    remap -> pyramid -> FAST cells -> octree -> cull -> orientation + rBRIEF     (ORBextractor::operator(), all frames per launch)
+    Frame::AssignFeaturesToGrid; TrackWithMotionModel's SearchByProjection(Cur, Last, th = 15): projection, GetFeaturesInArea windows,
+        greedy Hamming match, rotation histogram; TrackLocalMap's SearchLocalPoints (isInFrustum + windows + greedy match)
     Optimizer::PoseOptimization of every frame (one launch for the batch, own stream)
-    one local BA window (K=20 key frames, ~80k cubemap edges, BASELINE.json configs[3]) per `--ba-every` frames, on its own
-        stream / host thread like the reference's LocalMapping thread.
-Weak scaling over GPUs: every rank runs its own stream(s); the only exchange is an RCCL gather of the per-frame trajectory
-records [ts, t(3), q(4)] (System.cpp:261-262 order) to rank 0.
+    per `--ba-every` frames one key frame on the mapping side: LocalMapping::CreateNewMapPoints against 20 neighbours, then one local
+        BA window (K = 20 key frames, ~80k cubemap edges, BASELINE.json configs[3]); EVERY window of a step is a different problem
+        (own seed), the windows advance in lock-step groups on their own streams / host threads (the reference's LocalMapping thread).
+Two frame batches (different streams) alternate from step to step, so no step replays the previous step's inputs.
 
-Prints ONE JSON line (rank 0) incl. `roofline` for the dominant kernel (HIP-event timing on the library's stream) and
-`cpu_baseline` (the CPU oracle timed on this box's host cores, single thread, on a bounded sample of the same workload).
+`value` is measured with both batches resident in HBM (a device-to-device copy into the staging buffer opens the step).  A second
+timed pass streams the same batches from pinned host memory (cms_frames_upload_async: the copy of step s + 1 overlaps step s) and
+is reported as `config.with_input_streaming`.
+
+After the timed passes, outside any timed region: the local-BA results of a sample of windows are compared with the CPU oracle
+(iterations of both stages, outlier flags, updates), the CPU baseline is taken (rank 0, N = 1 only) and ONE JSON line is printed
+(rank 0) with `roofline` (dominant kernel of the step, HIP-event timing inside the timed region) and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
 
-# The frame path and every local-BA window run on their own HIP stream; the ROCm runtime multiplexes streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4), which serialises the BA windows behind each other.  Must be set before the
+# The frame path and every local-BA window group run on their own HIP stream; the ROCm runtime multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), which serialises the BA groups behind each other.  Must be set before the
 # HIP runtime initialises (measured: 4 -> 8 queues = +28 % frames/s with 4 concurrent windows).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -38,40 +52,195 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def make_frames(camd, B, seed):
-    """B consecutive frames of one synthetic stream: a large seeded texture drifting 3 px / frame under the fisheye."""
-    from cubemapslam_amd import synth
-    Ih, Iw = camd["Ih"], camd["Iw"]
-    big = synth.texture(Ih + 4 * B + 8, Iw + 4 * B + 8, seed)
-    return np.stack([big[2 * b:2 * b + Ih, 3 * b:3 * b + Iw] for b in range(B)]).copy()
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (default: 32 streams x 8 consecutive frames)")
-    ap.add_argument("--face", type=int, default=550)
+    ap.add_argument("--camera", choices=("lafida", "front"), default="lafida", help="front = BASELINE.json configs[4]: 8 front_cam streams, 1280x720, F=650")
+    ap.add_argument("--face", type=int, default=0, help="cube face size (default 550 for lafida, 650 for front)")
+    ap.add_argument("--batch", type=int, default=256, help="lafida: frames per step per GPU (default 32 streams x 8 consecutive frames)")
+    ap.add_argument("--streams", type=int, default=8, help="front: camera streams in total (stream s -> GPU s mod G)")
+    ap.add_argument("--frames-per-stream", type=int, default=16, help="front: consecutive frames of every stream per step")
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
     ap.add_argument("--ba-groups", type=int, default=4, help="host threads / streams the local-BA windows of a step are split over")
     ap.add_argument("--pose-edges", type=int, default=600, help="matched map points per frame for the pose-only optimisation")
     ap.add_argument("--save-trajectory", default="", help="rank 0 writes the gathered trajectory of the last step here (TUM format)")
     ap.add_argument("--force-gather", action="store_true", help="run the trajectory gather code path even with one rank (self-test)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--no-streaming-pass", action="store_true", help="skip the second timed pass with inputs streamed from pinned host memory")
+    ap.add_argument("--verify-windows", type=int, default=3, help="local-BA windows checked against the CPU oracle after the timed region (rank 0)")
+    ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks, one per GPU (one process per GPU)."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["CMS_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launcher_selftest(args, rank, world, local_rank):
     import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank], dtype=torch.int64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        seen = sorted(int(g.item()) for g in got)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = [0]
+    print(json.dumps({"launcher_selftest": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus_arg": args.gpus,
+                      "ranks_seen": seen, "pid": os.getpid(), "spawned_by_bench": os.environ.get("CMS_BENCH_SPAWNED") == "1"}), flush=True)
+
+
+def make_stream_frames(camd, n, seed):
+    """n consecutive frames of one synthetic camera stream: a seeded texture drifting 3 px / frame under the fisheye."""
+    from cubemapslam_amd import synth
+    Ih, Iw = camd["Ih"], camd["Iw"]
+    big = synth.texture(Ih + 4 * n + 8, Iw + 4 * n + 8, seed)
+    return np.stack([big[2 * b:2 * b + Ih, 3 * b:3 * b + Iw] for b in range(n)])
+
+
+class TrackSet:
+    """Everything the tracking side of a step needs for ONE batch of frames, resident on the device: the frames (staging layout), and --
+    built from the key points this batch extracts to -- per frame a predicted pose with the ~1400 map points of its last frame
+    (TrackWithMotionModel) and its local map (~2150 points, TrackLocalMap)."""
+
+    def __init__(self, ctx, torch, dev, camd, F, stream_seeds, frames_per_stream, seed0):
+        from cubemapslam_amd import api, synth
+        self.ctx, self.torch = ctx, torch
+        g = ctx.geom
+        B = len(stream_seeds) * frames_per_stream
+        self.B = B
+        Ih, Iw, fs = camd["Ih"], camd["Iw"], g.fisheye_stride
+        self.pinned = api.PinnedArray((B, Ih, fs))          # host copy in the device staging layout (input streaming)
+        self.pinned.array[:] = 0
+        self.stream_of_frame = np.repeat(np.arange(len(stream_seeds)), frames_per_stream)
+        for si, sd in enumerate(stream_seeds):
+            self.pinned.array[si * frames_per_stream:(si + 1) * frames_per_stream, :, :Iw] = make_stream_frames(camd, frames_per_stream, sd)
+        self.d_frames = torch.from_numpy(self.pinned.array).to(dev)        # resident copy
+        ctx.upload_device(self.d_frames.data_ptr(), B)
+        ctx.process(B, True)
+        ctx.sync()
+        self.fetched = [ctx.fetch(b) for b in range(B)]
+        fetched = self.fetched
+        ctx.area_grid(B)
+        # ---- frame-to-frame matching (ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th = 15), Tracking::TrackWithMotionModel)
+        self.mm = mm = [synth.motion_model_problem(F, k["x"], k["y"], k["octave"], k["angle"], d, seed=seed0 + 5000 + b) for b, (k, d) in enumerate(fetched)]
+        mm_off = np.concatenate([[0], np.cumsum([len(p["valid"]) for p in mm])]).astype(np.int32)
+        self.nq = nq = int(mm_off[-1])
+        mcat = lambda key, dt: torch.from_numpy(np.concatenate([p[key] for p in mm]).astype(dt)).to(dev)
+        self.d_mm_pose = torch.from_numpy(np.stack([p["pose12"] for p in mm])).to(dev)
+        self.d_mm_frame = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), np.diff(mm_off))).to(dev)
+        self.d_mm_valid, self.d_mm_xw, self.d_mm_oct, self.d_mm_ang, self.d_mm_desc = (mcat("valid", np.uint8), mcat("Xw", np.float32), mcat("octave", np.int32),
+                                                                                      mcat("angle", np.float32), mcat("desc", np.uint8))
+        self.d_mm_q = [torch.zeros(nq, dtype=torch.float32, device=dev) for _ in range(3)] + [torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.d_cnt = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev); self.d_off = torch.zeros(nq + 1, dtype=torch.int32, device=dev)
+        self.d_tot = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_mm_match = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev); self.d_mm_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.d_mm_mpoff = torch.from_numpy(mm_off).to(dev)
+        self.mm_windows(torch.zeros(1, dtype=torch.int32, device=dev), 0)       # dry run: size the candidate buffer
+        ctx.sync()
+        self.n_pairs = int(self.d_tot.item())
+        self.cand_cap = self.n_pairs + 4096
+        self.d_idx = torch.zeros(self.cand_cap, dtype=torch.int32, device=dev); self.d_mm_pd = torch.zeros(self.cand_cap, dtype=torch.int16, device=dev)
+        # ---- track local map (Tracking::SearchLocalPoints): every frame has its own pose and local map
+        self.lm = lm = [synth.local_map_problem(F, k["x"], k["y"], k["octave"], d, seed=seed0 + 7000 + b) for b, (k, d) in enumerate(fetched)]
+        lm_off = np.concatenate([[0], np.cumsum([len(p["pos"]) for p in lm])]).astype(np.int32)
+        self.n_mp = n_mp = int(lm_off[-1])
+        lcat = lambda key, dt: torch.from_numpy(np.concatenate([p[key] for p in lm]).astype(dt)).to(dev)
+        self.d_lm_pose = torch.from_numpy(np.stack([p["pose15"] for p in lm])).to(dev)
+        self.d_lm_frame = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), np.diff(lm_off))).to(dev)
+        self.d_lm_in = [lcat("pos", np.float32), lcat("normal", np.float32), lcat("min_dist", np.float32), lcat("max_dist", np.float32)]
+        self.d_lm_desc = lcat("desc", np.uint8)
+        self.d_lm_vis = torch.zeros(n_mp, dtype=torch.uint8, device=dev)
+        self.d_lm_f = [torch.zeros(n_mp, dtype=torch.float32, device=dev) for _ in range(4)]          # proj_x, proj_y, view_cos, qr
+        self.d_lm_i = [torch.zeros(n_mp, dtype=torch.int32, device=dev) for _ in range(5)]            # level, qmin, qmax, cnt, match
+        self.d_lm_off = torch.zeros(n_mp + 1, dtype=torch.int32, device=dev); self.d_lm_tot = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_lm_mpoff = torch.from_numpy(lm_off).to(dev)
+        self.lm_windows(torch.zeros(1, dtype=torch.int32, device=dev), 0)       # dry run: size the candidate buffer
+        ctx.sync()
+        self.lm_pairs = int(self.d_lm_tot.item())
+        self.lm_cap = self.lm_pairs + 4096
+        self.d_lm_idx = torch.zeros(self.lm_cap, dtype=torch.int32, device=dev); self.d_lm_pd = torch.zeros(self.lm_cap, dtype=torch.int16, device=dev)
+        kp_cap = g.kp_cap
+        self.d_kpmp0 = torch.full((B * kp_cap,), -1, dtype=torch.int32, device=dev); self.d_kpmp = self.d_kpmp0.clone()
+
+    def mm_windows(self, d_idx_buf, cap):
+        c = self.ctx
+        c.project_last_frame_device(self.nq, self.d_mm_frame.data_ptr(), self.d_mm_pose.data_ptr(), self.d_mm_valid.data_ptr(), self.d_mm_xw.data_ptr(),
+                                    self.d_mm_oct.data_ptr(), 15.0, [t.data_ptr() for t in self.d_mm_q])
+        c.features_in_area_batch_device(self.nq, self.d_mm_frame.data_ptr(), [t.data_ptr() for t in self.d_mm_q], self.d_cnt.data_ptr(), self.d_off.data_ptr(),
+                                        d_idx_buf.data_ptr(), cap, self.d_tot.data_ptr())
+
+    def lm_windows(self, d_idx_buf, cap):
+        c = self.ctx
+        c.is_in_frustum_device(self.n_mp, self.d_lm_frame.data_ptr(), self.d_lm_pose.data_ptr(), *[t.data_ptr() for t in self.d_lm_in], 0.5, 1.0,
+                               [self.d_lm_vis.data_ptr(), self.d_lm_f[0].data_ptr(), self.d_lm_f[1].data_ptr(), self.d_lm_i[0].data_ptr(), self.d_lm_f[2].data_ptr()],
+                               [self.d_lm_f[3].data_ptr(), self.d_lm_i[1].data_ptr(), self.d_lm_i[2].data_ptr()])
+        c.features_in_area_batch_device(self.n_mp, self.d_lm_frame.data_ptr(), [self.d_lm_f[0].data_ptr(), self.d_lm_f[1].data_ptr(), self.d_lm_f[3].data_ptr(),
+                                                                                  self.d_lm_i[1].data_ptr(), self.d_lm_i[2].data_ptr()],
+                                        self.d_lm_i[3].data_ptr(), self.d_lm_off.data_ptr(), d_idx_buf.data_ptr(), cap, self.d_lm_tot.data_ptr())
+
+    def enqueue_tracking(self, ext_stream):
+        """everything after the extraction for this batch, on the ctx stream"""
+        c, B, torch = self.ctx, self.B, self.torch
+        c.area_grid(B)            # Frame::AssignFeaturesToGrid of the B frames
+        with torch.cuda.stream(ext_stream):
+            self.d_kpmp.copy_(self.d_kpmp0)
+        # TrackWithMotionModel's matcher: projection + windows + greedy best match (Hamming inside) + rotation histogram ...
+        self.mm_windows(self.d_idx, self.cand_cap)
+        c.search_local_points_device(B, self.d_mm_mpoff.data_ptr(), self.d_mm_desc.data_ptr(), self.d_off.data_ptr(), self.d_idx.data_ptr(), self.d_mm_pd.data_ptr(),
+                                     -1.0, 100, self.d_kpmp.data_ptr(), self.d_mm_match.data_ptr())
+        c.rotation_filter_device(B, self.d_mm_mpoff.data_ptr(), self.d_mm_ang.data_ptr(), self.d_kpmp.data_ptr(), self.d_mm_match.data_ptr(), self.d_mm_n.data_ptr(), True)
+        # ... then TrackLocalMap's search over the key points that are still free
+        self.lm_windows(self.d_lm_idx, self.lm_cap)
+        c.search_local_points_device(B, self.d_lm_mpoff.data_ptr(), self.d_lm_desc.data_ptr(), self.d_lm_off.data_ptr(), self.d_lm_idx.data_ptr(), self.d_lm_pd.data_ptr(),
+                                     0.8, 100, self.d_kpmp.data_ptr(), self.d_lm_i[4].data_ptr())
+
+
+def main():
+    args = parse_args()
+    maybe_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (RANK/WORLD_SIZE environment)" % (args.gpus, world))
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world, local_rank)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: RCCL sees %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
     from cubemapslam_amd import api, build, synth
     from cubemapslam_amd import dist as cdist
     if rank == 0:
@@ -79,101 +248,53 @@ def main():
     if world > 1:
         dist.barrier()
 
-    B, F = args.batch, args.face
-    camd = synth.camera("lafida", F)
+    # ---- workload
+    front = args.camera == "front"
+    F = args.face or (650 if front else 550)
+    camd = synth.camera(args.camera, F)
     nfeat = camd["nfeatures"]
+    if front:       # configs[4]: the streams are split over the ranks (strong scaling)
+        my_streams = cdist.streams_of_rank(args.streams, world, rank)
+        if not my_streams:
+            raise SystemExit("bench.py: rank %d owns no stream (%d streams on %d GPUs)" % (rank, args.streams, world))
+        fps = args.frames_per_stream
+        total_frames_per_step = args.streams * fps
+        scaling = "strong"
+    else:           # every rank has its own 32 streams (weak scaling)
+        fps = 8
+        n_str = max(1, args.batch // fps)
+        my_streams = [rank * n_str + s for s in range(n_str)]
+        total_frames_per_step = n_str * fps * world
+        scaling = "weak"
+    B = len(my_streams) * fps
+    dev = torch.device("cuda", local_rank)
     ctx = api.Context(camd, nfeatures=nfeat, max_batch=B, device=local_rank)
     mask = synth.cubemap_valid_mask(camd)
     ctx.set_mask(mask)
-    frames = make_frames(camd, B, seed=100 + rank)
-    ctx.upload(frames)          # inputs resident in HBM before the timed region
-    ctx.process(B, True)
-    ctx.sync()
-    fetched = [ctx.fetch(b) for b in range(B)]
-    kps = [f[0] for f in fetched]
     g = ctx.geom
-    kp_cap = g.kp_cap
-    scales = [g.scale[l] for l in range(g.nlevels)]
-    dev = torch.device("cuda", local_rank)
-    # ---- frame-to-frame matching (ORBMatcher::SearchByProjection(CurrentFrame, LastFrame, th = 15), Tracking::TrackWithMotionModel): per
-    # frame a predicted pose and the ~1400 map points its last frame holds; projection, windows, greedy best match and the rotation
-    # histogram run on the device every step (the key points the windows are answered from are the ones this step extracts)
-    ctx.area_grid(B)
-    mm = [synth.motion_model_problem(F, k["x"], k["y"], k["octave"], k["angle"], d, seed=5000 + 100 * rank + b) for b, (k, d) in enumerate(fetched)]
-    mm_off = np.concatenate([[0], np.cumsum([len(p["valid"]) for p in mm])]).astype(np.int32)
-    nq = int(mm_off[-1])
-    mcat = lambda key, dt: torch.from_numpy(np.concatenate([p[key] for p in mm]).astype(dt)).to(dev)
-    d_mm_pose = torch.from_numpy(np.stack([p["pose12"] for p in mm])).to(dev)
-    d_mm_frame = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), np.diff(mm_off))).to(dev)
-    d_mm_valid, d_mm_xw, d_mm_oct, d_mm_ang, d_mm_desc = mcat("valid", np.uint8), mcat("Xw", np.float32), mcat("octave", np.int32), mcat("angle", np.float32), mcat("desc", np.uint8)
-    d_mm_q = [torch.zeros(nq, dtype=torch.float32, device=dev) for _ in range(3)] + [torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(2)]
-    d_cnt = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev); d_off = torch.zeros(nq + 1, dtype=torch.int32, device=dev)
-    d_tot = torch.zeros(1, dtype=torch.int32, device=dev)
-    d_mm_match = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev); d_mm_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_mm_mpoff = torch.from_numpy(mm_off).to(dev)
-
-    def mm_windows(d_idx_buf, cap):
-        ctx.project_last_frame_device(nq, d_mm_frame.data_ptr(), d_mm_pose.data_ptr(), d_mm_valid.data_ptr(), d_mm_xw.data_ptr(), d_mm_oct.data_ptr(), 15.0,
-                                      [t.data_ptr() for t in d_mm_q])
-        ctx.features_in_area_batch_device(nq, d_mm_frame.data_ptr(), [t.data_ptr() for t in d_mm_q], d_cnt.data_ptr(), d_off.data_ptr(),
-                                          d_idx_buf.data_ptr(), cap, d_tot.data_ptr())
-
-    mm_windows(torch.zeros(1, dtype=torch.int32, device=dev), 0)       # dry run: size the candidate buffer
-    ctx.sync()
-    n_pairs = int(d_tot.item())
-    cand_cap = n_pairs + 4096
-    d_idx = torch.zeros(cand_cap, dtype=torch.int32, device=dev); d_mm_pd = torch.zeros(cand_cap, dtype=torch.int16, device=dev)
-
-    # ---- track local map (Tracking::SearchLocalPoints): every frame has its own pose and local map (~2000 points, about two thirds in
-    # view, a quarter competing for a key point); projection, windows and the greedy search run on the device every step
-    lm = [synth.local_map_problem(F, k["x"], k["y"], k["octave"], d, seed=7000 + 100 * rank + b) for b, (k, d) in enumerate(fetched)]
-    lm_off = np.concatenate([[0], np.cumsum([len(p["pos"]) for p in lm])]).astype(np.int32)
-    n_mp = int(lm_off[-1])
-    lcat = lambda key, dt: torch.from_numpy(np.concatenate([p[key] for p in lm]).astype(dt)).to(dev)
-    d_lm_pose = torch.from_numpy(np.stack([p["pose15"] for p in lm])).to(dev)
-    d_lm_frame = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), np.diff(lm_off))).to(dev)
-    d_lm_in = [lcat("pos", np.float32), lcat("normal", np.float32), lcat("min_dist", np.float32), lcat("max_dist", np.float32)]
-    d_lm_desc = lcat("desc", np.uint8)
-    d_lm_vis = torch.zeros(n_mp, dtype=torch.uint8, device=dev)
-    d_lm_f = [torch.zeros(n_mp, dtype=torch.float32, device=dev) for _ in range(4)]          # proj_x, proj_y, view_cos, qr
-    d_lm_i = [torch.zeros(n_mp, dtype=torch.int32, device=dev) for _ in range(5)]            # level, qmin, qmax, cnt, match
-    d_lm_off = torch.zeros(n_mp + 1, dtype=torch.int32, device=dev); d_lm_tot = torch.zeros(1, dtype=torch.int32, device=dev)
-    d_lm_mpoff = torch.from_numpy(lm_off).to(dev)
-    d_kpmp0 = torch.full((B * kp_cap,), -1, dtype=torch.int32, device=dev); d_kpmp = d_kpmp0.clone()
+    # two batches of frames (all streams at time t and at time t + fps): consecutive steps never see the same inputs
+    sets = [TrackSet(ctx, torch, dev, camd, F, [100 + 977 * j + s for s in my_streams], fps, seed0=100000 * j + 100 * rank) for j in range(2)]
     ext_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    kps = [f[0] for S in sets for f in S.fetched]
 
-    def lm_windows(d_idx_buf, cap):
-        ctx.is_in_frustum_device(n_mp, d_lm_frame.data_ptr(), d_lm_pose.data_ptr(), *[t.data_ptr() for t in d_lm_in], 0.5, 1.0,
-                                 [d_lm_vis.data_ptr(), d_lm_f[0].data_ptr(), d_lm_f[1].data_ptr(), d_lm_i[0].data_ptr(), d_lm_f[2].data_ptr()],
-                                 [d_lm_f[3].data_ptr(), d_lm_i[1].data_ptr(), d_lm_i[2].data_ptr()])
-        ctx.features_in_area_batch_device(n_mp, d_lm_frame.data_ptr(), [d_lm_f[0].data_ptr(), d_lm_f[1].data_ptr(), d_lm_f[3].data_ptr(),
-                                                                        d_lm_i[1].data_ptr(), d_lm_i[2].data_ptr()],
-                                          d_lm_i[3].data_ptr(), d_lm_off.data_ptr(), d_idx_buf.data_ptr(), cap, d_lm_tot.data_ptr())
-
-    lm_windows(torch.zeros(1, dtype=torch.int32, device=dev), 0)       # dry run: size the candidate buffer
-    ctx.sync()
-    lm_pairs = int(d_lm_tot.item())
-    lm_cap = lm_pairs + 4096
-    d_lm_idx = torch.zeros(lm_cap, dtype=torch.int32, device=dev); d_lm_pd = torch.zeros(lm_cap, dtype=torch.int16, device=dev)
-
+    # ---- mapping side: one key frame per `ba_every` frames = CreateNewMapPoints + one local-BA window, every window its own problem
     n_ba = max(1, B // args.ba_every)
-    prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + rank)
-    # the local-BA windows of this step are independent LM problems: one host thread (LocalMapping-like) drives them as a batch,
-    # concurrent with the frame path on its own stream
-    bas = [api.BundleAdjuster(prob, device=local_rank) for _ in range(n_ba)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as tp:
+        probs = list(tp.map(lambda w: synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + 1000 * rank + w), range(n_ba)))
+    bas = [api.BundleAdjuster(p, device=local_rank) for p in probs]
     # tracking's pose-only optimisation (Optimizer::PoseOptimization, once per frame here; the reference calls it 1-3 times):
     # one problem per frame, ~600 matched map points with 10 % mismatches, resident on the device, one launch per step
     pose_probs = [synth.pose_problem(N=args.pose_edges, F=F, seed=1000 * rank + b, outlier_frac=0.1) for b in range(B)]
     po = api.PoseOptimizer(B, sum(len(p["Xw"]) for p in pose_probs), device=local_rank)
     po.upload(pose_probs)
-    ba_err = []
 
-    ba_ms = [0.0, 0]
-
-    # the windows are split into `--ba-groups` groups, each advanced in lock-step by its own host thread on its own stream:
-    # while one group waits for a Levenberg step (single-workgroup solve kernel, host decision), the other keeps the chip busy
+    # the windows are split into `--ba-groups` groups, each advanced in lock-step by its own host thread on its own stream
     n_grp = max(1, min(args.ba_groups, n_ba))
-    groups = [bas[g::n_grp] for g in range(n_grp)]
+    groups = [bas[gi::n_grp] for gi in range(n_grp)]
+    group_ids = [list(range(n_ba))[gi::n_grp] for gi in range(n_grp)]
+    for grp in groups:
+        grp[0].profile_kernel(3)          # HIP events around kb_ba_schur_points of every round (the BA chain's largest kernel)
 
     # LocalMapping::CreateNewMapPoints in front of every window's BA: the window's key frame against its 20 best covisible neighbours
     # (~1650 features each, FeatureVectors of ~400 nodes), key frames resident on the device; one store + context (stream) per group
@@ -196,92 +317,132 @@ def main():
                 st.put(base + i, K)
             jobs_g.append((base, list(range(base + 1, base + tri_nn + 1))))
         tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g)
-    tri_new = [0]
 
-    def ba_worker(grp, gi):
+    def ba_worker(grp, gi, keep):
+        """one window group of one step; returns (elapsed ms, new map points, per-window stats)"""
         t_ba0 = time.perf_counter()
-        try:
-            res = tri_store[gi].create_new_map_points(tri_jobs[gi])
-            tri_new[0] = sum(len(r[0]) for r in res)
-            api.ba_optimize_many(grp, (5, 10))   # the group's windows share every launch (kb_ba_* kernels, one window per blockIdx.z)
+        res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+        _, stats = api.ba_optimize_many(grp, (5, 10))   # the group's windows share every launch (kb_ba_* kernels, one window per blockIdx.z)
+        if not keep:
             for ba in grp:                       # benchmark plumbing: put the initial estimate back for the next step (asynchronous; done
                 ba.reset()                       # here, where the chip is quiet, rather than in front of the next step's first kernel)
-        except Exception as e:  # surfaced after join
-            ba_err.append(e)
-        ba_ms[0] += 1e3 * (time.perf_counter() - t_ba0) / n_grp; ba_ms[1] += 1.0 / n_grp
-
-    last_traj = [None]
+        return 1e3 * (time.perf_counter() - t_ba0), sum(len(r[0]) for r in res), stats
 
     part = os.environ.get("CMS_BENCH_PART", "")      # developer knob: "ba" / "frames" times one half of the step alone (not a bench line)
-
-    from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=n_grp)       # one standing host thread per window group (LocalMapping-like)
+    last = {"traj": None, "ba_stats": None, "tri_new": 0}
+    acc = {"ba_ms": 0.0, "ba_n": 0}
 
-    def step(i):
-        ths = [pool.submit(ba_worker, grp, gi) for gi, grp in enumerate(groups)] if part != "frames" else []   # the groups' standing host threads
-        if part == "ba":
-            for th in ths:
-                th.result()
-            return
-        po.launch()                 # own stream, overlaps the frame path
-        ctx.process(B, True)
-        ctx.area_grid(B)            # Frame::AssignFeaturesToGrid of the B frames
-        with torch.cuda.stream(ext_stream):
-            d_kpmp.copy_(d_kpmp0)
-        # TrackWithMotionModel's matcher: projection + windows + greedy best match (Hamming inside) + rotation histogram ...
-        mm_windows(d_idx, cand_cap)
-        ctx.search_local_points_device(B, d_mm_mpoff.data_ptr(), d_mm_desc.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), d_mm_pd.data_ptr(),
-                                       -1.0, 100, d_kpmp.data_ptr(), d_mm_match.data_ptr())
-        ctx.rotation_filter_device(B, d_mm_mpoff.data_ptr(), d_mm_ang.data_ptr(), d_kpmp.data_ptr(), d_mm_match.data_ptr(), d_mm_n.data_ptr(), True)
-        # ... then TrackLocalMap's search over the key points that are still free
-        lm_windows(d_lm_idx, lm_cap)
-        ctx.search_local_points_device(B, d_lm_mpoff.data_ptr(), d_lm_desc.data_ptr(), d_lm_off.data_ptr(), d_lm_idx.data_ptr(), d_lm_pd.data_ptr(),
-                                       0.8, 100, d_kpmp.data_ptr(), d_lm_i[4].data_ptr())
-        ctx.sync()
-        _, frame_poses, _, _ = po.fetch()
-        for th in ths:
-            th.result()
-        if ba_err:
-            raise ba_err[0]
-        if world > 1 or args.force_gather:   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
-            rec = cdist.make_records(rank, i * B + np.arange(B), frame_poses)   # the frames' optimised poses, TUM order
-            traj = cdist.gather_trajectory(rec, device=dev, dst=0)
+    def step(i, streaming, keep=False):
+        S = sets[i % 2]
+        ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)] if part != "frames" else []
+        if part != "ba":
+            po.launch()                 # own stream, overlaps the frame path
+            if not streaming:
+                ctx.upload_device(S.d_frames.data_ptr(), B)        # inputs resident in HBM: staging <- device copy
+            ctx.process(B, True)        # (streaming: waits on the device for the copy enqueued during the previous step)
+            if streaming:
+                ctx.upload_async(sets[(i + 1) % 2].pinned.array)   # next step's frames travel under this step's kernels
+            S.enqueue_tracking(ext_stream)
+            ctx.sync()
+            _, frame_poses, _, _ = po.fetch()
+        res = [th.result() for th in ths]     # raises what a worker raised
+        if res:
+            acc["ba_ms"] += sum(r[0] for r in res) / len(res); acc["ba_n"] += 1
+            last["tri_new"] = sum(r[1] for r in res)
+            last["ba_stats"] = [r[2] for r in res]
+        if part != "ba" and (world > 1 or args.force_gather):   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
+            recs = [cdist.make_records(my_streams[s], i * fps + np.arange(fps), frame_poses[s * fps:(s + 1) * fps]) for s in range(len(my_streams))]
+            traj = cdist.gather_trajectory(np.concatenate(recs, 0), device=dev, dst=0)
             if traj is not None:
-                last_traj[0] = traj
+                last["traj"] = traj
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(streaming):
+        if streaming:
+            ctx.upload_async(sets[0].pinned.array)
+        for i in range(args.warmup):
+            step(i, streaming)
+        stage = {}
+        for grp in groups:
+            grp[0].profile_kernel(3)
+        barrier()
+        acc["ba_ms"], acc["ba_n"] = 0.0, 0
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, streaming)
+            for k, v in (ctx.profile_ms().items() if part != "ba" else ()):
+                stage[k] = stage.get(k, 0.0) + v
+        barrier()
+        dt = time.perf_counter() - t0
+        if streaming:
+            ctx.upload_wait()
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        for k in stage:
+            stage[k] /= max(args.steps, 1)
+        schur = [grp[0].profile_get() for grp in groups]
+        return dt, stage, acc["ba_ms"] / max(acc["ba_n"], 1), schur
+
     ctx.profile(True)
-    for i in range(args.warmup):
-        step(i)
-    stage_ms = {}
-    barrier()
-    ba_ms[0], ba_ms[1] = 0.0, 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        for k, v in (ctx.profile_ms().items() if part != "ba" else ()):
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
-    barrier()
-    dt = time.perf_counter() - t0
-    pool.shutdown()
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    for k in stage_ms:
-        stage_ms[k] /= max(args.steps, 1)
+    dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
     if part:
         if rank == 0:
-            print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms[0] / max(ba_ms[1], 1), 3), "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
+            print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms_per_step, 3), "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
+        pool.shutdown()
         return
+    streamed = None
+    if not args.no_streaming_pass:
+        dt_s, _, ba_ms_s, _ = timed(True)
+        streamed = {"value": round(total_frames_per_step * args.steps / dt_s, 2), "ms_per_step": round(1e3 * dt_s / args.steps, 3), "ba_ms_per_step": round(ba_ms_s, 3),
+                    "host_bytes_per_step": int(B * camd["Ih"] * g.fisheye_stride),
+                    "note": "same steps with every batch copied from pinned host memory (cms_frames_upload_async, overlapped with the previous step)"}
 
-    # ---- roofline of the dominant extraction kernel (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
+    # ---- outside the timed region: local-BA results of a sample of windows against the CPU oracle
+    ba_check = None
+    cpu_ba_ms = []
+    if args.verify_windows > 0:
+        step(args.warmup + args.steps, False, keep=True)          # one more step (all ranks: it holds the gather) whose window estimates are kept
+    if rank == 0 and args.verify_windows > 0:
+        import orc
+        stats_of = {}
+        for gi, ids in enumerate(group_ids):
+            for wi, w in enumerate(ids):
+                stats_of[w] = last["ba_stats"][gi][wi]
+        sample = sorted(set(np.linspace(0, n_ba - 1, min(args.verify_windows, n_ba)).astype(int).tolist()))
+        worst = 0.0
+        for w in sample:
+            t1 = time.perf_counter()
+            want = orc.ba_run(probs[w])
+            cpu_ba_ms.append(1e3 * (time.perf_counter() - t1))
+            poses, pts, flags = bas[w].read()
+            st, ws = stats_of[w], want["stats"]
+            if list(st.iterations_done) != list(ws.iterations_done) or st.n_outliers_final != ws.n_outliers_final or not np.array_equal(flags, want["outliers"]):
+                raise SystemExit("bench.py: local-BA window %d differs from the CPU oracle: iterations %s vs %s, outliers %d vs %d" %
+                                 (w, list(st.iterations_done), list(ws.iterations_done), st.n_outliers_final, ws.n_outliers_final))
+            for got, ref, ref0 in ((pts, want["points"], probs[w]["points"]), (poses[:, :3], want["poses"][:, :3], probs[w]["poses"][:, :3])):
+                nrm = np.linalg.norm(ref - ref0, axis=1)
+                err = np.linalg.norm(got - ref, axis=1)
+                floor = 0.01 * np.median(nrm[nrm > 0]) if np.any(nrm > 0) else 0.0
+                r = float((err / np.maximum(nrm, max(floor, 1e-300))).max())
+                worst = max(worst, r)
+                if r > 1e-4:
+                    raise SystemExit("bench.py: local-BA window %d: update differs from the CPU oracle by %.3g relative" % (w, r))
+        its = [tuple(s.iterations_done) for gs in last["ba_stats"] for s in gs]
+        ba_check = {"windows_checked_against_oracle": sample, "worst_relative_update_error": float("%.3g" % worst),
+                    "iterations_done_min_max": [list(min(its)), list(max(its))], "distinct_iteration_counts": len(set(its))}
+
+    if args.verify_windows > 0:
+        for ba in bas:
+            ba.reset()
+
+    # ---- rooflines (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
     sumP = sum(g.level_w[l] * g.level_h[l] for l in range(g.nlevels))
     P = [g.level_w[l] * g.level_h[l] for l in range(g.nlevels)]
     nkp = float(np.mean([len(k) for k in kps]))
@@ -291,36 +452,50 @@ def main():
         "fast": sumP,                                                                # every pyramid pixel read once
         "describe": nkp * (43 * 43 + 32 + 24),                                       # raw patch + descriptor + key-point record
     }
-    # dominant kernel of the extraction path = the one with the longest average launch (k_resize is 7 short launches)
-    nl = {"pyramid": g.nlevels - 1}
-    per_launch = {k: stage_ms.get(k, 0.0) / nl.get(k, 1) for k in ("remap", "pyramid", "fast", "describe")}
-    dom = max(per_launch, key=per_launch.get)
-    kname = {"remap": "k_remap", "pyramid": "k_resize", "fast": "k_fast_cells", "describe": "k_describe"}[dom]
     peak = 8000.0
-    launches = nl.get(dom, 1)
-    ach = alg[dom] * B / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms.get(dom, 0) > 0 else None
-    # measured HBM traffic of that kernel: committed rocprofv3 PMC pass (FETCH_SIZE and WRITE_SIZE collected in separate runs,
-    # tools/run_profiles.sh), valid for the batch size the passes were taken at (the default, F = 550)
-    traffic = None
-    pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pj) and F == 550 and json.load(open(pj)).get("frames_per_dispatch", 64) == B:
-        kk = json.load(open(pj))["kernels"].get(kname)
+    # measured HBM traffic / instruction mix of the kernels: committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    # separate runs, tools/run_profiles.sh), valid for the batch size and geometry they were taken at
+    def pmc(name, kname):
+        for rnd in ("r02", "r01"):
+            pj = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
+            if os.path.exists(pj):
+                J = json.load(open(pj))
+                if J.get("frames_per_dispatch", 64) == B and J.get("face", 550) == F and kname in J.get("kernels", {}):
+                    return J["kernels"][kname]
+        return None
+    def traffic_of(kname):
+        kk = pmc("pmc_hbm_traffic", kname)
         if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
             # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section) -> doubled; unit KB
-            traffic = int((2.0 * kk["FETCH_SIZE"]["per_dispatch"] + kk["WRITE_SIZE"]["per_dispatch"]) * 1024)
-    # vector-ALU issue time of the same kernel from the committed SQ-counter pass (VALU instructions x 4 cycles per wave64 instruction /
-    # (256 CUs x 4 SIMDs x 2.4 GHz)): how much of the launch is spent just issuing its vector instructions
-    valu_us = None
-    pm = os.path.join(ROOT, "profiles", "r01_pmc_instruction_mix.json")
-    if os.path.exists(pm) and F == 550 and json.load(open(pm)).get("frames_per_dispatch", 64) == B:
-        kk = json.load(open(pm))["kernels"].get(kname)
-        if kk:
-            valu_us = kk["valu_issue_bound_us"]
-    roof = {"kernel": kname, "bound": "hbm", "achieved": None if ach is None else round(ach, 1), "peak": peak, "unit": "GB/s",
-            "frac": None if ach is None else round(ach / peak, 4), "traffic": traffic,
-            "ms_per_launch": round(stage_ms.get(dom, 0.0) / launches, 4), "valu_issue_bound_ms": None if valu_us is None else round(valu_us / 1e3, 4), "algorithmic_bytes_per_launch": int(alg[dom] * B / launches),
-            "all_stages_GBps": {k: round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in alg if stage_ms.get(k, 0) > 0}}
-    fast_gbs = alg["fast"] * B / (stage_ms["fast"] * 1e-3) / 1e9 if stage_ms.get("fast", 0) > 0 else None
+            return int((2.0 * kk["FETCH_SIZE"]["per_dispatch"] + kk["WRITE_SIZE"]["per_dispatch"]) * 1024)
+        return None
+    fast_ms = stage_ms.get("fast", 0.0)
+    fast_gbs = alg["fast"] * B / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else None
+    mixk = pmc("pmc_instruction_mix", "k_fast_cells")
+    roof_fast = {"kernel": "k_fast_cells", "bound": "hbm", "achieved": None if fast_gbs is None else round(fast_gbs, 1), "peak": peak, "unit": "GB/s",
+                 "frac": None if fast_gbs is None else round(fast_gbs / peak, 4), "traffic": traffic_of("k_fast_cells"),
+                 "ms_per_launch": round(fast_ms, 4), "ms_per_step": round(fast_ms, 4),
+                 "valu_issue_bound_ms": None if not mixk else round(mixk["valu_issue_bound_us"] / 1e3, 4),
+                 "algorithmic_bytes_per_launch": int(alg["fast"] * B),
+                 "all_stages_GBps": {k: round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in alg if stage_ms.get(k, 0) > 0}}
+    # kb_ba_schur_points: one launch = one Levenberg trial of one window group; algorithmic bytes = every edge's 6x3 pose-point block
+    # (144 B) + every point's inverted 3x3 block and reduced right-hand side (96 B) once ("Schur ... reading Hpl once")
+    sch_ms = sum(p[0] for p in schur_prof); sch_n = sum(p[1] for p in schur_prof)
+    grp_bytes = [sum(b.E * 144 + b.P * 96 for b in grp) for grp in groups]
+    roof_ba = None
+    if sch_n > 0:
+        avg_ms = sch_ms / sch_n
+        byt = float(np.mean(grp_bytes))
+        gbs = byt / (avg_ms * 1e-3) / 1e9
+        roof_ba = {"kernel": "kb_ba_schur_points", "bound": "hbm", "achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "frac": round(gbs / peak, 4),
+                   "traffic": traffic_of("kb_ba_schur_points"), "ms_per_launch": round(avg_ms, 4), "launches_per_step": round(sch_n / args.steps, 1),
+                   "ms_per_step": round(sch_ms / args.steps, 4), "algorithmic_bytes_per_launch": int(byt),
+                   "note": "HIP events on each window group's stream; the groups' launches overlap each other and the frame path, so ms_per_step is summed kernel time"}
+    # `roofline` = the kernel with the most time per step; the other one is reported next to it
+    if roof_ba and roof_ba["ms_per_step"] > roof_fast["ms_per_step"]:
+        roof, roof_other = roof_ba, roof_fast
+    else:
+        roof, roof_other = roof_fast, roof_ba
     # whole ORBextractor::operator() against SURVEY.md 8(d)'s compulsory traffic at the reference's stage granularity
     # (B_pyr + B_fast + B_blur + B_kp; the full-level blur pass is counted although the product never runs it)
     b_extract = (2 * P[0] + sum(P[l - 1] + P[l] for l in range(1, g.nlevels))) + sumP + 2 * sumP + nkp * (709 + 961 + 32 + 28)
@@ -335,61 +510,61 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         import orc
+        S0 = sets[0]
+        frames0 = S0.pinned.array[:, :, :camd["Iw"]]
         ocam = orc.make_camera(camd)
         m1, m2 = orc.build_lut(ocam)
         o = orc.Orb(nfeatures=nfeat)
         n = min(args.cpu_frames, B)
         t1 = time.perf_counter()
-        descs, cpu_kps = [], []
         for b in range(n):
-            cube = orc.fisheye_to_cubemap(ocam, m1, m2, frames[b])
-            k, d = o.extract(ocam, cube, mask)
-            descs.append(d); cpu_kps.append(k)
+            cube = orc.fisheye_to_cubemap(ocam, m1, m2, np.ascontiguousarray(frames0[b]))
+            o.extract(ocam, cube, mask)
         t_ext = time.perf_counter() - t1
         # TrackWithMotionModel's SearchByProjection, then TrackLocalMap's SearchLocalPoints on what is left, per frame like the GPU leg
         t1 = time.perf_counter()
         kp_after = []
         for b in range(n):
-            kb, db = fetched[b]
+            kb, db = S0.fetched[b]
+            m = S0.mm[b]
             kpm = np.full(len(kb), -1, np.int32)
-            orc.search_by_projection_frames(ocam, mm[b]["pose12"][:9], mm[b]["pose12"][9:], kb["x"], kb["y"], kb["octave"], kb["angle"], db, mm[b]["scale_factors"],
-                                            mm[b]["valid"], mm[b]["Xw"], mm[b]["octave"], mm[b]["angle"], mm[b]["desc"], kpm, th=15.0, check_ori=True)
+            orc.search_by_projection_frames(ocam, m["pose12"][:9], m["pose12"][9:], kb["x"], kb["y"], kb["octave"], kb["angle"], db, m["scale_factors"],
+                                            m["valid"], m["Xw"], m["octave"], m["angle"], m["desc"], kpm, th=15.0, check_ori=True)
             kp_after.append(kpm)
-        t_match = time.perf_counter() - t1
-        pairs = n
+        t_match = (time.perf_counter() - t1) / n
         t1 = time.perf_counter()
         for b in range(n):
-            kb, db = fetched[b]
-            fr = orc.is_in_frustum(ocam, lm[b]["pose15"], lm[b]["pos"], lm[b]["normal"], lm[b]["min_dist"], lm[b]["max_dist"])
-            orc.search_local_points(ocam, kb["x"], kb["y"], kb["octave"], db, lm[b]["scale_factors"], fr, lm[b]["desc"], kp_after[b])
+            kb, db = S0.fetched[b]
+            l = S0.lm[b]
+            fr = orc.is_in_frustum(ocam, l["pose15"], l["pos"], l["normal"], l["min_dist"], l["max_dist"])
+            orc.search_local_points(ocam, kb["x"], kb["y"], kb["octave"], db, l["scale_factors"], fr, l["desc"], kp_after[b])
         t_local = (time.perf_counter() - t1) / n
         t1 = time.perf_counter()
-        S0 = tri_sets[0]
-        oks = [orc.make_keyframe(ocam, k) for k in S0["kfs"]]
+        T0 = tri_sets[0]
+        oks = [orc.make_keyframe(ocam, k) for k in T0["kfs"]]
         for _ in range(2):
-            orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], S0["scale_factors"], S0["level_sigma2"], S0["kfs"][0]["mp"].copy())
+            orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], T0["scale_factors"], T0["level_sigma2"], T0["kfs"][0]["mp"].copy())
         t_tri = (time.perf_counter() - t1) / 2
-        t1 = time.perf_counter()
-        n_cpu_ba = 3
-        for _ in range(n_cpu_ba):
-            orc.ba_run(prob)
-        t_ba = (time.perf_counter() - t1) / n_cpu_ba
+        while len(cpu_ba_ms) < 3:            # the verification above already timed the oracle on its sample of windows
+            t1 = time.perf_counter()
+            orc.ba_run(probs[len(cpu_ba_ms) % n_ba])
+            cpu_ba_ms.append(1e3 * (time.perf_counter() - t1))
+        t_ba = 1e-3 * float(np.mean(cpu_ba_ms))
         t1 = time.perf_counter()
         for b in range(min(n, 8)):
             orc.pose_optimize(pose_probs[b])
         t_pose = (time.perf_counter() - t1) / min(n, 8)
-        per_frame = t_ext / n + t_match / max(pairs, 1e-9) + t_local + t_pose + (t_ba + t_tri) / args.ba_every
+        per_frame = t_ext / n + t_match + t_local + t_pose + (t_ba + t_tri) / args.ba_every
         cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "%d frames remap+extract (%.1f ms/frame), frame-to-frame SearchByProjection over %.1f frames (%.2f ms/frame), local-map search "
+               "sample": "%d frames remap+extract (%.1f ms/frame), frame-to-frame SearchByProjection (%.2f ms/frame), local-map search "
                          "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), CreateNewMapPoints (%.1f ms per key frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
                          "oracle/liborc.so, single thread" %
-                         (n, 1e3 * t_ext / n, pairs, 1e3 * t_match / max(pairs, 1e-9), 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, n_cpu_ba, 1e3 * t_ba,
-                          args.ba_every),
+                         (n, 1e3 * t_ext / n, 1e3 * t_match, 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, len(cpu_ba_ms), 1e3 * t_ba, args.ba_every),
                "host_cores_available": os.cpu_count()}
 
-    if rank == 0 and args.save_trajectory and last_traj[0] is not None:
+    if rank == 0 and args.save_trajectory and last["traj"] is not None:
         # rank 0's assembled trajectory of the last step in the reference's TUM format (System.cpp:238-268)
-        tr = last_traj[0]
+        tr = last["traj"]
         q = tr[:, 5:9]
         x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
         Tcw = np.zeros((len(tr), 4, 4), np.float32)
@@ -399,28 +574,32 @@ def main():
         Tcw[:, :3, 3] = tr[:, 2:5]; Tcw[:, 3, 3] = 1
         cdist.write_trajectory_tum(args.save_trajectory, tr[:, 1], Tcw)
     if rank == 0:
-        total_frames = B * args.steps * world
+        S0 = sets[0]
+        name = "front_cam (parkinglot_front) x %d streams" % args.streams if front else "Lafida cam0"
         out = {
-            "metric": "frames/sec (extract+match+localBA) on Lafida cam0",
-            "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "frames/sec (extract+match+localBA) on %s" % ("8 front_cam streams" if front else "Lafida cam0"),
+            "value": round(total_frames_per_step * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8 (extract/match), f64 (BA)", "data": "synthetic",
-            "config": {"workload": "Lafida cam0 synthetic stream, 754x480 fisheye, face=%d (%dx%d cross), nFeatures %d; per step %d frames: "
-                                   "remap+ORB extract, frame grids, frame-to-frame SearchByProjection (projection + GetFeaturesInArea windows + greedy Hamming match + rotation histogram: "
-                                   "%d map points, %d candidate pairs), "
-                                   "local-map search (isInFrustum + SearchByProjection, %d map points, %d candidate pairs), pose-only optimisation (%d edges/frame), "
-                                   "%d key frames x (CreateNewMapPoints against 20 neighbours + local BA window K=20, E=%d)"
-                                   % (F, 3 * F, 3 * F, nfeat, B, nq, n_pairs, n_mp, lm_pairs, args.pose_edges, n_ba, len(prob["e_pose"])),
-                       "frames_per_step_per_gpu": B, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
+            "config": {"workload": "%s synthetic streams, %dx%d fisheye, face=%d (%dx%d cross), nFeatures %d; per step and GPU %d frames (%d streams x %d consecutive frames; two "
+                                   "batches alternate): remap+ORB extract, frame grids, frame-to-frame SearchByProjection (projection + GetFeaturesInArea windows + greedy Hamming match + "
+                                   "rotation histogram: %d map points, %d candidate pairs), local-map search (isInFrustum + SearchByProjection, %d map points, %d candidate pairs), "
+                                   "pose-only optimisation (%d edges/frame), %d key frames x (CreateNewMapPoints against 20 neighbours + local BA window K=20, E~%d, every window a "
+                                   "different problem)"
+                                   % (name, camd["Iw"], camd["Ih"], F, 3 * F, 3 * F, nfeat, B, len(my_streams), fps, S0.nq, S0.n_pairs, S0.n_mp, S0.lm_pairs, args.pose_edges, n_ba,
+                                      int(np.mean([b.E for b in bas]))),
+                       "frames_per_step_per_gpu": B, "frames_per_step_total": total_frames_per_step, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
+                       "inputs": "resident in HBM (two batches, device-to-device copy into the staging buffer inside the step)",
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
                        "extractor_vs_survey_bytes": extractor,
-                       "ba_windows_per_step": n_ba, "ba_ms_per_step": round(ba_ms[0] / max(ba_ms[1], 1), 3)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "ba_windows_per_step": n_ba, "ba_groups": n_grp, "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
+                       "ba_check": ba_check, "with_input_streaming": streamed},
+            "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    pool.shutdown()
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -66,6 +66,14 @@ def lib():
         L.cms_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.cms_remap_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.cms_frames_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]
+        L.cms_frames_upload_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int]
+        L.cms_frames_upload_wait.argtypes = [C.c_void_p]
+        L.cms_frames_upload_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.cms_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        L.cms_host_free.argtypes = [C.c_void_p]
+        L.cms_host_free.restype = None
+        L.cms_ba_profile_kernel.argtypes = [C.c_void_p, C.c_int]
+        L.cms_ba_profile_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cms_frames_process.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cms_frames_sync.argtypes = [C.c_void_p]
         L.cms_frames_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -221,6 +229,19 @@ class Context:
         frames = np.ascontiguousarray(frames, np.uint8)
         assert frames.ndim == 3
         _chk(lib().cms_frames_upload(self.h, _p(frames), frames.strides[1], frames.strides[0], frames.shape[0]), "cms_frames_upload")
+
+    def upload_async(self, frames):
+        """input streaming: `frames` must live in pinned memory (host_alloc); the copy runs on the context's copy stream and the next
+        process() waits for it on the device"""
+        assert frames.ndim == 3 and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        _chk(lib().cms_frames_upload_async(self.h, _p(frames), frames.strides[1], frames.strides[0], frames.shape[0]), "cms_frames_upload_async")
+
+    def upload_device(self, d_ptr, B):
+        """staging <- device buffer [B][Ih][fisheye_stride] (inputs resident in HBM), asynchronous on the ctx stream"""
+        _chk(lib().cms_frames_upload_device(self.h, C.c_void_p(int(d_ptr)), B), "cms_frames_upload_device")
+
+    def upload_wait(self):
+        _chk(lib().cms_frames_upload_wait(self.h), "cms_frames_upload_wait")
 
     def process(self, B, from_fisheye=True):
         _chk(lib().cms_frames_process(self.h, B, 1 if from_fisheye else 0), "cms_frames_process")
@@ -392,6 +413,28 @@ class Context:
         return out
 
 
+class PinnedArray:
+    """uint8 numpy array over pinned host memory from cms_host_alloc (freed with the object)"""
+
+    def __init__(self, shape):
+        n = int(np.prod(shape))
+        self.p = C.c_void_p()
+        _chk(lib().cms_host_alloc(C.byref(self.p), n), "cms_host_alloc")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(self.p.value)).reshape(shape)
+
+    def close(self):
+        if self.p:
+            self.array = None
+            lib().cms_host_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Keyframe(C.Structure):
     """cms_keyframe (include/cubemapslam_hip.h)"""
     _fields_ = [("n", C.c_int), ("kps", C.c_void_p), ("desc", C.c_void_p), ("rays", C.c_void_p), ("mp", C.c_void_p),
@@ -536,6 +579,15 @@ class BundleAdjuster:
     @property
     def stream(self):
         return lib().cms_ba_stream(self.h)
+
+    def profile_kernel(self, kernel_id):
+        """HIP events around one kernel of the grouped driver's rounds (group owned by this handle); 3 = kb_ba_schur_points"""
+        _chk(lib().cms_ba_profile_kernel(self.h, kernel_id), "cms_ba_profile_kernel")
+
+    def profile_get(self):
+        ms = C.c_double(0); n = C.c_long(0)
+        _chk(lib().cms_ba_profile_get(self.h, C.byref(ms), C.byref(n)), "cms_ba_profile_get")
+        return ms.value, n.value
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -41,6 +41,9 @@ struct cms_ba {
   void* grp_items_dev = nullptr; void* grp_items_host = nullptr; double* grp_scal_dev = nullptr; double* grp_scal_host = nullptr;
   void* grp_lm_dev = nullptr; void* grp_lm_host = nullptr;   // BaLmDev per window (device-side Levenberg state) and its pinned mirror
   int grp_cap = 0;
+  // optional HIP-event bracket around ONE kernel of the grouped driver's rounds (bench.py's roofline of the dominant BA kernel):
+  // kernel ids 1 lin, 2 maxdiag, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points, 7 reduce2
+  int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   std::vector<void*> allocs;
 };
 
@@ -80,10 +83,21 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->grp_scal_host) hipHostFree(b->grp_scal_host);
   if (b->grp_lm_dev) hipFree(b->grp_lm_dev);
   if (b->grp_lm_host) hipHostFree(b->grp_lm_host);
+  for (hipEvent_t e : b->prof_ev) hipEventDestroy(e);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
 extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullptr; }
+extern "C" int cms_ba_profile_kernel(cms_ba* b, int kernel_id) {
+  if (!b || kernel_id < 0 || kernel_id > 7) return cms_fail(CMS_ERR_ARG, "cms_ba_profile_kernel: bad argument");
+  b->prof_kernel = kernel_id; b->prof_ms = 0; b->prof_launches = 0;
+  return CMS_OK;
+}
+extern "C" int cms_ba_profile_get(cms_ba* b, double* total_ms, long* launches) {
+  if (!b || !total_ms || !launches) return cms_fail(CMS_ERR_ARG, "cms_ba_profile_get: bad argument");
+  *total_ms = b->prof_ms; *launches = b->prof_launches;
+  return CMS_OK;
+}
 extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
   if (!b || !out8) return CMS_ERR_ARG;
   return hipMemcpy(out8, b->d_scal + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : CMS_ERR_HIP;

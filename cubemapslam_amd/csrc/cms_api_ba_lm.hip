@@ -317,6 +317,13 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // the flag is then honoured at the very next trial boundary).  It looks at the mirrored state and at the caller's stop flag before
   // every round it adds; the price is at most two rounds of idle launches after the last window finished.
   int k = 0;
+  const int pk = g->prof_kernel;
+  auto bracket = [&](int id, int which) {     // HIP events around the one kernel the caller asked to have timed (cms_ba_profile_kernel)
+    if (pk != id) return;
+    const size_t i = 2 * (size_t)k + which;
+    while (g->prof_ev.size() <= i) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return; g->prof_ev.push_back(e); }
+    hipEventRecord(g->prof_ev[i], s);
+  };
   auto enqueue_round = [&]() {
       if (first_round) {     // residuals of the stage's starting estimate: later iterations carry the accepted trial's over (every window starts at it == 0)
         hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
@@ -325,20 +332,34 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
       first_round = false;
       {
         const int npb = (max_P + 255) / 256;
+        bracket(1, 0);
         hipLaunchKernelGGL(kb_ba_lin, dim3(npb + max_K * BA_POSE_CHUNKS, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER, npb);
+        bracket(1, 1);
       }
+      bracket(2, 0);
       hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);      // + the pose slice sums (fold_finish)
+      bracket(2, 1);
       if (!all_sp)
         hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       if (all_sp) {
+        bracket(3, 0);
         hipLaunchKernelGGL(kb_ba_schur_points, dim3(max_R, 1, n), dim3(max_spt), sp_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        bracket(3, 1);
+        bracket(4, 0);
         hipLaunchKernelGGL(kb_ba_schur_reduce, dim3(max_pairs, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        bracket(4, 1);
       } else if (max_chunks > 0) {
         hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       }
+      bracket(5, 0);
       hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      bracket(5, 1);
+      bracket(6, 0);
       hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      bracket(6, 1);
+      bracket(7, 0);
       hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      bracket(7, 1);
       ++k;
   };
   const volatile BaLmDev* vh = reinterpret_cast<const volatile BaLmDev*>(hlm);
@@ -359,6 +380,11 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   HIPCHK(werr);
   HIPCHK(serr);
   HIPCHK(hipGetLastError());
+  if (pk > 0)
+    for (int r = 0; r < k && 2 * (size_t)r + 1 < g->prof_ev.size(); ++r) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, g->prof_ev[2 * r], g->prof_ev[2 * r + 1]) == hipSuccess) { g->prof_ms += ms; ++g->prof_launches; }
+    }
   for (int w = 0; w < n; ++w) {
     const BaLmDev& L = hlm[w];
     BaLm& t = st[w];

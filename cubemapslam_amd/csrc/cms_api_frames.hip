@@ -57,6 +57,9 @@ struct cms_ctx {
   uint16_t* d_area_sorted = nullptr; int* d_area_cell_start = nullptr; int* d_area_nvalid = nullptr; int area_frames = 0;
   int* d_area_bsum = nullptr; int area_bsum_cap = 0;
   uint8_t* h_fish_stage = nullptr; int fish_stage_frames = 0;   // pinned staging for cms_frames_upload
+  // input streaming (cms_frames_upload_async): the next batch travels on its own stream while the current one is being processed
+  hipStream_t copy_stream = nullptr; hipEvent_t ev_upload_done = nullptr, ev_remap_done = nullptr;
+  bool upload_pending = false, remap_recorded = false;
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;          // pinned staging of the one-frame host entries (one copy each way)
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
   // match scratch
@@ -158,6 +161,9 @@ static void cms_ctx_free(cms_ctx* c) {
   if (c->h_fish_stage) (void)hipHostFree(c->h_fish_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int i = 0; i < 8; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+  if (c->ev_upload_done) hipEventDestroy(c->ev_upload_done);
+  if (c->ev_remap_done) hipEventDestroy(c->ev_remap_done);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -385,6 +391,52 @@ extern "C" int cms_frames_upload(cms_ctx* c, const uint8_t* fisheye, int fstride
   return CMS_OK;
 }
 
+// Input streaming.  The fisheye staging buffer is read by exactly one kernel of a batch, k_remap (the first one), so one buffer is
+// enough for double buffering: the copy of batch s + 1 starts on the copy stream as soon as k_remap of batch s has finished and runs
+// under the pyramid / FAST / octree / descriptor kernels of batch s; cms_frames_process of batch s + 1 waits for it on the device.
+// The source must be pinned (cms_host_alloc, hipHostMalloc or hipHostRegister) and stay untouched until the next cms_frames_process
+// has been enqueued and cms_frames_sync returned, or until cms_frames_upload_wait.
+extern "C" int cms_frames_upload_async(cms_ctx* c, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B) {
+  if (!c || !fisheye || B < 1 || B > c->max_batch || fstride < c->cam.Iw) return cms_fail(CMS_ERR_ARG, "cms_frames_upload_async: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_upload_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_remap_done, hipEventDisableTiming));
+  }
+  if (c->remap_recorded) HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_remap_done, 0));   // write-after-read on the staging buffer
+  if (fstride == c->fstride && (frame_pitch == c->fish_pitch || B == 1)) {
+    HIPCHK(hipMemcpyAsync(c->d_fish, fisheye, c->fish_pitch * (size_t)B, hipMemcpyHostToDevice, c->copy_stream));   // caller uses the device layout
+  } else {
+    for (int b = 0; b < B; ++b)
+      HIPCHK(hipMemcpy2DAsync(c->d_fish + (size_t)b * c->fish_pitch, c->fstride, fisheye + (size_t)b * frame_pitch, fstride,
+                              c->cam.Iw, c->cam.Ih, hipMemcpyHostToDevice, c->copy_stream));
+  }
+  HIPCHK(hipEventRecord(c->ev_upload_done, c->copy_stream));
+  c->upload_pending = true;
+  return CMS_OK;
+}
+// device-to-device variant for inputs that are already resident in HBM (several batches kept on the device, one staging buffer):
+// d_src has the staging layout [B][Ih][fisheye_stride]; asynchronous on the ctx stream, in order with cms_frames_process
+extern "C" int cms_frames_upload_device(cms_ctx* c, const void* d_src, int B) {
+  if (!c || !d_src || B < 1 || B > c->max_batch) return cms_fail(CMS_ERR_ARG, "cms_frames_upload_device: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->d_fish, d_src, c->fish_pitch * (size_t)B, hipMemcpyDeviceToDevice, c->stream));
+  return CMS_OK;
+}
+extern "C" int cms_frames_upload_wait(cms_ctx* c) {
+  if (!c) return cms_fail(CMS_ERR_ARG, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->copy_stream) HIPCHK(hipStreamSynchronize(c->copy_stream));
+  return CMS_OK;
+}
+extern "C" int cms_host_alloc(void** out, size_t bytes) {
+  if (!out || bytes == 0) return cms_fail(CMS_ERR_ARG, "cms_host_alloc: bad argument");
+  HIPCHK(hipHostMalloc(out, bytes));
+  return CMS_OK;
+}
+extern "C" void cms_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int cms_set_mask(cms_ctx* c, const uint8_t* mask, int mstride) {
   if (!c || !mask || mstride < c->g.W) return cms_fail(CMS_ERR_ARG, "cms_set_mask: bad argument");
   HIPCHK(hipSetDevice(c->device));
@@ -406,9 +458,11 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   hipStream_t s = c->stream;
   if (c->prof) hipEventRecord(c->ev[0], s);
   if (from_fisheye) {
+    if (c->upload_pending) { HIPCHK(hipStreamWaitEvent(s, c->ev_upload_done, 0)); c->upload_pending = false; }   // streamed input (cms_frames_upload_async)
     dim3 grid((g.W / 4 + 255) / 256 + 1, g.W, std::min((B + CMS_REMAP_FPT - 1) / CMS_REMAP_FPT, CMS_REMAP_ZSPLIT));
     hipLaunchKernelGGL(k_remap, grid, dim3(256), 0, s, (const uint8_t*)c->d_fish, c->fish_pitch, c->fstride, c->cam.Iw,
                        c->cam.Ih, (const uint32_t*)c->d_lut, c->lut_stride, c->d_pyr, g.pyr_bytes, g.W, g.lv[0].stride, g.F, clean ? 0 : 1, B);
+    if (c->copy_stream) { HIPCHK(hipEventRecord(c->ev_remap_done, s)); c->remap_recorded = true; }   // the staging buffer is free from here on
   }
   if (c->prof) hipEventRecord(c->ev[1], s);
   for (int l = 1; l < L; ++l) {

@@ -88,9 +88,19 @@ int cms_remap_extract(cms_ctx* ctx, const uint8_t* fisheye, int fstride, cms_key
  *                        ctx stream (asynchronous).  from_fisheye = 0 skips the remap (level 0 was uploaded by cms_extract).
  * cms_frames_results() : device pointers of the outputs: kps [max_batch][kp_cap] cms_keypoint, desc [max_batch][kp_cap][32],
  *                        counts [max_batch] int.
+ * cms_frames_upload_async() : input streaming (the per-frame imread -> remap -> track loop of cubemap_lafida.cpp:128-154, batched): copies
+ *                        B fisheye frames from PINNED host memory (cms_host_alloc / hipHostMalloc / hipHostRegister) on the
+ *                        context's copy stream.  The staging buffer is only read by the first kernel of a batch (the remap), so the
+ *                        copy of batch s + 1 overlaps the rest of batch s; the next cms_frames_process waits for it on the device.
+ *                        The source must stay untouched until cms_frames_upload_wait() returns (or that process call was synced).
  */
 void* cms_frames_input(cms_ctx* ctx);
 int cms_frames_upload(cms_ctx* ctx, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B);
+int cms_frames_upload_async(cms_ctx* ctx, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B);
+int cms_frames_upload_wait(cms_ctx* ctx);
+int cms_frames_upload_device(cms_ctx* ctx, const void* d_src, int B);   /* device -> staging copy, [B][Ih][fisheye_stride], async on the ctx stream */
+int cms_host_alloc(void** out, size_t bytes);   /* pinned host memory for cms_frames_upload_async */
+void cms_host_free(void* p);
 int cms_frames_process(cms_ctx* ctx, int B, int from_fisheye);
 int cms_frames_sync(cms_ctx* ctx);
 int cms_frames_results(cms_ctx* ctx, void** d_kps, void** d_desc, void** d_counts);
@@ -152,6 +162,12 @@ int cms_ba_read(cms_ba* ba, double* poses, double* points, uint8_t* outlier_flag
 void* cms_ba_stream(cms_ba* ba);
 /* developer aid: 100 MHz wall-clock stamps of the last single-window solve kernel (start, assembled, factorised, solved, end) */
 int cms_ba_debug_clocks(cms_ba* ba, long long* out16);
+/* measurement aid (bench.py's roofline of the dominant BA kernel): HIP events on the group's stream around ONE kernel of every round the
+ * grouped driver enqueues for the group owned by `ba` (the first handle passed to cms_ba_optimize_many).  kernel_id: 0 off, 1 kb_ba_lin,
+ * 2 kb_ba_maxdiag, 3 kb_ba_schur_points, 4 kb_ba_schur_reduce, 5 kb_ba_trial_solve, 6 kb_ba_trial_points, 7 kb_ba_reduce2.
+ * cms_ba_profile_get returns the summed duration and the number of launches since cms_ba_profile_kernel was called. */
+int cms_ba_profile_kernel(cms_ba* ba, int kernel_id);
+int cms_ba_profile_get(cms_ba* ba, double* total_ms, long* launches);
 void cms_ba_destroy(cms_ba* ba);
 /* one-shot convenience: create + optimize + read + destroy */
 int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,

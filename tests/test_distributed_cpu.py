@@ -73,3 +73,26 @@ def test_partition_covers_all_streams():
     assert rec.shape == (2, 9) and np.all(rec[:, 0] == 3)
     one = cdist.gather_trajectory(rec)           # world size 1: local sort only
     assert one.shape == (2, 9)
+
+
+def test_bench_launcher_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (torch.distributed.run on 127.0.0.1), each with its own
+    RANK / LOCAL_RANK, all in one world of N; a world that is not --gpus is refused (the driver calls bench.py this way)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{") and "launcher_selftest" in l]
+    assert len(recs) == 2, out.stdout
+    assert sorted(r["rank"] for r in recs) == [0, 1] and sorted(r["local_rank"] for r in recs) == [0, 1]
+    assert all(r["world"] == 2 and r["gpus_arg"] == 2 and r["ranks_seen"] == [0, 1] and r["spawned_by_bench"] for r in recs)
+    assert len({r["pid"] for r in recs}) == 2
+    # under a launcher that started the wrong number of ranks the bench refuses to run
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
+    # N = 1: no launcher involved
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=120)
+    rec = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert one.returncode == 0 and rec["world"] == 1 and not rec["spawned_by_bench"]
