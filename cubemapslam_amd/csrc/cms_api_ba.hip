@@ -16,6 +16,8 @@ struct cms_ba {
   hipStream_t stream = nullptr;
   int K = 0, P = 0, E = 0, np = 0, nblk_e = 0, nblk_p = 0;
   std::vector<int> perm;       // sorted position -> caller's edge index
+  std::vector<int> pinv;       // internal point id -> caller's point index (points are permuted into collision-free chunks, see below)
+  std::vector<int> se_chunk_pt0;   // first internal point of every chunk of the edge-major Schur kernel
   BaDev d;
   // device memory
   uint8_t* d_fixed = nullptr; int* d_pose_slot = nullptr; int* d_e_pose = nullptr; int* d_e_point = nullptr;
@@ -35,6 +37,10 @@ struct cms_ba {
   int* d_sp_bat_e0 = nullptr; uint32_t* d_sp_off = nullptr; uint32_t* d_sp_list = nullptr; int* d_sp_slot_pair = nullptr; int* d_sp_tup_base = nullptr;
   int* d_sp_pair_slots = nullptr; double* d_sp_partial = nullptr; double* d_sp_sum = nullptr; int* d_sp_chunk_off = nullptr;
   int sp_threads = 0; size_t sp_lds = 0;
+  // edge-major Schur work list (se.R == 0: not available: too many free key frames for the LDS copy of the reduced system)
+  BaSe se = {};
+  int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
+  size_t se_lds = 0;
   int cur = 0;
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   // group resources (owned by the first window of a cms_ba_optimize_many call, grown on demand)
@@ -55,7 +61,7 @@ static int ba_lds_attrs_once(int device) {
   static bool done[64] = {false};
   std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || done[device]) return CMS_OK;
-  const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)k_ba_trial_solve,
+  const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)k_ba_trial_solve,
                        (const void*)kb_ba_trial_solve, (const void*)k_ba_solve_r192};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);
@@ -121,18 +127,38 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
 #define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
   BA_TRY(ba_lds_attrs_once(device));
   BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  // sort edges by (point, pose): CSR by point; per-pose edge lists reference sorted positions
+  // ---- chunks of the edge-major Schur kernel (cms_ba_schur_edges.hip): whole points, at most 64 edges, in the caller's point order.
+  // (Measured and dropped: permuting the points greedily so that no pose pair occurs twice in the same step of a chunk -- the chunks
+  // came out 99.7 % full and collision free, and the kernel was no faster: scattered f64 additions run at ~2.7 lanes per clock and CU
+  // whether or not lanes share an address now and then, tools/probe/lds_atomics.hip.  The internal point order stays the caller's;
+  // prank / pinv keep the translation in one place should that change.)
+  std::vector<int> prank(P), cp_off(P + 1, 0);
+  {
+    for (int e = 0; e < E; ++e) ++cp_off[e_point[e] + 1];
+    for (int p = 0; p < P; ++p) cp_off[p + 1] += cp_off[p];
+    b->pinv.resize(P);
+    b->se_chunk_pt0.assign(1, 0);
+    int cur_edges = 0;
+    for (int p = 0; p < P; ++p) {
+      prank[p] = p; b->pinv[p] = p;
+      const int k = cp_off[p + 1] - cp_off[p];
+      if (cur_edges + k > 64 && cur_edges > 0) { b->se_chunk_pt0.push_back(p); cur_edges = 0; }
+      cur_edges += k;
+    }
+    b->se_chunk_pt0.push_back(P);
+  }
+  // sort edges by (internal point, pose): CSR by point; per-pose edge lists reference sorted positions
   b->perm.resize(E);
   std::iota(b->perm.begin(), b->perm.end(), 0);
   std::stable_sort(b->perm.begin(), b->perm.end(), [&](int a, int c) {
-    return e_point[a] != e_point[c] ? e_point[a] < e_point[c] : e_pose[a] < e_pose[c];
+    return e_point[a] != e_point[c] ? prank[e_point[a]] < prank[e_point[c]] : e_pose[a] < e_pose[c];
   });
   std::vector<int> s_pose(E), s_point(E), pt_off(P + 1, 0), pose_off(K + 1, 0), pose_edges(E), pose_slot(K, -1);
   std::vector<double> s_obs(2 * (size_t)E), s_inv(E);
   std::vector<int8_t> s_face(E);
   for (int i = 0; i < E; ++i) {
     const int e = b->perm[i];
-    s_pose[i] = e_pose[e]; s_point[i] = e_point[e]; s_obs[2 * i] = e_obs[2 * e]; s_obs[2 * i + 1] = e_obs[2 * e + 1];
+    s_pose[i] = e_pose[e]; s_point[i] = prank[e_point[e]]; s_obs[2 * i] = e_obs[2 * e]; s_obs[2 * i + 1] = e_obs[2 * e + 1];
     s_inv[i] = e_invsig2[e]; s_face[i] = e_face[e];
     ++pt_off[s_point[i] + 1]; ++pose_off[s_pose[i] + 1];
   }
@@ -157,7 +183,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
   BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
-  BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(b->nblk_e, b->nblk_p) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 24));   // [8..16): developer clocks of k_ba_trial_solve
+  BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(std::max(b->nblk_e, b->nblk_p), (E + 63) / 64 + 8) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 24));   // [8..16): developer clocks of k_ba_trial_solve
   BA_TRY(ba_alloc(b, &b->d_flags, E));
   b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
   BA_HIP(hipHostMalloc((void**)&b->h_pin, 8 * sizeof(double)));
@@ -296,6 +322,65 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
         b->sp_lds = (size_t)BA_SP_MAXE * BA_SP_ROW * sizeof(double) + BA_SP_MAXT * 2 + (BA_SP_MAX_THREADS + 4) * 2;
       }
     }
+    // ---- work list of the edge-major Schur kernel (cms_ba_schur_edges.hip): chunks of whole points with <= 64 edges, one wavefront
+    // each; dense enumeration of the pose pairs s1 <= s2 and the matching tables for the solve kernel's assembly
+    if (np >= 1) {
+      const int NP2 = np * (np + 1) / 2;
+      const int nw = BA_SE_THREADS / 64;
+      const size_t lds = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)nw * 64 * 18 + (size_t)K * 12) * sizeof(double) +
+                         (size_t)nw * 64 * sizeof(int);
+      bool ok = lds <= BA_LDS_CEILING && K <= 256 && np <= 62;
+      std::vector<int> ce0;
+      std::vector<uint32_t> info(E);
+      for (size_t c = 0; c + 1 < b->se_chunk_pt0.size() && ok; ++c) {
+        const int p0 = b->se_chunk_pt0[c], p1 = b->se_chunk_pt0[c + 1];
+        if (p1 == p0) continue;
+        if (pt_off[p1] - pt_off[p0] > 64) { ok = false; break; }
+        ce0.push_back(pt_off[p0]);
+        int seen[256];
+        for (int k2 = 0; k2 < K; ++k2) seen[k2] = 0;
+        for (int p = p0; p < p1 && ok; ++p) {
+          const int ne = pt_off[p + 1] - pt_off[p];
+          if (ne > 31) { ok = false; break; }
+          for (int a1 = 0; a1 < ne; ++a1) {
+            const int e = pt_off[p] + a1;
+            if (a1 > 0 && s_pose[e] == s_pose[e - 1]) ok = false;       // a point seen twice by one key frame: the pair-owner kernel handles it
+            const int rank = seen[s_pose[e]]++ % BA_SE_DCOPIES;
+            info[e] = (uint32_t)a1 | ((uint32_t)ne << 5) | ((uint32_t)(pose_slot[s_pose[e]] + 1) << 10) | ((uint32_t)s_face[e] << 16) | ((uint32_t)s_pose[e] << 19) |
+                      ((uint32_t)rank << 27);
+          }
+        }
+      }
+      ce0.push_back(E);
+      if (ok) {
+        const int nchunks = (int)ce0.size() - 1;
+        const int cpw = std::max(1, (nchunks + BA_SE_RANGES - 1) / BA_SE_RANGES);
+        const int R = (nchunks + cpw - 1) / cpw;
+        std::vector<int> pob((size_t)NP2, 0), ident((size_t)NP2 + 1);
+        for (int I = 0; I < np; ++I)
+          for (int Kc = 0; Kc <= I; ++Kc) pob[(size_t)I * (I + 1) / 2 + Kc] = Kc * np - (Kc * (Kc - 1)) / 2 + (I - Kc);   // block (I, K): pair (s1 = K, s2 = I)
+        for (int i = 0; i <= NP2; ++i) ident[i] = i;
+        BA_TRY(ba_alloc(b, &b->d_se_chunk_e0, ce0.size())); BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)R * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_info, info.size()));
+        BA_HIP(hipMemcpy(b->d_se_info, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_pob, pob.size())); BA_TRY(ba_alloc(b, &b->d_se_chunk_off, ident.size()));
+        BA_HIP(hipMemcpy(b->d_se_chunk_e0, ce0.data(), ce0.size() * sizeof(int), hipMemcpyHostToDevice));
+        BA_HIP(hipMemcpy(b->d_se_pob, pob.data(), pob.size() * sizeof(int), hipMemcpyHostToDevice));
+        BA_HIP(hipMemcpy(b->d_se_chunk_off, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        {
+          std::vector<int> lone;                                             // points without observations are in no chunk
+          for (int p = 0; p < P; ++p) if (pt_off[p + 1] == pt_off[p]) lone.push_back(p);
+          int* d_lone = nullptr;
+          BA_TRY(ba_alloc(b, &d_lone, lone.size()));
+          if (!lone.empty()) BA_HIP(hipMemcpy(d_lone, lone.data(), lone.size() * sizeof(int), hipMemcpyHostToDevice));
+          b->se.lone = d_lone; b->se.nlone = (int)lone.size();
+          const int cpw_t = BA_TE_THREADS / 64;                              // one chunk per wavefront
+          b->se.cpw_t = cpw_t;
+          b->se.Rt = (nchunks + cpw_t - 1) / cpw_t;
+        }
+        b->se.R = R; b->se.nchunks = nchunks; b->se.cpw = cpw; b->se.npairs2 = NP2; b->se.chunk_e0 = b->d_se_chunk_e0; b->se.partial = b->d_se_partial; b->se.e_info = b->d_se_info;
+        b->se_lds = lds;
+      }
+    }
     std::vector<int> pcoff(1, 0);
     std::vector<int2> crange;
     for (size_t pr = 0; pr + 1 < poff.size(); ++pr) {
@@ -336,7 +421,11 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   UP(b->d_e_point, s_point.data(), E * sizeof(int)); UP(b->d_e_obs, s_obs.data(), 2 * (size_t)E * sizeof(double));
   UP(b->d_e_inv, s_inv.data(), E * sizeof(double)); UP(b->d_e_face, s_face.data(), E); UP(b->d_pt_off, pt_off.data(), (P + 1) * sizeof(int));
   UP(b->d_pose_off, pose_off.data(), (K + 1) * sizeof(int)); UP(b->d_pose_edges, pose_edges.data(), E * sizeof(int));
-  UP(b->d_poses0, p0.data(), 7 * (size_t)K * sizeof(double)); UP(b->d_pts0, points, 3 * (size_t)P * sizeof(double));
+  UP(b->d_poses0, p0.data(), 7 * (size_t)K * sizeof(double)); {
+    std::vector<double> pin(3 * (size_t)P);
+    for (int i = 0; i < P; ++i) for (int j = 0; j < 3; ++j) pin[3 * (size_t)i + j] = points[3 * (size_t)b->pinv[i] + j];
+    UP(b->d_pts0, pin.data(), 3 * (size_t)P * sizeof(double));
+  }
 #undef UP
   BaDev& d = b->d;
   d.K = K; d.P = P; d.E = E; d.np = np; d.fixed = b->d_fixed; d.pose_slot = b->d_pose_slot; d.e_pose = b->d_e_pose;
@@ -389,7 +478,11 @@ extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* ou
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   if (poses) HIPCHK(hipMemcpy(poses, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost));
-  if (points) HIPCHK(hipMemcpy(points, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost));
+  if (points) {
+    std::vector<double> pin(3 * (size_t)b->P);
+    HIPCHK(hipMemcpy(pin.data(), b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < b->P; ++i) for (int j = 0; j < 3; ++j) points[3 * (size_t)b->pinv[i] + j] = pin[3 * (size_t)i + j];
+  }
   if (outlier_flags) {
     std::vector<uint8_t> f(b->E);
     HIPCHK(hipMemcpy(f.data(), b->d_flags, b->E, hipMemcpyDeviceToHost));
@@ -438,8 +531,8 @@ extern "C" int cms_ba_linearize(int device, int K, const double* poses, const ui
   auto dl = [&](double* dptr, size_t cnt) { tmp.resize(cnt); hipMemcpy(tmp.data(), dptr, cnt * sizeof(double), hipMemcpyDeviceToHost); };
   if (err) { dl(b->d_err, 2 * (size_t)E); for (int i = 0; i < E; ++i) { err[2 * b->perm[i]] = tmp[2 * i]; err[2 * b->perm[i] + 1] = tmp[2 * i + 1]; } }
   if (Hpl) { dl(b->d_Hpl, 18 * (size_t)E); for (int i = 0; i < E; ++i) memcpy(Hpl + 18 * (size_t)b->perm[i], &tmp[18 * (size_t)i], 18 * sizeof(double)); }
-  if (Hll) { dl(b->d_Hll, 9 * (size_t)P); memcpy(Hll, tmp.data(), 9 * (size_t)P * sizeof(double)); }
-  if (bl) { dl(b->d_bl, 3 * (size_t)P); memcpy(bl, tmp.data(), 3 * (size_t)P * sizeof(double)); }
+  if (Hll) { dl(b->d_Hll, 9 * (size_t)P); for (int i = 0; i < P; ++i) memcpy(Hll + 9 * (size_t)b->pinv[i], &tmp[9 * (size_t)i], 9 * sizeof(double)); }
+  if (bl) { dl(b->d_bl, 3 * (size_t)P); for (int i = 0; i < P; ++i) memcpy(bl + 3 * (size_t)b->pinv[i], &tmp[3 * (size_t)i], 3 * sizeof(double)); }
   if (Hpp) { dl(b->d_Hpp, 36 * (size_t)std::max(b->np, 1)); memset(Hpp, 0, 36 * (size_t)K * sizeof(double)); for (int k = 0; k < K; ++k) if (slot[k] >= 0) memcpy(Hpp + 36 * (size_t)k, &tmp[36 * (size_t)slot[k]], 36 * sizeof(double)); }
   if (bp) { dl(b->d_bp, 6 * (size_t)std::max(b->np, 1)); memset(bp, 0, 6 * (size_t)K * sizeof(double)); for (int k = 0; k < K; ++k) if (slot[k] >= 0) memcpy(bp + 6 * (size_t)k, &tmp[6 * (size_t)slot[k]], 6 * sizeof(double)); }
   if (robust_chi2_sum) hipMemcpy(robust_chi2_sum, b->d_scal, sizeof(double), hipMemcpyDeviceToHost);

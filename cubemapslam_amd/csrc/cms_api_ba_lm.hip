@@ -189,10 +189,26 @@ static bool ba_all_sp(cms_ba** bas, int n) {
   for (int w = 0; w < n; ++w) if (bas[w]->sp.R <= 0) return false;
   return true;
 }
+// the edge-major Schur kernel (LDS accumulation, cms_ba_schur_edges.hip) runs when every window of the group has its work list and the
+// per-point path is available too (the two share the block-free linearisation); CMS_BA_DETERMINISTIC=1 keeps the pair-owner kernel
+static bool ba_use_se(cms_ba** bas, int n) {
+  static const bool det = getenv("CMS_BA_DETERMINISTIC") != nullptr || getenv("CMS_BA_HOST_LM") != nullptr;   // (the host-driven A/B driver only knows the pair-owner kernel)
+  if (det || !ba_all_sp(bas, n)) return false;
+  for (int w = 0; w < n; ++w) if (bas[w]->se.R <= 0) return false;
+  return true;
+}
+// ... and the edge-major trial kernel when, in addition, every point of every window has an observation
+static bool ba_use_te(cms_ba** bas, int n) {
+  static const bool off = getenv("CMS_BA_TRIAL_POINTS") != nullptr;
+  if (off || !ba_use_se(bas, n)) return false;
+  for (int w = 0; w < n; ++w) if (bas[w]->se.Rt <= 0) return false;
+  return true;
+}
 static int ba_upload_items(cms_ba** bas, int n) {
   cms_ba* g = bas[0];
   BaItem* items = reinterpret_cast<BaItem*>(g->grp_items_host);
   const bool all_sp = ba_all_sp(bas, n);
+  const bool use_se = ba_use_se(bas, n);
   for (int w = 0; w < n; ++w) {
     cms_ba* b = bas[w];
     BaItem& it = items[w];
@@ -208,6 +224,10 @@ static int ba_upload_items(cms_ba** bas, int n) {
     it.lm = reinterpret_cast<BaLmDev*>(g->grp_lm_dev) + w; it.hlm = reinterpret_cast<BaLmDev*>(g->grp_lm_host) + w;
     if (!all_sp) it.sp.R = 0;                       // one launch sequence for the whole group: per-point Schur only if every window has it
     if (all_sp) { it.chunk_sum = b->d_sp_sum; it.pair_chunk_off = b->d_sp_chunk_off; }
+    it.se = b->se;
+    if (!use_se) { it.se.R = 0; it.se.Rt = 0; }
+    if (use_se && !ba_use_te(bas, n)) it.se.Rt = 0;
+    if (use_se) { it.chunk_sum = b->d_se_sum; it.pair_chunk_off = b->d_se_chunk_off; it.pair_of_block = b->d_se_pob; }
   }
   HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
   return CMS_OK;
@@ -226,8 +246,12 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
     max_np = std::max(max_np, bas[w]->np); max_chunks = std::max(max_chunks, bas[w]->nchunks); max_P = std::max(max_P, bas[w]->P);
     lds = std::max(lds, bas[w]->blk_lds);
   }
-  int rc = ba_upload_items(bas, n);
-  if (rc) return rc;
+  int rc = CMS_OK;
+  {   // the classification after this stage counts outliers in the device-side state block: clear its slot
+    BaLmDev* hlm0 = reinterpret_cast<BaLmDev*>(g->grp_lm_host);
+    for (int w = 0; w < n; ++w) memset(&hlm0[w], 0, sizeof(BaLmDev));
+    hipLaunchKernelGGL(kb_ba_lm_load, dim3((n + 63) / 64), dim3(64), 0, s, ditems, n, st[0].robust ? 1 : 0);
+  }
   BaDyn dyn;
   memset(&dyn, 0, sizeof(dyn));
   dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0;
@@ -293,8 +317,6 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     lds = std::max(lds, bas[w]->blk_lds);
     max_it = std::max(max_it, st[w].iterations);
   }
-  int rc = ba_upload_items(bas, n);
-  if (rc) return rc;
   BaLmDev* hlm = reinterpret_cast<BaLmDev*>(g->grp_lm_host);
   for (int w = 0; w < n; ++w) {
     BaLmDev& L = hlm[w];
@@ -303,12 +325,20 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     L.cur = bas[w]->cur;
     L.next = (st[w].it >= st[w].iterations || ba_stopped(stop)) ? 2 : 0;
   }
-  HIPCHK(hipMemcpyAsync(g->grp_lm_dev, hlm, (size_t)n * sizeof(BaLmDev), hipMemcpyHostToDevice, s));
+  // the device copy is filled by a one-wave kernel reading the pinned block (a copy command in the stream costs ~20 us of queue time)
+  hipLaunchKernelGGL(kb_ba_lm_load, dim3((n + 63) / 64), dim3(64), 0, s, ditems, n, st[0].robust ? 1 : 0);
   BaDyn dyn;
   memset(&dyn, 0, sizeof(dyn));
   dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1; dyn.fold_finish = 1;
   bool first_round = false;
   for (int w = 0; w < n; ++w) first_round = first_round || st[w].it == 0;
+  const bool use_se = ba_use_se(bas, n);
+  const bool use_te = ba_use_te(bas, n);
+  int max_seR = 0, max_np2 = 0, max_Rt = 0; size_t se_lds = 0, te_lds = 0;
+  for (int w = 0; w < n; ++w) {
+    max_seR = std::max(max_seR, bas[w]->se.R); max_np2 = std::max(max_np2, bas[w]->se.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds);
+    max_Rt = std::max(max_Rt, bas[w]->se.Rt); te_lds = std::max(te_lds, ((size_t)24 * bas[w]->K + 6 * (size_t)std::max(bas[w]->np, 1)) * sizeof(double));
+  }
   // One "round" = the launches of one Levenberg trial (plus the linearisation in front of it for the windows that start an iteration).
   // The host never synchronises the stream inside a stage: a synchronisation -- or an event -- after a round makes the chip publish
   // its caches before the next kernel starts, 19 us of idle time per round, 0.4 ms per window group.  Instead the last kernel of a
@@ -318,6 +348,8 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // every round it adds; the price is at most two rounds of idle launches after the last window finished.
   int k = 0;
   const int pk = g->prof_kernel;
+  static const int dup = getenv("CMS_BA_DUP") ? atoi(getenv("CMS_BA_DUP")) : 0;   // developer knob: launch kernel <id> of every round twice (all of
+                                                                                 // 1 lin, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points are idempotent): how much does the step pay for it?
   auto bracket = [&](int id, int which) {     // HIP events around the one kernel the caller asked to have timed (cms_ba_profile_kernel)
     if (pk != id) return;
     const size_t i = 2 * (size_t)k + which;
@@ -334,6 +366,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         const int npb = (max_P + 255) / 256;
         bracket(1, 0);
         hipLaunchKernelGGL(kb_ba_lin, dim3(npb + max_K * BA_POSE_CHUNKS, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER, npb);
+        if (dup == 1) hipLaunchKernelGGL(kb_ba_lin, dim3(npb + max_K * BA_POSE_CHUNKS, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER, npb);
         bracket(1, 1);
       }
       bracket(2, 0);
@@ -341,21 +374,38 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
       bracket(2, 1);
       if (!all_sp)
         hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
-      if (all_sp) {
+      if (use_se) {
+        bracket(3, 0);
+        hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 3) hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        bracket(3, 1);
+        bracket(4, 0);
+        hipLaunchKernelGGL(kb_ba_schur_edges_reduce, dim3(max_np2, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        bracket(4, 1);
+      } else if (all_sp) {
         bracket(3, 0);
         hipLaunchKernelGGL(kb_ba_schur_points, dim3(max_R, 1, n), dim3(max_spt), sp_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 3) hipLaunchKernelGGL(kb_ba_schur_points, dim3(max_R, 1, n), dim3(max_spt), sp_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         bracket(3, 1);
         bracket(4, 0);
         hipLaunchKernelGGL(kb_ba_schur_reduce, dim3(max_pairs, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 4) hipLaunchKernelGGL(kb_ba_schur_reduce, dim3(max_pairs, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         bracket(4, 1);
       } else if (max_chunks > 0) {
         hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       }
       bracket(5, 0);
       hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (dup == 5) hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       bracket(5, 1);
       bracket(6, 0);
-      hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (use_te) {
+        hipLaunchKernelGGL(kb_ba_trial_edges, dim3(max_Rt, 1, n), dim3(BA_TE_THREADS), te_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 6) hipLaunchKernelGGL(kb_ba_trial_edges, dim3(max_Rt, 1, n), dim3(BA_TE_THREADS), te_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      } else {
+        hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 6) hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      }
       bracket(6, 1);
       bracket(7, 0);
       hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
@@ -399,11 +449,9 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   return CMS_OK;
 }
 
-static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<std::vector<uint8_t>>& flags) {
+static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<int>& counts) {
   cms_ba* g = bas[0];
   hipStream_t s = g->stream;
-  int rc = ba_upload_items(bas, n);
-  if (rc) return rc;
   BaDyn dyn;
   memset(&dyn, 0, sizeof(dyn));
   dyn.chi2_th = 5.991; dyn.set_level = set_level;
@@ -411,11 +459,14 @@ static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<s
   for (int w = 0; w < n; ++w) {
     dyn.phase[w] = BA_PHASE_CLASSIFY; dyn.cur[w] = (uint8_t)bas[w]->cur;
     max_e = std::max(max_e, bas[w]->nblk_e);
-    flags[w].resize(bas[w]->E);
   }
-  hipLaunchKernelGGL(kb_ba_classify, dim3(max_e, 1, n), dim3(256), 0, s, reinterpret_cast<const BaItem*>(g->grp_items_dev), dyn, (int)BA_PHASE_CLASSIFY);
-  for (int w = 0; w < n; ++w) HIPCHK(hipMemcpyAsync(flags[w].data(), bas[w]->d_flags, bas[w]->E, hipMemcpyDeviceToHost, s));
+  const BaItem* ditems = reinterpret_cast<const BaItem*>(g->grp_items_dev);
+  hipLaunchKernelGGL(kb_ba_classify, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_CLASSIFY);
+  hipLaunchKernelGGL(kb_ba_counts_publish, dim3((n + 63) / 64), dim3(64), 0, s, ditems, n);      // counts -> pinned block; flags stay on the device
   HIPCHK(hipStreamSynchronize(s));
+  const BaLmDev* hlm = reinterpret_cast<const BaLmDev*>(g->grp_lm_host);
+  counts.resize(n);
+  for (int w = 0; w < n; ++w) counts[w] = hlm[w].n_out[set_level ? 0 : 1];
   return CMS_OK;
 }
 
@@ -426,7 +477,9 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
   if (batched) {
     HIPCHK(hipSetDevice(bas[0]->device));
     for (int w = 0; w < n; ++w) HIPCHK(hipStreamSynchronize(bas[w]->stream));   // pending resets on the windows' own streams
-    const int rcg = ba_group_reserve(bas[0], n);
+    int rcg = ba_group_reserve(bas[0], n);
+    if (rcg) return rcg;
+    rcg = ba_upload_items(bas, n);          // static descriptions of the windows: once per call
     if (rcg) return rcg;
   }
   std::vector<cms_ba_stats> local(n);
@@ -443,8 +496,9 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
     local[w].lambda_final[0] = st[w].lam_fin;
   }
   std::vector<std::vector<uint8_t>> flags(n);
+  std::vector<int> counts(n, 0);
   auto classify = [&](int set_level) -> int {
-    if (batched) return ba_classify_batched(bas, n, set_level, flags);
+    if (batched) return ba_classify_batched(bas, n, set_level, counts);
     for (int w = 0; w < n; ++w) {
       cms_ba* b = bas[w];
       HIPCHK(hipSetDevice(b->device));
@@ -454,12 +508,13 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
       HIPCHK(hipMemcpyAsync(flags[w].data(), b->d_flags, b->E, hipMemcpyDeviceToHost, b->stream));
     }
     for (int w = 0; w < n; ++w) HIPCHK(hipStreamSynchronize(bas[w]->stream));
+    for (int w = 0; w < n; ++w) { counts[w] = 0; for (int e = 0; e < bas[w]->E; ++e) counts[w] += flags[w][e]; }
     return CMS_OK;
   };
   if (!ba_stopped(stop)) {   // Optimizer.cpp:366-397: exclude outliers, drop the kernel, optimize(10)
     rc = classify(1);
     if (rc) return rc;
-    for (int w = 0; w < n; ++w) for (int e = 0; e < bas[w]->E; ++e) local[w].n_outliers_mid += flags[w][e];
+    for (int w = 0; w < n; ++w) local[w].n_outliers_mid = counts[w];
     for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_final; st[w].robust = 0; st[w].delta = delta; }
     rc = batched ? (host_lm ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_batched_dev(bas, n, st, stop)) : ba_optimize_stage_many(bas, n, st, stop);
     if (rc) return rc;
@@ -470,7 +525,7 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
   }
   rc = classify(0);          // Optimizer.cpp:399-412
   if (rc) return rc;
-  for (int w = 0; w < n; ++w) for (int e = 0; e < bas[w]->E; ++e) local[w].n_outliers_final += flags[w][e];
+  for (int w = 0; w < n; ++w) local[w].n_outliers_final = counts[w];
   if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats));
   return CMS_OK;
 }

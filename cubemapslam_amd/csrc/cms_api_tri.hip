@@ -99,11 +99,20 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
   (void)o_cand;
   hipStream_t s = c->stream;
   uint8_t* p = work;
+  // inputs (pairs | jobs | pair -> job) and outputs (counts | neighbour | idx1 | idx2 | x3d) are contiguous in the work block: one copy
+  // each way through the context's pinned staging block instead of three + five copies between pageable buffers (every one of those
+  // was a separate staged transfer, ~80 us of queue time each)
+  const size_t in_bytes = o_nnew, out_bytes = o_cand - o_nnew;
+  int rcs = cms_hstage(c, in_bytes + out_bytes);
+  if (rcs) return rcs;
+  uint8_t* hin = c->h_stage;
+  uint8_t* hout = c->h_stage + in_bytes;
   if (nneigh > 0) {
-    HIPCHK(hipMemcpyAsync(p + o_pair, pairs.data(), (size_t)nneigh * sizeof(CmsTriPair), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_pjob, pair_job.data(), (size_t)nneigh * 4, hipMemcpyHostToDevice, s));
+    memcpy(hin + o_pair, pairs.data(), (size_t)nneigh * sizeof(CmsTriPair));
+    memcpy(hin + o_pjob, pair_job.data(), (size_t)nneigh * 4);
   }
-  HIPCHK(hipMemcpyAsync(p + o_job, jobs.data(), (size_t)njobs * sizeof(CmsTriJob), hipMemcpyHostToDevice, s));
+  memcpy(hin + o_job, jobs.data(), (size_t)njobs * sizeof(CmsTriJob));
+  HIPCHK(hipMemcpyAsync(p, hin, in_bytes, hipMemcpyHostToDevice, s));
   CmsTriArgs a;
   a.kf = dev.kf; a.pair = (const CmsTriPair*)(p + o_pair); a.job = (const CmsTriJob*)(p + o_job);
   a.kp = dev.kp; a.desc = dev.desc; a.rays = dev.rays; a.mp = dev.mp; a.feat_node = dev.feat_node;
@@ -126,14 +135,15 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
     hipLaunchKernelGGL(k_tri_resolve, dim3(njobs), dim3(1024), 0, s, a, (const CmsTriCand*)(p + o_cand), max_n1);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(n_new, p + o_nnew, (size_t)njobs * 4, hipMemcpyDeviceToHost, s));
-  if (cap > 0) {
-    HIPCHK(hipMemcpyAsync(out_neigh, p + o_on, nb * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out_idx1, p + o_o1, nb * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out_idx2, p + o_o2, nb * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out_x3d, p + o_ox, nb * 12, hipMemcpyDeviceToHost, s));
-  }
+  HIPCHK(hipMemcpyAsync(hout, p + o_nnew, cap > 0 ? out_bytes : tri_al((size_t)njobs * 4 + 16), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  memcpy(n_new, hout, (size_t)njobs * 4);
+  if (cap > 0) {
+    memcpy(out_neigh, hout + (o_on - o_nnew), nb * 4);
+    memcpy(out_idx1, hout + (o_o1 - o_nnew), nb * 4);
+    memcpy(out_idx2, hout + (o_o2 - o_nnew), nb * 4);
+    memcpy(out_x3d, hout + (o_ox - o_nnew), nb * 12);
+  }
   for (int j = 0; j < njobs; ++j)
     if (n_new[j] > cap) return cms_fail(CMS_ERR_OVERFLOW, "cms_create_new_map_points: more new points than cap_per_job (n_new holds the counts)");
   return CMS_OK;

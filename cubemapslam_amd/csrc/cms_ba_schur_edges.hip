@@ -1,0 +1,333 @@
+// cms_ba_schur_edges.hip -- Schur complement of the local BA, EDGE-major: one lane per observation, the reduced system of a workgroup's
+// slice of the window accumulated in LDS with ds_add_f64.
+//
+// The pair-owner kernel (cms_ba_schur_points.hip) is deterministic but pays for it: one lane per co-visible pose pair walks that
+// pair's tuples of a staged batch, and with ~1.6 tuples per pair and batch the waves run at a third of their lanes (profiles/r01:
+// 75 us for eight 80k-edge windows, 6 % of the FP64 rate).  Duplicating it in bench.py's step costs 4.6 ms of 16.4: it is the largest
+// consumer of the chip in the whole step.  Here the unit of work is the observation:
+//
+//   * edges are sorted by point (CSR); the host cuts them into CHUNKS of whole points with at most 64 edges; a wavefront takes a chunk,
+//     lane = edge;
+//   * the lane rebuilds its edge's 6x3 block B = ow Jp^T Jl from the estimate (as the pair-owner kernel's stagers do), factors the
+//     point's A = Hll + lambda I = L D L^T (3x3, no square roots) and forms W = B L^-T, so that  B_a A^-1 B_b^T = W_a D^-1 W_b^T;
+//     W goes to a wave-private LDS row, W D^-1 stays in registers;
+//   * the point's k(k-1)/2 off-diagonal tuples are spread over its k lanes: in step d = 1 .. k/2 lane a does the tuple
+//     (a, a + d mod k) -- the partner's W is a 144-byte LDS read from the neighbouring row, no barrier (LDS operations of one
+//     wavefront execute in order);
+//   * lanes of one LDS instruction that hit the SAME address are serialised (tools/probe/lds_atomics.hip: 7.6 f64 additions per
+//     clock and CU on consecutive addresses, 2.7 on scattered ones, 0.33 on one address); the diagonal tuples (a, a) -- 64 lanes on
+//     ~19 diagonal blocks cannot avoid each other -- therefore go to one of four copies of the diagonal blocks, chosen by the edge's
+//     rank among the edges of its key frame in the chunk.  The kernel's time follows its count of scattered additions (81 wave
+//     instructions per chunk, ~0.65 us each at eight windows per launch);
+//   * (a pose-major kernel for the diagonal tuples -- deterministic, butterfly reduction like ba_lin_poses_body -- was measured too:
+//     35 us for eight windows, bound by the three gathered cache lines per edge; dropped)
+//   * every product element is added to the workgroup's copy of the reduced system in LDS (one 6x6 block + 6 right-hand-side values per
+//     pose pair, dense upper-triangular pair enumeration) with ds_add_f64; when the loop is done the copy is written to this range's
+//     slice of `partial`, and kb_ba_schur_reduce adds the ranges in fixed order as before.
+//
+// The LDS additions of different wavefronts interleave in an order that is not fixed: sums may differ in the last bits from run to
+// run (the BA parity bar is 1e-4 relative on updates; the oracle's own summation order is different anyway).  CMS_BA_DETERMINISTIC=1
+// selects the pair-owner kernel instead.  (block_solver.hpp:367-437: Hschur -= Bi Dinv Bj^T, bschur -= Bi Dinv bl.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BA_SE_THREADS 512
+#define BA_SE_SSTRIDE 43          /* doubles per pose pair in the LDS copy: 36 + 6, padded against bank aliasing of neighbouring pairs */
+#define BA_SE_RANGES 32           /* workgroups per window */
+
+struct BaSe {                      // device view of the edge-major work list (cms_api_ba.hip)
+  int R, nchunks, cpw;            // ranges (workgroups), chunks, chunks per range
+  int Rt, cpw_t;                  // the same chunks cut into more, shorter ranges for the edge-major trial kernel (no LDS copy of the system to amortise)
+  int npairs2;                    // np (np + 1) / 2: pose pairs s1 <= s2 enumerated densely, row by row
+  const int* chunk_e0;            // nchunks + 1: first edge of every chunk (whole points, <= 64 edges)
+  const uint32_t* e_info;         // per edge: index within its point (5 bits) | edges of the point << 5 | (free-pose slot + 1) << 10 | face << 16 |
+                                  // key frame << 19 (8 bits) | copy of the diagonal blocks its (a, a) tuple goes to << 27 (2 bits)
+  double* partial;                // R x npairs2 x 42
+  const int* lone; int nlone;     // points without any observation (in no chunk): the trial kernel copies their position
+};
+
+__device__ __forceinline__ int ba_se_pair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 - 1)) >> 1) + (s2 - s1); }   // s1 <= s2, dense (with diagonal)
+__device__ __forceinline__ int ba_se_opair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 + 1)) >> 1) + (s2 - s1 - 1); }   // s1 < s2, off-diagonal only
+#define BA_SE_DCOPIES 4
+#define BA_SE_DSTRIDE 28          /* 21 (upper triangle) + 6 (right-hand side) + 1 */
+
+__device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
+                                                    const double* __restrict__ poses, const double* __restrict__ pts) {
+#pragma clang fp contract(fast)
+  extern __shared__ __align__(16) double se_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
+  double* S = se_lds;                                              // NPO x 43: off-diagonal pairs s1 < s2
+  double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);               // 4 x np x 28: copies of the diagonal blocks (upper triangle | rhs)
+  double* rows = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // nw x 64 x 18 (16-byte aligned)
+  double* prt = rows + (size_t)nw * 64 * 18;                       // K x 12: rotation (row major) | translation of every key frame
+  int* rslot = reinterpret_cast<int*>(prt + (size_t)d.K * 12);     // nw x 64: free-pose slot of the edge in a row, -1 = contributes nothing
+  for (int i = tid; i < (int)(rows - S); i += blockDim.x) S[i] = 0.0;
+  for (int k = tid; k < d.K; k += blockDim.x) {
+    double R[9];
+    quat_to_R(poses + 7 * k + 3, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) prt[12 * k + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prt[12 * k + 9 + i] = poses[7 * k + i];
+  }
+  __syncthreads();
+  double* myrows = rows + (size_t)wave * 64 * 18;
+  int* myslot = rslot + wave * 64;
+  const int c0 = BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);
+  // The loop is software pipelined over a wave's chunks: the per-edge words of chunk c + nw are requested before chunk c is worked on,
+  // its per-point operands (position, Hll, bl) right after chunk c's rows are published -- the atomics section hides their latency.
+  int n_p = 0; uint32_t n_info = 0; double n_ow = 0.0;
+  double n_X[3] = {0, 0, 0}, n_H[6] = {1, 0, 1, 0, 0, 1}, n_b[3] = {0, 0, 0};
+  auto load1 = [&](int c) {
+    n_info = 0; n_ow = 0.0; n_p = 0;
+    if (c < c1) {
+      const int e = se.chunk_e0[c] + lane;
+      if (e < se.chunk_e0[c + 1]) { n_p = d.e_point[e]; n_info = se.e_info[e]; n_ow = d.ow[e]; }
+    }
+  };
+  auto load2 = [&]() {
+    if (n_info != 0) {
+      const double* Xp = pts + 3 * (size_t)n_p; const double* H = Hll + 9 * (size_t)n_p; const double* bp = bl + 3 * (size_t)n_p;
+      n_X[0] = Xp[0]; n_X[1] = Xp[1]; n_X[2] = Xp[2];
+      n_H[0] = H[0]; n_H[1] = H[3]; n_H[2] = H[4]; n_H[3] = H[6]; n_H[4] = H[7]; n_H[5] = H[8];
+      n_b[0] = bp[0]; n_b[1] = bp[1]; n_b[2] = bp[2];
+    }
+  };
+  load1(c0 + wave);
+  load2();
+  for (int c = c0 + wave; c < c1; c += nw) {
+    const uint32_t info = n_info;
+    const double ow = n_ow;
+    const double X[3] = {n_X[0], n_X[1], n_X[2]}, Hc[6] = {n_H[0], n_H[1], n_H[2], n_H[3], n_H[4], n_H[5]}, bc[3] = {n_b[0], n_b[1], n_b[2]};
+    load1(c + nw);
+    int slot = -1, a = 0, k = 1;
+    double W[18], WD[18], z[3];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { W[i] = 0.0; WD[i] = 0.0; }
+    z[0] = z[1] = z[2] = 0.0;
+    if (info != 0) {
+      a = info & 31; k = (info >> 5) & 31;
+      const int s = (int)((info >> 10) & 63) - 1, face = (info >> 16) & 7, kp = (info >> 19) & 255;
+      if (s >= 0 && ow != 0.0) {
+        slot = s;
+        const double* Rt = prt + 12 * kp;
+        double R[9], Xc[3], Jp[12], Jl[6];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + Rt[9 + i];
+        edge_jac_face(d, face, Xc, R, Jp, Jl);
+        // A = Hll + lambda I = L D L^T (unit lower L)
+        const double a00 = Hc[0] + lambda, a10 = Hc[1], a11 = Hc[2] + lambda, a20 = Hc[3], a21 = Hc[4], a22 = Hc[5] + lambda;
+        const double i0 = 1.0 / a00;
+        const double l10 = a10 * i0, l20 = a20 * i0;
+        const double d1 = a11 - l10 * a10;
+        const double i1 = 1.0 / d1;
+        const double l21 = (a21 - l20 * a10) * i1;
+        const double d2 = a22 - l20 * a20 - l21 * (l21 * d1);
+        const double i2 = 1.0 / d2;
+        const double y0 = bc[0], y1 = bc[1] - l10 * y0, y2 = bc[2] - l20 * y0 - l21 * y1;      // y = L^-1 bl
+        z[0] = i0 * y0; z[1] = i1 * y1; z[2] = i2 * y2;                                          // D^-1 y
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double q0 = ow * (Jp[r] * Jl[0] + Jp[6 + r] * Jl[3]);                  // row r of B = ow Jp^T Jl
+          const double q1 = ow * (Jp[r] * Jl[1] + Jp[6 + r] * Jl[4]);
+          const double q2 = ow * (Jp[r] * Jl[2] + Jp[6 + r] * Jl[5]);
+          const double w0 = q0, w1 = q1 - w0 * l10, w2 = q2 - w0 * l20 - w1 * l21;     // W L^T = B
+          W[3 * r] = w0; W[3 * r + 1] = w1; W[3 * r + 2] = w2;
+          WD[3 * r] = w0 * i0; WD[3 * r + 1] = w1 * i1; WD[3 * r + 2] = w2 * i2;
+        }
+      }
+    }
+    // ---- publish this lane's W (LDS operations of one wavefront execute in program order: rows written here are what the reads
+    // below see, and the reads of the previous chunk are through before these writes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    {
+      double2* row2 = reinterpret_cast<double2*>(myrows + (size_t)lane * 18);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) row2[i] = make_double2(W[2 * i], W[2 * i + 1]);
+      myslot[lane] = slot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    load2();                     // next chunk's per-point operands travel while this chunk's products are added
+    // ---- diagonal tuple (a, a): W D^-1 W^T (upper triangle) and the right-hand side W D^-1 y, into this edge's copy of the diagonal blocks
+    if (slot >= 0) {
+      double* base = Dg + ((size_t)(info >> 27) * np + slot) * BA_SE_DSTRIDE;
+      int cidx = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int q = r; q < 6; ++q)
+          unsafeAtomicAdd(base + (cidx++), WD[3 * r] * W[3 * q] + WD[3 * r + 1] * W[3 * q + 1] + WD[3 * r + 2] * W[3 * q + 2]);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) unsafeAtomicAdd(base + 21 + r, W[3 * r] * z[0] + W[3 * r + 1] * z[1] + W[3 * r + 2] * z[2]);
+    }
+    // ---- off-diagonal tuples: step d pairs lane a with (a + d) mod k; for even k the last step is done by the lower half only
+    int kh = k >> 1;
+    for (int o = 32; o > 0; o >>= 1) kh = max(kh, __shfl_xor(kh, o));
+    for (int dd = 1; dd <= kh; ++dd) {
+      const bool mine = slot >= 0 && (2 * dd < k || (2 * dd == k && a < dd));
+      int b = a + dd;
+      const bool wrapped = b >= k;
+      if (wrapped) b -= k;
+      const int lb = mine ? lane - a + b : lane;
+      const int sb = myslot[lb];
+      if (mine && sb >= 0) {
+        double Wb[18];
+        const double2* row2 = reinterpret_cast<const double2*>(myrows + (size_t)lb * 18);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const double2 u = row2[i]; Wb[2 * i] = u.x; Wb[2 * i + 1] = u.y; }
+        // the block of pair (s1 < s2) is W_1 D^-1 W_2^T; a wrapped partner has the lower slot (edges of a point ascend by key frame),
+        // this lane then holds the TRANSPOSE of the pair's block: same products, rows and columns swapped in the address
+        double* base = S + (size_t)(wrapped ? ba_se_opair(np, sb, slot) : ba_se_opair(np, slot, sb)) * BA_SE_SSTRIDE;
+        const int sr = wrapped ? 1 : 6, sc = wrapped ? 6 : 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double* rowp = base + r * sr;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            const double v = WD[3 * r] * Wb[3 * q] + WD[3 * r + 1] * Wb[3 * q + 1] + WD[3 * r + 2] * Wb[3 * q + 2];
+            unsafeAtomicAdd(rowp + q * sc, v);      // (the host refuses this kernel for windows in which a point is seen twice by one key frame: sb != slot)
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- this range's slice of `partial`, in the dense pair enumeration the reduction and the solve kernel use
+  __syncthreads();
+  for (int o = tid; o < NP2 * 42; o += blockDim.x) {
+    const int pr = o / 42, i = o - 42 * pr;
+    int s1 = 0, off = 0;
+    while (off + (np - s1) <= pr) { off += np - s1; ++s1; }
+    const int s2 = s1 + (pr - off);
+    double v = 0.0;
+    if (s1 == s2) {
+      int ci;
+      if (i < 36) { const int r = i / 6, q = i - 6 * r, lo = min(r, q), hi = max(r, q); ci = lo * 6 - ((lo * (lo - 1)) >> 1) + (hi - lo); }
+      else ci = 21 + (i - 36);
+      for (int cp = 0; cp < BA_SE_DCOPIES; ++cp) v += Dg[((size_t)cp * np + s1) * BA_SE_DSTRIDE + ci];
+    } else if (i < 36) {
+      v = S[(size_t)ba_se_opair(np, s1, s2) * BA_SE_SSTRIDE + i];
+    }
+    se.partial[((size_t)BX * NP2 + pr) * 42 + i] = v;
+  }
+}
+
+// ---- landmark back-substitution + update + residuals at the trial state, EDGE-major (what ba_trial_points_body does with one thread per
+// point): the same chunks, lane = edge.  The lanes of a point hand their  ow Jl^T (Jp x_p)  to the point's first lane in edge order
+// (same summation order as the per-point loop), that lane solves for the landmark step and updates the point, every lane then evaluates
+// its own residual at the trial state.  One thread per point left the chip at 2.7 wavefronts per SIMD walking dependent loads (29 us for
+// eight windows against ~10 us of traffic and arithmetic); here every edge is a lane and the key frames' poses sit in LDS.
+// partial[BX] = chi2 sum, partial[GX + BX] = gain-denominator sum of this workgroup's points.
+#define BA_TE_THREADS 256
+__device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaSe se, const double* __restrict__ bl, const double* __restrict__ Hll,
+                                                    const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
+                                                    const double* __restrict__ poses_cur, const double* __restrict__ poses_new, int robust, double delta,
+                                                    double* __restrict__ partial) {
+  extern __shared__ __align__(16) double te_lds[];     // K x 12 (current poses) | K x 12 (trial poses) | np x 6 (pose update)
+  __shared__ double sh[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  double* prc = te_lds;
+  double* prn = prc + (size_t)d.K * 12;
+  double* xps = prn + (size_t)d.K * 12;
+  for (int k = tid; k < 2 * d.K; k += blockDim.x) {
+    const int kk = k < d.K ? k : k - d.K;
+    const double* pose = (k < d.K ? poses_cur : poses_new) + 7 * kk;
+    double* dst = (k < d.K ? prc : prn) + 12 * kk;
+    double R[9];
+    quat_to_R(pose + 3, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dst[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dst[9 + i] = pose[i];
+  }
+  for (int i = tid; i < 6 * d.np; i += blockDim.x) xps[i] = xp[i];
+  __syncthreads();
+  double sc = 0, chi = 0;
+  const int c0 = BX * se.cpw_t, c1 = min(se.nchunks, c0 + se.cpw_t);
+  for (int c = c0 + wave; c < c1; c += nw) {
+    const int e0 = se.chunk_e0[c], e1 = se.chunk_e0[c + 1];
+    const int e = e0 + lane;
+    const bool have = e < e1;
+    uint32_t info = 0;
+    int p = 0, a = 0, k = 1, kp = 0, face = 0, s = -1;
+    bool act = false;
+    double X[3] = {0, 0, 0}, cj[3] = {0, 0, 0};
+    if (have) {
+      info = se.e_info[e]; p = d.e_point[e];
+      a = info & 31; k = (info >> 5) & 31; s = (int)((info >> 10) & 63) - 1; face = (info >> 16) & 7; kp = (info >> 19) & 255;
+      act = d.level[e] == 0;
+      X[0] = pts[3 * (size_t)p]; X[1] = pts[3 * (size_t)p + 1]; X[2] = pts[3 * (size_t)p + 2];
+      if (act && s >= 0) {
+        const double* Rt = prc + 12 * kp;
+        double R[9], Xc[3], Jp[12], Jl[6];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + Rt[9 + i];
+        edge_jac_face(d, face, Xc, R, Jp, Jl);
+        double t0 = 0, t1 = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { t0 += Jp[i] * xps[6 * s + i]; t1 += Jp[6 + i] * xps[6 * s + i]; }
+        const double ow = d.ow[e];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cj[j] = ow * (Jl[j] * t0 + Jl[3 + j] * t1);
+      }
+    }
+    // ---- the point's first lane collects the contributions in edge order
+    int kmax = k;
+    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o));
+    const int nact_me = act ? 1 : 0;
+    int nact = nact_me;
+    double cl[3] = {0, 0, 0};
+    const bool head = have && a == 0;
+    if (head) { cl[0] = bl[3 * (size_t)p] - cj[0]; cl[1] = bl[3 * (size_t)p + 1] - cj[1]; cl[2] = bl[3 * (size_t)p + 2] - cj[2]; }
+    for (int dd = 1; dd < kmax; ++dd) {
+      const int src = min(lane + dd, 63);
+      const double v0 = __shfl(cj[0], src), v1 = __shfl(cj[1], src), v2 = __shfl(cj[2], src);
+      const int na = __shfl(nact_me, src);
+      if (head && dd < k) { cl[0] -= v0; cl[1] -= v1; cl[2] -= v2; nact += na; }
+    }
+    double Xn[3] = {X[0], X[1], X[2]};
+    if (head) {
+      double D[9], Di[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
+      inv3(D, Di);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double xl = nact > 0 ? Di[3 * i] * cl[0] + Di[3 * i + 1] * cl[1] + Di[3 * i + 2] * cl[2] : 0.0;
+        Xn[i] = X[i] + xl;
+        pts_new[3 * (size_t)p + i] = Xn[i];
+        sc += xl * (lambda * xl + bl[3 * (size_t)p + i]);
+      }
+    }
+    // ---- every lane gets its point's trial position from the point's first lane, then its own residual at the trial state
+    {
+      const int src = lane - a;
+      Xn[0] = __shfl(Xn[0], src); Xn[1] = __shfl(Xn[1], src); Xn[2] = __shfl(Xn[2], src);
+    }
+    if (have && act) {
+      const double* Rt = prn + 12 * kp;
+      double Xc[3], r[2], rho0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Xc[i] = Rt[3 * i] * Xn[0] + Rt[3 * i + 1] * Xn[1] + Rt[3 * i + 2] * Xn[2] + Rt[9 + i];
+      const double2 ob = reinterpret_cast<const double2*>(d.e_obs)[e];
+      edge_error_v(d, face, ob.x, ob.y, Xc, r);
+      reinterpret_cast<double2*>(d.err)[e] = make_double2(r[0], r[1]);
+      const double c2 = d.e_inv[e] * (r[0] * r[0] + r[1] * r[1]);
+      if (robust) { huber_w(c2, delta, &rho0); chi += rho0; } else chi += c2;
+    }
+  }
+  for (int i = BX * blockDim.x + tid; i < se.nlone; i += GX * blockDim.x) {      // points nobody observes keep their position (x_l = 0)
+    const int p = se.lone[i];
+    pts_new[3 * (size_t)p] = pts[3 * (size_t)p]; pts_new[3 * (size_t)p + 1] = pts[3 * (size_t)p + 1]; pts_new[3 * (size_t)p + 2] = pts[3 * (size_t)p + 2];
+  }
+  const double s1 = block_sum(chi, sh);
+  const double s2 = block_sum(sc, sh);
+  if (threadIdx.x == 0) { partial[BX] = s1; partial[GX + BX] = s2; }
+}

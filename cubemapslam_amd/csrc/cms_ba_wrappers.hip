@@ -18,6 +18,7 @@
 struct BaLmDev {
   double lambda, ni, currentChi, iniChi, rho, chi_ini, chi_fin, lam_fin;
   int it, iterations, qmax, nBad, done, next, cur, rounds;   // next: 0 = start an iteration, 1 = one more trial, 2 = finished
+  int n_out[2], pad[2];                                      // outliers counted by kb_ba_classify: [0] mid-way (set_level), [1] final
 };
 // static description of one window (device resident, uploaded once per optimisation stage) ...
 struct BaItem {
@@ -30,6 +31,7 @@ struct BaItem {
   uint8_t* flags;
   int nblk_e, nblk_p, nchunks, pad;
   BaSp sp;                                   // per-point Schur work lists (sp.R == 0: window uses the tuple-chunk kernel)
+  BaSe se;                                   // edge-major Schur work list (se.R > 0: the group runs kb_ba_schur_edges instead of kb_ba_schur_points)
   BaLmDev* lm; BaLmDev* hlm;                 // device-side LM state and its pinned host mirror (dyn.dev_lm)
 };
 // ... and what changes from launch to launch, passed BY VALUE as a kernel argument: no host->device copy per Levenberg step
@@ -235,6 +237,16 @@ extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS + BA_SP_STAGERS) 
   BA_ITEM(phase, it.sp.R)
   ba_schur_points_body(blockIdx.x, it.d, it.sp, it.Hpl, it.Dinv, it.db, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur]);   // inverts Hll + lambda I itself
 }
+extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_schur_edges(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.R)
+  ba_schur_edges_body(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur]);
+}
+extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_edges_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.R > 0 ? it.se.npairs2 : 0)
+  BaSp v;                                          // the range sum only looks at these three fields
+  v.R = it.se.R; v.npairs = it.se.npairs2; v.partial = it.se.partial;
+  ba_schur_reduce_body(blockIdx.x, v, it.chunk_sum);
+}
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R > 0 ? it.sp.npairs : 0)
   ba_schur_reduce_body(blockIdx.x, it.sp, it.chunk_sum);
@@ -249,10 +261,15 @@ extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaIte
   ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
                        dyn.delta, it.partial, it.sp.R > 0 ? it.Hll : nullptr, it.sp.R > 0 ? it.poses[cur] : nullptr);
 }
+extern "C" __global__ void __launch_bounds__(BA_TE_THREADS) kb_ba_trial_edges(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.Rt)
+  ba_trial_edges_body(blockIdx.x, it.se.Rt, it.d, it.se, it.bl, it.Hll, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[cur], it.poses[nxt], dyn.robust,
+                      dyn.delta, it.partial);
+}
 // last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
 __device__ __forceinline__ void kb_ba_reduce2_window(const BaItem* __restrict__ items, const BaDyn& dyn, int phase) {
   BA_ITEM(phase, 1)
-  ba_reduce2_body(0, 1, it.partial, it.nblk_p, it.scal, it.hscal);
+  ba_reduce2_body(0, 1, it.partial, it.se.Rt > 0 ? it.se.Rt : it.nblk_p, it.scal, it.hscal);   // partial sums of kb_ba_trial_edges / kb_ba_trial_points
   if (dyn.dev_lm && threadIdx.x == 0) {
     int ok2;
     memcpy(&ok2, &it.scal[4], sizeof(int));
@@ -278,4 +295,26 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __
 extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_e)
   ba_classify_body(blockIdx.x, it.nblk_e, it.d, it.poses[cur], it.pts[cur], dyn.chi2_th, dyn.set_level, it.flags);
+  // the driver only needs the NUMBER of outliers of a window (cms_ba_stats); the flags stay on the device for cms_ba_read
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = __syncthreads_count(e < it.d.E && it.flags[e] != 0);
+  if (threadIdx.x == 0 && n > 0) atomicAdd(&it.lm->n_out[dyn.set_level ? 0 : 1], n);
+}
+// start of a stage: the windows' Levenberg state comes from the pinned host block the driver just filled (no H2D copy in the stream),
+// the outlier counters are cleared by the first stage of a call
+extern "C" __global__ void __launch_bounds__(64) kb_ba_lm_load(const BaItem* __restrict__ items, int n, int clear_counts) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  BaLmDev L = *items[w].hlm;
+  const BaLmDev old = *items[w].lm;
+  L.n_out[0] = clear_counts ? 0 : old.n_out[0];      // the first stage of a call clears both counters (the final classification
+  L.n_out[1] = clear_counts ? 0 : old.n_out[1];      // also runs when a stop request skips the second stage)
+  *items[w].lm = L;
+}
+// after a classification: the windows' outlier counters -> pinned host block
+extern "C" __global__ void __launch_bounds__(64) kb_ba_counts_publish(const BaItem* __restrict__ items, int n) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  items[w].hlm->n_out[0] = items[w].lm->n_out[0];
+  items[w].hlm->n_out[1] = items[w].lm->n_out[1];
 }
