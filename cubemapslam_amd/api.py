@@ -378,6 +378,18 @@ class Context:
                                             C.addressof(nm)), "cms_search_by_projection")
         return match, nm.value
 
+    def search_for_initialization(self, b2, k1, d1, prev_matched, window=100, nnratio=0.9, check_ori=True):
+        """ORBMatcher::SearchForInitialization(F1, F2 = frame slot b2, vbPrevMatched, vnMatches12, windowSize) -> (matches12, nmatches); prev_matched
+        (n1, 2) float32 is updated in place"""
+        k1 = np.ascontiguousarray(k1, KP_DTYPE); d1 = np.ascontiguousarray(d1, np.uint8)
+        assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and prev_matched.shape == (len(k1), 2)
+        m12 = np.full(max(len(k1), 1), -1, np.int32); nm = C.c_int(0)
+        f = lib().cms_search_for_initialization
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        _chk(f(self.h, b2, len(k1), _p(k1), _p(d1), _p(prev_matched), int(window), float(nnratio), int(check_ori), _p(m12), C.addressof(nm)),
+             "cms_search_for_initialization")
+        return m12[:len(k1)], nm.value
+
     def project_last_frame_device(self, n, d_qframe, d_pose12, d_valid, d_Xw, d_oct, th, d_q5):
         """d_q5 = (qx, qy, qr, qmin, qmax) raw device pointers"""
         v = lambda a: C.c_void_p(int(a)) if a else None

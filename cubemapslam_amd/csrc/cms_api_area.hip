@@ -1,10 +1,20 @@
 // cms_api_area.hip -- host side of the frame grid + window query (Frame::AssignFeaturesToGrid / GetFeaturesInArea), included by
 // cms_lib.hip after cms_api_frames.hip (uses cms_ctx, cms_fail, HIPCHK, cms_scratch).
+#include <mutex>
 #include <vector>
 
 static int cms_area_reserve(cms_ctx* c) {
   if (c->d_area_sorted) return CMS_OK;
-  if (c->g.kp_cap > CMS_AREA_MAXKP) return cms_fail(CMS_ERR_UNSUPPORTED, "frame grid: more than 4095 key points per frame");
+  if (c->g.kp_cap > CMS_AREA_MAXKP) return cms_fail(CMS_ERR_UNSUPPORTED, "frame grid: more than 16383 key points per frame");
+  {   // the rank sort keeps 8 bytes per key point in LDS: above the 64 KB default for the 3 x nFeatures extractor of the initialisation
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (c->device >= 0 && c->device < 64 && !done[c->device]) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_area_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (CMS_AREA_MAXKP + 1) * 8));
+      done[c->device] = true;
+    }
+  }
   const size_t B = (size_t)c->max_batch;
   HIPCHK(hipMalloc((void**)&c->d_area_sorted, B * c->g.kp_cap * sizeof(uint16_t)));
   HIPCHK(hipMalloc((void**)&c->d_area_cell_start, B * (CMS_AREA_CELLS + 1) * sizeof(int)));
@@ -36,7 +46,7 @@ extern "C" int cms_area_grid(cms_ctx* c, int B) {
   int rc = cms_area_reserve(c);
   if (rc) return rc;
   const float inv = (float)(3 * CMS_AREA_G) / (float)c->g.W;          // mfGridElementLengthInv (Frame.cpp:149)
-  hipLaunchKernelGGL(k_area_grid, dim3(B), dim3(1024), 0, c->stream, (const CmsKeyPoint*)c->d_kps, (const int*)c->d_kp_cnt, c->g.kp_cap, c->g.F, inv,
+  hipLaunchKernelGGL(k_area_grid, dim3(B), dim3(1024), (size_t)(c->g.kp_cap + 1) * 8, c->stream, (const CmsKeyPoint*)c->d_kps, (const int*)c->d_kp_cnt, c->g.kp_cap, c->g.F, inv,
                      c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid);
   HIPCHK(hipGetLastError());
   c->area_frames = B;

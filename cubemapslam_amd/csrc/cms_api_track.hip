@@ -1,3 +1,4 @@
+#include <mutex>
 // cms_api_track.hip -- host side of the "track local map" step (Frame::isInFrustum + ORBMatcher::SearchByProjection over the local
 // map points, Tracking::SearchLocalPoints), included by cms_lib.hip after cms_api_area.hip.
 #include <cmath>
@@ -239,4 +240,83 @@ extern "C" int cms_search_by_projection(cms_ctx* c, int b, const float* pose12, 
     return CMS_OK;
   }
   return cms_fail(CMS_ERR_OVERFLOW, "cms_search_by_projection: candidate lists kept growing");
+}
+
+// ORBMatcher::SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBMatcher.cpp:676-794): F2 is
+// frame slot b2 (key points / descriptors on the device, cms_area_grid first), F1 comes from the caller.  prev_matched: n1 x 2 floats,
+// in/out (vbPrevMatched); matches12[i1] = key point of F2 or -1.
+extern "C" int cms_search_for_initialization(cms_ctx* c, int b2, int n1, const cms_keypoint* kps1, const uint8_t* desc1, float* prev_matched,
+                                             int window_size, float nnratio, int check_orientation, int* matches12, int* n_matches) {
+  if (!c || n1 < 0 || (n1 > 0 && (!kps1 || !desc1 || !prev_matched || !matches12)) || window_size < 0)
+    return cms_fail(CMS_ERR_ARG, "cms_search_for_initialization: bad argument");
+  if (b2 < 0 || b2 >= c->area_frames) return cms_fail(CMS_ERR_ARG, "cms_search_for_initialization: no grid for this frame (cms_area_grid first)");
+  if (n_matches) *n_matches = 0;
+  if (n1 == 0) return CMS_OK;
+  HIPCHK(hipSetDevice(c->device));
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&]() { attr_err = hipFuncSetAttribute((const void*)k_init_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
+  HIPCHK(attr_err);
+  const size_t lds = (size_t)c->g.kp_cap * 8;
+  if (lds > 160 * 1024 - 1024) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_for_initialization: too many key points per frame for the LDS tables");
+  hipStream_t s = c->stream;
+  std::vector<int> qi;
+  for (int i = 0; i < n1; ++i) if (kps1[i].octave <= 0) qi.push_back(i);      // only level 0 (:693-696)
+  const int nq = (int)qi.size();
+  for (int i = 0; i < n1; ++i) matches12[i] = -1;
+  if (nq == 0) return CMS_OK;
+  const size_t q4 = (size_t)nq * 4, n4 = (size_t)n1 * 4;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
+  const size_t o_qi = take(q4), o_qx = take(q4), o_qy = take(q4), o_qr = take(q4), o_qmin = take(q4), o_qmax = take(q4), o_qf = take(q4),
+               o_desc = take((size_t)n1 * 32), o_ang = take(n4), o_prev = take(2 * n4);
+  const size_t in_bytes = o;
+  const size_t o_m12 = take(n4), o_nm = take(16), o_tot = take(16);
+  const size_t out_begin = o_prev, out_bytes = o - o_prev;
+  const size_t o_bin = take(n1), o_cnt = take(q4), o_off = take(q4 + 4);
+  const size_t fixed = o;
+  int cap = 128 * nq + 4096;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
+    int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
+    if (rc) return rc;
+    rc = cms_hstage(c, std::max(in_bytes, out_bytes));
+    if (rc) return rc;
+    uint8_t* p = (uint8_t*)c->d_match;
+    uint8_t* h = c->h_stage;
+    {
+      int* hq = reinterpret_cast<int*>(h + o_qi); float* hx = reinterpret_cast<float*>(h + o_qx); float* hy = reinterpret_cast<float*>(h + o_qy);
+      float* hr = reinterpret_cast<float*>(h + o_qr); int* hmin = reinterpret_cast<int*>(h + o_qmin); int* hmax = reinterpret_cast<int*>(h + o_qmax);
+      int* hf = reinterpret_cast<int*>(h + o_qf);
+      for (int q = 0; q < nq; ++q) {
+        hq[q] = qi[q]; hx[q] = prev_matched[2 * qi[q]]; hy[q] = prev_matched[2 * qi[q] + 1]; hr[q] = (float)window_size; hmin[q] = 0; hmax[q] = 0; hf[q] = b2;
+      }
+      float* ha = reinterpret_cast<float*>(h + o_ang);
+      for (int i = 0; i < n1; ++i) ha[i] = kps1[i].angle;
+      memcpy(h + o_desc, desc1, (size_t)n1 * 32);
+      memcpy(h + o_prev, prev_matched, 2 * n4);
+    }
+    HIPCHK(hipMemcpyAsync(p, h, in_bytes, hipMemcpyHostToDevice, s));
+    rc = cms_features_in_area_batch_device(c, nq, p + o_qf, p + o_qx, p + o_qy, p + o_qr, p + o_qmin, p + o_qmax, p + o_cnt, p + o_off, p + o_idx, cap, p + o_tot);
+    if (rc) return rc;
+    CmsInitArgs a;
+    a.nq = nq; a.q_i1 = (const int*)(p + o_qi); a.cand_off = (const int*)(p + o_off); a.cand_idx = (const int*)(p + o_idx);
+    a.desc1 = (const uint4*)(p + o_desc); a.t_desc = (const uint4*)c->d_desc; a.kp2 = (const CmsKeyPoint*)c->d_kps; a.row0 = b2 * c->g.kp_cap; a.kp_cap = c->g.kp_cap;
+    a.angle1 = (const float*)(p + o_ang); a.pair_dist = (uint16_t*)(p + o_pd);
+    a.n1 = n1; a.matches12 = (int*)(p + o_m12); a.prev_matched = (float*)(p + o_prev); a.n_matches = (int*)(p + o_nm); a.bin_of = (int8_t*)(p + o_bin);
+    a.nnratio = nnratio; a.check_orientation = check_orientation; a.total = (const int*)(p + o_tot); a.cap = cap;
+    hipLaunchKernelGGL(k_init_dist, dim3(nq), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_init_greedy, dim3(1), dim3(64), lds, s, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h + out_begin, p + out_begin, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int tot = *reinterpret_cast<const int*>(h + o_tot);
+    if (tot > cap) { cap = tot + 64; continue; }
+    memcpy(matches12, h + o_m12, n4);
+    memcpy(prev_matched, h + o_prev, 2 * n4);
+    if (n_matches) *n_matches = *reinterpret_cast<const int*>(h + o_nm);
+    return CMS_OK;
+  }
+  return cms_fail(CMS_ERR_OVERFLOW, "cms_search_for_initialization: candidate lists kept growing");
 }

@@ -315,7 +315,7 @@ extern "C" int cms_kfstore_put(cms_kfstore* st, int slot, const cms_keyframe* kf
   HIPCHK(hipMemcpyAsync(st->d_kp_cnt + slot, &kf->n, sizeof(int), hipMemcpyHostToDevice, s));
   {
     const float inv = (float)(3 * CMS_AREA_G) / (float)c->g.W;          // mfGridElementLengthInv (Frame.cpp:149)
-    hipLaunchKernelGGL(k_area_grid, dim3(1), dim3(1024), 0, s, (const CmsKeyPoint*)(st->d_kp + f0), (const int*)(st->d_kp_cnt + slot), st->maxf, c->g.F, inv,
+    hipLaunchKernelGGL(k_area_grid, dim3(1), dim3(1024), (size_t)(st->maxf + 1) * 8, s, (const CmsKeyPoint*)(st->d_kp + f0), (const int*)(st->d_kp_cnt + slot), st->maxf, c->g.F, inv,
                        st->d_sorted + f0, st->d_cell_start + (size_t)slot * (CMS_AREA_CELLS + 1), st->d_nvalid + slot);
     HIPCHK(hipGetLastError());
   }

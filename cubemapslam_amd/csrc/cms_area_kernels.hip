@@ -1,8 +1,9 @@
 // cms_area_kernels.hip -- Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cpp:158-176, 728-744) and Frame::GetFeaturesInArea
 // (src/Frame.cpp:36-72, 251-716) on the device: the key points of a frame never leave HBM between extraction and matching.
 //
-//   k_area_grid    one workgroup per frame: every key point gets the key (cell << 12 | index); a rank sort in LDS (keys are
-//                  unique, n <= 4095) lists the indices cell-major with ascending index inside a cell -- the order the
+//   k_area_grid    one workgroup per frame: every key point gets the key (cell << 14 | index); a rank sort in LDS (keys are
+//                  unique, n <= 16383: the 3 x nFeatures extractor of the initialisation included) lists the indices cell-major with
+//                  ascending index inside a cell -- the order the
 //                  reference's per-cell vectors have -- and a start offset is written for each of the 5 x 50 x 50 cells.
 //   k_area_query   one thread per query: cms_area_rects() (the reference's 41 unfolding cases as a table, cms_area_table.h)
 //                  yields up to three cell rectangles; the thread walks them exactly like AddCells (ix outer, iy inner, level
@@ -15,13 +16,14 @@
 #include "cms_area_table.h"
 
 #define CMS_AREA_CELLS (5 * CMS_AREA_G * CMS_AREA_G)
-#define CMS_AREA_MAXKP 4095
+#define CMS_AREA_MAXKP 16383
 
 extern "C" __global__ void __launch_bounds__(1024)
 k_area_grid(const CmsKeyPoint* __restrict__ kps, const int* __restrict__ kp_cnt, int kp_cap, int F, float inv,
             uint16_t* __restrict__ sorted_idx, int* __restrict__ cell_start, int* __restrict__ n_valid_out) {
-  __shared__ uint32_t keys[CMS_AREA_MAXKP + 1];
-  __shared__ uint32_t sorted[CMS_AREA_MAXKP + 1];
+  extern __shared__ uint32_t area_lds[];                 // keys [kp_cap + 1] | sorted [kp_cap + 1]
+  uint32_t* keys = area_lds;
+  uint32_t* sorted = area_lds + (kp_cap + 1);
   __shared__ int s_nvalid;
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int n = min(kp_cnt[b], CMS_AREA_MAXKP);
@@ -37,10 +39,10 @@ k_area_grid(const CmsKeyPoint* __restrict__ kps, const int* __restrict__ kp_cnt,
     else if (fi >= 1 && fi < 2 && fj >= 1 && fj < 2) f = 0;
     else if (fi >= 1 && fi < 2 && fj >= 2 && fj < 3) f = 4;
     else if (fi >= 2 && fi < 3 && fj >= 1 && fj < 2) f = 2;
-    uint32_t key = 0xFFFFF000u | (uint32_t)i;                                   // not on a face: sorted behind every cell
+    uint32_t key = 0xFFFFC000u | (uint32_t)i;                                   // not on a face: sorted behind every cell
     if (f >= 0) {
       const int px = (int)(x * inv) % CMS_AREA_G, py = (int)(y * inv) % CMS_AREA_G;     // PosInGrid (Frame.cpp:734-742), mnMinX = 0
-      key = ((uint32_t)((f * CMS_AREA_G + px) * CMS_AREA_G + py) << 12) | (uint32_t)i;
+      key = ((uint32_t)((f * CMS_AREA_G + px) * CMS_AREA_G + py) << 14) | (uint32_t)i;
       atomicAdd(&s_nvalid, 1);
     }
     keys[i] = key;
@@ -57,11 +59,11 @@ k_area_grid(const CmsKeyPoint* __restrict__ kps, const int* __restrict__ kp_cnt,
   uint16_t* si = sorted_idx + (size_t)b * kp_cap;
   int* cs = cell_start + (size_t)b * (CMS_AREA_CELLS + 1);
   for (int s = tid; s < nv; s += T) {
-    const int c = (int)(sorted[s] >> 12), prev = s ? (int)(sorted[s - 1] >> 12) : -1;
-    si[s] = (uint16_t)(sorted[s] & 0xFFFu);
+    const int c = (int)(sorted[s] >> 14), prev = s ? (int)(sorted[s - 1] >> 14) : -1;
+    si[s] = (uint16_t)(sorted[s] & 0x3FFFu);
     for (int cc = prev + 1; cc <= c; ++cc) cs[cc] = s;
   }
-  const int last = nv ? (int)(sorted[nv - 1] >> 12) : -1;
+  const int last = nv ? (int)(sorted[nv - 1] >> 14) : -1;
   for (int cc = last + 1 + tid; cc <= CMS_AREA_CELLS; cc += T) cs[cc] = nv;
   if (tid == 0) n_valid_out[b] = nv;
 }

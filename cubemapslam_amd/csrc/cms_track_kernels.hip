@@ -270,3 +270,105 @@ extern "C" __global__ void __launch_bounds__(1024) k_rot_filter(CmsRotFilterArgs
   __syncthreads();
   if (tid == 0 && a.n_matches) a.n_matches[f] = s_n;
 }
+
+// ---- ORBMatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBMatcher.cpp:676-794), the matcher of
+// Tracking::MonocularInitialization.  The window query (level 0 only) is the shared cms_area path; k_init_dist evaluates the Hamming
+// distance of every candidate pair in parallel; k_init_greedy then walks the level-0 key points of F1 in order like the reference does
+// -- a key point of F2 may be taken over by a later, strictly better match, so the loop is inherently sequential in i1 -- with the 64
+// lanes of one wavefront sharing each scan (two smallest keys dist << 16 | position = the sequential scan's best / second best).
+// This runs for the first frames of a sequence only; it is latency, not throughput.
+struct CmsInitArgs {
+  int nq; const int* q_i1;                    // level-0 key points of F1, ascending
+  const int* cand_off; const int* cand_idx;   // CSR from the window query; indices are batch rows of frame b2
+  const uint4* desc1; const uint4* t_desc; const CmsKeyPoint* kp2; int row0, kp_cap;
+  const float* angle1; uint16_t* pair_dist;
+  int n1; int* matches12; float* prev_matched; int* n_matches; int8_t* bin_of;
+  float nnratio; int check_orientation;
+  const int* total; int cap;
+};
+extern "C" __global__ void __launch_bounds__(64) k_init_dist(CmsInitArgs a) {
+  if (*a.total > a.cap) return;
+  const int q = blockIdx.x, i1 = a.q_i1[q];
+  const uint4 q0 = a.desc1[2 * (size_t)i1], q1 = a.desc1[2 * (size_t)i1 + 1];
+  for (int c = a.cand_off[q] + threadIdx.x; c < a.cand_off[q + 1]; c += 64) {
+    const size_t row = (size_t)a.cand_idx[c];
+    a.pair_dist[c] = (uint16_t)track_hamming256(q0, q1, a.t_desc[2 * row], a.t_desc[2 * row + 1]);
+  }
+}
+extern "C" __global__ void __launch_bounds__(64) k_init_greedy(CmsInitArgs a) {
+  extern __shared__ int init_lds[];            // vMatchedDistance [kp_cap] | vnMatches21 [kp_cap]
+  __shared__ int hist[32];
+  int* md = init_lds;
+  int* m21 = init_lds + a.kp_cap;
+  const int lane = threadIdx.x;
+  for (int k = lane; k < a.kp_cap; k += 64) { md[k] = 0x7FFFFFFF; m21[k] = -1; }
+  if (lane < 32) hist[lane] = 0;
+  for (int i = lane; i < a.n1; i += 64) { a.matches12[i] = -1; a.bin_of[i] = -1; }
+  __syncthreads();
+  if (*a.total > a.cap) return;
+  int nmatches = 0;
+  for (int q = 0; q < a.nq; ++q) {
+    const int i1 = a.q_i1[q], c0 = a.cand_off[q], c1 = a.cand_off[q + 1];
+    if (c0 == c1) continue;
+    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;                 // the two smallest keys this lane has seen
+    for (int c = c0 + lane; c < c1; c += 64) {
+      const int i2 = a.cand_idx[c] - a.row0;
+      const unsigned dist = a.pair_dist[c];
+      if (md[i2] <= (int)dist) continue;                         // prevent several features of F1 from mapping to one of F2 (:720-722)
+      const unsigned key = (dist << 16) | (unsigned)(c - c0);
+      if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+    }
+    for (int o = 32; o > 0; o >>= 1) {                           // merge the lanes' pairs of smallest keys
+      const unsigned o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+      const unsigned lo = min(k1, o1), hi = max(k1, o1);
+      k2 = min(hi, min(k2, o2)); k1 = lo;
+    }
+    if (k1 == 0xFFFFFFFFu) continue;
+    const int bestDist = (int)(k1 >> 16);
+    const int bestDist2 = k2 == 0xFFFFFFFFu ? 0x7FFFFFFF : (int)(k2 >> 16);
+    if (bestDist <= 50 && (float)bestDist < __fmul_rn((float)bestDist2, a.nnratio)) {      // TH_LOW, mfNNratio (:733-739)
+      const int row = a.cand_idx[c0 + (int)(k1 & 0xFFFFu)], i2 = row - a.row0;
+      const int old = m21[i2];
+      __syncthreads();                                           // every lane has read the old state before lane 0 rewrites it
+      if (lane == 0) {
+        if (old >= 0) a.matches12[old] = -1;
+        a.matches12[i1] = i2; m21[i2] = i1; md[i2] = bestDist;
+        if (a.check_orientation) {
+          float rot = __fsub_rn(a.angle1[i1], a.kp2[row].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 12));
+          if (bin == 30) bin = 0;
+          ++hist[bin];                                           // the entry stays even if the match is taken over later (:750-759)
+          a.bin_of[i1] = (int8_t)bin;
+        }
+      }
+      nmatches += old >= 0 ? 0 : 1;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+  if (a.check_orientation) {
+    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    for (int b = 0; b < 30; ++b) {
+      const int s = hist[b];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = b; }
+      else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = b; }
+      else if (s > max3) { max3 = s; i3 = b; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) i3 = -1;
+    int removed = 0;
+    for (int i = lane; i < a.n1; i += 64) {
+      const int b = a.bin_of[i];
+      if (b < 0 || b == i1 || b == i2 || b == i3) continue;
+      if (a.matches12[i] >= 0) { a.matches12[i] = -1; ++removed; }
+    }
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    nmatches -= removed;
+  }
+  for (int i = lane; i < a.n1; i += 64) {
+    const int m = a.matches12[i];
+    if (m >= 0) { const CmsKeyPoint kp = a.kp2[a.row0 + m]; a.prev_matched[2 * i] = kp.x; a.prev_matched[2 * i + 1] = kp.y; }
+  }
+  if (lane == 0) *a.n_matches = nmatches;
+}

@@ -218,7 +218,8 @@ int cms_features_in_area_batch_device(cms_ctx* ctx, int nq, const void* d_qframe
  * cms_is_in_frustum_device also writes the window of every point (qr < 0: not in view) for cms_features_in_area_batch_device;
  * cms_search_local_points_device takes that CSR (indices = batch rows), mp_off[B+1] (map points grouped by frame, list order
  * inside a frame), scratch pair_dist (2 bytes per candidate) and kp_mp over all batch rows; mp_match = batch row or -1.
- * Limit: at most 4096 key points per frame (CMS_ERR_UNSUPPORTED); any number of map points per frame (a thread of the greedy kernel
+ * Limit: at most 4096 key points per frame for the greedy projection searches (CMS_ERR_UNSUPPORTED; the frame grid itself and
+ * cms_search_for_initialization take up to 16383, i.e. the 3 x nFeatures extractor); any number of map points per frame (a thread of the greedy kernel
  * takes every 1024th point of its frame). */
 int cms_area_set_descriptors(cms_ctx* ctx, int b, int n, const uint8_t* desc);
 /* ORBMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBMatcher.cpp:130-251), the matcher of
@@ -232,6 +233,13 @@ int cms_area_set_descriptors(cms_ctx* ctx, int b, int n, const uint8_t* desc);
 int cms_search_by_projection(cms_ctx* ctx, int b, const float* pose12, int nlast, const uint8_t* valid, const float* Xw, const int* octave,
                              const float* angle, const uint8_t* mp_desc, float th, int check_orientation, int th_high, int nkp, int* kp_mp,
                              int* match, int* n_matches);
+/* ORBMatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize)
+ * (include/ORBMatcher.h:58, src/ORBMatcher.cpp:676-794), the matcher of Tracking::MonocularInitialization (Tracking.cpp:428-429:
+ * ORBMatcher(0.9, true), window 100).  F2 = frame slot b2 on the device (cms_area_grid first), F1 = the caller's key points and
+ * descriptors.  Level-0 key points of F1 only; a key point of F2 is taken over by a later strictly better match; rotation histogram
+ * over every accepted match; prev_matched (n1 x 2 floats = vbPrevMatched) is updated for the matched key points. */
+int cms_search_for_initialization(cms_ctx* ctx, int b2, int n1, const cms_keypoint* kps1, const uint8_t* desc1, float* prev_matched,
+                                  int window_size, float nnratio, int check_orientation, int* matches12, int* n_matches);
 int cms_project_last_frame_device(cms_ctx* ctx, int n, const void* d_qframe, const void* d_pose12, const void* d_valid, const void* d_Xw,
                                   const void* d_oct, float th, void* d_qx, void* d_qy, void* d_qr, void* d_qmin, void* d_qmax);
 int cms_rotation_filter_device(cms_ctx* ctx, int B, const void* d_mp_off, const void* d_last_angle, void* d_kp_mp, void* d_mp_match,

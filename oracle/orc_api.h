@@ -145,6 +145,11 @@ int  orc_search_by_projection_frames(const orc_camera* cam, const float* Rcw, co
                                      const int* koct, const float* kangle, const uint8_t* kdesc, const float* scale_factors, int nlast,
                                      const uint8_t* valid, const float* Xw, const int* loct, const float* langle, const uint8_t* mp_desc,
                                      float th, int check_orientation, int th_high, int* kp_mp, int* match);
+/* ORBMatcher::SearchForInitialization (ORBMatcher.cpp:676-794); orc_track.cpp */
+int  orc_search_for_initialization(const orc_camera* cam, int n1, const float* k1x, const float* k1y, const int* k1oct, const float* k1angle,
+                                   const uint8_t* desc1, int n2, const float* k2x, const float* k2y, const int* k2oct, const float* k2angle,
+                                   const uint8_t* desc2, float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                   int* matches12);
 
 /* ---- ORBMatcher (ORBMatcher.cpp) ---- */
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);

@@ -185,3 +185,79 @@ extern "C" int orc_search_by_projection_frames(const orc_camera* cam, const floa
   }
   return nmatches;
 }
+
+// ORBMatcher::SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBMatcher.cpp:676-794), the
+// matcher of Tracking::MonocularInitialization (Tracking.cpp:428-429: ORBMatcher(0.9, true), windowSize 100).  Level-0 key points of F1
+// only (:693-696); candidates = F2.GetFeaturesInArea(prev_matched[i1], windowSize, 0, 0); a candidate already matched at a distance
+// <= this one is skipped (:720-722); accepted if bestDist <= TH_LOW (50) and bestDist < (float)bestDist2 * nnratio (:736-739); a key
+// point of F2 that was matched before is taken over (:741-745); the rotation histogram keeps the i1 of every accepted match, also of
+// those taken over later (:750-759), and the filter clears what is still matched (:763-783); finally vbPrevMatched follows the
+// matches (:786-789).  matches12: n1 ints (index in F2 or -1); prev_matched: n1 x 2 floats, in/out.  Returns nmatches.
+extern "C" int orc_search_for_initialization(const orc_camera* cam, int n1, const float* k1x, const float* k1y, const int* k1oct, const float* k1angle,
+                                             const uint8_t* desc1, int n2, const float* k2x, const float* k2y, const int* k2oct, const float* k2angle,
+                                             const uint8_t* desc2, float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                             int* matches12) {
+  const int HISTO_LENGTH = 12, TH_LOW = 50;
+  const int nBins = (int)std::ceil(360.0f / HISTO_LENGTH);
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<std::vector<int>> rotHist(nBins);
+  int nmatches = 0;
+  for (int i = 0; i < n1; ++i) matches12[i] = -1;
+  std::vector<int> vMatchedDistance((size_t)n2, 0x7FFFFFFF), vnMatches21((size_t)n2, -1);
+  // the windows do not depend on the matching state: all GetFeaturesInArea calls first
+  std::vector<float> qx, qy, qr;
+  std::vector<int> lo, hi, qi;
+  for (int i1 = 0; i1 < n1; ++i1) {
+    if (k1oct[i1] > 0) continue;
+    qx.push_back(prev_matched[2 * i1]); qy.push_back(prev_matched[2 * i1 + 1]); qr.push_back((float)window_size); lo.push_back(0); hi.push_back(0); qi.push_back(i1);
+  }
+  const int nq = (int)qi.size();
+  std::vector<int> off((size_t)nq + 1, 0), idx((size_t)256 * nq + 1024);
+  const int tot = orc_features_in_area(cam, n2, k2x, k2y, k2oct, nq, qx.data(), qy.data(), qr.data(), lo.data(), hi.data(), off.data(), idx.data(), (int)idx.size());
+  if (tot > (int)idx.size()) {
+    idx.resize((size_t)tot);
+    orc_features_in_area(cam, n2, k2x, k2y, k2oct, nq, qx.data(), qy.data(), qr.data(), lo.data(), hi.data(), off.data(), idx.data(), (int)idx.size());
+  }
+  for (int q = 0; q < nq; ++q) {
+    const int i1 = qi[q];
+    if (off[q + 1] == off[q]) continue;
+    int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx2 = -1;
+    for (int c = off[q]; c < off[q + 1]; ++c) {
+      const int i2 = idx[c];
+      const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW) {
+      if ((float)bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; --nmatches; }
+        matches12[i1] = bestIdx2; vnMatches21[bestIdx2] = i1; vMatchedDistance[bestIdx2] = bestDist; ++nmatches;
+        if (check_orientation) {
+          float rot = k1angle[i1] - k2angle[bestIdx2];
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == nBins) bin = 0;
+          rotHist[bin].push_back(i1);
+        }
+      }
+    }
+  }
+  if (check_orientation) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < nBins; ++i) {
+      const int s = (int)rotHist[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; } else if (max3 < 0.1f * (float)max1) ind3 = -1;
+    for (int i = 0; i < nBins; ++i) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int i1 : rotHist[i]) if (matches12[i1] >= 0) { matches12[i1] = -1; --nmatches; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; ++i1)
+    if (matches12[i1] >= 0) { prev_matched[2 * i1] = k2x[matches12[i1]]; prev_matched[2 * i1 + 1] = k2y[matches12[i1]]; }
+  return nmatches;
+}

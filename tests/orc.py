@@ -437,3 +437,18 @@ def search_by_projection_frames(cam, Rcw, tcw, kx, ky, koct, kangle, kdesc, sf, 
     n = L.orc_search_by_projection_frames(C.byref(cam), _p(a[0]), _p(a[1]), len(k[0]), *[_p(v) for v in k], len(l[0]), *[_p(v) for v in l], th, int(check_ori),
                                           th_high, _p(kp_mp), _p(match))
     return match, n
+
+
+def search_for_initialization(cam, k1, d1, k2, d2, prev_matched, window=100, nnratio=0.9, check_ori=True):
+    """ORBMatcher::SearchForInitialization (ORBMatcher.cpp:676-794); k1 / k2: key-point records (x, y, octave, angle), prev_matched (n1, 2) float32
+    updated in place -> (matches12, nmatches)"""
+    L = lib()
+    L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    f32 = lambda a: np.ascontiguousarray(a, np.float32); i32 = lambda a: np.ascontiguousarray(a, np.int32); u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+    a1 = [f32(k1["x"]), f32(k1["y"]), i32(k1["octave"]), f32(k1["angle"]), u8(d1)]
+    a2 = [f32(k2["x"]), f32(k2["y"]), i32(k2["octave"]), f32(k2["angle"]), u8(d2)]
+    assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and prev_matched.shape == (len(k1), 2)
+    m12 = np.full(len(k1), -1, np.int32)
+    n = L.orc_search_for_initialization(C.byref(cam), len(k1), *[_p(v) for v in a1], len(k2), *[_p(v) for v in a2], _p(prev_matched), int(window), float(nnratio),
+                                        int(check_ori), _p(m12))
+    return m12, n

@@ -890,6 +890,49 @@ def test_search_by_projection_frames_matches_oracle():
         ctx.close()
 
 
+def test_search_for_initialization_matches_oracle():
+    """ORBMatcher::SearchForInitialization (ORBMatcher.cpp:676-794) on the device against the oracle: match lists, counts and the updated
+    vbPrevMatched, with and without the rotation histogram, on synthetic pairs with competing near-duplicates (take-over path) and on
+    two consecutive EXTRACTED frames of the 3 x nFeatures initialisation extractor (Tracking.cpp:95-96, 145-148)."""
+    import test_oracle_track as tot
+    F = 350
+    camd = synth.camera("lafida", F)
+    ocam = orc.make_camera(camd)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=2)
+    for seed, check, rot, window in ((21, True, 20.0, 100), (22, False, 0.0, 100), (23, True, 0.0, 40), (24, True, 5.0, 100)):
+        k1, d1, k2, d2 = tot._init_pair(F, 1200, seed, rot_deg=rot)
+        ctx.area_set_keypoints(1, k2); ctx.area_set_descriptors(1, d2)
+        ctx.area_set_keypoints(0, k2[:1]); ctx.area_set_descriptors(0, d2[:1])
+        ctx.area_grid(2)
+        prev_w = np.stack([k1["x"], k1["y"]], 1).astype(np.float32); prev_g = prev_w.copy()
+        want_m, want_n = orc.search_for_initialization(ocam, k1, d1, k2, d2, prev_w, window, 0.9, check)
+        got_m, got_n = ctx.search_for_initialization(1, k1, d1, prev_g, window, 0.9, check)
+        assert got_n == want_n and np.array_equal(got_m, want_m), (seed, got_n, want_n, int((got_m != want_m).sum()))
+        assert np.array_equal(prev_g.view(np.uint32), prev_w.view(np.uint32))
+        assert want_n > 100
+    ctx.close()
+    # extracted frames, initialisation extractor (3 x nFeatures), frame 1 is frame 0 drifted by a few pixels
+    F = 450
+    camd = synth.camera("lafida", F)
+    ocam = orc.make_camera(camd)
+    nf = 3 * camd["nfeatures"]
+    ctx = api.Context(camd, nfeatures=nf, max_batch=2)
+    mask = synth.cubemap_valid_mask(camd)
+    ctx.set_mask(mask)
+    big = synth.texture(camd["Ih"] + 16, camd["Iw"] + 16, 77)
+    frames = np.stack([big[:camd["Ih"], :camd["Iw"]], big[3:3 + camd["Ih"], 5:5 + camd["Iw"]]]).copy()
+    ctx.upload(frames); ctx.process(2, True); ctx.sync()
+    (k1, d1), (k2, d2) = ctx.fetch(0), ctx.fetch(1)
+    assert len(k1) > 2000 and (k1["octave"] == 0).sum() > 500
+    ctx.area_grid(2)
+    prev_w = np.stack([k1["x"], k1["y"]], 1).astype(np.float32); prev_g = prev_w.copy()
+    want_m, want_n = orc.search_for_initialization(ocam, k1, d1, k2, d2, prev_w, 100, 0.9, True)
+    got_m, got_n = ctx.search_for_initialization(1, k1, d1, prev_g, 100, 0.9, True)
+    assert got_n == want_n and np.array_equal(got_m, want_m) and np.array_equal(prev_g, prev_w), (got_n, want_n)
+    assert want_n >= 100                      # Tracking.cpp:432: initialisation needs at least 100 matches
+    ctx.close()
+
+
 def test_product_reproduces_golden_vectors():
     """the HIP path against the committed regression vectors (tests/golden/oracle_v1.npz) directly -- no live oracle in between"""
     import sys

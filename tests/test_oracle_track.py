@@ -130,3 +130,108 @@ def test_search_by_projection_frames_against_python_loop():
         assert nm == (match >= 0).sum() and nm > 300
         if check:
             assert nm < (want >= 0).sum() + 10
+
+
+def _init_pair(F, n, seed, shift=(7.0, -4.0), rot_deg=0.0):
+    """two frames of level-0-heavy key points: F2 = F1 moved by `shift` px with descriptor noise, plus unrelated key points in both"""
+    rng = np.random.default_rng(seed)
+    kx, ky, ko = te._keypoints(F, n, seed)
+    ko = np.where(rng.uniform(size=len(kx)) < 0.7, 0, ko).astype(np.int32)          # most at level 0 (only those are matched)
+    kd = synth.descriptors(len(kx), seed + 1)
+    ka = rng.uniform(0, 360, len(kx)).astype(np.float32)
+    k1 = np.zeros(len(kx), api_kp()); k1["x"] = kx; k1["y"] = ky; k1["octave"] = ko; k1["angle"] = ka
+    keep = rng.uniform(size=len(kx)) < 0.8
+    k2 = k1[keep].copy()
+    k2["x"] = (k2["x"] + np.float32(shift[0]) + rng.normal(0, 1.0, keep.sum())).astype(np.float32)
+    k2["y"] = (k2["y"] + np.float32(shift[1]) + rng.normal(0, 1.0, keep.sum())).astype(np.float32)
+    k2["angle"] = np.mod(k2["angle"] + np.float32(rot_deg) + rng.normal(0, 3.0, keep.sum()).astype(np.float32), np.float32(360)).astype(np.float32)
+    flip = rng.uniform(size=(keep.sum(), 32)) < 0.04                                  # ~10 flipped bits per descriptor
+    d2 = kd[keep] ^ (flip * rng.integers(1, 255, size=(keep.sum(), 32))).astype(np.uint8)
+    # a few near-duplicates in F2 competing for the same F1 key point, and strangers
+    ndup = len(k2) // 6
+    dup = k2[:ndup].copy(); dup["x"] += np.float32(3.0)
+    ddup = d2[:ndup] ^ (rng.uniform(size=(ndup, 32)) < 0.02).astype(np.uint8)
+    ex, ey, eo = te._keypoints(F, n // 5, seed + 7)
+    extra = np.zeros(len(ex), api_kp()); extra["x"] = ex; extra["y"] = ey; extra["octave"] = 0; extra["angle"] = rng.uniform(0, 360, len(ex))
+    k2 = np.concatenate([k2, dup, extra]); d2 = np.concatenate([d2, ddup, synth.descriptors(len(ex), seed + 9)])
+    W = 3 * F
+    ok = (k2["x"] > 1) & (k2["x"] < W - 2) & (k2["y"] > 1) & (k2["y"] < W - 2) & (synth.face_of_pixel(F, k2["x"].astype(np.float64), k2["y"].astype(np.float64)) >= 0)
+    perm = rng.permutation(int(ok.sum()))
+    return k1, kd, np.ascontiguousarray(k2[ok][perm]), np.ascontiguousarray(d2[ok][perm])
+
+
+def api_kp():
+    return np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])
+
+
+def _init_python(cam, k1, d1, k2, d2, prev, window, nnratio, check):
+    """literal replay of ORBMatcher.cpp:676-794 over the oracle's own GetFeaturesInArea lists"""
+    n1, n2 = len(k1), len(k2)
+    m12 = np.full(n1, -1, np.int32); m21 = np.full(n2, -1, np.int64); md = np.full(n2, 2**31 - 1, np.int64)
+    hist = [[] for _ in range(30)]
+    sel = np.flatnonzero(k1["octave"] <= 0)
+    off, idx = orc.features_in_area(cam, k2["x"], k2["y"], k2["octave"], prev[sel, 0], prev[sel, 1], np.full(len(sel), window, np.float32),
+                                    np.zeros(len(sel), np.int32), np.zeros(len(sel), np.int32), cap=400 * len(sel) + 1024)
+    nm = 0
+    for q, i1 in enumerate(sel):
+        best = best2 = 2**31 - 1; bi = -1
+        for i2 in idx[off[q]:off[q + 1]]:
+            d = int(np.unpackbits(d1[i1] ^ d2[i2]).sum())
+            if md[i2] <= d:
+                continue
+            if d < best:
+                best2 = best; best = d; bi = i2
+            elif d < best2:
+                best2 = d
+        if best <= 50 and np.float32(best) < np.float32(best2) * np.float32(nnratio):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1; nm -= 1
+            m12[i1] = bi; m21[bi] = i1; md[bi] = best; nm += 1
+            if check:
+                rot = np.float32(k1["angle"][i1]) - np.float32(k2["angle"][bi])
+                if rot < 0:
+                    rot += np.float32(360)
+                b = int(np.floor(float(np.float32(rot) * np.float32(1.0 / 12)) + 0.5))
+                hist[0 if b == 30 else b].append(i1)
+    if check:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda b: (-sizes[b], b))
+        m1, m2, m3 = sizes[order[0]], sizes[order[1]], sizes[order[2]]
+        keep = {order[0]}
+        if m2 >= np.float32(0.1) * np.float32(m1):
+            keep.add(order[1])
+            if m3 >= np.float32(0.1) * np.float32(m1):
+                keep.add(order[2])
+        for b in range(30):
+            if b not in keep:
+                for i1 in hist[b]:
+                    if m12[i1] >= 0:
+                        m12[i1] = -1; nm -= 1
+    out_prev = prev.copy()
+    for i1 in range(n1):
+        if m12[i1] >= 0:
+            out_prev[i1] = (k2["x"][m12[i1]], k2["y"][m12[i1]])
+    return m12, nm, out_prev
+
+
+def test_search_for_initialization_against_python_loop():
+    """ORBMatcher::SearchForInitialization (ORBMatcher.cpp:676-794): level-0 only, take-over of a key point by a strictly better match,
+    histogram entries of taken-over matches, vbPrevMatched update -- oracle vs a literal Python replay"""
+    F = 350
+    cam = orc.make_camera(synth.camera("lafida", F))
+    for seed, check, rot in ((21, True, 20.0), (22, False, 0.0), (23, True, 0.0)):
+        k1, d1, k2, d2 = _init_pair(F, 1200, seed, rot_deg=rot)
+        prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)          # Tracking.cpp:404-406: mvbPrevMatched = the first frame's key points
+        want_m, want_n, want_prev = _init_python(cam, k1, d1, k2, d2, prev, 100, 0.9, check)
+        got_prev = prev.copy()
+        got_m, got_n = orc.search_for_initialization(cam, k1, d1, k2, d2, got_prev, 100, 0.9, check)
+        assert np.array_equal(got_m, want_m) and got_n == want_n == (want_m >= 0).sum(), (seed, got_n, want_n)
+        assert np.array_equal(got_prev, want_prev)
+        assert want_n > 150
+        assert (got_m[k1["octave"] > 0] == -1).all()
+        # matches are one to one
+        u = got_m[got_m >= 0]
+        assert len(np.unique(u)) == len(u)
+    # a second call continues from the updated vbPrevMatched (Tracking.cpp:428-429 calls it once per frame until initialisation succeeds)
+    m2, n2 = orc.search_for_initialization(cam, k1, d1, k2, d2, got_prev, 100, 0.9, True)
+    assert n2 >= got_n - 5
