@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-streaming-pass", action="store_true", help="skip the second timed pass with inputs streamed from pinned host memory")
     ap.add_argument("--verify-windows", type=int, default=3, help="local-BA windows checked against the CPU oracle after the timed region (rank 0)")
+    ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
     return ap.parse_args(argv)
 
@@ -562,6 +563,24 @@ def main():
                          (n, 1e3 * t_ext / n, 1e3 * t_match, 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, len(cpu_ba_ms), 1e3 * t_ba, args.ba_every),
                "host_cores_available": os.cpu_count()}
 
+    # ---- single stream, closed loop (configs[2] the way the reference runs it: one frame after the other, matches feed the pose feed the
+    # next projection; cubemapslam_amd/harness.py, parity in tests/test_gpu_harness.py) next to the batch figure above
+    closed = None
+    if rank == 0 and world == 1 and args.closed_loop_frames >= 8 and not front:
+        from cubemapslam_amd import harness
+        fr_cl, gt_cl = harness.render_sequence(camd, args.closed_loop_frames)
+        be = harness.GpuBackend(camd, mask, device=local_rank)
+        harness.run_sequence(camd, be, fr_cl[:6], gt_cl[:6])                     # warm-up
+        trk, secs = harness.run_sequence(camd, be, fr_cl, gt_cl)
+        be.close()
+        tr = [s_ for s_, r in zip(secs, trk.log) if r.get("stage") == "track" and "ba_iterations" not in r]
+        kfr = [s_ for s_, r in zip(secs, trk.log) if "ba_iterations" in r]
+        closed = {"frames": len(secs), "state": trk.state, "frames_per_s": round(len(secs) / sum(secs), 1),
+                  "median_ms_tracked_frame": round(1e3 * float(np.median(tr)), 3) if tr else None,
+                  "median_ms_key_frame_with_local_ba": round(1e3 * float(np.median(kfr)), 3) if kfr else None,
+                  "mean_inliers": round(float(np.mean([r["n_inliers"] for r in trk.log if "n_inliers" in r])), 1) if trk.state == "ok" else None,
+                  "note": "ray-cast box-room stream through the harness, one frame at a time through the host-buffer C-ABI entries; Python glue included"}
+
     if rank == 0 and args.save_trajectory and last["traj"] is not None:
         # rank 0's assembled trajectory of the last step in the reference's TUM format (System.cpp:238-268)
         tr = last["traj"]
@@ -594,7 +613,7 @@ def main():
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
                        "extractor_vs_survey_bytes": extractor,
                        "ba_windows_per_step": n_ba, "ba_groups": n_grp, "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
-                       "ba_check": ba_check, "with_input_streaming": streamed},
+                       "ba_check": ba_check, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

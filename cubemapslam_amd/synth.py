@@ -400,3 +400,93 @@ def candidate_lists(nq, nt, mean_cand, seed):
     off[1:] = np.cumsum(counts)
     idx = rs.randint(0, nt, size=int(off[-1])).astype(np.int32)
     return off, idx
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Ray-cast box-room renderer: a 6 x 3 x 4 m room with a seeded procedural texture on every wall, seen by
+# the fisheye camera model from a smooth trajectory.  Every pixel's ray comes from CamModelGeneral::ImgToWorld (include/CamModelGeneral.h:
+# 262-280), is intersected with the six walls and samples the wall texture bilinearly.  Ground truth (poses, the 3-D point behind any
+# cubemap pixel) comes with it: the closed-loop harness seeds its map points from it instead of running the Initializer / triangulation.
+def img_to_world(cam, u, v):
+    """CamModelGeneral::ImgToWorld: unit ray (camera frame, z forward) through fisheye pixel (u, v)."""
+    inv_aff = cam["c"] - cam["d"] * cam["e"]
+    ut = u - cam["u0"]; vt = v - cam["v0"]
+    x = (ut - cam["d"] * vt) / inv_aff
+    y = (-cam["e"] * ut + cam["c"] * vt) / inv_aff
+    z = -_horner(list(cam["pol"]), np.sqrt(x * x + y * y))
+    n = np.sqrt(x * x + y * y + z * z)
+    return np.stack([x / n, y / n, z / n], -1)
+
+
+ROOM_HALF = np.array([3.0, 1.5, 2.0])          # x (right), y (down), z (forward)
+_ROOM_PPM = 150.0                              # wall texture resolution, pixels per metre
+
+
+def room_scene(seed=0xC0FFEE):
+    """wall textures of the box room: for axis a and side s the wall spans the two other axes"""
+    walls = {}
+    for a in range(3):
+        o = [i for i in range(3) if i != a]
+        h = int(2 * ROOM_HALF[o[1]] * _ROOM_PPM) + 2; w = int(2 * ROOM_HALF[o[0]] * _ROOM_PPM) + 2
+        for s in (0, 1):
+            walls[(a, s)] = texture(h, w, (seed + 17 * a + 5 * s) & 0x7FFFFFFF).astype(np.float32)
+    return dict(walls=walls, seed=seed)
+
+
+def room_raycast(origin, dirs):
+    """first wall hit of rays origin + t * dirs (origin inside the room): (points, axis, side, t)"""
+    o = np.asarray(origin, np.float64)
+    d = np.asarray(dirs, np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bound = np.where(d > 0, ROOM_HALF, -ROOM_HALF)
+        t = np.where(d != 0, (bound - o) / d, np.inf)
+    axis = np.argmin(t, -1)
+    tt = np.take_along_axis(t, axis[..., None], -1)[..., 0]
+    P = o + d * tt[..., None]
+    side = (np.take_along_axis(d, axis[..., None], -1)[..., 0] > 0).astype(np.int64)
+    return P, axis, side, tt
+
+
+def room_pose(i, n=300):
+    """camera i of a smooth n-frame loop inside the room: (Rcw, tcw) world -> camera, float64"""
+    a = 2 * np.pi * i / n
+    cw = np.array([1.2 * np.cos(a), 0.15 * np.sin(2 * a), 0.7 * np.sin(a)])
+    yaw = a + np.pi / 2 + 0.15 * np.sin(3 * a)             # looking along the direction of travel, swaying a little
+    Rwc = _rot([0, 1, 0], -yaw) @ _rot([1, 0, 0], 0.08 * np.sin(2 * a)) @ _rot([0, 0, 1], 0.05 * np.sin(a))
+    Rcw = Rwc.T
+    return Rcw, -Rcw @ cw
+
+
+def render_fisheye(cam, scene, Rcw, tcw):
+    """the fisheye image (Ih x Iw, uint8) the camera at pose (Rcw, tcw) sees in the room"""
+    Ih, Iw = cam["Ih"], cam["Iw"]
+    vv, uu = np.meshgrid(np.arange(Ih, dtype=np.float64), np.arange(Iw, dtype=np.float64), indexing="ij")
+    rays_c = img_to_world(cam, uu, vv)
+    Rwc = np.asarray(Rcw, np.float64).T
+    cw = -Rwc @ np.asarray(tcw, np.float64)
+    rays_w = rays_c @ Rwc.T
+    P, axis, side, _ = room_raycast(cw, rays_w)
+    img = np.zeros((Ih, Iw), np.float32)
+    for a in range(3):
+        o = [i for i in range(3) if i != a]
+        for s in (0, 1):
+            m = (axis == a) & (side == s)
+            if not m.any():
+                continue
+            tex = scene["walls"][(a, s)]
+            x = (P[m][:, o[0]] + ROOM_HALF[o[0]]) * _ROOM_PPM; y = (P[m][:, o[1]] + ROOM_HALF[o[1]]) * _ROOM_PPM
+            x = np.clip(x, 0, tex.shape[1] - 1.001); y = np.clip(y, 0, tex.shape[0] - 1.001)
+            x0 = x.astype(np.int64); y0 = y.astype(np.int64); fx = (x - x0).astype(np.float32); fy = (y - y0).astype(np.float32)
+            img[m] = (tex[y0, x0] * (1 - fx) + tex[y0, x0 + 1] * fx) * (1 - fy) + (tex[y0 + 1, x0] * (1 - fx) + tex[y0 + 1, x0 + 1] * fx) * fy
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def room_points_behind_pixels(F, Rcw, tcw, px, py):
+    """ground truth: the room point seen at cubemap pixel (px, py) from pose (Rcw, tcw) -> (valid, Xw float64)"""
+    face, ray = pixel_to_ray(F, px, py)
+    Rwc = np.asarray(Rcw, np.float64).T
+    cw = -Rwc @ np.asarray(tcw, np.float64)
+    ok = face >= 0
+    ray = np.where(ok[:, None], ray, np.array([0.0, 0.0, 1.0]))
+    P, _, _, _ = room_raycast(cw, ray @ Rwc.T)
+    return ok, P

@@ -1,0 +1,52 @@
+"""configs[2] of BASELINE.json (Lafida cam0 full pipeline, face = 550) as a closed loop: the same rendered stream through the harness
+(cubemapslam_amd/harness.py: Tracking.cpp's order of extraction, initialisation matcher, motion-model and local-map searches, pose
+optimisation, local BA) once with the product (every step a C-ABI call into the HIP library) and once with the CPU oracle.  Matches
+feed pose optimisation feed the next frame's projection, so a wrong index anywhere sends the two runs apart: parity = identical match
+index lists frame by frame, identical inlier counts and BA iteration counts, poses within the BA tolerance."""
+import numpy as np
+import pytest
+from cubemapslam_amd import harness, synth
+from oracle_backend import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+def test_closed_loop_product_equals_oracle_frame_by_frame():
+    camd = synth.camera("lafida", 550)
+    mask = synth.cubemap_valid_mask(camd)
+    frames, gts = harness.render_sequence(camd, 14)
+    kw = dict(kf_every=4, ba_window=6, new_points_per_kf=400)
+    gpu = harness.GpuBackend(camd, mask)
+    ora = OracleBackend(camd, mask)
+    sf_g, is_g = gpu.scale_factors(); sf_o, is_o = ora.scale_factors()
+    assert np.array_equal(sf_g.view(np.uint32), sf_o.view(np.uint32)) and np.array_equal(is_g.view(np.uint32), is_o.view(np.uint32))
+    tg, secs = harness.run_sequence(camd, gpu, frames, gts, **kw)
+    to, _ = harness.run_sequence(camd, ora, frames, gts, **kw)
+    gpu.close()
+    assert tg.state == to.state == "ok"
+    assert len(tg.log) == len(to.log) == 14
+    n_ba = 0
+    worst = 0.0
+    for a, b in zip(tg.log, to.log):
+        f = a["frame"]
+        assert a["stage"] == b["stage"] and a["nkp"] == b["nkp"], (f, a["stage"], b["stage"], a["nkp"], b["nkp"])
+        for key in ("init_matches", "mm_match", "lm_match"):
+            if key in b:
+                assert key in a and np.array_equal(a[key], b[key]), (f, key, int((a[key] != b[key]).sum()))
+        for key in ("n_init", "n_map", "n_mm", "n_mm_inliers", "n_lm", "n_in_view", "n_inliers", "new_points", "ba_edges", "ba_iterations", "ba_outliers", "ba_kfs", "ba_points"):
+            assert a.get(key) == b.get(key), (f, key, a.get(key), b.get(key))
+        for key in ("pose", "pose_after_ba"):
+            if key in b:
+                # the parity bar of the optimisers is 1e-4 relative on the UPDATE (a frame's pose moves by centimetres per optimisation, so
+                # ~1e-6 absolute: the Levenberg loops stop on a chi2 criterion, not at machine precision); what the closed loop must
+                # preserve exactly is what the poses are used for -- the match lists and counts above
+                dmax = float(np.abs(a[key].astype(np.float64) - b[key].astype(np.float64)).max())
+                worst = max(worst, dmax)
+                assert dmax <= 5e-5, (f, key, dmax)
+        n_ba += "ba_iterations" in b
+    assert n_ba == 3 and to.log[1]["n_init"] >= 100 and all(r["n_inliers"] >= 30 for r in to.log[2:])
+    # the two runs' BA inputs already differ in the last float digits (poses above), and a point seen under a small parallax amplifies that
+    # along its ray: the map is compared statistically, the parity of the BA itself is test_gpu_parity.py's business
+    dm = np.linalg.norm(tg.mp_pos.astype(np.float64) - to.mp_pos.astype(np.float64), axis=1)
+    assert tg.mp_pos.shape == to.mp_pos.shape and np.median(dm) <= 1e-5 and np.percentile(dm, 99) <= 1e-3, (np.median(dm), np.percentile(dm, 99), dm.max())
+    print("closed loop: worst pose entry difference %.3g; map points: median %.3g m, 99 %% %.3g m, max %.3g m" % (worst, np.median(dm), np.percentile(dm, 99), dm.max()))
