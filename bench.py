@@ -334,9 +334,13 @@ def main():
     last = {"traj": None, "ba_stats": None, "tri_new": 0}
     acc = {"ba_ms": 0.0, "ba_n": 0}
 
+    # developer knob: queue the mapping side of a step behind the step's extraction (cms_stream_wait_extracted) instead of letting the two
+    # overlap.  Measured: the extractor then runs at 35 % instead of 33 % of its byte roofline inside the step (43 % with no local BA in
+    # the step at all: the FP64 chain also pulls the clocks down), and the step gets 4 % longer -- overlap stays the default
+    serial = os.environ.get("CMS_BENCH_SERIAL_EXTRACT", "") != ""
     def step(i, streaming, keep=False):
         S = sets[i % 2]
-        ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)] if part != "frames" else []
+        ths = []
         if part != "ba":
             po.launch()                 # own stream, overlaps the frame path
             if not streaming:
@@ -344,6 +348,16 @@ def main():
             ctx.process(B, True)        # (streaming: waits on the device for the copy enqueued during the previous step)
             if streaming:
                 ctx.upload_async(sets[(i + 1) % 2].pinned.array)   # next step's frames travel under this step's kernels
+        if part != "frames":
+            if serial and part != "ba":
+                # extraction and the local-BA chain each fill the chip; side by side they only slow each other down.  The mapping side of the
+                # step (CreateNewMapPoints + local BA of every window group) waits on the device for the extraction and overlaps the
+                # tracking kernels (grids, projection searches, pose optimisation) instead
+                for gi, grp in enumerate(groups):
+                    ctx.stream_wait_extracted(tri_ctx[gi].stream)
+                    ctx.stream_wait_extracted(grp[0].stream)
+            ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)]
+        if part != "ba":
             S.enqueue_tracking(ext_stream)
             ctx.sync()
             _, frame_poses, _, _ = po.fetch()

@@ -240,6 +240,12 @@ class Context:
         """staging <- device buffer [B][Ih][fisheye_stride] (inputs resident in HBM), asynchronous on the ctx stream"""
         _chk(lib().cms_frames_upload_device(self.h, C.c_void_p(int(d_ptr)), B), "cms_frames_upload_device")
 
+    def stream_wait_extracted(self, hip_stream):
+        """the given HIP stream waits (on the device) for the extraction of this context's last process() call"""
+        f = lib().cms_stream_wait_extracted
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(f(self.h, C.c_void_p(int(hip_stream))), "cms_stream_wait_extracted")
+
     def upload_wait(self):
         _chk(lib().cms_frames_upload_wait(self.h), "cms_frames_upload_wait")
 

@@ -60,6 +60,7 @@ struct cms_ctx {
   // input streaming (cms_frames_upload_async): the next batch travels on its own stream while the current one is being processed
   hipStream_t copy_stream = nullptr; hipEvent_t ev_upload_done = nullptr, ev_remap_done = nullptr;
   bool upload_pending = false, remap_recorded = false;
+  hipEvent_t ev_extracted = nullptr; bool extracted_recorded = false;   // end of the last cms_frames_process (cms_stream_wait_extracted)
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;          // pinned staging of the one-frame host entries (one copy each way)
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
   // match scratch
@@ -161,6 +162,7 @@ static void cms_ctx_free(cms_ctx* c) {
   if (c->h_fish_stage) (void)hipHostFree(c->h_fish_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int i = 0; i < 8; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+  if (c->ev_extracted) hipEventDestroy(c->ev_extracted);
   if (c->ev_upload_done) hipEventDestroy(c->ev_upload_done);
   if (c->ev_remap_done) hipEventDestroy(c->ev_remap_done);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -501,7 +503,20 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   hipLaunchKernelGGL(k_describe, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
                      (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc);
   if (c->prof) hipEventRecord(c->ev[6], s);
+  if (c->ev_extracted) { HIPCHK(hipEventRecord(c->ev_extracted, s)); c->extracted_recorded = true; }
   HIPCHK(hipGetLastError());
+  return CMS_OK;
+}
+
+// Scheduling aid: make another HIP stream (a mapping-side context's, a local-BA group's) wait on the device until the extraction
+// launched by the last cms_frames_process of `c` has finished.  The extraction kernels and the local-BA chain each fill the chip on their
+// own; run side by side they only slow each other down (the extractor drops from 43 % to 33 % of its byte roofline inside bench.py's
+// step, the step is no shorter), so the mapping side of a step is queued behind the extraction and overlaps the tracking kernels instead.
+extern "C" int cms_stream_wait_extracted(cms_ctx* c, void* hip_stream) {
+  if (!c || !hip_stream) return cms_fail(CMS_ERR_ARG, "cms_stream_wait_extracted: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->ev_extracted) { HIPCHK(hipEventCreateWithFlags(&c->ev_extracted, hipEventDisableTiming)); return CMS_OK; }   // armed from the next process call on
+  if (c->extracted_recorded) HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_extracted, 0));
   return CMS_OK;
 }
 

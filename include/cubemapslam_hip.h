@@ -98,6 +98,9 @@ void* cms_frames_input(cms_ctx* ctx);
 int cms_frames_upload(cms_ctx* ctx, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B);
 int cms_frames_upload_async(cms_ctx* ctx, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B);
 int cms_frames_upload_wait(cms_ctx* ctx);
+/* scheduling aid: `hip_stream` (cms_ctx_stream of a mapping-side context, cms_ba_stream of a window group) waits on the device for the
+ * extraction of ctx's last cms_frames_process; the first call only arms the event (takes effect from the next process call on) */
+int cms_stream_wait_extracted(cms_ctx* ctx, void* hip_stream);
 int cms_frames_upload_device(cms_ctx* ctx, const void* d_src, int B);   /* device -> staging copy, [B][Ih][fisheye_stride], async on the ctx stream */
 int cms_host_alloc(void** out, size_t bytes);   /* pinned host memory for cms_frames_upload_async */
 void cms_host_free(void* p);
