@@ -111,6 +111,13 @@ void ORBextractor::operator()(cv::InputArray image, cv::InputArray mask, std::ve
     kp.octave = kps[i].octave;
     keypoints.push_back(kp);
   }
+  if (mbKeepImagePyramid) {                                         // ORBExtractor.h:89: mvImagePyramid of the last call
+    mvImagePyramid.resize(g.nlevels); mvMaskPyramid.resize(g.nlevels);
+    for (int l = 0; l < g.nlevels; ++l) {
+      mvImagePyramid[l].create(g.level_h[l], g.level_w[l], cv::CV_8U);
+      if (cms_debug_level(ctx_, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step) != CMS_OK) throw std::runtime_error(cms_last_error());
+    }
+  }
   if (n == 0) { descriptors.release(); return; }                    // ORBExtractor.cpp:863-864
   descriptors.create(n, 32, cv::CV_8U);
   for (int i = 0; i < n; ++i) std::memcpy(descriptors.ptr<uint8_t>(i), &desc[(size_t)i * 32], 32);

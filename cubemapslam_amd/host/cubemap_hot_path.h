@@ -79,6 +79,13 @@ class ORBextractor {
   std::vector<float> GetScaleSigmaSquares() const { return mvLevelSigma2; }
   std::vector<float> GetInverseScaleSigmaSquares() const { return mvInvLevelSigma2; }
 
+  // ORBExtractor.h:89-90.  The reference keeps the (19-px padded) level images of the last call here; no stage of the hot path reads
+  // them afterwards, so the mirror only fetches them from the device when a caller sets mbKeepImagePyramid -- level l is the
+  // cvRound(W / scale_l)^2 image without the border frame ("19-px REFLECT_101 frame").
+  std::vector<cv::Mat> mvImagePyramid;
+  std::vector<cv::Mat> mvMaskPyramid;      // resized and never filled in the reference either (ORBExtractor.cpp:405)
+  bool mbKeepImagePyramid = false;
+
  protected:
   int nfeatures; double scaleFactor; int nlevels, iniThFAST, minThFAST;
   std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;

@@ -44,6 +44,22 @@ extern "C" int hm_extract(int nfeatures, float scale, int nlevels, int ini_th, i
     }
     return n;)
 }
+// ORBextractor::mvImagePyramid (ORBExtractor.h:89): extract with mbKeepImagePyramid and hand level `level` back (w x h written to wh)
+extern "C" int hm_extract_pyramid_level(int nfeatures, float scale, int nlevels, int ini_th, int min_th, const uint8_t* img, int stride, const uint8_t* mask,
+                                        int mstride, int level, uint8_t* out, int out_stride, int* wh) {
+  HM_TRY(
+    const int W = 3 * CamModelGeneral::GetCamera()->GetCubeFaceWidth();
+    ORBextractor ex(nfeatures, scale, nlevels, ini_th, min_th);
+    ex.mbKeepImagePyramid = true;
+    cv::Mat image(W, W, cv::CV_8U, (void*)img, (size_t)stride), m(W, W, cv::CV_8U, (void*)mask, (size_t)mstride), d;
+    std::vector<cv::KeyPoint> keys;
+    ex(image, m, keys, d);
+    if (level < 0 || level >= (int)ex.mvImagePyramid.size()) return -1;
+    const cv::Mat& lv = ex.mvImagePyramid[level];
+    wh[0] = lv.cols; wh[1] = lv.rows;
+    for (int r = 0; r < lv.rows; ++r) std::memcpy(out + (size_t)r * out_stride, lv.ptr<uint8_t>(r), (size_t)lv.cols);
+    return (int)keys.size();)
+}
 // frame-to-frame SearchByProjection: returns matches; cur_mp[j] receives the matched map-point id or -1
 extern "C" int hm_search_by_projection(int ncur, const cms_keypoint* cur_k, const uint8_t* cur_d, long* cur_mp, int nlast,
                                        const cms_keypoint* last_k, const uint8_t* last_d, const long* last_mp, const float* proj_xy,

@@ -19,6 +19,7 @@ def _host():
     L = C.CDLL(build.HOST_LIB)
     L.hm_last_error.restype = C.c_char_p
     L.hm_extract.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.hm_extract_pyramid_level.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.hm_search_by_projection.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int]
     L.hm_local_ba.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int]
@@ -105,6 +106,13 @@ def test_mirror_remap_extract_match():
         wk, wd = o.extract(ocam, ref, mask)
         assert n == len(wk) and np.array_equal(k[:n].view(np.uint8), wk.view(np.uint8)) and np.array_equal(d[:n], wd)
         outs.append((k[:n].copy(), d[:n].copy()))
+    # ORBextractor::mvImagePyramid (public in the reference, ORBExtractor.h:89): levels of the last call, on request
+    for lvl in (0, 3, 7):
+        want = o.level(lvl)
+        buf = np.zeros((W, W), np.uint8); wh = np.zeros(2, np.int32)
+        n2 = L.hm_extract_pyramid_level(1200, 1.2, 8, 20, 7, _p(ref), W, _p(mask), W, lvl, _p(buf), W, _p(wh))
+        assert n2 == n, L.hm_last_error()
+        assert (wh[0], wh[1]) == (want.shape[1], want.shape[0]) and np.array_equal(buf[:wh[1], :wh[0]], want)
     (lk, ld), (ck, cd) = outs
     scales = o.tables()["scale"]
     last_mp = np.arange(len(lk), dtype=np.int64); last_mp[::7] = -1
