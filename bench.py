@@ -318,6 +318,9 @@ def main():
                 st.put(base + i, K)
             jobs_g.append((base, list(range(base + 1, base + tri_nn + 1))))
         tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g)
+        if os.environ.get("CMS_BENCH_SHARED_STREAMS", "") != "":
+            for ba in grp:                   # developer knob: the whole mapping side of a group on ONE stream (cms_ba_set_stream).  Measured
+                ba.set_stream(cg.stream)     # slower (15.9 against 14.4 ms per step): the resets and CreateNewMapPoints then queue behind the group's BA
 
     def ba_worker(grp, gi, keep):
         """one window group of one step; returns (elapsed ms, new map points, per-window stats)"""

@@ -598,6 +598,11 @@ class BundleAdjuster:
     def stream(self):
         return lib().cms_ba_stream(self.h)
 
+    def set_stream(self, hip_stream):
+        f = lib().cms_ba_set_stream
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(f(self.h, C.c_void_p(int(hip_stream))), "cms_ba_set_stream")
+
     def profile_kernel(self, kernel_id):
         """HIP events around one kernel of the grouped driver's rounds (group owned by this handle); 3 = kb_ba_schur_points"""
         _chk(lib().cms_ba_profile_kernel(self.h, kernel_id), "cms_ba_profile_kernel")

@@ -13,7 +13,7 @@
 
 struct cms_ba {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr; bool own_stream = true;
   int K = 0, P = 0, E = 0, np = 0, nblk_e = 0, nblk_p = 0;
   std::vector<int> perm;       // sorted position -> caller's edge index
   std::vector<int> pinv;       // internal point id -> caller's point index (points are permuted into collision-free chunks, see below)
@@ -90,10 +90,21 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->grp_lm_dev) hipFree(b->grp_lm_dev);
   if (b->grp_lm_host) hipHostFree(b->grp_lm_host);
   for (hipEvent_t e : b->prof_ev) hipEventDestroy(e);
-  if (b->stream) hipStreamDestroy(b->stream);
+  if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
   delete b;
 }
 extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullptr; }
+// Let the window run on a stream the caller owns (e.g. cms_ctx_stream of the mapping thread's context, shared by all windows of a group):
+// a process that creates one stream per window ends up with more streams than hardware queues, and streams that share a queue
+// serialise behind each other whether or not they depend on each other.
+extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
+  if (!b || !hip_stream) return cms_fail(CMS_ERR_ARG, "cms_ba_set_stream: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->own_stream) HIPCHK(hipStreamDestroy(b->stream));
+  b->stream = (hipStream_t)hip_stream; b->own_stream = false;
+  return CMS_OK;
+}
 extern "C" int cms_ba_profile_kernel(cms_ba* b, int kernel_id) {
   if (!b || kernel_id < 0 || kernel_id > 7) return cms_fail(CMS_ERR_ARG, "cms_ba_profile_kernel: bad argument");
   b->prof_kernel = kernel_id; b->prof_ms = 0; b->prof_launches = 0;

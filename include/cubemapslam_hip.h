@@ -163,6 +163,9 @@ int cms_ba_optimize(cms_ba* ba, int its_robust, int its_final, const volatile ui
 int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats);
 int cms_ba_read(cms_ba* ba, double* poses, double* points, uint8_t* outlier_flags);
 void* cms_ba_stream(cms_ba* ba);
+/* run this window on a stream the caller owns (shared by the windows of a group, or the mapping context's own stream): keeps the
+ * number of streams of a process below the number of hardware queues */
+int cms_ba_set_stream(cms_ba* ba, void* hip_stream);
 /* developer aid: 100 MHz wall-clock stamps of the last single-window solve kernel (start, assembled, factorised, solved, end) */
 int cms_ba_debug_clocks(cms_ba* ba, long long* out16);
 /* measurement aid (bench.py's roofline of the dominant BA kernel): HIP events on the group's stream around ONE kernel of every round the
