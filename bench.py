@@ -576,8 +576,9 @@ def main():
         cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames remap+extract (%.1f ms/frame), frame-to-frame SearchByProjection (%.2f ms/frame), local-map search "
                          "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), CreateNewMapPoints (%.1f ms per key frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
-                         "oracle/liborc.so, single thread" %
+                         "oracle/liborc.so, single thread (two_threads_like_the_reference: the same timings with local BA on a second core next to tracking, System.cpp:108-127)" %
                          (n, 1e3 * t_ext / n, 1e3 * t_match, 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, len(cpu_ba_ms), 1e3 * t_ba, args.ba_every),
+               "two_threads_like_the_reference": round(1.0 / max(t_ext / n + t_match + t_local + t_pose, (t_ba + t_tri) / args.ba_every), 3),
                "host_cores_available": os.cpu_count()}
 
     # ---- single stream, closed loop (configs[2] the way the reference runs it: one frame after the other, matches feed the pose feed the

@@ -199,6 +199,11 @@ class Context:
         mask = np.ascontiguousarray(mask, np.uint8)
         _chk(lib().cms_set_mask(self.h, _p(mask), mask.strides[0]), "cms_set_mask")
 
+    def set_gaussian_mode(self, column_mode):
+        f = lib().cms_set_gaussian_mode
+        f.argtypes = [C.c_void_p, C.c_int]
+        _chk(f(self.h, int(column_mode)), "cms_set_gaussian_mode")
+
     def remap(self, fisheye, cubemap=None):
         fisheye = np.ascontiguousarray(fisheye, np.uint8)
         if cubemap is None:

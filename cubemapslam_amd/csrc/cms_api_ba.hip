@@ -137,7 +137,15 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
 #define BA_TRY(x) do { int _rc = (x); if (_rc) { cms_ba_destroy(b); return _rc; } } while (0)
 #define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
   BA_TRY(ba_lds_attrs_once(device));
-  BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  {
+    // CMS_BA_STREAM_PRIORITY=low: the window's queue yields to normal-priority queues (the frame path) whenever both have workgroups ready
+    const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
+    int lo = 0, hi = 0;
+    if (pr && pr[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      BA_HIP(hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, lo));
+    else
+      BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  }
   // ---- chunks of the edge-major Schur kernel (cms_ba_schur_edges.hip): whole points, at most 64 edges, in the caller's point order.
   // (Measured and dropped: permuting the points greedily so that no pose pair occurs twice in the same step of a chunk -- the chunks
   // came out 99.7 % full and collision free, and the kernel was no faster: scattered f64 additions run at ~2.7 lanes per clock and CU

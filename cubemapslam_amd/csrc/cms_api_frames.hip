@@ -235,6 +235,7 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   g.list_cap = wCellMax * hCellMax;
   g.cell_cap = (int)align_up((size_t)((wCellMax + 1) / 2) * ((hCellMax + 1) / 2), 8);   // strict 3x3 maxima cannot be 8-adjacent
   g.dbg_stop = getenv("CMS_DBG_FAST_STOP") ? atoi(getenv("CMS_DBG_FAST_STOP")) : 0;
+  g.gauss_column_mode = 0;
   if (wCellMax > 60 || hCellMax > 60) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 60 pixels"); }
   if (orb->scale_factor < 1.01f || orb->scale_factor > 1.9f) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "scaleFactor must be in [1.01, 1.9]"); }
   g.fast_cell_lds = (int)align_up((size_t)g.tile_h * g.tile_stride + (size_t)g.sc_h * g.sc_stride + 2 * (size_t)g.list_cap + 16, 16);
@@ -247,7 +248,16 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   c->mstride = (int)align_up((size_t)W, 64);
   const size_t B = (size_t)max_batch;
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { cms_ctx_free(c); return cms_fail(CMS_ERR_HIP, "hipMalloc " #ptr, _e); } } while (0)
-  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  // CMS_FRAME_STREAM_PRIORITY=high|low (developer knob): dispatch priority of the frame path's queue against the mapping side's
+  hipError_t e;
+  {
+    const char* pr = getenv("CMS_FRAME_STREAM_PRIORITY");
+    int lo = 0, hi = 0;
+    if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo);
+    else
+      e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  }
   if (e != hipSuccess) { cms_ctx_free(c); return cms_fail(CMS_ERR_HIP, "hipStreamCreate", e); }
   for (int i = 0; i < 8; ++i) hipEventCreate(&c->ev[i]);
   ALLOC(c->d_fish, B * c->fish_pitch + 256);
@@ -438,6 +448,15 @@ extern "C" int cms_host_alloc(void** out, size_t bytes) {
   return CMS_OK;
 }
 extern "C" void cms_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+// Which definition of cv::GaussianBlur's 8-bit column pass the descriptors are computed from: 0 (default) the integer formula
+// (sum + 32768) >> 16, 1 the float evaluation of an x86 (SSE2) build of OpenCV <= 3.2, which rounds ties to even.
+// A maintainer with a real OpenCV picks the one that matches it; the two differ on rare pixels by one grey level.
+extern "C" int cms_set_gaussian_mode(cms_ctx* c, int column_mode) {
+  if (!c || column_mode < 0 || column_mode > 1) return cms_fail(CMS_ERR_ARG, "cms_set_gaussian_mode: mode must be 0 or 1");
+  c->g.gauss_column_mode = column_mode;
+  return CMS_OK;
+}
 
 extern "C" int cms_set_mask(cms_ctx* c, const uint8_t* mask, int mstride) {
   if (!c || !mask || mstride < c->g.W) return cms_fail(CMS_ERR_ARG, "cms_set_mask: bad argument");

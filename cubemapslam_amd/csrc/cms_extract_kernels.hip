@@ -766,7 +766,15 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
                    __mul24(49, (int)((e2 & 0xFFFF) + (e4 & 0xFFFF))) + __mul24(55, (int)(e3 & 0xFFFF));
     const int sh = __mul24(18, (int)((e0 >> 16) + (e6 >> 16))) + __mul24(34, (int)((e1 >> 16) + (e5 >> 16))) +
                    __mul24(49, (int)((e2 >> 16) + (e4 >> 16))) + __mul24(55, (int)(e3 >> 16));
-    const int vl = min((sl + 32768) >> 16, 255), vh = min((sh + 32768) >> 16, 255);
+    int vl = min((sl + 32768) >> 16, 255), vh = min((sh + 32768) >> 16, 255);
+    if (g.gauss_column_mode == 1) {
+      // an x86 OpenCV <= 3.2 evaluates the column pass in float with round-half-to-EVEN for the columns its SSE2 loops cover
+      // (x < width & ~3; SURVEY.md Appendix C, oracle/orc_cv.cpp): every product and partial sum is exact in binary32, so the result
+      // differs from the integer formula exactly on ties (sum mod 65536 == 32768) with an even quotient
+      const int x0 = cx - 18 + 2 * cp, xvec = lv.w & ~3;
+      if (x0 < xvec && (sl & 0xFFFF) == 0x8000 && ((sl >> 16) & 1) == 0) vl = min(sl >> 16, 255);
+      if (x0 + 1 < xvec && (sh & 0xFFFF) == 0x8000 && ((sh >> 16) & 1) == 0) vh = min(sh >> 16, 255);
+    }
     *reinterpret_cast<uint16_t*>(blr + r * BS + 2 * cp) = (uint16_t)(vl | (vh << 8));
   }
   WAVE_SYNC();

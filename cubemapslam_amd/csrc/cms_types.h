@@ -40,6 +40,7 @@ struct CmsGeom {
   int fast_cell_lds;          // LDS bytes of one FAST cell (one wavefront); a workgroup holds CMS_FAST_WPB of them
   int skip_zero_cells;        // set per launch: the canvas was produced by k_remap, FAST cells inside the zero corners are skipped
   int dbg_stop;               // developer switch (env CMS_DBG_FAST_STOP): cut k_fast_cells short after phase N, 0 = off
+  int gauss_column_mode;      // 0: integer column pass of the 7x7 Gaussian; 1: SSE2 float column pass of an x86 OpenCV <= 3.2 build (cms_set_gaussian_mode)
   CmsLevel lv[CMS_MAX_LEVELS];
 };
 

@@ -78,6 +78,10 @@ void* cms_ctx_stream(cms_ctx* ctx);  /* hipStream_t of the frame path (for event
  *                    ORBExtractor.cpp:838-926).  *n receives the key-point count; returns CMS_ERR_OVERFLOW if cap is too small. */
 int cms_remap(cms_ctx* ctx, const uint8_t* fisheye, int fstride, uint8_t* cubemap, int cstride);
 int cms_set_mask(cms_ctx* ctx, const uint8_t* mask, int mstride);
+/* cv::GaussianBlur(7x7, sigma 2) in front of the descriptors (ORBExtractor.cpp:907-908): column_mode 0 (default) = the integer column pass
+ * (sum + 32768) >> 16 of OpenCV <= 3.2's generic path, 1 = the float column pass of its SSE2 functor (x86 builds: ties round to even for
+ * the columns x < width & ~3).  OpenCV is not vendored with the reference, so both definitions are offered. */
+int cms_set_gaussian_mode(cms_ctx* ctx, int column_mode);
 int cms_extract(cms_ctx* ctx, const uint8_t* cubemap, int cstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n);
 int cms_remap_extract(cms_ctx* ctx, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n);
 

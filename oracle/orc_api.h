@@ -72,12 +72,15 @@ void orc_fisheye_to_cubemap(const orc_camera* cam, const float* map1, const floa
 void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride,
                        uint8_t* dst, int dw, int dh, int dstride);
 void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* column_mode 0: integer column pass; 1: the SSE2 float column pass of an x86 OpenCV <= 3.2 build (differs on even ties) */
+void orc_gaussian_blur7_mode(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int column_mode);
 /* cv::FAST(img, kps, threshold, nonmaxSuppression=true); out triplets (x, y, score) */
 int  orc_fast(const uint8_t* img, int w, int h, int stride, int threshold, int* out_xys, int cap);
 
 /* ---- ORBextractor (ORBExtractor.cpp) ---- */
 typedef struct orc_orb orc_orb;
 orc_orb* orc_orb_create(const orc_orb_params* p);
+void orc_orb_set_gaussian_mode(orc_orb* o, int column_mode);
 void orc_orb_destroy(orc_orb* o);
 int  orc_orb_nlevels(const orc_orb* o);
 void orc_orb_tables(const orc_orb* o, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,

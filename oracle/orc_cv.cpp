@@ -140,7 +140,19 @@ void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t*
 
 // GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) 8UC1, OpenCV <= 3.2 fixed-point path:
 // integer kernel cvRound(k*256), int32 row pass, column pass (sum + 32768) >> 16, saturated.
-void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+//
+// column_mode 1 = what an x86 (SSE2) build of OpenCV 2.4 / 3.2 computes: the column functor SymmColumnVec_32s8u
+// converts the int32 row sums to float, multiplies by the kernel as float(k / 65536), accumulates in float in the order
+// S[0] k0 + (S[1] + S[-1]) k1 + (S[2] + S[-2]) k2 + (S[3] + S[-3]) k3, and converts with cvtps2dq (round half to EVEN) + saturating packs,
+// for the columns its 16- and 4-wide loops cover (x < width & ~3); the last width % 4 columns take the scalar integer formula.
+// Every product and partial sum is exact in binary32 while the sum is below 256, so the two modes differ exactly where the integer sum
+// sits on a tie (sum mod 65536 == 32768) whose quotient is even -- restated here literally in float arithmetic, not as that rule.
+static void gaussian_blur7_mode(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int column_mode);
+void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) { gaussian_blur7_mode(src, w, h, sstride, dst, dstride, 0); }
+void orc_gaussian_blur7_mode(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int column_mode) {
+  gaussian_blur7_mode(src, w, h, sstride, dst, dstride, column_mode);
+}
+static void gaussian_blur7_mode(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int column_mode) {
   int k[7];
   {
     const double sigma = 2.0, scale2X = -0.5 / (sigma * sigma);
@@ -170,6 +182,15 @@ void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* 
     for (int t = -3; t <= 3; ++t) r[t + 3] = &tmp[(size_t)reflect101(y + t, h) * w];
     uint8_t* drow = dst + (size_t)y * dstride;
     for (int x = 0; x < w; ++x) {
+      if (column_mode == 1 && x < (w & ~3)) {
+        const float kf[4] = {(float)(k[3] * (1.0 / 65536.0)), (float)(k[2] * (1.0 / 65536.0)), (float)(k[1] * (1.0 / 65536.0)), (float)(k[0] * (1.0 / 65536.0))};
+        float acc = (float)r[3][x] * kf[0] + 0.0f;                         // delta = 0
+        acc = acc + (float)(r[4][x] + r[2][x]) * kf[1];
+        acc = acc + (float)(r[5][x] + r[1][x]) * kf[2];
+        acc = acc + (float)(r[6][x] + r[0][x]) * kf[3];
+        drow[x] = sat_u8((int)std::nearbyintf(acc));                      // cvtps2dq under the default rounding mode: half to even
+        continue;
+      }
       const int s = k[0] * r[0][x] + k[1] * r[1][x] + k[2] * r[2][x] + k[3] * r[3][x] + k[4] * r[4][x] + k[5] * r[5][x] + k[6] * r[6][x];
       drow[x] = sat_u8((s + 32768) >> 16);
     }

@@ -165,9 +165,12 @@ struct orc_orb {
   std::vector<Img> pyr;
   std::vector<std::vector<KP>> cand;   // per level vToDistributeKeys
   std::vector<std::vector<KP>> dist;   // per level, after octree + orientation (level coords)
+  int gaussian_column_mode = 0;        // 0: integer column pass (the definition of record), 1: SSE2 float column pass (orc_cv.cpp)
 };
 
 extern "C" {
+
+void orc_orb_set_gaussian_mode(orc_orb* o, int column_mode) { o->gaussian_column_mode = column_mode; }
 
 orc_orb* orc_orb_create(const orc_orb_params* pp) {
   orc_orb* o = new orc_orb;
@@ -320,7 +323,7 @@ int orc_orb_extract(orc_orb* o, const orc_camera* cam, const uint8_t* image, int
     }
     const Img& im = o->pyr[l];
     blurred.resize((size_t)im.w * im.h);
-    orc_gaussian_blur7(im.d.data(), im.w, im.h, im.w, blurred.data(), im.w);
+    orc_gaussian_blur7_mode(im.d.data(), im.w, im.h, im.w, blurred.data(), im.w, o->gaussian_column_mode);
     for (size_t i = 0; i < kept.size(); ++i) {
       const KP& k = kept[i];
       const float angle = (float)k.angle * factorPI;

@@ -129,9 +129,14 @@ def resize(src, dw, dh):
     return dst
 
 
-def blur7(src):
+def blur7(src, column_mode=0):
     src = np.ascontiguousarray(src)
     dst = np.zeros_like(src)
+    if column_mode:
+        f = lib().orc_gaussian_blur7_mode
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        f(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0], int(column_mode))
+        return dst
     lib().orc_gaussian_blur7(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
     return dst
 
@@ -153,9 +158,13 @@ def distribute_octree(xys, min_x, max_x, min_y, max_y, N):
 
 
 class Orb:
-    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, gaussian_column_mode=0):
         self.params = OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
         self.h = C.c_void_p(lib().orc_orb_create(C.byref(self.params)))
+        if gaussian_column_mode:
+            f = lib().orc_orb_set_gaussian_mode
+            f.argtypes = [C.c_void_p, C.c_int]
+            f(self.h, int(gaussian_column_mode))
         self.nlevels = nlevels
 
     def __del__(self):

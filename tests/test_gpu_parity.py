@@ -92,6 +92,33 @@ def test_extract_stage_by_stage_bit_exact(name, F, nfeat, Ih):
     ctx.close()
 
 
+def test_extract_with_the_sse2_gaussian_definition():
+    """cms_set_gaussian_mode(1): descriptors from the float-column Gaussian an x86 OpenCV <= 3.2 computes (ties to even)
+    against the oracle in the same mode, bit-exact; key points (which do not depend on the blur) stay what mode 0 gives."""
+    camd, ocam, _ = _cfg("lafida", 450, 2000)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=3)
+    mask = synth.cubemap_valid_mask(camd)
+    ctx.set_mask(mask)
+    m1, m2 = orc.build_lut(ocam)
+    frames = np.stack([synth.texture(camd["Ih"], camd["Iw"], s) for s in (31, 32, 33)])
+    ctx.upload(frames)
+    ctx.process(3, True); ctx.sync()
+    base = [ctx.fetch(b) for b in range(3)]
+    ctx.set_gaussian_mode(1)
+    ctx.process(3, True); ctx.sync()
+    o1 = orc.Orb(nfeatures=2000, gaussian_column_mode=1)
+    for b in range(3):
+        cube = orc.fisheye_to_cubemap(ocam, m1, m2, frames[b])
+        wk, wd = o1.extract(ocam, cube, mask)
+        gk, gd = ctx.fetch(b)
+        assert np.array_equal(gk.view(np.uint8), wk.view(np.uint8)) and np.array_equal(gk.view(np.uint8), base[b][0].view(np.uint8))
+        assert np.array_equal(gd, wd), (b, int(np.unpackbits(gd ^ wd).sum()))
+    ctx.set_gaussian_mode(0)
+    with pytest.raises(api.CmsError):
+        ctx.set_gaussian_mode(2)
+    ctx.close()
+
+
 def test_extract_host_api_and_dense_texture():
     """ORBextractor::operator() drop-in on a caller-supplied cubemap image that is textured everywhere (corner blocks
     included, like a real call) -> many candidates per cell, octree final phase with ties, all-valid mask except a band."""

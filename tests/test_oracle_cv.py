@@ -72,3 +72,30 @@ def test_scoremap_formulation_equals_per_cell_fast():
         assert got.shape == want.shape and np.array_equal(got, want), l
         n_fallback += int((want[:, 2] < 20).sum())
     assert n_fallback > 0
+
+
+def test_gaussian_float_column_mode_differs_only_on_even_ties():
+    """the SSE2 column functor of OpenCV <= 3.2 evaluates the 8-bit Gaussian's column pass in float and converts with
+    round-half-to-even.  The oracle restates that literally (float products and sums, nearbyintf); every product and partial sum is exact in
+    binary32, so the result must equal the integer formula everywhere except on ties with an even quotient, for columns x < width & ~3 --
+    the rule the device kernel applies (cms_set_gaussian_mode)."""
+    rng = np.random.default_rng(5)
+    n_ties = 0
+    for w, h in ((61, 47), (128, 64), (203, 77), (1650, 400)):
+        # piecewise-constant images make exact ties frequent: 257 * v / 65536 ... force some by hand as well
+        img = (rng.integers(0, 4, (h, w)) * 64 + rng.integers(0, 2, (h, w)) * 63).astype(np.uint8)
+        img[: h // 3] = rng.integers(0, 256, (h // 3, w))
+        a = orc.blur7(img, 0); b = orc.blur7(img, 1)
+        # integer sums (kernel [18, 34, 49, 55, 49, 34, 18], REFLECT_101), straight from the definition
+        k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+        pad = np.pad(img.astype(np.int64), 3, mode="reflect")
+        rows = sum(k[i] * pad[:, i:i + w] for i in range(7))
+        s = sum(k[i] * rows[i:i + h] for i in range(7))
+        want0 = np.clip((s + 32768) >> 16, 0, 255)
+        tie_even = ((s & 0xFFFF) == 0x8000) & (((s >> 16) & 1) == 0) & (np.arange(w)[None, :] < (w & ~3))
+        want1 = np.where(tie_even, np.clip(s >> 16, 0, 255), want0)
+        assert np.array_equal(a, want0.astype(np.uint8))
+        assert np.array_equal(b, want1.astype(np.uint8))
+        assert np.array_equal(a != b, tie_even)
+        n_ties += int(tie_even.sum())
+    assert n_ties >= 1            # about one pixel in 10^5: "1 LSB on rare pixels"
