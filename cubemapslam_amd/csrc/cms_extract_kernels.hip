@@ -769,7 +769,7 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
     int vl = min((sl + 32768) >> 16, 255), vh = min((sh + 32768) >> 16, 255);
     if (g.gauss_column_mode == 1) {
       // an x86 OpenCV <= 3.2 evaluates the column pass in float with round-half-to-EVEN for the columns its SSE2 loops cover
-      // (x < width & ~3; SURVEY.md Appendix C, oracle/orc_cv.cpp): every product and partial sum is exact in binary32, so the result
+      // (x < width & ~3): every product and partial sum is exact in binary32, so the result
       // differs from the integer formula exactly on ties (sum mod 65536 == 32768) with an even quotient
       const int x0 = cx - 18 + 2 * cp, xvec = lv.w & ~3;
       if (x0 < xvec && (sl & 0xFFFF) == 0x8000 && ((sl >> 16) & 1) == 0) vl = min(sl >> 16, 255);
