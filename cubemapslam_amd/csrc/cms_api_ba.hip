@@ -31,7 +31,7 @@ struct cms_ba {
   double* d_pose_partial = nullptr; double* d_db = nullptr;
   int* d_pair_s1 = nullptr; int* d_pair_s2 = nullptr; int* d_pair_off = nullptr; int2* d_tup = nullptr;
   int* d_pair_chunk_off = nullptr; int2* d_chunk_range = nullptr; double* d_chunk_sum = nullptr; int* d_pair_of_block = nullptr;
-  int npairs = 0, nchunks = 0; size_t solve_lds = 0, blk_lds = 0; bool solve_in_lds = false, solve_blk = false;
+  int npairs = 0, nchunks = 0; size_t solve_lds = 0, blk_lds = 0, blk3_lds = 0; bool solve_in_lds = false, solve_blk = false, solve_blk3 = false;
   // per-point Schur work lists (sp.R == 0: not available for this window, the tuple-chunk kernel is used)
   BaSp sp = {};
   int* d_sp_bat_e0 = nullptr; uint32_t* d_sp_off = nullptr; uint32_t* d_sp_list = nullptr; int* d_sp_slot_pair = nullptr; int* d_sp_tup_base = nullptr;
@@ -62,7 +62,7 @@ static int ba_lds_attrs_once(int device) {
   std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || done[device]) return CMS_OK;
   const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)k_ba_trial_solve,
-                       (const void*)kb_ba_trial_solve, (const void*)k_ba_solve_r192};
+                       (const void*)kb_ba_trial_solve, (const void*)kb_ba_trial_solve3, (const void*)k_ba_solve_r192};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);
     if (e != hipSuccess) return cms_fail(CMS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
@@ -422,6 +422,9 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   }
   b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
   b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
+  // the three-lanes-per-block variant (grouped driver): 3 x blocks <= 1024 threads
+  b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 2 * (size_t)n + 8) * sizeof(double);
+  b->solve_blk3 = b->solve_blk && 3 * (np * (np + 1) / 2) <= 1024 && b->blk3_lds <= BA_LDS_CEILING;
   {
     const int NP = 192;
     b->solve_lds = ((size_t)n * (n + 1) / 2 + 4 * (size_t)NP + 8) * sizeof(double);

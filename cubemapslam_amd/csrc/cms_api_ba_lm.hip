@@ -334,6 +334,14 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   for (int w = 0; w < n; ++w) first_round = first_round || st[w].it == 0;
   const bool use_se = ba_use_se(bas, n);
   const bool use_te = ba_use_te(bas, n);
+  // trial solve: three lanes per 6x6 block where every window allows it (CMS_BA_SOLVE1=1: one lane per block, the single-window kernel's scheme)
+  static const bool solve1 = getenv("CMS_BA_SOLVE1") != nullptr;
+  bool use_s3 = !solve1;
+  int s3_threads = 64; size_t lds3 = 0;
+  for (int w = 0; w < n; ++w) {
+    use_s3 = use_s3 && bas[w]->solve_blk3;
+    s3_threads = std::max(s3_threads, (3 * (bas[w]->np * (bas[w]->np + 1) / 2) + 63) / 64 * 64); lds3 = std::max(lds3, bas[w]->blk3_lds);
+  }
   int max_seR = 0, max_np2 = 0, max_Rt = 0; size_t se_lds = 0, te_lds = 0;
   for (int w = 0; w < n; ++w) {
     max_seR = std::max(max_seR, bas[w]->se.R); max_np2 = std::max(max_np2, bas[w]->se.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds);
@@ -395,8 +403,13 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       }
       bracket(5, 0);
-      hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
-      if (dup == 5) hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (use_s3) {
+        hipLaunchKernelGGL(kb_ba_trial_solve3, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 5) hipLaunchKernelGGL(kb_ba_trial_solve3, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      } else {
+        hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 5) hipLaunchKernelGGL(kb_ba_trial_solve, dim3(1, 1, n), dim3(384), lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      }
       bracket(5, 1);
       bracket(6, 0);
       if (use_te) {

@@ -53,6 +53,67 @@ __device__ __forceinline__ void ba_factor_diag(double* a, int J, double* Ld, dou
   for (int r = 0; r < 6; ++r) { ybuf[6 * J + r] = z[r]; idg[6 * J + r] = idl[r]; }
 }
 
+// T <- exp(x) T for the free poses (types_six_dof_expmap.h:73-76), plain copy for the fixed ones; pose part of the gain denominator and the
+// solver status -> scal[5], scal[4] (shared by the two solve kernels)
+__device__ __forceinline__ void ba_trial_pose_update(BaDev d, const double* ybuf, const double* __restrict__ bp, double lambda, const double* __restrict__ poses,
+                                                     double* __restrict__ poses_new, double* __restrict__ scal, bool isbad) {
+  const int tid = threadIdx.x;
+  double sc = 0;
+  for (int k = tid; k < d.K; k += blockDim.x) {
+    const double* T = poses + 7 * k;
+    double* Tn = poses_new + 7 * k;
+    const int s = d.pose_slot[k];
+    if (s < 0) { for (int i = 0; i < 7; ++i) Tn[i] = T[i]; continue; }
+    const double* u = ybuf + 6 * s;
+    for (int i = 0; i < 6; ++i) sc += u[i] * (lambda * u[i] + bp[6 * s + i]);
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double Om[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double Om2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Om2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+      for (int i = 0; i < 9; ++i) { R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
+    } else {
+      const double sa = sin(theta) / theta, sb = (1 - cos(theta)) / (theta * theta), scc = (theta - sin(theta)) / (theta * theta * theta);
+      for (int i = 0; i < 9; ++i) {
+        const double Id = ((i & 3) == 0 ? 1.0 : 0.0);
+        R[i] = Id + sa * Om[i] + sb * Om2[i];
+        V[i] = Id + sb * Om[i] + scc * Om2[i];
+      }
+    }
+    double Eq[4], Et[3], RE[9];
+    R_to_quat(R, Eq);
+    for (int i = 0; i < 3; ++i) Et[i] = V[3 * i] * up[0] + V[3 * i + 1] * up[1] + V[3 * i + 2] * up[2];
+    normalize_rot(Eq);
+    quat_to_R(Eq, RE);
+    for (int i = 0; i < 3; ++i) Tn[i] = Et[i] + RE[3 * i] * T[0] + RE[3 * i + 1] * T[1] + RE[3 * i + 2] * T[2];
+    const double* A = Eq; const double* B = T + 3;
+    double q[4];
+    q[3] = A[3] * B[3] - A[0] * B[0] - A[1] * B[1] - A[2] * B[2];
+    q[0] = A[3] * B[0] + A[0] * B[3] + A[1] * B[2] - A[2] * B[1];
+    q[1] = A[3] * B[1] + A[1] * B[3] + A[2] * B[0] - A[0] * B[2];
+    q[2] = A[3] * B[2] + A[2] * B[3] + A[0] * B[1] - A[1] * B[0];
+    normalize_rot(q);
+    for (int i = 0; i < 4; ++i) Tn[3 + i] = q[i];
+  }
+  // pose part of the gain denominator + solver status (status travels as a double next to the other scalars)
+  __shared__ double shs[16];
+  for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
+  if ((tid & 63) == 0) shs[tid >> 6] = sc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += shs[i];
+    scal[5] = s;
+    int st = isbad ? 0 : 1;
+    double stv = 0;
+    memcpy(&stv, &st, sizeof(int));
+    scal[4] = stv;
+  }
+}
+
 __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
@@ -232,63 +293,187 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
   __syncthreads();
   BA_CLK(3);
   for (int i = tid; i < n; i += blockDim.x) xp_out[i] = ybuf[i];
-  // ---- T <- exp(x) T for the free poses (types_six_dof_expmap.h:73-76), plain copy for the fixed ones
-  double sc = 0;
-  for (int k = tid; k < d.K; k += blockDim.x) {
-    const double* T = poses + 7 * k;
-    double* Tn = poses_new + 7 * k;
-    const int s = d.pose_slot[k];
-    if (s < 0) { for (int i = 0; i < 7; ++i) Tn[i] = T[i]; continue; }
-    const double* u = ybuf + 6 * s;
-    for (int i = 0; i < 6; ++i) sc += u[i] * (lambda * u[i] + bp[6 * s + i]);
-    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
-    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
-    const double Om[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
-    double Om2[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Om2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
-    double R[9], V[9];
-    if (theta < 0.00001) {
-      for (int i = 0; i < 9; ++i) { R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
-    } else {
-      const double sa = sin(theta) / theta, sb = (1 - cos(theta)) / (theta * theta), scc = (theta - sin(theta)) / (theta * theta * theta);
-      for (int i = 0; i < 9; ++i) {
-        const double Id = ((i & 3) == 0 ? 1.0 : 0.0);
-        R[i] = Id + sa * Om[i] + sb * Om2[i];
-        V[i] = Id + sb * Om[i] + scc * Om2[i];
-      }
-    }
-    double Eq[4], Et[3], RE[9];
-    R_to_quat(R, Eq);
-    for (int i = 0; i < 3; ++i) Et[i] = V[3 * i] * up[0] + V[3 * i + 1] * up[1] + V[3 * i + 2] * up[2];
-    normalize_rot(Eq);
-    quat_to_R(Eq, RE);
-    for (int i = 0; i < 3; ++i) Tn[i] = Et[i] + RE[3 * i] * T[0] + RE[3 * i + 1] * T[1] + RE[3 * i + 2] * T[2];
-    const double* A = Eq; const double* B = T + 3;
-    double q[4];
-    q[3] = A[3] * B[3] - A[0] * B[0] - A[1] * B[1] - A[2] * B[2];
-    q[0] = A[3] * B[0] + A[0] * B[3] + A[1] * B[2] - A[2] * B[1];
-    q[1] = A[3] * B[1] + A[1] * B[3] + A[2] * B[0] - A[0] * B[2];
-    q[2] = A[3] * B[2] + A[2] * B[3] + A[0] * B[1] - A[1] * B[0];
-    normalize_rot(q);
-    for (int i = 0; i < 4; ++i) Tn[3 + i] = q[i];
-  }
-  // pose part of the gain denominator + solver status (status travels as a double next to the other scalars)
-  __shared__ double shs[16];
-  for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
-  if ((tid & 63) == 0) shs[tid >> 6] = sc;
-  __syncthreads();
-  if (tid == 0) {
-    double s = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += shs[i];
-    scal[5] = s;
-    int st = isbad ? 0 : 1;
-    double stv = 0;
-    memcpy(&stv, &st, sizeof(int));
-    scal[4] = stv;
-  }
+  ba_trial_pose_update(d, ybuf, bp, lambda, poses, poses_new, scal, isbad);
   BA_CLK(4);
 #undef BA_CLK
+}
+
+// ---- the same trial solve with every 6x6 block of the reduced system split over THREE lanes (two rows each).
+// One lane per block (above) leaves <= 171 lanes busy with 216 dependent FMAs per panel step: 19 steps of ~2.2 us = 43 of the kernel's 57 us,
+// pure latency with the other window groups' kernels waiting behind it.  Here a lane owns rows 2 rp, 2 rp + 1 of block (I, K): the trailing
+// update is 72 FMAs per lane, the panel solve 30; the strictly serial part (the 6x6 LDL^T of the next diagonal block) still runs in one
+// lane, as a look-ahead behind that lane's own trailing update.  Panels are stored row major, 38 doubles per block (304 B: the three lanes
+// of a block read the same L block -- a broadcast -- and neighbouring blocks fall on different banks).
+#define BA_S3_STRIDE 38
+__device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
+                 const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
+                 const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
+                 double* __restrict__ xp_out, double* __restrict__ scal) {
+  extern __shared__ __align__(16) double sm[];
+  const int nb = d.np, n = 6 * nb, nblk = nb * (nb + 1) / 2;
+  // LDS (doubles): L panels [nb (nb - 1) / 2][38] | diagonal factors [nb][36] | W double buffer [2][nb][38] | diag staging [36] | y [n] | 1/D [n]
+  double* Lp = sm;
+  double* Ldg = Lp + (size_t)BA_S3_STRIDE * (nb * (nb - 1) / 2);
+  double* Wbuf = Ldg + 36 * (size_t)nb;
+  double* dstage = Wbuf + 2 * (size_t)BA_S3_STRIDE * nb;
+  double* ybuf = dstage + 36;
+  double* idg = ybuf + n;
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  const int blk = tid / 3, rp = tid - 3 * blk;
+  int I = 0, K = 0;
+  const bool have = blk < nblk;
+  if (have) {
+    int off = 0;
+    while (off + (nb - K) <= blk) { off += nb - K; ++K; }
+    I = K + (blk - off);
+  }
+  if (tid == 0) bad = 0;
+  const int r0 = 2 * rp;
+  double a[12];
+  if (have) {
+#pragma unroll
+    for (int q = 0; q < 12; ++q) a[q] = 0.0;
+    if (I == K) {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) a[q] = Hpp[36 * I + 6 * r0 + q];
+      a[r0] += lambda; a[6 + r0 + 1] += lambda;
+    }
+    const int pr = pair_of_block[I * (I + 1) / 2 + K];
+    double yb[2] = {0, 0};
+    if (pr >= 0) {
+      for (int c = pair_chunk_off[pr]; c < pair_chunk_off[pr + 1]; ++c) {
+        const double* cs = chunk_sum + (size_t)c * 42;
+        // chunk sums are stored for the pair (s1 = K) <= (s2 = I), i.e. for block (K, I): transpose into (I, K)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { a[q] -= cs[6 * q + r0]; a[6 + q] -= cs[6 * q + r0 + 1]; }
+        if (I == K) { yb[0] += cs[36 + r0]; yb[1] += cs[36 + r0 + 1]; }
+      }
+    }
+    if (I == K) { ybuf[6 * I + r0] = bp[6 * I + r0] - yb[0]; ybuf[6 * I + r0 + 1] = bp[6 * I + r0 + 1] - yb[1]; }
+  }
+  // a diagonal block is gathered in LDS by its three lanes and factored by one (ba_factor_diag works on a full 6x6); the lanes of a block may
+  // sit in two wavefronts (3 does not divide 64), so block barriers order the staging against the read
+  if (have && I == 0 && K == 0) {
+#pragma unroll
+    for (int q = 0; q < 12; ++q) dstage[6 * r0 + q] = a[q];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double f[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) f[q] = dstage[q];
+    ba_factor_diag(f, 0, Ldg, ybuf, idg, &bad);
+  }
+  __syncthreads();
+  for (int J = 0; J < nb && !bad; ++J) {
+    const int m = nb - J - 1;
+    double* Wp = Wbuf + (size_t)(J & 1) * BA_S3_STRIDE * nb;
+    double* Lpan = Lp + (size_t)BA_S3_STRIDE * (J * nb - J * (J + 1) / 2);
+    if (have && K == J && I > J) {                   // panel rows: W = A L_JJ^-T, L = W D_J^-1, y_I -= L z_J (this lane's two rows)
+      const double* Ld = Ldg + 36 * (size_t)J;
+      double ld[15], idj[6], zj[6];
+#pragma unroll
+      for (int c = 1; c < 6; ++c)
+#pragma unroll
+        for (int q = 0; q < c; ++q) ld[c * (c - 1) / 2 + q] = Ld[6 * c + q];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { idj[c] = idg[6 * J + c]; zj[c] = ybuf[6 * J + c]; }
+      double yi[2] = {ybuf[6 * I + r0], ybuf[6 * I + r0 + 1]};
+      double w[12], lo[12];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = a[6 * r + c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) v = __builtin_fma(-w[6 * r + q], ld[c * (c - 1) / 2 + q], v);
+          w[6 * r + c] = v;
+        }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double l = w[6 * r + c] * idj[c];
+          lo[6 * r + c] = l;
+          yi[r] = __builtin_fma(-l, zj[c], yi[r]);
+        }
+      const int i = I - J - 1;
+      double2* W2 = reinterpret_cast<double2*>(Wp + (size_t)i * BA_S3_STRIDE + 6 * r0);
+      double2* L2 = reinterpret_cast<double2*>(Lpan + (size_t)i * BA_S3_STRIDE + 6 * r0);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { W2[q] = make_double2(w[2 * q], w[2 * q + 1]); L2[q] = make_double2(lo[2 * q], lo[2 * q + 1]); }
+      ybuf[6 * I + r0] = yi[0]; ybuf[6 * I + r0 + 1] = yi[1];
+    }
+    __syncthreads();
+    const bool next_diag = have && I == J + 1 && K == J + 1;
+    if (have && K > J) {                             // trailing update of this lane's two rows: A_IK -= W_IJ L_KJ^T
+      const int iw = I - J - 1, ik = K - J - 1;
+      double wv[12], lk[36];
+      const double2* W2 = reinterpret_cast<const double2*>(Wp + (size_t)iw * BA_S3_STRIDE + 6 * r0);
+      const double2* L2 = reinterpret_cast<const double2*>(Lpan + (size_t)ik * BA_S3_STRIDE);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { const double2 x = W2[q]; wv[2 * q] = x.x; wv[2 * q + 1] = x.y; }
+#pragma unroll
+      for (int q = 0; q < 18; ++q) { const double2 y = L2[q]; lk[2 * q] = y.x; lk[2 * q + 1] = y.y; }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          double v = a[6 * r + q];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v = __builtin_fma(-wv[6 * r + c], lk[6 * q + c], v);
+          a[6 * r + q] = v;
+        }
+      if (next_diag) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) dstage[6 * r0 + q] = a[q];
+      }
+    }
+    __syncthreads();
+    if (J + 1 < nb && tid == 3 * ((J + 1) * nb - (J + 1) * J / 2)) {      // first lane of block (J + 1, J + 1): look-ahead factorisation
+      double f[36];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) f[q] = dstage[q];
+      ba_factor_diag(f, J + 1, Ldg + 36 * (size_t)(J + 1), ybuf, idg, &bad);
+    }
+    __syncthreads();
+  }
+  const bool isbad = bad != 0;
+  if (!isbad && tid < 64) {
+    for (int i = tid; i < n; i += 64) ybuf[i] *= idg[i];
+    __builtin_amdgcn_wave_barrier();
+    for (int J = nb - 1; J >= 0; --J) {
+      const double* Ld = Ldg + 36 * (size_t)J;
+      double xj[6];
+#pragma unroll
+      for (int r = 5; r >= 0; --r) {
+        xj[r] = ybuf[6 * J + r];
+#pragma unroll
+        for (int q = r + 1; q < 6; ++q) xj[r] -= Ld[6 * q + r] * xj[q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (tid == 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ybuf[6 * J + r] = xj[r];
+      }
+      for (int o = tid; o < 6 * J; o += 64) {
+        const int Kq = o / 6, c = o - 6 * Kq;
+        // L_{J,Kq}: block i = J - Kq - 1 of the panel of column Kq, row major
+        const double* Lq = Lp + (size_t)BA_S3_STRIDE * (Kq * nb - Kq * (Kq + 1) / 2) + (size_t)(J - Kq - 1) * BA_S3_STRIDE;
+        double v = ybuf[o];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) v -= Lq[6 * r + c] * xj[r];
+        ybuf[o] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  if (isbad) for (int i = tid; i < n; i += blockDim.x) ybuf[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) xp_out[i] = ybuf[i];
+  ba_trial_pose_update(d, ybuf, bp, lambda, poses, poses_new, scal, isbad);
 }
 
 // per point: x_l = Dinv (b_l - sum B^T x_p), X_new = X + x_l, gain-denominator partial; then residuals + robust chi2 of the

@@ -256,6 +256,10 @@ extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem
   ba_trial_solve_body(0, 1, it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt],
                       it.x, it.scal);
 }
+extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, 1)
+  ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal);
+}
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
   ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
