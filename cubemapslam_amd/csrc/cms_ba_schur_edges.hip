@@ -25,6 +25,12 @@
 //     pose pair, dense upper-triangular pair enumeration) with ds_add_f64; when the loop is done the copy is written to this range's
 //     slice of `partial`, and kb_ba_schur_reduce adds the ranges in fixed order as before.
 //
+// Measured and dropped (profiles/r02_pmc_instruction_mix.json: 745 LDS instructions per wave, SQ_WAIT_INST_LDS 28 % of the wave cycles): the
+// partner's W through whole-wavefront DPP shifts (v_mov_b32_dpp wave_shl:1, tools/probe/dpp_wave_shift.hip) instead of LDS rows -- no
+// LDS reads to drain the in-order LDS counter, half the LDS, two workgroups per CU -- was no faster (60-67 us against 57): without the
+// cyclic pairing it needs k - 1 instead of k / 2 atomic steps per chunk, and the kernel's time IS its count of scattered ds_add_f64
+// instructions (81 per chunk x ~36 clocks x 41 chunks per CU = the 57 us measured), whatever the occupancy.
+//
 // The LDS additions of different wavefronts interleave in an order that is not fixed: sums may differ in the last bits from run to
 // run (the BA parity bar is 1e-4 relative on updates; the oracle's own summation order is different anyway).  CMS_BA_DETERMINISTIC=1
 // selects the pair-owner kernel instead.  (block_solver.hpp:367-437: Hschur -= Bi Dinv Bj^T, bschur -= Bi Dinv bl.)

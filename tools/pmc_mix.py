@@ -6,7 +6,7 @@ for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in sorted(acc.items()):
-    if not k.startswith("k_"):
+    if not k.startswith(("k_", "kb_")):
         continue
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     w = m.get("SQ_WAVES", 0) or 1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof/<tag>_* (rocprofv3 csv output) into the small, tracked summaries under profiles/."""
 import collections, csv, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 PB = int(os.environ.get("PROF_B", "256"))      # frames per dispatch of the PMC passes (tools/run_profiles.sh)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof"); dst = os.path.join(root, "profiles")
@@ -35,40 +35,48 @@ for extra, cmd in (("mapping", "python tools/prof_tri.py 8 20 5"), ("ba8", "pyth
                 f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
                                   "%.2f" % float(r["Percentage"]), r["MinNs"], r["MaxNs"]]) + "\n")
 pmc = {}
-for kind in ("fetch", "write"):
+for kind in ("fetch", "write", "fetch_ba", "write_ba"):
     p = os.path.join(src, "%s_pmc_%s_counter_collection.csv" % (tag, kind))
     if not os.path.exists(p):
         continue
-    agg = collections.defaultdict(lambda: [0.0, 0])
+    agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
     for r in csv.DictReader(open(p)):
         a = agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])]
-        a[0] += float(r["Counter_Value"]); a[1] += 1
-    for (k, c), (v, n) in agg.items():
-        pmc.setdefault(k, {})[c] = {"sum": v, "dispatches": n, "per_dispatch": v / n}
+        v = float(r["Counter_Value"])
+        a[0] += v; a[1] += 1; a[2] = max(a[2], v)
+    for (k, c), (v, n, mx) in agg.items():
+        # local-BA launches of a finished window group do nothing: the busiest dispatch (all windows active) is the one to price
+        pmc.setdefault(k, {})[c] = {"sum": v, "dispatches": n, "per_dispatch": (mx if kind.endswith("_ba") else v / n)}
 if pmc:
     with open(os.path.join(dst, tag + "_pmc_hbm_traffic.json"), "w") as f:
-        json.dump({"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/prof_frames.py %d 550 3" % PB, "frames_per_dispatch": PB,
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/prof_frames.py %d 550 3  |  python tools/prof_ba_many.py 8" % PB,
+                   "frames_per_dispatch": PB, "face": 550, "windows_per_dispatch": 8,
                    "note": "counter unit: KB (rocprofv3 derived metric); separate passes for FETCH_SIZE and WRITE_SIZE; "
                            "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section): bench.py doubles it; "
                            "calibration on this path: k_fast_cells with the XCD-striped cell list reports 183 MB against >= 300 MB of "
                            "non-zero cell bytes it must read (x2 = 366 MB incl. the 3-px halos); the plain row-major list reported 854 MB",
-                   "kernels": {k: v for k, v in pmc.items() if k.startswith("k_")}}, f, indent=1)
+                   "ba_note": "kb_ba_* kernels: per_dispatch = the busiest dispatch (eight windows of K = 20, E = 80k active)",
+                   "kernels": {k: v for k, v in pmc.items() if k.startswith(("k_", "kb_"))}}, f, indent=1)
 # ---- SQ instruction mix (tools/pmc_mix.sh): per kernel, counters per wave and the vector-ALU issue bound
 import glob
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(root, "gpurun_out", "pmc", "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for fam in ("pmc", "pmc_ba"):
+    for f in glob.glob(os.path.join(root, "gpurun_out", fam, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mix = {}
 for k, cs in sorted(acc.items()):
-    if not k.startswith("k_") or "SQ_WAVES" not in cs:
+    if not k.startswith(("k_", "kb_")) or "SQ_WAVES" not in cs:
         continue
-    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    # frame-path kernels: mean over the dispatches; local-BA kernels: the busiest dispatch (all eight windows active)
+    m = {c: (max(v) if k.startswith("kb_") else sum(v) / len(v)) for c, v in cs.items()}
     w = m["SQ_WAVES"] or 1.0
     per = lambda c: round(m.get(c, 0.0) / w, 1)
     mix[k] = {"waves_per_dispatch": int(w),
               "per_wave": {"valu": per("SQ_INSTS_VALU"), "salu": per("SQ_INSTS_SALU"), "lds": per("SQ_INSTS_LDS"), "smem": per("SQ_INSTS_SMEM"),
-                           "wave_quad_cycles": per("SQ_WAVE_CYCLES"), "wait_inst_any_quad_cycles": per("SQ_WAIT_INST_ANY")},
+                           "wave_quad_cycles": per("SQ_WAVE_CYCLES"), "wait_inst_any_quad_cycles": per("SQ_WAIT_INST_ANY"),
+                           "lds_bank_conflict_cycles": per("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": per("SQ_LDS_IDX_ACTIVE"),
+                           "wait_inst_lds_quad_cycles": per("SQ_WAIT_INST_LDS")},
               "valu_issue_bound_us": round(m.get("SQ_INSTS_VALU", 0.0) * 4 / (256 * 4 * 2.4e9) * 1e6, 1)}
 if mix:
     with open(os.path.join(dst, tag + "_pmc_instruction_mix.json"), "w") as f:
