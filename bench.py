@@ -479,14 +479,15 @@ def main():
             pj = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
             if os.path.exists(pj):
                 J = json.load(open(pj))
-                if J.get("frames_per_dispatch", 64) == B and J.get("face", 550) == F and kname in J.get("kernels", {}):
+                ok = kname.startswith("kb_") or J.get("frames_per_dispatch", 64) == B      # the local-BA passes are per 8 windows, whatever the frame batch
+                if ok and J.get("face", 550) == F and kname in J.get("kernels", {}):
                     return J["kernels"][kname]
         return None
-    def traffic_of(kname):
+    def traffic_of(kname, scale=1.0):
         kk = pmc("pmc_hbm_traffic", kname)
         if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
             # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section) -> doubled; unit KB
-            return int((2.0 * kk["FETCH_SIZE"]["per_dispatch"] + kk["WRITE_SIZE"]["per_dispatch"]) * 1024)
+            return int((2.0 * kk["FETCH_SIZE"]["per_dispatch"] + kk["WRITE_SIZE"]["per_dispatch"]) * 1024 * scale)
         return None
     fast_ms = stage_ms.get("fast", 0.0)
     fast_gbs = alg["fast"] * B / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else None
@@ -506,9 +507,13 @@ def main():
         avg_ms = sch_ms / sch_n
         byt = float(np.mean(grp_bytes))
         gbs = byt / (avg_ms * 1e-3) / 1e9
-        roof_ba = {"kernel": "kb_ba_schur_points", "bound": "hbm", "achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "frac": round(gbs / peak, 4),
-                   "traffic": traffic_of("kb_ba_schur_points"), "ms_per_launch": round(avg_ms, 4), "launches_per_step": round(sch_n / args.steps, 1),
+        schur_name = "kb_ba_schur_points" if os.environ.get("CMS_BA_DETERMINISTIC") or os.environ.get("CMS_BA_HOST_LM") else "kb_ba_schur_edges"
+        roof_ba = {"kernel": schur_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "frac": round(gbs / peak, 4),
+                   # PMC pass: 8 windows per dispatch (tools/prof_ba_many.py); one launch here carries a group of n_ba / n_grp windows
+                   "traffic": traffic_of(schur_name, (n_ba / n_grp) / 8.0), "ms_per_launch": round(avg_ms, 4), "launches_per_step": round(sch_n / args.steps, 1),
                    "ms_per_step": round(sch_ms / args.steps, 4), "algorithmic_bytes_per_launch": int(byt),
+                   "lds_atomic_bound": "the kernel adds 27 + 36 + 36 ds_add_f64 wave instructions per 64-edge chunk to its LDS copy of the reduced system; scattered f64 LDS "
+                                       "additions run at ~2.7 lanes per clock and CU (tools/probe/lds_atomics.hip): that, not HBM, is what its launch time follows",
                    "note": "HIP events on each window group's stream; the groups' launches overlap each other and the frame path, so ms_per_step is summed kernel time"}
     # `roofline` = the kernel with the most time per step; the other one is reported next to it
     if roof_ba and roof_ba["ms_per_step"] > roof_fast["ms_per_step"]:
