@@ -10,6 +10,8 @@ template <int MODE> __global__ void __launch_bounds__(512) k(double* out, int it
   // every lane hits its own slot (conflict free when stride == 1), `spread` slots apart per iteration
   int idx = (threadIdx.x * stride) & 8191;
   if (stride < 0) idx = (int)(((threadIdx.x * 2654435761u) >> 7) % 171u) * (-stride);      // stride < 0: a random "pair" per lane, |stride| doubles per pair
+  if (stride == -1000) idx = (int)((threadIdx.x * 37u) % 171u) * 43;                        // distinct pairs within a wave (37 is coprime to 171), residues mod 16 as they fall
+  if (stride == -1001) { const int l = threadIdx.x & 63; idx = ((l & 15) * 3 + (l >> 4) * 48) % 171 * 43; }   // distinct pairs, 43 * pair mod 16 perfectly balanced (4 lanes per f64 bank pair)
   double v = 1.0 + threadIdx.x;
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -42,6 +44,7 @@ template <int MODE> void run(const char* name, int stride, int spread) {
 int main() {
   run<0>("ds_add_f64", 1, 512); run<0>("ds_add_f64", 43, 1); run<0>("ds_add_f64 same-addr", 0, 1);
   run<0>("ds_add_f64 rand*43", -43, 1); run<0>("ds_add_f64 rand*42", -42, 1); run<0>("ds_add_f64 rand*47", -47, 1); run<5>("rmw b64 rand*43", -43, 1);
+  run<0>("f64 distinct pairs", -1000, 1); run<0>("f64 distinct+balanced", -1001, 1);
   run<1>("ds_add_u64", 1, 512); run<1>("ds_add_u64", 43, 1);
   run<2>("ds_add_f32", 1, 512); run<3>("ds_add_u32", 1, 512);
   run<4>("ds_write_b64", 1, 512); run<5>("read+add+write b64", 1, 512);
