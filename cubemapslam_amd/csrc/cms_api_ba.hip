@@ -9,11 +9,12 @@
 #include <cmath>
 #include <mutex>
 #include <numeric>
+#include <string>
 #include <thread>
 
 struct cms_ba {
   int device = 0;
-  hipStream_t stream = nullptr; bool own_stream = true;
+  hipStream_t stream = nullptr; bool own_stream = true, pooled_stream = false;
   int K = 0, P = 0, E = 0, np = 0, nblk_e = 0, nblk_p = 0;
   std::vector<int> perm;       // sorted position -> caller's edge index
   std::vector<int> pinv;       // internal point id -> caller's point index (points are permuted into collision-free chunks, see below)
@@ -39,7 +40,7 @@ struct cms_ba {
   int sp_threads = 0; size_t sp_lds = 0;
   // edge-major Schur work list (se.R == 0: not available: too many free key frames for the LDS copy of the reduced system)
   BaSe se = {};
-  int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
+  int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_bp_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
   size_t se_lds = 0;
   int cur = 0;
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
@@ -61,7 +62,7 @@ static int ba_lds_attrs_once(int device) {
   static bool done[64] = {false};
   std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || done[device]) return CMS_OK;
-  const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)k_ba_trial_solve,
+  const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)kb_ba_lin_schur_edges, (const void*)k_ba_trial_solve,
                        (const void*)kb_ba_trial_solve, (const void*)kb_ba_trial_solve3, (const void*)k_ba_solve_r192};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);
@@ -69,6 +70,27 @@ static int ba_lds_attrs_once(int device) {
   }
   done[device] = true;
   return CMS_OK;
+}
+
+// Streams of destroyed windows are kept for the next window of the device: creating a stream costs ~10 ms of host time (measured with
+// CMS_BA_CREATE_TIMING), a window's whole Levenberg run ~3.
+struct BaStreamPool { std::mutex mu; std::vector<hipStream_t> idle[64]; };
+static BaStreamPool& ba_stream_pool() { static BaStreamPool* p = new BaStreamPool; return *p; }      // never destroyed: no HIP calls at process exit
+static hipStream_t ba_stream_take(int device) {
+  BaStreamPool& pl = ba_stream_pool();
+  std::lock_guard<std::mutex> lk(pl.mu);
+  if (device < 0 || device >= 64 || pl.idle[device].empty()) return nullptr;
+  hipStream_t s = pl.idle[device].back();
+  pl.idle[device].pop_back();
+  return s;
+}
+static void ba_stream_give(int device, hipStream_t s) {
+  BaStreamPool& pl = ba_stream_pool();
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (device >= 0 && device < 64 && pl.idle[device].size() < 64 && hipStreamSynchronize(s) == hipSuccess) { pl.idle[device].push_back(s); return; }
+  }
+  hipStreamDestroy(s);
 }
 
 template <class T> static int ba_alloc(cms_ba* b, T** p, size_t n) {
@@ -90,7 +112,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->grp_lm_dev) hipFree(b->grp_lm_dev);
   if (b->grp_lm_host) hipHostFree(b->grp_lm_host);
   for (hipEvent_t e : b->prof_ev) hipEventDestroy(e);
-  if (b->stream && b->own_stream) hipStreamDestroy(b->stream);
+  if (b->stream && b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else hipStreamDestroy(b->stream); }
   delete b;
 }
 extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullptr; }
@@ -101,7 +123,7 @@ extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
   if (!b || !hip_stream) return cms_fail(CMS_ERR_ARG, "cms_ba_set_stream: bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
-  if (b->own_stream) HIPCHK(hipStreamDestroy(b->stream));
+  if (b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else HIPCHK(hipStreamDestroy(b->stream)); }
   b->stream = (hipStream_t)hip_stream; b->own_stream = false;
   return CMS_OK;
 }
@@ -136,6 +158,17 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   b->device = device; b->K = K; b->P = P; b->E = E;
 #define BA_TRY(x) do { int _rc = (x); if (_rc) { cms_ba_destroy(b); return _rc; } } while (0)
 #define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
+  // CMS_BA_CREATE_TIMING=1: where the host side of a window's set-up goes (stderr, one line per window)
+  static const bool timing = getenv("CMS_BA_CREATE_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  std::string t_log;
+  auto tick = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof(buf), " %s %.2f", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_log += buf; t_last = now;
+  };
   BA_TRY(ba_lds_attrs_once(device));
   {
     // CMS_BA_STREAM_PRIORITY=low: the window's queue yields to normal-priority queues (the frame path) whenever both have workgroups ready
@@ -143,29 +176,125 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     int lo = 0, hi = 0;
     if (pr && pr[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
       BA_HIP(hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, lo));
-    else
-      BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    else {
+      b->stream = ba_stream_take(device);
+      if (!b->stream) BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+      b->pooled_stream = true;
+    }
   }
-  // ---- chunks of the edge-major Schur kernel (cms_ba_schur_edges.hip): whole points, at most 64 edges, in the caller's point order.
-  // (Measured and dropped: permuting the points greedily so that no pose pair occurs twice in the same step of a chunk -- the chunks
-  // came out 99.7 % full and collision free, and the kernel was no faster: scattered f64 additions run at ~2.7 lanes per clock and CU
-  // whether or not lanes share an address now and then, tools/probe/lds_atomics.hip.  The internal point order stays the caller's;
-  // prank / pinv keep the translation in one place should that change.)
-  std::vector<int> prank(P), cp_off(P + 1, 0);
+  tick("stream");
+  // ---- internal point order = chunk composition of the edge-major Schur kernel (cms_ba_schur_edges.hip).  A wavefront takes a CHUNK of whole
+  // points with at most 64 edges; in step d the lane of a point's a-th edge adds its 6x6 product to the LDS block of the pose pair
+  // (pose_a, pose_(a+d) mod k), one element per instruction.  What such an instruction costs is decided by where its addresses fall
+  // (tools/probe/lds_atomics.hip): the LDS takes the 64 lanes of a ds_add_f64 in four groups of 16 CONSECUTIVE lanes, two clocks each when
+  // the 16 addresses fall on 16 different f64 banks (address mod 16 doubles), and two more clocks for every further lane on the fullest
+  // bank (same address: six more).  Lanes 16 or more apart never compete.  Random pairs cost ~3.1 slots per group (16 balls into 16 bins)
+  // -- the 2.7 lane-operations per clock measured against 7.8 on consecutive addresses.
+  // The host therefore composes the chunks: points are taken from a look-ahead window over the caller's order so that, within each group
+  // of 16 lanes and each step, the pairs' bank classes (pair index mod 16: the block stride is odd, and the block layout gives an element
+  // and its transpose the same bank) repeat as little as possible; the diagonal tuples pick, among the four copies of their key frame's
+  // diagonal block, the one whose bank is least used in their group.  Everything on the device is indexed by the internal point id;
+  // cms_ba_read / cms_ba_linearize translate back.  CMS_BA_NO_PERMUTE=1 keeps the caller's order (A/B).
+  std::vector<int> prank(P), cp_off(P + 1, 0), cp_pose(E);
+  std::vector<uint8_t> cp_rank(E, 0);                 // per (caller point, edge in pose order): copy of the diagonal blocks its (a, a) tuple goes to
   {
     for (int e = 0; e < E; ++e) ++cp_off[e_point[e] + 1];
     for (int p = 0; p < P; ++p) cp_off[p + 1] += cp_off[p];
+    std::vector<int> fill(cp_off.begin(), cp_off.end() - 1);
+    for (int e = 0; e < E; ++e) cp_pose[fill[e_point[e]]++] = e_pose[e];
+    for (int p = 0; p < P; ++p) std::sort(cp_pose.begin() + cp_off[p], cp_pose.begin() + cp_off[p + 1]);
+    std::vector<int> gslot(K, -1);
+    int gnp = 0;
+    for (int k = 0; k < K; ++k) if (!fixed[k]) gslot[k] = gnp++;
     b->pinv.resize(P);
-    b->se_chunk_pt0.assign(1, 0);
-    int cur_edges = 0;
-    for (int p = 0; p < P; ++p) {
-      prank[p] = p; b->pinv[p] = p;
+    static const int la_env = getenv("CMS_BA_LOOKAHEAD") ? atoi(getenv("CMS_BA_LOOKAHEAD")) : 48;
+    const bool greedy = getenv("CMS_BA_NO_PERMUTE") == nullptr && gnp >= 2 && gnp <= 62 && la_env > 1;
+    const int LA = std::max(la_env, 1), MAXD = 4;
+    std::vector<int> nxt(P + 1);                       // singly linked list of the points not placed yet, in the caller's order
+    for (int p = 0; p <= P; ++p) nxt[p] = p + 1;
+    int head = 0, placed = 0, cur_edges = 0;
+    // per open chunk: [step][group of 16 lanes][bank class] lanes so far; diagonal tuples: [group][class]; a point may straddle two groups
+    uint8_t cls[MAXD][4][16], dcls[4][16];
+    memset(cls, 0, sizeof(cls)); memset(dcls, 0, sizeof(dcls));
+    auto opair = [&](int s1, int s2) { return s1 * gnp - (s1 * (s1 + 1)) / 2 + (s2 - s1 - 1); };
+    // every point's off-diagonal tuples, once: step - 1 | edge within the point << 2 | bank class << 7
+    std::vector<int> tp_off(P + 1, 0);
+    std::vector<uint16_t> tp;
+    tp.reserve((size_t)E * 2);
+    for (int p = 0; p < P && greedy; ++p) {
       const int k = cp_off[p + 1] - cp_off[p];
-      if (cur_edges + k > 64 && cur_edges > 0) { b->se_chunk_pt0.push_back(p); cur_edges = 0; }
-      cur_edges += k;
+      const int* ps = &cp_pose[cp_off[p]];
+      for (int dd = 1; dd <= k / 2 && dd <= MAXD; ++dd)
+        for (int a1 = 0; a1 < k && a1 < 32; ++a1) {
+          if (2 * dd == k && a1 >= dd) break;
+          const int s1 = gslot[ps[a1]], s2 = gslot[ps[(a1 + dd) % k]];
+          if (s1 < 0 || s2 < 0 || s1 == s2) continue;
+          tp.push_back((uint16_t)((dd - 1) | (a1 << 2) | ((opair(std::min(s1, s2), std::max(s1, s2)) & 15) << 7)));
+        }
+      tp_off[p + 1] = (int)tp.size();
+    }
+    // what point p would add to the chunk's atomic slots if it were placed at lane cur_edges (0 = every tuple finds a free bank in its
+    // group); the tuples are counted in as they go (a point's own tuples compete too) and taken out again unless the point is placed
+    auto cost_of = [&](int p, bool mark, int limit) {
+      int cost = 0, t = tp_off[p];
+      const int t1 = tp_off[p + 1];
+      for (; t < t1 && cost < limit; ++t) {
+        const int w = tp[t];
+        cost += cls[w & 3][((cur_edges + ((w >> 2) & 31)) >> 4) & 3][w >> 7]++;
+      }
+      if (!mark)
+        for (int u = tp_off[p]; u < t; ++u) { const int w = tp[u]; --cls[w & 3][((cur_edges + ((w >> 2) & 31)) >> 4) & 3][w >> 7]; }
+      return cost;
+    };
+    auto place_diag = [&](int p) {                     // copies of the diagonal blocks: the least-used bank of the lane's group
+      const int k = cp_off[p + 1] - cp_off[p];
+      for (int a1 = 0; a1 < k; ++a1) {
+        const int s = gslot[cp_pose[cp_off[p] + a1]];
+        if (s < 0) continue;
+        const int g = ((cur_edges + a1) >> 4) & 3;
+        int best = 0, best_cost = 1 << 30;
+        for (int r = 0; r < 4; ++r) {
+          const int cost = dcls[g][(BA_SE_DSTRIDE * (r * gnp + s)) & 15] * 4 + r;
+          if (cost < best_cost) { best_cost = cost; best = r; }
+        }
+        cp_rank[cp_off[p] + a1] = (uint8_t)best;
+        ++dcls[g][(BA_SE_DSTRIDE * (best * gnp + s)) & 15];
+      }
+    };
+    b->se_chunk_pt0.assign(1, 0);
+    while (placed < P) {
+      int pick = -1, prev_pick = -1;
+      if (greedy) {
+        // good enough ends the scan: nothing may repeat while the 16-lane group is young, one or two repeats once it is three quarters full
+        // (16 tuples on 16 banks without any repeat is out of reach anyway; the scan is the host cost of a window's set-up)
+        const int q = (cur_edges & 15) >> 2, accept = q < 2 ? 0 : q - 1;
+        int prev = -1, scanned = 0, best_cost = 1 << 30;
+        for (int p = head; p < P && scanned < LA; prev = p, p = nxt[p], ++scanned) {
+          if (cur_edges + (cp_off[p + 1] - cp_off[p]) > 64) continue;
+          const int c = cost_of(p, false, best_cost);
+          if (c < best_cost) { best_cost = c; pick = p; prev_pick = prev; if (c <= accept) break; }
+        }
+      } else if (cur_edges + (cp_off[head + 1] - cp_off[head]) <= 64) {
+        pick = head;
+      }
+      if (pick < 0) {
+        if (cur_edges == 0) { pick = head; prev_pick = -1; }          // a point with more than 64 edges: the kernel is refused below
+        else {
+          b->se_chunk_pt0.push_back(placed);
+          cur_edges = 0;
+          memset(cls, 0, sizeof(cls)); memset(dcls, 0, sizeof(dcls));
+          continue;
+        }
+      }
+      if (greedy) cost_of(pick, true, 1 << 30);
+      place_diag(pick);
+      cur_edges += cp_off[pick + 1] - cp_off[pick];
+      prank[pick] = placed; b->pinv[placed] = pick; ++placed;
+      if (prev_pick < 0) head = nxt[pick]; else nxt[prev_pick] = nxt[pick];
     }
     b->se_chunk_pt0.push_back(P);
   }
+  tick("chunks");
   // sort edges by (internal point, pose): CSR by point; per-pose edge lists reference sorted positions
   b->perm.resize(E);
   std::iota(b->perm.begin(), b->perm.end(), 0);
@@ -192,6 +321,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   b->np = np;
   const int n = 6 * np;
   b->nblk_e = (E + 255) / 256; b->nblk_p = (P + 127) / 128;
+  tick("csr");
   BA_TRY(ba_alloc(b, &b->d_fixed, K)); BA_TRY(ba_alloc(b, &b->d_pose_slot, K)); BA_TRY(ba_alloc(b, &b->d_e_pose, E));
   BA_TRY(ba_alloc(b, &b->d_e_point, E)); BA_TRY(ba_alloc(b, &b->d_e_obs, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_inv, E));
   BA_TRY(ba_alloc(b, &b->d_e_face, E)); BA_TRY(ba_alloc(b, &b->d_pt_off, P + 1)); BA_TRY(ba_alloc(b, &b->d_pose_off, K + 1));
@@ -207,6 +337,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
   BA_HIP(hipHostMalloc((void**)&b->h_pin, 8 * sizeof(double)));
   BA_TRY(ba_alloc(b, &b->d_pose_partial, (size_t)std::max(np, 1) * BA_POSE_CHUNKS * 27)); BA_TRY(ba_alloc(b, &b->d_db, 3 * (size_t)P));
+  tick("alloc");
   // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2
   {
     struct Tup { int pair, a1, a2; };
@@ -221,7 +352,14 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
           tups.push_back({s1 * np + s2, a1, a2});
         }
       }
-    std::stable_sort(tups.begin(), tups.end(), [](const Tup& x, const Tup& y) { return x.pair < y.pair; });
+    {   // stable counting sort by pair (np^2 keys): the list has ~10 entries per point
+      std::vector<int> cnt((size_t)np * np + 1, 0);
+      for (const Tup& t : tups) ++cnt[t.pair + 1];
+      for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+      std::vector<Tup> sorted(tups.size());
+      for (const Tup& t : tups) sorted[cnt[t.pair]++] = t;
+      tups.swap(sorted);
+    }
     std::vector<int> ps1, ps2, poff;
     std::vector<int2> tt(tups.size());
     for (size_t i = 0; i < tups.size(); ++i) {
@@ -236,6 +374,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
       BA_TRY(ba_alloc(b, &b->d_pair_of_block, pob.size()));
       BA_HIP(hipMemcpy(b->d_pair_of_block, pob.data(), pob.size() * sizeof(int), hipMemcpyHostToDevice));
     }
+    tick("tuples");
     // ---- work lists of the per-point Schur kernel (cms_ba_schur_points.hip): batches of consecutive points whose edges fit
     // LDS, ranges of consecutive batches (one workgroup each), one owner slot per co-visible pair (several helper slots for
     // the diagonal pairs, which get one tuple per edge), per (batch, slot) the tuples as 16-bit local edge ids
@@ -287,33 +426,35 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
           const int h = rr[(size_t)bt * npairs + pr]++ % nhd;     // round robin over the helpers, per batch
           return slot_first[pr] + h;
         };
-        std::vector<std::vector<std::pair<int, uint16_t>>> per_batch(nbat);
-        for (int p = 0; p < P; ++p) {
-          const int bt = bat_of_point[p], e0 = bat_e0[bt];
-          for (int a1 = pt_off[p]; a1 < pt_off[p + 1]; ++a1) {
-            const int s1 = pose_slot[s_pose[a1]];
-            if (s1 < 0) continue;
-            for (int a2 = pt_off[p]; a2 < pt_off[p + 1]; ++a2) {
-              const int s2 = pose_slot[s_pose[a2]];
-              if (s2 < 0 || s2 < s1) continue;
-              const int sl = slot_of(bt, pair_idx[(size_t)s1 * np + s2]);
-              per_batch[bt].push_back(std::make_pair(sl, (uint16_t)((a1 - e0) | ((a2 - e0) << 8))));
-            }
-          }
-        }
+        // batch by batch (a batch's points are consecutive): the tuples with their slot, then a stable counting sort by slot
         std::vector<int> tup_base(nbat + 1, 0);
         std::vector<uint16_t> tup16, off16((size_t)nbat * off_stride * 2, 0);
-        for (int bt = 0; bt < nbat; ++bt) {
-          auto& v = per_batch[bt];
-          std::stable_sort(v.begin(), v.end(), [](const std::pair<int, uint16_t>& x, const std::pair<int, uint16_t>& y) { return x.first < y.first; });
-          uint16_t* off = &off16[(size_t)bt * off_stride * 2];
-          size_t i = 0;
-          for (int sl = 0; sl <= nslots; ++sl) {
-            while (i < v.size() && v[i].first < sl) ++i;
-            off[sl] = (uint16_t)i;
+        tup16.reserve((size_t)E * 3);
+        std::vector<std::pair<int, uint16_t>> v;
+        std::vector<int> cnt((size_t)nslots + 2);
+        for (int bt = 0, p = 0; bt < nbat; ++bt) {
+          const int e0 = bat_e0[bt];
+          v.clear();
+          for (; p < P && bat_of_point[p] == bt; ++p) {
+            for (int a1 = pt_off[p]; a1 < pt_off[p + 1]; ++a1) {
+              const int s1 = pose_slot[s_pose[a1]];
+              if (s1 < 0) continue;
+              for (int a2 = pt_off[p]; a2 < pt_off[p + 1]; ++a2) {
+                const int s2 = pose_slot[s_pose[a2]];
+                if (s2 < 0 || s2 < s1) continue;
+                v.push_back(std::make_pair(slot_of(bt, pair_idx[(size_t)s1 * np + s2]), (uint16_t)((a1 - e0) | ((a2 - e0) << 8))));
+              }
+            }
           }
+          std::fill(cnt.begin(), cnt.end(), 0);
+          for (const auto& x : v) ++cnt[x.first + 1];
+          for (int sl = 0; sl <= nslots; ++sl) cnt[sl + 1] += cnt[sl];
+          uint16_t* off = &off16[(size_t)bt * off_stride * 2];
+          for (int sl = 0; sl <= nslots; ++sl) off[sl] = (uint16_t)cnt[sl];
           tup_base[bt] = (int)(tup16.size() / 2);
-          for (const auto& x : v) tup16.push_back(x.second);
+          const size_t base = tup16.size();
+          tup16.resize(base + v.size());
+          for (const auto& x : v) tup16[base + cnt[x.first]++] = x.second;
           if (tup16.size() & 1) tup16.push_back(0);
         }
         tup_base[nbat] = (int)(tup16.size() / 2);
@@ -341,6 +482,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
         b->sp_lds = (size_t)BA_SP_MAXE * BA_SP_ROW * sizeof(double) + BA_SP_MAXT * 2 + (BA_SP_MAX_THREADS + 4) * 2;
       }
     }
+    tick("sp");
     // ---- work list of the edge-major Schur kernel (cms_ba_schur_edges.hip): chunks of whole points with <= 64 edges, one wavefront
     // each; dense enumeration of the pose pairs s1 <= s2 and the matching tables for the solve kernel's assembly
     if (np >= 1) {
@@ -356,15 +498,13 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
         if (p1 == p0) continue;
         if (pt_off[p1] - pt_off[p0] > 64) { ok = false; break; }
         ce0.push_back(pt_off[p0]);
-        int seen[256];
-        for (int k2 = 0; k2 < K; ++k2) seen[k2] = 0;
         for (int p = p0; p < p1 && ok; ++p) {
           const int ne = pt_off[p + 1] - pt_off[p];
           if (ne > 31) { ok = false; break; }
           for (int a1 = 0; a1 < ne; ++a1) {
             const int e = pt_off[p] + a1;
             if (a1 > 0 && s_pose[e] == s_pose[e - 1]) ok = false;       // a point seen twice by one key frame: the pair-owner kernel handles it
-            const int rank = seen[s_pose[e]]++ % BA_SE_DCOPIES;
+            const int rank = cp_rank[(size_t)cp_off[b->pinv[p]] + a1] % BA_SE_DCOPIES;      // chosen with the chunk (edges of a point are in pose order in both lists)
             info[e] = (uint32_t)a1 | ((uint32_t)ne << 5) | ((uint32_t)(pose_slot[s_pose[e]] + 1) << 10) | ((uint32_t)s_face[e] << 16) | ((uint32_t)s_pose[e] << 19) |
                       ((uint32_t)rank << 27);
           }
@@ -379,7 +519,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
         for (int I = 0; I < np; ++I)
           for (int Kc = 0; Kc <= I; ++Kc) pob[(size_t)I * (I + 1) / 2 + Kc] = Kc * np - (Kc * (Kc - 1)) / 2 + (I - Kc);   // block (I, K): pair (s1 = K, s2 = I)
         for (int i = 0; i <= NP2; ++i) ident[i] = i;
-        BA_TRY(ba_alloc(b, &b->d_se_chunk_e0, ce0.size())); BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)R * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_info, info.size()));
+        BA_TRY(ba_alloc(b, &b->d_se_chunk_e0, ce0.size())); BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)R * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)R * np * 6)); BA_TRY(ba_alloc(b, &b->d_se_info, info.size()));
         BA_HIP(hipMemcpy(b->d_se_info, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_pob, pob.size())); BA_TRY(ba_alloc(b, &b->d_se_chunk_off, ident.size()));
         BA_HIP(hipMemcpy(b->d_se_chunk_e0, ce0.data(), ce0.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -396,10 +536,11 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
           b->se.cpw_t = cpw_t;
           b->se.Rt = (nchunks + cpw_t - 1) / cpw_t;
         }
-        b->se.R = R; b->se.nchunks = nchunks; b->se.cpw = cpw; b->se.npairs2 = NP2; b->se.chunk_e0 = b->d_se_chunk_e0; b->se.partial = b->d_se_partial; b->se.e_info = b->d_se_info;
+        b->se.R = R; b->se.nchunks = nchunks; b->se.cpw = cpw; b->se.npairs2 = NP2; b->se.chunk_e0 = b->d_se_chunk_e0; b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial; b->se.e_info = b->d_se_info;
         b->se_lds = lds;
       }
     }
+    tick("se");
     std::vector<int> pcoff(1, 0);
     std::vector<int2> crange;
     for (size_t pr = 0; pr + 1 < poff.size(); ++pr) {
@@ -422,6 +563,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   }
   b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
   b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
+  tick("tuple-upload");
   // the three-lanes-per-block variant (grouped driver): 3 x blocks <= 1024 threads
   b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 2 * (size_t)n + 8) * sizeof(double);
   b->solve_blk3 = b->solve_blk && 3 * (np * (np + 1) / 2) <= 1024 && b->blk3_lds <= BA_LDS_CEILING;
@@ -454,8 +596,11 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   d.e_point = b->d_e_point; d.e_obs = b->d_e_obs; d.e_inv = b->d_e_inv; d.e_face = b->d_e_face; d.pt_off = b->d_pt_off;
   d.pose_off = b->d_pose_off; d.pose_edges = b->d_pose_edges; d.level = b->d_level; d.err = b->d_err; d.ow = b->d_ow;
   d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
+  tick("uploads");
   int rc = cms_ba_reset(b);
   if (rc) { cms_ba_destroy(b); return rc; }
+  tick("reset");
+  if (timing) fprintf(stderr, "[cms_ba_create] K %d P %d E %d ms:%s\n", K, P, E, t_log.c_str());
   *out = b;
   return CMS_OK;
 }

@@ -334,6 +334,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   for (int w = 0; w < n; ++w) first_round = first_round || st[w].it == 0;
   const bool use_se = ba_use_se(bas, n);
   const bool use_te = ba_use_te(bas, n);
+  bool iter_phase = true;           // fused linearisation: only the first round of a stage has an ITER phase
   // trial solve: three lanes per 6x6 block where every window allows it (CMS_BA_SOLVE1=1: one lane per block, the single-window kernel's scheme)
   static const bool solve1 = getenv("CMS_BA_SOLVE1") != nullptr;
   bool use_s3 = !solve1;
@@ -354,6 +355,10 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // host keeps at most two rounds in the queue: the one that is running and the one behind it (one, if the caller passed a stop flag:
   // the flag is then honoured at the very next trial boundary).  It looks at the mirrored state and at the caller's stop flag before
   // every round it adds; the price is at most two rounds of idle launches after the last window finished.
+  // linearisation inside the Schur kernel (cms_ba_schur_edges.hip, FUSED): needs the edge-major kernels and the three-lane solve
+  static const bool no_fused = getenv("CMS_BA_NO_FUSED_LIN") != nullptr;
+  const bool fused = use_se && use_te && use_s3 && !no_fused;
+  dyn.fused_lin = fused ? 1 : 0;
   int k = 0;
   const int pk = g->prof_kernel;
   static const int dup = getenv("CMS_BA_DUP") ? atoi(getenv("CMS_BA_DUP")) : 0;   // developer knob: launch kernel <id> of every round twice (all of
@@ -370,22 +375,28 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
       }
       first_round = false;
-      {
+      if (iter_phase) {
         const int npb = (max_P + 255) / 256;
         bracket(1, 0);
         hipLaunchKernelGGL(kb_ba_lin, dim3(npb + max_K * BA_POSE_CHUNKS, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER, npb);
         if (dup == 1) hipLaunchKernelGGL(kb_ba_lin, dim3(npb + max_K * BA_POSE_CHUNKS, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER, npb);
         bracket(1, 1);
+        bracket(2, 0);
+        hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);      // + the pose slice sums (fold_finish)
+        bracket(2, 1);
       }
-      bracket(2, 0);
-      hipLaunchKernelGGL(kb_ba_maxdiag, dim3(1, 1, n), dim3(1024), 0, s, ditems, dyn, (int)BA_PHASE_ITER);      // + the pose slice sums (fold_finish)
-      bracket(2, 1);
+      if (fused) iter_phase = false;
       if (!all_sp)
         hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       if (use_se) {
         bracket(3, 0);
-        hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
-        if (dup == 3) hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (fused) {
+          hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        } else {
+          hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          if (dup == 3) hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        }
         bracket(3, 1);
         bracket(4, 0);
         hipLaunchKernelGGL(kb_ba_schur_edges_reduce, dim3(max_np2, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);

@@ -308,7 +308,9 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
-                 double* __restrict__ xp_out, double* __restrict__ scal) {
+                 double* __restrict__ xp_out, double* __restrict__ scal, bool lumped = false) {
+  // lumped: the diagonal blocks of chunk_sum hold S - Hpp and s - bp already (fused linearisation, cms_ba_schur_edges.hip); bp is only
+  // read for the gain ratio
   extern __shared__ __align__(16) double sm[];
   const int nb = d.np, n = 6 * nb, nblk = nb * (nb + 1) / 2;
   // LDS (doubles): L panels [nb (nb - 1) / 2][38] | diagonal factors [nb][36] | W double buffer [2][nb][38] | diag staging [36] | y [n] | 1/D [n]
@@ -335,8 +337,10 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __re
 #pragma unroll
     for (int q = 0; q < 12; ++q) a[q] = 0.0;
     if (I == K) {
+      if (!lumped) {
 #pragma unroll
-      for (int q = 0; q < 12; ++q) a[q] = Hpp[36 * I + 6 * r0 + q];
+        for (int q = 0; q < 12; ++q) a[q] = Hpp[36 * I + 6 * r0 + q];
+      }
       a[r0] += lambda; a[6 + r0 + 1] += lambda;
     }
     const int pr = pair_of_block[I * (I + 1) / 2 + K];
@@ -350,7 +354,10 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __re
         if (I == K) { yb[0] += cs[36 + r0]; yb[1] += cs[36 + r0 + 1]; }
       }
     }
-    if (I == K) { ybuf[6 * I + r0] = bp[6 * I + r0] - yb[0]; ybuf[6 * I + r0 + 1] = bp[6 * I + r0 + 1] - yb[1]; }
+    if (I == K) {
+      ybuf[6 * I + r0] = (lumped ? 0.0 : bp[6 * I + r0]) - yb[0];
+      ybuf[6 * I + r0 + 1] = (lumped ? 0.0 : bp[6 * I + r0 + 1]) - yb[1];
+    }
   }
   // a diagonal block is gathered in LDS by its three lanes and factored by one (ba_factor_diag works on a full 6x6); the lanes of a block may
   // sit in two wavefronts (3 does not divide 64), so block barriers order the staging against the read

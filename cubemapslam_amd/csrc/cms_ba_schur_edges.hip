@@ -38,7 +38,7 @@
 #include <stdint.h>
 
 #define BA_SE_THREADS 512
-#define BA_SE_SSTRIDE 43          /* doubles per pose pair in the LDS copy: 36 + 6, padded against bank aliasing of neighbouring pairs */
+#define BA_SE_SSTRIDE 37          /* doubles per off-diagonal pose pair in the LDS copy: 36, padded to an odd count (bank aliasing of neighbouring pairs) */
 #define BA_SE_RANGES 32           /* workgroups per window */
 
 struct BaSe {                      // device view of the edge-major work list (cms_api_ba.hip)
@@ -49,16 +49,38 @@ struct BaSe {                      // device view of the edge-major work list (c
   const uint32_t* e_info;         // per edge: index within its point (5 bits) | edges of the point << 5 | (free-pose slot + 1) << 10 | face << 16 |
                                   // key frame << 19 (8 bits) | copy of the diagonal blocks its (a, a) tuple goes to << 27 (2 bits)
   double* partial;                // R x npairs2 x 42
+  double* bp_partial;             // R x np x 6: the ranges' sums of bp (fused linearisation: the diagonal blocks of `partial` then hold S - Hpp and s - bp)
   const int* lone; int nlone;     // points without any observation (in no chunk): the trial kernel copies their position
 };
 
 __device__ __forceinline__ int ba_se_pair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 - 1)) >> 1) + (s2 - s1); }   // s1 <= s2, dense (with diagonal)
 __device__ __forceinline__ int ba_se_opair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 + 1)) >> 1) + (s2 - s1 - 1); }   // s1 < s2, off-diagonal only
+// layout of a 6x6 block of S in LDS: strictly upper elements (r < q) at 0..14, their transposes at 16..30, the diagonal at 15, 31, 32..35
+__host__ __device__ constexpr int ba_se_upper(int r, int q) { return r * 5 - (r * (r - 1)) / 2 + (q - r - 1); }      // r < q
+__host__ __device__ constexpr int ba_se_off(int r, int q) {
+  return r < q ? ba_se_upper(r, q) : r > q ? 16 + ba_se_upper(q, r) : (r == 0 ? 15 : r == 1 ? 31 : 30 + r);
+}
 #define BA_SE_DCOPIES 4
-#define BA_SE_DSTRIDE 28          /* 21 (upper triangle) + 6 (right-hand side) + 1 */
+#define BA_SE_DSTRIDE 33          /* 21 (upper triangle) + 6 (right-hand side) + 6 (bp, fused linearisation only): an ODD number of doubles, so that consecutive
+                                     (copy, key frame) rows walk through all 16 f64 banks of the LDS (28 left them on four) */
 
-__device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
-                                                    const double* __restrict__ poses, const double* __restrict__ pts) {
+// key-frame-frame point from the LDS copy of a pose, in cam_point's operation order and WITHOUT contraction: the residual of the fused
+// linearisation must be the one ba_errors_body / the trial kernels compute (the projection is rounded to float: edge_error_v)
+__device__ __forceinline__ void ba_se_cam_point(const double* Rt, const double* X, double* Xc) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Xc[i] = Rt[3 * i] * X[0] + Rt[3 * i + 1] * X[1] + Rt[3 * i + 2] * X[2] + Rt[9 + i];
+}
+
+// FUSED = true: the kernel also LINEARISES (what kb_ba_lin does in front of the first trial of an iteration): a lane computes its edge's
+// residual, robust weight and Jacobians from the current estimate; the lanes of a point exchange their 3x3 / 3x1 contributions through
+// their LDS rows, so that every one of them holds Hll and bl of the point (its first lane stores them for the trial kernel); the key
+// frame's own block  ow Jp^T Jp  and gradient ride on the diagonal tuple's additions (the diagonal block of `partial` becomes
+// S_aa - Hpp_aa, its right-hand side  s_a - bp_a; bp alone goes to six more slots: the gain ratio needs it).  From the second iteration
+// of a stage on no other kernel linearises: kb_ba_lin + kb_ba_maxdiag drop out of the round (25 + 7 us of ~165 for eight windows), and a
+// rejected trial merely repeats arithmetic this kernel had to do anyway (it rebuilt the Jacobians from the estimate before, too).
+template <bool FUSED>
+__device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+                                                    const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
 #pragma clang fp contract(fast)
   extern __shared__ __align__(16) double se_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -83,47 +105,116 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, co
   const int c0 = BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);
   // The loop is software pipelined over a wave's chunks: the per-edge words of chunk c + nw are requested before chunk c is worked on,
   // its per-point operands (position, Hll, bl) right after chunk c's rows are published -- the atomics section hides their latency.
-  int n_p = 0; uint32_t n_info = 0; double n_ow = 0.0;
+  int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;          // FUSED: n_ow carries the edge's information (0 for an excluded edge)
   double n_X[3] = {0, 0, 0}, n_H[6] = {1, 0, 1, 0, 0, 1}, n_b[3] = {0, 0, 0};
+  double2 n_obs = make_double2(0.0, 0.0);
   auto load1 = [&](int c) {
-    n_info = 0; n_ow = 0.0; n_p = 0;
+    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0;
     if (c < c1) {
       const int e = se.chunk_e0[c] + lane;
-      if (e < se.chunk_e0[c + 1]) { n_p = d.e_point[e]; n_info = se.e_info[e]; n_ow = d.ow[e]; }
+      if (e < se.chunk_e0[c + 1]) {
+        n_p = d.e_point[e]; n_info = se.e_info[e]; n_e = e;
+        if (FUSED) { n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0; n_obs = reinterpret_cast<const double2*>(d.e_obs)[e]; }
+        else n_ow = d.ow[e];
+      }
     }
   };
   auto load2 = [&]() {
     if (n_info != 0) {
-      const double* Xp = pts + 3 * (size_t)n_p; const double* H = Hll + 9 * (size_t)n_p; const double* bp = bl + 3 * (size_t)n_p;
+      const double* Xp = pts + 3 * (size_t)n_p;
       n_X[0] = Xp[0]; n_X[1] = Xp[1]; n_X[2] = Xp[2];
-      n_H[0] = H[0]; n_H[1] = H[3]; n_H[2] = H[4]; n_H[3] = H[6]; n_H[4] = H[7]; n_H[5] = H[8];
-      n_b[0] = bp[0]; n_b[1] = bp[1]; n_b[2] = bp[2];
+      if (!FUSED) {
+        const double* H = Hll + 9 * (size_t)n_p; const double* bp = bl + 3 * (size_t)n_p;
+        n_H[0] = H[0]; n_H[1] = H[3]; n_H[2] = H[4]; n_H[3] = H[6]; n_H[4] = H[7]; n_H[5] = H[8];
+        n_b[0] = bp[0]; n_b[1] = bp[1]; n_b[2] = bp[2];
+      }
     }
   };
   load1(c0 + wave);
   load2();
   for (int c = c0 + wave; c < c1; c += nw) {
     const uint32_t info = n_info;
-    const double ow = n_ow;
-    const double X[3] = {n_X[0], n_X[1], n_X[2]}, Hc[6] = {n_H[0], n_H[1], n_H[2], n_H[3], n_H[4], n_H[5]}, bc[3] = {n_b[0], n_b[1], n_b[2]};
+    double ow = n_ow;
+    const int pnt = n_p, eid = n_e;
+    const double2 obs = n_obs;
+    const double X[3] = {n_X[0], n_X[1], n_X[2]};
+    double Hc[6] = {n_H[0], n_H[1], n_H[2], n_H[3], n_H[4], n_H[5]}, bc[3] = {n_b[0], n_b[1], n_b[2]};
     load1(c + nw);
     int slot = -1, a = 0, k = 1;
     double W[18], WD[18], z[3];
+    double Jp[12], Jl[6], o0 = 0.0, o1 = 0.0;         // FUSED: kept for the key frame's own block on the diagonal tuple
 #pragma unroll
     for (int i = 0; i < 18; ++i) { W[i] = 0.0; WD[i] = 0.0; }
     z[0] = z[1] = z[2] = 0.0;
+    bool have_jac = false;
     if (info != 0) {
       a = info & 31; k = (info >> 5) & 31;
       const int s = (int)((info >> 10) & 63) - 1, face = (info >> 16) & 7, kp = (info >> 19) & 255;
-      if (s >= 0 && ow != 0.0) {
-        slot = s;
+      if (FUSED ? (ow != 0.0) : (s >= 0 && ow != 0.0)) {
         const double* Rt = prt + 12 * kp;
-        double R[9], Xc[3], Jp[12], Jl[6];
+        double R[9], Xc[3];
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+        if (FUSED) {
+          ba_se_cam_point(Rt, X, Xc);
+          double r[2], rho0;
+          edge_error_v(d, face, obs.x, obs.y, Xc, r);
+          const double om = ow;
+          const double w = robust ? huber_w(om * (r[0] * r[0] + r[1] * r[1]), delta, &rho0) : 1.0;
+          ow = w * om;
+          o0 = -om * r[0] * w; o1 = -om * r[1] * w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) Xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + Rt[9 + i];
+          for (int i = 0; i < 3; ++i) Xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + Rt[9 + i];
+        }
         edge_jac_face(d, face, Xc, R, Jp, Jl);
+        have_jac = true;
+        if (s >= 0) slot = s;
+      }
+    }
+    if (FUSED) {
+      // ---- Hll and bl of the point: every lane publishes its edge's share (upper triangle | gradient) in its row, then adds the rows of its
+      // point's edges in edge order -- the order ba_lin_points_body adds them in; all lanes of a point end up with the same bits
+      double hl[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) hl[i] = 0.0;
+      if (have_jac) {
+        hl[0] = ow * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); hl[1] = ow * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); hl[2] = ow * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
+        hl[3] = ow * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); hl[4] = ow * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); hl[5] = ow * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+        hl[6] = Jl[0] * o0 + Jl[3] * o1; hl[7] = Jl[1] * o0 + Jl[4] * o1; hl[8] = Jl[2] * o0 + Jl[5] * o1;
+      }
+      if (info != 0) d.ow[eid] = have_jac ? ow : 0.0;          // the trial kernel rebuilds the edge's block from it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      {
+        double2* row2 = reinterpret_cast<double2*>(myrows + (size_t)lane * 18);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) row2[i] = make_double2(hl[2 * i], hl[2 * i + 1]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double sum[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) sum[i] = 0.0;
+      int kmax = k;
+      for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o));
+      for (int j = 0; j < kmax; ++j) {
+        if (info != 0 && j < k) {
+          const double2* row2 = reinterpret_cast<const double2*>(myrows + (size_t)(lane - a + j) * 18);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) { const double2 u = row2[i]; sum[2 * i] += u.x; sum[2 * i + 1] += u.y; }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();                       // the rows are reused for W below
+      if (info != 0 && a == 0) {
+        double* H = Hll + 9 * (size_t)pnt; double* bq = bl + 3 * (size_t)pnt;
+        H[0] = sum[0]; H[1] = sum[1]; H[2] = sum[2]; H[3] = sum[1]; H[4] = sum[3]; H[5] = sum[4]; H[6] = sum[2]; H[7] = sum[4]; H[8] = sum[5];
+        bq[0] = sum[6]; bq[1] = sum[7]; bq[2] = sum[8];
+      }
+      Hc[0] = sum[0]; Hc[1] = sum[1]; Hc[2] = sum[3]; Hc[3] = sum[2]; Hc[4] = sum[4]; Hc[5] = sum[5];      // (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+      bc[0] = sum[6]; bc[1] = sum[7]; bc[2] = sum[8];
+    }
+    if (slot >= 0) {
         // A = Hll + lambda I = L D L^T (unit lower L)
         const double a00 = Hc[0] + lambda, a10 = Hc[1], a11 = Hc[2] + lambda, a20 = Hc[3], a21 = Hc[4], a22 = Hc[5] + lambda;
         const double i0 = 1.0 / a00;
@@ -144,7 +235,6 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, co
           W[3 * r] = w0; W[3 * r + 1] = w1; W[3 * r + 2] = w2;
           WD[3 * r] = w0 * i0; WD[3 * r + 1] = w1 * i1; WD[3 * r + 2] = w2 * i2;
         }
-      }
     }
     // ---- publish this lane's W (LDS operations of one wavefront execute in program order: rows written here are what the reads
     // below see, and the reads of the previous chunk are through before these writes)
@@ -165,11 +255,22 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, co
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
 #pragma unroll
-        for (int q = r; q < 6; ++q)
-          unsafeAtomicAdd(base + (cidx++), WD[3 * r] * W[3 * q] + WD[3 * r + 1] * W[3 * q + 1] + WD[3 * r + 2] * W[3 * q + 2]);
+        for (int q = r; q < 6; ++q) {
+          double v = WD[3 * r] * W[3 * q] + WD[3 * r + 1] * W[3 * q + 1] + WD[3 * r + 2] * W[3 * q + 2];
+          if (FUSED) v -= ow * (Jp[r] * Jp[q] + Jp[6 + r] * Jp[6 + q]);          // S_aa - Hpp_aa
+          unsafeAtomicAdd(base + (cidx++), v);
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 6; ++r) unsafeAtomicAdd(base + 21 + r, W[3 * r] * z[0] + W[3 * r + 1] * z[1] + W[3 * r + 2] * z[2]);
+      for (int r = 0; r < 6; ++r) {
+        double v = W[3 * r] * z[0] + W[3 * r + 1] * z[1] + W[3 * r + 2] * z[2];
+        if (FUSED) {
+          const double g = Jp[r] * o0 + Jp[6 + r] * o1;                          // bp_a
+          v -= g;
+          unsafeAtomicAdd(base + 27 + r, g);
+        }
+        unsafeAtomicAdd(base + 21 + r, v);
+      }
     }
     // ---- off-diagonal tuples: step d pairs lane a with (a + d) mod k; for even k the last step is done by the lower half only
     int kh = k >> 1;
@@ -187,16 +288,19 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, co
 #pragma unroll
         for (int i = 0; i < 9; ++i) { const double2 u = row2[i]; Wb[2 * i] = u.x; Wb[2 * i + 1] = u.y; }
         // the block of pair (s1 < s2) is W_1 D^-1 W_2^T; a wrapped partner has the lower slot (edges of a point ascend by key frame),
-        // this lane then holds the TRANSPOSE of the pair's block: same products, rows and columns swapped in the address
+        // this lane then holds the TRANSPOSE of the pair's block: same products, element (q, r) instead of (r, q).  The block's layout
+        // (ba_se_off) puts an element and its transpose 16 doubles apart -- the same LDS bank: what the host balances per group of 16
+        // lanes, the pair's bank class, holds for every lane of the instruction, wrapped or not.
         double* base = S + (size_t)(wrapped ? ba_se_opair(np, sb, slot) : ba_se_opair(np, slot, sb)) * BA_SE_SSTRIDE;
-        const int sr = wrapped ? 1 : 6, sc = wrapped ? 6 : 1;
+        double* base_up = base + (wrapped ? 16 : 0);      // elements r < q of this lane's product
+        double* base_lo = base + (wrapped ? 0 : 16);      // elements r > q
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          double* rowp = base + r * sr;
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
             const double v = WD[3 * r] * Wb[3 * q] + WD[3 * r + 1] * Wb[3 * q + 1] + WD[3 * r + 2] * Wb[3 * q + 2];
-            unsafeAtomicAdd(rowp + q * sc, v);      // (the host refuses this kernel for windows in which a point is seen twice by one key frame: sb != slot)
+            double* dst = r < q ? base_up + ba_se_upper(r, q) : r > q ? base_lo + ba_se_upper(q, r) : base + ba_se_off(r, r);
+            unsafeAtomicAdd(dst, v);      // (the host refuses this kernel for windows in which a point is seen twice by one key frame: sb != slot)
           }
         }
       }
@@ -217,9 +321,17 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, co
       else ci = 21 + (i - 36);
       for (int cp = 0; cp < BA_SE_DCOPIES; ++cp) v += Dg[((size_t)cp * np + s1) * BA_SE_DSTRIDE + ci];
     } else if (i < 36) {
-      v = S[(size_t)ba_se_opair(np, s1, s2) * BA_SE_SSTRIDE + i];
+      v = S[(size_t)ba_se_opair(np, s1, s2) * BA_SE_SSTRIDE + ba_se_off(i / 6, i % 6)];
     }
     se.partial[((size_t)BX * NP2 + pr) * 42 + i] = v;
+  }
+  if (FUSED) {
+    for (int o = tid; o < 6 * np; o += blockDim.x) {
+      const int s1 = o / 6, i = o - 6 * s1;
+      double v = 0.0;
+      for (int cp = 0; cp < BA_SE_DCOPIES; ++cp) v += Dg[((size_t)cp * np + s1) * BA_SE_DSTRIDE + 27 + i];
+      se.bp_partial[((size_t)BX * np + s1) * 6 + i] = v;
+    }
   }
 }
 

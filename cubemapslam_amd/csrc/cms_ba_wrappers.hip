@@ -41,6 +41,7 @@ struct BaDyn {
   int robust, set_level;
   double delta, chi2_th;
   int dev_lm, fold_finish;                           // 1: phase / cur / lambda / first_iter come from BaItem::lm instead of the arrays above
+  int fused_lin, pad;                                // 1: kb_ba_schur_edges linearises itself (cms_ba_schur_edges.hip): no ITER phase after a stage's first iteration
 };
 enum { BA_PHASE_IDLE = 0, BA_PHASE_ITER = 1, BA_PHASE_TRIAL = 2, BA_PHASE_CLASSIFY = 3 };
 
@@ -117,7 +118,7 @@ __device__ __forceinline__ void ba_lm_after_iter(BaLmDev* L, BaLmDev* H, double 
   *H = *L;
 }
 // end of a TRIAL: accept / reject, lambda update, the 10-trial rule and the termination tests (ba_finish_trial)
-__device__ __forceinline__ void ba_lm_after_trial(BaLmDev* L, BaLmDev* H, double tempChi, double den, int ok2) {
+__device__ __forceinline__ void ba_lm_after_trial(BaLmDev* L, BaLmDev* H, double tempChi, double den, int ok2, bool fused_lin = false) {
   if (!ok2) tempChi = 1.7976931348623157e308;
   double rho = (L->currentChi - tempChi) / (den + 1e-3);
   L->rho = rho;
@@ -141,6 +142,9 @@ __device__ __forceinline__ void ba_lm_after_trial(BaLmDev* L, BaLmDev* H, double
   }
   ++L->it;
   L->next = (terminate || L->it >= L->iterations) ? 2 : 0;
+  if (fused_lin && L->next == 0) {      // the next iteration's linearisation happens inside its first trial: what ba_lm_after_iter would do
+    L->iniChi = L->currentChi; L->rho = 0; L->qmax = 0; L->next = 1;
+  }
   *H = *L;
 }
 
@@ -239,13 +243,29 @@ extern "C" __global__ void __launch_bounds__(BA_SP_MAX_THREADS + BA_SP_STAGERS) 
 }
 extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_schur_edges(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.se.R)
-  ba_schur_edges_body(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur]);
+  ba_schur_edges_body<false>(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], 0, 0.0);
+}
+// ... and with the linearisation inside (dyn.fused_lin)
+extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_edges(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.R)
+  ba_schur_edges_body<true>(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_edges_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.se.R > 0 ? it.se.npairs2 : 0)
   BaSp v;                                          // the range sum only looks at these three fields
   v.R = it.se.R; v.npairs = it.se.npairs2; v.partial = it.se.partial;
   ba_schur_reduce_body(blockIdx.x, v, it.chunk_sum);
+  if (dyn.fused_lin && (int)blockIdx.x < it.d.np) {      // bp of key frame blockIdx.x: the ranges' sums, added in fixed order
+    __shared__ double bps[6 * BA_SE_RANGES];
+    const int R = min(it.se.R, BA_SE_RANGES);
+    for (int t = threadIdx.x; t < 6 * R; t += blockDim.x) bps[t] = it.se.bp_partial[((size_t)(t / 6) * it.d.np + blockIdx.x) * 6 + (t % 6)];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double sum = 0.0;
+      for (int r = 0; r < R; ++r) sum += bps[6 * r + threadIdx.x];
+      it.bp[6 * blockIdx.x + threadIdx.x] = sum;
+    }
+  }
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.sp.R > 0 ? it.sp.npairs : 0)
@@ -258,7 +278,8 @@ extern "C" __global__ void __launch_bounds__(384) kb_ba_trial_solve(const BaItem
 }
 extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
-  ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal);
+  ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal,
+                       dyn.fused_lin != 0);
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
@@ -277,7 +298,7 @@ __device__ __forceinline__ void kb_ba_reduce2_window(const BaItem* __restrict__ 
   if (dyn.dev_lm && threadIdx.x == 0) {
     int ok2;
     memcpy(&ok2, &it.scal[4], sizeof(int));
-    ba_lm_after_trial(it.lm, it.hlm, it.scal[1], it.scal[2], ok2);
+    ba_lm_after_trial(it.lm, it.hlm, it.scal[1], it.scal[2], ok2, dyn.fused_lin != 0);
   }
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {

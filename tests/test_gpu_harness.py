@@ -18,6 +18,24 @@ def test_closed_loop_product_equals_oracle_frame_by_frame():
     kw = dict(kf_every=4, ba_window=6, new_points_per_kf=400)
     gpu = harness.GpuBackend(camd, mask)
     ora = OracleBackend(camd, mask)
+    # every local-BA problem the PRODUCT's loop poses is also given to the oracle: on identical input the outlier flags and iteration counts
+    # must be identical and the estimates agree within the BA bar.  (Between the two closed loops the BA inputs differ in the last float
+    # digits -- the write-back goes through float -- and an observation whose chi2 sits on the 5.991 threshold may then fall on either
+    # side: the loops' outlier COUNTS are compared with a margin of two.)
+    forced = []
+    product_ba = gpu.local_ba
+
+    def ba_and_check(prob):
+        r = product_ba(prob)
+        o = ora.local_ba(prob)
+        assert list(r[3]) == list(o[3]), (r[3], o[3])
+        assert np.array_equal(np.asarray(r[2]) != 0, np.asarray(o[2]) != 0), int(((np.asarray(r[2]) != 0) != (np.asarray(o[2]) != 0)).sum())
+        upd = max(float(np.abs(o[1] - prob["points"]).max()), 1e-12)
+        assert float(np.abs(r[1] - o[1]).max()) <= 1e-4 * upd and float(np.abs(r[0] - o[0]).max()) <= 1e-4 * upd, (np.abs(r[1] - o[1]).max(), upd)
+        forced.append(len(prob["e_pose"]))
+        return r
+
+    gpu.local_ba = ba_and_check
     sf_g, is_g = gpu.scale_factors(); sf_o, is_o = ora.scale_factors()
     assert np.array_equal(sf_g.view(np.uint32), sf_o.view(np.uint32)) and np.array_equal(is_g.view(np.uint32), is_o.view(np.uint32))
     tg, secs = harness.run_sequence(camd, gpu, frames, gts, **kw)
@@ -33,8 +51,10 @@ def test_closed_loop_product_equals_oracle_frame_by_frame():
         for key in ("init_matches", "mm_match", "lm_match"):
             if key in b:
                 assert key in a and np.array_equal(a[key], b[key]), (f, key, int((a[key] != b[key]).sum()))
-        for key in ("n_init", "n_map", "n_mm", "n_mm_inliers", "n_lm", "n_in_view", "n_inliers", "new_points", "ba_edges", "ba_iterations", "ba_outliers", "ba_kfs", "ba_points"):
+        for key in ("n_init", "n_map", "n_mm", "n_mm_inliers", "n_lm", "n_in_view", "n_inliers", "new_points", "ba_edges", "ba_iterations", "ba_kfs", "ba_points"):
             assert a.get(key) == b.get(key), (f, key, a.get(key), b.get(key))
+        if "ba_outliers" in b:
+            assert abs(a["ba_outliers"] - b["ba_outliers"]) <= 2, (f, a["ba_outliers"], b["ba_outliers"])
         for key in ("pose", "pose_after_ba"):
             if key in b:
                 # the parity bar of the optimisers is 1e-4 relative on the UPDATE (a frame's pose moves by centimetres per optimisation, so
@@ -44,7 +64,7 @@ def test_closed_loop_product_equals_oracle_frame_by_frame():
                 worst = max(worst, dmax)
                 assert dmax <= 5e-5, (f, key, dmax)
         n_ba += "ba_iterations" in b
-    assert n_ba == 3 and to.log[1]["n_init"] >= 100 and all(r["n_inliers"] >= 30 for r in to.log[2:])
+    assert n_ba == 3 and len(forced) == 3 and to.log[1]["n_init"] >= 100 and all(r["n_inliers"] >= 30 for r in to.log[2:])
     # the two runs' BA inputs already differ in the last float digits (poses above), and a point seen under a small parallax amplifies that
     # along its ray: the map is compared statistically, the parity of the BA itself is test_gpu_parity.py's business
     dm = np.linalg.norm(tg.mp_pos.astype(np.float64) - to.mp_pos.astype(np.float64), axis=1)

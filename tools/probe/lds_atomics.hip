@@ -12,6 +12,15 @@ template <int MODE> __global__ void __launch_bounds__(512) k(double* out, int it
   if (stride < 0) idx = (int)(((threadIdx.x * 2654435761u) >> 7) % 171u) * (-stride);      // stride < 0: a random "pair" per lane, |stride| doubles per pair
   if (stride == -1000) idx = (int)((threadIdx.x * 37u) % 171u) * 43;                        // distinct pairs within a wave (37 is coprime to 171), residues mod 16 as they fall
   if (stride == -1001) { const int l = threadIdx.x & 63; idx = ((l & 15) * 3 + (l >> 4) * 48) % 171 * 43; }   // distinct pairs, 43 * pair mod 16 perfectly balanced (4 lanes per f64 bank pair)
+  // which modulus matters?  pair p sits at double 43 p: 43 = 11 (mod 32), 11 * 3 = 1 (mod 32), 43 * 3 = 1 (mod 64)
+  if (stride == -1002) { const int l = threadIdx.x & 63; idx = ((3 * (l & 15)) % 32 + 32 * (l >> 4)) * 43; }   // balanced mod 16 (4 per class), only half of the classes mod 32
+  if (stride == -1003) { const int l = threadIdx.x & 63; idx = ((3 * (l & 31)) % 32 + 32 * (l >> 5)) * 43; }   // balanced mod 32 (2 per class)
+  if (stride == -1004) { const int l = threadIdx.x & 63; idx = ((3 * l) % 64) * 43; }                           // all 64 classes mod 64 distinct
+  if (stride == -1005) { const int l = threadIdx.x & 63; idx = ((3 * (l & 7)) % 8 + 8 * (l >> 3)) * 43; }        // balanced mod 8 (8 per class): classes mod 16 half used
+  // which lanes compete?  stride = -(2000 + x): lanes l and l ^ x get the same double modulo 64 (different addresses), all others differ
+  if (stride <= -2000 && stride > -2100) { const int l = threadIdx.x & 63, x = -stride - 2000; idx = (l & ~x) + 64 * ((l & x) ? 1 : 0) + 128 * (threadIdx.x >> 6); }
+  // stride = -(2100 + m): lane l at double l * m (which strides are conflict free?)
+  if (stride <= -2100 && stride > -2300) { const int l = threadIdx.x & 63, m = -stride - 2100; idx = l * m + (threadIdx.x >> 6) * 3; }
   double v = 1.0 + threadIdx.x;
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -45,6 +54,9 @@ int main() {
   run<0>("ds_add_f64", 1, 512); run<0>("ds_add_f64", 43, 1); run<0>("ds_add_f64 same-addr", 0, 1);
   run<0>("ds_add_f64 rand*43", -43, 1); run<0>("ds_add_f64 rand*42", -42, 1); run<0>("ds_add_f64 rand*47", -47, 1); run<5>("rmw b64 rand*43", -43, 1);
   run<0>("f64 distinct pairs", -1000, 1); run<0>("f64 distinct+balanced", -1001, 1);
+  run<0>("f64 bal16 half32", -1002, 1); run<0>("f64 bal32", -1003, 1); run<0>("f64 bal64", -1004, 1); run<0>("f64 bal8", -1005, 1);
+  for (int x : {0, 1, 2, 4, 8, 16, 32, 3, 7, 15}) run<0>("f64 l,l^x same bank", -2000 - x, 1);
+  for (int m : {1, 2, 4, 8, 16, 32, 64, 3, 5, 6, 12, 24, 48}) run<0>("f64 lane*m", -2100 - m, 1);
   run<1>("ds_add_u64", 1, 512); run<1>("ds_add_u64", 43, 1);
   run<2>("ds_add_f32", 1, 512); run<3>("ds_add_u32", 1, 512);
   run<4>("ds_write_b64", 1, 512); run<5>("read+add+write b64", 1, 512);
