@@ -296,7 +296,7 @@ def main():
     groups = [bas[gi::n_grp] for gi in range(n_grp)]
     group_ids = [list(range(n_ba))[gi::n_grp] for gi in range(n_grp)]
     for grp in groups:
-        grp[0].profile_kernel(3)          # HIP events around kb_ba_schur_points of every round (the BA chain's largest kernel)
+        grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (kb_ba_lin_schur_edges: linearisation + Schur complement -- the BA chain's largest kernel)
 
     # LocalMapping::CreateNewMapPoints in front of every window's BA: the window's key frame against its 20 best covisible neighbours
     # (~1650 features each, FeatureVectors of ~400 nodes), key frames resident on the device; one store + context (stream) per group
@@ -507,13 +507,15 @@ def main():
         avg_ms = sch_ms / sch_n
         byt = float(np.mean(grp_bytes))
         gbs = byt / (avg_ms * 1e-3) / 1e9
-        schur_name = "kb_ba_schur_points" if os.environ.get("CMS_BA_DETERMINISTIC") or os.environ.get("CMS_BA_HOST_LM") else "kb_ba_schur_edges"
+        schur_name = ("kb_ba_schur_points" if os.environ.get("CMS_BA_DETERMINISTIC") or os.environ.get("CMS_BA_HOST_LM") else
+                      "kb_ba_schur_edges" if os.environ.get("CMS_BA_NO_FUSED_LIN") else "kb_ba_lin_schur_edges")
         roof_ba = {"kernel": schur_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "frac": round(gbs / peak, 4),
                    # PMC pass: 8 windows per dispatch (tools/prof_ba_many.py); one launch here carries a group of n_ba / n_grp windows
                    "traffic": traffic_of(schur_name, (n_ba / n_grp) / 8.0), "ms_per_launch": round(avg_ms, 4), "launches_per_step": round(sch_n / args.steps, 1),
                    "ms_per_step": round(sch_ms / args.steps, 4), "algorithmic_bytes_per_launch": int(byt),
-                   "lds_atomic_bound": "the kernel adds 27 + 36 + 36 ds_add_f64 wave instructions per 64-edge chunk to its LDS copy of the reduced system; scattered f64 LDS "
-                                       "additions run at ~2.7 lanes per clock and CU (tools/probe/lds_atomics.hip): that, not HBM, is what its launch time follows",
+                   "lds_atomic_bound": "linearisation + Schur complement of one Levenberg trial in one kernel; it adds 33 + 36 + 36 ds_add_f64 wave instructions per "
+                                       "64-edge chunk to its LDS copy of the reduced system; the LDS takes them in groups of 16 lanes, 2 clocks per group plus 2 per lane "
+                                       "repeating a bank (tools/probe/lds_atomics.hip): that pipe (~80 % busy, profiles/), not HBM, is what its launch time follows",
                    "note": "HIP events on each window group's stream; the groups' launches overlap each other and the frame path, so ms_per_step is summed kernel time"}
     # `roofline` = the kernel with the most time per step; the other one is reported next to it
     if roof_ba and roof_ba["ms_per_step"] > roof_fast["ms_per_step"]:

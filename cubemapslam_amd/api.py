@@ -74,6 +74,7 @@ def lib():
         L.cms_host_free.restype = None
         L.cms_ba_profile_kernel.argtypes = [C.c_void_p, C.c_int]
         L.cms_ba_profile_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_ba_debug_compose.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cms_frames_process.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cms_frames_sync.argtypes = [C.c_void_p]
         L.cms_frames_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -627,6 +628,17 @@ class BundleAdjuster:
             self.close()
         except Exception:
             pass
+
+
+def ba_compose_chunks(fixed, n_points, e_pose, e_point, lookahead=48):
+    """Host-only: the chunk composition of the edge-major Schur kernel (cms_ba_debug_compose).  Returns (pinv, chunk_pt0, rank)."""
+    fixed = np.ascontiguousarray(fixed, np.uint8); e_pose = np.ascontiguousarray(e_pose, np.int32); e_point = np.ascontiguousarray(e_point, np.int32)
+    P, E = int(n_points), len(e_pose)
+    pinv = np.zeros(P, np.int32); pt0 = np.zeros(P + 1, np.int32); rank = np.zeros(E, np.uint8)
+    n = C.c_int(0)
+    _chk(lib().cms_ba_debug_compose(len(fixed), _p(fixed), P, E, _p(e_pose), _p(e_point), int(lookahead), _p(pinv), _p(pt0), C.byref(n), _p(rank)),
+         "cms_ba_debug_compose")
+    return pinv, pt0[:n.value + 1].copy(), rank
 
 
 def ba_optimize_many(bas, its=(5, 10), stop=None, stop_array=None):

@@ -142,6 +142,221 @@ extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
   return hipMemcpy(out8, b->d_scal + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
 }
 
+// lanes of one group of 16 -> LDS banks, every lane with four candidate banks: augmenting-path matching, the rest on their least-used bank
+struct BaDiagMatch {
+  int n = 0; uint8_t bank[64][4]; int choice[64]; int owner[16]; bool seen[16];
+  bool go(int i) {
+    for (int r = 0; r < 4; ++r) {
+      const int c = bank[i][r];
+      if (seen[c]) continue;
+      seen[c] = true;
+      if (owner[c] < 0 || go(owner[c])) { owner[c] = i; choice[i] = r; return true; }
+    }
+    return false;
+  }
+  void run() {
+    int load[16];
+    for (int c = 0; c < 16; ++c) { owner[c] = -1; load[c] = 0; }
+    for (int i = 0; i < n; ++i) choice[i] = -1;
+    for (int i = 0; i < n; ++i) {                               // a free bank among the lane's four, else an augmenting path
+      bool done = false;
+      for (int r = 0; r < 4 && !done; ++r) if (owner[bank[i][r]] < 0) { owner[bank[i][r]] = i; choice[i] = r; done = true; }
+      if (!done) { for (int c = 0; c < 16; ++c) seen[c] = false; go(i); }
+    }
+    for (int i = 0; i < n; ++i) if (choice[i] >= 0) ++load[bank[i][choice[i]]];
+    for (int i = 0; i < n; ++i)
+      if (choice[i] < 0) {
+        int best = 0;
+        for (int r = 1; r < 4; ++r) if (load[bank[i][r]] < load[bank[i][best]]) best = r;
+        choice[i] = best; ++load[bank[i][best]];
+      }
+  }
+};
+// Chunk composition of the edge-major Schur kernel (see cms_ba_create): pure host code.  Outputs: prank / pinv (caller point <-> internal
+// point), chunk_pt0 (first internal point of every chunk, P at the end), cp_off / cp_pose (CSR of the caller's points over their edges in
+// pose order) and cp_rank (per such edge: the copy of the diagonal blocks its (a, a) tuple goes to).  lookahead <= 1: the caller's order.
+static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int lookahead,
+                              std::vector<int>& prank, std::vector<int>& pinv, std::vector<int>& chunk_pt0, std::vector<int>& cp_off,
+                              std::vector<int>& cp_pose, std::vector<uint8_t>& cp_rank) {
+  static const bool ctiming = getenv("CMS_BA_COMPOSE_TIMING") != nullptr;
+  auto c_last = std::chrono::steady_clock::now();
+  double c_diag = 0;
+  auto ctick = [&](const char* what) {
+    const auto now = std::chrono::steady_clock::now();
+    if (ctiming) fprintf(stderr, "[compose] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - c_last).count());
+    c_last = now;
+  };
+  prank.assign(P, 0); cp_off.assign(P + 1, 0); cp_pose.assign(E, 0); cp_rank.assign(E, 0);
+  for (int e = 0; e < E; ++e) ++cp_off[e_point[e] + 1];
+  for (int p = 0; p < P; ++p) cp_off[p + 1] += cp_off[p];
+  std::vector<int> fill(cp_off.begin(), cp_off.end() - 1);
+  for (int e = 0; e < E; ++e) cp_pose[fill[e_point[e]]++] = e_pose[e];
+  for (int p = 0; p < P; ++p) std::sort(cp_pose.begin() + cp_off[p], cp_pose.begin() + cp_off[p + 1]);
+  ctick("csr + per-point sort");
+  std::vector<int> gslot(K, -1);
+  int gnp = 0;
+  for (int k = 0; k < K; ++k) if (!fixed[k]) gslot[k] = gnp++;
+  pinv.resize(P);
+  const bool greedy = lookahead > 1 && gnp >= 2 && gnp <= 62;
+  const int LA = std::max(lookahead, 1), MAXD = 4;
+  std::vector<int> nxt(P + 1);                       // singly linked list of the points not placed yet, in the caller's order
+  for (int p = 0; p <= P; ++p) nxt[p] = p + 1;
+  int head = 0, placed = 0, cur_edges = 0;
+  // per open chunk: [step][group of 16 lanes][bank class] lanes so far; diagonal tuples: [group][class]; a point may straddle two groups
+  uint8_t cls[MAXD][4][16], mx[MAXD][4];             // mx: lanes on the fullest bank = what the group costs in that step (start: see the scan below)
+  memset(cls, 0, sizeof(cls)); memset(mx, 1, sizeof(mx)); memset(mx[0], 2, sizeof(mx[0]));
+  struct DiagLane { int cp; int16_t s; int16_t g; };  // diagonal tuples of the open chunk: position in cp_rank, free-pose slot, group of 16 lanes
+  std::vector<DiagLane> dlanes;
+  auto opair = [&](int s1, int s2) { return s1 * gnp - (s1 * (s1 + 1)) / 2 + (s2 - s1 - 1); };
+  // every point's off-diagonal tuples, once: step - 1 | edge within the point << 2 | bank class << 7
+  // ... and per step the set of banks they touch (pm), with a flag for points that touch a bank twice in one step (those, and points that
+  // straddle two groups of lanes, take the exact count below; for all others the masks decide)
+  std::vector<int> tp_off(P + 1, 0);
+  std::vector<uint16_t> tp, pm((size_t)P * MAXD, 0), pm2((size_t)P * MAXD, 0);      // pm2: banks a point touches twice in one step
+  std::vector<uint8_t> twice(P, 0);                                                  // ... three times: exact count below
+  tp.reserve((size_t)E * 2);
+  for (int p = 0; p < P && greedy; ++p) {
+    const int k = cp_off[p + 1] - cp_off[p];
+    const int* ps = &cp_pose[cp_off[p]];
+    for (int dd = 1; dd <= k / 2 && dd <= MAXD; ++dd)
+      for (int a1 = 0; a1 < k && a1 < 32; ++a1) {
+        if (2 * dd == k && a1 >= dd) break;
+        const int s1 = gslot[ps[a1]], s2 = gslot[ps[(a1 + dd) % k]];
+        if (s1 < 0 || s2 < 0 || s1 == s2) continue;
+        const int c = opair(std::min(s1, s2), std::max(s1, s2)) & 15;
+        tp.push_back((uint16_t)((dd - 1) | (a1 << 2) | (c << 7)));
+        uint16_t& m = pm[(size_t)p * MAXD + dd - 1];
+        uint16_t& m2 = pm2[(size_t)p * MAXD + dd - 1];
+        if (m2 & (1u << c)) twice[p] = 1;
+        if (m & (1u << c)) m2 |= (uint16_t)(1u << c);
+        m |= (uint16_t)(1u << c);
+      }
+    tp_off[p + 1] = (int)tp.size();
+  }
+  uint16_t fullmask[MAXD][4], nearmask[MAXD][4];        // banks that hold as many lanes as the group's fullest (one more lane there costs a
+  memset(fullmask, 0, sizeof(fullmask));                // slot), and banks one lane short of that (two more lanes do)
+  memset(nearmask, 0xFF, sizeof(nearmask));
+  ctick("tuple table");
+  // how many LDS slots point p would add to the open chunk if it were placed at lane cur_edges: a group of 16 lanes costs, per step, as
+  // many slots as its fullest bank holds lanes (0 = the point's tuples leave every group's maximum where it is); the tuples are counted in
+  // as they go (a point's own tuples compete too) and taken out again unless the point is placed
+  auto cost_of = [&](int p, bool mark, int limit) {
+    int cost = 0, t = tp_off[p];
+    const int t1 = tp_off[p + 1];
+    const int kk = cp_off[p + 1] - cp_off[p], g0 = (cur_edges >> 4) & 3;
+    if (!mark && !twice[p] && kk > 0 && ((cur_edges + kk - 1) >> 4) == (cur_edges >> 4)) {
+      const uint16_t* m4 = &pm[(size_t)p * MAXD];
+      const uint16_t* d4 = &pm2[(size_t)p * MAXD];
+      int c4 = 0;
+      for (int st = 0; st < MAXD; ++st)
+        c4 += (int)(((m4[st] & fullmask[st][g0]) | (d4[st] & nearmask[st][g0])) != 0) + (int)((d4[st] & fullmask[st][g0]) != 0);
+      return c4;
+    }
+    uint8_t m[MAXD][4];
+    memcpy(m, mx, sizeof(m));
+    for (; t < t1 && cost < limit; ++t) {
+      const int w = tp[t], st = w & 3, g = ((cur_edges + ((w >> 2) & 31)) >> 4) & 3;
+      const uint8_t n = ++cls[st][g][w >> 7];
+      if (n > m[st][g]) { m[st][g] = n; ++cost; }
+    }
+    if (mark) {
+      memcpy(mx, m, sizeof(m));
+      uint32_t touched = 0;                                       // (step, group) pairs whose counts changed
+      for (int u = tp_off[p]; u < t1; ++u) { const int w = tp[u]; touched |= 1u << ((w & 3) * 4 + (((cur_edges + ((w >> 2) & 31)) >> 4) & 3)); }
+      for (int sg = 0; sg < 16; ++sg) {
+        if (!(touched >> sg & 1)) continue;
+        const int st = sg >> 2, g = sg & 3;
+        uint16_t f = 0, nf = 0;
+        for (int c = 0; c < 16; ++c) {
+          f |= (uint16_t)((cls[st][g][c] >= mx[st][g] ? 1u : 0u) << c);
+          nf |= (uint16_t)((cls[st][g][c] + 1 >= mx[st][g] ? 1u : 0u) << c);
+        }
+        fullmask[st][g] = f; nearmask[st][g] = nf;
+      }
+    } else
+      for (int u = tp_off[p]; u < t; ++u) { const int w = tp[u]; --cls[w & 3][((cur_edges + ((w >> 2) & 31)) >> 4) & 3][w >> 7]; }
+    return cost;
+  };
+  auto place_diag = [&](int p) {                     // the diagonal tuples wait for the chunk to be complete (finish_diag)
+    const int k = cp_off[p + 1] - cp_off[p];
+    for (int a1 = 0; a1 < k; ++a1) {
+      const int s = gslot[cp_pose[cp_off[p] + a1]];
+      if (s >= 0) dlanes.push_back({cp_off[p] + a1, (int16_t)s, (int16_t)(((cur_edges + a1) >> 4) & 3)});
+    }
+  };
+  // copies of the diagonal blocks: a lane may add to any of the four copies of its key frame's block, i.e. to one of four banks; per group of
+  // 16 lanes a bipartite matching (augmenting paths) gives as many lanes as possible a bank of their own, the rest take their least-used one
+  auto finish_diag = [&]() {
+    const auto d0 = std::chrono::steady_clock::now();
+    for (int g = 0; g < 4; ++g) {
+      int lanes[64], nl = 0;
+      for (size_t i = 0; i < dlanes.size(); ++i) if (dlanes[i].g == g && nl < 64) lanes[nl++] = (int)i;
+      if (nl == 0) continue;
+      BaDiagMatch M;
+      M.n = nl;
+      for (int i = 0; i < nl; ++i) for (int r = 0; r < 4; ++r) M.bank[i][r] = (uint8_t)((BA_SE_DSTRIDE * (r * gnp + dlanes[lanes[i]].s)) & 15);
+      M.run();
+      for (int i = 0; i < nl; ++i) cp_rank[dlanes[lanes[i]].cp] = (uint8_t)M.choice[i];
+    }
+    dlanes.clear();
+    c_diag += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
+  };
+  chunk_pt0.assign(1, 0);
+  while (placed < P) {
+    int pick = -1, prev_pick = -1;
+    if (greedy) {
+      // the first candidate that costs nothing ends the scan.  "Nothing" is measured against what a full group costs anyway: sixteen
+      // first-step tuples on sixteen banks without a repeat are out of reach (a group of four 4-edge points would need its last point to
+      // hit exactly the four free banks), so the first step's maximum starts at two lanes per bank, the later (half as dense) steps' at one
+      const int accept = 0;
+      int prev = -1, scanned = 0, best_cost = 1 << 30;
+      for (int p = head; p < P && scanned < LA; prev = p, p = nxt[p], ++scanned) {
+        if (cur_edges + (cp_off[p + 1] - cp_off[p]) > 64) continue;
+        const int c = cost_of(p, false, best_cost);
+        if (c < best_cost) { best_cost = c; pick = p; prev_pick = prev; if (c <= accept) break; }
+      }
+    } else if (cur_edges + (cp_off[head + 1] - cp_off[head]) <= 64) {
+      pick = head;
+    }
+    if (pick < 0) {
+      if (cur_edges == 0) { pick = head; prev_pick = -1; }          // a point with more than 64 edges: the kernel is refused below
+      else {
+        chunk_pt0.push_back(placed);
+        finish_diag();
+        cur_edges = 0;
+        memset(cls, 0, sizeof(cls)); memset(mx, 1, sizeof(mx)); memset(mx[0], 2, sizeof(mx[0])); memset(fullmask, 0, sizeof(fullmask)); memset(nearmask, 0xFF, sizeof(nearmask));
+        continue;
+      }
+    }
+    if (greedy) cost_of(pick, true, 1 << 30);
+    place_diag(pick);
+    cur_edges += cp_off[pick + 1] - cp_off[pick];
+    prank[pick] = placed; pinv[placed] = pick; ++placed;
+    if (prev_pick < 0) head = nxt[pick]; else nxt[prev_pick] = nxt[pick];
+  }
+  chunk_pt0.push_back(P);
+  finish_diag();
+  ctick("greedy loop (incl. diag)");
+  if (ctiming) fprintf(stderr, "[compose] of which diagonal matching %.2f ms\n", c_diag);
+}
+// developer / test entry: the composition alone (no device needed).  pinv: P, chunk_pt0: up to P + 1 entries (n_chunks + 1 are written),
+// rank: E (in the order of the caller's points, edges of a point by ascending key frame)
+extern "C" int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int lookahead,
+                                    int* pinv_out, int* chunk_pt0_out, int* n_chunks, uint8_t* rank_out) {
+  if (K < 1 || P < 1 || E < 1 || !fixed || !e_pose || !e_point || !pinv_out || !chunk_pt0_out || !n_chunks)
+    return cms_fail(CMS_ERR_ARG, "cms_ba_debug_compose: bad argument");
+  for (int e = 0; e < E; ++e)
+    if (e_pose[e] < 0 || e_pose[e] >= K || e_point[e] < 0 || e_point[e] >= P) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_compose: index out of range");
+  std::vector<int> prank, pinv, chunk_pt0, cp_off, cp_pose;
+  std::vector<uint8_t> cp_rank;
+  ba_compose_chunks(K, fixed, P, E, e_pose, e_point, lookahead, prank, pinv, chunk_pt0, cp_off, cp_pose, cp_rank);
+  memcpy(pinv_out, pinv.data(), (size_t)P * sizeof(int));
+  memcpy(chunk_pt0_out, chunk_pt0.data(), chunk_pt0.size() * sizeof(int));
+  *n_chunks = (int)chunk_pt0.size() - 1;
+  if (rank_out) memcpy(rank_out, cp_rank.data(), (size_t)E);
+  return CMS_OK;
+}
+
 extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P,
                              const double* points, int E, const int* e_pose, const int* e_point, const double* e_obs,
                              const double* e_invsig2, const int8_t* e_face, double fx, double fy, double cx, double cy) {
@@ -195,104 +410,12 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   // and its transpose the same bank) repeat as little as possible; the diagonal tuples pick, among the four copies of their key frame's
   // diagonal block, the one whose bank is least used in their group.  Everything on the device is indexed by the internal point id;
   // cms_ba_read / cms_ba_linearize translate back.  CMS_BA_NO_PERMUTE=1 keeps the caller's order (A/B).
-  std::vector<int> prank(P), cp_off(P + 1, 0), cp_pose(E);
-  std::vector<uint8_t> cp_rank(E, 0);                 // per (caller point, edge in pose order): copy of the diagonal blocks its (a, a) tuple goes to
+  std::vector<int> prank, cp_off, cp_pose;
+  std::vector<uint8_t> cp_rank;                       // per (caller point, edge in pose order): copy of the diagonal blocks its (a, a) tuple goes to
   {
-    for (int e = 0; e < E; ++e) ++cp_off[e_point[e] + 1];
-    for (int p = 0; p < P; ++p) cp_off[p + 1] += cp_off[p];
-    std::vector<int> fill(cp_off.begin(), cp_off.end() - 1);
-    for (int e = 0; e < E; ++e) cp_pose[fill[e_point[e]]++] = e_pose[e];
-    for (int p = 0; p < P; ++p) std::sort(cp_pose.begin() + cp_off[p], cp_pose.begin() + cp_off[p + 1]);
-    std::vector<int> gslot(K, -1);
-    int gnp = 0;
-    for (int k = 0; k < K; ++k) if (!fixed[k]) gslot[k] = gnp++;
-    b->pinv.resize(P);
-    static const int la_env = getenv("CMS_BA_LOOKAHEAD") ? atoi(getenv("CMS_BA_LOOKAHEAD")) : 48;
-    const bool greedy = getenv("CMS_BA_NO_PERMUTE") == nullptr && gnp >= 2 && gnp <= 62 && la_env > 1;
-    const int LA = std::max(la_env, 1), MAXD = 4;
-    std::vector<int> nxt(P + 1);                       // singly linked list of the points not placed yet, in the caller's order
-    for (int p = 0; p <= P; ++p) nxt[p] = p + 1;
-    int head = 0, placed = 0, cur_edges = 0;
-    // per open chunk: [step][group of 16 lanes][bank class] lanes so far; diagonal tuples: [group][class]; a point may straddle two groups
-    uint8_t cls[MAXD][4][16], dcls[4][16];
-    memset(cls, 0, sizeof(cls)); memset(dcls, 0, sizeof(dcls));
-    auto opair = [&](int s1, int s2) { return s1 * gnp - (s1 * (s1 + 1)) / 2 + (s2 - s1 - 1); };
-    // every point's off-diagonal tuples, once: step - 1 | edge within the point << 2 | bank class << 7
-    std::vector<int> tp_off(P + 1, 0);
-    std::vector<uint16_t> tp;
-    tp.reserve((size_t)E * 2);
-    for (int p = 0; p < P && greedy; ++p) {
-      const int k = cp_off[p + 1] - cp_off[p];
-      const int* ps = &cp_pose[cp_off[p]];
-      for (int dd = 1; dd <= k / 2 && dd <= MAXD; ++dd)
-        for (int a1 = 0; a1 < k && a1 < 32; ++a1) {
-          if (2 * dd == k && a1 >= dd) break;
-          const int s1 = gslot[ps[a1]], s2 = gslot[ps[(a1 + dd) % k]];
-          if (s1 < 0 || s2 < 0 || s1 == s2) continue;
-          tp.push_back((uint16_t)((dd - 1) | (a1 << 2) | ((opair(std::min(s1, s2), std::max(s1, s2)) & 15) << 7)));
-        }
-      tp_off[p + 1] = (int)tp.size();
-    }
-    // what point p would add to the chunk's atomic slots if it were placed at lane cur_edges (0 = every tuple finds a free bank in its
-    // group); the tuples are counted in as they go (a point's own tuples compete too) and taken out again unless the point is placed
-    auto cost_of = [&](int p, bool mark, int limit) {
-      int cost = 0, t = tp_off[p];
-      const int t1 = tp_off[p + 1];
-      for (; t < t1 && cost < limit; ++t) {
-        const int w = tp[t];
-        cost += cls[w & 3][((cur_edges + ((w >> 2) & 31)) >> 4) & 3][w >> 7]++;
-      }
-      if (!mark)
-        for (int u = tp_off[p]; u < t; ++u) { const int w = tp[u]; --cls[w & 3][((cur_edges + ((w >> 2) & 31)) >> 4) & 3][w >> 7]; }
-      return cost;
-    };
-    auto place_diag = [&](int p) {                     // copies of the diagonal blocks: the least-used bank of the lane's group
-      const int k = cp_off[p + 1] - cp_off[p];
-      for (int a1 = 0; a1 < k; ++a1) {
-        const int s = gslot[cp_pose[cp_off[p] + a1]];
-        if (s < 0) continue;
-        const int g = ((cur_edges + a1) >> 4) & 3;
-        int best = 0, best_cost = 1 << 30;
-        for (int r = 0; r < 4; ++r) {
-          const int cost = dcls[g][(BA_SE_DSTRIDE * (r * gnp + s)) & 15] * 4 + r;
-          if (cost < best_cost) { best_cost = cost; best = r; }
-        }
-        cp_rank[cp_off[p] + a1] = (uint8_t)best;
-        ++dcls[g][(BA_SE_DSTRIDE * (best * gnp + s)) & 15];
-      }
-    };
-    b->se_chunk_pt0.assign(1, 0);
-    while (placed < P) {
-      int pick = -1, prev_pick = -1;
-      if (greedy) {
-        // good enough ends the scan: nothing may repeat while the 16-lane group is young, one or two repeats once it is three quarters full
-        // (16 tuples on 16 banks without any repeat is out of reach anyway; the scan is the host cost of a window's set-up)
-        const int q = (cur_edges & 15) >> 2, accept = q < 2 ? 0 : q - 1;
-        int prev = -1, scanned = 0, best_cost = 1 << 30;
-        for (int p = head; p < P && scanned < LA; prev = p, p = nxt[p], ++scanned) {
-          if (cur_edges + (cp_off[p + 1] - cp_off[p]) > 64) continue;
-          const int c = cost_of(p, false, best_cost);
-          if (c < best_cost) { best_cost = c; pick = p; prev_pick = prev; if (c <= accept) break; }
-        }
-      } else if (cur_edges + (cp_off[head + 1] - cp_off[head]) <= 64) {
-        pick = head;
-      }
-      if (pick < 0) {
-        if (cur_edges == 0) { pick = head; prev_pick = -1; }          // a point with more than 64 edges: the kernel is refused below
-        else {
-          b->se_chunk_pt0.push_back(placed);
-          cur_edges = 0;
-          memset(cls, 0, sizeof(cls)); memset(dcls, 0, sizeof(dcls));
-          continue;
-        }
-      }
-      if (greedy) cost_of(pick, true, 1 << 30);
-      place_diag(pick);
-      cur_edges += cp_off[pick + 1] - cp_off[pick];
-      prank[pick] = placed; b->pinv[placed] = pick; ++placed;
-      if (prev_pick < 0) head = nxt[pick]; else nxt[prev_pick] = nxt[pick];
-    }
-    b->se_chunk_pt0.push_back(P);
+    static const int la_env = getenv("CMS_BA_LOOKAHEAD") ? atoi(getenv("CMS_BA_LOOKAHEAD")) : 24;
+    static const bool no_permute = getenv("CMS_BA_NO_PERMUTE") != nullptr;
+    ba_compose_chunks(K, fixed, P, E, e_pose, e_point, no_permute ? 1 : la_env, prank, b->pinv, b->se_chunk_pt0, cp_off, cp_pose, cp_rank);
   }
   tick("chunks");
   // sort edges by (internal point, pose): CSR by point; per-pose edge lists reference sorted positions

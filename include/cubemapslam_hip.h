@@ -174,10 +174,19 @@ int cms_ba_set_stream(cms_ba* ba, void* hip_stream);
 int cms_ba_debug_clocks(cms_ba* ba, long long* out16);
 /* measurement aid (bench.py's roofline of the dominant BA kernel): HIP events on the group's stream around ONE kernel of every round the
  * grouped driver enqueues for the group owned by `ba` (the first handle passed to cms_ba_optimize_many).  kernel_id: 0 off, 1 kb_ba_lin,
- * 2 kb_ba_maxdiag, 3 kb_ba_schur_points, 4 kb_ba_schur_reduce, 5 kb_ba_trial_solve, 6 kb_ba_trial_points, 7 kb_ba_reduce2.
+ * 2 kb_ba_maxdiag, 3 the Schur kernel of the path in use (kb_ba_lin_schur_edges by default: linearisation + Schur complement), 4 its range
+ * reduction, 5 kb_ba_trial_solve3, 6 kb_ba_trial_edges, 7 kb_ba_reduce2.
  * cms_ba_profile_get returns the summed duration and the number of launches since cms_ba_profile_kernel was called. */
 int cms_ba_profile_kernel(cms_ba* ba, int kernel_id);
 int cms_ba_profile_get(cms_ba* ba, double* total_ms, long* launches);
+/* developer / test aid, host only (no device needed): the chunk composition cms_ba_create builds for the edge-major Schur kernel -- which
+ * points share a wavefront (<= 64 observations), in which order, and which copy of its key frame's diagonal block every observation adds
+ * to -- chosen so that the lanes of one LDS addition fall on different banks.  lookahead <= 1: the caller's order.
+ * pinv: P entries (internal point -> caller's point); chunk_pt0: room for P + 1, *n_chunks + 1 are written (first internal point of every
+ * chunk, P last); rank (may be NULL): E entries, the caller's points in order, observations of a point by ascending key frame.
+ * The graph itself is what Optimizer::LocalBundleAdjustment hands to g2o (Optimizer.cpp:192-363); the composition has no counterpart there. */
+int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int lookahead,
+                         int* pinv, int* chunk_pt0, int* n_chunks, uint8_t* rank);
 void cms_ba_destroy(cms_ba* ba);
 /* one-shot convenience: create + optimize + read + destroy */
 int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,

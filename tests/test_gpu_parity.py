@@ -1033,3 +1033,17 @@ def test_kfstore_fuse_search_matches_oracle():
     with pytest.raises(api.CmsError):
         store.fuse_search([(0, jobs[0][1])])                    # empty slot
     store.close(); ctx.close()
+
+
+@pytest.mark.parametrize("knob", ["CMS_BA_NO_FUSED_LIN", "CMS_BA_DETERMINISTIC", "CMS_BA_NO_PERMUTE"])
+def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
+    """The grouped local-BA driver has three Schur paths -- linearisation fused into the edge-major kernel (default), the edge-major kernel
+    behind kb_ba_lin (CMS_BA_NO_FUSED_LIN), the deterministic pair-owner kernel (CMS_BA_DETERMINISTIC) -- and a host-side chunk
+    composition that can be switched off (CMS_BA_NO_PERMUTE).  The knobs are read once per process: the config-4 parity tests run again in
+    a child process with the knob set."""
+    import os, subprocess, sys
+    env = dict(os.environ); env[knob] = "1"
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "config4_size_eight or stop_flag_raised or mixed_sizes"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
