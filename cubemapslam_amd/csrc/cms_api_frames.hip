@@ -63,10 +63,12 @@ struct cms_ctx {
   hipEvent_t ev_extracted = nullptr; bool extracted_recorded = false;   // end of the last cms_frames_process (cms_stream_wait_extracted)
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;          // pinned staging of the one-frame host entries (one copy each way)
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
+  uint16_t* d_order = nullptr; uint32_t* d_aux_sorted = nullptr;      // per frame: the order k_describe works through the key points in (k_cull)
   // match scratch
   void* d_match = nullptr; size_t match_bytes = 0;
   // profiling
   bool prof = false;
+  bool desc_spatial = false;         // k_describe walks a frame's key points in spatial order on one XCD (CMS_DESC_SPATIAL_ORDER=1)
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t fast_lds = 0, qt_lds = 0;
 };
@@ -156,7 +158,7 @@ static void cms_ctx_free(cms_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_fish, c->d_lut, c->d_pyr, c->d_mask, c->d_tab, c->d_pattern, c->d_cand, c->d_node, c->d_cand_cnt,
-                  c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_desc, c->d_kp_cnt, c->d_match, c->d_cell_cand,
+                  c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_order, c->d_aux_sorted, c->d_desc, c->d_kp_cnt, c->d_match, c->d_cell_cand,
                   c->d_cell_cnt, c->d_cells_all, c->d_cells_nz, c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid, c->d_area_bsum};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_fish_stage) (void)hipHostFree(c->h_fish_stage);
@@ -235,6 +237,11 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   g.list_cap = wCellMax * hCellMax;
   g.cell_cap = (int)align_up((size_t)((wCellMax + 1) / 2) * ((hCellMax + 1) / 2), 8);   // strict 3x3 maxima cannot be 8-adjacent
   g.dbg_stop = getenv("CMS_DBG_FAST_STOP") ? atoi(getenv("CMS_DBG_FAST_STOP")) : 0;
+  // CMS_DESC_SPATIAL_ORDER=1: k_describe walks every frame's key points band by band on one XCD (k_cull builds the order).  Measured on 256
+  // frames (profiles/r02_describe_order.txt): HBM fetch 2.39 GB -> 0.86 GB per dispatch (3.2x -> 1.16x the patch bytes), kernel time 0.63 ->
+  // 0.66 ms -- the kernel is bound by its vector-ALU issue (748 instructions per key point = 0.63 ms), not by these bytes, so list order
+  // (all XCDs on every frame) stays the default
+  c->desc_spatial = getenv("CMS_DESC_SPATIAL_ORDER") != nullptr && g.kp_cap <= CMS_ORDER_MAX;
   g.gauss_column_mode = 0;
   if (wCellMax > 60 || hCellMax > 60) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 60 pixels"); }
   if (orb->scale_factor < 1.01f || orb->scale_factor > 1.9f) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "scaleFactor must be in [1.01, 1.9]"); }
@@ -276,6 +283,8 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   ALLOC(c->d_qt_cnt, B * L * sizeof(int));
   ALLOC(c->d_kps, B * g.kp_cap * sizeof(CmsKeyPoint));
   ALLOC(c->d_aux, B * g.kp_cap * 4);
+  ALLOC(c->d_order, B * g.kp_cap * 2);
+  ALLOC(c->d_aux_sorted, B * g.kp_cap * 4);
   ALLOC(c->d_desc, B * g.kp_cap * 32);
   ALLOC(c->d_kp_cnt, B * sizeof(int));
 #undef ALLOC
@@ -517,10 +526,15 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
                      c->d_node, c->d_qt_out, c->d_qt_cnt);
   if (c->prof) hipEventRecord(c->ev[4], s);
   hipLaunchKernelGGL(k_cull, dim3(B), dim3(256), 0, s, g, (const uint32_t*)c->d_qt_out, (const int*)c->d_qt_cnt,
-                     (const uint8_t*)c->d_mask, c->mstride, c->d_kps, c->d_aux, c->d_kp_cnt);
+                     (const uint8_t*)c->d_mask, c->mstride, c->d_kps, c->d_aux, c->d_kp_cnt, c->desc_spatial ? c->d_order : nullptr, c->d_aux_sorted);
   if (c->prof) hipEventRecord(c->ev[5], s);
-  hipLaunchKernelGGL(k_describe, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
-                     (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc);
+  if (c->desc_spatial)      // one frame per XCD, key points in spatial order (see k_cull)
+    hipLaunchKernelGGL(k_describe, dim3((unsigned)(((size_t)((B + 7) / 8) * 8 * g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB)), dim3(64 * CMS_DESC_WPB), 0, s,
+                       (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps, (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc,
+                       (const uint16_t*)c->d_order, (const uint32_t*)c->d_aux_sorted, B);
+  else
+    hipLaunchKernelGGL(k_describe, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
+                       (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc, (const uint16_t*)nullptr, (const uint32_t*)nullptr, B);
   if (c->prof) hipEventRecord(c->ev[6], s);
   if (c->ev_extracted) { HIPCHK(hipEventRecord(c->ev_extracted, s)); c->extracted_recorded = true; }
   HIPCHK(hipGetLastError());

@@ -574,12 +574,15 @@ k_quadtree(CmsGeom g, const uint32_t* __restrict__ cell_cand, const int* __restr
   if (threadIdx.x == 0) qt_cnt[b * g.nlevels + l] = S;
 }
 
+#define CMS_ORDER_MAX 65535      /* key points per frame the processing order of k_describe is built for (16-bit index) */
 // ------------------------------------------------------------------------------------------------ cull + compaction
 // One workgroup per frame walks the levels in order; survivors keep (level, list) order (ORBExtractor.cpp:875-921).
 extern "C" __global__ void __launch_bounds__(256)
 k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ qt_cnt, const uint8_t* __restrict__ mask,
-       int mstride, CmsKeyPoint* __restrict__ kps, uint32_t* __restrict__ aux, int* __restrict__ kp_cnt) {
+       int mstride, CmsKeyPoint* __restrict__ kps, uint32_t* __restrict__ aux, int* __restrict__ kp_cnt, uint16_t* __restrict__ order,
+       uint32_t* __restrict__ aux_sorted) {
   __shared__ int wsum[4];
+  __shared__ uint32_t skey[512];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int total = 0;
   const float Ff = (float)g.F;
@@ -621,6 +624,34 @@ k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ q
     }
   }
   if (tid == 0) kp_cnt[b] = total;
+  // ---- the order k_describe WORKS in (its output keeps the list order above): by level and band of 64 rows.  A key point's 43 patch rows
+  // are 48-byte pieces of 128-byte lines; walked in list order (the octree's node order, scattered over the level) every key point fetched
+  // its ~44 lines from HBM on its own -- 3.2x the patch bytes (profiles/r01).  k_describe gives all key points of a frame to one XCD, i.e.
+  // one L2, and a band of a level is ~100 KB of it: the order inside a band does not matter.  Counting sort on (level, band) in LDS.
+  if (order) {
+    __syncthreads();                                       // the block's own aux[] stores; skey free
+    for (int i = tid; i < 512; i += 256) skey[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < total; i += 256) {
+      const uint32_t a = aux[(size_t)b * g.kp_cap + i];
+      atomicAdd(&skey[min(255u, (a >> 24) * 32 + (((a >> 12) & 0xFFF) >> 6))], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {                                        // exclusive prefix over the 256 buckets: four per lane
+      const uint32_t c0 = skey[4 * tid], c1 = skey[4 * tid + 1], c2 = skey[4 * tid + 2], c3 = skey[4 * tid + 3];
+      uint32_t incl = c0 + c1 + c2 + c3;
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      const uint32_t base = incl - (c0 + c1 + c2 + c3);
+      skey[256 + 4 * tid] = base; skey[256 + 4 * tid + 1] = base + c0; skey[256 + 4 * tid + 2] = base + c0 + c1; skey[256 + 4 * tid + 3] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += 256) {
+      const uint32_t a = aux[(size_t)b * g.kp_cap + i];
+      const uint32_t pos = atomicAdd(&skey[256 + min(255u, (a >> 24) * 32 + (((a >> 12) & 0xFFF) >> 6))], 1u);
+      order[(size_t)b * g.kp_cap + pos] = (uint16_t)i;
+      aux_sorted[(size_t)b * g.kp_cap + pos] = a;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ orientation + rBRIEF
@@ -656,7 +687,7 @@ __device__ __constant__ __align__(16) uint32_t k_disc_mask[16 * 8] = {
 extern "C" __global__ void __launch_bounds__(64 * CMS_DESC_WPB)
 k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
            const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const float* __restrict__ pattern,
-           uint8_t* __restrict__ desc) {
+           uint8_t* __restrict__ desc, const uint16_t* __restrict__ order, const uint32_t* __restrict__ aux_sorted, int B) {
   // CMS_DESC_WPB key points per workgroup, one per wavefront, no data shared between them (wave-level synchronisation only)
   __shared__ __align__(16) uint8_t raw4[CMS_DESC_WPB][PW * PS + 16];
   __shared__ __align__(16) uint16_t rowp4[CMS_DESC_WPB][PW * RW];
@@ -667,8 +698,20 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #endif
   uint8_t* raw = raw4[wave]; uint16_t* rowp = rowp4[wave]; uint8_t* blr = blr4[wave];
-  const int b = blockIdx.y, k = blockIdx.x * CMS_DESC_WPB + wave;
-  if (k >= kp_cnt[b]) return;
+  // order != nullptr (1-D grid): workgroups go round-robin to the 8 XCDs; XCD x takes frame 8 f + x and walks its key points in the spatial
+  // order k_cull built, so that patch rows shared by neighbouring key points are fetched into that XCD's L2 once
+  int b, k;
+  if (order) {
+    const int L = blockIdx.x * CMS_DESC_WPB + wave, t = L >> 3;
+    const int fgrp = t / g.kp_cap, ks = t - fgrp * g.kp_cap;
+    b = 8 * fgrp + (L & 7);
+    if (b >= B || ks >= kp_cnt[b]) return;
+    k = order[(size_t)b * g.kp_cap + ks];
+    aux = aux_sorted + ks - k;                 // aux[b * kp_cap + k] below then reads aux_sorted[b * kp_cap + ks]: no load behind a load
+  } else {
+    b = blockIdx.y; k = blockIdx.x * CMS_DESC_WPB + wave;
+    if (k >= kp_cnt[b]) return;
+  }
   const uint32_t a = aux[(size_t)b * g.kp_cap + k];
   const int cx = a & 0xFFF, cy = (a >> 12) & 0xFFF, l = a >> 24;
   const CmsLevel& lv = g.lv[l];

@@ -1047,3 +1047,14 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
                         "config4_size_eight or stop_flag_raised or mixed_sizes"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_describe_in_spatial_order_is_bit_identical():
+    """CMS_DESC_SPATIAL_ORDER=1 changes the order k_describe WORKS in (band by band, one frame per XCD: a third of the HBM fetches), not
+    its output: the extraction parity tests run again in a child process with the knob set (it is read when a context is created)."""
+    import os, subprocess, sys
+    env = dict(os.environ); env["CMS_DESC_SPATIAL_ORDER"] = "1"
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k", "extract and not spatial"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
