@@ -528,13 +528,16 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   hipLaunchKernelGGL(k_cull, dim3(B), dim3(256), 0, s, g, (const uint32_t*)c->d_qt_out, (const int*)c->d_qt_cnt,
                      (const uint8_t*)c->d_mask, c->mstride, c->d_kps, c->d_aux, c->d_kp_cnt, c->desc_spatial ? c->d_order : nullptr, c->d_aux_sorted);
   if (c->prof) hipEventRecord(c->ev[5], s);
-  if (c->desc_spatial)      // one frame per XCD, key points in spatial order (see k_cull)
-    hipLaunchKernelGGL(k_describe, dim3((unsigned)(((size_t)((B + 7) / 8) * 8 * g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB)), dim3(64 * CMS_DESC_WPB), 0, s,
-                       (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps, (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc,
-                       (const uint16_t*)c->d_order, (const uint32_t*)c->d_aux_sorted, B);
-  else
-    hipLaunchKernelGGL(k_describe, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
-                       (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc, (const uint16_t*)nullptr, (const uint32_t*)nullptr, B);
+  {
+    auto kdesc = g.gauss_column_mode == 1 ? k_describe_sse2 : k_describe;
+    if (c->desc_spatial)      // one frame per XCD, key points in spatial order (see k_cull)
+      hipLaunchKernelGGL(kdesc, dim3((unsigned)(((size_t)((B + 7) / 8) * 8 * g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB)), dim3(64 * CMS_DESC_WPB), 0, s,
+                         (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps, (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc,
+                         (const uint16_t*)c->d_order, (const uint32_t*)c->d_aux_sorted, B);
+    else
+      hipLaunchKernelGGL(kdesc, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
+                         (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc, (const uint16_t*)nullptr, (const uint32_t*)nullptr, B);
+  }
   if (c->prof) hipEventRecord(c->ev[6], s);
   if (c->ev_extracted) { HIPCHK(hipEventRecord(c->ev_extracted, s)); c->extracted_recorded = true; }
   HIPCHK(hipGetLastError());

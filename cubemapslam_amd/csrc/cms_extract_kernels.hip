@@ -684,20 +684,22 @@ __device__ __constant__ __align__(16) uint32_t k_disc_mask[16 * 8] = {
   DMROW(9), DMROW(8), DMROW(6), DMROW(3)};
 #undef DMROW
 #undef DM
-extern "C" __global__ void __launch_bounds__(64 * CMS_DESC_WPB)
-k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
+// SSE2: the column pass follows an x86 OpenCV's float tie rule (cms_set_gaussian_mode).  A compile-time switch: as a run-time test inside
+// the column loop it cost 30 of the loop's 71 vector instructions per step even when off (short predicated blocks are issued, not skipped).
+template <bool SSE2>
+__device__ __forceinline__ void describe_body(const uint8_t* __restrict__ pyr, size_t pyr_bytes, const CmsGeom& g, CmsKeyPoint* __restrict__ kps,
            const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const float* __restrict__ pattern,
            uint8_t* __restrict__ desc, const uint16_t* __restrict__ order, const uint32_t* __restrict__ aux_sorted, int B) {
   // CMS_DESC_WPB key points per workgroup, one per wavefront, no data shared between them (wave-level synchronisation only)
   __shared__ __align__(16) uint8_t raw4[CMS_DESC_WPB][PW * PS + 16];
-  __shared__ __align__(16) uint16_t rowp4[CMS_DESC_WPB][PW * RW];
+  __shared__ __align__(16) uint32_t rowp4[CMS_DESC_WPB][((PW + 1) / 2) * RW];      // row sums of rows 2m (low half) and 2m + 1 (high half), column by column
   __shared__ __align__(4) uint8_t blr4[CMS_DESC_WPB][BW * BS];
 #if CMS_DESC_WPB == 1
   const int wave = 0, lane = threadIdx.x;
 #else
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #endif
-  uint8_t* raw = raw4[wave]; uint16_t* rowp = rowp4[wave]; uint8_t* blr = blr4[wave];
+  uint8_t* raw = raw4[wave]; uint32_t* rowp = rowp4[wave]; uint8_t* blr = blr4[wave];
   // order != nullptr (1-D grid): workgroups go round-robin to the 8 XCDs; XCD x takes frame 8 f + x and walks its key points in the spatial
   // order k_cull built, so that patch rows shared by neighbouring key points are fetched into that XCD's L2 once
   int b, k;
@@ -792,33 +794,45 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
         const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, i), hi = __builtin_amdgcn_alignbyte(w2, w1, i);
         o[i] = __builtin_amdgcn_udot4(hi, kb, __builtin_amdgcn_udot4(lo, ka, 0u, false), false);
       }
-      uint2 out;
-      out.x = o[0] | (o[1] << 16); out.y = o[2] | (o[3] << 16);            // row sums <= 255 * 257 = 65535
-      *reinterpret_cast<uint2*>(rowp + r * RW + 4 * q) = out;
+      // row sums <= 255 * 257 = 65535: 16 bits.  Rows 2m and 2m + 1 share a dword per column, so that the column pass can take two
+      // vertical taps per v_dot2_u32_u16
+      uint16_t* dst = reinterpret_cast<uint16_t*>(rowp + (r >> 1) * RW + 4 * q) + (r & 1);
+      dst[0] = (uint16_t)o[0]; dst[2] = (uint16_t)o[1]; dst[4] = (uint16_t)o[2]; dst[6] = (uint16_t)o[3];
     }
   }
   WAVE_SYNC();
-  // Column pass, two neighbouring columns per lane and step (one dword = two 16-bit row sums)
-  for (int task = lane; task < BW * (RW / 2); task += 64) {
-    const int r = __mul24(task, 3277) >> 16, cp = task - r * (RW / 2);            // task / 20, exact for task < 804
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + r * RW) + cp;
-    const uint32_t e0 = p[0], e1 = p[RW / 2], e2 = p[2 * (RW / 2)], e3 = p[3 * (RW / 2)], e4 = p[4 * (RW / 2)], e5 = p[5 * (RW / 2)],
-                   e6 = p[6 * (RW / 2)];
-    // (row sums are < 2^17: 24-bit multiplies)
-    const int sl = __mul24(18, (int)((e0 & 0xFFFF) + (e6 & 0xFFFF))) + __mul24(34, (int)((e1 & 0xFFFF) + (e5 & 0xFFFF))) +
-                   __mul24(49, (int)((e2 & 0xFFFF) + (e4 & 0xFFFF))) + __mul24(55, (int)(e3 & 0xFFFF));
-    const int sh = __mul24(18, (int)((e0 >> 16) + (e6 >> 16))) + __mul24(34, (int)((e1 >> 16) + (e5 >> 16))) +
-                   __mul24(49, (int)((e2 >> 16) + (e4 >> 16))) + __mul24(55, (int)(e3 >> 16));
-    int vl = min((sl + 32768) >> 16, 255), vh = min((sh + 32768) >> 16, 255);
-    if (g.gauss_column_mode == 1) {
-      // an x86 OpenCV <= 3.2 evaluates the column pass in float with round-half-to-EVEN for the columns its SSE2 loops cover
-      // (x < width & ~3): every product and partial sum is exact in binary32, so the result
-      // differs from the integer formula exactly on ties (sum mod 65536 == 32768) with an even quotient
-      const int x0 = cx - 18 + 2 * cp, xvec = lv.w & ~3;
-      if (x0 < xvec && (sl & 0xFFFF) == 0x8000 && ((sl >> 16) & 1) == 0) vl = min(sl >> 16, 255);
-      if (x0 + 1 < xvec && (sh & 0xFFFF) == 0x8000 && ((sh >> 16) & 1) == 0) vh = min(sh >> 16, 255);
+  // Column pass, four neighbouring columns per lane and step.  Output row ro needs the row sums ro .. ro + 6: four row PAIRS starting at pair
+  // ro >> 1 -- for an even ro the taps (18 34)(49 55)(49 34)(18 -), for an odd one (- 18)(34 49)(55 49)(34 18) -- four dot products of
+  // 16-bit pairs per output instead of seven multiplies and as many unpacking operations.
+  for (int task = lane; task < BW * (RW / 4); task += 64) {
+    const int r = __mul24(task, 6554) >> 16, q = task - r * (RW / 4);             // task / 10, exact for task < 494
+    const uint4* p = reinterpret_cast<const uint4*>(rowp + (r >> 1) * RW) + q;
+    const uint4 e0 = p[0], e1 = p[RW / 4], e2 = p[2 * (RW / 4)], e3 = p[3 * (RW / 4)];
+    const bool odd = (r & 1) != 0;
+    const uint32_t w0 = odd ? (18u << 16) : (18u | (34u << 16)), w1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
+                   w2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), w3 = odd ? (34u | (18u << 16)) : 18u;
+    auto col = [&](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) -> int {
+      uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a0), __builtin_bit_cast(us2_t, w0), 0u, false);
+      acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a1), __builtin_bit_cast(us2_t, w1), acc, false);
+      acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a2), __builtin_bit_cast(us2_t, w2), acc, false);
+      acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a3), __builtin_bit_cast(us2_t, w3), acc, false);
+      return (int)acc;
+    };
+    const int sv[4] = {col(e0.x, e1.x, e2.x, e3.x), col(e0.y, e1.y, e2.y, e3.y), col(e0.z, e1.z, e2.z, e3.z), col(e0.w, e1.w, e2.w, e3.w)};
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int v = min((sv[i] + 32768) >> 16, 255);
+      if (SSE2) {
+        // an x86 OpenCV <= 3.2 evaluates the column pass in float with round-half-to-EVEN for the columns its SSE2 loops cover
+        // (x < width & ~3): every product and partial sum is exact in binary32, so the result
+        // differs from the integer formula exactly on ties (sum mod 65536 == 32768) with an even quotient
+        const int x0 = cx - 18 + 4 * q + i, xvec = lv.w & ~3;
+        if (x0 < xvec && (sv[i] & 0xFFFF) == 0x8000 && ((sv[i] >> 16) & 1) == 0) v = min(sv[i] >> 16, 255);
+      }
+      out |= (uint32_t)v << (8 * i);
     }
-    *reinterpret_cast<uint16_t*>(blr + r * BS + 2 * cp) = (uint16_t)(vl | (vh << 8));
+    *reinterpret_cast<uint32_t*>(blr + r * BS + 4 * q) = out;
   }
   WAVE_SYNC();
   // ---- steered BRIEF: lane i evaluates tests 4i .. 4i+3
@@ -839,4 +853,16 @@ k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyP
   const int other = __shfl_xor(nib, 1);
   if ((lane & 1) == 0) desc[((size_t)b * g.kp_cap + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
   if (lane == 0) kps[(size_t)b * g.kp_cap + k].angle = angle;
+}
+extern "C" __global__ void __launch_bounds__(64 * CMS_DESC_WPB)
+k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
+           const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const float* __restrict__ pattern,
+           uint8_t* __restrict__ desc, const uint16_t* __restrict__ order, const uint32_t* __restrict__ aux_sorted, int B) {
+  describe_body<false>(pyr, pyr_bytes, g, kps, aux, kp_cnt, pattern, desc, order, aux_sorted, B);
+}
+extern "C" __global__ void __launch_bounds__(64 * CMS_DESC_WPB)
+k_describe_sse2(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
+                const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const float* __restrict__ pattern,
+                uint8_t* __restrict__ desc, const uint16_t* __restrict__ order, const uint32_t* __restrict__ aux_sorted, int B) {
+  describe_body<true>(pyr, pyr_bytes, g, kps, aux, kp_cnt, pattern, desc, order, aux_sorted, B);
 }
