@@ -514,8 +514,9 @@ def main():
                    "traffic": traffic_of(schur_name, (n_ba / n_grp) / 8.0), "ms_per_launch": round(avg_ms, 4), "launches_per_step": round(sch_n / args.steps, 1),
                    "ms_per_step": round(sch_ms / args.steps, 4), "algorithmic_bytes_per_launch": int(byt),
                    "lds_atomic_bound": "linearisation + Schur complement of one Levenberg trial in one kernel; it adds 33 + 36 + 36 ds_add_f64 wave instructions per "
-                                       "64-edge chunk to its LDS copy of the reduced system; the LDS takes them in groups of 16 lanes, 2 clocks per group plus 2 per lane "
-                                       "repeating a bank (tools/probe/lds_atomics.hip): that pipe (~80 % busy, profiles/), not HBM, is what its launch time follows",
+                                       "64-edge chunk to its LDS copy of the reduced system (the LDS takes them in groups of 16 lanes, 2 clocks per group plus 2 per lane "
+                                       "repeating a bank: tools/probe/lds_atomics.hip; the host composes the chunks against that).  148 KB of LDS per workgroup leave two "
+                                       "wavefronts per SIMD: LDS pipe 45 % busy, vector-ALU issue 34 % of the launch (profiles/r02_pmc_instruction_mix.json) -- latency, not HBM",
                    "note": "HIP events on each window group's stream; the groups' launches overlap each other and the frame path, so ms_per_step is summed kernel time"}
     # `roofline` = the kernel with the most time per step; the other one is reported next to it
     if roof_ba and roof_ba["ms_per_step"] > roof_fast["ms_per_step"]:
