@@ -144,9 +144,9 @@ extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
 
 // lanes of one group of 16 -> LDS banks, every lane with four candidate banks: augmenting-path matching, the rest on their least-used bank
 struct BaDiagMatch {
-  int n = 0; uint8_t bank[64][4]; int choice[64]; int owner[16]; bool seen[16];
+  int n = 0; uint8_t bank[64][BA_SE_DCOPIES]; int choice[64]; int owner[16]; bool seen[16];
   bool go(int i) {
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < BA_SE_DCOPIES; ++r) {
       const int c = bank[i][r];
       if (seen[c]) continue;
       seen[c] = true;
@@ -160,14 +160,14 @@ struct BaDiagMatch {
     for (int i = 0; i < n; ++i) choice[i] = -1;
     for (int i = 0; i < n; ++i) {                               // a free bank among the lane's four, else an augmenting path
       bool done = false;
-      for (int r = 0; r < 4 && !done; ++r) if (owner[bank[i][r]] < 0) { owner[bank[i][r]] = i; choice[i] = r; done = true; }
+      for (int r = 0; r < BA_SE_DCOPIES && !done; ++r) if (owner[bank[i][r]] < 0) { owner[bank[i][r]] = i; choice[i] = r; done = true; }
       if (!done) { for (int c = 0; c < 16; ++c) seen[c] = false; go(i); }
     }
     for (int i = 0; i < n; ++i) if (choice[i] >= 0) ++load[bank[i][choice[i]]];
     for (int i = 0; i < n; ++i)
       if (choice[i] < 0) {
         int best = 0;
-        for (int r = 1; r < 4; ++r) if (load[bank[i][r]] < load[bank[i][best]]) best = r;
+        for (int r = 1; r < BA_SE_DCOPIES; ++r) if (load[bank[i][r]] < load[bank[i][best]]) best = r;
         choice[i] = best; ++load[bank[i][best]];
       }
   }
@@ -294,7 +294,7 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
       if (nl == 0) continue;
       BaDiagMatch M;
       M.n = nl;
-      for (int i = 0; i < nl; ++i) for (int r = 0; r < 4; ++r) M.bank[i][r] = (uint8_t)((BA_SE_DSTRIDE * (r * gnp + dlanes[lanes[i]].s)) & 15);
+      for (int i = 0; i < nl; ++i) for (int r = 0; r < BA_SE_DCOPIES; ++r) M.bank[i][r] = (uint8_t)((BA_SE_DSTRIDE * (r * gnp + dlanes[lanes[i]].s)) & 15);
       M.run();
       for (int i = 0; i < nl; ++i) cp_rank[dlanes[lanes[i]].cp] = (uint8_t)M.choice[i];
     }

@@ -37,7 +37,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef BA_SE_THREADS
 #define BA_SE_THREADS 512
+#endif
 #define BA_SE_SSTRIDE 37          /* doubles per off-diagonal pose pair in the LDS copy: 36, padded to an odd count (bank aliasing of neighbouring pairs) */
 #define BA_SE_RANGES 32           /* workgroups per window */
 
@@ -60,7 +62,9 @@ __host__ __device__ constexpr int ba_se_upper(int r, int q) { return r * 5 - (r 
 __host__ __device__ constexpr int ba_se_off(int r, int q) {
   return r < q ? ba_se_upper(r, q) : r > q ? 16 + ba_se_upper(q, r) : (r == 0 ? 15 : r == 1 ? 31 : 30 + r);
 }
+#ifndef BA_SE_DCOPIES
 #define BA_SE_DCOPIES 4
+#endif
 #define BA_SE_DSTRIDE 33          /* 21 (upper triangle) + 6 (right-hand side) + 6 (bp, fused linearisation only): an ODD number of doubles, so that consecutive
                                      (copy, key frame) rows walk through all 16 f64 banks of the LDS (28 left them on four) */
 
