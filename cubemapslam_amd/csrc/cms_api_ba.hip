@@ -41,7 +41,7 @@ struct cms_ba {
   // edge-major Schur work list (se.R == 0: not available: too many free key frames for the LDS copy of the reduced system)
   BaSe se = {};
   int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_bp_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
-  size_t se_lds = 0;
+  size_t se_lds_fixed = 0; int se_waves = 0;      // LDS of the edge-major kernel without the per-wavefront part; wavefronts per workgroup that fit
   int cur = 0;
   double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   // group resources (owned by the first window of a cms_ba_optimize_many call, grown on demand)
@@ -610,9 +610,13 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     // each; dense enumeration of the pose pairs s1 <= s2 and the matching tables for the solve kernel's assembly
     if (np >= 1) {
       const int NP2 = np * (np + 1) / 2;
-      const int nw = BA_SE_THREADS / 64;
-      const size_t lds = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)nw * 64 * 18 + (size_t)K * 12) * sizeof(double) +
-                         (size_t)nw * 64 * sizeof(int);
+      // LDS: the reduced system, the diagonal copies and the key frames' poses, plus a W row and a slot per lane of every wavefront.  Windows with
+      // more free key frames get fewer wavefronts per workgroup (8 up to 20 key frames, 6 / 4 / 2 up to 25); beyond that the copy does not fit
+      const size_t lds_fixed = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)K * 12) * sizeof(double);
+      const size_t lds_wave = (size_t)64 * 18 * sizeof(double) + 64 * sizeof(int);
+      int nw = BA_SE_THREADS / 64;
+      while (nw > 2 && lds_fixed + nw * lds_wave > BA_LDS_CEILING) nw -= 2;
+      const size_t lds = lds_fixed + nw * lds_wave;
       bool ok = lds <= BA_LDS_CEILING && K <= 256 && np <= 62;
       std::vector<int> ce0;
       std::vector<uint32_t> info(E);
@@ -660,7 +664,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
           b->se.Rt = (nchunks + cpw_t - 1) / cpw_t;
         }
         b->se.R = R; b->se.nchunks = nchunks; b->se.cpw = cpw; b->se.npairs2 = NP2; b->se.chunk_e0 = b->d_se_chunk_e0; b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial; b->se.e_info = b->d_se_info;
-        b->se_lds = lds;
+        b->se_lds_fixed = lds_fixed; b->se_waves = nw;
       }
     }
     tick("se");

@@ -343,9 +343,9 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     use_s3 = use_s3 && bas[w]->solve_blk3;
     s3_threads = std::max(s3_threads, (3 * (bas[w]->np * (bas[w]->np + 1) / 2) + 63) / 64 * 64); lds3 = std::max(lds3, bas[w]->blk3_lds);
   }
-  int max_seR = 0, max_np2 = 0, max_Rt = 0; size_t se_lds = 0, te_lds = 0;
+  int max_seR = 0, max_np2 = 0, max_Rt = 0, se_waves = BA_SE_THREADS / 64; size_t se_lds = 0, te_lds = 0;
   for (int w = 0; w < n; ++w) {
-    max_seR = std::max(max_seR, bas[w]->se.R); max_np2 = std::max(max_np2, bas[w]->se.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds);
+    max_seR = std::max(max_seR, bas[w]->se.R); max_np2 = std::max(max_np2, bas[w]->se.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds_fixed); se_waves = std::min(se_waves, bas[w]->se_waves > 0 ? bas[w]->se_waves : se_waves);
     max_Rt = std::max(max_Rt, bas[w]->se.Rt); te_lds = std::max(te_lds, ((size_t)24 * bas[w]->K + 6 * (size_t)std::max(bas[w]->np, 1)) * sizeof(double));
   }
   // One "round" = the launches of one Levenberg trial (plus the linearisation in front of it for the windows that start an iteration).
@@ -355,6 +355,8 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // host keeps at most two rounds in the queue: the one that is running and the one behind it (one, if the caller passed a stop flag:
   // the flag is then honoured at the very next trial boundary).  It looks at the mirrored state and at the caller's stop flag before
   // every round it adds; the price is at most two rounds of idle launches after the last window finished.
+  se_lds += (size_t)se_waves * ((size_t)64 * 18 * sizeof(double) + 64 * sizeof(int));      // the group runs with the wavefront count its largest window allows
+  const int se_threads = 64 * se_waves;
   // linearisation inside the Schur kernel (cms_ba_schur_edges.hip, FUSED): needs the edge-major kernels and the three-lane solve
   static const bool no_fused = getenv("CMS_BA_NO_FUSED_LIN") != nullptr;
   const bool fused = use_se && use_te && use_s3 && !no_fused;
@@ -391,11 +393,11 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
       if (use_se) {
         bracket(3, 0);
         if (fused) {
-          hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
-          if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         } else {
-          hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
-          if (dup == 3) hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(BA_SE_THREADS), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          if (dup == 3) hipLaunchKernelGGL(kb_ba_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         }
         bracket(3, 1);
         bracket(4, 0);
