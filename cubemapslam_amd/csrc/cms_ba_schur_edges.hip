@@ -345,7 +345,9 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, do
 // its own residual at the trial state.  One thread per point left the chip at 2.7 wavefronts per SIMD walking dependent loads (29 us for
 // eight windows against ~10 us of traffic and arithmetic); here every edge is a lane and the key frames' poses sit in LDS.
 // partial[BX] = chi2 sum, partial[GX + BX] = gain-denominator sum of this workgroup's points.
+#ifndef BA_TE_THREADS
 #define BA_TE_THREADS 256
+#endif
 __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaSe se, const double* __restrict__ bl, const double* __restrict__ Hll,
                                                     const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
                                                     const double* __restrict__ poses_cur, const double* __restrict__ poses_new, int robust, double delta,
@@ -371,6 +373,9 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
   __syncthreads();
   double sc = 0, chi = 0;
   const int c0 = BX * se.cpw_t, c1 = min(se.nchunks, c0 + se.cpw_t);
+  // Everything a lane reads from global memory is requested up front, in two waves of loads: the per-edge words (they depend only on the edge
+  // index), then what hangs on the point index -- position and, for the point's first lane, Hll and bl.  Left where they are used (weight and
+  // observation inside the branches, Hll / bl behind the shuffle loop) they were five dependent round trips per chunk instead of three.
   for (int c = c0 + wave; c < c1; c += nw) {
     const int e0 = se.chunk_e0[c], e1 = se.chunk_e0[c + 1];
     const int e = e0 + lane;
@@ -379,11 +384,22 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
     int p = 0, a = 0, k = 1, kp = 0, face = 0, s = -1;
     bool act = false;
     double X[3] = {0, 0, 0}, cj[3] = {0, 0, 0};
+    double ow = 0.0, einv = 0.0;
+    double2 ob = make_double2(0.0, 0.0);
+    double Hp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bp3[3] = {0, 0, 0};
     if (have) {
       info = se.e_info[e]; p = d.e_point[e];
-      a = info & 31; k = (info >> 5) & 31; s = (int)((info >> 10) & 63) - 1; face = (info >> 16) & 7; kp = (info >> 19) & 255;
       act = d.level[e] == 0;
+      ow = d.ow[e]; einv = d.e_inv[e];
+      ob = reinterpret_cast<const double2*>(d.e_obs)[e];
+      a = info & 31; k = (info >> 5) & 31; s = (int)((info >> 10) & 63) - 1; face = (info >> 16) & 7; kp = (info >> 19) & 255;
       X[0] = pts[3 * (size_t)p]; X[1] = pts[3 * (size_t)p + 1]; X[2] = pts[3 * (size_t)p + 2];
+      if (a == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Hp[i] = Hll[9 * (size_t)p + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bp3[i] = bl[3 * (size_t)p + i];
+      }
       if (act && s >= 0) {
         const double* Rt = prc + 12 * kp;
         double R[9], Xc[3], Jp[12], Jl[6];
@@ -395,7 +411,6 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
         double t0 = 0, t1 = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) { t0 += Jp[i] * xps[6 * s + i]; t1 += Jp[6 + i] * xps[6 * s + i]; }
-        const double ow = d.ow[e];
 #pragma unroll
         for (int j = 0; j < 3; ++j) cj[j] = ow * (Jl[j] * t0 + Jl[3 + j] * t1);
       }
@@ -407,7 +422,7 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
     int nact = nact_me;
     double cl[3] = {0, 0, 0};
     const bool head = have && a == 0;
-    if (head) { cl[0] = bl[3 * (size_t)p] - cj[0]; cl[1] = bl[3 * (size_t)p + 1] - cj[1]; cl[2] = bl[3 * (size_t)p + 2] - cj[2]; }
+    if (head) { cl[0] = bp3[0] - cj[0]; cl[1] = bp3[1] - cj[1]; cl[2] = bp3[2] - cj[2]; }
     for (int dd = 1; dd < kmax; ++dd) {
       const int src = min(lane + dd, 63);
       const double v0 = __shfl(cj[0], src), v1 = __shfl(cj[1], src), v2 = __shfl(cj[2], src);
@@ -418,14 +433,14 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
     if (head) {
       double D[9], Di[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) D[i] = Hll[9 * (size_t)p + i] + ((i & 3) == 0 ? lambda : 0.0);
+      for (int i = 0; i < 9; ++i) D[i] = Hp[i] + ((i & 3) == 0 ? lambda : 0.0);
       inv3(D, Di);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const double xl = nact > 0 ? Di[3 * i] * cl[0] + Di[3 * i + 1] * cl[1] + Di[3 * i + 2] * cl[2] : 0.0;
         Xn[i] = X[i] + xl;
         pts_new[3 * (size_t)p + i] = Xn[i];
-        sc += xl * (lambda * xl + bl[3 * (size_t)p + i]);
+        sc += xl * (lambda * xl + bp3[i]);
       }
     }
     // ---- every lane gets its point's trial position from the point's first lane, then its own residual at the trial state
@@ -438,10 +453,9 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
       double Xc[3], r[2], rho0;
 #pragma unroll
       for (int i = 0; i < 3; ++i) Xc[i] = Rt[3 * i] * Xn[0] + Rt[3 * i + 1] * Xn[1] + Rt[3 * i + 2] * Xn[2] + Rt[9 + i];
-      const double2 ob = reinterpret_cast<const double2*>(d.e_obs)[e];
       edge_error_v(d, face, ob.x, ob.y, Xc, r);
       reinterpret_cast<double2*>(d.err)[e] = make_double2(r[0], r[1]);
-      const double c2 = d.e_inv[e] * (r[0] * r[0] + r[1] * r[1]);
+      const double c2 = einv * (r[0] * r[0] + r[1] * r[1]);
       if (robust) { huber_w(c2, delta, &rho0); chi += rho0; } else chi += c2;
     }
   }
