@@ -204,6 +204,17 @@ static bool ba_use_te(cms_ba** bas, int n) {
   for (int w = 0; w < n; ++w) if (bas[w]->se.Rt <= 0) return false;
   return true;
 }
+// Workgroups (ranges of chunks) per window for the edge-major Schur kernel of a GROUP: one workgroup fills a CU (148 KB of LDS), so the launch
+// should have at most as many workgroups as the chip has CUs -- 11 windows x 32 ranges = 352 workgroups run as one full round plus a round
+// at 37 %.  Windows keep the 32 ranges their buffers are sized for as the upper limit.
+static int ba_group_ranges(cms_ba** bas, int n) {
+  static int cus = 0;
+  if (cus == 0) { hipDeviceProp_t pr; cus = hipGetDeviceProperties(&pr, bas[0]->device) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+  static const bool fixed = getenv("CMS_BA_FIXED_RANGES") != nullptr;
+  int R = BA_SE_RANGES;
+  if (!fixed && n > 0) R = std::max(4, std::min(BA_SE_RANGES, cus / n));
+  return R;
+}
 static int ba_upload_items(cms_ba** bas, int n) {
   cms_ba* g = bas[0];
   BaItem* items = reinterpret_cast<BaItem*>(g->grp_items_host);
@@ -228,6 +239,11 @@ static int ba_upload_items(cms_ba** bas, int n) {
     if (!use_se) { it.se.R = 0; it.se.Rt = 0; }
     if (use_se && !ba_use_te(bas, n)) it.se.Rt = 0;
     if (use_se) { it.chunk_sum = b->d_se_sum; it.pair_chunk_off = b->d_se_chunk_off; it.pair_of_block = b->d_se_pob; }
+    if (use_se && it.se.R > 0) {
+      const int Rg = std::min(it.se.R, ba_group_ranges(bas, n));
+      it.se.cpw = std::max(1, (it.se.nchunks + Rg - 1) / Rg);
+      it.se.R = (it.se.nchunks + it.se.cpw - 1) / it.se.cpw;
+    }
   }
   HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
   return CMS_OK;
@@ -345,7 +361,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   }
   int max_seR = 0, max_np2 = 0, max_Rt = 0, se_waves = BA_SE_THREADS / 64; size_t se_lds = 0, te_lds = 0;
   for (int w = 0; w < n; ++w) {
-    max_seR = std::max(max_seR, bas[w]->se.R); max_np2 = std::max(max_np2, bas[w]->se.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds_fixed); se_waves = std::min(se_waves, bas[w]->se_waves > 0 ? bas[w]->se_waves : se_waves);
+    max_seR = std::max(max_seR, std::min(bas[w]->se.R, ba_group_ranges(bas, n))); max_np2 = std::max(max_np2, bas[w]->se.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds_fixed); se_waves = std::min(se_waves, bas[w]->se_waves > 0 ? bas[w]->se_waves : se_waves);
     max_Rt = std::max(max_Rt, bas[w]->se.Rt); te_lds = std::max(te_lds, ((size_t)24 * bas[w]->K + 6 * (size_t)std::max(bas[w]->np, 1)) * sizeof(double));
   }
   // One "round" = the launches of one Levenberg trial (plus the linearisation in front of it for the windows that start an iteration).
