@@ -12,6 +12,7 @@
 #include <string>
 #include <thread>
 
+struct BaBlock { void* p; size_t bytes; };      // a device slab / pinned block of the per-device pool (below)
 struct cms_ba {
   int device = 0;
   hipStream_t stream = nullptr; bool own_stream = true, pooled_stream = false;
@@ -43,7 +44,7 @@ struct cms_ba {
   int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_bp_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
   size_t se_lds_fixed = 0; int se_waves = 0;      // LDS of the edge-major kernel without the per-wavefront part; wavefronts per workgroup that fit
   int cur = 0;
-  double* h_pin = nullptr;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
+  double* h_pin = nullptr; size_t h_pin_bytes = 0;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   // group resources (owned by the first window of a cms_ba_optimize_many call, grown on demand)
   void* grp_items_dev = nullptr; void* grp_items_host = nullptr; double* grp_scal_dev = nullptr; double* grp_scal_host = nullptr;
   void* grp_lm_dev = nullptr; void* grp_lm_host = nullptr;   // BaLmDev per window (device-side Levenberg state) and its pinned mirror
@@ -51,7 +52,8 @@ struct cms_ba {
   // optional HIP-event bracket around ONE kernel of the grouped driver's rounds (bench.py's roofline of the dominant BA kernel):
   // kernel ids 1 lin, 2 maxdiag, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points, 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
-  std::vector<void*> allocs;
+  std::vector<BaBlock> slabs; size_t slab_off = 0;      // device memory of the window: carved from pooled slabs (ba_alloc)
+  size_t grp_pin_bytes[3] = {0, 0, 0};                  // sizes of grp_items_host, grp_scal_host, grp_lm_host (pooled pinned blocks)
 };
 
 // Dynamic-LDS ceilings of the BA kernels: hipFuncAttributeMaxDynamicSharedMemorySize is a per-function (per device) global, so it is
@@ -93,24 +95,86 @@ static void ba_stream_give(int device, hipStream_t s) {
   hipStreamDestroy(s);
 }
 
+// ---- memory of a window comes from a per-device pool.  A window of configs[3] size needs ~50 device buffers: allocated and freed one by
+// one (hipMalloc is cheap, hipFree is not: ~40 us each) a LocalBundleAdjustment call spent 2 ms of its 17 in cms_ba_destroy, and the
+// grouped driver's pinned blocks (hipHostMalloc: ~0.3 ms each) another millisecond.  Windows now carve their buffers out of a few slabs;
+// slabs and pinned blocks of destroyed windows wait in the pool for the next window of the device (bounded: 2 GB of slabs, 64 pinned blocks).
+struct BaMemPool {
+  std::mutex mu;
+  std::vector<BaBlock> dev[64], pin[64];
+  size_t dev_cached[64] = {0};
+};
+static BaMemPool& ba_pool() { static BaMemPool* p = new BaMemPool; return *p; }      // never destroyed: no HIP calls at process exit
+static void* ba_pool_take(std::vector<BaBlock>& v, size_t bytes, size_t* got) {      // smallest cached block that is large enough (and not absurdly larger)
+  int best = -1;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].bytes >= bytes && v[i].bytes <= 4 * bytes + (1u << 20) && (best < 0 || v[i].bytes < v[best].bytes)) best = (int)i;
+  if (best < 0) return nullptr;
+  void* p = v[best].p; *got = v[best].bytes;
+  v[best] = v.back(); v.pop_back();
+  return p;
+}
+static hipError_t ba_dev_take(int device, size_t bytes, void** p, size_t* got) {
+  BaMemPool& pl = ba_pool();
+  if (device >= 0 && device < 64) {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if ((*p = ba_pool_take(pl.dev[device], bytes, got)) != nullptr) { pl.dev_cached[device] -= *got; return hipSuccess; }
+  }
+  *got = bytes;
+  return hipMalloc(p, bytes);
+}
+static void ba_dev_give(int device, void* p, size_t bytes) {
+  BaMemPool& pl = ba_pool();
+  if (device >= 0 && device < 64) {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (pl.dev_cached[device] + bytes <= ((size_t)2 << 30)) { pl.dev[device].push_back({p, bytes}); pl.dev_cached[device] += bytes; return; }
+  }
+  hipFree(p);
+}
+// pinned, device-visible, explicitly coherent host memory (the grouped driver's mirrors are written by running kernels)
+static hipError_t ba_pin_take(int device, size_t bytes, void** p, size_t* got) {
+  BaMemPool& pl = ba_pool();
+  if (device >= 0 && device < 64) {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if ((*p = ba_pool_take(pl.pin[device], bytes, got)) != nullptr) return hipSuccess;
+  }
+  *got = bytes;
+  return hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+}
+static void ba_pin_give(int device, void* p, size_t bytes) {
+  BaMemPool& pl = ba_pool();
+  if (device >= 0 && device < 64) {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (pl.pin[device].size() < 64) { pl.pin[device].push_back({p, bytes}); return; }
+  }
+  hipHostFree(p);
+}
+
 template <class T> static int ba_alloc(cms_ba* b, T** p, size_t n) {
-  hipError_t e = hipMalloc((void**)p, (n > 0 ? n : 1) * sizeof(T));
-  if (e != hipSuccess) return cms_fail(CMS_ERR_HIP, "hipMalloc (BA)", e);
-  b->allocs.push_back(*p);
+  // carve from the window's current slab (256-byte granules); a new slab is at least twice the previous one
+  const size_t need = (((n > 0 ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+  if (b->slabs.empty() || b->slab_off + need > b->slabs.back().bytes) {
+    size_t want = std::max(need, b->slabs.empty() ? (size_t)1 << 20 : 2 * b->slabs.back().bytes);
+    void* sp = nullptr; size_t got = 0;
+    hipError_t e = ba_dev_take(b->device, want, &sp, &got);
+    if (e != hipSuccess) return cms_fail(CMS_ERR_HIP, "hipMalloc (BA)", e);
+    b->slabs.push_back({sp, got});
+    b->slab_off = 0;
+  }
+  *p = reinterpret_cast<T*>(static_cast<char*>(b->slabs.back().p) + b->slab_off);
+  b->slab_off += need;
   return CMS_OK;
 }
 
 extern "C" void cms_ba_destroy(cms_ba* b) {
   if (!b) return;
   hipSetDevice(b->device);
-  for (void* p : b->allocs) hipFree(p);
-  if (b->h_pin) hipHostFree(b->h_pin);
-  if (b->grp_items_dev) hipFree(b->grp_items_dev);
-  if (b->grp_scal_dev) hipFree(b->grp_scal_dev);
-  if (b->grp_items_host) hipHostFree(b->grp_items_host);
-  if (b->grp_scal_host) hipHostFree(b->grp_scal_host);
-  if (b->grp_lm_dev) hipFree(b->grp_lm_dev);
-  if (b->grp_lm_host) hipHostFree(b->grp_lm_host);
+  if (b->stream) hipStreamSynchronize(b->stream);      // nothing of this window may still be running when its memory goes back to the pool
+  for (const BaBlock& sl : b->slabs) ba_dev_give(b->device, sl.p, sl.bytes);
+  if (b->h_pin) ba_pin_give(b->device, b->h_pin, b->h_pin_bytes);
+  if (b->grp_items_host) ba_pin_give(b->device, b->grp_items_host, b->grp_pin_bytes[0]);
+  if (b->grp_scal_host) ba_pin_give(b->device, b->grp_scal_host, b->grp_pin_bytes[1]);
+  if (b->grp_lm_host) ba_pin_give(b->device, b->grp_lm_host, b->grp_pin_bytes[2]);
   for (hipEvent_t e : b->prof_ev) hipEventDestroy(e);
   if (b->stream && b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else hipStreamDestroy(b->stream); }
   delete b;
@@ -458,7 +522,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(std::max(b->nblk_e, b->nblk_p), (E + 63) / 64 + 8) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 24));   // [8..16): developer clocks of k_ba_trial_solve
   BA_TRY(ba_alloc(b, &b->d_flags, E));
   b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
-  BA_HIP(hipHostMalloc((void**)&b->h_pin, 8 * sizeof(double)));
+  BA_HIP(ba_pin_take(device, 8 * sizeof(double), (void**)&b->h_pin, &b->h_pin_bytes));
   BA_TRY(ba_alloc(b, &b->d_pose_partial, (size_t)std::max(np, 1) * BA_POSE_CHUNKS * 27)); BA_TRY(ba_alloc(b, &b->d_db, 3 * (size_t)P));
   tick("alloc");
   // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2

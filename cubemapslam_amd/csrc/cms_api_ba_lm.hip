@@ -159,28 +159,29 @@ static int ba_optimize_stage_many(cms_ba** bas, int n, std::vector<BaLm>& st, co
 // ---- batched variant: the windows share every launch (kb_ba_* kernels, blockIdx.z = window) and every synchronisation.
 // Used when all windows fit the fused trial path and live on one device; results are identical to the per-window path.
 static bool ba_can_batch(cms_ba** bas, int n) {
-  if (n < 2 || n > BA_MAX_GROUP) return false;
+  static const bool single_old = getenv("CMS_BA_SINGLE_HOST_LM") != nullptr;      // A/B: a single window through the host-driven per-window path
+  if (n < (single_old ? 2 : 1) || n > BA_MAX_GROUP) return false;      // (a single window too: device-side Levenberg loop, edge-major kernels)
   for (int w = 0; w < n; ++w) if (!bas[w]->solve_blk || bas[w]->device != bas[0]->device) return false;
   return true;
 }
 static int ba_group_reserve(cms_ba* owner, int n) {
   if (owner->grp_cap >= n) return CMS_OK;
-  if (owner->grp_items_dev) hipFree(owner->grp_items_dev);
-  if (owner->grp_scal_dev) hipFree(owner->grp_scal_dev);
-  if (owner->grp_items_host) hipHostFree(owner->grp_items_host);
-  if (owner->grp_scal_host) hipHostFree(owner->grp_scal_host);
-  if (owner->grp_lm_dev) hipFree(owner->grp_lm_dev);
-  if (owner->grp_lm_host) hipHostFree(owner->grp_lm_host);
-  owner->grp_lm_dev = nullptr; owner->grp_lm_host = nullptr;
+  // (device blocks of an outgrown group stay in the window's slabs until it is destroyed; the pinned ones go back to the pool)
+  if (owner->grp_items_host) ba_pin_give(owner->device, owner->grp_items_host, owner->grp_pin_bytes[0]);
+  if (owner->grp_scal_host) ba_pin_give(owner->device, owner->grp_scal_host, owner->grp_pin_bytes[1]);
+  if (owner->grp_lm_host) ba_pin_give(owner->device, owner->grp_lm_host, owner->grp_pin_bytes[2]);
+  owner->grp_items_host = nullptr; owner->grp_scal_host = nullptr; owner->grp_lm_host = nullptr;
   owner->grp_cap = 0;
-  HIPCHK(hipMalloc(&owner->grp_items_dev, (size_t)n * sizeof(BaItem)));
-  HIPCHK(hipMalloc((void**)&owner->grp_scal_dev, (size_t)n * 8 * sizeof(double)));
-  HIPCHK(hipHostMalloc(&owner->grp_items_host, (size_t)n * sizeof(BaItem)));
-  // device-visible and explicitly coherent (fine-grained, uncached on the device side): kernels publish the windows' state and the round
-  // counter into these while they run, so visibility must not depend on HIP_HOST_COHERENT's default
-  HIPCHK(hipHostMalloc((void**)&owner->grp_scal_host, (size_t)n * 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-  HIPCHK(hipMalloc(&owner->grp_lm_dev, (size_t)n * sizeof(BaLmDev)));
-  HIPCHK(hipHostMalloc(&owner->grp_lm_host, (size_t)n * sizeof(BaLmDev), hipHostMallocMapped | hipHostMallocCoherent));
+  const int cap = std::max(n, 8);
+  { char* q = nullptr; int rc = ba_alloc(owner, &q, (size_t)cap * sizeof(BaItem)); if (rc) return rc; owner->grp_items_dev = q; }
+  { int rc = ba_alloc(owner, &owner->grp_scal_dev, (size_t)cap * 8); if (rc) return rc; }
+  { char* q = nullptr; int rc = ba_alloc(owner, &q, (size_t)cap * sizeof(BaLmDev)); if (rc) return rc; owner->grp_lm_dev = q; }
+  // pinned, device-visible and explicitly coherent (fine-grained, uncached on the device side): kernels publish the windows' state and the
+  // round counter into these while they run, so visibility must not depend on HIP_HOST_COHERENT's default
+  HIPCHK(ba_pin_take(owner->device, (size_t)cap * sizeof(BaItem), &owner->grp_items_host, &owner->grp_pin_bytes[0]));
+  HIPCHK(ba_pin_take(owner->device, (size_t)cap * 8 * sizeof(double), (void**)&owner->grp_scal_host, &owner->grp_pin_bytes[1]));
+  HIPCHK(ba_pin_take(owner->device, (size_t)cap * sizeof(BaLmDev), &owner->grp_lm_host, &owner->grp_pin_bytes[2]));
+  n = cap;
   owner->grp_cap = n;
   return CMS_OK;
 }

@@ -41,7 +41,7 @@
 #define BA_SE_THREADS 512
 #endif
 #define BA_SE_SSTRIDE 37          /* doubles per off-diagonal pose pair in the LDS copy: 36, padded to an odd count (bank aliasing of neighbouring pairs) */
-#define BA_SE_RANGES 32           /* workgroups per window */
+#define BA_SE_RANGES 128          /* workgroups per window at most (a window alone; a group shares the chip: ba_group_ranges) */
 
 struct BaSe {                      // device view of the edge-major work list (cms_api_ba.hip)
   int R, nchunks, cpw;            // ranges (workgroups), chunks, chunks per range
