@@ -483,11 +483,18 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   }
   tick("chunks");
   // sort edges by (internal point, pose): CSR by point; per-pose edge lists reference sorted positions
+  // (two stable counting passes, by key frame and then by internal point: what a stable comparison sort on (point, key frame) gives, in O(E))
   b->perm.resize(E);
-  std::iota(b->perm.begin(), b->perm.end(), 0);
-  std::stable_sort(b->perm.begin(), b->perm.end(), [&](int a, int c) {
-    return e_point[a] != e_point[c] ? prank[e_point[a]] < prank[e_point[c]] : e_pose[a] < e_pose[c];
-  });
+  {
+    std::vector<int> by_pose(E), cnt((size_t)std::max(K, P) + 1, 0);
+    for (int e = 0; e < E; ++e) ++cnt[e_pose[e] + 1];
+    for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
+    for (int e = 0; e < E; ++e) by_pose[cnt[e_pose[e]]++] = e;
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int e = 0; e < E; ++e) ++cnt[prank[e_point[e]] + 1];
+    for (int p = 0; p < P; ++p) cnt[p + 1] += cnt[p];
+    for (int i = 0; i < E; ++i) { const int e = by_pose[i]; b->perm[cnt[prank[e_point[e]]]++] = e; }
+  }
   std::vector<int> s_pose(E), s_point(E), pt_off(P + 1, 0), pose_off(K + 1, 0), pose_edges(E), pose_slot(K, -1);
   std::vector<double> s_obs(2 * (size_t)E), s_inv(E);
   std::vector<int8_t> s_face(E);
