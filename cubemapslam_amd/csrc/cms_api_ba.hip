@@ -52,6 +52,7 @@ struct cms_ba {
   // optional HIP-event bracket around ONE kernel of the grouped driver's rounds (bench.py's roofline of the dominant BA kernel):
   // kernel ids 1 lin, 2 maxdiag, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points, 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
+  bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   std::vector<BaBlock> slabs; size_t slab_off = 0;      // device memory of the window: carved from pooled slabs (ba_alloc)
   size_t grp_pin_bytes[3] = {0, 0, 0};                  // sizes of grp_items_host, grp_scal_host, grp_lm_host (pooled pinned blocks)
 };
@@ -523,7 +524,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   for (int i = 0; i < 2; ++i) { BA_TRY(ba_alloc(b, &b->d_poses[i], 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts[i], 3 * (size_t)P)); }
   BA_TRY(ba_alloc(b, &b->d_poses0, 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts0, 3 * (size_t)P));
   BA_TRY(ba_alloc(b, &b->d_Hpp, 36 * (size_t)std::max(np, 1))); BA_TRY(ba_alloc(b, &b->d_bp, 6 * (size_t)std::max(np, 1)));
-  BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
+  BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P));
   BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
   BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
   BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(std::max(b->nblk_e, b->nblk_p), (E + 63) / 64 + 8) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 24));   // [8..16): developer clocks of k_ba_trial_solve
@@ -532,8 +533,80 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_HIP(ba_pin_take(device, 8 * sizeof(double), (void**)&b->h_pin, &b->h_pin_bytes));
   BA_TRY(ba_alloc(b, &b->d_pose_partial, (size_t)std::max(np, 1) * BA_POSE_CHUNKS * 27)); BA_TRY(ba_alloc(b, &b->d_db, 3 * (size_t)P));
   tick("alloc");
+  b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
+  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
+  // ---- work list of the edge-major Schur kernel (cms_ba_schur_edges.hip): chunks of whole points with <= 64 edges, one wavefront
+  // each; dense enumeration of the pose pairs s1 <= s2 and the matching tables for the solve kernel's assembly
+  if (np >= 1) {
+    const int NP2 = np * (np + 1) / 2;
+    // LDS: the reduced system, the diagonal copies and the key frames' poses, plus a W row and a slot per lane of every wavefront.  Windows with
+    // more free key frames get fewer wavefronts per workgroup (8 up to 20 key frames, 6 / 4 / 2 up to 25); beyond that the copy does not fit
+    const size_t lds_fixed = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)K * 12) * sizeof(double);
+    const size_t lds_wave = (size_t)64 * 18 * sizeof(double) + 64 * sizeof(int);
+    int nw = BA_SE_THREADS / 64;
+    while (nw > 2 && lds_fixed + nw * lds_wave > BA_LDS_CEILING) nw -= 2;
+    const size_t lds = lds_fixed + nw * lds_wave;
+    bool ok = lds <= BA_LDS_CEILING && K <= 256 && np <= 62;
+    std::vector<int> ce0;
+    std::vector<uint32_t> info(E);
+    for (size_t c = 0; c + 1 < b->se_chunk_pt0.size() && ok; ++c) {
+      const int p0 = b->se_chunk_pt0[c], p1 = b->se_chunk_pt0[c + 1];
+      if (p1 == p0) continue;
+      if (pt_off[p1] - pt_off[p0] > 64) { ok = false; break; }
+      ce0.push_back(pt_off[p0]);
+      for (int p = p0; p < p1 && ok; ++p) {
+        const int ne = pt_off[p + 1] - pt_off[p];
+        if (ne > 31) { ok = false; break; }
+        for (int a1 = 0; a1 < ne; ++a1) {
+          const int e = pt_off[p] + a1;
+          if (a1 > 0 && s_pose[e] == s_pose[e - 1]) ok = false;       // a point seen twice by one key frame: the pair-owner kernel handles it
+          const int rank = cp_rank[(size_t)cp_off[b->pinv[p]] + a1] % BA_SE_DCOPIES;      // chosen with the chunk (edges of a point are in pose order in both lists)
+          info[e] = (uint32_t)a1 | ((uint32_t)ne << 5) | ((uint32_t)(pose_slot[s_pose[e]] + 1) << 10) | ((uint32_t)s_face[e] << 16) | ((uint32_t)s_pose[e] << 19) |
+                    ((uint32_t)rank << 27);
+        }
+      }
+    }
+    ce0.push_back(E);
+    if (ok) {
+      const int nchunks = (int)ce0.size() - 1;
+      const int cpw = std::max(1, (nchunks + BA_SE_RANGES - 1) / BA_SE_RANGES);
+      const int R = (nchunks + cpw - 1) / cpw;
+      std::vector<int> pob((size_t)NP2, 0), ident((size_t)NP2 + 1);
+      for (int I = 0; I < np; ++I)
+        for (int Kc = 0; Kc <= I; ++Kc) pob[(size_t)I * (I + 1) / 2 + Kc] = Kc * np - (Kc * (Kc - 1)) / 2 + (I - Kc);   // block (I, K): pair (s1 = K, s2 = I)
+      for (int i = 0; i <= NP2; ++i) ident[i] = i;
+      BA_TRY(ba_alloc(b, &b->d_se_chunk_e0, ce0.size())); BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)R * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)R * np * 6)); BA_TRY(ba_alloc(b, &b->d_se_info, info.size()));
+      BA_HIP(hipMemcpy(b->d_se_info, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_pob, pob.size())); BA_TRY(ba_alloc(b, &b->d_se_chunk_off, ident.size()));
+      BA_HIP(hipMemcpy(b->d_se_chunk_e0, ce0.data(), ce0.size() * sizeof(int), hipMemcpyHostToDevice));
+      BA_HIP(hipMemcpy(b->d_se_pob, pob.data(), pob.size() * sizeof(int), hipMemcpyHostToDevice));
+      BA_HIP(hipMemcpy(b->d_se_chunk_off, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+      {
+        std::vector<int> lone;                                             // points without observations are in no chunk
+        for (int p = 0; p < P; ++p) if (pt_off[p + 1] == pt_off[p]) lone.push_back(p);
+        int* d_lone = nullptr;
+        BA_TRY(ba_alloc(b, &d_lone, lone.size()));
+        if (!lone.empty()) BA_HIP(hipMemcpy(d_lone, lone.data(), lone.size() * sizeof(int), hipMemcpyHostToDevice));
+        b->se.lone = d_lone; b->se.nlone = (int)lone.size();
+        const int cpw_t = BA_TE_THREADS / 64;                              // one chunk per wavefront
+        b->se.cpw_t = cpw_t;
+        b->se.Rt = (nchunks + cpw_t - 1) / cpw_t;
+      }
+      b->se.R = R; b->se.nchunks = nchunks; b->se.cpw = cpw; b->se.npairs2 = NP2; b->se.chunk_e0 = b->d_se_chunk_e0; b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial; b->se.e_info = b->d_se_info;
+      b->se_lds_fixed = lds_fixed; b->se_waves = nw;
+    }
+  }
+  tick("se");
+  // A window that has the edge-major work list runs through the grouped driver with the edge-major kernels (cms_ba_optimize_many also puts
+  // it into a group of its own kind): the pair-owner and tuple-chunk kernels' work lists (co-visibility tuples: ~10 per point, 2.4 ms of
+  // host time at 80 k edges) and the stored 6x3 blocks (144 B per edge) are then never touched and are not built.  The A/B switches that
+  // select those kernels bring them back.
+  static const bool want_all_lists = getenv("CMS_BA_DETERMINISTIC") || getenv("CMS_BA_HOST_LM") || getenv("CMS_BA_SINGLE_HOST_LM") ||
+                                     getenv("CMS_BA_SCHUR_CHUNKS") || getenv("CMS_BA_SCHUR_POINTS") || getenv("CMS_BA_ALL_LISTS");
+  b->se_only = b->se.R > 0 && b->solve_blk && !want_all_lists;
+  if (!b->se_only) BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2
-  {
+  if (!b->se_only) {
     struct Tup { int pair, a1, a2; };
     std::vector<Tup> tups;
     for (int p = 0; p < P; ++p)
@@ -677,68 +750,6 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
       }
     }
     tick("sp");
-    // ---- work list of the edge-major Schur kernel (cms_ba_schur_edges.hip): chunks of whole points with <= 64 edges, one wavefront
-    // each; dense enumeration of the pose pairs s1 <= s2 and the matching tables for the solve kernel's assembly
-    if (np >= 1) {
-      const int NP2 = np * (np + 1) / 2;
-      // LDS: the reduced system, the diagonal copies and the key frames' poses, plus a W row and a slot per lane of every wavefront.  Windows with
-      // more free key frames get fewer wavefronts per workgroup (8 up to 20 key frames, 6 / 4 / 2 up to 25); beyond that the copy does not fit
-      const size_t lds_fixed = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)K * 12) * sizeof(double);
-      const size_t lds_wave = (size_t)64 * 18 * sizeof(double) + 64 * sizeof(int);
-      int nw = BA_SE_THREADS / 64;
-      while (nw > 2 && lds_fixed + nw * lds_wave > BA_LDS_CEILING) nw -= 2;
-      const size_t lds = lds_fixed + nw * lds_wave;
-      bool ok = lds <= BA_LDS_CEILING && K <= 256 && np <= 62;
-      std::vector<int> ce0;
-      std::vector<uint32_t> info(E);
-      for (size_t c = 0; c + 1 < b->se_chunk_pt0.size() && ok; ++c) {
-        const int p0 = b->se_chunk_pt0[c], p1 = b->se_chunk_pt0[c + 1];
-        if (p1 == p0) continue;
-        if (pt_off[p1] - pt_off[p0] > 64) { ok = false; break; }
-        ce0.push_back(pt_off[p0]);
-        for (int p = p0; p < p1 && ok; ++p) {
-          const int ne = pt_off[p + 1] - pt_off[p];
-          if (ne > 31) { ok = false; break; }
-          for (int a1 = 0; a1 < ne; ++a1) {
-            const int e = pt_off[p] + a1;
-            if (a1 > 0 && s_pose[e] == s_pose[e - 1]) ok = false;       // a point seen twice by one key frame: the pair-owner kernel handles it
-            const int rank = cp_rank[(size_t)cp_off[b->pinv[p]] + a1] % BA_SE_DCOPIES;      // chosen with the chunk (edges of a point are in pose order in both lists)
-            info[e] = (uint32_t)a1 | ((uint32_t)ne << 5) | ((uint32_t)(pose_slot[s_pose[e]] + 1) << 10) | ((uint32_t)s_face[e] << 16) | ((uint32_t)s_pose[e] << 19) |
-                      ((uint32_t)rank << 27);
-          }
-        }
-      }
-      ce0.push_back(E);
-      if (ok) {
-        const int nchunks = (int)ce0.size() - 1;
-        const int cpw = std::max(1, (nchunks + BA_SE_RANGES - 1) / BA_SE_RANGES);
-        const int R = (nchunks + cpw - 1) / cpw;
-        std::vector<int> pob((size_t)NP2, 0), ident((size_t)NP2 + 1);
-        for (int I = 0; I < np; ++I)
-          for (int Kc = 0; Kc <= I; ++Kc) pob[(size_t)I * (I + 1) / 2 + Kc] = Kc * np - (Kc * (Kc - 1)) / 2 + (I - Kc);   // block (I, K): pair (s1 = K, s2 = I)
-        for (int i = 0; i <= NP2; ++i) ident[i] = i;
-        BA_TRY(ba_alloc(b, &b->d_se_chunk_e0, ce0.size())); BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)R * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)R * np * 6)); BA_TRY(ba_alloc(b, &b->d_se_info, info.size()));
-        BA_HIP(hipMemcpy(b->d_se_info, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_pob, pob.size())); BA_TRY(ba_alloc(b, &b->d_se_chunk_off, ident.size()));
-        BA_HIP(hipMemcpy(b->d_se_chunk_e0, ce0.data(), ce0.size() * sizeof(int), hipMemcpyHostToDevice));
-        BA_HIP(hipMemcpy(b->d_se_pob, pob.data(), pob.size() * sizeof(int), hipMemcpyHostToDevice));
-        BA_HIP(hipMemcpy(b->d_se_chunk_off, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
-        {
-          std::vector<int> lone;                                             // points without observations are in no chunk
-          for (int p = 0; p < P; ++p) if (pt_off[p + 1] == pt_off[p]) lone.push_back(p);
-          int* d_lone = nullptr;
-          BA_TRY(ba_alloc(b, &d_lone, lone.size()));
-          if (!lone.empty()) BA_HIP(hipMemcpy(d_lone, lone.data(), lone.size() * sizeof(int), hipMemcpyHostToDevice));
-          b->se.lone = d_lone; b->se.nlone = (int)lone.size();
-          const int cpw_t = BA_TE_THREADS / 64;                              // one chunk per wavefront
-          b->se.cpw_t = cpw_t;
-          b->se.Rt = (nchunks + cpw_t - 1) / cpw_t;
-        }
-        b->se.R = R; b->se.nchunks = nchunks; b->se.cpw = cpw; b->se.npairs2 = NP2; b->se.chunk_e0 = b->d_se_chunk_e0; b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial; b->se.e_info = b->d_se_info;
-        b->se_lds_fixed = lds_fixed; b->se_waves = nw;
-      }
-    }
-    tick("se");
     std::vector<int> pcoff(1, 0);
     std::vector<int2> crange;
     for (size_t pr = 0; pr + 1 < poff.size(); ++pr) {
@@ -759,8 +770,6 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     }
     BA_HIP(hipMemcpy(b->d_pair_off, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
   }
-  b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
-  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
   tick("tuple-upload");
   // the three-lanes-per-block variant (grouped driver): 3 x blocks <= 1024 threads
   b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 2 * (size_t)n + 8) * sizeof(double);
@@ -878,6 +887,10 @@ extern "C" int cms_ba_linearize(int device, int K, const double* poses, const ui
   cms_ba* b = nullptr;
   int rc = cms_ba_create(&b, device, K, poses, fixed, P, points, E, e_pose, e_point, e_obs, e_invsig2, e_face, fx, fy, cx, cy);
   if (rc) return rc;
+  if (!b->d_Hpl) {      // the window carries only the edge-major work list: the stored-block buffer this entry reports is allocated here
+    rc = ba_alloc(b, &b->d_Hpl, 18 * (size_t)E);
+    if (rc) { cms_ba_destroy(b); return rc; }
+  }
   hipStream_t s = b->stream;
   ba_errors(b, 0, robust, huber_delta, 0);
   hipLaunchKernelGGL(k_ba_lin_points, dim3(b->nblk_p), dim3(128), 0, s, b->d, (const double*)b->d_poses[0], (const double*)b->d_pts[0],

@@ -194,7 +194,7 @@ static bool ba_all_sp(cms_ba** bas, int n) {
 // per-point path is available too (the two share the block-free linearisation); CMS_BA_DETERMINISTIC=1 keeps the pair-owner kernel
 static bool ba_use_se(cms_ba** bas, int n) {
   static const bool det = getenv("CMS_BA_DETERMINISTIC") != nullptr || getenv("CMS_BA_HOST_LM") != nullptr;   // (the host-driven A/B driver only knows the pair-owner kernel)
-  if (det || !ba_all_sp(bas, n)) return false;
+  if (det) return false;
   for (int w = 0; w < n; ++w) if (bas[w]->se.R <= 0) return false;
   return true;
 }
@@ -231,7 +231,7 @@ static int ba_upload_items(cms_ba** bas, int n) {
     it.scal = g->grp_scal_dev + 8 * w; it.hscal = g->grp_scal_host + 8 * w;
     it.chunk_range = b->d_chunk_range; it.tup = b->d_tup; it.pair_of_block = b->d_pair_of_block; it.pair_chunk_off = b->d_pair_chunk_off;
     it.flags = b->d_flags;
-    it.nblk_e = b->nblk_e; it.nblk_p = b->nblk_p; it.nchunks = b->nchunks; it.pad = 0;
+    it.nblk_e = b->nblk_e; it.nblk_p = b->nblk_p; it.nchunks = b->nchunks; it.block_free = (all_sp || use_se) ? 1 : 0;
     it.sp = b->sp;
     it.lm = reinterpret_cast<BaLmDev*>(g->grp_lm_dev) + w; it.hlm = reinterpret_cast<BaLmDev*>(g->grp_lm_host) + w;
     if (!all_sp) it.sp.R = 0;                       // one launch sequence for the whole group: per-point Schur only if every window has it
@@ -405,7 +405,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         bracket(2, 1);
       }
       if (fused) iter_phase = false;
-      if (!all_sp)
+      if (!all_sp && !use_se)
         hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       if (use_se) {
         bracket(3, 0);
@@ -513,9 +513,33 @@ static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<i
   return CMS_OK;
 }
 
+static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats);
+// Windows are independent problems; the grouped driver wants a group of one kind (one device; all with the edge-major work list, or none:
+// a window that has it carries no other list) of at most BA_MAX_GROUP windows.  A call that mixes kinds is run as several groups, one
+// after the other -- same results, the caller's order of `stats` kept.
 extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats) {
   if (!bas || n < 1) return cms_fail(CMS_ERR_ARG, "cms_ba_optimize_many: bad argument");
   for (int w = 0; w < n; ++w) if (!bas[w]) return cms_fail(CMS_ERR_ARG, "null ba");
+  auto kind = [&](int w) { return bas[w]->device * 2 + (bas[w]->se.R > 0 ? 1 : 0); };
+  bool one = n <= BA_MAX_GROUP;
+  for (int w = 1; w < n && one; ++w) one = kind(w) == kind(0);
+  if (one) return ba_optimize_group(bas, n, its_robust, its_final, stop, stats);
+  std::vector<char> done(n, 0);
+  int rc_all = CMS_OK;
+  for (int w0 = 0; w0 < n; ++w0) {
+    if (done[w0]) continue;
+    std::vector<cms_ba*> grp; std::vector<int> idx;
+    for (int w = w0; w < n && (int)grp.size() < BA_MAX_GROUP; ++w)
+      if (!done[w] && kind(w) == kind(w0)) { grp.push_back(bas[w]); idx.push_back(w); done[w] = 1; }
+    std::vector<cms_ba_stats> gs(grp.size());
+    const int rc = ba_optimize_group(grp.data(), (int)grp.size(), its_robust, its_final, stop, gs.data());
+    if (stats) for (size_t i = 0; i < idx.size(); ++i) stats[idx[i]] = gs[i];
+    if (rc < 0) return rc;                 // an error ends the call; "stopped" (1) lets the remaining groups see the flag themselves
+    if (rc != CMS_OK) rc_all = rc;
+  }
+  return rc_all;
+}
+static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats) {
   const bool batched = ba_can_batch(bas, n);
   if (batched) {
     HIPCHK(hipSetDevice(bas[0]->device));

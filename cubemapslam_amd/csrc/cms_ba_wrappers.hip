@@ -29,7 +29,7 @@ struct BaItem {
   double* hscal;                             // pinned host mirror of scal[0..6), written by the last kernel of a phase
   const int2* chunk_range; const int2* tup; const int* pair_of_block; const int* pair_chunk_off;
   uint8_t* flags;
-  int nblk_e, nblk_p, nchunks, pad;
+  int nblk_e, nblk_p, nchunks, block_free;   // block_free: the 6x3 pose-point blocks are rebuilt from the estimate, never stored (per-point and edge-major Schur paths)
   BaSp sp;                                   // per-point Schur work lists (sp.R == 0: window uses the tuple-chunk kernel)
   BaSe se;                                   // edge-major Schur work list (se.R > 0: the group runs kb_ba_schur_edges instead of kb_ba_schur_points)
   BaLmDev* lm; BaLmDev* hlm;                 // device-side LM state and its pinned host mirror (dyn.dev_lm)
@@ -165,7 +165,7 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce(const BaItem* __r
 extern "C" __global__ void __launch_bounds__(128) kb_ba_lin_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
   ba_lin_points_body(blockIdx.x, it.nblk_p, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.Hll, it.bl,
-                     it.sp.R > 0 ? nullptr : it.Hpl);   // per-point Schur path: blocks are rebuilt on the fly, only the weights are stored
+                     it.block_free ? nullptr : it.Hpl);   // per-point / edge-major Schur paths: blocks are rebuilt on the fly, only the weights are stored
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_lin_poses(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.d.K)        // blockIdx.y = slice of the pose's edge list
@@ -178,7 +178,7 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_lin(const BaItem* __rest
   BA_ITEM(phase, 1 << 30)
   if ((int)blockIdx.x < npb) {
     if ((int)blockIdx.x * 256 >= it.d.P) return;
-    ba_lin_points_body(blockIdx.x, npb, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.Hll, it.bl, it.sp.R > 0 ? nullptr : it.Hpl);
+    ba_lin_points_body(blockIdx.x, npb, it.d, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.Hll, it.bl, it.block_free ? nullptr : it.Hpl);
   } else {
     const int j = (int)blockIdx.x - npb, k = j / BA_POSE_CHUNKS, ch = j - k * BA_POSE_CHUNKS;
     if (k >= it.d.K) return;
@@ -284,7 +284,7 @@ extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3(const BaIt
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
   ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
-                       dyn.delta, it.partial, it.sp.R > 0 ? it.Hll : nullptr, it.sp.R > 0 ? it.poses[cur] : nullptr);
+                       dyn.delta, it.partial, it.block_free ? it.Hll : nullptr, it.block_free ? it.poses[cur] : nullptr);
 }
 extern "C" __global__ void __launch_bounds__(BA_TE_THREADS) kb_ba_trial_edges(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.se.Rt)
