@@ -110,8 +110,11 @@ def launcher_selftest(args, rank, world, local_rank):
         dist.destroy_process_group()
     else:
         seen = [0]
-    print(json.dumps({"launcher_selftest": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus_arg": args.gpus,
-                      "ranks_seen": seen, "pid": os.getpid(), "spawned_by_bench": os.environ.get("CMS_BENCH_SPAWNED") == "1"}), flush=True)
+    # one write per record: the ranks share the launcher's stdout, and a record and its newline written separately can interleave
+    line = json.dumps({"launcher_selftest": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus_arg": args.gpus,
+                       "ranks_seen": seen, "pid": os.getpid(), "spawned_by_bench": os.environ.get("CMS_BENCH_SPAWNED") == "1"}) + "\n"
+    sys.stdout.flush()
+    os.write(sys.stdout.fileno(), line.encode())
 
 
 def make_stream_frames(camd, n, seed):

@@ -75,6 +75,19 @@ def test_partition_covers_all_streams():
     assert one.shape == (2, 9)
 
 
+def _json_records(text):
+    """the launcher self-test records in a process group's shared stdout (several objects may share a line)"""
+    import json
+    dec, recs, i = json.JSONDecoder(), [], 0
+    while True:
+        i = text.find('{"launcher_selftest"', i)
+        if i < 0:
+            return recs
+        obj, end = dec.raw_decode(text, i)
+        recs.append(obj)
+        i = end
+
+
 def test_bench_launcher_spawns_one_rank_per_gpu():
     """`python bench.py --gpus N` without a launcher starts N ranks itself (torch.distributed.run on 127.0.0.1), each with its own
     RANK / LOCAL_RANK, all in one world of N; a world that is not --gpus is refused (the driver calls bench.py this way)."""
@@ -83,7 +96,7 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{") and "launcher_selftest" in l]
+    recs = _json_records(out.stdout)
     assert len(recs) == 2, out.stdout
     assert sorted(r["rank"] for r in recs) == [0, 1] and sorted(r["local_rank"] for r in recs) == [0, 1]
     assert all(r["world"] == 2 and r["gpus_arg"] == 2 and r["ranks_seen"] == [0, 1] and r["spawned_by_bench"] for r in recs)
