@@ -245,7 +245,6 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
                               std::vector<int>& cp_pose, std::vector<uint8_t>& cp_rank) {
   static const bool ctiming = getenv("CMS_BA_COMPOSE_TIMING") != nullptr;
   auto c_last = std::chrono::steady_clock::now();
-  double c_diag = 0;
   auto ctick = [&](const char* what) {
     const auto now = std::chrono::steady_clock::now();
     if (ctiming) fprintf(stderr, "[compose] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - c_last).count());
@@ -256,8 +255,7 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
   for (int p = 0; p < P; ++p) cp_off[p + 1] += cp_off[p];
   std::vector<int> fill(cp_off.begin(), cp_off.end() - 1);
   for (int e = 0; e < E; ++e) cp_pose[fill[e_point[e]]++] = e_pose[e];
-  for (int p = 0; p < P; ++p) std::sort(cp_pose.begin() + cp_off[p], cp_pose.begin() + cp_off[p + 1]);
-  ctick("csr + per-point sort");
+  ctick("csr");
   std::vector<int> gslot(K, -1);
   int gnp = 0;
   for (int k = 0; k < K; ++k) if (!fixed[k]) gslot[k] = gnp++;
@@ -266,24 +264,26 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
   const int LA = std::max(lookahead, 1), MAXD = 4;
   std::vector<int> nxt(P + 1);                       // singly linked list of the points not placed yet, in the caller's order
   for (int p = 0; p <= P; ++p) nxt[p] = p + 1;
-  int head = 0, placed = 0, cur_edges = 0;
-  // per open chunk: [step][group of 16 lanes][bank class] lanes so far; diagonal tuples: [group][class]; a point may straddle two groups
-  uint8_t cls[MAXD][4][16], mx[MAXD][4];             // mx: lanes on the fullest bank = what the group costs in that step (start: see the scan below)
-  memset(cls, 0, sizeof(cls)); memset(mx, 1, sizeof(mx)); memset(mx[0], 2, sizeof(mx[0]));
   struct DiagLane { int cp; int16_t s; int16_t g; };  // diagonal tuples of the open chunk: position in cp_rank, free-pose slot, group of 16 lanes
-  std::vector<DiagLane> dlanes;
   auto opair = [&](int s1, int s2) { return s1 * gnp - (s1 * (s1 + 1)) / 2 + (s2 - s1 - 1); };
-  // every point's off-diagonal tuples, once: step - 1 | edge within the point << 2 | bank class << 7
-  // ... and per step the set of banks they touch (pm), with a flag for points that touch a bank twice in one step (those, and points that
-  // straddle two groups of lanes, take the exact count below; for all others the masks decide)
-  std::vector<int> tp_off(P + 1, 0);
-  std::vector<uint16_t> tp, pm((size_t)P * MAXD, 0), pm2((size_t)P * MAXD, 0);      // pm2: banks a point touches twice in one step
+  std::vector<int> tp_beg(P, 0), tp_end(P, 0);                                      // a point's tuples in its segment's table
+  std::vector<uint16_t> pm((size_t)P * MAXD, 0), pm2((size_t)P * MAXD, 0);           // per step: banks a point touches / touches twice
   std::vector<uint8_t> twice(P, 0);                                                  // ... three times: exact count below
-  tp.reserve((size_t)E * 2);
-  for (int p = 0; p < P && greedy; ++p) {
+  // ---- the composition proper, for the points [p_begin, p_end) of the caller's order: they fill the internal positions [p_begin, p_end).
+  // Large windows are cut into segments composed by as many host threads (the segments are fixed by P alone: the result does not depend on
+  // the machine); a segment ends with a chunk that may be short.
+  auto compose_range = [&](int p_begin, int p_end, std::vector<int>& chunk_starts) {
+  // the key frames of a point in ascending order, and every point's off-diagonal tuples, once: step - 1 | edge within the point << 2 | bank
+  // class << 7; per step the set of banks they touch (pm), with a flag for points that touch a bank three times in one step (those, and points
+  // that straddle two groups of lanes, take the exact count below; for all others the masks decide)
+  std::vector<uint16_t> tp;
+  tp.reserve((size_t)(cp_off[p_end] - cp_off[p_begin]) * 2);
+  for (int p = p_begin; p < p_end; ++p) {
+    std::sort(cp_pose.begin() + cp_off[p], cp_pose.begin() + cp_off[p + 1]);
+    tp_beg[p] = (int)tp.size();
     const int k = cp_off[p + 1] - cp_off[p];
     const int* ps = &cp_pose[cp_off[p]];
-    for (int dd = 1; dd <= k / 2 && dd <= MAXD; ++dd)
+    for (int dd = 1; greedy && dd <= k / 2 && dd <= MAXD; ++dd)
       for (int a1 = 0; a1 < k && a1 < 32; ++a1) {
         if (2 * dd == k && a1 >= dd) break;
         const int s1 = gslot[ps[a1]], s2 = gslot[ps[(a1 + dd) % k]];
@@ -296,18 +296,22 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
         if (m & (1u << c)) m2 |= (uint16_t)(1u << c);
         m |= (uint16_t)(1u << c);
       }
-    tp_off[p + 1] = (int)tp.size();
+    tp_end[p] = (int)tp.size();
   }
+  int head = p_begin, placed = p_begin, cur_edges = 0;
+  // per open chunk: [step][group of 16 lanes][bank class] lanes so far; a point may straddle two groups
+  uint8_t cls[MAXD][4][16], mx[MAXD][4];             // mx: lanes on the fullest bank = what the group costs in that step (start: see the scan below)
+  memset(cls, 0, sizeof(cls)); memset(mx, 1, sizeof(mx)); memset(mx[0], 2, sizeof(mx[0]));
+  std::vector<DiagLane> dlanes;
   uint16_t fullmask[MAXD][4], nearmask[MAXD][4];        // banks that hold as many lanes as the group's fullest (one more lane there costs a
   memset(fullmask, 0, sizeof(fullmask));                // slot), and banks one lane short of that (two more lanes do)
   memset(nearmask, 0xFF, sizeof(nearmask));
-  ctick("tuple table");
   // how many LDS slots point p would add to the open chunk if it were placed at lane cur_edges: a group of 16 lanes costs, per step, as
   // many slots as its fullest bank holds lanes (0 = the point's tuples leave every group's maximum where it is); the tuples are counted in
   // as they go (a point's own tuples compete too) and taken out again unless the point is placed
   auto cost_of = [&](int p, bool mark, int limit) {
-    int cost = 0, t = tp_off[p];
-    const int t1 = tp_off[p + 1];
+    int cost = 0, t = tp_beg[p];
+    const int t1 = tp_end[p];
     const int kk = cp_off[p + 1] - cp_off[p], g0 = (cur_edges >> 4) & 3;
     if (!mark && !twice[p] && kk > 0 && ((cur_edges + kk - 1) >> 4) == (cur_edges >> 4)) {
       const uint16_t* m4 = &pm[(size_t)p * MAXD];
@@ -327,7 +331,7 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
     if (mark) {
       memcpy(mx, m, sizeof(m));
       uint32_t touched = 0;                                       // (step, group) pairs whose counts changed
-      for (int u = tp_off[p]; u < t1; ++u) { const int w = tp[u]; touched |= 1u << ((w & 3) * 4 + (((cur_edges + ((w >> 2) & 31)) >> 4) & 3)); }
+      for (int u = tp_beg[p]; u < t1; ++u) { const int w = tp[u]; touched |= 1u << ((w & 3) * 4 + (((cur_edges + ((w >> 2) & 31)) >> 4) & 3)); }
       for (int sg = 0; sg < 16; ++sg) {
         if (!(touched >> sg & 1)) continue;
         const int st = sg >> 2, g = sg & 3;
@@ -339,7 +343,7 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
         fullmask[st][g] = f; nearmask[st][g] = nf;
       }
     } else
-      for (int u = tp_off[p]; u < t; ++u) { const int w = tp[u]; --cls[w & 3][((cur_edges + ((w >> 2) & 31)) >> 4) & 3][w >> 7]; }
+      for (int u = tp_beg[p]; u < t; ++u) { const int w = tp[u]; --cls[w & 3][((cur_edges + ((w >> 2) & 31)) >> 4) & 3][w >> 7]; }
     return cost;
   };
   auto place_diag = [&](int p) {                     // the diagonal tuples wait for the chunk to be complete (finish_diag)
@@ -352,7 +356,6 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
   // copies of the diagonal blocks: a lane may add to any of the four copies of its key frame's block, i.e. to one of four banks; per group of
   // 16 lanes a bipartite matching (augmenting paths) gives as many lanes as possible a bank of their own, the rest take their least-used one
   auto finish_diag = [&]() {
-    const auto d0 = std::chrono::steady_clock::now();
     for (int g = 0; g < 4; ++g) {
       int lanes[64], nl = 0;
       for (size_t i = 0; i < dlanes.size(); ++i) if (dlanes[i].g == g && nl < 64) lanes[nl++] = (int)i;
@@ -364,10 +367,9 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
       for (int i = 0; i < nl; ++i) cp_rank[dlanes[lanes[i]].cp] = (uint8_t)M.choice[i];
     }
     dlanes.clear();
-    c_diag += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
   };
-  chunk_pt0.assign(1, 0);
-  while (placed < P) {
+  chunk_starts.assign(1, p_begin);
+  while (placed < p_end) {
     int pick = -1, prev_pick = -1;
     if (greedy) {
       // the first candidate that costs nothing ends the scan.  "Nothing" is measured against what a full group costs anyway: sixteen
@@ -375,7 +377,7 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
       // hit exactly the four free banks), so the first step's maximum starts at two lanes per bank, the later (half as dense) steps' at one
       const int accept = 0;
       int prev = -1, scanned = 0, best_cost = 1 << 30;
-      for (int p = head; p < P && scanned < LA; prev = p, p = nxt[p], ++scanned) {
+      for (int p = head; p < p_end && scanned < LA; prev = p, p = nxt[p], ++scanned) {
         if (cur_edges + (cp_off[p + 1] - cp_off[p]) > 64) continue;
         const int c = cost_of(p, false, best_cost);
         if (c < best_cost) { best_cost = c; pick = p; prev_pick = prev; if (c <= accept) break; }
@@ -386,7 +388,7 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
     if (pick < 0) {
       if (cur_edges == 0) { pick = head; prev_pick = -1; }          // a point with more than 64 edges: the kernel is refused below
       else {
-        chunk_pt0.push_back(placed);
+        chunk_starts.push_back(placed);
         finish_diag();
         cur_edges = 0;
         memset(cls, 0, sizeof(cls)); memset(mx, 1, sizeof(mx)); memset(mx[0], 2, sizeof(mx[0])); memset(fullmask, 0, sizeof(fullmask)); memset(nearmask, 0xFF, sizeof(nearmask));
@@ -399,10 +401,22 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
     prank[pick] = placed; pinv[placed] = pick; ++placed;
     if (prev_pick < 0) head = nxt[pick]; else nxt[prev_pick] = nxt[pick];
   }
-  chunk_pt0.push_back(P);
   finish_diag();
-  ctick("greedy loop (incl. diag)");
-  if (ctiming) fprintf(stderr, "[compose] of which diagonal matching %.2f ms\n", c_diag);
+  };      // compose_range
+  static const int seg_env = getenv("CMS_BA_COMPOSE_SEGMENTS") ? atoi(getenv("CMS_BA_COMPOSE_SEGMENTS")) : 0;      // A/B: fixed number of segments
+  const int nseg = std::max(1, seg_env > 0 ? std::min(seg_env, std::max(1, P / 64)) : std::min(8, P / 2048));
+  std::vector<std::vector<int>> seg_chunks(nseg);
+  {
+    std::vector<std::thread> workers;
+    for (int t = 1; t < nseg; ++t)
+      workers.emplace_back([&, t]() { compose_range((int)((long long)P * t / nseg), (int)((long long)P * (t + 1) / nseg), seg_chunks[t]); });
+    compose_range(0, (int)((long long)P / nseg), seg_chunks[0]);
+    for (std::thread& w : workers) w.join();
+  }
+  chunk_pt0.clear();
+  for (int t = 0; t < nseg; ++t) chunk_pt0.insert(chunk_pt0.end(), seg_chunks[t].begin(), seg_chunks[t].end());
+  chunk_pt0.push_back(P);
+  ctick("composition");
 }
 // developer / test entry: the composition alone (no device needed).  pinv: P, chunk_pt0: up to P + 1 entries (n_chunks + 1 are written),
 // rank: E (in the order of the caller's points, edges of a point by ascending key frame)
