@@ -1058,3 +1058,49 @@ def test_describe_in_spatial_order_is_bit_identical():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k", "extract and not spatial"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_ba_optimize_many_ragged_windows_edge_major_path():
+    """Windows whose points have very different numbers of observations (1 .. 12: up to six pairing steps per chunk, points straddling
+    the 16-lane groups the chunk composition balances, chunks closed by a point that does not fit), two fixed key frames, key frames
+    nobody observes -- through the grouped driver's default (edge-major, fused) path, every window against its own oracle run."""
+    rng = np.random.default_rng(11)
+    probs = []
+    for i, (K, P, opp) in enumerate(((16, 2500, 12), (21, 4000, 7), (9, 1200, 9))):
+        p = synth.ba_problem(K=K, P=P, obs_per_point=opp, F=550, seed=70 + i)
+        # thin the observations out at random so that the per-point counts spread over 1 .. opp
+        keep = rng.uniform(size=len(p["e_pose"])) < 0.7
+        for key in ("e_pose", "e_point", "e_invsig2", "e_face"):
+            p[key] = np.ascontiguousarray(p[key][keep])
+        p["e_obs"] = np.ascontiguousarray(p["e_obs"][keep])
+        p["fixed"][1] = 1                                    # a second fixed key frame
+        probs.append(p)
+    counts = np.bincount(probs[0]["e_point"], minlength=probs[0]["points"].shape[0])
+    assert counts.min() <= 1 and counts.max() >= 10
+    bas = [api.BundleAdjuster(p) for p in probs]
+    rc, stats = api.ba_optimize_many(bas)
+    assert rc == 0
+    for i, (ba, p, st) in enumerate(zip(bas, probs, stats)):
+        poses, pts, flags = ba.read()
+        w = orc.ba_run(p)
+        assert list(st.iterations_done) == list(w["stats"].iterations_done), (i, list(st.iterations_done), list(w["stats"].iterations_done))
+        assert np.array_equal(flags, w["outliers"]), (i, int((flags != w["outliers"]).sum()))
+        _ba_updates_close(p, poses, pts, w, tag="ragged window %d" % i)
+        ba.close()
+
+
+def test_ba_optimize_many_call_mixing_window_kinds_is_split_into_groups():
+    """One cms_ba_optimize_many call over windows that have the edge-major work list (up to 25 free key frames) and windows that do not
+    (29 and 39 free key frames): the call runs them as separate groups and reports the statistics in the caller's order."""
+    probs = [synth.ba_problem(K=20, P=2000, obs_per_point=4, F=550, seed=81), synth.ba_problem(K=30, P=1500, obs_per_point=5, F=550, seed=82),
+             synth.ba_problem(K=12, P=900, obs_per_point=3, F=650, seed=83), synth.ba_problem(K=40, P=1800, obs_per_point=6, F=550, seed=84)]
+    bas = [api.BundleAdjuster(p) for p in probs]
+    rc, stats = api.ba_optimize_many(bas)
+    assert rc == 0
+    for i, (ba, p, st) in enumerate(zip(bas, probs, stats)):
+        poses, pts, flags = ba.read()
+        w = orc.ba_run(p)
+        assert list(st.iterations_done) == list(w["stats"].iterations_done), i
+        assert st.n_outliers_final == w["stats"].n_outliers_final and np.array_equal(flags, w["outliers"]), i
+        _ba_updates_close(p, poses, pts, w, tag="window %d" % i)
+        ba.close()
