@@ -287,7 +287,9 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=8) as tp:
         probs = list(tp.map(lambda w: synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + 1000 * rank + w), range(n_ba)))
+    t_setup = time.perf_counter()
     bas = [api.BundleAdjuster(p, device=local_rank) for p in probs]
+    ba_setup_ms = 1e3 * (time.perf_counter() - t_setup) / max(len(bas), 1)      # cms_ba_create per window (the first ones also create their streams)
     # tracking's pose-only optimisation (Optimizer::PoseOptimization, once per frame here; the reference calls it 1-3 times):
     # one problem per frame, ~600 matched map points with 10 % mismatches, resident on the device, one launch per step
     pose_probs = [synth.pose_problem(N=args.pose_edges, F=F, seed=1000 * rank + b, outlier_frac=0.1) for b in range(B)]
@@ -642,7 +644,10 @@ def main():
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
                        "extractor_vs_survey_bytes": extractor,
-                       "ba_windows_per_step": n_ba, "ba_groups": n_grp, "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
+                       "ba_windows_per_step": n_ba, "ba_groups": n_grp,
+                       "ba_window_setup": {"in_timed_region": False, "ms_per_window": round(ba_setup_ms, 2),
+                                           "note": "the windows' graphs (cms_ba_create: host work lists + uploads) are built once before the timed steps and reset between them; "
+                                                   "one LocalBundleAdjustment call incl. set-up, read-back and destroy: tools/prof_ba_latency.py (DESIGN.md section 3)"}, "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
                        "ba_check": ba_check, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
         }
