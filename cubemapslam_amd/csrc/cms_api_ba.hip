@@ -152,10 +152,13 @@ static void ba_pin_give(int device, void* p, size_t bytes) {
 }
 
 template <class T> static int ba_alloc(cms_ba* b, T** p, size_t n) {
-  // carve from the window's current slab (256-byte granules); a new slab is at least twice the previous one
+  // carve from the window's current slab (256-byte granules); the first slab is sized for the window (~170 B per edge, ~400 B per point, the
+  // edge-major kernel's partial sums), further ones are 4 MB or what the request needs
   const size_t need = (((n > 0 ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
   if (b->slabs.empty() || b->slab_off + need > b->slabs.back().bytes) {
-    size_t want = std::max(need, b->slabs.empty() ? (size_t)1 << 20 : 2 * b->slabs.back().bytes);
+    const size_t kk = (size_t)std::min(b->K, 26);       // (the edge-major partial sums exist for up to 25 free key frames)
+    const size_t first = (size_t)b->E * 176 + (size_t)b->P * 416 + kk * kk * 22000 + ((size_t)1 << 20);
+    size_t want = std::max(need, b->slabs.empty() ? first : (size_t)4 << 20);
     void* sp = nullptr; size_t got = 0;
     hipError_t e = ba_dev_take(b->device, want, &sp, &got);
     if (e != hipSuccess) return cms_fail(CMS_ERR_HIP, "hipMalloc (BA)", e);
