@@ -22,6 +22,16 @@ static int cms_area_reserve(cms_ctx* c) {
   return CMS_OK;
 }
 
+// hit buffer of the query kernel's first pass (CMS_AREA_TMP entries per query)
+static int cms_area_tmp_reserve(cms_ctx* c, int nq) {
+  if ((size_t)nq <= c->area_tmp_cap) return CMS_OK;
+  if (c->d_area_tmp) hipFree(c->d_area_tmp);
+  c->d_area_tmp = nullptr; c->area_tmp_cap = 0;
+  const size_t cap = (size_t)nq + (size_t)nq / 4 + 1024;
+  HIPCHK(hipMalloc((void**)&c->d_area_tmp, cap * CMS_AREA_TMP * sizeof(int)));
+  c->area_tmp_cap = cap;
+  return CMS_OK;
+}
 static int cms_area_bsum_reserve(cms_ctx* c, int nblk) {
   if (nblk <= c->area_bsum_cap) return CMS_OK;
   if (c->d_area_bsum) hipFree(c->d_area_bsum);
@@ -72,6 +82,9 @@ extern "C" int cms_features_in_area_device(cms_ctx* c, int b, int nq, const void
     const int nblk = (nq + 1023) / 1024, qgrid = (nq * CMS_AREA_QL + 255) / 256;
     int rcb = cms_area_bsum_reserve(c, nblk);
     if (rcb) return rcb;
+    rcb = cms_area_tmp_reserve(c, nq);
+    if (rcb) return rcb;
+    a.tmp = c->d_area_tmp;
     hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 0);
     hipLaunchKernelGGL(k_area_blocksum, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, c->d_area_bsum);
     hipLaunchKernelGGL(k_area_scan, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, (const int*)c->d_area_bsum, (int*)d_cand_off, (int*)d_total);
@@ -99,6 +112,9 @@ extern "C" int cms_features_in_area_batch_device(cms_ctx* c, int nq, const void*
     const int nblk = (nq + 1023) / 1024, qgrid = (nq * CMS_AREA_QL + 255) / 256;
     int rcb = cms_area_bsum_reserve(c, nblk);
     if (rcb) return rcb;
+    rcb = cms_area_tmp_reserve(c, nq);
+    if (rcb) return rcb;
+    a.tmp = c->d_area_tmp;
     hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 0);
     hipLaunchKernelGGL(k_area_blocksum, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, c->d_area_bsum);
     hipLaunchKernelGGL(k_area_scan, dim3(nblk), dim3(1024), 0, s, (const int*)d_cnt_scratch, nq, (const int*)c->d_area_bsum, (int*)d_cand_off, (int*)d_total);

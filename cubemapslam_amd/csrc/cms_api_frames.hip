@@ -56,6 +56,7 @@ struct cms_ctx {
   // frame grid (Frame::AssignFeaturesToGrid), allocated on first use
   uint16_t* d_area_sorted = nullptr; int* d_area_cell_start = nullptr; int* d_area_nvalid = nullptr; int area_frames = 0;
   int* d_area_bsum = nullptr; int area_bsum_cap = 0;
+  int* d_area_tmp = nullptr; size_t area_tmp_cap = 0;      // first-pass hit buffer of k_area_query (queries)
   uint8_t* h_fish_stage = nullptr; int fish_stage_frames = 0;   // pinned staging for cms_frames_upload
   // input streaming (cms_frames_upload_async): the next batch travels on its own stream while the current one is being processed
   hipStream_t copy_stream = nullptr; hipEvent_t ev_upload_done = nullptr, ev_remap_done = nullptr;
@@ -159,7 +160,7 @@ static void cms_ctx_free(cms_ctx* c) {
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_fish, c->d_lut, c->d_pyr, c->d_mask, c->d_tab, c->d_pattern, c->d_cand, c->d_node, c->d_cand_cnt,
                   c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_order, c->d_aux_sorted, c->d_desc, c->d_kp_cnt, c->d_match, c->d_cell_cand,
-                  c->d_cell_cnt, c->d_cells_all, c->d_cells_nz, c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid, c->d_area_bsum};
+                  c->d_cell_cnt, c->d_cells_all, c->d_cells_nz, c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid, c->d_area_bsum, c->d_area_tmp};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_fish_stage) (void)hipHostFree(c->h_fish_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);

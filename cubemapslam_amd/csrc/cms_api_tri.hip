@@ -564,6 +564,7 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
     hipLaunchKernelGGL(k_fuse_project, dim3((nmp + 255) / 256), dim3(256), 0, s, fa);
     // window query against the grids of the store's slots
     CmsAreaArgs a;
+    a.tmp = nullptr;
     a.kp = (const CmsKeyPoint*)st->d_kp; a.sorted_idx = st->d_sorted; a.cell_start = st->d_cell_start;
     a.qx = fa.qx; a.qy = fa.qy; a.qr = fa.qr; a.qmin = fa.qmin; a.qmax = fa.qmax;
     a.q_frame = (const int*)(p + o_slot); a.kp_cap = st->maxf;

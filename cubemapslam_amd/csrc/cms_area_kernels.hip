@@ -79,7 +79,10 @@ struct CmsAreaArgs {
   int* cnt;                     // pass 0: candidates per query
   const int* off;               // pass 1: CSR offsets
   int* idx; int cap; int idx_base;
+  int* tmp;                     // optional: nq x CMS_AREA_TMP -- pass 0 leaves the first hits of every query here (final values, in order) and pass 1
+                                // only copies them for the queries that have no more than that (nearly all: ~2 candidates per window on average)
 };
+#define CMS_AREA_TMP 8
 
 // Eight lanes per query (eight queries per wavefront): the lanes of a group take the cell columns ix of a rectangle in turn, so the
 // dependent loads of a query (cell offsets -> index list -> key point) run eight wide; a group-wide prefix sum of the per-column
@@ -94,9 +97,18 @@ extern "C" __global__ void __launch_bounds__(256) k_area_query(CmsAreaArgs a, in
   const int minLevel = a.qmin[qq], maxLevel = a.qmax[qq];
   const bool check = (minLevel > 0) || (maxLevel >= 0);
   CmsAreaRectI rc[3];
-  const int nr = live ? cms_area_rects(x, y, r, a.F, a.inv, rc) : 0;
-  int n = 0;                                               // hits of the whole query so far (same in all lanes of the group)
   const int base = (pass && live) ? a.off[qq] : 0;
+  bool copied = false;
+  if (pass && a.tmp && live) {                             // the search of pass 0 kept this query's hits: copy, no second search
+    const int c = a.cnt[qq];
+    if (c <= CMS_AREA_TMP) {
+      if (gl < c && base + gl < a.cap) a.idx[base + gl] = a.tmp[(size_t)qq * CMS_AREA_TMP + gl];
+      copied = true;
+    }
+  }
+  const int nr = (live && !copied) ? cms_area_rects(x, y, r, a.F, a.inv, rc) : 0;
+  int n = 0;                                               // hits of the whole query so far (same in all lanes of the group)
+  int* tmpq = (!pass && a.tmp) ? a.tmp + (size_t)qq * CMS_AREA_TMP : nullptr;
   const int fr = a.q_frame ? a.q_frame[qq] : 0;
   const CmsKeyPoint* kp = a.kp + (size_t)fr * a.kp_cap;
   const uint16_t* sorted_idx = a.sorted_idx + (size_t)fr * a.kp_cap;
@@ -140,6 +152,24 @@ extern "C" __global__ void __launch_bounds__(256) k_area_query(CmsAreaArgs a, in
 #pragma unroll
       for (int o = 1; o < CMS_AREA_QL; o <<= 1) { const int t = __shfl_up(incl, o, CMS_AREA_QL); if (gl >= o) incl += t; }
       const int tot = __shfl(incl, CMS_AREA_QL - 1, CMS_AREA_QL);
+      if (tmpq && nh > 0) {                                 // pass 0: the first CMS_AREA_TMP hits of the query, already in output order
+        int w = n + incl - nh;
+        if (w < CMS_AREA_TMP) {
+          if (nh <= 4) {
+            tmpq[w] = idx_base + h0;
+            if (nh > 1 && w + 1 < CMS_AREA_TMP) tmpq[w + 1] = idx_base + h1;
+            if (nh > 2 && w + 2 < CMS_AREA_TMP) tmpq[w + 2] = idx_base + h2;
+            if (nh > 3 && w + 3 < CMS_AREA_TMP) tmpq[w + 3] = idx_base + h3;
+          } else {
+            for (int s = s0; s < s1 && w < CMS_AREA_TMP; ++s) {
+              const int j = sorted_idx[s];
+              const CmsKeyPoint p = kp[j];
+              if (check && (p.octave < minLevel || (maxLevel >= 0 && p.octave > maxLevel))) continue;
+              if (fabsf(p.x - x) < r && fabsf(p.y - y) < r) { tmpq[w] = idx_base + j; ++w; }
+            }
+          }
+        }
+      }
       if (pass && nh > 0) {
         int w = base + n + incl - nh;
         if (nh <= 4) {
