@@ -595,6 +595,17 @@ def main():
                "two_threads_like_the_reference": round(1.0 / max(t_ext / n + t_match + t_local + t_pose, (t_ba + t_tri) / args.ba_every), 3),
                "host_cores_available": os.cpu_count()}
 
+    # ---- one LocalBundleAdjustment call as the reference issues it (cms_ba_run: graph set-up + optimisation + read-back + destroy), chip quiet
+    ba_call = None
+    if rank == 0 and world == 1 and n_ba > 0:
+        ts = []
+        for _ in range(4):
+            t1 = time.perf_counter()
+            api.ba_run(probs[0], device=local_rank)
+            ts.append(1e3 * (time.perf_counter() - t1))
+        ba_call = {"ms": round(float(np.median(ts[1:])), 2), "edges": int(len(probs[0]["e_pose"])),
+                   "note": "cms_ba_run on window 0's problem: set-up (host work list, uploads) + both optimisation stages + read-back + destroy; median of 3"}
+
     # ---- single stream, closed loop (configs[2] the way the reference runs it: one frame after the other, matches feed the pose feed the
     # next projection; cubemapslam_amd/harness.py, parity in tests/test_gpu_harness.py) next to the batch figure above
     closed = None
@@ -648,7 +659,7 @@ def main():
                        "ba_window_setup": {"in_timed_region": False, "ms_per_window": round(ba_setup_ms, 2),
                                            "note": "the windows' graphs (cms_ba_create: host work lists + uploads) are built once before the timed steps and reset between them; "
                                                    "one LocalBundleAdjustment call incl. set-up, read-back and destroy: tools/prof_ba_latency.py (DESIGN.md section 3)"}, "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
-                       "ba_check": ba_check, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
+                       "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
