@@ -14,22 +14,25 @@
 //   * the point's k(k-1)/2 off-diagonal tuples are spread over its k lanes: in step d = 1 .. k/2 lane a does the tuple
 //     (a, a + d mod k) -- the partner's W is a 144-byte LDS read from the neighbouring row, no barrier (LDS operations of one
 //     wavefront execute in order);
-//   * lanes of one LDS instruction that hit the SAME address are serialised (tools/probe/lds_atomics.hip: 7.6 f64 additions per
-//     clock and CU on consecutive addresses, 2.7 on scattered ones, 0.33 on one address); the diagonal tuples (a, a) -- 64 lanes on
-//     ~19 diagonal blocks cannot avoid each other -- therefore go to one of four copies of the diagonal blocks, chosen by the edge's
-//     rank among the edges of its key frame in the chunk.  The kernel's time follows its count of scattered additions (81 wave
-//     instructions per chunk, ~0.65 us each at eight windows per launch);
+//   * the LDS takes the 64 lanes of a ds_add_f64 in four groups of 16 consecutive lanes: two clocks per group when its addresses fall on
+//     16 different f64 banks (address mod 16 doubles), two more for every further lane on the fullest bank, much more for lanes on the
+//     SAME address (tools/probe/lds_atomics.hip: 7.8 additions per clock and CU on consecutive addresses, 2.7 for random pose pairs,
+//     0.33 on one address).  Three things follow.  The diagonal tuples (a, a) -- 64 lanes on ~19 diagonal blocks cannot avoid each other --
+//     go to one of four copies of the diagonal blocks.  A 6x6 block is laid out so that element (r, q) and its transpose are 16 doubles
+//     apart (ba_se_off): a wrapped partner, which holds the transposed block, hits the same banks as an unwrapped one.  And the host
+//     composes the chunks (cms_api_ba.hip, ba_compose_chunks): which points share a chunk, in which order, and which diagonal copy an
+//     edge adds to, so that the lanes of a group repeat banks as little as possible;
 //   * (a pose-major kernel for the diagonal tuples -- deterministic, butterfly reduction like ba_lin_poses_body -- was measured too:
 //     35 us for eight windows, bound by the three gathered cache lines per edge; dropped)
-//   * every product element is added to the workgroup's copy of the reduced system in LDS (one 6x6 block + 6 right-hand-side values per
-//     pose pair, dense upper-triangular pair enumeration) with ds_add_f64; when the loop is done the copy is written to this range's
-//     slice of `partial`, and kb_ba_schur_reduce adds the ranges in fixed order as before.
+//   * every product element is added to the workgroup's copy of the reduced system in LDS (36 doubles per off-diagonal pose pair; per copy
+//     and key frame 21 + 6 + 6 for the diagonal block, its right-hand side and bp) with ds_add_f64; when the loop is done the copy is
+//     written to this range's slice of `partial`, and kb_ba_schur_edges_reduce adds the ranges in fixed order.
 //
-// Measured and dropped (profiles/r02_pmc_instruction_mix.json: 745 LDS instructions per wave, SQ_WAIT_INST_LDS 28 % of the wave cycles): the
-// partner's W through whole-wavefront DPP shifts (v_mov_b32_dpp wave_shl:1, tools/probe/dpp_wave_shift.hip) instead of LDS rows -- no
-// LDS reads to drain the in-order LDS counter, half the LDS, two workgroups per CU -- was no faster (60-67 us against 57): without the
-// cyclic pairing it needs k - 1 instead of k / 2 atomic steps per chunk, and the kernel's time IS its count of scattered ds_add_f64
-// instructions (81 per chunk x ~36 clocks x 41 chunks per CU = the 57 us measured), whatever the occupancy.
+// Where the time goes (profiles/r02_pmc_instruction_mix.json, eight 80k-edge windows, fused variant): 65 us with all windows active; LDS pipe
+// 45 % busy (80 % before the composition, a third of it bank conflicts), vector-ALU issue 22 us; 148 KB of LDS per workgroup leave two
+// wavefronts per SIMD, so what is left is latency.  Measured and dropped: the exchanges between lanes through wavefront shuffles / DPP
+// shifts instead of LDS rows (two workgroups per CU, but ~150 ds_bpermute per chunk and spills at three wavefronts per SIMD: 75 us);
+// ten wavefronts with two diagonal copies (59 us).
 //
 // The LDS additions of different wavefronts interleave in an order that is not fixed: sums may differ in the last bits from run to
 // run (the BA parity bar is 1e-4 relative on updates; the oracle's own summation order is different anyway).  CMS_BA_DETERMINISTIC=1
@@ -89,8 +92,8 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, do
   extern __shared__ __align__(16) double se_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
-  double* S = se_lds;                                              // NPO x 43: off-diagonal pairs s1 < s2
-  double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);               // 4 x np x 28: copies of the diagonal blocks (upper triangle | rhs)
+  double* S = se_lds;                                              // NPO x 37: off-diagonal pairs s1 < s2
+  double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);               // 4 x np x 33: copies of the diagonal blocks (upper triangle | rhs | bp)
   double* rows = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // nw x 64 x 18 (16-byte aligned)
   double* prt = rows + (size_t)nw * 64 * 18;                       // K x 12: rotation (row major) | translation of every key frame
   int* rslot = reinterpret_cast<int*>(prt + (size_t)d.K * 12);     // nw x 64: free-pose slot of the edge in a row, -1 = contributes nothing
