@@ -50,7 +50,8 @@ struct cms_ba {
   void* grp_lm_dev = nullptr; void* grp_lm_host = nullptr;   // BaLmDev per window (device-side Levenberg state) and its pinned mirror
   int grp_cap = 0;
   // optional HIP-event bracket around ONE kernel of the grouped driver's rounds (bench.py's roofline of the dominant BA kernel):
-  // kernel ids 1 lin, 2 maxdiag, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points, 7 reduce2
+  // kernel ids 1 lin, 2 maxdiag, 3 the Schur kernel of the path in use (kb_ba_lin_schur_edges by default), 4 its range reduction, 5 the trial solve,
+  // 6 the trial kernel (kb_ba_trial_edges), 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   std::vector<BaBlock> slabs; size_t slab_off = 0;      // device memory of the window: carved from pooled slabs (ba_alloc)
