@@ -88,3 +88,20 @@ def test_composition_edge_cases():
     prob["fixed"] = np.array([1] * (K - 1) + [0], np.uint8)          # one free key frame: no pairs at all
     pinv, pt0, rank = api.ba_compose_chunks(prob["fixed"], P, prob["e_pose"], prob["e_point"], lookahead=48)
     check_valid(prob, pinv, pt0, rank)
+
+
+def test_composition_in_segments_is_valid_and_repeatable():
+    """Windows of more than 4096 points are composed in segments by several host threads; the segments are fixed by the number of points, so
+    the result is the same on every run (and machine), a valid work list, and still better than the caller's order."""
+    prob = synth.ba_problem(K=20, P=9000, obs_per_point=4, F=550, seed=8)
+    P = prob["points"].shape[0]
+    a = api.ba_compose_chunks(prob["fixed"], P, prob["e_pose"], prob["e_point"], lookahead=24)
+    check_valid(prob, *a)
+    for _ in range(3):
+        b = api.ba_compose_chunks(prob["fixed"], P, prob["e_pose"], prob["e_point"], lookahead=24)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    ident = api.ba_compose_chunks(prob["fixed"], P, prob["e_pose"], prob["e_point"], lookahead=1)
+    assert np.array_equal(ident[0], np.arange(P))
+    o1, d1 = slot_cost(prob, *a)
+    o0, d0 = slot_cost(prob, *ident)
+    assert o1 <= 0.8 * o0, (o1, o0)
