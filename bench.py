@@ -63,8 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=8, help="front: camera streams in total (stream s -> GPU s mod G)")
     ap.add_argument("--frames-per-stream", type=int, default=16, help="front: consecutive frames of every stream per step")
     ap.add_argument("--ba-every", type=int, default=8, help="one local-BA window per this many frames")
-    ap.add_argument("--ba-groups", type=int, default=3, help="host threads / streams the local-BA windows of a step are split over (3 groups of ~11 windows: "
-                    "within 2 %% of the best step time (4 groups) and the extraction kernels keep 40 %% of their byte roofline next to the BA chain; 4 groups: 35 %%)")
+    ap.add_argument("--ba-groups", type=int, default=2, help="host threads / streams the local-BA windows of a step are split over (2 groups of 16 windows: "
+                    "11.5 ms per step against 11.8 with 3 groups and 12.3 with 4, interleaved runs; the extraction kernels keep 41 %% of their byte roofline either way)")
     ap.add_argument("--pose-edges", type=int, default=600, help="matched map points per frame for the pose-only optimisation")
     ap.add_argument("--save-trajectory", default="", help="rank 0 writes the gathered trajectory of the last step here (TUM format)")
     ap.add_argument("--force-gather", action="store_true", help="run the trajectory gather code path even with one rank (self-test)")
