@@ -3,18 +3,22 @@
 #include <mutex>
 #include <vector>
 
+// the rank sort of k_area_grid keeps 8 bytes per key point in LDS: above the 64 KB default for the 3 x nFeatures extractor of the
+// initialisation.  The attribute is per function AND per device; every launcher of the kernel (frame grids, key-frame store) calls this.
+static int cms_area_grid_attr(int device) {
+  static std::mutex mu;
+  static bool done[64] = {false};
+  std::lock_guard<std::mutex> lk(mu);
+  if (device >= 0 && device < 64 && !done[device]) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_area_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (CMS_AREA_MAXKP + 1) * 8));
+    done[device] = true;
+  }
+  return CMS_OK;
+}
 static int cms_area_reserve(cms_ctx* c) {
   if (c->d_area_sorted) return CMS_OK;
   if (c->g.kp_cap > CMS_AREA_MAXKP) return cms_fail(CMS_ERR_UNSUPPORTED, "frame grid: more than 16383 key points per frame");
-  {   // the rank sort keeps 8 bytes per key point in LDS: above the 64 KB default for the 3 x nFeatures extractor of the initialisation
-    static std::mutex mu;
-    static bool done[64] = {false};
-    std::lock_guard<std::mutex> lk(mu);
-    if (c->device >= 0 && c->device < 64 && !done[c->device]) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_area_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (CMS_AREA_MAXKP + 1) * 8));
-      done[c->device] = true;
-    }
-  }
+  { const int rca = cms_area_grid_attr(c->device); if (rca) return rca; }
   const size_t B = (size_t)c->max_batch;
   HIPCHK(hipMalloc((void**)&c->d_area_sorted, B * c->g.kp_cap * sizeof(uint16_t)));
   HIPCHK(hipMalloc((void**)&c->d_area_cell_start, B * (CMS_AREA_CELLS + 1) * sizeof(int)));

@@ -11,6 +11,39 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <unordered_map>
+
+// Every A/B switch of the local-BA host code, read ONCE (first use) so that the choices made when a window is built (which work lists exist)
+// and the choices made when it is optimised (which kernels run) can never disagree.  Tests that flip a switch use a child process.
+struct BaKnobs {
+  bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
+  bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce;
+  int lookahead, compose_segments, dup, run_min_chunks;
+  char stream_priority;
+};
+static const BaKnobs& ba_knobs() {
+  static const BaKnobs k = [] {
+    BaKnobs q;
+    auto on = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+    q.deterministic = on("CMS_BA_DETERMINISTIC"); q.host_lm = on("CMS_BA_HOST_LM"); q.single_host_lm = on("CMS_BA_SINGLE_HOST_LM");
+    q.schur_chunks = on("CMS_BA_SCHUR_CHUNKS"); q.schur_points = on("CMS_BA_SCHUR_POINTS"); q.all_lists = on("CMS_BA_ALL_LISTS");
+    // the pair-owner / tuple-chunk kernels' work lists and the stored 6x3 blocks: only built when a switch selects those kernels
+    q.want_all_lists = q.deterministic || q.host_lm || q.single_host_lm || q.schur_chunks || q.schur_points || q.all_lists;
+    q.no_fused = on("CMS_BA_NO_FUSED_LIN"); q.solve1 = on("CMS_BA_SOLVE1"); q.trial_points = on("CMS_BA_TRIAL_POINTS");
+    q.fixed_ranges = on("CMS_BA_FIXED_RANGES"); q.no_permute = on("CMS_BA_NO_PERMUTE");
+    q.create_timing = on("CMS_BA_CREATE_TIMING"); q.compose_timing = on("CMS_BA_COMPOSE_TIMING");
+    q.runs = !on("CMS_BA_NO_RUNS");                      // signature runs (cms_ba_schur_runs.hip); off = every point through the edge-major kernel
+    q.runs_as_edges = on("CMS_BA_RUNS_AS_EDGES");        // keep the run order of the points but let the edge-major body take the run chunks too
+    q.separate_reduce = on("CMS_BA_SEPARATE_REDUCE");    // kb_ba_schur_edges_reduce as its own launch instead of inside the solve kernel
+    q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
+    q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", 2));
+    const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
+    q.stream_priority = pr ? pr[0] : 0;
+    return q;
+  }();
+  return k;
+}
 
 struct BaBlock { void* p; size_t bytes; };      // a device slab / pinned block of the per-device pool (below)
 struct cms_ba {
@@ -42,7 +75,10 @@ struct cms_ba {
   // edge-major Schur work list (se.R == 0: not available: too many free key frames for the LDS copy of the reduced system)
   BaSe se = {};
   int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_bp_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
+  int* d_se_lone = nullptr; int4* d_rm_chunk = nullptr; uint2* d_run_lane = nullptr;
   size_t se_lds_fixed = 0; int se_waves = 0;      // LDS of the edge-major kernel without the per-wavefront part; wavefronts per workgroup that fit
+  size_t rm_lds = 0; int n_runs = 0, rm_points = 0;   // run-major part (cms_ba_schur_runs.hip): LDS it needs (0: the window has no runs), runs, points inside runs
+  char* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned block the window's uploads went through; cms_ba_read's read-back reuses it
   int cur = 0;
   double* h_pin = nullptr; size_t h_pin_bytes = 0;     // pinned host mirror of d_scal (one small D2H per Levenberg trial)
   // group resources (owned by the first window of a cms_ba_optimize_many call, grown on demand)
@@ -54,6 +90,7 @@ struct cms_ba {
   // 6 the trial kernel (kb_ba_trial_edges), 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
+  BaSe grp_se = {};          // the window's share of the current group's Schur launch (ba_upload_items)
   std::vector<BaBlock> slabs; size_t slab_off = 0;      // device memory of the window: carved from pooled slabs (ba_alloc)
   size_t grp_pin_bytes[3] = {0, 0, 0};                  // sizes of grp_items_host, grp_scal_host, grp_lm_host (pooled pinned blocks)
 };
@@ -147,7 +184,7 @@ static void ba_pin_give(int device, void* p, size_t bytes) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (pl.pin[device].size() < 64) { pl.pin[device].push_back({p, bytes}); return; }
+    if (pl.pin[device].size() < 512) { pl.pin[device].push_back({p, bytes}); return; }
   }
   hipHostFree(p);
 }
@@ -177,6 +214,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->stream) hipStreamSynchronize(b->stream);      // nothing of this window may still be running when its memory goes back to the pool
   for (const BaBlock& sl : b->slabs) ba_dev_give(b->device, sl.p, sl.bytes);
   if (b->h_pin) ba_pin_give(b->device, b->h_pin, b->h_pin_bytes);
+  if (b->h_stage) ba_pin_give(b->device, b->h_stage, b->h_stage_bytes);
   if (b->grp_items_host) ba_pin_give(b->device, b->grp_items_host, b->grp_pin_bytes[0]);
   if (b->grp_scal_host) ba_pin_give(b->device, b->grp_scal_host, b->grp_pin_bytes[1]);
   if (b->grp_lm_host) ba_pin_give(b->device, b->grp_lm_host, b->grp_pin_bytes[2]);
@@ -247,7 +285,7 @@ struct BaDiagMatch {
 static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int lookahead,
                               std::vector<int>& prank, std::vector<int>& pinv, std::vector<int>& chunk_pt0, std::vector<int>& cp_off,
                               std::vector<int>& cp_pose, std::vector<uint8_t>& cp_rank) {
-  static const bool ctiming = getenv("CMS_BA_COMPOSE_TIMING") != nullptr;
+  const bool ctiming = ba_knobs().compose_timing;
   auto c_last = std::chrono::steady_clock::now();
   auto ctick = [&](const char* what) {
     const auto now = std::chrono::steady_clock::now();
@@ -407,8 +445,8 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
   }
   finish_diag();
   };      // compose_range
-  static const int seg_env = getenv("CMS_BA_COMPOSE_SEGMENTS") ? atoi(getenv("CMS_BA_COMPOSE_SEGMENTS")) : 0;      // A/B: fixed number of segments
-  const int nseg = std::max(1, seg_env > 0 ? std::min(seg_env, std::max(1, P / 64)) : std::min(8, P / 2048));
+  const int seg_env = ba_knobs().compose_segments;      // A/B: fixed number of segments
+  const int nseg = std::max(1, seg_env > 0 ? std::min(seg_env, std::max(1, P / 64)) : std::min(8, P / 512));
   std::vector<std::vector<int>> seg_chunks(nseg);
   {
     std::vector<std::thread> workers;
@@ -440,6 +478,313 @@ extern "C" int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, c
   return CMS_OK;
 }
 
+// Workgroups of one window for the Schur launch: `Rtotal` ranges are split between the run-major body (chunks [0, n_rm)) and the edge-major
+// body (the left-over chunks) by their work -- a run chunk costs about half an edge-major one.
+static void ba_se_split(BaSe& se, int Rtotal) {
+  const int n_se = se.nchunks - se.n_rm;
+  Rtotal = std::max(2, std::min(Rtotal, BA_SE_RANGES));
+  int R_rm = 0, R_se = 0;
+  if (se.n_rm > 0 && n_se > 0) {
+    const double w_rm = 0.5 * se.n_rm, w_se = (double)n_se;
+    R_rm = (int)std::lround(Rtotal * w_rm / (w_rm + w_se));
+    R_rm = std::max(1, std::min(R_rm, Rtotal - 1));
+    R_se = Rtotal - R_rm;
+  } else if (se.n_rm > 0) R_rm = Rtotal;
+  else R_se = Rtotal;
+  if (se.n_rm > 0) R_rm = std::min(R_rm, (se.n_rm + BA_RM_PAIRS - 1) / BA_RM_PAIRS);      // a producer / consumer pair wants at least one chunk
+  se.cpw = n_se > 0 ? std::max(1, (n_se + R_se - 1) / R_se) : 1;
+  se.R = n_se > 0 ? (n_se + se.cpw - 1) / se.cpw : 0;
+  se.R_rm = R_rm;
+}
+
+// ---- everything cms_ba_create decides on the host (no device needed: cms_ba_debug_plan runs it alone) -- the internal point order (signature
+// runs first, then the composed left-over chunks), the sorted edge arrays and the work lists of the edge-major / run-major Schur kernels
+struct BaPlan {
+  std::vector<int> pose_slot, prank, s_pose, s_point, pt_off, pose_off, pose_edges, ce0, pob, ident, lone;
+  std::vector<double> s_obs, s_inv;
+  std::vector<int8_t> s_face;
+  std::vector<uint32_t> info;
+  std::vector<int4> rm_chunk;
+  std::vector<uint2> run_lane;
+  bool se_built = false;
+};
+template <class Tick>
+static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, const double* e_obs,
+                    const double* e_invsig2, const int8_t* e_face, Tick&& tick) {
+  std::vector<int>&pose_slot = pl.pose_slot, &prank = pl.prank, &s_pose = pl.s_pose, &s_point = pl.s_point, &pt_off = pl.pt_off, &pose_off = pl.pose_off,
+                  &pose_edges = pl.pose_edges, &ce0 = pl.ce0, &pob = pl.pob, &ident = pl.ident, &lone = pl.lone;
+  std::vector<double>&s_obs = pl.s_obs, &s_inv = pl.s_inv;
+  std::vector<int8_t>& s_face = pl.s_face;
+  std::vector<uint32_t>& info = pl.info;
+  std::vector<int4>& rm_chunk = pl.rm_chunk;
+  std::vector<uint2>& run_lane = pl.run_lane;
+  bool& se_built = pl.se_built;
+  const BaKnobs& kn = ba_knobs();
+  // ---- CSR of the caller's points over their observations, a point's observations by ascending key frame (two stable counting passes)
+  std::vector<int> cpo(P + 1, 0), cpe(E);
+  {
+    std::vector<int> by_pose(E), cnt((size_t)std::max(K, P) + 1, 0);
+    for (int e = 0; e < E; ++e) ++cnt[e_pose[e] + 1];
+    for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
+    for (int e = 0; e < E; ++e) by_pose[cnt[e_pose[e]]++] = e;
+    for (int e = 0; e < E; ++e) ++cpo[e_point[e] + 1];
+    for (int p = 0; p < P; ++p) cpo[p + 1] += cpo[p];
+    std::vector<int> fill(cpo.begin(), cpo.end() - 1);
+    for (int i = 0; i < E; ++i) { const int e = by_pose[i]; cpe[fill[e_point[e]]++] = e; }
+  }
+  pose_slot.assign(K, -1);
+  int np = 0;
+  for (int k = 0; k < K; ++k) if (!fixed[k]) pose_slot[k] = np++;
+  b->np = np;
+  const int n = 6 * np;
+  b->nblk_e = (E + 255) / 256; b->nblk_p = (P + 127) / 128;
+  b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
+  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
+  b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 3 * (size_t)n + 8) * sizeof(double);
+  b->solve_blk3 = b->solve_blk && 3 * (np * (np + 1) / 2) <= 1024 && b->blk3_lds <= BA_LDS_CEILING;
+  // ---- can this window run the edge-major / run-major kernels at all?  (LDS copy of the reduced system, <= 31 observations per point, no
+  // point seen twice by one key frame: the pair-owner kernel handles those)
+  const int NP2 = np * (np + 1) / 2;
+  const size_t se_fixed_lds = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)K * 12) * sizeof(double);
+  const size_t se_wave_lds = (size_t)64 * 18 * sizeof(double) + 64 * sizeof(int);
+  int se_nw = BA_SE_THREADS / 64;
+  while (se_nw > 2 && se_fixed_lds + se_nw * se_wave_lds > BA_LDS_CEILING) se_nw -= 2;
+  bool se_ok = np >= 1 && se_fixed_lds + se_nw * se_wave_lds <= BA_LDS_CEILING && K <= 256 && np <= 62;
+  for (int p = 0; p < P && se_ok; ++p) {
+    if (cpo[p + 1] - cpo[p] > 31) se_ok = false;
+    for (int i = cpo[p] + 1; i < cpo[p + 1] && se_ok; ++i) if (e_pose[cpe[i]] == e_pose[cpe[i - 1]]) se_ok = false;
+  }
+  // ---- observation signatures -> runs (cms_ba_schur_runs.hip).  Points seen by the same set of key frames are grouped (first appearance
+  // orders the groups, the caller's order the points of a group: the result depends on the input alone); a group with at least
+  // `run_min_chunks` full chunks becomes a run, its tail (< 3/4 of a chunk) and all smaller groups are the left-over points of the
+  // edge-major kernel.  Runs need the fused path (linearisation inside the Schur kernel: three-lane solve, edge-major trial kernel) and the
+  // LDS for four producer / consumer pairs.
+  const size_t rm_lds = se_fixed_lds + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF * sizeof(double);
+  const bool rm_ok = se_ok && kn.runs && !kn.no_fused && !kn.want_all_lists && !kn.solve1 && !kn.trial_points && b->solve_blk3 && rm_lds <= BA_LDS_CEILING &&
+                     BA_SE_THREADS == 128 * BA_RM_PAIRS;
+  struct Run { int k, first, npts, chunks, m; };              // first: a member point (its key frames are the signature)
+  std::vector<Run> runs;
+  std::vector<int> rm_points;                                 // caller ids, run after run
+  std::vector<int> left;                                      // caller ids of the left-over points, caller's order
+  std::vector<int> rm_run_pt0;                                // per run: first position in rm_points
+  if (rm_ok) {
+    std::vector<int> gid(P, -1), gcount, gfirst;
+    std::unordered_map<uint64_t, std::vector<int>> table;     // signature hash -> groups with that hash
+    table.reserve((size_t)std::min(P, 1 << 16));
+    for (int p = 0; p < P; ++p) {
+      const int k = cpo[p + 1] - cpo[p];
+      uint64_t h = 1469598103934665603ull ^ (uint64_t)k;
+      for (int i = cpo[p]; i < cpo[p + 1]; ++i) { h ^= (uint64_t)(e_pose[cpe[i]] + 1); h *= 1099511628211ull; }
+      std::vector<int>& cand = table[h];
+      int g = -1;
+      for (int c : cand) {
+        const int q = gfirst[c];
+        if (cpo[q + 1] - cpo[q] != k) continue;
+        bool same = true;
+        for (int i = 0; i < k && same; ++i) same = e_pose[cpe[cpo[p] + i]] == e_pose[cpe[cpo[q] + i]];
+        if (same) { g = c; break; }
+      }
+      if (g < 0) { g = (int)gfirst.size(); gfirst.push_back(p); gcount.push_back(0); cand.push_back(g); }
+      gid[p] = g; ++gcount[g];
+    }
+    const int ng = (int)gfirst.size();
+    std::vector<int> run_of_group(ng, -1), take(ng, 0);
+    for (int g = 0; g < ng; ++g) {
+      const int q = gfirst[g], k = cpo[q + 1] - cpo[q];
+      int kf = 0;
+      for (int i = cpo[q]; i < cpo[q + 1]; ++i) kf += pose_slot[e_pose[cpe[i]]] >= 0;
+      if (k < 1 || kf < 1 || kf * (kf + 1) / 2 > 64) continue;
+      const int m = std::min(64 / k, BA_RM_PTS);
+      if (gcount[g] < kn.run_min_chunks * m) continue;
+      const int full = gcount[g] / m, tail = gcount[g] - full * m;
+      const bool keep_tail = tail > 0 && 4 * tail >= 3 * m;
+      run_of_group[g] = (int)runs.size();
+      take[g] = full * m + (keep_tail ? tail : 0);
+      runs.push_back({k, q, take[g], full + (keep_tail ? 1 : 0), m});
+    }
+    rm_run_pt0.assign(runs.size() + 1, 0);
+    for (size_t r = 0; r < runs.size(); ++r) rm_run_pt0[r + 1] = rm_run_pt0[r] + runs[r].npts;
+    rm_points.assign(rm_run_pt0.back(), 0);
+    std::vector<int> fill(rm_run_pt0.begin(), rm_run_pt0.end() - 1), seen(ng, 0);
+    for (int p = 0; p < P; ++p) {
+      const int g = gid[p], r = run_of_group[g];
+      if (r >= 0 && seen[g] < take[g]) { rm_points[fill[r]++] = p; ++seen[g]; }
+      else left.push_back(p);
+    }
+  } else {
+    left.resize(P);
+    for (int p = 0; p < P; ++p) left[p] = p;
+  }
+  const int P_rm = (int)rm_points.size(), PL = (int)left.size();
+  tick("runs");
+  // ---- internal point order: the runs' points first, then the left-over points in the chunk composition of the edge-major Schur kernel
+  // (cms_ba_schur_edges.hip).  There a wavefront takes a CHUNK of whole points with at most 64 edges; in step d the lane of a point's a-th edge
+  // adds its 6x6 product to the LDS block of the pose pair (pose_a, pose_(a+d) mod k), one element per instruction.  What such an instruction
+  // costs is decided by where its addresses fall (tools/probe/lds_atomics.hip): the LDS takes the 64 lanes of a ds_add_f64 in four groups of
+  // 16 CONSECUTIVE lanes, two clocks each when the 16 addresses fall on 16 different f64 banks (address mod 16 doubles), and two more clocks
+  // for every further lane on the fullest bank (same address: six more).  Lanes 16 or more apart never compete.  Random pairs cost ~3.1 slots
+  // per group (16 balls into 16 bins) -- the 2.7 lane-operations per clock measured against 7.8 on consecutive addresses.
+  // The host therefore composes the chunks: points are taken from a look-ahead window over the caller's order so that, within each group
+  // of 16 lanes and each step, the pairs' bank classes (pair index mod 16: the block stride is odd, and the block layout gives an element
+  // and its transpose the same bank) repeat as little as possible; the diagonal tuples pick, among the four copies of their key frame's
+  // diagonal block, the one whose bank is least used in their group.  Everything on the device is indexed by the internal point id;
+  // cms_ba_read / cms_ba_linearize translate back.  CMS_BA_NO_PERMUTE=1 keeps the caller's order (A/B).
+  std::vector<int> prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL;
+  prank.assign(P, 0);
+  std::vector<uint8_t> cp_rankL;                      // per (left-over point, edge in pose order): copy of the diagonal blocks its (a, a) tuple goes to
+  b->pinv.resize(P);
+  if (PL > 0) {
+    std::vector<int> loc(P, -1), ep, ept;
+    for (int i = 0; i < PL; ++i) loc[left[i]] = i;
+    if (PL == P) ba_compose_chunks(K, fixed, P, E, e_pose, e_point, kn.no_permute ? 1 : kn.lookahead, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
+    else {
+      ep.reserve(E); ept.reserve(E);
+      for (int e = 0; e < E; ++e) if (loc[e_point[e]] >= 0) { ep.push_back(e_pose[e]); ept.push_back(loc[e_point[e]]); }
+      ba_compose_chunks(K, fixed, PL, (int)ep.size(), ep.data(), ept.data(), kn.no_permute ? 1 : kn.lookahead, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
+    }
+  } else {
+    chunk_pt0L.assign(1, 0);
+  }
+  for (int i = 0; i < P_rm; ++i) { prank[rm_points[i]] = i; b->pinv[i] = rm_points[i]; }
+  for (int i = 0; i < PL; ++i) { prank[left[i]] = P_rm + prankL[i]; b->pinv[P_rm + prankL[i]] = left[i]; }
+  // chunks: the runs' chunks (whole points of one signature), then the composed chunks of the left-over points
+  b->se_chunk_pt0.clear();
+  std::vector<int> rm_chunk_run;
+  for (size_t r = 0; r < runs.size(); ++r)
+    for (int c = 0; c < runs[r].chunks; ++c) { b->se_chunk_pt0.push_back(rm_run_pt0[r] + c * runs[r].m); rm_chunk_run.push_back((int)r); }
+  const int n_rm = (int)rm_chunk_run.size();
+  for (size_t c = 0; c + 1 < chunk_pt0L.size(); ++c) if (chunk_pt0L[c + 1] > chunk_pt0L[c]) b->se_chunk_pt0.push_back(P_rm + chunk_pt0L[c]);
+  b->se_chunk_pt0.push_back(P);
+  tick("chunks");
+  // ---- edges sorted by (internal point, key frame): CSR by point; per-pose edge lists reference sorted positions
+  b->perm.resize(E);
+  s_pose.assign(E, 0); s_point.assign(E, 0); pt_off.assign(P + 1, 0); pose_off.assign(K + 1, 0); pose_edges.assign(E, 0);
+  s_obs.assign(e_obs ? 2 * (size_t)E : 0, 0.0); s_inv.assign(e_invsig2 ? E : 0, 0.0); s_face.assign(E, 0);
+  {
+    int i = 0;
+    for (int p = 0; p < P; ++p) {
+      const int q = b->pinv[p];
+      pt_off[p] = i;
+      for (int t = cpo[q]; t < cpo[q + 1]; ++t, ++i) {
+        const int e = cpe[t];
+        b->perm[i] = e;
+        s_pose[i] = e_pose[e]; s_point[i] = p; s_face[i] = e_face ? e_face[e] : 0;
+        if (e_obs) { s_obs[2 * i] = e_obs[2 * e]; s_obs[2 * i + 1] = e_obs[2 * e + 1]; }
+        if (e_invsig2) s_inv[i] = e_invsig2[e];
+        ++pose_off[s_pose[i] + 1];
+      }
+    }
+    pt_off[P] = i;
+  }
+  for (int k = 0; k < K; ++k) pose_off[k + 1] += pose_off[k];
+  {
+    std::vector<int> fill(pose_off.begin(), pose_off.end() - 1);
+    for (int i = 0; i < E; ++i) pose_edges[fill[s_pose[i]]++] = i;
+  }
+  tick("csr");
+  // ---- work lists of the edge-major / run-major Schur kernels: chunks of whole points with <= 64 edges (one wavefront each), the per-edge
+  // words, the runs' chunk descriptors and consumer-lane tables, the dense enumeration of the pose pairs s1 <= s2 for the solve kernel
+  ce0.clear(); pob.clear(); ident.clear(); lone.clear(); info.clear(); rm_chunk.clear(); run_lane.clear();
+  se_built = false;
+  if (se_ok) {
+    bool ok = true;
+    info.resize(E);
+    for (size_t c = 0; c + 1 < b->se_chunk_pt0.size() && ok; ++c) {
+      const int p0 = b->se_chunk_pt0[c], p1 = b->se_chunk_pt0[c + 1];
+      if (pt_off[p1] - pt_off[p0] > 64) { ok = false; break; }
+      ce0.push_back(pt_off[p0]);
+      for (int p = p0; p < p1; ++p) {
+        const int ne = pt_off[p + 1] - pt_off[p];
+        for (int a1 = 0; a1 < ne; ++a1) {
+          const int e = pt_off[p] + a1;
+          const int rank = p < P_rm ? ((p - p0) & (BA_SE_DCOPIES - 1)) : cp_rankL[(size_t)cp_offL[pinvL[p - P_rm]] + a1] % BA_SE_DCOPIES;      // chosen with the chunk (edges of a point are in pose order in both lists)
+          info[e] = (uint32_t)a1 | ((uint32_t)ne << 5) | ((uint32_t)(pose_slot[s_pose[e]] + 1) << 10) | ((uint32_t)s_face[e] << 16) | ((uint32_t)s_pose[e] << 19) |
+                    ((uint32_t)rank << 27);
+        }
+      }
+    }
+    ce0.push_back(E);
+    if (ok) {
+      const int nchunks = (int)ce0.size() - 1;
+      pob.assign((size_t)NP2, 0); ident.resize((size_t)NP2 + 1);
+      for (int I = 0; I < np; ++I)
+        for (int Kc = 0; Kc <= I; ++Kc) pob[(size_t)I * (I + 1) / 2 + Kc] = Kc * np - (Kc * (Kc - 1)) / 2 + (I - Kc);   // block (I, K): pair (s1 = K, s2 = I)
+      for (int i = 0; i <= NP2; ++i) ident[i] = i;
+      for (int p = 0; p < P; ++p) if (pt_off[p + 1] == pt_off[p]) lone.push_back(p);      // points without observations are in no chunk
+      // run chunks and the consumer lanes' tables
+      const uint32_t dg_off = (uint32_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1);
+      rm_chunk.resize(n_rm);
+      for (int c = 0; c < n_rm; ++c) {
+        const Run& R = runs[rm_chunk_run[c]];
+        const int p0 = b->se_chunk_pt0[c], p1 = std::min(b->se_chunk_pt0[c + 1], rm_run_pt0[rm_chunk_run[c] + 1]);
+        rm_chunk[c] = make_int4(pt_off[p0], (pt_off[p1] - pt_off[p0]) | (R.k << 8) | ((p1 - p0) << 16), rm_chunk_run[c], (65536 + R.k - 1) / R.k);
+      }
+      run_lane.assign(runs.size() * 64, make_uint2(0u, 0u));
+      for (size_t r = 0; r < runs.size(); ++r) {
+        const int q = runs[r].first;
+        int fpos[32], fslot[32], kf = 0;
+        for (int i = cpo[q]; i < cpo[q + 1]; ++i) { const int s = pose_slot[e_pose[cpe[i]]]; if (s >= 0) { fpos[kf] = i - cpo[q]; fslot[kf] = s; ++kf; } }
+        const int T = kf * (kf + 1) / 2, Q = 64 / T;
+        int t = 0;
+        for (int ia = 0; ia < kf; ++ia)
+          for (int ib = ia; ib < kf; ++ib, ++t)
+            for (int qq = 0; qq < Q; ++qq) {
+              uint2& w = run_lane[r * 64 + (size_t)qq * T + t];
+              w.x = ba_rm_lane_word(fpos[ia], fpos[ib], qq, Q, ia == ib);
+              w.y = ia == ib ? dg_off + (uint32_t)(((qq % BA_SE_DCOPIES) * np + fslot[ia]) * BA_SE_DSTRIDE)
+                             : (uint32_t)((fslot[ia] * np - (fslot[ia] * (fslot[ia] + 1)) / 2 + (fslot[ib] - fslot[ia] - 1)) * BA_SE_SSTRIDE);
+            }
+      }
+      if (run_lane.empty()) run_lane.push_back(make_uint2(0u, 0u));
+      if (rm_chunk.empty()) rm_chunk.push_back(make_int4(0, 0, -1, 0));
+      BaSe& se = b->se;
+      se.nchunks = nchunks; se.n_rm = n_rm; se.npairs2 = NP2;
+      se.cpw_t = BA_TE_THREADS / 64;                              // the trial kernel: one chunk per wavefront
+      se.Rt = (nchunks + se.cpw_t - 1) / se.cpw_t;
+      se.nlone = (int)lone.size();
+      ba_se_split(se, BA_SE_RANGES);                              // a window on its own; a group re-splits (ba_upload_items)
+      if (lone.empty()) lone.push_back(0);
+      b->se_lds_fixed = se_fixed_lds; b->se_waves = se_nw; b->rm_lds = n_rm > 0 ? rm_lds : 0;
+      b->n_runs = (int)runs.size(); b->rm_points = P_rm;
+      se_built = true;
+    }
+  }
+}
+
+// developer / test entry, host only: the plan cms_ba_create makes for a window -- internal point order, chunks, signature runs, the run-major
+// kernel's chunk descriptors and consumer-lane tables, the per-edge words -- so that the index arithmetic of cms_ba_schur_runs.hip can be
+// replayed on the CPU (tests/test_ba_runs_cpu.py).  Sizes: pinv P, perm E, info E, chunk_pt0 P + 2, rm_chunk 4 x P, run_lane 128 x P (upper
+// bounds; counts[] = chunks, run chunks, runs, np, points inside runs, range split of a window on its own: R_rm, R).
+extern "C" int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int* pinv_out, int* perm_out,
+                                 uint32_t* info_out, int* chunk_pt0_out, int* rm_chunk_out, uint32_t* run_lane_out, int* counts) {
+  if (K < 1 || P < 1 || E < 1 || !fixed || !e_pose || !e_point || !pinv_out || !perm_out || !info_out || !chunk_pt0_out || !rm_chunk_out || !run_lane_out || !counts)
+    return cms_fail(CMS_ERR_ARG, "cms_ba_debug_plan: bad argument");
+  for (int e = 0; e < E; ++e)
+    if (e_pose[e] < 0 || e_pose[e] >= K || e_point[e] < 0 || e_point[e] >= P) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_plan: index out of range");
+  cms_ba* b = new cms_ba;
+  b->K = K; b->P = P; b->E = E;
+  BaPlan pl;
+  auto t_last = std::chrono::steady_clock::now();
+  const bool timing = ba_knobs().create_timing;
+  ba_plan(b, pl, K, fixed, P, E, e_pose, e_point, nullptr, nullptr, nullptr, [&](const char* what) {
+    const auto now = std::chrono::steady_clock::now();
+    if (timing) fprintf(stderr, "[cms_ba_debug_plan] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  });
+  memcpy(pinv_out, b->pinv.data(), (size_t)P * sizeof(int));
+  memcpy(perm_out, b->perm.data(), (size_t)E * sizeof(int));
+  memcpy(chunk_pt0_out, b->se_chunk_pt0.data(), b->se_chunk_pt0.size() * sizeof(int));
+  counts[0] = (int)b->se_chunk_pt0.size() - 1; counts[1] = pl.se_built ? b->se.n_rm : 0; counts[2] = pl.se_built ? b->n_runs : 0; counts[3] = b->np;
+  counts[4] = pl.se_built ? b->rm_points : 0; counts[5] = pl.se_built ? b->se.R_rm : 0; counts[6] = pl.se_built ? b->se.R : 0; counts[7] = pl.se_built ? 1 : 0;
+  if (pl.se_built) {
+    memcpy(info_out, pl.info.data(), (size_t)E * sizeof(uint32_t));
+    if (b->se.n_rm > 0) memcpy(rm_chunk_out, pl.rm_chunk.data(), (size_t)b->se.n_rm * sizeof(int4));
+    if (b->n_runs > 0) memcpy(run_lane_out, pl.run_lane.data(), (size_t)b->n_runs * 64 * sizeof(uint2));
+  }
+  delete b;
+  return CMS_OK;
+}
+
 extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P,
                              const double* points, int E, const int* e_pose, const int* e_point, const double* e_obs,
                              const double* e_invsig2, const int8_t* e_face, double fx, double fy, double cx, double cy) {
@@ -457,7 +802,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
 #define BA_TRY(x) do { int _rc = (x); if (_rc) { cms_ba_destroy(b); return _rc; } } while (0)
 #define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
   // CMS_BA_CREATE_TIMING=1: where the host side of a window's set-up goes (stderr, one line per window)
-  static const bool timing = getenv("CMS_BA_CREATE_TIMING") != nullptr;
+  const bool timing = ba_knobs().create_timing;
   auto t_last = std::chrono::steady_clock::now();
   std::string t_log;
   auto tick = [&](const char* what) {
@@ -470,9 +815,8 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BA_TRY(ba_lds_attrs_once(device));
   {
     // CMS_BA_STREAM_PRIORITY=low: the window's queue yields to normal-priority queues (the frame path) whenever both have workgroups ready
-    const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
     int lo = 0, hi = 0;
-    if (pr && pr[0] == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+    if (ba_knobs().stream_priority == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
       BA_HIP(hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, lo));
     else {
       b->stream = ba_stream_take(device);
@@ -481,147 +825,35 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     }
   }
   tick("stream");
-  // ---- internal point order = chunk composition of the edge-major Schur kernel (cms_ba_schur_edges.hip).  A wavefront takes a CHUNK of whole
-  // points with at most 64 edges; in step d the lane of a point's a-th edge adds its 6x6 product to the LDS block of the pose pair
-  // (pose_a, pose_(a+d) mod k), one element per instruction.  What such an instruction costs is decided by where its addresses fall
-  // (tools/probe/lds_atomics.hip): the LDS takes the 64 lanes of a ds_add_f64 in four groups of 16 CONSECUTIVE lanes, two clocks each when
-  // the 16 addresses fall on 16 different f64 banks (address mod 16 doubles), and two more clocks for every further lane on the fullest
-  // bank (same address: six more).  Lanes 16 or more apart never compete.  Random pairs cost ~3.1 slots per group (16 balls into 16 bins)
-  // -- the 2.7 lane-operations per clock measured against 7.8 on consecutive addresses.
-  // The host therefore composes the chunks: points are taken from a look-ahead window over the caller's order so that, within each group
-  // of 16 lanes and each step, the pairs' bank classes (pair index mod 16: the block stride is odd, and the block layout gives an element
-  // and its transpose the same bank) repeat as little as possible; the diagonal tuples pick, among the four copies of their key frame's
-  // diagonal block, the one whose bank is least used in their group.  Everything on the device is indexed by the internal point id;
-  // cms_ba_read / cms_ba_linearize translate back.  CMS_BA_NO_PERMUTE=1 keeps the caller's order (A/B).
-  std::vector<int> prank, cp_off, cp_pose;
-  std::vector<uint8_t> cp_rank;                       // per (caller point, edge in pose order): copy of the diagonal blocks its (a, a) tuple goes to
-  {
-    static const int la_env = getenv("CMS_BA_LOOKAHEAD") ? atoi(getenv("CMS_BA_LOOKAHEAD")) : 24;
-    static const bool no_permute = getenv("CMS_BA_NO_PERMUTE") != nullptr;
-    ba_compose_chunks(K, fixed, P, E, e_pose, e_point, no_permute ? 1 : la_env, prank, b->pinv, b->se_chunk_pt0, cp_off, cp_pose, cp_rank);
-  }
-  tick("chunks");
-  // sort edges by (internal point, pose): CSR by point; per-pose edge lists reference sorted positions
-  // (two stable counting passes, by key frame and then by internal point: what a stable comparison sort on (point, key frame) gives, in O(E))
-  b->perm.resize(E);
-  {
-    std::vector<int> by_pose(E), cnt((size_t)std::max(K, P) + 1, 0);
-    for (int e = 0; e < E; ++e) ++cnt[e_pose[e] + 1];
-    for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
-    for (int e = 0; e < E; ++e) by_pose[cnt[e_pose[e]]++] = e;
-    std::fill(cnt.begin(), cnt.end(), 0);
-    for (int e = 0; e < E; ++e) ++cnt[prank[e_point[e]] + 1];
-    for (int p = 0; p < P; ++p) cnt[p + 1] += cnt[p];
-    for (int i = 0; i < E; ++i) { const int e = by_pose[i]; b->perm[cnt[prank[e_point[e]]]++] = e; }
-  }
-  std::vector<int> s_pose(E), s_point(E), pt_off(P + 1, 0), pose_off(K + 1, 0), pose_edges(E), pose_slot(K, -1);
-  std::vector<double> s_obs(2 * (size_t)E), s_inv(E);
-  std::vector<int8_t> s_face(E);
-  for (int i = 0; i < E; ++i) {
-    const int e = b->perm[i];
-    s_pose[i] = e_pose[e]; s_point[i] = prank[e_point[e]]; s_obs[2 * i] = e_obs[2 * e]; s_obs[2 * i + 1] = e_obs[2 * e + 1];
-    s_inv[i] = e_invsig2[e]; s_face[i] = e_face[e];
-    ++pt_off[s_point[i] + 1]; ++pose_off[s_pose[i] + 1];
-  }
-  for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
-  for (int k = 0; k < K; ++k) pose_off[k + 1] += pose_off[k];
-  {
-    std::vector<int> fill(pose_off.begin(), pose_off.end() - 1);
-    for (int i = 0; i < E; ++i) pose_edges[fill[s_pose[i]]++] = i;
-  }
-  int np = 0;
-  for (int k = 0; k < K; ++k) if (!fixed[k]) pose_slot[k] = np++;
-  b->np = np;
-  const int n = 6 * np;
-  b->nblk_e = (E + 255) / 256; b->nblk_p = (P + 127) / 128;
-  tick("csr");
-  BA_TRY(ba_alloc(b, &b->d_fixed, K)); BA_TRY(ba_alloc(b, &b->d_pose_slot, K)); BA_TRY(ba_alloc(b, &b->d_e_pose, E));
-  BA_TRY(ba_alloc(b, &b->d_e_point, E)); BA_TRY(ba_alloc(b, &b->d_e_obs, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_inv, E));
-  BA_TRY(ba_alloc(b, &b->d_e_face, E)); BA_TRY(ba_alloc(b, &b->d_pt_off, P + 1)); BA_TRY(ba_alloc(b, &b->d_pose_off, K + 1));
-  BA_TRY(ba_alloc(b, &b->d_pose_edges, E)); BA_TRY(ba_alloc(b, &b->d_level, E)); BA_TRY(ba_alloc(b, &b->d_err, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_ow, (size_t)E));
-  for (int i = 0; i < 2; ++i) { BA_TRY(ba_alloc(b, &b->d_poses[i], 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts[i], 3 * (size_t)P)); }
-  BA_TRY(ba_alloc(b, &b->d_poses0, 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts0, 3 * (size_t)P));
-  BA_TRY(ba_alloc(b, &b->d_Hpp, 36 * (size_t)std::max(np, 1))); BA_TRY(ba_alloc(b, &b->d_bp, 6 * (size_t)std::max(np, 1)));
-  BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P));
-  BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
-  BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
-  BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(std::max(b->nblk_e, b->nblk_p), (E + 63) / 64 + 8) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 24));   // [8..16): developer clocks of k_ba_trial_solve
-  BA_TRY(ba_alloc(b, &b->d_flags, E));
-  b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
-  BA_HIP(ba_pin_take(device, 8 * sizeof(double), (void**)&b->h_pin, &b->h_pin_bytes));
-  BA_TRY(ba_alloc(b, &b->d_pose_partial, (size_t)std::max(np, 1) * BA_POSE_CHUNKS * 27)); BA_TRY(ba_alloc(b, &b->d_db, 3 * (size_t)P));
-  tick("alloc");
-  b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
-  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
-  // ---- work list of the edge-major Schur kernel (cms_ba_schur_edges.hip): chunks of whole points with <= 64 edges, one wavefront
-  // each; dense enumeration of the pose pairs s1 <= s2 and the matching tables for the solve kernel's assembly
-  if (np >= 1) {
+  const BaKnobs& kn = ba_knobs();
+  BaPlan pl;
+  ba_plan(b, pl, K, fixed, P, E, e_pose, e_point, e_obs, e_invsig2, e_face, tick);
+  std::vector<int>&pose_slot = pl.pose_slot, &prank = pl.prank, &s_pose = pl.s_pose, &s_point = pl.s_point, &pt_off = pl.pt_off, &pose_off = pl.pose_off, &pose_edges = pl.pose_edges;
+  std::vector<double>&s_obs = pl.s_obs, &s_inv = pl.s_inv;
+  std::vector<int8_t>& s_face = pl.s_face;
+  const bool se_built = pl.se_built;
+  const int np = b->np, n = 6 * np;
+  // ---- everything the window uploads goes through ONE pinned block and ONE asynchronous copy on the window's stream (a dozen synchronous
+  // hipMemcpy calls from pageable memory were 0.3 ms of a 2 ms set-up and serialised the host threads that build windows side by side)
+  struct Up { const void* src; size_t bytes; void** dst; };
+  std::vector<Up> ups;
+  auto up = [&](const void* src, size_t bytes, auto** dst) { ups.push_back({src, bytes, reinterpret_cast<void**>(dst)}); };
+  if (se_built) {
     const int NP2 = np * (np + 1) / 2;
-    // LDS: the reduced system, the diagonal copies and the key frames' poses, plus a W row and a slot per lane of every wavefront.  Windows with
-    // more free key frames get fewer wavefronts per workgroup (8 up to 20 key frames, 6 / 4 / 2 up to 25); beyond that the copy does not fit
-    const size_t lds_fixed = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)K * 12) * sizeof(double);
-    const size_t lds_wave = (size_t)64 * 18 * sizeof(double) + 64 * sizeof(int);
-    int nw = BA_SE_THREADS / 64;
-    while (nw > 2 && lds_fixed + nw * lds_wave > BA_LDS_CEILING) nw -= 2;
-    const size_t lds = lds_fixed + nw * lds_wave;
-    bool ok = lds <= BA_LDS_CEILING && K <= 256 && np <= 62;
-    std::vector<int> ce0;
-    std::vector<uint32_t> info(E);
-    for (size_t c = 0; c + 1 < b->se_chunk_pt0.size() && ok; ++c) {
-      const int p0 = b->se_chunk_pt0[c], p1 = b->se_chunk_pt0[c + 1];
-      if (p1 == p0) continue;
-      if (pt_off[p1] - pt_off[p0] > 64) { ok = false; break; }
-      ce0.push_back(pt_off[p0]);
-      for (int p = p0; p < p1 && ok; ++p) {
-        const int ne = pt_off[p + 1] - pt_off[p];
-        if (ne > 31) { ok = false; break; }
-        for (int a1 = 0; a1 < ne; ++a1) {
-          const int e = pt_off[p] + a1;
-          if (a1 > 0 && s_pose[e] == s_pose[e - 1]) ok = false;       // a point seen twice by one key frame: the pair-owner kernel handles it
-          const int rank = cp_rank[(size_t)cp_off[b->pinv[p]] + a1] % BA_SE_DCOPIES;      // chosen with the chunk (edges of a point are in pose order in both lists)
-          info[e] = (uint32_t)a1 | ((uint32_t)ne << 5) | ((uint32_t)(pose_slot[s_pose[e]] + 1) << 10) | ((uint32_t)s_face[e] << 16) | ((uint32_t)s_pose[e] << 19) |
-                    ((uint32_t)rank << 27);
-        }
-      }
-    }
-    ce0.push_back(E);
-    if (ok) {
-      const int nchunks = (int)ce0.size() - 1;
-      const int cpw = std::max(1, (nchunks + BA_SE_RANGES - 1) / BA_SE_RANGES);
-      const int R = (nchunks + cpw - 1) / cpw;
-      std::vector<int> pob((size_t)NP2, 0), ident((size_t)NP2 + 1);
-      for (int I = 0; I < np; ++I)
-        for (int Kc = 0; Kc <= I; ++Kc) pob[(size_t)I * (I + 1) / 2 + Kc] = Kc * np - (Kc * (Kc - 1)) / 2 + (I - Kc);   // block (I, K): pair (s1 = K, s2 = I)
-      for (int i = 0; i <= NP2; ++i) ident[i] = i;
-      BA_TRY(ba_alloc(b, &b->d_se_chunk_e0, ce0.size())); BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)R * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)R * np * 6)); BA_TRY(ba_alloc(b, &b->d_se_info, info.size()));
-      BA_HIP(hipMemcpy(b->d_se_info, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_pob, pob.size())); BA_TRY(ba_alloc(b, &b->d_se_chunk_off, ident.size()));
-      BA_HIP(hipMemcpy(b->d_se_chunk_e0, ce0.data(), ce0.size() * sizeof(int), hipMemcpyHostToDevice));
-      BA_HIP(hipMemcpy(b->d_se_pob, pob.data(), pob.size() * sizeof(int), hipMemcpyHostToDevice));
-      BA_HIP(hipMemcpy(b->d_se_chunk_off, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
-      {
-        std::vector<int> lone;                                             // points without observations are in no chunk
-        for (int p = 0; p < P; ++p) if (pt_off[p + 1] == pt_off[p]) lone.push_back(p);
-        int* d_lone = nullptr;
-        BA_TRY(ba_alloc(b, &d_lone, lone.size()));
-        if (!lone.empty()) BA_HIP(hipMemcpy(d_lone, lone.data(), lone.size() * sizeof(int), hipMemcpyHostToDevice));
-        b->se.lone = d_lone; b->se.nlone = (int)lone.size();
-        const int cpw_t = BA_TE_THREADS / 64;                              // one chunk per wavefront
-        b->se.cpw_t = cpw_t;
-        b->se.Rt = (nchunks + cpw_t - 1) / cpw_t;
-      }
-      b->se.R = R; b->se.nchunks = nchunks; b->se.cpw = cpw; b->se.npairs2 = NP2; b->se.chunk_e0 = b->d_se_chunk_e0; b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial; b->se.e_info = b->d_se_info;
-      b->se_lds_fixed = lds_fixed; b->se_waves = nw;
-    }
+    BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)BA_SE_RANGES * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)BA_SE_RANGES * np * 6));
+    BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42));
+    b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial;
+    up(pl.ce0.data(), pl.ce0.size() * sizeof(int), &b->d_se_chunk_e0); up(pl.info.data(), pl.info.size() * sizeof(uint32_t), &b->d_se_info);
+    up(pl.pob.data(), pl.pob.size() * sizeof(int), &b->d_se_pob); up(pl.ident.data(), pl.ident.size() * sizeof(int), &b->d_se_chunk_off);
+    up(pl.lone.data(), pl.lone.size() * sizeof(int), &b->d_se_lone);
+    up(pl.rm_chunk.data(), pl.rm_chunk.size() * sizeof(int4), &b->d_rm_chunk); up(pl.run_lane.data(), pl.run_lane.size() * sizeof(uint2), &b->d_run_lane);
   }
   tick("se");
   // A window that has the edge-major work list runs through the grouped driver with the edge-major kernels (cms_ba_optimize_many also puts
   // it into a group of its own kind): the pair-owner and tuple-chunk kernels' work lists (co-visibility tuples: ~10 per point, 2.4 ms of
   // host time at 80 k edges) and the stored 6x3 blocks (144 B per edge) are then never touched and are not built.  The A/B switches that
   // select those kernels bring them back.
-  static const bool want_all_lists = getenv("CMS_BA_DETERMINISTIC") || getenv("CMS_BA_HOST_LM") || getenv("CMS_BA_SINGLE_HOST_LM") ||
-                                     getenv("CMS_BA_SCHUR_CHUNKS") || getenv("CMS_BA_SCHUR_POINTS") || getenv("CMS_BA_ALL_LISTS");
-  b->se_only = b->se.R > 0 && b->solve_blk && !want_all_lists;
+  b->se_only = se_built && b->solve_blk && !kn.want_all_lists;
   if (!b->se_only) BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2
   if (!b->se_only) {
@@ -668,7 +900,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
       std::vector<int> pair_idx((size_t)std::max(np * np, 1), -1);
       int ndiag = 0;
       for (int pr = 0; pr < npairs; ++pr) { pair_idx[(size_t)ps1[pr] * np + ps2[pr]] = pr; ndiag += ps1[pr] == ps2[pr]; }
-      bool ok = npairs > 0 && getenv("CMS_BA_SCHUR_CHUNKS") == nullptr;
+      bool ok = npairs > 0 && !kn.schur_chunks;
       std::vector<int> bat_e0(1, 0), bat_of_point(P, 0);
       for (int p = 0, cur = 0, curt = 0; p < P && ok; ++p) {
         const int ne = pt_off[p + 1] - pt_off[p];
@@ -789,9 +1021,6 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     BA_HIP(hipMemcpy(b->d_pair_off, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   tick("tuple-upload");
-  // the three-lanes-per-block variant (grouped driver): 3 x blocks <= 1024 threads
-  b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 2 * (size_t)n + 8) * sizeof(double);
-  b->solve_blk3 = b->solve_blk && 3 * (np * (np + 1) / 2) <= 1024 && b->blk3_lds <= BA_LDS_CEILING;
   {
     const int NP = 192;
     b->solve_lds = ((size_t)n * (n + 1) / 2 + 4 * (size_t)NP + 8) * sizeof(double);
@@ -805,22 +1034,51 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     for (int i = 0; i < 4; ++i) q[i] /= nn;
   }
-#define UP(dst, src, bytes) BA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice))
-  UP(b->d_fixed, fixed, K); UP(b->d_pose_slot, pose_slot.data(), K * sizeof(int)); UP(b->d_e_pose, s_pose.data(), E * sizeof(int));
-  UP(b->d_e_point, s_point.data(), E * sizeof(int)); UP(b->d_e_obs, s_obs.data(), 2 * (size_t)E * sizeof(double));
-  UP(b->d_e_inv, s_inv.data(), E * sizeof(double)); UP(b->d_e_face, s_face.data(), E); UP(b->d_pt_off, pt_off.data(), (P + 1) * sizeof(int));
-  UP(b->d_pose_off, pose_off.data(), (K + 1) * sizeof(int)); UP(b->d_pose_edges, pose_edges.data(), E * sizeof(int));
-  UP(b->d_poses0, p0.data(), 7 * (size_t)K * sizeof(double)); {
-    std::vector<double> pin(3 * (size_t)P);
-    for (int i = 0; i < P; ++i) for (int j = 0; j < 3; ++j) pin[3 * (size_t)i + j] = points[3 * (size_t)b->pinv[i] + j];
-    UP(b->d_pts0, pin.data(), 3 * (size_t)P * sizeof(double));
+  std::vector<double> pin(3 * (size_t)P);
+  for (int i = 0; i < P; ++i) for (int j = 0; j < 3; ++j) pin[3 * (size_t)i + j] = points[3 * (size_t)b->pinv[i] + j];
+  up(fixed, K, &b->d_fixed); up(pose_slot.data(), K * sizeof(int), &b->d_pose_slot); up(s_pose.data(), E * sizeof(int), &b->d_e_pose);
+  up(s_point.data(), E * sizeof(int), &b->d_e_point); up(s_obs.data(), 2 * (size_t)E * sizeof(double), &b->d_e_obs);
+  up(s_inv.data(), E * sizeof(double), &b->d_e_inv); up(s_face.data(), E, &b->d_e_face); up(pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off);
+  up(pose_off.data(), (K + 1) * sizeof(int), &b->d_pose_off); up(pose_edges.data(), E * sizeof(int), &b->d_pose_edges);
+  up(p0.data(), 7 * (size_t)K * sizeof(double), &b->d_poses0); up(pin.data(), 3 * (size_t)P * sizeof(double), &b->d_pts0);
+  // ---- buffers the device only writes / works in
+  BA_TRY(ba_alloc(b, &b->d_level, E)); BA_TRY(ba_alloc(b, &b->d_err, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_ow, (size_t)E));
+  for (int i = 0; i < 2; ++i) { BA_TRY(ba_alloc(b, &b->d_poses[i], 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts[i], 3 * (size_t)P)); }
+  BA_TRY(ba_alloc(b, &b->d_Hpp, 36 * (size_t)std::max(np, 1))); BA_TRY(ba_alloc(b, &b->d_bp, 6 * (size_t)std::max(np, 1)));
+  BA_TRY(ba_alloc(b, &b->d_Hll, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_bl, 3 * (size_t)P));
+  BA_TRY(ba_alloc(b, &b->d_Dinv, 9 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_Hs, (size_t)std::max(n * n, 1))); BA_TRY(ba_alloc(b, &b->d_bs, std::max(n, 1)));
+  BA_TRY(ba_alloc(b, &b->d_x, std::max(n, 1))); BA_TRY(ba_alloc(b, &b->d_Dg, std::max(n, 1)));
+  BA_TRY(ba_alloc(b, &b->d_partial, 2 * (size_t)std::max(std::max(b->nblk_e, b->nblk_p), (E + 63) / 64 + 8) + 8)); BA_TRY(ba_alloc(b, &b->d_scal, 24));   // [8..16): developer clocks of k_ba_trial_solve
+  BA_TRY(ba_alloc(b, &b->d_flags, E));
+  b->d_status = reinterpret_cast<int*>(b->d_scal + 4);   // solver status travels with the scalars
+  BA_HIP(ba_pin_take(device, 8 * sizeof(double), (void**)&b->h_pin, &b->h_pin_bytes));
+  BA_TRY(ba_alloc(b, &b->d_pose_partial, (size_t)std::max(np, 1) * BA_POSE_CHUNKS * 27)); BA_TRY(ba_alloc(b, &b->d_db, 3 * (size_t)P));
+  tick("alloc");
+  // ---- the one staging block and the one copy
+  {
+    size_t total = 0;
+    std::vector<size_t> offs(ups.size());
+    for (size_t i = 0; i < ups.size(); ++i) { offs[i] = total; total += (ups[i].bytes + 255) & ~(size_t)255; }
+    // (the read-back of cms_ba_read reuses the block: poses, points, flags)
+    total = std::max(total, ((size_t)7 * K * 8 + 255 + (size_t)3 * P * 8 + 255 + (size_t)E + 255));
+    char* dev = nullptr;
+    BA_TRY(ba_alloc(b, &dev, total));
+    BA_HIP(ba_pin_take(device, total, (void**)&b->h_stage, &b->h_stage_bytes));
+    for (size_t i = 0; i < ups.size(); ++i) {
+      if (ups[i].bytes) memcpy(b->h_stage + offs[i], ups[i].src, ups[i].bytes);
+      *ups[i].dst = dev + offs[i];
+    }
+    BA_HIP(hipMemcpyAsync(dev, b->h_stage, total, hipMemcpyHostToDevice, b->stream));
   }
-#undef UP
   BaDev& d = b->d;
   d.K = K; d.P = P; d.E = E; d.np = np; d.fixed = b->d_fixed; d.pose_slot = b->d_pose_slot; d.e_pose = b->d_e_pose;
   d.e_point = b->d_e_point; d.e_obs = b->d_e_obs; d.e_inv = b->d_e_inv; d.e_face = b->d_e_face; d.pt_off = b->d_pt_off;
   d.pose_off = b->d_pose_off; d.pose_edges = b->d_pose_edges; d.level = b->d_level; d.err = b->d_err; d.ow = b->d_ow;
   d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
+  if (se_built) {
+    BaSe& se = b->se;
+    se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane;
+  }
   tick("uploads");
   int rc = cms_ba_reset(b);
   if (rc) { cms_ba_destroy(b); return rc; }
@@ -868,16 +1126,21 @@ static void ba_errors(cms_ba* b, int which, int robust, double delta, int slot) 
 extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* outlier_flags) {
   if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
   HIPCHK(hipSetDevice(b->device));
+  // one pinned block (the window's upload staging, sized for this at creation), up to three copies, one synchronisation
+  const size_t o_pose = 0, o_pts = ((size_t)7 * b->K * 8 + 255) & ~(size_t)255, o_flags = o_pts + (((size_t)3 * b->P * 8 + 255) & ~(size_t)255);
+  if (!b->h_stage || b->h_stage_bytes < o_flags + (size_t)b->E) return cms_fail(CMS_ERR_HIP, "cms_ba_read: staging block missing");
+  char* h = b->h_stage;
+  if (poses) HIPCHK(hipMemcpyAsync(h + o_pose, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  if (points) HIPCHK(hipMemcpyAsync(h + o_pts, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  if (outlier_flags) HIPCHK(hipMemcpyAsync(h + o_flags, b->d_flags, b->E, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  if (poses) HIPCHK(hipMemcpy(poses, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost));
+  if (poses) memcpy(poses, h + o_pose, 7 * (size_t)b->K * sizeof(double));
   if (points) {
-    std::vector<double> pin(3 * (size_t)b->P);
-    HIPCHK(hipMemcpy(pin.data(), b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost));
+    const double* pin = reinterpret_cast<const double*>(h + o_pts);
     for (int i = 0; i < b->P; ++i) for (int j = 0; j < 3; ++j) points[3 * (size_t)b->pinv[i] + j] = pin[3 * (size_t)i + j];
   }
   if (outlier_flags) {
-    std::vector<uint8_t> f(b->E);
-    HIPCHK(hipMemcpy(f.data(), b->d_flags, b->E, hipMemcpyDeviceToHost));
+    const uint8_t* f = reinterpret_cast<const uint8_t*>(h + o_flags);
     for (int i = 0; i < b->E; ++i) outlier_flags[b->perm[i]] = f[i];
   }
   return CMS_OK;

@@ -55,7 +55,7 @@ static int ba_enqueue_trial(cms_ba* b, const BaLm& st) {
     // A window on its own is a latency problem: the tuple-chunk kernel (hundreds of short workgroups, 13 us) beats the
     // per-point kernel (64 workgroups walking 6 batches each, 40 us).  The per-point kernel pays off when several windows
     // share the launches and the chunk kernel becomes bandwidth bound -- the batched driver below uses it.
-    const bool sp = b->sp.R > 0 && getenv("CMS_BA_SCHUR_POINTS") != nullptr;
+    const bool sp = b->sp.R > 0 && ba_knobs().schur_points;
     if (sp) {
       hipLaunchKernelGGL(k_ba_schur_points, dim3(b->sp.R), dim3(b->sp_threads), b->sp_lds, s, b->d, b->sp, (const double*)b->d_Hpl,
                          (const double*)b->d_Dinv, (const double*)b->d_db);
@@ -159,7 +159,7 @@ static int ba_optimize_stage_many(cms_ba** bas, int n, std::vector<BaLm>& st, co
 // ---- batched variant: the windows share every launch (kb_ba_* kernels, blockIdx.z = window) and every synchronisation.
 // Used when all windows fit the fused trial path and live on one device; results are identical to the per-window path.
 static bool ba_can_batch(cms_ba** bas, int n) {
-  static const bool single_old = getenv("CMS_BA_SINGLE_HOST_LM") != nullptr;      // A/B: a single window through the host-driven per-window path
+  const bool single_old = ba_knobs().single_host_lm;      // A/B: a single window through the host-driven per-window path
   if (n < (single_old ? 2 : 1) || n > BA_MAX_GROUP) return false;      // (a single window too: device-side Levenberg loop, edge-major kernels)
   for (int w = 0; w < n; ++w) if (!bas[w]->solve_blk || bas[w]->device != bas[0]->device) return false;
   return true;
@@ -193,15 +193,13 @@ static bool ba_all_sp(cms_ba** bas, int n) {
 // the edge-major Schur kernel (LDS accumulation, cms_ba_schur_edges.hip) runs when every window of the group has its work list and the
 // per-point path is available too (the two share the block-free linearisation); CMS_BA_DETERMINISTIC=1 keeps the pair-owner kernel
 static bool ba_use_se(cms_ba** bas, int n) {
-  static const bool det = getenv("CMS_BA_DETERMINISTIC") != nullptr || getenv("CMS_BA_HOST_LM") != nullptr;   // (the host-driven A/B driver only knows the pair-owner kernel)
-  if (det) return false;
-  for (int w = 0; w < n; ++w) if (bas[w]->se.R <= 0) return false;
+  if (ba_knobs().deterministic || ba_knobs().host_lm) return false;   // (the host-driven A/B driver only knows the pair-owner kernel)
+  for (int w = 0; w < n; ++w) if (bas[w]->se.nchunks <= 0) return false;
   return true;
 }
 // ... and the edge-major trial kernel when, in addition, every point of every window has an observation
 static bool ba_use_te(cms_ba** bas, int n) {
-  static const bool off = getenv("CMS_BA_TRIAL_POINTS") != nullptr;
-  if (off || !ba_use_se(bas, n)) return false;
+  if (ba_knobs().trial_points || !ba_use_se(bas, n)) return false;
   for (int w = 0; w < n; ++w) if (bas[w]->se.Rt <= 0) return false;
   return true;
 }
@@ -209,18 +207,46 @@ static bool ba_use_te(cms_ba** bas, int n) {
 // should have at most as many workgroups as the chip has CUs -- 11 windows x 32 ranges = 352 workgroups run as one full round plus a round
 // at 37 %.  Windows keep the 32 ranges their buffers are sized for as the upper limit.
 static int ba_group_ranges(cms_ba** bas, int n) {
-  static int cus = 0;
-  if (cus == 0) { hipDeviceProp_t pr; cus = hipGetDeviceProperties(&pr, bas[0]->device) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-  static const bool fixed = getenv("CMS_BA_FIXED_RANGES") != nullptr;
+  static std::mutex mu;
+  static int cus_of[64] = {0};                  // compute units per device (a process may drive several)
+  const int dev = bas[0]->device;
+  int cus = 256;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64) {
+      if (cus_of[dev] == 0) { hipDeviceProp_t pr; cus_of[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+      cus = cus_of[dev];
+    }
+  }
   int R = BA_SE_RANGES;
-  if (!fixed && n > 0) R = std::max(4, std::min(BA_SE_RANGES, cus / n));
+  if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, cus / n));
   return R;
+}
+// Which kernels a group's rounds are made of: decided ONCE per group from the windows' lists and the knobs (ba_upload_items and the stage
+// driver both use it).  fused: the Schur kernel linearises itself (edge-major kernels + three-lane solve); rm: windows with signature runs
+// send them through the run-major body (needs the fused path and full 512-thread workgroups)
+struct BaGroupMode { bool use_se, use_te, use_s3, fused, rm; int se_waves; };
+static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
+  BaGroupMode m;
+  m.use_se = ba_use_se(bas, n); m.use_te = ba_use_te(bas, n);
+  m.use_s3 = !ba_knobs().solve1;
+  m.se_waves = BA_SE_THREADS / 64;
+  size_t rm_lds = 0;
+  for (int w = 0; w < n; ++w) {
+    m.use_s3 = m.use_s3 && bas[w]->solve_blk3;
+    if (bas[w]->se_waves > 0) m.se_waves = std::min(m.se_waves, bas[w]->se_waves);
+    rm_lds = std::max(rm_lds, bas[w]->rm_lds);
+  }
+  m.fused = m.use_se && m.use_te && m.use_s3 && !ba_knobs().no_fused;
+  m.rm = m.fused && rm_lds > 0 && m.se_waves == BA_SE_THREADS / 64 && !ba_knobs().runs_as_edges;
+  return m;
 }
 static int ba_upload_items(cms_ba** bas, int n) {
   cms_ba* g = bas[0];
   BaItem* items = reinterpret_cast<BaItem*>(g->grp_items_host);
   const bool all_sp = ba_all_sp(bas, n);
-  const bool use_se = ba_use_se(bas, n);
+  const BaGroupMode gm = ba_group_mode(bas, n);
+  const bool use_se = gm.use_se;
   for (int w = 0; w < n; ++w) {
     cms_ba* b = bas[w];
     BaItem& it = items[w];
@@ -238,13 +264,16 @@ static int ba_upload_items(cms_ba** bas, int n) {
     if (all_sp) { it.chunk_sum = b->d_sp_sum; it.pair_chunk_off = b->d_sp_chunk_off; }
     it.se = b->se;
     if (!use_se) { it.se.R = 0; it.se.Rt = 0; }
-    if (use_se && !ba_use_te(bas, n)) it.se.Rt = 0;
+    if (!use_se) { it.se.nchunks = 0; it.se.n_rm = 0; it.se.R_rm = 0; }
+    if (use_se && !gm.use_te) it.se.Rt = 0;
     if (use_se) { it.chunk_sum = b->d_se_sum; it.pair_chunk_off = b->d_se_chunk_off; it.pair_of_block = b->d_se_pob; }
-    if (use_se && it.se.R > 0) {
-      const int Rg = std::min(it.se.R, ba_group_ranges(bas, n));
-      it.se.cpw = std::max(1, (it.se.nchunks + Rg - 1) / Rg);
-      it.se.R = (it.se.nchunks + it.se.cpw - 1) / it.se.cpw;
+    if (use_se) {
+      // workgroups of this window in the group's Schur launch: one workgroup fills a CU, so the group shares the chip's CUs; a window's share
+      // is split between its run chunks and its left-over chunks (without the run-major body the edge-major one takes every chunk)
+      if (!gm.rm) it.se.n_rm = 0;
+      ba_se_split(it.se, ba_group_ranges(bas, n));
     }
+    b->grp_se = it.se;
   }
   HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
   return CMS_OK;
@@ -349,21 +378,22 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1; dyn.fold_finish = 1;
   bool first_round = false;
   for (int w = 0; w < n; ++w) first_round = first_round || st[w].it == 0;
-  const bool use_se = ba_use_se(bas, n);
-  const bool use_te = ba_use_te(bas, n);
+  const BaGroupMode gm = ba_group_mode(bas, n);
+  const bool use_se = gm.use_se, use_te = gm.use_te;
   bool iter_phase = true;           // fused linearisation: only the first round of a stage has an ITER phase
   // trial solve: three lanes per 6x6 block where every window allows it (CMS_BA_SOLVE1=1: one lane per block, the single-window kernel's scheme)
-  static const bool solve1 = getenv("CMS_BA_SOLVE1") != nullptr;
-  bool use_s3 = !solve1;
+  const bool use_s3 = gm.use_s3;
   int s3_threads = 64; size_t lds3 = 0;
+  for (int w = 0; w < n; ++w) { s3_threads = std::max(s3_threads, (3 * (bas[w]->np * (bas[w]->np + 1) / 2) + 63) / 64 * 64); lds3 = std::max(lds3, bas[w]->blk3_lds); }
+  int max_seR = 0, max_np2 = 0, max_Rt = 0; size_t se_lds = 0, te_lds = 0, rm_lds = 0;
+  const int se_waves = gm.se_waves;
+  bool any_runs = false;
   for (int w = 0; w < n; ++w) {
-    use_s3 = use_s3 && bas[w]->solve_blk3;
-    s3_threads = std::max(s3_threads, (3 * (bas[w]->np * (bas[w]->np + 1) / 2) + 63) / 64 * 64); lds3 = std::max(lds3, bas[w]->blk3_lds);
-  }
-  int max_seR = 0, max_np2 = 0, max_Rt = 0, se_waves = BA_SE_THREADS / 64; size_t se_lds = 0, te_lds = 0;
-  for (int w = 0; w < n; ++w) {
-    max_seR = std::max(max_seR, std::min(bas[w]->se.R, ba_group_ranges(bas, n))); max_np2 = std::max(max_np2, bas[w]->se.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds_fixed); se_waves = std::min(se_waves, bas[w]->se_waves > 0 ? bas[w]->se_waves : se_waves);
-    max_Rt = std::max(max_Rt, bas[w]->se.Rt); te_lds = std::max(te_lds, ((size_t)24 * bas[w]->K + 6 * (size_t)std::max(bas[w]->np, 1)) * sizeof(double));
+    const BaSe& gs = bas[w]->grp_se;             // this group's split of the window (ba_upload_items)
+    max_seR = std::max(max_seR, gs.R_rm + gs.R); max_np2 = std::max(max_np2, gs.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds_fixed);
+    any_runs = any_runs || gs.R_rm > 0;
+    if (gs.R_rm > 0) rm_lds = std::max(rm_lds, bas[w]->rm_lds);
+    max_Rt = std::max(max_Rt, gs.Rt); te_lds = std::max(te_lds, ((size_t)24 * bas[w]->K + 6 * (size_t)std::max(bas[w]->np, 1)) * sizeof(double));
   }
   // One "round" = the launches of one Levenberg trial (plus the linearisation in front of it for the windows that start an iteration).
   // The host never synchronises the stream inside a stage: a synchronisation -- or an event -- after a round makes the chip publish
@@ -373,15 +403,17 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // the flag is then honoured at the very next trial boundary).  It looks at the mirrored state and at the caller's stop flag before
   // every round it adds; the price is at most two rounds of idle launches after the last window finished.
   se_lds += (size_t)se_waves * ((size_t)64 * 18 * sizeof(double) + 64 * sizeof(int));      // the group runs with the wavefront count its largest window allows
+  se_lds = std::max(se_lds, rm_lds);                                                        // (the run-major body's chunk buffers, when a window has runs)
   const int se_threads = 64 * se_waves;
   // linearisation inside the Schur kernel (cms_ba_schur_edges.hip, FUSED): needs the edge-major kernels and the three-lane solve
-  static const bool no_fused = getenv("CMS_BA_NO_FUSED_LIN") != nullptr;
-  const bool fused = use_se && use_te && use_s3 && !no_fused;
+  const bool fused = gm.fused;
+  // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
+  const bool solve_reduces = fused && !ba_knobs().separate_reduce;
   dyn.fused_lin = fused ? 1 : 0;
   int k = 0;
   const int pk = g->prof_kernel;
-  static const int dup = getenv("CMS_BA_DUP") ? atoi(getenv("CMS_BA_DUP")) : 0;   // developer knob: launch kernel <id> of every round twice (all of
-                                                                                 // 1 lin, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points are idempotent): how much does the step pay for it?
+  const int dup = ba_knobs().dup;   // developer knob: launch kernel <id> of every round twice (all of
+                                    // 1 lin, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points are idempotent): how much does the step pay for it?
   auto bracket = [&](int id, int which) {     // HIP events around the one kernel the caller asked to have timed (cms_ba_profile_kernel)
     if (pk != id) return;
     const size_t i = 2 * (size_t)k + which;
@@ -409,7 +441,10 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       if (use_se) {
         bracket(3, 0);
-        if (fused) {
+        if (fused && any_runs) {
+          hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        } else if (fused) {
           hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
           if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         } else {
@@ -418,7 +453,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         }
         bracket(3, 1);
         bracket(4, 0);
-        hipLaunchKernelGGL(kb_ba_schur_edges_reduce, dim3(max_np2, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (!solve_reduces) hipLaunchKernelGGL(kb_ba_schur_edges_reduce, dim3(max_np2, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         bracket(4, 1);
       } else if (all_sp) {
         bracket(3, 0);
@@ -433,7 +468,10 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       }
       bracket(5, 0);
-      if (use_s3) {
+      if (use_s3 && solve_reduces) {
+        hipLaunchKernelGGL(kb_ba_trial_solve3r, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        if (dup == 5) hipLaunchKernelGGL(kb_ba_trial_solve3r, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      } else if (use_s3) {
         hipLaunchKernelGGL(kb_ba_trial_solve3, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         if (dup == 5) hipLaunchKernelGGL(kb_ba_trial_solve3, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       } else {
@@ -520,7 +558,7 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
 extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats) {
   if (!bas || n < 1) return cms_fail(CMS_ERR_ARG, "cms_ba_optimize_many: bad argument");
   for (int w = 0; w < n; ++w) if (!bas[w]) return cms_fail(CMS_ERR_ARG, "null ba");
-  auto kind = [&](int w) { return bas[w]->device * 2 + (bas[w]->se.R > 0 ? 1 : 0); };
+  auto kind = [&](int w) { return bas[w]->device * 2 + (bas[w]->se.nchunks > 0 ? 1 : 0); };
   bool one = n <= BA_MAX_GROUP;
   for (int w = 1; w < n && one; ++w) one = kind(w) == kind(0);
   if (one) return ba_optimize_group(bas, n, its_robust, its_final, stop, stats);
@@ -555,7 +593,10 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
   const double delta = std::sqrt(5.991);
   std::vector<BaLm> st(n);
   for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_robust; st[w].robust = 1; st[w].delta = delta; }
-  const bool host_lm = getenv("CMS_BA_HOST_LM") != nullptr;
+  const bool host_lm = ba_knobs().host_lm;
+  for (int w = 0; w < n; ++w)      // (cannot happen while the knobs are read once: the lists were chosen by the same switches)
+    if (bas[w]->se_only && (!batched || host_lm || !ba_use_se(bas, n)))
+      return cms_fail(CMS_ERR_UNSUPPORTED, "cms_ba_optimize: the window carries only the edge-major work list but another kernel path was selected");
   int rc = batched ? (host_lm ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_batched_dev(bas, n, st, stop)) : ba_optimize_stage_many(bas, n, st, stop);
   if (rc) return rc;
   for (int w = 0; w < n; ++w) {

@@ -425,6 +425,10 @@ extern "C" int cms_frames_upload_async(cms_ctx* c, const uint8_t* fisheye, int f
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_upload_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_remap_done, hipEventDisableTiming));
+    // first upload of this context: a remap of an earlier, not yet synchronised cms_frames_process may still read the staging buffer, and it
+    // was enqueued before this event existed -- everything the frame stream holds so far goes in front of the copy
+    HIPCHK(hipEventRecord(c->ev_remap_done, c->stream));
+    c->remap_recorded = true;
   }
   if (c->remap_recorded) HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_remap_done, 0));   // write-after-read on the staging buffer
   if (fstride == c->fstride && (frame_pitch == c->fish_pitch || B == 1)) {

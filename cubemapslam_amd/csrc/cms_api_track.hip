@@ -86,7 +86,7 @@ extern "C" int cms_search_local_points(cms_ctx* c, int b, const float* pose15, i
     const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
     int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
     if (rc) return rc;
-    rc = cms_hstage(c, std::max(in_bytes, out_bytes));
+    rc = cms_hstage(c, std::max(in_bytes, out_begin + out_bytes));      // the read-back lands at h + out_begin, not at h
     if (rc) return rc;
     uint8_t* p = (uint8_t*)c->d_match;
     uint8_t* h = c->h_stage;
@@ -203,7 +203,7 @@ extern "C" int cms_search_by_projection(cms_ctx* c, int b, const float* pose12, 
     const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
     int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
     if (rc) return rc;
-    rc = cms_hstage(c, std::max(in_bytes, out_bytes));
+    rc = cms_hstage(c, std::max(in_bytes, out_begin + out_bytes));      // the read-back lands at h + out_begin, not at h
     if (rc) return rc;
     uint8_t* p = (uint8_t*)c->d_match;
     uint8_t* h = c->h_stage;
@@ -253,10 +253,15 @@ extern "C" int cms_search_for_initialization(cms_ctx* c, int b2, int n1, const c
   if (n_matches) *n_matches = 0;
   if (n1 == 0) return CMS_OK;
   HIPCHK(hipSetDevice(c->device));
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&]() { attr_err = hipFuncSetAttribute((const void*)k_init_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
-  HIPCHK(attr_err);
+  {   // the attribute is per device: one flag per device, like ba_lds_attrs_once / cms_area_reserve
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (c->device >= 0 && c->device < 64 && !done[c->device]) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_init_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      done[c->device] = true;
+    }
+  }
   const size_t lds = (size_t)c->g.kp_cap * 8;
   if (lds > 160 * 1024 - 1024) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_for_initialization: too many key points per frame for the LDS tables");
   hipStream_t s = c->stream;
@@ -281,7 +286,7 @@ extern "C" int cms_search_for_initialization(cms_ctx* c, int b2, int n1, const c
     const size_t o_idx = fixed, o_pd = fixed + al((size_t)cap * 4);
     int rc = cms_scratch(c, o_pd + al((size_t)cap * 2));
     if (rc) return rc;
-    rc = cms_hstage(c, std::max(in_bytes, out_bytes));
+    rc = cms_hstage(c, std::max(in_bytes, out_begin + out_bytes));      // the read-back lands at h + out_begin, not at h
     if (rc) return rc;
     uint8_t* p = (uint8_t*)c->d_match;
     uint8_t* h = c->h_stage;

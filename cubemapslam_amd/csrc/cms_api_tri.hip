@@ -256,8 +256,9 @@ extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
 
 extern "C" int cms_kfstore_create(cms_kfstore** out, cms_ctx* c, int max_keyframes, int max_features, int max_nodes) {
   if (!out || !c || max_keyframes < 1 || max_features < 1 || max_features > CMS_AREA_MAXKP || max_nodes < 1)
-    return cms_fail(CMS_ERR_ARG, "cms_kfstore_create: bad argument (at most 4095 features per key frame)");
+    return cms_fail(CMS_ERR_ARG, "cms_kfstore_create: bad argument (at most 16383 features per key frame)");
   HIPCHK(hipSetDevice(c->device));
+  { const int rca = cms_area_grid_attr(c->device); if (rca) return rca; }      // cms_kfstore_put launches k_area_grid with up to 128 KB of LDS
   cms_kfstore* st = new cms_kfstore();
   st->c = c; st->maxkf = max_keyframes; st->maxf = max_features; st->maxn = max_nodes;
   const size_t K = (size_t)max_keyframes, Fq = (size_t)max_features, Nq = (size_t)max_nodes;

@@ -26,7 +26,7 @@ k_area_grid(const CmsKeyPoint* __restrict__ kps, const int* __restrict__ kp_cnt,
   uint32_t* sorted = area_lds + (kp_cap + 1);
   __shared__ int s_nvalid;
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-  const int n = min(kp_cnt[b], CMS_AREA_MAXKP);
+  const int n = min(kp_cnt[b], min(kp_cap, CMS_AREA_MAXKP));      // the LDS arrays hold kp_cap + 1 entries each
   const CmsKeyPoint* kp = kps + (size_t)b * kp_cap;
   if (tid == 0) s_nvalid = 0;
   __syncthreads();

@@ -308,18 +308,31 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
-                 double* __restrict__ xp_out, double* __restrict__ scal, bool lumped = false) {
+                 double* __restrict__ xp_out, double* __restrict__ scal, bool lumped = false, const double* __restrict__ partial = nullptr,
+                 const double* __restrict__ bp_partial = nullptr, int n_slices = 0, int NP2 = 0) {
   // lumped: the diagonal blocks of chunk_sum hold S - Hpp and s - bp already (fused linearisation, cms_ba_schur_edges.hip); bp is only
   // read for the gain ratio
+  // partial != nullptr (implies lumped): the Schur kernel's range slices [n_slices][NP2][42] are summed here, in slice order, instead of by
+  // kb_ba_schur_edges_reduce -- one launch less per round; bp (sum of the slices of bp_partial) is formed in LDS and stored for later readers
   extern __shared__ __align__(16) double sm[];
   const int nb = d.np, n = 6 * nb, nblk = nb * (nb + 1) / 2;
-  // LDS (doubles): L panels [nb (nb - 1) / 2][38] | diagonal factors [nb][36] | W double buffer [2][nb][38] | diag staging [36] | y [n] | 1/D [n]
+  // LDS (doubles): L panels [nb (nb - 1) / 2][38] | diagonal factors [nb][36] | W double buffer [2][nb][38] | diag staging [36] | y [n] | 1/D [n] | bp [n]
   double* Lp = sm;
   double* Ldg = Lp + (size_t)BA_S3_STRIDE * (nb * (nb - 1) / 2);
   double* Wbuf = Ldg + 36 * (size_t)nb;
   double* dstage = Wbuf + 2 * (size_t)BA_S3_STRIDE * nb;
   double* ybuf = dstage + 36;
   double* idg = ybuf + n;
+  double* bps = idg + n;
+  if (partial) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int s1 = i / 6, c = i - 6 * s1;
+      double v = 0.0;
+      for (int r = 0; r < n_slices; ++r) v += bp_partial[((size_t)r * nb + s1) * 6 + c];
+      bps[i] = v;
+      const_cast<double*>(bp)[i] = v;
+    }
+  }
   __shared__ int bad;
   const int tid = threadIdx.x;
   const int blk = tid / 3, rp = tid - 3 * blk;
@@ -345,7 +358,17 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __re
     }
     const int pr = pair_of_block[I * (I + 1) / 2 + K];
     double yb[2] = {0, 0};
-    if (pr >= 0) {
+    if (partial) {
+      // dense pair enumeration (se_pob): slice r holds this pair's 42 sums at (r NP2 + pr) 42; two slices' loads are in flight together
+      // (the kernel is compiled for up to 1024 threads, 128 registers: four slices spilled)
+#pragma unroll 2
+      for (int r = 0; r < n_slices; ++r) {
+        const double* cs = partial + ((size_t)r * NP2 + pr) * 42;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { a[q] -= cs[6 * q + r0]; a[6 + q] -= cs[6 * q + r0 + 1]; }
+        if (I == K) { yb[0] += cs[36 + r0]; yb[1] += cs[36 + r0 + 1]; }
+      }
+    } else if (pr >= 0) {
       for (int c = pair_chunk_off[pr]; c < pair_chunk_off[pr + 1]; ++c) {
         const double* cs = chunk_sum + (size_t)c * 42;
         // chunk sums are stored for the pair (s1 = K) <= (s2 = I), i.e. for block (K, I): transpose into (I, K)
@@ -480,7 +503,7 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __re
   if (isbad) for (int i = tid; i < n; i += blockDim.x) ybuf[i] = 0.0;
   __syncthreads();
   for (int i = tid; i < n; i += blockDim.x) xp_out[i] = ybuf[i];
-  ba_trial_pose_update(d, ybuf, bp, lambda, poses, poses_new, scal, isbad);
+  ba_trial_pose_update(d, ybuf, partial ? bps : bp, lambda, poses, poses_new, scal, isbad);      // (bps was complete before the first barrier above)
 }
 
 // per point: x_l = Dinv (b_l - sum B^T x_p), X_new = X + x_l, gain-denominator partial; then residuals + robust chi2 of the

@@ -47,7 +47,11 @@
 #define BA_SE_RANGES 128          /* workgroups per window at most (a window alone; a group shares the chip: ba_group_ranges) */
 
 struct BaSe {                      // device view of the edge-major work list (cms_api_ba.hip)
-  int R, nchunks, cpw;            // ranges (workgroups), chunks, chunks per range
+  int R, nchunks, cpw;            // ranges (workgroups) of the edge-major body over the chunks [n_rm, nchunks), all chunks, chunks per range
+  int n_rm, R_rm;                 // chunks [0, n_rm) hold points of ONE observation signature each (cms_ba_schur_runs.hip): R_rm workgroups take them;
+                                  // their slices of `partial` come first, the edge-major ranges' slices follow (R_rm + R slices in all)
+  const int4* rm_chunk;           // n_rm: first edge | edges + (edges per point << 8) + (points << 16) | run | ceil(65536 / edges per point)
+  const uint2* run_lane;          // runs x 64: which tuple of the signature a consumer lane multiplies, and where its sum goes (ba_rm_lane_*)
   int Rt, cpw_t;                  // the same chunks cut into more, shorter ranges for the edge-major trial kernel (no LDS copy of the system to amortise)
   int npairs2;                    // np (np + 1) / 2: pose pairs s1 <= s2 enumerated densely, row by row
   const int* chunk_e0;            // nchunks + 1: first edge of every chunk (whole points, <= 64 edges)
@@ -85,6 +89,7 @@ __device__ __forceinline__ void ba_se_cam_point(const double* Rt, const double* 
 // S_aa - Hpp_aa, its right-hand side  s_a - bp_a; bp alone goes to six more slots: the gain ratio needs it).  From the second iteration
 // of a stage on no other kernel linearises: kb_ba_lin + kb_ba_maxdiag drop out of the round (25 + 7 us of ~165 for eight windows), and a
 // rejected trial merely repeats arithmetic this kernel had to do anyway (it rebuilt the Jacobians from the estimate before, too).
+template <bool FUSED> __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSe& se);
 template <bool FUSED>
 __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                     const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
@@ -109,7 +114,7 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, do
   __syncthreads();
   double* myrows = rows + (size_t)wave * 64 * 18;
   int* myslot = rslot + wave * 64;
-  const int c0 = BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);
+  const int c0 = se.n_rm + BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);      // (the chunks in front of n_rm belong to the run-major body)
   // The loop is software pipelined over a wave's chunks: the per-edge words of chunk c + nw are requested before chunk c is worked on,
   // its per-point operands (position, Hll, bl) right after chunk c's rows are published -- the atomics section hides their latency.
   int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;          // FUSED: n_ow carries the edge's information (0 for an excluded edge)
@@ -314,8 +319,15 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, do
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // ---- this range's slice of `partial`, in the dense pair enumeration the reduction and the solve kernel use
   __syncthreads();
+  ba_se_writeout<FUSED>(se.R_rm + BX, np, NP2, S, Dg, se);
+}
+
+// ---- a workgroup's LDS copy of the reduced system -> its slice of `partial`, in the dense pair enumeration the reduction and the solve kernel use
+template <bool FUSED>
+__device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSe& se) {
+  const int tid = threadIdx.x;
+  const int BX = slice;
   for (int o = tid; o < NP2 * 42; o += blockDim.x) {
     const int pr = o / 42, i = o - 42 * pr;
     int s1 = 0, off = 0;

@@ -1,0 +1,317 @@
+// cms_ba_schur_runs.hip -- linearisation + Schur complement of a Levenberg trial, RUN-major: points that are seen by the same set of key
+// frames (one "observation signature") are worked on together, and their 6x6 products are summed in REGISTERS before anything is added to
+// the workgroup's LDS copy of the reduced system.
+//
+// The edge-major kernel (cms_ba_schur_edges.hip) adds every element of every tuple product to LDS with ds_add_f64: 36 atomic wave
+// instructions per tuple step, ~90 per 64 observations, at two wavefronts per SIMD (148 KB of LDS per workgroup).  It is bound by the latency
+// of those additions, not by arithmetic (profiles/r02: LDS pipe 45 % busy, vector ALU issue a third of the launch).  A local window's points
+// are not seen by arbitrary subsets of its key frames, though: a map point is tracked over a stretch of consecutive key frames, so many
+// points share their signature -- with K = 20 key frames and 22 k points (configs[3]) a few hundred signatures cover the window.  The host
+// (cms_ba_create) groups the points by signature; a signature with enough points becomes a RUN, cut into chunks of whole points with at
+// most 64 observations; what is left over (rare signatures, the tail of a run) goes through the edge-major kernel as before.
+//
+// A workgroup has four PRODUCER and four CONSUMER wavefronts, paired one to one; every SIMD hosts one of each (two wavefronts per SIMD,
+// different instruction mixes).  A pair walks a contiguous range of run chunks, the consumer one chunk behind the producer:
+//
+//   producer  lane = observation, exactly the front half of the fused edge-major kernel: residual (bit for bit the one kb_ba_errors / the
+//             trial kernel store), Huber weight, Jacobians; the lanes of a point exchange their 3x3 / 3x1 shares through the chunk's LDS
+//             rows and add them in edge order (Hll, bl: the first lane stores them for the trial kernel); A = Hll + lambda I = L D L^T;
+//             W = B L^-T goes to the lane's row, D^-1 and z = D^-1 L^-1 bl to the point's slot.  The key frame's own block ow Jp^T Jp and
+//             gradient -- 27 sums per lane -- stay in registers for as long as the run lasts: lane (point j, edge a) sees the same key frame
+//             in every chunk of a run.
+//   consumer  lane = (sequence q, tuple t of the signature): the run's k (k + 1) / 2 pose pairs are spread over the lanes, Q = 64 / tuples
+//             lanes share a pair and take the chunk's points q, q + Q, ...  A lane reads W_a, W_b, D^-1 of its point (21 16-byte LDS reads)
+//             and accumulates W_a D^-1 W_b^T (and W_a z on the diagonal pairs) into 42 registers -- the pair never changes inside a run.
+//
+// Only when the run ends (or the pair's range does) are the sums added to the LDS copy of the reduced system: 36 ds_add_f64 per consumer
+// lane and 33 per producer lane PER RUN instead of ~90 per chunk.  The copy, the write-out of the workgroup's slice and everything behind
+// it (kb_ba_schur_edges_reduce, kb_ba_trial_solve3, kb_ba_trial_edges) are shared with the edge-major kernel: the two bodies are ONE launch
+// (kb_ba_lin_schur_runs: the first R_rm workgroups of a window run this body, the rest the edge-major one on the left-over chunks).
+// (block_solver.hpp:367-437: Hschur -= Bi Dinv Bj^T, bschur -= Bi Dinv bl; base_binary_edge.hpp:54-120.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BA_RM_PAIRS 4                         /* producer / consumer pairs per workgroup (8 wavefronts, BA_SE_THREADS = 512) */
+#define BA_RM_PTS 32                          /* points per chunk at most (64 observations, >= 2 per point) */
+#define BA_RM_BUF (64 * 18 + BA_RM_PTS * 6)   /* doubles per chunk buffer: a W row per lane | D^-1 (3) and z (3) per point */
+
+// run_lane[run * 64 + lane]: x = position of edge a within the point | position of edge b << 5 | sequence q << 10 | sequences Q << 16 |
+// valid << 23 | diagonal << 24;  y = where the lane's sums go, in doubles from the start of the LDS copy (a 37-double block of S for an
+// off-diagonal pair, a 33-double row of the diagonal copies for a diagonal one)
+__host__ __device__ constexpr uint32_t ba_rm_lane_word(int pa, int pb, int q, int Q, bool diag) {
+  return (uint32_t)pa | ((uint32_t)pb << 5) | ((uint32_t)q << 10) | ((uint32_t)Q << 16) | (1u << 23) | ((diag ? 1u : 0u) << 24);
+}
+
+__device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+                                                   const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
+#pragma clang fp contract(fast)
+  extern __shared__ __align__(16) double se_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
+  double* S = se_lds;                                              // same layout as the edge-major body: the write-out is shared
+  double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);
+  double* bufs = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // BA_RM_PAIRS x 2 chunk buffers (16-byte aligned: all terms are even)
+  double* prt = bufs + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF;        // K x 12: rotation (row major) | translation of every key frame
+  for (int i = tid; i < (int)(bufs - S); i += blockDim.x) S[i] = 0.0;
+  for (int k = tid; k < d.K; k += blockDim.x) {
+    double R[9];
+    quat_to_R(poses + 7 * k + 3, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) prt[12 * k + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prt[12 * k + 9 + i] = poses[7 * k + i];
+  }
+  __syncthreads();
+  const int pi = wave & (BA_RM_PAIRS - 1);
+  const bool producer = __builtin_amdgcn_readfirstlane(wave) < BA_RM_PAIRS;      // a scalar branch: the two roles are separate loops (separate
+                                                                               // register live ranges), each with its own barrier per step
+  // chunk ranges of the workgroup's pairs: an even split of the window's run chunks over all pairs of all run-major workgroups
+  const long long total_pairs = (long long)se.R_rm * BA_RM_PAIRS;
+  int cb = 0, ce = 0, nsteps = 0;
+#pragma unroll
+  for (int i = 0; i < BA_RM_PAIRS; ++i) {
+    const long long g = (long long)BX * BA_RM_PAIRS + i;
+    const int b0 = (int)(g * se.n_rm / total_pairs), b1 = (int)((g + 1) * se.n_rm / total_pairs);
+    if (i == pi) { cb = b0; ce = b1; }
+    nsteps = max(nsteps, b1 - b0);
+  }
+  nsteps += 1;                                                      // the consumer runs one chunk behind
+  double* mybufs = bufs + (size_t)pi * 2 * BA_RM_BUF;
+
+  if (producer) {
+  // ---- producer state: the next chunk's per-edge words travel while the current chunk is worked on (as in the edge-major body)
+  double hp[27];                                                   // key frame's own block (21) and gradient (6), summed over the run
+#pragma unroll
+  for (int i = 0; i < 27; ++i) hp[i] = 0.0;
+  int hp_slot = -1;
+  int4 n_desc = make_int4(0, 0, -1, 0);
+  int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;
+  double n_X[3] = {0, 0, 0};
+  double2 n_obs = make_double2(0.0, 0.0);
+  auto load1 = [&](int c) {
+    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0; n_desc = make_int4(0, 0, -1, 0);
+    if (c < ce) {
+      n_desc = se.rm_chunk[c];
+      const int e = n_desc.x + lane;
+      if (lane < (n_desc.y & 255)) {
+        n_p = d.e_point[e]; n_info = se.e_info[e]; n_e = e;
+        n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0;
+        n_obs = reinterpret_cast<const double2*>(d.e_obs)[e];
+      }
+    }
+  };
+  auto load2 = [&]() {
+    if (n_info != 0) {
+      const double* Xp = pts + 3 * (size_t)n_p;
+      n_X[0] = Xp[0]; n_X[1] = Xp[1]; n_X[2] = Xp[2];
+    }
+  };
+  load1(cb); load2();
+  for (int s = 0; s < nsteps; ++s) {
+    {
+      const int c = cb + s;
+      if (c < ce) {
+        double* buf = mybufs + (size_t)(s & 1) * BA_RM_BUF;
+        const int4 desc = n_desc;
+        const uint32_t info = n_info;
+        double ow = n_ow;
+        const int pnt = n_p, eid = n_e;
+        const double2 obs = n_obs;
+        const double X[3] = {n_X[0], n_X[1], n_X[2]};
+        load1(c + 1);
+        const int k_run = (desc.y >> 8) & 255;
+        int slot = -1, a = 0;
+        double Jp[12], Jl[6], o0 = 0.0, o1 = 0.0;
+        bool have_jac = false;
+        if (info != 0) {
+          a = info & 31;
+          const int s_ = (int)((info >> 10) & 63) - 1, face = (info >> 16) & 7, kp = (info >> 19) & 255;
+          if (ow != 0.0) {
+            const double* Rt = prt + 12 * kp;
+            double R[9], Xc[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+            ba_se_cam_point(Rt, X, Xc);
+            double r[2], rho0;
+            edge_error_v(d, face, obs.x, obs.y, Xc, r);
+            const double om = ow;
+            const double w = robust ? huber_w(om * (r[0] * r[0] + r[1] * r[1]), delta, &rho0) : 1.0;
+            ow = w * om;
+            o0 = -om * r[0] * w; o1 = -om * r[1] * w;
+            edge_jac_face(d, face, Xc, R, Jp, Jl);
+            have_jac = true;
+            if (s_ >= 0) slot = s_;
+          }
+          if (s_ >= 0) hp_slot = s_;                               // where this lane's key-frame sums go at the end of the run
+        }
+        // ---- Hll and bl of the point: every lane publishes its edge's share in its row, then adds the rows of its point's edges in edge
+        // order -- the order ba_lin_points_body adds them in; all lanes of a point end up with the same bits
+        double hl[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) hl[i] = 0.0;
+        if (have_jac) {
+          hl[0] = ow * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); hl[1] = ow * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); hl[2] = ow * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
+          hl[3] = ow * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); hl[4] = ow * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); hl[5] = ow * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+          hl[6] = Jl[0] * o0 + Jl[3] * o1; hl[7] = Jl[1] * o0 + Jl[4] * o1; hl[8] = Jl[2] * o0 + Jl[5] * o1;
+        }
+        if (info != 0) d.ow[eid] = have_jac ? ow : 0.0;            // the trial kernel rebuilds the edge's block from it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        {
+          double2* row2 = reinterpret_cast<double2*>(buf + (size_t)lane * 18);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) row2[i] = make_double2(hl[2 * i], hl[2 * i + 1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double sum[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) sum[i] = 0.0;
+        for (int j = 0; j < k_run; ++j) {                          // every point of a run chunk has k_run edges
+          if (info != 0) {
+            const double2* row2 = reinterpret_cast<const double2*>(buf + (size_t)(lane - a + j) * 18);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { const double2 u = row2[i]; sum[2 * i] += u.x; sum[2 * i + 1] += u.y; }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // the rows are reused for W below
+        if (info != 0 && a == 0) {
+          double* H = Hll + 9 * (size_t)pnt; double* bq = bl + 3 * (size_t)pnt;
+          H[0] = sum[0]; H[1] = sum[1]; H[2] = sum[2]; H[3] = sum[1]; H[4] = sum[3]; H[5] = sum[4]; H[6] = sum[2]; H[7] = sum[4]; H[8] = sum[5];
+          bq[0] = sum[6]; bq[1] = sum[7]; bq[2] = sum[8];
+        }
+        double W[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) W[i] = 0.0;
+        if (info != 0) {
+          // A = Hll + lambda I = L D L^T (unit lower L); every lane of the point computes the same factors
+          const double a00 = sum[0] + lambda, a10 = sum[1], a11 = sum[3] + lambda, a20 = sum[2], a21 = sum[4], a22 = sum[5] + lambda;
+          const double i0 = 1.0 / a00;
+          const double l10 = a10 * i0, l20 = a20 * i0;
+          const double d1 = a11 - l10 * a10;
+          const double i1 = 1.0 / d1;
+          const double l21 = (a21 - l20 * a10) * i1;
+          const double d2 = a22 - l20 * a20 - l21 * (l21 * d1);
+          const double i2 = 1.0 / d2;
+          if (a == 0) {                                            // the point's slot: D^-1 | z = D^-1 L^-1 bl
+            const double y0 = sum[6], y1 = sum[7] - l10 * y0, y2 = sum[8] - l20 * y0 - l21 * y1;
+            const int j = ((lane - a) * desc.w) >> 16;             // point of the chunk: lane / k_run
+            double2* pp = reinterpret_cast<double2*>(buf + 64 * 18 + (size_t)j * 6);
+            pp[0] = make_double2(i0, i1); pp[1] = make_double2(i2, i0 * y0); pp[2] = make_double2(i1 * y1, i2 * y2);
+          }
+          if (slot >= 0) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              const double q0 = ow * (Jp[r] * Jl[0] + Jp[6 + r] * Jl[3]);          // row r of B = ow Jp^T Jl
+              const double q1 = ow * (Jp[r] * Jl[1] + Jp[6 + r] * Jl[4]);
+              const double q2 = ow * (Jp[r] * Jl[2] + Jp[6 + r] * Jl[5]);
+              const double w0 = q0, w1 = q1 - w0 * l10, w2 = q2 - w0 * l20 - w1 * l21;     // W L^T = B
+              W[3 * r] = w0; W[3 * r + 1] = w1; W[3 * r + 2] = w2;
+            }
+            // the key frame's own block and gradient: summed here until the run ends
+            int cidx = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+              for (int q = r; q < 6; ++q) hp[cidx++] += ow * (Jp[r] * Jp[q] + Jp[6 + r] * Jp[6 + q]);
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) hp[21 + r] += Jp[r] * o0 + Jp[6 + r] * o1;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        {
+          double2* row2 = reinterpret_cast<double2*>(buf + (size_t)lane * 18);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) row2[i] = make_double2(W[2 * i], W[2 * i + 1]);
+        }
+        load2();
+        // ---- end of the run (or of this pair's range): S_aa - Hpp_aa and s_a - bp_a get the key frame's part, bp its own six slots.  Lanes
+        // of one key frame are k_run apart; they are spread over the four diagonal copies by their point
+        if (n_desc.z != desc.z) {
+          if (hp_slot >= 0) {
+            const int j = ((lane - a) * desc.w) >> 16;
+            double* base = Dg + ((size_t)(j & (BA_SE_DCOPIES - 1)) * np + hp_slot) * BA_SE_DSTRIDE;
+#pragma unroll
+            for (int i = 0; i < 21; ++i) unsafeAtomicAdd(base + i, -hp[i]);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) { unsafeAtomicAdd(base + 21 + r, -hp[21 + r]); unsafeAtomicAdd(base + 27 + r, hp[21 + r]); }
+          }
+#pragma unroll
+          for (int i = 0; i < 27; ++i) hp[i] = 0.0;
+          hp_slot = -1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  } else {
+  // ---- consumer state
+  double acc[42];
+#pragma unroll
+  for (int i = 0; i < 42; ++i) acc[i] = 0.0;
+  int cur_run = -1;
+  uint2 lt = make_uint2(0u, 0u);
+  int4 c_desc = cb < ce ? se.rm_chunk[cb] : make_int4(0, 0, -1, 0);       // descriptor of the chunk the next step consumes
+  for (int s = 0; s < nsteps; ++s) {
+    {
+      const int c = cb + s - 1;
+      if (s >= 1 && c < ce) {
+        const double* buf = mybufs + (size_t)((s - 1) & 1) * BA_RM_BUF;
+        const int4 desc = c_desc;
+        c_desc = c + 1 < ce ? se.rm_chunk[c + 1] : make_int4(0, 0, -1, 0);   // (its run is only looked at after the products below)
+        const int next_run = c_desc.z;
+        if (desc.z != cur_run) { cur_run = desc.z; lt = se.run_lane[(size_t)cur_run * 64 + lane]; }
+        const int k_run = (desc.y >> 8) & 255, m = desc.y >> 16;
+        const bool valid = (lt.x >> 23) & 1u, diag = (lt.x >> 24) & 1u;
+        if (valid) {
+          const int pa = lt.x & 31, pb = (lt.x >> 5) & 31, q0 = (lt.x >> 10) & 63, Q = (lt.x >> 16) & 127;
+          const double zsel = diag ? 1.0 : 0.0;
+          for (int j = q0; j < m; j += Q) {
+            const double2* ra = reinterpret_cast<const double2*>(buf + (size_t)(j * k_run + pa) * 18);
+            const double2* rb = reinterpret_cast<const double2*>(buf + (size_t)(j * k_run + pb) * 18);
+            const double2* pp = reinterpret_cast<const double2*>(buf + 64 * 18 + (size_t)j * 6);
+            double Wa[18], Wb[18];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { const double2 u = ra[i], v = rb[i]; Wa[2 * i] = u.x; Wa[2 * i + 1] = u.y; Wb[2 * i] = v.x; Wb[2 * i + 1] = v.y; }
+            const double2 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            const double di[3] = {p0.x, p0.y, p1.x}, z[3] = {p1.y * zsel, p2.x * zsel, p2.y * zsel};
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              const double w0 = Wa[3 * r] * di[0], w1 = Wa[3 * r + 1] * di[1], w2 = Wa[3 * r + 2] * di[2];       // row r of W_a D^-1
+#pragma unroll
+              for (int qq = 0; qq < 6; ++qq) acc[6 * r + qq] += w0 * Wb[3 * qq] + w1 * Wb[3 * qq + 1] + w2 * Wb[3 * qq + 2];
+              acc[36 + r] += Wa[3 * r] * z[0] + Wa[3 * r + 1] * z[1] + Wa[3 * r + 2] * z[2];                     // W_a z (diagonal pairs only)
+            }
+          }
+        }
+        if (next_run != cur_run) {                                 // the run (or this pair's range) ends: one set of additions
+          if (valid) {
+            double* base = S + lt.y;
+            if (diag) {
+              int cidx = 0;
+#pragma unroll
+              for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int qq = r; qq < 6; ++qq) unsafeAtomicAdd(base + (cidx++), acc[6 * r + qq]);
+              }
+#pragma unroll
+              for (int r = 0; r < 6; ++r) unsafeAtomicAdd(base + 21 + r, acc[36 + r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int qq = 0; qq < 6; ++qq) unsafeAtomicAdd(base + ba_se_off(r, qq), acc[6 * r + qq]);      // pa < pb: the lower slot comes first
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 42; ++i) acc[i] = 0.0;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  }
+  ba_se_writeout<true>(BX, np, NP2, S, Dg, se);
+}

@@ -250,14 +250,21 @@ extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_edge
   BA_ITEM(phase, it.se.R)
   ba_schur_edges_body<true>(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
 }
+// ... and with the points of frequent observation signatures taken run-major (cms_ba_schur_runs.hip): the first R_rm workgroups of a window
+// work through its run chunks, the rest through the left-over chunks edge-major -- one launch, one LDS layout, one kind of slice
+extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_runs(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.R_rm + it.se.R)
+  if ((int)blockIdx.x < it.se.R_rm) ba_schur_runs_body(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
+  else ba_schur_edges_body<true>((int)blockIdx.x - it.se.R_rm, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
+}
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_edges_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
-  BA_ITEM(phase, it.se.R > 0 ? it.se.npairs2 : 0)
+  BA_ITEM(phase, it.se.nchunks > 0 ? it.se.npairs2 : 0)
   BaSp v;                                          // the range sum only looks at these three fields
-  v.R = it.se.R; v.npairs = it.se.npairs2; v.partial = it.se.partial;
+  v.R = it.se.R_rm + it.se.R; v.npairs = it.se.npairs2; v.partial = it.se.partial;
   ba_schur_reduce_body(blockIdx.x, v, it.chunk_sum);
   if (dyn.fused_lin && (int)blockIdx.x < it.d.np) {      // bp of key frame blockIdx.x: the ranges' sums, added in fixed order
     __shared__ double bps[6 * BA_SE_RANGES];
-    const int R = min(it.se.R, BA_SE_RANGES);
+    const int R = min(it.se.R_rm + it.se.R, BA_SE_RANGES);
     for (int t = threadIdx.x; t < 6 * R; t += blockDim.x) bps[t] = it.se.bp_partial[((size_t)(t / 6) * it.d.np + blockIdx.x) * 6 + (t % 6)];
     __syncthreads();
     if (threadIdx.x < 6) {
@@ -280,6 +287,12 @@ extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3(const BaIt
   BA_ITEM(phase, 1)
   ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal,
                        dyn.fused_lin != 0);
+}
+// ... and with the sum over the Schur kernel's range slices done by the assembly itself (no kb_ba_schur_edges_reduce launch in the round)
+extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3r(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, 1)
+  ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal,
+                       true, it.se.partial, it.se.bp_partial, it.se.R_rm + it.se.R, it.se.npairs2);
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)

@@ -152,8 +152,14 @@ def _quat_from_R(R):
     return q / np.linalg.norm(q)
 
 
-def ba_problem(K=20, P=20000, obs_per_point=4, F=650, seed=42, outlier_frac=0.05, nlevels=8, scale=1.2):
-    """Config 4 of BASELINE.json: K keyframes on a 2 m arc (KF 0 fixed), P points, obs_per_point views each."""
+def ba_problem(K=20, P=20000, obs_per_point=4, F=650, seed=42, outlier_frac=0.05, nlevels=8, scale=1.2, views="random", dropout=0.07):
+    """Config 4 of BASELINE.json: K keyframes on a 2 m arc (KF 0 fixed), P points, obs_per_point views each.
+
+    views = "random": every point is seen by obs_per_point key frames drawn at random (no structure at all: ~C(K, 4) different observation
+    sets).  views = "track": a map point is TRACKED -- it is seen by a stretch of consecutive key frames along the arc (obs_per_point on
+    average, 2 .. obs_per_point + 3), and every observation of the stretch is missing with probability `dropout` (a failed match).  That is
+    how Tracking / LocalMapping create observations (a point enters the map at a key frame and is re-observed by the following ones until it
+    leaves the view or its scale range), and it is what gives a local window points that share their set of observing key frames."""
     rs = np.random.RandomState(seed)
     Rt, tt = [], []
     for k in range(K):
@@ -180,11 +186,22 @@ def ba_problem(K=20, P=20000, obs_per_point=4, F=650, seed=42, outlier_frac=0.05
     py = (vp + noise[..., 1]).astype(np.float32).astype(np.float64)
     f2 = face_of_pixel(F, px, py)
     ok = (face >= 0) & (f2 >= 0) & (ray_z >= np.cos(np.deg2rad(190.0 / 2)))
-    order = np.argsort(rs.uniform(size=(P, K)), axis=1)
-    ok_o = np.take_along_axis(ok, order, 1)
-    take_o = ok_o & (np.cumsum(ok_o, axis=1) <= obs_per_point)
-    pp, jj = np.nonzero(take_o)
-    kk = order[pp, jj]
+    if views == "track":
+        nvalid = ok.sum(1)                                      # key frames that see the point at all (in front of the camera, on a face)
+        rank = np.cumsum(ok, axis=1) - 1                        # position of a key frame among those
+        ln = np.minimum(np.clip(obs_per_point + rs.choice([-2, -1, -1, 0, 0, 0, 1, 1, 2, 3], size=P), 2, K), nvalid)
+        start = (rs.uniform(size=P) * (nvalid - ln + 1)).astype(int)
+        vis = ok & (rank >= start[:, None]) & (rank < (start + ln)[:, None])
+        keep = vis & ~(rs.uniform(size=(P, K)) < dropout)
+        few = keep.sum(1) < 2                                   # a map point has at least two observations: such a point keeps its whole stretch
+        keep[few] = vis[few]
+        pp, kk = np.nonzero(keep)
+    else:
+        order = np.argsort(rs.uniform(size=(P, K)), axis=1)
+        ok_o = np.take_along_axis(ok, order, 1)
+        take_o = ok_o & (np.cumsum(ok_o, axis=1) <= obs_per_point)
+        pp, jj = np.nonzero(take_o)
+        kk = order[pp, jj]
     u = px[pp, kk] - np.floor(px[pp, kk] / F) * F
     v = py[pp, kk] - np.floor(py[pp, kk] / F) * F
     e_pose, e_point = kk, pp

@@ -1,0 +1,164 @@
+"""Host-only checks of the plan cms_ba_create makes for the run-major Schur kernel (cubemapslam_amd/csrc/cms_ba_schur_runs.hip): the
+index arithmetic of the kernel -- which lane multiplies which pair of observations of which point, where its sum is flushed, which chunks a
+producer / consumer pair walks -- is replayed here in Python on integer stand-ins for the 6x6 products, and has to reproduce the plain
+double loop "for every point, for every pair of its free observations" exactly.  No GPU, no oracle: this is list-construction logic.
+(The graph is what Optimizer::LocalBundleAdjustment hands to g2o, Optimizer.cpp:192-363; the Schur complement it feeds is block_solver.hpp:367-437.)"""
+import numpy as np
+import pytest
+
+from cubemapslam_amd import api, synth
+
+SSTRIDE, DSTRIDE, DCOPIES, PAIRS = 37, 33, 4, 4
+
+
+def _opair(np_, s1, s2):
+    return s1 * np_ - (s1 * (s1 + 1)) // 2 + (s2 - s1 - 1)
+
+
+def _structure(prob):
+    P, E = len(prob["points"]), len(prob["e_pose"])
+    pl = api.ba_plan(prob["fixed"], P, prob["e_pose"], prob["e_point"])
+    assert pl["usable"]
+    pinv, perm = pl["pinv"], pl["perm"]
+    assert np.array_equal(np.sort(pinv), np.arange(P)) and np.array_equal(np.sort(perm), np.arange(E))
+    prank = np.empty(P, np.int64); prank[pinv] = np.arange(P)
+    s_pose = prob["e_pose"][perm]; s_pt = prank[prob["e_point"][perm]]
+    assert np.all(np.diff(s_pt) >= 0)                                        # sorted by internal point ...
+    same = np.diff(s_pt) == 0
+    assert np.all(np.diff(s_pose)[same] > 0)                                 # ... and by key frame inside a point (no key frame twice)
+    pt_off = np.searchsorted(s_pt, np.arange(P + 1))
+    slot_of = np.full(len(prob["fixed"]), -1); slot_of[prob["fixed"] == 0] = np.arange(int((prob["fixed"] == 0).sum()))
+    info = pl["info"]
+    a = info & 31; k = (info >> 5) & 31; s = ((info >> 10) & 63).astype(int) - 1; kp = (info >> 19) & 255
+    assert np.array_equal(a, np.arange(E) - pt_off[s_pt]) and np.array_equal(k, (pt_off[1:] - pt_off[:-1])[s_pt])
+    assert np.array_equal(s, slot_of[s_pose]) and np.array_equal(kp, s_pose)
+    c0 = pl["chunk_pt0"]
+    assert c0[0] == 0 and c0[-1] == P and np.all(np.diff(c0) > 0)
+    assert np.all(pt_off[c0[1:]] - pt_off[c0[:-1]] <= 64)                    # a chunk is one wavefront
+    return pl, pt_off, s_pose, s_pt, slot_of, a, s
+
+
+@pytest.mark.parametrize("K,P,views,seed", [(20, 22150, "track", 42), (12, 3000, "track", 3), (7, 900, "track", 5), (20, 4000, "random", 1)])
+def test_run_plan_replays_the_schur_sum(K, P, views, seed):
+    prob = synth.ba_problem(K=K, P=P, obs_per_point=4, F=550, seed=seed, views=views)
+    pl, pt_off, s_pose, s_pt, slot_of, a_of, s_of = _structure(prob)
+    E = len(s_pose); np_ = pl["np"]; NP2 = np_ * (np_ + 1) // 2
+    n_rm, rmc, rl = pl["n_rm"], pl["rm_chunk"], pl["run_lane"]
+    c0 = pl["chunk_pt0"]
+    if views == "track" and P >= 3000:
+        assert pl["rm_points"] > 0.5 * P and n_rm > 0                       # tracked points share their signatures: most of a large window is in runs
+    # ---- run chunks: whole points of ONE signature, descriptor fields
+    P_rm = pl["rm_points"]
+    assert (c0[n_rm] if n_rm < len(c0) else P) == P_rm
+    for c in range(n_rm):
+        e0, word, run, invk = (int(v) for v in rmc[c])
+        ne, k, m = word & 255, (word >> 8) & 255, word >> 16
+        p0, p1 = c0[c], c0[c + 1]
+        assert e0 == pt_off[p0] and ne == pt_off[p1] - pt_off[p0] and m == p1 - p0 and ne == k * m and invk == (65536 + k - 1) // k
+        assert 0 <= run < pl["n_runs"] and m <= 32
+        sig = s_pose[pt_off[p0]:pt_off[p0] + k]
+        assert np.array_equal(s_pose[e0:e0 + ne].reshape(m, k), np.tile(sig, (m, 1)))
+        if c > 0 and rmc[c - 1][2] == run:                                   # chunks of a run are consecutive and share the signature
+            pe0 = int(rmc[c - 1][0])
+            assert np.array_equal(s_pose[pe0:pe0 + k], sig)
+        lanes = np.arange(ne)
+        assert np.array_equal(((lanes - a_of[e0:e0 + ne]) * invk) >> 16, lanes // k)      # the kernel's point-of-lane arithmetic
+    # ---- integer stand-ins: w per edge (0 for fixed key frames: W = 0 there), d per point, h per edge (the key frame's own block)
+    rs = np.random.RandomState(seed)
+    w = rs.randint(1, 50, E).astype(np.int64) * (s_of >= 0); dpt = rs.randint(1, 9, P).astype(np.int64); h = rs.randint(1, 1000, E).astype(np.int64) * (s_of >= 0)
+    ref_S = np.zeros((np_, np_), np.int64); ref_h = np.zeros(np_, np.int64)
+    for p in range(P_rm):
+        es = np.arange(pt_off[p], pt_off[p + 1]); es = es[s_of[es] >= 0]
+        for i, ea in enumerate(es):
+            ref_h[s_of[ea]] += h[ea]
+            for eb in es[i:]:
+                ref_S[s_of[ea], s_of[eb]] += w[ea] * dpt[p] * w[eb]
+    dg_off = ((NP2 - np_) * SSTRIDE + 1) & ~1
+    for R_rm in sorted({max(pl["R_rm"], 1), 1, 7}):
+        if n_rm == 0:
+            break
+        lds = np.zeros(dg_off + DCOPIES * np_ * DSTRIDE, np.int64)
+        hsum = np.zeros((DCOPIES, np_), np.int64)
+        total_pairs = R_rm * PAIRS
+        covered = 0
+        for g in range(total_pairs):
+            cb, ce = g * n_rm // total_pairs, (g + 1) * n_rm // total_pairs
+            covered += ce - cb
+            acc = np.zeros(64, np.int64); hp = np.zeros(64, np.int64); hp_slot = np.full(64, -1)
+            cur_run = -1; lt = None
+            for c in range(cb, ce):
+                e0, word, run, invk = (int(v) for v in rmc[c])
+                ne, k, m = word & 255, (word >> 8) & 255, word >> 16
+                nxt = int(rmc[c + 1][2]) if c + 1 < ce else -1
+                # producer
+                for lane in range(ne):
+                    e = e0 + lane
+                    if s_of[e] >= 0:
+                        hp_slot[lane] = s_of[e]; hp[lane] += h[e]
+                if nxt != run:
+                    for lane in range(64):
+                        if hp_slot[lane] >= 0:
+                            j = ((lane - (a_of[e0 + lane] if lane < ne else 0)) * invk) >> 16
+                            hsum[j & (DCOPIES - 1), hp_slot[lane]] += hp[lane]
+                    hp[:] = 0; hp_slot[:] = -1
+                # consumer
+                if run != cur_run:
+                    cur_run = run; lt = rl[run]
+                for lane in range(64):
+                    x, y = int(lt[lane][0]), int(lt[lane][1])
+                    if not (x >> 23) & 1:
+                        continue
+                    pa, pb, q0, Q = x & 31, (x >> 5) & 31, (x >> 10) & 63, (x >> 16) & 127
+                    for j in range(q0, m, Q):
+                        ea, eb = e0 + j * k + pa, e0 + j * k + pb
+                        acc[lane] += w[ea] * dpt[s_pt[ea]] * w[eb]
+                if nxt != cur_run:
+                    for lane in range(64):
+                        x, y = int(lt[lane][0]), int(lt[lane][1])
+                        if (x >> 23) & 1:
+                            lds[y] += acc[lane]
+                    acc[:] = 0
+        assert covered == n_rm
+        got_S = np.zeros((np_, np_), np.int64)
+        for s1 in range(np_):
+            for s2 in range(s1 + 1, np_):
+                got_S[s1, s2] = lds[_opair(np_, s1, s2) * SSTRIDE]
+            got_S[s1, s1] = sum(lds[dg_off + (cp * np_ + s1) * DSTRIDE] for cp in range(DCOPIES))
+        assert np.array_equal(got_S, ref_S), R_rm
+        assert np.array_equal(hsum.sum(0), ref_h), R_rm
+    # ---- lane tables: every tuple of a run's free observations exactly Q times (sequences 0 .. Q - 1), diagonal flag and targets consistent
+    for r in range(pl["n_runs"]):
+        c = int(np.flatnonzero(rmc[:, 2] == r)[0])
+        e0, word = int(rmc[c][0]), int(rmc[c][1])
+        k = (word >> 8) & 255
+        free = [i for i in range(k) if s_of[e0 + i] >= 0]
+        T = len(free) * (len(free) + 1) // 2
+        seen = {}
+        for lane in range(64):
+            x, y = int(rl[r][lane][0]), int(rl[r][lane][1])
+            if not (x >> 23) & 1:
+                continue
+            pa, pb, q0, Q, diag = x & 31, (x >> 5) & 31, (x >> 10) & 63, (x >> 16) & 127, (x >> 24) & 1
+            assert pa in free and pb in free and pa <= pb and diag == (pa == pb) and Q == 64 // T and q0 < Q
+            sa, sb = s_of[e0 + pa], s_of[e0 + pb]
+            if diag:
+                assert y == dg_off + ((q0 % DCOPIES) * np_ + sa) * DSTRIDE
+            else:
+                assert sa < sb and y == _opair(np_, sa, sb) * SSTRIDE
+            seen.setdefault((pa, pb), []).append(q0)
+        assert len(seen) == T and all(sorted(v) == list(range(64 // T)) for v in seen.values())
+
+
+def test_range_split_and_left_over_chunks():
+    prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=7, views="track")
+    pl, pt_off, s_pose, s_pt, slot_of, a_of, s_of = _structure(prob)
+    assert pl["R_rm"] >= 1 and pl["R"] >= 1 and pl["R_rm"] + pl["R"] <= 128
+    assert pl["R_rm"] * PAIRS <= max(pl["n_rm"], PAIRS)                        # a producer / consumer pair has at least one chunk
+    # with CMS_BA_NO_RUNS (child process: the switch is read once) every point is a left-over point and the plan is the old composition
+    import os, subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); from cubemapslam_amd import api, synth; "
+            "p = synth.ba_problem(K=20, P=3000, obs_per_point=4, F=550, seed=7, views='track'); "
+            "pl = api.ba_plan(p['fixed'], len(p['points']), p['e_pose'], p['e_point']); print(pl['n_rm'], pl['n_runs'], pl['rm_points'], pl['n_chunks'])"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CMS_BA_NO_RUNS="1"), capture_output=True, text=True, check=True).stdout.split()
+    assert out[:3] == ["0", "0", "0"] and int(out[3]) > 0
