@@ -19,9 +19,14 @@ One step = one batch of frames through, all on the device:
     Frame::AssignFeaturesToGrid; TrackWithMotionModel's SearchByProjection(Cur, Last, th = 15): projection, GetFeaturesInArea windows,
         greedy Hamming match, rotation histogram; TrackLocalMap's SearchLocalPoints (isInFrustum + windows + greedy match)
     Optimizer::PoseOptimization of every frame (one launch for the batch, own stream)
-    per `--ba-every` frames one key frame on the mapping side: LocalMapping::CreateNewMapPoints against 20 neighbours, then one local
-        BA window (K = 20 key frames, ~80k cubemap edges, BASELINE.json configs[3]); EVERY window of a step is a different problem
-        (own seed), the windows advance in lock-step groups on their own streams / host threads (the reference's LocalMapping thread).
+    per `--ba-every` frames one key frame on the mapping side: LocalMapping::CreateNewMapPoints against 20 neighbours, then one
+        Optimizer::LocalBundleAdjustment call (K = 20 key frames, ~80k cubemap edges, BASELINE.json configs[3]) with its WHOLE life cycle
+        inside the step, as the reference has it (Optimizer.cpp:192-358 builds the graph per call, :419-450 writes the result back):
+        cms_ba_create from the problem's host arrays (host work lists, one pinned upload), optimisation, cms_ba_read of poses / points /
+        outlier flags into host arrays, cms_ba_destroy.  EVERY window of a step is a different problem (own seed; map points tracked over
+        consecutive key frames, synth.ba_problem(views="track")) and two sets of problems alternate from step to step.  The windows advance
+        in lock-step groups on their own streams / host threads (the reference's LocalMapping thread); a pool of host threads builds the
+        windows of step s + 1 while step s runs and reads back / destroys the windows of step s -- all of it inside the timed region.
 Two frame batches (different streams) alternate from step to step, so no step replays the previous step's inputs.
 
 `value` is measured with both batches resident in HBM (a device-to-device copy into the staging buffer opens the step).  A second
@@ -70,7 +75,12 @@ def parse_args(argv=None):
     ap.add_argument("--force-gather", action="store_true", help="run the trajectory gather code path even with one rank (self-test)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-streaming-pass", action="store_true", help="skip the second timed pass with inputs streamed from pinned host memory")
-    ap.add_argument("--verify-windows", type=int, default=3, help="local-BA windows checked against the CPU oracle after the timed region (rank 0)")
+    ap.add_argument("--verify-windows", type=int, default=3, help="local-BA windows whose estimates are checked against the CPU oracle after the timed region (rank 0); "
+                    "the iteration counts and outlier counts of ALL windows of that step are checked as well (0 = no check)")
+    ap.add_argument("--ba-views", choices=("track", "random"), default="track", help="how the synthetic windows' observations are drawn (synth.ba_problem)")
+    ap.add_argument("--window-threads", type=int, default=0, help="host threads that build / read back / destroy local-BA windows (0 = min(32, cores / 4))")
+    ap.add_argument("--optimise-only-steps", type=int, default=10, help="steps of the extra pass that keeps the windows and only resets them between steps "
+                    "(round 2's headline, reported as config.optimise_only; 0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
     return ap.parse_args(argv)
@@ -284,12 +294,29 @@ def main():
 
     # ---- mapping side: one key frame per `ba_every` frames = CreateNewMapPoints + one local-BA window, every window its own problem
     n_ba = max(1, B // args.ba_every)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=8) as tp:
-        probs = list(tp.map(lambda w: synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + 1000 * rank + w), range(n_ba)))
+    from concurrent.futures import ThreadPoolExecutor, wait as fut_wait
+    with ThreadPoolExecutor(max_workers=8) as tp:       # two sets of window problems alternate from step to step, like the frame batches
+        all_probs = list(tp.map(lambda w: synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + 1000 * rank + w, views=args.ba_views), range(2 * n_ba)))
+    prob_sets = [all_probs[:n_ba], all_probs[n_ba:]]
+    probs = prob_sets[0]
+    for p in all_probs:        # contiguous arrays of the C-ABI's types once, so that a window's creation is nothing but the cms_ba_create call
+        p["poses"] = np.ascontiguousarray(p["poses"], np.float64); p["points"] = np.ascontiguousarray(p["points"], np.float64)
+        p["e_obs"] = np.ascontiguousarray(p["e_obs"], np.float64)
+    n_wthreads = args.window_threads or max(4, min(32, (os.cpu_count() or 8) // 4))
+    wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
+    def make_window(p):
+        t1 = time.perf_counter()
+        ba = api.BundleAdjuster(p, device=local_rank)
+        return ba, 1e3 * (time.perf_counter() - t1)
+    def finish_window(ba):
+        out = ba.read()             # poses, points, outlier flags -> host arrays (Optimizer.cpp:419-450)
+        ba.close()                  # cms_ba_destroy
+        return out
+    for ba, _ in [f.result() for f in [wpool.submit(make_window, p) for p in probs]]:      # warm the per-device pools (streams, slabs, pinned blocks)
+        ba.close()
     t_setup = time.perf_counter()
     bas = [api.BundleAdjuster(p, device=local_rank) for p in probs]
-    ba_setup_ms = 1e3 * (time.perf_counter() - t_setup) / max(len(bas), 1)      # cms_ba_create per window (the first ones also create their streams)
+    ba_setup_ms = 1e3 * (time.perf_counter() - t_setup) / max(len(bas), 1)      # cms_ba_create per window, one after the other, pools warm
     # tracking's pose-only optimisation (Optimizer::PoseOptimization, once per frame here; the reference calls it 1-3 times):
     # one problem per frame, ~600 matched map points with 10 % mismatches, resident on the device, one launch per step
     pose_probs = [synth.pose_problem(N=args.pose_edges, F=F, seed=1000 * rank + b, outlier_frac=0.1) for b in range(B)]
@@ -298,10 +325,8 @@ def main():
 
     # the windows are split into `--ba-groups` groups, each advanced in lock-step by its own host thread on its own stream
     n_grp = max(1, min(args.ba_groups, n_ba))
-    groups = [bas[gi::n_grp] for gi in range(n_grp)]
+    groups = [bas[gi::n_grp] for gi in range(n_grp)]            # the standing windows of the optimise-only pass
     group_ids = [list(range(n_ba))[gi::n_grp] for gi in range(n_grp)]
-    for grp in groups:
-        grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (kb_ba_lin_schur_edges: linearisation + Schur complement -- the BA chain's largest kernel)
 
     # LocalMapping::CreateNewMapPoints in front of every window's BA: the window's key frame against its 20 best covisible neighbours
     # (~1650 features each, FeatureVectors of ~400 nodes), key frames resident on the device; one store + context (stream) per group
@@ -328,20 +353,41 @@ def main():
             for ba in grp:                   # developer knob: the whole mapping side of a group on ONE stream (cms_ba_set_stream).  Measured
                 ba.set_stream(cg.stream)     # slower (15.9 against 14.4 ms per step): the resets and CreateNewMapPoints then queue behind the group's BA
 
+    schur_acc = {"ms": 0.0, "n": 0}
     def ba_worker(grp, gi, keep):
-        """one window group of one step; returns (elapsed ms, new map points, per-window stats)"""
+        """optimise-only pass: one group of STANDING windows of one step; returns (elapsed ms, new map points, per-window stats)"""
         t_ba0 = time.perf_counter()
         res = tri_store[gi].create_new_map_points(tri_jobs[gi])
         _, stats = api.ba_optimize_many(grp, (5, 10))   # the group's windows share every launch (kb_ba_* kernels, one window per blockIdx.z)
         if not keep:
             for ba in grp:                       # benchmark plumbing: put the initial estimate back for the next step (asynchronous; done
                 ba.reset()                       # here, where the chip is quiet, rather than in front of the next step's first kernel)
-        return 1e3 * (time.perf_counter() - t_ba0), sum(len(r[0]) for r in res), stats
+        return 1e3 * (time.perf_counter() - t_ba0), sum(len(r[0]) for r in res), stats, None, None
+
+    def ba_worker_life(futs, gi, keep):
+        """one window group of one step with the windows' whole life cycle: the group's windows were built by the pool while the previous
+        step ran (futs); here they are optimised, then handed back to the pool to be read back and destroyed.  Returns (elapsed ms, new map
+        points, per-window stats, futures of the read-backs, the windows' creation times)"""
+        t_ba0 = time.perf_counter()
+        made = [f.result() for f in futs]
+        grp = [m[0] for m in made]
+        grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (the BA chain's largest kernel)
+        res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+        _, stats = api.ba_optimize_many(grp, (5, 10))
+        ms, nl = grp[0].profile_get()
+        schur_acc["ms"] += ms; schur_acc["n"] += nl
+        outs = [wpool.submit(finish_window, ba) for ba in grp]
+        return 1e3 * (time.perf_counter() - t_ba0), sum(len(r[0]) for r in res), stats, outs, [m[1] for m in made]
 
     part = os.environ.get("CMS_BENCH_PART", "")      # developer knob: "ba" / "frames" times one half of the step alone (not a bench line)
     pool = ThreadPoolExecutor(max_workers=n_grp)       # one standing host thread per window group (LocalMapping-like)
-    last = {"traj": None, "ba_stats": None, "tri_new": 0}
-    acc = {"ba_ms": 0.0, "ba_n": 0}
+    last = {"traj": None, "ba_stats": None, "tri_new": 0, "ba_out": None, "set": 0}
+    acc = {"ba_ms": 0.0, "ba_n": 0, "create_ms": 0.0, "create_n": 0}
+    life = {"on": True, "pending": None, "pending_set": 0, "reads": []}
+    def submit_windows(j):
+        """the pool starts building the n_ba windows of problem set j; returned per group"""
+        life["pending_set"] = j
+        life["pending"] = [[wpool.submit(make_window, prob_sets[j][w]) for w in ids] for ids in group_ids]
 
     # developer knob: queue the mapping side of a step behind the step's extraction (cms_stream_wait_extracted) instead of letting the two
     # overlap.  Measured: the extractor then runs at 35 % instead of 33 % of its byte roofline inside the step (43 % with no local BA in
@@ -365,7 +411,13 @@ def main():
                 for gi, grp in enumerate(groups):
                     ctx.stream_wait_extracted(tri_ctx[gi].stream)
                     ctx.stream_wait_extracted(grp[0].stream)
-            ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)]
+            if life["on"]:
+                cur, cur_set = life["pending"], life["pending_set"]
+                submit_windows(cur_set ^ 1)                # the next step's windows are built under this step
+                ths = [pool.submit(ba_worker_life, cur[gi], gi, keep) for gi in range(n_grp)]
+                last["set"] = cur_set
+            else:
+                ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)]
         if part != "ba":
             S.enqueue_tracking(ext_stream)
             ctx.sync()
@@ -375,6 +427,15 @@ def main():
             acc["ba_ms"] += sum(r[0] for r in res) / len(res); acc["ba_n"] += 1
             last["tri_new"] = sum(r[1] for r in res)
             last["ba_stats"] = [r[2] for r in res]
+            if res[0][3] is not None:
+                # the read-backs of THIS step's windows finish under the next step; at most two steps' worth are ever outstanding
+                for f in life["reads"]:
+                    f.result()
+                life["reads"] = [f for r in res for f in r[3]]
+                if keep:
+                    last["ba_out"] = [[f.result() for f in r[3]] for r in res]
+                for r in res:
+                    acc["create_ms"] += sum(r[4]); acc["create_n"] += len(r[4])
         if part != "ba" and (world > 1 or args.force_gather):   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
             recs = [cdist.make_records(my_streams[s], i * fps + np.arange(fps), frame_poses[s * fps:(s + 1) * fps]) for s in range(len(my_streams))]
             traj = cdist.gather_trajectory(np.concatenate(recs, 0), device=dev, dst=0)
@@ -386,23 +447,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(streaming):
+    def drain():
+        """everything the window pool still owes: read-backs of the last step, and the windows built for a step that will not run"""
+        for f in life["reads"]:
+            f.result()
+        life["reads"] = []
+        if life["pending"] is not None:
+            for futs in life["pending"]:
+                for f in futs:
+                    f.result()[0].close()
+            life["pending"] = None
+
+    def timed(streaming, lifecycle=True, steps=None):
+        steps = args.steps if steps is None else steps
+        life["on"] = lifecycle and part != "frames"
         if streaming:
             ctx.upload_async(sets[0].pinned.array)
+        if life["on"]:
+            submit_windows(0)
         for i in range(args.warmup):
             step(i, streaming)
         stage = {}
-        for grp in groups:
-            grp[0].profile_kernel(3)
+        if not life["on"]:
+            for grp in groups:
+                grp[0].profile_kernel(3)
         barrier()
-        acc["ba_ms"], acc["ba_n"] = 0.0, 0
+        acc["ba_ms"], acc["ba_n"], acc["create_ms"], acc["create_n"] = 0.0, 0, 0.0, 0
+        schur_acc["ms"], schur_acc["n"] = 0.0, 0
+        # The timed region holds, per step, the creation of one set of windows (the NEXT step's, by the pool), the optimisation of one set, and the
+        # read-back + destruction of one set (the PREVIOUS step's finish under this one); the region ends only when the last step's read-backs are
+        # through.  The windows the last step built for a step that never runs are destroyed after the clock stops (they were built inside it).
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(steps):
             step(args.warmup + i, streaming)
             for k, v in (ctx.profile_ms().items() if part != "ba" else ()):
                 stage[k] = stage.get(k, 0.0) + v
+        for f in life["reads"]:
+            f.result()
+        life["reads"] = []
         barrier()
         dt = time.perf_counter() - t0
+        drain()
         if streaming:
             ctx.upload_wait()
         if world > 1:
@@ -410,16 +495,18 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         for k in stage:
-            stage[k] /= max(args.steps, 1)
-        schur = [grp[0].profile_get() for grp in groups]
+            stage[k] /= max(steps, 1)
+        schur = [(schur_acc["ms"], schur_acc["n"])] if life["on"] else [grp[0].profile_get() for grp in groups]
         return dt, stage, acc["ba_ms"] / max(acc["ba_n"], 1), schur
 
     ctx.profile(True)
     dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
+    create_ms_in_step = acc["create_ms"] / max(acc["create_n"], 1)
     if part:
         if rank == 0:
             print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms_per_step, 3), "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
         pool.shutdown()
+        wpool.shutdown()
         return
     streamed = None
     if not args.no_streaming_pass:
@@ -428,29 +515,45 @@ def main():
                     "host_bytes_per_step": int(B * camd["Ih"] * g.fisheye_stride),
                     "note": "same steps with every batch copied from pinned host memory (cms_frames_upload_async, overlapped with the previous step)"}
 
-    # ---- outside the timed region: local-BA results of a sample of windows against the CPU oracle
+    # ---- round 2's figure for comparison: the same steps with STANDING windows that are only reset between steps (no creation, no read-back,
+    # no destruction inside the timed region) -- what the kernels alone allow
+    optimise_only = None
+    if args.optimise_only_steps > 0:
+        dt_o, _, ba_ms_o, _ = timed(False, lifecycle=False, steps=args.optimise_only_steps)
+        optimise_only = {"value": round(total_frames_per_step * args.optimise_only_steps / dt_o, 2), "ms_per_step": round(1e3 * dt_o / args.optimise_only_steps, 3),
+                         "ba_ms_per_step": round(ba_ms_o, 3), "steps": args.optimise_only_steps,
+                         "note": "windows created once before the timed steps and reset between them (BENCH_r02's headline): kernels only, NOT like for like with the CPU baseline"}
+
+    # ---- outside the timed region: one more step with the windows' whole life cycle whose results are kept; iteration counts and outlier
+    # counts of ALL its windows, and the estimates of a sample, against the CPU oracle
     ba_check = None
     cpu_ba_ms = []
     if args.verify_windows > 0:
-        step(args.warmup + args.steps, False, keep=True)          # one more step (all ranks: it holds the gather) whose window estimates are kept
+        life["on"] = True
+        submit_windows(0)
+        step(args.warmup + args.steps, False, keep=True)          # (all ranks: it holds the gather)
+        drain()
     if rank == 0 and args.verify_windows > 0:
         import orc
-        stats_of = {}
+        vprobs = prob_sets[last["set"]]
+        stats_of, out_of = {}, {}
         for gi, ids in enumerate(group_ids):
             for wi, w in enumerate(ids):
-                stats_of[w] = last["ba_stats"][gi][wi]
+                stats_of[w] = last["ba_stats"][gi][wi]; out_of[w] = last["ba_out"][gi][wi]
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as tp:     # the oracle on every window (its own threads: the check, not a timing)
+            wants = list(tp.map(orc.ba_run, vprobs))
+        for w in range(n_ba):
+            st, ws = stats_of[w], wants[w]["stats"]
+            if list(st.iterations_done) != list(ws.iterations_done) or st.n_outliers_mid != ws.n_outliers_mid or st.n_outliers_final != ws.n_outliers_final or \
+                    not np.array_equal(out_of[w][2], wants[w]["outliers"]):
+                raise SystemExit("bench.py: local-BA window %d differs from the CPU oracle: iterations %s vs %s, outliers %d vs %d" %
+                                 (w, list(st.iterations_done), list(ws.iterations_done), st.n_outliers_final, ws.n_outliers_final))
         sample = sorted(set(np.linspace(0, n_ba - 1, min(args.verify_windows, n_ba)).astype(int).tolist()))
         worst = 0.0
         for w in sample:
-            t1 = time.perf_counter()
-            want = orc.ba_run(probs[w])
-            cpu_ba_ms.append(1e3 * (time.perf_counter() - t1))
-            poses, pts, flags = bas[w].read()
-            st, ws = stats_of[w], want["stats"]
-            if list(st.iterations_done) != list(ws.iterations_done) or st.n_outliers_final != ws.n_outliers_final or not np.array_equal(flags, want["outliers"]):
-                raise SystemExit("bench.py: local-BA window %d differs from the CPU oracle: iterations %s vs %s, outliers %d vs %d" %
-                                 (w, list(st.iterations_done), list(ws.iterations_done), st.n_outliers_final, ws.n_outliers_final))
-            for got, ref, ref0 in ((pts, want["points"], probs[w]["points"]), (poses[:, :3], want["poses"][:, :3], probs[w]["poses"][:, :3])):
+            want = wants[w]
+            poses, pts, flags = out_of[w]
+            for got, ref, ref0 in ((pts, want["points"], vprobs[w]["points"]), (poses[:, :3], want["poses"][:, :3], vprobs[w]["poses"][:, :3])):
                 nrm = np.linalg.norm(ref - ref0, axis=1)
                 err = np.linalg.norm(got - ref, axis=1)
                 floor = 0.01 * np.median(nrm[nrm > 0]) if np.any(nrm > 0) else 0.0
@@ -459,12 +562,9 @@ def main():
                 if r > 1e-4:
                     raise SystemExit("bench.py: local-BA window %d: update differs from the CPU oracle by %.3g relative" % (w, r))
         its = [tuple(s.iterations_done) for gs in last["ba_stats"] for s in gs]
-        ba_check = {"windows_checked_against_oracle": sample, "worst_relative_update_error": float("%.3g" % worst),
+        ba_check = {"windows_with_iterations_and_outlier_flags_equal_to_the_oracle": n_ba, "windows_with_estimates_checked": sample,
+                    "worst_relative_update_error": float("%.3g" % worst),
                     "iterations_done_min_max": [list(min(its)), list(max(its))], "distinct_iteration_counts": len(set(its))}
-
-    if args.verify_windows > 0:
-        for ba in bas:
-            ba.reset()
 
     # ---- rooflines (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
     sumP = sum(g.level_w[l] * g.level_h[l] for l in range(g.nlevels))
@@ -480,7 +580,7 @@ def main():
     # measured HBM traffic / instruction mix of the kernels: committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
     # separate runs, tools/run_profiles.sh), valid for the batch size and geometry they were taken at
     def pmc(name, kname):
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             pj = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
             if os.path.exists(pj):
                 J = json.load(open(pj))
@@ -503,26 +603,61 @@ def main():
                  "valu_issue_bound_ms": None if not mixk else round(mixk["valu_issue_bound_us"] / 1e3, 4),
                  "algorithmic_bytes_per_launch": int(alg["fast"] * B),
                  "all_stages_GBps": {k: round(alg[k] * B / (stage_ms[k] * 1e-3) / 1e9, 1) for k in alg if stage_ms.get(k, 0) > 0}}
-    # kb_ba_schur_points: one launch = one Levenberg trial of one window group; algorithmic bytes = every edge's 6x3 pose-point block
-    # (144 B) + every point's inverted 3x3 block and reduced right-hand side (96 B) once ("Schur ... reading Hpl once")
+    # The Schur kernel of the local-BA chain (kb_ba_lin_schur_runs by default: linearisation + Schur complement of one Levenberg trial of one
+    # window group per launch).  It moves little memory (the 6x3 blocks are rebuilt from the estimate, never read: PMC traffic is a fraction of
+    # the E 144 + P 96 bytes SURVEY.md 8d counts), so HBM is not its ceiling.  Two ceilings apply and both are reported:
+    #   fp64 vector issue  algorithmic flops (per observation: residual, Huber weight, Jacobians, its shares of Hll / bl / Hpp / bp, W = B L^-T:
+    #                      320; per point: the 3x3 LDL^T: 30; per tuple of observations of one point, diagonal ones included: W_a D^-1 W_b^T and
+    #                      its share of the right-hand side: 234) against 78.6 TFLOP/s (gfx950: the FP64 matrix rate equals the vector rate)
+    #   LDS atomics        ds_add_f64 lane-operations on the workgroup's copy of the reduced system against the 7.8 per clock and CU the LDS
+    #                      takes on conflict-free addresses (tools/probe/lds_atomics.hip, profiles/r03_probe_lds_atomics.txt)
+    # `bound` names the ceiling the kernel sits closer to.
     sch_ms = sum(p[0] for p in schur_prof); sch_n = sum(p[1] for p in schur_prof)
-    grp_bytes = [sum(b.E * 144 + b.P * 96 for b in grp) for grp in groups]
     roof_ba = None
-    if sch_n > 0:
+    if sch_n > 0 and rank == 0:
         avg_ms = sch_ms / sch_n
-        byt = float(np.mean(grp_bytes))
-        gbs = byt / (avg_ms * 1e-3) / 1e9
+        wpl = n_ba / n_grp                     # windows per launch
+        fl, atom, byt, run_stats = [], [], [], []
+        fixed0 = probs[0]["fixed"]
+        slot_free = fixed0 == 0
+        for pw in probs[:8]:
+            Pn, En = len(pw["points"]), len(pw["e_pose"])
+            plan = api.ba_plan(pw["fixed"], Pn, pw["e_pose"], pw["e_point"])
+            kf = np.bincount(pw["e_point"][slot_free[pw["e_pose"]]], minlength=Pn).astype(np.int64)      # free observations per point
+            tuples = int((kf * (kf + 1) // 2).sum())
+            fl.append(En * 320.0 + Pn * 30.0 + tuples * 234.0)
+            byt.append(En * 144.0 + Pn * 96.0)
+            prank = np.empty(Pn, np.int64); prank[plan["pinv"]] = np.arange(Pn)
+            left = prank >= plan["rm_points"]                                                           # points the edge-major body takes
+            a_se = int((kf[left] * 33 + (kf[left] * (kf[left] - 1) // 2) * 36).sum())
+            R_rm_grp = max(1, int(round(256 / wpl * 0.5 * plan["n_rm"] / max(0.5 * plan["n_rm"] + plan["n_chunks"] - plan["n_rm"], 1)))) if plan["n_rm"] else 0
+            a_rm = (plan["n_runs"] + 4 * R_rm_grp) * 64 * (36 + 33) if plan["n_rm"] else 0              # one set of additions per run and per pair range
+            atom.append(a_se + a_rm)
+            run_stats.append((plan["n_runs"], plan["rm_points"] / Pn, plan["n_rm"], plan["n_chunks"]))
+        flops = float(np.mean(fl)) * wpl; atoms = float(np.mean(atom)) * wpl
+        tflops = flops / (avg_ms * 1e-3) / 1e12
+        lane_ops = atoms / (avg_ms * 1e-3 * 2.4e9 * 256)
+        f_fp64, f_lds = tflops / 78.6, lane_ops / 7.8
         schur_name = ("kb_ba_schur_points" if os.environ.get("CMS_BA_DETERMINISTIC") or os.environ.get("CMS_BA_HOST_LM") else
-                      "kb_ba_schur_edges" if os.environ.get("CMS_BA_NO_FUSED_LIN") else "kb_ba_lin_schur_edges")
-        roof_ba = {"kernel": schur_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "frac": round(gbs / peak, 4),
-                   # PMC pass: 8 windows per dispatch (tools/prof_ba_many.py); one launch here carries a group of n_ba / n_grp windows
-                   "traffic": traffic_of(schur_name, (n_ba / n_grp) / 8.0), "ms_per_launch": round(avg_ms, 4), "launches_per_step": round(sch_n / args.steps, 1),
-                   "ms_per_step": round(sch_ms / args.steps, 4), "algorithmic_bytes_per_launch": int(byt),
-                   "lds_atomic_bound": "linearisation + Schur complement of one Levenberg trial in one kernel; it adds 33 + 36 + 36 ds_add_f64 wave instructions per "
-                                       "64-edge chunk to its LDS copy of the reduced system (the LDS takes them in groups of 16 lanes, 2 clocks per group plus 2 per lane "
-                                       "repeating a bank: tools/probe/lds_atomics.hip; the host composes the chunks against that).  148 KB of LDS per workgroup leave two "
-                                       "wavefronts per SIMD: LDS pipe 45 % busy, vector-ALU issue 34 % of the launch (profiles/r02_pmc_instruction_mix.json) -- latency, not HBM",
-                   "note": "HIP events on each window group's stream; the groups' launches overlap each other and the frame path, so ms_per_step is summed kernel time"}
+                      "kb_ba_schur_edges" if os.environ.get("CMS_BA_NO_FUSED_LIN") else
+                      "kb_ba_lin_schur_edges" if os.environ.get("CMS_BA_NO_RUNS") or os.environ.get("CMS_BA_RUNS_AS_EDGES") or args.ba_views == "random" else "kb_ba_lin_schur_runs")
+        traffic = traffic_of(schur_name, wpl / 8.0)       # PMC pass: 8 windows per dispatch (tools/prof_ba_many.py); one launch here carries n_ba / n_grp windows
+        fp64_bound = f_fp64 >= f_lds
+        roof_ba = {"kernel": schur_name, "bound": "fp64-valu" if fp64_bound else "lds-atomic",
+                   "achieved": round(tflops, 3) if fp64_bound else round(lane_ops, 3), "peak": 78.6 if fp64_bound else 7.8,
+                   "unit": "TFLOP/s" if fp64_bound else "ds_add_f64 lane-ops/clk/CU", "frac": round(max(f_fp64, f_lds), 4), "traffic": traffic,
+                   "fp64": {"algorithmic_flops_per_launch": int(flops), "TFLOPs": round(tflops, 3), "peak_TFLOPs": 78.6, "frac": round(f_fp64, 4)},
+                   "lds_atomic": {"lane_ops_per_launch": int(atoms), "per_clk_per_cu": round(lane_ops, 3), "peak_per_clk_per_cu": 7.8, "frac": round(f_lds, 4),
+                                  "clock_GHz_assumed": 2.4},
+                   "hbm_GBps_measured": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 1),
+                   "hbm_equivalent": {"survey_bytes_per_launch": int(float(np.mean(byt)) * wpl), "GBps": round(float(np.mean(byt)) * wpl / (avg_ms * 1e-3) / 1e9, 1),
+                                      "note": "E 144 + P 96 bytes per window (SURVEY.md 8d) the kernel never moves: not a ceiling, kept for comparison with BENCH_r02"},
+                   "ms_per_launch": round(avg_ms, 4), "launches_per_step": round(sch_n / args.steps, 1), "ms_per_step": round(sch_ms / args.steps, 4),
+                   "windows_per_launch": wpl,
+                   "signature_runs": {"runs_per_window": round(float(np.mean([r[0] for r in run_stats])), 1), "points_in_runs": round(float(np.mean([r[1] for r in run_stats])), 3),
+                                      "run_chunks_of_all_chunks": "%d / %d" % (int(np.mean([r[2] for r in run_stats])), int(np.mean([r[3] for r in run_stats])))},
+                   "note": "HIP events on each window group's stream around the kernel of every round, inside the timed region; the groups' launches overlap each "
+                           "other and the frame path, so ms_per_step is summed kernel time"}
     # `roofline` = the kernel with the most time per step; the other one is reported next to it
     if roof_ba and roof_ba["ms_per_step"] > roof_fast["ms_per_step"]:
         roof, roof_other = roof_ba, roof_fast
@@ -577,7 +712,7 @@ def main():
         for _ in range(2):
             orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], T0["scale_factors"], T0["level_sigma2"], T0["kfs"][0]["mp"].copy())
         t_tri = (time.perf_counter() - t1) / 2
-        while len(cpu_ba_ms) < 3:            # the verification above already timed the oracle on its sample of windows
+        while len(cpu_ba_ms) < 3:            # three windows, one after the other, one thread
             t1 = time.perf_counter()
             orc.ba_run(probs[len(cpu_ba_ms) % n_ba])
             cpu_ba_ms.append(1e3 * (time.perf_counter() - t1))
@@ -656,14 +791,19 @@ def main():
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
                        "extractor_vs_survey_bytes": extractor,
                        "ba_windows_per_step": n_ba, "ba_groups": n_grp,
-                       "ba_window_setup": {"in_timed_region": False, "ms_per_window": round(ba_setup_ms, 2),
-                                           "note": "the windows' graphs (cms_ba_create: host work lists + uploads) are built once before the timed steps and reset between them; "
-                                                   "one LocalBundleAdjustment call incl. set-up, read-back and destroy: tools/prof_ba_latency.py (DESIGN.md section 3)"}, "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
+                       "ba_window_setup": {"in_timed_region": True, "ms_per_window_one_after_the_other": round(ba_setup_ms, 2),
+                                           "ms_per_window_inside_the_step": round(create_ms_in_step, 2), "window_threads": n_wthreads,
+                                           "note": "every step creates its %d windows from the problems' host arrays (cms_ba_create: host work lists, one pinned upload), optimises "
+                                                   "them, reads poses / points / outlier flags back (cms_ba_read) and destroys them; a pool of host threads builds step s + 1's "
+                                                   "windows and finishes step s - 1's while step s runs, all inside the timed region" % n_ba},
+                       "optimise_only": optimise_only, "ba_views": args.ba_views,
+                       "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
                        "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     pool.shutdown()
+    wpool.shutdown()
     if world > 1:
         dist.destroy_process_group()
 

@@ -129,7 +129,7 @@ static void ba_stream_give(int device, hipStream_t s) {
   BaStreamPool& pl = ba_stream_pool();
   {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (device >= 0 && device < 64 && pl.idle[device].size() < 64 && hipStreamSynchronize(s) == hipSuccess) { pl.idle[device].push_back(s); return; }
+    if (device >= 0 && device < 64 && pl.idle[device].size() < 256 && hipStreamSynchronize(s) == hipSuccess) { pl.idle[device].push_back(s); return; }
   }
   hipStreamDestroy(s);
 }
@@ -137,7 +137,8 @@ static void ba_stream_give(int device, hipStream_t s) {
 // ---- memory of a window comes from a per-device pool.  A window of configs[3] size needs ~50 device buffers: allocated and freed one by
 // one (hipMalloc is cheap, hipFree is not: ~40 us each) a LocalBundleAdjustment call spent 2 ms of its 17 in cms_ba_destroy, and the
 // grouped driver's pinned blocks (hipHostMalloc: ~0.3 ms each) another millisecond.  Windows now carve their buffers out of a few slabs;
-// slabs and pinned blocks of destroyed windows wait in the pool for the next window of the device (bounded: 2 GB of slabs, 64 pinned blocks).
+// slabs and pinned blocks of destroyed windows wait in the pool for the next window of the device (bounded: 16 GB of slabs -- a step of bench.py has ~100
+// windows of 45 MB alive, and a hipFree in the middle of a step synchronises the device --, 512 pinned blocks).
 struct BaMemPool {
   std::mutex mu;
   std::vector<BaBlock> dev[64], pin[64];
@@ -166,7 +167,7 @@ static void ba_dev_give(int device, void* p, size_t bytes) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (pl.dev_cached[device] + bytes <= ((size_t)2 << 30)) { pl.dev[device].push_back({p, bytes}); pl.dev_cached[device] += bytes; return; }
+    if (pl.dev_cached[device] + bytes <= ((size_t)16 << 30)) { pl.dev[device].push_back({p, bytes}); pl.dev_cached[device] += bytes; return; }
   }
   hipFree(p);
 }
