@@ -75,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-gather", action="store_true", help="run the trajectory gather code path even with one rank (self-test)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-streaming-pass", action="store_true", help="skip the second timed pass with inputs streamed from pinned host memory")
-    ap.add_argument("--verify-windows", type=int, default=3, help="local-BA windows whose estimates are checked against the CPU oracle after the timed region (rank 0); "
+    ap.add_argument("--verify-windows", type=int, default=8, help="local-BA windows whose estimates are checked against the CPU oracle after the timed region (rank 0); "
                     "the iteration counts and outlier counts of ALL windows of that step are checked as well (0 = no check)")
     ap.add_argument("--ba-views", choices=("track", "random"), default="track", help="how the synthetic windows' observations are drawn (synth.ba_problem)")
     ap.add_argument("--window-threads", type=int, default=0, help="host threads that build / read back / destroy local-BA windows (0 = min(32, cores / 4))")
@@ -549,21 +549,33 @@ def main():
                 raise SystemExit("bench.py: local-BA window %d differs from the CPU oracle: iterations %s vs %s, outliers %d vs %d" %
                                  (w, list(st.iterations_done), list(ws.iterations_done), st.n_outliers_final, ws.n_outliers_final))
         sample = sorted(set(np.linspace(0, n_ba - 1, min(args.verify_windows, n_ba)).astype(int).tolist()))
-        worst = 0.0
+        # estimates, per block, against the oracle's (1e-4 of the block's update, floor 1 % of the median update).  The reference rounds the
+        # camera-frame point to float inside the double optimisation (g2o_cubemap_vertices_edges.cpp:225-233): about one window in twenty gets a
+        # rounding flip that cascades (the oracle does it to itself under a 1e-12 m perturbation: tests/test_oracle_ba.py) -- such a window's
+        # key frames must still be within 1e-4, of its points at most 2 % may be beyond and none beyond 1e-2; it is counted, not hidden
+        worst, cascaded = 0.0, []
         for w in sample:
             want = wants[w]
             poses, pts, flags = out_of[w]
+            rel = []
             for got, ref, ref0 in ((pts, want["points"], vprobs[w]["points"]), (poses[:, :3], want["poses"][:, :3], vprobs[w]["poses"][:, :3])):
                 nrm = np.linalg.norm(ref - ref0, axis=1)
                 err = np.linalg.norm(got - ref, axis=1)
                 floor = 0.01 * np.median(nrm[nrm > 0]) if np.any(nrm > 0) else 0.0
-                r = float((err / np.maximum(nrm, max(floor, 1e-300))).max())
-                worst = max(worst, r)
-                if r > 1e-4:
-                    raise SystemExit("bench.py: local-BA window %d: update differs from the CPU oracle by %.3g relative" % (w, r))
+                rel.append(err / np.maximum(nrm, max(floor, 1e-300)))
+            if rel[1].max() > 1e-4:
+                raise SystemExit("bench.py: local-BA window %d: key-frame update differs from the CPU oracle by %.3g relative" % (w, rel[1].max()))
+            if rel[0].max() > 1e-4:
+                if (rel[0] > 1e-4).mean() > 0.02 or rel[0].max() > 1e-2:
+                    raise SystemExit("bench.py: local-BA window %d: point updates differ from the CPU oracle (%.3g relative, %d points beyond 1e-4)" %
+                                     (w, rel[0].max(), int((rel[0] > 1e-4).sum())))
+                cascaded.append({"window": w, "points_beyond_1e-4": int((rel[0] > 1e-4).sum()), "worst_point": float("%.3g" % rel[0].max()),
+                                 "worst_key_frame": float("%.3g" % rel[1].max())})
+            else:
+                worst = max(worst, float(rel[0].max()), float(rel[1].max()))
         its = [tuple(s.iterations_done) for gs in last["ba_stats"] for s in gs]
         ba_check = {"windows_with_iterations_and_outlier_flags_equal_to_the_oracle": n_ba, "windows_with_estimates_checked": sample,
-                    "worst_relative_update_error": float("%.3g" % worst),
+                    "worst_relative_update_error": float("%.3g" % worst), "windows_with_a_float_rounding_cascade": cascaded,
                     "iterations_done_min_max": [list(min(its)), list(max(its))], "distinct_iteration_counts": len(set(its))}
 
     # ---- rooflines (algorithmic bytes: SURVEY.md 8d / DESIGN.md)

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <atomic>
 #include <cmath>
 #include <mutex>
 #include <numeric>
@@ -18,7 +19,7 @@
 struct BaKnobs {
   bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce;
-  int lookahead, compose_segments, dup, run_min_chunks;
+  int lookahead, compose_segments, dup, run_min_chunks, rm_weight;
   char stream_priority;
 };
 static const BaKnobs& ba_knobs() {
@@ -38,6 +39,7 @@ static const BaKnobs& ba_knobs() {
     q.separate_reduce = on("CMS_BA_SEPARATE_REDUCE");    // kb_ba_schur_edges_reduce as its own launch instead of inside the solve kernel
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
     q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", 2));
+    q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 100)));
     const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
     q.stream_priority = pr ? pr[0] : 0;
     return q;
@@ -250,6 +252,7 @@ extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
   return hipMemcpy(out8, b->d_scal + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
 }
 
+static std::atomic<int> ba_plans_in_flight{0};      // windows being planned right now (cms_ba_create / cms_ba_debug_plan calls of all host threads)
 // lanes of one group of 16 -> LDS banks, every lane with four candidate banks: augmenting-path matching, the rest on their least-used bank
 struct BaDiagMatch {
   int n = 0; uint8_t bank[64][BA_SE_DCOPIES]; int choice[64]; int owner[16]; bool seen[16];
@@ -293,10 +296,13 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
     if (ctiming) fprintf(stderr, "[compose] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - c_last).count());
     c_last = now;
   };
+  // (scratch vectors are per host thread and keep their capacity from call to call: a pool of threads builds windows side by side, and
+  // fresh multi-megabyte allocations -- page faults under the process-wide memory-map lock -- were most of a window's set-up time there)
+#define BA_TLV(type, name) static thread_local std::vector<type> tl_##name; std::vector<type>& name = tl_##name
   prank.assign(P, 0); cp_off.assign(P + 1, 0); cp_pose.assign(E, 0); cp_rank.assign(E, 0);
   for (int e = 0; e < E; ++e) ++cp_off[e_point[e] + 1];
   for (int p = 0; p < P; ++p) cp_off[p + 1] += cp_off[p];
-  std::vector<int> fill(cp_off.begin(), cp_off.end() - 1);
+  BA_TLV(int, fill); fill.assign(cp_off.begin(), cp_off.end() - 1);
   for (int e = 0; e < E; ++e) cp_pose[fill[e_point[e]]++] = e_pose[e];
   ctick("csr");
   std::vector<int> gslot(K, -1);
@@ -305,13 +311,13 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
   pinv.resize(P);
   const bool greedy = lookahead > 1 && gnp >= 2 && gnp <= 62;
   const int LA = std::max(lookahead, 1), MAXD = 4;
-  std::vector<int> nxt(P + 1);                       // singly linked list of the points not placed yet, in the caller's order
+  BA_TLV(int, nxt); nxt.assign(P + 1, 0);            // singly linked list of the points not placed yet, in the caller's order
   for (int p = 0; p <= P; ++p) nxt[p] = p + 1;
   struct DiagLane { int cp; int16_t s; int16_t g; };  // diagonal tuples of the open chunk: position in cp_rank, free-pose slot, group of 16 lanes
   auto opair = [&](int s1, int s2) { return s1 * gnp - (s1 * (s1 + 1)) / 2 + (s2 - s1 - 1); };
-  std::vector<int> tp_beg(P, 0), tp_end(P, 0);                                      // a point's tuples in its segment's table
-  std::vector<uint16_t> pm((size_t)P * MAXD, 0), pm2((size_t)P * MAXD, 0);           // per step: banks a point touches / touches twice
-  std::vector<uint8_t> twice(P, 0);                                                  // ... three times: exact count below
+  BA_TLV(int, tp_beg); BA_TLV(int, tp_end); tp_beg.assign(P, 0); tp_end.assign(P, 0);                  // a point's tuples in its segment's table
+  BA_TLV(uint16_t, pm); BA_TLV(uint16_t, pm2); pm.assign((size_t)P * MAXD, 0); pm2.assign((size_t)P * MAXD, 0);   // per step: banks a point touches / touches twice
+  BA_TLV(uint8_t, twice); twice.assign(P, 0);                                                          // ... three times: exact count below
   // ---- the composition proper, for the points [p_begin, p_end) of the caller's order: they fill the internal positions [p_begin, p_end).
   // Large windows are cut into segments composed by as many host threads (the segments are fixed by P alone: the result does not depend on
   // the machine); a segment ends with a chunk that may be short.
@@ -319,7 +325,8 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
   // the key frames of a point in ascending order, and every point's off-diagonal tuples, once: step - 1 | edge within the point << 2 | bank
   // class << 7; per step the set of banks they touch (pm), with a flag for points that touch a bank three times in one step (those, and points
   // that straddle two groups of lanes, take the exact count below; for all others the masks decide)
-  std::vector<uint16_t> tp;
+  static thread_local std::vector<uint16_t> tp;      // (per thread that runs a segment)
+  tp.clear();
   tp.reserve((size_t)(cp_off[p_end] - cp_off[p_begin]) * 2);
   for (int p = p_begin; p < p_end; ++p) {
     std::sort(cp_pose.begin() + cp_off[p], cp_pose.begin() + cp_off[p + 1]);
@@ -449,7 +456,11 @@ static void ba_compose_chunks(int K, const uint8_t* fixed, int P, int E, const i
   const int seg_env = ba_knobs().compose_segments;      // A/B: fixed number of segments
   const int nseg = std::max(1, seg_env > 0 ? std::min(seg_env, std::max(1, P / 64)) : std::min(8, P / 512));
   std::vector<std::vector<int>> seg_chunks(nseg);
-  {
+  if (ba_plans_in_flight.load(std::memory_order_relaxed) > 1) {
+    // several windows are being built side by side (a pool of host threads, bench.py): their segments are already spread over the cores --
+    // one after the other here, same segments, same result
+    for (int t = 0; t < nseg; ++t) compose_range((int)((long long)P * t / nseg), (int)((long long)P * (t + 1) / nseg), seg_chunks[t]);
+  } else {
     std::vector<std::thread> workers;
     for (int t = 1; t < nseg; ++t)
       workers.emplace_back([&, t]() { compose_range((int)((long long)P * t / nseg), (int)((long long)P * (t + 1) / nseg), seg_chunks[t]); });
@@ -480,13 +491,13 @@ extern "C" int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, c
 }
 
 // Workgroups of one window for the Schur launch: `Rtotal` ranges are split between the run-major body (chunks [0, n_rm)) and the edge-major
-// body (the left-over chunks) by their work -- a run chunk costs about half an edge-major one.
+// body (the left-over chunks) by their work -- CMS_BA_RM_WEIGHT: cost of a run chunk in percent of an edge-major one (measured: about equal).
 static void ba_se_split(BaSe& se, int Rtotal) {
   const int n_se = se.nchunks - se.n_rm;
   Rtotal = std::max(2, std::min(Rtotal, BA_SE_RANGES));
   int R_rm = 0, R_se = 0;
   if (se.n_rm > 0 && n_se > 0) {
-    const double w_rm = 0.5 * se.n_rm, w_se = (double)n_se;
+    const double w_rm = 0.01 * ba_knobs().rm_weight * se.n_rm, w_se = (double)n_se;
     R_rm = (int)std::lround(Rtotal * w_rm / (w_rm + w_se));
     R_rm = std::max(1, std::min(R_rm, Rtotal - 1));
     R_se = Rtotal - R_rm;
@@ -520,17 +531,18 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   std::vector<int4>& rm_chunk = pl.rm_chunk;
   std::vector<uint2>& run_lane = pl.run_lane;
   bool& se_built = pl.se_built;
+  struct InFlight { InFlight() { ba_plans_in_flight.fetch_add(1); } ~InFlight() { ba_plans_in_flight.fetch_sub(1); } } in_flight;
   const BaKnobs& kn = ba_knobs();
   // ---- CSR of the caller's points over their observations, a point's observations by ascending key frame (two stable counting passes)
-  std::vector<int> cpo(P + 1, 0), cpe(E);
+  BA_TLV(int, cpo); BA_TLV(int, cpe); cpo.assign(P + 1, 0); cpe.assign(E, 0);
   {
-    std::vector<int> by_pose(E), cnt((size_t)std::max(K, P) + 1, 0);
+    BA_TLV(int, by_pose); BA_TLV(int, cnt); by_pose.assign(E, 0); cnt.assign((size_t)std::max(K, P) + 1, 0);
     for (int e = 0; e < E; ++e) ++cnt[e_pose[e] + 1];
     for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
     for (int e = 0; e < E; ++e) by_pose[cnt[e_pose[e]]++] = e;
     for (int e = 0; e < E; ++e) ++cpo[e_point[e] + 1];
     for (int p = 0; p < P; ++p) cpo[p + 1] += cpo[p];
-    std::vector<int> fill(cpo.begin(), cpo.end() - 1);
+    BA_TLV(int, fill); fill.assign(cpo.begin(), cpo.end() - 1);
     for (int i = 0; i < E; ++i) { const int e = by_pose[i]; cpe[fill[e_point[e]]++] = e; }
   }
   pose_slot.assign(K, -1);
@@ -565,11 +577,12 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
                      BA_SE_THREADS == 128 * BA_RM_PAIRS;
   struct Run { int k, first, npts, chunks, m; };              // first: a member point (its key frames are the signature)
   std::vector<Run> runs;
-  std::vector<int> rm_points;                                 // caller ids, run after run
-  std::vector<int> left;                                      // caller ids of the left-over points, caller's order
+  BA_TLV(int, rm_points); rm_points.clear();                  // caller ids, run after run
+  BA_TLV(int, left); left.clear();                            // caller ids of the left-over points, caller's order
   std::vector<int> rm_run_pt0;                                // per run: first position in rm_points
   if (rm_ok) {
-    std::vector<int> gid(P, -1), gcount, gfirst;
+    BA_TLV(int, gid); gid.assign(P, -1);
+    std::vector<int> gcount, gfirst;
     std::unordered_map<uint64_t, std::vector<int>> table;     // signature hash -> groups with that hash
     table.reserve((size_t)std::min(P, 1 << 16));
     for (int p = 0; p < P; ++p) {
@@ -630,18 +643,19 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   // and its transpose the same bank) repeat as little as possible; the diagonal tuples pick, among the four copies of their key frame's
   // diagonal block, the one whose bank is least used in their group.  Everything on the device is indexed by the internal point id;
   // cms_ba_read / cms_ba_linearize translate back.  CMS_BA_NO_PERMUTE=1 keeps the caller's order (A/B).
-  std::vector<int> prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL;
+  BA_TLV(int, prankL); BA_TLV(int, pinvL); BA_TLV(int, chunk_pt0L); BA_TLV(int, cp_offL); BA_TLV(int, cp_poseL);
   prank.assign(P, 0);
-  std::vector<uint8_t> cp_rankL;                      // per (left-over point, edge in pose order): copy of the diagonal blocks its (a, a) tuple goes to
+  BA_TLV(uint8_t, cp_rankL);                          // per (left-over point, edge in pose order): copy of the diagonal blocks its (a, a) tuple goes to
   b->pinv.resize(P);
   if (PL > 0) {
-    std::vector<int> loc(P, -1), ep, ept;
+    BA_TLV(int, loc); BA_TLV(int, ep); BA_TLV(int, ept); loc.assign(P, -1); ep.clear(); ept.clear();
     for (int i = 0; i < PL; ++i) loc[left[i]] = i;
     if (PL == P) ba_compose_chunks(K, fixed, P, E, e_pose, e_point, kn.no_permute ? 1 : kn.lookahead, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
     else {
       ep.reserve(E); ept.reserve(E);
       for (int e = 0; e < E; ++e) if (loc[e_point[e]] >= 0) { ep.push_back(e_pose[e]); ept.push_back(loc[e_point[e]]); }
-      ba_compose_chunks(K, fixed, PL, (int)ep.size(), ep.data(), ept.data(), kn.no_permute ? 1 : kn.lookahead, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
+      // (the left-over points are the ones with rare signatures: a third of the look-ahead finds them partners almost as well, in a third of the time)
+      ba_compose_chunks(K, fixed, PL, (int)ep.size(), ep.data(), ept.data(), kn.no_permute ? 1 : std::max(2, kn.lookahead / 3), prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
     }
   } else {
     chunk_pt0L.assign(1, 0);
@@ -718,7 +732,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
       for (int c = 0; c < n_rm; ++c) {
         const Run& R = runs[rm_chunk_run[c]];
         const int p0 = b->se_chunk_pt0[c], p1 = std::min(b->se_chunk_pt0[c + 1], rm_run_pt0[rm_chunk_run[c] + 1]);
-        rm_chunk[c] = make_int4(pt_off[p0], (pt_off[p1] - pt_off[p0]) | (R.k << 8) | ((p1 - p0) << 16), rm_chunk_run[c], (65536 + R.k - 1) / R.k);
+        rm_chunk[c] = make_int4(pt_off[p0], (pt_off[p1] - pt_off[p0]) | (R.k << 8) | ((p1 - p0) << 16), rm_chunk_run[c], p0);
       }
       run_lane.assign(runs.size() * 64, make_uint2(0u, 0u));
       for (size_t r = 0; r < runs.size(); ++r) {
@@ -827,7 +841,8 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   }
   tick("stream");
   const BaKnobs& kn = ba_knobs();
-  BaPlan pl;
+  static thread_local BaPlan tl_pl;            // (keeps its vectors' capacity for the next window this host thread builds)
+  BaPlan& pl = tl_pl;
   ba_plan(b, pl, K, fixed, P, E, e_pose, e_point, e_obs, e_invsig2, e_face, tick);
   std::vector<int>&pose_slot = pl.pose_slot, &prank = pl.prank, &s_pose = pl.s_pose, &s_point = pl.s_point, &pt_off = pl.pt_off, &pose_off = pl.pose_off, &pose_edges = pl.pose_edges;
   std::vector<double>&s_obs = pl.s_obs, &s_inv = pl.s_inv;
@@ -1035,7 +1050,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     for (int i = 0; i < 4; ++i) q[i] /= nn;
   }
-  std::vector<double> pin(3 * (size_t)P);
+  BA_TLV(double, pin); pin.assign(3 * (size_t)P, 0.0);
   for (int i = 0; i < P; ++i) for (int j = 0; j < 3; ++j) pin[3 * (size_t)i + j] = points[3 * (size_t)b->pinv[i] + j];
   up(fixed, K, &b->d_fixed); up(pose_slot.data(), K * sizeof(int), &b->d_pose_slot); up(s_pose.data(), E * sizeof(int), &b->d_e_pose);
   up(s_point.data(), E * sizeof(int), &b->d_e_point); up(s_obs.data(), 2 * (size_t)E * sizeof(double), &b->d_e_obs);

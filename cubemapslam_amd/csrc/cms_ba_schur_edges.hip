@@ -50,7 +50,7 @@ struct BaSe {                      // device view of the edge-major work list (c
   int R, nchunks, cpw;            // ranges (workgroups) of the edge-major body over the chunks [n_rm, nchunks), all chunks, chunks per range
   int n_rm, R_rm;                 // chunks [0, n_rm) hold points of ONE observation signature each (cms_ba_schur_runs.hip): R_rm workgroups take them;
                                   // their slices of `partial` come first, the edge-major ranges' slices follow (R_rm + R slices in all)
-  const int4* rm_chunk;           // n_rm: first edge | edges + (edges per point << 8) + (points << 16) | run | ceil(65536 / edges per point)
+  const int4* rm_chunk;           // n_rm: first edge | edges + (edges per point << 8) + (points << 16) | run | first (internal) point
   const uint2* run_lane;          // runs x 64: which tuple of the signature a consumer lane multiplies, and where its sum goes (ba_rm_lane_*)
   int Rt, cpw_t;                  // the same chunks cut into more, shorter ranges for the edge-major trial kernel (no LDS copy of the system to amortise)
   int npairs2;                    // np (np + 1) / 2: pose pairs s1 <= s2 enumerated densely, row by row

@@ -84,42 +84,47 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
 #pragma unroll
   for (int i = 0; i < 27; ++i) hp[i] = 0.0;
   int hp_slot = -1;
-  int4 n_desc = make_int4(0, 0, -1, 0);
+  // Loads run two chunks ahead and never depend on each other inside a step: the descriptor of chunk c + 2 and everything chunk c + 1 needs
+  // (its per-edge words AND its points' positions -- the points of a run chunk are consecutive, so a lane's point follows from the chunk's
+  // first point and the lane: no index has to arrive first) are requested when chunk c is started.  (A first version fetched the positions
+  // at the end of the step, behind the point index: every step then began by waiting a memory round trip.)
+  int4 d_cur = make_int4(0, 0, -1, 0), d_nxt = make_int4(0, 0, -1, 0);
+  if (cb < ce) d_cur = se.rm_chunk[cb];
+  if (cb + 1 < ce) d_nxt = se.rm_chunk[cb + 1];
   int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;
   double n_X[3] = {0, 0, 0};
   double2 n_obs = make_double2(0.0, 0.0);
-  auto load1 = [&](int c) {
-    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0; n_desc = make_int4(0, 0, -1, 0);
-    if (c < ce) {
-      n_desc = se.rm_chunk[c];
-      const int e = n_desc.x + lane;
-      if (lane < (n_desc.y & 255)) {
-        n_p = d.e_point[e]; n_info = se.e_info[e]; n_e = e;
-        n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0;
-        n_obs = reinterpret_cast<const double2*>(d.e_obs)[e];
-      }
-    }
-  };
-  auto load2 = [&]() {
-    if (n_info != 0) {
+  auto load_chunk = [&](const int4 dc) {      // requests everything the chunk described by dc needs from global memory
+    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0;
+    const int ne = dc.y & 255, kk = (dc.y >> 8) & 255;
+    if (dc.z >= 0 && lane < ne) {
+      const int e = dc.x + lane;
+      n_e = e; n_info = se.e_info[e];
+      n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0;
+      n_obs = reinterpret_cast<const double2*>(d.e_obs)[e];
+      n_p = dc.w + ((lane * ((65536 + kk - 1) / kk)) >> 16);          // first point of the chunk + lane / edges per point
       const double* Xp = pts + 3 * (size_t)n_p;
       n_X[0] = Xp[0]; n_X[1] = Xp[1]; n_X[2] = Xp[2];
     }
   };
-  load1(cb); load2();
+  load_chunk(d_cur);
   for (int s = 0; s < nsteps; ++s) {
     {
       const int c = cb + s;
       if (c < ce) {
         double* buf = mybufs + (size_t)(s & 1) * BA_RM_BUF;
-        const int4 desc = n_desc;
+        const int4 desc = d_cur;
         const uint32_t info = n_info;
         double ow = n_ow;
         const int pnt = n_p, eid = n_e;
         const double2 obs = n_obs;
         const double X[3] = {n_X[0], n_X[1], n_X[2]};
-        load1(c + 1);
+        d_cur = d_nxt;
+        d_nxt = make_int4(0, 0, -1, 0);
+        if (c + 2 < ce) d_nxt = se.rm_chunk[c + 2];
+        load_chunk(d_cur);
         const int k_run = (desc.y >> 8) & 255;
+        const int invk = (65536 + k_run - 1) / k_run;
         int slot = -1, a = 0;
         double Jp[12], Jl[6], o0 = 0.0, o1 = 0.0;
         bool have_jac = false;
@@ -195,7 +200,7 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
           const double i2 = 1.0 / d2;
           if (a == 0) {                                            // the point's slot: D^-1 | z = D^-1 L^-1 bl
             const double y0 = sum[6], y1 = sum[7] - l10 * y0, y2 = sum[8] - l20 * y0 - l21 * y1;
-            const int j = ((lane - a) * desc.w) >> 16;             // point of the chunk: lane / k_run
+            const int j = ((lane - a) * invk) >> 16;               // point of the chunk: lane / k_run
             double2* pp = reinterpret_cast<double2*>(buf + 64 * 18 + (size_t)j * 6);
             pp[0] = make_double2(i0, i1); pp[1] = make_double2(i2, i0 * y0); pp[2] = make_double2(i1 * y1, i2 * y2);
           }
@@ -225,12 +230,11 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
 #pragma unroll
           for (int i = 0; i < 9; ++i) row2[i] = make_double2(W[2 * i], W[2 * i + 1]);
         }
-        load2();
         // ---- end of the run (or of this pair's range): S_aa - Hpp_aa and s_a - bp_a get the key frame's part, bp its own six slots.  Lanes
         // of one key frame are k_run apart; they are spread over the four diagonal copies by their point
-        if (n_desc.z != desc.z) {
+        if (d_cur.z != desc.z) {
           if (hp_slot >= 0) {
-            const int j = ((lane - a) * desc.w) >> 16;
+            const int j = ((lane - a) * invk) >> 16;
             double* base = Dg + ((size_t)(j & (BA_SE_DCOPIES - 1)) * np + hp_slot) * BA_SE_DSTRIDE;
 #pragma unroll
             for (int i = 0; i < 21; ++i) unsafeAtomicAdd(base + i, -hp[i]);
@@ -251,17 +255,20 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
 #pragma unroll
   for (int i = 0; i < 42; ++i) acc[i] = 0.0;
   int cur_run = -1;
-  uint2 lt = make_uint2(0u, 0u);
-  int4 c_desc = cb < ce ? se.rm_chunk[cb] : make_int4(0, 0, -1, 0);       // descriptor of the chunk the next step consumes
+  int4 c_desc = make_int4(0, 0, -1, 0);                                   // descriptor of the chunk the next step consumes
+  if (cb < ce) c_desc = se.rm_chunk[cb];
+  uint2 lt = make_uint2(0u, 0u), lt_next = make_uint2(0u, 0u);
+  if (c_desc.z >= 0) lt_next = se.run_lane[(size_t)c_desc.z * 64 + lane];
   for (int s = 0; s < nsteps; ++s) {
     {
       const int c = cb + s - 1;
       if (s >= 1 && c < ce) {
         const double* buf = mybufs + (size_t)((s - 1) & 1) * BA_RM_BUF;
         const int4 desc = c_desc;
-        c_desc = c + 1 < ce ? se.rm_chunk[c + 1] : make_int4(0, 0, -1, 0);   // (its run is only looked at after the products below)
+        c_desc = make_int4(0, 0, -1, 0);
+        if (c + 1 < ce) c_desc = se.rm_chunk[c + 1];                        // (its run is only looked at after the products below)
         const int next_run = c_desc.z;
-        if (desc.z != cur_run) { cur_run = desc.z; lt = se.run_lane[(size_t)cur_run * 64 + lane]; }
+        if (desc.z != cur_run) { cur_run = desc.z; lt = lt_next; }         // (requested when the previous run ended)
         const int k_run = (desc.y >> 8) & 255, m = desc.y >> 16;
         const bool valid = (lt.x >> 23) & 1u, diag = (lt.x >> 24) & 1u;
         if (valid) {
@@ -307,6 +314,7 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
           }
 #pragma unroll
           for (int i = 0; i < 42; ++i) acc[i] = 0.0;
+          if (next_run >= 0) lt_next = se.run_lane[(size_t)next_run * 64 + lane];      // the next run's lane table travels behind the barrier
         }
       }
     }

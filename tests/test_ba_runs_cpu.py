@@ -51,10 +51,12 @@ def test_run_plan_replays_the_schur_sum(K, P, views, seed):
     P_rm = pl["rm_points"]
     assert (c0[n_rm] if n_rm < len(c0) else P) == P_rm
     for c in range(n_rm):
-        e0, word, run, invk = (int(v) for v in rmc[c])
+        e0, word, run, pfirst = (int(v) for v in rmc[c])
         ne, k, m = word & 255, (word >> 8) & 255, word >> 16
+        invk = (65536 + k - 1) // k
         p0, p1 = c0[c], c0[c + 1]
-        assert e0 == pt_off[p0] and ne == pt_off[p1] - pt_off[p0] and m == p1 - p0 and ne == k * m and invk == (65536 + k - 1) // k
+        assert e0 == pt_off[p0] and ne == pt_off[p1] - pt_off[p0] and m == p1 - p0 and ne == k * m and pfirst == p0
+        assert np.array_equal(s_pt[e0:e0 + ne], pfirst + ((np.arange(ne) * invk) >> 16))      # a lane's point follows from the chunk's first point
         assert 0 <= run < pl["n_runs"] and m <= 32
         sig = s_pose[pt_off[p0]:pt_off[p0] + k]
         assert np.array_equal(s_pose[e0:e0 + ne].reshape(m, k), np.tile(sig, (m, 1)))
@@ -87,8 +89,9 @@ def test_run_plan_replays_the_schur_sum(K, P, views, seed):
             acc = np.zeros(64, np.int64); hp = np.zeros(64, np.int64); hp_slot = np.full(64, -1)
             cur_run = -1; lt = None
             for c in range(cb, ce):
-                e0, word, run, invk = (int(v) for v in rmc[c])
+                e0, word, run, _ = (int(v) for v in rmc[c])
                 ne, k, m = word & 255, (word >> 8) & 255, word >> 16
+                invk = (65536 + k - 1) // k
                 nxt = int(rmc[c + 1][2]) if c + 1 < ce else -1
                 # producer
                 for lane in range(ne):

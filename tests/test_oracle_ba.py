@@ -103,3 +103,45 @@ def test_stop_flag_returns_untouched():
     prob = small_problem(4)
     out = orc.ba_run(prob, stop=True)
     assert out["rc"] == 1 and np.array_equal(out["poses"], prob["poses"]) and np.array_equal(out["points"], prob["points"])
+
+
+def ba_point_update_errors(prob, a, b):
+    """per point: |a - b| relative to b's update of that point, with the parity bar's floor (1 % of the median update)"""
+    nrm = np.linalg.norm(b["points"] - prob["points"], axis=1)
+    err = np.linalg.norm(a["points"] - b["points"], axis=1)
+    moved = nrm[nrm > 0]
+    return err / np.maximum(nrm, 0.01 * (np.median(moved) if len(moved) else 0.0))
+
+
+def test_reference_algorithm_is_chaotic_at_float_rounding():
+    """The reference evaluates the residual through a float: multipinhole_project casts the camera-frame point to cv::Vec3f and stores the
+    projection in float (g2o_cubemap_vertices_edges.cpp:225-233) inside an otherwise double optimisation.  Two runs
+    whose estimates differ in the 15th digit can round a coordinate to different floats; each flip moves one residual by a float ulp
+    (3e-5 px), which makes the next flips likelier.  Shown here on the ORACLE ALONE: the same window with its initial points moved by 1e-12 m
+    ends, after the same number of iterations and with the same outlier flags, with key-frame updates that differ by up to ~1e-6 and a few
+    hundred point updates that differ by more than 1e-4 (up to ~1e-3) of their size -- whether the window's points are tracked over
+    neighbouring key frames or seen from random, wide-baseline views.  The product meets the oracle to ~1e-10 on most windows because its
+    estimates agree with the oracle's to the last few bits for the first iterations and no coordinate happens to sit on a float boundary;
+    about one 80 k-edge window in twenty gets a first flip and cascades.  This is why the GPU parity tests
+    (tests/test_gpu_parity.py::_ba_updates_close_or_cascade) hold a window that cascaded to "key frames within 1e-4, points no worse than
+    the oracle does to itself" instead of 1e-4 per point."""
+    rs = np.random.RandomState(0)
+    out = {}
+    for views in ("track", "random"):
+        prob = synth.ba_problem(K=20, P=6000, obs_per_point=4, F=550, seed=312, views=views)
+        w = orc.ba_run(prob)
+        worst_pt, worst_pose, n_bad = 0.0, 0.0, 0
+        for t in range(2):
+            p2 = dict(prob); p2["points"] = prob["points"] + rs.normal(0, 1e-12, prob["points"].shape)
+            w2 = orc.ba_run(p2)
+            assert list(w2["stats"].iterations_done) == list(w["stats"].iterations_done)
+            r = ba_point_update_errors(prob, w2, w)
+            tn = np.linalg.norm(w["poses"][:, :3] - prob["poses"][:, :3], axis=1)
+            te = np.linalg.norm(w2["poses"][:, :3] - w["poses"][:, :3], axis=1)
+            worst_pt = max(worst_pt, float(r.max())); n_bad = max(n_bad, int((r > 1e-4).sum()))
+            worst_pose = max(worst_pose, float((te[tn > 0] / tn[tn > 0]).max()))
+        out[views] = (worst_pt, worst_pose, n_bad)
+    # a 1e-12 m perturbation is 1e-10 of a point update: anything beyond ~1e-8 relative is amplification by the float round trip
+    for views in ("track", "random"):
+        assert out[views][0] > 1e-5 and out[views][1] > 1e-9, out        # amplified by many orders of magnitude ...
+        assert out[views][1] < 1e-4 and out[views][0] < 2e-2, out        # ... yet the key frames stay far inside the bar, the points within a percent
