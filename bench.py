@@ -304,10 +304,14 @@ def main():
         p["e_obs"] = np.ascontiguousarray(p["e_obs"], np.float64)
     n_wthreads = args.window_threads or max(4, min(32, (os.cpu_count() or 8) // 4))
     wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
-    def make_window(p):
+    group_stream = []           # one long-lived stream per window group (filled below): CreateNewMapPoints and the group's BA rounds
+    def make_window(p, gi=-1):
         t1 = time.perf_counter()
-        ba = api.BundleAdjuster(p, device=local_rank)
-        return ba, 1e3 * (time.perf_counter() - t1)
+        ba = api.BundleAdjuster(p, device=local_rank)      # uploads on a stream from the library's pool ...
+        if gi >= 0 and not own_streams:
+            ba.set_stream(group_stream[gi])                # ... and runs on its group's stream.  (Every window on a stream of its own meant ~100
+        return ba, 1e3 * (time.perf_counter() - t1)        # streams on 8 hardware queues: the two groups' chains and CreateNewMapPoints queued behind each other)
+    own_streams = os.environ.get("CMS_BENCH_WINDOW_STREAMS", "") != ""      # developer knob: the old behaviour
     def finish_window(ba):
         out = ba.read()             # poses, points, outlier flags -> host arrays (Optimizer.cpp:419-450)
         ba.close()                  # cms_ba_destroy
@@ -348,12 +352,13 @@ def main():
                 K, keep = api.make_keyframe(k)
                 st.put(base + i, K)
             jobs_g.append((base, list(range(base + 1, base + tri_nn + 1))))
-        tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g)
+        tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g); group_stream.append(cg.stream)
         if os.environ.get("CMS_BENCH_SHARED_STREAMS", "") != "":
             for ba in grp:                   # developer knob: the whole mapping side of a group on ONE stream (cms_ba_set_stream).  Measured
                 ba.set_stream(cg.stream)     # slower (15.9 against 14.4 ms per step): the resets and CreateNewMapPoints then queue behind the group's BA
 
     schur_acc = {"ms": 0.0, "n": 0}
+    worker_ms = {}
     def ba_worker(grp, gi, keep):
         """optimise-only pass: one group of STANDING windows of one step; returns (elapsed ms, new map points, per-window stats)"""
         t_ba0 = time.perf_counter()
@@ -370,13 +375,19 @@ def main():
         points, per-window stats, futures of the read-backs, the windows' creation times)"""
         t_ba0 = time.perf_counter()
         made = [f.result() for f in futs]
+        t_w = time.perf_counter()
         grp = [m[0] for m in made]
         grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (the BA chain's largest kernel)
         res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+        t_t = time.perf_counter()
         _, stats = api.ba_optimize_many(grp, (5, 10))
+        t_o = time.perf_counter()
         ms, nl = grp[0].profile_get()
         schur_acc["ms"] += ms; schur_acc["n"] += nl
         outs = [wpool.submit(finish_window, ba) for ba in grp]
+        for k_, v_ in (("wait_for_windows", t_w - t_ba0), ("create_new_map_points", t_t - t_w), ("optimize_many", t_o - t_t), ("hand_over", time.perf_counter() - t_o)):
+            worker_ms[k_] = worker_ms.get(k_, 0.0) + 1e3 * v_
+        worker_ms["n"] = worker_ms.get("n", 0) + 1
         return 1e3 * (time.perf_counter() - t_ba0), sum(len(r[0]) for r in res), stats, outs, [m[1] for m in made]
 
     part = os.environ.get("CMS_BENCH_PART", "")      # developer knob: "ba" / "frames" times one half of the step alone (not a bench line)
@@ -387,15 +398,25 @@ def main():
     def submit_windows(j):
         """the pool starts building the n_ba windows of problem set j; returned per group"""
         life["pending_set"] = j
-        life["pending"] = [[wpool.submit(make_window, prob_sets[j][w]) for w in ids] for ids in group_ids]
+        life["pending"] = [[wpool.submit(make_window, prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]
 
     # developer knob: queue the mapping side of a step behind the step's extraction (cms_stream_wait_extracted) instead of letting the two
     # overlap.  Measured: the extractor then runs at 35 % instead of 33 % of its byte roofline inside the step (43 % with no local BA in
     # the step at all: the FP64 chain also pulls the clocks down), and the step gets 4 % longer -- overlap stays the default
     serial = os.environ.get("CMS_BENCH_SERIAL_EXTRACT", "") != ""
+    ba_first = os.environ.get("CMS_BENCH_BA_FIRST", "")     # developer knob: hand the mapping side to its threads BEFORE the frame path is enqueued (value = head start in us)
     def step(i, streaming, keep=False):
         S = sets[i % 2]
         ths = []
+        if ba_first and part != "frames" and life["on"]:
+            cur, cur_set = life["pending"], life["pending_set"]
+            submit_windows(cur_set ^ 1)
+            ths = [pool.submit(ba_worker_life, cur[gi], gi, keep) for gi in range(n_grp)]
+            last["set"] = cur_set
+            if int(ba_first) > 0:
+                t_hs = time.perf_counter()
+                while time.perf_counter() - t_hs < 1e-6 * int(ba_first):
+                    pass
         if part != "ba":
             po.launch()                 # own stream, overlaps the frame path
             if not streaming:
@@ -411,7 +432,9 @@ def main():
                 for gi, grp in enumerate(groups):
                     ctx.stream_wait_extracted(tri_ctx[gi].stream)
                     ctx.stream_wait_extracted(grp[0].stream)
-            if life["on"]:
+            if ths:
+                pass
+            elif life["on"]:
                 cur, cur_set = life["pending"], life["pending_set"]
                 submit_windows(cur_set ^ 1)                # the next step's windows are built under this step
                 ths = [pool.submit(ba_worker_life, cur[gi], gi, keep) for gi in range(n_grp)]
@@ -474,6 +497,7 @@ def main():
         barrier()
         acc["ba_ms"], acc["ba_n"], acc["create_ms"], acc["create_n"] = 0.0, 0, 0.0, 0
         schur_acc["ms"], schur_acc["n"] = 0.0, 0
+        worker_ms.clear()
         # The timed region holds, per step, the creation of one set of windows (the NEXT step's, by the pool), the optimisation of one set, and the
         # read-back + destruction of one set (the PREVIOUS step's finish under this one); the region ends only when the last step's read-backs are
         # through.  The windows the last step built for a step that never runs are destroyed after the clock stops (they were built inside it).
@@ -502,9 +526,10 @@ def main():
     ctx.profile(True)
     dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
     create_ms_in_step = acc["create_ms"] / max(acc["create_n"], 1)
+    worker_break = {k_: round(v_ / max(worker_ms.get("n", 1), 1), 3) for k_, v_ in worker_ms.items() if k_ != "n"}      # per window group and step
     if part:
         if rank == 0:
-            print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms_per_step, 3), "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
+            print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms_per_step, 3), "ba_window_setup": {"ms_per_window_inside_the_step": round(create_ms_in_step, 2)}, "ba_worker_ms": worker_break, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
         pool.shutdown()
         wpool.shutdown()
         return
@@ -808,7 +833,7 @@ def main():
                                            "note": "every step creates its %d windows from the problems' host arrays (cms_ba_create: host work lists, one pinned upload), optimises "
                                                    "them, reads poses / points / outlier flags back (cms_ba_read) and destroys them; a pool of host threads builds step s + 1's "
                                                    "windows and finishes step s - 1's while step s runs, all inside the timed region" % n_ba},
-                       "optimise_only": optimise_only, "ba_views": args.ba_views,
+                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "ba_views": args.ba_views,
                        "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
                        "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,

@@ -641,16 +641,18 @@ def ba_compose_chunks(fixed, n_points, e_pose, e_point, lookahead=48):
     return pinv, pt0[:n.value + 1].copy(), rank
 
 
-def ba_plan(fixed, n_points, e_pose, e_point):
+def ba_plan(fixed, n_points, e_pose, e_point, tables=False):
     """Host-only: the plan cms_ba_create makes (cms_ba_debug_plan): internal order, chunks, signature runs and the run-major kernel's tables."""
     fixed = np.ascontiguousarray(fixed, np.uint8); e_pose = np.ascontiguousarray(e_pose, np.int32); e_point = np.ascontiguousarray(e_point, np.int32)
     P, E = int(n_points), len(e_pose)
     pinv = np.zeros(P, np.int32); perm = np.zeros(E, np.int32); info = np.zeros(E, np.uint32); pt0 = np.zeros(P + 2, np.int32)
     rmc = np.zeros((P, 4), np.int32); rl = np.zeros((P, 64, 2), np.uint32); cnt = np.zeros(8, np.int32)
-    _chk(lib().cms_ba_debug_plan(len(fixed), _p(fixed), P, E, _p(e_pose), _p(e_point), _p(pinv), _p(perm), _p(info), _p(pt0), _p(rmc), _p(rl), _p(cnt)),
-         "cms_ba_debug_plan")
+    mf = np.zeros((P, 64), np.uint32) if tables else None; fl = np.zeros((P, 64, 12), np.uint32) if tables else None
+    _chk(lib().cms_ba_debug_plan(len(fixed), _p(fixed), P, E, _p(e_pose), _p(e_point), _p(pinv), _p(perm), _p(info), _p(pt0), _p(rmc), _p(rl), _p(cnt),
+                                 _p(mf), _p(fl)), "cms_ba_debug_plan")
     nch, n_rm, nruns = int(cnt[0]), int(cnt[1]), int(cnt[2])
     return dict(pinv=pinv, perm=perm, info=info, chunk_pt0=pt0[:nch + 1].copy(), rm_chunk=rmc[:n_rm].copy(), run_lane=rl[:nruns].copy(), n_chunks=nch,
+                run_mf=None if mf is None else mf[:nruns].copy(), run_fl=None if fl is None else fl[:nruns].copy(),
                 n_rm=n_rm, n_runs=nruns, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), usable=bool(cnt[7]))
 
 

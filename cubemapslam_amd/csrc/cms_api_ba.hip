@@ -18,7 +18,7 @@
 // and the choices made when it is optimised (which kernels run) can never disagree.  Tests that flip a switch use a child process.
 struct BaKnobs {
   bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
-  bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce;
+  bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, rm_valu;
   int lookahead, compose_segments, dup, run_min_chunks, rm_weight;
   char stream_priority;
 };
@@ -36,9 +36,10 @@ static const BaKnobs& ba_knobs() {
     q.create_timing = on("CMS_BA_CREATE_TIMING"); q.compose_timing = on("CMS_BA_COMPOSE_TIMING");
     q.runs = !on("CMS_BA_NO_RUNS");                      // signature runs (cms_ba_schur_runs.hip); off = every point through the edge-major kernel
     q.runs_as_edges = on("CMS_BA_RUNS_AS_EDGES");        // keep the run order of the points but let the edge-major body take the run chunks too
+    q.rm_valu = on("CMS_BA_RM_VALU");                    // the runs' tuple products on the vector ALU (producer / consumer pairs) instead of MFMA tiles
     q.separate_reduce = on("CMS_BA_SEPARATE_REDUCE");    // kb_ba_schur_edges_reduce as its own launch instead of inside the solve kernel
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
-    q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", 2));
+    q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", q.rm_valu ? 2 : 1));
     q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 100)));
     const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
     q.stream_priority = pr ? pr[0] : 0;
@@ -77,7 +78,7 @@ struct cms_ba {
   // edge-major Schur work list (se.R == 0: not available: too many free key frames for the LDS copy of the reduced system)
   BaSe se = {};
   int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_bp_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
-  int* d_se_lone = nullptr; int4* d_rm_chunk = nullptr; uint2* d_run_lane = nullptr;
+  int* d_se_lone = nullptr; int4* d_rm_chunk = nullptr; uint2* d_run_lane = nullptr; uint32_t* d_run_mf = nullptr; uint32_t* d_run_fl = nullptr;
   size_t se_lds_fixed = 0; int se_waves = 0;      // LDS of the edge-major kernel without the per-wavefront part; wavefronts per workgroup that fit
   size_t rm_lds = 0; int n_runs = 0, rm_points = 0;   // run-major part (cms_ba_schur_runs.hip): LDS it needs (0: the window has no runs), runs, points inside runs
   char* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned block the window's uploads went through; cms_ba_read's read-back reuses it
@@ -92,6 +93,7 @@ struct cms_ba {
   // 6 the trial kernel (kb_ba_trial_edges), 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
+  bool async_pending = false;   // something asynchronous (upload, reset) was enqueued on `stream` and nothing has waited for it yet
   BaSe grp_se = {};          // the window's share of the current group's Schur launch (ba_upload_items)
   std::vector<BaBlock> slabs; size_t slab_off = 0;      // device memory of the window: carved from pooled slabs (ba_alloc)
   size_t grp_pin_bytes[3] = {0, 0, 0};                  // sizes of grp_items_host, grp_scal_host, grp_lm_host (pooled pinned blocks)
@@ -105,7 +107,8 @@ static int ba_lds_attrs_once(int device) {
   static bool done[64] = {false};
   std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || done[device]) return CMS_OK;
-  const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)kb_ba_lin_schur_edges, (const void*)k_ba_trial_solve,
+  const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)kb_ba_lin_schur_edges,
+                       (const void*)kb_ba_lin_schur_runs, (const void*)kb_ba_lin_schur_runs_valu, (const void*)kb_ba_trial_solve3r, (const void*)k_ba_trial_solve,
                        (const void*)kb_ba_trial_solve, (const void*)kb_ba_trial_solve3, (const void*)k_ba_solve_r192};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);
@@ -214,7 +217,10 @@ template <class T> static int ba_alloc(cms_ba* b, T** p, size_t n) {
 extern "C" void cms_ba_destroy(cms_ba* b) {
   if (!b) return;
   hipSetDevice(b->device);
-  if (b->stream) hipStreamSynchronize(b->stream);      // nothing of this window may still be running when its memory goes back to the pool
+  // nothing of this window may still be running when its memory goes back to the pool.  A window on a stream of its own waits for that
+  // stream; a window on a stream it shares (cms_ba_set_stream: the group's stream, busy with the NEXT windows by now) only when it has
+  // something of its own pending there -- optimise / read return with the window's work complete
+  if (b->stream && (b->own_stream || b->async_pending)) hipStreamSynchronize(b->stream);
   for (const BaBlock& sl : b->slabs) ba_dev_give(b->device, sl.p, sl.bytes);
   if (b->h_pin) ba_pin_give(b->device, b->h_pin, b->h_pin_bytes);
   if (b->h_stage) ba_pin_give(b->device, b->h_stage, b->h_stage_bytes);
@@ -233,6 +239,7 @@ extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
   if (!b || !hip_stream) return cms_fail(CMS_ERR_ARG, "cms_ba_set_stream: bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
+  b->async_pending = false;
   if (b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else HIPCHK(hipStreamDestroy(b->stream)); }
   b->stream = (hipStream_t)hip_stream; b->own_stream = false;
   return CMS_OK;
@@ -247,6 +254,11 @@ extern "C" int cms_ba_profile_get(cms_ba* b, double* total_ms, long* launches) {
   *total_ms = b->prof_ms; *launches = b->prof_launches;
   return CMS_OK;
 }
+#ifdef BA_RM_CLK
+extern "C" int cms_ba_debug_rm_clocks(long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(ba_rm_clk), 16 * sizeof(long long)) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
+}
+#endif
 extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
   if (!b || !out8) return CMS_ERR_ARG;
   return hipMemcpy(out8, b->d_scal + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
@@ -503,7 +515,8 @@ static void ba_se_split(BaSe& se, int Rtotal) {
     R_se = Rtotal - R_rm;
   } else if (se.n_rm > 0) R_rm = Rtotal;
   else R_se = Rtotal;
-  if (se.n_rm > 0) R_rm = std::min(R_rm, (se.n_rm + BA_RM_PAIRS - 1) / BA_RM_PAIRS);      // a producer / consumer pair wants at least one chunk
+  const int per_wg = ba_knobs().rm_valu ? BA_RM_PAIRS : BA_SE_THREADS / 64;            // chunk walkers per workgroup: pairs (vector variant) or wavefronts
+  if (se.n_rm > 0) R_rm = std::min(R_rm, (se.n_rm + per_wg - 1) / per_wg);              // each wants at least one chunk
   se.cpw = n_se > 0 ? std::max(1, (n_se + R_se - 1) / R_se) : 1;
   se.R = n_se > 0 ? (n_se + se.cpw - 1) / se.cpw : 0;
   se.R_rm = R_rm;
@@ -518,6 +531,7 @@ struct BaPlan {
   std::vector<uint32_t> info;
   std::vector<int4> rm_chunk;
   std::vector<uint2> run_lane;
+  std::vector<uint32_t> run_mf, run_fl;
   bool se_built = false;
 };
 template <class Tick>
@@ -530,6 +544,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   std::vector<uint32_t>& info = pl.info;
   std::vector<int4>& rm_chunk = pl.rm_chunk;
   std::vector<uint2>& run_lane = pl.run_lane;
+  std::vector<uint32_t>&run_mf = pl.run_mf, &run_fl = pl.run_fl;
   bool& se_built = pl.se_built;
   struct InFlight { InFlight() { ba_plans_in_flight.fetch_add(1); } ~InFlight() { ba_plans_in_flight.fetch_sub(1); } } in_flight;
   const BaKnobs& kn = ba_knobs();
@@ -607,11 +622,12 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
       const int q = gfirst[g], k = cpo[q + 1] - cpo[q];
       int kf = 0;
       for (int i = cpo[q]; i < cpo[q + 1]; ++i) kf += pose_slot[e_pose[cpe[i]]] >= 0;
-      if (k < 1 || kf < 1 || kf * (kf + 1) / 2 > 64) continue;
+      if (k < 1 || kf < 1 || kf * (kf + 1) / 2 > 64 || (!kn.rm_valu && 6 * kf + 1 > 48)) continue;      // (lane tables of the vector variant / three MFMA tiles a side)
       const int m = std::min(64 / k, BA_RM_PTS);
-      if (gcount[g] < kn.run_min_chunks * m) continue;
+      if (gcount[g] < kn.run_min_chunks * m) continue;           // at least that many FULL chunks: a run pays for one set of LDS additions
       const int full = gcount[g] / m, tail = gcount[g] - full * m;
-      const bool keep_tail = tail > 0 && 4 * tail >= 3 * m;
+      const bool keep_tail = tail > 0 && 2 * tail >= m;          // a last chunk that is at least half full
+      if (full == 0 && !keep_tail) continue;
       run_of_group[g] = (int)runs.size();
       take[g] = full * m + (keep_tail ? tail : 0);
       runs.push_back({k, q, take[g], full + (keep_tail ? 1 : 0), m});
@@ -699,7 +715,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   tick("csr");
   // ---- work lists of the edge-major / run-major Schur kernels: chunks of whole points with <= 64 edges (one wavefront each), the per-edge
   // words, the runs' chunk descriptors and consumer-lane tables, the dense enumeration of the pose pairs s1 <= s2 for the solve kernel
-  ce0.clear(); pob.clear(); ident.clear(); lone.clear(); info.clear(); rm_chunk.clear(); run_lane.clear();
+  ce0.clear(); pob.clear(); ident.clear(); lone.clear(); info.clear(); rm_chunk.clear(); run_lane.clear(); run_mf.clear(); run_fl.clear();
   se_built = false;
   if (se_ok) {
     bool ok = true;
@@ -750,6 +766,50 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
                              : (uint32_t)((fslot[ia] * np - (fslot[ia] * (fslot[ia] + 1)) / 2 + (fslot[ib] - fslot[ia] - 1)) * BA_SE_SSTRIDE);
             }
       }
+      // the MFMA variant's stacked matrix of a signature: row / column i = (free key frame a = i / 6, row r = i % 6), then the rhs column
+      run_mf.assign(runs.size() * 64, BA_RM_MF_NONE);
+      for (size_t r = 0; r < runs.size(); ++r) {
+        const int q = runs[r].first;
+        int kf = 0;
+        for (int i = cpo[q]; i < cpo[q + 1]; ++i) {
+          const int s = pose_slot[e_pose[cpe[i]]];
+          if (s < 0) continue;
+          if (kf < 8) {                                            // (signatures with more free key frames exist in the vector variant only)
+            for (int rr = 0; rr < 6; ++rr) run_mf[r * 64 + 6 * kf + rr] = (uint32_t)((i - cpo[q]) * 18 + 3 * rr);
+            run_mf[r * 64 + 48 + kf] = (uint32_t)s;
+          }
+          ++kf;
+        }
+        if (6 * kf < 48) run_mf[r * 64 + 6 * kf] = BA_RM_MF_RHS;
+        run_mf[r * 64 + 56] = (uint32_t)kf;
+      }
+      // ... and where a lane's accumulators go: accumulator g of tile (ti, tj) in lane l holds G[16 ti + (l >> 4) + 4 g][16 tj + (l & 15)]; the
+      // upper triangle of every (key frame, key frame) block and the rhs column have a place in the LDS copy (block layout: ba_se_off; diagonal
+      // blocks and right-hand sides in the diagonal copy g), everything else (lower triangle, padding) goes nowhere
+      run_fl.assign(runs.size() * 64 * 12, 0xFFFFFFFFu);
+      static const int tile_i[6] = {0, 0, 1, 0, 1, 2}, tile_j[6] = {0, 1, 1, 2, 2, 2};
+      for (size_t r = 0; r < runs.size(); ++r) {
+        const int kf = (int)run_mf[r * 64 + 56], n6 = 6 * kf;
+        if (n6 + 1 > 48) continue;                                 // (vector variant only)
+        for (int l = 0; l < 64; ++l)
+          for (int t = 0; t < 6; ++t)
+            for (int g = 0; g < 4; ++g) {
+              const int I = 16 * tile_i[t] + (l >> 4) + 4 * g, N = 16 * tile_j[t] + (l & 15);
+              if (!(I < n6 && N <= n6 && (N == n6 || I <= N))) continue;
+              const int a1 = I / 6, r1 = I % 6, s1 = (int)run_mf[r * 64 + 48 + a1];
+              uint32_t off;
+              if (N == n6) off = dg_off + (uint32_t)((g * np + s1) * BA_SE_DSTRIDE + 21 + r1);
+              else {
+                const int a2 = N / 6, r2 = N % 6, s2 = (int)run_mf[r * 64 + 48 + a2];
+                if (a1 == a2) off = dg_off + (uint32_t)((g * np + s1) * BA_SE_DSTRIDE + (r1 * 6 - (r1 * (r1 - 1)) / 2 + (r2 - r1)));
+                else off = (uint32_t)((s1 * np - (s1 * (s1 + 1)) / 2 + (s2 - s1 - 1)) * BA_SE_SSTRIDE + ba_se_off(r1, r2));
+              }
+              uint32_t& w = run_fl[(r * 64 + l) * 12 + (4 * t + g) / 2];
+              w = ((4 * t + g) & 1) ? ((w & 0x0000FFFFu) | (off << 16)) : ((w & 0xFFFF0000u) | off);
+            }
+      }
+      if (run_fl.empty()) run_fl.assign(12, 0xFFFFFFFFu);
+      if (run_mf.empty()) run_mf.assign(64, BA_RM_MF_NONE);
       if (run_lane.empty()) run_lane.push_back(make_uint2(0u, 0u));
       if (rm_chunk.empty()) rm_chunk.push_back(make_int4(0, 0, -1, 0));
       BaSe& se = b->se;
@@ -768,10 +828,12 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
 
 // developer / test entry, host only: the plan cms_ba_create makes for a window -- internal point order, chunks, signature runs, the run-major
 // kernel's chunk descriptors and consumer-lane tables, the per-edge words -- so that the index arithmetic of cms_ba_schur_runs.hip can be
-// replayed on the CPU (tests/test_ba_runs_cpu.py).  Sizes: pinv P, perm E, info E, chunk_pt0 P + 2, rm_chunk 4 x P, run_lane 128 x P (upper
-// bounds; counts[] = chunks, run chunks, runs, np, points inside runs, range split of a window on its own: R_rm, R).
+// replayed on the CPU (tests/test_ba_runs_cpu.py).  Sizes: pinv P, perm E, info E, chunk_pt0 P + 2, rm_chunk 4 x P, run_lane 128 x P, run_mf
+// 64 x P, run_fl 768 x P (upper bounds; the last two may be NULL; counts[] = chunks, run chunks, runs, np, points inside runs, range split
+// of a window on its own: R_rm, R).
 extern "C" int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int* pinv_out, int* perm_out,
-                                 uint32_t* info_out, int* chunk_pt0_out, int* rm_chunk_out, uint32_t* run_lane_out, int* counts) {
+                                 uint32_t* info_out, int* chunk_pt0_out, int* rm_chunk_out, uint32_t* run_lane_out, int* counts,
+                                 uint32_t* run_mf_out, uint32_t* run_fl_out) {
   if (K < 1 || P < 1 || E < 1 || !fixed || !e_pose || !e_point || !pinv_out || !perm_out || !info_out || !chunk_pt0_out || !rm_chunk_out || !run_lane_out || !counts)
     return cms_fail(CMS_ERR_ARG, "cms_ba_debug_plan: bad argument");
   for (int e = 0; e < E; ++e)
@@ -795,6 +857,8 @@ extern "C" int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, cons
     memcpy(info_out, pl.info.data(), (size_t)E * sizeof(uint32_t));
     if (b->se.n_rm > 0) memcpy(rm_chunk_out, pl.rm_chunk.data(), (size_t)b->se.n_rm * sizeof(int4));
     if (b->n_runs > 0) memcpy(run_lane_out, pl.run_lane.data(), (size_t)b->n_runs * 64 * sizeof(uint2));
+    if (b->n_runs > 0 && run_mf_out) memcpy(run_mf_out, pl.run_mf.data(), (size_t)b->n_runs * 64 * sizeof(uint32_t));
+    if (b->n_runs > 0 && run_fl_out) memcpy(run_fl_out, pl.run_fl.data(), (size_t)b->n_runs * 64 * 12 * sizeof(uint32_t));
   }
   delete b;
   return CMS_OK;
@@ -863,6 +927,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     up(pl.pob.data(), pl.pob.size() * sizeof(int), &b->d_se_pob); up(pl.ident.data(), pl.ident.size() * sizeof(int), &b->d_se_chunk_off);
     up(pl.lone.data(), pl.lone.size() * sizeof(int), &b->d_se_lone);
     up(pl.rm_chunk.data(), pl.rm_chunk.size() * sizeof(int4), &b->d_rm_chunk); up(pl.run_lane.data(), pl.run_lane.size() * sizeof(uint2), &b->d_run_lane);
+    up(pl.run_mf.data(), pl.run_mf.size() * sizeof(uint32_t), &b->d_run_mf); up(pl.run_fl.data(), pl.run_fl.size() * sizeof(uint32_t), &b->d_run_fl);
   }
   tick("se");
   // A window that has the edge-major work list runs through the grouped driver with the edge-major kernels (cms_ba_optimize_many also puts
@@ -1085,6 +1150,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
       *ups[i].dst = dev + offs[i];
     }
     BA_HIP(hipMemcpyAsync(dev, b->h_stage, total, hipMemcpyHostToDevice, b->stream));
+    b->async_pending = true;
   }
   BaDev& d = b->d;
   d.K = K; d.P = P; d.E = E; d.np = np; d.fixed = b->d_fixed; d.pose_slot = b->d_pose_slot; d.e_pose = b->d_e_pose;
@@ -1093,7 +1159,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
   if (se_built) {
     BaSe& se = b->se;
-    se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane;
+    se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane; se.run_mf = b->d_run_mf; se.run_fl = b->d_run_fl;
   }
   tick("uploads");
   int rc = cms_ba_reset(b);
@@ -1126,6 +1192,7 @@ extern "C" int cms_ba_reset(cms_ba* b) {
   hipLaunchKernelGGL(k_ba_reset, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, b->stream, b->K, b->P, b->E, (const double*)b->d_poses0,
                      (const double*)b->d_pts0, b->d_poses[0], b->d_pts[0], b->d_level, b->d_err, b->d_flags);
   HIPCHK(hipGetLastError());
+  b->async_pending = true;
   return CMS_OK;       // asynchronous on the window's stream: every consumer (optimize, read) orders itself behind it
 }
 
@@ -1146,10 +1213,23 @@ extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* ou
   const size_t o_pose = 0, o_pts = ((size_t)7 * b->K * 8 + 255) & ~(size_t)255, o_flags = o_pts + (((size_t)3 * b->P * 8 + 255) & ~(size_t)255);
   if (!b->h_stage || b->h_stage_bytes < o_flags + (size_t)b->E) return cms_fail(CMS_ERR_HIP, "cms_ba_read: staging block missing");
   char* h = b->h_stage;
-  if (poses) HIPCHK(hipMemcpyAsync(h + o_pose, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  if (points) HIPCHK(hipMemcpyAsync(h + o_pts, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  if (outlier_flags) HIPCHK(hipMemcpyAsync(h + o_flags, b->d_flags, b->E, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  // A window that runs on a stream it shares with others (cms_ba_set_stream) reads back on a stream taken from the pool: the shared one may
+  // be busy with the next windows for milliseconds, and this window's results are complete (optimise returned) unless a reset is pending
+  hipStream_t rs = b->stream;
+  bool temp = false;
+  if (!b->own_stream && !b->async_pending) {
+    rs = ba_stream_take(b->device);
+    if (!rs) HIPCHK(hipStreamCreateWithFlags(&rs, hipStreamNonBlocking));
+    temp = true;
+  }
+  hipError_t re = hipSuccess;
+  if (poses && re == hipSuccess) re = hipMemcpyAsync(h + o_pose, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost, rs);
+  if (points && re == hipSuccess) re = hipMemcpyAsync(h + o_pts, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, rs);
+  if (outlier_flags && re == hipSuccess) re = hipMemcpyAsync(h + o_flags, b->d_flags, b->E, hipMemcpyDeviceToHost, rs);
+  if (re == hipSuccess) re = hipStreamSynchronize(rs);
+  if (temp) ba_stream_give(b->device, rs);
+  HIPCHK(re);
+  b->async_pending = false;
   if (poses) memcpy(poses, h + o_pose, 7 * (size_t)b->K * sizeof(double));
   if (points) {
     const double* pin = reinterpret_cast<const double*>(h + o_pts);

@@ -441,7 +441,10 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         hipLaunchKernelGGL(kb_ba_dinv, dim3((max_P + 255) / 256, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       if (use_se) {
         bracket(3, 0);
-        if (fused && any_runs) {
+        if (fused && any_runs && ba_knobs().rm_valu) {
+          hipLaunchKernelGGL(kb_ba_lin_schur_runs_valu, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_runs_valu, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        } else if (fused && any_runs) {
           hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
           if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         } else if (fused) {
@@ -581,7 +584,8 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
   const bool batched = ba_can_batch(bas, n);
   if (batched) {
     HIPCHK(hipSetDevice(bas[0]->device));
-    for (int w = 0; w < n; ++w) HIPCHK(hipStreamSynchronize(bas[w]->stream));   // pending resets on the windows' own streams
+    for (int w = 0; w < n; ++w)      // pending uploads / resets on the windows' streams
+      if (bas[w]->async_pending) { HIPCHK(hipStreamSynchronize(bas[w]->stream)); bas[w]->async_pending = false; }
     int rcg = ba_group_reserve(bas[0], n);
     if (rcg) return rcg;
     rcg = ba_upload_items(bas, n);          // static descriptions of the windows: once per call

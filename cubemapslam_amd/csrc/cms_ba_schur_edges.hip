@@ -52,6 +52,8 @@ struct BaSe {                      // device view of the edge-major work list (c
                                   // their slices of `partial` come first, the edge-major ranges' slices follow (R_rm + R slices in all)
   const int4* rm_chunk;           // n_rm: first edge | edges + (edges per point << 8) + (points << 16) | run | first (internal) point
   const uint2* run_lane;          // runs x 64: which tuple of the signature a consumer lane multiplies, and where its sum goes (ba_rm_lane_*)
+  const uint32_t* run_mf;         // runs x 64: rows / columns of a signature's stacked matrix for the MFMA variant (cms_ba_schur_runs.hip, BA_RM_MF_*)
+  const uint32_t* run_fl;         // runs x 64 x 12: per lane, where its 24 MFMA accumulators are added (two 16-bit LDS offsets per word)
   int Rt, cpw_t;                  // the same chunks cut into more, shorter ranges for the edge-major trial kernel (no LDS copy of the system to amortise)
   int npairs2;                    // np (np + 1) / 2: pose pairs s1 <= s2 enumerated densely, row by row
   const int* chunk_e0;            // nchunks + 1: first edge of every chunk (whole points, <= 64 edges)

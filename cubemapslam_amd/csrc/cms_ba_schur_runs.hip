@@ -323,3 +323,383 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
   }
   ba_se_writeout<true>(BX, np, NP2, S, Dg, se);
 }
+
+// ================================================================================================================================
+// MFMA variant (the default): no producer / consumer split -- every wavefront walks its own range of run chunks, builds a chunk's W rows
+// exactly as above, and then multiplies them on the MATRIX pipe instead of with 126 vector FMAs per tuple.
+//
+// For the points j of a chunk (one signature, kf free key frames) stack  Y = [W_1 ; ... ; W_kf]  -- 6 kf rows (key frame a, row r), 3 columns
+// (c) per point.  All of the chunk's tuple products at once are the Gram-like product
+//
+//     G = sum_j  Y_j D_j^-1 Y_j^T          (6 kf x 6 kf; block (a, b) = sum_j W_a D^-1 W_b^T),       g = sum_j Y_j D_j^-1 y_j   (the right-hand side)
+//
+// i.e. a dense (6 kf) x (3 m) by (3 m) x (6 kf + 1) matrix product: v_mfma_f64_16x16x4_f64 tiles, four of the 3 m inner indices (point j,
+// column c) per instruction.  Lane l supplies A[i = l & 15][kk = l >> 4] = W[j, a_i][r_i][c] D_j^-1[c] and B[kk][n = l & 15] = W[j, a_n][r_n][c]
+// (or y_j[c] for the extra column n = 6 kf) straight from the chunk's LDS rows; the upper tiles of G stay in the accumulators (16 x 16 per
+// tile, four doubles per lane) for as long as the run lasts.  6 kf + 1 <= 32 (kf <= 5): one or three upper tiles, all resident.  kf = 6, 7
+// (<= 43 columns): the three tiles of the third tile column are summed per CHUNK in temporaries and added to LDS after every chunk (twelve
+// additions per lane and chunk instead of ~90 in the edge-major body; six resident tiles made the kernel spill at two wavefronts per SIMD).
+//
+// What this buys over the vector version: the products leave the vector ALU (which the front half of the kernel keeps busy: residual,
+// Jacobians, 3x3 factorisation, W) for a pipe that was idle, the 84 accumulator registers become 8 .. 48, and the two roles, their hand-over
+// buffers and their barrier per chunk disappear -- a wavefront's matrix phase overlaps its SIMD neighbour's vector phase by itself.
+// The FP64 matrix rate of gfx950 equals its vector rate (78.6 TFLOP/s), and a 24 x 25 product fills 39 % of its three tiles, so the matrix
+// pipe is not where the time goes; it is where the vector ALU's time no longer goes.
+//
+// run_mf[run * 64 + i], i < 48: entry of row / column i of the stacked matrix: offset of W[a][r][0] inside a point's rows (position of edge a
+// x 18 + 3 r), BA_RM_MF_RHS for the right-hand-side column, BA_RM_MF_NONE beyond it; [48 .. 55]: free-pose slot of key frame a; [56]: kf.
+// run_fl[(run * 64 + lane) * 12 + w]: where the lane's accumulators go, two 16-bit LDS offsets (doubles from the start of the copy; 0xFFFF:
+// nowhere -- lower triangle, padding) per word: accumulator g of tile t at index 4 t + g, tiles (0,0) (0,1) (1,1) | (0,2) (1,2) (2,2).
+#define BA_RM_MF_NONE 0xFFFFu
+#define BA_RM_MF_RHS 0xFFFEu
+typedef double ba_v4d __attribute__((ext_vector_type(4)));
+
+#ifdef BA_RM_CLK
+// developer instrumentation (tools/ab_build.sh rmclk -DBA_RM_CLK): where a wavefront's cycles go, phase by phase, summed over the chunks of
+// wavefront 0 of workgroup 0 of window 0; read with cms_ba_debug_rm_clocks
+__device__ long long ba_rm_clk[16];
+#define BA_RM_STAMP(i) do { if (clk_on) { const long long now_ = (long long)__builtin_readcyclecounter(); clk_acc[i] += now_ - clk_last; clk_last = now_; } } while (0)
+#else
+#define BA_RM_STAMP(i) do { } while (0)
+#endif
+// a double of quad lane P (P = 0 .. 3) in every lane of the quad: two DPP moves, no LDS
+template <int P> __device__ __forceinline__ double ba_quad_bcast(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), P * 0x55, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), P * 0x55, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// ... and of the lane's pair partner positions: PERM = quad_perm (lane i reads lane PERM[i])
+template <int PERM> __device__ __forceinline__ double ba_quad_perm(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), PERM, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), PERM, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+                                                        const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
+#pragma clang fp contract(fast)
+  extern __shared__ __align__(16) double se_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
+  double* S = se_lds;
+  double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);
+  double* bufs = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // one chunk buffer per wavefront
+  double* prt = bufs + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF;        // (eight buffers: the same LDS budget as the vector variant's 4 x 2)
+  for (int i = tid; i < (int)(bufs - S); i += blockDim.x) S[i] = 0.0;
+  for (int k = tid; k < d.K; k += blockDim.x) {
+    double R[9];
+    quat_to_R(poses + 7 * k + 3, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) prt[12 * k + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prt[12 * k + 9 + i] = poses[7 * k + i];
+  }
+  __syncthreads();
+  double* buf = bufs + (size_t)wave * BA_RM_BUF;
+  const long long total_waves = (long long)se.R_rm * nw;
+  const long long gw = (long long)BX * nw + wave;
+  const int cb = (int)(gw * se.n_rm / total_waves), ce = (int)((gw + 1) * se.n_rm / total_waves);
+  const int li = lane & 15, lk = lane >> 4;
+
+  double hp[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) hp[i] = 0.0;
+  int hp_slot = -1;
+  ba_v4d acc[3];                                                   // resident upper tiles (0,0) (0,1) (1,1)
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (ba_v4d){0.0, 0.0, 0.0, 0.0};
+  int cur_run = -1, NT = 1, kf = 1;
+  uint32_t ent[3] = {BA_RM_MF_NONE, BA_RM_MF_NONE, BA_RM_MF_NONE}, n_ent[3] = {BA_RM_MF_NONE, BA_RM_MF_NONE, BA_RM_MF_NONE};
+  uint32_t n_kf = 1;
+  uint32_t fl_hi[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u}, n_fl_hi[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u};      // targets of the per-chunk tiles (kf > 5 only)
+  auto load_tab = [&](int run) {                                   // the lane's table entries of a run (requested ahead of the run)
+    const uint32_t* t = se.run_mf + (size_t)run * 64;
+    n_ent[0] = t[li]; n_ent[1] = t[16 + li]; n_ent[2] = t[32 + li]; n_kf = t[56];
+    if (n_kf > 5) {                                                // (wave uniform: the whole table row is the run's)
+      const uint32_t* f = se.run_fl + ((size_t)run * 64 + lane) * 12 + 6;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) n_fl_hi[i] = f[i];
+    }
+  };
+  auto add_at = [&](uint32_t word, int half, double v) {           // one accumulator to its place in the LDS copy
+    const uint32_t o = half ? (word >> 16) : (word & 0xFFFFu);
+    if (o != 0xFFFFu) unsafeAtomicAdd(S + o, v);
+  };
+  // the inner index of the matrix product runs over (point, column): kappa = 3 j + c, four of them per instruction (kk = lane >> 4).  Three
+  // instructions cover twelve indices = four points exactly, so per lane the three (point offset, column) pairs are constants
+  int mj[3], mc[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { const int kap = 4 * u + lk; mj[u] = kap / 3; mc[u] = kap - 3 * mj[u]; }
+  int4 d_cur = make_int4(0, 0, -1, 0), d_nxt = make_int4(0, 0, -1, 0);
+  if (cb < ce) { d_cur = se.rm_chunk[cb]; load_tab(d_cur.z); }
+  if (cb + 1 < ce) d_nxt = se.rm_chunk[cb + 1];
+  int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;
+  double n_X[3] = {0, 0, 0};
+  double2 n_obs = make_double2(0.0, 0.0);
+  auto load_chunk = [&](const int4 dc) {
+    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0;
+    const int ne = dc.y & 255, kk = (dc.y >> 8) & 255;
+    if (dc.z >= 0 && lane < ne) {
+      const int e = dc.x + lane;
+      n_e = e; n_info = se.e_info[e];
+      n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0;
+      n_obs = reinterpret_cast<const double2*>(d.e_obs)[e];
+      n_p = dc.w + ((lane * (int)__builtin_ceilf(65536.0f * __builtin_amdgcn_rcpf((float)kk))) >> 16);      // + lane / kk (the slack of the rounding is far below 1 / 64)
+      const double* Xp = pts + 3 * (size_t)n_p;
+      n_X[0] = Xp[0]; n_X[1] = Xp[1]; n_X[2] = Xp[2];
+    }
+  };
+  load_chunk(d_cur);
+#ifdef BA_RM_CLK
+  const bool clk_on = BX == 0 && blockIdx.z == 0 && wave == 0;
+  long long clk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long clk_last = (long long)__builtin_readcyclecounter();
+#endif
+  for (int c = cb; c < ce; ++c) {
+    BA_RM_STAMP(0);                                                // loop overhead / previous flush tail
+    const int4 desc = d_cur;
+    const uint32_t info = n_info;
+    double ow = n_ow;
+    const int pnt = n_p, eid = n_e;
+    const double2 obs = n_obs;
+    const double X[3] = {n_X[0], n_X[1], n_X[2]};
+    if (desc.z != cur_run) {                                       // a new run: its table entries were requested when the previous run ended
+      cur_run = desc.z;
+      ent[0] = n_ent[0]; ent[1] = n_ent[1]; ent[2] = n_ent[2]; kf = (int)n_kf;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) fl_hi[i] = n_fl_hi[i];
+      NT = (6 * kf + 1 + 15) >> 4;
+    }
+    const int k_run = (desc.y >> 8) & 255, m = desc.y >> 16;
+    const int invk = (int)__builtin_ceilf(65536.0f * __builtin_amdgcn_rcpf((float)k_run));
+    BA_RM_STAMP(1);                                                // operands of the chunk in registers (waits for the prefetch)
+    // ---------------------------------------------------------------- vector phase: the chunk's rows (as in the vector variant's producer)
+    int slot = -1, a = 0;
+    double Jp[12], Jl[6], o0 = 0.0, o1 = 0.0;
+    bool have_jac = false;
+    if (info != 0) {
+      a = info & 31;
+      const int s_ = (int)((info >> 10) & 63) - 1, face = (info >> 16) & 7, kp = (info >> 19) & 255;
+      if (ow != 0.0) {
+        const double* Rt = prt + 12 * kp;
+        double R[9], Xc[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+        ba_se_cam_point(Rt, X, Xc);
+        double r[2], rho0;
+        edge_error_v(d, face, obs.x, obs.y, Xc, r);
+        const double om = ow;
+        const double w = robust ? huber_w(om * (r[0] * r[0] + r[1] * r[1]), delta, &rho0) : 1.0;
+        ow = w * om;
+        o0 = -om * r[0] * w; o1 = -om * r[1] * w;
+        edge_jac_face(d, face, Xc, R, Jp, Jl);
+        have_jac = true;
+        if (s_ >= 0) slot = s_;
+      }
+      if (s_ >= 0) hp_slot = s_;
+    }
+    double hl[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) hl[i] = 0.0;
+    if (have_jac) {
+      hl[0] = ow * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); hl[1] = ow * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); hl[2] = ow * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
+      hl[3] = ow * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); hl[4] = ow * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); hl[5] = ow * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+      hl[6] = Jl[0] * o0 + Jl[3] * o1; hl[7] = Jl[1] * o0 + Jl[4] * o1; hl[8] = Jl[2] * o0 + Jl[5] * o1;
+    }
+    if (info != 0) d.ow[eid] = have_jac ? ow : 0.0;
+    BA_RM_STAMP(2);                                                // residual, weight, Jacobians, the edge's share of Hll / bl
+    // the point's lanes add their shares.  Four (or two) edges per point: the lanes of a point are (half of) a quad of the wavefront and
+    // the shares move with DPP quad permutes -- no LDS round trip (the exchange through the rows cost 1800 of a chunk's 17 000 cycles);
+    // every lane adds in edge order, so all lanes of a point hold the same bits.  Other point sizes: through the rows.
+    double sum[10];
+    sum[9] = 0.0;
+    if (k_run == 4) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sum[i] = ((ba_quad_bcast<0>(hl[i]) + ba_quad_bcast<1>(hl[i])) + ba_quad_bcast<2>(hl[i])) + ba_quad_bcast<3>(hl[i]);
+    } else if (k_run == 2) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sum[i] = ba_quad_perm<0xA0>(hl[i]) + ba_quad_perm<0xF5>(hl[i]);      // lanes {0, 0, 2, 2} + lanes {1, 1, 3, 3}
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      {
+        double2* row2 = reinterpret_cast<double2*>(buf + (size_t)lane * 18);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) row2[i] = make_double2(hl[2 * i], hl[2 * i + 1]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sum[i] = 0.0;
+      for (int j = 0; j < k_run; ++j) {
+        if (info != 0) {
+          const double2* row2 = reinterpret_cast<const double2*>(buf + (size_t)(lane - a + j) * 18);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) { const double2 u = row2[i]; sum[2 * i] += u.x; sum[2 * i + 1] += u.y; }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    BA_RM_STAMP(3);                                                // exchange through the rows: Hll, bl of the point in every lane
+    if (info != 0 && a == 0) {
+      double* H = Hll + 9 * (size_t)pnt; double* bq = bl + 3 * (size_t)pnt;
+      H[0] = sum[0]; H[1] = sum[1]; H[2] = sum[2]; H[3] = sum[1]; H[4] = sum[3]; H[5] = sum[4]; H[6] = sum[2]; H[7] = sum[4]; H[8] = sum[5];
+      bq[0] = sum[6]; bq[1] = sum[7]; bq[2] = sum[8];
+    }
+    double W[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) W[i] = 0.0;
+    if (info != 0) {
+      const double a00 = sum[0] + lambda, a10 = sum[1], a11 = sum[3] + lambda, a20 = sum[2], a21 = sum[4], a22 = sum[5] + lambda;
+      const double i0 = 1.0 / a00;
+      const double l10 = a10 * i0, l20 = a20 * i0;
+      const double d1 = a11 - l10 * a10;
+      const double i1 = 1.0 / d1;
+      const double l21 = (a21 - l20 * a10) * i1;
+      const double d2 = a22 - l20 * a20 - l21 * (l21 * d1);
+      const double i2 = 1.0 / d2;
+      if (a == 0) {                                                // the point's slot: D^-1 | y = L^-1 bl
+        const double y0 = sum[6], y1 = sum[7] - l10 * y0, y2 = sum[8] - l20 * y0 - l21 * y1;
+        const int j = ((lane - a) * invk) >> 16;
+        double2* pp = reinterpret_cast<double2*>(buf + 64 * 18 + (size_t)j * 6);
+        pp[0] = make_double2(i0, i1); pp[1] = make_double2(i2, y0); pp[2] = make_double2(y1, y2);
+      }
+      if (slot >= 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double q0 = ow * (Jp[r] * Jl[0] + Jp[6 + r] * Jl[3]);
+          const double q1 = ow * (Jp[r] * Jl[1] + Jp[6 + r] * Jl[4]);
+          const double q2 = ow * (Jp[r] * Jl[2] + Jp[6 + r] * Jl[5]);
+          const double w0 = q0, w1 = q1 - w0 * l10, w2 = q2 - w0 * l20 - w1 * l21;
+          W[3 * r] = w0; W[3 * r + 1] = w1; W[3 * r + 2] = w2;
+        }
+        int cidx = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int q = r; q < 6; ++q) hp[cidx++] += ow * (Jp[r] * Jp[q] + Jp[6 + r] * Jp[6 + q]);
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) hp[21 + r] += Jp[r] * o0 + Jp[6 + r] * o1;
+      }
+    }
+    BA_RM_STAMP(4);                                                // 3x3 factorisation, W, the key frame's own sums
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    {
+      double2* row2 = reinterpret_cast<double2*>(buf + (size_t)lane * 18);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) row2[i] = make_double2(W[2 * i], W[2 * i + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    BA_RM_STAMP(5);                                                // rows published
+    // The next chunk's operands are requested here, not at the top of the loop: the vector phase's registers (Jacobians, W, the 3x3
+    // factors) are dead by now, and the matrix phase below gives the loads a microsecond to land.  (Requested at the top, both chunks'
+    // operands were alive through the vector phase and the kernel spilled.)
+    d_cur = d_nxt;
+    d_nxt = make_int4(0, 0, -1, 0);
+    if (c + 2 < ce) d_nxt = se.rm_chunk[c + 2];
+    load_chunk(d_cur);
+    BA_RM_STAMP(6);                                                // next chunk's loads issued
+    // ---------------------------------------------------------------- matrix phase: G += Y D^-1 Y^T over the chunk's points
+    {
+      // per lane and instruction u of a group of three: where its operands sit -- the W entry of its row / column (or the point's y for the
+      // right-hand-side column) at point 4 q + mj[u], column mc[u]; one formula for both kinds of entry: base + point * stride
+      const bool va0 = ent[0] < BA_RM_MF_RHS, va1 = ent[1] < BA_RM_MF_RHS, va2 = ent[2] < BA_RM_MF_RHS;       // W entries (rows of G never include the rhs column)
+      const bool vb0 = ent[0] <= BA_RM_MF_RHS, vb1 = ent[1] <= BA_RM_MF_RHS && NT > 1, vb2 = ent[2] <= BA_RM_MF_RHS && NT > 2;
+      const int rs = k_run * 18;
+      const int o0b = va0 ? (int)ent[0] : 64 * 18 + 3, s0b = va0 ? rs : 6;
+      const int o1b = va1 ? (int)ent[1] : 64 * 18 + 3, s1b = va1 ? rs : 6;
+      const int o2b = va2 ? (int)ent[2] : 64 * 18 + 3, s2b = va2 ? rs : 6;
+      const int niter = (m + 3) >> 2;
+      if (NT <= 2) {
+        for (int q = 0; q < niter; ++q) {
+          double Bv0[3], Bv1[3], Dv[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {                            // all nine reads first, then the nine instructions
+            const int j = 4 * q + mj[u];
+            const bool in = j < m;
+            Dv[u] = in ? buf[64 * 18 + j * 6 + mc[u]] : 0.0;
+            Bv0[u] = in && vb0 ? buf[o0b + j * s0b + mc[u]] : 0.0;
+            Bv1[u] = in && vb1 ? buf[o1b + j * s1b + mc[u]] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const double A0 = va0 ? Bv0[u] * Dv[u] : 0.0, A1 = va1 ? Bv1[u] * Dv[u] : 0.0;
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv0[u], acc[0], 0, 0, 0);
+            if (NT > 1) {
+              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv1[u], acc[1], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv1[u], acc[2], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        // six or seven free key frames: the third tile column (0,2) (1,2) (2,2) lives in temporaries for this chunk only
+        ba_v4d tmp[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) tmp[t] = (ba_v4d){0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < niter; ++q) {
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int j = 4 * q + mj[u];
+            const bool in = j < m;
+            const double dvv = in ? buf[64 * 18 + j * 6 + mc[u]] : 0.0;
+            const double b0 = in && vb0 ? buf[o0b + j * s0b + mc[u]] : 0.0;
+            const double b1 = in && vb1 ? buf[o1b + j * s1b + mc[u]] : 0.0;
+            const double b2 = in && vb2 ? buf[o2b + j * s2b + mc[u]] : 0.0;
+            const double A0 = va0 ? b0 * dvv : 0.0, A1 = va1 ? b1 * dvv : 0.0, A2 = va2 ? b2 * dvv : 0.0;
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, b1, acc[2], 0, 0, 0);
+            tmp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, b2, tmp[0], 0, 0, 0);
+            tmp[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, b2, tmp[1], 0, 0, 0);
+            tmp[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, b2, tmp[2], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) add_at(fl_hi[(4 * t + g) >> 1], (4 * t + g) & 1, tmp[t][g]);
+        }
+      }
+    }
+    BA_RM_STAMP(7);                                                // matrix phase
+    // ---------------------------------------------------------------- end of the run (or of this wavefront's range): one set of LDS additions
+    if (d_cur.z != desc.z) {
+      if (hp_slot >= 0) {
+        const int j = ((lane - a) * invk) >> 16;
+        double* base = Dg + ((size_t)(j & (BA_SE_DCOPIES - 1)) * np + hp_slot) * BA_SE_DSTRIDE;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) unsafeAtomicAdd(base + i, -hp[i]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { unsafeAtomicAdd(base + 21 + r, -hp[21 + r]); unsafeAtomicAdd(base + 27 + r, hp[21 + r]); }
+      }
+#pragma unroll
+      for (int i = 0; i < 27; ++i) hp[i] = 0.0;
+      hp_slot = -1;
+      // accumulator g of tile (ti, tj) in lane l is G[16 ti + (l >> 4) + 4 g][16 tj + (l & 15)]: the upper triangle (and the rhs column) goes
+      // out, to the places the host worked out per lane (run_fl)
+      {
+        const uint32_t* f = se.run_fl + ((size_t)desc.z * 64 + lane) * 12;
+        uint32_t w[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = f[i];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) add_at(w[(4 * t + g) >> 1], (4 * t + g) & 1, acc[t][g]);
+          acc[t] = (ba_v4d){0.0, 0.0, 0.0, 0.0};
+        }
+      }
+      if (d_cur.z >= 0) load_tab(d_cur.z);                         // the next run's entries travel while its first chunk's rows are built
+      BA_RM_STAMP(8);                                              // flush
+    }
+  }
+#ifdef BA_RM_CLK
+  if (clk_on && lane == 0) {
+    for (int i = 0; i < 12; ++i) ba_rm_clk[i] = clk_acc[i];
+    ba_rm_clk[12] = ce - cb;
+  }
+#endif
+  __syncthreads();
+  ba_se_writeout<true>(BX, np, NP2, S, Dg, se);
+}

@@ -254,6 +254,12 @@ extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_edge
 // work through its run chunks, the rest through the left-over chunks edge-major -- one launch, one LDS layout, one kind of slice
 extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_runs(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.se.R_rm + it.se.R)
+  if ((int)blockIdx.x < it.se.R_rm) ba_schur_runs_mfma_body(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
+  else ba_schur_edges_body<true>((int)blockIdx.x - it.se.R_rm, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
+}
+// ... the same with the runs' products on the vector ALU (producer / consumer wavefront pairs; CMS_BA_RM_VALU=1, A/B)
+extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_runs_valu(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.R_rm + it.se.R)
   if ((int)blockIdx.x < it.se.R_rm) ba_schur_runs_body(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
   else ba_schur_edges_body<true>((int)blockIdx.x - it.se.R_rm, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
 }

@@ -191,11 +191,12 @@ int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, const int* e
  * signature) are grouped; a signature with enough points becomes a RUN whose chunks the run-major Schur kernel sums in registers
  * (cubemapslam_amd/csrc/cms_ba_schur_runs.hip), the rest are the composed chunks of cms_ba_debug_compose.  Outputs (upper-bound sizes): pinv P
  * (internal point -> caller's point), perm E (sorted edge -> caller's edge), info E (per-edge word of the kernels), chunk_pt0 P + 2, rm_chunk
- * 4 ints per run chunk (<= P), run_lane 128 u32 per run (<= P runs), counts[8] = chunks, run chunks, runs, free key frames, points inside runs,
+ * 4 ints per run chunk (<= P), run_lane 128 u32 per run (<= P runs), run_mf 64 / run_fl 768 u32 per run (the MFMA variant's tables; may be
+ * NULL), counts[8] = chunks, run chunks, runs, free key frames, points inside runs,
  * workgroups of a lone window for the run chunks / the left-over chunks, 1 if the window can use these kernels at all.  No counterpart in the
  * reference: the graph is what Optimizer::LocalBundleAdjustment hands to g2o (Optimizer.cpp:192-363). */
 int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int* pinv, int* perm, uint32_t* info,
-                      int* chunk_pt0, int* rm_chunk, uint32_t* run_lane, int* counts);
+                      int* chunk_pt0, int* rm_chunk, uint32_t* run_lane, int* counts, uint32_t* run_mf, uint32_t* run_fl);
 void cms_ba_destroy(cms_ba* ba);
 /* one-shot convenience: create + optimize + read + destroy */
 int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,

@@ -17,7 +17,7 @@ def _opair(np_, s1, s2):
 
 def _structure(prob):
     P, E = len(prob["points"]), len(prob["e_pose"])
-    pl = api.ba_plan(prob["fixed"], P, prob["e_pose"], prob["e_point"])
+    pl = api.ba_plan(prob["fixed"], P, prob["e_pose"], prob["e_point"], tables=True)
     assert pl["usable"]
     pinv, perm = pl["pinv"], pl["perm"]
     assert np.array_equal(np.sort(pinv), np.arange(P)) and np.array_equal(np.sort(perm), np.arange(E))
@@ -156,7 +156,7 @@ def test_range_split_and_left_over_chunks():
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=7, views="track")
     pl, pt_off, s_pose, s_pt, slot_of, a_of, s_of = _structure(prob)
     assert pl["R_rm"] >= 1 and pl["R"] >= 1 and pl["R_rm"] + pl["R"] <= 128
-    assert pl["R_rm"] * PAIRS <= max(pl["n_rm"], PAIRS)                        # a producer / consumer pair has at least one chunk
+    assert pl["R_rm"] * 8 <= max(pl["n_rm"], 8) + 7                            # a wavefront of the run-major workgroups has at least one chunk
     # with CMS_BA_NO_RUNS (child process: the switch is read once) every point is a left-over point and the plan is the old composition
     import os, subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); from cubemapslam_amd import api, synth; "
@@ -165,3 +165,83 @@ def test_range_split_and_left_over_chunks():
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CMS_BA_NO_RUNS="1"), capture_output=True, text=True, check=True).stdout.split()
     assert out[:3] == ["0", "0", "0"] and int(out[3]) > 0
+
+
+@pytest.mark.parametrize("K,P,obs,seed", [(20, 6000, 4, 11), (16, 5000, 6, 12), (9, 2500, 2, 13)])
+def test_mfma_tables_replay_the_schur_sum(K, P, obs, seed):
+    """The MFMA variant of the run-major body (ba_schur_runs_mfma_body): a signature's W rows are stacked into a (6 kf) x (6 kf + 1) Gram-like
+    product evaluated in 16 x 16 tiles.  run_mf says which W entry a lane feeds into row / column i of the stacked matrix, run_fl where each
+    of a lane's accumulators is added in the LDS copy.  Replayed here with integer stand-ins: G = sum_j Y_j D_j Y_j^T per run from the table's
+    row entries, the accumulator -> LDS map applied lane by lane, and the result compared with the plain double loop over tuples."""
+    prob = synth.ba_problem(K=K, P=P, obs_per_point=obs, F=550, seed=seed, views="track", dropout=0.05)
+    if seed == 12:
+        prob["fixed"][3] = 1
+    pl, pt_off, s_pose, s_pt, slot_of, a_of, s_of = _structure(prob)
+    np_ = pl["np"]; NP2 = np_ * (np_ + 1) // 2
+    n_rm, rmc, mf, fl = pl["n_rm"], pl["rm_chunk"], pl["run_mf"], pl["run_fl"]
+    assert n_rm > 0 and pl["n_runs"] > 3
+    dg_off = ((NP2 - np_) * SSTRIDE + 1) & ~1
+    NONE, RHS = 0xFFFF, 0xFFFE
+    tile_i, tile_j = [0, 0, 1, 0, 1, 2], [0, 1, 1, 2, 2, 2]
+    rs = np.random.RandomState(seed)
+    E = len(s_pose)
+    Wst = rs.randint(1, 9, (E, 6, 3)).astype(np.int64) * (s_of >= 0)[:, None, None]      # stand-in for W (zero for fixed key frames)
+    Dst = rs.randint(1, 5, (P, 3)).astype(np.int64); yst = rs.randint(1, 7, (P, 3)).astype(np.int64)
+    lds = np.zeros(dg_off + DCOPIES * np_ * DSTRIDE, np.int64)
+    ref_S = {}; ref_rhs = np.zeros((np_, 6), np.int64)
+    for c in range(n_rm):
+        e0, word, run, p0 = (int(v) for v in rmc[c])
+        ne, k, m = word & 255, (word >> 8) & 255, word >> 16
+        tab = mf[run]; kf = int(tab[56]); n6 = 6 * kf
+        assert n6 + 1 <= 48 and int(tab[n6]) == RHS and all(int(tab[i]) == NONE for i in range(n6 + 1, 48))
+        G = np.zeros((48, 48), np.int64)
+        for j in range(m):
+            pnt = p0 + j
+            Y = np.zeros((48, 3), np.int64)
+            for i in range(n6):
+                ent = int(tab[i]); pos, r = ent // 18, (ent % 18) // 3
+                assert ent % 3 == 0 and pos < k and r == i % 6
+                e = e0 + j * k + pos
+                assert s_of[e] == int(tab[48 + i // 6])              # the slot the table names is the edge's key frame
+                Y[i] = Wst[e, r]
+            Yc = Y.copy(); Yc[n6] = yst[pnt]                          # the rhs column
+            G += (Y * Dst[pnt]) @ Yc.T
+            # reference: the tuples of this point
+            es = [e0 + j * k + a for a in range(k) if s_of[e0 + j * k + a] >= 0]
+            for ia, ea in enumerate(es):
+                ref_rhs[s_of[ea]] += (Wst[ea] * Dst[pnt]) @ yst[pnt]
+                for eb in es[ia:]:
+                    key = (s_of[ea], s_of[eb])
+                    ref_S[key] = ref_S.get(key, 0) + (Wst[ea] * Dst[pnt]) @ Wst[eb].T
+        # the accumulators of every lane -> LDS, as the kernel adds them (resident tiles at the run's end, the third tile column per chunk:
+        # the sum over chunks is the same either way)
+        for lane in range(64):
+            for t in range(6):
+                for g in range(4):
+                    w = int(fl[run][lane][(4 * t + g) // 2]); off = (w >> 16) if (4 * t + g) & 1 else (w & 0xFFFF)
+                    if off != 0xFFFF:
+                        lds[off] += G[16 * tile_i[t] + (lane >> 4) + 4 * g, 16 * tile_j[t] + (lane & 15)]
+    # read the LDS copy back the way the write-out does
+    def off_el(r, q):
+        up = lambda a, b: a * 5 - (a * (a - 1)) // 2 + (b - a - 1)
+        return up(r, q) if r < q else 16 + up(q, r) if r > q else (15 if r == 0 else 31 if r == 1 else 30 + r)
+    for (s1, s2), blk in ref_S.items():
+        for r in range(6):
+            for q in range(6):
+                if s1 == s2:
+                    if r > q:
+                        continue
+                    got = sum(lds[dg_off + (cp * np_ + s1) * DSTRIDE + (r * 6 - (r * (r - 1)) // 2 + (q - r))] for cp in range(DCOPIES))
+                else:
+                    got = lds[_opair(np_, s1, s2) * SSTRIDE + off_el(r, q)]
+                assert got == blk[r, q], (s1, s2, r, q)
+    for s1 in range(np_):
+        for r in range(6):
+            assert sum(lds[dg_off + (cp * np_ + s1) * DSTRIDE + 21 + r] for cp in range(DCOPIES)) == ref_rhs[s1, r]
+    # nothing was added anywhere else
+    used = np.zeros(len(lds), bool)
+    for (s1, s2) in ref_S:
+        if s1 != s2:
+            used[_opair(np_, s1, s2) * SSTRIDE:_opair(np_, s1, s2) * SSTRIDE + 36] = True
+    used[dg_off:] = True
+    assert not lds[~used].any()

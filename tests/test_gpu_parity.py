@@ -1061,10 +1061,11 @@ def test_kfstore_fuse_search_matches_oracle():
 
 
 @pytest.mark.parametrize("knob", ["CMS_BA_NO_FUSED_LIN", "CMS_BA_DETERMINISTIC", "CMS_BA_NO_PERMUTE", "CMS_BA_NO_RUNS", "CMS_BA_RUNS_AS_EDGES",
-                                  "CMS_BA_SEPARATE_REDUCE"])
+                                  "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU"])
 def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
-    """The grouped local-BA driver has several Schur paths -- signature runs summed in registers + edge-major left-overs, linearisation fused
-    (default); every point edge-major (CMS_BA_NO_RUNS), also with the run order kept (CMS_BA_RUNS_AS_EDGES); the edge-major kernel behind
+    """The grouped local-BA driver has several Schur paths -- signature runs multiplied in MFMA tiles + edge-major left-overs, linearisation
+    fused (default); the runs' products on the vector ALU by producer / consumer wavefront pairs (CMS_BA_RM_VALU); every point edge-major
+    (CMS_BA_NO_RUNS), also with the run order kept (CMS_BA_RUNS_AS_EDGES); the edge-major kernel behind
     kb_ba_lin (CMS_BA_NO_FUSED_LIN); the deterministic pair-owner kernel (CMS_BA_DETERMINISTIC) -- a host-side chunk composition that can be
     switched off (CMS_BA_NO_PERMUTE), and the range sum either inside the solve kernel or as its own launch (CMS_BA_SEPARATE_REDUCE).  The
     knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""

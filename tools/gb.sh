@@ -13,8 +13,8 @@ else:
     j = json.loads(l[-1]); c = j["config"]
     st = c.get("stage_ms_per_step", {})
     ro = [r for r in (j.get("roofline"), j.get("roofline_other")) if r]
-    print("%-14s value %8.1f  step %6.3f ms  ba %6.3f ms  frames %5.2f ms  ext_frac %s  create %s ms  %s" % (
+    print("%-14s value %8.1f  step %6.3f ms  ba %6.3f ms  frames %5.2f ms  ext_frac %s  create %s ms  %s  %s" % (
         tag, j.get("value", 0), j.get("ms_per_step", 0), c.get("ba_ms_per_step", 0), st.get("total", 0),
         (c.get("extractor_vs_survey_bytes") or {}).get("frac_of_8TBps"), (c.get("ba_window_setup") or {}).get("ms_per_window_inside_the_step"),
-        " ".join("%s=%.1fus" % (r["kernel"], 1e3 * r["ms_per_launch"]) for r in ro)))
+        " ".join("%s=%.1fus" % (r["kernel"], 1e3 * r["ms_per_launch"]) for r in ro), c.get("ba_worker_ms")))
 PY
