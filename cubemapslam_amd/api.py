@@ -200,6 +200,11 @@ class Context:
         mask = np.ascontiguousarray(mask, np.uint8)
         _chk(lib().cms_set_mask(self.h, _p(mask), mask.strides[0]), "cms_set_mask")
 
+    def set_distance_bounds_mode(self, scaled):
+        f = lib().cms_set_distance_bounds_mode
+        f.argtypes = [C.c_void_p, C.c_int]
+        _chk(f(self.h, int(scaled)), "cms_set_distance_bounds_mode")
+
     def set_gaussian_mode(self, column_mode):
         f = lib().cms_set_gaussian_mode
         f.argtypes = [C.c_void_p, C.c_int]

@@ -61,6 +61,7 @@ struct cms_ctx {
   // input streaming (cms_frames_upload_async): the next batch travels on its own stream while the current one is being processed
   hipStream_t copy_stream = nullptr; hipEvent_t ev_upload_done = nullptr, ev_remap_done = nullptr;
   bool upload_pending = false, remap_recorded = false;
+  int dist_bounds_scaled = 0;      // cms_set_distance_bounds_mode: map points' distance bounds come from the public MapPoint getters
   hipEvent_t ev_extracted = nullptr; bool extracted_recorded = false;   // end of the last cms_frames_process (cms_stream_wait_extracted)
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;          // pinned staging of the one-frame host entries (one copy each way)
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;

@@ -12,6 +12,16 @@ extern "C" int cms_area_set_descriptors(cms_ctx* c, int b, int n, const uint8_t*
   return CMS_OK;
 }
 
+// Which numbers a caller hands over as min_dist / max_dist of a map point: 0 (default) MapPoint::mfMinDistance / mfMaxDistance themselves
+// (private members: a binding needs two accessors), 1 the public MapPoint::GetMinDistanceInvariance() / GetMaxDistanceInvariance()
+// (MapPoint.cpp:375-385: 0.8f / 1.2f already applied) -- the reference's headers stay byte-identical.  Applies to cms_search_local_points,
+// cms_is_in_frustum_device, cms_fuse_search and cms_kfstore_fuse_search of this context.
+extern "C" int cms_set_distance_bounds_mode(cms_ctx* c, int scaled) {
+  if (!c || scaled < 0 || scaled > 1) return cms_fail(CMS_ERR_ARG, "cms_set_distance_bounds_mode: mode must be 0 or 1");
+  c->dist_bounds_scaled = scaled;
+  return CMS_OK;
+}
+
 extern "C" int cms_is_in_frustum_device(cms_ctx* c, int nmp, const void* d_mp_frame, const void* d_pose15, const void* d_pos, const void* d_normal,
                                         const void* d_min_dist, const void* d_max_dist, float viewing_cos_limit, float th, void* d_in_view,
                                         void* d_proj_x, void* d_proj_y, void* d_level, void* d_view_cos, void* d_qr, void* d_qmin, void* d_qmax) {
@@ -24,7 +34,7 @@ extern "C" int cms_is_in_frustum_device(cms_ctx* c, int nmp, const void* d_mp_fr
   CmsFrustumArgs a;
   a.pose15 = (const float*)d_pose15; a.mp_frame = (const int*)d_mp_frame; a.n = nmp;
   a.P = (const float*)d_pos; a.normal = (const float*)d_normal; a.min_dist = (const float*)d_min_dist; a.max_dist = (const float*)d_max_dist;
-  a.viewing_cos_limit = viewing_cos_limit; a.th = th;
+  a.viewing_cos_limit = viewing_cos_limit; a.th = th; a.bounds_scaled = c->dist_bounds_scaled;
   a.log_scale = std::log(c->g.nlevels > 1 ? c->scale[1] : 1.2f);          // mfLogScaleFactor = log(mfScaleFactor), float (Frame.cpp:113)
   a.nlevels = c->g.nlevels; a.F = c->g.F;
   for (int l = 0; l < 16; ++l) a.sf[l] = l < c->g.nlevels ? c->scale[l] : 0.0f;

@@ -405,6 +405,7 @@ extern "C" int cms_fuse_search(cms_ctx* c, int b, const float* pose15, int nmp, 
     const std::vector<int> qf((size_t)nmp, b);
     HIPCHK(hipMemcpyAsync(p + o_qf, qf.data(), n4, hipMemcpyHostToDevice, s));
     CmsFuseArgs fa;
+    fa.bounds_scaled = c->dist_bounds_scaled;
     fa.pose15 = (const float*)(p + o_pose); fa.mp_frame = nullptr; fa.n = nmp; fa.skip = skip ? p + o_skip : nullptr;
     fa.P = (const float*)(p + o_pos); fa.normal = (const float*)(p + o_nrm); fa.min_dist = (const float*)(p + o_min); fa.max_dist = (const float*)(p + o_max);
     fa.th = th; fa.log_scale = std::log(c->scale[1]); fa.nlevels = c->g.nlevels; fa.F = c->g.F;
@@ -556,6 +557,7 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
     HIPCHK(hipMemcpyAsync(p + o_max, max_dist, n4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice, s));
     CmsFuseArgs fa;
+    fa.bounds_scaled = c->dist_bounds_scaled;
     fa.pose15 = (const float*)(p + o_pose); fa.mp_frame = (const int*)(p + o_job); fa.n = nmp; fa.skip = skip ? p + o_skip : nullptr;
     fa.P = (const float*)(p + o_pos); fa.normal = (const float*)(p + o_nrm); fa.min_dist = (const float*)(p + o_min); fa.max_dist = (const float*)(p + o_max);
     fa.th = th; fa.log_scale = std::log(c->scale[1]); fa.nlevels = c->g.nlevels; fa.F = c->g.F;

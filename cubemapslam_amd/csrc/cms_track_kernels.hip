@@ -22,10 +22,26 @@ struct CmsFrustumArgs {
   const float* P; const float* normal; const float* min_dist; const float* max_dist;   // mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance
   float viewing_cos_limit, log_scale, th;
   int nlevels, F;
+  int bounds_scaled;        // 1: min_dist / max_dist are MapPoint::GetMinDistanceInvariance() / GetMaxDistanceInvariance() (0.8f / 1.2f applied)
   float sf[16];             // mvScaleFactors
   uint8_t* in_view; float* proj_x; float* proj_y; int* level; float* view_cos;            // mbTrackInView, mTrackProjX/Y, mnTrackScaleLevel, mTrackViewCos
   float* qr; int* qmin; int* qmax;                                                      // window of SearchByProjection (ORBMatcher.cpp:69-75)
 };
+
+// Scale-invariance bounds of a map point (MapPoint.cpp:375-385) and mfMaxDistance itself, from what the caller handed over
+// (cms_set_distance_bounds_mode): the raw members, or the public getters' values
+__device__ __forceinline__ void track_distance_bounds(int scaled, float min_in, float max_in, float& minDistance, float& maxDistance, float& raw_max) {
+  if (scaled) {
+    maxDistance = max_in; minDistance = min_in;
+    float r = (float)((double)max_in / (double)1.2f);
+    const float lo = __uint_as_float(__float_as_uint(r) - 1u), hi = __uint_as_float(__float_as_uint(r) + 1u);
+    if (r > 0.0f && __fmul_rn(1.2f, lo) == max_in) r = lo;
+    else if (__fmul_rn(1.2f, r) != max_in && __fmul_rn(1.2f, hi) == max_in) r = hi;
+    raw_max = r;
+  } else {
+    raw_max = max_in; maxDistance = __fmul_rn(1.2f, max_in); minDistance = __fmul_rn(0.8f, min_in);
+  }
+}
 
 // CamModelGeneral::TransformRaysToCubemap (src/CamModelGeneral.cpp:95-154): face choice on float ratios, pixel through the double
 // intrinsics (fx = fy = cx = cy = F / 2 are double members, so `_x * fx / _z + cx` is evaluated in double and narrowed on assignment)
@@ -66,8 +82,12 @@ extern "C" __global__ void __launch_bounds__(256) k_in_frustum(CmsFrustumArgs a)
     const int face = track_rays_to_cubemap(a.F, Pc[0], Pc[1], Pc[2], u, v);
     if (face < 0) break;
     if (u < 0.0f || u > mnMax || v < 0.0f || v > mnMax) break;
-    const float maxd = a.max_dist[i];
-    const float maxDistance = __fmul_rn(1.2f, maxd), minDistance = __fmul_rn(0.8f, a.min_dist[i]);
+    // mfMaxDistance itself (PredictScale's ratio) and the two invariance bounds.  Handed the public getters' values, the bounds are used as
+    // they are and mfMaxDistance is recovered as the float r with 1.2f * r == bound (the product rounds up to two neighbouring r onto one
+    // bound when it crosses a power of two; the smaller one is taken -- PredictScale can then differ from the reference only where
+    // log(ratio) / log(scale factor) sits within an ulp of an integer)
+    float maxd, maxDistance, minDistance;
+    track_distance_bounds(a.bounds_scaled, a.min_dist[i], a.max_dist[i], minDistance, maxDistance, maxd);
     const float PO[3] = {__fsub_rn(px, ps[12]), __fsub_rn(py, ps[13]), __fsub_rn(pz, ps[14])};
     double s = 0;
 #pragma unroll

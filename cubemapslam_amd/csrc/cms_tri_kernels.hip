@@ -444,6 +444,7 @@ struct CmsFuseArgs {
   const uint8_t* skip; const float* P; const float* normal; const float* min_dist; const float* max_dist;
   float th, log_scale; int nlevels, F; float sf[16];
   float* qx; float* qy; float* qr; int* qmin; int* qmax; int* level;
+  int bounds_scaled;           // cms_set_distance_bounds_mode
 };
 extern "C" __global__ void __launch_bounds__(256) k_fuse_project(CmsFuseArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,8 +459,8 @@ extern "C" __global__ void __launch_bounds__(256) k_fuse_project(CmsFuseArgs a) 
     track_rays_to_cubemap(a.F, pc[0], pc[1], pc[2], u, v);       // the face is not looked at (ORBMatcher.cpp:1151)
     const float mx = (float)(3 * a.F);
     if (!(u >= 0.0f && u < mx && v >= 0.0f && v < mx)) break;      // KeyFrame::IsInImage
-    const float maxd = a.max_dist[i];
-    const float maxDistance = __fmul_rn(1.2f, maxd), minDistance = __fmul_rn(0.8f, a.min_dist[i]);
+    float maxd, maxDistance, minDistance;
+    track_distance_bounds(a.bounds_scaled, a.min_dist[i], a.max_dist[i], minDistance, maxDistance, maxd);
     const float PO[3] = {__fsub_rn(p[0], ps[12]), __fsub_rn(p[1], ps[13]), __fsub_rn(p[2], ps[14])};
     const float dist3D = (float)tri_dnorm3(PO);
     if (dist3D < minDistance || dist3D > maxDistance) break;

@@ -251,6 +251,14 @@ int cms_features_in_area_batch_device(cms_ctx* ctx, int nq, const void* d_qframe
  * cms_search_for_initialization take up to 16383, i.e. the 3 x nFeatures extractor); any number of map points per frame (a thread of the greedy kernel
  * takes every 1024th point of its frame). */
 int cms_area_set_descriptors(cms_ctx* ctx, int b, int n, const uint8_t* desc);
+/* What the caller hands over as min_dist / max_dist of a map point (cms_search_local_points, cms_is_in_frustum_device, cms_fuse_search,
+ * cms_kfstore_fuse_search of this context): scaled = 0 (default) MapPoint::mfMinDistance / mfMaxDistance themselves -- private members, a binding
+ * needs two one-line accessors; scaled = 1 the public MapPoint::GetMinDistanceInvariance() / GetMaxDistanceInvariance() (src/MapPoint.cpp:375-385:
+ * 0.8f / 1.2f already applied), so that the reference's headers stay byte-identical.  With scaled = 1 the bounds of Frame::isInFrustum / Fuse
+ * are exactly the getters' values; mfMaxDistance (the numerator of MapPoint::PredictScale, :387-419) is recovered as the float r with
+ * 1.2f * r == bound -- where the product crossed a power of two, two neighbouring r share a bound and the smaller is taken: the predicted
+ * level can then differ from the reference only if log(ratio) / log(scale factor) sits within an ulp of an integer. */
+int cms_set_distance_bounds_mode(cms_ctx* ctx, int scaled);
 /* ORBMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBMatcher.cpp:130-251), the matcher of
  * Tracking::TrackWithMotionModel, whole on the device: the last frame's map points are projected with the current pose (Rcw | tcw of
  * CurrentFrame.mTcw; z < cosFovTh and UNKNOWN_FACE are dropped), windows th * scale[octave] over octave -1 .. +1, greedy best match

@@ -54,6 +54,7 @@ cms_ctx* CreateContext(const cms_orb_params& orb) {
   c.Iw = cam->GetFisheyeWidth(); c.Ih = cam->GetFisheyeHeight(); c.face = cam->GetCubeFaceWidth(); c.fov_deg = g_fov_deg;
   cms_ctx* ctx = nullptr;
   check(cms_ctx_create(&ctx, g_device, &c, &orb, 1), "cms_ctx_create");
+  check(cms_set_distance_bounds_mode(ctx, 1), "cms_set_distance_bounds_mode");     // map points' bounds come from MapPoint's public getters
   return ctx;
 }
 
@@ -116,10 +117,8 @@ int SearchLocalPoints(cms_ctx* ctx, Frame& F, const std::vector<MapPoint*>& vpMa
     MapPoint* p = vpMapPoints[i];
     const cv::Mat x = p->GetWorldPos(), nn = p->GetNormal();
     for (int k = 0; k < 3; ++k) { pos[3 * i + k] = x.at<float>(k); nrm[3 * i + k] = nn.at<float>(k); }
-    dmin[i] = p->GetRawMinDistance();                              // mfMinDistance / mfMaxDistance themselves: the entry applies the 0.8 / 1.2 factors of
-    dmax[i] = p->GetRawMaxDistance();                              // Get{Min,Max}DistanceInvariance (MapPoint.cpp:375-385) the way Frame::isInFrustum sees them.
-                                                                   // Two one-line accessors to add to MapPoint.h (dividing the public getters' values by
-                                                                   // 0.8f / 1.2f would not round-trip in float)
+    dmin[i] = p->GetMinDistanceInvariance();                       // the PUBLIC getters (MapPoint.cpp:375-385: 0.8f / 1.2f applied); the context was put
+    dmax[i] = p->GetMaxDistanceInvariance();                       // into cms_set_distance_bounds_mode(ctx, 1) by the bridge's set-up: MapPoint.h stays untouched
     const cv::Mat d = p->GetDescriptor();
     std::memcpy(&desc[(size_t)i * 32], d.data, 32);
   }

@@ -1282,3 +1282,37 @@ def test_ba_optimize_many_call_mixing_window_kinds_is_split_into_groups():
         assert st.n_outliers_final == w["stats"].n_outliers_final and np.array_equal(flags, w["outliers"]), i
         _ba_updates_close(p, poses, pts, w, tag="window %d" % i)
         ba.close()
+
+
+def test_distance_bounds_from_the_public_getters():
+    """cms_set_distance_bounds_mode(ctx, 1): the caller hands over MapPoint::GetMinDistanceInvariance() / GetMaxDistanceInvariance()
+    (0.8f * mfMinDistance, 1.2f * mfMaxDistance in float, MapPoint.cpp:375-385) instead of the private members, so that a binding does not
+    have to touch MapPoint.h.  Same frame, same local map (a few thousand points), both modes: visibility, projections, predicted levels, view cosines and
+    the matches must be identical (the recovery of mfMaxDistance from 1.2f * mfMaxDistance is exact except where two floats share a product,
+    and there it only matters if PredictScale's quotient sits on an integer)."""
+    camd, ocam, _ = _cfg("lafida", 450, 2000)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=1)
+    mask = synth.cubemap_valid_mask(camd)
+    ctx.set_mask(mask)
+    k, d = ctx.remap_extract(synth.texture(camd["Ih"], camd["Iw"], 5))
+    ctx.area_grid(1)
+    lm = synth.local_map_problem(450, k["x"], k["y"], k["octave"], d, seed=21, extra=3.0)
+    raw = ctx.search_local_points(0, lm["pose15"], lm["pos"], lm["normal"], lm["min_dist"], lm["max_dist"], lm["desc"], np.full(len(k), -1, np.int32))
+    ctx.set_distance_bounds_mode(1)
+    smin = (np.float32(0.8) * lm["min_dist"].astype(np.float32)).astype(np.float32)
+    smax = (np.float32(1.2) * lm["max_dist"].astype(np.float32)).astype(np.float32)
+    pub = ctx.search_local_points(0, lm["pose15"], lm["pos"], lm["normal"], smin, smax, lm["desc"], np.full(len(k), -1, np.int32))
+    ctx.set_distance_bounds_mode(0)
+    assert raw["in_view"].sum() > 100
+    for key in ("in_view", "level", "match"):
+        assert np.array_equal(raw[key], pub[key]), key
+    for key in ("proj_x", "proj_y", "view_cos"):
+        assert np.array_equal(raw[key].view(np.uint32), pub[key].view(np.uint32)), key
+    # the recovery itself, on a million floats: 1.2f * r == 1.2f * recovered r
+    x = np.random.RandomState(3).uniform(0.05, 80.0, 1000000).astype(np.float32)
+    s_ = (np.float32(1.2) * x).astype(np.float32)
+    r = (s_.astype(np.float64) / np.float64(np.float32(1.2))).astype(np.float32)
+    lo = (r.view(np.uint32) - 1).view(np.float32); hi = (r.view(np.uint32) + 1).view(np.float32)
+    rec = np.where((np.float32(1.2) * lo).astype(np.float32) == s_, lo, np.where((np.float32(1.2) * r).astype(np.float32) == s_, r, hi))
+    assert np.array_equal((np.float32(1.2) * rec).astype(np.float32), s_) and (rec != x).mean() < 0.5 and np.abs(rec.view(np.int32) - x.view(np.int32)).max() <= 1
+    ctx.close()
