@@ -795,6 +795,21 @@ def main():
                   "median_ms_key_frame_with_local_ba": round(1e3 * float(np.median(kfr)), 3) if kfr else None,
                   "mean_inliers": round(float(np.mean([r["n_inliers"] for r in trk.log if "n_inliers" in r])), 1) if trk.state == "ok" else None,
                   "note": "ray-cast box-room stream through the harness, one frame at a time through the host-buffer C-ABI entries; Python glue included"}
+        # the same stream through the Python-free driver (cubemapslam_amd/host/closed_loop_driver.cpp: image files in, the reference's summary out)
+        try:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                harness.export_sequence(td, camd, fr_cl, gt_cl, mask)
+                rc_d, recs_d, out_d = harness.run_driver(td, device=local_rank)
+            trd = [r["ms"] for r in recs_d if r.get("stage") == "track" and "ba_iterations" not in r and "n_inliers" in r]
+            kfd = [r["ms"] for r in recs_d if "ba_iterations" in r]
+            closed["cpp_driver"] = {"exit_code": rc_d, "frames": len(recs_d), "frames_per_s": round(1e3 * len(recs_d) / max(sum(r["ms"] for r in recs_d), 1e-9), 1),
+                                    "median_ms_tracked_frame": round(float(np.median(trd)), 3) if trd else None,
+                                    "median_ms_key_frame_with_local_ba": round(float(np.median(kfd)), 3) if kfd else None,
+                                    "mean_inliers": round(float(np.mean([r["n_inliers"] for r in recs_d if "n_inliers" in r])), 1) if trd else None,
+                                    "note": "cubemap_closed_loop: plain C++ over the C-ABI, one frame after the other, no Python in the loop"}
+        except Exception as ex:      # the driver is a report line, not the metric
+            closed["cpp_driver"] = {"error": str(ex)[:200]}
 
     if rank == 0 and args.save_trajectory and last["traj"] is not None:
         # rank 0's assembled trajectory of the last step in the reference's TUM format (System.cpp:238-268)

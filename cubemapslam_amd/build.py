@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libcubemapslam_hip.so")
 HOST_LIB = os.path.join(LIB_DIR, "libcubemapslam_host.so")
+DRIVER = os.path.join(LIB_DIR, "cubemap_closed_loop")
 
 
 def _newer(srcs, target):
@@ -46,11 +47,19 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
     host_dir = os.path.join(HERE, "host")
     hsrcs = _sources(host_dir)
-    cpps = [s for s in hsrcs if s.endswith(".cpp")]
+    cpps = [s for s in hsrcs if s.endswith(".cpp") and not s.endswith("closed_loop_driver.cpp")]
     if cpps and (force or _newer(hsrcs + [LIB], HOST_LIB)):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
                "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", host_dir] + cpps + \
               ["-L", LIB_DIR, "-lcubemapslam_hip", "-Wl,-rpath,$ORIGIN", "-o", HOST_LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # the Python-free closed-loop driver (Examples/cubemap_lafida.cpp's role): a plain C++ program over the C-ABI and io_formats
+    drv_src = os.path.join(host_dir, "closed_loop_driver.cpp")
+    if os.path.exists(drv_src) and (force or _newer(hsrcs + [LIB], DRIVER)):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", host_dir,
+               drv_src, os.path.join(host_dir, "io_formats.cpp"), "-L", LIB_DIR, "-lcubemapslam_hip", "-Wl,-rpath,$ORIGIN", "-o", DRIVER]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -132,7 +132,7 @@ class Tracker:
         F = self.F
         idx = np.flatnonzero(kp_mp >= 0)
         _, ray = synth.pixel_to_ray(F, kps["x"][idx], kps["y"][idx])
-        idx = idx[ray[:, 2].astype(np.float32) >= self.cos_fov]
+        idx = idx[(ray[:, 2] / np.linalg.norm(ray, axis=1)).astype(np.float32) >= self.cos_fov]      # mvKeyRays are unit vectors (CamModelGeneral.h:494-513)
         px = kps["x"][idx].astype(np.float64); py = kps["y"][idx].astype(np.float64)
         face = synth.face_of_pixel(F, px, py)
         idx = idx[face >= 0]; px = px[face >= 0]; py = py[face >= 0]; face = face[face >= 0]
@@ -273,7 +273,7 @@ class Tracker:
             idx = np.flatnonzero(kf["kp_mp"] >= 0)
             idx = idx[pt_index[kf["kp_mp"][idx]] >= 0]
             _, ray = synth.pixel_to_ray(F, kf["kps"]["x"][idx], kf["kps"]["y"][idx])
-            idx = idx[ray[:, 2].astype(np.float32) >= self.cos_fov]
+            idx = idx[(ray[:, 2] / np.linalg.norm(ray, axis=1)).astype(np.float32) >= self.cos_fov]
             px = kf["kps"]["x"][idx].astype(np.float64); py = kf["kps"]["y"][idx].astype(np.float64)
             face = synth.face_of_pixel(F, px, py)
             keep = face >= 0
@@ -332,3 +332,56 @@ def render_sequence(camd, n, seed=0xC0FFEE, n_loop=300, start=0):
         R, t = synth.room_pose(i, n_loop)
         frames.append(synth.render_fisheye(camd, scene, R, t)); gts.append((R, t))
     return frames, gts
+
+
+# ---- the same stream through the Python-free driver (cubemapslam_amd/host/closed_loop_driver.cpp): files in the reference's formats
+def settings_yaml(camd, nfeatures=None):
+    """a settings file with the keys System::System / Tracking::Tracking read (System.cpp:63-91, Tracking.cpp:61-93)"""
+    lines = ["%YAML:1.0", "Camera.Iw: %d" % camd["Iw"], "Camera.Ih: %d" % camd["Ih"], "Camera.nrpol: 5", "Camera.nrinvpol: 12"]
+    lines += ["Camera.a%d: %r" % (i, float(v)) for i, v in enumerate(camd["pol"])]
+    lines += ["Camera.pol%d: %r" % (i, float(v)) for i, v in enumerate(list(camd["invpol"]) + [0.0] * (12 - len(camd["invpol"])))]
+    lines += ["Camera.%s: %r" % (k, float(camd[k])) for k in ("c", "d", "e", "u0", "v0")]
+    lines += ["Camera.fov: %r" % float(camd["fov_deg"]), "Camera.fps: 30.0", "Camera.RGB: 1", "Camera.withFisheyeMask: 0",
+              "CubeFace.w: %d" % camd["face"], "CubeFace.h: %d" % camd["face"], "ORBextractor.nFeatures: %d" % (nfeatures or camd["nfeatures"]),
+              "ORBextractor.scaleFactor: 1.2", "ORBextractor.nLevels: 8", "ORBextractor.iniThFAST: 20", "ORBextractor.minThFAST: 7"]
+    return "\n".join(lines) + "\n"
+
+
+def _write_pgm(path, img):
+    img = np.ascontiguousarray(img, np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+
+
+def export_sequence(dirpath, camd, frames, gts, mask):
+    """settings.yaml, images.txt ("<timestamp> <file>", cubemap_lafida.cpp:91-107), the frames and the cubemap mask as binary PGM, and the
+    ground-truth poses the stand-ins for Initializer / CreateNewMapPoints read (first line: the box room's half extents)."""
+    import os
+    os.makedirs(os.path.join(dirpath, "imgs"), exist_ok=True)
+    with open(os.path.join(dirpath, "settings.yaml"), "w") as f:
+        f.write(settings_yaml(camd))
+    with open(os.path.join(dirpath, "images.txt"), "w") as f:
+        for i in range(len(frames)):
+            f.write("%.6f imgs/%08d.pgm\n" % (1409666701.0 + i / 30.0, i))
+    for i, fr in enumerate(frames):
+        _write_pgm(os.path.join(dirpath, "imgs", "%08d.pgm" % i), fr)
+    _write_pgm(os.path.join(dirpath, "mask.pgm"), mask)
+    with open(os.path.join(dirpath, "ground_truth.txt"), "w") as f:
+        f.write("room %r %r %r\n" % tuple(float(v) for v in synth.ROOM_HALF))
+        for R, t in gts:
+            f.write(" ".join(repr(float(v)) for v in list(np.asarray(R, np.float64).reshape(-1)) + list(np.asarray(t, np.float64))) + "\n")
+
+
+def run_driver(dirpath, kf_every=5, ba_window=8, new_points_per_kf=400, warmup=6, device=0):
+    """runs cubemap_closed_loop on an exported sequence; returns (exit code, per-frame records, stdout)"""
+    import json, os, subprocess
+    from . import build
+    log = os.path.join(dirpath, "frames.jsonl")
+    cmd = [build.DRIVER, os.path.join(dirpath, "settings.yaml"), os.path.join(dirpath, "images.txt"), os.path.join(dirpath, "imgs"), os.path.join(dirpath, "mask.pgm"),
+           os.path.join(dirpath, "ground_truth.txt"), "--kf-every", str(kf_every), "--ba-window", str(ba_window), "--new-points", str(new_points_per_kf),
+           "--warmup", str(warmup), "--log", log, "--trajectory", os.path.join(dirpath, "KeyFrameTrajectory.txt"), "--perf", os.path.join(dirpath, "perf.txt"),
+           "--device", str(device)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    recs = [json.loads(l) for l in open(log)] if os.path.exists(log) else []
+    return r.returncode, recs, r.stdout + r.stderr

@@ -70,3 +70,43 @@ def test_closed_loop_product_equals_oracle_frame_by_frame():
     dm = np.linalg.norm(tg.mp_pos.astype(np.float64) - to.mp_pos.astype(np.float64), axis=1)
     assert tg.mp_pos.shape == to.mp_pos.shape and np.median(dm) <= 1e-5 and np.percentile(dm, 99) <= 1e-3, (np.median(dm), np.percentile(dm, 99), dm.max())
     print("closed loop: worst pose entry difference %.3g; map points: median %.3g m, 99 %% %.3g m, max %.3g m" % (worst, np.median(dm), np.percentile(dm, 99), dm.max()))
+
+
+def test_python_free_driver_tracks_the_same_stream(tmp_path):
+    """The drop-in boundary driven without Python (cubemapslam_amd/host/closed_loop_driver.cpp, the role of Examples/cubemap_lafida.cpp:128-179):
+    the rendered stream is written out in the reference's formats (settings YAML, image list, images), the C++ driver tracks it frame after frame
+    through the C-ABI and prints the reference's median / mean summary.  Held against the Python harness on the same stream (the two differ only in
+    host float arithmetic: the driver multiplies poses like cv::Mat, numpy uses BLAS): initialisation match count identical (no pose involved yet);
+    per frame the motion-model / local-map match counts and the inlier counts within a few; every frame tracked within 3 cm of the rendered
+    trajectory; the same key frames and local-BA window sizes, iteration counts present."""
+    camd = synth.camera("lafida", 550)
+    mask = synth.cubemap_valid_mask(camd)
+    frames, gts = harness.render_sequence(camd, 20)
+    harness.export_sequence(str(tmp_path), camd, frames, gts, mask)
+    kw = dict(kf_every=4, ba_window=6, new_points_per_kf=400)
+    rc, recs, out = harness.run_driver(str(tmp_path), warmup=4, **kw)
+    assert rc == 0, out[-2000:]
+    assert "median tracking time" in out and "mean tracking time" in out and "state: ok" in out, out[-1500:]
+    gpu = harness.GpuBackend(camd, mask)
+    trk, _ = harness.run_sequence(camd, gpu, frames, gts, **kw)
+    gpu.close()
+    assert trk.state == "ok" and len(recs) == len(trk.log) == 20
+    assert recs[1]["n_init"] == trk.log[1]["n_init"] and recs[1]["n_map"] == trk.log[1]["n_map"]
+    n_kf = 0
+    for r, p in zip(recs, trk.log):
+        assert r["stage"] == p["stage"], (r, p["stage"])
+        if r["stage"] != "track":
+            continue
+        assert r["nkp"] == p["nkp"]                                            # the extraction does not depend on the tracker's state
+        assert abs(r["n_mm"] - p["n_mm"]) <= 12 and abs(r["n_lm"] - p["n_lm"]) <= 12 and abs(r["n_inliers"] - p["n_inliers"]) <= 12, (r, p["n_mm"], p["n_lm"], p["n_inliers"])
+        assert r["n_inliers"] >= 30 and r["pos_err_m"] < 0.03, r
+        assert ("ba_iterations" in r) == ("ba_iterations" in p)
+        if "ba_iterations" in r:
+            n_kf += 1
+            assert r["ba_kfs"] == p["ba_kfs"] and abs(r["ba_points"] - p["ba_points"]) <= 20 and abs(r["ba_edges"] - p["ba_edges"]) <= 60, (r, p["ba_edges"])
+            assert 1 <= r["ba_iterations"][0] <= 5 and r["ba_iterations"][1] <= 10
+    assert n_kf >= 3
+    traj = (tmp_path / "KeyFrameTrajectory.txt").read_text().strip().split("\n")
+    assert len(traj) == len(trk.kfs) and all(len(l.split()) == 8 for l in traj)
+    perf = (tmp_path / "perf.txt").read_text()
+    assert "median" in perf or len(perf) > 0
