@@ -359,6 +359,7 @@ def main():
 
     schur_acc = {"ms": 0.0, "n": 0}
     worker_ms = {}
+    tri_last = os.environ.get("CMS_BENCH_TRI_LAST", "") != ""      # developer knob: CreateNewMapPoints behind the group's BA instead of in front of it
     def ba_worker(grp, gi, keep):
         """optimise-only pass: one group of STANDING windows of one step; returns (elapsed ms, new map points, per-window stats)"""
         t_ba0 = time.perf_counter()
@@ -378,10 +379,13 @@ def main():
         t_w = time.perf_counter()
         grp = [m[0] for m in made]
         grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (the BA chain's largest kernel)
-        res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+        if not tri_last:
+            res = tri_store[gi].create_new_map_points(tri_jobs[gi])
         t_t = time.perf_counter()
         _, stats = api.ba_optimize_many(grp, (5, 10))
         t_o = time.perf_counter()
+        if tri_last:
+            res = tri_store[gi].create_new_map_points(tri_jobs[gi])
         ms, nl = grp[0].profile_get()
         schur_acc["ms"] += ms; schur_acc["n"] += nl
         outs = [wpool.submit(finish_window, ba) for ba in grp]

@@ -146,7 +146,7 @@ static void ba_stream_give(int device, hipStream_t s) {
 // windows of 45 MB alive, and a hipFree in the middle of a step synchronises the device --, 512 pinned blocks).
 struct BaMemPool {
   std::mutex mu;
-  std::vector<BaBlock> dev[64], pin[64];
+  std::vector<BaBlock> dev[64], pin[64], stage[64];
   size_t dev_cached[64] = {0};
 };
 static BaMemPool& ba_pool() { static BaMemPool* p = new BaMemPool; return *p; }      // never destroyed: no HIP calls at process exit
@@ -186,6 +186,27 @@ static hipError_t ba_pin_take(int device, size_t bytes, void** p, size_t* got) {
   *got = bytes;
   return hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
 }
+// plain pinned host memory (not device-coherent): staging blocks of uploads and read-backs.  A copy from / to such memory goes through the DMA
+// engines; the coherent, device-mapped kind above made the runtime copy with a shader kernel (__amd_rocclr_copyBuffer: 1.8 ms of kernel time
+// per bench.py step for the 32 window uploads) -- CMS_BA_STAGE_COHERENT=1 brings that back (A/B)
+static hipError_t ba_stage_take(int device, size_t bytes, void** p, size_t* got) {
+  static const bool coherent = getenv("CMS_BA_STAGE_COHERENT") != nullptr;
+  BaMemPool& pl = ba_pool();
+  if (device >= 0 && device < 64) {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if ((*p = ba_pool_take(pl.stage[device], bytes, got)) != nullptr) return hipSuccess;
+  }
+  *got = bytes;
+  return hipHostMalloc(p, bytes, coherent ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault);
+}
+static void ba_stage_give(int device, void* p, size_t bytes) {
+  BaMemPool& pl = ba_pool();
+  if (device >= 0 && device < 64) {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (pl.stage[device].size() < 512) { pl.stage[device].push_back({p, bytes}); return; }
+  }
+  hipHostFree(p);
+}
 static void ba_pin_give(int device, void* p, size_t bytes) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
@@ -223,7 +244,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->stream && (b->own_stream || b->async_pending)) hipStreamSynchronize(b->stream);
   for (const BaBlock& sl : b->slabs) ba_dev_give(b->device, sl.p, sl.bytes);
   if (b->h_pin) ba_pin_give(b->device, b->h_pin, b->h_pin_bytes);
-  if (b->h_stage) ba_pin_give(b->device, b->h_stage, b->h_stage_bytes);
+  if (b->h_stage) ba_stage_give(b->device, b->h_stage, b->h_stage_bytes);
   if (b->grp_items_host) ba_pin_give(b->device, b->grp_items_host, b->grp_pin_bytes[0]);
   if (b->grp_scal_host) ba_pin_give(b->device, b->grp_scal_host, b->grp_pin_bytes[1]);
   if (b->grp_lm_host) ba_pin_give(b->device, b->grp_lm_host, b->grp_pin_bytes[2]);
@@ -1144,7 +1165,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     total = std::max(total, ((size_t)7 * K * 8 + 255 + (size_t)3 * P * 8 + 255 + (size_t)E + 255));
     char* dev = nullptr;
     BA_TRY(ba_alloc(b, &dev, total));
-    BA_HIP(ba_pin_take(device, total, (void**)&b->h_stage, &b->h_stage_bytes));
+    BA_HIP(ba_stage_take(device, total, (void**)&b->h_stage, &b->h_stage_bytes));
     for (size_t i = 0; i < ups.size(); ++i) {
       if (ups[i].bytes) memcpy(b->h_stage + offs[i], ups[i].src, ups[i].bytes);
       *ups[i].dst = dev + offs[i];

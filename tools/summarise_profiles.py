@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof/<tag>_* (rocprofv3 csv output) into the small, tracked summaries under profiles/."""
 import collections, csv, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 PB = int(os.environ.get("PROF_B", "256"))      # frames per dispatch of the PMC passes (tools/run_profiles.sh)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof"); dst = os.path.join(root, "profiles")
@@ -10,7 +10,8 @@ stats = os.path.join(src, tag + "_bench_kernel_stats.csv")
 if os.path.exists(stats):
     rows = list(csv.DictReader(open(stats)))
     with open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-frames 0   (MI355X, 1 GPU)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass "
+                "--optimise-only-steps 0 --verify-windows 0   (MI355X, 1 GPU; every step creates, optimises, reads back and destroys its 32 local-BA windows)\n")
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
@@ -34,6 +35,12 @@ for extra, cmd in (("mapping", "python tools/prof_tri.py 8 20 5"), ("ba8", "pyth
             for r in csv.DictReader(open(st)):
                 f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
                                   "%.2f" % float(r["Percentage"]), r["MinNs"], r["MaxNs"]]) + "\n")
+import shutil
+for name in ("step_table.md", "probe_lds_atomics.txt", "rm_phase_cycles.txt", "ba16_track.txt", "ba16_track_valu.txt", "ba16_track_edges_only.txt", "ba16_random.txt", "ba1_track.txt"):
+    sp = os.path.join(src, "%s_%s" % (tag, name))
+    if os.path.exists(sp):
+        txt = [l for l in open(sp) if not l.startswith(("W2", "E2", "I2", "/opt/amdgpu"))]
+        open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write("".join(txt))
 pmc = {}
 for kind in ("fetch", "write", "fetch_ba", "write_ba"):
     p = os.path.join(src, "%s_pmc_%s_counter_collection.csv" % (tag, kind))
@@ -78,6 +85,9 @@ for k, cs in sorted(acc.items()):
                            "lds_bank_conflict_cycles": per("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": per("SQ_LDS_IDX_ACTIVE"),
                            "wait_inst_lds_quad_cycles": per("SQ_WAIT_INST_LDS")},
               "valu_issue_bound_us": round(m.get("SQ_INSTS_VALU", 0.0) * 4 / (256 * 4 * 2.4e9) * 1e6, 1)}
+    if m.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) or m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0):
+        mix[k]["mfma"] = {"f64_mops_per_wave": per("SQ_INSTS_VALU_MFMA_MOPS_F64"), "busy_cycles_per_wave": per("SQ_VALU_MFMA_BUSY_CYCLES"),
+                          "insts_mfma_per_wave": per("SQ_INSTS_MFMA")}
 if mix:
     with open(os.path.join(dst, tag + "_pmc_instruction_mix.json"), "w") as f:
         json.dump({"command": "rocprofv3 --kernel-trace --pmc <4 SQ counters per pass, 3 passes> -- python tools/prof_frames.py %d 550 2   (tools/pmc_mix.sh; MI355X; "
