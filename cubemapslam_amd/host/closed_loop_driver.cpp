@@ -142,6 +142,21 @@ struct Room {
 };
 
 #define CHECK(call) do { const int rc_ = (call); if (rc_ < 0) { std::fprintf(stderr, "%s failed: %s\n", #call, cms_last_error()); std::exit(2); } } while (0)
+// CMS_DRIVER_CALL_TIMES=1: wall time of every boundary call (host work + launches + the wait for its results), summed per entry point and
+// printed after the summary -- where a tracked frame's time goes
+struct CallTimes {
+  struct Slot { const char* name; double s; long n; };
+  std::vector<Slot> slots;
+  bool on = std::getenv("CMS_DRIVER_CALL_TIMES") != nullptr;
+  void add(const char* name, double sec) {
+    for (Slot& sl : slots) if (std::strcmp(sl.name, name) == 0) { sl.s += sec; ++sl.n; return; }
+    slots.push_back({name, sec, 1});
+  }
+  void clear() { slots.clear(); }
+};
+static CallTimes g_calls;
+#define TIMED(name, call) do { if (!g_calls.on) { CHECK(call); break; } const auto c0_ = std::chrono::steady_clock::now(); CHECK(call); \
+  g_calls.add(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - c0_).count()); } while (0)
 
 struct FrameData {
   Mat4f T = eye4();
@@ -218,9 +233,9 @@ class Tracker {
     const int cap = init ? cap_ini_ : cap_trk_;
     fr.kps.resize(cap); fr.desc.resize((size_t)cap * 32);
     int n = 0;
-    CHECK(cms_remap_extract(cur_, fisheye.px.data(), fisheye.w, fr.kps.data(), fr.desc.data(), cap, &n));
+    TIMED("cms_remap_extract", cms_remap_extract(cur_, fisheye.px.data(), fisheye.w, fr.kps.data(), fr.desc.data(), cap, &n));
     fr.kps.resize(n); fr.desc.resize((size_t)n * 32);
-    CHECK(cms_area_grid(cur_, 1));                       // Frame::AssignFeaturesToGrid
+    TIMED("cms_area_grid", cms_area_grid(cur_, 1));                       // Frame::AssignFeaturesToGrid
     fr.kp_mp.assign(n, -1); fr.outlier.assign(n, 0);
   }
 
@@ -260,7 +275,7 @@ class Tracker {
     std::vector<uint8_t> out(idx.size());
     int ninl = 0;
     cms_pose_stats st;
-    CHECK(cms_pose_optimize_batch(pose_, 1, off, Xw.data(), obs.data(), inv.data(), face.data(), F_ / 2.0, F_ / 2.0, F_ / 2.0, F_ / 2.0, pose7,
+    TIMED("cms_pose_optimize_batch", cms_pose_optimize_batch(pose_, 1, off, Xw.data(), obs.data(), inv.data(), face.data(), F_ / 2.0, F_ / 2.0, F_ / 2.0, F_ / 2.0, pose7,
                                   out.data(), &ninl, &st));
     fr.T = T_from_pose7(pose7);
     std::fill(fr.outlier.begin(), fr.outlier.end(), 0);
@@ -292,7 +307,7 @@ class Tracker {
     const int n1 = (int)ini_.kps.size();
     std::vector<int> m12(n1, -1);
     int nm = 0;
-    CHECK(cms_search_for_initialization(cur_, 0, n1, ini_.kps.data(), ini_.desc.data(), ini_prev_.data(), 100, 0.9f, 1, m12.data(), &nm));
+    TIMED("cms_search_for_initialization", cms_search_for_initialization(cur_, 0, n1, ini_.kps.data(), ini_.desc.data(), ini_prev_.data(), 100, 0.9f, 1, m12.data(), &nm));
     log << ", \"n_init\": " << nm;
     if (nm < 100) { have_ini_ = false; return; }
     // ground-truth stand-in for Initializer + GlobalBA: both poses and the matched points' positions
@@ -338,11 +353,11 @@ class Tracker {
     }
     std::vector<int> kp_slot(n, -1), match(nl, -1);
     int nm = 0;
-    CHECK(cms_search_by_projection(cur_, 0, pose12, nl, valid.data(), Xw.data(), oct.data(), ang.data(), mdesc.data(), 15.0f, 1, 100, n, kp_slot.data(),
+    TIMED("cms_search_by_projection", cms_search_by_projection(cur_, 0, pose12, nl, valid.data(), Xw.data(), oct.data(), ang.data(), mdesc.data(), 15.0f, 1, 100, n, kp_slot.data(),
                                    match.data(), &nm));
     if (nm < 20) {
       std::fill(kp_slot.begin(), kp_slot.end(), -1);
-      CHECK(cms_search_by_projection(cur_, 0, pose12, nl, valid.data(), Xw.data(), oct.data(), ang.data(), mdesc.data(), 30.0f, 1, 100, n, kp_slot.data(),
+      TIMED("cms_search_by_projection", cms_search_by_projection(cur_, 0, pose12, nl, valid.data(), Xw.data(), oct.data(), ang.data(), mdesc.data(), 30.0f, 1, 100, n, kp_slot.data(),
                                      match.data(), &nm));
     }
     log << ", \"n_mm\": " << nm;
@@ -374,7 +389,7 @@ class Tracker {
     for (int k = 0; k < n; ++k) kp_lm[k] = cur.kp_mp[k] >= 0 ? (1 << 20) : -1;
     int nlm = 0, rounds = 0;
     if (nc > 0)
-      CHECK(cms_search_local_points(cur_, 0, pose15, nc, cpos.data(), cnrm.data(), cmin.data(), cmax.data(), cdesc.data(), 0.5f, 1.0f, 0.8f, 100, n,
+      TIMED("cms_search_local_points", cms_search_local_points(cur_, 0, pose15, nc, cpos.data(), cnrm.data(), cmin.data(), cmax.data(), cdesc.data(), 0.5f, 1.0f, 0.8f, 100, n,
                                     kp_lm.data(), in_view.data(), nullptr, nullptr, nullptr, nullptr, lmatch.data(), &nlm, &rounds));
     for (int k = 0; k < n; ++k) if (kp_lm[k] >= 0 && kp_lm[k] < (1 << 20)) cur.kp_mp[k] = cand[kp_lm[k]];
     log << ", \"n_lm\": " << nlm;
@@ -470,7 +485,7 @@ class Tracker {
     for (size_t p = 0; p < pts.size(); ++p) for (int c = 0; c < 3; ++c) points[3 * p + c] = (double)mp_pos[3 * (size_t)pts[p] + c];
     std::vector<uint8_t> out(e_pose.size(), 0);
     cms_ba_stats st;
-    CHECK(cms_ba_run(device_, (int)kf_ids.size(), poses.data(), fixed.data(), (int)pts.size(), points.data(), (int)e_pose.size(), e_pose.data(), e_point.data(),
+    TIMED("cms_ba_run", cms_ba_run(device_, (int)kf_ids.size(), poses.data(), fixed.data(), (int)pts.size(), points.data(), (int)e_pose.size(), e_pose.data(), e_point.data(),
                      e_obs.data(), e_inv.data(), e_face.data(), F_ / 2.0, F_ / 2.0, F_ / 2.0, F_ / 2.0, 5, 10, nullptr, out.data(), &st));
     int nout = 0;
     for (uint8_t o : out) nout += o;
@@ -537,6 +552,7 @@ int main(int argc, char** argv) {
     Tracker w(st, mask, room, device, kf_every, ba_window, new_pts);
     for (int i = 0; i < warmup && i < (int)images.size(); ++i) w.feed(i, images[i], gts[i]);
   }
+  g_calls.clear();
   Tracker trk(st, mask, room, device, kf_every, ba_window, new_pts);
   std::vector<float> vTimesTrack;
   std::ofstream logf;
@@ -554,6 +570,8 @@ int main(int argc, char** argv) {
   std::vector<float> times = vTimesTrack;
   const std::string summary = CubemapSLAM::WriteTrackingSummary(perf_path, times, (int)images.size());
   std::fputs(summary.c_str(), stdout);
+  for (const CallTimes::Slot& sl : g_calls.slots)
+    std::printf("call times: %-30s %6ld calls, %8.3f ms each, %8.3f ms per image\n", sl.name, sl.n, 1e3 * sl.s / sl.n, 1e3 * sl.s / (double)images.size());
   if (!traj_path.empty()) {
     // System::SaveKeyFrameTrajectoryTUM (System.cpp:238-268): "ts tx ty tz qx qy qz qw" of the camera centre and R^T, per key frame
     std::ofstream f(traj_path);
