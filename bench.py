@@ -283,7 +283,17 @@ def main():
         scaling = "weak"
     B = len(my_streams) * fps
     dev = torch.device("cuda", local_rank)
+    # The frame path's queue runs at LOW dispatch priority (CMS_FRAME_STREAM_PRIORITY, read by cms_ctx_create): its kernels are few and
+    # chip-filling, the mapping side's are a long chain of short dependent launches -- when both have workgroups ready the chain goes first.
+    # Measured 13.9-14.1 against 14.6-15.5 ms per step (tools/r03_run14.sh; "high" does the same: what counts is that the queue classes
+    # differ).  CMS_BENCH_FRAME_PRIORITY=normal|high|low overrides; the mapping side's contexts keep the default.
+    fprio = os.environ.get("CMS_BENCH_FRAME_PRIORITY", "low")
+    fprio = "" if fprio == "normal" else fprio
+    if fprio:
+        os.environ["CMS_FRAME_STREAM_PRIORITY"] = fprio
     ctx = api.Context(camd, nfeatures=nfeat, max_batch=B, device=local_rank)
+    if fprio:
+        del os.environ["CMS_FRAME_STREAM_PRIORITY"]
     mask = synth.cubemap_valid_mask(camd)
     ctx.set_mask(mask)
     g = ctx.geom
@@ -342,7 +352,12 @@ def main():
             k["rays"] = r.astype(np.float32)
     tri_ctx, tri_store, tri_jobs = [], [], []
     for gi, grp in enumerate(groups):
+        mprio = os.environ.get("CMS_BENCH_MAP_PRIORITY", "")       # developer knob: the same for the mapping side's queues (one per window group)
+        if mprio:
+            os.environ["CMS_FRAME_STREAM_PRIORITY"] = mprio
         cg = api.Context(camd, nfeatures=nfeat, max_batch=1, device=local_rank)
+        if mprio:
+            del os.environ["CMS_FRAME_STREAM_PRIORITY"]
         st = api.KeyframeStore(cg, max_keyframes=len(grp) * (tri_nn + 1), max_features=2048, max_nodes=1024)
         jobs_g = []
         for wi in range(len(grp)):
@@ -843,6 +858,7 @@ def main():
                                       int(np.mean([b.E for b in bas]))),
                        "frames_per_step_per_gpu": B, "frames_per_step_total": total_frames_per_step, "keypoints_per_frame": round(nkp, 1), "ba_every_frames": args.ba_every,
                        "inputs": "resident in HBM (two batches, device-to-device copy into the staging buffer inside the step)",
+                       "queues": {"frame_path_priority": fprio or "normal", "mapping_side_priority": os.environ.get("CMS_BENCH_MAP_PRIORITY", "") or "normal"},
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
                        "extractor_vs_survey_bytes": extractor,
