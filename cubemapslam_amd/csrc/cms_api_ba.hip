@@ -19,6 +19,7 @@
 struct BaKnobs {
   bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, rm_valu;
+  int solve_reduce_max;
   int lookahead, compose_segments, dup, run_min_chunks, rm_weight;
   char stream_priority;
 };
@@ -38,6 +39,8 @@ static const BaKnobs& ba_knobs() {
     q.runs_as_edges = on("CMS_BA_RUNS_AS_EDGES");        // keep the run order of the points but let the edge-major body take the run chunks too
     q.rm_valu = on("CMS_BA_RM_VALU");                    // the runs' tuple products on the vector ALU (producer / consumer pairs) instead of MFMA tiles
     q.separate_reduce = on("CMS_BA_SEPARATE_REDUCE");    // kb_ba_schur_edges_reduce as its own launch instead of inside the solve kernel
+    // ... which only pays while a window has few slices to sum (one workgroup reads them all): with more than this many the sum stays a launch
+    { const char* v = getenv("CMS_BA_SOLVE_REDUCE_MAX"); q.solve_reduce_max = v ? atoi(v) : 24; }
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
     q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", q.rm_valu ? 2 : 1));
     q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 100)));

@@ -408,7 +408,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // linearisation inside the Schur kernel (cms_ba_schur_edges.hip, FUSED): needs the edge-major kernels and the three-lane solve
   const bool fused = gm.fused;
   // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
-  const bool solve_reduces = fused && !ba_knobs().separate_reduce;
+  const bool solve_reduces = fused && !ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max;
   dyn.fused_lin = fused ? 1 : 0;
   int k = 0;
   const int pk = g->prof_kernel;

@@ -1061,16 +1061,18 @@ def test_kfstore_fuse_search_matches_oracle():
 
 
 @pytest.mark.parametrize("knob", ["CMS_BA_NO_FUSED_LIN", "CMS_BA_DETERMINISTIC", "CMS_BA_NO_PERMUTE", "CMS_BA_NO_RUNS", "CMS_BA_RUNS_AS_EDGES",
-                                  "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU"])
+                                  "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU", "CMS_BA_SOLVE_REDUCE_MAX=1000"])
 def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     """The grouped local-BA driver has several Schur paths -- signature runs multiplied in MFMA tiles + edge-major left-overs, linearisation
     fused (default); the runs' products on the vector ALU by producer / consumer wavefront pairs (CMS_BA_RM_VALU); every point edge-major
     (CMS_BA_NO_RUNS), also with the run order kept (CMS_BA_RUNS_AS_EDGES); the edge-major kernel behind
     kb_ba_lin (CMS_BA_NO_FUSED_LIN); the deterministic pair-owner kernel (CMS_BA_DETERMINISTIC) -- a host-side chunk composition that can be
-    switched off (CMS_BA_NO_PERMUTE), and the range sum either inside the solve kernel or as its own launch (CMS_BA_SEPARATE_REDUCE).  The
+    switched off (CMS_BA_NO_PERMUTE), and the range sum either inside the solve kernel (the default for groups whose windows have at most 24
+    range slices each, i.e. 11 or more windows per group; CMS_BA_SOLVE_REDUCE_MAX=1000: always) or as its own launch (CMS_BA_SEPARATE_REDUCE).  The
     knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""
     import os, subprocess, sys
-    env = dict(os.environ); env[knob] = "1"
+    env = dict(os.environ)
+    env[knob.split("=")[0]] = knob.split("=")[1] if "=" in knob else "1"
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
                         "config4_size_eight or stop_flag_raised or mixed_sizes or tracked_windows"], env=env, capture_output=True, text=True, timeout=900)

@@ -41,3 +41,33 @@ def test_closed_loop_tracks_on_the_oracle():
     bas = [r for r in tracked if "ba_iterations" in r]
     assert len(bas) >= 2 and all(r["ba_edges"] > 300 and sum(r["ba_iterations"]) >= 2 for r in bas)
     assert any(r["n_lm"] > 0 for r in tracked)               # the local-map search adds matches on top of the motion model's
+
+
+def test_closed_loop_windows_are_mostly_signature_runs():
+    """The run-major Schur kernel (cms_ba_schur_runs.hip) pays off when a window's points share key-frame sets.  The windows
+    Tracking / LocalMapping actually produce do: a map point is seen by a stretch of consecutive key frames, so the closed loop's own
+    LocalBundleAdjustment problems (Optimizer.cpp:192-363 builds them) fall into a handful of observation signatures.  Plan of every window
+    the oracle-driven loop hands to local BA: >= 60 % of the points lie in runs, nearly all chunks are run chunks."""
+    import collections
+    from cubemapslam_amd import api
+    camd = synth.camera("lafida", 350)
+    mask = synth.cubemap_valid_mask(camd)
+    frames, gts = harness.render_sequence(camd, 16)
+    be = OracleBackend(camd, mask)
+    probs, inner = [], be.local_ba
+    def capture(prob):
+        probs.append(prob)
+        return inner(prob)
+    be.local_ba = capture
+    trk, _ = harness.run_sequence(camd, be, frames, gts, kf_every=3, ba_window=6, new_points_per_kf=300)
+    assert trk.state == "ok" and len(probs) >= 4
+    for p in probs:
+        P = len(p["points"])
+        pl = api.ba_plan(p["fixed"], P, p["e_pose"], p["e_point"])
+        seen = collections.defaultdict(list)
+        for k, j in zip(p["e_pose"], p["e_point"]):
+            seen[int(j)].append(int(k))
+        signatures = collections.Counter(tuple(sorted(v)) for v in seen.values())
+        assert pl["usable"] and pl["rm_points"] >= 0.6 * P, (P, pl["rm_points"], len(signatures))
+        assert pl["n_rm"] >= 0.8 * pl["n_chunks"]
+        assert len(signatures) <= 8 * len(p["poses"])            # 5 / 10 / 18 / 34 signatures for 3 / 4 / 5 / 6 key frames
