@@ -20,6 +20,7 @@ struct BaKnobs {
   bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, rm_valu;
   int solve_reduce_max;
+  bool global_sum;
   int lookahead, compose_segments, dup, run_min_chunks, rm_weight;
   char stream_priority;
 };
@@ -41,6 +42,9 @@ static const BaKnobs& ba_knobs() {
     q.separate_reduce = on("CMS_BA_SEPARATE_REDUCE");    // kb_ba_schur_edges_reduce as its own launch instead of inside the solve kernel
     // ... which only pays while a window has few slices to sum (one workgroup reads them all): with more than this many the sum stays a launch
     { const char* v = getenv("CMS_BA_SOLVE_REDUCE_MAX"); q.solve_reduce_max = v ? atoi(v) : 24; }
+    // the Schur kernel's workgroups add their copies of the reduced system to ONE global copy (FP64 atomics) instead of writing a slice each that
+    // somebody has to sum: tools/probe/global_atomics.hip -- 256 workgroups x 6512 additions cost 10 us against 4 us for the stores
+    q.global_sum = !on("CMS_BA_NO_GLOBAL_SUM");
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
     q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", q.rm_valu ? 2 : 1));
     q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 100)));
@@ -1197,8 +1201,13 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
 // restore the initial estimate and clear the per-edge state: one launch (five copies / memsets cost more in dispatch than in work)
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_reset(int K, int P, int E, const double* __restrict__ poses0, const double* __restrict__ pts0, double* __restrict__ poses,
-           double* __restrict__ pts, uint8_t* __restrict__ level, double* __restrict__ err, uint8_t* __restrict__ flags) {
+           double* __restrict__ pts, uint8_t* __restrict__ level, double* __restrict__ err, uint8_t* __restrict__ flags,
+           double* __restrict__ gsum, int n_gsum, double* __restrict__ gsum_bp, int n_gsum_bp) {
   const int gs = gridDim.x * blockDim.x;
+  // the global copy of the reduced system the Schur kernel's workgroups add to (BaSe::gsum): zero before the first round; every round's
+  // solve kernel leaves it zero again
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_gsum; i += gs) gsum[i] = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_gsum_bp; i += gs) gsum_bp[i] = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * E; i += gs) {
     err[i] = 0.0;
     if (i < E) { level[i] = 0; flags[i] = 0; }
@@ -1214,7 +1223,8 @@ extern "C" int cms_ba_reset(cms_ba* b) {
   b->cur = 0;
   const int n = std::max(2 * b->E, std::max(3 * b->P, 7 * b->K));
   hipLaunchKernelGGL(k_ba_reset, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, b->stream, b->K, b->P, b->E, (const double*)b->d_poses0,
-                     (const double*)b->d_pts0, b->d_poses[0], b->d_pts[0], b->d_level, b->d_err, b->d_flags);
+                     (const double*)b->d_pts0, b->d_poses[0], b->d_pts[0], b->d_level, b->d_err, b->d_flags,
+                     b->d_se_partial, b->d_se_partial ? b->se.npairs2 * 42 : 0, b->d_se_bp_partial, b->d_se_bp_partial ? b->np * 6 : 0);
   HIPCHK(hipGetLastError());
   b->async_pending = true;
   return CMS_OK;       // asynchronous on the window's stream: every consumer (optimize, read) orders itself behind it

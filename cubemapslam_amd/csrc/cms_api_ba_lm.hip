@@ -225,7 +225,7 @@ static int ba_group_ranges(cms_ba** bas, int n) {
 // Which kernels a group's rounds are made of: decided ONCE per group from the windows' lists and the knobs (ba_upload_items and the stage
 // driver both use it).  fused: the Schur kernel linearises itself (edge-major kernels + three-lane solve); rm: windows with signature runs
 // send them through the run-major body (needs the fused path and full 512-thread workgroups)
-struct BaGroupMode { bool use_se, use_te, use_s3, fused, rm; int se_waves; };
+struct BaGroupMode { bool use_se, use_te, use_s3, fused, rm, gsum; int se_waves; };
 static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
   BaGroupMode m;
   m.use_se = ba_use_se(bas, n); m.use_te = ba_use_te(bas, n);
@@ -239,6 +239,9 @@ static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
   }
   m.fused = m.use_se && m.use_te && m.use_s3 && !ba_knobs().no_fused;
   m.rm = m.fused && rm_lds > 0 && m.se_waves == BA_SE_THREADS / 64 && !ba_knobs().runs_as_edges;
+  // one global copy of the reduced system per window, added to by all its workgroups (not with the A/B knobs that want the slices or launch a
+  // kernel of the round twice)
+  m.gsum = m.fused && ba_knobs().global_sum && !ba_knobs().separate_reduce && ba_knobs().dup == 0;
   return m;
 }
 static int ba_upload_items(cms_ba** bas, int n) {
@@ -273,6 +276,7 @@ static int ba_upload_items(cms_ba** bas, int n) {
       if (!gm.rm) it.se.n_rm = 0;
       ba_se_split(it.se, ba_group_ranges(bas, n));
     }
+    it.se.gsum = (use_se && gm.gsum) ? 1 : 0;
     b->grp_se = it.se;
   }
   HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
@@ -408,7 +412,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // linearisation inside the Schur kernel (cms_ba_schur_edges.hip, FUSED): needs the edge-major kernels and the three-lane solve
   const bool fused = gm.fused;
   // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
-  const bool solve_reduces = fused && !ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max;
+  const bool solve_reduces = fused && (gm.gsum || (!ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max));
   dyn.fused_lin = fused ? 1 : 0;
   int k = 0;
   const int pk = g->prof_kernel;

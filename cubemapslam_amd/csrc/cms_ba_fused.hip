@@ -308,12 +308,14 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
-                 double* __restrict__ xp_out, double* __restrict__ scal, bool lumped = false, const double* __restrict__ partial = nullptr,
-                 const double* __restrict__ bp_partial = nullptr, int n_slices = 0, int NP2 = 0) {
+                 double* __restrict__ xp_out, double* __restrict__ scal, bool lumped = false, double* partial = nullptr,
+                 double* bp_partial = nullptr, int n_slices = 0, int NP2 = 0, bool consume = false) {
   // lumped: the diagonal blocks of chunk_sum hold S - Hpp and s - bp already (fused linearisation, cms_ba_schur_edges.hip); bp is only
   // read for the gain ratio
   // partial != nullptr (implies lumped): the Schur kernel's range slices [n_slices][NP2][42] are summed here, in slice order, instead of by
   // kb_ba_schur_edges_reduce -- one launch less per round; bp (sum of the slices of bp_partial) is formed in LDS and stored for later readers
+  // consume (n_slices == 1): the Schur kernel's workgroups ADDED their copies to the one slice (BaSe::gsum); every element is read by exactly
+  // one thread here, which puts the zero back for the next round's additions
   extern __shared__ __align__(16) double sm[];
   const int nb = d.np, n = 6 * nb, nblk = nb * (nb + 1) / 2;
   // LDS (doubles): L panels [nb (nb - 1) / 2][38] | diagonal factors [nb][36] | W double buffer [2][nb][38] | diag staging [36] | y [n] | 1/D [n] | bp [n]
@@ -329,6 +331,7 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __re
       const int s1 = i / 6, c = i - 6 * s1;
       double v = 0.0;
       for (int r = 0; r < n_slices; ++r) v += bp_partial[((size_t)r * nb + s1) * 6 + c];
+      if (consume) bp_partial[i] = 0.0;
       bps[i] = v;
       const_cast<double*>(bp)[i] = v;
     }
@@ -363,10 +366,15 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __re
       // (the kernel is compiled for up to 1024 threads, 128 registers: four slices spilled)
 #pragma unroll 2
       for (int r = 0; r < n_slices; ++r) {
-        const double* cs = partial + ((size_t)r * NP2 + pr) * 42;
+        double* cs = partial + ((size_t)r * NP2 + pr) * 42;
 #pragma unroll
         for (int q = 0; q < 6; ++q) { a[q] -= cs[6 * q + r0]; a[6 + q] -= cs[6 * q + r0 + 1]; }
         if (I == K) { yb[0] += cs[36 + r0]; yb[1] += cs[36 + r0 + 1]; }
+        if (consume) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { cs[6 * q + r0] = 0.0; cs[6 * q + r0 + 1] = 0.0; }
+          if (I == K) { cs[36 + r0] = 0.0; cs[36 + r0 + 1] = 0.0; }
+        }
       }
     } else if (pr >= 0) {
       for (int c = pair_chunk_off[pr]; c < pair_chunk_off[pr + 1]; ++c) {

@@ -62,6 +62,8 @@ struct BaSe {                      // device view of the edge-major work list (c
   double* partial;                // R x npairs2 x 42
   double* bp_partial;             // R x np x 6: the ranges' sums of bp (fused linearisation: the diagonal blocks of `partial` then hold S - Hpp and s - bp)
   const int* lone; int nlone;     // points without any observation (in no chunk): the trial kernel copies their position
+  int gsum;                       // 1: the workgroups ADD their LDS copies to slice 0 of partial / bp_partial (global_atomic_add_f64) instead of writing a slice
+                                  // each; the solve kernel reads that one slice and puts the zeros back (kb_ba_trial_solve3r)
 };
 
 __device__ __forceinline__ int ba_se_pair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 - 1)) >> 1) + (s2 - s1); }   // s1 <= s2, dense (with diagonal)
@@ -344,14 +346,16 @@ __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const
     } else if (i < 36) {
       v = S[(size_t)ba_se_opair(np, s1, s2) * BA_SE_SSTRIDE + ba_se_off(i / 6, i % 6)];
     }
-    se.partial[((size_t)BX * NP2 + pr) * 42 + i] = v;
+    if (se.gsum) { if (v != 0.0) unsafeAtomicAdd(&se.partial[(size_t)pr * 42 + i], v); }
+    else se.partial[((size_t)BX * NP2 + pr) * 42 + i] = v;
   }
   if (FUSED) {
     for (int o = tid; o < 6 * np; o += blockDim.x) {
       const int s1 = o / 6, i = o - 6 * s1;
       double v = 0.0;
       for (int cp = 0; cp < BA_SE_DCOPIES; ++cp) v += Dg[((size_t)cp * np + s1) * BA_SE_DSTRIDE + 27 + i];
-      se.bp_partial[((size_t)BX * np + s1) * 6 + i] = v;
+      if (se.gsum) { if (v != 0.0) unsafeAtomicAdd(&se.bp_partial[(size_t)s1 * 6 + i], v); }
+      else se.bp_partial[((size_t)BX * np + s1) * 6 + i] = v;
     }
   }
 }
