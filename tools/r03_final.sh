@@ -3,6 +3,7 @@
 set -u
 R=$PWD; O=gpurun_out/final; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q > $O/t_gpu.log 2>&1; tail -5 $O/t_gpu.log
+timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 timeout 600 python bench.py > $O/bench_full.json 2> $O/bench_full.err; tail -c 600 $O/bench_full.json
 timeout 300 python tools/driver_call_times.py 40 > $O/r03_driver_call_times.txt 2>&1; tail -12 $O/r03_driver_call_times.txt
 timeout 1500 bash tools/run_profiles.sh r03 > $O/run_profiles.log 2>&1; tail -5 $O/run_profiles.log
