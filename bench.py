@@ -793,7 +793,7 @@ def main():
 
     # ---- one LocalBundleAdjustment call as the reference issues it (cms_ba_run: graph set-up + optimisation + read-back + destroy), chip quiet
     ba_call = None
-    if rank == 0 and world == 1 and n_ba > 0:
+    if rank == 0 and world == 1 and n_ba > 0 and args.closed_loop_frames > 0:      # (--closed-loop-frames 0, the profiling command: only the step's own launches in the trace)
         ts = []
         for _ in range(4):
             t1 = time.perf_counter()
