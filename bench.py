@@ -38,6 +38,7 @@ After the timed passes, outside any timed region: the local-BA results of a samp
 (rank 0) with `roofline` (dominant kernel of the step, HIP-event timing inside the timed region) and `cpu_baseline`.
 """
 import argparse
+import collections
 import json
 import os
 import socket
@@ -78,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--verify-windows", type=int, default=8, help="local-BA windows whose estimates are checked against the CPU oracle after the timed region (rank 0); "
                     "the iteration counts and outlier counts of ALL windows of that step are checked as well (0 = no check)")
     ap.add_argument("--ba-views", choices=("track", "random"), default="track", help="how the synthetic windows' observations are drawn (synth.ba_problem)")
-    ap.add_argument("--window-threads", type=int, default=0, help="host threads that build / read back / destroy local-BA windows (0 = min(32, cores / 4))")
+    ap.add_argument("--window-threads", type=int, default=0, help="host threads that build / read back / destroy local-BA windows (0 = min(32, cores / max(4, 2 x ranks)))")
     ap.add_argument("--optimise-only-steps", type=int, default=10, help="steps of the extra pass that keeps the windows and only resets them between steps "
                     "(round 2's headline, reported as config.optimise_only; 0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
@@ -312,7 +313,7 @@ def main():
     for p in all_probs:        # contiguous arrays of the C-ABI's types once, so that a window's creation is nothing but the cms_ba_create call
         p["poses"] = np.ascontiguousarray(p["poses"], np.float64); p["points"] = np.ascontiguousarray(p["points"], np.float64)
         p["e_obs"] = np.ascontiguousarray(p["e_obs"], np.float64)
-    n_wthreads = args.window_threads or max(4, min(32, (os.cpu_count() or 8) // 4))
+    n_wthreads = args.window_threads or max(4, min(32, (os.cpu_count() or 8) // max(4, 2 * world)))      # the ranks of a node share its cores
     wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
     group_stream = []           # one long-lived stream per window group (filled below): CreateNewMapPoints and the group's BA rounds
     def make_window(p, gi=-1):
@@ -415,11 +416,18 @@ def main():
     pool = ThreadPoolExecutor(max_workers=n_grp)       # one standing host thread per window group (LocalMapping-like)
     last = {"traj": None, "ba_stats": None, "tri_new": 0, "ba_out": None, "set": 0}
     acc = {"ba_ms": 0.0, "ba_n": 0, "create_ms": 0.0, "create_n": 0}
-    life = {"on": True, "pending": None, "pending_set": 0, "reads": []}
+    life = {"on": True, "queue": collections.deque(), "reads": []}
+    ahead = max(1, int(os.environ.get("CMS_BENCH_WINDOWS_AHEAD", "2")))      # sets of windows under construction in front of the running step
     def submit_windows(j):
         """the pool starts building the n_ba windows of problem set j; returned per group"""
-        life["pending_set"] = j
-        life["pending"] = [[wpool.submit(make_window, prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]
+        life["queue"].append((j, [[wpool.submit(make_window, prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]))
+
+    def next_windows():
+        """the oldest set of windows under construction (this step's), and one more set submitted in its place: `ahead` sets are always in the
+        pool's hands, so a host hiccup of a step's length does not reach the critical path"""
+        cur_set, cur = life["queue"].popleft()
+        submit_windows(life["queue"][-1][0] ^ 1 if life["queue"] else cur_set ^ 1)
+        return cur, cur_set
 
     # developer knob: queue the mapping side of a step behind the step's extraction (cms_stream_wait_extracted) instead of letting the two
     # overlap.  Measured: the extractor then runs at 35 % instead of 33 % of its byte roofline inside the step (43 % with no local BA in
@@ -430,8 +438,7 @@ def main():
         S = sets[i % 2]
         ths = []
         if ba_first and part != "frames" and life["on"]:
-            cur, cur_set = life["pending"], life["pending_set"]
-            submit_windows(cur_set ^ 1)
+            cur, cur_set = next_windows()
             ths = [pool.submit(ba_worker_life, cur[gi], gi, keep) for gi in range(n_grp)]
             last["set"] = cur_set
             if int(ba_first) > 0:
@@ -456,8 +463,7 @@ def main():
             if ths:
                 pass
             elif life["on"]:
-                cur, cur_set = life["pending"], life["pending_set"]
-                submit_windows(cur_set ^ 1)                # the next step's windows are built under this step
+                cur, cur_set = next_windows()             # the coming steps' windows are built under this one
                 ths = [pool.submit(ba_worker_life, cur[gi], gi, keep) for gi in range(n_grp)]
                 last["set"] = cur_set
             else:
@@ -496,11 +502,10 @@ def main():
         for f in life["reads"]:
             f.result()
         life["reads"] = []
-        if life["pending"] is not None:
-            for futs in life["pending"]:
+        while life["queue"]:
+            for futs in life["queue"].popleft()[1]:
                 for f in futs:
                     f.result()[0].close()
-            life["pending"] = None
 
     def timed(streaming, lifecycle=True, steps=None):
         steps = args.steps if steps is None else steps
@@ -508,7 +513,8 @@ def main():
         if streaming:
             ctx.upload_async(sets[0].pinned.array)
         if life["on"]:
-            submit_windows(0)
+            for a_ in range(ahead):
+                submit_windows(a_ & 1)
         for i in range(args.warmup):
             step(i, streaming)
         stage = {}
@@ -576,7 +582,8 @@ def main():
     cpu_ba_ms = []
     if args.verify_windows > 0:
         life["on"] = True
-        submit_windows(0)
+        for a_ in range(ahead):
+            submit_windows(a_ & 1)
         step(args.warmup + args.steps, False, keep=True)          # (all ranks: it holds the gather)
         drain()
     if rank == 0 and args.verify_windows > 0:
