@@ -352,6 +352,7 @@ def main():
             _, r = synth.pixel_to_ray(F, k["x"].astype(np.float64), k["y"].astype(np.float64))
             k["rays"] = r.astype(np.float32)
     tri_ctx, tri_store, tri_jobs = [], [], []
+    split_tri = os.environ.get("CMS_BENCH_SPLIT_TRI_STREAM", "") != ""; ba_streams = []
     for gi, grp in enumerate(groups):
         mprio = os.environ.get("CMS_BENCH_MAP_PRIORITY", "")       # developer knob: the same for the mapping side's queues (one per window group)
         if mprio:
@@ -368,7 +369,11 @@ def main():
                 K, keep = api.make_keyframe(k)
                 st.put(base + i, K)
             jobs_g.append((base, list(range(base + 1, base + tri_nn + 1))))
-        tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g); group_stream.append(cg.stream)
+        tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g)
+        if split_tri:          # developer knob: the group's BA rounds on a stream of their own, CreateNewMapPoints alone on the context's
+            bs = torch.cuda.Stream(device=dev); ba_streams.append(bs); group_stream.append(bs.cuda_stream)
+        else:
+            group_stream.append(cg.stream)
         if os.environ.get("CMS_BENCH_SHARED_STREAMS", "") != "":
             for ba in grp:                   # developer knob: the whole mapping side of a group on ONE stream (cms_ba_set_stream).  Measured
                 ba.set_stream(cg.stream)     # slower (15.9 against 14.4 ms per step): the resets and CreateNewMapPoints then queue behind the group's BA
