@@ -39,7 +39,10 @@ __device__ __forceinline__ void pose_exp_mul(const double* u, const double* T, d
   if (theta < 0.00001) {
     for (int i = 0; i < 9; ++i) { R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
   } else {
-    const double sa = sin(theta) / theta, sb = (1 - cos(theta)) / (theta * theta), scc = (theta - sin(theta)) / (theta * theta * theta);
+    double sn, cs;
+    sincos(theta, &sn, &cs);            // one argument reduction for both (this runs in one lane, in the serial part of every trial)
+    const double it = 1.0 / theta, it2 = it * it;
+    const double sa = sn * it, sb = (1 - cs) * it2, scc = (theta - sn) * (it2 * it);
     for (int i = 0; i < 9; ++i) {
       const double Id = ((i & 3) == 0 ? 1.0 : 0.0);
       R[i] = Id + sa * Om[i] + sb * Om2[i];
@@ -64,7 +67,7 @@ __device__ __forceinline__ void pose_exp_mul(const double* u, const double* T, d
 
 // dense LDL^T of the 6x6 system (LinearSolverDense); false on a zero / non-finite pivot (-> the trial is rejected)
 __device__ __forceinline__ bool pose_solve6(const double* H, const double* b, double lambda, double* x) {
-  double A[36], D[6];
+  double A[36], D[6], RD[6];
 #pragma unroll
   for (int i = 0; i < 36; ++i) A[i] = H[i];
 #pragma unroll
@@ -77,12 +80,14 @@ __device__ __forceinline__ bool pose_solve6(const double* H, const double* b, do
     for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k] * D[k];
     if (!isfinite(d) || d == 0.0) ok = false;
     D[j] = d;
+    const double rd = 1.0 / d;             // one division per pivot; the column is scaled by the reciprocal (<= 1 ulp from the quotient)
+    RD[j] = rd;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double s = A[6 * i + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= A[6 * i + k] * A[6 * j + k] * D[k];
-      A[6 * i + j] = s / d;
+      A[6 * i + j] = s * rd;
     }
   }
 #pragma unroll
@@ -92,7 +97,7 @@ __device__ __forceinline__ bool pose_solve6(const double* H, const double* b, do
 #pragma unroll
     for (int k = 0; k < i; ++k) x[i] -= A[6 * i + k] * x[k];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] /= D[i];
+  for (int i = 0; i < 6; ++i) x[i] *= RD[i];
 #pragma unroll
   for (int i = 5; i >= 0; --i)
 #pragma unroll
@@ -239,7 +244,7 @@ extern "C" __global__ void __launch_bounds__(256) k_pose_optimize_g(PoseDev P) {
             double tempChi = ok2 ? tempChi0 : 1.7976931348623157e308;
             rho = (currentChi - tempChi) / (scale + 1e-3);
             if (rho > 0 && isfinite(tempChi)) {
-              double alpha = 1. - pow((2 * rho - 1), 3.0);
+              const double t21 = 2 * rho - 1; double alpha = 1. - t21 * t21 * t21;     // pow(2 rho - 1, 3): the cube, two roundings instead of a ~200-instruction pow in the serial part
               alpha = fmin(alpha, 2. / 3.);
               lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
               for (int i = 0; i < 7; ++i) s_pose[i] = s_trial[i];
@@ -437,7 +442,7 @@ extern "C" __global__ void __launch_bounds__(256) k_pose_optimize(PoseDev P) {
             double tempChi = ok2 ? tempChi0 : 1.7976931348623157e308;
             rho = (currentChi - tempChi) / (scale + 1e-3);
             if (rho > 0 && isfinite(tempChi)) {
-              double alpha = 1. - pow((2 * rho - 1), 3.0);
+              const double t21 = 2 * rho - 1; double alpha = 1. - t21 * t21 * t21;     // pow(2 rho - 1, 3): the cube, two roundings instead of a ~200-instruction pow in the serial part
               alpha = fmin(alpha, 2. / 3.);
               lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
               for (int i = 0; i < 7; ++i) s_pose[i] = s_trial[i];
