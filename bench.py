@@ -39,6 +39,7 @@ After the timed passes, outside any timed region: the local-BA results of a samp
 """
 import argparse
 import collections
+import gc
 import json
 import os
 import socket
@@ -327,7 +328,9 @@ def main():
         out = ba.read()             # poses, points, outlier flags -> host arrays (Optimizer.cpp:419-450)
         ba.close()                  # cms_ba_destroy
         return out
-    for ba, _ in [f.result() for f in [wpool.submit(make_window, p) for p in probs]]:      # warm the per-device pools (streams, slabs, pinned blocks)
+    # warm the per-device pools (streams, slabs, pinned blocks) to the steady state's high-water mark: the running step's windows, the two sets under
+    # construction and the set being read back are alive at once -- growing a pool inside a timed step costs a device allocation (a 20-25 ms step)
+    for ba, _ in [f.result() for f in [wpool.submit(make_window, p) for _ in range(4) for p in probs]]:
         ba.close()
     t_setup = time.perf_counter()
     bas = [api.BundleAdjuster(p, device=local_rank) for p in probs]
@@ -512,6 +515,7 @@ def main():
                 for f in futs:
                     f.result()[0].close()
 
+    step_times = [] if os.environ.get("CMS_BENCH_STEP_TIMES", "") != "" else None      # developer knob: host wall time of every timed step (stderr)
     def timed(streaming, lifecycle=True, steps=None):
         steps = args.steps if steps is None else steps
         life["on"] = lifecycle and part != "frames"
@@ -533,9 +537,16 @@ def main():
         # The timed region holds, per step, the creation of one set of windows (the NEXT step's, by the pool), the optimisation of one set, and the
         # read-back + destruction of one set (the PREVIOUS step's finish under this one); the region ends only when the last step's read-backs are
         # through.  The windows the last step built for a step that never runs are destroyed after the clock stops (they were built inside it).
+        # Python's cyclic garbage collector is held off for the timed steps (and run right before them): a generation-2 pass over this
+        # process's ~10^6 objects took 45-70 ms in the middle of a 50-step run (one step of 84 ms among steps of 13-14: CMS_BENCH_STEP_TIMES=1);
+        # reference counting still frees everything the steps allocate.  Bench plumbing, not product: the library is C++.
+        gc.collect(); gc.disable()
         t0 = time.perf_counter()
+        t_prev = t0
         for i in range(steps):
             step(args.warmup + i, streaming)
+            if step_times is not None:
+                t_now = time.perf_counter(); step_times.append(round(1e3 * (t_now - t_prev), 2)); t_prev = t_now
             for k, v in (ctx.profile_ms().items() if part != "ba" else ()):
                 stage[k] = stage.get(k, 0.0) + v
         for f in life["reads"]:
@@ -543,6 +554,7 @@ def main():
         life["reads"] = []
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         drain()
         if streaming:
             ctx.upload_wait()
@@ -557,6 +569,8 @@ def main():
 
     ctx.profile(True)
     dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
+    if step_times is not None:
+        print("step times (ms):", step_times, file=sys.stderr); step_times.clear()
     create_ms_in_step = acc["create_ms"] / max(acc["create_n"], 1)
     worker_break = {k_: round(v_ / max(worker_ms.get("n", 1), 1), 3) for k_, v_ in worker_ms.items() if k_ != "n"}      # per window group and step
     if part:
