@@ -389,7 +389,9 @@ extern "C" int cms_ctx_geometry(const cms_ctx* c, cms_geometry* o) {
 
 extern "C" void* cms_frames_input(cms_ctx* c) { return c ? (void*)c->d_fish : nullptr; }
 
-extern "C" int cms_frames_upload(cms_ctx* c, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B) {
+// wait = false (cms_remap_extract): the copy reads the library's own pinned staging block, the caller's buffer is free once the rows have been
+// repacked; the entry synchronises the stream before it returns anyway
+static int cms_frames_upload_impl(cms_ctx* c, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B, bool wait) {
   if (!c || !fisheye || B < 1 || B > c->max_batch || fstride < c->cam.Iw) return cms_fail(CMS_ERR_ARG, "cms_frames_upload: bad argument");
   HIPCHK(hipSetDevice(c->device));
   // A pitched 2D copy from pageable memory goes row by row through the runtime (3.5 ms for one 754 x 480 frame); the rows are
@@ -410,8 +412,11 @@ extern "C" int cms_frames_upload(cms_ctx* c, const uint8_t* fisheye, int fstride
       HIPCHK(hipMemcpy2DAsync(c->d_fish + (size_t)b * c->fish_pitch, c->fstride, fisheye + (size_t)b * frame_pitch, fstride,
                               c->cam.Iw, c->cam.Ih, hipMemcpyHostToDevice, c->stream));
   }
-  HIPCHK(hipStreamSynchronize(c->stream));   // the caller may free / reuse its host buffer as soon as we return
+  if (wait || !c->h_fish_stage) HIPCHK(hipStreamSynchronize(c->stream));   // the caller may free / reuse its host buffer as soon as we return
   return CMS_OK;
+}
+extern "C" int cms_frames_upload(cms_ctx* c, const uint8_t* fisheye, int fstride, size_t frame_pitch, int B) {
+  return cms_frames_upload_impl(c, fisheye, fstride, frame_pitch, B, true);
 }
 
 // Input streaming.  The fisheye staging buffer is read by exactly one kernel of a batch, k_remap (the first one), so one buffer is
@@ -625,15 +630,37 @@ extern "C" int cms_extract(cms_ctx* c, const uint8_t* cubemap, int cstride, cms_
   if (rc) return rc;
   return cms_frames_fetch(c, 0, kps, desc, cap, n);
 }
+static int cms_hstage(cms_ctx* c, size_t bytes);
+// One frame, host buffers in and out: ONE synchronisation.  The image leaves from the pinned upload staging without a wait, the kernels follow,
+// and overflow flag | key-point count | key points | descriptors come back as four asynchronous copies into the pinned result staging behind
+// them (the upload, cms_frames_sync and cms_frames_fetch one after the other were five synchronous round trips of 15-20 us each).
 extern "C" int cms_remap_extract(cms_ctx* c, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n) {
-  if (!c || !fisheye || !n) return cms_fail(CMS_ERR_ARG, "cms_remap_extract: bad argument");
-  int rc = cms_frames_upload(c, fisheye, fstride, 0, 1);
+  if (!c || !fisheye || !n || cap < 0) return cms_fail(CMS_ERR_ARG, "cms_remap_extract: bad argument");
+  int rc = cms_frames_upload_impl(c, fisheye, fstride, 0, 1, false);
   if (rc) return rc;
   rc = cms_launch_frames(c, 1, 1);
   if (rc) return rc;
-  rc = cms_frames_sync(c);
+  const int m = std::min(cap, c->g.kp_cap);
+  const size_t o_kp = 256, o_desc = o_kp + (((size_t)m * sizeof(cms_keypoint) + 255) & ~(size_t)255), total = o_desc + (size_t)m * 32;
+  rc = cms_hstage(c, total);
   if (rc) return rc;
-  return cms_frames_fetch(c, 0, kps, desc, cap, n);
+  uint8_t* h = c->h_stage;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(h, c->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h + 64, c->d_kp_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (m > 0 && kps) HIPCHK(hipMemcpyAsync(h + o_kp, c->d_kps, (size_t)m * sizeof(cms_keypoint), hipMemcpyDeviceToHost, s));
+  if (m > 0 && desc) HIPCHK(hipMemcpyAsync(h + o_desc, c->d_desc, (size_t)m * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  int ov = 0, cnt = 0;
+  memcpy(&ov, h, sizeof(int)); memcpy(&cnt, h + 64, sizeof(int));
+  if (ov) return cms_fail(CMS_ERR_OVERFLOW, "candidate list overflow");
+  *n = cnt;
+  if (cnt > cap) return cms_fail(CMS_ERR_OVERFLOW, "cms_frames_fetch: caller capacity too small");
+  if (cnt > 0) {
+    if (kps) memcpy(kps, h + o_kp, (size_t)cnt * sizeof(cms_keypoint));
+    if (desc) memcpy(desc, h + o_desc, (size_t)cnt * 32);
+  }
+  return CMS_OK;
 }
 
 // ---- debug read-back
