@@ -14,7 +14,7 @@ frames, gts = harness.render_sequence(camd, n)
 d = tempfile.mkdtemp()
 harness.export_sequence(d, camd, frames, gts, mask)
 os.environ["CMS_DRIVER_CALL_TIMES"] = "1"
-rc, recs, out = harness.run_driver(d, kf_every=5, ba_window=8, new_points_per_kf=400, warmup=6)
+rc, recs, out = harness.run_driver(d, kf_every=5, ba_window=8, new_points_per_kf=400, warmup=n)      # a throw-away tracker goes through the images once first
 print("exit code %d, %d frames (Lafida cam0 geometry, face 550; key frame every 5 frames, local BA over 8 key frames)" % (rc, len(recs)))
 print(out)
 ms = {}
