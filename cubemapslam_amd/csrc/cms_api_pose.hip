@@ -109,7 +109,8 @@ extern "C" int cms_pose_launch(cms_pose* p) {
   d.nf = p->nf; d.off = p->d_off; d.Xw = p->d_Xw; d.obs = p->d_obs; d.inv = p->d_inv; d.face = p->d_face; d.outlier = p->d_out;
   d.err = p->d_err; d.poses = p->d_poses; d.result = p->d_res; d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy;
   // edges of a frame in registers when they fit (256 threads x PO_MAXJ edges), otherwise the variant that walks them in memory
-  if (p->max_n <= 256 * PO_MAXJ && !getenv("CMS_POSE_GLOBAL")) hipLaunchKernelGGL(k_pose_optimize, dim3(p->nf), dim3(256), 0, s, d);
+  static const bool force_global = getenv("CMS_POSE_GLOBAL") != nullptr;      // developer knob, read once per process
+  if (p->max_n <= 256 * PO_MAXJ && !force_global) hipLaunchKernelGGL(k_pose_optimize, dim3(p->nf), dim3(256), 0, s, d);
   else hipLaunchKernelGGL(k_pose_optimize_g, dim3(p->nf), dim3(256), 0, s, d);
   HIPCHK(hipGetLastError());
   return CMS_OK;
