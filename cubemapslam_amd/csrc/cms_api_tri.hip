@@ -128,8 +128,8 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
   for (int l = 0; l < 16; ++l) { a.sf[l] = l < c->g.nlevels ? c->scale[l] : 1.0f; a.sigma2[l] = l < c->g.nlevels ? c->sigma2[l] : 1.0f; }
   a.cap = cap;
   a.n_new = (int*)(p + o_nnew); a.out_neigh = (int*)(p + o_on); a.out_idx1 = (int*)(p + o_o1); a.out_idx2 = (int*)(p + o_o2); a.out_x3d = (float*)(p + o_ox);
-  static const bool force_sequential = getenv("CMS_TRI_SEQUENTIAL") != nullptr;      // developer knob, read once per process
-  if (check_orientation || max_pairs > 64 || nneigh == 0 || force_sequential) {
+  // (CMS_TRI_SEQUENTIAL is read per call on purpose: test_create_new_map_points toggles it inside one process to hold the two kernels to identical records)
+  if (check_orientation || max_pairs > 64 || nneigh == 0 || getenv("CMS_TRI_SEQUENTIAL")) {
     hipLaunchKernelGGL(k_create_new_map_points, dim3(njobs), dim3(512), 0, s, a);      // neighbour after neighbour (the rotation histogram of a
   } else {                                                                            // neighbour depends on which features are still free)
     hipLaunchKernelGGL(k_tri_candidates, dim3((max_n1 + 255) / 256, nneigh), dim3(256), 0, s, a, (const int*)(p + o_pjob), (CmsTriCand*)(p + o_cand), max_n1);
