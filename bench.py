@@ -287,7 +287,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     # The frame path's queue runs at LOW dispatch priority (CMS_FRAME_STREAM_PRIORITY, read by cms_ctx_create): its kernels are few and
     # chip-filling, the mapping side's are a long chain of short dependent launches -- when both have workgroups ready the chain goes first.
-    # Measured 13.9-14.1 against 14.6-15.5 ms per step (tools/r03_run14.sh; "high" does the same: what counts is that the queue classes
+    # Measured 13.9-14.1 against 14.6-15.5 ms per step (tools/experiments_r03/r03_run14.sh; "high" does the same: what counts is that the queue classes
     # differ).  CMS_BENCH_FRAME_PRIORITY=normal|high|low overrides; the mapping side's contexts keep the default.
     fprio = os.environ.get("CMS_BENCH_FRAME_PRIORITY", "low")
     fprio = "" if fprio == "normal" else fprio
