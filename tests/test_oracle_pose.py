@@ -53,3 +53,17 @@ def test_pose_early_exits():
     n_in, pose, out, st = orc.pose_optimize(pr, n=8)
     assert st.rounds == 1 and st.iterations_done[0] >= 1 and st.iterations_done[1] == 0
     assert n_in == 8 - out.sum()
+
+
+def test_pose_optimisation_against_a_numpy_restatement():
+    """oracle/orc_ba.cpp's PoseOptimization against tests/npref_pose.py, the same procedure written from the reference's text with numpy's dense
+    solver: inlier counts, outlier flags and the iteration counts of the four rounds identical, poses equal to 1e-9 (one 6x6 system: the two
+    programs differ in the order of a few hundred additions)."""
+    import npref_pose
+    for seed, N in ((2, 300), (5, 120), (9, 40), (14, 600), (23, 8)):
+        pr = synth.pose_problem(N=N, seed=seed, outlier_frac=0.12)
+        n_w, pose_w, out_w, its_w = npref_pose.pose_optimize(pr)
+        n_g, pose_g, out_g, st = orc.pose_optimize(pr)
+        assert n_g == n_w and np.array_equal(out_g, out_w), (seed, n_g, n_w, int((out_g != out_w).sum()))
+        assert [st.iterations_done[i] for i in range(st.rounds)] == its_w, (seed, [st.iterations_done[i] for i in range(4)], its_w)
+        assert np.abs(pose_g - pose_w).max() <= 1e-9, (seed, np.abs(pose_g - pose_w).max())
