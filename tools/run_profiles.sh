@@ -37,6 +37,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_ba8 -- py
 rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv
 # probes and stamps behind DESIGN.md's statements: LDS atomic rates, per-phase cycles of the run-major MFMA body, the Python-free driver
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/probe/lds_atomics.hip -o /tmp/lds_atomics 2>/dev/null && /tmp/lds_atomics > $OUT/${TAG}_probe_lds_atomics.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics $R/tools/probe/global_atomics.hip -o /tmp/global_atomics 2>/dev/null && /tmp/global_atomics > $OUT/${TAG}_probe_global_atomics.txt 2>&1
 [ -f $R/cubemapslam_amd/lib/ab_rmclk.so ] && CMS_HIP_LIB=$R/cubemapslam_amd/lib/ab_rmclk.so python $R/tools/prof_rm_clk.py 16 > $OUT/${TAG}_rm_phase_cycles.txt 2>&1
 python $R/tools/prof_ba_many.py 16 track diff > $OUT/${TAG}_ba16_track.txt 2>&1
 CMS_BA_RM_VALU=1 CMS_BA_RM_WEIGHT=60 python $R/tools/prof_ba_many.py 16 track diff > $OUT/${TAG}_ba16_track_valu.txt 2>&1

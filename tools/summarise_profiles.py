@@ -36,7 +36,7 @@ for extra, cmd in (("mapping", "python tools/prof_tri.py 8 20 5"), ("ba8", "pyth
                 f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
                                   "%.2f" % float(r["Percentage"]), r["MinNs"], r["MaxNs"]]) + "\n")
 import shutil
-for name in ("step_table.md", "probe_lds_atomics.txt", "rm_phase_cycles.txt", "ba16_track.txt", "ba16_track_valu.txt", "ba16_track_edges_only.txt", "ba16_random.txt", "ba1_track.txt"):
+for name in ("step_table.md", "probe_lds_atomics.txt", "probe_global_atomics.txt", "rm_phase_cycles.txt", "ba16_track.txt", "ba16_track_valu.txt", "ba16_track_edges_only.txt", "ba16_random.txt", "ba1_track.txt"):
     sp = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(sp):
         txt = [l for l in open(sp) if not l.startswith(("W2", "E2", "I2", "/opt/amdgpu"))]
