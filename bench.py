@@ -236,6 +236,11 @@ class TrackSet:
 
 
 def main():
+    # developer knob: every hipStreamSynchronize / hipEventSynchronize of this process blocks instead of spinning (hipDeviceScheduleBlockingSync);
+    # must be set before the first HIP call of the process
+    if os.environ.get("CMS_BENCH_BLOCKING_SYNC", "") != "":
+        import ctypes
+        ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(0x4))
     args = parse_args()
     maybe_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -317,16 +322,20 @@ def main():
     n_wthreads = args.window_threads or max(4, min(32, (os.cpu_count() or 8) // max(4, 2 * world)))      # the ranks of a node share its cores
     wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
     group_stream = []           # one long-lived stream per window group (filled below): CreateNewMapPoints and the group's BA rounds
+    cpu_acc = {"create": 0.0, "finish": 0.0, "n": 0}      # thread CPU seconds (developer knob CMS_BENCH_THREAD_CPU)
     def make_window(p, gi=-1):
-        t1 = time.perf_counter()
+        t1 = time.perf_counter(); c1 = time.thread_time()
         ba = api.BundleAdjuster(p, device=local_rank)      # uploads on a stream from the library's pool ...
         if gi >= 0 and not own_streams:
             ba.set_stream(group_stream[gi])                # ... and runs on its group's stream.  (Every window on a stream of its own meant ~100
+        cpu_acc["create"] += time.thread_time() - c1; cpu_acc["n"] += 1
         return ba, 1e3 * (time.perf_counter() - t1)        # streams on 8 hardware queues: the two groups' chains and CreateNewMapPoints queued behind each other)
     own_streams = os.environ.get("CMS_BENCH_WINDOW_STREAMS", "") != ""      # developer knob: the old behaviour
     def finish_window(ba):
+        c1 = time.thread_time()
         out = ba.read()             # poses, points, outlier flags -> host arrays (Optimizer.cpp:419-450)
         ba.close()                  # cms_ba_destroy
+        cpu_acc["finish"] += time.thread_time() - c1
         return out
     # warm the per-device pools (streams, slabs, pinned blocks) to the steady state's high-water mark: the running step's windows, the two sets under
     # construction and the set being read back are alive at once -- growing a pool inside a timed step costs a device allocation (a 20-25 ms step)
@@ -430,11 +439,18 @@ def main():
         """the pool starts building the n_ba windows of problem set j; returned per group"""
         life["queue"].append((j, [[wpool.submit(make_window, prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]))
 
+    # developer knob: hand the next set of windows to the pool only after the step's frame path has been waited for (the pool's uploads and
+    # gather / reset kernels then stay off the extraction kernels -- and land on the Levenberg rounds instead: 14.8-15.4 against 14.4-14.7 ms)
+    late_submit = os.environ.get("CMS_BENCH_LATE_SUBMIT", "") != ""
     def next_windows():
         """the oldest set of windows under construction (this step's), and one more set submitted in its place: `ahead` sets are always in the
         pool's hands, so a host hiccup of a step's length does not reach the critical path"""
         cur_set, cur = life["queue"].popleft()
-        submit_windows(life["queue"][-1][0] ^ 1 if life["queue"] else cur_set ^ 1)
+        nxt_set = life["queue"][-1][0] ^ 1 if life["queue"] else cur_set ^ 1
+        if late_submit:
+            life["deferred"] = nxt_set          # ... submitted once this step's frame path is through (see step)
+        else:
+            submit_windows(nxt_set)
         return cur, cur_set
 
     # developer knob: queue the mapping side of a step behind the step's extraction (cms_stream_wait_extracted) instead of letting the two
@@ -480,6 +496,8 @@ def main():
             S.enqueue_tracking(ext_stream)
             ctx.sync()
             _, frame_poses, _, _ = po.fetch()
+        if life.get("deferred") is not None:
+            submit_windows(life.pop("deferred"))
         res = [th.result() for th in ths]     # raises what a worker raised
         if res:
             acc["ba_ms"] += sum(r[0] for r in res) / len(res); acc["ba_n"] += 1
@@ -567,8 +585,31 @@ def main():
         schur = [(schur_acc["ms"], schur_acc["n"])] if life["on"] else [grp[0].profile_get() for grp in groups]
         return dt, stage, acc["ba_ms"] / max(acc["ba_n"], 1), schur
 
+    def thread_cpu():
+        """CPU seconds (user + system) of every thread of this process by name: /proc/self/task/*/stat (developer knob CMS_BENCH_THREAD_CPU)"""
+        out = {}
+        tck = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open("/proc/self/task/%s/stat" % tid) as f:
+                    st = f.read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                fld = st[st.rindex(")") + 2:].split()
+                out[(tid, name)] = (int(fld[11]) + int(fld[12])) / tck
+            except (OSError, ValueError):
+                pass
+        return out
+    cpu0 = thread_cpu() if os.environ.get("CMS_BENCH_THREAD_CPU", "") != "" else None
     ctx.profile(True)
     dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
+    if cpu0 is not None:
+        cpu1 = thread_cpu()
+        use = sorted(((cpu1[k] - cpu0.get(k, 0.0), k) for k in cpu1), reverse=True)
+        tot = sum(u for u, _ in use)
+        print("window threads: cms_ba_create %.2f ms CPU per window, read + destroy %.2f ms CPU per window (%d windows since start)" % (
+            1e3 * cpu_acc["create"] / max(cpu_acc["n"], 1), 1e3 * cpu_acc["finish"] / max(cpu_acc["n"], 1), cpu_acc["n"]), file=sys.stderr)
+        print("thread CPU over the timed pass: %.2f s in %.2f s of wall = %.1f cores; top: %s" % (
+            tot, dt, tot / dt, ", ".join("%s/%s %.0f%%" % (k[1], k[0], 100 * u / dt) for u, k in use[:48])), file=sys.stderr)
     if step_times is not None:
         print("step times (ms):", step_times, file=sys.stderr); step_times.clear()
     create_ms_in_step = acc["create_ms"] / max(acc["create_n"], 1)

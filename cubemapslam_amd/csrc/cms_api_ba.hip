@@ -19,7 +19,7 @@
 struct BaKnobs {
   bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, rm_valu;
-  int solve_reduce_max;
+  int solve_reduce_max, leftover_lookahead;
   bool global_sum;
   int lookahead, compose_segments, dup, run_min_chunks, rm_weight;
   char stream_priority;
@@ -45,6 +45,7 @@ static const BaKnobs& ba_knobs() {
     // the Schur kernel's workgroups add their copies of the reduced system to ONE global copy (FP64 atomics) instead of writing a slice each that
     // somebody has to sum: tools/probe/global_atomics.hip -- 256 workgroups x 6512 additions cost 10 us against 4 us for the stores
     q.global_sum = !on("CMS_BA_NO_GLOBAL_SUM");
+    q.leftover_lookahead = num("CMS_BA_LEFTOVER_LOOKAHEAD", 0);      // 0: automatic (see ba_plan)
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
     q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", q.rm_valu ? 2 : 1));
     q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 100)));
@@ -67,6 +68,7 @@ struct cms_ba {
   // device memory
   uint8_t* d_fixed = nullptr; int* d_pose_slot = nullptr; int* d_e_pose = nullptr; int* d_e_point = nullptr;
   double* d_e_obs = nullptr; double* d_e_inv = nullptr; int8_t* d_e_face = nullptr; int* d_pt_off = nullptr;
+  double* d_raw_obs = nullptr; double* d_raw_inv = nullptr; double* d_raw_pts = nullptr; int* d_perm = nullptr; int* d_pinv = nullptr;   // the caller's arrays and orders (k_ba_gather)
   int* d_pose_off = nullptr; int* d_pose_edges = nullptr; uint8_t* d_level = nullptr; double* d_err = nullptr; double* d_ow = nullptr;
   double* d_poses[2] = {nullptr, nullptr}; double* d_pts[2] = {nullptr, nullptr};
   double* d_poses0 = nullptr; double* d_pts0 = nullptr;
@@ -626,8 +628,35 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   if (rm_ok) {
     BA_TLV(int, gid); gid.assign(P, -1);
     std::vector<int> gcount, gfirst;
-    std::unordered_map<uint64_t, std::vector<int>> table;     // signature hash -> groups with that hash
-    table.reserve((size_t)std::min(P, 1 << 16));
+    std::unordered_map<uint64_t, std::vector<int>> table;     // signature hash -> groups with that hash (windows of more than 64 key frames)
+    if (K <= 64) {
+      // the signature IS a 64-bit set of key frames (a point is seen at most once by a key frame, checked below): open addressing on the set
+      // itself, no chains, no allocation (a node-based map with a vector per signature was 0.4 of this phase's 0.67 ms)
+      int cap = 1024;
+      while (cap < 4 * 1024 && cap < 2 * P) cap <<= 1;            // signatures are few (hundreds); the table only has to stay sparse
+      BA_TLV(uint64_t, hkey); BA_TLV(int, hval);
+      auto rehash = [&](int ncap) {
+        std::vector<uint64_t> ok(hkey.begin(), hkey.end()); std::vector<int> ov(hval.begin(), hval.end());
+        hkey.assign(ncap, 0); hval.assign(ncap, -1);
+        for (size_t i = 0; i < ok.size(); ++i)
+          if (ov[i] >= 0) { size_t j = (size_t)((ok[i] * 0x9E3779B97F4A7C15ull) >> 40) & (ncap - 1); while (hval[j] >= 0) j = (j + 1) & (ncap - 1); hkey[j] = ok[i]; hval[j] = ov[i]; }
+        cap = ncap;
+      };
+      hkey.assign(cap, 0); hval.assign(cap, -1);
+      for (int p = 0; p < P; ++p) {
+        uint64_t key = 0;
+        for (int i = cpo[p]; i < cpo[p + 1]; ++i) key |= 1ull << e_pose[cpe[i]];
+        if (__builtin_popcountll(key) != cpo[p + 1] - cpo[p]) key = ~0ull - (uint64_t)p;      // seen twice by a key frame: a group of its own (never a run)
+        size_t j = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (cap - 1);
+        while (hval[j] >= 0 && hkey[j] != key) j = (j + 1) & (cap - 1);
+        int g = hval[j];
+        if (g < 0) {
+          g = (int)gfirst.size(); gfirst.push_back(p); gcount.push_back(0); hkey[j] = key; hval[j] = g;
+          if (2 * (int)gfirst.size() > cap) rehash(2 * cap);
+        }
+        gid[p] = g; ++gcount[g];
+      }
+    } else
     for (int p = 0; p < P; ++p) {
       const int k = cpo[p + 1] - cpo[p];
       uint64_t h = 1469598103934665603ull ^ (uint64_t)k;
@@ -698,8 +727,13 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
     else {
       ep.reserve(E); ept.reserve(E);
       for (int e = 0; e < E; ++e) if (loc[e_point[e]] >= 0) { ep.push_back(e_pose[e]); ept.push_back(loc[e_point[e]]); }
-      // (the left-over points are the ones with rare signatures: a third of the look-ahead finds them partners almost as well, in a third of the time)
-      ba_compose_chunks(K, fixed, PL, (int)ep.size(), ep.data(), ept.data(), kn.no_permute ? 1 : std::max(2, kn.lookahead / 3), prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
+      // (the left-over points are the ones with rare signatures: a third of the look-ahead finds them partners almost as well, in a third of the time;
+      // a sixth when they are a minority of the window -- the usual case once there are runs: 19 % of a tracked configs[3] window, most of them
+      // with eight or more observations, the expensive ones to place.  Measured on 16 windows per launch: look-ahead 8 / 4 / 2 / none = 108.0 /
+      // 104.9 / 114.4 / 116.6 us for the Schur kernel, and the composition is the largest single item of cms_ba_create's ~5 ms of CPU time -- a host
+      // that builds 32 windows per 14 ms step inside a 16-CPU quota runs out of CPU first.  CMS_BA_LEFTOVER_LOOKAHEAD=n forces a look-ahead.)
+      const int la_left = kn.no_permute ? 1 : kn.leftover_lookahead > 0 ? kn.leftover_lookahead : std::max(2, kn.lookahead / (3 * PL <= P ? 6 : 3));
+      ba_compose_chunks(K, fixed, PL, (int)ep.size(), ep.data(), ept.data(), la_left, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
     }
   } else {
     chunk_pt0L.assign(1, 0);
@@ -717,8 +751,8 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   tick("chunks");
   // ---- edges sorted by (internal point, key frame): CSR by point; per-pose edge lists reference sorted positions
   b->perm.resize(E);
-  s_pose.assign(E, 0); s_point.assign(E, 0); pt_off.assign(P + 1, 0); pose_off.assign(K + 1, 0); pose_edges.assign(E, 0);
-  s_obs.assign(e_obs ? 2 * (size_t)E : 0, 0.0); s_inv.assign(e_invsig2 ? E : 0, 0.0); s_face.assign(E, 0);
+  s_pose.resize(E); s_point.resize(E); pt_off.resize(P + 1); pose_off.assign(K + 1, 0); pose_edges.resize(E);      // (all written in full below)
+  s_face.resize(E);
   {
     int i = 0;
     for (int p = 0; p < P; ++p) {
@@ -728,9 +762,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
         const int e = cpe[t];
         b->perm[i] = e;
         s_pose[i] = e_pose[e]; s_point[i] = p; s_face[i] = e_face ? e_face[e] : 0;
-        if (e_obs) { s_obs[2 * i] = e_obs[2 * e]; s_obs[2 * i + 1] = e_obs[2 * e + 1]; }
-        if (e_invsig2) s_inv[i] = e_invsig2[e];
-        ++pose_off[s_pose[i] + 1];
+        ++pose_off[s_pose[i] + 1];      // (measurements, informations and point positions are put in this order ON THE DEVICE: k_ba_gather)
       }
     }
     pt_off[P] = i;
@@ -890,6 +922,23 @@ extern "C" int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, cons
   }
   delete b;
   return CMS_OK;
+}
+
+// edge i of the internal order is the caller's edge perm[i], point i the caller's point pinv[i]: measurements, informations and initial positions
+// into that order (cms_ba_create uploads the caller's arrays untouched)
+extern "C" __global__ void __launch_bounds__(256)
+k_ba_gather(int P, int E, const int* __restrict__ perm, const int* __restrict__ pinv, const double* __restrict__ raw_obs, const double* __restrict__ raw_inv,
+            const double* __restrict__ raw_pts, double* __restrict__ e_obs, double* __restrict__ e_inv, double* __restrict__ pts0) {
+  const int gs = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gs) {
+    const int e = perm[i];
+    reinterpret_cast<double2*>(e_obs)[i] = reinterpret_cast<const double2*>(raw_obs)[e];
+    e_inv[i] = raw_inv[e];
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gs) {
+    const int q = pinv[i];
+    pts0[3 * (size_t)i] = raw_pts[3 * (size_t)q]; pts0[3 * (size_t)i + 1] = raw_pts[3 * (size_t)q + 1]; pts0[3 * (size_t)i + 2] = raw_pts[3 * (size_t)q + 2];
+  }
 }
 
 extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P,
@@ -1143,13 +1192,17 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     for (int i = 0; i < 4; ++i) q[i] /= nn;
   }
-  BA_TLV(double, pin); pin.assign(3 * (size_t)P, 0.0);
-  for (int i = 0; i < P; ++i) for (int j = 0; j < 3; ++j) pin[3 * (size_t)i + j] = points[3 * (size_t)b->pinv[i] + j];
+  // The caller's measurements, informations and point positions travel AS THEY ARE (sequential copies into the staging block) together with the
+  // two permutations; k_ba_gather puts them into the internal edge / point order on the device.  On the host those three gathers were four
+  // random cache lines per point over arrays no other window shares: 1.2 of cms_ba_create's 2.8 ms alone and 2.0-2.7 of ~5 ms when 32 host
+  // threads build windows side by side (memory bound) -- the part a host inside a CPU quota could least afford.
   up(fixed, K, &b->d_fixed); up(pose_slot.data(), K * sizeof(int), &b->d_pose_slot); up(s_pose.data(), E * sizeof(int), &b->d_e_pose);
-  up(s_point.data(), E * sizeof(int), &b->d_e_point); up(s_obs.data(), 2 * (size_t)E * sizeof(double), &b->d_e_obs);
-  up(s_inv.data(), E * sizeof(double), &b->d_e_inv); up(s_face.data(), E, &b->d_e_face); up(pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off);
+  up(s_point.data(), E * sizeof(int), &b->d_e_point); up(e_obs, 2 * (size_t)E * sizeof(double), &b->d_raw_obs);
+  up(e_invsig2, E * sizeof(double), &b->d_raw_inv); up(s_face.data(), E, &b->d_e_face); up(pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off);
   up(pose_off.data(), (K + 1) * sizeof(int), &b->d_pose_off); up(pose_edges.data(), E * sizeof(int), &b->d_pose_edges);
-  up(p0.data(), 7 * (size_t)K * sizeof(double), &b->d_poses0); up(pin.data(), 3 * (size_t)P * sizeof(double), &b->d_pts0);
+  up(p0.data(), 7 * (size_t)K * sizeof(double), &b->d_poses0); up(points, 3 * (size_t)P * sizeof(double), &b->d_raw_pts);
+  up(b->perm.data(), E * sizeof(int), &b->d_perm); up(b->pinv.data(), P * sizeof(int), &b->d_pinv);
+  BA_TRY(ba_alloc(b, &b->d_e_obs, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_inv, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_pts0, 3 * (size_t)P));
   // ---- buffers the device only writes / works in
   BA_TRY(ba_alloc(b, &b->d_level, E)); BA_TRY(ba_alloc(b, &b->d_err, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_ow, (size_t)E));
   for (int i = 0; i < 2; ++i) { BA_TRY(ba_alloc(b, &b->d_poses[i], 7 * (size_t)K)); BA_TRY(ba_alloc(b, &b->d_pts[i], 3 * (size_t)P)); }
@@ -1179,6 +1232,9 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     }
     BA_HIP(hipMemcpyAsync(dev, b->h_stage, total, hipMemcpyHostToDevice, b->stream));
     b->async_pending = true;
+    hipLaunchKernelGGL(k_ba_gather, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, P, E, (const int*)b->d_perm, (const int*)b->d_pinv,
+                       (const double*)b->d_raw_obs, (const double*)b->d_raw_inv, (const double*)b->d_raw_pts, b->d_e_obs, b->d_e_inv, b->d_pts0);
+    BA_HIP(hipGetLastError());
   }
   BaDev& d = b->d;
   d.K = K; d.P = P; d.E = E; d.np = np; d.fixed = b->d_fixed; d.pose_slot = b->d_pose_slot; d.e_pose = b->d_e_pose;
