@@ -435,9 +435,19 @@ def main():
     acc = {"ba_ms": 0.0, "ba_n": 0, "create_ms": 0.0, "create_n": 0}
     life = {"on": True, "queue": collections.deque(), "reads": []}
     ahead = max(1, int(os.environ.get("CMS_BENCH_WINDOWS_AHEAD", "2")))      # sets of windows under construction in front of the running step
+    # The pool starts window w of a set w / 32 x 6 ms late: the windows' uploads and gather / reset kernels are then spread over the step instead
+    # of landing together on its first milliseconds, the frame path's (32 key frames of 32 streams do not arrive in the same instant either).
+    # Measured: extractor inside the step 0.38 against 0.33-0.35 of 8 TB/s on SURVEY's bytes, the step the same within noise
+    # (tools/experiments_r03/r03_run38.sh).  CMS_BENCH_SPREAD_MS=0: all at once.
+    spread_ms = float(os.environ.get("CMS_BENCH_SPREAD_MS", "6"))
+    def make_window_at(delay, p, gi):
+        if delay > 0:
+            time.sleep(delay)
+        return make_window(p, gi)
+
     def submit_windows(j):
         """the pool starts building the n_ba windows of problem set j; returned per group"""
-        life["queue"].append((j, [[wpool.submit(make_window, prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]))
+        life["queue"].append((j, [[wpool.submit(make_window_at, 1e-3 * spread_ms * w / max(n_ba, 1), prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]))
 
     # developer knob: hand the next set of windows to the pool only after the step's frame path has been waited for (the pool's uploads and
     # gather / reset kernels then stay off the extraction kernels -- and land on the Levenberg rounds instead: 14.8-15.4 against 14.4-14.7 ms)
