@@ -435,11 +435,11 @@ def main():
     acc = {"ba_ms": 0.0, "ba_n": 0, "create_ms": 0.0, "create_n": 0}
     life = {"on": True, "queue": collections.deque(), "reads": []}
     ahead = max(1, int(os.environ.get("CMS_BENCH_WINDOWS_AHEAD", "2")))      # sets of windows under construction in front of the running step
-    # The pool starts window w of a set w / 32 x 6 ms late: the windows' uploads and gather / reset kernels are then spread over the step instead
-    # of landing together on its first milliseconds, the frame path's (32 key frames of 32 streams do not arrive in the same instant either).
-    # Measured: extractor inside the step 0.38 against 0.33-0.35 of 8 TB/s on SURVEY's bytes, the step the same within noise
-    # (tools/experiments_r03/r03_run38.sh).  CMS_BENCH_SPREAD_MS=0: all at once.
-    spread_ms = float(os.environ.get("CMS_BENCH_SPREAD_MS", "6"))
+    # developer knob: the pool starts window w of a set w / 32 x spread_ms late, so that the windows' uploads and gather / reset kernels are spread
+    # over the step instead of landing together on its first milliseconds, the frame path's.  Measured with 6 ms: extractor inside the step 0.38
+    # against 0.33-0.35 of 8 TB/s on SURVEY's bytes, the step the same within noise -- and the Schur kernel of the Levenberg rounds, which the
+    # spread-out uploads then overlap instead, 160-180 against 145-160 us per launch.  Off by default: the chain's kernels are the step's critical path.
+    spread_ms = float(os.environ.get("CMS_BENCH_SPREAD_MS", "0"))
     def make_window_at(delay, p, gi):
         if delay > 0:
             time.sleep(delay)
