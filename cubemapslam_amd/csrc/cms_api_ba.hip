@@ -925,20 +925,29 @@ extern "C" int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, cons
 }
 
 // edge i of the internal order is the caller's edge perm[i], point i the caller's point pinv[i]: measurements, informations and initial positions
-// into that order (cms_ba_create uploads the caller's arrays untouched)
+// into that order (cms_ba_create uploads the caller's arrays untouched) -- and, in the same launch, what k_ba_reset does for a window that
+// starts its life: current estimate = initial estimate, per-edge state and the global copy of the reduced system cleared
 extern "C" __global__ void __launch_bounds__(256)
-k_ba_gather(int P, int E, const int* __restrict__ perm, const int* __restrict__ pinv, const double* __restrict__ raw_obs, const double* __restrict__ raw_inv,
-            const double* __restrict__ raw_pts, double* __restrict__ e_obs, double* __restrict__ e_inv, double* __restrict__ pts0) {
-  const int gs = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gs) {
+k_ba_gather(int K, int P, int E, const int* __restrict__ perm, const int* __restrict__ pinv, const double* __restrict__ raw_obs, const double* __restrict__ raw_inv,
+            const double* __restrict__ raw_pts, double* __restrict__ e_obs, double* __restrict__ e_inv, double* __restrict__ pts0,
+            const double* __restrict__ poses0, double* __restrict__ poses, double* __restrict__ pts, uint8_t* __restrict__ level, double* __restrict__ err,
+            uint8_t* __restrict__ flags, double* __restrict__ gsum, int n_gsum, double* __restrict__ gsum_bp, int n_gsum_bp) {
+  const int gs = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = t0; i < E; i += gs) {
     const int e = perm[i];
     reinterpret_cast<double2*>(e_obs)[i] = reinterpret_cast<const double2*>(raw_obs)[e];
     e_inv[i] = raw_inv[e];
+    reinterpret_cast<double2*>(err)[i] = make_double2(0.0, 0.0);
+    level[i] = 0; flags[i] = 0;
   }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gs) {
+  for (int i = t0; i < P; i += gs) {
     const int q = pinv[i];
-    pts0[3 * (size_t)i] = raw_pts[3 * (size_t)q]; pts0[3 * (size_t)i + 1] = raw_pts[3 * (size_t)q + 1]; pts0[3 * (size_t)i + 2] = raw_pts[3 * (size_t)q + 2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const double v = raw_pts[3 * (size_t)q + j]; pts0[3 * (size_t)i + j] = v; pts[3 * (size_t)i + j] = v; }
   }
+  for (int i = t0; i < 7 * K; i += gs) poses[i] = poses0[i];
+  for (int i = t0; i < n_gsum; i += gs) gsum[i] = 0.0;
+  for (int i = t0; i < n_gsum_bp; i += gs) gsum_bp[i] = 0.0;
 }
 
 extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P,
@@ -1232,9 +1241,6 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     }
     BA_HIP(hipMemcpyAsync(dev, b->h_stage, total, hipMemcpyHostToDevice, b->stream));
     b->async_pending = true;
-    hipLaunchKernelGGL(k_ba_gather, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, P, E, (const int*)b->d_perm, (const int*)b->d_pinv,
-                       (const double*)b->d_raw_obs, (const double*)b->d_raw_inv, (const double*)b->d_raw_pts, b->d_e_obs, b->d_e_inv, b->d_pts0);
-    BA_HIP(hipGetLastError());
   }
   BaDev& d = b->d;
   d.K = K; d.P = P; d.E = E; d.np = np; d.fixed = b->d_fixed; d.pose_slot = b->d_pose_slot; d.e_pose = b->d_e_pose;
@@ -1246,8 +1252,13 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane; se.run_mf = b->d_run_mf; se.run_fl = b->d_run_fl;
   }
   tick("uploads");
-  int rc = cms_ba_reset(b);
-  if (rc) { cms_ba_destroy(b); return rc; }
+  b->cur = 0;
+  hipLaunchKernelGGL(k_ba_gather, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, K, P, E, (const int*)b->d_perm, (const int*)b->d_pinv,
+                     (const double*)b->d_raw_obs, (const double*)b->d_raw_inv, (const double*)b->d_raw_pts, b->d_e_obs, b->d_e_inv, b->d_pts0,
+                     (const double*)b->d_poses0, b->d_poses[0], b->d_pts[0], b->d_level, b->d_err, b->d_flags,
+                     b->d_se_partial, b->d_se_partial ? b->se.npairs2 * 42 : 0, b->d_se_bp_partial, b->d_se_bp_partial ? b->np * 6 : 0);
+  BA_HIP(hipGetLastError());
+  b->async_pending = true;
   tick("reset");
   if (timing) fprintf(stderr, "[cms_ba_create] K %d P %d E %d ms:%s\n", K, P, E, t_log.c_str());
   *out = b;
