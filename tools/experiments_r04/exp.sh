@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-4 GPU experiments, one parametrised script (run on the GPU box: gpurun -- 'bash tools/experiments_r04/exp.sh <case> [args]').
+# Output goes to gpurun_out/r04/<case>*.  Cases:
+#   probe        tools/probe/f64_pipes.hip (do FP64 MFMA and FP64 vector instructions of two wavefronts of a SIMD overlap?)
+#   ba16 [libs]  tools/prof_ba_many.py 16 track diff for every kernel of the round (3 Schur, 5 solve, 6 trial, 7 reduce2), per library variant
+#   bench [libs] tools/gb.sh (short bench line) per library variant (default | ab_NAME)
+#   tests        pytest -m gpu
+set -u
+O=gpurun_out/r04; mkdir -p $O
+libpath() { if [ "$1" = "default" ]; then echo $PWD/cubemapslam_amd/lib/libcubemapslam_hip.so; else echo $PWD/cubemapslam_amd/lib/ab_$1.so; fi; }
+case "$1" in
+  probe)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probe/f64_pipes.hip -o /tmp/f64p 2>/dev/null && /tmp/f64p | tee $O/probe_f64_pipes.txt ;;
+  ba16)
+    shift
+    for v in ${@:-default}; do
+      for k in 3 5 6 7; do
+        echo "$v kernel $k: $(CMS_HIP_LIB=$(libpath $v) timeout 300 python tools/prof_ba_many.py 16 track diff $k 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/ba16.txt
+      done
+    done ;;
+  ba16s)   # Schur kernel only
+    shift
+    for v in ${@:-default}; do
+      echo "$v: $(CMS_HIP_LIB=$(libpath $v) timeout 300 python tools/prof_ba_many.py 16 track diff 3 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/ba16.txt
+    done ;;
+  bench)
+    shift
+    for v in ${@:-default}; do CMS_HIP_LIB=$(libpath $v) bash tools/gb.sh r04_$v | tee -a $O/bench.txt; done ;;
+  tests)
+    timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/tests.txt ;;
+  *) echo "unknown case $1"; exit 2 ;;
+esac
