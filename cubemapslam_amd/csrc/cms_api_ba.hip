@@ -21,7 +21,7 @@ struct BaKnobs {
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, rm_valu;
   int solve_reduce_max, leftover_lookahead;
   bool global_sum;
-  int lookahead, compose_segments, dup, run_min_chunks, rm_weight;
+  int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap;
   char stream_priority;
 };
 static const BaKnobs& ba_knobs() {
@@ -49,6 +49,7 @@ static const BaKnobs& ba_knobs() {
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
     q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", q.rm_valu ? 2 : 1));
     q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 100)));
+    q.se_waves_cap = num("CMS_BA_SE_WAVES", 0);          // developer A/B: fewer wavefronts per Schur workgroup (how much of the kernel is latency?)
     const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
     q.stream_priority = pr ? pr[0] : 0;
     return q;

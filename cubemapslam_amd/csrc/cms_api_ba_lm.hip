@@ -239,6 +239,7 @@ static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
   }
   m.fused = m.use_se && m.use_te && m.use_s3 && !ba_knobs().no_fused;
   m.rm = m.fused && rm_lds > 0 && m.se_waves == BA_SE_THREADS / 64 && !ba_knobs().runs_as_edges;
+  if (ba_knobs().se_waves_cap > 0 && !ba_knobs().rm_valu) m.se_waves = std::max(1, std::min(m.se_waves, ba_knobs().se_waves_cap));      // (the MFMA body takes any count)
   // one global copy of the reduced system per window, added to by all its workgroups (not with the A/B knobs that want the slices or launch a
   // kernel of the round twice)
   m.gsum = m.fused && ba_knobs().global_sum && !ba_knobs().separate_reduce && ba_knobs().dup == 0;

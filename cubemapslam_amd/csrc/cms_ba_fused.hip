@@ -55,7 +55,7 @@ __device__ __forceinline__ void ba_factor_diag(double* a, int J, double* Ld, dou
 
 // T <- exp(x) T for the free poses (types_six_dof_expmap.h:73-76), plain copy for the fixed ones; pose part of the gain denominator and the
 // solver status -> scal[5], scal[4] (shared by the two solve kernels)
-__device__ __forceinline__ void ba_trial_pose_update(BaDev d, const double* ybuf, const double* __restrict__ bp, double lambda, const double* __restrict__ poses,
+__device__ __forceinline__ void ba_trial_pose_update(BaDevG d, const double* ybuf, const double* __restrict__ bp, double lambda, const double* __restrict__ poses,
                                                      double* __restrict__ poses_new, double* __restrict__ scal, bool isbad) {
   const int tid = threadIdx.x;
   double sc = 0;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void ba_trial_pose_update(BaDev d, const double* ybuf
   }
 }
 
-__device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
+__device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDevG d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
                  double* __restrict__ xp_out, double* __restrict__ scal, long long* __restrict__ clk = nullptr) {
@@ -305,7 +305,7 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDev d, con
 // lane, as a look-ahead behind that lane's own trailing update.  Panels are stored row major, 38 doubles per block (304 B: the three lanes
 // of a block read the same L block -- a broadcast -- and neighbouring blocks fall on different banks).
 #define BA_S3_STRIDE 38
-__device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
+__device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
                  double* __restrict__ xp_out, double* __restrict__ scal, bool lumped = false, double* partial = nullptr,
@@ -516,7 +516,7 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDev d, const double* __re
 
 // per point: x_l = Dinv (b_l - sum B^T x_p), X_new = X + x_l, gain-denominator partial; then residuals + robust chi2 of the
 // point's edges at the trial state.  partial[blk] = chi2 sum, partial[nblk + blk] = denominator sum.
-__device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+__device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDevG d, const double* __restrict__ bl, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                   const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
                   const double* __restrict__ poses_new, int robust, double delta, double* __restrict__ partial,
                   const double* __restrict__ Hll = nullptr, const double* __restrict__ poses_cur = nullptr) {
@@ -582,7 +582,7 @@ __device__ __forceinline__ void ba_trial_points_body(int BX, int GX, BaDev d, co
       quat_to_R(pose + 3, R);
       cam_point(pose, R, X, Xc);
       edge_error(d, e, Xc, r);
-      reinterpret_cast<double2*>(d.err)[e] = make_double2(r[0], r[1]);
+      BA_ERR2_ST(d, e, r[0], r[1]);
       const double c2 = d.e_inv[e] * (r[0] * r[0] + r[1] * r[1]);
       if (robust) { huber_w(c2, delta, &rho0); chi += rho0; } else chi += c2;
     }

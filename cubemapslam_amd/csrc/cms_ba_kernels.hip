@@ -29,6 +29,45 @@ struct BaDev {
                                    // pose-point block of an edge can be rebuilt from the estimate instead of being stored (144 B / edge)
   double fx, fy, cx, cy;
 };
+// The same view with every pointer typed as a GLOBAL-memory pointer (address space 1).  The batched kernels (kb_ba_*) read a window's pointers
+// from a BaItem in memory; for such pointers the compiler cannot know the address space and emits flat_load / flat_store -- and a flat
+// operation counts in BOTH wait counters (vmcnt and lgkmcnt): every wait for LDS data then also waits for the outstanding prefetches from
+// HBM, i.e. nothing a wavefront requests ahead overlaps its LDS work (round 3's run-major Schur kernel spent a quarter of its life in such
+// waits).  All device bodies take this view; the plain BaDev (what the host fills in) converts implicitly.
+#define BA_AS1 __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ BA_AS1 T* ba_g(T* p) { return (BA_AS1 T*)p; }
+struct BaDevG {
+  int K, P, E, np;
+  const BA_AS1 uint8_t* fixed;
+  const BA_AS1 int* pose_slot;
+  const BA_AS1 int* e_pose; const BA_AS1 int* e_point;
+  const BA_AS1 double* e_obs; const BA_AS1 double* e_inv; const BA_AS1 int8_t* e_face;
+  const BA_AS1 int* pt_off;
+  const BA_AS1 int* pose_off; const BA_AS1 int* pose_edges;
+  BA_AS1 uint8_t* level;
+  BA_AS1 double* err;
+  BA_AS1 double* ow;
+  double fx, fy, cx, cy;
+  __device__ __forceinline__ BaDevG() {}
+  __device__ __forceinline__ BaDevG(const BaDev& d)
+      : K(d.K), P(d.P), E(d.E), np(d.np), fixed(ba_g(d.fixed)), pose_slot(ba_g(d.pose_slot)), e_pose(ba_g(d.e_pose)), e_point(ba_g(d.e_point)),
+        e_obs(ba_g(d.e_obs)), e_inv(ba_g(d.e_inv)), e_face(ba_g(d.e_face)), pt_off(ba_g(d.pt_off)), pose_off(ba_g(d.pose_off)),
+        pose_edges(ba_g(d.pose_edges)), level(ba_g(d.level)), err(ba_g(d.err)), ow(ba_g(d.ow)), fx(d.fx), fy(d.fy), cx(d.cx), cy(d.cy) {}
+};
+// 16-byte accesses through global-memory pointers (the HIP vector classes only bind to generic references: native vectors carry the address space)
+typedef double ba_nv2d __attribute__((ext_vector_type(2)));
+typedef int ba_nv4i __attribute__((ext_vector_type(4)));
+typedef unsigned int ba_nv2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ba_ld2(const BA_AS1 double* p) { const ba_nv2d v = *reinterpret_cast<const BA_AS1 ba_nv2d*>(p); return make_double2(v.x, v.y); }
+__device__ __forceinline__ void ba_st2(BA_AS1 double* p, double a, double b) { ba_nv2d v; v.x = a; v.y = b; *reinterpret_cast<BA_AS1 ba_nv2d*>(p) = v; }
+__device__ __forceinline__ int4 ba_ld4i(const BA_AS1 int4* p) { const ba_nv4i v = *reinterpret_cast<const BA_AS1 ba_nv4i*>(p); return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 ba_ld2u(const BA_AS1 uint2* p) { const ba_nv2u v = *reinterpret_cast<const BA_AS1 ba_nv2u*>(p); return make_uint2(v.x, v.y); }
+// FP64 addition to global memory without a return value (global_atomic_add_f64)
+__device__ __forceinline__ void ba_gadd(BA_AS1 double* p, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64(p, v); }
+// an edge's measurement / stored residual as one 16-byte access
+#define BA_OBS2(d, e) ba_ld2((d).e_obs + 2 * (size_t)(e))
+#define BA_ERR2_LD(d, e) ba_ld2((d).err + 2 * (size_t)(e))
+#define BA_ERR2_ST(d, e, a, b) ba_st2((d).err + 2 * (size_t)(e), a, b)
 
 __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
   const double x = q[0], y = q[1], z = q[2], w = q[3];
@@ -62,7 +101,7 @@ __device__ __forceinline__ void face_R(int face, double* Rf) {
 __device__ __forceinline__ void cam_point(const double* pose, const double* R, const double* X, double* Xc) {
   for (int i = 0; i < 3; ++i) Xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + pose[i];
 }
-__device__ __forceinline__ void edge_error_v(const BaDev& d, int face, double o0, double o1, const double* Xc, double* r) {
+template <class BAD> __device__ __forceinline__ void edge_error_v(const BAD& d, int face, double o0, double o1, const double* Xc, double* r) {
   // multipinhole_project: the camera-frame point is cast to float first (cv::Vec3f), projection stored in float
   const double Xf[3] = {(double)(float)Xc[0], (double)(float)Xc[1], (double)(float)Xc[2]};
   double l[3];
@@ -72,7 +111,7 @@ __device__ __forceinline__ void edge_error_v(const BaDev& d, int face, double o0
   r[0] = o0 - (double)u;
   r[1] = o1 - (double)v;
 }
-__device__ __forceinline__ void edge_error(const BaDev& d, int e, const double* Xc, double* r) {
+template <class BAD> __device__ __forceinline__ void edge_error(const BAD& d, int e, const double* Xc, double* r) {
   edge_error_v(d, d.e_face[e], d.e_obs[2 * e], d.e_obs[2 * e + 1], Xc, r);
 }
 __device__ __forceinline__ double huber_w(double e2, double delta, double* rho0) {
@@ -86,10 +125,15 @@ __device__ __forceinline__ double huber_w(double e2, double delta, double* rho0)
 // Jl (2x3).  The reference multiplies dense 3x3 matrices; R_face is a signed permutation, so its products are picked apart here, the
 // four divisions by z share one reciprocal and mul+add pairs may contract to FMAs.  The linearisation is outside the bit-exact part
 // (updates within 1e-4); the residual (edge_error) is not touched by any of this.
-__device__ __forceinline__ void edge_jac_face(const BaDev& d, int face, const double* Xc, const double* R, double* Jp, double* Jl) {
-#pragma clang fp contract(fast)
+// (edge_jac_local: the same from the face-local point l the caller computed -- the run-major Schur body replaces l for excluded edges)
+template <class BAD> __device__ __forceinline__ void edge_jac_local(const BAD& d, int face, const double* l, const double* Xc, const double* R, double* Jp, double* Jl);
+template <class BAD> __device__ __forceinline__ void edge_jac_face(const BAD& d, int face, const double* Xc, const double* R, double* Jp, double* Jl) {
   double l[3];
   face_local(face, Xc, l);
+  edge_jac_local(d, face, l, Xc, R, Jp, Jl);
+}
+template <class BAD> __device__ __forceinline__ void edge_jac_local(const BAD& d, int face, const double* l, const double* Xc, const double* R, double* Jp, double* Jl) {
+#pragma clang fp contract(fast)
   const double iz = 1.0 / l[2];
   const double g00 = d.fx * iz, g11 = d.fy * iz, g02 = -(g00 * l[0]) * iz, g12 = -(g11 * l[1]) * iz;   // G = [g00 0 g02; 0 g11 g12]
   // M = -(G * R_face): the face-frame gradient carried back to the camera frame
@@ -113,12 +157,12 @@ __device__ __forceinline__ void edge_jac_face(const BaDev& d, int face, const do
   }
 }
 
-__device__ __forceinline__ void edge_jac(const BaDev& d, int e, const double* Xc, const double* R, double* Jp, double* Jl) {
+template <class BAD> __device__ __forceinline__ void edge_jac(const BAD& d, int e, const double* Xc, const double* R, double* Jp, double* Jl) {
   edge_jac_face(d, d.e_face[e], Xc, R, Jp, Jl);
 }
 // Hpl block of edge e (6x3, row major) rebuilt from the estimate the system was linearised at and the stored weight ow[e]:
 // B = ow * Jp^T Jl.  Zero for excluded edges and fixed poses, like the stored block.
-__device__ __forceinline__ void edge_block(const BaDev& d, int e, const double* __restrict__ poses, const double* __restrict__ pts, double* Bv) {
+template <class BAD> __device__ __forceinline__ void edge_block(const BAD& d, int e, const double* __restrict__ poses, const double* __restrict__ pts, double* Bv) {
 #pragma clang fp contract(fast)
   const int k = d.e_pose[e];
   const double ow = d.ow[e];
@@ -150,7 +194,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 }
 
 // ---- residuals + robust chi2 partial sums (one partial per workgroup, reduced in fixed order by k_ba_reduce)
-__device__ __forceinline__ void ba_errors_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+__device__ __forceinline__ void ba_errors_body(int BX, int GX, BaDevG d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
             double* __restrict__ partial) {
   __shared__ double sh[16];
   const int e = BX * blockDim.x + threadIdx.x;
@@ -161,7 +205,7 @@ __device__ __forceinline__ void ba_errors_body(int BX, int GX, BaDev d, const do
     quat_to_R(pose + 3, R);
     cam_point(pose, R, pts + 3 * d.e_point[e], Xc);
     edge_error(d, e, Xc, r);
-    reinterpret_cast<double2*>(d.err)[e] = make_double2(r[0], r[1]);
+    BA_ERR2_ST(d, e, r[0], r[1]);
     const double c2 = d.e_inv[e] * (r[0] * r[0] + r[1] * r[1]);
     if (robust) huber_w(c2, delta, &rho0); else rho0 = c2;
   }
@@ -177,7 +221,7 @@ __device__ __forceinline__ void ba_reduce_body(int BX, int GX, const double* __r
 }
 
 // ---- per-point blocks: Hll (3x3), bl, Hpl per edge (6x3); one thread per point over its (point-sorted) edges
-__device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+__device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDevG d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
                 double* __restrict__ Hll, double* __restrict__ bl, double* __restrict__ Hpl) {
 #pragma clang fp contract(fast)                       // block accumulation: FMAs allowed (not part of the bit-exact surface)
   const int p = BX * blockDim.x + threadIdx.x;
@@ -197,7 +241,7 @@ __device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, cons
     quat_to_R(pose + 3, R);
     cam_point(pose, R, pts + 3 * p, Xc);
     edge_jac(d, e, Xc, R, Jp, Jl);
-    const double2 rr = reinterpret_cast<const double2*>(d.err)[e];
+    const double2 rr = BA_ERR2_LD(d, e);
     const double r0 = rr.x, r1 = rr.y, om = d.e_inv[e];
     double w = 1.0, rho0;
     if (robust) w = huber_w(om * (r0 * r0 + r1 * r1), delta, &rho0);
@@ -225,7 +269,7 @@ __device__ __forceinline__ void ba_lin_points_body(int BX, int GX, BaDev d, cons
 // k_ba_pose_finish adds the slices in fixed order (deterministic, no atomics).
 #define BA_POSE_CHUNKS 8
 template <int N, int H> __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, int off);   // defined below
-__device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
+__device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDevG d, const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta,
                double* __restrict__ pose_partial, int ch_arg = -1) {
 #pragma clang fp contract(fast)
   __shared__ double sh[16][27];
@@ -247,7 +291,7 @@ __device__ __forceinline__ void ba_lin_poses_body(int BX, int GX, BaDev d, const
     double Xc[3], Jp[12], Jl[6];
     cam_point(pose, R, pts + 3 * d.e_point[e], Xc);
     edge_jac(d, e, Xc, R, Jp, Jl);
-    const double2 rr = reinterpret_cast<const double2*>(d.err)[e];
+    const double2 rr = BA_ERR2_LD(d, e);
     const double r0 = rr.x, r1 = rr.y, om = d.e_inv[e];
     double w = 1.0, rho0;
     if (robust) w = huber_w(om * (r0 * r0 + r1 * r1), delta, &rho0);
@@ -362,7 +406,7 @@ __device__ __forceinline__ void rs_step(const double* in, double* out, bool hi, 
     out[i] = keep + __shfl_xor(send, off);
   }
 }
-__device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDev d, const int2* __restrict__ chunk_range, const int2* __restrict__ tup, const double* __restrict__ Hpl,
+__device__ __forceinline__ void ba_schur_chunks_body(int BX, int GX, BaDevG d, const int2* __restrict__ chunk_range, const int2* __restrict__ tup, const double* __restrict__ Hpl,
                   const double* __restrict__ Dinv, const double* __restrict__ db, double* __restrict__ chunk_sum) {
   __shared__ double sh[16][42];
   const int2 rg = chunk_range[BX];
@@ -677,7 +721,7 @@ k_ba_update_poses(BaDev d, const double* __restrict__ xp, const double* __restri
 }
 
 // ---- outlier test of Optimizer.cpp:376-382 / 404-410: chi2 of the STORED error > th or depth <= 0
-__device__ __forceinline__ void ba_classify_body(int BX, int GX, BaDev d, const double* __restrict__ poses, const double* __restrict__ pts, double chi2_th, int set_level,
+__device__ __forceinline__ void ba_classify_body(int BX, int GX, BaDevG d, const double* __restrict__ poses, const double* __restrict__ pts, double chi2_th, int set_level,
               uint8_t* __restrict__ flags) {
   const int e = BX * blockDim.x + threadIdx.x;
   if (e >= d.E) return;

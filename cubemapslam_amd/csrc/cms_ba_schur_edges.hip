@@ -66,6 +66,21 @@ struct BaSe {                      // device view of the edge-major work list (c
                                   // each; the solve kernel reads that one slice and puts the zeros back (kb_ba_trial_solve3r)
 };
 
+struct BaSeG {                     // BaSe with global-memory pointer types (see BaDevG, cms_ba_kernels.hip): what the device bodies take
+  int R, nchunks, cpw, n_rm, R_rm;
+  const BA_AS1 int4* rm_chunk; const BA_AS1 uint2* run_lane; const BA_AS1 uint32_t* run_mf; const BA_AS1 uint32_t* run_fl;
+  int Rt, cpw_t, npairs2;
+  const BA_AS1 int* chunk_e0; const BA_AS1 uint32_t* e_info;
+  BA_AS1 double* partial; BA_AS1 double* bp_partial;
+  const BA_AS1 int* lone; int nlone;
+  int gsum;
+  __device__ __forceinline__ BaSeG() {}
+  __device__ __forceinline__ BaSeG(const BaSe& s)
+      : R(s.R), nchunks(s.nchunks), cpw(s.cpw), n_rm(s.n_rm), R_rm(s.R_rm), rm_chunk(ba_g(s.rm_chunk)), run_lane(ba_g(s.run_lane)), run_mf(ba_g(s.run_mf)),
+        run_fl(ba_g(s.run_fl)), Rt(s.Rt), cpw_t(s.cpw_t), npairs2(s.npairs2), chunk_e0(ba_g(s.chunk_e0)), e_info(ba_g(s.e_info)), partial(ba_g(s.partial)),
+        bp_partial(ba_g(s.bp_partial)), lone(ba_g(s.lone)), nlone(s.nlone), gsum(s.gsum) {}
+};
+
 __device__ __forceinline__ int ba_se_pair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 - 1)) >> 1) + (s2 - s1); }   // s1 <= s2, dense (with diagonal)
 __device__ __forceinline__ int ba_se_opair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 + 1)) >> 1) + (s2 - s1 - 1); }   // s1 < s2, off-diagonal only
 // layout of a 6x6 block of S in LDS: strictly upper elements (r < q) at 0..14, their transposes at 16..30, the diagonal at 15, 31, 32..35
@@ -93,9 +108,9 @@ __device__ __forceinline__ void ba_se_cam_point(const double* Rt, const double* 
 // S_aa - Hpp_aa, its right-hand side  s_a - bp_a; bp alone goes to six more slots: the gain ratio needs it).  From the second iteration
 // of a stage on no other kernel linearises: kb_ba_lin + kb_ba_maxdiag drop out of the round (25 + 7 us of ~165 for eight windows), and a
 // rejected trial merely repeats arithmetic this kernel had to do anyway (it rebuilt the Jacobians from the estimate before, too).
-template <bool FUSED> __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSe& se);
+template <bool FUSED> __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSeG& se);
 template <bool FUSED>
-__device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+__device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                     const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
 #pragma clang fp contract(fast)
   extern __shared__ __align__(16) double se_lds[];
@@ -121,16 +136,17 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, do
   const int c0 = se.n_rm + BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);      // (the chunks in front of n_rm belong to the run-major body)
   // The loop is software pipelined over a wave's chunks: the per-edge words of chunk c + nw are requested before chunk c is worked on,
   // its per-point operands (position, Hll, bl) right after chunk c's rows are published -- the atomics section hides their latency.
-  int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;          // FUSED: n_ow carries the edge's information (0 for an excluded edge)
+  int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;          // FUSED: n_ow carries the edge's information, n_lvl its exclusion flag -- RAW: the
+  uint8_t n_lvl = 0;                                                      // selection happens where the chunk is worked on (a select here would wait for both loads at once)
   double n_X[3] = {0, 0, 0}, n_H[6] = {1, 0, 1, 0, 0, 1}, n_b[3] = {0, 0, 0};
   double2 n_obs = make_double2(0.0, 0.0);
   auto load1 = [&](int c) {
-    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0;
+    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0; n_lvl = 0;
     if (c < c1) {
       const int e = se.chunk_e0[c] + lane;
       if (e < se.chunk_e0[c + 1]) {
         n_p = d.e_point[e]; n_info = se.e_info[e]; n_e = e;
-        if (FUSED) { n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0; n_obs = reinterpret_cast<const double2*>(d.e_obs)[e]; }
+        if (FUSED) { n_ow = d.e_inv[e]; n_lvl = d.level[e]; n_obs = BA_OBS2(d, e); }
         else n_ow = d.ow[e];
       }
     }
@@ -150,7 +166,7 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, do
   load2();
   for (int c = c0 + wave; c < c1; c += nw) {
     const uint32_t info = n_info;
-    double ow = n_ow;
+    double ow = (FUSED && n_lvl != 0) ? 0.0 : n_ow;
     const int pnt = n_p, eid = n_e;
     const double2 obs = n_obs;
     const double X[3] = {n_X[0], n_X[1], n_X[2]};
@@ -329,34 +345,41 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDev d, BaSe se, do
 
 // ---- a workgroup's LDS copy of the reduced system -> its slice of `partial`, in the dense pair enumeration the reduction and the solve kernel use
 template <bool FUSED>
-__device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSe& se) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSeG& se) {
+  // One pose pair per wavefront and step, lane = element (0 .. 35 the 6x6 block, 36 .. 41 the right-hand side, 42 .. 47 bp of a diagonal pair):
+  // the pair (s1, s2) is wave-uniform and advanced incrementally on the scalar unit, the element's place inside a block is a per-lane constant.
+  // (One thread per element of the slice, with a division by 42, a search for s1 and the block-layout arithmetic per element, was ~1300 vector
+  // instructions per thread: a sixth of everything the run-major body issues for a workgroup of ten chunks per wavefront.)
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const int BX = slice;
-  for (int o = tid; o < NP2 * 42; o += blockDim.x) {
-    const int pr = o / 42, i = o - 42 * pr;
-    int s1 = 0, off = 0;
-    while (off + (np - s1) <= pr) { off += np - s1; ++s1; }
-    const int s2 = s1 + (pr - off);
+  int off_od = -1, off_dg = -1;
+  if (lane < 36) {
+    const int r = lane / 6, q = lane - 6 * r, lo = min(r, q), hi = max(r, q);
+    off_od = ba_se_off(r, q);
+    off_dg = lo * 6 - ((lo * (lo - 1)) >> 1) + (hi - lo);
+  } else if (lane < 42) off_dg = 21 + (lane - 36);
+  else if (FUSED && lane < 48) off_dg = 27 + (lane - 42);
+  int s1 = 0, s2 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  while (s2 >= np && s1 < np) { ++s1; s2 = s2 - np + s1; }
+  for (int pr = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); pr < NP2; pr += nw) {
     double v = 0.0;
     if (s1 == s2) {
-      int ci;
-      if (i < 36) { const int r = i / 6, q = i - 6 * r, lo = min(r, q), hi = max(r, q); ci = lo * 6 - ((lo * (lo - 1)) >> 1) + (hi - lo); }
-      else ci = 21 + (i - 36);
-      for (int cp = 0; cp < BA_SE_DCOPIES; ++cp) v += Dg[((size_t)cp * np + s1) * BA_SE_DSTRIDE + ci];
-    } else if (i < 36) {
-      v = S[(size_t)ba_se_opair(np, s1, s2) * BA_SE_SSTRIDE + ba_se_off(i / 6, i % 6)];
+      if (off_dg >= 0) {
+#pragma unroll
+        for (int cp = 0; cp < BA_SE_DCOPIES; ++cp) v += Dg[((size_t)cp * np + s1) * BA_SE_DSTRIDE + off_dg];
+      }
+    } else if (off_od >= 0) {
+      v = S[(size_t)ba_se_opair(np, s1, s2) * BA_SE_SSTRIDE + off_od];
     }
-    if (se.gsum) { if (v != 0.0) unsafeAtomicAdd(&se.partial[(size_t)pr * 42 + i], v); }
-    else se.partial[((size_t)BX * NP2 + pr) * 42 + i] = v;
-  }
-  if (FUSED) {
-    for (int o = tid; o < 6 * np; o += blockDim.x) {
-      const int s1 = o / 6, i = o - 6 * s1;
-      double v = 0.0;
-      for (int cp = 0; cp < BA_SE_DCOPIES; ++cp) v += Dg[((size_t)cp * np + s1) * BA_SE_DSTRIDE + 27 + i];
-      if (se.gsum) { if (v != 0.0) unsafeAtomicAdd(&se.bp_partial[(size_t)s1 * 6 + i], v); }
-      else se.bp_partial[((size_t)BX * np + s1) * 6 + i] = v;
+    if (lane < 42) {
+      if (se.gsum) { if (v != 0.0) ba_gadd(&se.partial[(size_t)pr * 42 + lane], v); }
+      else se.partial[((size_t)BX * NP2 + pr) * 42 + lane] = v;
+    } else if (FUSED && lane < 48 && s1 == s2) {
+      if (se.gsum) { if (v != 0.0) ba_gadd(&se.bp_partial[(size_t)s1 * 6 + (lane - 42)], v); }
+      else se.bp_partial[((size_t)BX * np + s1) * 6 + (lane - 42)] = v;
     }
+    s2 += nw;
+    while (s2 >= np && s1 < np) { ++s1; s2 = s2 - np + s1; }
   }
 }
 
@@ -369,7 +392,7 @@ __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const
 #ifndef BA_TE_THREADS
 #define BA_TE_THREADS 256
 #endif
-__device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaSe se, const double* __restrict__ bl, const double* __restrict__ Hll,
+__device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDevG d, BaSeG se, const double* __restrict__ bl, const double* __restrict__ Hll,
                                                     const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
                                                     const double* __restrict__ poses_cur, const double* __restrict__ poses_new, int robust, double delta,
                                                     double* __restrict__ partial) {
@@ -412,7 +435,7 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
       info = se.e_info[e]; p = d.e_point[e];
       act = d.level[e] == 0;
       ow = d.ow[e]; einv = d.e_inv[e];
-      ob = reinterpret_cast<const double2*>(d.e_obs)[e];
+      ob = BA_OBS2(d, e);
       a = info & 31; k = (info >> 5) & 31; s = (int)((info >> 10) & 63) - 1; face = (info >> 16) & 7; kp = (info >> 19) & 255;
       X[0] = pts[3 * (size_t)p]; X[1] = pts[3 * (size_t)p + 1]; X[2] = pts[3 * (size_t)p + 2];
       if (a == 0) {
@@ -475,7 +498,7 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDev d, BaS
 #pragma unroll
       for (int i = 0; i < 3; ++i) Xc[i] = Rt[3 * i] * Xn[0] + Rt[3 * i + 1] * Xn[1] + Rt[3 * i + 2] * Xn[2] + Rt[9 + i];
       edge_error_v(d, face, ob.x, ob.y, Xc, r);
-      reinterpret_cast<double2*>(d.err)[e] = make_double2(r[0], r[1]);
+      BA_ERR2_ST(d, e, r[0], r[1]);
       const double c2 = einv * (r[0] * r[0] + r[1] * r[1]);
       if (robust) { huber_w(c2, delta, &rho0); chi += rho0; } else chi += c2;
     }

@@ -43,7 +43,17 @@ struct BaSp {                      // device view of the host-built work lists (
   double* partial;                // R x npairs x 42
 };
 
-__device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
+struct BaSpG {                     // BaSp with global-memory pointer types (see BaDevG)
+  int nbat, bpw, nslots, npairs, R, nd_slots;
+  const BA_AS1 int* bat_e0; int off_stride; const BA_AS1 int* tup_base; const BA_AS1 uint32_t* tup32; const BA_AS1 uint32_t* off32;
+  const BA_AS1 int* slot_pair; const BA_AS1 int* pair_slots; BA_AS1 double* partial;
+  __device__ __forceinline__ BaSpG() {}
+  __device__ __forceinline__ BaSpG(const BaSp& s)
+      : nbat(s.nbat), bpw(s.bpw), nslots(s.nslots), npairs(s.npairs), R(s.R), nd_slots(s.nd_slots), bat_e0(ba_g(s.bat_e0)), off_stride(s.off_stride),
+        tup_base(ba_g(s.tup_base)), tup32(ba_g(s.tup32)), off32(ba_g(s.off32)), slot_pair(ba_g(s.slot_pair)), pair_slots(ba_g(s.pair_slots)), partial(ba_g(s.partial)) {}
+};
+
+__device__ __forceinline__ void ba_schur_points_body(int BX, BaDevG d, BaSpG sp, const double* __restrict__ Hpl, const double* __restrict__ Dinv,
                                                      const double* __restrict__ db, const double* __restrict__ Hll = nullptr,
                                                      const double* __restrict__ bl = nullptr, double lambda = 0.0,
                                                      const double* __restrict__ poses = nullptr, const double* __restrict__ pts = nullptr) {
@@ -160,7 +170,7 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
 #pragma unroll
     for (int i = 0; i < 42; ++i) sp_lds[(size_t)tid * 42 + i] = acc[i];
   } else if (have) {
-    double* out = sp.partial + ((size_t)BX * sp.npairs + sp.slot_pair[tid]) * 42;
+    BA_AS1 double* out = sp.partial + ((size_t)BX * sp.npairs + sp.slot_pair[tid]) * 42;
 #pragma unroll
     for (int i = 0; i < 42; ++i) out[i] = acc[i];
   }
@@ -176,7 +186,7 @@ __device__ __forceinline__ void ba_schur_points_body(int BX, BaDev d, BaSp sp, c
 }
 
 // sum over the ranges, in order: one workgroup per pair; 4 x 64 threads = 4 interleaved range sub-sums x 42 values
-__device__ __forceinline__ void ba_schur_reduce_body(int BX, BaSp sp, double* __restrict__ pair_sum) {
+__device__ __forceinline__ void ba_schur_reduce_body(int BX, BaSpG sp, double* __restrict__ pair_sum) {
   __shared__ double sh[4][42];
   const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
   double v = 0;

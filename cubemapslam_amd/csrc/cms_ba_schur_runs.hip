@@ -42,7 +42,7 @@ __host__ __device__ constexpr uint32_t ba_rm_lane_word(int pa, int pb, int q, in
   return (uint32_t)pa | ((uint32_t)pb << 5) | ((uint32_t)q << 10) | ((uint32_t)Q << 16) | (1u << 23) | ((diag ? 1u : 0u) << 24);
 }
 
-__device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+__device__ __forceinline__ void ba_schur_runs_body(int BX, BaDevG d, BaSeG se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                    const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
 #pragma clang fp contract(fast)
   extern __shared__ __align__(16) double se_lds[];
@@ -89,8 +89,8 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
   // first point and the lane: no index has to arrive first) are requested when chunk c is started.  (A first version fetched the positions
   // at the end of the step, behind the point index: every step then began by waiting a memory round trip.)
   int4 d_cur = make_int4(0, 0, -1, 0), d_nxt = make_int4(0, 0, -1, 0);
-  if (cb < ce) d_cur = se.rm_chunk[cb];
-  if (cb + 1 < ce) d_nxt = se.rm_chunk[cb + 1];
+  if (cb < ce) d_cur = ba_ld4i(se.rm_chunk + (cb));
+  if (cb + 1 < ce) d_nxt = ba_ld4i(se.rm_chunk + (cb + 1));
   int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;
   double n_X[3] = {0, 0, 0};
   double2 n_obs = make_double2(0.0, 0.0);
@@ -100,8 +100,8 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
     if (dc.z >= 0 && lane < ne) {
       const int e = dc.x + lane;
       n_e = e; n_info = se.e_info[e];
-      n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0;
-      n_obs = reinterpret_cast<const double2*>(d.e_obs)[e];
+      { const double inv_e = d.e_inv[e]; n_ow = d.level[e] == 0 ? inv_e : 0.0; }      // (unconditional load: the information does not wait for the flag)
+      n_obs = BA_OBS2(d, e);
       n_p = dc.w + ((lane * ((65536 + kk - 1) / kk)) >> 16);          // first point of the chunk + lane / edges per point
       const double* Xp = pts + 3 * (size_t)n_p;
       n_X[0] = Xp[0]; n_X[1] = Xp[1]; n_X[2] = Xp[2];
@@ -121,7 +121,7 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
         const double X[3] = {n_X[0], n_X[1], n_X[2]};
         d_cur = d_nxt;
         d_nxt = make_int4(0, 0, -1, 0);
-        if (c + 2 < ce) d_nxt = se.rm_chunk[c + 2];
+        if (c + 2 < ce) d_nxt = ba_ld4i(se.rm_chunk + (c + 2));
         load_chunk(d_cur);
         const int k_run = (desc.y >> 8) & 255;
         const int invk = (65536 + k_run - 1) / k_run;
@@ -256,9 +256,9 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
   for (int i = 0; i < 42; ++i) acc[i] = 0.0;
   int cur_run = -1;
   int4 c_desc = make_int4(0, 0, -1, 0);                                   // descriptor of the chunk the next step consumes
-  if (cb < ce) c_desc = se.rm_chunk[cb];
+  if (cb < ce) c_desc = ba_ld4i(se.rm_chunk + (cb));
   uint2 lt = make_uint2(0u, 0u), lt_next = make_uint2(0u, 0u);
-  if (c_desc.z >= 0) lt_next = se.run_lane[(size_t)c_desc.z * 64 + lane];
+  if (c_desc.z >= 0) lt_next = ba_ld2u(se.run_lane + ((size_t)c_desc.z * 64 + lane));
   for (int s = 0; s < nsteps; ++s) {
     {
       const int c = cb + s - 1;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
         const double* buf = mybufs + (size_t)((s - 1) & 1) * BA_RM_BUF;
         const int4 desc = c_desc;
         c_desc = make_int4(0, 0, -1, 0);
-        if (c + 1 < ce) c_desc = se.rm_chunk[c + 1];                        // (its run is only looked at after the products below)
+        if (c + 1 < ce) c_desc = ba_ld4i(se.rm_chunk + (c + 1));                        // (its run is only looked at after the products below)
         const int next_run = c_desc.z;
         if (desc.z != cur_run) { cur_run = desc.z; lt = lt_next; }         // (requested when the previous run ended)
         const int k_run = (desc.y >> 8) & 255, m = desc.y >> 16;
@@ -314,7 +314,7 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDev d, BaSe se, dou
           }
 #pragma unroll
           for (int i = 0; i < 42; ++i) acc[i] = 0.0;
-          if (next_run >= 0) lt_next = se.run_lane[(size_t)next_run * 64 + lane];      // the next run's lane table travels behind the barrier
+          if (next_run >= 0) lt_next = ba_ld2u(se.run_lane + ((size_t)next_run * 64 + lane));      // the next run's lane table travels behind the barrier
         }
       }
     }
@@ -374,17 +374,30 @@ template <int PERM> __device__ __forceinline__ double ba_quad_perm(double v) {
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), PERM, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+__device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                         const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
 #pragma clang fp contract(fast)
+  // Round 4: what the wavefront waits for.  Round 3's body spent a quarter of its life in s_waitcnt (profiles/r03_pmc_instruction_mix.json):
+  //   * the next chunk's operands were requested ahead of the matrix phase, but the information of an edge was SELECTED by its exclusion flag
+  //     at the place of the request (`level == 0 ? e_inv : 0`), so the wavefront waited for both loads right there -- the prefetch never ran
+  //     beside the matrix phase.  Now the raw words travel and the selection happens when the chunk is worked on;
+  //   * (all pointers of a window used to be flat: see BaDevG);
+  //   * the lanes of a chunk that hold no observation used to be branched around, piece by piece.  Now every lane runs the same straight-line
+  //     code on the data of a real edge (lanes past the chunk's last edge repeat it) with a weight of zero, the handful of places where a zero
+  //     weight could meet a non-finite factor are made finite, and only stores are predicated;
+  //   * the chunk descriptors live in scalar registers (the wavefront index is made uniform with readfirstlane), and with them the loop control;
+  //   * the matrix phase reads its operands unconditionally from addresses that advance by a per-lane step: rows or columns beyond the
+  //     signature's 6 kf + 1 produce tile entries nobody flushes, and points beyond the chunk's last are annihilated by a zero D^-1 in their
+  //     slot instead of by a predicate per read.
   extern __shared__ __align__(16) double se_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
   double* S = se_lds;
   double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);
   double* bufs = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // one chunk buffer per wavefront
   double* prt = bufs + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF;        // (eight buffers: the same LDS budget as the vector variant's 4 x 2)
-  for (int i = tid; i < (int)(bufs - S); i += blockDim.x) S[i] = 0.0;
+  for (int i = tid; i < (int)(prt - S); i += blockDim.x) S[i] = 0.0;      // the chunk buffers too: whatever the matrix phase reads must be finite
   for (int k = tid; k < d.K; k += blockDim.x) {
     double R[9];
     quat_to_R(poses + 7 * k + 3, R);
@@ -394,7 +407,8 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
     for (int i = 0; i < 3; ++i) prt[12 * k + 9 + i] = poses[7 * k + i];
   }
   __syncthreads();
-  double* buf = bufs + (size_t)wave * BA_RM_BUF;
+  double* slots = bufs + (size_t)wave * BA_RM_BUF;               // the wavefront's chunk buffer: D^-1 | y of up to 32 points (6 doubles each), then
+  double* buf = slots + BA_RM_PTS * 6;                            // a row of 18 doubles per lane (the slots sit BELOW the rows: one upper limit for every read)
   const long long total_waves = (long long)se.R_rm * nw;
   const long long gw = (long long)BX * nw + wave;
   const int cb = (int)(gw * se.n_rm / total_waves), ce = (int)((gw + 1) * se.n_rm / total_waves);
@@ -408,17 +422,17 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
 #pragma unroll
   for (int t = 0; t < 3; ++t) acc[t] = (ba_v4d){0.0, 0.0, 0.0, 0.0};
   int cur_run = -1, NT = 1, kf = 1;
-  uint32_t ent[3] = {BA_RM_MF_NONE, BA_RM_MF_NONE, BA_RM_MF_NONE}, n_ent[3] = {BA_RM_MF_NONE, BA_RM_MF_NONE, BA_RM_MF_NONE};
-  uint32_t n_kf = 1;
-  uint32_t fl_hi[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u}, n_fl_hi[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u};      // targets of the per-chunk tiles (kf > 5 only)
-  auto load_tab = [&](int run) {                                   // the lane's table entries of a run (requested ahead of the run)
-    const uint32_t* t = se.run_mf + (size_t)run * 64;
-    n_ent[0] = t[li]; n_ent[1] = t[16 + li]; n_ent[2] = t[32 + li]; n_kf = t[56];
-    if (n_kf > 5) {                                                // (wave uniform: the whole table row is the run's)
-      const uint32_t* f = se.run_fl + ((size_t)run * 64 + lane) * 12 + 6;
+  uint32_t ent[3] = {BA_RM_MF_NONE, BA_RM_MF_NONE, BA_RM_MF_NONE};
+  uint32_t v_kf = 1;
+  uint32_t fl_hi[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u};             // targets of the per-chunk tiles (kf > 5 only)
+  // the lane's table entries of a run: requested when the run's first chunk is started, first looked at in that chunk's matrix phase -- the
+  // vector phase in between is all the time they need (round 3 kept a second set of registers to fetch them one run ahead)
+  auto load_tab = [&](int run) {
+    const BA_AS1 uint32_t* t = se.run_mf + (size_t)run * 64;
+    ent[0] = t[li]; ent[1] = t[16 + li]; ent[2] = t[32 + li]; v_kf = t[56];
+    const BA_AS1 uint32_t* f = se.run_fl + ((size_t)run * 64 + lane) * 12 + 6;      // (only looked at for kf > 5)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) n_fl_hi[i] = f[i];
-    }
+    for (int i = 0; i < 6; ++i) fl_hi[i] = f[i];
   };
   auto add_at = [&](uint32_t word, int half, double v) {           // one accumulator to its place in the LDS copy
     const uint32_t o = half ? (word >> 16) : (word & 0xFFFFu);
@@ -426,24 +440,29 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
   };
   // the inner index of the matrix product runs over (point, column): kappa = 3 j + c, four of them per instruction (kk = lane >> 4).  Three
   // instructions cover twelve indices = four points exactly, so per lane the three (point offset, column) pairs are constants
-  int mj[3], mc[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) { const int kap = 4 * u + lk; mj[u] = kap / 3; mc[u] = kap - 3 * mj[u]; }
-  int4 d_cur = make_int4(0, 0, -1, 0), d_nxt = make_int4(0, 0, -1, 0);
-  if (cb < ce) { d_cur = se.rm_chunk[cb]; load_tab(d_cur.z); }
-  if (cb + 1 < ce) d_nxt = se.rm_chunk[cb + 1];
-  int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;
-  double n_X[3] = {0, 0, 0};
+  // (mj[u], mc[u]) = ((4 u + lk) / 3, (4 u + lk) % 3): recomputed where the addresses are formed
+  // ---- chunk descriptors: the one being worked on in scalar registers, the next one too (its operands are requested from it), the one after
+  // that travelling as a vector load of one address.  first edge | edges + (edges per point << 8) + (points << 16) | run | first point
+  auto sdesc = [&](const int4 v) { return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w)); };
+  const int4 none = make_int4(0, 0, -1, 0);
+  int4 d_cur = none, d_nxt = none, v_nn = none;
+  if (cb < ce) d_cur = sdesc(ba_ld4i(se.rm_chunk + cb));
+  if (cb + 1 < ce) d_nxt = sdesc(ba_ld4i(se.rm_chunk + (cb + 1)));
+  if (cb + 2 < ce) v_nn = ba_ld4i(se.rm_chunk + (cb + 2));
+  // ---- operands of a chunk, as raw words (nothing is computed from them where they are requested: no wait there).  Lanes past the chunk's last
+  // edge repeat it -- every lane then holds the data of a real observation
+  uint32_t n_info = 0; uint8_t n_lvl = 0; double n_inv = 0.0;
+  int n_p = 0, n_e = 0;
+  double n_X[3] = {0, 0, 1};
   double2 n_obs = make_double2(0.0, 0.0);
   auto load_chunk = [&](const int4 dc) {
-    n_info = 0; n_ow = 0.0; n_p = 0; n_e = 0;
-    const int ne = dc.y & 255, kk = (dc.y >> 8) & 255;
-    if (dc.z >= 0 && lane < ne) {
-      const int e = dc.x + lane;
-      n_e = e; n_info = se.e_info[e];
-      n_ow = d.level[e] == 0 ? d.e_inv[e] : 0.0;
-      n_obs = reinterpret_cast<const double2*>(d.e_obs)[e];
-      n_p = dc.w + ((lane * (int)__builtin_ceilf(65536.0f * __builtin_amdgcn_rcpf((float)kk))) >> 16);      // + lane / kk (the slack of the rounding is far below 1 / 64)
+    if (dc.z >= 0) {                                               // (uniform)
+      const int ne = dc.y & 255, kk = (dc.y >> 8) & 255;
+      const int le = min(lane, ne - 1);
+      const int e = dc.x + le;
+      n_e = e; n_info = se.e_info[e]; n_lvl = d.level[e]; n_inv = d.e_inv[e];
+      n_obs = BA_OBS2(d, e);
+      n_p = dc.w + ((le * (int)__builtin_ceilf(65536.0f * __builtin_amdgcn_rcpf((float)kk))) >> 16);      // + le / kk (the slack of the rounding is far below 1 / 64)
       const double* Xp = pts + 3 * (size_t)n_p;
       n_X[0] = Xp[0]; n_X[1] = Xp[1]; n_X[2] = Xp[2];
     }
@@ -457,61 +476,63 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
   for (int c = cb; c < ce; ++c) {
     BA_RM_STAMP(0);                                                // loop overhead / previous flush tail
     const int4 desc = d_cur;
+    const int ne = desc.y & 255, k_run = (desc.y >> 8) & 255, m = desc.y >> 16;
     const uint32_t info = n_info;
-    double ow = n_ow;
+    const bool live = lane < ne;
+    double ow = (live && n_lvl == 0) ? n_inv : 0.0;                // information of an active edge; 0: excluded edge, or a lane without one
     const int pnt = n_p, eid = n_e;
     const double2 obs = n_obs;
     const double X[3] = {n_X[0], n_X[1], n_X[2]};
-    if (desc.z != cur_run) {                                       // a new run: its table entries were requested when the previous run ended
-      cur_run = desc.z;
-      ent[0] = n_ent[0]; ent[1] = n_ent[1]; ent[2] = n_ent[2]; kf = (int)n_kf;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) fl_hi[i] = n_fl_hi[i];
-      NT = (6 * kf + 1 + 15) >> 4;
-    }
-    const int k_run = (desc.y >> 8) & 255, m = desc.y >> 16;
+    const bool new_run = desc.z != cur_run;
+    if (new_run) { cur_run = desc.z; load_tab(cur_run); }
     const int invk = (int)__builtin_ceilf(65536.0f * __builtin_amdgcn_rcpf((float)k_run));
     BA_RM_STAMP(1);                                                // operands of the chunk in registers (waits for the prefetch)
-    // ---------------------------------------------------------------- vector phase: the chunk's rows (as in the vector variant's producer)
-    int slot = -1, a = 0;
-    double Jp[12], Jl[6], o0 = 0.0, o1 = 0.0;
-    bool have_jac = false;
-    if (info != 0) {
-      a = info & 31;
-      const int s_ = (int)((info >> 10) & 63) - 1, face = (info >> 16) & 7, kp = (info >> 19) & 255;
-      if (ow != 0.0) {
-        const double* Rt = prt + 12 * kp;
-        double R[9], Xc[3];
+    // ---------------------------------------------------------------- vector phase: the chunk's rows, every lane the same code
+    const int a = info & 31, s_ = (int)((info >> 10) & 63) - 1, face = (info >> 16) & 7, kp = (info >> 19) & 255;
+    const bool act = ow != 0.0;
+    double Jp[12], Jl[6], o0, o1;
+    {
+      const double* Rt = prt + 12 * kp;
+      double R[9], Xc[3];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = Rt[i];
-        ba_se_cam_point(Rt, X, Xc);
-        double r[2], rho0;
-        edge_error_v(d, face, obs.x, obs.y, Xc, r);
-        const double om = ow;
-        const double w = robust ? huber_w(om * (r[0] * r[0] + r[1] * r[1]), delta, &rho0) : 1.0;
-        ow = w * om;
-        o0 = -om * r[0] * w; o1 = -om * r[1] * w;
-        edge_jac_face(d, face, Xc, R, Jp, Jl);
-        have_jac = true;
-        if (s_ >= 0) slot = s_;
+      for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+      ba_se_cam_point(Rt, X, Xc);
+      double r[2], rho0;
+      edge_error_v(d, face, obs.x, obs.y, Xc, r);
+      r[0] = act ? r[0] : 0.0; r[1] = act ? r[1] : 0.0;            // (an excluded edge may sit at depth zero: no infinity times zero below)
+      const double om = ow;
+      const double w = robust ? huber_w(om * (r[0] * r[0] + r[1] * r[1]), delta, &rho0) : 1.0;
+      ow = w * om;
+      o0 = -om * r[0] * w; o1 = -om * r[1] * w;
+      double lf[3];
+      face_local(face, Xc, lf);
+      if (!act) { lf[0] = 0.0; lf[1] = 0.0; lf[2] = 1.0; }         // finite Jacobians whatever the excluded edge looks like
+      edge_jac_local(d, face, lf, Xc, R, Jp, Jl);
+    }
+    if (live && s_ >= 0) hp_slot = s_;                             // where this lane's key-frame sums go at the end of the run
+    const double owf = s_ >= 0 ? ow : 0.0;                         // a fixed key frame's edge has no row in the reduced system
+    {
+      // the key frame's own block and gradient: summed in registers until the run ends
+      int cidx = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int q = r; q < 6; ++q) hp[cidx++] += owf * (Jp[r] * Jp[q] + Jp[6 + r] * Jp[6 + q]);
       }
-      if (s_ >= 0) hp_slot = s_;
-    }
-    double hl[10];
+      const double of0 = s_ >= 0 ? o0 : 0.0, of1 = s_ >= 0 ? o1 : 0.0;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) hl[i] = 0.0;
-    if (have_jac) {
-      hl[0] = ow * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); hl[1] = ow * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); hl[2] = ow * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
-      hl[3] = ow * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); hl[4] = ow * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); hl[5] = ow * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
-      hl[6] = Jl[0] * o0 + Jl[3] * o1; hl[7] = Jl[1] * o0 + Jl[4] * o1; hl[8] = Jl[2] * o0 + Jl[5] * o1;
+      for (int r = 0; r < 6; ++r) hp[21 + r] += Jp[r] * of0 + Jp[6 + r] * of1;
     }
-    if (info != 0) d.ow[eid] = have_jac ? ow : 0.0;
+    double hl[9];
+    hl[0] = ow * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); hl[1] = ow * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); hl[2] = ow * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
+    hl[3] = ow * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); hl[4] = ow * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); hl[5] = ow * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+    hl[6] = Jl[0] * o0 + Jl[3] * o1; hl[7] = Jl[1] * o0 + Jl[4] * o1; hl[8] = Jl[2] * o0 + Jl[5] * o1;
+    if (live) d.ow[eid] = ow;                                      // the trial kernel rebuilds the edge's block from it
     BA_RM_STAMP(2);                                                // residual, weight, Jacobians, the edge's share of Hll / bl
     // the point's lanes add their shares.  Four (or two) edges per point: the lanes of a point are (half of) a quad of the wavefront and
-    // the shares move with DPP quad permutes -- no LDS round trip (the exchange through the rows cost 1800 of a chunk's 17 000 cycles);
-    // every lane adds in edge order, so all lanes of a point hold the same bits.  Other point sizes: through the rows.
-    double sum[10];
-    sum[9] = 0.0;
+    // the shares move with DPP quad permutes -- no LDS round trip; every lane adds in edge order, so all lanes of a point hold the same bits.
+    // Other point sizes: through the rows.
+    double sum[9];
     if (k_run == 4) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) sum[i] = ((ba_quad_bcast<0>(hl[i]) + ba_quad_bcast<1>(hl[i])) + ba_quad_bcast<2>(hl[i])) + ba_quad_bcast<3>(hl[i]);
@@ -523,33 +544,34 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
       {
         double2* row2 = reinterpret_cast<double2*>(buf + (size_t)lane * 18);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) row2[i] = make_double2(hl[2 * i], hl[2 * i + 1]);
+        for (int i = 0; i < 4; ++i) row2[i] = make_double2(hl[2 * i], hl[2 * i + 1]);
+        row2[4] = make_double2(hl[8], 0.0);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int i = 0; i < 9; ++i) sum[i] = 0.0;
-      for (int j = 0; j < k_run; ++j) {
-        if (info != 0) {
-          const double2* row2 = reinterpret_cast<const double2*>(buf + (size_t)(lane - a + j) * 18);
+      for (int j = 0; j < k_run; ++j) {                            // (lanes past the last edge read rows of the last point: within the buffer)
+        const double2* row2 = reinterpret_cast<const double2*>(buf + (size_t)(lane - a + j) * 18);
 #pragma unroll
-          for (int i = 0; i < 5; ++i) { const double2 u = row2[i]; sum[2 * i] += u.x; sum[2 * i + 1] += u.y; }
-        }
+        for (int i = 0; i < 4; ++i) { const double2 u = row2[i]; sum[2 * i] += u.x; sum[2 * i + 1] += u.y; }
+        sum[8] += row2[4].x;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    BA_RM_STAMP(3);                                                // exchange through the rows: Hll, bl of the point in every lane
-    if (info != 0 && a == 0) {
+    BA_RM_STAMP(3);                                                // exchange: Hll, bl of the point in every lane
+    if (live && a == 0) {
       double* H = Hll + 9 * (size_t)pnt; double* bq = bl + 3 * (size_t)pnt;
       H[0] = sum[0]; H[1] = sum[1]; H[2] = sum[2]; H[3] = sum[1]; H[4] = sum[3]; H[5] = sum[4]; H[6] = sum[2]; H[7] = sum[4]; H[8] = sum[5];
       bq[0] = sum[6]; bq[1] = sum[7]; bq[2] = sum[8];
     }
-    double W[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) W[i] = 0.0;
-    if (info != 0) {
-      const double a00 = sum[0] + lambda, a10 = sum[1], a11 = sum[3] + lambda, a20 = sum[2], a21 = sum[4], a22 = sum[5] + lambda;
+    const int jpt = ((lane - a) * invk) >> 16;                     // point of the chunk: lane / k_run
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    {
+      // A = Hll + lambda I = L D L^T (unit lower L); every lane of the point computes the same factors (a lane without an edge: of the identity)
+      const double dead = live ? 0.0 : 1.0;
+      const double a00 = sum[0] + lambda + dead, a10 = sum[1], a11 = sum[3] + lambda + dead, a20 = sum[2], a21 = sum[4], a22 = sum[5] + lambda + dead;
       const double i0 = 1.0 / a00;
       const double l10 = a10 * i0, l20 = a20 * i0;
       const double d1 = a11 - l10 * a10;
@@ -557,80 +579,97 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
       const double l21 = (a21 - l20 * a10) * i1;
       const double d2 = a22 - l20 * a20 - l21 * (l21 * d1);
       const double i2 = 1.0 / d2;
-      if (a == 0) {                                                // the point's slot: D^-1 | y = L^-1 bl
+      if (live && a == 0) {                                        // the point's slot: D^-1 | y = L^-1 bl
         const double y0 = sum[6], y1 = sum[7] - l10 * y0, y2 = sum[8] - l20 * y0 - l21 * y1;
-        const int j = ((lane - a) * invk) >> 16;
-        double2* pp = reinterpret_cast<double2*>(buf + 64 * 18 + (size_t)j * 6);
+        double2* pp = reinterpret_cast<double2*>(slots + (size_t)jpt * 6);
         pp[0] = make_double2(i0, i1); pp[1] = make_double2(i2, y0); pp[2] = make_double2(y1, y2);
       }
-      if (slot >= 0) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          const double q0 = ow * (Jp[r] * Jl[0] + Jp[6 + r] * Jl[3]);
-          const double q1 = ow * (Jp[r] * Jl[1] + Jp[6 + r] * Jl[4]);
-          const double q2 = ow * (Jp[r] * Jl[2] + Jp[6 + r] * Jl[5]);
-          const double w0 = q0, w1 = q1 - w0 * l10, w2 = q2 - w0 * l20 - w1 * l21;
-          W[3 * r] = w0; W[3 * r + 1] = w1; W[3 * r + 2] = w2;
-        }
-        int cidx = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-          for (int q = r; q < 6; ++q) hp[cidx++] += ow * (Jp[r] * Jp[q] + Jp[6 + r] * Jp[6 + q]);
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) hp[21 + r] += Jp[r] * o0 + Jp[6 + r] * o1;
-      }
-    }
-    BA_RM_STAMP(4);                                                // 3x3 factorisation, W, the key frame's own sums
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    {
+      // rows of W = B L^-T, two at a time straight into the lane's row (three 16-byte stores per pair: no eighteen values alive at once)
       double2* row2 = reinterpret_cast<double2*>(buf + (size_t)lane * 18);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) row2[i] = make_double2(W[2 * i], W[2 * i + 1]);
+      for (int r = 0; r < 6; r += 2) {
+        double wv[6];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double q0 = owf * (Jp[r + h] * Jl[0] + Jp[6 + r + h] * Jl[3]);
+          const double q1 = owf * (Jp[r + h] * Jl[1] + Jp[6 + r + h] * Jl[4]);
+          const double q2 = owf * (Jp[r + h] * Jl[2] + Jp[6 + r + h] * Jl[5]);
+          const double w0 = q0, w1 = q1 - w0 * l10, w2 = q2 - w0 * l20 - w1 * l21;
+          wv[3 * h] = w0; wv[3 * h + 1] = w1; wv[3 * h + 2] = w2;
+        }
+        row2[3 * (r >> 1)] = make_double2(wv[0], wv[1]); row2[3 * (r >> 1) + 1] = make_double2(wv[2], wv[3]); row2[3 * (r >> 1) + 2] = make_double2(wv[4], wv[5]);
+      }
+    }
+    BA_RM_STAMP(4);                                                // 3x3 factorisation, W
+    const int niter = (m + 3) >> 2;
+    {
+      // points of the last group of four that the chunk does not have: a zero D^-1 (and y) annihilates whatever the matrix phase reads for them
+      if (lane < 4 * niter - m) {
+        double2* pp = reinterpret_cast<double2*>(slots + (size_t)(m + lane) * 6);
+        pp[0] = make_double2(0.0, 0.0); pp[1] = make_double2(0.0, 0.0); pp[2] = make_double2(0.0, 0.0);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     BA_RM_STAMP(5);                                                // rows published
     // The next chunk's operands are requested here, not at the top of the loop: the vector phase's registers (Jacobians, W, the 3x3
-    // factors) are dead by now, and the matrix phase below gives the loads a microsecond to land.  (Requested at the top, both chunks'
-    // operands were alive through the vector phase and the kernel spilled.)
+    // factors) are dead by now, and the matrix phase below gives the loads a microsecond to land.
     d_cur = d_nxt;
-    d_nxt = make_int4(0, 0, -1, 0);
-    if (c + 2 < ce) d_nxt = se.rm_chunk[c + 2];
+    d_nxt = sdesc(v_nn);
+    v_nn = none;
+    if (c + 3 < ce) v_nn = ba_ld4i(se.rm_chunk + (c + 3));
     load_chunk(d_cur);
+    if (new_run) { kf = __builtin_amdgcn_readfirstlane((int)v_kf); NT = (6 * kf + 1 + 15) >> 4; }
     BA_RM_STAMP(6);                                                // next chunk's loads issued
     // ---------------------------------------------------------------- matrix phase: G += Y D^-1 Y^T over the chunk's points
     {
-      // per lane and instruction u of a group of three: where its operands sit -- the W entry of its row / column (or the point's y for the
-      // right-hand-side column) at point 4 q + mj[u], column mc[u]; one formula for both kinds of entry: base + point * stride
-      const bool va0 = ent[0] < BA_RM_MF_RHS, va1 = ent[1] < BA_RM_MF_RHS, va2 = ent[2] < BA_RM_MF_RHS;       // W entries (rows of G never include the rhs column)
-      const bool vb0 = ent[0] <= BA_RM_MF_RHS, vb1 = ent[1] <= BA_RM_MF_RHS && NT > 1, vb2 = ent[2] <= BA_RM_MF_RHS && NT > 2;
-      const int rs = k_run * 18;
-      const int o0b = va0 ? (int)ent[0] : 64 * 18 + 3, s0b = va0 ? rs : 6;
-      const int o1b = va1 ? (int)ent[1] : 64 * 18 + 3, s1b = va1 ? rs : 6;
-      const int o2b = va2 ? (int)ent[2] : 64 * 18 + 3, s2b = va2 ? rs : 6;
-      const int niter = (m + 3) >> 2;
+      // byte addresses (from the start of the chunk buffer) of the lane's operands, per tile operand t (its row / column entry ent[t]) and inner
+      // index u: a W entry at point mj[u] -> ent + mj[u] * k_run * 18 + mc[u], advancing by four points per step; the right-hand-side column
+      // (and every entry beyond it: what such a row or column collects is never flushed) reads the point's y.
+      // (addresses count from the start of the slots; the rows begin BA_RM_PTS * 48 bytes further up)
+      const uint32_t rs8 = (uint32_t)k_run * 144u, row0 = BA_RM_PTS * 48u;
+      const uint32_t lim = row0 + (64u * 18u - 1u) * 8u;           // the last step of a chunk may point past the rows: any finite double will do there
+      uint32_t ad[3][3], st[3], dd[3];
+      int mj[3], mc[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { const int kap = 4 * u + lk; mj[u] = (kap * 11) >> 5; mc[u] = kap - 3 * mj[u]; }      // kap / 3, kap % 3 for kap < 12
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const bool isw = ent[t] < BA_RM_MF_RHS;
+        st[t] = isw ? 4u * rs8 : 192u;
+        const uint32_t base = isw ? row0 + ent[t] * 8u : 24u, per = isw ? rs8 : 48u;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) ad[t][u] = base + (uint32_t)mj[u] * per + (uint32_t)mc[u] * 8u;
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) dd[u] = ((uint32_t)mj[u] * 6u + (uint32_t)mc[u]) * 8u;
+      const char* bb = reinterpret_cast<const char*>(slots);
+      auto ldsd = [&](uint32_t off) { return *reinterpret_cast<const double*>(bb + off); };
       if (NT <= 2) {
         for (int q = 0; q < niter; ++q) {
+          if (q == niter - 1) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { ad[0][u] = min(ad[0][u], lim); ad[1][u] = min(ad[1][u], lim); }
+          }
           double Bv0[3], Bv1[3], Dv[3];
 #pragma unroll
-          for (int u = 0; u < 3; ++u) {                            // all nine reads first, then the nine instructions
-            const int j = 4 * q + mj[u];
-            const bool in = j < m;
-            Dv[u] = in ? buf[64 * 18 + j * 6 + mc[u]] : 0.0;
-            Bv0[u] = in && vb0 ? buf[o0b + j * s0b + mc[u]] : 0.0;
-            Bv1[u] = in && vb1 ? buf[o1b + j * s1b + mc[u]] : 0.0;
+          for (int u = 0; u < 3; ++u) {                            // all reads first, then the instructions
+            Dv[u] = ldsd(dd[u]);
+            Bv0[u] = ldsd(ad[0][u]);
+            Bv1[u] = NT > 1 ? ldsd(ad[1][u]) : 0.0;
           }
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
-            const double A0 = va0 ? Bv0[u] * Dv[u] : 0.0, A1 = va1 ? Bv1[u] * Dv[u] : 0.0;
+            const double A0 = Bv0[u] * Dv[u];
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv0[u], acc[0], 0, 0, 0);
             if (NT > 1) {
+              const double A1 = Bv1[u] * Dv[u];
               acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv1[u], acc[1], 0, 0, 0);
               acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv1[u], acc[2], 0, 0, 0);
             }
           }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) { dd[u] += 192u; ad[0][u] += st[0]; ad[1][u] += st[1]; }
         }
       } else {
         // six or seven free key frames: the third tile column (0,2) (1,2) (2,2) lives in temporaries for this chunk only
@@ -638,15 +677,18 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
 #pragma unroll
         for (int t = 0; t < 3; ++t) tmp[t] = (ba_v4d){0.0, 0.0, 0.0, 0.0};
         for (int q = 0; q < niter; ++q) {
+          if (q == niter - 1) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { ad[0][u] = min(ad[0][u], lim); ad[1][u] = min(ad[1][u], lim); ad[2][u] = min(ad[2][u], lim); }
+          }
+          // one inner index at a time (four reads, six instructions), the next one's operands requested first: the twelve operands of a
+          // step alive at once, next to six tiles, spilled the chunk's just-requested operands
+          double c0 = ldsd(ad[0][0]), c1 = ldsd(ad[1][0]), c2 = ldsd(ad[2][0]), cd = ldsd(dd[0]);
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
-            const int j = 4 * q + mj[u];
-            const bool in = j < m;
-            const double dvv = in ? buf[64 * 18 + j * 6 + mc[u]] : 0.0;
-            const double b0 = in && vb0 ? buf[o0b + j * s0b + mc[u]] : 0.0;
-            const double b1 = in && vb1 ? buf[o1b + j * s1b + mc[u]] : 0.0;
-            const double b2 = in && vb2 ? buf[o2b + j * s2b + mc[u]] : 0.0;
-            const double A0 = va0 ? b0 * dvv : 0.0, A1 = va1 ? b1 * dvv : 0.0, A2 = va2 ? b2 * dvv : 0.0;
+            const double b0 = c0, b1 = c1, b2 = c2, dv = cd;
+            if (u < 2) { c0 = ldsd(ad[0][u + 1]); c1 = ldsd(ad[1][u + 1]); c2 = ldsd(ad[2][u + 1]); cd = ldsd(dd[u + 1]); }
+            const double A0 = b0 * dv, A1 = b1 * dv, A2 = b2 * dv;
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, b1, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, b1, acc[2], 0, 0, 0);
@@ -654,6 +696,8 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
             tmp[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, b2, tmp[1], 0, 0, 0);
             tmp[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, b2, tmp[2], 0, 0, 0);
           }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) { dd[u] += 192u; ad[0][u] += st[0]; ad[1][u] += st[1]; ad[2][u] += st[2]; }
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -666,8 +710,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
     // ---------------------------------------------------------------- end of the run (or of this wavefront's range): one set of LDS additions
     if (d_cur.z != desc.z) {
       if (hp_slot >= 0) {
-        const int j = ((lane - a) * invk) >> 16;
-        double* base = Dg + ((size_t)(j & (BA_SE_DCOPIES - 1)) * np + hp_slot) * BA_SE_DSTRIDE;
+        double* base = Dg + ((size_t)(jpt & (BA_SE_DCOPIES - 1)) * np + hp_slot) * BA_SE_DSTRIDE;
 #pragma unroll
         for (int i = 0; i < 21; ++i) unsafeAtomicAdd(base + i, -hp[i]);
 #pragma unroll
@@ -679,7 +722,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
       // accumulator g of tile (ti, tj) in lane l is G[16 ti + (l >> 4) + 4 g][16 tj + (l & 15)]: the upper triangle (and the rhs column) goes
       // out, to the places the host worked out per lane (run_fl)
       {
-        const uint32_t* f = se.run_fl + ((size_t)desc.z * 64 + lane) * 12;
+        const BA_AS1 uint32_t* f = se.run_fl + ((size_t)desc.z * 64 + lane) * 12;
         uint32_t w[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) w[i] = f[i];
@@ -690,7 +733,6 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDev d, BaSe se
           acc[t] = (ba_v4d){0.0, 0.0, 0.0, 0.0};
         }
       }
-      if (d_cur.z >= 0) load_tab(d_cur.z);                         // the next run's entries travel while its first chunk's rows are built
       BA_RM_STAMP(8);                                              // flush
     }
   }

@@ -34,6 +34,39 @@ struct BaItem {
   BaSe se;                                   // edge-major Schur work list (se.R > 0: the group runs kb_ba_schur_edges instead of kb_ba_schur_points)
   BaLmDev* lm; BaLmDev* hlm;                 // device-side LM state and its pinned host mirror (dyn.dev_lm)
 };
+// the same with global-memory pointer types (see BaDevG): what a kb_ba_* kernel builds from its window's BaItem before it calls a body.
+// BaGP<T> holds the pointer in address space 1; used directly ([] / ->) it is a global access, handed to a body's `T*` parameter it converts
+// with ONE address-space cast, which the compiler's address-space inference follows back after inlining (a cast pair would fold away)
+template <class T> struct BaGP {
+  BA_AS1 T* p;
+  __device__ __forceinline__ BaGP() {}
+  __device__ __forceinline__ BaGP(T* q) : p((BA_AS1 T*)q) {}
+  __device__ __forceinline__ operator T*() const { return (T*)p; }
+  __device__ __forceinline__ BA_AS1 T& operator[](size_t i) const { return p[i]; }
+  __device__ __forceinline__ BA_AS1 T* operator->() const { return p; }
+};
+struct BaGP2 {      // the two estimate buffers: picked with a select (an indexed array member would put the whole view into scratch memory)
+  BaGP<double> a, b;
+  __device__ __forceinline__ BaGP<double> operator[](int i) const { BaGP<double> r; r.p = i ? b.p : a.p; return r; }
+};
+struct BaItemG {
+  BaDevG d;
+  BaGP2 poses, pts;
+  BaGP<double> Hll, bl, Hpl, Hpp, bp, pose_partial, Dinv, db, chunk_sum, x, partial, scal, hscal;
+  BaGP<const int2> chunk_range, tup;
+  BaGP<const int> pair_of_block, pair_chunk_off;
+  BaGP<uint8_t> flags;
+  int nblk_e, nblk_p, nchunks, block_free;
+  BaSpG sp; BaSeG se;
+  BaGP<BaLmDev> lm, hlm;
+  __device__ __forceinline__ BaItemG(const BaItem& t)
+      : d(t.d), Hll(t.Hll), bl(t.bl), Hpl(t.Hpl), Hpp(t.Hpp), bp(t.bp), pose_partial(t.pose_partial), Dinv(t.Dinv), db(t.db), chunk_sum(t.chunk_sum), x(t.x),
+        partial(t.partial), scal(t.scal), hscal(t.hscal), chunk_range(t.chunk_range), tup(t.tup), pair_of_block(t.pair_of_block),
+        pair_chunk_off(t.pair_chunk_off), flags(t.flags), nblk_e(t.nblk_e), nblk_p(t.nblk_p), nchunks(t.nchunks), block_free(t.block_free), sp(t.sp), se(t.se),
+        lm(t.lm), hlm(t.hlm) {
+    poses.a = BaGP<double>(t.poses[0]); poses.b = BaGP<double>(t.poses[1]); pts.a = BaGP<double>(t.pts[0]); pts.b = BaGP<double>(t.pts[1]);
+  }
+};
 // ... and what changes from launch to launch, passed BY VALUE as a kernel argument: no host->device copy per Levenberg step
 struct BaDyn {
   double lambda[BA_MAX_GROUP];
@@ -97,7 +130,7 @@ k_ba_reduce2(const double* partial, int n, double* scal) { ba_reduce2_body(block
 // ------------------------------------------------------------------------------------------------ many windows per launch
 #define BA_ITEM(PHASE, NBLK)                                                                              \
   const int z = blockIdx.z;                                                                               \
-  const BaItem& it = items[z];                                                                            \
+  const BaItemG it(items[z]);                                                                             \
   int ba_ph = dyn.phase[z], cur = dyn.cur[z];                                                             \
   double ba_lambda = dyn.lambda[z];                                                                       \
   bool ba_first = dyn.first_iter[z] != 0;                                                                 \
@@ -265,7 +298,7 @@ extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_runs
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_schur_edges_reduce(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.se.nchunks > 0 ? it.se.npairs2 : 0)
-  BaSp v;                                          // the range sum only looks at these three fields
+  BaSpG v;                                         // the range sum only looks at these three fields
   v.R = it.se.R_rm + it.se.R; v.npairs = it.se.npairs2; v.partial = it.se.partial;
   ba_schur_reduce_body(blockIdx.x, v, it.chunk_sum);
   if (dyn.fused_lin && (int)blockIdx.x < it.d.np) {      // bp of key frame blockIdx.x: the ranges' sums, added in fixed order
@@ -298,7 +331,7 @@ extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3(const BaIt
 extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3r(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
   ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal,
-                       true, it.se.partial, it.se.bp_partial, it.se.gsum ? 1 : it.se.R_rm + it.se.R, it.se.npairs2, it.se.gsum != 0);
+                       true, (double*)it.se.partial, (double*)it.se.bp_partial, it.se.gsum ? 1 : it.se.R_rm + it.se.R, it.se.npairs2, it.se.gsum != 0);
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
@@ -315,8 +348,7 @@ __device__ __forceinline__ void kb_ba_reduce2_window(const BaItem* __restrict__ 
   BA_ITEM(phase, 1)
   ba_reduce2_body(0, 1, it.partial, it.se.Rt > 0 ? it.se.Rt : it.nblk_p, it.scal, it.hscal);   // partial sums of kb_ba_trial_edges / kb_ba_trial_points
   if (dyn.dev_lm && threadIdx.x == 0) {
-    int ok2;
-    memcpy(&ok2, &it.scal[4], sizeof(int));
+    const int ok2 = (int)__double_as_longlong(it.scal[4]);      // (the solver's status word sits in the low half of scal[4])
     ba_lm_after_trial(it.lm, it.hlm, it.scal[1], it.scal[2], ok2, dyn.fused_lin != 0);
   }
 }
@@ -342,7 +374,7 @@ extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* _
   // the driver only needs the NUMBER of outliers of a window (cms_ba_stats); the flags stay on the device for cms_ba_read
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = __syncthreads_count(e < it.d.E && it.flags[e] != 0);
-  if (threadIdx.x == 0 && n > 0) atomicAdd(&it.lm->n_out[dyn.set_level ? 0 : 1], n);
+  if (threadIdx.x == 0 && n > 0) atomicAdd((int*)&it.lm->n_out[dyn.set_level ? 0 : 1], n);
 }
 // start of a stage: the windows' Levenberg state comes from the pinned host block the driver just filled (no H2D copy in the stream),
 // the outlier counters are cleared by the first stage of a call

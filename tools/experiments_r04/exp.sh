@@ -26,6 +26,21 @@ case "$1" in
   bench)
     shift
     for v in ${@:-default}; do CMS_HIP_LIB=$(libpath $v) bash tools/gb.sh r04_$v | tee -a $O/bench.txt; done ;;
+  pmcba)   # instruction counters of the local-BA kernels, 16 tracked windows per launch, per library variant
+    shift
+    R=$PWD
+    for v in ${@:-default}; do
+      OUT=$R/$O/pmc_$v; rm -rf $OUT; mkdir -p $OUT
+      i=0
+      for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VMEM"; do
+        i=$((i+1))
+        (cd /tmp && TMPDIR=/tmp CMS_HIP_LIB=$(cd $R && libpath $v) timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT -o p$i -- python $R/tools/prof_ba_many.py 16 track diff > $OUT/p$i.log 2>&1)
+      done
+      rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv
+      echo "== $v"; python tools/pmc_mix.py $OUT | grep "schur\|trial\|reduce2" | tee -a $O/pmcba.txt
+    done ;;
+  batests)  # the BA parity tests only
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ba_" 2>&1 | tail -8 | tee $O/batests.txt ;;
   tests)
     timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/tests.txt ;;
   *) echo "unknown case $1"; exit 2 ;;
