@@ -52,7 +52,9 @@ class GpuBackend:
     """the product: every call is a C-ABI entry of libcubemapslam_hip.so"""
     name = "hip"
 
-    def __init__(self, camd, mask, device=0):
+    def __init__(self, camd, mask, device=0, gaussian_mode=0):
+        """gaussian_mode: cms_set_gaussian_mode -- 0 the integer definition of the 8-bit GaussianBlur, 1 what an x86 (SSE2) build of OpenCV <= 3.2
+        computes (the definition the reference's maintainers get: integration/CubemapHipBridge.cpp selects it)"""
         from . import api
         self.api = api
         self.camd = camd
@@ -61,6 +63,8 @@ class GpuBackend:
         self.ctx_trk = api.Context(camd, nfeatures=nf, max_batch=1, device=device)
         for c in (self.ctx_ini, self.ctx_trk):
             c.set_mask(mask)
+            if gaussian_mode:
+                c.set_gaussian_mode(gaussian_mode)
         self.cur = None
         self.device = device
 

@@ -55,6 +55,14 @@ cms_ctx* CreateContext(const cms_orb_params& orb) {
   cms_ctx* ctx = nullptr;
   check(cms_ctx_create(&ctx, g_device, &c, &orb, 1), "cms_ctx_create");
   check(cms_set_distance_bounds_mode(ctx, 1), "cms_set_distance_bounds_mode");     // map points' bounds come from MapPoint's public getters
+  // Which 8-bit GaussianBlur (ORBExtractor.cpp:907-908)?  The reference links OpenCV 2.4.11 / 3.2 (README.md:59); on x86 those run the SSE2 column
+  // functor (float sums, ties to even) -- definition 1.  A build of the reference on a machine without SSE2 (or against an OpenCV built with
+  // -DENABLE_SSE2=OFF) runs the integer column pass: define CUBEMAP_HIP_INTEGER_GAUSSIAN for that one (definition 0, the library's own default).
+#ifdef CUBEMAP_HIP_INTEGER_GAUSSIAN
+  check(cms_set_gaussian_mode(ctx, 0), "cms_set_gaussian_mode");
+#else
+  check(cms_set_gaussian_mode(ctx, 1), "cms_set_gaussian_mode");
+#endif
   return ctx;
 }
 

@@ -6,14 +6,14 @@ import orc
 class OracleBackend:
     name = "oracle"
 
-    def __init__(self, camd, mask):
+    def __init__(self, camd, mask, gaussian_mode=0):
         self.camd = camd
         self.cam = orc.make_camera(camd)
         self.m1, self.m2 = orc.build_lut(self.cam)
         self.mask = mask
         nf = camd["nfeatures"]
-        self.orb_ini = orc.Orb(nfeatures=3 * nf)
-        self.orb_trk = orc.Orb(nfeatures=nf)
+        self.orb_ini = orc.Orb(nfeatures=3 * nf, gaussian_column_mode=gaussian_mode)
+        self.orb_trk = orc.Orb(nfeatures=nf, gaussian_column_mode=gaussian_mode)
         self.cur = None
         # ORBextractor's tables (ORBExtractor.cpp:386-403): sf[i] = float(sf[i-1] * (double)1.2f), sigma2 = sf^2, inverse in float
         sf = [np.float32(1.0)]

@@ -11,13 +11,16 @@ from oracle_backend import OracleBackend
 pytestmark = pytest.mark.gpu
 
 
-def test_closed_loop_product_equals_oracle_frame_by_frame():
+@pytest.mark.parametrize("gaussian_mode", [0, 1])
+def test_closed_loop_product_equals_oracle_frame_by_frame(gaussian_mode):
+    """gaussian_mode 0: the integer definition of OpenCV's 8-bit GaussianBlur (the definition of record); 1: the float column pass an x86 (SSE2) build of
+    OpenCV <= 3.2 runs -- what a maintainer of the reference gets through integration/CubemapHipBridge.cpp.  Both loops must close."""
     camd = synth.camera("lafida", 550)
     mask = synth.cubemap_valid_mask(camd)
     frames, gts = harness.render_sequence(camd, 14)
     kw = dict(kf_every=4, ba_window=6, new_points_per_kf=400)
-    gpu = harness.GpuBackend(camd, mask)
-    ora = OracleBackend(camd, mask)
+    gpu = harness.GpuBackend(camd, mask, gaussian_mode=gaussian_mode)
+    ora = OracleBackend(camd, mask, gaussian_mode=gaussian_mode)
     # every local-BA problem the PRODUCT's loop poses is also given to the oracle: on identical input the outlier flags and iteration counts
     # must be identical and the estimates agree within the BA bar.  (Between the two closed loops the BA inputs differ in the last float
     # digits -- the write-back goes through float -- and an observation whose chi2 sits on the 5.991 threshold may then fall on either

@@ -70,17 +70,21 @@ def test_lut_and_remap_bit_exact():
         ctx.close()
 
 
+@pytest.mark.parametrize("gaussian_mode", [0, 1])
 @pytest.mark.parametrize("name,F,nfeat,Ih", [("lafida", 450, 2000, None), ("front", 650, 3000, 1024), ("lafida", 550, 2000, None),
                                              ("front", 650, 3000, None)])
-def test_extract_stage_by_stage_bit_exact(name, F, nfeat, Ih):
+def test_extract_stage_by_stage_bit_exact(name, F, nfeat, Ih, gaussian_mode):
     """configs[0] (Lafida F=450), configs[1] (single 1280x1024 frame, F=650, 5-face ORB extract), configs[2]'s extractor geometry
-    (Lafida F=550: what bench.py times) and configs[4]'s (front_cam 1280x720, F=650, nFeatures 3000) of BASELINE.json."""
+    (Lafida F=550: what bench.py times) and configs[4]'s (front_cam 1280x720, F=650, nFeatures 3000) of BASELINE.json -- each under both
+    definitions of the 8-bit Gaussian (cms_set_gaussian_mode: 0 integer, 1 the SSE2 float column of an x86 OpenCV <= 3.2, ORBExtractor.cpp:907-908)."""
     camd, ocam, _ = _cfg(name, F, nfeat, Ih)
     ctx = api.Context(camd, nfeatures=nfeat, max_batch=2)
     mask = synth.cubemap_valid_mask(camd)
     ctx.set_mask(mask)
+    if gaussian_mode:
+        ctx.set_gaussian_mode(gaussian_mode)
     m1, m2 = orc.build_lut(ocam)
-    o = orc.Orb(nfeatures=nfeat)
+    o = orc.Orb(nfeatures=nfeat, gaussian_column_mode=gaussian_mode)
     frames = np.stack([synth.texture(camd["Ih"], camd["Iw"], 1), synth.texture(camd["Ih"], camd["Iw"], 2)])
     ctx.upload(frames)
     ctx.process(2, True)

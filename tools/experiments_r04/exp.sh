@@ -39,6 +39,10 @@ case "$1" in
       rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv
       echo "== $v"; python tools/pmc_mix.py $OUT | grep "schur\|trial\|reduce2" | tee -a $O/pmcba.txt
     done ;;
+  rmclk)   # cycle stamps of one wavefront of the run-major body (needs tools/ab_build.sh rmclk -DBA_RM_CLK)
+    CMS_HIP_LIB=$(libpath rmclk) timeout 300 python tools/prof_rm_clk.py 16 2>&1 | tail -12 | tee $O/rmclk.txt ;;
+  waves)   # the Schur kernel with fewer wavefronts per workgroup: how much of its time is latency?
+    for w in 8 6 4 2; do echo "CMS_BA_SE_WAVES=$w: $(CMS_BA_SE_WAVES=$w timeout 300 python tools/prof_ba_many.py 16 track diff 3 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/waves.txt; done ;;
   batests)  # the BA parity tests only
     timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ba_" 2>&1 | tail -8 | tee $O/batests.txt ;;
   tests)
