@@ -235,6 +235,28 @@ class Context:
         _chk(lib().cms_remap_extract(self.h, _p(fisheye), fisheye.strides[0], _p(kps), _p(desc), cap, C.byref(n)), "cms_remap_extract")
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def remap_extract_rays(self, fisheye, cap=None):
+        """cms_remap_extract_rays: key points, descriptors and Frame::mvKeyRays (n x 3 float) of one frame, one synchronisation"""
+        fisheye = np.ascontiguousarray(fisheye, np.uint8)
+        cap = cap or self.geom.kp_cap
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); rays = np.zeros((cap, 3), np.float32)
+        n = C.c_int()
+        _chk(lib().cms_remap_extract_rays(self.h, _p(fisheye), fisheye.strides[0], _p(kps), _p(desc), _p(rays), cap, C.byref(n)), "cms_remap_extract_rays")
+        return kps[:n.value].copy(), desc[:n.value].copy(), rays[:n.value].copy()
+
+    def fetch_rays(self, b):
+        """cms_frames_fetch_rays: mvKeyRays of frame b of the last process() call"""
+        cap = self.geom.kp_cap
+        rays = np.zeros((cap, 3), np.float32)
+        n = C.c_int()
+        _chk(lib().cms_frames_fetch_rays(self.h, b, _p(rays), cap, C.byref(n)), "cms_frames_fetch_rays")
+        return rays[:n.value].copy()
+
+    def rays_ptr(self):
+        a = C.c_void_p()
+        _chk(lib().cms_frames_rays(self.h, C.byref(a)), "cms_frames_rays")
+        return a.value
+
     # ---- batched device path
     def upload(self, frames):
         frames = np.ascontiguousarray(frames, np.uint8)
@@ -485,6 +507,18 @@ def make_keyframe(kf):
     K.nnodes = len(keep[4]); K.node_id = keep[4].ctypes.data; K.node_off = keep[5].ctypes.data; K.node_feat = keep[6].ctypes.data
     K.median_depth = float(kf["median_depth"])
     return K, keep
+
+
+def search_for_triangulation(ctx, K1, K2, E12=None, check_orientation=False):
+    """cms_search_for_triangulation: ORBMatcher::SearchForTriangulation(pKF1, pKF2, E12, ...) alone.  K1, K2: Keyframe structs; E12 (9 floats,
+    row major) or None = ComputeE12 of the two poses.  Returns (matches12 int32[n1], nmatches)."""
+    m = np.full(max(K1.n, 1), -1, np.int32)
+    n = C.c_int()
+    e = None if E12 is None else np.ascontiguousarray(E12, np.float32)
+    lib().cms_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _chk(lib().cms_search_for_triangulation(ctx.h, C.byref(K1), C.byref(K2), _p(e) if e is not None else None, int(check_orientation), _p(m), C.byref(n)),
+         "cms_search_for_triangulation")
+    return m[:K1.n].copy(), n.value
 
 
 def create_new_map_points(ctx, jobs, check_orientation=False, cap=None):

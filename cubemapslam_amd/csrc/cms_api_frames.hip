@@ -65,12 +65,12 @@ struct cms_ctx {
   hipEvent_t ev_extracted = nullptr; bool extracted_recorded = false;   // end of the last cms_frames_process (cms_stream_wait_extracted)
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;          // pinned staging of the one-frame host entries (one copy each way)
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
-  uint16_t* d_order = nullptr; uint32_t* d_aux_sorted = nullptr;      // per frame: the order k_describe works through the key points in (k_cull)
+  uint32_t* d_order = nullptr; uint32_t* d_aux_sorted = nullptr; int* d_walk_cnt = nullptr; float* d_rays = nullptr;      // the batch's key-point walk: the order k_describe works in (k_cull)
   // match scratch
   void* d_match = nullptr; size_t match_bytes = 0;
   // profiling
   bool prof = false;
-  bool desc_spatial = false;         // k_describe walks a frame's key points in spatial order on one XCD (CMS_DESC_SPATIAL_ORDER=1)
+  bool desc_spatial = false;         // k_describe works through the batch's key points in spatial order, an eighth of the walk per XCD (CMS_DESC_SPATIAL_ORDER=1)
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t fast_lds = 0, qt_lds = 0;
 };
@@ -161,7 +161,7 @@ static void cms_ctx_free(cms_ctx* c) {
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_fish, c->d_lut, c->d_pyr, c->d_mask, c->d_tab, c->d_pattern, c->d_cand, c->d_node, c->d_cand_cnt,
                   c->d_overflow, c->d_qt_out, c->d_qt_cnt, c->d_kps, c->d_aux, c->d_order, c->d_aux_sorted, c->d_desc, c->d_kp_cnt, c->d_match, c->d_cell_cand,
-                  c->d_cell_cnt, c->d_cells_all, c->d_cells_nz, c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid, c->d_area_bsum, c->d_area_tmp};
+                  c->d_cell_cnt, c->d_cells_all, c->d_cells_nz, c->d_area_sorted, c->d_area_cell_start, c->d_area_nvalid, c->d_area_bsum, c->d_area_tmp, c->d_walk_cnt, c->d_rays};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_fish_stage) (void)hipHostFree(c->h_fish_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -239,11 +239,12 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   g.list_cap = wCellMax * hCellMax;
   g.cell_cap = (int)align_up((size_t)((wCellMax + 1) / 2) * ((hCellMax + 1) / 2), 8);   // strict 3x3 maxima cannot be 8-adjacent
   g.dbg_stop = getenv("CMS_DBG_FAST_STOP") ? atoi(getenv("CMS_DBG_FAST_STOP")) : 0;
-  // CMS_DESC_SPATIAL_ORDER=1: k_describe walks every frame's key points band by band on one XCD (k_cull builds the order).  Measured on 256
-  // frames (profiles/r02_describe_order.txt): HBM fetch 2.39 GB -> 0.86 GB per dispatch (3.2x -> 1.16x the patch bytes), kernel time 0.63 ->
-  // 0.66 ms -- the kernel is bound by its vector-ALU issue (748 instructions per key point = 0.63 ms), not by these bytes, so list order
-  // (all XCDs on every frame) stays the default
-  c->desc_spatial = getenv("CMS_DESC_SPATIAL_ORDER") != nullptr && g.kp_cap <= CMS_ORDER_MAX;
+  // CMS_DESC_SPATIAL_ORDER=1: k_describe works through the batch's key points band by band of their levels (k_cull builds the walk), an eighth of
+  // the walk per XCD: a third of the HBM fetches of the octree's list order (profiles/r02_describe_order.txt: 2.39 GB -> 0.86 GB per 256 frames).
+  // It is NOT the default: the kernel is bound by its vector-ALU issue, alone (0.600 against 0.576 ms per 256 frames) and inside bench.py's
+  // step next to the local BA's traffic (round 4, four profiled runs each: 0.84-1.02 ms against 0.65-0.87 in list order) -- the bytes it
+  // saves are not what the kernel waits for.
+  c->desc_spatial = getenv("CMS_DESC_SPATIAL_ORDER") != nullptr && g.kp_cap <= CMS_ORDER_MAX && max_batch <= 65535;
   g.gauss_column_mode = 0;
   if (wCellMax > 60 || hCellMax > 60) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "FAST cell larger than 60 pixels"); }
   if (orb->scale_factor < 1.01f || orb->scale_factor > 1.9f) { delete c; return cms_fail(CMS_ERR_UNSUPPORTED, "scaleFactor must be in [1.01, 1.9]"); }
@@ -285,7 +286,9 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   ALLOC(c->d_qt_cnt, B * L * sizeof(int));
   ALLOC(c->d_kps, B * g.kp_cap * sizeof(CmsKeyPoint));
   ALLOC(c->d_aux, B * g.kp_cap * 4);
-  ALLOC(c->d_order, B * g.kp_cap * 2);
+  ALLOC(c->d_order, B * g.kp_cap * 4);
+  ALLOC(c->d_walk_cnt, 16);
+  ALLOC(c->d_rays, B * g.kp_cap * 12);      // mvKeyRays of every frame (k_cull)
   ALLOC(c->d_aux_sorted, B * g.kp_cap * 4);
   ALLOC(c->d_desc, B * g.kp_cap * 32);
   ALLOC(c->d_kp_cnt, B * sizeof(int));
@@ -534,20 +537,20 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
   if (c->prof) hipEventRecord(c->ev[3], s);
   hipLaunchKernelGGL(k_quadtree, dim3(L, B), dim3(512), c->qt_lds, s, g, (const uint32_t*)c->d_cell_cand, (const int*)c->d_cell_cnt,
                      c->d_cand, c->d_cand_cnt, c->d_overflow,
-                     c->d_node, c->d_qt_out, c->d_qt_cnt);
+                     c->d_node, c->d_qt_out, c->d_qt_cnt, c->desc_spatial ? c->d_walk_cnt : nullptr);
   if (c->prof) hipEventRecord(c->ev[4], s);
   hipLaunchKernelGGL(k_cull, dim3(B), dim3(256), 0, s, g, (const uint32_t*)c->d_qt_out, (const int*)c->d_qt_cnt,
-                     (const uint8_t*)c->d_mask, c->mstride, c->d_kps, c->d_aux, c->d_kp_cnt, c->desc_spatial ? c->d_order : nullptr, c->d_aux_sorted);
+                     (const uint8_t*)c->d_mask, c->mstride, c->d_kps, c->d_aux, c->d_kp_cnt, c->desc_spatial ? c->d_order : nullptr, c->d_aux_sorted, c->d_walk_cnt, c->d_rays);
   if (c->prof) hipEventRecord(c->ev[5], s);
   {
     auto kdesc = g.gauss_column_mode == 1 ? k_describe_sse2 : k_describe;
-    if (c->desc_spatial)      // one frame per XCD, key points in spatial order (see k_cull)
-      hipLaunchKernelGGL(kdesc, dim3((unsigned)(((size_t)((B + 7) / 8) * 8 * g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB)), dim3(64 * CMS_DESC_WPB), 0, s,
+    if (c->desc_spatial)      // the batch's walk in eight segments, one per XCD (see k_cull); the grid covers the longest walk possible (+ 8: the segments' rounding)
+      hipLaunchKernelGGL(kdesc, dim3((unsigned)(((size_t)B * g.kp_cap + 8 + CMS_DESC_WPB - 1) / CMS_DESC_WPB)), dim3(64 * CMS_DESC_WPB), 0, s,
                          (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps, (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc,
-                         (const uint16_t*)c->d_order, (const uint32_t*)c->d_aux_sorted, B);
+                         (const uint32_t*)c->d_order, (const uint32_t*)c->d_aux_sorted, (const int*)c->d_walk_cnt);
     else
       hipLaunchKernelGGL(kdesc, dim3((g.kp_cap + CMS_DESC_WPB - 1) / CMS_DESC_WPB, B), dim3(64 * CMS_DESC_WPB), 0, s, (const uint8_t*)c->d_pyr, g.pyr_bytes, g, c->d_kps,
-                         (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc, (const uint16_t*)nullptr, (const uint32_t*)nullptr, B);
+                         (const uint32_t*)c->d_aux, (const int*)c->d_kp_cnt, (const float*)c->d_pattern, c->d_desc, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const int*)nullptr);
   }
   if (c->prof) hipEventRecord(c->ev[6], s);
   if (c->ev_extracted) { HIPCHK(hipEventRecord(c->ev_extracted, s)); c->extracted_recorded = true; }
@@ -586,6 +589,22 @@ extern "C" int cms_frames_results(cms_ctx* c, void** d_kps, void** d_desc, void*
   if (d_kps) *d_kps = c->d_kps;
   if (d_desc) *d_desc = c->d_desc;
   if (d_counts) *d_counts = c->d_kp_cnt;
+  return CMS_OK;
+}
+extern "C" int cms_frames_rays(cms_ctx* c, void** d_rays) {
+  if (!c || !d_rays) return cms_fail(CMS_ERR_ARG, "cms_frames_rays: bad argument");
+  *d_rays = c->d_rays;
+  return CMS_OK;
+}
+extern "C" int cms_frames_fetch_rays(cms_ctx* c, int b, float* rays, int cap, int* n) {
+  if (!c || b < 0 || b >= c->max_batch || !n || !rays) return cms_fail(CMS_ERR_ARG, "cms_frames_fetch_rays: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int cnt = 0;
+  HIPCHK(hipMemcpy(&cnt, c->d_kp_cnt + b, sizeof(int), hipMemcpyDeviceToHost));
+  *n = cnt;
+  if (cnt > cap) return cms_fail(CMS_ERR_OVERFLOW, "cms_frames_fetch_rays: caller capacity too small");
+  if (cnt > 0) HIPCHK(hipMemcpy(rays, c->d_rays + (size_t)b * c->g.kp_cap * 3, (size_t)cnt * 12, hipMemcpyDeviceToHost));
   return CMS_OK;
 }
 extern "C" int cms_frames_fetch(cms_ctx* c, int b, cms_keypoint* kps, uint8_t* desc, int cap, int* n) {
@@ -634,14 +653,22 @@ static int cms_hstage(cms_ctx* c, size_t bytes);
 // One frame, host buffers in and out: ONE synchronisation.  The image leaves from the pinned upload staging without a wait, the kernels follow,
 // and overflow flag | key-point count | key points | descriptors come back as four asynchronous copies into the pinned result staging behind
 // them (the upload, cms_frames_sync and cms_frames_fetch one after the other were five synchronous round trips of 15-20 us each).
+static int cms_remap_extract_impl(cms_ctx* c, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, float* rays, int cap, int* n);
 extern "C" int cms_remap_extract(cms_ctx* c, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n) {
+  return cms_remap_extract_impl(c, fisheye, fstride, kps, desc, nullptr, cap, n);
+}
+extern "C" int cms_remap_extract_rays(cms_ctx* c, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, float* rays, int cap, int* n) {
+  return cms_remap_extract_impl(c, fisheye, fstride, kps, desc, rays, cap, n);
+}
+static int cms_remap_extract_impl(cms_ctx* c, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, float* rays, int cap, int* n) {
   if (!c || !fisheye || !n || cap < 0) return cms_fail(CMS_ERR_ARG, "cms_remap_extract: bad argument");
   int rc = cms_frames_upload_impl(c, fisheye, fstride, 0, 1, false);
   if (rc) return rc;
   rc = cms_launch_frames(c, 1, 1);
   if (rc) return rc;
   const int m = std::min(cap, c->g.kp_cap);
-  const size_t o_kp = 256, o_desc = o_kp + (((size_t)m * sizeof(cms_keypoint) + 255) & ~(size_t)255), total = o_desc + (size_t)m * 32;
+  const size_t o_kp = 256, o_desc = o_kp + (((size_t)m * sizeof(cms_keypoint) + 255) & ~(size_t)255), o_rays = o_desc + (((size_t)m * 32 + 255) & ~(size_t)255),
+               total = o_rays + (rays ? (size_t)m * 12 : 0);
   rc = cms_hstage(c, total);
   if (rc) return rc;
   uint8_t* h = c->h_stage;
@@ -650,6 +677,7 @@ extern "C" int cms_remap_extract(cms_ctx* c, const uint8_t* fisheye, int fstride
   HIPCHK(hipMemcpyAsync(h + 64, c->d_kp_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   if (m > 0 && kps) HIPCHK(hipMemcpyAsync(h + o_kp, c->d_kps, (size_t)m * sizeof(cms_keypoint), hipMemcpyDeviceToHost, s));
   if (m > 0 && desc) HIPCHK(hipMemcpyAsync(h + o_desc, c->d_desc, (size_t)m * 32, hipMemcpyDeviceToHost, s));
+  if (m > 0 && rays) HIPCHK(hipMemcpyAsync(h + o_rays, c->d_rays, (size_t)m * 12, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   int ov = 0, cnt = 0;
   memcpy(&ov, h, sizeof(int)); memcpy(&cnt, h + 64, sizeof(int));
@@ -659,6 +687,7 @@ extern "C" int cms_remap_extract(cms_ctx* c, const uint8_t* fisheye, int fstride
   if (cnt > 0) {
     if (kps) memcpy(kps, h + o_kp, (size_t)cnt * sizeof(cms_keypoint));
     if (desc) memcpy(desc, h + o_desc, (size_t)cnt * 32);
+    if (rays) memcpy(rays, h + o_rays, (size_t)cnt * 12);
   }
   return CMS_OK;
 }

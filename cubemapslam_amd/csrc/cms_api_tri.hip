@@ -151,33 +151,26 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
 }
 }  // namespace
 
-extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyframe* cur, const int* neigh_off, const cms_keyframe* neigh,
-                                         int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
-                                         float* out_x3d) {
-  if (!c || njobs < 0 || cap_per_job < 0 || (njobs > 0 && (!cur || !neigh_off || !n_new)) ||
-      (njobs > 0 && cap_per_job > 0 && (!out_neigh || !out_idx1 || !out_idx2 || !out_x3d)))
-    return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: bad argument");
-  if (njobs == 0) return CMS_OK;
-  if (c->g.nlevels > 16 || c->g.nlevels < 2) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_create_new_map_points: 2..16 pyramid levels");
-  const int nneigh = neigh_off[njobs];
-  if (nneigh < 0 || (nneigh > 0 && !neigh)) return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: bad neighbour list");
-  // ---- flatten: key frames = the njobs current ones, then all neighbours
-  const int nkf = njobs + nneigh;
-  std::vector<CmsTriKF> kfs((size_t)nkf);
-  std::vector<float> median((size_t)nkf);
+// ---- key frames of a call, flattened (features, FeatureVector, poses concatenated) and uploaded into the context's scratch arena; the work
+// area of the call follows at o_work.  kf_at(i): the i-th key frame of the call; the first n_current of them are "current" key frames
+// (max_n1 = their largest feature count); work_bytes(max_n1): what the caller needs behind the key frames.
+template <class KfAt, class WorkBytes>
+static int tri_flatten_upload(cms_ctx* c, int nkf, KfAt&& kf_at, int n_current, const char* who, std::vector<CmsTriKF>& kfs, std::vector<float>& median,
+                              TriDev& dev, size_t& o_work, int& max_n1, WorkBytes&& work_bytes) {
+  kfs.assign((size_t)nkf, CmsTriKF());
+  median.assign((size_t)nkf, 0.f);
   size_t nf = 0, nn = 0, nno = 0, nnf = 0;
-  int max_n1 = 1;
-  auto kf_at = [&](int i) -> const cms_keyframe& { return i < njobs ? cur[i] : neigh[i - njobs]; };
+  max_n1 = 1;
   for (int i = 0; i < nkf; ++i) {
     const cms_keyframe& k = kf_at(i);
-    const int rc = tri_check_keyframe(k, "cms_create_new_map_points: bad key frame (at most 4096 features)");
+    const int rc = tri_check_keyframe(k, who);
     if (rc) return rc;
     CmsTriKF& d = kfs[(size_t)i];
     d.f0 = (int)nf; d.n = k.n; d.node0 = (int)nn; d.nnodes = k.nnodes; d.noff0 = (int)nno; d.nfeat0 = (int)nnf;
     std::memcpy(d.Rcw, k.Rcw, sizeof(d.Rcw)); std::memcpy(d.tcw, k.tcw, sizeof(d.tcw)); std::memcpy(d.Ow, k.Ow, sizeof(d.Ow));
     median[(size_t)i] = k.median_depth;
     nf += (size_t)k.n; nn += (size_t)k.nnodes; nno += (size_t)k.nnodes + 1; nnf += k.nnodes > 0 ? (size_t)k.node_off[k.nnodes] : 0;
-    if (i < njobs) max_n1 = std::max(max_n1, k.n);
+    if (i < n_current) max_n1 = std::max(max_n1, k.n);
   }
   std::vector<CmsKeyPoint> kp(nf + 1);
   std::vector<uint8_t> desc(32 * nf + 32);
@@ -207,8 +200,8 @@ extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyfra
   const size_t o_kf = take(kfs.size() * sizeof(CmsTriKF)), o_kp = take(kp.size() * sizeof(CmsKeyPoint)), o_desc = take(desc.size()), o_rays = take(rays.size() * 4),
                o_mp = take(mp.size() * 4), o_fn = take(feat_node.size() * 4), o_nid = take(node_id.size() * 4), o_noff = take(node_off.size() * 4),
                o_nfeat = take(node_feat.size() * 4);
-  const size_t o_work = o;
-  int rc = cms_scratch(c, o_work + tri_work_bytes(njobs, nneigh, max_n1, cap_per_job));
+  o_work = o;
+  int rc = cms_scratch(c, o_work + work_bytes(max_n1));
   if (rc) return rc;
   uint8_t* p = (uint8_t*)c->d_match;
   hipStream_t s = c->stream;
@@ -222,15 +215,87 @@ extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyfra
   HIPCHK(up(o_nid, node_id.data(), node_id.size() * 4));
   HIPCHK(up(o_noff, node_off.data(), node_off.size() * 4));
   HIPCHK(up(o_nfeat, node_feat.data(), node_feat.size() * 4));
-  TriDev dev;
+  HIPCHK(hipStreamSynchronize(s));      // the sources are this function's vectors (the resident store, cms_kfstore_*, is the path without this copy)
   dev.kf = (const CmsTriKF*)(p + o_kf); dev.kp = (const CmsKeyPoint*)(p + o_kp); dev.desc = (const uint4*)(p + o_desc); dev.rays = (const float*)(p + o_rays);
   dev.mp = (const int*)(p + o_mp); dev.feat_node = (const int*)(p + o_fn); dev.node_id = (const int*)(p + o_nid); dev.node_off = (const int*)(p + o_noff);
   dev.node_feat = (const int*)(p + o_nfeat);
+  return CMS_OK;
+}
+
+extern "C" int cms_create_new_map_points(cms_ctx* c, int njobs, const cms_keyframe* cur, const int* neigh_off, const cms_keyframe* neigh,
+                                         int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
+                                         float* out_x3d) {
+  if (!c || njobs < 0 || cap_per_job < 0 || (njobs > 0 && (!cur || !neigh_off || !n_new)) ||
+      (njobs > 0 && cap_per_job > 0 && (!out_neigh || !out_idx1 || !out_idx2 || !out_x3d)))
+    return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: bad argument");
+  if (njobs == 0) return CMS_OK;
+  if (c->g.nlevels > 16 || c->g.nlevels < 2) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_create_new_map_points: 2..16 pyramid levels");
+  const int nneigh = neigh_off[njobs];
+  if (nneigh < 0 || (nneigh > 0 && !neigh)) return cms_fail(CMS_ERR_ARG, "cms_create_new_map_points: bad neighbour list");
+  // ---- flatten: key frames = the njobs current ones, then all neighbours
+  const int nkf = njobs + nneigh;
+  std::vector<CmsTriKF> kfs;
+  std::vector<float> median;
+  auto kf_at = [&](int i) -> const cms_keyframe& { return i < njobs ? cur[i] : neigh[i - njobs]; };
+  TriDev dev;
+  size_t o_work = 0;
+  int max_n1 = 1;
+  int rc = tri_flatten_upload(c, nkf, kf_at, njobs, "cms_create_new_map_points: bad key frame (at most 4096 features)", kfs, median, dev, o_work, max_n1,
+                              [&](int mn1) { return tri_work_bytes(njobs, nneigh, mn1, cap_per_job); });
+  if (rc) return rc;
+  uint8_t* p = (uint8_t*)c->d_match;
   std::vector<int> cur_idx((size_t)njobs), neigh_idx((size_t)nneigh + 1);
   for (int j = 0; j < njobs; ++j) cur_idx[(size_t)j] = j;
   for (int q = 0; q < nneigh; ++q) neigh_idx[(size_t)q] = njobs + q;
   return tri_run(c, dev, kfs.data(), median.data(), njobs, cur_idx.data(), neigh_off, neigh_idx.data(), check_orientation, cap_per_job, p + o_work, n_new,
                  out_neigh, out_idx1, out_idx2, out_x3d);
+}
+
+// ORBMatcher::SearchForTriangulation(pKF1, pKF2, E12, vMatchedPairs) (include/ORBMatcher.h:61, src/ORBMatcher.cpp:971-1125) on its own: what
+// LocalMapping::CreateNewMapPoints calls per neighbour (LocalMapping.cpp:254) before it triangulates.  E12 = NULL: ComputeE12 of the two poses.
+extern "C" int cms_search_for_triangulation(cms_ctx* c, const cms_keyframe* kf1, const cms_keyframe* kf2, const float* E12, int check_orientation,
+                                            int* matches12, int* n_matches) {
+  if (!c || !kf1 || !kf2 || !matches12 || !n_matches) return cms_fail(CMS_ERR_ARG, "cms_search_for_triangulation: bad argument");
+  if (c->g.nlevels > 16 || c->g.nlevels < 2) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_search_for_triangulation: 2..16 pyramid levels");
+  *n_matches = 0;
+  if (kf1->n == 0) return CMS_OK;
+  std::vector<CmsTriKF> kfs;
+  std::vector<float> median;
+  auto kf_at = [&](int i) -> const cms_keyframe& { return i == 0 ? *kf1 : *kf2; };
+  TriDev dev;
+  size_t o_work = 0;
+  int max_n1 = 1;
+  const size_t o_pair = 0, o_job = tri_al(sizeof(CmsTriPair) + 16), o_m = o_job + tri_al(sizeof(CmsTriJob) + 16);
+  int rc = tri_flatten_upload(c, 2, kf_at, 1, "cms_search_for_triangulation: bad key frame (at most 4096 features)", kfs, median, dev, o_work, max_n1,
+                              [&](int mn1) { return o_m + tri_al((size_t)mn1 * 4 + 16) + 256; });
+  if (rc) return rc;
+  uint8_t* p = (uint8_t*)c->d_match + o_work;
+  const size_t o_n = o_m + tri_al((size_t)max_n1 * 4 + 16);
+  CmsTriPair pr;
+  pr.kf2 = 1; pr.skip = 0;
+  if (E12) std::memcpy(pr.E12, E12, sizeof(pr.E12));
+  else tri_h_e12(kfs[0].Rcw, kfs[0].tcw, kfs[1].Rcw, kfs[1].tcw, pr.E12);
+  float C2[3];                                                       // the epipole in the second image (ORBMatcher.cpp:976-982)
+  for (int r = 0; r < 3; ++r) C2[r] = (float)((double)tri_h_small(kfs[1].Rcw + 3 * r, kfs[0].Ow, 1) * 1.0 + (double)kfs[1].tcw[r] * 1.0);
+  track_rays_to_cubemap(c->g.F, C2[0], C2[1], C2[2], pr.ex, pr.ey);
+  CmsTriJob jb; jb.kf1 = 0; jb.pair0 = 0; jb.npairs = 1;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(p + o_pair, &pr, sizeof(pr), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p + o_job, &jb, sizeof(jb), hipMemcpyHostToDevice, s));
+  CmsTriArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.kf = dev.kf; a.pair = (const CmsTriPair*)(p + o_pair); a.job = (const CmsTriJob*)(p + o_job);
+  a.kp = dev.kp; a.desc = dev.desc; a.rays = dev.rays; a.mp = dev.mp; a.feat_node = dev.feat_node;
+  a.node_id = dev.node_id; a.node_off = dev.node_off; a.node_feat = dev.node_feat;
+  a.F = c->g.F;
+  a.check_orientation = check_orientation;
+  for (int l = 0; l < 16; ++l) { a.sf[l] = l < c->g.nlevels ? c->scale[l] : 1.0f; a.sigma2[l] = l < c->g.nlevels ? c->sigma2[l] : 1.0f; }
+  hipLaunchKernelGGL(k_tri_search, dim3(1), dim3(1024), 0, s, a, (int*)(p + o_m), (int*)(p + o_n));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(matches12, p + o_m, (size_t)kf1->n * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(n_matches, p + o_n, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CMS_OK;
 }
 
 // ---- resident key frames: the map's key frames live on the device in fixed-size slots (features, FeatureVector, pose); a call names

@@ -503,9 +503,10 @@ k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, const
 extern "C" __global__ void __launch_bounds__(512)
 k_quadtree(CmsGeom g, const uint32_t* __restrict__ cell_cand, const int* __restrict__ cell_cnt, uint32_t* __restrict__ cand,
            int* __restrict__ cand_cnt, int* __restrict__ overflow, uint16_t* __restrict__ node_of,
-           uint32_t* __restrict__ qt_out, int* __restrict__ qt_cnt) {
+           uint32_t* __restrict__ qt_out, int* __restrict__ qt_cnt, int* __restrict__ walk_cnt) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int l = blockIdx.x, b = blockIdx.y;
+  if (walk_cnt && l == 0 && b == 0 && threadIdx.x == 0) *walk_cnt = 0;      // length of the batch's key-point walk (k_cull appends to it, k_describe reads it)
   const CmsLevel& lv = g.lv[l];
   const int maxn = g.qt_maxn;
   QtWork w;
@@ -584,9 +585,10 @@ k_quadtree(CmsGeom g, const uint32_t* __restrict__ cell_cand, const int* __restr
 // One workgroup per frame walks the levels in order; survivors keep (level, list) order (ORBExtractor.cpp:875-921).
 extern "C" __global__ void __launch_bounds__(256)
 k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ qt_cnt, const uint8_t* __restrict__ mask,
-       int mstride, CmsKeyPoint* __restrict__ kps, uint32_t* __restrict__ aux, int* __restrict__ kp_cnt, uint16_t* __restrict__ order,
-       uint32_t* __restrict__ aux_sorted) {
+       int mstride, CmsKeyPoint* __restrict__ kps, uint32_t* __restrict__ aux, int* __restrict__ kp_cnt, uint32_t* __restrict__ walk,
+       uint32_t* __restrict__ walk_aux, int* __restrict__ walk_cnt, float* __restrict__ rays) {
   __shared__ int wsum[4];
+  __shared__ int s_walk_base;
   __shared__ uint32_t skey[512];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int total = 0;
@@ -623,6 +625,26 @@ k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ q
         kp.x = px; kp.y = py; kp.size = lv.patch_size; kp.angle = -1.f; kp.response = (float)(e >> 24); kp.octave = l;
         kps[(size_t)b * g.kp_cap + pos] = kp;
         aux[(size_t)b * g.kp_cap + pos] = (e & 0xFFFFFFu) | ((uint32_t)l << 24);
+        if (rays) {
+          // Frame::ComputeKeyPointRays -> CamModelGeneral::TransformCubemapToRays (src/Frame.cpp:746-760, include/CamModelGeneral.h:494-513): the pixel's
+          // place inside its face in double, through the face intrinsics fx = fy = cx = cy = F / 2, cast to float, turned into rig axes
+          // (cvtFacesToRig, :388-414), normalised with a double norm and a double reciprocal (cv::norm, Vec3f * double)
+          const float fi = px / Ff, fj = py / Ff;
+          const double Fd = (double)g.F, hF = Fd / 2.0;
+          double di = (double)px, dj = (double)py;
+          di = di - (double)((int)(di / Fd) * g.F); dj = dj - (double)((int)(dj / Fd) * g.F);
+          const float lx = (float)((di - hF) * 1.0 / hF), ly = (float)((dj - hF) * 1.0 / hF), lz = 1.0f;
+          float rx, ry, rz;
+          if (fi >= 0 && fi < 1) { rx = -lz; ry = ly; rz = lx; }                       // LEFT   (FaceInCubemap(Point2f), :445-456: the order of its tests)
+          else if (fi >= 1 && fi < 2 && fj >= 0 && fj < 1) { rx = lx; ry = -lz; rz = ly; }   // UPPER
+          else if (fi >= 1 && fi < 2 && fj >= 1 && fj < 2) { rx = lx; ry = ly; rz = lz; }    // FRONT
+          else if (fi >= 1 && fi < 2) { rx = lx; ry = lz; rz = -ly; }                  // LOWER
+          else { rx = lz; ry = ly; rz = -lx; }                                         // RIGHT
+          const double nrm = sqrt((double)rx * (double)rx + (double)ry * (double)ry + (double)rz * (double)rz);
+          const double sc = nrm > 0 ? 1. / nrm : 0.;
+          float* rp = rays + 3 * ((size_t)b * g.kp_cap + pos);
+          rp[0] = (float)((double)rx * sc); rp[1] = (float)((double)ry * sc); rp[2] = (float)((double)rz * sc);
+        }
       }
       total += chunk;
       __syncthreads();
@@ -631,11 +653,15 @@ k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ q
   if (tid == 0) kp_cnt[b] = total;
   // ---- the order k_describe WORKS in (its output keeps the list order above): by level and band of 64 rows.  A key point's 43 patch rows
   // are 48-byte pieces of 128-byte lines; walked in list order (the octree's node order, scattered over the level) every key point fetched
-  // its ~44 lines from HBM on its own -- 3.2x the patch bytes (profiles/r01).  k_describe gives all key points of a frame to one XCD, i.e.
-  // one L2, and a band of a level is ~100 KB of it: the order inside a band does not matter.  Counting sort on (level, band) in LDS.
-  if (order) {
+  // its ~44 lines from HBM on its own -- 3.2x the patch bytes (profiles/r01, r02_describe_order.txt).  Counting sort on (level, band) in LDS;
+  // the frame's sorted list is then APPENDED to one walk of the whole batch (one atomic per frame: the frames' order in the walk does not
+  // matter, a frame's key points stay together).  k_describe cuts the walk into eight contiguous segments, one per XCD -- neighbours in the
+  // walk share patch rows and meet in one L2 -- with equal numbers of key points per XCD whatever the frames hold (round 2's version pinned
+  // frame f to XCD f mod 8).  Optional (CMS_DESC_SPATIAL_ORDER=1): see cms_ctx_create for the measurements.
+  if (walk) {
     __syncthreads();                                       // the block's own aux[] stores; skey free
     for (int i = tid; i < 512; i += 256) skey[i] = 0;
+    if (tid == 0) s_walk_base = atomicAdd(walk_cnt, total);
     __syncthreads();
     for (int i = tid; i < total; i += 256) {
       const uint32_t a = aux[(size_t)b * g.kp_cap + i];
@@ -650,11 +676,12 @@ k_cull(CmsGeom g, const uint32_t* __restrict__ qt_out, const int* __restrict__ q
       skey[256 + 4 * tid] = base; skey[256 + 4 * tid + 1] = base + c0; skey[256 + 4 * tid + 2] = base + c0 + c1; skey[256 + 4 * tid + 3] = base + c0 + c1 + c2;
     }
     __syncthreads();
+    const size_t wb = (size_t)s_walk_base;
     for (int i = tid; i < total; i += 256) {
       const uint32_t a = aux[(size_t)b * g.kp_cap + i];
       const uint32_t pos = atomicAdd(&skey[256 + min(255u, (a >> 24) * 32 + (((a >> 12) & 0xFFF) >> 6))], 1u);
-      order[(size_t)b * g.kp_cap + pos] = (uint16_t)i;
-      aux_sorted[(size_t)b * g.kp_cap + pos] = a;
+      walk[wb + pos] = ((uint32_t)b << 16) | (uint32_t)i;  // frame | key point (both < 65536: CMS_ORDER_MAX)
+      walk_aux[wb + pos] = a;
     }
   }
 }
@@ -694,7 +721,7 @@ __device__ __constant__ __align__(16) uint32_t k_disc_mask[16 * 8] = {
 template <bool SSE2>
 __device__ __forceinline__ void describe_body(const uint8_t* __restrict__ pyr, size_t pyr_bytes, const CmsGeom& g, CmsKeyPoint* __restrict__ kps,
            const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const float* __restrict__ pattern,
-           uint8_t* __restrict__ desc, const uint16_t* __restrict__ order, const uint32_t* __restrict__ aux_sorted, int B) {
+           uint8_t* __restrict__ desc, const uint32_t* __restrict__ walk, const uint32_t* __restrict__ walk_aux, const int* __restrict__ walk_cnt) {
   // CMS_DESC_WPB key points per workgroup, one per wavefront, no data shared between them (wave-level synchronisation only)
   __shared__ __align__(16) uint8_t raw4[CMS_DESC_WPB][PW * PS + 16];
   __shared__ __align__(16) uint32_t rowp4[CMS_DESC_WPB][((PW + 1) / 2) * RW];      // row sums of rows 2m (low half) and 2m + 1 (high half), column by column
@@ -705,21 +732,23 @@ __device__ __forceinline__ void describe_body(const uint8_t* __restrict__ pyr, s
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #endif
   uint8_t* raw = raw4[wave]; uint32_t* rowp = rowp4[wave]; uint8_t* blr = blr4[wave];
-  // order != nullptr (1-D grid): workgroups go round-robin to the 8 XCDs; XCD x takes frame 8 f + x and walks its key points in the spatial
-  // order k_cull built, so that patch rows shared by neighbouring key points are fetched into that XCD's L2 once
+  // walk != nullptr (1-D grid): workgroups go round-robin to the 8 XCDs; XCD x works through the x-th eighth of the batch's walk (k_cull) in
+  // order, so that patch rows shared by neighbouring key points are fetched into that XCD's L2 once
   int b, k;
-  if (order) {
+  uint32_t a;
+  if (walk) {
     const int L = blockIdx.x * CMS_DESC_WPB + wave, t = L >> 3;
-    const int fgrp = t / g.kp_cap, ks = t - fgrp * g.kp_cap;
-    b = 8 * fgrp + (L & 7);
-    if (b >= B || ks >= kp_cnt[b]) return;
-    k = order[(size_t)b * g.kp_cap + ks];
-    aux = aux_sorted + ks - k;                 // aux[b * kp_cap + k] below then reads aux_sorted[b * kp_cap + ks]: no load behind a load
+    const int N = *walk_cnt, per = (N + 7) >> 3;
+    const int pos = (L & 7) * per + t;
+    if (t >= per || pos >= N) return;
+    const uint32_t w = walk[pos];
+    a = walk_aux[pos];
+    b = (int)(w >> 16); k = (int)(w & 0xFFFFu);
   } else {
     b = blockIdx.y; k = blockIdx.x * CMS_DESC_WPB + wave;
     if (k >= kp_cnt[b]) return;
+    a = aux[(size_t)b * g.kp_cap + k];
   }
-  const uint32_t a = aux[(size_t)b * g.kp_cap + k];
   const int cx = a & 0xFFF, cy = (a >> 12) & 0xFFF, l = a >> 24;
   const CmsLevel& lv = g.lv[l];
   const uint8_t* img = pyr + (size_t)b * pyr_bytes + lv.off;
@@ -862,12 +891,12 @@ __device__ __forceinline__ void describe_body(const uint8_t* __restrict__ pyr, s
 extern "C" __global__ void __launch_bounds__(64 * CMS_DESC_WPB)
 k_describe(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
            const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const float* __restrict__ pattern,
-           uint8_t* __restrict__ desc, const uint16_t* __restrict__ order, const uint32_t* __restrict__ aux_sorted, int B) {
-  describe_body<false>(pyr, pyr_bytes, g, kps, aux, kp_cnt, pattern, desc, order, aux_sorted, B);
+           uint8_t* __restrict__ desc, const uint32_t* __restrict__ walk, const uint32_t* __restrict__ walk_aux, const int* __restrict__ walk_cnt) {
+  describe_body<false>(pyr, pyr_bytes, g, kps, aux, kp_cnt, pattern, desc, walk, walk_aux, walk_cnt);
 }
 extern "C" __global__ void __launch_bounds__(64 * CMS_DESC_WPB)
 k_describe_sse2(const uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsGeom g, CmsKeyPoint* __restrict__ kps,
                 const uint32_t* __restrict__ aux, const int* __restrict__ kp_cnt, const float* __restrict__ pattern,
-                uint8_t* __restrict__ desc, const uint16_t* __restrict__ order, const uint32_t* __restrict__ aux_sorted, int B) {
-  describe_body<true>(pyr, pyr_bytes, g, kps, aux, kp_cnt, pattern, desc, order, aux_sorted, B);
+                uint8_t* __restrict__ desc, const uint32_t* __restrict__ walk, const uint32_t* __restrict__ walk_aux, const int* __restrict__ walk_cnt) {
+  describe_body<true>(pyr, pyr_bytes, g, kps, aux, kp_cnt, pattern, desc, walk, walk_aux, walk_cnt);
 }

@@ -373,6 +373,60 @@ extern "C" __global__ void __launch_bounds__(512) k_create_new_map_points(CmsTri
   if (tid == 0) a.n_new[blockIdx.x] = s_base;
 }
 
+// ORBMatcher::SearchForTriangulation alone (cms_search_for_triangulation): job 0's key frame against the one neighbour of pair 0; matches12[idx1] =
+// index in the neighbour or -1, *n_matches = the count (after the rotation histogram when it is on).  One workgroup: the histogram is per call.
+extern "C" __global__ void __launch_bounds__(1024) k_tri_search(CmsTriArgs a, int* __restrict__ matches12, int* __restrict__ n_matches) {
+  __shared__ int s_hist[32];
+  __shared__ int s_keep[3];
+  __shared__ int s_cnt;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const CmsTriJob jb = a.job[0];
+  const CmsTriKF k1 = a.kf[jb.kf1];
+  const CmsTriPair pr = a.pair[jb.pair0];
+  const CmsTriKF k2 = a.kf[pr.kf2];
+  if (tid < 32) s_hist[tid] = 0;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  auto bin_of = [&](int idx1, int idx2) {
+    float rot = __fsub_rn(a.kp[k1.f0 + idx1].angle, a.kp[k2.f0 + idx2].angle);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / 12));
+    return bin == 30 ? 0 : bin;
+  };
+  for (int idx1 = tid; idx1 < k1.n; idx1 += nt) {
+    const int best2 = a.mp[k1.f0 + idx1] >= 0 ? -1 : tri_search_feature(a, k1, k2, pr, idx1);
+    matches12[idx1] = best2;
+    if (best2 >= 0 && a.check_orientation) atomicAdd(&s_hist[bin_of(idx1, best2)], 1);
+  }
+  __syncthreads();
+  if (a.check_orientation) {                         // ComputeThreeMaxima (ORBMatcher.cpp:905-946) on the bin sizes
+    if (tid == 0) {
+      int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+      for (int i = 0; i < 30; ++i) {
+        const int s = s_hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+        else if (s > max3) { max3 = s; i3 = i; }
+      }
+      if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) i3 = -1;
+      s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+    }
+    __syncthreads();
+  }
+  int mine = 0;
+  for (int idx1 = tid; idx1 < k1.n; idx1 += nt) {
+    int m = matches12[idx1];
+    if (m >= 0 && a.check_orientation) {
+      const int bin = bin_of(idx1, m);
+      if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) { m = -1; matches12[idx1] = -1; }
+    }
+    mine += m >= 0;
+  }
+  if (mine) atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  if (tid == 0) *n_matches = s_cnt;
+}
+
 // ---- the same result without walking the neighbours one after the other (check_orientation == 0, the reference's call site).
 // Neither the search nor the triangulation of (feature, neighbour) looks at what other features did; the only coupling is "a feature
 // that got its point from an earlier neighbour is skipped by the later ones".  So every (neighbour, feature) pair is evaluated at once

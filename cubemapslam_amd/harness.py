@@ -75,7 +75,7 @@ class GpuBackend:
     def extract(self, fisheye, init):
         """System::CvtFisheyeToCubeMap + ORBextractor::operator(); the frame stays on the device as the current frame"""
         self.cur = self.ctx_ini if init else self.ctx_trk
-        k, d = self.cur.remap_extract(fisheye)
+        k, d, self.last_rays = self.cur.remap_extract_rays(fisheye)      # + Frame::ComputeKeyPointRays (Frame.cpp:746-760) from the device
         self.cur.area_grid(1)                                  # Frame::AssignFeaturesToGrid
         return k, d
 
@@ -131,12 +131,12 @@ class Tracker:
         self.mp_max = np.concatenate([self.mp_max, mx]); self.mp_min = np.concatenate([self.mp_min, (mx / self.sf[-1]).astype(np.float32)])
         return np.arange(base, base + len(Xw), dtype=np.int32)
 
-    def _pose_problem(self, T, kps, kp_mp):
-        """Optimizer::PoseOptimization's edges (Optimizer.cpp:78-129): key points holding a map point whose ray is inside the field of view"""
+    def _pose_problem(self, T, kps, kp_mp, rays):
+        """Optimizer::PoseOptimization's edges (Optimizer.cpp:78-129): key points holding a map point whose ray is inside the field of view.
+        rays: the frame's mvKeyRays as the backend's extraction delivered them (unit vectors, CamModelGeneral.h:494-513)"""
         F = self.F
         idx = np.flatnonzero(kp_mp >= 0)
-        _, ray = synth.pixel_to_ray(F, kps["x"][idx], kps["y"][idx])
-        idx = idx[(ray[:, 2] / np.linalg.norm(ray, axis=1)).astype(np.float32) >= self.cos_fov]      # mvKeyRays are unit vectors (CamModelGeneral.h:494-513)
+        idx = idx[rays[idx, 2] >= self.cos_fov]
         px = kps["x"][idx].astype(np.float64); py = kps["y"][idx].astype(np.float64)
         face = synth.face_of_pixel(F, px, py)
         idx = idx[face >= 0]; px = px[face >= 0]; py = py[face >= 0]; face = face[face >= 0]
@@ -146,7 +146,7 @@ class Tracker:
                          fx=F / 2.0, fy=F / 2.0, cx=F / 2.0, cy=F / 2.0)
 
     def _optimize_pose(self, fr):
-        idx, prob = self._pose_problem(fr["T"], fr["kps"], fr["kp_mp"])
+        idx, prob = self._pose_problem(fr["T"], fr["kps"], fr["kp_mp"], fr["rays"])
         if len(idx) < 3:
             return 0
         n, pose, out = self.be.pose_optimize(prob)
@@ -161,7 +161,7 @@ class Tracker:
         rec = dict(frame=i, stage="init", nkp=len(k))
         if self.ini is None:
             if len(k) > 100:
-                self.ini = dict(i=i, kps=k, desc=d, gt=gt, prev=np.stack([k["x"], k["y"]], 1).astype(np.float32))
+                self.ini = dict(i=i, kps=k, desc=d, gt=gt, rays=self.be.last_rays, prev=np.stack([k["x"], k["y"]], 1).astype(np.float32))
             self.log.append(rec)
             return
         if len(k) <= 100:
@@ -181,8 +181,8 @@ class Tracker:
         ids = self._add_points(Xw, d[m12[sel]], k["octave"][m12[sel]], Ow1)
         kp_mp0 = np.full(len(ini["kps"]), -1, np.int32); kp_mp0[sel] = ids
         kp_mp1 = np.full(len(k), -1, np.int32); kp_mp1[m12[sel]] = ids
-        self.kfs = [dict(T=T0, kps=ini["kps"], kp_mp=kp_mp0, frame=ini["i"]), dict(T=T1, kps=k, kp_mp=kp_mp1, frame=i)]
-        self.last = dict(T=T1, kps=k, desc=d, kp_mp=kp_mp1, outlier=np.zeros(len(k), bool))
+        self.kfs = [dict(T=T0, kps=ini["kps"], kp_mp=kp_mp0, frame=ini["i"], rays=ini["rays"]), dict(T=T1, kps=k, kp_mp=kp_mp1, frame=i, rays=self.be.last_rays)]
+        self.last = dict(T=T1, kps=k, desc=d, kp_mp=kp_mp1, outlier=np.zeros(len(k), bool), rays=self.be.last_rays)
         self.velocity = None
         self.state = "ok"
         rec.update(n_map=len(ids))
@@ -194,7 +194,7 @@ class Tracker:
         k, d = be.extract(fisheye, init=False)
         rec = dict(frame=i, stage="track", nkp=len(k))
         last = self.last
-        cur = dict(kps=k, desc=d, kp_mp=np.full(len(k), -1, np.int32), outlier=np.zeros(len(k), bool))
+        cur = dict(kps=k, desc=d, kp_mp=np.full(len(k), -1, np.int32), outlier=np.zeros(len(k), bool), rays=be.last_rays)
         # TrackWithMotionModel (Tracking.cpp:620-677); the very first tracked frame has no velocity yet: TrackReferenceKeyFrame needs BoW, the
         # harness starts the motion model from a standing camera instead
         cur["T"] = (self.velocity @ last["T"]).astype(np.float32) if self.velocity is not None else last["T"].copy()
@@ -261,7 +261,7 @@ class Tracker:
         Ow = (-(T[:3, :3].T @ T[:3, 3])).astype(np.float32)
         ids = self._add_points(Xw_est, cur["desc"][free], k["octave"][free], Ow)
         cur["kp_mp"][free] = ids
-        self.kfs.append(dict(T=cur["T"].copy(), kps=k, kp_mp=cur["kp_mp"].copy(), frame=i))
+        self.kfs.append(dict(T=cur["T"].copy(), kps=k, kp_mp=cur["kp_mp"].copy(), frame=i, rays=cur["rays"]))
         rec.update(new_points=len(ids))
         # Optimizer::LocalBundleAdjustment (Optimizer.cpp:192-451): the last `ba_window` key frames are free, older ones that see the same
         # points are fixed; edges = every observation of the window's points whose ray is inside the field of view
@@ -276,8 +276,7 @@ class Tracker:
         for kj, kf in enumerate(kfs):
             idx = np.flatnonzero(kf["kp_mp"] >= 0)
             idx = idx[pt_index[kf["kp_mp"][idx]] >= 0]
-            _, ray = synth.pixel_to_ray(F, kf["kps"]["x"][idx], kf["kps"]["y"][idx])
-            idx = idx[(ray[:, 2] / np.linalg.norm(ray, axis=1)).astype(np.float32) >= self.cos_fov]
+            idx = idx[kf["rays"][idx, 2] >= self.cos_fov]                 # Optimizer.cpp:323-325 on the key frame's mvKeyRays
             px = kf["kps"]["x"][idx].astype(np.float64); py = kf["kps"]["y"][idx].astype(np.float64)
             face = synth.face_of_pixel(F, px, py)
             keep = face >= 0

@@ -162,6 +162,7 @@ struct FrameData {
   Mat4f T = eye4();
   std::vector<cms_keypoint> kps;
   std::vector<uint8_t> desc;          // n x 32
+  std::vector<float> rays;            // n x 3: Frame::mvKeyRays, from the device (cms_remap_extract_rays)
   std::vector<int> kp_mp;             // map point per key point or -1
   std::vector<uint8_t> outlier;
   int frame = 0;
@@ -231,10 +232,10 @@ class Tracker {
   void extract(const Image& fisheye, bool init, FrameData& fr) {
     cur_ = init ? ctx_ini_ : ctx_trk_;
     const int cap = init ? cap_ini_ : cap_trk_;
-    fr.kps.resize(cap); fr.desc.resize((size_t)cap * 32);
+    fr.kps.resize(cap); fr.desc.resize((size_t)cap * 32); fr.rays.resize((size_t)cap * 3);
     int n = 0;
-    TIMED("cms_remap_extract", cms_remap_extract(cur_, fisheye.px.data(), fisheye.w, fr.kps.data(), fr.desc.data(), cap, &n));
-    fr.kps.resize(n); fr.desc.resize((size_t)n * 32);
+    TIMED("cms_remap_extract", cms_remap_extract_rays(cur_, fisheye.px.data(), fisheye.w, fr.kps.data(), fr.desc.data(), fr.rays.data(), cap, &n));
+    fr.kps.resize(n); fr.desc.resize((size_t)n * 32); fr.rays.resize((size_t)n * 3);
     TIMED("cms_area_grid", cms_area_grid(cur_, 1));                       // Frame::AssignFeaturesToGrid
     fr.kp_mp.assign(n, -1); fr.outlier.assign(n, 0);
   }
@@ -260,9 +261,8 @@ class Tracker {
       if (fr.kp_mp[i] < 0) continue;
       double ray[3];
       const double px = fr.kps[i].x, py = fr.kps[i].y;
-      const int fc = pixel_to_ray(F_, px, py, ray);
-      const double nr = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
-      if ((float)(ray[2] / nr) < cos_fov_ || fc < 0) continue;      // key ray outside the field of view / not on a face
+      const int fc = pixel_to_ray(F_, px, py, ray);                 // (the face; the key ray itself comes from the device)
+      if (fr.rays[3 * i + 2] < cos_fov_ || fc < 0) continue;        // Optimizer.cpp:97: key ray outside the field of view / not on a face
       idx.push_back((int)i);
       for (int k = 0; k < 3; ++k) Xw.push_back((double)mp_pos[3 * (size_t)fr.kp_mp[i] + k]);
       obs.push_back(px - std::floor(px / F_) * F_); obs.push_back(py - std::floor(py / F_) * F_);
@@ -469,8 +469,7 @@ class Tracker {
         double ray[3];
         const double px = kf.kps[k].x, py = kf.kps[k].y;
         const int fc = pixel_to_ray(F_, px, py, ray);
-        const double nr = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
-        if ((float)(ray[2] / nr) < cos_fov_ || fc < 0) continue;
+        if (kf.rays[3 * k + 2] < cos_fov_ || fc < 0) continue;        // Optimizer.cpp:323-325 on the key frame's mvKeyRays
         e_pose.push_back((int)kj); e_point.push_back(pt_index[mp]);
         e_obs.push_back(px - std::floor(px / F_) * F_); e_obs.push_back(py - std::floor(py / F_) * F_);
         e_inv.push_back((double)inv_sigma2_[kf.kps[k].octave]); e_face.push_back((int8_t)fc);

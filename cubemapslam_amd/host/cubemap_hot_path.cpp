@@ -298,6 +298,77 @@ int Tracking::SearchLocalPoints(FrameView& F, std::vector<MapPointView>& mps, fl
   return nm;
 }
 
+int ORBMatcher::SearchByProjection(FrameView& F, std::vector<MapPointView>& vpMapPoints, float th) {
+  // the reference walks vpMapPoints and skips !mbTrackInView (ORBMatcher.cpp:58-59): the marked ones go to the device as one list, in order
+  std::vector<MapPointView> marked;
+  std::vector<size_t> src;
+  for (size_t i = 0; i < vpMapPoints.size(); ++i)
+    if (vpMapPoints[i].mbTrackInView) { marked.push_back(vpMapPoints[i]); src.push_back(i); }
+  if (marked.empty()) return 0;
+  // viewing-cosine limit below any cosine: the caller's isInFrustum applied its own; every other test of isInFrustum repeats with the same result
+  const int n = Tracking::SearchLocalPoints(F, marked, th, mfNNratio, -2.0f);
+  for (size_t k = 0; k < src.size(); ++k) {
+    MapPointView& d = vpMapPoints[src[k]];
+    d.mTrackProjX = marked[k].mTrackProjX; d.mTrackProjY = marked[k].mTrackProjY; d.mnTrackScaleLevel = marked[k].mnTrackScaleLevel; d.mTrackViewCos = marked[k].mTrackViewCos;
+  }
+  return n;
+}
+
+int ORBMatcher::SearchForInitialization(FrameView& F1, FrameView& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize) {
+  const int N1 = (int)F1.mvKeys.size(), N2 = (int)F2.mvKeys.size();
+  vnMatches12.assign(N1, -1);
+  if (N1 == 0 || N2 == 0) return 0;
+  if ((int)vbPrevMatched.size() != N1) throw std::runtime_error("SearchForInitialization: vbPrevMatched must have one entry per key point of F1");
+  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+  auto pack = [](const FrameView& f, std::vector<cms_keypoint>& k, std::vector<uint8_t>& d) {
+    const int n = (int)f.mvKeys.size();
+    k.resize(n); d.resize(32 * (size_t)n);
+    for (int j = 0; j < n; ++j) {
+      const cv::KeyPoint& q = f.mvKeys[j];
+      k[j].x = q.pt.x; k[j].y = q.pt.y; k[j].size = q.size; k[j].angle = q.angle; k[j].response = q.response; k[j].octave = q.octave;
+      std::memcpy(&d[32 * (size_t)j], f.mDescriptors.ptr<uint8_t>(j), 32);
+    }
+  };
+  std::vector<cms_keypoint> k1, k2;
+  std::vector<uint8_t> d1, d2;
+  pack(F1, k1, d1); pack(F2, k2, d2);
+  std::vector<float> prev(2 * (size_t)N1);
+  for (int i = 0; i < N1; ++i) { prev[2 * (size_t)i] = vbPrevMatched[i].x; prev[2 * (size_t)i + 1] = vbPrevMatched[i].y; }
+  int nm = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    int rc = cms_area_set_keypoints(ctx, 0, N2, k2.data());
+    if (rc == CMS_OK) rc = cms_area_set_descriptors(ctx, 0, N2, d2.data());
+    if (rc == CMS_OK) rc = cms_area_grid(ctx, 1);
+    if (rc == CMS_OK) rc = cms_search_for_initialization(ctx, 0, N1, k1.data(), d1.data(), prev.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                                         vnMatches12.data(), &nm);
+    if (rc != CMS_OK) throw std::runtime_error(std::string("cms_search_for_initialization: ") + cms_last_error());
+  }
+  for (int i = 0; i < N1; ++i) vbPrevMatched[i] = cv::Point2f(prev[2 * (size_t)i], prev[2 * (size_t)i + 1]);
+  return nm;
+}
+
+int ORBMatcher::SearchForTriangulation(const KeyFrameView& pKF1, const KeyFrameView& pKF2, const cv::Mat& E12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs) {
+  vMatchedPairs.clear();
+  if (pKF1.mvKeys.empty() || pKF2.mvKeys.empty()) return 0;
+  if (E12.rows != 3 || E12.cols != 3 || E12.type() != cv::CV_32F) throw std::runtime_error("SearchForTriangulation: E12 must be 3x3 CV_32F");
+  cms_ctx* ctx = SharedContext(g_ctx_orb.nfeatures, g_ctx_orb.scale_factor, g_ctx_orb.nlevels, g_ctx_orb.ini_th_fast, g_ctx_orb.min_th_fast);
+  KfPack p1, p2;
+  const cms_keyframe k1 = pack_keyframe(pKF1, p1), k2 = pack_keyframe(pKF2, p2);
+  float e[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) e[3 * r + c] = E12.at<float>(r, c);
+  std::vector<int> m12(pKF1.mvKeys.size(), -1);
+  int nm = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (cms_search_for_triangulation(ctx, &k1, &k2, e, mbCheckOrientation ? 1 : 0, m12.data(), &nm) != CMS_OK)
+      throw std::runtime_error(std::string("cms_search_for_triangulation: ") + cms_last_error());
+  }
+  vMatchedPairs.reserve(nm);
+  for (size_t i = 0; i < m12.size(); ++i) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+  return nm;
+}
+
 int ORBMatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, float th, bool) {
   const int N2 = (int)Cur.mvKeys.size();
   if (!Last.mvMapPointPos.empty() && Cur.mTcw.rows == 4 && Cur.mTcw.cols == 4 && N2 > 0) {

@@ -123,6 +123,18 @@ class ORBMatcher {
   // distances / arg-min run on the GPU (cms_hamming_best2) and the greedy acceptance is replayed on the host in the reference's
   // order.  Returns the number of matches, fills CurrentFrame.mvpMapPoints.
   int SearchByProjection(FrameView& CurrentFrame, const FrameView& LastFrame, float th, bool bMono);
+  // ORBMatcher.cpp:50-128, Tracking.cpp:841: search matches between the frame's key points and the projected map points Frame::isInFrustum marked
+  // (mbTrackInView with mTrackProjX / Y, mnTrackScaleLevel, mTrackViewCos).  Points not in view are skipped like the reference does; for the
+  // others the device repeats isInFrustum on F.mTcw (the same arithmetic gives the same fields) and runs the greedy search with mfNNratio.
+  // Fills F.mvpMapPoints with the matched points' ids, returns the number of matches.
+  int SearchByProjection(FrameView& F, std::vector<MapPointView>& vpMapPoints, float th = 3.0f);
+  // ORBMatcher.cpp:676-794, Tracking.cpp:428-429: level-0 key points of F1 against F2 inside windows around vbPrevMatched (updated for the matches
+  // like the reference), best / second best with mfNNratio, take-over of a key point of F2 by a strictly better match, rotation histogram.
+  // vnMatches12[i1] = index in F2 or -1; returns the number of matches.  (cms_search_for_initialization)
+  int SearchForInitialization(FrameView& F1, FrameView& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10);
+  // ORBMatcher.cpp:971-1125, LocalMapping.cpp:254: features of pKF1 without a map point against those of pKF2 in the same vocabulary node,
+  // epipole distance and epipolar gate with E12 (3x3 CV_32F).  vMatchedPairs in ascending idx1.  (cms_search_for_triangulation)
+  int SearchForTriangulation(const KeyFrameView& pKF1, const KeyFrameView& pKF2, const cv::Mat& E12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs);
   // ORBMatcher.cpp:1127-1226: search on the device (cms_fuse_search), then the reference's Replace / AddObservation decisions in list
   // order: fused[i] = key point map point i is fused with (or -1); returns nFused.  mvpMapPoints of pKF is updated for additions.
   int Fuse(KeyFrameView& pKF, const std::vector<MapPointView>& vpMapPoints, const std::vector<uint8_t>& skip, float th, std::vector<int>& fused);

@@ -144,6 +144,89 @@ extern "C" int hm_search_local_points(int ncur, const cms_keypoint* cur_k, const
     }
     return n;)
 }
+// ORBMatcher::SearchByProjection(F, vpMapPoints, th) through the mirror: the caller marks the points in view (what Frame::isInFrustum left in them)
+extern "C" int hm_search_by_projection_map(int ncur, const cms_keypoint* cur_k, const uint8_t* cur_d, long* cur_mp, const float* scale_factors, int nlevels,
+                                           float* Tcw, int nmp, const long* mp_id, const float* pos, const float* normal, const float* min_dist,
+                                           const float* max_dist, const uint8_t* mp_desc, const uint8_t* in_view, float th, float nnratio) {
+  HM_TRY(
+    FrameView cur;
+    cur.mvKeys.resize(ncur);
+    cur.mDescriptors.create(ncur > 0 ? ncur : 1, 32, cv::CV_8U);
+    for (int i = 0; i < ncur; ++i) {
+      cur.mvKeys[i].pt = cv::Point2f(cur_k[i].x, cur_k[i].y); cur.mvKeys[i].angle = cur_k[i].angle; cur.mvKeys[i].octave = cur_k[i].octave;
+      std::memcpy(cur.mDescriptors.ptr<uint8_t>(i), cur_d + (size_t)i * 32, 32);
+    }
+    cur.mvpMapPoints.assign(cur_mp, cur_mp + ncur);
+    cur.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+    cur.mTcw = cv::Mat(4, 4, cv::CV_32F, Tcw, 16);
+    std::vector<MapPointView> mps(nmp);
+    for (int i = 0; i < nmp; ++i) {
+      mps[i].mnId = mp_id[i];
+      mps[i].mWorldPos = cv::Mat(3, 1, cv::CV_32F, const_cast<float*>(pos) + 3 * (size_t)i, 4);
+      mps[i].mNormalVector = cv::Mat(3, 1, cv::CV_32F, const_cast<float*>(normal) + 3 * (size_t)i, 4);
+      mps[i].mfMinDistance = min_dist[i]; mps[i].mfMaxDistance = max_dist[i];
+      mps[i].mDescriptor = cv::Mat(1, 32, cv::CV_8U, const_cast<uint8_t*>(mp_desc) + 32 * (size_t)i, 32);
+      mps[i].mbTrackInView = in_view[i] != 0;
+    }
+    ORBMatcher matcher(nnratio, true);
+    const int n = matcher.SearchByProjection(cur, mps, th);
+    for (int j = 0; j < ncur; ++j) cur_mp[j] = cur.mvpMapPoints[j];
+    return n;)
+}
+// ORBMatcher::SearchForInitialization through the mirror; prev_xy (n1 x 2) is vbPrevMatched, in / out
+extern "C" int hm_search_for_initialization(int n1, const cms_keypoint* k1, const uint8_t* d1, int n2, const cms_keypoint* k2, const uint8_t* d2,
+                                            float* prev_xy, int window, float nnratio, int check_ori, int* matches12) {
+  HM_TRY(
+    FrameView f1, f2;
+    auto fill = [](FrameView& f, int n, const cms_keypoint* k, const uint8_t* d) {
+      f.mvKeys.resize(n);
+      f.mDescriptors.create(n > 0 ? n : 1, 32, cv::CV_8U);
+      for (int i = 0; i < n; ++i) {
+        f.mvKeys[i].pt = cv::Point2f(k[i].x, k[i].y); f.mvKeys[i].angle = k[i].angle; f.mvKeys[i].octave = k[i].octave; f.mvKeys[i].size = k[i].size;
+        f.mvKeys[i].response = k[i].response;
+        std::memcpy(f.mDescriptors.ptr<uint8_t>(i), d + (size_t)i * 32, 32);
+      }
+    };
+    fill(f1, n1, k1, d1); fill(f2, n2, k2, d2);
+    std::vector<cv::Point2f> prev(n1);
+    for (int i = 0; i < n1; ++i) prev[i] = cv::Point2f(prev_xy[2 * i], prev_xy[2 * i + 1]);
+    std::vector<int> m12;
+    ORBMatcher matcher(nnratio, check_ori != 0);
+    const int n = matcher.SearchForInitialization(f1, f2, prev, m12, window);
+    for (int i = 0; i < n1; ++i) { matches12[i] = m12[i]; prev_xy[2 * i] = prev[i].x; prev_xy[2 * i + 1] = prev[i].y; }
+    return n;)
+}
+// ORBMatcher::SearchForTriangulation through the mirror: two key frames in hm_create_new_map_points' flat layout (nkf = 2), E12 row major
+extern "C" int hm_search_for_triangulation(const int* feat_off, const cms_keypoint* kps, const uint8_t* desc, const float* rays, const long* mp,
+                                           float* Tcw, const int* node_off2, const int* node_id, const int* node_cnt, const int* node_feat,
+                                           float* E12, int check_ori, int cap, int* out_idx1, int* out_idx2) {
+  HM_TRY(
+    std::vector<KeyFrameView> kfs(2);
+    size_t nf_cursor = 0;
+    for (int k = 0; k < 2; ++k) {
+      KeyFrameView& v = kfs[k];
+      const int f0 = feat_off[k], n = feat_off[k + 1] - f0;
+      v.mnId = k; v.mvKeys.resize(n); v.mvKeyRays.resize(n); v.mvpMapPoints.assign(mp + f0, mp + f0 + n);
+      v.mDescriptors.create(n > 0 ? n : 1, 32, cv::CV_8U);
+      for (int i = 0; i < n; ++i) {
+        const cms_keypoint& s = kps[f0 + i];
+        v.mvKeys[i].pt = cv::Point2f(s.x, s.y); v.mvKeys[i].angle = s.angle; v.mvKeys[i].octave = s.octave;
+        std::memcpy(v.mDescriptors.ptr<uint8_t>(i), desc + 32 * (size_t)(f0 + i), 32);
+        for (int c = 0; c < 3; ++c) v.mvKeyRays[i].v[c] = rays[3 * (size_t)(f0 + i) + c];
+      }
+      v.Tcw = cv::Mat(4, 4, cv::CV_32F, Tcw + 16 * (size_t)k, 16);
+      for (int e = node_off2[k]; e < node_off2[k + 1]; ++e) {
+        std::vector<unsigned> fl(node_feat + nf_cursor, node_feat + nf_cursor + node_cnt[e]);
+        nf_cursor += (size_t)node_cnt[e];
+        v.mFeatVec.emplace_back((unsigned)node_id[e], std::move(fl));
+      }
+    }
+    std::vector<std::pair<size_t, size_t>> pairs;
+    ORBMatcher matcher(0.6f, check_ori != 0);
+    const int n = matcher.SearchForTriangulation(kfs[0], kfs[1], cv::Mat(3, 3, cv::CV_32F, E12, 12), pairs);
+    for (int i = 0; i < (int)pairs.size() && i < cap; ++i) { out_idx1[i] = (int)pairs[i].first; out_idx2[i] = (int)pairs[i].second; }
+    return n;)
+}
 // LocalMapping::CreateNewMapPoints through the mirror: key frame 0 is the current one, 1..nkf-1 its neighbours.  Flat inputs:
 // feat_off[nkf+1]; per feature kps/desc/rays/mp; Tcw nkf x 16; FeatureVector per key frame as node_off2[nkf+1] into (node_id, node_cnt)
 // and the features of the nodes concatenated in node_feat; median_depth[nkf].  Outputs up to cap records.

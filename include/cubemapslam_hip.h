@@ -84,6 +84,13 @@ int cms_set_mask(cms_ctx* ctx, const uint8_t* mask, int mstride);
 int cms_set_gaussian_mode(cms_ctx* ctx, int column_mode);
 int cms_extract(cms_ctx* ctx, const uint8_t* cubemap, int cstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n);
 int cms_remap_extract(cms_ctx* ctx, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* ... and with Frame::mvKeyRays: Frame::ComputeKeyPointRays -> CamModelGeneral::TransformCubemapToRays of every key point (src/Frame.cpp:746-760,
+ * include/CamModelGeneral.h:494-513), rays[3 i .. 3 i + 2] = unit bearing vector of key point i in rig axes.  The extraction computes them anyway
+ * (every consumer behind it -- PoseOptimization's and LocalBundleAdjustment's edge filter ray.z < cosFovTh, Optimizer.cpp:97 / 323-325, cms_keyframe.rays
+ * -- wants them); cms_frames_rays: device pointer [max_batch][kp_cap][3] float of the batched path; cms_frames_fetch_rays: frame b's to the host. */
+int cms_remap_extract_rays(cms_ctx* ctx, const uint8_t* fisheye, int fstride, cms_keypoint* kps, uint8_t* desc, float* rays, int cap, int* n);
+int cms_frames_rays(cms_ctx* ctx, void** d_rays);
+int cms_frames_fetch_rays(cms_ctx* ctx, int b, float* rays, int cap, int* n);
 
 /* ---- batched, device-resident frame path (many frames / streams per launch; inputs already in HBM)
  * cms_frames_input()   : device pointer of the fisheye staging buffer, [max_batch][Ih][fisheye_stride] bytes.
@@ -319,6 +326,13 @@ typedef struct {
 int cms_create_new_map_points(cms_ctx* ctx, int njobs, const cms_keyframe* cur, const int* neigh_off, const cms_keyframe* neigh,
                               int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
                               float* out_x3d);
+/* ORBMatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat E12, vector<pair<size_t, size_t>>& vMatchedPairs) (include/ORBMatcher.h:61,
+ * src/ORBMatcher.cpp:971-1125) on its own -- the call of LocalMapping.cpp:254 for callers that triangulate themselves: for every feature of kf1
+ * without a map point, the best feature of kf2 (same vocabulary node, no map point, Hamming <= TH_LOW, away from the epipole, inside the
+ * epipolar gate), then the rotation histogram if check_orientation.  E12: the 3 x 3 essential matrix the caller computed (row major), NULL =
+ * LocalMapping::ComputeE12 of the two poses.  matches12[i1] = index in kf2 or -1 (kf1->n entries); *n_matches = their number. */
+int cms_search_for_triangulation(cms_ctx* ctx, const cms_keyframe* kf1, const cms_keyframe* kf2, const float* E12, int check_orientation,
+                                 int* matches12, int* n_matches);
 /* Resident key frames: the map's key frames stay on the device in fixed-size slots, a CreateNewMapPoints call names slots and only
  * ~100 bytes per (current, neighbour) pair travel.  cms_kfstore_put uploads / replaces a key frame; cms_kfstore_update refreshes what
  * changes between calls (pose after a local BA, median depth, map-point slots; NULL = unchanged).  Results as above. */

@@ -29,6 +29,7 @@ class OracleBackend:
         cube = orc.fisheye_to_cubemap(self.cam, self.m1, self.m2, np.ascontiguousarray(fisheye))
         k, d = (self.orb_ini if init else self.orb_trk).extract(self.cam, cube, self.mask)
         self.cur = (k, d)
+        self.last_rays = orc.keyframe_rays(self.cam, k["x"], k["y"])      # Frame::ComputeKeyPointRays
         return k, d
 
     def search_for_initialization(self, k1, d1, k2, d2, prev_matched):

@@ -344,3 +344,107 @@ def test_mirror_search_by_projection_device_path():
     assert n == nm and nm > 300, (n, nm, L.hm_last_error())
     want_mp = np.where(want_kp >= 0, np.where(want_kp == 10**6, 10**6, want_kp + 7000), -1)
     assert np.array_equal(cur_mp, want_mp)
+
+
+def _mirror_context(L, F, seed):
+    """camera + one extraction (a Frame always comes from an ORBextractor: constructing one sizes the shared device context)"""
+    camd = synth.camera("lafida", F)
+    cam = api.make_camera(camd)
+    assert L.hm_set_camera(C.byref(cam)) == 0
+    W = 3 * F
+    img = np.ascontiguousarray(synth.texture(W, W, seed)); msk = np.full((W, W), 255, np.uint8)
+    k0 = np.zeros(3000, KP); d0 = np.zeros((3000, 32), np.uint8)
+    assert L.hm_extract(2000, 1.2, 8, 20, 7, _p(img), W, _p(msk), W, _p(k0), _p(d0), 3000) > 0, L.hm_last_error()
+    return camd, orc.make_camera(camd)
+
+
+def test_mirror_search_by_projection_map_points():
+    """ORBMatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) under its reference name (ORBMatcher.h:50, Tracking.cpp:841): the map points
+    carry what Frame::isInFrustum left in them (mbTrackInView ...); == oracle SearchByProjection on the oracle's isInFrustum fields"""
+    import test_area_emu as te
+    L = _host()
+    L.hm_search_by_projection_map.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_float]
+    F = 450
+    camd, ocam = _mirror_context(L, F, 170)
+    kx, ky, ko = te._keypoints(F, 1800, 171)
+    kd = synth.descriptors(len(kx), 172)
+    pr = synth.local_map_problem(F, kx, ky, ko, kd, seed=173)
+    ck = np.zeros(len(kx), KP); ck["x"] = kx; ck["y"] = ky; ck["octave"] = ko
+    Tcw = np.eye(4, dtype=np.float32); Tcw[:3, :3] = pr["pose15"][:9].reshape(3, 3); Tcw[:3, 3] = pr["pose15"][9:12]
+    Ow = (-(Tcw[:3, :3].astype(np.float64).T @ Tcw[:3, 3].astype(np.float64))).astype(np.float32)
+    pose15 = np.concatenate([pr["pose15"][:12], Ow]).astype(np.float32)
+    th = 3.0
+    fr = orc.is_in_frustum(ocam, pose15, pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"])      # Tracking::SearchLocalPoints' loop (Tracking.cpp:818-833)
+    taken = np.full(len(kx), -1, np.int32); taken[::11] = 10**6
+    want_kp = taken.copy()
+    want, nm = orc.search_local_points(ocam, kx, ky, ko, kd, pr["scale_factors"], fr, pr["desc"], want_kp, th=th)
+    n = len(pr["pos"])
+    ids = (np.arange(n, dtype=np.int64) + 5000)
+    cur_mp = np.where(taken >= 0, 10**6, -1).astype(np.int64)
+    got_n = L.hm_search_by_projection_map(len(ck), _p(ck), _p(kd), _p(cur_mp), _p(pr["scale_factors"]), 8, _p(Tcw), n, _p(ids), _p(pr["pos"]), _p(pr["normal"]),
+                                          _p(pr["min_dist"]), _p(pr["max_dist"]), _p(pr["desc"]), _p(np.ascontiguousarray(fr["in_view"], np.uint8)), th, 0.8)
+    assert got_n == nm and nm > 200, (got_n, nm, L.hm_last_error())
+    want_mp = np.where(want_kp >= 0, np.where(want_kp == 10**6, 10**6, want_kp + 5000), -1)
+    assert np.array_equal(cur_mp, want_mp)
+
+
+def test_mirror_search_for_initialization():
+    """ORBMatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) under its reference name (ORBMatcher.h:58, Tracking.cpp:428-429)
+    == oracle, including the updated vbPrevMatched"""
+    import test_oracle_track as tot
+    L = _host()
+    L.hm_search_for_initialization.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    F = 450
+    camd, ocam = _mirror_context(L, F, 180)
+    for seed, check, rot in ((181, True, 20.0), (182, False, 0.0)):
+        k1, d1, k2, d2 = tot._init_pair(F, 1200, seed, rot_deg=rot)
+        prev_w = np.stack([k1["x"], k1["y"]], 1).astype(np.float32); prev_g = prev_w.copy()
+        want_m, want_n = orc.search_for_initialization(ocam, k1, d1, k2, d2, prev_w, 100, 0.9, check)
+        a1 = np.zeros(len(k1), KP); a2 = np.zeros(len(k2), KP)
+        for f in ("x", "y", "octave", "angle"):
+            a1[f] = k1[f]; a2[f] = k2[f]
+        got_m = np.full(len(k1), -7, np.int32)
+        got_n = L.hm_search_for_initialization(len(a1), _p(a1), _p(np.ascontiguousarray(d1)), len(a2), _p(a2), _p(np.ascontiguousarray(d2)), _p(prev_g), 100, 0.9,
+                                               int(check), _p(got_m))
+        assert got_n == want_n and want_n > 100, (got_n, want_n, L.hm_last_error())
+        assert np.array_equal(got_m, want_m) and np.array_equal(prev_g.view(np.uint32), prev_w.view(np.uint32))
+
+
+def test_mirror_search_for_triangulation():
+    """ORBMatcher::SearchForTriangulation(pKF1, pKF2, E12, vMatchedPairs) under its reference name (ORBMatcher.h:61, LocalMapping.cpp:254) == oracle;
+    the pairs come in ascending idx1 like the reference's vMatchedPairs"""
+    L = _host()
+    L.hm_search_for_triangulation.argtypes = [C.c_void_p] * 11 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    F = 450
+    camd, ocam = _mirror_context(L, F, 190)
+    S = synth.keyframe_set(F, n_kf=3, n_pts=2200, seed=191)
+    kfs = S["kfs"]
+    for k in kfs:                     # the mirror derives Ow from Tcw like KeyFrame::SetPose does: feed the oracle the same value
+        k["Ow"] = (-(k["R"].astype(np.float64).T @ k["t"].astype(np.float64))).astype(np.float32)
+    oks = [orc.make_keyframe(ocam, k) for k in kfs]
+    for j, check in ((1, False), (2, True)):
+        pair = [kfs[0], kfs[j]]
+        E12 = orc.compute_e12(kfs[0], kfs[j])
+        want, wn = orc.search_for_triangulation(ocam, oks[0][0], oks[j][0], E12, S["scale_factors"], S["level_sigma2"], check)
+        feat_off = np.concatenate([[0], np.cumsum([len(k["x"]) for k in pair])]).astype(np.int32)
+        kps = np.zeros(feat_off[-1], KP)
+        for i, k in enumerate(pair):
+            sl = slice(feat_off[i], feat_off[i + 1])
+            kps["x"][sl] = k["x"]; kps["y"][sl] = k["y"]; kps["octave"][sl] = k["octave"]; kps["angle"][sl] = k["angle"]
+        desc = np.concatenate([k["desc"] for k in pair]); rays = np.concatenate([k["rays"] for k in pair]).astype(np.float32)
+        mp = np.concatenate([k["mp"] for k in pair]).astype(np.int64)
+        Tcw = np.zeros((2, 4, 4), np.float32)
+        for i, k in enumerate(pair):
+            Tcw[i, :3, :3] = k["R"]; Tcw[i, :3, 3] = k["t"]; Tcw[i, 3, 3] = 1
+        node_off2 = np.concatenate([[0], np.cumsum([len(k["node_id"]) for k in pair])]).astype(np.int32)
+        node_id = np.concatenate([k["node_id"] for k in pair]).astype(np.int32)
+        node_cnt = np.concatenate([np.diff(k["node_off"]) for k in pair]).astype(np.int32)
+        node_feat = np.concatenate([k["node_feat"] for k in pair]).astype(np.int32)
+        cap = len(kfs[0]["x"])
+        o1 = np.zeros(cap, np.int32); o2 = np.zeros(cap, np.int32)
+        E = np.ascontiguousarray(E12, np.float32)
+        n = L.hm_search_for_triangulation(_p(feat_off), _p(kps), _p(desc), _p(rays), _p(mp), _p(Tcw), _p(node_off2), _p(node_id), _p(node_cnt), _p(node_feat),
+                                          _p(E), int(check), cap, _p(o1), _p(o2))
+        assert n == wn and wn > 100, (n, wn, L.hm_last_error())
+        idx1 = np.flatnonzero(want >= 0)
+        assert np.array_equal(o1[:n], idx1) and np.array_equal(o2[:n], want[idx1])

@@ -45,6 +45,10 @@ def _compare_frame(ctx, b, o, ocam, cube, mask, tag):
         assert len(bad) == 0, (tag, "key-point field %s differs at %d points, first %s vs %s" % (f, len(bad), got_k[f][bad[:3]], want_k[f][bad[:3]]))
     nbits = int(np.unpackbits(got_d ^ want_d).sum())
     assert nbits == 0, (tag, "descriptors: %d differing bits in %d rows" % (nbits, int((got_d != want_d).any(1).sum())))
+    # Frame::mvKeyRays (Frame::ComputeKeyPointRays -> CamModelGeneral::TransformCubemapToRays, Frame.cpp:746-760): bit for bit
+    want_r = orc.keyframe_rays(ocam, want_k["x"], want_k["y"])
+    got_r = ctx.fetch_rays(b)
+    assert got_r.shape == want_r.shape and np.array_equal(got_r.view(np.uint32), want_r.view(np.uint32)), (tag, "key rays", int((got_r.view(np.uint32) != want_r.view(np.uint32)).any(1).sum()))
     return len(got_k)
 
 
@@ -799,6 +803,30 @@ def test_create_new_map_points_matches_oracle():
     ctx.close()
 
 
+def test_search_for_triangulation_matches_oracle():
+    """cms_search_for_triangulation (ORBMatcher::SearchForTriangulation alone, ORBMatcher.cpp:971-1125, the call of LocalMapping.cpp:254) against the
+    oracle: match lists with the caller's E12 and with the library's ComputeE12, with and without the rotation histogram."""
+    F = 450
+    camd = synth.camera("lafida", F)
+    ocam = orc.make_camera(camd)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=1)
+    ks = synth.keyframe_set(F, n_kf=4, n_pts=2400, seed=41)
+    oks = [orc.make_keyframe(ocam, q) for q in ks["kfs"]]
+    gks = [api.make_keyframe(q) for q in ks["kfs"]]
+    total = 0
+    for j in (1, 2, 3):
+        E12 = orc.compute_e12(ks["kfs"][0], ks["kfs"][j])
+        for check in (False, True):
+            want, wn = orc.search_for_triangulation(ocam, oks[0][0], oks[j][0], E12, ks["scale_factors"], ks["level_sigma2"], check)
+            got, gn = api.search_for_triangulation(ctx, gks[0][0], gks[j][0], E12, check)
+            assert gn == wn and np.array_equal(got, want), (j, check, gn, wn, int((got != want).sum()))
+            got2, gn2 = api.search_for_triangulation(ctx, gks[0][0], gks[j][0], None, check)      # ComputeE12 inside the library
+            assert gn2 == wn and np.array_equal(got2, want), (j, check, "library E12", gn2, wn)
+            total += wn
+    assert total > 600
+    ctx.close()
+
+
 def test_fuse_search_matches_oracle():
     """search half of ORBMatcher::Fuse: the key point every map point would be fused with"""
     import test_area_emu as te
@@ -1234,8 +1262,9 @@ def test_front_camera_eight_stream_batch_matches_oracle():
 
 
 def test_describe_in_spatial_order_is_bit_identical():
-    """CMS_DESC_SPATIAL_ORDER=1 changes the order k_describe WORKS in (band by band, one frame per XCD: a third of the HBM fetches), not
-    its output: the extraction parity tests run again in a child process with the knob set (it is read when a context is created)."""
+    """CMS_DESC_SPATIAL_ORDER=1 changes the order k_describe WORKS in (the batch's key points band by band of their levels, an eighth of that walk
+    per XCD: a third of the HBM fetches), not its output: the extraction parity tests run again in a child process with the knob set (it is read
+    when a context is created)."""
     import os, subprocess, sys
     env = dict(os.environ); env["CMS_DESC_SPATIAL_ORDER"] = "1"
     here = os.path.dirname(os.path.abspath(__file__))

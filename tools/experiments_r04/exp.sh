@@ -43,6 +43,25 @@ case "$1" in
     CMS_HIP_LIB=$(libpath rmclk) timeout 300 python tools/prof_rm_clk.py 16 2>&1 | tail -12 | tee $O/rmclk.txt ;;
   waves)   # the Schur kernel with fewer wavefronts per workgroup: how much of its time is latency?
     for w in 8 6 4 2; do echo "CMS_BA_SE_WAVES=$w: $(CMS_BA_SE_WAVES=$w timeout 300 python tools/prof_ba_many.py 16 track diff 3 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/waves.txt; done ;;
+  frames)  # the frame path alone, 256 frames per launch: stage times, list order of k_describe against the spatial walk
+    for i in 1 2; do
+      echo "walk:       $(CMS_DESC_SPATIAL_ORDER=1 timeout 300 python tools/prof_frames.py 256 550 5 2>&1 | tail -1)" | tee -a $O/frames.txt
+      echo "list order: $(timeout 300 python tools/prof_frames.py 256 550 5 2>&1 | tail -1)" | tee -a $O/frames.txt
+    done ;;
+  exttests) # the extraction parity tests only
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "extract or lut or golden or front_camera" 2>&1 | tail -8 | tee $O/exttests.txt ;;
+  steptrace)  # bench.py under rocprofv3 --kernel-trace --stats: in-step average duration of every kernel.  usage: steptrace <tag> [ENV=VAL ...]
+    shift; TAG=$1; shift
+    R=$PWD; OUT=$R/$O/trace_$TAG; rm -rf $OUT; mkdir -p $OUT
+    (cd /tmp && export TMPDIR=/tmp && env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 > $OUT/bench.json 2> $OUT/bench.err)
+    python - $OUT/t_kernel_stats.csv $TAG <<'PY' | tee -a $O/steptrace.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+print("== %s" % sys.argv[2])
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:26]:
+    print("%-34s calls %6s  avg %9.1f us  total %8.2f ms" % (r["Name"].split("(")[0][:34], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+    tail -c 400 $OUT/bench.json | cut -c1-300; rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv ;;
   batests)  # the BA parity tests only
     timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ba_" 2>&1 | tail -8 | tee $O/batests.txt ;;
   tests)
