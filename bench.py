@@ -80,7 +80,11 @@ def parse_args(argv=None):
     ap.add_argument("--verify-windows", type=int, default=8, help="local-BA windows whose estimates are checked against the CPU oracle after the timed region (rank 0); "
                     "the iteration counts and outlier counts of ALL windows of that step are checked as well (0 = no check)")
     ap.add_argument("--ba-views", choices=("track", "random"), default="track", help="how the synthetic windows' observations are drawn (synth.ba_problem)")
-    ap.add_argument("--window-threads", type=int, default=0, help="host threads that build / read back / destroy local-BA windows (0 = min(32, cores / max(4, 2 x ranks)))")
+    ap.add_argument("--window-threads", type=int, default=0, help="host threads that build / read back / destroy local-BA windows (0 = this rank's share of the "
+                    "node's usable cores minus two, between 4 and 32: host_budget())")
+    ap.add_argument("--extract-only-steps", type=int, default=10, help="steps of the extra pass that runs the frame path alone (config.extract_only; 0 = skip)")
+    ap.add_argument("--random-views-steps", type=int, default=8, help="steps of the extra pass on windows with RANDOM views (no signature runs: round 2's windows), "
+                    "reported as config.ba_views_random next to the headline (0 = skip)")
     ap.add_argument("--optimise-only-steps", type=int, default=10, help="steps of the extra pass that keeps the windows and only resets them between steps "
                     "(round 2's headline, reported as config.optimise_only; 0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
@@ -108,6 +112,40 @@ def maybe_spawn(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def host_budget(world, local_rank, window_threads_arg=0, pin=True):
+    """Host cores of THIS rank: the ranks of a node split the cores the process may use (scheduler affinity, bounded by the cgroup's CPU quota)
+    into disjoint slices -- every rank builds, reads back and destroys its local-BA windows on host threads, and eight ranks that each size
+    their pool for the whole machine throttle each other (10 cores per rank on a 16-core quota).  With more than one rank on the
+    node the process is pinned to its slice (CMS_BENCH_NO_PIN=1: not).  Returns a dict that goes into the JSON line."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    usable = len(cores) if quota is None else min(len(cores), quota)
+    budget = max(2, usable // local_world)
+    lo = (local_rank % local_world) * (len(cores) // local_world)
+    mine = cores[lo:lo + max(budget, 1)] if local_world > 1 else cores
+    pinned = False
+    if pin and local_world > 1 and mine and os.environ.get("CMS_BENCH_NO_PIN", "") == "":
+        try:
+            os.sched_setaffinity(0, mine)
+            pinned = True
+        except (AttributeError, OSError):
+            pass
+    # one pool thread per core of the slice (between 4 and 32): the threads spend half their time waiting on the device, the main thread and the group threads wait too
+    wthreads = window_threads_arg or max(4, min(32, budget))
+    return {"cores_visible": len(cores), "cpu_quota_cores": quota, "local_world_size": local_world, "thread_budget": budget,
+            "core_slice": [mine[0], mine[-1]] if mine else None, "pinned": pinned, "window_threads": wthreads}
+
+
 def launcher_selftest(args, rank, world, local_rank):
     import torch
     import torch.distributed as dist
@@ -123,8 +161,10 @@ def launcher_selftest(args, rank, world, local_rank):
     else:
         seen = [0]
     # one write per record: the ranks share the launcher's stdout, and a record and its newline written separately can interleave
+    hb = host_budget(world, local_rank, args.window_threads)
     line = json.dumps({"launcher_selftest": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus_arg": args.gpus,
-                       "ranks_seen": seen, "pid": os.getpid(), "spawned_by_bench": os.environ.get("CMS_BENCH_SPAWNED") == "1"}) + "\n"
+                       "ranks_seen": seen, "pid": os.getpid(), "spawned_by_bench": os.environ.get("CMS_BENCH_SPAWNED") == "1", "host": hb,
+                       "affinity_now": sorted(os.sched_getaffinity(0))[:4] + ["..."] if hasattr(os, "sched_getaffinity") else None}) + "\n"
     sys.stdout.flush()
     os.write(sys.stdout.fileno(), line.encode())
 
@@ -319,7 +359,8 @@ def main():
     for p in all_probs:        # contiguous arrays of the C-ABI's types once, so that a window's creation is nothing but the cms_ba_create call
         p["poses"] = np.ascontiguousarray(p["poses"], np.float64); p["points"] = np.ascontiguousarray(p["points"], np.float64)
         p["e_obs"] = np.ascontiguousarray(p["e_obs"], np.float64)
-    n_wthreads = args.window_threads or max(4, min(32, (os.cpu_count() or 8) // max(4, 2 * world)))      # the ranks of a node share its cores
+    host = host_budget(world, local_rank, args.window_threads)      # the ranks of a node split its usable cores (and are pinned to their slice)
+    n_wthreads = host["window_threads"]
     wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
     group_stream = []           # one long-lived stream per window group (filled below): CreateNewMapPoints and the group's BA rounds
     cpu_acc = {"create": 0.0, "finish": 0.0, "n": 0}      # thread CPU seconds (developer knob CMS_BENCH_THREAD_CPU)
@@ -430,6 +471,7 @@ def main():
         return 1e3 * (time.perf_counter() - t_ba0), sum(len(r[0]) for r in res), stats, outs, [m[1] for m in made]
 
     part = os.environ.get("CMS_BENCH_PART", "")      # developer knob: "ba" / "frames" times one half of the step alone (not a bench line)
+    part_env = part
     pool = ThreadPoolExecutor(max_workers=n_grp)       # one standing host thread per window group (LocalMapping-like)
     last = {"traj": None, "ba_stats": None, "tri_new": 0, "ba_out": None, "set": 0}
     acc = {"ba_ms": 0.0, "ba_n": 0, "create_ms": 0.0, "create_n": 0}
@@ -469,6 +511,7 @@ def main():
     serial = os.environ.get("CMS_BENCH_SERIAL_EXTRACT", "") != ""
     ba_first = os.environ.get("CMS_BENCH_BA_FIRST", "")     # developer knob: hand the mapping side to its threads BEFORE the frame path is enqueued (value = head start in us)
     def step(i, streaming, keep=False):
+        part = life.get("part", part_env)             # (the extract-only pass sets "frames" for its steps)
         S = sets[i % 2]
         ths = []
         if ba_first and part != "frames" and life["on"]:
@@ -544,8 +587,10 @@ def main():
                     f.result()[0].close()
 
     step_times = [] if os.environ.get("CMS_BENCH_STEP_TIMES", "") != "" else None      # developer knob: host wall time of every timed step (stderr)
-    def timed(streaming, lifecycle=True, steps=None):
+    def timed(streaming, lifecycle=True, steps=None, only=""):
         steps = args.steps if steps is None else steps
+        part = only or part_env
+        life["part"] = part
         life["on"] = lifecycle and part != "frames"
         if streaming:
             ctx.upload_async(sets[0].pinned.array)
@@ -593,6 +638,7 @@ def main():
         for k in stage:
             stage[k] /= max(steps, 1)
         schur = [(schur_acc["ms"], schur_acc["n"])] if life["on"] else [grp[0].profile_get() for grp in groups]
+        life["part"] = part_env
         return dt, stage, acc["ba_ms"] / max(acc["ba_n"], 1), schur
 
     def thread_cpu():
@@ -611,7 +657,13 @@ def main():
         return out
     cpu0 = thread_cpu() if os.environ.get("CMS_BENCH_THREAD_CPU", "") != "" else None
     ctx.profile(True)
+    cpu_t0 = time.process_time()
     dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
+    host["host_cores_used"] = round((time.process_time() - cpu_t0) / max(dt, 1e-9), 2)      # CPU seconds of this process per second of the timed pass (warm-up included in both)
+    host_all = [host]
+    if world > 1:
+        host_all = [None] * world
+        dist.all_gather_object(host_all, host)
     if cpu0 is not None:
         cpu1 = thread_cpu()
         use = sorted(((cpu1[k] - cpu0.get(k, 0.0), k) for k in cpu1), reverse=True)
@@ -645,6 +697,30 @@ def main():
         optimise_only = {"value": round(total_frames_per_step * args.optimise_only_steps / dt_o, 2), "ms_per_step": round(1e3 * dt_o / args.optimise_only_steps, 3),
                          "ba_ms_per_step": round(ba_ms_o, 3), "steps": args.optimise_only_steps,
                          "note": "windows created once before the timed steps and reset between them (BENCH_r02's headline): kernels only, NOT like for like with the CPU baseline"}
+
+    # ---- the frame path alone (no mapping side in the step): the extractor's roofline without the local BA next to it, timed by this run
+    extract_only = None
+    if args.extract_only_steps > 0:
+        dt_f, stage_f, _, _ = timed(False, lifecycle=False, steps=args.extract_only_steps, only="frames")
+        extract_only = {"ms_per_step": round(1e3 * dt_f / args.extract_only_steps, 3), "steps": args.extract_only_steps,
+                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_f.items()},
+                        "note": "the same batches through remap + extraction + grids + searches + pose optimisation with no local BA / CreateNewMapPoints in the step"}
+    # ---- windows with RANDOM views (every point seen by an arbitrary subset of key frames: no signature runs, round 2's windows, the edge-major body
+    # on every point) next to the headline's tracked views: same steps, same life cycle
+    random_views = None
+    if args.random_views_steps > 0 and args.ba_views != "random":
+        with ThreadPoolExecutor(max_workers=8) as tp:
+            rp = list(tp.map(lambda w: synth.ba_problem(K=20, P=22150, obs_per_point=4, F=F, seed=42 + 1000 * rank + w, views="random"), range(2 * n_ba)))
+        for p_ in rp:
+            p_["poses"] = np.ascontiguousarray(p_["poses"], np.float64); p_["points"] = np.ascontiguousarray(p_["points"], np.float64)
+            p_["e_obs"] = np.ascontiguousarray(p_["e_obs"], np.float64)
+        keep_sets = list(prob_sets)
+        prob_sets[0], prob_sets[1] = rp[:n_ba], rp[n_ba:]
+        dt_r, _, ba_ms_r, _ = timed(False, steps=args.random_views_steps)
+        prob_sets[0], prob_sets[1] = keep_sets
+        random_views = {"value": round(total_frames_per_step * args.random_views_steps / dt_r, 2), "ms_per_step": round(1e3 * dt_r / args.random_views_steps, 3),
+                        "ba_ms_per_step": round(ba_ms_r, 3), "steps": args.random_views_steps, "edges_per_window": int(np.mean([len(p_["e_pose"]) for p_ in rp])),
+                        "note": "synth.ba_problem(views='random'): no point shares its set of observing key frames with enough others, every point goes through the edge-major Schur body"}
 
     # ---- outside the timed region: one more step with the windows' whole life cycle whose results are kept; iteration counts and outlier
     # counts of ALL its windows, and the estimates of a sample, against the CPU oracle
@@ -696,6 +772,10 @@ def main():
                                  "worst_key_frame": float("%.3g" % rel[1].max())})
             else:
                 worst = max(worst, float(rel[0].max()), float(rel[1].max()))
+        # about one window in twenty cascades; three or more in a sample of eight (0.6 % by chance) means something else is wrong
+        if len(cascaded) > max(2, len(sample) // 4):
+            raise SystemExit("bench.py: %d of %d sampled local-BA windows show a float-rounding cascade against the CPU oracle (expected about 1 in 20): %s" %
+                             (len(cascaded), len(sample), cascaded))
         its = [tuple(s.iterations_done) for gs in last["ba_stats"] for s in gs]
         ba_check = {"windows_with_iterations_and_outlier_flags_equal_to_the_oracle": n_ba, "windows_with_estimates_checked": sample,
                     "worst_relative_update_error": float("%.3g" % worst), "windows_with_a_float_rounding_cascade": cascaded,
@@ -715,7 +795,7 @@ def main():
     # measured HBM traffic / instruction mix of the kernels: committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
     # separate runs, tools/run_profiles.sh), valid for the batch size and geometry they were taken at
     def pmc(name, kname):
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             pj = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
             if os.path.exists(pj):
                 J = json.load(open(pj))
@@ -804,12 +884,15 @@ def main():
     # whole ORBextractor::operator() against SURVEY.md 8(d)'s compulsory traffic at the reference's stage granularity
     # (B_pyr + B_fast + B_blur + B_kp; the full-level blur pass is counted although the product never runs it)
     b_extract = (2 * P[0] + sum(P[l - 1] + P[l] for l in range(1, g.nlevels))) + sumP + 2 * sumP + nkp * (709 + 961 + 32 + 28)
-    ext_ms = sum(stage_ms.get(k, 0.0) for k in ("pyramid", "fast", "octree", "cull", "describe"))
-    extractor = None
-    if ext_ms > 0:
+    def extractor_of(stage):
+        ext_ms = sum(stage.get(k, 0.0) for k in ("pyramid", "fast", "octree", "cull", "describe"))
+        if ext_ms <= 0:
+            return None
         ext_gbs = b_extract * B / (ext_ms * 1e-3) / 1e9
-        extractor = {"survey_bytes_per_frame": int(b_extract), "us_per_frame": round(1e3 * ext_ms / B, 2), "GBps": round(ext_gbs, 1),
-                     "frac_of_8TBps": round(ext_gbs / peak, 4)}
+        return {"survey_bytes_per_frame": int(b_extract), "us_per_frame": round(1e3 * ext_ms / B, 2), "GBps": round(ext_gbs, 1), "frac_of_8TBps": round(ext_gbs / peak, 4)}
+    extractor = extractor_of(stage_ms)
+    if extract_only is not None:
+        extract_only["extractor_vs_survey_bytes"] = extractor_of(extract_only["stage_ms_per_step"])
 
     # ---- CPU baseline: the oracle, single thread, on a bounded sample of the same workload (rank 0, N=1 only)
     cpu = None
@@ -945,14 +1028,15 @@ def main():
                        "queues": {"frame_path_priority": fprio or "normal", "mapping_side_priority": os.environ.get("CMS_BENCH_MAP_PRIORITY", "") or "normal"},
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "fast_kernel_GBps": None if fast_gbs is None else round(fast_gbs, 1),
-                       "extractor_vs_survey_bytes": extractor,
+                       "extractor_vs_survey_bytes": extractor, "extract_only": extract_only,
+                       "host": host_all if world > 1 else host,
                        "ba_windows_per_step": n_ba, "ba_groups": n_grp,
                        "ba_window_setup": {"in_timed_region": True, "ms_per_window_one_after_the_other": round(ba_setup_ms, 2),
                                            "ms_per_window_inside_the_step": round(create_ms_in_step, 2), "window_threads": n_wthreads,
                                            "note": "every step creates its %d windows from the problems' host arrays (cms_ba_create: host work lists, one pinned upload), optimises "
                                                    "them, reads poses / points / outlier flags back (cms_ba_read) and destroys them; a pool of host threads builds step s + 1's "
                                                    "windows and finishes step s - 1's while step s runs, all inside the timed region" % n_ba},
-                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "ba_views": args.ba_views,
+                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "ba_views": args.ba_views, "ba_views_random": random_views,
                        "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
                        "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,

@@ -103,7 +103,9 @@ struct cms_ba {
   // 6 the trial kernel (kb_ba_trial_edges), 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
-  bool async_pending = false;   // something asynchronous (upload, reset) was enqueued on `stream` and nothing has waited for it yet
+  bool async_pending = false;   // something asynchronous (upload, reset, a group's rounds) was enqueued on `stream` and nothing has waited for it yet
+  bool gsum_clean = false;      // slice 0 of the Schur partial sums (the ONE global copy the workgroups add to, BaSe::gsum) is all zero: true after
+                                // k_ba_gather / k_ba_reset and after every consuming solve kernel, false once a slice-STORING group ran on the window
   BaSe grp_se = {};          // the window's share of the current group's Schur launch (ba_upload_items)
   std::vector<BaBlock> slabs; size_t slab_off = 0;      // device memory of the window: carved from pooled slabs (ba_alloc)
   size_t grp_pin_bytes[3] = {0, 0, 0};                  // sizes of grp_items_host, grp_scal_host, grp_lm_host (pooled pinned blocks)
@@ -157,7 +159,7 @@ static void ba_stream_give(int device, hipStream_t s) {
 struct BaMemPool {
   std::mutex mu;
   std::vector<BaBlock> dev[64], pin[64], stage[64];
-  size_t dev_cached[64] = {0};
+  size_t dev_cached[64] = {0}, pin_cached[64] = {0}, stage_cached[64] = {0};      // bytes held per kind (pinned kinds: at most 2 GB each)
 };
 static BaMemPool& ba_pool() { static BaMemPool* p = new BaMemPool; return *p; }      // never destroyed: no HIP calls at process exit
 static void* ba_pool_take(std::vector<BaBlock>& v, size_t bytes, size_t* got) {      // smallest cached block that is large enough (and not absurdly larger)
@@ -169,6 +171,35 @@ static void* ba_pool_take(std::vector<BaBlock>& v, size_t bytes, size_t* got) { 
   v[best] = v.back(); v.pop_back();
   return p;
 }
+// give the cached blocks of a device back to the runtime (all kinds, or only the device slabs); returns the bytes released
+static size_t ba_pool_trim_device(int device, bool pinned_too) {
+  BaMemPool& pl = ba_pool();
+  if (device < 0 || device >= 64) return 0;
+  std::vector<BaBlock> dv, pn, st;
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    dv.swap(pl.dev[device]); pl.dev_cached[device] = 0;
+    if (pinned_too) { pn.swap(pl.pin[device]); st.swap(pl.stage[device]); pl.pin_cached[device] = 0; pl.stage_cached[device] = 0; }
+  }
+  size_t n = 0;
+  for (const BaBlock& b : dv) { hipFree(b.p); n += b.bytes; }
+  for (const BaBlock& b : pn) { hipHostFree(b.p); n += b.bytes; }
+  for (const BaBlock& b : st) { hipHostFree(b.p); n += b.bytes; }
+  return n;
+}
+// The pool keeps slabs and pinned blocks of destroyed windows for the next window (a hipFree in the middle of a step synchronises the device).
+// Callers that share the device with other allocators can hand them back: bytes released are returned in *released (may be NULL).
+extern "C" int cms_ba_pool_trim(int device, size_t* released) {
+  if (device < 0 || device >= 64) return cms_fail(CMS_ERR_ARG, "cms_ba_pool_trim: bad device");
+  HIPCHK(hipSetDevice(device));
+  const size_t n = ba_pool_trim_device(device, true);
+  if (released) *released = n;
+  return CMS_OK;
+}
+static size_t ba_pool_cap_bytes() {      // CMS_BA_POOL_MB: upper bound of the cached device slabs per device (default 16 GB)
+  static const size_t cap = [] { const char* v = getenv("CMS_BA_POOL_MB"); return v ? (size_t)std::max(0, atoi(v)) << 20 : (size_t)16 << 30; }();
+  return cap;
+}
 static hipError_t ba_dev_take(int device, size_t bytes, void** p, size_t* got) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
@@ -176,13 +207,18 @@ static hipError_t ba_dev_take(int device, size_t bytes, void** p, size_t* got) {
     if ((*p = ba_pool_take(pl.dev[device], bytes, got)) != nullptr) { pl.dev_cached[device] -= *got; return hipSuccess; }
   }
   *got = bytes;
-  return hipMalloc(p, bytes);
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {      // gigabytes may sit idle in the cache: release them and try once more
+    (void)hipGetLastError();
+    if (ba_pool_trim_device(device, false) > 0) e = hipMalloc(p, bytes);
+  }
+  return e;
 }
 static void ba_dev_give(int device, void* p, size_t bytes) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (pl.dev_cached[device] + bytes <= ((size_t)16 << 30)) { pl.dev[device].push_back({p, bytes}); pl.dev_cached[device] += bytes; return; }
+    if (pl.dev_cached[device] + bytes <= ba_pool_cap_bytes()) { pl.dev[device].push_back({p, bytes}); pl.dev_cached[device] += bytes; return; }
   }
   hipFree(p);
 }
@@ -191,10 +227,12 @@ static hipError_t ba_pin_take(int device, size_t bytes, void** p, size_t* got) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if ((*p = ba_pool_take(pl.pin[device], bytes, got)) != nullptr) return hipSuccess;
+    if ((*p = ba_pool_take(pl.pin[device], bytes, got)) != nullptr) { pl.pin_cached[device] -= *got; return hipSuccess; }
   }
   *got = bytes;
-  return hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+  hipError_t e = hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) { (void)hipGetLastError(); if (ba_pool_trim_device(device, true) > 0) e = hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent); }
+  return e;
 }
 // plain pinned host memory (not device-coherent): staging blocks of uploads and read-backs.  A copy from / to such memory goes through the DMA
 // engines; the coherent, device-mapped kind above made the runtime copy with a shader kernel (__amd_rocclr_copyBuffer: 1.8 ms of kernel time
@@ -204,16 +242,19 @@ static hipError_t ba_stage_take(int device, size_t bytes, void** p, size_t* got)
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if ((*p = ba_pool_take(pl.stage[device], bytes, got)) != nullptr) return hipSuccess;
+    if ((*p = ba_pool_take(pl.stage[device], bytes, got)) != nullptr) { pl.stage_cached[device] -= *got; return hipSuccess; }
   }
   *got = bytes;
-  return hipHostMalloc(p, bytes, coherent ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault);
+  const unsigned flags = coherent ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault;
+  hipError_t e = hipHostMalloc(p, bytes, flags);
+  if (e != hipSuccess) { (void)hipGetLastError(); if (ba_pool_trim_device(device, true) > 0) e = hipHostMalloc(p, bytes, flags); }
+  return e;
 }
 static void ba_stage_give(int device, void* p, size_t bytes) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (pl.stage[device].size() < 512) { pl.stage[device].push_back({p, bytes}); return; }
+    if (pl.stage[device].size() < 512 && pl.stage_cached[device] + bytes <= ((size_t)2 << 30)) { pl.stage[device].push_back({p, bytes}); pl.stage_cached[device] += bytes; return; }
   }
   hipHostFree(p);
 }
@@ -221,7 +262,7 @@ static void ba_pin_give(int device, void* p, size_t bytes) {
   BaMemPool& pl = ba_pool();
   if (device >= 0 && device < 64) {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (pl.pin[device].size() < 512) { pl.pin[device].push_back({p, bytes}); return; }
+    if (pl.pin[device].size() < 512 && pl.pin_cached[device] + bytes <= ((size_t)2 << 30)) { pl.pin[device].push_back({p, bytes}); pl.pin_cached[device] += bytes; return; }
   }
   hipHostFree(p);
 }
@@ -1260,6 +1301,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
                      b->d_se_partial, b->d_se_partial ? b->se.npairs2 * 42 : 0, b->d_se_bp_partial, b->d_se_bp_partial ? b->np * 6 : 0);
   BA_HIP(hipGetLastError());
   b->async_pending = true;
+  b->gsum_clean = true;
   tick("reset");
   if (timing) fprintf(stderr, "[cms_ba_create] K %d P %d E %d ms:%s\n", K, P, E, t_log.c_str());
   *out = b;
@@ -1295,6 +1337,7 @@ extern "C" int cms_ba_reset(cms_ba* b) {
                      b->d_se_partial, b->d_se_partial ? b->se.npairs2 * 42 : 0, b->d_se_bp_partial, b->d_se_bp_partial ? b->np * 6 : 0);
   HIPCHK(hipGetLastError());
   b->async_pending = true;
+  b->gsum_clean = true;
   return CMS_OK;       // asynchronous on the window's stream: every consumer (optimize, read) orders itself behind it
 }
 

@@ -279,6 +279,15 @@ static int ba_upload_items(cms_ba** bas, int n) {
     }
     it.se.gsum = (use_se && gm.gsum) ? 1 : 0;
     b->grp_se = it.se;
+    if (use_se && b->d_se_partial) {
+      // the global copy of the reduced system (slice 0) must be zero when the first round of a gsum group adds to it; the consuming solve kernel
+      // leaves it zero, a slice-storing group (CMS_BA_NO_GLOBAL_SUM, mixed groups) does not
+      if (it.se.gsum && !b->gsum_clean) {
+        HIPCHK(hipMemsetAsync(b->d_se_partial, 0, (size_t)b->se.npairs2 * 42 * sizeof(double), g->stream));
+        HIPCHK(hipMemsetAsync(b->d_se_bp_partial, 0, (size_t)b->np * 6 * sizeof(double), g->stream));
+      }
+      b->gsum_clean = it.se.gsum != 0;
+    }
   }
   HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
   return CMS_OK;
@@ -595,6 +604,9 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
     if (rcg) return rcg;
     rcg = ba_upload_items(bas, n);          // static descriptions of the windows: once per call
     if (rcg) return rcg;
+    // from here on kernels of the group may be in flight on the shared stream: a window destroyed after an early error return must wait for
+    // them (cms_ba_destroy synchronises a shared stream only for windows with async_pending); cleared at the successful end of the call
+    for (int w = 0; w < n; ++w) bas[w]->async_pending = true;
   }
   std::vector<cms_ba_stats> local(n);
   for (int w = 0; w < n; ++w) memset(&local[w], 0, sizeof(cms_ba_stats));
@@ -644,6 +656,7 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
   if (rc) return rc;
   for (int w = 0; w < n; ++w) local[w].n_outliers_final = counts[w];
   if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats));
+  if (batched) for (int w = 0; w < n; ++w) bas[w]->async_pending = false;      // classify synchronised the group's stream: nothing of the windows is in flight
   return CMS_OK;
 }
 

@@ -69,11 +69,14 @@ static int cms_pose_upload_impl(cms_pose* p, int nf, const int* edge_off, const 
     const size_t o_off = 0, o_X = al(((size_t)nf + 1) * 4), o_obs = o_X + al((size_t)ne * 24), o_inv = o_obs + al((size_t)ne * 16), o_face = o_inv + al((size_t)ne * 8),
                  o_pose = o_face + al((size_t)ne), in_bytes = o_pose + al((size_t)nf * 56);
     const size_t out_bytes = al((size_t)nf * 32) + al((size_t)nf * 56) + al((size_t)ne);
-    if (in_bytes + out_bytes > p->h_stage_bytes) {
+    // the inputs use the first half of the block, the results of cms_pose_optimize_batch the second: EACH must fit its half (a block kept from
+    // a smaller call could hold in + out together and still be too short for a result set larger than the inputs)
+    if (2 * std::max(in_bytes, out_bytes) > p->h_stage_bytes) {
       if (p->h_stage) (void)hipHostFree(p->h_stage);
       p->h_stage = nullptr; p->h_stage_bytes = 0;
-      HIPCHK(hipHostMalloc((void**)&p->h_stage, 2 * (in_bytes + out_bytes)));
-      p->h_stage_bytes = 2 * (in_bytes + out_bytes);
+      const size_t want = 4 * std::max(in_bytes, out_bytes);
+      HIPCHK(hipHostMalloc((void**)&p->h_stage, want));
+      p->h_stage_bytes = want;
     }
     uint8_t* h = p->h_stage;
     memcpy(h + o_off, edge_off, ((size_t)nf + 1) * 4);

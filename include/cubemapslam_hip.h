@@ -205,6 +205,10 @@ int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, const int* e
 int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int* pinv, int* perm, uint32_t* info,
                       int* chunk_pt0, int* rm_chunk, uint32_t* run_lane, int* counts, uint32_t* run_mf, uint32_t* run_fl);
 void cms_ba_destroy(cms_ba* ba);
+/* Device slabs and pinned blocks of destroyed windows wait in a per-device pool for the next window (CMS_BA_POOL_MB bounds the device part, default
+ * 16384; the pool is also emptied and the allocation retried when hipMalloc fails).  cms_ba_pool_trim hands everything cached for `device` back
+ * to the runtime -- for callers that share the device with other allocators; *released (may be NULL) receives the bytes. */
+int cms_ba_pool_trim(int device, size_t* released);
 /* one-shot convenience: create + optimize + read + destroy */
 int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,
                const int* e_point, const double* e_obs, const double* e_invsig2, const int8_t* e_face, double fx, double fy,

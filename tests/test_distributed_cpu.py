@@ -109,3 +109,31 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=120)
     rec = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert one.returncode == 0 and rec["world"] == 1 and not rec["spawned_by_bench"]
+
+
+def test_ranks_of_a_node_get_disjoint_host_thread_budgets():
+    """Every rank builds, reads back and destroys its local-BA windows on host threads; the ranks of one node must not size their pools for the
+    whole machine (10 host cores per GPU).  bench.py's host_budget() splits the usable cores (scheduler affinity, bounded by the
+    cgroup's quota) into disjoint slices, one per local rank, pins the rank to its slice and sizes the window pool from it."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    ncores = len(os.sched_getaffinity(0))
+    if ncores < 4:
+        pytest.skip("needs at least four cores")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = sorted(_json_records(out.stdout), key=lambda r: r["local_rank"])
+    assert len(recs) == 2
+    hosts = [r["host"] for r in recs]
+    assert all(h["local_world_size"] == 2 and h["pinned"] for h in hosts)
+    assert sum(h["thread_budget"] for h in hosts) <= ncores
+    (a0, a1), (b0, b1) = hosts[0]["core_slice"], hosts[1]["core_slice"]
+    assert a1 < b0 or b1 < a0, hosts                                   # the slices do not overlap
+    assert all(4 <= h["window_threads"] <= max(4, h["thread_budget"]) for h in hosts)
+    # a single rank keeps the whole affinity mask and is not pinned
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=120)
+    h = _json_records(one.stdout)[0]["host"]
+    assert h["local_world_size"] == 1 and not h["pinned"] and h["thread_budget"] >= min(ncores, h["cpu_quota_cores"] or ncores)
+    # --window-threads overrides the pool size, not the budget
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-selftest", "--window-threads", "5"], env=env, capture_output=True, text=True, timeout=120)
+    assert _json_records(two.stdout)[0]["host"]["window_threads"] == 5

@@ -1351,3 +1351,43 @@ def test_distance_bounds_from_the_public_getters():
     rec = np.where((np.float32(1.2) * lo).astype(np.float32) == s_, lo, np.where((np.float32(1.2) * r).astype(np.float32) == s_, r, hi))
     assert np.array_equal((np.float32(1.2) * rec).astype(np.float32), s_) and (rec != x).mean() < 0.5 and np.abs(rec.view(np.int32) - x.view(np.int32)).max() <= 1
     ctx.close()
+
+
+def test_two_host_threads_create_contexts_and_windows_on_one_device():
+    """Per-device state of the library (the dynamic-LDS ceilings set once per device, the BA pools, the CU count of the range split) is keyed by the
+    device and guarded: two host threads that create contexts and local-BA windows on device 0 at the same time -- Tracking and LocalMapping do
+    (SURVEY.md 8b), and so do the ranks' window pools -- get the results of a quiet run."""
+    import threading
+    camd = synth.camera("lafida", 350)
+    mask = synth.cubemap_valid_mask(camd)
+    fish = synth.texture(camd["Ih"], camd["Iw"], 5)
+    prob = synth.ba_problem(K=6, P=600, obs_per_point=4, F=350, seed=77, views="track")
+    ref_ctx = api.Context(camd, nfeatures=1000, max_batch=1, device=0); ref_ctx.set_mask(mask)
+    ref_k, ref_d = ref_ctx.remap_extract(fish); ref_ctx.close()
+    ref_ba = api.ba_run(prob)
+    out, errs = [None, None], []
+
+    def worker(i):
+        try:
+            res = []
+            for rep in range(3):
+                c = api.Context(camd, nfeatures=1000, max_batch=1, device=0); c.set_mask(mask)
+                k, d = c.remap_extract(fish)
+                r = api.ba_run(prob, device=0)
+                c.close()
+                res.append((k, d, r))
+            out[i] = res
+        except Exception as ex:          # noqa: BLE001 -- reported by the main thread
+            errs.append(ex)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for res in out:
+        for k, d, r in res:
+            assert np.array_equal(k.view(np.uint8), ref_k.view(np.uint8)) and np.array_equal(d, ref_d)
+            assert list(r["stats"].iterations_done) == list(ref_ba["stats"].iterations_done) and np.array_equal(r["outliers"], ref_ba["outliers"])
+            assert np.abs(r["points"] - ref_ba["points"]).max() <= 1e-6 * max(np.abs(ref_ba["points"] - prob["points"]).max(), 1e-12) + 1e-12
