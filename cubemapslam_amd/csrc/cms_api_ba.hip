@@ -21,7 +21,7 @@ struct BaKnobs {
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, rm_valu;
   int solve_reduce_max, leftover_lookahead;
   bool global_sum;
-  int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap;
+  int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap, em_cost_a, em_cost_b; bool unified;
   char stream_priority;
 };
 static const BaKnobs& ba_knobs() {
@@ -48,7 +48,9 @@ static const BaKnobs& ba_knobs() {
     q.leftover_lookahead = num("CMS_BA_LEFTOVER_LOOKAHEAD", 0);      // 0: automatic (see ba_plan)
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
     q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", q.rm_valu ? 2 : 1));
-    q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 100)));
+    q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 58)));
+    q.unified = !on("CMS_BA_SPLIT_WORKGROUPS");          // 1: every Schur workgroup of a window takes run chunks and left-over chunks (cut by cost); 0: separate workgroups
+    q.em_cost_a = num("CMS_BA_EM_COST_A", 40); q.em_cost_b = num("CMS_BA_EM_COST_B", 30);      // cost of a left-over chunk: a + b x (edges of its largest point / 2), units of ba_rm_chunk_cost
     q.se_waves_cap = num("CMS_BA_SE_WAVES", 0);          // developer A/B: fewer wavefronts per Schur workgroup (how much of the kernel is latency?)
     const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
     q.stream_priority = pr ? pr[0] : 0;
@@ -88,7 +90,7 @@ struct cms_ba {
   // edge-major Schur work list (se.R == 0: not available: too many free key frames for the LDS copy of the reduced system)
   BaSe se = {};
   int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_bp_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
-  int* d_se_lone = nullptr; int4* d_rm_chunk = nullptr; uint2* d_run_lane = nullptr; uint32_t* d_run_mf = nullptr; uint32_t* d_run_fl = nullptr;
+  int* d_se_lone = nullptr; int4* d_rm_chunk = nullptr; uint2* d_run_lane = nullptr; uint32_t* d_run_mf = nullptr; uint32_t* d_run_fl = nullptr; uint32_t* d_rm_cost = nullptr;
   size_t se_lds_fixed = 0; int se_waves = 0;      // LDS of the edge-major kernel without the per-wavefront part; wavefronts per workgroup that fit
   size_t rm_lds = 0; int n_runs = 0, rm_points = 0;   // run-major part (cms_ba_schur_runs.hip): LDS it needs (0: the window has no runs), runs, points inside runs
   char* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned block the window's uploads went through; cms_ba_read's read-back reuses it
@@ -574,12 +576,21 @@ extern "C" int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, c
   return CMS_OK;
 }
 
-// Workgroups of one window for the Schur launch: `Rtotal` ranges are split between the run-major body (chunks [0, n_rm)) and the edge-major
-// body (the left-over chunks) by their work -- CMS_BA_RM_WEIGHT: cost of a run chunk in percent of an edge-major one (measured: about equal).
+// Workgroups of one window for the Schur launch.  Default: all `Rtotal` workgroups run the run-major body, whose wavefronts take equal shares of the
+// estimated cost of ALL chunks (run chunks, then left-over chunks: the edge-major chunk loop inside that body) -- measured on 16 tracked configs[3]
+// windows (tools/experiments_r04/exp.sh emcost, rmweight): 94 us a launch.  CMS_BA_SPLIT_WORKGROUPS=1: separate workgroups for the two kinds, split
+// by CMS_BA_RM_WEIGHT (cost of a run chunk in percent of an edge-major one: 100 -> 102.5 us, 60 -> 95.0, 50 -> 95.2, 40 -> 101.7: with 14 + 2
+// workgroups the two edge-major ones were the launch's long pole; a left-over chunk costs about 1.8 run chunks when eight wavefronts of a
+// workgroup all add to LDS, less next to run-major wavefronts).
 static void ba_se_split(BaSe& se, int Rtotal) {
   const int n_se = se.nchunks - se.n_rm;
   Rtotal = std::max(2, std::min(Rtotal, BA_SE_RANGES));
   int R_rm = 0, R_se = 0;
+  if (se.n_rm > 0 && n_se > 0 && ba_knobs().unified && !ba_knobs().rm_valu) {
+    // the run-major body's workgroups take the left-over chunks too (a wavefront's range is cut by cost over all chunks): se.R = 0 tells it so
+    se.cpw = 1; se.R = 0; se.R_rm = std::min(Rtotal, (se.nchunks + BA_SE_THREADS / 64 - 1) / (BA_SE_THREADS / 64));
+    return;
+  }
   if (se.n_rm > 0 && n_se > 0) {
     const double w_rm = 0.01 * ba_knobs().rm_weight * se.n_rm, w_se = (double)n_se;
     R_rm = (int)std::lround(Rtotal * w_rm / (w_rm + w_se));
@@ -603,7 +614,7 @@ struct BaPlan {
   std::vector<uint32_t> info;
   std::vector<int4> rm_chunk;
   std::vector<uint2> run_lane;
-  std::vector<uint32_t> run_mf, run_fl;
+  std::vector<uint32_t> run_mf, run_fl, rm_cost;
   bool se_built = false;
 };
 template <class Tick>
@@ -616,7 +627,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   std::vector<uint32_t>& info = pl.info;
   std::vector<int4>& rm_chunk = pl.rm_chunk;
   std::vector<uint2>& run_lane = pl.run_lane;
-  std::vector<uint32_t>&run_mf = pl.run_mf, &run_fl = pl.run_fl;
+  std::vector<uint32_t>&run_mf = pl.run_mf, &run_fl = pl.run_fl, &rm_cost = pl.rm_cost;
   bool& se_built = pl.se_built;
   struct InFlight { InFlight() { ba_plans_in_flight.fetch_add(1); } ~InFlight() { ba_plans_in_flight.fetch_sub(1); } } in_flight;
   const BaKnobs& kn = ba_knobs();
@@ -817,7 +828,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   tick("csr");
   // ---- work lists of the edge-major / run-major Schur kernels: chunks of whole points with <= 64 edges (one wavefront each), the per-edge
   // words, the runs' chunk descriptors and consumer-lane tables, the dense enumeration of the pose pairs s1 <= s2 for the solve kernel
-  ce0.clear(); pob.clear(); ident.clear(); lone.clear(); info.clear(); rm_chunk.clear(); run_lane.clear(); run_mf.clear(); run_fl.clear();
+  ce0.clear(); pob.clear(); ident.clear(); lone.clear(); info.clear(); rm_chunk.clear(); run_lane.clear(); run_mf.clear(); run_fl.clear(); rm_cost.clear();
   se_built = false;
   if (se_ok) {
     bool ok = true;
@@ -909,6 +920,19 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
               uint32_t& w = run_fl[(r * 64 + l) * 12 + (4 * t + g) / 2];
               w = ((4 * t + g) & 1) ? ((w & 0x0000FFFFu) | (off << 16)) : ((w & 0xFFFF0000u) | off);
             }
+      }
+      // running sum of the run chunks' estimated cost: the run-major body cuts the wavefronts' ranges by it
+      // (... and behind them the left-over chunks: an edge-major chunk costs a constant plus its steps of pair products -- half the edges of its
+      // largest point)
+      rm_cost.assign((size_t)nchunks + 1, 0u);
+      for (int c = 0; c < n_rm; ++c) {
+        const Run& R = runs[rm_chunk_run[c]];
+        rm_cost[(size_t)c + 1] = rm_cost[c] + ba_rm_chunk_cost(R.k, (int)run_mf[(size_t)rm_chunk_run[c] * 64 + 56], rm_chunk[c].y >> 16);
+      }
+      for (int c = n_rm; c < nchunks; ++c) {
+        int kmax = 1;
+        for (int e = ce0[c]; e < ce0[c + 1]; ++e) kmax = std::max(kmax, (int)((info[e] >> 5) & 31));
+        rm_cost[(size_t)c + 1] = rm_cost[c] + (uint32_t)(kn.em_cost_a + kn.em_cost_b * (kmax / 2));
       }
       if (run_fl.empty()) run_fl.assign(12, 0xFFFFFFFFu);
       if (run_mf.empty()) run_mf.assign(64, BA_RM_MF_NONE);
@@ -1056,6 +1080,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     up(pl.lone.data(), pl.lone.size() * sizeof(int), &b->d_se_lone);
     up(pl.rm_chunk.data(), pl.rm_chunk.size() * sizeof(int4), &b->d_rm_chunk); up(pl.run_lane.data(), pl.run_lane.size() * sizeof(uint2), &b->d_run_lane);
     up(pl.run_mf.data(), pl.run_mf.size() * sizeof(uint32_t), &b->d_run_mf); up(pl.run_fl.data(), pl.run_fl.size() * sizeof(uint32_t), &b->d_run_fl);
+    up(pl.rm_cost.data(), pl.rm_cost.size() * sizeof(uint32_t), &b->d_rm_cost);
   }
   tick("se");
   // A window that has the edge-major work list runs through the grouped driver with the edge-major kernels (cms_ba_optimize_many also puts
@@ -1291,7 +1316,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
   if (se_built) {
     BaSe& se = b->se;
-    se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane; se.run_mf = b->d_run_mf; se.run_fl = b->d_run_fl;
+    se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane; se.run_mf = b->d_run_mf; se.run_fl = b->d_run_fl; se.rm_cost = b->d_rm_cost;
   }
   tick("uploads");
   b->cur = 0;

@@ -54,6 +54,7 @@ struct BaSe {                      // device view of the edge-major work list (c
   const uint2* run_lane;          // runs x 64: which tuple of the signature a consumer lane multiplies, and where its sum goes (ba_rm_lane_*)
   const uint32_t* run_mf;         // runs x 64: rows / columns of a signature's stacked matrix for the MFMA variant (cms_ba_schur_runs.hip, BA_RM_MF_*)
   const uint32_t* run_fl;         // runs x 64 x 12: per lane, where its 24 MFMA accumulators are added (two 16-bit LDS offsets per word)
+  const uint32_t* rm_cost;        // n_rm + 1: running sum of the run chunks' estimated cost (ba_rm_chunk_cost): the wavefronts' ranges are cut by cost, not by count
   int Rt, cpw_t;                  // the same chunks cut into more, shorter ranges for the edge-major trial kernel (no LDS copy of the system to amortise)
   int npairs2;                    // np (np + 1) / 2: pose pairs s1 <= s2 enumerated densely, row by row
   const int* chunk_e0;            // nchunks + 1: first edge of every chunk (whole points, <= 64 edges)
@@ -68,7 +69,7 @@ struct BaSe {                      // device view of the edge-major work list (c
 
 struct BaSeG {                     // BaSe with global-memory pointer types (see BaDevG, cms_ba_kernels.hip): what the device bodies take
   int R, nchunks, cpw, n_rm, R_rm;
-  const BA_AS1 int4* rm_chunk; const BA_AS1 uint2* run_lane; const BA_AS1 uint32_t* run_mf; const BA_AS1 uint32_t* run_fl;
+  const BA_AS1 int4* rm_chunk; const BA_AS1 uint2* run_lane; const BA_AS1 uint32_t* run_mf; const BA_AS1 uint32_t* run_fl; const BA_AS1 uint32_t* rm_cost;
   int Rt, cpw_t, npairs2;
   const BA_AS1 int* chunk_e0; const BA_AS1 uint32_t* e_info;
   BA_AS1 double* partial; BA_AS1 double* bp_partial;
@@ -77,7 +78,7 @@ struct BaSeG {                     // BaSe with global-memory pointer types (see
   __device__ __forceinline__ BaSeG() {}
   __device__ __forceinline__ BaSeG(const BaSe& s)
       : R(s.R), nchunks(s.nchunks), cpw(s.cpw), n_rm(s.n_rm), R_rm(s.R_rm), rm_chunk(ba_g(s.rm_chunk)), run_lane(ba_g(s.run_lane)), run_mf(ba_g(s.run_mf)),
-        run_fl(ba_g(s.run_fl)), Rt(s.Rt), cpw_t(s.cpw_t), npairs2(s.npairs2), chunk_e0(ba_g(s.chunk_e0)), e_info(ba_g(s.e_info)), partial(ba_g(s.partial)),
+        run_fl(ba_g(s.run_fl)), rm_cost(ba_g(s.rm_cost)), Rt(s.Rt), cpw_t(s.cpw_t), npairs2(s.npairs2), chunk_e0(ba_g(s.chunk_e0)), e_info(ba_g(s.e_info)), partial(ba_g(s.partial)),
         bp_partial(ba_g(s.bp_partial)), lone(ba_g(s.lone)), nlone(s.nlone), gsum(s.gsum) {}
 };
 
@@ -109,31 +110,16 @@ __device__ __forceinline__ void ba_se_cam_point(const double* Rt, const double* 
 // of a stage on no other kernel linearises: kb_ba_lin + kb_ba_maxdiag drop out of the round (25 + 7 us of ~165 for eight windows), and a
 // rejected trial merely repeats arithmetic this kernel had to do anyway (it rebuilt the Jacobians from the estimate before, too).
 template <bool FUSED> __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSeG& se);
+// The chunks [c_begin, c_end) in steps of c_step, worked on by ONE wavefront: its 64 rows and row slots in LDS, the workgroup's copy (S, Dg) of the
+// reduced system and the key frames' rotations / translations (prt) are the caller's -- the edge-major body below (a wavefront takes every nw-th
+// chunk of the workgroup's range) and the run-major body (cms_ba_schur_runs.hip: a wavefront's share of the left-over chunks behind its run chunks).
 template <bool FUSED>
-__device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
-                                                    const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
+__device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c1, const int c_step, const BaDevG& d, const BaSeG& se, double* __restrict__ Hll,
+                                                  double* __restrict__ bl, const double lambda, const double* __restrict__ pts, const int robust, const double delta,
+                                                  double* S, double* Dg, double* myrows, int* myslot, const double* prt) {
 #pragma clang fp contract(fast)
-  extern __shared__ __align__(16) double se_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
-  double* S = se_lds;                                              // NPO x 37: off-diagonal pairs s1 < s2
-  double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);               // 4 x np x 33: copies of the diagonal blocks (upper triangle | rhs | bp)
-  double* rows = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // nw x 64 x 18 (16-byte aligned)
-  double* prt = rows + (size_t)nw * 64 * 18;                       // K x 12: rotation (row major) | translation of every key frame
-  int* rslot = reinterpret_cast<int*>(prt + (size_t)d.K * 12);     // nw x 64: free-pose slot of the edge in a row, -1 = contributes nothing
-  for (int i = tid; i < (int)(rows - S); i += blockDim.x) S[i] = 0.0;
-  for (int k = tid; k < d.K; k += blockDim.x) {
-    double R[9];
-    quat_to_R(poses + 7 * k + 3, R);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) prt[12 * k + i] = R[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) prt[12 * k + 9 + i] = poses[7 * k + i];
-  }
-  __syncthreads();
-  double* myrows = rows + (size_t)wave * 64 * 18;
-  int* myslot = rslot + wave * 64;
-  const int c0 = se.n_rm + BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);      // (the chunks in front of n_rm belong to the run-major body)
+  const int lane = threadIdx.x & 63;
+  const int np = d.np;
   // The loop is software pipelined over a wave's chunks: the per-edge words of chunk c + nw are requested before chunk c is worked on,
   // its per-point operands (position, Hll, bl) right after chunk c's rows are published -- the atomics section hides their latency.
   int n_p = 0, n_e = 0; uint32_t n_info = 0; double n_ow = 0.0;          // FUSED: n_ow carries the edge's information, n_lvl its exclusion flag -- RAW: the
@@ -162,16 +148,16 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, 
       }
     }
   };
-  load1(c0 + wave);
+  load1(c_begin);
   load2();
-  for (int c = c0 + wave; c < c1; c += nw) {
+  for (int c = c_begin; c < c1; c += c_step) {
     const uint32_t info = n_info;
     double ow = (FUSED && n_lvl != 0) ? 0.0 : n_ow;
     const int pnt = n_p, eid = n_e;
     const double2 obs = n_obs;
     const double X[3] = {n_X[0], n_X[1], n_X[2]};
     double Hc[6] = {n_H[0], n_H[1], n_H[2], n_H[3], n_H[4], n_H[5]}, bc[3] = {n_b[0], n_b[1], n_b[2]};
-    load1(c + nw);
+    load1(c + c_step);
     int slot = -1, a = 0, k = 1;
     double W[18], WD[18], z[3];
     double Jp[12], Jl[6], o0 = 0.0, o1 = 0.0;         // FUSED: kept for the key frame's own block on the diagonal tuple
@@ -339,6 +325,31 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, 
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <bool FUSED>
+__device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+                                                    const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
+  extern __shared__ __align__(16) double se_lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
+  double* S = se_lds;                                              // NPO x 37: off-diagonal pairs s1 < s2
+  double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);               // 4 x np x 33: copies of the diagonal blocks (upper triangle | rhs | bp)
+  double* rows = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // nw x 64 x 18 (16-byte aligned)
+  double* prt = rows + (size_t)nw * 64 * 18;                       // K x 12: rotation (row major) | translation of every key frame
+  int* rslot = reinterpret_cast<int*>(prt + (size_t)d.K * 12);     // nw x 64: free-pose slot of the edge in a row, -1 = contributes nothing
+  for (int i = tid; i < (int)(rows - S); i += blockDim.x) S[i] = 0.0;
+  for (int k = tid; k < d.K; k += blockDim.x) {
+    double R[9];
+    quat_to_R(poses + 7 * k + 3, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) prt[12 * k + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prt[12 * k + 9 + i] = poses[7 * k + i];
+  }
+  __syncthreads();
+  const int c0 = se.n_rm + BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);      // (the chunks in front of n_rm belong to the run-major body)
+  ba_se_wave_chunks<FUSED>(c0 + wave, c1, nw, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, rows + (size_t)wave * 64 * 18, rslot + wave * 64, prt);
   __syncthreads();
   ba_se_writeout<FUSED>(se.R_rm + BX, np, NP2, S, Dg, se);
 }

@@ -350,6 +350,14 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDevG d, BaSeG se, d
 // x 18 + 3 r), BA_RM_MF_RHS for the right-hand-side column, BA_RM_MF_NONE beyond it; [48 .. 55]: free-pose slot of key frame a; [56]: kf.
 // run_fl[(run * 64 + lane) * 12 + w]: where the lane's accumulators go, two 16-bit LDS offsets (doubles from the start of the copy; 0xFFFF:
 // nowhere -- lower triangle, padding) per word: accumulator g of tile t at index 4 t + g, tiles (0,0) (0,1) (1,1) | (0,2) (1,2) (2,2).
+// Estimated cost of a run chunk for the split of a window's run chunks over the wavefronts (units of ~170 cycles at two wavefronts per SIMD,
+// from the cycle stamps of profiles/r04_rm_phase_cycles.txt): a constant for the vector phase, the matrix instructions of the chunk (tiles of the
+// signature x three per four points), a little more when the points' shares go through the LDS rows instead of DPP.  Cut by COUNT the slowest
+// wavefront of a tracked configs[3] window carried 1.25x the mean (chunks of two-key-frame signatures cost 0.6x those of seven), and a
+// workgroup is as slow as its slowest wavefront; cut by this cost 1.10x.
+__host__ __device__ constexpr uint32_t ba_rm_chunk_cost(int k_run, int kf, int m) {
+  return 45u + (uint32_t)((kf <= 2 ? 1 : kf <= 5 ? 3 : 6) * 3 * ((m + 3) >> 2)) + ((k_run == 2 || k_run == 4) ? 0u : 5u);
+}
 #define BA_RM_MF_NONE 0xFFFFu
 #define BA_RM_MF_RHS 0xFFFEu
 typedef double ba_v4d __attribute__((ext_vector_type(4)));
@@ -411,7 +419,36 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   double* buf = slots + BA_RM_PTS * 6;                            // a row of 18 doubles per lane (the slots sit BELOW the rows: one upper limit for every read)
   const long long total_waves = (long long)se.R_rm * nw;
   const long long gw = (long long)BX * nw + wave;
-  const int cb = (int)(gw * se.n_rm / total_waves), ce = (int)((gw + 1) * se.n_rm / total_waves);
+  // the wavefront's range of chunks: equal shares of the chunks' estimated COST (se.rm_cost = its running sum over ALL chunks of the window: the
+  // run chunks [0, n_rm), then the left-over chunks).  se.R == 0: this body's workgroups take the left-over chunks too -- a wavefront whose
+  // range reaches behind n_rm hands that part to the edge-major body's chunk loop (below the run loop): the split between the two kinds of
+  // chunk then has the granularity of a wavefront, not of a workgroup (2 or 3 of a window's 16, the long pole of the launch either way).
+  // first chunk whose running sum reaches the wavefront's share: a 64-wide search, two rounds for up to 4095 chunks
+  const int n_all = se.R == 0 ? se.nchunks : se.n_rm;
+  auto first_at = [&](unsigned long long target) {
+    int lo = 0, span = n_all + 1;                                  // answer in [lo, lo + span): rm_cost[n_all] >= any target
+    while (span > 1) {
+      const int step = (span + 63) >> 6;
+      const int idx = min(lo + lane * step, n_all);
+      const bool below = lane * step < span && (unsigned long long)se.rm_cost[idx] < target;
+      const int nb = __popcll(__ballot(below));                    // probes below the target form a prefix (the sums ascend)
+      if (nb == 0) break;                                          // already the first probe reaches it: lo
+      const int hi = lo + span;
+      const int lo2 = lo + (nb - 1) * step + 1;                    // the answer lies behind the last probe below the target ...
+      span = min(lo + nb * step + 1, hi) - lo2;                    // ... and not behind the next probe (which may be the answer itself)
+      lo = lo2;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+  };
+  int cb, ce, eb, ee;                                              // run chunks [cb, ce), left-over chunks [eb, ee)
+  {
+    const unsigned long long total_cost = se.rm_cost[n_all];
+    int b0 = gw == 0 ? 0 : first_at((total_cost * (unsigned long long)gw + total_waves - 1) / total_waves);
+    int b1 = gw + 1 >= total_waves ? n_all : first_at((total_cost * (unsigned long long)(gw + 1) + total_waves - 1) / total_waves);
+    b0 = min(b0, n_all); b1 = max(min(b1, n_all), b0);
+    cb = min(b0, se.n_rm); ce = min(b1, se.n_rm);
+    eb = max(b0, se.n_rm); ee = max(b1, se.n_rm);
+  }
   const int li = lane & 15, lk = lane >> 4;
 
   double hp[27];
@@ -468,6 +505,10 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     }
   };
   load_chunk(d_cur);
+#ifdef BA_RM_DESYNC
+  // developer experiment: the two wavefronts of a SIMD (w and w + 4) start half a chunk apart
+  if (wave >= 4) { for (int i = 0; i < BA_RM_DESYNC; ++i) __builtin_amdgcn_s_sleep(127); }
+#endif
 #ifdef BA_RM_CLK
   const bool clk_on = BX == 0 && blockIdx.z == 0 && wave == 0;
   long long clk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -706,6 +747,23 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
         }
       }
     }
+#if defined(BA_RM_X_LDS) || defined(BA_RM_X_VALU) || defined(BA_RM_X_MFMA)
+    {
+      // developer experiment (sensitivity of the kernel to one more unit of each resource per chunk; results are NOT changed: the extra work
+      // feeds a value that is multiplied by zero)
+      double xacc = 0.0;
+#ifdef BA_RM_X_LDS
+      for (int i = 0; i < BA_RM_X_LDS; ++i) { const double v = *reinterpret_cast<volatile const double*>(buf + ((lane * 18 + i) & 1023)); xacc += v; }
+#endif
+#ifdef BA_RM_X_VALU
+      { double t = (double)lane; for (int i = 0; i < BA_RM_X_VALU; ++i) t = __builtin_fma(t, 1.0000001, 0.5); xacc += t; }
+#endif
+#ifdef BA_RM_X_MFMA
+      { ba_v4d t = (ba_v4d){0.0, 0.0, 0.0, 0.0}; for (int i = 0; i < BA_RM_X_MFMA; ++i) t = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lane, 1.0, t, 0, 0, 0); xacc += t[0]; }
+#endif
+      if (xacc == 123.456789) hp[0] += 1.0;
+    }
+#endif
     BA_RM_STAMP(7);                                                // matrix phase
     // ---------------------------------------------------------------- end of the run (or of this wavefront's range): one set of LDS additions
     if (d_cur.z != desc.z) {
@@ -742,6 +800,8 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     ba_rm_clk[12] = ce - cb;
   }
 #endif
+  // ---- the wavefront's left-over chunks (se.R == 0 only): the edge-major chunk loop on this wavefront's buffer (64 rows of 18 doubles, then the row slots)
+  if (eb < ee) ba_se_wave_chunks<true>(eb, ee, 1, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt);
   __syncthreads();
   ba_se_writeout<true>(BX, np, NP2, S, Dg, se);
 }

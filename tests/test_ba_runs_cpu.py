@@ -155,10 +155,19 @@ def test_run_plan_replays_the_schur_sum(K, P, views, seed):
 def test_range_split_and_left_over_chunks():
     prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=7, views="track")
     pl, pt_off, s_pose, s_pt, slot_of, a_of, s_of = _structure(prob)
-    assert pl["R_rm"] >= 1 and pl["R"] >= 1 and pl["R_rm"] + pl["R"] <= 128
-    assert pl["R_rm"] * 8 <= max(pl["n_rm"], 8) + 7                            # a wavefront of the run-major workgroups has at least one chunk
-    # with CMS_BA_NO_RUNS (child process: the switch is read once) every point is a left-over point and the plan is the old composition
+    # default: the run-major body's workgroups take every chunk of the window (its wavefronts' ranges are cut by cost over all of them)
+    assert pl["R_rm"] >= 1 and pl["R"] == 0 and pl["R_rm"] <= 128 and pl["n_rm"] < pl["n_chunks"]
+    assert pl["R_rm"] * 8 <= max(pl["n_chunks"], 8) + 7                        # a wavefront has at least one chunk
     import os, subprocess, sys
+    # CMS_BA_SPLIT_WORKGROUPS (child process: the switches are read once): separate workgroups for run chunks and left-over chunks
+    code = ("import sys; sys.path.insert(0, %r); from cubemapslam_amd import api, synth; "
+            "p = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=7, views='track'); "
+            "pl = api.ba_plan(p['fixed'], len(p['points']), p['e_pose'], p['e_point']); print(pl['R_rm'], pl['R'], pl['n_rm'])"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    R_rm, R, n_rm = (int(v) for v in subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CMS_BA_SPLIT_WORKGROUPS="1"), capture_output=True, text=True,
+                                                     check=True).stdout.split())
+    assert R_rm >= 1 and R >= 1 and R_rm + R <= 128 and R_rm * 8 <= max(n_rm, 8) + 7
+    # with CMS_BA_NO_RUNS every point is a left-over point and the plan is the old composition
     code = ("import sys; sys.path.insert(0, %r); from cubemapslam_amd import api, synth; "
             "p = synth.ba_problem(K=20, P=3000, obs_per_point=4, F=550, seed=7, views='track'); "
             "pl = api.ba_plan(p['fixed'], len(p['points']), p['e_pose'], p['e_point']); print(pl['n_rm'], pl['n_runs'], pl['rm_points'], pl['n_chunks'])"

@@ -62,6 +62,25 @@ for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:26]:
     print("%-34s calls %6s  avg %9.1f us  total %8.2f ms" % (r["Name"].split("(")[0][:34], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
     tail -c 400 $OUT/bench.json | cut -c1-300; rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv ;;
+  pmcwait)  # where a wavefront's cycles go (disjoint: WAIT_ANY parked in s_waitcnt / barrier, WAIT_INST_ANY issue stall, ACTIVE_INST_ANY issuing)
+    shift
+    R=$PWD
+    for v in ${@:-default}; do
+      OUT=$R/$O/pmcw_$v; rm -rf $OUT; mkdir -p $OUT
+      i=0
+      for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM"; do
+        i=$((i+1))
+        (cd /tmp && TMPDIR=/tmp CMS_HIP_LIB=$(cd $R && libpath $v) timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT -o p$i -- python $R/tools/prof_ba_many.py 16 track diff > $OUT/p$i.log 2>&1)
+      done
+      rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv
+      echo "== $v"; python tools/pmc_mix.py $OUT | grep "schur\|trial_edges" | tr ' ' '\n' | tee -a $O/pmcwait.txt
+    done ;;
+  rmweight)  # split of a window's workgroups between the run-major and the edge-major body (CMS_BA_RM_WEIGHT)
+    for w in 100 60 50 40 30; do echo "CMS_BA_RM_WEIGHT=$w: $(CMS_BA_RM_WEIGHT=$w timeout 300 python tools/prof_ba_many.py 16 track diff 3 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/rmweight.txt; done ;;
+  emcost)  # run chunks and left-over chunks in the same workgroups: cost model of a left-over chunk (a + b x steps), against separate workgroups
+    run1() { echo "$1: $(env $1 timeout 300 python tools/prof_ba_many.py 16 track diff 3 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/emcost.txt; }
+    run1 "CMS_BA_SPLIT_WORKGROUPS=1"
+    for ab in ${EMCOST_SET:-60:45 40:30 80:60 110:80 60:20 100:40 140:100}; do run1 "CMS_BA_EM_COST_A=${ab%:*} CMS_BA_EM_COST_B=${ab#*:}"; done ;;
   batests)  # the BA parity tests only
     timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ba_" 2>&1 | tail -8 | tee $O/batests.txt ;;
   tests)
