@@ -312,7 +312,7 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
     for (int w = 0; w < n; ++w) memset(&hlm0[w], 0, sizeof(BaLmDev));
     hipLaunchKernelGGL(kb_ba_lm_load, dim3((n + 63) / 64), dim3(64), 0, s, ditems, n, st[0].robust ? 1 : 0);
   }
-  BaDyn dyn;
+  BaDyn dyn{};
   memset(&dyn, 0, sizeof(dyn));
   dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0;
   for (;;) {
@@ -387,7 +387,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   }
   // the device copy is filled by a one-wave kernel reading the pinned block (a copy command in the stream costs ~20 us of queue time)
   hipLaunchKernelGGL(kb_ba_lm_load, dim3((n + 63) / 64), dim3(64), 0, s, ditems, n, st[0].robust ? 1 : 0);
-  BaDyn dyn;
+  BaDyn dyn{};
   memset(&dyn, 0, sizeof(dyn));
   dyn.robust = st[0].robust; dyn.delta = st[0].delta; dyn.chi2_th = 5.991; dyn.set_level = 0; dyn.dev_lm = 1; dyn.fold_finish = 1;
   bool first_round = false;
@@ -424,6 +424,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
   const bool solve_reduces = fused && (gm.gsum || (!ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max));
   dyn.fused_lin = fused ? 1 : 0;
+  dyn.fold_reduce = (use_te && !ba_knobs().separate_reduce2) ? 1 : 0;      // the trial kernel sums its own partial sums and decides the trial (kb_ba_trial_edges)
   int k = 0;
   const int pk = g->prof_kernel;
   const int dup = ba_knobs().dup;   // developer knob: launch kernel <id> of every round twice (all of
@@ -506,7 +507,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
       }
       bracket(6, 1);
       bracket(7, 0);
-      hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      if (!dyn.fold_reduce) hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);      // (otherwise the trial kernel's last workgroup per window)
       bracket(7, 1);
       ++k;
   };
@@ -550,7 +551,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
 static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<int>& counts) {
   cms_ba* g = bas[0];
   hipStream_t s = g->stream;
-  BaDyn dyn;
+  BaDyn dyn{};
   memset(&dyn, 0, sizeof(dyn));
   dyn.chi2_th = 5.991; dyn.set_level = set_level;
   int max_e = 0;

@@ -406,7 +406,7 @@ __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const
 __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDevG d, BaSeG se, const double* __restrict__ bl, const double* __restrict__ Hll,
                                                     const double* __restrict__ xp, double lambda, const double* __restrict__ pts, double* __restrict__ pts_new,
                                                     const double* __restrict__ poses_cur, const double* __restrict__ poses_new, int robust, double delta,
-                                                    double* __restrict__ partial) {
+                                                    double* __restrict__ partial, bool handover = false) {
   extern __shared__ __align__(16) double te_lds[];     // K x 12 (current poses) | K x 12 (trial poses) | np x 6 (pose update)
   __shared__ double sh[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -520,5 +520,13 @@ __device__ __forceinline__ void ba_trial_edges_body(int BX, int GX, BaDevG d, Ba
   }
   const double s1 = block_sum(chi, sh);
   const double s2 = block_sum(sc, sh);
-  if (threadIdx.x == 0) { partial[BX] = s1; partial[GX + BX] = s2; }
+  if (threadIdx.x == 0) {
+    if (handover) {
+      // (kb_ba_trial_edges, dyn.fold_reduce) the sums are read by another workgroup of this launch: atomic exchanges, and their returned
+      // values waited for -- both are performed before this thread takes its ticket
+      const unsigned long long o1 = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(partial + BX), (unsigned long long)__double_as_longlong(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long o2 = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(partial + GX + BX), (unsigned long long)__double_as_longlong(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" :: "v"(o1), "v"(o2) : "memory");
+    } else { partial[BX] = s1; partial[GX + BX] = s2; }
+  }
 }

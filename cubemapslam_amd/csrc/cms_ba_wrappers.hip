@@ -74,7 +74,7 @@ struct BaDyn {
   int robust, set_level;
   double delta, chi2_th;
   int dev_lm, fold_finish;                           // 1: phase / cur / lambda / first_iter come from BaItem::lm instead of the arrays above
-  int fused_lin, pad;                                // 1: kb_ba_schur_edges linearises itself (cms_ba_schur_edges.hip): no ITER phase after a stage's first iteration
+  int fused_lin, fold_reduce;                        // fused_lin 1: kb_ba_schur_edges linearises itself (cms_ba_schur_edges.hip): no ITER phase after a stage's first iteration
 };
 enum { BA_PHASE_IDLE = 0, BA_PHASE_ITER = 1, BA_PHASE_TRIAL = 2, BA_PHASE_CLASSIFY = 3 };
 
@@ -338,35 +338,71 @@ extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaIte
   ba_trial_points_body(blockIdx.x, it.nblk_p, it.d, it.bl, it.Hpl, it.Dinv, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[nxt], dyn.robust,
                        dyn.delta, it.partial, it.block_free ? it.Hll : nullptr, it.block_free ? it.poses[cur] : nullptr);
 }
-extern "C" __global__ void __launch_bounds__(BA_TE_THREADS) kb_ba_trial_edges(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
-  BA_ITEM(phase, it.se.Rt)
-  ba_trial_edges_body(blockIdx.x, it.se.Rt, it.d, it.se, it.bl, it.Hll, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[cur], it.poses[nxt], dyn.robust,
-                      dyn.delta, it.partial);
+// last step of the TRIAL phase: chi2(trial), gain denominator, accept / reject, then publish (see kb_ba_maxdiag)
+__device__ __forceinline__ void ba_round_count(const BaItem* __restrict__ items) {
+  // round counter of the group (one thread per round calls this), mirrored into pinned host memory AFTER window 0's state: the host driver
+  // paces its launches on it without ever synchronising the stream (see ba_optimize_stage_batched_dev); bumped first, the host saw the round
+  // end before the windows' "finished" flags and queued idle rounds (5 per window group and call instead of 2).  The mirror is fine-grained
+  // coherent host memory (uncached on the device, hipHostMallocCoherent): stores of one thread arrive in order, no fence -- a system-scope
+  // release would write back this XCD's whole L2, the 19 us the pacing scheme exists to avoid.  The other windows' blocks are not ordered
+  // against this counter; the host only uses the mirrored state to decide whether to queue another round (an early counter costs at most
+  // one idle round) and reads the final state after synchronising the stream.
+  BaLmDev* L0 = items[0].lm;
+  const int r = L0->rounds + 1;
+  L0->rounds = r;
+  *reinterpret_cast<volatile int*>(&items[0].hlm->rounds) = r;
 }
-// last kernel of the TRIAL phase: chi2(trial), gain denominator, then publish (see kb_ba_maxdiag)
-__device__ __forceinline__ void kb_ba_reduce2_window(const BaItem* __restrict__ items, const BaDyn& dyn, int phase) {
-  BA_ITEM(phase, 1)
-  ba_reduce2_body(0, 1, it.partial, it.se.Rt > 0 ? it.se.Rt : it.nblk_p, it.scal, it.hscal);   // partial sums of kb_ba_trial_edges / kb_ba_trial_points
+__device__ __forceinline__ void ba_trial_publish(const BaItemG& it, const BaDyn& dyn) {
   if (dyn.dev_lm && threadIdx.x == 0) {
     const int ok2 = (int)__double_as_longlong(it.scal[4]);      // (the solver's status word sits in the low half of scal[4])
     ba_lm_after_trial(it.lm, it.hlm, it.scal[1], it.scal[2], ok2, dyn.fused_lin != 0);
   }
 }
+// dyn.fold_reduce: the trial kernel is the round's LAST launch -- the workgroup of a window that finishes last sums the window's partial sums
+// (what kb_ba_reduce2 did in a launch of its own: 8 us alone, 24 us inside the step, plus the gap in front of it) and decides the trial.
+// A workgroup hands its two sums over with returning atomic exchanges (read-modify-writes are coherent across the XCDs' L2 caches, plain
+// stores only become so at the end of the kernel), waits for the returned values -- the exchanges are then performed -- and takes a ticket;
+// the holder of the last ticket reads the partial sums back the same way (an atomic addition of zero) and adds them in kb_ba_reduce2's
+// order: the same bits as the separate launch, whichever workgroup comes last.  No fence: nothing but these atomics is handed over.
+#define BA_TICKET_SLOT 7       /* scal[7] (the group keeps eight scalars per window): the window's ticket counter (an int; zeroed by kb_ba_lm_load, put back to zero by the last workgroup) */
+extern "C" __global__ void __launch_bounds__(BA_TE_THREADS) kb_ba_trial_edges(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  // the group's round counter follows window 0's state when that window takes part in the round (its last workgroup, below); a window 0 that
+  // is through counts the round right away (the host then queues the next round a little early: at most one idle round, see ba_round_count)
+  if (dyn.fold_reduce && dyn.dev_lm && blockIdx.z == 0 && blockIdx.x == 0 && threadIdx.x == 0 && (items[0].lm->next != 1 || items[0].se.Rt < 1)) ba_round_count(items);
+  BA_ITEM(phase, it.se.Rt)
+  ba_trial_edges_body(blockIdx.x, it.se.Rt, it.d, it.se, it.bl, it.Hll, it.x, ba_lambda, it.pts[cur], it.pts[nxt], it.poses[cur], it.poses[nxt], dyn.robust,
+                      dyn.delta, it.partial, dyn.fold_reduce != 0);
+  if (!dyn.fold_reduce) return;
+  __shared__ int last_sh;
+  __shared__ double sh2[16];
+  const int n = it.se.Rt;
+  int* ticket = reinterpret_cast<int*>((double*)it.scal + BA_TICKET_SLOT);
+  if (threadIdx.x == 0) last_sh = atomicAdd(ticket, 1) == n - 1;      // (the body's thread 0 waited for its two exchanges before it returned)
+  __syncthreads();
+  if (!last_sh) return;
+  double* partial = it.partial;
+  double v1 = 0, v2 = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { v1 += atomicAdd(partial + i, 0.0); v2 += atomicAdd(partial + n + i, 0.0); }
+  const double s1 = block_sum(v1, sh2);
+  const double s2 = block_sum(v2, sh2);
+  if (threadIdx.x == 0) {
+    const double den = s2 + it.scal[5];
+    it.scal[1] = s1; it.scal[2] = den;
+    it.hscal[1] = s1; it.hscal[2] = den; it.hscal[4] = it.scal[4];      // pinned host mirror (batched driver)
+    atomicExch(ticket, 0);
+  }
+  ba_trial_publish(it, dyn);
+  if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) ba_round_count(items);
+}
+// last kernel of the TRIAL phase when the trial kernel does not fold it
+__device__ __forceinline__ void kb_ba_reduce2_window(const BaItem* __restrict__ items, const BaDyn& dyn, int phase) {
+  BA_ITEM(phase, 1)
+  ba_reduce2_body(0, 1, it.partial, it.se.Rt > 0 ? it.se.Rt : it.nblk_p, it.scal, it.hscal);   // partial sums of kb_ba_trial_edges / kb_ba_trial_points
+  ba_trial_publish(it, dyn);
+}
 extern "C" __global__ void __launch_bounds__(256) kb_ba_reduce2(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   kb_ba_reduce2_window(items, dyn, phase);
-  if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) {
-    // round counter of the group, mirrored into pinned host memory AFTER this window's state: the host driver paces its launches on
-    // it without ever synchronising the stream (see ba_optimize_stage_batched_dev); bumped first, the host saw the round end before
-    // the windows' "finished" flags and queued idle rounds (5 per window group and call instead of 2).  The mirror is fine-grained
-    // coherent host memory (uncached on the device, hipHostMallocCoherent): stores of one thread arrive in order, no fence -- a
-    // system-scope release would write back this XCD's whole L2, the 19 us the pacing scheme exists to avoid.  The other windows'
-    // blocks are not ordered against this counter; the host only uses the mirrored state to decide whether to queue another round
-    // (an early counter costs at most one idle round) and reads the final state after synchronising the stream.
-    BaLmDev* L0 = items[0].lm;
-    const int r = L0->rounds + 1;
-    L0->rounds = r;
-    *reinterpret_cast<volatile int*>(&items[0].hlm->rounds) = r;
-  }
+  if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) ba_round_count(items);
 }
 extern "C" __global__ void __launch_bounds__(256) kb_ba_classify(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_e)
@@ -386,6 +422,7 @@ extern "C" __global__ void __launch_bounds__(64) kb_ba_lm_load(const BaItem* __r
   L.n_out[0] = clear_counts ? 0 : old.n_out[0];      // the first stage of a call clears both counters (the final classification
   L.n_out[1] = clear_counts ? 0 : old.n_out[1];      // also runs when a stop request skips the second stage)
   *items[w].lm = L;
+  reinterpret_cast<int*>(items[w].scal + 7)[0] = 0;        // ticket counter of the trial kernel's folded reduction (BA_TICKET_SLOT)
 }
 // after a classification: the windows' outlier counters -> pinned host block
 extern "C" __global__ void __launch_bounds__(64) kb_ba_counts_publish(const BaItem* __restrict__ items, int n) {
