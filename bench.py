@@ -433,12 +433,13 @@ def main():
 
     schur_acc = {"ms": 0.0, "n": 0}
     worker_ms = {}
+    step_trace = [] if os.environ.get("CMS_BENCH_STEP_TRACE", "") != "" else None      # developer knob: host time stamps of the step loop (stderr at exit)
     stagger = os.environ.get("CMS_BENCH_STAGGER", "") != ""        # developer knob: odd groups run their BA first and CreateNewMapPoints (of their NEXT step's key frames) after it
     tri_last = os.environ.get("CMS_BENCH_TRI_LAST", "") != ""      # developer knob: CreateNewMapPoints behind the group's BA instead of in front of it
     def ba_worker(grp, gi, keep):
         """optimise-only pass: one group of STANDING windows of one step; returns (elapsed ms, new map points, per-window stats)"""
         t_ba0 = time.perf_counter()
-        res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+        res = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=False)
         _, stats = api.ba_optimize_many(grp, (5, 10))   # the group's windows share every launch (kb_ba_* kernels, one window per blockIdx.z)
         if not keep:
             for ba in grp:                       # benchmark plumbing: put the initial estimate back for the next step (asynchronous; done
@@ -455,16 +456,21 @@ def main():
         grp = [m[0] for m in made]
         grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (the BA chain's largest kernel)
         last_here = tri_last or (stagger and gi % 2 == 1)
+        t_p = time.perf_counter()
         if not last_here:
-            res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+            res = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=False)
         t_t = time.perf_counter()
+        worker_ms["profile_arm"] = worker_ms.get("profile_arm", 0.0) + 1e3 * (t_p - t_w)
+        worker_ms["create_new_map_points_library_call"] = worker_ms.get("create_new_map_points_library_call", 0.0) + getattr(tri_store[gi], "last_call_ms", 0.0)
         _, stats = api.ba_optimize_many(grp, (5, 10))
         t_o = time.perf_counter()
         if last_here:
-            res = tri_store[gi].create_new_map_points(tri_jobs[gi])
+            res = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=False)
         ms, nl = grp[0].profile_get()
         schur_acc["ms"] += ms; schur_acc["n"] += nl
         outs = [wpool.submit(finish_window, ba) for ba in grp]
+        if step_trace is not None:
+            step_trace.append(("worker %d" % gi, t_ba0, t_w, t_t, t_o, time.perf_counter()))
         for k_, v_ in (("wait_for_windows", t_w - t_ba0), ("create_new_map_points", t_t - t_w), ("optimize_many", t_o - t_t), ("hand_over", time.perf_counter() - t_o)):
             worker_ms[k_] = worker_ms.get(k_, 0.0) + 1e3 * v_
         worker_ms["n"] = worker_ms.get("n", 0) + 1
@@ -512,6 +518,8 @@ def main():
     ba_first = os.environ.get("CMS_BENCH_BA_FIRST", "")     # developer knob: hand the mapping side to its threads BEFORE the frame path is enqueued (value = head start in us)
     def step(i, streaming, keep=False):
         part = life.get("part", part_env)             # (the extract-only pass sets "frames" for its steps)
+        if step_trace is not None:
+            step_trace.append(("step %d begins" % i, time.perf_counter()))
         S = sets[i % 2]
         ths = []
         if ba_first and part != "frames" and life["on"]:
@@ -551,7 +559,11 @@ def main():
             _, frame_poses, _, _ = po.fetch()
         if life.get("deferred") is not None:
             submit_windows(life.pop("deferred"))
+        if step_trace is not None:
+            step_trace.append(("frame path waited for", time.perf_counter()))
         res = [th.result() for th in ths]     # raises what a worker raised
+        if step_trace is not None:
+            step_trace.append(("workers done", time.perf_counter()))
         if res:
             acc["ba_ms"] += sum(r[0] for r in res) / len(res); acc["ba_n"] += 1
             last["tri_new"] = sum(r[1] for r in res)
@@ -560,6 +572,8 @@ def main():
                 # the read-backs of THIS step's windows finish under the next step; at most two steps' worth are ever outstanding
                 for f in life["reads"]:
                     f.result()
+                if step_trace is not None:
+                    step_trace.append(("previous step's read-backs waited for", time.perf_counter()))
                 life["reads"] = [f for r in res for f in r[3]]
                 if keep:
                     last["ba_out"] = [[f.result() for f in r[3]] for r in res]
@@ -674,6 +688,13 @@ def main():
             tot, dt, tot / dt, ", ".join("%s/%s %.0f%%" % (k[1], k[0], 100 * u / dt) for u, k in use[:48])), file=sys.stderr)
     if step_times is not None:
         print("step times (ms):", step_times, file=sys.stderr); step_times.clear()
+    if step_trace:
+        # the last three steps: every stamp in ms after the step's beginning
+        begins = [k for k, e in enumerate(step_trace) if e[0].startswith("step ")]
+        for b0, b1 in zip(begins[-3:], begins[-2:] + [len(step_trace)]):
+            tb = step_trace[b0][1]
+            print(step_trace[b0][0] + ": " + "; ".join("%s %s" % (e[0], " ".join("%.2f" % (1e3 * (t - tb)) for t in e[1:])) for e in sorted(step_trace[b0 + 1:b1], key=lambda e: e[-1])), file=sys.stderr)
+        step_trace.clear()
     create_ms_in_step = acc["create_ms"] / max(acc["create_n"], 1)
     worker_break = {k_: round(v_ / max(worker_ms.get("n", 1), 1), 3) for k_, v_ in worker_ms.items() if k_ != "n"}      # per window group and step
     if part:

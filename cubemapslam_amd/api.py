@@ -3,6 +3,7 @@
 Plumbing only: every call goes straight to the hand-written HIP library.  There is NO CPU fallback: if the shared
 library is missing or no MI355X is visible the calls raise.
 """
+import time
 import ctypes as C
 import os
 import numpy as np
@@ -574,16 +575,29 @@ class KeyframeStore:
         _chk(lib().cms_kfstore_fuse_search(self.h, nj, _p(slots), _p(off), *[_p(v) for v in a], th, _p(bi), _p(bd)), "cms_kfstore_fuse_search")
         return [(bi[off[j]:off[j + 1]].copy(), bd[off[j]:off[j + 1]].copy()) for j in range(nj)]
 
-    def create_new_map_points(self, jobs, check_orientation=False, cap=2048):
-        """jobs: list of (current slot, [neighbour slots in covisibility order]) -> per job (neigh, idx1, idx2, x3d)"""
+    def create_new_map_points(self, jobs, check_orientation=False, cap=2048, copy=True):
+        """jobs: list of (current slot, [neighbour slots in covisibility order]) -> per job (neigh, idx1, idx2, x3d).
+        The job arrays and the output buffers are kept between calls with the same job list (a mapping thread calls this once per key frame,
+        next to threads that hold the interpreter lock: fresh 0.8 MB of zeroed arrays per call were ~2 ms of a 3 ms call whose library
+        part takes 0.3 ms).  copy=False returns views into those buffers, valid until the next call."""
         nj = len(jobs)
-        cur = np.array([j[0] for j in jobs], np.int32)
-        neigh = np.array([s for j in jobs for s in j[1]] + [0], np.int32)
-        off = np.concatenate([[0], np.cumsum([len(j[1]) for j in jobs])]).astype(np.int32)
-        n_new = np.zeros(max(nj, 1), np.int32)
-        on = np.zeros((max(nj, 1), cap), np.int32); o1 = np.zeros_like(on); o2 = np.zeros_like(on); ox = np.zeros((max(nj, 1), cap, 3), np.float32)
-        _chk(lib().cms_kfstore_create_new_map_points(self.h, nj, _p(cur), _p(off), _p(neigh), int(check_orientation), cap, _p(n_new), _p(on), _p(o1), _p(o2),
-                                                     _p(ox)), "cms_kfstore_create_new_map_points")
+        key = (id(jobs), nj, cap)
+        st = getattr(self, "_cnmp", None)
+        if st is None or st[0] != key:
+            cur = np.array([j[0] for j in jobs], np.int32)
+            neigh = np.array([s for j in jobs for s in j[1]] + [0], np.int32)
+            off = np.concatenate([[0], np.cumsum([len(j[1]) for j in jobs])]).astype(np.int32)
+            n_new = np.zeros(max(nj, 1), np.int32)
+            on = np.zeros((max(nj, 1), cap), np.int32); o1 = np.zeros_like(on); o2 = np.zeros_like(on); ox = np.zeros((max(nj, 1), cap, 3), np.float32)
+            arrs = (cur, off, neigh, n_new, on, o1, o2, ox)
+            st = self._cnmp = (key, arrs, [_p(a) for a in arrs], jobs)
+        cur, off, neigh, n_new, on, o1, o2, ox = st[1]
+        pc, po, pn, pnn, pon, po1, po2, pox = st[2]
+        t0 = time.perf_counter()
+        _chk(lib().cms_kfstore_create_new_map_points(self.h, nj, pc, po, pn, int(check_orientation), cap, pnn, pon, po1, po2, pox), "cms_kfstore_create_new_map_points")
+        self.last_call_ms = 1e3 * (time.perf_counter() - t0)      # the library call alone (the wrapper's array handling is Python's)
+        if not copy:
+            return [(on[j, :n_new[j]], o1[j, :n_new[j]], o2[j, :n_new[j]], ox[j, :n_new[j]]) for j in range(nj)]
         return [(on[j, :n_new[j]].copy(), o1[j, :n_new[j]].copy(), o2[j, :n_new[j]].copy(), ox[j, :n_new[j]].copy()) for j in range(nj)]
 
 

@@ -289,7 +289,11 @@ static int ba_upload_items(cms_ba** bas, int n) {
       b->gsum_clean = it.se.gsum != 0;
     }
   }
-  HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
+  // (fetched from the pinned block by a kernel, not by a copy engine: those carry the megabyte uploads / read-backs of the windows other host
+  // threads are building and finishing, and this hand-over sits on the optimisation's critical path)
+  static_assert(sizeof(BaItem) % 16 == 0, "BaItem is copied in 16-byte words");
+  hipLaunchKernelGGL(k_copy16, dim3(1), dim3(1024), 0, g->stream, (uint4*)g->grp_items_dev, (const uint4*)items, (int)((size_t)n * sizeof(BaItem) / 16));
+  HIPCHK(hipGetLastError());
   return CMS_OK;
 }
 static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st, const volatile uint8_t* stop) {

@@ -133,9 +133,55 @@ extern "C" int cms_pose_fetch(cms_pose* p, double* poses7, uint8_t* outlier, int
   }
   return CMS_OK;
 }
+// A handful of frames (tracking's one call per frame: ~600 edges, 30 KB): the kernel reads its edges straight from the handle's pinned block -- once,
+// into registers -- and stores poses, counts and outlier flags straight into it.  No copy at all: the six uploads, the pose copy and the three
+// read-backs of the staged path each cost a trip through a copy engine's queue, ~70 us of a 230 us call whose kernel runs for ~140.
+static int cms_pose_optimize_direct(cms_pose* p, int nf, const int* edge_off, const double* Xw, const double* obs_uv, const double* inv_sigma2,
+                                    const int8_t* face, double fx, double fy, double cx, double cy, double* poses7, uint8_t* outlier,
+                                    int* n_inliers, cms_pose_stats* stats) {
+  const int ne = edge_off[nf];
+  HIPCHK(hipSetDevice(p->device));
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_off = 0, o_X = al(((size_t)nf + 1) * 4), o_obs = o_X + al((size_t)ne * 24), o_inv = o_obs + al((size_t)ne * 16), o_face = o_inv + al((size_t)ne * 8),
+               o_pose = o_face + al((size_t)ne), o_res = o_pose + al((size_t)nf * 56), o_out = o_res + al((size_t)nf * 32), total = o_out + al((size_t)ne);
+  if (total > p->h_stage_bytes) {
+    if (p->h_stage) (void)hipHostFree(p->h_stage);
+    p->h_stage = nullptr; p->h_stage_bytes = 0;
+    HIPCHK(hipHostMalloc((void**)&p->h_stage, 4 * total));
+    p->h_stage_bytes = 4 * total;
+  }
+  uint8_t* h = p->h_stage;
+  memcpy(h + o_off, edge_off, ((size_t)nf + 1) * 4);
+  if (ne > 0) { memcpy(h + o_X, Xw, (size_t)ne * 24); memcpy(h + o_obs, obs_uv, (size_t)ne * 16); memcpy(h + o_inv, inv_sigma2, (size_t)ne * 8); memcpy(h + o_face, face, (size_t)ne); }
+  memcpy(h + o_pose, poses7, (size_t)nf * 56);
+  PoseDev d;
+  d.nf = nf; d.off = (const int*)(h + o_off); d.Xw = (const double*)(h + o_X); d.obs = (const double*)(h + o_obs); d.inv = (const double*)(h + o_inv);
+  d.face = (const int8_t*)(h + o_face); d.outlier = h + o_out; d.err = p->d_err; d.poses = (double*)(h + o_pose); d.result = (int*)(h + o_res);
+  d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
+  hipLaunchKernelGGL(k_pose_optimize, dim3(nf), dim3(256), 0, p->stream, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(p->stream));
+  p->nf = 0;                                                       // (nothing resident for cms_pose_launch / cms_pose_fetch)
+  const int* res = (const int*)(h + o_res);
+  memcpy(poses7, h + o_pose, (size_t)nf * 56);
+  if (outlier && ne > 0) memcpy(outlier, h + o_out, (size_t)ne);
+  for (int f = 0; f < nf; ++f) {
+    if (n_inliers) n_inliers[f] = res[8 * f];
+    if (stats) { stats[f].n_bad = res[8 * f + 1]; stats[f].rounds = res[8 * f + 2]; for (int i = 0; i < 4; ++i) stats[f].iterations_done[i] = res[8 * f + 4 + i]; }
+  }
+  return CMS_OK;
+}
 extern "C" int cms_pose_optimize_batch(cms_pose* p, int nf, const int* edge_off, const double* Xw, const double* obs_uv, const double* inv_sigma2,
                                        const int8_t* face, double fx, double fy, double cx, double cy, double* poses7, uint8_t* outlier,
                                        int* n_inliers, cms_pose_stats* stats) {
+  static const bool copies = getenv("CMS_POSE_COPY_ENGINE") != nullptr;      // developer A/B: the staged copies for small calls too
+  if (!copies && p && nf >= 1 && nf <= 8 && nf <= p->cap_f && edge_off && poses7 && edge_off[0] == 0 && edge_off[nf] >= 0 && edge_off[nf] <= p->cap_e &&
+      (edge_off[nf] == 0 || (Xw && obs_uv && inv_sigma2 && face))) {
+    bool ok = true; int max_n = 0;
+    for (int f = 0; f < nf && ok; ++f) { ok = edge_off[f + 1] >= edge_off[f]; max_n = std::max(max_n, edge_off[f + 1] - edge_off[f]); }
+    for (int e = 0; e < edge_off[nf] && ok; ++e) ok = face[e] >= 0 && face[e] <= 4;
+    if (ok && max_n <= 256 * PO_MAXJ) return cms_pose_optimize_direct(p, nf, edge_off, Xw, obs_uv, inv_sigma2, face, fx, fy, cx, cy, poses7, outlier, n_inliers, stats);
+  }                                                                // (anything else: the staged path, which also reports bad arguments)
   int rc = cms_pose_upload_impl(p, nf, edge_off, Xw, obs_uv, inv_sigma2, face, fx, fy, cx, cy, poses7, true);
   if (rc) return rc;
   rc = cms_pose_launch(p);

@@ -64,6 +64,8 @@ void tri_feat_node(const cms_keyframe& k, int* feat_node /* k.n entries */) {
 int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hmedian, int njobs, const int* cur_idx, const int* neigh_off,
             const int* neigh_idx, int check_orientation, int cap, uint8_t* work, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2, float* out_x3d) {
   const int nneigh = neigh_off[njobs];
+  static const bool timing = getenv("CMS_TRI_TIMING") != nullptr;      // developer knob: where a call's host time goes (stderr)
+  const auto t_0 = std::chrono::steady_clock::now();
   std::vector<CmsTriPair> pairs((size_t)nneigh + 1);
   std::vector<CmsTriJob> jobs((size_t)njobs);
   std::vector<int> pair_job((size_t)nneigh + 1, 0);
@@ -99,9 +101,12 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
   (void)o_cand;
   hipStream_t s = c->stream;
   uint8_t* p = work;
-  // inputs (pairs | jobs | pair -> job) and outputs (counts | neighbour | idx1 | idx2 | x3d) are contiguous in the work block: one copy
-  // each way through the context's pinned staging block instead of three + five copies between pageable buffers (every one of those
-  // was a separate staged transfer, ~80 us of queue time each)
+  // inputs (pairs | jobs | pair -> job) and outputs (counts | neighbour | idx1 | idx2 | x3d) are contiguous in the work block and mirrored in the
+  // context's pinned staging block.  Neither direction uses the copy engines: inside a running system they are busy with the local-BA windows'
+  // uploads and read-backs (megabytes each), and this call's ~20 KB in and few KB out waited their turn behind them -- 2.7 ms per call next
+  // to 0.45 ms alone, on the mapping thread's critical path.  The inputs are fetched from the pinned block by a one-workgroup kernel, and the
+  // kernels store the new points straight into it (a few thousand posted 4-byte writes).  CMS_TRI_COPY_ENGINE=1: the copies of before.
+  static const bool copy_engine = getenv("CMS_TRI_COPY_ENGINE") != nullptr;
   const size_t in_bytes = o_nnew, out_bytes = o_cand - o_nnew;
   int rcs = cms_hstage(c, in_bytes + out_bytes);
   if (rcs) return rcs;
@@ -112,7 +117,9 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
     memcpy(hin + o_pjob, pair_job.data(), (size_t)nneigh * 4);
   }
   memcpy(hin + o_job, jobs.data(), (size_t)njobs * sizeof(CmsTriJob));
-  HIPCHK(hipMemcpyAsync(p, hin, in_bytes, hipMemcpyHostToDevice, s));
+  if (copy_engine) HIPCHK(hipMemcpyAsync(p, hin, in_bytes, hipMemcpyHostToDevice, s));
+  else hipLaunchKernelGGL(k_copy16, dim3(1), dim3(1024), 0, s, (uint4*)p, (const uint4*)hin, (int)(in_bytes / 16));      // (offsets are multiples of 256)
+  uint8_t* po = copy_engine ? p + o_nnew : hout;          // where the kernels put their results
   CmsTriArgs a;
   a.kf = dev.kf; a.pair = (const CmsTriPair*)(p + o_pair); a.job = (const CmsTriJob*)(p + o_job);
   a.kp = dev.kp; a.desc = dev.desc; a.rays = dev.rays; a.mp = dev.mp; a.feat_node = dev.feat_node;
@@ -127,7 +134,8 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
   a.check_orientation = check_orientation;
   for (int l = 0; l < 16; ++l) { a.sf[l] = l < c->g.nlevels ? c->scale[l] : 1.0f; a.sigma2[l] = l < c->g.nlevels ? c->sigma2[l] : 1.0f; }
   a.cap = cap;
-  a.n_new = (int*)(p + o_nnew); a.out_neigh = (int*)(p + o_on); a.out_idx1 = (int*)(p + o_o1); a.out_idx2 = (int*)(p + o_o2); a.out_x3d = (float*)(p + o_ox);
+  a.n_new = (int*)po; a.out_neigh = (int*)(po + (o_on - o_nnew)); a.out_idx1 = (int*)(po + (o_o1 - o_nnew)); a.out_idx2 = (int*)(po + (o_o2 - o_nnew));
+  a.out_x3d = (float*)(po + (o_ox - o_nnew));
   // (CMS_TRI_SEQUENTIAL is read per call on purpose: test_create_new_map_points toggles it inside one process to hold the two kernels to identical records)
   if (check_orientation || max_pairs > 64 || nneigh == 0 || getenv("CMS_TRI_SEQUENTIAL")) {
     hipLaunchKernelGGL(k_create_new_map_points, dim3(njobs), dim3(512), 0, s, a);      // neighbour after neighbour (the rotation histogram of a
@@ -136,14 +144,21 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
     hipLaunchKernelGGL(k_tri_resolve, dim3(njobs), dim3(1024), 0, s, a, (const CmsTriCand*)(p + o_cand), max_n1);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(hout, p + o_nnew, cap > 0 ? out_bytes : tri_al((size_t)njobs * 4 + 16), hipMemcpyDeviceToHost, s));
+  if (copy_engine) HIPCHK(hipMemcpyAsync(hout, p + o_nnew, cap > 0 ? out_bytes : tri_al((size_t)njobs * 4 + 16), hipMemcpyDeviceToHost, s));
+  const auto t_1 = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(s));
+  if (timing) {
+    const auto t_2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tri_run] jobs %d pairs %d: host + enqueue %.3f ms, wait %.3f ms\n", njobs, nneigh, std::chrono::duration<double, std::milli>(t_1 - t_0).count(),
+            std::chrono::duration<double, std::milli>(t_2 - t_1).count());
+  }
   memcpy(n_new, hout, (size_t)njobs * 4);
-  if (cap > 0) {
-    memcpy(out_neigh, hout + (o_on - o_nnew), nb * 4);
-    memcpy(out_idx1, hout + (o_o1 - o_nnew), nb * 4);
-    memcpy(out_idx2, hout + (o_o2 - o_nnew), nb * 4);
-    memcpy(out_x3d, hout + (o_ox - o_nnew), nb * 12);
+  for (int j = 0; j < njobs && cap > 0; ++j) {                        // (entries behind a job's count were never written)
+    const size_t at = (size_t)j * (size_t)cap, cnt = (size_t)std::max(0, std::min(n_new[j], cap));
+    memcpy(out_neigh + at, hout + (o_on - o_nnew) + 4 * at, cnt * 4);
+    memcpy(out_idx1 + at, hout + (o_o1 - o_nnew) + 4 * at, cnt * 4);
+    memcpy(out_idx2 + at, hout + (o_o2 - o_nnew) + 4 * at, cnt * 4);
+    memcpy(out_x3d + 3 * at, hout + (o_ox - o_nnew) + 12 * at, cnt * 12);
   }
   for (int j = 0; j < njobs; ++j)
     if (n_new[j] > cap) return cms_fail(CMS_ERR_OVERFLOW, "cms_create_new_map_points: more new points than cap_per_job (n_new holds the counts)");

@@ -81,6 +81,12 @@ PY
     run1() { echo "$1: $(env $1 timeout 300 python tools/prof_ba_many.py 16 track diff 3 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/emcost.txt; }
     run1 "CMS_BA_SPLIT_WORKGROUPS=1"
     for ab in ${EMCOST_SET:-60:45 40:30 80:60 110:80 60:20 100:40 140:100}; do run1 "CMS_BA_EM_COST_A=${ab%:*} CMS_BA_EM_COST_B=${ab#*:}"; done ;;
+  timeline)  # kernel trace of a few steps (CSV kept: analysed by tools/timeline.py).  usage: timeline <tag> [ENV=VAL ...]
+    shift; TAG=$1; shift
+    R=$PWD; OUT=$R/$O/tl_$TAG; rm -rf $OUT; mkdir -p $OUT
+    (cd /tmp && export TMPDIR=/tmp && env "$@" rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/bench.py --steps 4 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 > $OUT/bench.json 2> $OUT/bench.err)
+    python tools/timeline.py $OUT/t_kernel_trace.csv | tee $O/timeline_$TAG.txt
+    rm -f $OUT/*_agent_info.csv; gzip -f $OUT/t_kernel_trace.csv ;;
   batests)  # the BA parity tests only
     timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ba_" 2>&1 | tail -8 | tee $O/batests.txt ;;
   tests)
