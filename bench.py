@@ -87,6 +87,7 @@ def parse_args(argv=None):
                     "reported as config.ba_views_random next to the headline (0 = skip)")
     ap.add_argument("--optimise-only-steps", type=int, default=10, help="steps of the extra pass that keeps the windows and only resets them between steps "
                     "(round 2's headline, reported as config.optimise_only; 0 = skip)")
+    ap.add_argument("--mapping-only-steps", type=int, default=6, help="steps of the mapping side alone (CreateNewMapPoints + local BA, no frame path): config.mapping_only, and the Schur kernel's launch time without the frame path next to it in roofline (0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
     return ap.parse_args(argv)
@@ -726,6 +727,14 @@ def main():
         extract_only = {"ms_per_step": round(1e3 * dt_f / args.extract_only_steps, 3), "steps": args.extract_only_steps,
                         "stage_ms_per_step": {k: round(v, 4) for k, v in stage_f.items()},
                         "note": "the same batches through remap + extraction + grids + searches + pose optimisation with no local BA / CreateNewMapPoints in the step"}
+    # ---- the mapping side alone (no frame path in the step): what the Levenberg rounds' kernels take when nothing else shares the chip
+    mapping_only = None
+    if args.mapping_only_steps > 0 and n_ba > 0:
+        dt_m, _, ba_ms_m, schur_m = timed(False, steps=args.mapping_only_steps, only="ba")
+        sm_ms, sm_n = sum(m for m, _ in schur_m), sum(n for _, n in schur_m)
+        mapping_only = {"ms_per_step": round(1e3 * dt_m / args.mapping_only_steps, 3), "ba_ms_per_step": round(ba_ms_m, 3), "steps": args.mapping_only_steps,
+                        "schur_ms_per_launch": round(sm_ms / max(sm_n, 1), 4), "schur_launches": int(sm_n),
+                        "note": "the same windows (created, optimised, read back, destroyed) and CreateNewMapPoints with no frame path in the step"}
     # ---- windows with RANDOM views (every point seen by an arbitrary subset of key frames: no signature runs, round 2's windows, the edge-major body
     # on every point) next to the headline's tracked views: same steps, same life cycle
     random_views = None
@@ -897,6 +906,12 @@ def main():
                                       "run_chunks_of_all_chunks": "%d / %d" % (int(np.mean([r[2] for r in run_stats])), int(np.mean([r[3] for r in run_stats])))},
                    "note": "HIP events on each window group's stream around the kernel of every round, inside the timed region; the groups' launches overlap each "
                            "other and the frame path, so ms_per_step is summed kernel time"}
+    if roof_ba and mapping_only is not None and mapping_only["schur_launches"] > 0:
+        # the same kernel, the same windows, with no frame path next to it (config.mapping_only): what the launch takes when only the mapping side's
+        # own queues share the chip -- `frac` above stays the driver's figure, measured inside the full step
+        ms_a = mapping_only["schur_ms_per_launch"]
+        roof_ba["without_the_frame_path"] = {"ms_per_launch": ms_a, "TFLOPs": round(flops / (ms_a * 1e-3) / 1e12, 3), "frac": round(flops / (ms_a * 1e-3) / 1e12 / 78.6, 4),
+                                             "launches": mapping_only["schur_launches"]}
     # `roofline` = the kernel with the most time per step; the other one is reported next to it
     if roof_ba and roof_ba["ms_per_step"] > roof_fast["ms_per_step"]:
         roof, roof_other = roof_ba, roof_fast
@@ -1057,7 +1072,7 @@ def main():
                                            "note": "every step creates its %d windows from the problems' host arrays (cms_ba_create: host work lists, one pinned upload), optimises "
                                                    "them, reads poses / points / outlier flags back (cms_ba_read) and destroys them; a pool of host threads builds step s + 1's "
                                                    "windows and finishes step s - 1's while step s runs, all inside the timed region" % n_ba},
-                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "ba_views": args.ba_views, "ba_views_random": random_views,
+                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "mapping_only": mapping_only, "ba_views": args.ba_views, "ba_views_random": random_views,
                        "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
                        "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,

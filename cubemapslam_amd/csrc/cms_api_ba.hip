@@ -21,7 +21,7 @@ struct BaKnobs {
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, separate_reduce2, rm_valu;
   int solve_reduce_max, leftover_lookahead;
   bool global_sum;
-  int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap, em_cost_a, em_cost_b; bool unified;
+  int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap, em_cost_a, em_cost_b, te_chunks; bool unified;
   char stream_priority;
 };
 static const BaKnobs& ba_knobs() {
@@ -52,6 +52,7 @@ static const BaKnobs& ba_knobs() {
     q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 58)));
     q.unified = !on("CMS_BA_SPLIT_WORKGROUPS");          // 1: every Schur workgroup of a window takes run chunks and left-over chunks (cut by cost); 0: separate workgroups
     q.em_cost_a = num("CMS_BA_EM_COST_A", 40); q.em_cost_b = num("CMS_BA_EM_COST_B", 30);      // cost of a left-over chunk: a + b x (edges of its largest point / 2), units of ba_rm_chunk_cost
+    q.te_chunks = std::max(1, std::min(16, num("CMS_BA_TE_CHUNKS", 2)));      // chunks per wavefront of kb_ba_trial_edges
     q.se_waves_cap = num("CMS_BA_SE_WAVES", 0);          // developer A/B: fewer wavefronts per Schur workgroup (how much of the kernel is latency?)
     const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
     q.stream_priority = pr ? pr[0] : 0;
@@ -941,7 +942,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
       if (rm_chunk.empty()) rm_chunk.push_back(make_int4(0, 0, -1, 0));
       BaSe& se = b->se;
       se.nchunks = nchunks; se.n_rm = n_rm; se.npairs2 = NP2;
-      se.cpw_t = BA_TE_THREADS / 64;                              // the trial kernel: one chunk per wavefront
+      se.cpw_t = (BA_TE_THREADS / 64) * kn.te_chunks;             // the trial kernel: te_chunks chunks per wavefront (its workgroups stage the key frames' rotations first)
       se.Rt = (nchunks + se.cpw_t - 1) / se.cpw_t;
       se.nlone = (int)lone.size();
       ba_se_split(se, BA_SE_RANGES);                              // a window on its own; a group re-splits (ba_upload_items)

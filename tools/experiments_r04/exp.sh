@@ -87,6 +87,8 @@ PY
     (cd /tmp && export TMPDIR=/tmp && env "$@" rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/bench.py --steps 4 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 > $OUT/bench.json 2> $OUT/bench.err)
     python tools/timeline.py $OUT/t_kernel_trace.csv | tee $O/timeline_$TAG.txt
     rm -f $OUT/*_agent_info.csv; gzip -f $OUT/t_kernel_trace.csv ;;
+  techunks)  # chunks per wavefront of the trial kernel
+    for w in ${TE_SET:-1 2 3 4 6 8}; do echo "CMS_BA_TE_CHUNKS=$w: $(CMS_BA_TE_CHUNKS=$w timeout 300 python tools/prof_ba_many.py 16 track diff 6 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/techunks.txt; done ;;
   batests)  # the BA parity tests only
     timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ba_" 2>&1 | tail -8 | tee $O/batests.txt ;;
   tests)
