@@ -18,7 +18,7 @@
 // and the choices made when it is optimised (which kernels run) can never disagree.  Tests that flip a switch use a child process.
 struct BaKnobs {
   bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
-  bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, separate_reduce2, rm_valu;
+  bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, separate_reduce2, separate_first_pass, rm_valu;
   int solve_reduce_max, leftover_lookahead;
   bool global_sum;
   int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap, em_cost_a, em_cost_b, te_chunks; bool unified;
@@ -39,6 +39,7 @@ static const BaKnobs& ba_knobs() {
     q.runs = !on("CMS_BA_NO_RUNS");                      // signature runs (cms_ba_schur_runs.hip); off = every point through the edge-major kernel
     q.runs_as_edges = on("CMS_BA_RUNS_AS_EDGES");        // keep the run order of the points but let the edge-major body take the run chunks too
     q.rm_valu = on("CMS_BA_RM_VALU");                    // the runs' tuple products on the vector ALU (producer / consumer pairs) instead of MFMA tiles
+    q.separate_first_pass = on("CMS_BA_SEPARATE_FIRST_PASS");      // kb_ba_errors / reduce / lin / maxdiag in front of a stage's first trial instead of kb_ba_first_pass (developer A/B)
     q.separate_reduce2 = on("CMS_BA_SEPARATE_REDUCE2");  // kb_ba_reduce2 as its own launch behind the trial kernel (developer A/B)
     q.separate_reduce = on("CMS_BA_SEPARATE_REDUCE");    // kb_ba_schur_edges_reduce as its own launch instead of inside the solve kernel
     // ... which only pays while a window has few slices to sum (one workgroup reads them all): with more than this many the sum stays a launch

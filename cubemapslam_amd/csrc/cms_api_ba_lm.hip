@@ -428,6 +428,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
   const bool solve_reduces = fused && (gm.gsum || (!ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max));
   dyn.fused_lin = fused ? 1 : 0;
+  const bool first_pass = fused && use_te && first_round && !ba_knobs().separate_first_pass;      // (a stage's windows all start at it == 0)
   dyn.fold_reduce = (use_te && !ba_knobs().separate_reduce2) ? 1 : 0;      // the trial kernel sums its own partial sums and decides the trial (kb_ba_trial_edges)
   int k = 0;
   const int pk = g->prof_kernel;
@@ -440,7 +441,12 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     hipEventRecord(g->prof_ev[i], s);
   };
   auto enqueue_round = [&]() {
-      if (first_round) {     // residuals of the stage's starting estimate: later iterations carry the accepted trial's over (every window starts at it == 0)
+      if (first_round && first_pass) {      // errors + chi2 + lambda's maximum diagonal of the stage's starting estimate in one launch (kb_ba_first_pass)
+        bracket(1, 0);
+        hipLaunchKernelGGL(kb_ba_first_pass, dim3(max_Rt, 1, n), dim3(BA_TE_THREADS), te_lds, s, ditems, dyn, (int)BA_PHASE_ITER);
+        bracket(1, 1);
+        iter_phase = false;
+      } else if (first_round) {     // residuals of the stage's starting estimate: later iterations carry the accepted trial's over (every window starts at it == 0)
         hipLaunchKernelGGL(kb_ba_errors, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
         hipLaunchKernelGGL(kb_ba_reduce, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_ITER);
       }

@@ -354,6 +354,103 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, 
   ba_se_writeout<FUSED>(se.R_rm + BX, np, NP2, S, Dg, se);
 }
 
+// ---- what a stage's FIRST iteration needs before its first trial, in one pass over the window's chunks (dyn.fused_lin: every later linearisation
+// happens inside the Schur kernel): the residuals and the robust chi2 of the starting estimate (computeActiveErrors + activeRobustChi2) and the
+// largest diagonal entry of the Hessian (computeLambdaInit: lambda = 1e-5 x that).  kb_ba_errors, kb_ba_reduce, kb_ba_lin and kb_ba_maxdiag did
+// this in four launches, building all of Hpp / Hll / bl only to look at their diagonals (the Schur kernel rebuilds them anyway).  Here a lane
+// takes one observation: its squared Jacobian columns go to the key frame's six diagonal sums (LDS, then one global addition per workgroup and
+// entry) and, summed over the lanes of its point, to the point's three -- of which only the maximum is kept.
+__device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaSeG se, const double* __restrict__ poses, const double* __restrict__ pts, int robust,
+                                                   double delta, double* __restrict__ partial, double* __restrict__ pose_diag, unsigned long long* __restrict__ pt_max) {
+#pragma clang fp contract(fast)
+  extern __shared__ __align__(16) double te_lds[];     // K x 12 (rotation | translation) | np x 6 (diagonal sums of the free key frames)
+  __shared__ double sh[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  double* prc = te_lds;
+  double* pd = prc + (size_t)d.K * 12;
+  for (int k = tid; k < d.K; k += blockDim.x) {
+    const double* pose = poses + 7 * k;
+    double R[9];
+    quat_to_R(pose + 3, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) prc[12 * k + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prc[12 * k + 9 + i] = pose[i];
+  }
+  for (int i = tid; i < 6 * d.np; i += blockDim.x) pd[i] = 0.0;
+  __syncthreads();
+  double chi = 0, mx = 0;
+  const int c0 = BX * se.cpw_t, c1 = min(se.nchunks, c0 + se.cpw_t);
+  for (int c = c0 + wave; c < c1; c += nw) {
+    const int e0 = se.chunk_e0[c], e1 = se.chunk_e0[c + 1];
+    const int e = e0 + lane;
+    const bool have = e < e1;
+    int a = 0, k = 1;
+    double dl[3] = {0, 0, 0};
+    if (have) {
+      const uint32_t info = se.e_info[e];
+      const int p = d.e_point[e];
+      const bool act = d.level[e] == 0;
+      const double einv = d.e_inv[e];
+      const double2 ob = BA_OBS2(d, e);
+      a = info & 31; k = (info >> 5) & 31;
+      const int s = (int)((info >> 10) & 63) - 1, face = (info >> 16) & 7, kp = (info >> 19) & 255;
+      if (act) {
+        const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+        const double* Rt = prc + 12 * kp;
+        double R[9], Xc[3], r[2], Jp[12], Jl[6], rho0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+        ba_se_cam_point(Rt, X, Xc);
+        edge_error_v(d, face, ob.x, ob.y, Xc, r);
+        BA_ERR2_ST(d, e, r[0], r[1]);
+        const double c2 = einv * (r[0] * r[0] + r[1] * r[1]);
+        double w = 1.0;
+        if (robust) w = huber_w(c2, delta, &rho0); else rho0 = c2;
+        chi += rho0;
+        const double ow = w * einv;
+        edge_jac_face(d, face, Xc, R, Jp, Jl);
+        if (s >= 0) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) unsafeAtomicAdd(pd + 6 * s + i, ow * (Jp[i] * Jp[i] + Jp[6 + i] * Jp[6 + i]));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dl[j] = ow * (Jl[j] * Jl[j] + Jl[3 + j] * Jl[3 + j]);
+      }
+    }
+    // the point's first lane adds its lanes' shares in edge order
+    int kmax = k;
+    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o));
+    const bool head = have && a == 0;
+    double sl[3] = {dl[0], dl[1], dl[2]};
+    for (int dd = 1; dd < kmax; ++dd) {
+      const int src = min(lane + dd, 63);
+      const double v0 = __shfl(dl[0], src), v1 = __shfl(dl[1], src), v2 = __shfl(dl[2], src);
+      if (head && dd < k) { sl[0] += v0; sl[1] += v1; sl[2] += v2; }
+    }
+    if (head) mx = fmax(mx, fmax(sl[0], fmax(sl[1], sl[2])));
+  }
+  const double s1 = block_sum(chi, sh);
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  __syncthreads();
+  if (lane == 0) sh[wave] = mx;
+  __syncthreads();                                     // (also: every lane's LDS additions to pd are through)
+  // hand-over to the window's last workgroup (kb_ba_first_pass): returning atomics only, every one waited for before the barrier behind which
+  // thread 0 takes its ticket
+  if (tid < 6 * d.np) {
+    const double v = pd[tid];
+    if (v != 0.0) { const double o = atomicAdd(pose_diag + tid, v); asm volatile("" :: "v"(o) : "memory"); }
+  }
+  if (tid == 0) {
+    double m = 0;
+    for (int i = 0; i < nw; ++i) m = fmax(m, sh[i]);
+    const unsigned long long o1 = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(partial + BX), (unsigned long long)__double_as_longlong(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long o2 = atomicMax(pt_max, (unsigned long long)__double_as_longlong(m));      // (non-negative doubles order like their bit patterns)
+    asm volatile("" :: "v"(o1), "v"(o2) : "memory");
+  }
+  __syncthreads();
+}
+
 // ---- a workgroup's LDS copy of the reduced system -> its slice of `partial`, in the dense pair enumeration the reduction and the solve kernel use
 template <bool FUSED>
 __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSeG& se) {

@@ -394,6 +394,41 @@ extern "C" __global__ void __launch_bounds__(BA_TE_THREADS) kb_ba_trial_edges(co
   ba_trial_publish(it, dyn);
   if (dyn.dev_lm && blockIdx.z == 0 && threadIdx.x == 0) ba_round_count(items);
 }
+// ITER phase of a fused group in ONE launch (ba_first_pass_body): the last workgroup of a window to finish adds the workgroups' chi2 sums in a
+// fixed order, takes the maximum of the diagonal sums and does what kb_ba_maxdiag did at the end of the phase (lambda, Levenberg state, mirror)
+#define BA_PTMAX_SLOT 6        /* scal[6]: largest diagonal entry over the window's points, as the bits of a non-negative double (zeroed by kb_ba_lm_load) */
+extern "C" __global__ void __launch_bounds__(BA_TE_THREADS) kb_ba_first_pass(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.Rt)
+  unsigned long long* pt_max = reinterpret_cast<unsigned long long*>((double*)it.scal + BA_PTMAX_SLOT);
+  ba_first_pass_body(blockIdx.x, it.se.Rt, it.d, it.se, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta, it.partial, it.Hpp, pt_max);
+  __shared__ int last_sh;
+  __shared__ double sh2[16];
+  const int n = it.se.Rt;
+  int* ticket = reinterpret_cast<int*>((double*)it.scal + BA_TICKET_SLOT);
+  if (threadIdx.x == 0) last_sh = atomicAdd(ticket, 1) == n - 1;
+  __syncthreads();
+  if (!last_sh) return;
+  double* partial = it.partial;
+  double v = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += atomicAdd(partial + i, 0.0);
+  const double chi = block_sum(v, sh2);
+  double m = 0;
+  double* pose_diag = it.Hpp;
+  for (int i = threadIdx.x; i < 6 * it.d.np; i += blockDim.x)       // (read and put back to zero for the next stage)
+    m = fmax(m, fabs(__longlong_as_double((long long)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(pose_diag + i), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+  if (threadIdx.x == 0) m = fmax(m, __longlong_as_double((long long)atomicExch(pt_max, 0ull)));
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh2[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mx = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) mx = fmax(mx, sh2[i]);
+    it.scal[0] = chi; it.hscal[0] = chi; it.scal[3] = mx; it.hscal[3] = mx;
+    atomicExch(ticket, 0);
+    if (dyn.dev_lm) ba_lm_after_iter(it.lm, it.hlm, chi, mx);
+  }
+}
 // last kernel of the TRIAL phase when the trial kernel does not fold it
 __device__ __forceinline__ void kb_ba_reduce2_window(const BaItem* __restrict__ items, const BaDyn& dyn, int phase) {
   BA_ITEM(phase, 1)
@@ -423,6 +458,8 @@ extern "C" __global__ void __launch_bounds__(64) kb_ba_lm_load(const BaItem* __r
   L.n_out[1] = clear_counts ? 0 : old.n_out[1];      // also runs when a stop request skips the second stage)
   *items[w].lm = L;
   reinterpret_cast<int*>(items[w].scal + 7)[0] = 0;        // ticket counter of the trial kernel's folded reduction (BA_TICKET_SLOT)
+  items[w].scal[6] = 0.0;                                  // kb_ba_first_pass: the points' largest diagonal entry (BA_PTMAX_SLOT) ...
+  for (int i = 0; i < 6 * items[w].d.np; ++i) items[w].Hpp[i] = 0.0;      // ... and the key frames' diagonal sums (the head of Hpp, unused by fused groups)
 }
 // after a classification: the windows' outlier counters -> pinned host block
 extern "C" __global__ void __launch_bounds__(64) kb_ba_counts_publish(const BaItem* __restrict__ items, int n) {
