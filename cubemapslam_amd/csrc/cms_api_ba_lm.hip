@@ -289,10 +289,12 @@ static int ba_upload_items(cms_ba** bas, int n) {
       b->gsum_clean = it.se.gsum != 0;
     }
   }
-  // (fetched from the pinned block by a kernel, not by a copy engine: those carry the megabyte uploads / read-backs of the windows other host
-  // threads are building and finishing, and this hand-over sits on the optimisation's critical path)
+  // (fetched from the pinned block by a kernel instead of a copy-engine transfer: one queue entry on the group's own stream; measured neutral
+  // inside the bench's step -- CMS_BA_ITEMS_COPY_ENGINE=1 is the transfer of round 3)
   static_assert(sizeof(BaItem) % 16 == 0, "BaItem is copied in 16-byte words");
-  hipLaunchKernelGGL(k_copy16, dim3(1), dim3(1024), 0, g->stream, (uint4*)g->grp_items_dev, (const uint4*)items, (int)((size_t)n * sizeof(BaItem) / 16));
+  static const bool items_by_copy_engine = getenv("CMS_BA_ITEMS_COPY_ENGINE") != nullptr;      // developer A/B
+  if (items_by_copy_engine) HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
+  else hipLaunchKernelGGL(k_copy16, dim3(1), dim3(1024), 0, g->stream, (uint4*)g->grp_items_dev, (const uint4*)items, (int)((size_t)n * sizeof(BaItem) / 16));
   HIPCHK(hipGetLastError());
   return CMS_OK;
 }

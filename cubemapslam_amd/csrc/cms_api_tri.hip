@@ -102,10 +102,10 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
   hipStream_t s = c->stream;
   uint8_t* p = work;
   // inputs (pairs | jobs | pair -> job) and outputs (counts | neighbour | idx1 | idx2 | x3d) are contiguous in the work block and mirrored in the
-  // context's pinned staging block.  Neither direction uses the copy engines: inside a running system they are busy with the local-BA windows'
-  // uploads and read-backs (megabytes each), and this call's ~20 KB in and few KB out waited their turn behind them -- 2.7 ms per call next
-  // to 0.45 ms alone, on the mapping thread's critical path.  The inputs are fetched from the pinned block by a one-workgroup kernel, and the
-  // kernels store the new points straight into it (a few thousand posted 4-byte writes).  CMS_TRI_COPY_ENGINE=1: the copies of before.
+  // context's pinned staging block.  Neither direction uses a copy engine: the inputs (~20 KB) are fetched from the pinned block by a one-workgroup
+  // kernel, and the kernels store the new points straight into it (a few thousand posted 4-byte writes) -- two queue entries less per call.
+  // Measured inside the bench's step the call takes the same 0.9-1.1 ms either way (CMS_TRI_COPY_ENGINE=1: the copies of round 3; 0.3 ms alone):
+  // what made it 3 ms there was not the transfers but the Python wrapper's per-call arrays (see api.KeyframeStore.create_new_map_points).
   static const bool copy_engine = getenv("CMS_TRI_COPY_ENGINE") != nullptr;
   const size_t in_bytes = o_nnew, out_bytes = o_cand - o_nnew;
   int rcs = cms_hstage(c, in_bytes + out_bytes);
