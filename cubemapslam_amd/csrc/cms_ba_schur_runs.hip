@@ -687,18 +687,35 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
       const char* bb = reinterpret_cast<const char*>(slots);
       auto ldsd = [&](uint32_t off) { return *reinterpret_cast<const double*>(bb + off); };
       if (NT <= 2) {
-        for (int q = 0; q < niter; ++q) {
-          if (q == niter - 1) {
+        // software pipelined over the groups of four points: the operands of group q + 1 are requested before the instructions of group q are
+        // issued -- issued behind them they only left once the matrix pipe had taken the group's last instruction, and the pipe then stood still
+        // for the LDS round trip of every group (BA_RM_NO_MATRIX_PREFETCH: that order, for A/B)
+        double nB0[3], nB1[3], nD[3];
+        auto fetch = [&](bool last) {
+          if (last) {
 #pragma unroll
             for (int u = 0; u < 3; ++u) { ad[0][u] = min(ad[0][u], lim); ad[1][u] = min(ad[1][u], lim); }
           }
-          double Bv0[3], Bv1[3], Dv[3];
 #pragma unroll
-          for (int u = 0; u < 3; ++u) {                            // all reads first, then the instructions
-            Dv[u] = ldsd(dd[u]);
-            Bv0[u] = ldsd(ad[0][u]);
-            Bv1[u] = NT > 1 ? ldsd(ad[1][u]) : 0.0;
+          for (int u = 0; u < 3; ++u) {
+            nD[u] = ldsd(dd[u]);
+            nB0[u] = ldsd(ad[0][u]);
+            nB1[u] = NT > 1 ? ldsd(ad[1][u]) : 0.0;
           }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) { dd[u] += 192u; ad[0][u] += st[0]; ad[1][u] += st[1]; }
+        };
+#ifndef BA_RM_NO_MATRIX_PREFETCH
+        fetch(niter == 1);
+#endif
+        for (int q = 0; q < niter; ++q) {
+#ifdef BA_RM_NO_MATRIX_PREFETCH
+          fetch(q == niter - 1);
+#endif
+          const double Bv0[3] = {nB0[0], nB0[1], nB0[2]}, Bv1[3] = {nB1[0], nB1[1], nB1[2]}, Dv[3] = {nD[0], nD[1], nD[2]};
+#ifndef BA_RM_NO_MATRIX_PREFETCH
+          if (q + 1 < niter) fetch(q + 2 == niter);
+#endif
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
             const double A0 = Bv0[u] * Dv[u];
@@ -709,8 +726,6 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
               acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv1[u], acc[2], 0, 0, 0);
             }
           }
-#pragma unroll
-          for (int u = 0; u < 3; ++u) { dd[u] += 192u; ad[0][u] += st[0]; ad[1][u] += st[1]; }
         }
       } else {
         // six or seven free key frames: the third tile column (0,2) (1,2) (2,2) lives in temporaries for this chunk only

@@ -89,6 +89,19 @@ PY
     rm -f $OUT/*_agent_info.csv; gzip -f $OUT/t_kernel_trace.csv ;;
   techunks)  # chunks per wavefront of the trial kernel
     for w in ${TE_SET:-1 2 3 4 6 8}; do echo "CMS_BA_TE_CHUNKS=$w: $(CMS_BA_TE_CHUNKS=$w timeout 300 python tools/prof_ba_many.py 16 track diff 6 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/techunks.txt; done ;;
+  pmcifetch)  # instruction fetch of the local-BA kernels: requests, hits / misses of the shared instruction cache, its busy cycles
+    shift
+    R=$PWD
+    for v in ${@:-default}; do
+      OUT=$R/$O/pmci_$v; rm -rf $OUT; mkdir -p $OUT
+      i=0
+      for grp in "SQ_WAVES SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS" "SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES SQ_BUSY_CYCLES" "SQC_ICACHE_INPUT_VALID_READYB SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "InstrFetchLatency"; do
+        i=$((i+1))
+        (cd /tmp && TMPDIR=/tmp CMS_HIP_LIB=$(cd $R && libpath $v) timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT -o p$i -- python $R/tools/prof_ba_many.py 16 track diff > $OUT/p$i.log 2>&1)
+      done
+      rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv
+      echo "== $v"; python tools/pmc_mix.py $OUT | grep "schur\|trial_edges\|solve" | tr ' ' '\n' | tee -a $O/pmcifetch.txt
+    done ;;
   batests)  # the BA parity tests only
     timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "ba_" 2>&1 | tail -8 | tee $O/batests.txt ;;
   tests)
