@@ -87,6 +87,7 @@ def parse_args(argv=None):
                     "reported as config.ba_views_random next to the headline (0 = skip)")
     ap.add_argument("--optimise-only-steps", type=int, default=10, help="steps of the extra pass that keeps the windows and only resets them between steps "
                     "(round 2's headline, reported as config.optimise_only; 0 = skip)")
+    ap.add_argument("--unpipelined-steps", type=int, default=10, help="steps of the loop that waits for every step's own mapping side (config.unpipelined; 0 = skip)")
     ap.add_argument("--mapping-only-steps", type=int, default=6, help="steps of the mapping side alone (CreateNewMapPoints + local BA, no frame path): config.mapping_only, and the Schur kernel's launch time without the frame path next to it in roofline (0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
@@ -434,6 +435,10 @@ def main():
 
     schur_acc = {"ms": 0.0, "n": 0}
     worker_ms = {}
+    # steps overlap by one: the mapping side of step s (CreateNewMapPoints + local BA of its 32 windows) is waited for at the end of step s + 1, so it
+    # runs next to step s + 1's frame path the way LocalMapping runs next to Tracking.  CMS_BENCH_NO_PIPELINE=1 (and config.unpipelined): every step
+    # waits for its own mapping side, round 3's loop
+    pipeline_default = os.environ.get("CMS_BENCH_NO_PIPELINE", "") == ""
     step_trace = [] if os.environ.get("CMS_BENCH_STEP_TRACE", "") != "" else None      # developer knob: host time stamps of the step loop (stderr at exit)
     stagger = os.environ.get("CMS_BENCH_STAGGER", "") != ""        # developer knob: odd groups run their BA first and CreateNewMapPoints (of their NEXT step's key frames) after it
     tri_last = os.environ.get("CMS_BENCH_TRI_LAST", "") != ""      # developer knob: CreateNewMapPoints behind the group's BA instead of in front of it
@@ -517,6 +522,32 @@ def main():
     # the step at all: the FP64 chain also pulls the clocks down), and the step gets 4 % longer -- overlap stays the default
     serial = os.environ.get("CMS_BENCH_SERIAL_EXTRACT", "") != ""
     ba_first = os.environ.get("CMS_BENCH_BA_FIRST", "")     # developer knob: hand the mapping side to its threads BEFORE the frame path is enqueued (value = head start in us)
+    def collect(ths, keep):
+        """wait for a step's window groups (raises what a worker raised) and book their results"""
+        res = [th.result() for th in ths]
+        if step_trace is not None:
+            step_trace.append(("workers done", time.perf_counter()))
+        if res:
+            acc["ba_ms"] += sum(r[0] for r in res) / len(res); acc["ba_n"] += 1
+            last["tri_new"] = sum(r[1] for r in res)
+            last["ba_stats"] = [r[2] for r in res]
+            if res[0][3] is not None:
+                # the read-backs of these windows finish under the next step; at most two steps' worth are ever outstanding
+                for f in life["reads"]:
+                    f.result()
+                if step_trace is not None:
+                    step_trace.append(("earlier read-backs waited for", time.perf_counter()))
+                life["reads"] = [f for r in res for f in r[3]]
+                if keep:
+                    last["ba_out"] = [[f.result() for f in r[3]] for r in res]
+                for r in res:
+                    acc["create_ms"] += sum(r[4]); acc["create_n"] += len(r[4])
+
+    def collect_inflight():
+        prev = life.pop("inflight", None)
+        if prev is not None:
+            collect(*prev)
+
     def step(i, streaming, keep=False):
         part = life.get("part", part_env)             # (the extract-only pass sets "frames" for its steps)
         if step_trace is not None:
@@ -562,24 +593,18 @@ def main():
             submit_windows(life.pop("deferred"))
         if step_trace is not None:
             step_trace.append(("frame path waited for", time.perf_counter()))
-        res = [th.result() for th in ths]     # raises what a worker raised
-        if step_trace is not None:
-            step_trace.append(("workers done", time.perf_counter()))
-        if res:
-            acc["ba_ms"] += sum(r[0] for r in res) / len(res); acc["ba_n"] += 1
-            last["tri_new"] = sum(r[1] for r in res)
-            last["ba_stats"] = [r[2] for r in res]
-            if res[0][3] is not None:
-                # the read-backs of THIS step's windows finish under the next step; at most two steps' worth are ever outstanding
-                for f in life["reads"]:
-                    f.result()
-                if step_trace is not None:
-                    step_trace.append(("previous step's read-backs waited for", time.perf_counter()))
-                life["reads"] = [f for r in res for f in r[3]]
-                if keep:
-                    last["ba_out"] = [[f.result() for f in r[3]] for r in res]
-                for r in res:
-                    acc["create_ms"] += sum(r[4]); acc["create_n"] += len(r[4])
+        # The mapping side of step s is waited for at the end of step s + 1 (life["pipeline"]): like the reference's LocalMapping thread next to
+        # Tracking (System.cpp:108-127), the local BA of one batch's key frames runs while the next batch is tracked.  The window groups' host
+        # threads take step s + 1's windows as soon as step s's are through, so the Levenberg chain never waits for the frame path's host side.
+        # Every step's work still happens inside the timed region: timed() collects the last step's mapping side before it stops the clock.
+        if life["on"] and life.get("pipeline") and not keep:
+            prev = life.pop("inflight", None)
+            life["inflight"] = (ths, keep)
+            if prev is not None:
+                collect(*prev)
+        else:
+            collect_inflight()
+            collect(ths, keep)
         if part != "ba" and (world > 1 or args.force_gather):   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
             recs = [cdist.make_records(my_streams[s], i * fps + np.arange(fps), frame_poses[s * fps:(s + 1) * fps]) for s in range(len(my_streams))]
             traj = cdist.gather_trajectory(np.concatenate(recs, 0), device=dev, dst=0)
@@ -593,6 +618,7 @@ def main():
 
     def drain():
         """everything the window pool still owes: read-backs of the last step, and the windows built for a step that will not run"""
+        collect_inflight()
         for f in life["reads"]:
             f.result()
         life["reads"] = []
@@ -602,11 +628,12 @@ def main():
                     f.result()[0].close()
 
     step_times = [] if os.environ.get("CMS_BENCH_STEP_TIMES", "") != "" else None      # developer knob: host wall time of every timed step (stderr)
-    def timed(streaming, lifecycle=True, steps=None, only=""):
+    def timed(streaming, lifecycle=True, steps=None, only="", pipeline=None):
         steps = args.steps if steps is None else steps
         part = only or part_env
         life["part"] = part
         life["on"] = lifecycle and part != "frames"
+        life["pipeline"] = pipeline_default if pipeline is None else pipeline
         if streaming:
             ctx.upload_async(sets[0].pinned.array)
         if life["on"]:
@@ -614,6 +641,7 @@ def main():
                 submit_windows(a_ & 1)
         for i in range(args.warmup):
             step(i, streaming)
+        collect_inflight()                     # (the warm-up's last mapping side ends before the clock starts)
         stage = {}
         if not life["on"]:
             for grp in groups:
@@ -637,6 +665,7 @@ def main():
                 t_now = time.perf_counter(); step_times.append(round(1e3 * (t_now - t_prev), 2)); t_prev = t_now
             for k, v in (ctx.profile_ms().items() if part != "ba" else ()):
                 stage[k] = stage.get(k, 0.0) + v
+        collect_inflight()                     # the last step's mapping side (pipelined steps)
         for f in life["reads"]:
             f.result()
         life["reads"] = []
@@ -727,6 +756,13 @@ def main():
         extract_only = {"ms_per_step": round(1e3 * dt_f / args.extract_only_steps, 3), "steps": args.extract_only_steps,
                         "stage_ms_per_step": {k: round(v, 4) for k, v in stage_f.items()},
                         "note": "the same batches through remap + extraction + grids + searches + pose optimisation with no local BA / CreateNewMapPoints in the step"}
+    # ---- round 3's loop for comparison: every step waits for its own mapping side before the next one starts
+    unpipelined = None
+    if args.unpipelined_steps > 0 and n_ba > 0 and pipeline_default:
+        dt_u, _, ba_ms_u, _ = timed(False, steps=args.unpipelined_steps, pipeline=False)
+        unpipelined = {"value": round(total_frames_per_step * args.unpipelined_steps / dt_u, 2), "ms_per_step": round(1e3 * dt_u / args.unpipelined_steps, 3),
+                       "ba_ms_per_step": round(ba_ms_u, 3), "steps": args.unpipelined_steps,
+                       "note": "the same steps, each waiting for its own CreateNewMapPoints + local BA before the next step's frames are enqueued (BENCH_r03's loop)"}
     # ---- the mapping side alone (no frame path in the step): what the Levenberg rounds' kernels take when nothing else shares the chip
     mapping_only = None
     if args.mapping_only_steps > 0 and n_ba > 0:
@@ -1072,7 +1108,9 @@ def main():
                                            "note": "every step creates its %d windows from the problems' host arrays (cms_ba_create: host work lists, one pinned upload), optimises "
                                                    "them, reads poses / points / outlier flags back (cms_ba_read) and destroys them; a pool of host threads builds step s + 1's "
                                                    "windows and finishes step s - 1's while step s runs, all inside the timed region" % n_ba},
-                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "mapping_only": mapping_only, "ba_views": args.ba_views, "ba_views_random": random_views,
+                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "unpipelined": unpipelined, "mapping_only": mapping_only,
+                       "step_pipelining": ("the mapping side of step s (CreateNewMapPoints + local BA, windows created / read back / destroyed) is waited for at the end of step s + 1: "
+                                           "it overlaps the next batch's frame path like LocalMapping overlaps Tracking; all of it inside the timed region") if pipeline_default else "off (CMS_BENCH_NO_PIPELINE)", "ba_views": args.ba_views, "ba_views_random": random_views,
                        "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
                        "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
