@@ -407,7 +407,11 @@ def main():
             _, r = synth.pixel_to_ray(F, k["x"].astype(np.float64), k["y"].astype(np.float64))
             k["rays"] = r.astype(np.float32)
     tri_ctx, tri_store, tri_jobs = [], [], []
-    split_tri = os.environ.get("CMS_BENCH_SPLIT_TRI_STREAM", "") != ""; ba_streams = []
+    # CreateNewMapPoints of a window group's key frames runs on a host thread and a queue of its own (tri_pool below): the group's local BA waits
+    # for it (LocalMapping's order for a key frame: LocalMapping.cpp:80-110), but the NEXT step's CreateNewMapPoints -- other camera streams' key
+    # frames -- no longer queues behind this step's Levenberg rounds (tri_pools below).  CMS_BENCH_TRI_INLINE=1: called by the BA worker itself, on the group's queue
+    tri_inline = os.environ.get("CMS_BENCH_TRI_INLINE", "") != ""
+    split_tri = os.environ.get("CMS_BENCH_SPLIT_TRI_STREAM", "") != "" or not tri_inline; ba_streams = []
     for gi, grp in enumerate(groups):
         mprio = os.environ.get("CMS_BENCH_MAP_PRIORITY", "")       # developer knob: the same for the mapping side's queues (one per window group)
         if mprio:
@@ -452,7 +456,8 @@ def main():
                 ba.reset()                       # here, where the chip is quiet, rather than in front of the next step's first kernel)
         return 1e3 * (time.perf_counter() - t_ba0), sum(len(r[0]) for r in res), stats, None, None
 
-    def ba_worker_life(futs, gi, keep):
+    tri_pools = [ThreadPoolExecutor(max_workers=1) for _ in range(n_grp)]      # one thread per group: a store's calls stay in order
+    def ba_worker_life(futs, gi, keep, tri_fut=None):
         """one window group of one step with the windows' whole life cycle: the group's windows were built by the pool while the previous
         step ran (futs); here they are optimised, then handed back to the pool to be read back and destroyed.  Returns (elapsed ms, new map
         points, per-window stats, futures of the read-backs, the windows' creation times)"""
@@ -463,14 +468,16 @@ def main():
         grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (the BA chain's largest kernel)
         last_here = tri_last or (stagger and gi % 2 == 1)
         t_p = time.perf_counter()
-        if not last_here:
+        if tri_fut is not None:
+            res = tri_fut.result()        # (submitted when the step began; usually through long before this group's previous windows were)
+        elif not last_here:
             res = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=False)
         t_t = time.perf_counter()
         worker_ms["profile_arm"] = worker_ms.get("profile_arm", 0.0) + 1e3 * (t_p - t_w)
         worker_ms["create_new_map_points_library_call"] = worker_ms.get("create_new_map_points_library_call", 0.0) + getattr(tri_store[gi], "last_call_ms", 0.0)
         _, stats = api.ba_optimize_many(grp, (5, 10))
         t_o = time.perf_counter()
-        if last_here:
+        if last_here and tri_fut is None:
             res = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=False)
         ms, nl = grp[0].profile_get()
         schur_acc["ms"] += ms; schur_acc["n"] += nl
@@ -522,6 +529,14 @@ def main():
     # the step at all: the FP64 chain also pulls the clocks down), and the step gets 4 % longer -- overlap stays the default
     serial = os.environ.get("CMS_BENCH_SERIAL_EXTRACT", "") != ""
     ba_first = os.environ.get("CMS_BENCH_BA_FIRST", "")     # developer knob: hand the mapping side to its threads BEFORE the frame path is enqueued (value = head start in us)
+    def timed_tri(gi):
+        t0_ = time.perf_counter()
+        r = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=True)      # (copies: the store's buffers serve the next call while this result waits)
+        worker_ms["create_new_map_points_own_thread"] = worker_ms.get("create_new_map_points_own_thread", 0.0) + 1e3 * (time.perf_counter() - t0_)
+        return r
+    def submit_tri(gi):
+        return None if tri_inline else tri_pools[gi].submit(timed_tri, gi)
+
     def collect(ths, keep):
         """wait for a step's window groups (raises what a worker raised) and book their results"""
         res = [th.result() for th in ths]
@@ -556,7 +571,7 @@ def main():
         ths = []
         if ba_first and part != "frames" and life["on"]:
             cur, cur_set = next_windows()
-            ths = [pool.submit(ba_worker_life, cur[gi], gi, keep) for gi in range(n_grp)]
+            ths = [pool.submit(ba_worker_life, cur[gi], gi, keep, submit_tri(gi)) for gi in range(n_grp)]
             last["set"] = cur_set
             if int(ba_first) > 0:
                 t_hs = time.perf_counter()
@@ -581,7 +596,7 @@ def main():
                 pass
             elif life["on"]:
                 cur, cur_set = next_windows()             # the coming steps' windows are built under this one
-                ths = [pool.submit(ba_worker_life, cur[gi], gi, keep) for gi in range(n_grp)]
+                ths = [pool.submit(ba_worker_life, cur[gi], gi, keep, submit_tri(gi)) for gi in range(n_grp)]
                 last["set"] = cur_set
             else:
                 ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)]
@@ -732,6 +747,8 @@ def main():
             print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms_per_step, 3), "ba_window_setup": {"ms_per_window_inside_the_step": round(create_ms_in_step, 2)}, "ba_worker_ms": worker_break, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
         pool.shutdown()
         wpool.shutdown()
+        for tp_ in tri_pools:
+            tp_.shutdown()
         return
     streamed = None
     if not args.no_streaming_pass:
@@ -1118,6 +1135,8 @@ def main():
         print(json.dumps(out), flush=True)
     pool.shutdown()
     wpool.shutdown()
+    for tp_ in tri_pools:
+        tp_.shutdown()
     if world > 1:
         dist.destroy_process_group()
 
