@@ -430,7 +430,10 @@ def main():
             jobs_g.append((base, list(range(base + 1, base + tri_nn + 1))))
         tri_ctx.append(cg); tri_store.append(st); tri_jobs.append(jobs_g)
         if split_tri:          # developer knob: the group's BA rounds on a stream of their own, CreateNewMapPoints alone on the context's
-            bs = torch.cuda.Stream(device=dev); ba_streams.append(bs); group_stream.append(bs.cuda_stream)
+            # (CMS_BENCH_BA_PRIORITY=high: the rounds' queue in the high-priority class -- hardware queues of its own, not shared with the
+            # window pool's upload streams, whose multi-megabyte transfers otherwise sit in front of the chain's launches)
+            bprio = {"high": -1, "low": 1}.get(os.environ.get("CMS_BENCH_BA_PRIORITY", ""), 0)
+            bs = torch.cuda.Stream(device=dev, priority=bprio); ba_streams.append(bs); group_stream.append(bs.cuda_stream)
         else:
             group_stream.append(cg.stream)
         if os.environ.get("CMS_BENCH_SHARED_STREAMS", "") != "":

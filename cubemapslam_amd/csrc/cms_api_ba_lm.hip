@@ -294,7 +294,10 @@ static int ba_upload_items(cms_ba** bas, int n) {
   static_assert(sizeof(BaItem) % 16 == 0, "BaItem is copied in 16-byte words");
   static const bool items_by_copy_engine = getenv("CMS_BA_ITEMS_COPY_ENGINE") != nullptr;      // developer A/B
   if (items_by_copy_engine) HIPCHK(hipMemcpyAsync(g->grp_items_dev, items, (size_t)n * sizeof(BaItem), hipMemcpyHostToDevice, g->stream));
-  else hipLaunchKernelGGL(k_copy16, dim3(1), dim3(1024), 0, g->stream, (uint4*)g->grp_items_dev, (const uint4*)items, (int)((size_t)n * sizeof(BaItem) / 16));
+  else {      // (wavefront-sized workgroups: a 1024-thread workgroup waited up to a millisecond for sixteen free wavefront slots on ONE CU next to the frame path)
+    const int n16 = (int)((size_t)n * sizeof(BaItem) / 16);
+    hipLaunchKernelGGL(k_copy16, dim3((n16 + 63) / 64), dim3(64), 0, g->stream, (uint4*)g->grp_items_dev, (const uint4*)items, n16);
+  }
   HIPCHK(hipGetLastError());
   return CMS_OK;
 }
@@ -609,10 +612,20 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
 }
 static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats) {
   const bool batched = ba_can_batch(bas, n);
+  static const bool call_timing = getenv("CMS_BA_CALL_TIMING") != nullptr;      // developer knob: where a call's host time goes (stderr, ms since entry)
+  const auto t_in = std::chrono::steady_clock::now();
+  std::string t_log;
+  auto tick = [&](const char* what) {
+    if (!call_timing) return;
+    char buf[64];
+    snprintf(buf, sizeof(buf), " %s %.3f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
+    t_log += buf;
+  };
   if (batched) {
     HIPCHK(hipSetDevice(bas[0]->device));
     for (int w = 0; w < n; ++w)      // pending uploads / resets on the windows' streams
       if (bas[w]->async_pending) { HIPCHK(hipStreamSynchronize(bas[w]->stream)); bas[w]->async_pending = false; }
+    tick("uploads-waited");
     int rcg = ba_group_reserve(bas[0], n);
     if (rcg) return rcg;
     rcg = ba_upload_items(bas, n);          // static descriptions of the windows: once per call
@@ -620,6 +633,7 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
     // from here on kernels of the group may be in flight on the shared stream: a window destroyed after an early error return must wait for
     // them (cms_ba_destroy synchronises a shared stream only for windows with async_pending); cleared at the successful end of the call
     for (int w = 0; w < n; ++w) bas[w]->async_pending = true;
+    tick("items");
   }
   std::vector<cms_ba_stats> local(n);
   for (int w = 0; w < n; ++w) memset(&local[w], 0, sizeof(cms_ba_stats));
@@ -633,6 +647,7 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
       return cms_fail(CMS_ERR_UNSUPPORTED, "cms_ba_optimize: the window carries only the edge-major work list but another kernel path was selected");
   int rc = batched ? (host_lm ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_batched_dev(bas, n, st, stop)) : ba_optimize_stage_many(bas, n, st, stop);
   if (rc) return rc;
+  tick("stage1");
   for (int w = 0; w < n; ++w) {
     local[w].iterations_done[0] = st[w].done; local[w].chi2_initial[0] = st[w].chi_ini; local[w].chi2_final[0] = st[w].chi_fin;
     local[w].lambda_final[0] = st[w].lam_fin;
@@ -657,6 +672,7 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
     rc = classify(1);
     if (rc) return rc;
     for (int w = 0; w < n; ++w) local[w].n_outliers_mid = counts[w];
+    tick("classified");
     for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_final; st[w].robust = 0; st[w].delta = delta; }
     rc = batched ? (host_lm ? ba_optimize_stage_batched(bas, n, st, stop) : ba_optimize_stage_batched_dev(bas, n, st, stop)) : ba_optimize_stage_many(bas, n, st, stop);
     if (rc) return rc;
@@ -664,9 +680,12 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
       local[w].iterations_done[1] = st[w].done; local[w].chi2_initial[1] = st[w].chi_ini; local[w].chi2_final[1] = st[w].chi_fin;
       local[w].lambda_final[1] = st[w].lam_fin;
     }
+    tick("stage2");
   }
   rc = classify(0);          // Optimizer.cpp:399-412
   if (rc) return rc;
+  tick("classified");
+  if (call_timing) fprintf(stderr, "[cms_ba_optimize_many] %d windows:%s\n", n, t_log.c_str());
   for (int w = 0; w < n; ++w) local[w].n_outliers_final = counts[w];
   if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats));
   if (batched) for (int w = 0; w < n; ++w) bas[w]->async_pending = false;      // classify synchronised the group's stream: nothing of the windows is in flight

@@ -118,7 +118,7 @@ int tri_run(cms_ctx* c, const TriDev& dev, const CmsTriKF* hkf, const float* hme
   }
   memcpy(hin + o_job, jobs.data(), (size_t)njobs * sizeof(CmsTriJob));
   if (copy_engine) HIPCHK(hipMemcpyAsync(p, hin, in_bytes, hipMemcpyHostToDevice, s));
-  else hipLaunchKernelGGL(k_copy16, dim3(1), dim3(1024), 0, s, (uint4*)p, (const uint4*)hin, (int)(in_bytes / 16));      // (offsets are multiples of 256)
+  else hipLaunchKernelGGL(k_copy16, dim3((unsigned)((in_bytes / 16 + 63) / 64)), dim3(64), 0, s, (uint4*)p, (const uint4*)hin, (int)(in_bytes / 16));      // (offsets are multiples of 256; wavefront-sized workgroups find a slot at once)
   uint8_t* po = copy_engine ? p + o_nnew : hout;          // where the kernels put their results
   CmsTriArgs a;
   a.kf = dev.kf; a.pair = (const CmsTriPair*)(p + o_pair); a.job = (const CmsTriJob*)(p + o_job);

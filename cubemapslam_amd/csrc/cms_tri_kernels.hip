@@ -286,7 +286,7 @@ __device__ int tri_search_feature(const CmsTriArgs& a, const CmsTriKF& k1, const
 
 // n16 x 16 bytes from src to dst by one launch: the small host -> device hand-overs of the mapping side (src: pinned host memory the device
 // can read) that must not queue behind the copy engines' large transfers
-extern "C" __global__ void __launch_bounds__(1024) k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
+extern "C" __global__ void __launch_bounds__(64) k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 extern "C" __global__ void __launch_bounds__(512) k_create_new_map_points(CmsTriArgs a) {
