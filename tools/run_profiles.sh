@@ -8,14 +8,14 @@
 # Summaries are then copied into profiles/ by tools/summarise_profiles.py.  Counter passes never carry --stats / trace domains beyond
 # --kernel-trace.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 PB=${PROF_B:-256}          # frames per dispatch of the PMC passes = bench.py's default --batch
 export PROF_B=$PB
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 # the same trace, condensed to (kernel, start, end, queue, stream): input of tools/step_table.py (per-step chip-time table)
 python - "$OUT/${TAG}_bench_kernel_trace.csv" "$OUT/${TAG}_trace_small.csv" <<'PY'
 import csv, sys
@@ -38,9 +38,10 @@ rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv
 # probes and stamps behind DESIGN.md's statements: LDS atomic rates, per-phase cycles of the run-major MFMA body, the Python-free driver
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/probe/lds_atomics.hip -o /tmp/lds_atomics 2>/dev/null && /tmp/lds_atomics > $OUT/${TAG}_probe_lds_atomics.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics $R/tools/probe/global_atomics.hip -o /tmp/global_atomics 2>/dev/null && /tmp/global_atomics > $OUT/${TAG}_probe_global_atomics.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/probe/f64_pipes.hip -o /tmp/f64_pipes 2>/dev/null && /tmp/f64_pipes > $OUT/${TAG}_probe_f64_pipes.txt 2>&1
 [ -f $R/cubemapslam_amd/lib/ab_rmclk.so ] && CMS_HIP_LIB=$R/cubemapslam_amd/lib/ab_rmclk.so python $R/tools/prof_rm_clk.py 16 > $OUT/${TAG}_rm_phase_cycles.txt 2>&1
 python $R/tools/prof_ba_many.py 16 track diff > $OUT/${TAG}_ba16_track.txt 2>&1
-CMS_BA_RM_VALU=1 CMS_BA_RM_WEIGHT=60 python $R/tools/prof_ba_many.py 16 track diff > $OUT/${TAG}_ba16_track_valu.txt 2>&1
+CMS_BA_RM_VALU=1 python $R/tools/prof_ba_many.py 16 track diff > $OUT/${TAG}_ba16_track_valu.txt 2>&1
 CMS_BA_NO_RUNS=1 python $R/tools/prof_ba_many.py 16 track diff > $OUT/${TAG}_ba16_track_edges_only.txt 2>&1
 python $R/tools/prof_ba_many.py 16 random diff > $OUT/${TAG}_ba16_random.txt 2>&1
 python $R/tools/prof_ba_many.py 1 track > $OUT/${TAG}_ba1_track.txt 2>&1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof/<tag>_* (rocprofv3 csv output) into the small, tracked summaries under profiles/."""
 import collections, csv, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 PB = int(os.environ.get("PROF_B", "256"))      # frames per dispatch of the PMC passes (tools/run_profiles.sh)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof"); dst = os.path.join(root, "profiles")
@@ -11,7 +11,8 @@ if os.path.exists(stats):
     rows = list(csv.DictReader(open(stats)))
     with open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass "
-                "--optimise-only-steps 0 --verify-windows 0   (MI355X, 1 GPU; every step creates, optimises, reads back and destroys its 32 local-BA windows)\n")
+                "--optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0   (MI355X, 1 GPU; every step creates, "
+                "optimises, reads back and destroys its 32 local-BA windows; only the timed pass's launches are in the trace)\n")
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
@@ -36,7 +37,7 @@ for extra, cmd in (("mapping", "python tools/prof_tri.py 8 20 5"), ("ba8", "pyth
                 f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
                                   "%.2f" % float(r["Percentage"]), r["MinNs"], r["MaxNs"]]) + "\n")
 import shutil
-for name in ("step_table.md", "probe_lds_atomics.txt", "probe_global_atomics.txt", "rm_phase_cycles.txt", "ba16_track.txt", "ba16_track_valu.txt", "ba16_track_edges_only.txt", "ba16_random.txt", "ba1_track.txt"):
+for name in ("step_table.md", "probe_lds_atomics.txt", "probe_global_atomics.txt", "probe_f64_pipes.txt", "rm_phase_cycles.txt", "ba16_track.txt", "ba16_track_valu.txt", "ba16_track_edges_only.txt", "ba16_random.txt", "ba1_track.txt"):
     sp = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(sp):
         txt = [l for l in open(sp) if not l.startswith(("W2", "E2", "I2", "/opt/amdgpu"))]
