@@ -336,7 +336,9 @@ def main():
     # chip-filling, the mapping side's are a long chain of short dependent launches -- when both have workgroups ready the chain goes first.
     # Measured 13.9-14.1 against 14.6-15.5 ms per step (tools/experiments_r03/r03_run14.sh; "high" does the same: what counts is that the queue classes
     # differ).  CMS_BENCH_FRAME_PRIORITY=normal|high|low overrides; the mapping side's contexts keep the default.
-    fprio = os.environ.get("CMS_BENCH_FRAME_PRIORITY", "low")
+    # Round 4: with the steps pipelined (the mapping side of step s next to the frame path of step s + 1) the step takes the same 11.0-11.3 ms
+    # with either class, and the extractor keeps 0.35 instead of 0.30 of its byte roofline inside the step at normal priority: the default again.
+    fprio = os.environ.get("CMS_BENCH_FRAME_PRIORITY", "normal")
     fprio = "" if fprio == "normal" else fprio
     if fprio:
         os.environ["CMS_FRAME_STREAM_PRIORITY"] = fprio
@@ -585,6 +587,8 @@ def main():
             if not streaming:
                 ctx.upload_device(S.d_frames.data_ptr(), B)        # inputs resident in HBM: staging <- device copy
             ctx.process(B, True)        # (streaming: waits on the device for the copy enqueued during the previous step)
+        if step_trace is not None:
+            step_trace.append(("frame path enqueued", time.perf_counter()))
             if streaming:
                 ctx.upload_async(sets[(i + 1) % 2].pinned.array)   # next step's frames travel under this step's kernels
         if part != "frames":
@@ -601,11 +605,17 @@ def main():
                 cur, cur_set = next_windows()             # the coming steps' windows are built under this one
                 ths = [pool.submit(ba_worker_life, cur[gi], gi, keep, submit_tri(gi)) for gi in range(n_grp)]
                 last["set"] = cur_set
+                if step_trace is not None:
+                    step_trace.append(("windows + workers submitted", time.perf_counter()))
             else:
                 ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)]
         if part != "ba":
             S.enqueue_tracking(ext_stream)
+        if step_trace is not None:
+            step_trace.append(("tracking enqueued", time.perf_counter()))
             ctx.sync()
+        if step_trace is not None:
+            step_trace.append(("ctx.sync returned", time.perf_counter()))
             _, frame_poses, _, _ = po.fetch()
         if life.get("deferred") is not None:
             submit_windows(life.pop("deferred"))

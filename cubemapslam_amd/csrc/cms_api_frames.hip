@@ -62,6 +62,7 @@ struct cms_ctx {
   hipStream_t copy_stream = nullptr; hipEvent_t ev_upload_done = nullptr, ev_remap_done = nullptr;
   bool upload_pending = false, remap_recorded = false;
   int dist_bounds_scaled = 0;      // cms_set_distance_bounds_mode: map points' distance bounds come from the public MapPoint getters
+  hipEvent_t ev_block = nullptr; int last_batch = 0;                     // cms_frames_sync after a large batch sleeps on this event instead of spinning (hipEventBlockingSync)
   hipEvent_t ev_extracted = nullptr; bool extracted_recorded = false;   // end of the last cms_frames_process (cms_stream_wait_extracted)
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;          // pinned staging of the one-frame host entries (one copy each way)
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
@@ -167,6 +168,7 @@ static void cms_ctx_free(cms_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int i = 0; i < 8; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
   if (c->ev_extracted) hipEventDestroy(c->ev_extracted);
+  if (c->ev_block) hipEventDestroy(c->ev_block);
   if (c->ev_upload_done) hipEventDestroy(c->ev_upload_done);
   if (c->ev_remap_done) hipEventDestroy(c->ev_remap_done);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -491,6 +493,7 @@ extern "C" int cms_set_mask(cms_ctx* c, const uint8_t* mask, int mstride) {
 }
 
 static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
+  c->last_batch = B;
   c->g.skip_zero_cells = from_fisheye ? 1 : 0;   // a caller-supplied canvas (cms_extract) may hold anything in its corner blocks
   // the corner blocks of every level are 0 from cms_ctx_create on and k_remap never writes there; only a caller-supplied canvas
   // can dirty them, in which case the next remapped launch rewrites the zeros in full
@@ -578,6 +581,13 @@ extern "C" int cms_frames_process(cms_ctx* c, int B, int from_fisheye) {
 extern "C" int cms_frames_sync(cms_ctx* c) {
   if (!c) return cms_fail(CMS_ERR_ARG, "null ctx");
   HIPCHK(hipSetDevice(c->device));
+  if (c->last_batch >= 32) {
+    // a large batch keeps the stream busy for milliseconds: the calling thread sleeps until the stream is through instead of spinning on it (a
+    // host core per context otherwise; the wake-up costs some tens of microseconds, nothing against such a batch).  Small batches: spin as before
+    if (!c->ev_block) HIPCHK(hipEventCreateWithFlags(&c->ev_block, hipEventDisableTiming | hipEventBlockingSync));
+    HIPCHK(hipEventRecord(c->ev_block, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_block));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   int ov = 0;
   HIPCHK(hipMemcpy(&ov, c->d_overflow, sizeof(int), hipMemcpyDeviceToHost));

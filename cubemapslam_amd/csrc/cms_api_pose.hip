@@ -14,6 +14,7 @@ struct cms_pose {
   uint8_t* d_out = nullptr; double* d_err = nullptr; double* d_poses = nullptr; double* d_poses0 = nullptr; int* d_res = nullptr;
   double fx = 0, fy = 0, cx = 0, cy = 0;
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;     // pinned staging of cms_pose_optimize_batch (inputs out, results back: no pageable copies)
+  uint8_t* h_fetch = nullptr; size_t h_fetch_bytes = 0;     // pinned landing block of cms_pose_fetch
 };
 
 static void cms_pose_free(cms_pose* p) {
@@ -22,6 +23,7 @@ static void cms_pose_free(cms_pose* p) {
   void* ptrs[] = {p->d_off, p->d_Xw, p->d_obs, p->d_inv, p->d_face, p->d_out, p->d_err, p->d_poses, p->d_poses0, p->d_res};
   for (void* q : ptrs) if (q) hipFree(q);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
+  if (p->h_fetch) (void)hipHostFree(p->h_fetch);
   if (p->stream) hipStreamDestroy(p->stream);
   delete p;
 }
@@ -122,11 +124,24 @@ extern "C" int cms_pose_fetch(cms_pose* p, double* poses7, uint8_t* outlier, int
   if (!p || p->nf < 1) return cms_fail(CMS_ERR_ARG, "cms_pose_fetch: nothing launched");
   HIPCHK(hipSetDevice(p->device));
   hipStream_t s = p->stream;
-  std::vector<int> res((size_t)p->nf * 8);
-  HIPCHK(hipMemcpyAsync(res.data(), p->d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-  if (poses7) HIPCHK(hipMemcpyAsync(poses7, p->d_poses, (size_t)p->nf * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (outlier && p->ne > 0) HIPCHK(hipMemcpyAsync(outlier, p->d_out, (size_t)p->ne, hipMemcpyDeviceToHost, s));
+  // results through the handle's pinned block, one synchronisation: three copies into the caller's pageable arrays were three staged,
+  // waited-for transfers (1.2 ms for 256 frames next to a busy PCIe link, on the thread that drives the frame path)
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_res = 0, o_pose = al((size_t)p->nf * 32), o_out = o_pose + al((size_t)p->nf * 56), total = o_out + al((size_t)std::max(p->ne, 1));
+  if (total > p->h_fetch_bytes) {
+    if (p->h_fetch) (void)hipHostFree(p->h_fetch);
+    p->h_fetch = nullptr; p->h_fetch_bytes = 0;
+    HIPCHK(hipHostMalloc((void**)&p->h_fetch, 2 * total));
+    p->h_fetch_bytes = 2 * total;
+  }
+  uint8_t* h = p->h_fetch;
+  HIPCHK(hipMemcpyAsync(h + o_res, p->d_res, (size_t)p->nf * 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (poses7) HIPCHK(hipMemcpyAsync(h + o_pose, p->d_poses, (size_t)p->nf * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (outlier && p->ne > 0) HIPCHK(hipMemcpyAsync(h + o_out, p->d_out, (size_t)p->ne, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  const int* res = (const int*)(h + o_res);
+  if (poses7) memcpy(poses7, h + o_pose, (size_t)p->nf * 56);
+  if (outlier && p->ne > 0) memcpy(outlier, h + o_out, (size_t)p->ne);
   for (int f = 0; f < p->nf; ++f) {
     if (n_inliers) n_inliers[f] = res[8 * f];
     if (stats) { stats[f].n_bad = res[8 * f + 1]; stats[f].rounds = res[8 * f + 2]; for (int i = 0; i < 4; ++i) stats[f].iterations_done[i] = res[8 * f + 4 + i]; }
