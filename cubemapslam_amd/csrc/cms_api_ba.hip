@@ -147,11 +147,27 @@ static hipStream_t ba_stream_take(int device) {
   pl.idle[device].pop_back();
   return s;
 }
+// hipStreamSynchronize that gives the core away: a short spin for waits of a few microseconds, then queries between 40-us sleeps.  The host threads
+// that build, drive and finish windows outnumber the cores a rank gets (16 window threads + the group threads next to a 16-core quota), and the
+// runtime's own wait spins: measured 1.1 ms of CPU per window in cms_ba_read alone, most of it waiting for a 0.6 MB read-back to get its turn.
+static hipError_t ba_wait_stream(hipStream_t s) {
+  static const bool spin = getenv("CMS_BA_SPIN_WAIT") != nullptr;      // developer A/B: the runtime's wait
+  if (spin) return hipStreamSynchronize(s);
+  for (int i = 0; i < 64; ++i) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q != hipErrorNotReady) return q == hipSuccess ? hipStreamSynchronize(s) : q;
+  }
+  for (;;) {
+    std::this_thread::sleep_for(std::chrono::microseconds(40));
+    const hipError_t q = hipStreamQuery(s);
+    if (q != hipErrorNotReady) return q == hipSuccess ? hipStreamSynchronize(s) : q;
+  }
+}
 static void ba_stream_give(int device, hipStream_t s) {
   BaStreamPool& pl = ba_stream_pool();
   {
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (device >= 0 && device < 64 && pl.idle[device].size() < 256 && hipStreamSynchronize(s) == hipSuccess) { pl.idle[device].push_back(s); return; }
+    if (device >= 0 && device < 64 && pl.idle[device].size() < 256 && hipStreamQuery(s) == hipSuccess) { pl.idle[device].push_back(s); return; }
   }
   hipStreamDestroy(s);
 }
@@ -297,7 +313,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   // nothing of this window may still be running when its memory goes back to the pool.  A window on a stream of its own waits for that
   // stream; a window on a stream it shares (cms_ba_set_stream: the group's stream, busy with the NEXT windows by now) only when it has
   // something of its own pending there -- optimise / read return with the window's work complete
-  if (b->stream && (b->own_stream || b->async_pending)) hipStreamSynchronize(b->stream);
+  if (b->stream && (b->own_stream || b->async_pending)) (void)ba_wait_stream(b->stream);
   for (const BaBlock& sl : b->slabs) ba_dev_give(b->device, sl.p, sl.bytes);
   if (b->h_pin) ba_pin_give(b->device, b->h_pin, b->h_pin_bytes);
   if (b->h_stage) ba_stage_give(b->device, b->h_stage, b->h_stage_bytes);
@@ -315,7 +331,7 @@ extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullpt
 extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
   if (!b || !hip_stream) return cms_fail(CMS_ERR_ARG, "cms_ba_set_stream: bad argument");
   HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(ba_wait_stream(b->stream));          // (the window's upload and gather: a few hundred microseconds the building thread need not spin through)
   b->async_pending = false;
   if (b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else HIPCHK(hipStreamDestroy(b->stream)); }
   b->stream = (hipStream_t)hip_stream; b->own_stream = false;
@@ -1399,7 +1415,7 @@ extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* ou
   if (poses && re == hipSuccess) re = hipMemcpyAsync(h + o_pose, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost, rs);
   if (points && re == hipSuccess) re = hipMemcpyAsync(h + o_pts, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, rs);
   if (outlier_flags && re == hipSuccess) re = hipMemcpyAsync(h + o_flags, b->d_flags, b->E, hipMemcpyDeviceToHost, rs);
-  if (re == hipSuccess) re = hipStreamSynchronize(rs);
+  if (re == hipSuccess) re = ba_wait_stream(rs);
   if (temp) ba_stream_give(b->device, rs);
   HIPCHK(re);
   b->async_pending = false;

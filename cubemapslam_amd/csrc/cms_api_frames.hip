@@ -1,5 +1,7 @@
 // cms_api_frames.hip -- host side of the C-ABI for the frame path (context, LUT / table construction, launches).
 // Included by cms_lib.hip (single translation unit together with the kernels).
+#include <chrono>
+#include <thread>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -62,7 +64,7 @@ struct cms_ctx {
   hipStream_t copy_stream = nullptr; hipEvent_t ev_upload_done = nullptr, ev_remap_done = nullptr;
   bool upload_pending = false, remap_recorded = false;
   int dist_bounds_scaled = 0;      // cms_set_distance_bounds_mode: map points' distance bounds come from the public MapPoint getters
-  hipEvent_t ev_block = nullptr; int last_batch = 0;                     // cms_frames_sync after a large batch sleeps on this event instead of spinning (hipEventBlockingSync)
+  hipEvent_t ev_block = nullptr; int last_batch = 0;                     // cms_frames_sync after a large batch polls this event between short sleeps instead of spinning
   hipEvent_t ev_extracted = nullptr; bool extracted_recorded = false;   // end of the last cms_frames_process (cms_stream_wait_extracted)
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;          // pinned staging of the one-frame host entries (one copy each way)
   CmsKeyPoint* d_kps = nullptr; uint32_t* d_aux = nullptr; uint8_t* d_desc = nullptr; int* d_kp_cnt = nullptr;
@@ -584,9 +586,15 @@ extern "C" int cms_frames_sync(cms_ctx* c) {
   if (c->last_batch >= 32) {
     // a large batch keeps the stream busy for milliseconds: the calling thread sleeps until the stream is through instead of spinning on it (a
     // host core per context otherwise; the wake-up costs some tens of microseconds, nothing against such a batch).  Small batches: spin as before
-    if (!c->ev_block) HIPCHK(hipEventCreateWithFlags(&c->ev_block, hipEventDisableTiming | hipEventBlockingSync));
+    // (polled with short sleeps: hipEventSynchronize on a hipEventBlockingSync event was measured to keep the core just as busy on this runtime)
+    if (!c->ev_block) HIPCHK(hipEventCreateWithFlags(&c->ev_block, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c->ev_block, c->stream));
-    HIPCHK(hipEventSynchronize(c->ev_block));
+    for (;;) {
+      const hipError_t q = hipEventQuery(c->ev_block);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return cms_fail(CMS_ERR_HIP, "cms_frames_sync", q);
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   int ov = 0;
