@@ -355,7 +355,7 @@ static int ba_optimize_stage_batched(cms_ba** bas, int n, std::vector<BaLm>& st,
       hipLaunchKernelGGL(kb_ba_trial_points, dim3(max_p, 1, n), dim3(128), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       hipLaunchKernelGGL(kb_ba_reduce2, dim3(1, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
     }
-    HIPCHK(ba_wait_stream(s));          // the last kernel of each phase wrote the scalars into the pinned mirror
+    HIPCHK(hipStreamSynchronize(s));          // the last kernel of each phase wrote the scalars into the pinned mirror
     for (int w = 0; w < n; ++w) {
       if (dyn.phase[w] == BA_PHASE_IDLE) continue;
       memcpy(bas[w]->h_pin, g->grp_scal_host + 8 * w, 8 * sizeof(double));
@@ -536,11 +536,13 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
     if (spins < 256) std::this_thread::yield();                         // a round takes 100-250 us: spin briefly, then back off so that
     else std::this_thread::sleep_for(std::chrono::microseconds(20));    // several groups' host threads do not burn a core each
     if ((++spins & 0xFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) {      // the stream drained (or failed) without the counter moving
-      werr = ba_wait_stream(s);
+      werr = hipStreamSynchronize(s);
       if (werr != hipSuccess || k - vh[0].rounds >= 2) { if (werr == hipSuccess) werr = hipErrorUnknown; break; }
     }
   }
-  const hipError_t serr = ba_wait_stream(s);                  // final state of every window: mirrored into hlm by the kernels
+  // (the group driver's waits stay the runtime's spinning ones: they are short -- the mirror already said the windows are through -- and sit on the
+  // chain's critical path; queries between sleeps cost 0.3-0.5 ms per call here, measured)
+  const hipError_t serr = hipStreamSynchronize(s);                  // final state of every window: mirrored into hlm by the kernels
   HIPCHK(werr);
   HIPCHK(serr);
   HIPCHK(hipGetLastError());
@@ -577,7 +579,7 @@ static int ba_classify_batched(cms_ba** bas, int n, int set_level, std::vector<i
   const BaItem* ditems = reinterpret_cast<const BaItem*>(g->grp_items_dev);
   hipLaunchKernelGGL(kb_ba_classify, dim3(max_e, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_CLASSIFY);
   hipLaunchKernelGGL(kb_ba_counts_publish, dim3((n + 63) / 64), dim3(64), 0, s, ditems, n);      // counts -> pinned block; flags stay on the device
-  HIPCHK(ba_wait_stream(s));
+  HIPCHK(hipStreamSynchronize(s));
   const BaLmDev* hlm = reinterpret_cast<const BaLmDev*>(g->grp_lm_host);
   counts.resize(n);
   for (int w = 0; w < n; ++w) counts[w] = hlm[w].n_out[set_level ? 0 : 1];

@@ -583,7 +583,8 @@ extern "C" int cms_frames_process(cms_ctx* c, int B, int from_fisheye) {
 extern "C" int cms_frames_sync(cms_ctx* c) {
   if (!c) return cms_fail(CMS_ERR_ARG, "null ctx");
   HIPCHK(hipSetDevice(c->device));
-  if (c->last_batch >= 32) {
+  static const bool relaxed = getenv("CMS_BA_RELAXED_WAIT") != nullptr;      // (one switch for every host wait that can sleep: see ba_wait_stream)
+  if (relaxed && c->last_batch >= 32) {
     // a large batch keeps the stream busy for milliseconds: the calling thread sleeps until the stream is through instead of spinning on it (a
     // host core per context otherwise; the wake-up costs some tens of microseconds, nothing against such a batch).  Small batches: spin as before
     // (polled with short sleeps: hipEventSynchronize on a hipEventBlockingSync event was measured to keep the core just as busy on this runtime)
