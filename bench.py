@@ -142,12 +142,10 @@ def host_budget(world, local_rank, window_threads_arg=0, pin=True):
             pinned = True
         except (AttributeError, OSError):
             pass
-    # one pool thread per core of the slice (between 4 and 32): the threads spend a third of their time waiting on the device.  A rank with fewer
-    # than 14 cores lets those waits sleep instead of spin (CMS_BA_RELAXED_WAIT, read once by the library: ~3 cores less per GPU for 2-3 % of the
-    # throughput, measured on a 16-core box) and gets 1.5 threads per core -- a sleeping thread holds a pool slot, not a core
-    relaxed = budget < 14 or os.environ.get("CMS_BA_RELAXED_WAIT", "") != ""
-    if relaxed:
-        os.environ["CMS_BA_RELAXED_WAIT"] = "1"
+    # one pool thread per core of the slice (between 4 and 32): the threads spend a third of their time waiting on the device.  CMS_BA_RELAXED_WAIT=1
+    # (read once by the library) lets those waits sleep instead of spin: ~3 cores less per GPU, but 3-16 % of the throughput on a 16-core box (windows
+    # are ready later, the chain's kernels measure slower) -- an option for hosts short of cores, not a default; with it 1.5 threads per core
+    relaxed = os.environ.get("CMS_BA_RELAXED_WAIT", "") != ""
     wthreads = window_threads_arg or max(4, min(32, (3 * budget) // 2 if relaxed else budget))
     return {"cores_visible": len(cores), "cpu_quota_cores": quota, "local_world_size": local_world, "thread_budget": budget,
             "core_slice": [mine[0], mine[-1]] if mine else None, "pinned": pinned, "window_threads": wthreads, "host_waits": "sleep" if relaxed else "spin"}

@@ -151,8 +151,8 @@ static hipStream_t ba_stream_take(int device) {
 // that build, drive and finish windows outnumber the cores a rank gets (16 window threads + the group threads next to a 16-core quota), and the
 // runtime's own wait spins: measured 1.1 ms of CPU per window in cms_ba_read alone, most of it waiting for a 0.6 MB read-back to get its turn.
 static hipError_t ba_wait_stream(hipStream_t s) {
-  // CMS_BA_RELAXED_WAIT=1 turns it on.  Off by default: on a host with cores to spare the sleeping waits cost 2-3 % of the bench's throughput
-  // (windows are ready later, the chain's kernels measure slower) for three cores saved; bench.py sets it for ranks with fewer than 14 cores
+  // CMS_BA_RELAXED_WAIT=1 turns it on.  Off by default: on a host with cores to spare the sleeping waits cost 3-16 % of the bench's throughput
+  // (windows are ready later, the chain's kernels measure slower) for three cores saved: an option for hosts short of cores
   static const bool relaxed = getenv("CMS_BA_RELAXED_WAIT") != nullptr;
   if (!relaxed) return hipStreamSynchronize(s);
   for (int i = 0; i < 64; ++i) {
