@@ -1093,14 +1093,19 @@ def test_kfstore_fuse_search_matches_oracle():
 
 
 @pytest.mark.parametrize("knob", ["CMS_BA_NO_FUSED_LIN", "CMS_BA_DETERMINISTIC", "CMS_BA_NO_PERMUTE", "CMS_BA_NO_RUNS", "CMS_BA_RUNS_AS_EDGES",
-                                  "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU", "CMS_BA_SOLVE_REDUCE_MAX=1000"])
+                                  "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU", "CMS_BA_SOLVE_REDUCE_MAX=1000",
+                                  "CMS_BA_SPLIT_WORKGROUPS", "CMS_BA_SEPARATE_REDUCE2", "CMS_BA_SEPARATE_FIRST_PASS", "CMS_BA_TE_CHUNKS=1", "CMS_BA_TE_CHUNKS=5",
+                                  "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT"])
 def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     """The grouped local-BA driver has several Schur paths -- signature runs multiplied in MFMA tiles + edge-major left-overs, linearisation
     fused (default); the runs' products on the vector ALU by producer / consumer wavefront pairs (CMS_BA_RM_VALU); every point edge-major
     (CMS_BA_NO_RUNS), also with the run order kept (CMS_BA_RUNS_AS_EDGES); the edge-major kernel behind
     kb_ba_lin (CMS_BA_NO_FUSED_LIN); the deterministic pair-owner kernel (CMS_BA_DETERMINISTIC) -- a host-side chunk composition that can be
     switched off (CMS_BA_NO_PERMUTE), and the range sum either inside the solve kernel (the default for groups whose windows have at most 24
-    range slices each, i.e. 11 or more windows per group; CMS_BA_SOLVE_REDUCE_MAX=1000: always) or as its own launch (CMS_BA_SEPARATE_REDUCE).  The
+    range slices each, i.e. 11 or more windows per group; CMS_BA_SOLVE_REDUCE_MAX=1000: always) or as its own launch (CMS_BA_SEPARATE_REDUCE).
+    Round 4's alternatives: separate workgroups for run chunks and left-over chunks instead of cost-balanced ranges over both
+    (CMS_BA_SPLIT_WORKGROUPS), kb_ba_reduce2 / the four first-iteration launches instead of their folded forms (CMS_BA_SEPARATE_REDUCE2,
+    CMS_BA_SEPARATE_FIRST_PASS), one or five chunks per wavefront of the trial kernel, the window descriptions through a copy engine, sleeping host waits.  The
     knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""
     import os, subprocess, sys
     env = dict(os.environ)
