@@ -4,7 +4,15 @@
 #   probe        tools/probe/f64_pipes.hip (do FP64 MFMA and FP64 vector instructions of two wavefronts of a SIMD overlap?)
 #   ba16 [libs]  tools/prof_ba_many.py 16 track diff for every kernel of the round (3 Schur, 5 solve, 6 trial, 7 reduce2), per library variant
 #   bench [libs] tools/gb.sh (short bench line) per library variant (default | ab_NAME)
-#   tests        pytest -m gpu
+#   tests / batests / exttests          pytest -m gpu / the BA parity subset / the extraction subset
+#   ba16s [libs]                        ... the Schur kernel only
+#   pmcba / pmcwait / pmcifetch [libs]  PMC passes over the local-BA kernels: instruction mix / where a wavefront's cycles go / instruction fetch
+#   rmclk                               per-phase cycle stamps of the run-major body (needs tools/ab_build.sh rmclk -DBA_RM_CLK)
+#   waves / rmweight / emcost / techunks   sweeps of CMS_BA_SE_WAVES / CMS_BA_RM_WEIGHT (split workgroups) / CMS_BA_EM_COST_A,B / CMS_BA_TE_CHUNKS
+#   frames                              the frame path alone: describe walk against list order
+#   steptrace <tag> [ENV=..]            bench.py under rocprofv3 --stats: average duration of every kernel inside the step
+#   timeline <tag> [ENV=..]             bench.py under rocprofv3 --kernel-trace, per-queue busy time and gaps (tools/timeline.py)
+# (profiles/r04_experiments.txt collects the outputs DESIGN.md quotes)
 set -u
 O=gpurun_out/r04; mkdir -p $O
 libpath() { if [ "$1" = "default" ]; then echo $PWD/cubemapslam_amd/lib/libcubemapslam_hip.so; else echo $PWD/cubemapslam_amd/lib/ab_$1.so; fi; }
