@@ -21,7 +21,7 @@ struct BaKnobs {
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, separate_reduce2, separate_first_pass, rm_valu;
   int solve_reduce_max, leftover_lookahead;
   bool global_sum;
-  int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap, em_cost_a, em_cost_b, te_chunks; bool unified;
+  int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap, em_cost_a, em_cost_b, te_chunks, run_min_pct; bool unified;
   char stream_priority;
 };
 static const BaKnobs& ba_knobs() {
@@ -50,6 +50,7 @@ static const BaKnobs& ba_knobs() {
     q.leftover_lookahead = num("CMS_BA_LEFTOVER_LOOKAHEAD", 0);      // 0: automatic (see ba_plan)
     q.lookahead = num("CMS_BA_LOOKAHEAD", 24); q.compose_segments = num("CMS_BA_COMPOSE_SEGMENTS", 0); q.dup = num("CMS_BA_DUP", 0);
     q.run_min_chunks = std::max(1, num("CMS_BA_RUN_MIN_CHUNKS", q.rm_valu ? 2 : 1));
+    q.run_min_pct = std::max(10, std::min(100, num("CMS_BA_RUN_MIN_PCT", 100)));      // ... or this share of one chunk (a signature with half a chunk of points as a one-chunk run)
     q.rm_weight = std::max(10, std::min(400, num("CMS_BA_RM_WEIGHT", 58)));
     q.unified = !on("CMS_BA_SPLIT_WORKGROUPS");          // 1: every Schur workgroup of a window takes run chunks and left-over chunks (cut by cost); 0: separate workgroups
     q.em_cost_a = num("CMS_BA_EM_COST_A", 40); q.em_cost_b = num("CMS_BA_EM_COST_B", 30);      // cost of a left-over chunk: a + b x (edges of its largest point / 2), units of ba_rm_chunk_cost
@@ -755,7 +756,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
       for (int i = cpo[q]; i < cpo[q + 1]; ++i) kf += pose_slot[e_pose[cpe[i]]] >= 0;
       if (k < 1 || kf < 1 || kf * (kf + 1) / 2 > 64 || (!kn.rm_valu && 6 * kf + 1 > 48)) continue;      // (lane tables of the vector variant / three MFMA tiles a side)
       const int m = std::min(64 / k, BA_RM_PTS);
-      if (gcount[g] < kn.run_min_chunks * m) continue;           // at least that many FULL chunks: a run pays for one set of LDS additions
+      if (gcount[g] * 100 < kn.run_min_chunks * m * kn.run_min_pct) continue;      // at least that many FULL chunks (x run_min_pct / 100): a run pays for one set of LDS additions
       const int full = gcount[g] / m, tail = gcount[g] - full * m;
       const bool keep_tail = tail > 0 && 2 * tail >= m;          // a last chunk that is at least half full
       if (full == 0 && !keep_tail) continue;
