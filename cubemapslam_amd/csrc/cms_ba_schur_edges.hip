@@ -437,9 +437,9 @@ __device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaS
   __syncthreads();                                     // (also: every lane's LDS additions to pd are through)
   // hand-over to the window's last workgroup (kb_ba_first_pass): returning atomics only, every one waited for before the barrier behind which
   // thread 0 takes its ticket
-  if (tid < 6 * d.np) {
-    const double v = pd[tid];
-    if (v != 0.0) { const double o = atomicAdd(pose_diag + tid, v); asm volatile("" :: "v"(o) : "memory"); }
+  for (int i = tid; i < 6 * d.np; i += blockDim.x) {           // (up to 62 free key frames: more entries than threads)
+    const double v = pd[i];
+    if (v != 0.0) { const double o = atomicAdd(pose_diag + i, v); asm volatile("" :: "v"(o) : "memory"); }
   }
   if (tid == 0) {
     double m = 0;
