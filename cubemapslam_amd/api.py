@@ -581,7 +581,7 @@ class KeyframeStore:
         next to threads that hold the interpreter lock: fresh 0.8 MB of zeroed arrays per call were ~2 ms of a 3 ms call whose library
         part takes 0.3 ms).  copy=False returns views into those buffers, valid until the next call."""
         nj = len(jobs)
-        key = (id(jobs), nj, cap)
+        key = (cap, tuple((int(j[0]), tuple(int(s) for s in j[1])) for j in jobs))      # (the content, not the list's identity: a caller may edit its list in place)
         st = getattr(self, "_cnmp", None)
         if st is None or st[0] != key:
             cur = np.array([j[0] for j in jobs], np.int32)
@@ -590,7 +590,7 @@ class KeyframeStore:
             n_new = np.zeros(max(nj, 1), np.int32)
             on = np.zeros((max(nj, 1), cap), np.int32); o1 = np.zeros_like(on); o2 = np.zeros_like(on); ox = np.zeros((max(nj, 1), cap, 3), np.float32)
             arrs = (cur, off, neigh, n_new, on, o1, o2, ox)
-            st = self._cnmp = (key, arrs, [_p(a) for a in arrs], jobs)
+            st = self._cnmp = (key, arrs, [_p(a) for a in arrs])
         cur, off, neigh, n_new, on, o1, o2, ox = st[1]
         pc, po, pn, pnn, pon, po1, po2, pox = st[2]
         t0 = time.perf_counter()
