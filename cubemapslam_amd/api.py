@@ -709,6 +709,15 @@ def ba_plan(fixed, n_points, e_pose, e_point, tables=False):
                 n_rm=n_rm, n_runs=nruns, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), usable=bool(cnt[7]))
 
 
+def ba_set_deterministic(on):
+    """cms_ba_set_deterministic: windows created afterwards run the fixed-order (bit-repeatable) kernels, like the reference's single-threaded g2o."""
+    _chk(lib().cms_ba_set_deterministic(1 if on else 0), "cms_ba_set_deterministic")
+
+
+def ba_get_deterministic():
+    return bool(lib().cms_ba_get_deterministic())
+
+
 def ba_optimize_many(bas, its=(5, 10), stop=None, stop_array=None):
     """cms_ba_optimize_many: advance several BundleAdjuster windows in lock-step from one host thread.  stop_array: a uint8[1] array
     another thread may set while the call runs (Optimizer::LocalBundleAdjustment's pbStopFlag); None = no flag."""
@@ -797,6 +806,22 @@ class PoseOptimizer:
     def optimize(self, probs):
         self.upload(probs); self.launch()
         return self.fetch()
+
+    def optimize_batch(self, probs):
+        """cms_pose_optimize_batch on this handle (a few frames: the direct path through the handle's pinned block); the resident batch of
+        upload / launch is left alone.  Returns (n_inliers, poses, outlier flags per frame, stats)."""
+        nf = len(probs)
+        cnt = [len(q["Xw"]) for q in probs]
+        off = np.zeros(nf + 1, np.int32); off[1:] = np.cumsum(cnt)
+        cat = lambda k, dt, w: (np.ascontiguousarray(np.concatenate([np.asarray(q[k], dt).reshape(-1, w) for q in probs]), dt)
+                                if off[-1] else np.zeros((0, w), dt))
+        Xw, obs, inv, face = cat("Xw", np.float64, 3), cat("obs", np.float64, 2), cat("invsig2", np.float64, 1), cat("face", np.int8, 1)
+        poses = np.ascontiguousarray(np.stack([q["pose0"] for q in probs]), np.float64)
+        out = np.zeros(max(int(off[-1]), 1), np.uint8); ninl = np.zeros(nf, np.int32); st = (PoseStats * nf)()
+        p0 = probs[0]
+        _chk(lib().cms_pose_optimize_batch(self.h, nf, _p(off), _p(Xw), _p(obs), _p(inv), _p(face), C.c_double(p0["fx"]), C.c_double(p0["fy"]),
+                                           C.c_double(p0["cx"]), C.c_double(p0["cy"]), _p(poses), _p(out), _p(ninl), C.byref(st)), "cms_pose_optimize_batch")
+        return ninl, poses, [out[off[f]:off[f + 1]].copy() for f in range(nf)], list(st)
 
 
 def pose_optimize(prob, n=None, device=0):

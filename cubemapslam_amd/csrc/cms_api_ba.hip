@@ -109,6 +109,8 @@ struct cms_ba {
   // 6 the trial kernel (kb_ba_trial_edges), 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
+  bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
+  hipStream_t grp_stream = nullptr;   // the stream of the group whose rounds may still be in flight for this window (ba_optimize_group; cleared at its successful end)
   bool async_pending = false;   // something asynchronous (upload, reset, a group's rounds) was enqueued on `stream` and nothing has waited for it yet
   bool gsum_clean = false;      // slice 0 of the Schur partial sums (the ONE global copy the workgroups add to, BaSe::gsum) is all zero: true after
                                 // k_ba_gather / k_ba_reset and after every consuming solve kernel, false once a slice-STORING group ran on the window
@@ -317,6 +319,8 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   // stream; a window on a stream it shares (cms_ba_set_stream: the group's stream, busy with the NEXT windows by now) only when it has
   // something of its own pending there -- optimise / read return with the window's work complete
   if (b->stream && (b->own_stream || b->async_pending)) (void)ba_wait_stream(b->stream);
+  // ... and a window of a group whose call ended early (an error between two rounds): the group's kernels run on the group OWNER's stream
+  if (b->async_pending && b->grp_stream && b->grp_stream != b->stream) (void)ba_wait_stream(b->grp_stream);
   for (const BaBlock& sl : b->slabs) ba_dev_give(b->device, sl.p, sl.bytes);
   if (b->h_pin) ba_pin_give(b->device, b->h_pin, b->h_pin_bytes);
   if (b->h_stage) ba_stage_give(b->device, b->h_stage, b->h_stage_bytes);
@@ -360,6 +364,12 @@ extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
   return hipMemcpy(out8, b->d_scal + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
 }
 
+// Determinism as a product mode (cms_ba_set_deterministic; the environment variable CMS_BA_DETERMINISTIC gives the initial value): windows
+// created while it is on carry the pair-owner kernel's work lists and run kb_ba_schur_points -- fixed summation order, bit-identical runs, like the
+// reference's single-threaded g2o (ThirdParty/g2o/config.h:4).  The choice is taken when a window is CREATED and travels with it.
+static std::atomic<int>& ba_det_mode() { static std::atomic<int> m{ba_knobs().deterministic ? 1 : 0}; return m; }
+extern "C" int cms_ba_set_deterministic(int on) { ba_det_mode().store(on ? 1 : 0); return CMS_OK; }
+extern "C" int cms_ba_get_deterministic(void) { return ba_det_mode().load(); }
 static std::atomic<int> ba_plans_in_flight{0};      // windows being planned right now (cms_ba_create / cms_ba_debug_plan calls of all host threads)
 // lanes of one group of 16 -> LDS banks, every lane with four candidate banks: augmenting-path matching, the rest on their least-used bank
 struct BaDiagMatch {
@@ -693,7 +703,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   // edge-major kernel.  Runs need the fused path (linearisation inside the Schur kernel: three-lane solve, edge-major trial kernel) and the
   // LDS for four producer / consumer pairs.
   const size_t rm_lds = se_fixed_lds + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF * sizeof(double);
-  const bool rm_ok = se_ok && kn.runs && !kn.no_fused && !kn.want_all_lists && !kn.solve1 && !kn.trial_points && b->solve_blk3 && rm_lds <= BA_LDS_CEILING &&
+  const bool rm_ok = se_ok && kn.runs && !kn.no_fused && !kn.want_all_lists && !b->deterministic && !kn.solve1 && !kn.trial_points && b->solve_blk3 && rm_lds <= BA_LDS_CEILING &&
                      BA_SE_THREADS == 128 * BA_RM_PAIRS;
   struct Run { int k, first, npts, chunks, m; };              // first: a member point (its key frames are the signature)
   std::vector<Run> runs;
@@ -1052,6 +1062,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   HIPCHK(hipSetDevice(device));
   cms_ba* b = new cms_ba;
   b->device = device; b->K = K; b->P = P; b->E = E;
+  b->deterministic = ba_det_mode().load() != 0;
 #define BA_TRY(x) do { int _rc = (x); if (_rc) { cms_ba_destroy(b); return _rc; } } while (0)
 #define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
   // CMS_BA_CREATE_TIMING=1: where the host side of a window's set-up goes (stderr, one line per window)
@@ -1109,7 +1120,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   // it into a group of its own kind): the pair-owner and tuple-chunk kernels' work lists (co-visibility tuples: ~10 per point, 2.4 ms of
   // host time at 80 k edges) and the stored 6x3 blocks (144 B per edge) are then never touched and are not built.  The A/B switches that
   // select those kernels bring them back.
-  b->se_only = se_built && b->solve_blk && !kn.want_all_lists;
+  b->se_only = se_built && b->solve_blk && !kn.want_all_lists && !b->deterministic;
   if (!b->se_only) BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2
   if (!b->se_only) {

@@ -193,8 +193,8 @@ static bool ba_all_sp(cms_ba** bas, int n) {
 // the edge-major Schur kernel (LDS accumulation, cms_ba_schur_edges.hip) runs when every window of the group has its work list and the
 // per-point path is available too (the two share the block-free linearisation); CMS_BA_DETERMINISTIC=1 keeps the pair-owner kernel
 static bool ba_use_se(cms_ba** bas, int n) {
-  if (ba_knobs().deterministic || ba_knobs().host_lm) return false;   // (the host-driven A/B driver only knows the pair-owner kernel)
-  for (int w = 0; w < n; ++w) if (bas[w]->se.nchunks <= 0) return false;
+  if (ba_knobs().host_lm) return false;   // (the host-driven A/B driver only knows the pair-owner kernel)
+  for (int w = 0; w < n; ++w) if (bas[w]->se.nchunks <= 0 || bas[w]->deterministic) return false;      // (deterministic windows: the pair-owner kernel)
   return true;
 }
 // ... and the edge-major trial kernel when, in addition, every point of every window has an observation
@@ -286,7 +286,9 @@ static int ba_upload_items(cms_ba** bas, int n) {
         HIPCHK(hipMemsetAsync(b->d_se_partial, 0, (size_t)b->se.npairs2 * 42 * sizeof(double), g->stream));
         HIPCHK(hipMemsetAsync(b->d_se_bp_partial, 0, (size_t)b->np * 6 * sizeof(double), g->stream));
       }
-      b->gsum_clean = it.se.gsum != 0;
+      // (dirty from here on: only a call that ends with every round's solve kernel through leaves the copy zero again -- ba_optimize_group
+      // marks it clean at its successful end; after an error or an aborted call the next gsum group clears it)
+      b->gsum_clean = false;
     }
   }
   // (fetched from the pinned block by a kernel instead of a copy-engine transfer: one queue entry on the group's own stream; measured neutral
@@ -434,11 +436,13 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   const bool solve_reduces = fused && (gm.gsum || (!ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max));
   dyn.fused_lin = fused ? 1 : 0;
   const bool first_pass = fused && use_te && first_round && !ba_knobs().separate_first_pass;      // (a stage's windows all start at it == 0)
-  dyn.fold_reduce = (use_te && !ba_knobs().separate_reduce2) ? 1 : 0;      // the trial kernel sums its own partial sums and decides the trial (kb_ba_trial_edges)
+  // the trial kernel sums its own partial sums and decides the trial (kb_ba_trial_edges) -- not with CMS_BA_DUP: the deciding kernel is not
+  // idempotent (its last workgroup advances the Levenberg state and counts the round), a duplicated launch would evaluate a different state
+  dyn.fold_reduce = (use_te && !ba_knobs().separate_reduce2 && ba_knobs().dup == 0) ? 1 : 0;
   int k = 0;
   const int pk = g->prof_kernel;
-  const int dup = ba_knobs().dup;   // developer knob: launch kernel <id> of every round twice (all of
-                                    // 1 lin, 3 schur_points, 4 schur_reduce, 5 trial_solve, 6 trial_points are idempotent): how much does the step pay for it?
+  const int dup = ba_knobs().dup;   // developer knob: launch kernel <id> of every round twice (1 lin, 3 the Schur kernel, 4 schur_reduce, 5 trial_solve,
+                                    // 6 the trial kernel: idempotent once the global sum and the folded reduce are off, which dup != 0 does): how much does the step pay for it?
   auto bracket = [&](int id, int which) {     // HIP events around the one kernel the caller asked to have timed (cms_ba_profile_kernel)
     if (pk != id) return;
     const size_t i = 2 * (size_t)k + which;
@@ -593,7 +597,7 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
 extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats) {
   if (!bas || n < 1) return cms_fail(CMS_ERR_ARG, "cms_ba_optimize_many: bad argument");
   for (int w = 0; w < n; ++w) if (!bas[w]) return cms_fail(CMS_ERR_ARG, "null ba");
-  auto kind = [&](int w) { return bas[w]->device * 2 + (bas[w]->se.nchunks > 0 ? 1 : 0); };
+  auto kind = [&](int w) { return bas[w]->device * 4 + (bas[w]->se.nchunks > 0 ? 2 : 0) + (bas[w]->deterministic ? 1 : 0); };
   bool one = n <= BA_MAX_GROUP;
   for (int w = 1; w < n && one; ++w) one = kind(w) == kind(0);
   if (one) return ba_optimize_group(bas, n, its_robust, its_final, stop, stats);
@@ -634,12 +638,16 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
     if (rcg) return rcg;
     // from here on kernels of the group may be in flight on the shared stream: a window destroyed after an early error return must wait for
     // them (cms_ba_destroy synchronises a shared stream only for windows with async_pending); cleared at the successful end of the call
-    for (int w = 0; w < n; ++w) bas[w]->async_pending = true;
+    for (int w = 0; w < n; ++w) { bas[w]->async_pending = true; bas[w]->grp_stream = bas[0]->stream; }
     tick("items");
   }
   std::vector<cms_ba_stats> local(n);
   for (int w = 0; w < n; ++w) memset(&local[w], 0, sizeof(cms_ba_stats));
-  if (ba_stopped(stop)) { if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats)); return 1; }   // Optimizer.cpp:359-361
+  if (ba_stopped(stop)) {   // Optimizer.cpp:359-361 (no round ran: the global copies cleared by ba_upload_items stay zero once the stream is through)
+    if (batched) for (int w = 0; w < n; ++w) bas[w]->gsum_clean = bas[w]->grp_se.gsum != 0;
+    if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats));
+    return 1;
+  }
   const double delta = std::sqrt(5.991);
   std::vector<BaLm> st(n);
   for (int w = 0; w < n; ++w) { st[w] = BaLm(); st[w].iterations = its_robust; st[w].robust = 1; st[w].delta = delta; }
@@ -690,7 +698,8 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
   if (call_timing) fprintf(stderr, "[cms_ba_optimize_many] %d windows:%s\n", n, t_log.c_str());
   for (int w = 0; w < n; ++w) local[w].n_outliers_final = counts[w];
   if (stats) memcpy(stats, local.data(), n * sizeof(cms_ba_stats));
-  if (batched) for (int w = 0; w < n; ++w) bas[w]->async_pending = false;      // classify synchronised the group's stream: nothing of the windows is in flight
+  if (batched)      // classify synchronised the group's stream: nothing of the windows is in flight, and every round's solve kernel left the global copy zero
+    for (int w = 0; w < n; ++w) { bas[w]->async_pending = false; bas[w]->grp_stream = nullptr; bas[w]->gsum_clean = bas[w]->grp_se.gsum != 0; }
   return CMS_OK;
 }
 

@@ -15,6 +15,7 @@ struct cms_pose {
   double fx = 0, fy = 0, cx = 0, cy = 0;
   uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;     // pinned staging of cms_pose_optimize_batch (inputs out, results back: no pageable copies)
   uint8_t* h_fetch = nullptr; size_t h_fetch_bytes = 0;     // pinned landing block of cms_pose_fetch
+  uint8_t* h_direct = nullptr; size_t h_direct_bytes = 0;   // pinned block of the direct (few frames) path: its own, so that a staged upload still copying out of h_stage is never overwritten
 };
 
 static void cms_pose_free(cms_pose* p) {
@@ -24,6 +25,7 @@ static void cms_pose_free(cms_pose* p) {
   for (void* q : ptrs) if (q) hipFree(q);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
   if (p->h_fetch) (void)hipHostFree(p->h_fetch);
+  if (p->h_direct) (void)hipHostFree(p->h_direct);
   if (p->stream) hipStreamDestroy(p->stream);
   delete p;
 }
@@ -159,13 +161,15 @@ static int cms_pose_optimize_direct(cms_pose* p, int nf, const int* edge_off, co
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_off = 0, o_X = al(((size_t)nf + 1) * 4), o_obs = o_X + al((size_t)ne * 24), o_inv = o_obs + al((size_t)ne * 16), o_face = o_inv + al((size_t)ne * 8),
                o_pose = o_face + al((size_t)ne), o_res = o_pose + al((size_t)nf * 56), o_out = o_res + al((size_t)nf * 32), total = o_out + al((size_t)ne);
-  if (total > p->h_stage_bytes) {
-    if (p->h_stage) (void)hipHostFree(p->h_stage);
-    p->h_stage = nullptr; p->h_stage_bytes = 0;
-    HIPCHK(hipHostMalloc((void**)&p->h_stage, 4 * total));
-    p->h_stage_bytes = 4 * total;
+  // (a block of the direct path's own: the handle's resident batch -- cms_pose_upload + cms_pose_launch, possibly still copying out of h_stage --
+  // is not touched by this call, and a cms_pose_fetch afterwards still finds it: p->nf / p->ne stay as they are)
+  if (total > p->h_direct_bytes) {
+    if (p->h_direct) { HIPCHK(hipStreamSynchronize(p->stream)); (void)hipHostFree(p->h_direct); }
+    p->h_direct = nullptr; p->h_direct_bytes = 0;
+    HIPCHK(hipHostMalloc((void**)&p->h_direct, 4 * total));
+    p->h_direct_bytes = 4 * total;
   }
-  uint8_t* h = p->h_stage;
+  uint8_t* h = p->h_direct;
   memcpy(h + o_off, edge_off, ((size_t)nf + 1) * 4);
   if (ne > 0) { memcpy(h + o_X, Xw, (size_t)ne * 24); memcpy(h + o_obs, obs_uv, (size_t)ne * 16); memcpy(h + o_inv, inv_sigma2, (size_t)ne * 8); memcpy(h + o_face, face, (size_t)ne); }
   memcpy(h + o_pose, poses7, (size_t)nf * 56);
@@ -176,7 +180,6 @@ static int cms_pose_optimize_direct(cms_pose* p, int nf, const int* edge_off, co
   hipLaunchKernelGGL(k_pose_optimize, dim3(nf), dim3(256), 0, p->stream, d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(p->stream));
-  p->nf = 0;                                                       // (nothing resident for cms_pose_launch / cms_pose_fetch)
   const int* res = (const int*)(h + o_res);
   memcpy(poses7, h + o_pose, (size_t)nf * 56);
   if (outlier && ne > 0) memcpy(outlier, h + o_out, (size_t)ne);

@@ -439,11 +439,13 @@ __device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaS
   // thread 0 takes its ticket
   for (int i = tid; i < 6 * d.np; i += blockDim.x) {           // (up to 62 free key frames: more entries than threads)
     const double v = pd[i];
-    if (v != 0.0) { const double o = atomicAdd(pose_diag + i, v); asm volatile("" :: "v"(o) : "memory"); }
+    // (a non-finite sum stays out, like the fmax of the kernel this one replaced dropped NaNs: lambda's start must not be poisoned by one degenerate edge)
+    if (v != 0.0 && isfinite(v)) { const double o = atomicAdd(pose_diag + i, v); asm volatile("" :: "v"(o) : "memory"); }
   }
   if (tid == 0) {
     double m = 0;
     for (int i = 0; i < nw; ++i) m = fmax(m, sh[i]);
+    m = (isfinite(m) && m > 0.0) ? m : 0.0;                    // the integer maximum below orders bit patterns: a NaN's (above +inf's) must never enter
     const unsigned long long o1 = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(partial + BX), (unsigned long long)__double_as_longlong(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long o2 = atomicMax(pt_max, (unsigned long long)__double_as_longlong(m));      // (non-negative doubles order like their bit patterns)
     asm volatile("" :: "v"(o1), "v"(o2) : "memory");

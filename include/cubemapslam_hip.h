@@ -209,6 +209,14 @@ void cms_ba_destroy(cms_ba* ba);
  * 16384; the pool is also emptied and the allocation retried when hipMalloc fails).  cms_ba_pool_trim hands everything cached for `device` back
  * to the runtime -- for callers that share the device with other allocators; *released (may be NULL) receives the bytes. */
 int cms_ba_pool_trim(int device, size_t* released);
+/* Determinism as a product mode.  The reference optimises with a single-threaded g2o (ThirdParty/g2o/config.h:4: no OpenMP), so two runs on
+ * the same window give the same bits.  The default device path adds with FP64 atomics (order varies from run to run: last bits differ, see
+ * DESIGN.md section 2); cms_ba_set_deterministic(1) makes every window created AFTERWARDS run the fixed-order kernels (pair-owner Schur kernel,
+ * kb_ba_schur_points: bit-identical runs, slower).  The choice is taken at cms_ba_create and travels with the window; windows of both kinds may
+ * be passed to one cms_ba_optimize_many call (they run as separate groups).  Process-wide; the environment variable CMS_BA_DETERMINISTIC=1 gives
+ * the initial value.  cms_ba_get_deterministic returns the current setting. */
+int cms_ba_set_deterministic(int on);
+int cms_ba_get_deterministic(void);
 /* one-shot convenience: create + optimize + read + destroy */
 int cms_ba_run(int device, int K, double* poses, const uint8_t* fixed, int P, double* points, int E, const int* e_pose,
                const int* e_point, const double* e_obs, const double* e_invsig2, const int8_t* e_face, double fx, double fy,

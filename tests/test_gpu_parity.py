@@ -508,6 +508,54 @@ def test_pose_optimization_matches_oracle():
     assert n1 == ninl[0] and np.array_equal(out1, outs[0]) and np.array_equal(pose1, poses[0])
 
 
+def test_pose_direct_call_leaves_the_resident_batch_alone():
+    """a small cms_pose_optimize_batch (the direct path through a pinned block of its own) between cms_pose_launch and cms_pose_fetch of
+    a resident batch on the SAME handle must neither drop the resident batch ("nothing launched") nor disturb its result."""
+    probs = [synth.pose_problem(N=n, seed=s, outlier_frac=0.1) for n, s in ((600, 21), (300, 22), (900, 23), (450, 24), (120, 25), (700, 26), (64, 27), (500, 28), (333, 29), (256, 30))]
+    po = api.PoseOptimizer(len(probs), sum(len(p["Xw"]) for p in probs))
+    ninl0, poses0, outs0, _ = po.optimize(probs)
+    po.upload(probs); po.launch()                      # asynchronous: the batch is in flight / resident
+    small = [synth.pose_problem(N=200, seed=41, outlier_frac=0.2), synth.pose_problem(N=350, seed=42, outlier_frac=0.0)]
+    n_s, poses_s, outs_s, _ = po.optimize_batch(small)   # nf <= 8: the direct path
+    for f, pr in enumerate(small):
+        w_n, w_pose, w_out, _ = orc.pose_optimize(pr)
+        assert n_s[f] == w_n and np.array_equal(outs_s[f], w_out)
+    ninl1, poses1, outs1, _ = po.fetch()               # the resident batch's results are still there
+    assert np.array_equal(ninl0, ninl1) and np.array_equal(poses0, poses1) and all(np.array_equal(a, b) for a, b in zip(outs0, outs1))
+    po.close()
+
+
+@pytest.mark.parametrize("views", ["track", "random"])
+def test_ba_deterministic_mode_is_bit_repeatable_and_matches_the_oracle(views):
+    """cms_ba_set_deterministic(1): windows created afterwards run the fixed-order kernels -- bit-identical poses, points and flags run after run
+    (the reference's g2o is single-threaded and so deterministic), at the parity bar of the default path; windows of both kinds in ONE
+    cms_ba_optimize_many call run as separate groups and each gives its own kind's result; switching the mode off restores the default path."""
+    prob = synth.ba_problem(K=12, P=6000, obs_per_point=4, F=550, seed=91, views=views)
+    w = orc.ba_run(prob)
+    assert not api.ba_get_deterministic()
+    api.ba_set_deterministic(True)
+    try:
+        assert api.ba_get_deterministic()
+        runs = [api.ba_run(prob) for _ in range(4)]
+        det = api.BundleAdjuster(prob)
+    finally:
+        api.ba_set_deterministic(False)
+    for g in runs[1:]:
+        assert np.array_equal(g["poses"], runs[0]["poses"]) and np.array_equal(g["points"], runs[0]["points"]) and np.array_equal(g["outliers"], runs[0]["outliers"])
+    g = runs[0]
+    assert list(g["stats"].iterations_done) == list(w["stats"].iterations_done) and np.array_equal(g["outliers"], w["outliers"])
+    _ba_updates_close_or_cascade(prob, g["poses"], g["points"], w, tag="deterministic " + views)
+    # a mixed call: one window created under the mode, one after it was switched off
+    dflt = api.BundleAdjuster(prob)
+    _, stats = api.ba_optimize_many([det, dflt], (5, 10))
+    o_det, o_dflt = det.read(), dflt.read()
+    assert np.array_equal(o_det[0], runs[0]["poses"]) and np.array_equal(o_det[1], runs[0]["points"])      # the deterministic window: the same bits again
+    for st in stats:
+        assert list(st.iterations_done) == list(w["stats"].iterations_done)
+    _ba_updates_close_or_cascade(prob, o_dflt[0], o_dflt[1], w, tag="default next to deterministic " + views)
+    det.close(); dflt.close()
+
+
 def test_c_abi_error_paths():
     """the C-ABI reports misuse with a status code and a message instead of crashing or silently truncating"""
     import ctypes as C
