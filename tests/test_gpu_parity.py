@@ -100,6 +100,31 @@ def test_extract_stage_by_stage_bit_exact(name, F, nfeat, Ih, gaussian_mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,F,nfeat", [("lafida", 450, 2000), ("lafida", 550, 2000), ("lafida", 650, 2000), ("front", 650, 3000)])
+def test_extract_with_the_reference_masks_bit_exact(name, F, nfeat):
+    """The stage-by-stage comparison of test_extract_stage_by_stage_bit_exact with the masks the REFERENCE ships (Masks/gray_lafida_cubemap_mask_
+    {450,550,650}.png, gray_cubemap_front_mask_650.png; committed as data by tests/golden/make_reference_fixtures.py) instead of the
+    model-derived synthetic one: the irregular hand-drawn edge at the cull of ORBExtractor.cpp:887-904, at the face sizes of Config/*.yaml."""
+    import refdata
+    camd, ocam, _ = _cfg(name, F, nfeat)
+    ctx = api.Context(camd, nfeatures=nfeat, max_batch=2)
+    mask = refdata.reference_mask(name, F)
+    ctx.set_mask(mask)
+    m1, m2 = orc.build_lut(ocam)
+    o = orc.Orb(nfeatures=nfeat)
+    frames = np.stack([synth.texture(camd["Ih"], camd["Iw"], 51), synth.texture(camd["Ih"], camd["Iw"], 52)])
+    ctx.upload(frames)
+    ctx.process(2, True)
+    ctx.sync()
+    for b in range(2):
+        cube = orc.fisheye_to_cubemap(ocam, m1, m2, frames[b])
+        n = _compare_frame(ctx, b, o, ocam, cube, mask, "%s/F%d/reference mask/frame%d" % (name, F, b))
+        assert n > 500
+        gk, _ = ctx.fetch(b)
+        assert np.all(mask[(gk["y"] + 0.5).astype(int), (gk["x"] + 0.5).astype(int)] != 0)
+    ctx.close()
+
+
 def test_extract_with_the_sse2_gaussian_definition():
     """cms_set_gaussian_mode(1): descriptors from the float-column Gaussian an x86 OpenCV <= 3.2 computes (ties to even)
     against the oracle in the same mode, bit-exact; key points (which do not depend on the blur) stay what mode 0 gives."""
