@@ -1,6 +1,6 @@
 // CubemapHipBridge.cpp -- see CubemapHipBridge.h.  Compiled inside the reference's tree (OpenCV, Eigen, g2o types); every function gathers
 // what the reference function reads into flat arrays, makes ONE call into libcubemapslam_hip.so and writes the result back through the
-// reference's own setters, in the reference's order.  Not built in this repository (integration/README.md); the same logic over plain
+// reference's own setters, in the reference's order.  Not built in this repository (integration/README.md; syntax-checked by tests/test_integration_syntax.py); the same logic over plain
 // structs is cubemapslam_amd/host/cubemap_hot_path.cpp, which is built and tested here.
 #include "CubemapHipBridge.h"
 

@@ -1,6 +1,6 @@
 // CubemapHipBridge.h -- adapters between the reference's pointer-graph types and the C-ABI of libcubemapslam_hip.so.
 // Written against the reference's real headers (global-namespace Frame / KeyFrame / MapPoint / Map / Converter / CamModelGeneral);
-// NOT compiled in this repository, see integration/README.md.  Each function is the new body of the reference function it names.
+// Not built in this repository (syntax-checked against the reference's headers by tests/test_integration_syntax.py), see integration/README.md.  Each function is the new body of the reference function it names.
 #ifndef CUBEMAP_HIP_BRIDGE_H
 #define CUBEMAP_HIP_BRIDGE_H
 #include <vector>

@@ -1,6 +1,7 @@
 // OrbExtractorHip.h -- drop-in for the reference's include/ORBExtractor.h + src/ORBExtractor.cpp: same class name, constructor,
 // operator(), getters and public members (ORBExtractor.h:55-90), implemented on libcubemapslam_hip.so.
-// NOT compiled in this repository (needs OpenCV); see integration/README.md.
+// Not BUILT in this repository (needs OpenCV); syntax-checked against the reference's real headers by tests/test_integration_syntax.py;
+// see integration/README.md.
 #ifndef ORBEXTRACTOR_H
 #define ORBEXTRACTOR_H
 #include <vector>
@@ -30,7 +31,11 @@ class ORBextractor {
     cv::Mat image = _image.getMat(), mask = _mask.getMat();
     assert(image.type() == CV_8UC1);
     assert(mask.type() == CV_8UC1 && !mask.empty());
-    if (mask.data != last_mask) { cms_set_mask(ctx, mask.data, (int)mask.step); last_mask = mask.data; }   // the mask is the same cv::Mat every frame (Tracking.cpp:131)
+    // The mask is the same cv::Mat every frame (Tracking.cpp:131), so its upload (3F x 3F bytes) is skipped while it is recognisably the same one:
+    // same buffer, geometry AND fingerprint (a few thousand sampled words: a caller that REWRITES the same cv::Mat in place is noticed unless the
+    // change misses every sample -- SetMask / InvalidateMask below are the guaranteed way after an in-place edit).
+    const unsigned long long fp = Fingerprint(mask);
+    if (mask.data != last_mask || mask.rows != last_rows || mask.cols != last_cols || (size_t)mask.step != last_step || fp != last_fp) SetMask(mask);
     std::vector<cms_keypoint> k(kp_cap);
     cv::Mat d(kp_cap, 32, CV_8U);
     int n = 0;
@@ -44,6 +49,14 @@ class ORBextractor {
         cms_debug_level(ctx, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step);
       }
   }
+
+  // upload `mask` now, whatever was cached (call after editing a mask cv::Mat in place); InvalidateMask: the next operator() uploads its mask
+  void SetMask(const cv::Mat& mask) {
+    assert(mask.type() == CV_8UC1 && !mask.empty());
+    cms_set_mask(ctx, mask.data, (int)mask.step);
+    last_mask = mask.data; last_rows = mask.rows; last_cols = mask.cols; last_step = (size_t)mask.step; last_fp = Fingerprint(mask);
+  }
+  void InvalidateMask() { last_mask = nullptr; }
 
   int inline GetLevels() { return nlevels; }
   float inline GetScaleFactor() { return scaleFactor; }
@@ -63,5 +76,19 @@ class ORBextractor {
   std::vector<int> level_w, level_h;
   int kp_cap = 0;
   const unsigned char* last_mask = nullptr;
+  int last_rows = 0, last_cols = 0; size_t last_step = 0; unsigned long long last_fp = 0;
+  // FNV-1a over one 8-byte word in 61 of every 16th row (~10^4 words of a 1650 x 1650 mask: a few microseconds)
+  static unsigned long long Fingerprint(const cv::Mat& m) {
+    unsigned long long h = 1469598103934665603ull;
+    for (int y = 0; y < m.rows; y += 16) {
+      const unsigned char* row = m.data + (size_t)y * (size_t)m.step;
+      for (int x = 0; x + 8 <= m.cols; x += 8 * 61) {
+        unsigned long long w = 0;
+        for (int b = 0; b < 8; ++b) w |= (unsigned long long)row[x + b] << (8 * b);
+        h = (h ^ w) * 1099511628211ull;
+      }
+    }
+    return h;
+  }
 };
 #endif

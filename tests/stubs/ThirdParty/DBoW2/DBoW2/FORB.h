@@ -1,0 +1,1 @@
+#include "dbow2_stub.h"

@@ -1,0 +1,1 @@
+#include "g2o_stub.h"

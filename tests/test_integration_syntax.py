@@ -1,0 +1,43 @@
+"""integration/CubemapHipBridge.cpp + OrbExtractorHip.h are written against the reference's REAL headers (Frame.h, KeyFrame.h, MapPoint.h, Map.h,
+Converter.h, CamModelGeneral.h, ORBMatcher.h) and cannot be built in this image (no OpenCV / Eigen).  This test stops typos from shipping:
+`g++ -fsyntax-only` over the bridge, with the reference's include/ directory as a maintainer would have it after the integration step
+(ORBExtractor.h replaced by OrbExtractorHip.h) and DECLARATIONS-ONLY stand-ins for OpenCV / Eigen / g2o / DBoW2 under tests/stubs/.
+It pins nothing about parity -- no body is compiled into anything, nothing is linked or run.  Skipped where /root/reference is absent."""
+import os
+import shutil
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_INC = "/root/reference/include"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF_INC), reason="the reference checkout only exists in the build container")
+
+
+def _syntax_check(tmp_path, integration_dir):
+    inc = tmp_path / "refinc"
+    inc.mkdir()
+    for f in os.listdir(REF_INC):
+        if f != "ORBExtractor.h":
+            os.symlink(os.path.join(REF_INC, f), inc / f)
+    shutil.copy(os.path.join(integration_dir, "OrbExtractorHip.h"), inc / "ORBExtractor.h")      # integration/README.md: the header the extractor's users include
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "tests", "stubs"), "-I", integration_dir, "-I", os.path.join(ROOT, "include"),
+           "-I", str(inc), os.path.join(integration_dir, "CubemapHipBridge.cpp")]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+
+
+def test_bridge_and_extractor_header_parse_against_the_reference_headers(tmp_path):
+    r = _syntax_check(tmp_path, os.path.join(ROOT, "integration"))
+    assert r.returncode == 0 and "error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_the_check_sees_both_files(tmp_path):
+    """a misspelt C-ABI call in either file must fail the check (i.e. both files are really parsed, with their function bodies)"""
+    for fname, old, new in (("OrbExtractorHip.h", "cms_extract(ctx,", "cms_extrakt(ctx,"), ("CubemapHipBridge.cpp", "cms_area_grid(ctx, 1)", "cms_area_grid(ctx)")):
+        d = tmp_path / ("broken_" + fname.split(".")[0])
+        shutil.copytree(os.path.join(ROOT, "integration"), d)
+        src = (d / fname).read_text()
+        assert old in src
+        (d / fname).write_text(src.replace(old, new, 1))
+        sub = tmp_path / ("t_" + fname.split(".")[0]); sub.mkdir()
+        r = _syntax_check(sub, str(d))
+        assert r.returncode != 0 and "error" in r.stderr, fname
