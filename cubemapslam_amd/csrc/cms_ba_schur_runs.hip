@@ -10,23 +10,32 @@
 // (cms_ba_create) groups the points by signature; a signature with enough points becomes a RUN, cut into chunks of whole points with at
 // most 64 observations; what is left over (rare signatures, the tail of a run) goes through the edge-major kernel as before.
 //
-// A workgroup has four PRODUCER and four CONSUMER wavefronts, paired one to one; every SIMD hosts one of each (two wavefronts per SIMD,
-// different instruction mixes).  A pair walks a contiguous range of run chunks, the consumer one chunk behind the producer:
+// THE DEFAULT BODY is ba_schur_runs_mfma_body (kernel kb_ba_lin_schur_runs), further down: every wavefront walks its own range of chunks (cut by
+// estimated cost over run chunks and left-over chunks alike), lane = observation builds the chunk's rows
 //
-//   producer  lane = observation, exactly the front half of the fused edge-major kernel: residual (bit for bit the one kb_ba_errors / the
-//             trial kernel store), Huber weight, Jacobians; the lanes of a point exchange their 3x3 / 3x1 shares through the chunk's LDS
-//             rows and add them in edge order (Hll, bl: the first lane stores them for the trial kernel); A = Hll + lambda I = L D L^T;
-//             W = B L^-T goes to the lane's row, D^-1 and z = D^-1 L^-1 bl to the point's slot.  The key frame's own block ow Jp^T Jp and
-//             gradient -- 27 sums per lane -- stay in registers for as long as the run lasts: lane (point j, edge a) sees the same key frame
-//             in every chunk of a run.
+//   residual (bit for bit the one kb_ba_errors / the trial kernel store), Huber weight, Jacobians; the lanes of a point add their 3x3 / 3x1
+//   shares (DPP quad permutes for 2 or 4 observations per point, the chunk's LDS rows otherwise) so that every lane holds Hll, bl of its point
+//   (the first lane stores them for the trial kernel); A = Hll + lambda I = L D L^T; W = B L^-T goes to the lane's row, D^-1 and y = L^-1 bl to
+//   the point's slot; the key frame's own block ow Jp^T Jp and gradient -- 27 sums per lane -- stay in registers for as long as the run lasts
+//
+// and then multiplies them on the matrix pipe: with Y = [W_1; ...; W_kf] (6 kf rows, 3 columns per point) all tuple products of the chunk are
+// G = sum_j Y_j D_j^-1 Y_j^T and g = sum_j Y_j D_j^-1 y_j -- v_mfma_f64_16x16x4_f64 tiles whose upper triangle stays in the accumulators for
+// the whole run.  Only when the run ends (or the wavefront's range does) are the sums added to the workgroup's LDS copy of the reduced system:
+// ~36 ds_add_f64 per lane PER RUN instead of ~90 per chunk.  The details (operand tables run_mf / run_fl, the third tile column of signatures
+// with six or seven free key frames, what the wavefront waits for) are in the comment in front of that body.
+//
+// The VECTOR variant (ba_schur_runs_body right below, kernel kb_ba_lin_schur_runs_valu, CMS_BA_RM_VALU=1: round 3's first version, kept for A/B)
+// multiplies on the vector ALU instead.  There a workgroup has four PRODUCER and four CONSUMER wavefronts, paired one to one; every SIMD hosts
+// one of each.  A pair walks a contiguous range of run chunks, the consumer one chunk behind the producer:
+//
+//   producer  the rows as above (through the chunk's LDS rows), the key frame's 27 sums in registers.
 //   consumer  lane = (sequence q, tuple t of the signature): the run's k (k + 1) / 2 pose pairs are spread over the lanes, Q = 64 / tuples
 //             lanes share a pair and take the chunk's points q, q + Q, ...  A lane reads W_a, W_b, D^-1 of its point (21 16-byte LDS reads)
 //             and accumulates W_a D^-1 W_b^T (and W_a z on the diagonal pairs) into 42 registers -- the pair never changes inside a run.
 //
-// Only when the run ends (or the pair's range does) are the sums added to the LDS copy of the reduced system: 36 ds_add_f64 per consumer
-// lane and 33 per producer lane PER RUN instead of ~90 per chunk.  The copy, the write-out of the workgroup's slice and everything behind
-// it (kb_ba_schur_edges_reduce, kb_ba_trial_solve3, kb_ba_trial_edges) are shared with the edge-major kernel: the two bodies are ONE launch
-// (kb_ba_lin_schur_runs: the first R_rm workgroups of a window run this body, the rest the edge-major one on the left-over chunks).
+// Either way the copy, the write-out (one global FP64 addition per element into the window's ONE copy of the reduced system) and everything
+// behind it (kb_ba_trial_solve3r, kb_ba_trial_edges) are shared with the edge-major kernel, and the left-over chunks go through the edge-major
+// chunk loop (ba_se_wave_chunks) inside the same launch.
 // (block_solver.hpp:367-437: Hschur -= Bi Dinv Bj^T, bschur -= Bi Dinv bl; base_binary_edge.hpp:54-120.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -340,11 +349,12 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDevG d, BaSeG se, d
 // (<= 43 columns): the three tiles of the third tile column are summed per CHUNK in temporaries and added to LDS after every chunk (twelve
 // additions per lane and chunk instead of ~90 in the edge-major body; six resident tiles made the kernel spill at two wavefronts per SIMD).
 //
-// What this buys over the vector version: the products leave the vector ALU (which the front half of the kernel keeps busy: residual,
-// Jacobians, 3x3 factorisation, W) for a pipe that was idle, the 84 accumulator registers become 8 .. 48, and the two roles, their hand-over
-// buffers and their barrier per chunk disappear -- a wavefront's matrix phase overlaps its SIMD neighbour's vector phase by itself.
-// The FP64 matrix rate of gfx950 equals its vector rate (78.6 TFLOP/s), and a 24 x 25 product fills 39 % of its three tiles, so the matrix
-// pipe is not where the time goes; it is where the vector ALU's time no longer goes.
+// What this buys over the vector version: the 126 FMAs per tuple leave the instruction stream (3 x 9 matrix instructions per four points
+// instead), the 84 accumulator registers become 8 .. 48, and the two roles, their hand-over buffers and their barrier per chunk disappear.
+// What it does NOT buy (measured in round 4, tools/probe/f64_pipes.hip): pipe time.  On gfx950 the FP64 matrix rate equals the FP64 vector rate
+// (78.6 TFLOP/s) and the two kinds of instruction of one SIMD's wavefronts do not overlap -- the matrix phase of one wavefront and the vector
+// phase of its SIMD neighbour share the pipe.  A 24 x 25 product fills 39 % of its three tiles; vector + matrix instructions occupy ~59 % of
+// a SIMD's time at two wavefronts per SIMD, the rest is dependent LDS round trips and FP64 latency.
 //
 // run_mf[run * 64 + i], i < 48: entry of row / column i of the stacked matrix: offset of W[a][r][0] inside a point's rows (position of edge a
 // x 18 + 3 r), BA_RM_MF_RHS for the right-hand-side column, BA_RM_MF_NONE beyond it; [48 .. 55]: free-pose slot of key frame a; [56]: kf.
