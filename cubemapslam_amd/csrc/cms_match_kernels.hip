@@ -4,8 +4,11 @@
 // runs over the candidate list of a query (ORBMatcher.cpp:84-113, 186-205).  The sequential scan keeps the two
 // smallest distances with "first one wins" on ties, i.e. the first two elements of the candidate list stably sorted
 // by distance.  With the key (distance << 22 | position-in-list) that is simply the two smallest keys, so the scan
-// parallelises: one wavefront per query, lanes stride the candidates (8 x xor + v_bcnt_u32_b32 each), the two
-// smallest keys of the wave are merged with butterfly shuffles.  The greedy assignment loops stay on the host.
+// parallelises: one wavefront per query (lane id from v_mbcnt), lanes stride the candidates (8 x xor + v_bcnt_u32_b32 each), and the two
+// smallest keys of the wave are merged without a trip through LDS memory: DPP quad permutes and row mirrors inside a row of 16 lanes
+// (v_mov_b32 dpp, no LDS pipe at all), one ds_swizzle stage across the two rows of a half (the crossbar only, no bank access), and a
+// v_readlane for the other half -- lane 0 is the only one that needs the answer.  (Round 4 used six __shfl_xor stages = twelve
+// ds_bpermute_b32 per query.)  The greedy assignment loops stay on the host.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -19,7 +22,7 @@ k_hamming_best2(const uint4* __restrict__ qdesc, const int* __restrict__ q_row, 
                 const int* __restrict__ cand_off, const int* __restrict__ cand_idx, const int* __restrict__ tlevel,
                 const uint8_t* __restrict__ texcl, int* __restrict__ best_idx, int* __restrict__ best_dist,
                 int* __restrict__ best_level, int* __restrict__ second_dist, int* __restrict__ second_level) {
-  const int lane = threadIdx.x & 63;
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // lane of the wavefront (workgroups are whole wavefronts)
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= nq) return;
   const size_t qr = q_row ? (size_t)q_row[q] : (size_t)q;   // optional gather: query q lives in row q_row[q]
@@ -34,13 +37,19 @@ k_hamming_best2(const uint4* __restrict__ qdesc, const int* __restrict__ q_row, 
     if (key < k1) { k2 = k1; k1 = key; }
     else if (key < k2) k2 = key;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
-    const uint32_t lo = min(k1, o1), hi = max(k1, o1);
-    k2 = min(hi, min(k2, o2));
-    k1 = lo;
-  }
+  // merge of two (smallest, second smallest) pairs over disjoint lane sets; every stage pairs a group of lanes with a disjoint one, so that
+  // after it both groups hold the merged pair: quads (xor 1, xor 2), the two quads of a half row (mirror of 8), the halves of a row (mirror of
+  // 16), the two rows of a half wave (ds_swizzle xor 16), and finally lane 0 with lane 32
+#define CMS_MERGE2(o1_, o2_) do { const uint32_t a1_ = (o1_), a2_ = (o2_); const uint32_t hi_ = max(k1, a1_); k1 = min(k1, a1_); k2 = min(hi_, min(k2, a2_)); } while (0)
+#define CMS_DPP(v_, ctrl_) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v_), (ctrl_), 0xF, 0xF, false))
+  { const uint32_t o1 = CMS_DPP(k1, 0xB1), o2 = CMS_DPP(k2, 0xB1); CMS_MERGE2(o1, o2); }        // quad_perm [1, 0, 3, 2]
+  { const uint32_t o1 = CMS_DPP(k1, 0x4E), o2 = CMS_DPP(k2, 0x4E); CMS_MERGE2(o1, o2); }        // quad_perm [2, 3, 0, 1]
+  { const uint32_t o1 = CMS_DPP(k1, 0x141), o2 = CMS_DPP(k2, 0x141); CMS_MERGE2(o1, o2); }      // row_half_mirror: lane i <-> 7 - i of its group of eight
+  { const uint32_t o1 = CMS_DPP(k1, 0x140), o2 = CMS_DPP(k2, 0x140); CMS_MERGE2(o1, o2); }      // row_mirror: lane i <-> 15 - i of its row
+  { const uint32_t o1 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)k1, 0x401F), o2 = (uint32_t)__builtin_amdgcn_ds_swizzle((int)k2, 0x401F); CMS_MERGE2(o1, o2); }   // bit mode: and 0x1F, or 0, xor 0x10
+  { const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 32), o2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 32); CMS_MERGE2(o1, o2); }             // (only lanes 0 .. 31 merge something new: lane 0 is read)
+#undef CMS_MERGE2
+#undef CMS_DPP
   if (lane == 0) {
     int bi = -1, bd = 256, bl = -1, sd = 256, sl = -1;
     if (k1 != 0xFFFFFFFFu) {
