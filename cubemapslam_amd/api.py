@@ -653,6 +653,24 @@ class BundleAdjuster:
         _chk(lib().cms_ba_read(self.h, _p(poses), _p(pts), _p(flags)), "cms_ba_read")
         return poses, pts, flags
 
+    def fetch_plan(self):
+        """cms_ba_debug_fetch_plan: the plan arrays as the device holds them (whichever planner made the window)"""
+        P, E = self.P, self.E
+        out = dict(pinv=np.zeros(P, np.int32), perm=np.zeros(E, np.int32), info=np.zeros(E, np.uint32), pt_off=np.zeros(P + 1, np.int32),
+                   e_pose=np.zeros(E, np.int32), e_point=np.zeros(E, np.int32), e_face=np.zeros(E, np.int8), chunk_e0=np.zeros(P + 2, np.int32),
+                   rm_chunk=np.zeros((P, 4), np.int32), rm_cost=np.zeros(P + 2, np.uint32), run_mf=np.zeros((P, 64), np.uint32), run_fl=np.zeros((P, 64, 12), np.uint32))
+        cnt = np.zeros(8, np.int32)
+        L = lib()
+        L.cms_ba_debug_fetch_plan.argtypes = [C.c_void_p] * 14
+        _chk(L.cms_ba_debug_fetch_plan(self.h, _p(out["pinv"]), _p(out["perm"]), _p(out["info"]), _p(out["pt_off"]), _p(out["e_pose"]), _p(out["e_point"]),
+                                       _p(out["e_face"]), _p(out["chunk_e0"]), _p(out["rm_chunk"]), _p(out["rm_cost"]), _p(out["run_mf"]), _p(out["run_fl"]), _p(cnt)),
+             "cms_ba_debug_fetch_plan")
+        nch, n_rm, nr = int(cnt[0]), int(cnt[1]), int(cnt[2])
+        out.update(n_chunks=nch, n_rm=n_rm, n_runs=nr, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), device_planned=bool(cnt[7]))
+        out["chunk_e0"] = out["chunk_e0"][:nch + 1].copy(); out["rm_chunk"] = out["rm_chunk"][:n_rm].copy(); out["rm_cost"] = out["rm_cost"][:nch + 1].copy()
+        out["run_mf"] = out["run_mf"][:nr].copy(); out["run_fl"] = out["run_fl"][:nr].copy()
+        return out
+
     @property
     def stream(self):
         return lib().cms_ba_stream(self.h)
@@ -706,6 +724,19 @@ def ba_plan(fixed, n_points, e_pose, e_point, tables=False):
     nch, n_rm, nruns = int(cnt[0]), int(cnt[1]), int(cnt[2])
     return dict(pinv=pinv, perm=perm, info=info, chunk_pt0=pt0[:nch + 1].copy(), rm_chunk=rmc[:n_rm].copy(), run_lane=rl[:nruns].copy(), n_chunks=nch,
                 run_mf=None if mf is None else mf[:nruns].copy(), run_fl=None if fl is None else fl[:nruns].copy(),
+                n_rm=n_rm, n_runs=nruns, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), usable=bool(cnt[7]))
+
+
+def ba_plan_fast(fixed, n_points, e_pose, e_point):
+    """Host-only: the device-side planner's result for a window (cms_ba_debug_plan_fast); `usable` False when it does not take the window."""
+    fixed = np.ascontiguousarray(fixed, np.uint8); e_pose = np.ascontiguousarray(e_pose, np.int32); e_point = np.ascontiguousarray(e_point, np.int32)
+    P, E = int(n_points), len(e_pose)
+    pinv = np.zeros(P, np.int32); perm = np.zeros(E, np.int32); info = np.zeros(E, np.uint32); pt0 = np.zeros(P + 2, np.int32)
+    rmc = np.zeros((P, 4), np.int32); cnt = np.zeros(8, np.int32); mf = np.zeros((P, 64), np.uint32); fl = np.zeros((P, 64, 12), np.uint32)
+    _chk(lib().cms_ba_debug_plan_fast(len(fixed), _p(fixed), P, E, _p(e_pose), _p(e_point), _p(pinv), _p(perm), _p(info), _p(pt0), _p(rmc), _p(cnt), _p(mf), _p(fl)),
+         "cms_ba_debug_plan_fast")
+    nch, n_rm, nruns = int(cnt[0]), int(cnt[1]), int(cnt[2])
+    return dict(pinv=pinv, perm=perm, info=info, chunk_pt0=pt0[:nch + 1].copy(), rm_chunk=rmc[:n_rm].copy(), n_chunks=nch, run_mf=mf[:nruns].copy(), run_fl=fl[:nruns].copy(),
                 n_rm=n_rm, n_runs=nruns, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), usable=bool(cnt[7]))
 
 

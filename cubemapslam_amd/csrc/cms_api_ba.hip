@@ -108,6 +108,9 @@ struct cms_ba {
   // kernel ids 1 lin, 2 maxdiag, 3 the Schur kernel of the path in use (kb_ba_lin_schur_edges by default), 4 its range reduction, 5 the trial solve,
   // 6 the trial kernel (kb_ba_trial_edges), 7 reduce2
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
+  bool fast_plan = false;    // planned by ba_plan_fast (cms_api_ba_plan.hip): the permutations and the per-edge arrays exist on the device only
+  int* d_raw_pose = nullptr; int* d_raw_point = nullptr; int8_t* d_raw_face = nullptr; int* d_prank = nullptr; int* d_cpo = nullptr; int* d_cedge = nullptr;
+  uint8_t* d_pcopy = nullptr; uint64_t* d_run_sig = nullptr; double* d_rb_pts = nullptr; uint8_t* d_rb_flags = nullptr;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
   hipStream_t grp_stream = nullptr;   // the stream of the group whose rounds may still be in flight for this window (ba_optimize_group; cleared at its successful end)
@@ -370,6 +373,7 @@ extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
 static std::atomic<int>& ba_det_mode() { static std::atomic<int> m{ba_knobs().deterministic ? 1 : 0}; return m; }
 extern "C" int cms_ba_set_deterministic(int on) { ba_det_mode().store(on ? 1 : 0); return CMS_OK; }
 extern "C" int cms_ba_get_deterministic(void) { return ba_det_mode().load(); }
+static thread_local bool ba_tl_force_host_plan = false;      // cms_ba_linearize: the host plan for the window this thread creates next
 static std::atomic<int> ba_plans_in_flight{0};      // windows being planned right now (cms_ba_create / cms_ba_debug_plan calls of all host threads)
 // lanes of one group of 16 -> LDS banks, every lane with four candidate banks: augmenting-path matching, the rest on their least-used bank
 struct BaDiagMatch {
@@ -637,6 +641,22 @@ static void ba_se_split(BaSe& se, int Rtotal) {
   se.R_rm = R_rm;
 }
 
+// sizes that follow from the window's dimensions alone (both planners)
+static void ba_plan_sizes(cms_ba* b, int K, int P, int E, int np) {
+  b->np = np;
+  const int n = 6 * np;
+  b->nblk_e = (E + 255) / 256; b->nblk_p = (P + 127) / 128;
+  b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
+  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
+  b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 3 * (size_t)n + 8) * sizeof(double);
+  b->solve_blk3 = b->solve_blk && 3 * (np * (np + 1) / 2) <= 1024 && b->blk3_lds <= BA_LDS_CEILING;
+}
+// LDS of the edge-major / run-major Schur kernels without the per-wavefront part: the copy of the reduced system + the key frames' rotations
+static size_t ba_se_fixed_lds(int K, int np) {
+  const int NP2 = np * (np + 1) / 2;
+  return ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)K * 12) * sizeof(double);
+}
+
 // ---- everything cms_ba_create decides on the host (no device needed: cms_ba_debug_plan runs it alone) -- the internal point order (signature
 // runs first, then the composed left-over chunks), the sorted edge arrays and the work lists of the edge-major / run-major Schur kernels
 struct BaPlan {
@@ -678,17 +698,12 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   pose_slot.assign(K, -1);
   int np = 0;
   for (int k = 0; k < K; ++k) if (!fixed[k]) pose_slot[k] = np++;
-  b->np = np;
+  ba_plan_sizes(b, K, P, E, np);
   const int n = 6 * np;
-  b->nblk_e = (E + 255) / 256; b->nblk_p = (P + 127) / 128;
-  b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
-  b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
-  b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 3 * (size_t)n + 8) * sizeof(double);
-  b->solve_blk3 = b->solve_blk && 3 * (np * (np + 1) / 2) <= 1024 && b->blk3_lds <= BA_LDS_CEILING;
   // ---- can this window run the edge-major / run-major kernels at all?  (LDS copy of the reduced system, <= 31 observations per point, no
   // point seen twice by one key frame: the pair-owner kernel handles those)
   const int NP2 = np * (np + 1) / 2;
-  const size_t se_fixed_lds = ((size_t)(((NP2 - np) * BA_SE_SSTRIDE + 1) & ~1) + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE + (size_t)K * 12) * sizeof(double);
+  const size_t se_fixed_lds = ba_se_fixed_lds(K, np);
   const size_t se_wave_lds = (size_t)64 * 18 * sizeof(double) + 64 * sizeof(int);
   int se_nw = BA_SE_THREADS / 64;
   while (se_nw > 2 && se_fixed_lds + se_nw * se_wave_lds > BA_LDS_CEILING) se_nw -= 2;
@@ -817,7 +832,10 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
       // with eight or more observations, the expensive ones to place.  Measured on 16 windows per launch: look-ahead 8 / 4 / 2 / none = 108.0 /
       // 104.9 / 114.4 / 116.6 us for the Schur kernel, and the composition is the largest single item of cms_ba_create's ~5 ms of CPU time -- a host
       // that builds 32 windows per 14 ms step inside a 16-CPU quota runs out of CPU first.  CMS_BA_LEFTOVER_LOOKAHEAD=n forces a look-ahead.)
-      const int la_left = kn.no_permute ? 1 : kn.leftover_lookahead > 0 ? kn.leftover_lookahead : std::max(2, kn.lookahead / (3 * PL <= P ? 6 : 3));
+      // Round 5: when the left-over points are a minority (<= a third of the window) they keep the caller's order -- look-ahead 1 / 4 / 8 measured
+      // 88.7 / 89.6 / 86.9 us for the Schur launch (profiles/r04_experiments.txt): what the kernel needs is the matching of the diagonal copies per
+      // group of 16 lanes, which every look-ahead keeps -- and the device-side planner (cms_api_ba_plan.hip) produces the very same chunks.
+      const int la_left = kn.no_permute ? 1 : kn.leftover_lookahead > 0 ? kn.leftover_lookahead : (3 * PL <= P ? 1 : std::max(2, kn.lookahead / 3));
       ba_compose_chunks(K, fixed, PL, (int)ep.size(), ep.data(), ept.data(), la_left, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
     }
   } else {
@@ -1022,6 +1040,8 @@ extern "C" int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, cons
   return CMS_OK;
 }
 
+#include "cms_api_ba_plan.hip"
+
 // edge i of the internal order is the caller's edge perm[i], point i the caller's point pinv[i]: measurements, informations and initial positions
 // into that order (cms_ba_create uploads the caller's arrays untouched) -- and, in the same launch, what k_ba_reset does for a window that
 // starts its life: current estimate = initial estimate, per-edge state and the global copy of the reduced system cleared
@@ -1056,9 +1076,6 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return cms_fail(CMS_ERR_NO_DEVICE, "no HIP device: the product path has no CPU fallback");
-  for (int e = 0; e < E; ++e)
-    if (e_pose[e] < 0 || e_pose[e] >= K || e_point[e] < 0 || e_point[e] >= P || e_face[e] < 0 || e_face[e] > 4)
-      return cms_fail(CMS_ERR_ARG, "cms_ba_create: edge index / face out of range (unknown-face edges must be culled by the caller)");
   HIPCHK(hipSetDevice(device));
   cms_ba* b = new cms_ba;
   b->device = device; b->K = K; b->P = P; b->E = E;
@@ -1092,11 +1109,27 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   const BaKnobs& kn = ba_knobs();
   static thread_local BaPlan tl_pl;            // (keeps its vectors' capacity for the next window this host thread builds)
   BaPlan& pl = tl_pl;
-  ba_plan(b, pl, K, fixed, P, E, e_pose, e_point, e_obs, e_invsig2, e_face, tick);
+  static thread_local BaFastPlan tl_fp;
+  BaFastPlan& fp = tl_fp;
+  // the device-side planner for the windows it takes (cms_api_ba_plan.hip: one pass over the observations on the host, the rest per point);
+  // it validates the indices in that pass.  Everything else: the host plan, after the validation loop
+  const int fast_rc = ba_tl_force_host_plan ? 0 : ba_plan_fast(b, fp, K, fixed, P, E, e_pose, e_point, e_face, tick);
+  const bool fast = fast_rc > 0;
+  bool bad_index = fast_rc < 0;
+  if (!fast && !bad_index)
+    for (int e = 0; e < E && !bad_index; ++e)
+      bad_index = e_pose[e] < 0 || e_pose[e] >= K || e_point[e] < 0 || e_point[e] >= P || e_face[e] < 0 || e_face[e] > 4;
+  if (bad_index) {
+    cms_ba_destroy(b);
+    return cms_fail(CMS_ERR_ARG, "cms_ba_create: edge index / face out of range (unknown-face edges must be culled by the caller)");
+  }
+  b->fast_plan = fast;
+  if (fast) pl.pose_slot = fp.pose_slot;
+  else ba_plan(b, pl, K, fixed, P, E, e_pose, e_point, e_obs, e_invsig2, e_face, tick);
   std::vector<int>&pose_slot = pl.pose_slot, &prank = pl.prank, &s_pose = pl.s_pose, &s_point = pl.s_point, &pt_off = pl.pt_off, &pose_off = pl.pose_off, &pose_edges = pl.pose_edges;
   std::vector<double>&s_obs = pl.s_obs, &s_inv = pl.s_inv;
   std::vector<int8_t>& s_face = pl.s_face;
-  const bool se_built = pl.se_built;
+  const bool se_built = fast || pl.se_built;
   const int np = b->np, n = 6 * np;
   // ---- everything the window uploads goes through ONE pinned block and ONE asynchronous copy on the window's stream (a dozen synchronous
   // hipMemcpy calls from pageable memory were 0.3 ms of a 2 ms set-up and serialised the host threads that build windows side by side)
@@ -1108,6 +1141,16 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)BA_SE_RANGES * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)BA_SE_RANGES * np * 6));
     BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42));
     b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial;
+  }
+  if (fast) {
+    up(fp.ce0.data(), fp.ce0.size() * sizeof(int), &b->d_se_chunk_e0); up(fp.pob.data(), fp.pob.size() * sizeof(int), &b->d_se_pob);
+    up(fp.ident.data(), fp.ident.size() * sizeof(int), &b->d_se_chunk_off); up(fp.lone.data(), fp.lone.size() * sizeof(int), &b->d_se_lone);
+    up(fp.rm_chunk.data(), fp.rm_chunk.size() * sizeof(int4), &b->d_rm_chunk); up(fp.rm_cost.data(), fp.rm_cost.size() * sizeof(uint32_t), &b->d_rm_cost);
+    up(fp.run_sig.data(), fp.run_sig.size() * sizeof(uint64_t), &b->d_run_sig);
+    // what the expansion kernels write: the per-edge words and the runs' tables (run_lane: the vector variant's table, never read on this path)
+    BA_TRY(ba_alloc(b, &b->d_se_info, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_run_mf, (size_t)std::max(fp.n_runs, 1) * 64));
+    BA_TRY(ba_alloc(b, &b->d_run_fl, (size_t)std::max(fp.n_runs, 1) * 64 * 12)); BA_TRY(ba_alloc(b, &b->d_run_lane, 1));
+  } else if (se_built) {
     up(pl.ce0.data(), pl.ce0.size() * sizeof(int), &b->d_se_chunk_e0); up(pl.info.data(), pl.info.size() * sizeof(uint32_t), &b->d_se_info);
     up(pl.pob.data(), pl.pob.size() * sizeof(int), &b->d_se_pob); up(pl.ident.data(), pl.ident.size() * sizeof(int), &b->d_se_chunk_off);
     up(pl.lone.data(), pl.lone.size() * sizeof(int), &b->d_se_lone);
@@ -1120,7 +1163,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   // it into a group of its own kind): the pair-owner and tuple-chunk kernels' work lists (co-visibility tuples: ~10 per point, 2.4 ms of
   // host time at 80 k edges) and the stored 6x3 blocks (144 B per edge) are then never touched and are not built.  The A/B switches that
   // select those kernels bring them back.
-  b->se_only = se_built && b->solve_blk && !kn.want_all_lists && !b->deterministic;
+  b->se_only = fast || (se_built && b->solve_blk && !kn.want_all_lists && !b->deterministic);
   if (!b->se_only) BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2
   if (!b->se_only) {
@@ -1305,12 +1348,28 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   // two permutations; k_ba_gather puts them into the internal edge / point order on the device.  On the host those three gathers were four
   // random cache lines per point over arrays no other window shares: 1.2 of cms_ba_create's 2.8 ms alone and 2.0-2.7 of ~5 ms when 32 host
   // threads build windows side by side (memory bound) -- the part a host inside a CPU quota could least afford.
-  up(fixed, K, &b->d_fixed); up(pose_slot.data(), K * sizeof(int), &b->d_pose_slot); up(s_pose.data(), E * sizeof(int), &b->d_e_pose);
-  up(s_point.data(), E * sizeof(int), &b->d_e_point); up(e_obs, 2 * (size_t)E * sizeof(double), &b->d_raw_obs);
-  up(e_invsig2, E * sizeof(double), &b->d_raw_inv); up(s_face.data(), E, &b->d_e_face); up(pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off);
-  up(pose_off.data(), (K + 1) * sizeof(int), &b->d_pose_off); up(pose_edges.data(), E * sizeof(int), &b->d_pose_edges);
+  up(fixed, K, &b->d_fixed); up(pose_slot.data(), K * sizeof(int), &b->d_pose_slot);
+  up(e_obs, 2 * (size_t)E * sizeof(double), &b->d_raw_obs); up(e_invsig2, E * sizeof(double), &b->d_raw_inv);
   up(p0.data(), 7 * (size_t)K * sizeof(double), &b->d_poses0); up(points, 3 * (size_t)P * sizeof(double), &b->d_raw_pts);
-  up(b->perm.data(), E * sizeof(int), &b->d_perm); up(b->pinv.data(), P * sizeof(int), &b->d_pinv);
+  std::vector<int> zero_off;
+  if (fast) {
+    // the caller's index arrays as they are; sorted edge arrays, per-edge words and the edge permutation are written by k_ba_expand_edges
+    up(e_pose, E * sizeof(int), &b->d_raw_pose); up(e_point, E * sizeof(int), &b->d_raw_point); up(e_face, E, &b->d_raw_face);
+    up(fp.pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off); up(fp.prank.data(), P * sizeof(int), &b->d_prank); up(fp.pinv.data(), P * sizeof(int), &b->d_pinv);
+    up(fp.cpo.data(), (P + 1) * sizeof(int), &b->d_cpo); up(fp.pcopy.data(), P, &b->d_pcopy);
+    if (!fp.grouped) up(fp.cedge.data(), E * sizeof(int), &b->d_cedge);
+    // (the per-key-frame edge lists serve kb_ba_lin, which a group of such windows never launches: an empty CSR)
+    zero_off.assign(K + 1, 0);
+    up(zero_off.data(), (K + 1) * sizeof(int), &b->d_pose_off);
+    BA_TRY(ba_alloc(b, &b->d_e_pose, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_point, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_face, (size_t)E));
+    BA_TRY(ba_alloc(b, &b->d_perm, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_pose_edges, 1));
+    BA_TRY(ba_alloc(b, &b->d_rb_pts, 3 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_rb_flags, (size_t)E));
+  } else {
+    up(s_pose.data(), E * sizeof(int), &b->d_e_pose); up(s_point.data(), E * sizeof(int), &b->d_e_point);
+    up(s_face.data(), E, &b->d_e_face); up(pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off);
+    up(pose_off.data(), (K + 1) * sizeof(int), &b->d_pose_off); up(pose_edges.data(), E * sizeof(int), &b->d_pose_edges);
+    up(b->perm.data(), E * sizeof(int), &b->d_perm); up(b->pinv.data(), P * sizeof(int), &b->d_pinv);
+  }
   BA_TRY(ba_alloc(b, &b->d_e_obs, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_inv, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_pts0, 3 * (size_t)P));
   // ---- buffers the device only writes / works in
   BA_TRY(ba_alloc(b, &b->d_level, E)); BA_TRY(ba_alloc(b, &b->d_err, 2 * (size_t)E)); BA_TRY(ba_alloc(b, &b->d_ow, (size_t)E));
@@ -1353,6 +1412,20 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   }
   tick("uploads");
   b->cur = 0;
+  if (fast) {
+    BaExpand x;
+    x.K = K; x.P = P; x.E = E; x.np = np;
+    x.e_pose = b->d_raw_pose; x.e_point = b->d_raw_point; x.e_face = b->d_raw_face; x.cedge = fp.grouped ? nullptr : b->d_cedge; x.cpo = b->d_cpo;
+    x.prank = b->d_prank; x.pinv = b->d_pinv; x.pt_off = b->d_pt_off; x.pcopy = b->d_pcopy; x.pose_slot = b->d_pose_slot;
+    x.raw_obs = b->d_raw_obs; x.raw_inv = b->d_raw_inv; x.raw_pts = b->d_raw_pts; x.poses0 = b->d_poses0;
+    x.perm = b->d_perm; x.s_pose = b->d_e_pose; x.s_point = b->d_e_point; x.s_face = b->d_e_face; x.info = b->d_se_info;
+    x.e_obs = b->d_e_obs; x.e_inv = b->d_e_inv; x.pts0 = b->d_pts0; x.poses = b->d_poses[0]; x.pts = b->d_pts[0]; x.level = b->d_level; x.err = b->d_err; x.flags = b->d_flags;
+    x.gsum = b->d_se_partial; x.n_gsum = b->se.npairs2 * 42; x.gsum_bp = b->d_se_bp_partial; x.n_gsum_bp = b->np * 6;
+    x.ce0 = b->d_se_chunk_e0; x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl;
+    hipLaunchKernelGGL(k_ba_expand_edges, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, x);
+    const int n_tab = 4 * (fp.nchunks - fp.n_rm) + 64 * fp.n_runs;
+    if (n_tab > 0) hipLaunchKernelGGL(k_ba_expand_tables, dim3((n_tab + 63) / 64), dim3(64), 0, b->stream, x);
+  } else
   hipLaunchKernelGGL(k_ba_gather, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, K, P, E, (const int*)b->d_perm, (const int*)b->d_pinv,
                      (const double*)b->d_raw_obs, (const double*)b->d_raw_inv, (const double*)b->d_raw_pts, b->d_e_obs, b->d_e_inv, b->d_pts0,
                      (const double*)b->d_poses0, b->d_poses[0], b->d_pts[0], b->d_level, b->d_err, b->d_flags,
@@ -1364,6 +1437,38 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   if (timing) fprintf(stderr, "[cms_ba_create] K %d P %d E %d ms:%s\n", K, P, E, t_log.c_str());
   *out = b;
   return CMS_OK;
+}
+
+// developer / test entry: the plan arrays AS THE DEVICE HOLDS THEM (after the window's set-up has run), whichever planner made them -- for the
+// comparison of the device-side planner with cms_ba_debug_plan.  Sizes: pinv P, perm E, info E, pt_off P + 1, e_pose / e_point E, e_face E,
+// chunk_e0 chunks + 1 (<= P + 2), rm_chunk 4 ints per run chunk, rm_cost chunks + 1, run_mf 64 / run_fl 768 words per run; any pointer may be NULL.
+// counts[8] = chunks, run chunks, runs, free key frames, points inside runs, R_rm, R, 1 if the device-side planner made the window.
+extern "C" int cms_ba_debug_fetch_plan(cms_ba* b, int* pinv, int* perm, uint32_t* info, int* pt_off, int* e_pose, int* e_point, int8_t* e_face, int* chunk_e0,
+                                       int* rm_chunk, uint32_t* rm_cost, uint32_t* run_mf, uint32_t* run_fl, int* counts) {
+  if (!b || !counts) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_fetch_plan: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->async_pending = false;
+  const int nch = b->se.nchunks, n_rm = b->se.n_rm, nr = b->n_runs;
+  counts[0] = nch; counts[1] = n_rm; counts[2] = nr; counts[3] = b->np; counts[4] = b->rm_points; counts[5] = b->se.R_rm; counts[6] = b->se.R; counts[7] = b->fast_plan ? 1 : 0;
+  auto dl = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (!dst || !src || bytes == 0) return CMS_OK;
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : cms_fail(CMS_ERR_HIP, "cms_ba_debug_fetch_plan: copy");
+  };
+  int rc = CMS_OK;
+  if (!rc) rc = dl(pinv, b->d_pinv, (size_t)b->P * 4);
+  if (!rc) rc = dl(perm, b->d_perm, (size_t)b->E * 4);
+  if (!rc && nch > 0) rc = dl(info, b->d_se_info, (size_t)b->E * 4);
+  if (!rc) rc = dl(pt_off, b->d_pt_off, ((size_t)b->P + 1) * 4);
+  if (!rc) rc = dl(e_pose, b->d_e_pose, (size_t)b->E * 4);
+  if (!rc) rc = dl(e_point, b->d_e_point, (size_t)b->E * 4);
+  if (!rc) rc = dl(e_face, b->d_e_face, (size_t)b->E);
+  if (!rc && nch > 0) rc = dl(chunk_e0, b->d_se_chunk_e0, ((size_t)nch + 1) * 4);
+  if (!rc && n_rm > 0) rc = dl(rm_chunk, b->d_rm_chunk, (size_t)n_rm * 16);
+  if (!rc && nch > 0) rc = dl(rm_cost, b->d_rm_cost, ((size_t)nch + 1) * 4);
+  if (!rc && nr > 0) rc = dl(run_mf, b->d_run_mf, (size_t)nr * 64 * 4);
+  if (!rc && nr > 0) rc = dl(run_fl, b->d_run_fl, (size_t)nr * 64 * 12 * 4);
+  return rc;
 }
 
 // restore the initial estimate and clear the per-edge state: one launch (five copies / memsets cost more in dispatch than in work)
@@ -1426,19 +1531,28 @@ extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* ou
     temp = true;
   }
   hipError_t re = hipSuccess;
+  const double* src_pts = b->d_pts[b->cur]; const uint8_t* src_flags = b->d_flags;
+  if (b->fast_plan && (points || outlier_flags)) {      // the permutations live on the device: points and flags are put into the caller's order there
+    hipLaunchKernelGGL(k_ba_unpermute, dim3(std::min((std::max(b->E, b->P) + 255) / 256, 512)), dim3(256), 0, rs, b->P, b->E, (const int*)b->d_pinv, (const int*)b->d_perm,
+                       (const double*)b->d_pts[b->cur], (const uint8_t*)b->d_flags, points ? b->d_rb_pts : nullptr, outlier_flags ? b->d_rb_flags : nullptr);
+    re = hipGetLastError();
+    src_pts = b->d_rb_pts; src_flags = b->d_rb_flags;
+  }
   if (poses && re == hipSuccess) re = hipMemcpyAsync(h + o_pose, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost, rs);
-  if (points && re == hipSuccess) re = hipMemcpyAsync(h + o_pts, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, rs);
-  if (outlier_flags && re == hipSuccess) re = hipMemcpyAsync(h + o_flags, b->d_flags, b->E, hipMemcpyDeviceToHost, rs);
+  if (points && re == hipSuccess) re = hipMemcpyAsync(h + o_pts, src_pts, 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, rs);
+  if (outlier_flags && re == hipSuccess) re = hipMemcpyAsync(h + o_flags, src_flags, b->E, hipMemcpyDeviceToHost, rs);
   if (re == hipSuccess) re = ba_wait_stream(rs);
   if (temp) ba_stream_give(b->device, rs);
   HIPCHK(re);
   b->async_pending = false;
   if (poses) memcpy(poses, h + o_pose, 7 * (size_t)b->K * sizeof(double));
-  if (points) {
+  if (points && b->fast_plan) memcpy(points, h + o_pts, 3 * (size_t)b->P * sizeof(double));
+  else if (points) {
     const double* pin = reinterpret_cast<const double*>(h + o_pts);
     for (int i = 0; i < b->P; ++i) for (int j = 0; j < 3; ++j) points[3 * (size_t)b->pinv[i] + j] = pin[3 * (size_t)i + j];
   }
-  if (outlier_flags) {
+  if (outlier_flags && b->fast_plan) memcpy(outlier_flags, h + o_flags, (size_t)b->E);
+  else if (outlier_flags) {
     const uint8_t* f = reinterpret_cast<const uint8_t*>(h + o_flags);
     for (int i = 0; i < b->E; ++i) outlier_flags[b->perm[i]] = f[i];
   }
@@ -1465,7 +1579,9 @@ extern "C" int cms_ba_linearize(int device, int K, const double* poses, const ui
                                 const int8_t* e_face, double fx, double fy, double cx, double cy, int robust, double huber_delta,
                                 double* err, double* Hpp, double* bp, double* Hll, double* bl, double* Hpl, double* robust_chi2_sum) {
   cms_ba* b = nullptr;
+  ba_tl_force_host_plan = true;      // (this entry reports in the caller's order through the host-side permutations, and launches the per-key-frame linearisation)
   int rc = cms_ba_create(&b, device, K, poses, fixed, P, points, E, e_pose, e_point, e_obs, e_invsig2, e_face, fx, fy, cx, cy);
+  ba_tl_force_host_plan = false;
   if (rc) return rc;
   if (!b->d_Hpl) {      // the window carries only the edge-major work list: the stored-block buffer this entry reports is allocated here
     rc = ba_alloc(b, &b->d_Hpl, 18 * (size_t)E);

@@ -597,7 +597,8 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
 extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats) {
   if (!bas || n < 1) return cms_fail(CMS_ERR_ARG, "cms_ba_optimize_many: bad argument");
   for (int w = 0; w < n; ++w) if (!bas[w]) return cms_fail(CMS_ERR_ARG, "null ba");
-  auto kind = [&](int w) { return bas[w]->device * 4 + (bas[w]->se.nchunks > 0 ? 2 : 0) + (bas[w]->deterministic ? 1 : 0); };
+  // (device-planned windows among themselves: their groups always run the fused kernels, which is all they carry lists for)
+  auto kind = [&](int w) { return bas[w]->device * 8 + (bas[w]->fast_plan ? 4 : 0) + (bas[w]->se.nchunks > 0 ? 2 : 0) + (bas[w]->deterministic ? 1 : 0); };
   bool one = n <= BA_MAX_GROUP;
   for (int w = 1; w < n && one; ++w) one = kind(w) == kind(0);
   if (one) return ba_optimize_group(bas, n, its_robust, its_final, stop, stats);

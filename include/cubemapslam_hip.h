@@ -204,6 +204,19 @@ int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, const int* e
  * reference: the graph is what Optimizer::LocalBundleAdjustment hands to g2o (Optimizer.cpp:192-363). */
 int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int* pinv, int* perm, uint32_t* info,
                       int* chunk_pt0, int* rm_chunk, uint32_t* run_lane, int* counts, uint32_t* run_mf, uint32_t* run_fl);
+/* developer / test aid: the plan arrays as the DEVICE holds them for this window (after its set-up ran), whichever planner made them.  Since round 5
+ * cms_ba_create plans most windows with one sequential pass over the observations on the host and per-point work only; the observation-sized
+ * arrays (edge permutation, sorted edge arrays, per-edge words, diagonal copies, the runs' tables) are written by kernels
+ * (cubemapslam_amd/csrc/cms_api_ba_plan.hip).  For the windows both planners take they give the same arrays: this entry is how the tests
+ * compare them with cms_ba_debug_plan.  Sizes: pinv P, perm E, info E, pt_off P + 1, e_pose / e_point / e_face E, chunk_e0 chunks + 1, rm_chunk
+ * 4 ints per run chunk, rm_cost chunks + 1, run_mf 64 / run_fl 768 words per run (any may be NULL); counts[8] as cms_ba_debug_plan's, with
+ * counts[7] = 1 if the device-side planner made the window.  CMS_BA_HOST_PLAN=1 selects the host planner for every window (A/B). */
+int cms_ba_debug_fetch_plan(cms_ba* ba, int* pinv, int* perm, uint32_t* info, int* pt_off, int* e_pose, int* e_point, int8_t* e_face, int* chunk_e0,
+                            int* rm_chunk, uint32_t* rm_cost, uint32_t* run_mf, uint32_t* run_fl, int* counts);
+/* ... and the same planner run entirely on the host (no device needed; the expansion kernels' bodies over host arrays): outputs as cms_ba_debug_plan's
+ * (run_lane excepted); counts[7] = 0 when the window is not one the device-side planner takes (cms_ba_create then uses the host planner). */
+int cms_ba_debug_plan_fast(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int* pinv, int* perm, uint32_t* info,
+                           int* chunk_pt0, int* rm_chunk, int* counts, uint32_t* run_mf, uint32_t* run_fl);
 void cms_ba_destroy(cms_ba* ba);
 /* Device slabs and pinned blocks of destroyed windows wait in a per-device pool for the next window (CMS_BA_POOL_MB bounds the device part, default
  * 16384; the pool is also emptied and the allocation retried when hipMalloc fails).  cms_ba_pool_trim hands everything cached for `device` back

@@ -1168,7 +1168,7 @@ def test_kfstore_fuse_search_matches_oracle():
 @pytest.mark.parametrize("knob", ["CMS_BA_NO_FUSED_LIN", "CMS_BA_DETERMINISTIC", "CMS_BA_NO_PERMUTE", "CMS_BA_NO_RUNS", "CMS_BA_RUNS_AS_EDGES",
                                   "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU", "CMS_BA_SOLVE_REDUCE_MAX=1000",
                                   "CMS_BA_SPLIT_WORKGROUPS", "CMS_BA_SEPARATE_REDUCE2", "CMS_BA_SEPARATE_FIRST_PASS", "CMS_BA_TE_CHUNKS=1", "CMS_BA_TE_CHUNKS=5",
-                                  "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT"])
+                                  "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT", "CMS_BA_HOST_PLAN", "CMS_BA_LEFTOVER_LOOKAHEAD=4"])
 def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     """The grouped local-BA driver has several Schur paths -- signature runs multiplied in MFMA tiles + edge-major left-overs, linearisation
     fused (default); the runs' products on the vector ALU by producer / consumer wavefront pairs (CMS_BA_RM_VALU); every point edge-major
@@ -1178,7 +1178,8 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     range slices each, i.e. 11 or more windows per group; CMS_BA_SOLVE_REDUCE_MAX=1000: always) or as its own launch (CMS_BA_SEPARATE_REDUCE).
     Round 4's alternatives: separate workgroups for run chunks and left-over chunks instead of cost-balanced ranges over both
     (CMS_BA_SPLIT_WORKGROUPS), kb_ba_reduce2 / the four first-iteration launches instead of their folded forms (CMS_BA_SEPARATE_REDUCE2,
-    CMS_BA_SEPARATE_FIRST_PASS), one or five chunks per wavefront of the trial kernel, the window descriptions through a copy engine, sleeping host waits.  The
+    CMS_BA_SEPARATE_FIRST_PASS), one or five chunks per wavefront of the trial kernel, the window descriptions through a copy engine, sleeping host waits.
+    Round 5: the host planner for every window instead of the device-side one (CMS_BA_HOST_PLAN), and round 4's look-ahead for the left-over points.  The
     knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""
     import os, subprocess, sys
     env = dict(os.environ)
@@ -1187,6 +1188,44 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
                         "config4_size_eight or stop_flag_raised or mixed_sizes or tracked_windows"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_ba_device_plan_equals_host_plan(shuffle):
+    """cms_ba_create plans a tracked window with one host pass over the observations + per-point work and lets kernels write the observation-sized
+    arrays (cms_api_ba_plan.hip).  What the device then holds -- point and edge permutations, sorted edge arrays, per-edge words with the matched
+    diagonal copies, chunk descriptors, the runs' MFMA tables -- must be what the host planner (cms_ba_debug_plan) computes, byte for byte; it must
+    be a valid partition (every observation once, runs homogeneous, chunks <= 64); and the results come back in the caller's order.  `shuffle`: the
+    caller's edges in arbitrary order, as the reference's std::map<KeyFrame*, size_t> iteration gives them (Optimizer.cpp:263-300)."""
+    prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=64, views="track")
+    if shuffle:
+        o = np.random.default_rng(3).permutation(len(prob["e_pose"]))
+        prob = dict(prob, **{k: np.ascontiguousarray(prob[k][o]) for k in ("e_pose", "e_point", "e_obs", "e_invsig2", "e_face")})
+    P, E = len(prob["points"]), len(prob["e_pose"])
+    ba = api.BundleAdjuster(prob)
+    d = ba.fetch_plan()
+    assert d["device_planned"]
+    h = api.ba_plan(prob["fixed"], P, prob["e_pose"], prob["e_point"], tables=True)
+    for k in ("n_chunks", "n_rm", "n_runs", "np", "rm_points"):
+        assert d[k] == h[k], (k, d[k], h[k])
+    for k in ("pinv", "perm", "info", "rm_chunk", "run_mf", "run_fl"):
+        assert d[k].shape == h[k].shape and np.array_equal(d[k], h[k]), k
+    # a valid partition, from the device arrays alone
+    assert np.array_equal(np.sort(d["perm"]), np.arange(E)) and np.array_equal(np.sort(d["pinv"]), np.arange(P))
+    prank = np.empty(P, np.int64); prank[d["pinv"]] = np.arange(P)
+    assert np.array_equal(d["e_pose"], prob["e_pose"][d["perm"]]) and np.array_equal(d["e_point"], prank[prob["e_point"][d["perm"]]]) and np.array_equal(d["e_face"], prob["e_face"][d["perm"]])
+    assert np.all(np.diff(d["e_point"]) >= 0) and np.array_equal(d["pt_off"], np.searchsorted(d["e_point"], np.arange(P + 1)))
+    assert np.array_equal(d["chunk_e0"], d["pt_off"][h["chunk_pt0"]]) and np.all(np.diff(d["chunk_e0"]) <= 64) and d["chunk_e0"][-1] == E
+    for c in range(d["n_rm"]):                                   # a run chunk: whole points of one signature
+        e0, word, run, p0 = (int(v) for v in d["rm_chunk"][c])
+        ne, k, m = word & 255, (word >> 8) & 255, word >> 16
+        poses = d["e_pose"][e0:e0 + ne].reshape(m, k)
+        assert ne == k * m and np.all(poses == poses[0]), c
+    assert np.all(np.diff(d["rm_cost"].astype(np.int64)) > 0)
+    # ... and the window optimises to the oracle's result, reported in the caller's order
+    _, st = ba.optimize()
+    _check_window(0, ba, prob, st, tag="device plan" + (" (shuffled edges)" if shuffle else ""))
+    ba.close()
 
 
 def _check_window(i, ba, p, st, w=None, tag="window"):
