@@ -563,6 +563,42 @@ class KeyframeStore:
         a = [f(R, np.float32), f(t, np.float32), f(Ow, np.float32), None if median_depth is None else np.array([median_depth], np.float32), f(mp, np.int32)]
         _chk(lib().cms_kfstore_update(self.h, slot, *[_p(v) for v in a]), "cms_kfstore_update")
 
+    def put_from_frame(self, slot, src_ctx, b, n, kf):
+        """cms_kfstore_put_from_frame: frame b of src_ctx's last batch (key points, descriptors, rays, grid: device to device) becomes the key frame in
+        `slot`; kf supplies what the host holds: R, t, Ow, median_depth, mp (or None), node_id / node_off / node_feat.  Asynchronous."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        i32 = lambda a: None if a is None else np.ascontiguousarray(a, np.int32)
+        R, t, Ow = f32(np.asarray(kf["R"]).reshape(9)), f32(kf["t"]), f32(kf["Ow"])
+        mp, nid, noff, nfeat = i32(kf.get("mp")), i32(kf["node_id"]), i32(kf["node_off"]), i32(kf["node_feat"])
+        L = lib()
+        L.cms_kfstore_put_from_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(L.cms_kfstore_put_from_frame(self.h, slot, src_ctx.h, b, n, _p(R), _p(t), _p(Ow), float(kf["median_depth"]), _p(mp), len(nid), _p(nid), _p(noff), _p(nfeat)),
+             "cms_kfstore_put_from_frame")
+
+    def debug_fetch(self, slot, max_features=16384, max_nodes=16384):
+        """cms_kfstore_debug_fetch: the slot's device contents as a dict"""
+        hdr = np.zeros(21, np.uint32); misc = np.zeros(2, np.int32)
+        L = lib()
+        L.cms_kfstore_debug_fetch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 12
+        _chk(L.cms_kfstore_debug_fetch(self.h, slot, *([None] * 10), _p(hdr), _p(misc)), "cms_kfstore_debug_fetch")
+        n, nn = int(hdr[1]), int(hdr[3])
+        o = dict(kps=np.zeros(n, KP_DTYPE), desc=np.zeros((n, 32), np.uint8), rays=np.zeros((n, 3), np.float32), mp=np.zeros(n, np.int32), feat_node=np.zeros(n, np.int32),
+                 sorted=np.zeros(n, np.uint16), node_id=np.zeros(nn, np.int32), node_off=np.zeros(nn + 1, np.int32), node_feat=np.zeros(max(n, 1), np.int32),
+                 cell_start=np.zeros(5 * 50 * 50 + 1, np.int32))
+        _chk(L.cms_kfstore_debug_fetch(self.h, slot, _p(o["kps"]), _p(o["desc"]), _p(o["rays"]), _p(o["mp"]), _p(o["feat_node"]), _p(o["sorted"]), _p(o["node_id"]),
+                                       _p(o["node_off"]), _p(o["node_feat"]), _p(o["cell_start"]), _p(hdr), _p(misc)), "cms_kfstore_debug_fetch")
+        o["node_feat"] = o["node_feat"][:int(o["node_off"][-1]) if nn else 0]
+        o["header"] = hdr; o["nvalid"] = int(misc[0]); o["kp_cnt"] = int(misc[1])
+        return o
+
+    def update_poses(self, slots, R, t, Ow):
+        """cms_kfstore_update_poses: poses of resident key frames after a local BA, one asynchronous call"""
+        slots = np.ascontiguousarray(slots, np.int32)
+        a = [np.ascontiguousarray(R, np.float32).reshape(-1), np.ascontiguousarray(t, np.float32).reshape(-1), np.ascontiguousarray(Ow, np.float32).reshape(-1)]
+        assert len(a[0]) == 9 * len(slots) and len(a[1]) == 3 * len(slots) and len(a[2]) == 3 * len(slots)
+        _chk(lib().cms_kfstore_update_poses(self.h, len(slots), _p(slots), _p(a[0]), _p(a[1]), _p(a[2])), "cms_kfstore_update_poses")
+
     def fuse_search(self, jobs, th=3.0):
         """jobs: list of (slot, dict(skip, pos, normal, min_dist, max_dist, desc)) -> per job (best_idx, best_dist)"""
         nj = len(jobs)

@@ -25,56 +25,83 @@
 #include <stdint.h>
 
 // lanes of one group of 16 -> LDS banks, every lane with BA_SE_DCOPIES candidate banks: augmenting-path matching, the rest on their least-used
-// bank.  Same algorithm and visiting order as BaDiagMatch (the host's recursive version); iterative so that a device thread can run it.
+// bank.  Same algorithm and visiting order as BaDiagMatch (the host's recursive version), iterative, and with ALL of its state packed into a few
+// 64-bit registers: a device thread that kept owner[] / choice[] / the search stack in indexable arrays worked out of scratch memory and took
+// ~0.9 ms per group (k_ba_expand_tables then blocked its hardware queue for that long, 32 times per bench step).
 struct BaDiagMatchHD {
-  int n; uint8_t bank[16][BA_SE_DCOPIES]; int8_t choice[16]; int8_t owner[16];
-  __host__ __device__ bool augment(int i0, bool* seen) {
-    int8_t node[18], ridx[18];
+  int n, np;
+  unsigned long long slots[2];     // free-pose slot of lane i: 8 bits at 8 (i & 7) of slots[i >> 3]
+  unsigned long long owner[2];     // lane + 1 that holds bank c (0: free): 8 bits at 8 (c & 7) of owner[c >> 3]
+  unsigned long long choice;       // copy + 1 chosen by lane i (0: none yet): 4 bits at 4 i
+  __host__ __device__ static unsigned get8(const unsigned long long* a, int i) { return (unsigned)(((i & 8) ? a[1] : a[0]) >> (8 * (i & 7))) & 0xFFu; }
+  __host__ __device__ static void set8(unsigned long long* a, int i, unsigned v) {
+    const unsigned long long m = 0xFFull << (8 * (i & 7)), w = (unsigned long long)v << (8 * (i & 7));
+    if (i & 8) a[1] = (a[1] & ~m) | w; else a[0] = (a[0] & ~m) | w;
+  }
+  __host__ __device__ void set_slot(int i, int s) { set8(slots, i, (unsigned)s); }
+  __host__ __device__ int bank(int i, int r) const { return (BA_SE_DSTRIDE * (r * np + (int)get8(slots, i))) & 15; }
+  __host__ __device__ int get_choice(int i) const { return (int)((choice >> (4 * i)) & 15u) - 1; }
+  __host__ __device__ void set_choice(int i, int r) { choice = (choice & ~(0xFull << (4 * i))) | ((unsigned long long)(r + 1) << (4 * i)); }
+  __host__ __device__ bool augment(int i0) {
+    // depth-first search for an augmenting path; the stack (lane and candidate index per level, <= 17 levels: every level marks a new bank)
+    // is two packed words: 4 bits per level for the lane, 3 for the candidate index
+    unsigned long long node_lo = 0, node_hi = 0, ridx = 0;      // lanes of levels 0..15 in node_lo (4 bits each), level 16.. in node_hi; ridx: 3 bits per level
+    unsigned seen = 0;
+    auto node_get = [&](int d) { return (int)(((d < 16 ? node_lo >> (4 * d) : node_hi >> (4 * (d - 16)))) & 15u); };
+    auto node_set = [&](int d, int v) { if (d < 16) node_lo = (node_lo & ~(0xFull << (4 * d))) | ((unsigned long long)v << (4 * d)); else node_hi = (node_hi & ~(0xFull << (4 * (d - 16)))) | ((unsigned long long)v << (4 * (d - 16))); };
+    auto r_get = [&](int d) { return (int)((ridx >> (3 * d)) & 7u); };
+    auto r_set = [&](int d, int v) { ridx = (ridx & ~(7ull << (3 * d))) | ((unsigned long long)v << (3 * d)); };
     int d = 0;
-    node[0] = (int8_t)i0; ridx[0] = 0;
+    node_set(0, i0); r_set(0, 0);
     while (d >= 0) {
-      const int i = node[d];
-      if (ridx[d] == BA_SE_DCOPIES) { --d; if (d >= 0) ++ridx[d]; continue; }      // this lane found nothing: its caller tries its next bank
-      const int c = bank[i][ridx[d]];
-      if (seen[c]) { ++ridx[d]; continue; }
-      seen[c] = true;
-      if (owner[c] < 0) {                                                            // a free bank: everybody on the path moves one over
-        for (int dd = d; dd >= 0; --dd) { const int ii = node[dd], rr = ridx[dd]; owner[bank[ii][rr]] = (int8_t)ii; choice[ii] = (int8_t)rr; }
+      const int i = node_get(d), r = r_get(d);
+      if (r == BA_SE_DCOPIES) { --d; if (d >= 0) r_set(d, r_get(d) + 1); continue; }      // this lane found nothing: its caller tries its next bank
+      const int c = bank(i, r);
+      if ((seen >> c) & 1u) { r_set(d, r + 1); continue; }
+      seen |= 1u << c;
+      const int o = (int)get8(owner, c) - 1;
+      if (o < 0) {                                                                          // a free bank: everybody on the path moves one over
+        for (int dd = d; dd >= 0; --dd) { const int ii = node_get(dd), rr = r_get(dd); set8(owner, bank(ii, rr), (unsigned)(ii + 1)); set_choice(ii, rr); }
         return true;
       }
-      node[d + 1] = owner[c]; ridx[d + 1] = 0; ++d;
+      node_set(d + 1, o); r_set(d + 1, 0); ++d;
     }
     return false;
   }
   __host__ __device__ void run() {
-    int load[16];
-    for (int c = 0; c < 16; ++c) { owner[c] = -1; load[c] = 0; }
-    for (int i = 0; i < n; ++i) choice[i] = -1;
+    owner[0] = owner[1] = 0; choice = 0;
     for (int i = 0; i < n; ++i) {
       bool done = false;
-      for (int r = 0; r < BA_SE_DCOPIES && !done; ++r) if (owner[bank[i][r]] < 0) { owner[bank[i][r]] = (int8_t)i; choice[i] = (int8_t)r; done = true; }
-      if (!done) { bool seen[16]; for (int c = 0; c < 16; ++c) seen[c] = false; augment(i, seen); }
+      for (int r = 0; r < BA_SE_DCOPIES && !done; ++r) { const int c = bank(i, r); if (get8(owner, c) == 0) { set8(owner, c, (unsigned)(i + 1)); set_choice(i, r); done = true; } }
+      if (!done) augment(i);
     }
-    for (int i = 0; i < n; ++i) if (choice[i] >= 0) ++load[bank[i][choice[i]]];
+    unsigned long long load = 0;                                   // lanes per bank, 4 bits each
+    for (int i = 0; i < n; ++i) if (get_choice(i) >= 0) load += 1ull << (4 * bank(i, get_choice(i)));
     for (int i = 0; i < n; ++i)
-      if (choice[i] < 0) {
+      if (get_choice(i) < 0) {
         int best = 0;
-        for (int r = 1; r < BA_SE_DCOPIES; ++r) if (load[bank[i][r]] < load[bank[i][best]]) best = r;
-        choice[i] = (int8_t)best; ++load[bank[i][best]];
+        for (int r = 1; r < BA_SE_DCOPIES; ++r) if (((load >> (4 * bank(i, r))) & 15u) < ((load >> (4 * bank(i, best))) & 15u)) best = r;
+        set_choice(i, best); load += 1ull << (4 * bank(i, best));
       }
   }
 };
 
 // the free key frames of a signature (a 64-bit set of key frames), in ascending key-frame order: position of the observation within its point
-// (points' observations are sorted by key frame) and free-pose slot; at most eight are kept (signatures of runs have <= 7)
-struct BaRunSig { int kf; int fpos[8]; int fslot[8]; };
+// (points' observations are sorted by key frame) and free-pose slot; at most eight are kept (signatures of runs have <= 7).  Packed (8 bits
+// each) for the same reason as above.
+struct BaRunSig {
+  int kf; unsigned long long fpos8, fslot8;
+  __host__ __device__ int fpos(int a) const { return (int)((fpos8 >> (8 * a)) & 0xFFu); }
+  __host__ __device__ int fslot(int a) const { return (int)((fslot8 >> (8 * a)) & 0xFFu); }
+};
 __host__ __device__ inline void ba_run_decode(uint64_t sig, const int* pose_slot, BaRunSig& rs) {
-  rs.kf = 0;
+  rs.kf = 0; rs.fpos8 = 0; rs.fslot8 = 0;
   int pos = 0;
-  for (int k = 0; k < 64; ++k) {
-    if (!((sig >> k) & 1ull)) continue;
+  while (sig) {
+    const int k = __builtin_ctzll(sig);
+    sig &= sig - 1;
     const int s = pose_slot[k];
-    if (s >= 0) { if (rs.kf < 8) { rs.fpos[rs.kf] = pos; rs.fslot[rs.kf] = s; } ++rs.kf; }
+    if (s >= 0) { if (rs.kf < 8) { rs.fpos8 |= (unsigned long long)pos << (8 * rs.kf); rs.fslot8 |= (unsigned long long)s << (8 * rs.kf); } ++rs.kf; }
     ++pos;
   }
 }
@@ -82,30 +109,30 @@ __host__ __device__ inline void ba_run_decode(uint64_t sig, const int* pose_slot
 __host__ __device__ inline uint32_t ba_run_mf_word(const BaRunSig& rs, int i) {
   if (i < 48) {
     const int a = i / 6, rr = i - 6 * a;
-    if (a < rs.kf && a < 8) return (uint32_t)(rs.fpos[a] * 18 + 3 * rr);
+    if (a < rs.kf && a < 8) return (uint32_t)(rs.fpos(a) * 18 + 3 * rr);
     if (i == 6 * rs.kf) return BA_RM_MF_RHS;
     return BA_RM_MF_NONE;
   }
-  if (i < 56) return (i - 48 < rs.kf) ? (uint32_t)rs.fslot[i - 48] : BA_RM_MF_NONE;
+  if (i < 56) return (i - 48 < rs.kf) ? (uint32_t)rs.fslot(i - 48) : BA_RM_MF_NONE;
   if (i == 56) return (uint32_t)rs.kf;
   return BA_RM_MF_NONE;
 }
 // run_fl[(run * 64 + lane) * 12 + w]: where accumulators 2 w and 2 w + 1 of the lane go (16-bit LDS offsets, 0xFFFF: nowhere)
 __host__ __device__ inline uint32_t ba_run_fl_word(const BaRunSig& rs, int np, int l, int w) {
-  const int tile_i[6] = {0, 0, 1, 0, 1, 2}, tile_j[6] = {0, 1, 1, 2, 2, 2};
   const int n6 = 6 * rs.kf;
   uint32_t word = 0xFFFFFFFFu;
   if (n6 + 1 > 48) return word;
   const uint32_t dg_off = (uint32_t)((((np * (np + 1) / 2) - np) * BA_SE_SSTRIDE + 1) & ~1);
   for (int h = 0; h < 2; ++h) {
     const int idx = 2 * w + h, t = idx >> 2, g = idx & 3;
-    const int I = 16 * tile_i[t] + (l >> 4) + 4 * g, N = 16 * tile_j[t] + (l & 15);
+    const int ti = (0x210100 >> (4 * t)) & 15, tj = (0x222110 >> (4 * t)) & 15;      // tiles (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
+    const int I = 16 * ti + (l >> 4) + 4 * g, N = 16 * tj + (l & 15);
     if (!(I < n6 && N <= n6 && (N == n6 || I <= N))) continue;
-    const int a1 = I / 6, r1 = I % 6, s1 = rs.fslot[a1];
+    const int a1 = I / 6, r1 = I % 6, s1 = rs.fslot(a1);
     uint32_t off;
     if (N == n6) off = dg_off + (uint32_t)((g * np + s1) * BA_SE_DSTRIDE + 21 + r1);
     else {
-      const int a2 = N / 6, r2 = N % 6, s2 = rs.fslot[a2];
+      const int a2 = N / 6, r2 = N % 6, s2 = rs.fslot(a2);
       if (a1 == a2) off = dg_off + (uint32_t)((g * np + s1) * BA_SE_DSTRIDE + (r1 * 6 - (r1 * (r1 - 1)) / 2 + (r2 - r1)));
       else off = (uint32_t)((s1 * np - (s1 * (s1 + 1)) / 2 + (s2 - s1 - 1)) * BA_SE_SSTRIDE + ba_se_off(r1, r2));
     }
@@ -164,17 +191,18 @@ __host__ __device__ inline void ba_expand_table_at(const BaExpand& x, int t) {
     const int c = x.n_rm + (t >> 2), g = t & 3;
     const int e0 = x.ce0[c], ne = x.ce0[c + 1] - e0;
     BaDiagMatchHD M;
-    int lane_of[16];
-    M.n = 0;
+    unsigned long long lanes = 0;                                 // lane (within the group) of matcher entry i: 4 bits each
+    M.n = 0; M.np = x.np; M.slots[0] = M.slots[1] = 0;
     for (int L = 16 * g; L < 16 * g + 16 && L < ne; ++L) {
       const int s = x.pose_slot[x.s_pose[e0 + L]];
       if (s < 0) continue;
-      for (int r = 0; r < BA_SE_DCOPIES; ++r) M.bank[M.n][r] = (uint8_t)((BA_SE_DSTRIDE * (r * x.np + s)) & 15);
-      lane_of[M.n++] = L;
+      M.set_slot(M.n, s);
+      lanes |= (unsigned long long)(L & 15) << (4 * M.n);
+      ++M.n;
     }
     if (M.n == 0) return;
     M.run();
-    for (int i = 0; i < M.n; ++i) x.info[e0 + lane_of[i]] |= (uint32_t)M.choice[i] << 27;
+    for (int i = 0; i < M.n; ++i) x.info[e0 + 16 * g + (int)((lanes >> (4 * i)) & 15u)] |= (uint32_t)M.get_choice(i) << 27;
     return;
   }
   const int u = t - 4 * n_lo;

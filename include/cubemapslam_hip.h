@@ -366,6 +366,24 @@ int cms_kfstore_create(cms_kfstore** out, cms_ctx* ctx, int max_keyframes, int m
 void cms_kfstore_destroy(cms_kfstore* st);
 int cms_kfstore_put(cms_kfstore* st, int slot, const cms_keyframe* kf);
 int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, const float* tcw, const float* Ow, const float* median_depth, const int* mp);
+/* LocalMapping::ProcessNewKeyFrame's device half (src/LocalMapping.cpp:52-117: the frame Tracking turned into a key frame enters the map): the key
+ * points, descriptors, key rays (Frame::mvKeyRays) and the frame grid of frame b of `src`'s last batch are already on the device (cms_frames_process
+ * + cms_area_grid left them there); one kernel copies them device to device into `slot` -- no trip through the host, no second grid build, no
+ * synchronisation -- and reads what only the host has from a pinned block: the FeatureVector (KeyFrame::ComputeBoW, DBoW2 on the host) and the
+ * map-point slots mp[n] (NULL: none).  n = the frame's key-point count (what cms_frames_fetch reports).  Asynchronous: the copy is enqueued on `src`'s
+ * stream -- behind the work that produced frame b and in front of the next batch, like the KeyFrame constructor's copy on the Tracking thread
+ * (Tracking.cpp:1015-1017) -- and the store's stream waits for it on the device; `src` may be the store's own context.  Equivalent to cms_kfstore_put of the
+ * fetched frame (tests/test_gpu_parity.py::test_kfstore_put_from_frame_equals_put). */
+int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow, float median_depth,
+                               const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat);
+/* the poses of n resident key frames after a local BA (Optimizer.cpp:419-431 writes them back into the KeyFrames): Rcw n x 9, tcw n x 3, Ow n x 3.
+ * One kernel reading a pinned block, asynchronous -- cms_kfstore_update per key frame costs a copy and a stream wait each. */
+int cms_kfstore_update_poses(cms_kfstore* st, int n, const int* slots, const float* Rcw, const float* tcw, const float* Ow);
+/* developer / test aid: what a slot holds on the device (any pointer may be NULL): kps / desc / rays / mp / feat_node / sorted n entries (n = header[1]),
+ * node_id nnodes, node_off nnodes + 1, node_feat node_off[nnodes], cell_start 5 x 50 x 50 + 1, header = the slot's 21-word record (f0, n, node0, nnodes,
+ * noff0, nfeat0, Rcw, tcw, Ow), misc[2] = valid grid entries, stored key-point count */
+int cms_kfstore_debug_fetch(cms_kfstore* st, int slot, cms_keypoint* kps, uint8_t* desc, float* rays, int* mp, int* feat_node, uint16_t* sorted,
+                            int* node_id, int* node_off, int* node_feat, int* cell_start, uint32_t* header, int* misc);
 /* SearchInNeighbors' Fuse calls (src/LocalMapping.cpp:388-467) on resident key frames in one launch sequence: job j searches the map points
  * [mp_off[j], mp_off[j+1]) of the concatenated host arrays in the key frame of slot job_slot[j]; arguments and results as cms_fuse_search. */
 int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const uint8_t* skip, const float* pos,

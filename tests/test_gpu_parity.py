@@ -1130,6 +1130,66 @@ def test_product_reproduces_golden_vectors():
     ctx.close()
 
 
+def test_kfstore_put_from_frame_equals_put():
+    """LocalMapping::ProcessNewKeyFrame's device half (LocalMapping.cpp:52-117): cms_kfstore_put_from_frame copies frame b's key points, descriptors,
+    key rays and frame grid out of the frame context device to device.  The slot must hold, byte for byte, what cms_kfstore_put stores when it
+    is handed the SAME frame fetched to the host (key points, descriptors, rays, map-point slots, FeatureVector, grid: sorted list, cell offsets,
+    valid count), the Fuse search on it must give the oracle's result, and cms_kfstore_update_poses must do what cms_kfstore_update does."""
+    F = 550
+    camd, ocam, _ = _cfg("lafida", F, 2000)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=3)
+    ctx.set_mask(synth.cubemap_valid_mask(camd))
+    frames = np.stack([synth.texture(camd["Ih"], camd["Iw"], s_) for s_ in (71, 72, 73)])
+    ctx.upload(frames); ctx.process(3, True); ctx.area_grid(3); ctx.sync()
+    cg = api.Context(camd, nfeatures=2000, max_batch=1)              # the mapping side's context (its own stream), like bench.py's window groups
+    sA = api.KeyframeStore(cg, max_keyframes=4, max_features=2048, max_nodes=512)
+    sB = api.KeyframeStore(cg, max_keyframes=4, max_features=2048, max_nodes=512)
+    rng = np.random.default_rng(7)
+    kfs = {}
+    for b, slot in ((1, 2), (2, 0)):
+        k, d = ctx.fetch(b); rays = ctx.fetch_rays(b)
+        n = len(k)
+        assert n > 1000
+        node = (d[:, 0].astype(np.int32) * 2 + (d[:, 1] >> 7)) % 300           # a FeatureVector: features binned by descriptor bits, 10 % left out
+        keepf = rng.random(n) < 0.9
+        order = np.lexsort((np.arange(n), node)); order = order[keepf[order]]
+        ids, starts = np.unique(node[order], return_index=True)
+        pr = synth.local_map_problem(F, k["x"], k["y"], k["octave"], d, seed=200 + b)
+        kf = dict(x=k["x"], y=k["y"], octave=k["octave"], angle=k["angle"], desc=d, rays=rays, mp=np.where(rng.random(n) < 0.4, rng.integers(0, 5000, n), -1).astype(np.int32),
+                  R=pr["pose15"][:9], t=pr["pose15"][9:12], Ow=pr["pose15"][12:], node_id=ids.astype(np.int32), node_off=np.concatenate([starts, [len(order)]]).astype(np.int32),
+                  node_feat=order.astype(np.int32), median_depth=2.5 + b)
+        K, keep = api.make_keyframe(kf)
+        kp = keep[0]; kp["size"] = k["size"]; kp["response"] = k["response"]  # (make_keyframe fills the fields the mapping kernels read; here every field must match)
+        sA.put(slot, K)
+        sB.put_from_frame(slot, ctx, b, n, kf)
+        kfs[slot] = (kf, pr)
+    for slot in (2, 0):
+        a, bb = sA.debug_fetch(slot), sB.debug_fetch(slot)
+        for key in ("kps", "desc", "rays", "mp", "feat_node", "sorted", "node_id", "node_off", "node_feat", "cell_start", "header"):
+            x, y = a[key], bb[key]
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint8), y.view(np.uint8)), (slot, key)
+        assert a["nvalid"] == bb["nvalid"] and a["kp_cnt"] == bb["kp_cnt"] == len(kfs[slot][0]["x"])
+    # the Fuse search on the device-to-device key frame against the oracle
+    sf = kfs[2][1]["scale_factors"]; inv_s2 = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    for slot in (2, 0):
+        kf, pr = kfs[slot]
+        skip = (np.arange(len(pr["pos"])) % 7 == 0).astype(np.uint8)
+        job = dict(skip=skip, pos=pr["pos"], normal=pr["normal"], min_dist=pr["min_dist"], max_dist=pr["max_dist"], desc=pr["desc"])
+        okf = orc.make_keyframe(ocam, kf)
+        want = orc.fuse_search(ocam, okf[0], skip, pr["pos"], pr["normal"], pr["min_dist"], pr["max_dist"], pr["desc"], 3.0, sf, inv_s2)
+        got = sB.fuse_search([(slot, job)], th=3.0)[0]
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and (want[0] >= 0).sum() > 300, slot
+    # poses after a local BA: one asynchronous call for several key frames
+    R2 = np.stack([np.roll(np.asarray(kfs[s_][0]["R"], np.float32).reshape(9), 3) for s_ in (2, 0)]); t2 = np.array([[1, 2, 3], [4, 5, 6]], np.float32); O2 = -t2
+    sB.update_poses([2, 0], R2, t2, O2)
+    for i, slot in enumerate((2, 0)):
+        sA.update(slot, R=R2[i], t=t2[i], Ow=O2[i])
+        assert np.array_equal(sA.debug_fetch(slot)["header"], sB.debug_fetch(slot)["header"]), slot
+    with pytest.raises(api.CmsError):
+        sB.put_from_frame(1, ctx, 5, 10, kfs[0][0])                  # no such frame in the batch
+    sA.close(); sB.close(); cg.close(); ctx.close()
+
+
 def test_kfstore_fuse_search_matches_oracle():
     """SearchInNeighbors' Fuse calls on resident key frames: three key frames in a store, four jobs (one slot used twice) in one call"""
     import test_area_emu as te
@@ -1208,8 +1268,10 @@ def test_ba_device_plan_equals_host_plan(shuffle):
     h = api.ba_plan(prob["fixed"], P, prob["e_pose"], prob["e_point"], tables=True)
     for k in ("n_chunks", "n_rm", "n_runs", "np", "rm_points"):
         assert d[k] == h[k], (k, d[k], h[k])
-    for k in ("pinv", "perm", "info", "rm_chunk", "run_mf", "run_fl"):
+    for k in ("pinv", "perm", "rm_chunk", "run_mf", "run_fl"):
         assert d[k].shape == h[k].shape and np.array_equal(d[k], h[k]), k
+    # (cms_ba_debug_plan is not given the faces: the per-edge words are compared without their face field, which is checked on its own)
+    assert np.array_equal(d["info"] & ~np.uint32(7 << 16), h["info"]) and np.array_equal((d["info"] >> 16) & 7, prob["e_face"][d["perm"]].astype(np.uint32))
     # a valid partition, from the device arrays alone
     assert np.array_equal(np.sort(d["perm"]), np.arange(E)) and np.array_equal(np.sort(d["pinv"]), np.arange(P))
     prank = np.empty(P, np.int64); prank[d["pinv"]] = np.arange(P)
