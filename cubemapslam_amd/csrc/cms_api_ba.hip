@@ -110,7 +110,7 @@ struct cms_ba {
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   bool fast_plan = false;    // planned by ba_plan_fast (cms_api_ba_plan.hip): the permutations and the per-edge arrays exist on the device only
   int* d_raw_pose = nullptr; int* d_raw_point = nullptr; int8_t* d_raw_face = nullptr; int* d_prank = nullptr; int* d_cpo = nullptr; int* d_cedge = nullptr;
-  uint8_t* d_pcopy = nullptr; uint64_t* d_run_sig = nullptr; double* d_rb_pts = nullptr; uint8_t* d_rb_flags = nullptr;
+  uint8_t* d_pcopy = nullptr; uint8_t* d_lo_copy = nullptr; uint64_t* d_run_sig = nullptr; double* d_rb_pts = nullptr; uint8_t* d_rb_flags = nullptr;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
   hipStream_t grp_stream = nullptr;   // the stream of the group whose rounds may still be in flight for this window (ba_optimize_group; cleared at its successful end)
@@ -1356,7 +1356,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     // the caller's index arrays as they are; sorted edge arrays, per-edge words and the edge permutation are written by k_ba_expand_edges
     up(e_pose, E * sizeof(int), &b->d_raw_pose); up(e_point, E * sizeof(int), &b->d_raw_point); up(e_face, E, &b->d_raw_face);
     up(fp.pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off); up(fp.prank.data(), P * sizeof(int), &b->d_prank); up(fp.pinv.data(), P * sizeof(int), &b->d_pinv);
-    up(fp.cpo.data(), (P + 1) * sizeof(int), &b->d_cpo); up(fp.pcopy.data(), P, &b->d_pcopy);
+    up(fp.cpo.data(), (P + 1) * sizeof(int), &b->d_cpo); up(fp.pcopy.data(), P, &b->d_pcopy); up(fp.lo_copy.data(), fp.lo_copy.size(), &b->d_lo_copy);
     if (!fp.grouped) up(fp.cedge.data(), E * sizeof(int), &b->d_cedge);
     // (the per-key-frame edge lists serve kb_ba_lin, which a group of such windows never launches: an empty CSR)
     zero_off.assign(K + 1, 0);
@@ -1416,15 +1416,13 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     BaExpand x;
     x.K = K; x.P = P; x.E = E; x.np = np;
     x.e_pose = b->d_raw_pose; x.e_point = b->d_raw_point; x.e_face = b->d_raw_face; x.cedge = fp.grouped ? nullptr : b->d_cedge; x.cpo = b->d_cpo;
-    x.prank = b->d_prank; x.pinv = b->d_pinv; x.pt_off = b->d_pt_off; x.pcopy = b->d_pcopy; x.pose_slot = b->d_pose_slot;
+    x.prank = b->d_prank; x.pinv = b->d_pinv; x.pt_off = b->d_pt_off; x.pcopy = b->d_pcopy; x.lo_copy = b->d_lo_copy; x.e_lo0 = fp.pt_off[fp.P_rm]; x.pose_slot = b->d_pose_slot;
     x.raw_obs = b->d_raw_obs; x.raw_inv = b->d_raw_inv; x.raw_pts = b->d_raw_pts; x.poses0 = b->d_poses0;
     x.perm = b->d_perm; x.s_pose = b->d_e_pose; x.s_point = b->d_e_point; x.s_face = b->d_e_face; x.info = b->d_se_info;
     x.e_obs = b->d_e_obs; x.e_inv = b->d_e_inv; x.pts0 = b->d_pts0; x.poses = b->d_poses[0]; x.pts = b->d_pts[0]; x.level = b->d_level; x.err = b->d_err; x.flags = b->d_flags;
     x.gsum = b->d_se_partial; x.n_gsum = b->se.npairs2 * 42; x.gsum_bp = b->d_se_bp_partial; x.n_gsum_bp = b->np * 6;
     x.ce0 = b->d_se_chunk_e0; x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl;
-    hipLaunchKernelGGL(k_ba_expand_edges, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, x);
-    const int n_tab = 4 * (fp.nchunks - fp.n_rm) + 64 * fp.n_runs;
-    if (n_tab > 0) hipLaunchKernelGGL(k_ba_expand_tables, dim3((n_tab + 63) / 64), dim3(64), 0, b->stream, x);
+    hipLaunchKernelGGL(k_ba_expand_edges, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, x);      // (+ the runs' tables)
   } else
   hipLaunchKernelGGL(k_ba_gather, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, K, P, E, (const int*)b->d_perm, (const int*)b->d_pinv,
                      (const double*)b->d_raw_obs, (const double*)b->d_raw_inv, (const double*)b->d_raw_pts, b->d_e_obs, b->d_e_inv, b->d_pts0,

@@ -9,13 +9,15 @@
 //
 //   host    signature groups (open addressing on the 64-bit key-frame set) -> runs -> internal point order (runs first, then the left-over
 //           points in the caller's order) -> chunks (run chunks; left-over points packed greedily into chunks of <= 64 observations) ->
-//           point CSR offsets, chunk descriptors, chunk costs.  P-sized, sequential, ~0.1 ms.
+//           point CSR offsets, chunk descriptors, chunk costs, the left-over observations' diagonal copies.  P-sized, sequential, ~0.2 ms.
 //   device  k_ba_expand_edges   one thread per observation: its position in the internal order (rank of its key frame among its point's),
 //                               the sorted edge arrays, the per-edge word, and k_ba_gather's work (measurements into the internal order,
 //                               initial estimate, cleared per-edge state)
-//           k_ba_expand_tables  one thread per (left-over chunk, group of 16 lanes): which copy of its key frame's diagonal block every
-//                               observation adds to (bipartite matching lanes -> LDS banks, BaDiagMatchHD); one thread per (run, lane):
-//                               the MFMA body's operand table run_mf and flush table run_fl
+//                               ... and, in the same launch, one thread per (run, lane): the MFMA body's operand table run_mf and flush
+//                               table run_fl
+// (Which copy of its key frame's diagonal block a LEFT-OVER observation adds to -- a bipartite matching lanes -> LDS banks per group of 16 lanes,
+// BaDiagMatchHD -- is decided on the host after all: a point's key frames in ascending order ARE the set bits of its signature, so the matching
+// needs no observation-sized data either, and as a device kernel it was a few hundred serial threads that held a hardware queue for 0.26 ms.)
 //
 // The look-ahead composition of the left-over chunks is gone from this path: round 4 measured it neutral for windows whose left-over points
 // are a minority (profiles/r04_experiments.txt: look-ahead 1 / 4 / 8 = 88.7 / 89.6 / 86.9 us for the Schur launch); what matters is the
@@ -24,71 +26,9 @@
 // the windows both can plan, the two give byte-identical device arrays (tests/test_gpu_parity.py::test_ba_device_plan_equals_host_plan).
 #include <stdint.h>
 
-// lanes of one group of 16 -> LDS banks, every lane with BA_SE_DCOPIES candidate banks: augmenting-path matching, the rest on their least-used
-// bank.  Same algorithm and visiting order as BaDiagMatch (the host's recursive version), iterative, and with ALL of its state packed into a few
-// 64-bit registers: a device thread that kept owner[] / choice[] / the search stack in indexable arrays worked out of scratch memory and took
-// ~0.9 ms per group (k_ba_expand_tables then blocked its hardware queue for that long, 32 times per bench step).
-struct BaDiagMatchHD {
-  int n, np;
-  unsigned long long slots[2];     // free-pose slot of lane i: 8 bits at 8 (i & 7) of slots[i >> 3]
-  unsigned long long owner[2];     // lane + 1 that holds bank c (0: free): 8 bits at 8 (c & 7) of owner[c >> 3]
-  unsigned long long choice;       // copy + 1 chosen by lane i (0: none yet): 4 bits at 4 i
-  __host__ __device__ static unsigned get8(const unsigned long long* a, int i) { return (unsigned)(((i & 8) ? a[1] : a[0]) >> (8 * (i & 7))) & 0xFFu; }
-  __host__ __device__ static void set8(unsigned long long* a, int i, unsigned v) {
-    const unsigned long long m = 0xFFull << (8 * (i & 7)), w = (unsigned long long)v << (8 * (i & 7));
-    if (i & 8) a[1] = (a[1] & ~m) | w; else a[0] = (a[0] & ~m) | w;
-  }
-  __host__ __device__ void set_slot(int i, int s) { set8(slots, i, (unsigned)s); }
-  __host__ __device__ int bank(int i, int r) const { return (BA_SE_DSTRIDE * (r * np + (int)get8(slots, i))) & 15; }
-  __host__ __device__ int get_choice(int i) const { return (int)((choice >> (4 * i)) & 15u) - 1; }
-  __host__ __device__ void set_choice(int i, int r) { choice = (choice & ~(0xFull << (4 * i))) | ((unsigned long long)(r + 1) << (4 * i)); }
-  __host__ __device__ bool augment(int i0) {
-    // depth-first search for an augmenting path; the stack (lane and candidate index per level, <= 17 levels: every level marks a new bank)
-    // is two packed words: 4 bits per level for the lane, 3 for the candidate index
-    unsigned long long node_lo = 0, node_hi = 0, ridx = 0;      // lanes of levels 0..15 in node_lo (4 bits each), level 16.. in node_hi; ridx: 3 bits per level
-    unsigned seen = 0;
-    auto node_get = [&](int d) { return (int)(((d < 16 ? node_lo >> (4 * d) : node_hi >> (4 * (d - 16)))) & 15u); };
-    auto node_set = [&](int d, int v) { if (d < 16) node_lo = (node_lo & ~(0xFull << (4 * d))) | ((unsigned long long)v << (4 * d)); else node_hi = (node_hi & ~(0xFull << (4 * (d - 16)))) | ((unsigned long long)v << (4 * (d - 16))); };
-    auto r_get = [&](int d) { return (int)((ridx >> (3 * d)) & 7u); };
-    auto r_set = [&](int d, int v) { ridx = (ridx & ~(7ull << (3 * d))) | ((unsigned long long)v << (3 * d)); };
-    int d = 0;
-    node_set(0, i0); r_set(0, 0);
-    while (d >= 0) {
-      const int i = node_get(d), r = r_get(d);
-      if (r == BA_SE_DCOPIES) { --d; if (d >= 0) r_set(d, r_get(d) + 1); continue; }      // this lane found nothing: its caller tries its next bank
-      const int c = bank(i, r);
-      if ((seen >> c) & 1u) { r_set(d, r + 1); continue; }
-      seen |= 1u << c;
-      const int o = (int)get8(owner, c) - 1;
-      if (o < 0) {                                                                          // a free bank: everybody on the path moves one over
-        for (int dd = d; dd >= 0; --dd) { const int ii = node_get(dd), rr = r_get(dd); set8(owner, bank(ii, rr), (unsigned)(ii + 1)); set_choice(ii, rr); }
-        return true;
-      }
-      node_set(d + 1, o); r_set(d + 1, 0); ++d;
-    }
-    return false;
-  }
-  __host__ __device__ void run() {
-    owner[0] = owner[1] = 0; choice = 0;
-    for (int i = 0; i < n; ++i) {
-      bool done = false;
-      for (int r = 0; r < BA_SE_DCOPIES && !done; ++r) { const int c = bank(i, r); if (get8(owner, c) == 0) { set8(owner, c, (unsigned)(i + 1)); set_choice(i, r); done = true; } }
-      if (!done) augment(i);
-    }
-    unsigned long long load = 0;                                   // lanes per bank, 4 bits each
-    for (int i = 0; i < n; ++i) if (get_choice(i) >= 0) load += 1ull << (4 * bank(i, get_choice(i)));
-    for (int i = 0; i < n; ++i)
-      if (get_choice(i) < 0) {
-        int best = 0;
-        for (int r = 1; r < BA_SE_DCOPIES; ++r) if (((load >> (4 * bank(i, r))) & 15u) < ((load >> (4 * bank(i, best))) & 15u)) best = r;
-        set_choice(i, best); load += 1ull << (4 * bank(i, best));
-      }
-  }
-};
-
 // the free key frames of a signature (a 64-bit set of key frames), in ascending key-frame order: position of the observation within its point
 // (points' observations are sorted by key frame) and free-pose slot; at most eight are kept (signatures of runs have <= 7).  Packed (8 bits
-// each) for the same reason as above.
+// each): indexable arrays would live in scratch memory on the device.
 struct BaRunSig {
   int kf; unsigned long long fpos8, fslot8;
   __host__ __device__ int fpos(int a) const { return (int)((fpos8 >> (8 * a)) & 0xFFu); }
@@ -149,6 +89,7 @@ struct BaExpand {
   const int* cpo;                                                   // P + 1: offsets of the caller's points in that grouped order
   const int* prank; const int* pinv; const int* pt_off;             // caller point -> internal point, back, and the internal CSR offsets
   const uint8_t* pcopy;                                             // P (internal): copy of the diagonal blocks for a run point's observations, 0xFF: left-over point
+  const uint8_t* lo_copy; int e_lo0;                                // ... and per left-over observation (sorted position - e_lo0): the copy the host's matching chose
   const int* pose_slot;
   const double* raw_obs; const double* raw_inv; const double* raw_pts; const double* poses0;
   int* perm; int* s_pose; int* s_point; int8_t* s_face; uint32_t* info;
@@ -174,7 +115,7 @@ __host__ __device__ inline void ba_expand_edge_at(const BaExpand& x, int i) {
   const int p = x.prank[q], pos = x.pt_off[p] + a;
   const int face = x.e_face[e];
   x.perm[pos] = e; x.s_pose[pos] = k; x.s_point[pos] = p; x.s_face[pos] = (int8_t)face;
-  const uint32_t copy = x.pcopy[p] == 0xFF ? 0u : (uint32_t)x.pcopy[p];      // (left-over points: ba_expand_table_at adds theirs)
+  const uint32_t copy = x.pcopy[p] == 0xFF ? (uint32_t)x.lo_copy[pos - x.e_lo0] : (uint32_t)x.pcopy[p];
   x.info[pos] = (uint32_t)a | ((uint32_t)n << 5) | ((uint32_t)(x.pose_slot[k] + 1) << 10) | ((uint32_t)face << 16) | ((uint32_t)k << 19) | (copy << 27);
   if (x.e_obs) {
     x.e_obs[2 * (size_t)pos] = x.raw_obs[2 * (size_t)e]; x.e_obs[2 * (size_t)pos + 1] = x.raw_obs[2 * (size_t)e + 1];
@@ -183,30 +124,8 @@ __host__ __device__ inline void ba_expand_edge_at(const BaExpand& x, int i) {
     x.level[pos] = 0; x.flags[pos] = 0;
   }
 }
-// entries [0, 4 x left-over chunks): one (chunk, group of 16 lanes) each -> the diagonal copies of that group's observations;
-// entries behind them: one (run, lane) each -> the run's tables
-__host__ __device__ inline void ba_expand_table_at(const BaExpand& x, int t) {
-  const int n_lo = x.nchunks - x.n_rm;
-  if (t < 4 * n_lo) {
-    const int c = x.n_rm + (t >> 2), g = t & 3;
-    const int e0 = x.ce0[c], ne = x.ce0[c + 1] - e0;
-    BaDiagMatchHD M;
-    unsigned long long lanes = 0;                                 // lane (within the group) of matcher entry i: 4 bits each
-    M.n = 0; M.np = x.np; M.slots[0] = M.slots[1] = 0;
-    for (int L = 16 * g; L < 16 * g + 16 && L < ne; ++L) {
-      const int s = x.pose_slot[x.s_pose[e0 + L]];
-      if (s < 0) continue;
-      M.set_slot(M.n, s);
-      lanes |= (unsigned long long)(L & 15) << (4 * M.n);
-      ++M.n;
-    }
-    if (M.n == 0) return;
-    M.run();
-    for (int i = 0; i < M.n; ++i) x.info[e0 + 16 * g + (int)((lanes >> (4 * i)) & 15u)] |= (uint32_t)M.get_choice(i) << 27;
-    return;
-  }
-  const int u = t - 4 * n_lo;
-  if (u >= 64 * x.n_runs) return;
+// one (run, lane): the run's tables
+__host__ __device__ inline void ba_expand_table_at(const BaExpand& x, int u) {
   const int r = u >> 6, l = u & 63;
   BaRunSig rs;
   ba_run_decode(x.run_sig[r], x.pose_slot, rs);
@@ -217,6 +136,7 @@ __host__ __device__ inline void ba_expand_table_at(const BaExpand& x, int t) {
 extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges(BaExpand x) {
   const int gs = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   for (int i = t0; i < x.E; i += gs) ba_expand_edge_at(x, i);
+  for (int u = t0; u < 64 * x.n_runs; u += gs) ba_expand_table_at(x, u);
   for (int i = t0; i < x.P; i += gs) {
     const int q = x.pinv[i];
 #pragma unroll
@@ -226,8 +146,6 @@ extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges(BaExpand x) 
   for (int i = t0; i < x.n_gsum; i += gs) x.gsum[i] = 0.0;
   for (int i = t0; i < x.n_gsum_bp; i += gs) x.gsum_bp[i] = 0.0;
 }
-extern "C" __global__ void __launch_bounds__(64) k_ba_expand_tables(BaExpand x) { ba_expand_table_at(x, blockIdx.x * blockDim.x + threadIdx.x); }
-
 // results back into the caller's order on the device (cms_ba_read of a window whose permutations only the device holds)
 extern "C" __global__ void __launch_bounds__(256)
 k_ba_unpermute(int P, int E, const int* __restrict__ pinv, const int* __restrict__ perm, const double* __restrict__ pts, const uint8_t* __restrict__ flags,
@@ -246,7 +164,7 @@ k_ba_unpermute(int P, int E, const int* __restrict__ pinv, const int* __restrict
 // ---- host side: everything of the plan that is decided per POINT
 struct BaFastPlan {
   std::vector<int> pose_slot, cnt, cpo, cedge, prank, pinv, pt_off, chunk_pt0, ce0, lone, pob, ident, pose_cnt;
-  std::vector<uint8_t> pcopy;
+  std::vector<uint8_t> pcopy, lo_copy;
   std::vector<uint64_t> sig, run_sig;
   std::vector<int4> rm_chunk;
   std::vector<uint32_t> rm_cost;
@@ -414,6 +332,40 @@ static int ba_plan_fast(cms_ba* b, BaFastPlan& fp, int K, const uint8_t* fixed, 
     for (int p = chunk_pt0[c]; p < chunk_pt0[c + 1]; ++p) kmax = std::max(kmax, cnt[pinv[p]]);
     fp.rm_cost[(size_t)c + 1] = fp.rm_cost[c] + (uint32_t)(kn.em_cost_a + kn.em_cost_b * (kmax / 2));
   }
+  // ---- the left-over observations' copies of their key frames' diagonal blocks: per chunk and group of 16 lanes a matching lanes -> LDS banks
+  // (every lane may use any of the BA_SE_DCOPIES copies = banks).  A point's observations in ascending key-frame order are the set bits of
+  // its signature, so the lanes' slots follow from per-point data alone.
+  {
+    const int e_lo0 = pt_off[P_rm];
+    fp.lo_copy.assign((size_t)std::max(E - e_lo0, 1), 0);
+    for (int c = n_rm; c < nchunks; ++c) {
+      BaDiagMatch M[4];                                             // (the host planner's matcher: same lanes in the same order, same choices)
+      uint8_t lane_of[4][16];
+      for (int g = 0; g < 4; ++g) M[g].n = 0;
+      const int e0 = fp.ce0[c];
+      int L = 0;
+      for (int p = chunk_pt0[c]; p < chunk_pt0[c + 1]; ++p) {
+        uint64_t bits = sig[pinv[p]];
+        while (bits) {
+          const int k = __builtin_ctzll(bits);
+          bits &= bits - 1;
+          const int sl = pose_slot[k], g = (L >> 4) & 3;
+          if (sl >= 0) {
+            BaDiagMatch& m = M[g];
+            for (int r = 0; r < BA_SE_DCOPIES; ++r) m.bank[m.n][r] = (uint8_t)((BA_SE_DSTRIDE * (r * np + sl)) & 15);
+            lane_of[g][m.n++] = (uint8_t)(L & 15);
+          }
+          ++L;
+        }
+      }
+      for (int g = 0; g < 4; ++g) {
+        if (M[g].n == 0) continue;
+        M[g].run();
+        for (int i = 0; i < M[g].n; ++i) fp.lo_copy[(size_t)(e0 - e_lo0) + 16 * g + lane_of[g][i]] = (uint8_t)M[g].choice[i];
+      }
+    }
+  }
+  tick("copies");
   fp.lone.clear();
   for (int p = 0; p < P; ++p) if (pt_off[p + 1] == pt_off[p]) fp.lone.push_back(p);
   fp.pob.assign((size_t)NP2, 0); fp.ident.resize((size_t)NP2 + 1);
@@ -466,9 +418,9 @@ extern "C" int cms_ba_debug_plan_fast(int K, const uint8_t* fixed, int P, int E,
   x.prank = fp.prank.data(); x.pinv = fp.pinv.data(); x.pt_off = fp.pt_off.data(); x.pcopy = fp.pcopy.data(); x.pose_slot = fp.pose_slot.data();
   x.perm = perm_out; x.s_pose = s_pose.data(); x.s_point = s_point.data(); x.s_face = s_face.data(); x.info = info_out;
   x.ce0 = fp.ce0.data(); x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = fp.run_sig.data(); x.n_runs = fp.n_runs; x.run_mf = run_mf.data(); x.run_fl = run_fl.data();
+  x.lo_copy = fp.lo_copy.data(); x.e_lo0 = fp.pt_off[fp.P_rm];
   for (int i = 0; i < E; ++i) ba_expand_edge_at(x, i);
-  const int n_tab = 4 * (fp.nchunks - fp.n_rm) + 64 * fp.n_runs;
-  for (int t = 0; t < n_tab; ++t) ba_expand_table_at(x, t);
+  for (int u = 0; u < 64 * fp.n_runs; ++u) ba_expand_table_at(x, u);
   memcpy(pinv_out, fp.pinv.data(), (size_t)P * sizeof(int));
   memcpy(chunk_pt0_out, fp.chunk_pt0.data(), fp.chunk_pt0.size() * sizeof(int));
   if (fp.n_rm > 0) memcpy(rm_chunk_out, fp.rm_chunk.data(), (size_t)fp.n_rm * sizeof(int4));
