@@ -45,6 +45,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -379,9 +380,11 @@ def main():
         cpu_acc["create"] += time.thread_time() - c1; cpu_acc["n"] += 1
         return ba, 1e3 * (time.perf_counter() - t1)        # streams on 8 hardware queues: the two groups' chains and CreateNewMapPoints queued behind each other)
     own_streams = os.environ.get("CMS_BENCH_WINDOW_STREAMS", "") != ""      # developer knob: the old behaviour
-    def finish_window(ba):
+    def finish_window(ba, gw=None):
         c1 = time.thread_time()
         out = ba.read()             # poses, points, outlier flags -> host arrays (Optimizer.cpp:419-450)
+        if gw is not None and life.get("mapping_full"):
+            write_back(*gw)         # the window's key frames' poses back into the store (Optimizer.cpp:419-431; see mapping_side)
         ba.close()                  # cms_ba_destroy
         cpu_acc["finish"] += time.thread_time() - c1
         return out
@@ -412,6 +415,7 @@ def main():
             _, r = synth.pixel_to_ray(F, k["x"].astype(np.float64), k["y"].astype(np.float64))
             k["rays"] = r.astype(np.float32)
     tri_ctx, tri_store, tri_jobs = [], [], []
+    kf_max_features = max(2048, (max(len(k) for k in kps) + 255) // 256 * 256)
     # CreateNewMapPoints of a window group's key frames runs on a host thread and a queue of its own (tri_pool below): the group's local BA waits
     # for it (LocalMapping's order for a key frame: LocalMapping.cpp:80-110), but the NEXT step's CreateNewMapPoints -- other camera streams' key
     # frames -- no longer queues behind this step's Levenberg rounds (tri_pools below).  CMS_BENCH_TRI_INLINE=1: called by the BA worker itself, on the group's queue
@@ -424,7 +428,8 @@ def main():
         cg = api.Context(camd, nfeatures=nfeat, max_batch=1, device=local_rank)
         if mprio:
             del os.environ["CMS_FRAME_STREAM_PRIORITY"]
-        st = api.KeyframeStore(cg, max_keyframes=len(grp) * (tri_nn + 1), max_features=2048, max_nodes=1024)
+        # one more slot per window: where the key frame made from this step's frame lands (cms_kfstore_put_from_frame, see mapping_side below)
+        st = api.KeyframeStore(cg, max_keyframes=len(grp) * (tri_nn + 2), max_features=kf_max_features, max_nodes=1024)
         jobs_g = []
         for wi in range(len(grp)):
             S = tri_sets[(gi + wi) % len(tri_sets)]
@@ -444,6 +449,117 @@ def main():
         if os.environ.get("CMS_BENCH_SHARED_STREAMS", "") != "":
             for ba in grp:                   # developer knob: the whole mapping side of a group on ONE stream (cms_ba_set_stream).  Measured
                 ba.set_stream(cg.stream)     # slower (15.9 against 14.4 ms per step): the resets and CreateNewMapPoints then queue behind the group's BA
+
+    # ---- the rest of LocalMapping's per-key-frame sequence (LocalMapping::Run, LocalMapping.cpp:52-117, 388-466), inside the timed region since round 5:
+    #   ProcessNewKeyFrame   the key frame made from this step's frame enters the store: cms_kfstore_put_from_frame -- key points, descriptors, rays and
+    #                        the frame grid device to device out of the frame context, FeatureVector + map-point slots from a pinned block; enqueued by
+    #                        the frame path's thread behind the frame's tracking, like the KeyFrame constructor on the Tracking thread
+    #   CreateNewMapPoints   as before (against 20 resident neighbours)
+    #   SearchInNeighbors    both Fuse directions as jobs of ONE cms_kfstore_fuse_search call per window group: the key frame's map points into each
+    #                        of its 20 neighbours, the neighbours' map points (union) into the key frame; map points already seen by the target skipped
+    #   LocalBundleAdjustment as before
+    #   pose write-back      cms_kfstore_update_poses for the window's 20 key frames (Optimizer.cpp:419-431), after the window's read-back
+    # The synthetic streams are not one consistent scene (frames are drifting textures, the CreateNewMapPoints scenes and the BA windows are separate
+    # synthetic problems), so the inserted key frame lands in a slot of its own next to the scene's key frames, and the write-back writes the scene's
+    # key frames' own poses: every call's COST is in the step, CreateNewMapPoints' input geometry stays consistent.  CMS_BENCH_MAPPING_MINIMAL=1 (and
+    # config.mapping_side.minimal): CreateNewMapPoints + local BA only, round 4's step.
+    mapping_full_default = os.environ.get("CMS_BENCH_MAPPING_MINIMAL", "") == ""
+    import ctypes as C_
+    L_ = api.lib()
+    def kf_info_of(S, b):
+        k, d = S.fetched[b]
+        n = len(k)
+        node = (d[:, 0].astype(np.int32) * 4 + (d[:, 1] >> 6)) % 1024           # FeatureVector stand-in: features binned by descriptor bits (KeyFrame::ComputeBoW is DBoW2 on the host)
+        order = np.lexsort((np.arange(n), node)).astype(np.int32)
+        ids, starts = np.unique(node[order], return_index=True)
+        pose = S.lm[b]["pose15"]
+        a = dict(n=n, R=np.ascontiguousarray(pose[:9], np.float32), t=np.ascontiguousarray(pose[9:12], np.float32), Ow=np.ascontiguousarray(pose[12:15], np.float32),
+                 mp=np.where(np.arange(n) % 3 == 0, -1, np.arange(n)).astype(np.int32), nid=ids.astype(np.int32),
+                 noff=np.concatenate([starts, [n]]).astype(np.int32), nfeat=order)
+        a["args"] = (b, n, api._p(a["R"]), api._p(a["t"]), api._p(a["Ow"]), C_.c_float(2.0), api._p(a["mp"]), len(a["nid"]), api._p(a["nid"]), api._p(a["noff"]), api._p(a["nfeat"]))
+        return a
+    kf_frame = [min(B - 1, w * args.ba_every + args.ba_every - 1) for w in range(n_ba)]      # the frame of every window's stream that becomes its key frame
+    kf_infos = [[kf_info_of(S, kf_frame[w]) for w in range(n_ba)] for S in sets]
+    def put_keyframes(set_idx):
+        """ProcessNewKeyFrame for the n_ba key frames of this step's batch: behind the batch's tracking on the frame path's stream"""
+        for gi, ids in enumerate(group_ids):
+            h = tri_store[gi].h
+            slot0 = len(ids) * (tri_nn + 1)
+            for wi, w in enumerate(ids):
+                a = kf_infos[set_idx][w]["args"]
+                rc = L_.cms_kfstore_put_from_frame(h, slot0 + wi, ctx.h, *a)
+                if rc < 0:
+                    raise RuntimeError("cms_kfstore_put_from_frame: %s" % L_.cms_last_error().decode())
+    def fuse_jobs_of(S, base):
+        """SearchInNeighbors for the scene's current key frame (slot `base`) and its neighbours (base + 1 ...): (slot, map points) jobs"""
+        kfs, X, sf = S["kfs"], S["X"], S["scale_factors"]
+        def mps(kf):
+            sel = np.flatnonzero(kf["mp"] >= 0)
+            pid = kf["point"][sel]
+            pos = X[pid].astype(np.float32)
+            v = pos - np.asarray(kf["Ow"], np.float32)[None, :]
+            dist = np.linalg.norm(v, axis=1).astype(np.float32)
+            maxd = (dist * sf[kf["octave"][sel]]).astype(np.float32)            # MapPoint::UpdateNormalAndDepth (MapPoint.cpp:332-373)
+            return pid, pos, (v / dist[:, None]).astype(np.float32), (maxd / sf[-1]).astype(np.float32), maxd, kf["desc"][sel]
+        cur = mps(kfs[0])
+        have = [set(k["point"][k["mp"] >= 0].tolist()) for k in kfs]
+        jobs = []
+        for i in range(1, len(kfs)):                                           # the key frame's map points into neighbour i
+            skip = np.fromiter((p in have[i] for p in cur[0]), np.uint8, len(cur[0]))
+            jobs.append((base + i, skip) + cur[1:])
+        seen, parts = set(), []
+        for i in range(1, len(kfs)):                                           # the neighbours' map points (union) into the key frame
+            m = mps(kfs[i])
+            new = np.array([p not in seen for p in m[0]], bool)
+            seen.update(m[0][new].tolist())
+            parts.append(tuple(a[new] for a in m))
+        u = tuple(np.concatenate([q[j] for q in parts]) for j in range(6))
+        jobs.append((base, np.fromiter((p in have[0] for p in u[0]), np.uint8, len(u[0]))) + u[1:])
+        return jobs
+    fuse_prep = []
+    for gi, ids in enumerate(group_ids):
+        jobs = []
+        for wi in range(len(ids)):
+            jobs += fuse_jobs_of(tri_sets[(gi + wi) % len(tri_sets)], wi * (tri_nn + 1))
+        off = np.concatenate([[0], np.cumsum([len(j[1]) for j in jobs])]).astype(np.int32)
+        n_mp = int(off[-1])
+        def pin(arr):                                                          # pinned host copies: the call's uploads are asynchronous DMA transfers
+            arr = np.ascontiguousarray(arr)
+            pa = api.PinnedArray((max(arr.nbytes, 16),))
+            v = pa.array[:arr.nbytes].view(arr.dtype).reshape(arr.shape); v[...] = arr
+            return pa, v
+        cols = [pin(np.concatenate([j[c] for j in jobs])) for c in range(1, 7)]   # skip, pos, normal, min, max, desc
+        slots = np.array([j[0] for j in jobs], np.int32)
+        bi = np.zeros(n_mp, np.int32); bd = np.zeros(n_mp, np.int32)
+        fuse_prep.append(dict(keep=(cols, slots, off, bi, bd), njobs=len(jobs), n_mp=n_mp, best_idx=bi,
+                              args=(len(jobs), api._p(slots), api._p(off)) + tuple(api._p(v) for _, v in cols) + (C_.c_float(3.0), api._p(bi), api._p(bd))))
+    store_lock = [threading.Lock() for _ in range(n_grp)]         # a store's calls from its mapping thread and from the pool's write-backs, one at a time
+    upd_prep = []
+    for gi, ids in enumerate(group_ids):
+        per_w = []
+        for wi in range(len(ids)):
+            S = tri_sets[(gi + wi) % len(tri_sets)]
+            sl = np.arange(wi * (tri_nn + 1), wi * (tri_nn + 1) + 20, dtype=np.int32)
+            R = np.ascontiguousarray(np.stack([np.asarray(k["R"], np.float32).reshape(9) for k in S["kfs"][:20]])); t = np.ascontiguousarray(np.stack([k["t"] for k in S["kfs"][:20]]), np.float32)
+            Ow = np.ascontiguousarray(np.stack([k["Ow"] for k in S["kfs"][:20]]), np.float32)
+            per_w.append(dict(keep=(sl, R, t, Ow), args=(20, api._p(sl), api._p(R), api._p(t), api._p(Ow))))
+        upd_prep.append(per_w)
+    map_acc = {"fuse_ms": 0.0, "fuse_n": 0, "fused": 0, "put_ms": 0.0, "put_n": 0, "upd_ms": 0.0, "upd_n": 0}
+    def fuse_group(gi):
+        t0_ = time.perf_counter()
+        with store_lock[gi]:
+            rc = L_.cms_kfstore_fuse_search(tri_store[gi].h, *fuse_prep[gi]["args"])
+        if rc < 0:
+            raise RuntimeError("cms_kfstore_fuse_search: %s" % L_.cms_last_error().decode())
+        map_acc["fuse_ms"] += 1e3 * (time.perf_counter() - t0_); map_acc["fuse_n"] += 1
+        map_acc["fused"] = int((fuse_prep[gi]["best_idx"] >= 0).sum())
+    def write_back(gi, wi):
+        t0_ = time.perf_counter()
+        with store_lock[gi]:
+            rc = L_.cms_kfstore_update_poses(tri_store[gi].h, *upd_prep[gi][wi]["args"])
+        if rc < 0:
+            raise RuntimeError("cms_kfstore_update_poses: %s" % L_.cms_last_error().decode())
+        map_acc["upd_ms"] += 1e3 * (time.perf_counter() - t0_); map_acc["upd_n"] += 1
 
     schur_acc = {"ms": 0.0, "n": 0}
     worker_ms = {}
@@ -489,7 +605,7 @@ def main():
             res = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=False)
         ms, nl = grp[0].profile_get()
         schur_acc["ms"] += ms; schur_acc["n"] += nl
-        outs = [wpool.submit(finish_window, ba) for ba in grp]
+        outs = [wpool.submit(finish_window, ba, (gi, wi)) for wi, ba in enumerate(grp)]
         if step_trace is not None:
             step_trace.append(("worker %d" % gi, t_ba0, t_w, t_t, t_o, time.perf_counter()))
         for k_, v_ in (("wait_for_windows", t_w - t_ba0), ("create_new_map_points", t_t - t_w), ("optimize_many", t_o - t_t), ("hand_over", time.perf_counter() - t_o)):
@@ -539,8 +655,11 @@ def main():
     ba_first = os.environ.get("CMS_BENCH_BA_FIRST", "")     # developer knob: hand the mapping side to its threads BEFORE the frame path is enqueued (value = head start in us)
     def timed_tri(gi):
         t0_ = time.perf_counter()
-        r = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=True)      # (copies: the store's buffers serve the next call while this result waits)
+        with store_lock[gi]:
+            r = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=True)      # (copies: the store's buffers serve the next call while this result waits)
         worker_ms["create_new_map_points_own_thread"] = worker_ms.get("create_new_map_points_own_thread", 0.0) + 1e3 * (time.perf_counter() - t0_)
+        if life.get("mapping_full"):
+            fuse_group(gi)          # SearchInNeighbors: both Fuse directions of the group's key frames, one call (the group's local BA waits for it too)
         return r
     def submit_tri(gi):
         return None if tri_inline else tri_pools[gi].submit(timed_tri, gi)
@@ -614,6 +733,10 @@ def main():
                 ths = [pool.submit(ba_worker, grp, gi, keep) for gi, grp in enumerate(groups)]
         if part != "ba":
             S.enqueue_tracking(ext_stream)
+            if life["on"] and life.get("mapping_full"):
+                t_put = time.perf_counter()
+                put_keyframes(i % 2)        # ProcessNewKeyFrame: this batch's key frames enter the stores (device to device, behind the tracking just enqueued)
+                map_acc["put_ms"] += 1e3 * (time.perf_counter() - t_put); map_acc["put_n"] += 1
         if step_trace is not None:
             step_trace.append(("tracking enqueued", time.perf_counter()))
             ctx.sync()
@@ -659,10 +782,13 @@ def main():
                     f.result()[0].close()
 
     step_times = [] if os.environ.get("CMS_BENCH_STEP_TIMES", "") != "" else None      # developer knob: host wall time of every timed step (stderr)
-    def timed(streaming, lifecycle=True, steps=None, only="", pipeline=None):
+    def timed(streaming, lifecycle=True, steps=None, only="", pipeline=None, mapping_full=None):
         steps = args.steps if steps is None else steps
         part = only or part_env
         life["part"] = part
+        life["mapping_full"] = (mapping_full_default if mapping_full is None else mapping_full) and lifecycle and not tri_inline
+        for k_ in map_acc:
+            map_acc[k_] = 0 if k_ == "fused" else 0.0
         life["on"] = lifecycle and part != "frames"
         life["pipeline"] = pipeline_default if pipeline is None else pipeline
         if streaming:
@@ -756,6 +882,19 @@ def main():
             tb = step_trace[b0][1]
             print(step_trace[b0][0] + ": " + "; ".join("%s %s" % (e[0], " ".join("%.2f" % (1e3 * (t - tb)) for t in e[1:])) for e in sorted(step_trace[b0 + 1:b1], key=lambda e: e[-1])), file=sys.stderr)
         step_trace.clear()
+    # what the rest of LocalMapping's sequence took inside the headline pass (host wall time of the calls; their device work overlaps the step)
+    mapping_side = {"in_timed_region": bool(life.get("mapping_full")),
+                    "calls_per_key_frame": ["cms_kfstore_put_from_frame (ProcessNewKeyFrame: frame -> store, device to device)", "cms_kfstore_create_new_map_points",
+                                            "cms_kfstore_fuse_search (SearchInNeighbors: key frame's map points into 20 neighbours + the neighbours' into the key frame)",
+                                            "cms_ba_create / cms_ba_optimize_many / cms_ba_read (LocalBundleAdjustment)", "cms_kfstore_update_poses (20 key-frame poses written back)"],
+                    "put_from_frame_ms_per_step": round(map_acc["put_ms"] / max(map_acc["put_n"], 1), 3), "key_frames_per_step": n_ba,
+                    "fuse_search_ms_per_group_call": round(map_acc["fuse_ms"] / max(map_acc["fuse_n"], 1), 3),
+                    "fuse_jobs_per_step": int(sum(fq["njobs"] for fq in fuse_prep)), "fuse_map_points_per_step": int(sum(fq["n_mp"] for fq in fuse_prep)),
+                    "fused_matches_last_group_call": int(map_acc["fused"]),
+                    "update_poses_ms_per_window": round(map_acc["upd_ms"] / max(map_acc["upd_n"], 1), 4),
+                    "note": "LocalMapping::Run's sequence per key frame (LocalMapping.cpp:52-117, 388-466) inside the timed region since round 5.  The synthetic streams are not one "
+                            "consistent scene: the inserted key frame lands in a slot of its own, the write-back writes the scene key frames' own poses -- every call's cost is in "
+                            "the step, CreateNewMapPoints' geometry stays consistent.  `minimal` = the same steps with CreateNewMapPoints + local BA only (round 4's step)"}
     create_ms_in_step = acc["create_ms"] / max(acc["create_n"], 1)
     worker_break = {k_: round(v_ / max(worker_ms.get("n", 1), 1), 3) for k_, v_ in worker_ms.items() if k_ != "n"}      # per window group and step
     if part:
@@ -796,6 +935,11 @@ def main():
         unpipelined = {"value": round(total_frames_per_step * args.unpipelined_steps / dt_u, 2), "ms_per_step": round(1e3 * dt_u / args.unpipelined_steps, 3),
                        "ba_ms_per_step": round(ba_ms_u, 3), "steps": args.unpipelined_steps,
                        "note": "the same steps, each waiting for its own CreateNewMapPoints + local BA before the next step's frames are enqueued (BENCH_r03's loop)"}
+    # ---- round 4's mapping side for comparison: CreateNewMapPoints + local BA only (no key-frame insertion, no Fuse, no pose write-back)
+    if args.unpipelined_steps > 0 and n_ba > 0 and mapping_side["in_timed_region"]:
+        dt_n, _, ba_ms_n, _ = timed(False, steps=args.unpipelined_steps, mapping_full=False)
+        mapping_side["minimal"] = {"value": round(total_frames_per_step * args.unpipelined_steps / dt_n, 2), "ms_per_step": round(1e3 * dt_n / args.unpipelined_steps, 3),
+                                   "ba_ms_per_step": round(ba_ms_n, 3), "steps": args.unpipelined_steps}
     # ---- the mapping side alone (no frame path in the step): what the Levenberg rounds' kernels take when nothing else shares the chip
     mapping_only = None
     if args.mapping_only_steps > 0 and n_ba > 0:
@@ -1038,6 +1182,12 @@ def main():
         for _ in range(2):
             orc.create_new_map_points(ocam, oks[0][0], [k for k, _ in oks[1:]], T0["scale_factors"], T0["level_sigma2"], T0["kfs"][0]["mp"].copy())
         t_tri = (time.perf_counter() - t1) / 2
+        # SearchInNeighbors' Fuse searches for one key frame (both directions: 21 jobs), the oracle's scan
+        t1 = time.perf_counter()
+        inv_s2 = (np.float32(1.0) / (T0["scale_factors"] * T0["scale_factors"])).astype(np.float32)
+        for slot_, skip_, pos_, nrm_, mind_, maxd_, desc_ in fuse_jobs_of(T0, 0):
+            orc.fuse_search(ocam, oks[slot_][0], skip_, pos_, nrm_, mind_, maxd_, desc_, 3.0, T0["scale_factors"], inv_s2)
+        t_fuse = time.perf_counter() - t1
         while len(cpu_ba_ms) < 3:            # three windows, one after the other, one thread
             t1 = time.perf_counter()
             orc.ba_run(probs[len(cpu_ba_ms) % n_ba])
@@ -1047,13 +1197,13 @@ def main():
         for b in range(min(n, 8)):
             orc.pose_optimize(pose_probs[b])
         t_pose = (time.perf_counter() - t1) / min(n, 8)
-        per_frame = t_ext / n + t_match + t_local + t_pose + (t_ba + t_tri) / args.ba_every
+        per_frame = t_ext / n + t_match + t_local + t_pose + (t_ba + t_tri + t_fuse) / args.ba_every
         cpu = {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames remap+extract (%.1f ms/frame), frame-to-frame SearchByProjection (%.2f ms/frame), local-map search "
-                         "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), CreateNewMapPoints (%.1f ms per key frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
+                         "(%.2f ms/frame), pose-only optimisation (%.2f ms/frame), CreateNewMapPoints (%.1f ms per key frame), SearchInNeighbors' Fuse searches (%.1f ms per key frame), %d local-BA windows (%.1f ms each, 1 per %d frames); "
                          "oracle/liborc.so, single thread (two_threads_like_the_reference: the same timings with local BA on a second core next to tracking, System.cpp:108-127)" %
-                         (n, 1e3 * t_ext / n, 1e3 * t_match, 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, len(cpu_ba_ms), 1e3 * t_ba, args.ba_every),
-               "two_threads_like_the_reference": round(1.0 / max(t_ext / n + t_match + t_local + t_pose, (t_ba + t_tri) / args.ba_every), 3),
+                         (n, 1e3 * t_ext / n, 1e3 * t_match, 1e3 * t_local, 1e3 * t_pose, 1e3 * t_tri, 1e3 * t_fuse, len(cpu_ba_ms), 1e3 * t_ba, args.ba_every),
+               "two_threads_like_the_reference": round(1.0 / max(t_ext / n + t_match + t_local + t_pose, (t_ba + t_tri + t_fuse) / args.ba_every), 3),
                "host_cores_available": os.cpu_count()}
 
     # ---- one LocalBundleAdjustment call as the reference issues it (cms_ba_run: graph set-up + optimisation + read-back + destroy), chip quiet
@@ -1141,7 +1291,7 @@ def main():
                                            "note": "every step creates its %d windows from the problems' host arrays (cms_ba_create: host work lists, one pinned upload), optimises "
                                                    "them, reads poses / points / outlier flags back (cms_ba_read) and destroys them; a pool of host threads builds step s + 1's "
                                                    "windows and finishes step s - 1's while step s runs, all inside the timed region" % n_ba},
-                       "ba_worker_ms": worker_break, "optimise_only": optimise_only, "unpipelined": unpipelined, "mapping_only": mapping_only,
+                       "ba_worker_ms": worker_break, "mapping_side": mapping_side, "optimise_only": optimise_only, "unpipelined": unpipelined, "mapping_only": mapping_only,
                        "step_pipelining": ("the mapping side of step s (CreateNewMapPoints + local BA, windows created / read back / destroyed) is waited for at the end of step s + 1: "
                                            "it overlaps the next batch's frame path like LocalMapping overlaps Tracking; all of it inside the timed region") if pipeline_default else "off (CMS_BENCH_NO_PIPELINE)", "ba_views": args.ba_views, "ba_views_random": random_views,
                        "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],

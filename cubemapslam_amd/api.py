@@ -125,6 +125,11 @@ def lib():
         L.cms_kfstore_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cms_kfstore_update.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.cms_kfstore_fuse_search.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_void_p, C.c_void_p]
+        L.cms_kfstore_put_from_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cms_kfstore_update_poses.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.cms_kfstore_debug_fetch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 12
+        L.cms_ba_debug_fetch_plan.argtypes = [C.c_void_p] * 14
         L.cms_kfstore_create_new_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.cms_distinctive_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cms_update_normal_and_depth.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
@@ -571,8 +576,6 @@ class KeyframeStore:
         R, t, Ow = f32(np.asarray(kf["R"]).reshape(9)), f32(kf["t"]), f32(kf["Ow"])
         mp, nid, noff, nfeat = i32(kf.get("mp")), i32(kf["node_id"]), i32(kf["node_off"]), i32(kf["node_feat"])
         L = lib()
-        L.cms_kfstore_put_from_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,
-                                                 C.c_void_p, C.c_void_p, C.c_void_p]
         _chk(L.cms_kfstore_put_from_frame(self.h, slot, src_ctx.h, b, n, _p(R), _p(t), _p(Ow), float(kf["median_depth"]), _p(mp), len(nid), _p(nid), _p(noff), _p(nfeat)),
              "cms_kfstore_put_from_frame")
 
@@ -580,7 +583,6 @@ class KeyframeStore:
         """cms_kfstore_debug_fetch: the slot's device contents as a dict"""
         hdr = np.zeros(21, np.uint32); misc = np.zeros(2, np.int32)
         L = lib()
-        L.cms_kfstore_debug_fetch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 12
         _chk(L.cms_kfstore_debug_fetch(self.h, slot, *([None] * 10), _p(hdr), _p(misc)), "cms_kfstore_debug_fetch")
         n, nn = int(hdr[1]), int(hdr[3])
         o = dict(kps=np.zeros(n, KP_DTYPE), desc=np.zeros((n, 32), np.uint8), rays=np.zeros((n, 3), np.float32), mp=np.zeros(n, np.int32), feat_node=np.zeros(n, np.int32),
@@ -697,7 +699,6 @@ class BundleAdjuster:
                    rm_chunk=np.zeros((P, 4), np.int32), rm_cost=np.zeros(P + 2, np.uint32), run_mf=np.zeros((P, 64), np.uint32), run_fl=np.zeros((P, 64, 12), np.uint32))
         cnt = np.zeros(8, np.int32)
         L = lib()
-        L.cms_ba_debug_fetch_plan.argtypes = [C.c_void_p] * 14
         _chk(L.cms_ba_debug_fetch_plan(self.h, _p(out["pinv"]), _p(out["perm"]), _p(out["info"]), _p(out["pt_off"]), _p(out["e_pose"]), _p(out["e_point"]),
                                        _p(out["e_face"]), _p(out["chunk_e0"]), _p(out["rm_chunk"]), _p(out["rm_cost"]), _p(out["run_mf"]), _p(out["run_fl"]), _p(cnt)),
              "cms_ba_debug_fetch_plan")

@@ -113,6 +113,7 @@ struct cms_ba {
   uint8_t* d_pcopy = nullptr; uint8_t* d_lo_copy = nullptr; uint64_t* d_run_sig = nullptr; double* d_rb_pts = nullptr; uint8_t* d_rb_flags = nullptr;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
+  hipEvent_t ev_setup = nullptr;      // cms_ba_set_stream: marks the end of the window's set-up on the stream it was created on
   hipStream_t grp_stream = nullptr;   // the stream of the group whose rounds may still be in flight for this window (ba_optimize_group; cleared at its successful end)
   bool async_pending = false;   // something asynchronous (upload, reset, a group's rounds) was enqueued on `stream` and nothing has waited for it yet
   bool gsum_clean = false;      // slice 0 of the Schur partial sums (the ONE global copy the workgroups add to, BaSe::gsum) is all zero: true after
@@ -171,13 +172,36 @@ static hipError_t ba_wait_stream(hipStream_t s) {
     if (q != hipErrorNotReady) return q == hipSuccess ? hipStreamSynchronize(s) : q;
   }
 }
+// (a stream may come back with work still queued on it -- cms_ba_set_stream hands a window's set-up over to the group's stream with an event, not a
+// host wait: whoever takes the stream next simply queues behind that work.  Only a stream in an error state is destroyed.)
 static void ba_stream_give(int device, hipStream_t s) {
   BaStreamPool& pl = ba_stream_pool();
   {
+    const hipError_t q = hipStreamQuery(s);
     std::lock_guard<std::mutex> lk(pl.mu);
-    if (device >= 0 && device < 64 && pl.idle[device].size() < 256 && hipStreamQuery(s) == hipSuccess) { pl.idle[device].push_back(s); return; }
+    if (device >= 0 && device < 64 && pl.idle[device].size() < 256 && (q == hipSuccess || q == hipErrorNotReady)) { pl.idle[device].push_back(s); return; }
   }
   hipStreamDestroy(s);
+}
+// events for such hand-overs, pooled like the streams
+struct BaEventPool { std::mutex mu; std::vector<hipEvent_t> idle[64]; };
+static BaEventPool& ba_event_pool() { static BaEventPool* p = new BaEventPool; return *p; }
+static hipEvent_t ba_event_take(int device) {
+  BaEventPool& pl = ba_event_pool();
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (device >= 0 && device < 64 && !pl.idle[device].empty()) { hipEvent_t e = pl.idle[device].back(); pl.idle[device].pop_back(); return e; }
+  }
+  hipEvent_t e = nullptr;
+  return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr;
+}
+static void ba_event_give(int device, hipEvent_t e) {
+  BaEventPool& pl = ba_event_pool();
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (device >= 0 && device < 64 && pl.idle[device].size() < 1024) { pl.idle[device].push_back(e); return; }
+  }
+  hipEventDestroy(e);
 }
 
 // ---- memory of a window comes from a per-device pool.  A window of configs[3] size needs ~50 device buffers: allocated and freed one by
@@ -331,6 +355,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->grp_scal_host) ba_pin_give(b->device, b->grp_scal_host, b->grp_pin_bytes[1]);
   if (b->grp_lm_host) ba_pin_give(b->device, b->grp_lm_host, b->grp_pin_bytes[2]);
   for (hipEvent_t e : b->prof_ev) hipEventDestroy(e);
+  if (b->ev_setup) ba_event_give(b->device, b->ev_setup);      // (the waits on it are long through: the window's work on the new stream was waited for above)
   if (b->stream && b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else hipStreamDestroy(b->stream); }
   delete b;
 }
@@ -341,8 +366,20 @@ extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullpt
 extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
   if (!b || !hip_stream) return cms_fail(CMS_ERR_ARG, "cms_ba_set_stream: bad argument");
   HIPCHK(hipSetDevice(b->device));
-  HIPCHK(ba_wait_stream(b->stream));          // (the window's upload and gather: a few hundred microseconds the building thread need not spin through)
-  b->async_pending = false;
+  // The window's set-up (one upload, one kernel) may still be queued on the stream it was created on: the NEW stream waits for it on the device
+  // (an event), the calling thread does not -- it used to spin here for the ~1-2 ms the set-up takes to get its turn inside a busy step, a host
+  // core per window-building thread (CMS_BA_SET_STREAM_WAIT=1: that host wait, A/B).
+  static const bool host_wait = getenv("CMS_BA_SET_STREAM_WAIT") != nullptr;
+  if (host_wait || !b->async_pending || (hipStream_t)hip_stream == b->stream) {
+    HIPCHK(ba_wait_stream(b->stream));
+    b->async_pending = false;
+  } else {
+    if (!b->ev_setup) b->ev_setup = ba_event_take(b->device);
+    if (!b->ev_setup) return cms_fail(CMS_ERR_HIP, "cms_ba_set_stream: no event");
+    HIPCHK(hipEventRecord(b->ev_setup, b->stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, b->ev_setup, 0));
+    // (async_pending stays set: the set-up now counts as pending work of the new stream; optimise / read / destroy order themselves behind it)
+  }
   if (b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else HIPCHK(hipStreamDestroy(b->stream)); }
   b->stream = (hipStream_t)hip_stream; b->own_stream = false;
   return CMS_OK;
