@@ -476,20 +476,33 @@ def main():
         a = dict(n=n, R=np.ascontiguousarray(pose[:9], np.float32), t=np.ascontiguousarray(pose[9:12], np.float32), Ow=np.ascontiguousarray(pose[12:15], np.float32),
                  mp=np.where(np.arange(n) % 3 == 0, -1, np.arange(n)).astype(np.int32), nid=ids.astype(np.int32),
                  noff=np.concatenate([starts, [n]]).astype(np.int32), nfeat=order)
-        a["args"] = (b, n, api._p(a["R"]), api._p(a["t"]), api._p(a["Ow"]), C_.c_float(2.0), api._p(a["mp"]), len(a["nid"]), api._p(a["nid"]), api._p(a["noff"]), api._p(a["nfeat"]))
+        a["b"] = b
         return a
     kf_frame = [min(B - 1, w * args.ba_every + args.ba_every - 1) for w in range(n_ba)]      # the frame of every window's stream that becomes its key frame
     kf_infos = [[kf_info_of(S, kf_frame[w]) for w in range(n_ba)] for S in sets]
+    class KfFromFrame(C_.Structure):      # cms_kf_from_frame (include/cubemapslam_hip.h)
+        _fields_ = [("slot", C_.c_int), ("b", C_.c_int), ("n", C_.c_int), ("Rcw", C_.c_void_p), ("tcw", C_.c_void_p), ("Ow", C_.c_void_p), ("median_depth", C_.c_float),
+                    ("mp", C_.c_void_p), ("nnodes", C_.c_int), ("node_id", C_.c_void_p), ("node_off", C_.c_void_p), ("node_feat", C_.c_void_p)]
+    L_.cms_kfstore_put_from_frames.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_int, C_.c_void_p]
+    put_items = []                                      # [set][group] -> array of items: one library call per window group and step (a Python loop of 32
+    for j_ in range(len(sets)):                         # calls re-took the interpreter lock 64 times next to 20 busy threads: 6 ms per step)
+        per_g = []
+        for gi, ids in enumerate(group_ids):
+            arr = (KfFromFrame * len(ids))()
+            for wi, w in enumerate(ids):
+                a = kf_infos[j_][w]
+                q = arr[wi]
+                q.slot = len(ids) * (tri_nn + 1) + wi; q.b = a["b"]; q.n = a["n"]; q.Rcw = a["R"].ctypes.data; q.tcw = a["t"].ctypes.data; q.Ow = a["Ow"].ctypes.data
+                q.median_depth = 2.0; q.mp = a["mp"].ctypes.data; q.nnodes = len(a["nid"]); q.node_id = a["nid"].ctypes.data; q.node_off = a["noff"].ctypes.data
+                q.node_feat = a["nfeat"].ctypes.data
+            per_g.append(arr)
+        put_items.append(per_g)
     def put_keyframes(set_idx):
         """ProcessNewKeyFrame for the n_ba key frames of this step's batch: behind the batch's tracking on the frame path's stream"""
         for gi, ids in enumerate(group_ids):
-            h = tri_store[gi].h
-            slot0 = len(ids) * (tri_nn + 1)
-            for wi, w in enumerate(ids):
-                a = kf_infos[set_idx][w]["args"]
-                rc = L_.cms_kfstore_put_from_frame(h, slot0 + wi, ctx.h, *a)
-                if rc < 0:
-                    raise RuntimeError("cms_kfstore_put_from_frame: %s" % L_.cms_last_error().decode())
+            rc = L_.cms_kfstore_put_from_frames(tri_store[gi].h, ctx.h, len(ids), put_items[set_idx][gi])
+            if rc < 0:
+                raise RuntimeError("cms_kfstore_put_from_frames: %s" % L_.cms_last_error().decode())
     def fuse_jobs_of(S, base):
         """SearchInNeighbors for the scene's current key frame (slot `base`) and its neighbours (base + 1 ...): (slot, map points) jobs"""
         kfs, X, sf = S["kfs"], S["X"], S["scale_factors"]
@@ -530,10 +543,11 @@ def main():
             return pa, v
         cols = [pin(np.concatenate([j[c] for j in jobs])) for c in range(1, 7)]   # skip, pos, normal, min, max, desc
         slots = np.array([j[0] for j in jobs], np.int32)
-        bi = np.zeros(n_mp, np.int32); bd = np.zeros(n_mp, np.int32)
-        fuse_prep.append(dict(keep=(cols, slots, off, bi, bd), njobs=len(jobs), n_mp=n_mp, best_idx=bi,
+        pbi, bi = pin(np.zeros(n_mp, np.int32)); pbd, bd = pin(np.zeros(n_mp, np.int32))
+        fuse_prep.append(dict(keep=(cols, slots, off, pbi, pbd), njobs=len(jobs), n_mp=n_mp, best_idx=bi,
                               args=(len(jobs), api._p(slots), api._p(off)) + tuple(api._p(v) for _, v in cols) + (C_.c_float(3.0), api._p(bi), api._p(bd))))
-    store_lock = [threading.Lock() for _ in range(n_grp)]         # a store's calls from its mapping thread and from the pool's write-backs, one at a time
+    store_lock = [threading.Lock() for _ in range(n_grp)]         # a store's calls one at a time (its mapping thread; the optimise-only pass's worker)
+    wb_queue = [collections.deque() for _ in range(n_grp)]        # pose write-backs of read-back windows, applied by the group's mapping thread before its next key frames
     upd_prep = []
     for gi, ids in enumerate(group_ids):
         per_w = []
@@ -554,12 +568,17 @@ def main():
         map_acc["fuse_ms"] += 1e3 * (time.perf_counter() - t0_); map_acc["fuse_n"] += 1
         map_acc["fused"] = int((fuse_prep[gi]["best_idx"] >= 0).sum())
     def write_back(gi, wi):
-        t0_ = time.perf_counter()
-        with store_lock[gi]:
+        """a window was read back (pool thread): its key frames' poses go to the store with the mapping thread's next turn, like LocalMapping applies a
+        local BA's result before it takes the next key frame"""
+        wb_queue[gi].append(wi)
+    def apply_write_backs(gi):
+        while wb_queue[gi]:
+            wi = wb_queue[gi].popleft()
+            t0_ = time.perf_counter()
             rc = L_.cms_kfstore_update_poses(tri_store[gi].h, *upd_prep[gi][wi]["args"])
-        if rc < 0:
-            raise RuntimeError("cms_kfstore_update_poses: %s" % L_.cms_last_error().decode())
-        map_acc["upd_ms"] += 1e3 * (time.perf_counter() - t0_); map_acc["upd_n"] += 1
+            if rc < 0:
+                raise RuntimeError("cms_kfstore_update_poses: %s" % L_.cms_last_error().decode())
+            map_acc["upd_ms"] += 1e3 * (time.perf_counter() - t0_); map_acc["upd_n"] += 1
 
     schur_acc = {"ms": 0.0, "n": 0}
     worker_ms = {}
@@ -656,6 +675,8 @@ def main():
     def timed_tri(gi):
         t0_ = time.perf_counter()
         with store_lock[gi]:
+            if life.get("mapping_full"):
+                apply_write_backs(gi)   # poses of the windows read back since this thread's last turn (Optimizer.cpp:419-431)
             r = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=True)      # (copies: the store's buffers serve the next call while this result waits)
         worker_ms["create_new_map_points_own_thread"] = worker_ms.get("create_new_map_points_own_thread", 0.0) + 1e3 * (time.perf_counter() - t0_)
         if life.get("mapping_full"):
@@ -826,6 +847,10 @@ def main():
         for f in life["reads"]:
             f.result()
         life["reads"] = []
+        if life.get("mapping_full"):
+            for gi_ in range(n_grp):           # the last read-backs' pose write-backs (no further mapping-thread turn would apply them)
+                with store_lock[gi_]:
+                    apply_write_backs(gi_)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()

@@ -114,6 +114,7 @@ struct cms_ba {
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
   hipEvent_t ev_setup = nullptr;      // cms_ba_set_stream: marks the end of the window's set-up on the stream it was created on
+  bool setup_wait_pending = false;    // ... and b->stream has not been told to wait for it yet (ba_order_behind_setup, at the window's first use there)
   hipStream_t grp_stream = nullptr;   // the stream of the group whose rounds may still be in flight for this window (ba_optimize_group; cleared at its successful end)
   bool async_pending = false;   // something asynchronous (upload, reset, a group's rounds) was enqueued on `stream` and nothing has waited for it yet
   bool gsum_clean = false;      // slice 0 of the Schur partial sums (the ONE global copy the workgroups add to, BaSe::gsum) is all zero: true after
@@ -345,6 +346,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   // nothing of this window may still be running when its memory goes back to the pool.  A window on a stream of its own waits for that
   // stream; a window on a stream it shares (cms_ba_set_stream: the group's stream, busy with the NEXT windows by now) only when it has
   // something of its own pending there -- optimise / read return with the window's work complete
+  if (b->setup_wait_pending) { (void)hipEventSynchronize(b->ev_setup); b->setup_wait_pending = false; b->async_pending = false; }      // (never used on its new stream: only its set-up can be in flight)
   if (b->stream && (b->own_stream || b->async_pending)) (void)ba_wait_stream(b->stream);
   // ... and a window of a group whose call ended early (an error between two rounds): the group's kernels run on the group OWNER's stream
   if (b->async_pending && b->grp_stream && b->grp_stream != b->stream) (void)ba_wait_stream(b->grp_stream);
@@ -359,6 +361,12 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->stream && b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else hipStreamDestroy(b->stream); }
   delete b;
 }
+// first use of a window on the stream cms_ba_set_stream gave it: that stream waits (on the device) for the window's set-up
+static hipError_t ba_order_behind_setup(cms_ba* b) {
+  if (!b->setup_wait_pending) return hipSuccess;
+  b->setup_wait_pending = false;
+  return hipStreamWaitEvent(b->stream, b->ev_setup, 0);
+}
 extern "C" void* cms_ba_stream(cms_ba* b) { return b ? (void*)b->stream : nullptr; }
 // Let the window run on a stream the caller owns (e.g. cms_ctx_stream of the mapping thread's context, shared by all windows of a group):
 // a process that creates one stream per window ends up with more streams than hardware queues, and streams that share a queue
@@ -369,6 +377,8 @@ extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
   // The window's set-up (one upload, one kernel) may still be queued on the stream it was created on: the NEW stream waits for it on the device
   // (an event), the calling thread does not -- it used to spin here for the ~1-2 ms the set-up takes to get its turn inside a busy step, a host
   // core per window-building thread (CMS_BA_SET_STREAM_WAIT=1: that host wait, A/B).
+  // The wait is put into the new stream only when the window is first USED there (ba_order_behind_setup): a window is usually handed over
+  // steps ahead of its optimisation, and a wait inserted now would hold up whatever the group's stream is running in the meantime.
   static const bool host_wait = getenv("CMS_BA_SET_STREAM_WAIT") != nullptr;
   if (host_wait || !b->async_pending || (hipStream_t)hip_stream == b->stream) {
     HIPCHK(ba_wait_stream(b->stream));
@@ -377,8 +387,8 @@ extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
     if (!b->ev_setup) b->ev_setup = ba_event_take(b->device);
     if (!b->ev_setup) return cms_fail(CMS_ERR_HIP, "cms_ba_set_stream: no event");
     HIPCHK(hipEventRecord(b->ev_setup, b->stream));
-    HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, b->ev_setup, 0));
-    // (async_pending stays set: the set-up now counts as pending work of the new stream; optimise / read / destroy order themselves behind it)
+    b->setup_wait_pending = true;
+    // (async_pending stays set: the set-up counts as pending work of the new stream; optimise / read / reset / destroy order themselves behind it)
   }
   if (b->own_stream) { if (b->pooled_stream) ba_stream_give(b->device, b->stream); else HIPCHK(hipStreamDestroy(b->stream)); }
   b->stream = (hipStream_t)hip_stream; b->own_stream = false;
@@ -1482,6 +1492,7 @@ extern "C" int cms_ba_debug_fetch_plan(cms_ba* b, int* pinv, int* perm, uint32_t
                                        int* rm_chunk, uint32_t* rm_cost, uint32_t* run_mf, uint32_t* run_fl, int* counts) {
   if (!b || !counts) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_fetch_plan: bad argument");
   HIPCHK(hipSetDevice(b->device));
+  HIPCHK(ba_order_behind_setup(b));
   HIPCHK(hipStreamSynchronize(b->stream));
   b->async_pending = false;
   const int nch = b->se.nchunks, n_rm = b->se.n_rm, nr = b->n_runs;
@@ -1528,6 +1539,7 @@ k_ba_reset(int K, int P, int E, const double* __restrict__ poses0, const double*
 extern "C" int cms_ba_reset(cms_ba* b) {
   if (!b) return cms_fail(CMS_ERR_ARG, "null ba");
   HIPCHK(hipSetDevice(b->device));
+  HIPCHK(ba_order_behind_setup(b));
   b->cur = 0;
   const int n = std::max(2 * b->E, std::max(3 * b->P, 7 * b->K));
   hipLaunchKernelGGL(k_ba_reset, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, b->stream, b->K, b->P, b->E, (const double*)b->d_poses0,
@@ -1558,6 +1570,7 @@ extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* ou
   char* h = b->h_stage;
   // A window that runs on a stream it shares with others (cms_ba_set_stream) reads back on a stream taken from the pool: the shared one may
   // be busy with the next windows for milliseconds, and this window's results are complete (optimise returned) unless a reset is pending
+  HIPCHK(ba_order_behind_setup(b));
   hipStream_t rs = b->stream;
   bool temp = false;
   if (!b->own_stream && !b->async_pending) {

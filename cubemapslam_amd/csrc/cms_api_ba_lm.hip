@@ -630,8 +630,13 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
   };
   if (batched) {
     HIPCHK(hipSetDevice(bas[0]->device));
-    for (int w = 0; w < n; ++w)      // pending uploads / resets on the windows' streams
-      if (bas[w]->async_pending) { HIPCHK(ba_wait_stream(bas[w]->stream)); bas[w]->async_pending = false; }
+    for (int w = 0; w < n; ++w) {     // pending uploads / resets on the windows' streams
+      HIPCHK(ba_order_behind_setup(bas[w]));      // (a window handed to this stream by cms_ba_set_stream: the stream waits for its set-up, the host does not)
+      // a window on a stream of its own: the group's stream (bas[0]'s) must not start before that window's pending work is through -- the host waits.
+      // A window that already sits on the group's stream is ordered by the stream itself.
+      if (bas[w]->async_pending && bas[w]->stream != bas[0]->stream) { HIPCHK(ba_wait_stream(bas[w]->stream)); bas[w]->async_pending = false; }
+    }
+    if (bas[0]->async_pending && bas[0]->own_stream) { HIPCHK(ba_wait_stream(bas[0]->stream)); bas[0]->async_pending = false; }
     tick("uploads-waited");
     int rcg = ba_group_reserve(bas[0], n);
     if (rcg) return rcg;

@@ -510,6 +510,17 @@ extern "C" int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* sr
   return CMS_OK;
 }
 
+// several key frames of one batch in one call (a process that tracks many camera streams per GPU inserts one key frame per stream and step)
+extern "C" int cms_kfstore_put_from_frames(cms_kfstore* st, cms_ctx* src, int n_items, const cms_kf_from_frame* items) {
+  if (!st || !src || n_items < 0 || (n_items > 0 && !items)) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frames: bad argument");
+  for (int i = 0; i < n_items; ++i) {
+    const cms_kf_from_frame& q = items[i];
+    const int rc = cms_kfstore_put_from_frame(st, q.slot, src, q.b, q.n, q.Rcw, q.tcw, q.Ow, q.median_depth, q.mp, q.nnodes, q.node_id, q.node_off, q.node_feat);
+    if (rc) return rc;
+  }
+  return CMS_OK;
+}
+
 // the poses of n resident key frames after a local BA (Optimizer.cpp:419-431 writes them back; LocalMapping's next CreateNewMapPoints reads them):
 // one kernel, the values read from a pinned block, no synchronisation -- cms_kfstore_update per key frame is a copy and a stream wait each
 extern "C" __global__ void __launch_bounds__(64) k_kf_update_poses(CmsTriKF* kf, const float* upd, int n) {
@@ -669,6 +680,7 @@ extern "C" int cms_fuse_search(cms_ctx* c, int b, const float* pose15, int nmp, 
     HIPCHK(hipStreamSynchronize(s));
     if (tot > cap) { cap = tot + 64; continue; }
     CmsFuseScanArgs sa;
+    sa.cap = 0;
     sa.n = nmp; sa.qx = (const float*)(p + o_qx); sa.qy = (const float*)(p + o_qy); sa.level = (const int*)(p + o_lvl); sa.mp_desc = (const uint4*)(p + o_desc);
     sa.cand_off = (const int*)(p + o_off); sa.cand_idx = (const int*)(p + o_idx); sa.kp = (const CmsKeyPoint*)c->d_kps; sa.t_desc = (const uint4*)c->d_desc;
     for (int l = 0; l < 16; ++l) sa.inv_sigma2[l] = l < c->g.nlevels ? c->inv_sigma2[l] : 0.0f;
@@ -758,35 +770,51 @@ extern "C" int cms_update_normal_and_depth(cms_ctx* c, int npts, const int* obs_
 
 // SearchInNeighbors' Fuse calls on resident key frames, all in one launch sequence: job j searches the map points [mp_off[j], mp_off[j+1])
 // (host arrays, concatenated) in the key frame of slot job_slot[j].  best_idx[i] = key point of that key frame or -1.
+// per map point of a batched Fuse call: its job (binary search in the jobs' offsets) and the job's slot -- on the device: with a quarter of a million
+// map points per call (SearchInNeighbors of 16 key frames: each one's ~750 map points into 20 neighbours) the host loops that filled these two
+// arrays, their upload and the host loop over the results were a third of the call
+extern "C" __global__ void __launch_bounds__(256)
+k_fuse_expand_jobs(int nmp, int njobs, const int* __restrict__ mp_off, const int* __restrict__ job_slot, int* __restrict__ mp_job, int* __restrict__ mp_slot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nmp) return;
+  int lo = 0, hi = njobs;                                          // last job whose first map point is <= i (empty jobs skipped by the search)
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (mp_off[mid] <= i) lo = mid; else hi = mid; }
+  mp_job[i] = lo; mp_slot[i] = job_slot[lo];
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_fuse_store_rows_to_index(int nmp, const int* __restrict__ mp_slot, int maxf, int* __restrict__ best_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nmp && best_idx[i] >= 0) best_idx[i] -= mp_slot[i] * maxf;      // store row -> key point index of its key frame
+}
 extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const uint8_t* skip, const float* pos,
                                        const float* normal, const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th,
                                        int* best_idx, int* best_dist) {
   if (!st || njobs < 0 || (njobs > 0 && (!job_slot || !mp_off))) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search: bad argument");
   if (njobs == 0) return CMS_OK;
   const int nmp = mp_off[njobs];
-  if (nmp < 0 || (nmp > 0 && (!pos || !normal || !min_dist || !max_dist || !mp_desc || !best_idx || !best_dist)))
+  if (nmp < 0 || mp_off[0] != 0 || (nmp > 0 && (!pos || !normal || !min_dist || !max_dist || !mp_desc || !best_idx || !best_dist)))
     return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search: bad map-point arrays");
   if (nmp == 0) return CMS_OK;
   cms_ctx* c = st->c;
   if (c->g.nlevels > 16) return cms_fail(CMS_ERR_UNSUPPORTED, "cms_kfstore_fuse_search: more than 16 pyramid levels");
-  std::vector<float> pose((size_t)njobs * 15);
-  std::vector<int> mp_job((size_t)nmp), mp_slot((size_t)nmp);
+  // per JOB on the host: the slot's pose; per MAP POINT everything happens on the device
+  static thread_local std::vector<float> pose;
+  pose.resize((size_t)njobs * 15);
   for (int j = 0; j < njobs; ++j) {
     const int sl = job_slot[j];
     if (sl < 0 || sl >= st->maxkf || !st->used[(size_t)sl] || mp_off[j + 1] < mp_off[j]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search: bad job");
     const CmsTriKF& k = st->h_kf[(size_t)sl];
     memcpy(&pose[15 * (size_t)j], k.Rcw, 36); memcpy(&pose[15 * (size_t)j + 9], k.tcw, 12); memcpy(&pose[15 * (size_t)j + 12], k.Ow, 12);
-    for (int i = mp_off[j]; i < mp_off[j + 1]; ++i) { mp_job[(size_t)i] = j; mp_slot[(size_t)i] = sl; }
   }
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const size_t n4 = (size_t)nmp * 4;
+  const size_t n4 = (size_t)nmp * 4, j4 = (size_t)njobs * 4;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
-  const size_t o_pose = take(pose.size() * 4), o_job = take(n4), o_slot = take(n4), o_skip = take(nmp), o_pos = take(3 * n4), o_nrm = take(3 * n4), o_min = take(n4),
-               o_max = take(n4), o_desc = take((size_t)nmp * 32), o_qx = take(n4), o_qy = take(n4), o_qr = take(n4), o_qmin = take(n4), o_qmax = take(n4),
-               o_lvl = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16), o_bi = take(n4), o_bd = take(n4);
+  const size_t o_pose = take(pose.size() * 4), o_joff = take(j4 + 4), o_jslot = take(j4), o_job = take(n4), o_slot = take(n4), o_skip = take(nmp), o_pos = take(3 * n4),
+               o_nrm = take(3 * n4), o_min = take(n4), o_max = take(n4), o_desc = take((size_t)nmp * 32), o_qx = take(n4), o_qy = take(n4), o_qr = take(n4),
+               o_qmin = take(n4), o_qmax = take(n4), o_lvl = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16), o_bi = take(n4), o_bd = take(n4);
   const size_t fixed = o;
   int cap = 64 * nmp + 1024;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -795,14 +823,15 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
     uint8_t* p = (uint8_t*)c->d_match;
     const size_t o_idx = fixed;
     HIPCHK(hipMemcpyAsync(p + o_pose, pose.data(), pose.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_job, mp_job.data(), n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_slot, mp_slot.data(), n4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_joff, mp_off, j4 + 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_jslot, job_slot, j4, hipMemcpyHostToDevice, s));
     if (skip) HIPCHK(hipMemcpyAsync(p + o_skip, skip, nmp, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(p + o_pos, pos, 3 * n4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(p + o_nrm, normal, 3 * n4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(p + o_min, min_dist, n4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(p + o_max, max_dist, n4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_fuse_expand_jobs, dim3((nmp + 255) / 256), dim3(256), 0, s, nmp, njobs, (const int*)(p + o_joff), (const int*)(p + o_jslot), (int*)(p + o_job), (int*)(p + o_slot));
     CmsFuseArgs fa;
     fa.bounds_scaled = c->dist_bounds_scaled;
     fa.pose15 = (const float*)(p + o_pose); fa.mp_frame = (const int*)(p + o_job); fa.n = nmp; fa.skip = skip ? p + o_skip : nullptr;
@@ -827,24 +856,25 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
       hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 0);
       hipLaunchKernelGGL(k_area_blocksum, dim3(nblk), dim3(1024), 0, s, (const int*)(p + o_cnt), nmp, c->d_area_bsum);
       hipLaunchKernelGGL(k_area_scan, dim3(nblk), dim3(1024), 0, s, (const int*)(p + o_cnt), nmp, (const int*)c->d_area_bsum, (int*)(p + o_off), (int*)(p + o_tot));
-      hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 1);
+      hipLaunchKernelGGL(k_area_query, dim3(qgrid), dim3(256), 0, s, a, 1);      // (writes at most `cap` candidates: a list that does not fit is noticed below)
     }
-    HIPCHK(hipGetLastError());
-    int tot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (tot > cap) { cap = tot + 64; continue; }
+    // The scan is enqueued right behind the windows: the total is looked at together with the results (ONE synchronisation per call; the fill pass
+    // never writes beyond `cap`, and a call whose lists did not fit is simply repeated with room for them)
     CmsFuseScanArgs sa;
+    sa.cap = cap;
     sa.n = nmp; sa.qx = fa.qx; sa.qy = fa.qy; sa.level = fa.level; sa.mp_desc = (const uint4*)(p + o_desc);
     sa.cand_off = (const int*)(p + o_off); sa.cand_idx = (const int*)(p + o_idx); sa.kp = (const CmsKeyPoint*)st->d_kp; sa.t_desc = (const uint4*)st->d_desc;
     for (int l = 0; l < 16; ++l) sa.inv_sigma2[l] = l < c->g.nlevels ? c->inv_sigma2[l] : 0.0f;
     sa.best_idx = (int*)(p + o_bi); sa.best_dist = (int*)(p + o_bd);
     hipLaunchKernelGGL(k_fuse_scan, dim3((nmp * 8 + 255) / 256), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(k_fuse_store_rows_to_index, dim3((nmp + 255) / 256), dim3(256), 0, s, nmp, (const int*)(p + o_slot), st->maxf, (int*)(p + o_bi));
     HIPCHK(hipGetLastError());
+    int tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(best_idx, p + o_bi, n4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(best_dist, p + o_bd, n4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    for (int i = 0; i < nmp; ++i) if (best_idx[i] >= 0) best_idx[i] -= mp_slot[(size_t)i] * st->maxf;     // store row -> key point index
+    if (tot > cap) { cap = tot + 64; continue; }
     return CMS_OK;
   }
   return cms_fail(CMS_ERR_OVERFLOW, "cms_kfstore_fuse_search: candidate lists kept growing");

@@ -536,6 +536,7 @@ extern "C" __global__ void __launch_bounds__(256) k_fuse_project(CmsFuseArgs a) 
 struct CmsFuseScanArgs {
   int n; const float* qx; const float* qy; const int* level; const uint4* mp_desc; const int* cand_off; const int* cand_idx;
   const CmsKeyPoint* kp; const uint4* t_desc; float inv_sigma2[16]; int* best_idx; int* best_dist;
+  int cap;                      // entries of cand_idx that exist (0: all of them): a scan enqueued before the host has seen the total never reads beyond them
 };
 extern "C" __global__ void __launch_bounds__(256) k_fuse_scan(CmsFuseScanArgs a) {
   const int n = a.n;
@@ -546,7 +547,7 @@ extern "C" __global__ void __launch_bounds__(256) k_fuse_scan(CmsFuseScanArgs a)
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const bool live = i < n;
   const int ii = live ? i : 0;
-  const int c0 = live ? cand_off[ii] : 0, c1 = live ? cand_off[ii + 1] : 0;
+  const int c0 = live ? cand_off[ii] : 0, c1 = live ? (a.cap > 0 ? min(cand_off[ii + 1], a.cap) : cand_off[ii + 1]) : 0;
   const int lvl = level[ii];
   const float u = qx[ii], v = qy[ii];
   uint32_t key = 0xFFFFFFFFu;                        // dist << 20 | position: the first minimum in list order wins

@@ -376,6 +376,13 @@ int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, const float*
  * fetched frame (tests/test_gpu_parity.py::test_kfstore_put_from_frame_equals_put). */
 int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow, float median_depth,
                                const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat);
+/* ... several key frames of one batch in one call (one per camera stream and step when a process tracks many streams per GPU) */
+typedef struct {
+  int slot, b, n;
+  const float* Rcw; const float* tcw; const float* Ow; float median_depth;
+  const int* mp; int nnodes; const int* node_id; const int* node_off; const int* node_feat;
+} cms_kf_from_frame;
+int cms_kfstore_put_from_frames(cms_kfstore* st, cms_ctx* src, int n_items, const cms_kf_from_frame* items);
 /* the poses of n resident key frames after a local BA (Optimizer.cpp:419-431 writes them back into the KeyFrames): Rcw n x 9, tcw n x 3, Ow n x 3.
  * One kernel reading a pinned block, asynchronous -- cms_kfstore_update per key frame costs a copy and a stream wait each. */
 int cms_kfstore_update_poses(cms_kfstore* st, int n, const int* slots, const float* Rcw, const float* tcw, const float* Ow);
