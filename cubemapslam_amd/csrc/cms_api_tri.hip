@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 namespace {
@@ -326,8 +327,12 @@ struct cms_kfstore {
   std::vector<CmsTriKF> h_kf; std::vector<float> h_median; std::vector<uint8_t> used;
   // cms_kfstore_put_from_frame / cms_kfstore_update_poses: what still comes from the host (FeatureVector, map-point slots, poses) travels through a
   // pinned block per slot that the copying kernel reads itself -- no copy-engine transfer, no synchronisation; an event per slot guards its reuse
-  int* h_ff = nullptr; size_t ff_stride = 0; std::vector<hipEvent_t> ff_ev; std::vector<uint8_t> ff_busy;
-  float* h_upd = nullptr; hipEvent_t upd_ev = nullptr; bool upd_busy = false;
+  // (one event per CALL, shared by the slots the call filled: a slot's block is rewritten only after the call that last read it is through)
+  struct PutCall { hipEvent_t ev = nullptr; ~PutCall() { if (ev) (void)hipEventDestroy(ev); } };
+  int* h_ff = nullptr; size_t ff_stride = 0; std::vector<std::shared_ptr<PutCall>> ff_call;
+  void* h_items = nullptr; int items_gen = 0; std::shared_ptr<PutCall> items_call[2];      // the batch's descriptors: two pinned arrays, used alternately
+  float* h_upd = nullptr; std::vector<uint8_t> upd_par;      // two 16-float blocks per SLOT, used alternately: a block is rewritten only by the SECOND later update
+                                                             // of the same slot, long after the kernel of the first has read it (no event, no wait)
 };
 
 extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
@@ -337,9 +342,8 @@ extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
                   st->d_sorted, st->d_cell_start, st->d_nvalid, st->d_kp_cnt};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (st->h_ff) (void)hipHostFree(st->h_ff);
+  if (st->h_items) (void)hipHostFree(st->h_items);
   if (st->h_upd) (void)hipHostFree(st->h_upd);
-  for (hipEvent_t e : st->ff_ev) if (e) (void)hipEventDestroy(e);
-  if (st->upd_ev) (void)hipEventDestroy(st->upd_ev);
   delete st;
 }
 
@@ -427,7 +431,8 @@ struct CmsKfFromFrame {
   const int* h_mp; const int* h_fn; const int* h_nid; const int* h_noff; const int* h_nfeat;                                          // pinned host block (h_mp may be NULL: no map points)
   CmsTriKF kf; int n, nnodes, nfeat;
 };
-extern "C" __global__ void __launch_bounds__(256) k_kf_put_from_frame(CmsKfFromFrame a) {
+extern "C" __global__ void __launch_bounds__(256) k_kf_put_from_frame(const CmsKfFromFrame* __restrict__ items) {      // blockIdx.y = key frame of the batch
+  const CmsKfFromFrame a = items[blockIdx.y];
   const int gs = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.n;
   {
@@ -450,16 +455,17 @@ static int kfstore_ff_reserve(cms_kfstore* st) {
   if (st->h_ff) return CMS_OK;
   st->ff_stride = ((size_t)3 * st->maxf + 2 * (size_t)st->maxn + 1 + 63) & ~(size_t)63;      // ints per slot: mp | feat_node | node_feat | node_id | node_off
   HIPCHK(hipHostMalloc((void**)&st->h_ff, (size_t)st->maxkf * st->ff_stride * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
-  st->ff_ev.assign((size_t)st->maxkf, nullptr); st->ff_busy.assign((size_t)st->maxkf, 0);
+  HIPCHK(hipHostMalloc((void**)&st->h_items, 2 * (size_t)st->maxkf * sizeof(CmsKfFromFrame), hipHostMallocMapped | hipHostMallocCoherent));
+  st->ff_call.assign((size_t)st->maxkf, nullptr);
   return CMS_OK;
 }
-extern "C" int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow,
-                                          float median_depth, const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat) {
-  if (!st || !src || slot < 0 || slot >= st->maxkf || b < 0 || b >= src->max_batch || n < 0 || nnodes < 0 || !Rcw || !tcw || !Ow ||
+// validation + the slot's pinned block + the descriptor of one key frame (no launch)
+static int kf_put_prepare(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow, float median_depth,
+                          const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat, CmsKfFromFrame& a) {
+  if (slot < 0 || slot >= st->maxkf || b < 0 || b >= src->max_batch || n < 0 || nnodes < 0 || !Rcw || !tcw || !Ow ||
       (nnodes > 0 && (!node_id || !node_off || !node_feat)))
     return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: bad argument");
   cms_ctx* c = st->c;
-  if (src->device != c->device || src->g.F != c->g.F || src->g.W != c->g.W) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: the frame context and the store must share device and cubemap geometry");
   if (b >= src->area_frames) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: no frame grid for this frame (cms_area_grid on the batch first)");
   if (n > st->maxf || n > src->g.kp_cap || nnodes > st->maxn) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: key frame larger than the store's slots");
   {
@@ -470,20 +476,17 @@ extern "C" int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* sr
     const int rc = tri_check_keyframe(chk, "cms_kfstore_put_from_frame: bad key frame");
     if (rc) return rc;
   }
-  HIPCHK(hipSetDevice(c->device));
-  { const int rc = kfstore_ff_reserve(st); if (rc) return rc; }
-  if (st->ff_busy[(size_t)slot]) { HIPCHK(hipEventSynchronize(st->ff_ev[(size_t)slot])); st->ff_busy[(size_t)slot] = 0; }      // (the slot's previous put still reading its block: rare)
-  int* h = st->h_ff + (size_t)slot * st->ff_stride;
-  int* h_mp = h; int* h_fn = h + st->maxf; int* h_nfeat = h + 2 * (size_t)st->maxf; int* h_nid = h + 3 * (size_t)st->maxf; int* h_noff = h_nid + st->maxn;
   const int nfeat = nnodes > 0 ? node_off[nnodes] : 0;
   if (nfeat > st->maxf) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: FeatureVector lists more features than the slot holds");
+  if (st->ff_call[(size_t)slot]) { HIPCHK(hipEventSynchronize(st->ff_call[(size_t)slot]->ev)); st->ff_call[(size_t)slot].reset(); }      // (the call that last read this block: long through)
+  int* h = st->h_ff + (size_t)slot * st->ff_stride;
+  int* h_mp = h; int* h_fn = h + st->maxf; int* h_nfeat = h + 2 * (size_t)st->maxf; int* h_nid = h + 3 * (size_t)st->maxf; int* h_noff = h_nid + st->maxn;
   if (mp && n > 0) std::memcpy(h_mp, mp, 4 * (size_t)n);
   for (int i = 0; i < n; ++i) h_fn[i] = -1;
   for (int e = 0; e < nnodes; ++e)
     for (int q = node_off[e]; q < node_off[e + 1]; ++q) h_fn[node_feat[q]] = e;
   if (nnodes > 0) { std::memcpy(h_nid, node_id, 4 * (size_t)nnodes); std::memcpy(h_noff, node_off, 4 * ((size_t)nnodes + 1)); std::memcpy(h_nfeat, node_feat, 4 * (size_t)nfeat); }
   const size_t f0 = (size_t)slot * st->maxf, n0 = (size_t)slot * st->maxn, o0 = (size_t)slot * (st->maxn + 1);
-  CmsKfFromFrame a;
   std::memset(&a, 0, sizeof(a));
   CmsTriKF& d = a.kf;
   d.f0 = (int)f0; d.n = n; d.node0 = (int)n0; d.nnodes = nnodes; d.noff0 = (int)o0; d.nfeat0 = (int)f0;
@@ -496,38 +499,60 @@ extern "C" int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* sr
   a.o_mp = st->d_mp + f0; a.o_fn = st->d_fn + f0; a.o_nid = st->d_nid + n0; a.o_noff = st->d_noff + o0; a.o_nfeat = st->d_nfeat + f0; a.o_kf = st->d_kf + slot;
   a.h_mp = mp ? h_mp : nullptr; a.h_fn = h_fn; a.h_nid = h_nid; a.h_noff = h_noff; a.h_nfeat = h_nfeat;
   a.n = n; a.nnodes = nnodes; a.nfeat = nfeat;
-  // The copy runs on the FRAME context's stream: right behind the work that produced frame b, and in front of whatever the caller enqueues there
+  st->h_kf[(size_t)slot] = d; st->h_median[(size_t)slot] = median_depth; st->used[(size_t)slot] = 1;
+  (void)c;
+  return CMS_OK;
+}
+// several key frames of one batch in one call (a process that tracks many camera streams per GPU inserts one key frame per stream and step): ONE
+// kernel, one event, one stream wait for all of them
+extern "C" int cms_kfstore_put_from_frames(cms_kfstore* st, cms_ctx* src, int n_items, const cms_kf_from_frame* items) {
+  if (!st || !src || n_items < 0 || n_items > st->maxkf || (n_items > 0 && !items)) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frames: bad argument");
+  if (n_items == 0) return CMS_OK;
+  cms_ctx* c = st->c;
+  if (src->device != c->device || src->g.F != c->g.F || src->g.W != c->g.W) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: the frame context and the store must share device and cubemap geometry");
+  HIPCHK(hipSetDevice(c->device));
+  { const int rc = kfstore_ff_reserve(st); if (rc) return rc; }
+  const int gen = (st->items_gen ^= 1);
+  if (st->items_call[gen]) { HIPCHK(hipEventSynchronize(st->items_call[gen]->ev)); st->items_call[gen].reset(); }      // (two calls ago)
+  CmsKfFromFrame* h_items = reinterpret_cast<CmsKfFromFrame*>(st->h_items) + (size_t)gen * st->maxkf;
+  int max_n = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const cms_kf_from_frame& q = items[i];
+    const int rc = kf_put_prepare(st, q.slot, src, q.b, q.n, q.Rcw, q.tcw, q.Ow, q.median_depth, q.mp, q.nnodes, q.node_id, q.node_off, q.node_feat, h_items[i]);
+    if (rc) return rc;
+    max_n = std::max(max_n, q.n);
+  }
+  // The copy runs on the FRAME context's stream: right behind the work that produced the frames, and in front of whatever the caller enqueues there
   // next (the next batch overwrites the frame buffers) -- the KeyFrame constructor's copy happens on the Tracking thread in the reference too
   // (Tracking.cpp:1015-1017, KeyFrame.cpp:29-55).  The store's stream then waits for it on the device.
   hipStream_t s = src->stream;
-  hipLaunchKernelGGL(k_kf_put_from_frame, dim3(std::max(1, std::min(64, (6 * n + 255) / 256))), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_kf_put_from_frame, dim3(std::max(1, std::min(32, (6 * max_n + 255) / 256)), n_items), dim3(256), 0, s, (const CmsKfFromFrame*)h_items);
   HIPCHK(hipGetLastError());
-  if (!st->ff_ev[(size_t)slot]) HIPCHK(hipEventCreateWithFlags(&st->ff_ev[(size_t)slot], hipEventDisableTiming));
-  HIPCHK(hipEventRecord(st->ff_ev[(size_t)slot], s));
-  st->ff_busy[(size_t)slot] = 1;
-  if (c->stream != s) HIPCHK(hipStreamWaitEvent(c->stream, st->ff_ev[(size_t)slot], 0));
-  st->h_kf[(size_t)slot] = d; st->h_median[(size_t)slot] = median_depth; st->used[(size_t)slot] = 1;
+  auto call = std::make_shared<cms_kfstore::PutCall>();
+  HIPCHK(hipEventCreateWithFlags(&call->ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(call->ev, s));
+  if (c->stream != s) HIPCHK(hipStreamWaitEvent(c->stream, call->ev, 0));
+  for (int i = 0; i < n_items; ++i) st->ff_call[(size_t)items[i].slot] = call;
+  st->items_call[gen] = call;
   return CMS_OK;
 }
-
-// several key frames of one batch in one call (a process that tracks many camera streams per GPU inserts one key frame per stream and step)
-extern "C" int cms_kfstore_put_from_frames(cms_kfstore* st, cms_ctx* src, int n_items, const cms_kf_from_frame* items) {
-  if (!st || !src || n_items < 0 || (n_items > 0 && !items)) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frames: bad argument");
-  for (int i = 0; i < n_items; ++i) {
-    const cms_kf_from_frame& q = items[i];
-    const int rc = cms_kfstore_put_from_frame(st, q.slot, src, q.b, q.n, q.Rcw, q.tcw, q.Ow, q.median_depth, q.mp, q.nnodes, q.node_id, q.node_off, q.node_feat);
-    if (rc) return rc;
-  }
-  return CMS_OK;
+extern "C" int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow,
+                                          float median_depth, const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat) {
+  cms_kf_from_frame q;
+  q.slot = slot; q.b = b; q.n = n; q.Rcw = Rcw; q.tcw = tcw; q.Ow = Ow; q.median_depth = median_depth; q.mp = mp; q.nnodes = nnodes;
+  q.node_id = node_id; q.node_off = node_off; q.node_feat = node_feat;
+  return cms_kfstore_put_from_frames(st, src, 1, &q);
 }
 
 // the poses of n resident key frames after a local BA (Optimizer.cpp:419-431 writes them back; LocalMapping's next CreateNewMapPoints reads them):
 // one kernel, the values read from a pinned block, no synchronisation -- cms_kfstore_update per key frame is a copy and a stream wait each
-extern "C" __global__ void __launch_bounds__(64) k_kf_update_poses(CmsTriKF* kf, const float* upd, int n) {
+struct CmsKfUpdSlots { int n; int slot[62]; };      // (by value in the kernel arguments: nothing of a call lives in memory another call could overwrite)
+extern "C" __global__ void __launch_bounds__(64) k_kf_update_poses(CmsTriKF* kf, const float* upd, CmsKfUpdSlots sl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* u = upd + 16 * (size_t)i;
-  CmsTriKF& d = kf[__float_as_int(u[15])];
+  if (i >= sl.n) return;
+  const int slot = sl.slot[i] & 0x3FFFFFFF, par = (sl.slot[i] >> 30) & 1;
+  const float* u = upd + 16 * (2 * (size_t)slot + par);
+  CmsTriKF& d = kf[slot];
   for (int j = 0; j < 9; ++j) d.Rcw[j] = u[j];
   for (int j = 0; j < 3; ++j) { d.tcw[j] = u[9 + j]; d.Ow[j] = u[12 + j]; }
 }
@@ -538,48 +563,25 @@ extern "C" int cms_kfstore_update_poses(cms_kfstore* st, int n, const int* slots
   cms_ctx* c = st->c;
   HIPCHK(hipSetDevice(c->device));
   if (!st->h_upd) {
-    HIPCHK(hipHostMalloc((void**)&st->h_upd, (size_t)st->maxkf * 16 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
-    HIPCHK(hipEventCreateWithFlags(&st->upd_ev, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void**)&st->h_upd, (size_t)st->maxkf * 32 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    st->upd_par.assign((size_t)st->maxkf, 0);
   }
-  if (st->upd_busy) { HIPCHK(hipEventSynchronize(st->upd_ev)); st->upd_busy = false; }
-  for (int i = 0; i < n; ++i) {
-    float* u = st->h_upd + 16 * (size_t)i;
-    std::memcpy(u, Rcw + 9 * (size_t)i, 36); std::memcpy(u + 9, tcw + 3 * (size_t)i, 12); std::memcpy(u + 12, Ow + 3 * (size_t)i, 12);
-    std::memcpy(u + 15, &slots[i], 4);
-    CmsTriKF& d = st->h_kf[(size_t)slots[i]];
-    std::memcpy(d.Rcw, Rcw + 9 * (size_t)i, 36); std::memcpy(d.tcw, tcw + 3 * (size_t)i, 12); std::memcpy(d.Ow, Ow + 3 * (size_t)i, 12);
+  for (int i0 = 0; i0 < n; i0 += 62) {
+    CmsKfUpdSlots sl;
+    sl.n = std::min(62, n - i0);
+    for (int i = 0; i < sl.n; ++i) {
+      const int slot = slots[i0 + i];
+      const size_t k = (size_t)(i0 + i);
+      const int par = (st->upd_par[(size_t)slot] ^= 1);
+      float* u = st->h_upd + 16 * (2 * (size_t)slot + par);
+      std::memcpy(u, Rcw + 9 * k, 36); std::memcpy(u + 9, tcw + 3 * k, 12); std::memcpy(u + 12, Ow + 3 * k, 12);
+      CmsTriKF& d = st->h_kf[(size_t)slot];
+      std::memcpy(d.Rcw, Rcw + 9 * k, 36); std::memcpy(d.tcw, tcw + 3 * k, 12); std::memcpy(d.Ow, Ow + 3 * k, 12);
+      sl.slot[i] = slot | (par << 30);
+    }
+    hipLaunchKernelGGL(k_kf_update_poses, dim3(1), dim3(64), 0, c->stream, st->d_kf, (const float*)st->h_upd, sl);
   }
-  hipLaunchKernelGGL(k_kf_update_poses, dim3((n + 63) / 64), dim3(64), 0, c->stream, st->d_kf, (const float*)st->h_upd, n);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(st->upd_ev, c->stream));
-  st->upd_busy = true;
-  return CMS_OK;
-}
-
-// developer / test entry: what a slot holds on the device (any pointer may be NULL).  kps / desc / rays / mp / feat_node / sorted: n entries (n = header[1]);
-// node_id nnodes, node_off nnodes + 1, node_feat node_off[nnodes]; cell_start 12501 ints; header: the 21 32-bit words of the slot's record (f0, n, node0,
-// nnodes, noff0, nfeat0, Rcw[9], tcw[3], Ow[3]); misc[2] = valid grid entries, stored key-point count
-extern "C" int cms_kfstore_debug_fetch(cms_kfstore* st, int slot, cms_keypoint* kps, uint8_t* desc, float* rays, int* mp, int* feat_node, uint16_t* sorted,
-                                       int* node_id, int* node_off, int* node_feat, int* cell_start, uint32_t* header, int* misc) {
-  if (!st || slot < 0 || slot >= st->maxkf || !st->used[(size_t)slot]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_debug_fetch: bad slot");
-  cms_ctx* c = st->c;
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  CmsTriKF d;
-  HIPCHK(hipMemcpy(&d, st->d_kf + slot, sizeof(d), hipMemcpyDeviceToHost));
-  static_assert(sizeof(CmsTriKF) == 21 * 4, "CmsTriKF is 21 words");
-  if (header) std::memcpy(header, &d, sizeof(d));
-  const size_t f0 = (size_t)slot * st->maxf, n0 = (size_t)slot * st->maxn, o0 = (size_t)slot * (st->maxn + 1);
-  const size_t n = (size_t)std::max(0, std::min(d.n, st->maxf)), nn = (size_t)std::max(0, std::min(d.nnodes, st->maxn));
-  auto dl = [&](void* dst, const void* src, size_t bytes) { return (!dst || bytes == 0) ? hipSuccess : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
-  HIPCHK(dl(kps, st->d_kp + f0, n * sizeof(CmsKeyPoint))); HIPCHK(dl(desc, st->d_desc + 32 * f0, 32 * n)); HIPCHK(dl(rays, st->d_rays + 3 * f0, 12 * n));
-  HIPCHK(dl(mp, st->d_mp + f0, 4 * n)); HIPCHK(dl(feat_node, st->d_fn + f0, 4 * n)); HIPCHK(dl(sorted, st->d_sorted + f0, 2 * n));
-  HIPCHK(dl(node_id, st->d_nid + n0, 4 * nn)); HIPCHK(dl(node_off, st->d_noff + o0, 4 * (nn + 1)));
-  int nfeat = 0;
-  if (nn > 0) HIPCHK(hipMemcpy(&nfeat, st->d_noff + o0 + nn, 4, hipMemcpyDeviceToHost));
-  HIPCHK(dl(node_feat, st->d_nfeat + f0, 4 * (size_t)std::max(0, std::min(nfeat, st->maxf))));
-  HIPCHK(dl(cell_start, st->d_cell_start + (size_t)slot * (CMS_AREA_CELLS + 1), 4 * ((size_t)CMS_AREA_CELLS + 1)));
-  if (misc) { HIPCHK(hipMemcpy(misc, st->d_nvalid + slot, 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(misc + 1, st->d_kp_cnt + slot, 4, hipMemcpyDeviceToHost)); }
   return CMS_OK;
 }
 
