@@ -585,6 +585,33 @@ extern "C" int cms_kfstore_update_poses(cms_kfstore* st, int n, const int* slots
   return CMS_OK;
 }
 
+// developer / test entry: what a slot holds on the device (any pointer may be NULL).  kps / desc / rays / mp / feat_node / sorted: n entries (n = header[1]);
+// node_id nnodes, node_off nnodes + 1, node_feat node_off[nnodes]; cell_start 12501 ints; header: the 21 32-bit words of the slot's record (f0, n, node0,
+// nnodes, noff0, nfeat0, Rcw[9], tcw[3], Ow[3]); misc[2] = valid grid entries, stored key-point count
+extern "C" int cms_kfstore_debug_fetch(cms_kfstore* st, int slot, cms_keypoint* kps, uint8_t* desc, float* rays, int* mp, int* feat_node, uint16_t* sorted,
+                                       int* node_id, int* node_off, int* node_feat, int* cell_start, uint32_t* header, int* misc) {
+  if (!st || slot < 0 || slot >= st->maxkf || !st->used[(size_t)slot]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_debug_fetch: bad slot");
+  cms_ctx* c = st->c;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  CmsTriKF d;
+  HIPCHK(hipMemcpy(&d, st->d_kf + slot, sizeof(d), hipMemcpyDeviceToHost));
+  static_assert(sizeof(CmsTriKF) == 21 * 4, "CmsTriKF is 21 words");
+  if (header) std::memcpy(header, &d, sizeof(d));
+  const size_t f0 = (size_t)slot * st->maxf, n0 = (size_t)slot * st->maxn, o0 = (size_t)slot * (st->maxn + 1);
+  const size_t n = (size_t)std::max(0, std::min(d.n, st->maxf)), nn = (size_t)std::max(0, std::min(d.nnodes, st->maxn));
+  auto dl = [&](void* dst, const void* src, size_t bytes) { return (!dst || bytes == 0) ? hipSuccess : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
+  HIPCHK(dl(kps, st->d_kp + f0, n * sizeof(CmsKeyPoint))); HIPCHK(dl(desc, st->d_desc + 32 * f0, 32 * n)); HIPCHK(dl(rays, st->d_rays + 3 * f0, 12 * n));
+  HIPCHK(dl(mp, st->d_mp + f0, 4 * n)); HIPCHK(dl(feat_node, st->d_fn + f0, 4 * n)); HIPCHK(dl(sorted, st->d_sorted + f0, 2 * n));
+  HIPCHK(dl(node_id, st->d_nid + n0, 4 * nn)); HIPCHK(dl(node_off, st->d_noff + o0, 4 * (nn + 1)));
+  int nfeat = 0;
+  if (nn > 0) HIPCHK(hipMemcpy(&nfeat, st->d_noff + o0 + nn, 4, hipMemcpyDeviceToHost));
+  HIPCHK(dl(node_feat, st->d_nfeat + f0, 4 * (size_t)std::max(0, std::min(nfeat, st->maxf))));
+  HIPCHK(dl(cell_start, st->d_cell_start + (size_t)slot * (CMS_AREA_CELLS + 1), 4 * ((size_t)CMS_AREA_CELLS + 1)));
+  if (misc) { HIPCHK(hipMemcpy(misc, st->d_nvalid + slot, 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(misc + 1, st->d_kp_cnt + slot, 4, hipMemcpyDeviceToHost)); }
+  return CMS_OK;
+}
+
 // what changes on a key frame between CreateNewMapPoints calls: pose (local BA), median depth, map-point slots (any may be NULL: unchanged)
 extern "C" int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, const float* tcw, const float* Ow, const float* median_depth, const int* mp) {
   if (!st || slot < 0 || slot >= st->maxkf || !st->used[(size_t)slot]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_update: bad slot");
