@@ -455,7 +455,7 @@ def main():
     #                        the frame grid device to device out of the frame context, FeatureVector + map-point slots from a pinned block; enqueued by
     #                        the frame path's thread behind the frame's tracking, like the KeyFrame constructor on the Tracking thread
     #   CreateNewMapPoints   as before (against 20 resident neighbours)
-    #   SearchInNeighbors    both Fuse directions as jobs of ONE cms_kfstore_fuse_search call per window group: the key frame's map points into each
+    #   SearchInNeighbors    both Fuse directions as jobs of ONE cms_kfstore_fuse_search_sets call per window group: the key frame's map points into each
     #                        of its 20 neighbours, the neighbours' map points (union) into the key frame; map points already seen by the target skipped
     #   LocalBundleAdjustment as before
     #   pose write-back      cms_kfstore_update_poses for the window's 20 key frames (Optimizer.cpp:419-431), after the window's read-back
@@ -530,22 +530,31 @@ def main():
         jobs.append((base, np.fromiter((p in have[0] for p in u[0]), np.uint8, len(u[0]))) + u[1:])
         return jobs
     fuse_prep = []
+    L_.cms_kfstore_fuse_search_sets.argtypes = [C_.c_void_p, C_.c_int] + [C_.c_void_p] * 6 + [C_.c_int] + [C_.c_void_p] * 3 + [C_.c_float, C_.c_void_p, C_.c_void_p]
+    def pin(arr):                                                              # pinned host copies: the call's uploads are asynchronous DMA transfers
+        arr = np.ascontiguousarray(arr)
+        pa = api.PinnedArray((max(arr.nbytes, 16),))
+        v = pa.array[:arr.nbytes].view(arr.dtype).reshape(arr.shape); v[...] = arr
+        return pa, v
     for gi, ids in enumerate(group_ids):
-        jobs = []
+        # per window two SETS of map points (the key frame's; the union of its neighbours') uploaded once each, and 21 jobs that refer to them
+        # (cms_kfstore_fuse_search_sets): the key frame's set goes to 20 neighbours
+        sets_g, jobs_g2 = [], []
         for wi in range(len(ids)):
-            jobs += fuse_jobs_of(tri_sets[(gi + wi) % len(tri_sets)], wi * (tri_nn + 1))
-        off = np.concatenate([[0], np.cumsum([len(j[1]) for j in jobs])]).astype(np.int32)
-        n_mp = int(off[-1])
-        def pin(arr):                                                          # pinned host copies: the call's uploads are asynchronous DMA transfers
-            arr = np.ascontiguousarray(arr)
-            pa = api.PinnedArray((max(arr.nbytes, 16),))
-            v = pa.array[:arr.nbytes].view(arr.dtype).reshape(arr.shape); v[...] = arr
-            return pa, v
-        cols = [pin(np.concatenate([j[c] for j in jobs])) for c in range(1, 7)]   # skip, pos, normal, min, max, desc
-        slots = np.array([j[0] for j in jobs], np.int32)
+            jl = fuse_jobs_of(tri_sets[(gi + wi) % len(tri_sets)], wi * (tri_nn + 1))
+            sets_g.append(jl[0][2:]); sets_g.append(jl[-1][2:])                   # (pos, normal, min, max, desc) of the key frame's points / of the neighbours' union
+            for j in jl[:-1]:
+                jobs_g2.append((j[0], 2 * wi, j[1]))
+            jobs_g2.append((jl[-1][0], 2 * wi + 1, jl[-1][1]))
+        set_off = np.concatenate([[0], np.cumsum([len(q[0]) for q in sets_g])]).astype(np.int32)
+        cols = [pin(np.concatenate([q[c] for q in sets_g])) for c in range(5)]    # pos, normal, min, max, desc per SET point
+        slots = np.array([j[0] for j in jobs_g2], np.int32); jset = np.array([j[1] for j in jobs_g2], np.int32)
+        pskip, skip = pin(np.concatenate([j[2] for j in jobs_g2]).astype(np.uint8))
+        n_mp = len(skip)
         pbi, bi = pin(np.zeros(n_mp, np.int32)); pbd, bd = pin(np.zeros(n_mp, np.int32))
-        fuse_prep.append(dict(keep=(cols, slots, off, pbi, pbd), njobs=len(jobs), n_mp=n_mp, best_idx=bi,
-                              args=(len(jobs), api._p(slots), api._p(off)) + tuple(api._p(v) for _, v in cols) + (C_.c_float(3.0), api._p(bi), api._p(bd))))
+        fuse_prep.append(dict(keep=(cols, slots, jset, set_off, pskip, pbi, pbd), njobs=len(jobs_g2), n_mp=n_mp, n_set_points=int(set_off[-1]), best_idx=bi,
+                              args=(len(sets_g), api._p(set_off)) + tuple(api._p(v) for _, v in cols) + (len(jobs_g2), api._p(slots), api._p(jset), api._p(skip),
+                                                                                                          C_.c_float(3.0), api._p(bi), api._p(bd))))
     store_lock = [threading.Lock() for _ in range(n_grp)]         # a store's calls one at a time (its mapping thread; the optimise-only pass's worker)
     wb_queue = [collections.deque() for _ in range(n_grp)]        # pose write-backs of read-back windows, applied by the group's mapping thread before its next key frames
     upd_prep = []
@@ -562,9 +571,9 @@ def main():
     def fuse_group(gi):
         t0_ = time.perf_counter()
         with store_lock[gi]:
-            rc = L_.cms_kfstore_fuse_search(tri_store[gi].h, *fuse_prep[gi]["args"])
+            rc = L_.cms_kfstore_fuse_search_sets(tri_store[gi].h, *fuse_prep[gi]["args"])
         if rc < 0:
-            raise RuntimeError("cms_kfstore_fuse_search: %s" % L_.cms_last_error().decode())
+            raise RuntimeError("cms_kfstore_fuse_search_sets: %s" % L_.cms_last_error().decode())
         map_acc["fuse_ms"] += 1e3 * (time.perf_counter() - t0_); map_acc["fuse_n"] += 1
         map_acc["fused"] = int((fuse_prep[gi]["best_idx"] >= 0).sum())
     def write_back(gi, wi):
@@ -910,11 +919,12 @@ def main():
     # what the rest of LocalMapping's sequence took inside the headline pass (host wall time of the calls; their device work overlaps the step)
     mapping_side = {"in_timed_region": bool(life.get("mapping_full")),
                     "calls_per_key_frame": ["cms_kfstore_put_from_frame (ProcessNewKeyFrame: frame -> store, device to device)", "cms_kfstore_create_new_map_points",
-                                            "cms_kfstore_fuse_search (SearchInNeighbors: key frame's map points into 20 neighbours + the neighbours' into the key frame)",
+                                            "cms_kfstore_fuse_search_sets (SearchInNeighbors: the key frame's map points into 20 neighbours + the neighbours' into the key frame; every set of map points uploaded once)",
                                             "cms_ba_create / cms_ba_optimize_many / cms_ba_read (LocalBundleAdjustment)", "cms_kfstore_update_poses (20 key-frame poses written back)"],
                     "put_from_frame_ms_per_step": round(map_acc["put_ms"] / max(map_acc["put_n"], 1), 3), "key_frames_per_step": n_ba,
                     "fuse_search_ms_per_group_call": round(map_acc["fuse_ms"] / max(map_acc["fuse_n"], 1), 3),
-                    "fuse_jobs_per_step": int(sum(fq["njobs"] for fq in fuse_prep)), "fuse_map_points_per_step": int(sum(fq["n_mp"] for fq in fuse_prep)),
+                    "fuse_jobs_per_step": int(sum(fq["njobs"] for fq in fuse_prep)), "fuse_projections_per_step": int(sum(fq["n_mp"] for fq in fuse_prep)),
+                    "fuse_map_points_uploaded_per_step": int(sum(fq["n_set_points"] for fq in fuse_prep)),
                     "fused_matches_last_group_call": int(map_acc["fused"]),
                     "update_poses_ms_per_window": round(map_acc["upd_ms"] / max(map_acc["upd_n"], 1), 4),
                     "note": "LocalMapping::Run's sequence per key frame (LocalMapping.cpp:52-117, 388-466) inside the timed region since round 5.  The synthetic streams are not one "

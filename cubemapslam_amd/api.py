@@ -125,6 +125,7 @@ def lib():
         L.cms_kfstore_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cms_kfstore_update.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.cms_kfstore_fuse_search.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_void_p, C.c_void_p]
+        L.cms_kfstore_fuse_search_sets.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_void_p]
         L.cms_kfstore_put_from_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
         L.cms_kfstore_update_poses.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
@@ -612,6 +613,21 @@ class KeyframeStore:
         bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32)
         _chk(lib().cms_kfstore_fuse_search(self.h, nj, _p(slots), _p(off), *[_p(v) for v in a], th, _p(bi), _p(bd)), "cms_kfstore_fuse_search")
         return [(bi[off[j]:off[j + 1]].copy(), bd[off[j]:off[j + 1]].copy()) for j in range(nj)]
+
+    def fuse_search_sets(self, sets, jobs, th=3.0):
+        """cms_kfstore_fuse_search_sets.  sets: list of dict(pos, normal, min_dist, max_dist, desc); jobs: list of (slot, set index, skip array or None)
+        -> per job (best_idx, best_dist)"""
+        soff = np.concatenate([[0], np.cumsum([len(q["pos"]) for q in sets])]).astype(np.int32)
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(q[k]) for q in sets]), dt)
+        a = [cat("pos", np.float32), cat("normal", np.float32), cat("min_dist", np.float32), cat("max_dist", np.float32), cat("desc", np.uint8)]
+        slots = np.array([j[0] for j in jobs], np.int32); jset = np.array([j[1] for j in jobs], np.int32)
+        sizes = [int(soff[j[1] + 1] - soff[j[1]]) for j in jobs]
+        eoff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        skip = np.ascontiguousarray(np.concatenate([np.zeros(sz, np.uint8) if j[2] is None else np.asarray(j[2], np.uint8) for j, sz in zip(jobs, sizes)]), np.uint8)
+        bi = np.zeros(int(eoff[-1]), np.int32); bd = np.zeros(int(eoff[-1]), np.int32)
+        _chk(lib().cms_kfstore_fuse_search_sets(self.h, len(sets), _p(soff), *[_p(v) for v in a], len(jobs), _p(slots), _p(jset), _p(skip), th, _p(bi), _p(bd)),
+             "cms_kfstore_fuse_search_sets")
+        return [(bi[eoff[j]:eoff[j + 1]].copy(), bd[eoff[j]:eoff[j + 1]].copy()) for j in range(len(jobs))]
 
     def create_new_map_points(self, jobs, check_orientation=False, cap=2048, copy=True):
         """jobs: list of (current slot, [neighbour slots in covisibility order]) -> per job (neigh, idx1, idx2, x3d).

@@ -514,11 +514,36 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
     if (c->copy_stream) { HIPCHK(hipEventRecord(c->ev_remap_done, s)); c->remap_recorded = true; }   // the staging buffer is free from here on
   }
   if (c->prof) hipEventRecord(c->ev[1], s);
+  // levels (1, 2), (3, 4), ... two per launch (k_resize2: the intermediate level is never read back); a last odd level, and every level with
+  // CMS_RESIZE_SINGLE=1 (A/B), through k_resize
+  static const bool rz_single = getenv("CMS_RESIZE_SINGLE") != nullptr;
   for (int l = 1; l < L; ++l) {
-    const CmsLevel& d = g.lv[l];
     dim3 block(64, 4);
+    const double ratio = (double)g.lv[l - 1].w / g.lv[l].w;
+    if (!rz_single && l + 1 < L) {
+      const double ratio2 = (double)g.lv[l].w / g.lv[l + 1].w;
+      const int la = (int)align_up((size_t)ceil(256 * ratio2) + 34, 16);                 // mid rectangle: k_resize's staged width for the tile of level l + 1
+      const int ls = (int)align_up((size_t)ceil((la + 2) * ratio) + 34, 16);             // ... and the src rectangle behind it
+      const int arows = (int)ceil(CMS_RZ_ROWS * ratio2) + 7;
+      const int srows = (int)ceil((arows + 1) * ratio) + 7;
+      if (la <= 512 && ls <= 512 && arows <= CMS_RZ2_AROWS && srows <= CMS_RZ2_SROWS) {
+        const CmsLevel& d = g.lv[l + 1];
+        CmsResize2 a;
+        a.src = g.lv[l - 1]; a.mid = g.lv[l]; a.dst = d;
+        a.tabx1 = (const CmsResizeTab*)(c->d_tab + g.lv[l].tab_off); a.taby1 = a.tabx1 + g.lv[l].w;
+        a.tabx2 = (const CmsResizeTab*)(c->d_tab + d.tab_off); a.taby2 = a.tabx2 + d.w;
+        a.ls = ls; a.la = la; a.arows = CMS_RZ2_AROWS;
+        a.lo1 = (int)floor(ratio * 65536.0); a.hi1 = (int)ceil(ratio * 65536.0); a.lo2 = (int)floor(ratio2 * 65536.0); a.hi2 = (int)ceil(ratio2 * 65536.0);
+        a.skip_zero = clean;
+        const size_t lds = (size_t)ls * CMS_RZ2_SROWS + (size_t)la * CMS_RZ2_AROWS + (size_t)(la + 16) * sizeof(CmsResizeTab);
+        dim3 grid((d.w + 255) / 256, (d.h + CMS_RZ_ROWS - 1) / CMS_RZ_ROWS, B);
+        hipLaunchKernelGGL(k_resize2, grid, block, lds, s, c->d_pyr, g.pyr_bytes, a);
+        ++l;
+        continue;
+      }
+    }
+    const CmsLevel& d = g.lv[l];
     dim3 grid((d.w + 255) / 256, (d.h + CMS_RZ_ROWS - 1) / CMS_RZ_ROWS, B);
-    const double ratio = (double)g.lv[l - 1].w / d.w;
     const int ls = (int)align_up((size_t)ceil(256 * ratio) + 34, 16);    // LDS row stride of the staged source rectangle (16-byte columns)
     const int lrows = (int)ceil(CMS_RZ_ROWS * ratio) + 7;               // the kernel's integer bounds can be one row wider on either side
     hipLaunchKernelGGL(k_resize, grid, block, (size_t)ls * lrows, s, c->d_pyr, g.pyr_bytes, g.lv[l - 1], d,

@@ -692,6 +692,7 @@ extern "C" int cms_fuse_search(cms_ctx* c, int b, const float* pose15, int nmp, 
     const std::vector<int> qf((size_t)nmp, b);
     HIPCHK(hipMemcpyAsync(p + o_qf, qf.data(), n4, hipMemcpyHostToDevice, s));
     CmsFuseArgs fa;
+    fa.src = nullptr;
     fa.bounds_scaled = c->dist_bounds_scaled;
     fa.pose15 = (const float*)(p + o_pose); fa.mp_frame = nullptr; fa.n = nmp; fa.skip = skip ? p + o_skip : nullptr;
     fa.P = (const float*)(p + o_pos); fa.normal = (const float*)(p + o_nrm); fa.min_dist = (const float*)(p + o_min); fa.max_dist = (const float*)(p + o_max);
@@ -709,7 +710,7 @@ extern "C" int cms_fuse_search(cms_ctx* c, int b, const float* pose15, int nmp, 
     HIPCHK(hipStreamSynchronize(s));
     if (tot > cap) { cap = tot + 64; continue; }
     CmsFuseScanArgs sa;
-    sa.cap = 0;
+    sa.cap = 0; sa.src = nullptr;
     sa.n = nmp; sa.qx = (const float*)(p + o_qx); sa.qy = (const float*)(p + o_qy); sa.level = (const int*)(p + o_lvl); sa.mp_desc = (const uint4*)(p + o_desc);
     sa.cand_off = (const int*)(p + o_off); sa.cand_idx = (const int*)(p + o_idx); sa.kp = (const CmsKeyPoint*)c->d_kps; sa.t_desc = (const uint4*)c->d_desc;
     for (int l = 0; l < 16; ++l) sa.inv_sigma2[l] = l < c->g.nlevels ? c->inv_sigma2[l] : 0.0f;
@@ -803,21 +804,25 @@ extern "C" int cms_update_normal_and_depth(cms_ctx* c, int npts, const int* obs_
 // map points per call (SearchInNeighbors of 16 key frames: each one's ~750 map points into 20 neighbours) the host loops that filled these two
 // arrays, their upload and the host loop over the results were a third of the call
 extern "C" __global__ void __launch_bounds__(256)
-k_fuse_expand_jobs(int nmp, int njobs, const int* __restrict__ mp_off, const int* __restrict__ job_slot, int* __restrict__ mp_job, int* __restrict__ mp_slot) {
+k_fuse_expand_jobs(int nmp, int njobs, const int* __restrict__ mp_off, const int* __restrict__ job_slot, int* __restrict__ mp_job, int* __restrict__ mp_slot,
+                   const int* __restrict__ job_set0, int* __restrict__ mp_src) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nmp) return;
   int lo = 0, hi = njobs;                                          // last job whose first map point is <= i (empty jobs skipped by the search)
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (mp_off[mid] <= i) lo = mid; else hi = mid; }
   mp_job[i] = lo; mp_slot[i] = job_slot[lo];
+  if (mp_src) mp_src[i] = job_set0[lo] + (i - mp_off[lo]);         // jobs over shared sets of map points: entry -> the set's map point
 }
 extern "C" __global__ void __launch_bounds__(256)
 k_fuse_store_rows_to_index(int nmp, const int* __restrict__ mp_slot, int maxf, int* __restrict__ best_idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nmp && best_idx[i] >= 0) best_idx[i] -= mp_slot[i] * maxf;      // store row -> key point index of its key frame
 }
-extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const uint8_t* skip, const float* pos,
-                                       const float* normal, const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th,
-                                       int* best_idx, int* best_dist) {
+// job_set0 == NULL: every job brings its own map points (entry i of the concatenated arrays IS map point i; npts = entries).  Otherwise the jobs
+// refer to SETS of map points uploaded once (job j's entries are the points job_set0[j] .. of the npts-long arrays): SearchInNeighbors sends one key
+// frame's map points to each of its ~20 neighbours, and 20 copies of the same positions / normals / descriptors were 15 of the 16 MB a call uploaded.
+static int kfstore_fuse_core(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const int* job_set0, int npts, const uint8_t* skip, const float* pos,
+                             const float* normal, const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, int* best_idx, int* best_dist) {
   if (!st || njobs < 0 || (njobs > 0 && (!job_slot || !mp_off))) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search: bad argument");
   if (njobs == 0) return CMS_OK;
   const int nmp = mp_off[njobs];
@@ -837,12 +842,13 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
   }
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const size_t n4 = (size_t)nmp * 4, j4 = (size_t)njobs * 4;
+  if (!job_set0) npts = nmp;
+  const size_t n4 = (size_t)nmp * 4, j4 = (size_t)njobs * 4, p4 = (size_t)npts * 4;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
-  const size_t o_pose = take(pose.size() * 4), o_joff = take(j4 + 4), o_jslot = take(j4), o_job = take(n4), o_slot = take(n4), o_skip = take(nmp), o_pos = take(3 * n4),
-               o_nrm = take(3 * n4), o_min = take(n4), o_max = take(n4), o_desc = take((size_t)nmp * 32), o_qx = take(n4), o_qy = take(n4), o_qr = take(n4),
+  const size_t o_pose = take(pose.size() * 4), o_joff = take(j4 + 4), o_jslot = take(j4), o_jset = take(j4), o_src = take(n4), o_job = take(n4), o_slot = take(n4), o_skip = take(nmp),
+               o_pos = take(3 * p4), o_nrm = take(3 * p4), o_min = take(p4), o_max = take(p4), o_desc = take((size_t)npts * 32), o_qx = take(n4), o_qy = take(n4), o_qr = take(n4),
                o_qmin = take(n4), o_qmax = take(n4), o_lvl = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16), o_bi = take(n4), o_bd = take(n4);
   const size_t fixed = o;
   int cap = 64 * nmp + 1024;
@@ -855,13 +861,17 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
     HIPCHK(hipMemcpyAsync(p + o_joff, mp_off, j4 + 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(p + o_jslot, job_slot, j4, hipMemcpyHostToDevice, s));
     if (skip) HIPCHK(hipMemcpyAsync(p + o_skip, skip, nmp, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_pos, pos, 3 * n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_nrm, normal, 3 * n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_min, min_dist, n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_max, max_dist, n4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_fuse_expand_jobs, dim3((nmp + 255) / 256), dim3(256), 0, s, nmp, njobs, (const int*)(p + o_joff), (const int*)(p + o_jslot), (int*)(p + o_job), (int*)(p + o_slot));
+    if (job_set0) HIPCHK(hipMemcpyAsync(p + o_jset, job_set0, j4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_pos, pos, 3 * p4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_nrm, normal, 3 * p4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_min, min_dist, p4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_max, max_dist, p4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(p + o_desc, mp_desc, (size_t)npts * 32, hipMemcpyHostToDevice, s));
+    const int* src_dev = job_set0 ? (const int*)(p + o_src) : nullptr;
+    hipLaunchKernelGGL(k_fuse_expand_jobs, dim3((nmp + 255) / 256), dim3(256), 0, s, nmp, njobs, (const int*)(p + o_joff), (const int*)(p + o_jslot), (int*)(p + o_job), (int*)(p + o_slot),
+                       job_set0 ? (const int*)(p + o_jset) : nullptr, job_set0 ? (int*)(p + o_src) : nullptr);
     CmsFuseArgs fa;
+    fa.src = src_dev;
     fa.bounds_scaled = c->dist_bounds_scaled;
     fa.pose15 = (const float*)(p + o_pose); fa.mp_frame = (const int*)(p + o_job); fa.n = nmp; fa.skip = skip ? p + o_skip : nullptr;
     fa.P = (const float*)(p + o_pos); fa.normal = (const float*)(p + o_nrm); fa.min_dist = (const float*)(p + o_min); fa.max_dist = (const float*)(p + o_max);
@@ -890,7 +900,7 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
     // The scan is enqueued right behind the windows: the total is looked at together with the results (ONE synchronisation per call; the fill pass
     // never writes beyond `cap`, and a call whose lists did not fit is simply repeated with room for them)
     CmsFuseScanArgs sa;
-    sa.cap = cap;
+    sa.cap = cap; sa.src = src_dev;
     sa.n = nmp; sa.qx = fa.qx; sa.qy = fa.qy; sa.level = fa.level; sa.mp_desc = (const uint4*)(p + o_desc);
     sa.cand_off = (const int*)(p + o_off); sa.cand_idx = (const int*)(p + o_idx); sa.kp = (const CmsKeyPoint*)st->d_kp; sa.t_desc = (const uint4*)st->d_desc;
     for (int l = 0; l < 16; ++l) sa.inv_sigma2[l] = l < c->g.nlevels ? c->inv_sigma2[l] : 0.0f;
@@ -907,4 +917,31 @@ extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* jo
     return CMS_OK;
   }
   return cms_fail(CMS_ERR_OVERFLOW, "cms_kfstore_fuse_search: candidate lists kept growing");
+}
+extern "C" int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const uint8_t* skip, const float* pos,
+                                       const float* normal, const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th,
+                                       int* best_idx, int* best_dist) {
+  return kfstore_fuse_core(st, njobs, job_slot, mp_off, nullptr, 0, skip, pos, normal, min_dist, max_dist, mp_desc, th, best_idx, best_dist);
+}
+// SearchInNeighbors' shape (LocalMapping.cpp:388-466): nsets sets of map points (set s = points set_off[s] .. set_off[s + 1] of pos / normal / min_dist /
+// max_dist / mp_desc), njobs jobs (key frame slot job_slot[j], set job_set[j]); skip / best_idx / best_dist are per ENTRY: job after job, a job's entries
+// in the order of its set (skip may be NULL)
+extern "C" int cms_kfstore_fuse_search_sets(cms_kfstore* st, int nsets, const int* set_off, const float* pos, const float* normal, const float* min_dist,
+                                            const float* max_dist, const uint8_t* mp_desc, int njobs, const int* job_slot, const int* job_set, const uint8_t* skip,
+                                            float th, int* best_idx, int* best_dist) {
+  if (!st || nsets < 0 || njobs < 0 || (nsets > 0 && !set_off) || (njobs > 0 && (!job_slot || !job_set))) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search_sets: bad argument");
+  if (njobs == 0) return CMS_OK;
+  if (nsets == 0 || set_off[0] != 0) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search_sets: bad sets");
+  for (int s = 0; s < nsets; ++s) if (set_off[s + 1] < set_off[s]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search_sets: set offsets must ascend");
+  static thread_local std::vector<int> off, set0;
+  off.resize((size_t)njobs + 1); set0.resize((size_t)njobs);
+  off[0] = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (job_set[j] < 0 || job_set[j] >= nsets) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search_sets: bad set index");
+    set0[(size_t)j] = set_off[job_set[j]];
+    const long long nx = (long long)off[(size_t)j] + (set_off[job_set[j] + 1] - set_off[job_set[j]]);
+    if (nx > 0x7FFFFFFF / 80) return cms_fail(CMS_ERR_ARG, "cms_kfstore_fuse_search_sets: too many entries for one call");
+    off[(size_t)j + 1] = (int)nx;
+  }
+  return kfstore_fuse_core(st, njobs, job_slot, off.data(), set0.data(), set_off[nsets], skip, pos, normal, min_dist, max_dist, mp_desc, th, best_idx, best_dist);
 }

@@ -179,6 +179,132 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
   }
 }
 
+// ------------------------------------------------------------------------------------------------ resize, two levels per launch
+// Level l + 1 is computed from level l, so a launch per level reads every intermediate level back from HBM right after writing it (and pays a
+// launch's latency per level: seven small launches per batch).  Here a workgroup produces a 256 x CMS_RZ_ROWS tile of level l + 1 AND the part of
+// level l that tile is computed from: it stages the rectangle of level l - 1 behind it in LDS, computes its rectangle of level l into LDS,
+// stores the part of it that it OWNS (rectangles of neighbouring workgroups overlap by a few pixels: the boundaries between them are the left /
+// top edges of the rectangles, which ascend with the tile index), and computes its tile of level l + 1 from the LDS copy.  Same integer
+// arithmetic per pixel as k_resize (cv::resize INTER_LINEAR, 11-bit coefficients): bit-identical levels; about 10 % of level l is computed twice
+// (the overlaps); level l is never read back.  Levels (1, 2), (3, 4), (5, 6) go through this kernel, level 7 through k_resize.
+//   src = level l - 1, mid = level l, dst = level l + 1; tab?1 = mid's tables (from src), tab?2 = dst's tables (from mid)
+//   ls = LDS row stride of the staged src rectangle, la = of the mid rectangle (both multiples of 16); lo? / hi?: the ratios w(l-1) / w(l) and
+//   w(l) / w(l+1) rounded down / up to 16 fractional bits
+#define CMS_RZ2_SROWS 40          /* rows of src a workgroup may stage: 16 x 1.2 + 4 rows of mid, x 1.2 + 4 rows of src = 32 at the pyramid's ratio */
+#define CMS_RZ2_AROWS 26          /* rows of mid */
+struct CmsResize2 {
+  CmsLevel src, mid, dst;
+  const CmsResizeTab* tabx1; const CmsResizeTab* taby1; const CmsResizeTab* tabx2; const CmsResizeTab* taby2;
+  int ls, la, arows, lo1, hi1, lo2, hi2, skip_zero;
+};
+extern "C" __global__ void __launch_bounds__(256)
+k_resize2(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsResize2 a) {
+  extern __shared__ __align__(16) uint8_t rtile[];
+  const CmsLevel& src = a.src; const CmsLevel& mid = a.mid; const CmsLevel& dst = a.dst;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int xb = blockIdx.x * 256, yb = blockIdx.y * CMS_RZ_ROWS, b = blockIdx.z;
+  const int xl = min(xb + 255, dst.w - 1), yl = min(yb + CMS_RZ_ROWS - 1, dst.h - 1);
+  // the rectangle of mid this tile is computed from (k_resize's bounds) and the part of it this workgroup owns: up to where the next tile's
+  // rectangle begins (the last tile of a row / column: up to the level's edge)
+  auto lo_of = [&](int d, int lo, int lim) { return min(max(((d * lo) >> 16) - 1, 0), lim); };
+  const int ac0 = lo_of(xb, a.lo2, mid.w - 1) & ~15;
+  const int ac1 = min((((xl + 1) * a.hi2 + 65535) >> 16) + 1, mid.w - 1);
+  const int ar0 = lo_of(yb, a.lo2, mid.h - 1);
+  const int ar1 = min((((yl + 1) * a.hi2 + 65535) >> 16) + 1, mid.h - 1);
+  const int ox1 = (int)blockIdx.x + 1 < (int)gridDim.x ? (lo_of(xb + 256, a.lo2, mid.w - 1) & ~15) : mid.w;
+  const int oy1 = (int)blockIdx.y + 1 < (int)gridDim.y ? lo_of(yb + CMS_RZ_ROWS, a.lo2, mid.h - 1) : mid.h;
+  // both the tile of dst and the owned part of mid inside the constant-zero corner region of a remapped cross: nothing to do
+  if (a.skip_zero && (xl < dst.zlo || xb >= dst.w - dst.zhi) && (yl < dst.zlo || yb >= dst.h - dst.zhi) &&
+      (ox1 - 1 < mid.zlo || ac0 >= mid.w - mid.zhi) && (oy1 - 1 < mid.zlo || ar0 >= mid.h - mid.zhi)) return;
+  // ... and the rectangle of src behind the rectangle of mid
+  const int sc0 = lo_of(ac0, a.lo1, src.w - 1) & ~15;
+  const int sc1 = min((((ac1 + 1) * a.hi1 + 65535) >> 16) + 1, src.w - 1);
+  const int sr0 = lo_of(ar0, a.lo1, src.h - 1);
+  const int sr1 = min((((ar1 + 1) * a.hi1 + 65535) >> 16) + 1, src.h - 1);
+  const int nq = ((sc1 - sc0) >> 4) + 1, nr = sr1 - sr0 + 1;      // 16-byte columns (<= 32), rows (<= CMS_RZ2_SROWS)
+  uint8_t* tS = rtile;                                             // staged src rectangle, row stride ls
+  uint8_t* tA = rtile + (size_t)a.ls * CMS_RZ2_SROWS;              // mid rectangle, row stride la (a.arows rows)
+  CmsResizeTab* tX = reinterpret_cast<CmsResizeTab*>(tA + (size_t)a.la * a.arows);      // mid's x table for columns ac0 .. ac1
+  const uint8_t* simg = pyr + (size_t)b * pyr_bytes + src.off;
+  {
+    const int c = tid & 31, rs = tid >> 5;
+    const uint8_t* gp = simg + (size_t)sr0 * src.stride + sc0 + 16 * c;
+    uint4 tmp[CMS_RZ2_SROWS / 8];
+#pragma unroll
+    for (int k = 0; k < CMS_RZ2_SROWS / 8; ++k) {
+      const int r = rs + 8 * k;
+      tmp[k] = (c < nq && r < nr) ? *reinterpret_cast<const uint4*>(gp + (uint32_t)__mul24(r, src.stride)) : make_uint4(0, 0, 0, 0);
+    }
+    const int nax = ac1 - ac0 + 1;
+    for (int i = tid; i < nax; i += 256) tX[i] = a.tabx1[min(ac0 + i, mid.w - 1)];
+#pragma unroll
+    for (int k = 0; k < CMS_RZ2_SROWS / 8; ++k) {
+      const int r = rs + 8 * k;
+      if (c < nq && r < nr) reinterpret_cast<uint4*>(tS + __mul24(r, a.ls))[c] = tmp[k];
+    }
+  }
+  __syncthreads();
+  // ---- the rectangle of mid: four pixels per task, tasks over (row, dword column)
+  {
+    const int ndw = ((ac1 - ac0) >> 2) + 1, nar = ar1 - ar0 + 1;
+    uint8_t* mimg = pyr + (size_t)b * pyr_bytes + mid.off;
+    for (int row = ty; row < nar; row += 4) {
+      const int y = ar0 + row;
+      const CmsResizeTab tyy = a.taby1[y];
+      const uint8_t* S0 = tS + __mul24(min(max((int)tyy.s, 0), src.h - 1) - sr0, a.ls);
+      const uint8_t* S1 = tS + __mul24(min(max((int)tyy.s + 1, 0), src.h - 1) - sr0, a.ls);
+      const int b0 = tyy.a0, b1 = tyy.a1;
+      for (int dw = tx; dw < ndw; dw += 64) {
+        const int x0 = ac0 + 4 * dw;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const CmsResizeTab t = tX[min(4 * dw + i, ac1 - ac0)];
+          const int ca = (int)t.s - sc0, cb = min((int)t.s + 1, src.w - 1) - sc0;
+          const int h0 = __mul24(S0[ca], t.a0) + __mul24(S0[cb], t.a1);
+          const int h1 = __mul24(S1[ca], t.a0) + __mul24(S1[cb], t.a1);
+          const int v = (int)((((uint32_t)b0 & 0xFFFu) * (((uint32_t)h0 >> 4) & 0xFFFFu) >> 16) +
+                              (((uint32_t)b1 & 0xFFFu) * (((uint32_t)h1 >> 4) & 0xFFFFu) >> 16) + 2) >> 2;
+          out |= (uint32_t)(v & 0xFF) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(tA + __mul24(row, a.la) + 4 * dw) = out;
+        if (x0 < ox1 && y < oy1) *reinterpret_cast<uint32_t*>(mimg + (size_t)y * mid.stride + x0) = out;      // (x0 and ox1 are multiples of 4 or the level's width)
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the tile of dst from the LDS copy of mid: k_resize's body
+  const int x0 = xb + 4 * tx;
+  if (x0 >= dst.w) return;
+  int ca[4], cb[4], a0[4], a1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const CmsResizeTab t = a.tabx2[min(x0 + i, dst.w - 1)];
+    ca[i] = (int)t.s - ac0;
+    cb[i] = min((int)t.s + 1, mid.w - 1) - ac0;
+    a0[i] = t.a0; a1[i] = t.a1;
+  }
+#pragma unroll
+  for (int rr = 0; rr < CMS_RZ_ROWS / 4; ++rr) {
+    const int y = yb + ty + 4 * rr;
+    if (y >= dst.h) break;
+    const CmsResizeTab tyy = a.taby2[y];
+    const uint8_t* S0 = tA + __mul24(min(max((int)tyy.s, 0), mid.h - 1) - ar0, a.la);
+    const uint8_t* S1 = tA + __mul24(min(max((int)tyy.s + 1, 0), mid.h - 1) - ar0, a.la);
+    const int b0 = tyy.a0, b1 = tyy.a1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h0 = __mul24(S0[ca[i]], a0[i]) + __mul24(S0[cb[i]], a1[i]);
+      const int h1 = __mul24(S1[ca[i]], a0[i]) + __mul24(S1[cb[i]], a1[i]);
+      const int v = (int)((((uint32_t)b0 & 0xFFFu) * (((uint32_t)h0 >> 4) & 0xFFFFu) >> 16) +
+                          (((uint32_t)b1 & 0xFFFu) * (((uint32_t)h1 >> 4) & 0xFFFFu) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xFF) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(pyr + (size_t)b * pyr_bytes + dst.off + (size_t)y * dst.stride + x0) = out;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ FAST cells
 // Arc score A(p) = max over the 16 contiguous 9-arcs and both polarities of min |v - x|; cornerScore<16> == A - 1.
 // p is a corner at threshold t  <=>  A(p) > t.   Returns A-1 if A > t else 0.

@@ -504,6 +504,7 @@ struct CmsFuseArgs {
   float th, log_scale; int nlevels, F; float sf[16];
   float* qx; float* qy; float* qr; int* qmin; int* qmax; int* level;
   int bounds_scaled;           // cms_set_distance_bounds_mode
+  const int* src;              // NULL, or per entry the map point whose P / normal / min_dist / max_dist it stands for (jobs that share a set of map points)
 };
 extern "C" __global__ void __launch_bounds__(256) k_fuse_project(CmsFuseArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -512,18 +513,19 @@ extern "C" __global__ void __launch_bounds__(256) k_fuse_project(CmsFuseArgs a) 
   float u = -1.0f, v = -1.0f, r = -1.0f; int lvl = -1;
   do {
     if (a.skip && a.skip[i]) break;
-    const float p[3] = {a.P[3 * (size_t)i], a.P[3 * (size_t)i + 1], a.P[3 * (size_t)i + 2]};
+    const size_t m = a.src ? (size_t)a.src[i] : (size_t)i;
+    const float p[3] = {a.P[3 * m], a.P[3 * m + 1], a.P[3 * m + 2]};
     float pc[3];
     tri_mat3_vec(ps, p, ps + 9, pc);
     track_rays_to_cubemap(a.F, pc[0], pc[1], pc[2], u, v);       // the face is not looked at (ORBMatcher.cpp:1151)
     const float mx = (float)(3 * a.F);
     if (!(u >= 0.0f && u < mx && v >= 0.0f && v < mx)) break;      // KeyFrame::IsInImage
     float maxd, maxDistance, minDistance;
-    track_distance_bounds(a.bounds_scaled, a.min_dist[i], a.max_dist[i], minDistance, maxDistance, maxd);
+    track_distance_bounds(a.bounds_scaled, a.min_dist[m], a.max_dist[m], minDistance, maxDistance, maxd);
     const float PO[3] = {__fsub_rn(p[0], ps[12]), __fsub_rn(p[1], ps[13]), __fsub_rn(p[2], ps[14])};
     const float dist3D = (float)tri_dnorm3(PO);
     if (dist3D < minDistance || dist3D > maxDistance) break;
-    if (tri_ddot3(PO, a.normal + 3 * (size_t)i) < __dmul_rn(0.5, (double)dist3D)) break;
+    if (tri_ddot3(PO, a.normal + 3 * m) < __dmul_rn(0.5, (double)dist3D)) break;
     const float ratio = maxd / dist3D;
     int ns = (int)ceilf((float)log((double)ratio) / a.log_scale);
     if (ns < 0) ns = 0; else if (ns >= a.nlevels) ns = a.nlevels - 1;
@@ -537,6 +539,7 @@ struct CmsFuseScanArgs {
   int n; const float* qx; const float* qy; const int* level; const uint4* mp_desc; const int* cand_off; const int* cand_idx;
   const CmsKeyPoint* kp; const uint4* t_desc; float inv_sigma2[16]; int* best_idx; int* best_dist;
   int cap;                      // entries of cand_idx that exist (0: all of them): a scan enqueued before the host has seen the total never reads beyond them
+  const int* src;               // NULL, or per entry the map point whose descriptor it scans with (see CmsFuseArgs::src)
 };
 extern "C" __global__ void __launch_bounds__(256) k_fuse_scan(CmsFuseScanArgs a) {
   const int n = a.n;
@@ -552,7 +555,8 @@ extern "C" __global__ void __launch_bounds__(256) k_fuse_scan(CmsFuseScanArgs a)
   const float u = qx[ii], v = qy[ii];
   uint32_t key = 0xFFFFFFFFu;                        // dist << 20 | position: the first minimum in list order wins
   if (c1 > c0) {
-    const uint4 d0 = mp_desc[2 * (size_t)ii], d1 = mp_desc[2 * (size_t)ii + 1];
+    const size_t mi = a.src ? (size_t)a.src[ii] : (size_t)ii;
+    const uint4 d0 = mp_desc[2 * mi], d1 = mp_desc[2 * mi + 1];
     for (int c = c0 + gl; c < c1; c += 8) {
       const size_t row = (size_t)cand_idx[c];
       const CmsKeyPoint k = kp[row];

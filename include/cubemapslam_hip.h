@@ -396,6 +396,13 @@ int cms_kfstore_debug_fetch(cms_kfstore* st, int slot, cms_keypoint* kps, uint8_
 int cms_kfstore_fuse_search(cms_kfstore* st, int njobs, const int* job_slot, const int* mp_off, const uint8_t* skip, const float* pos,
                             const float* normal, const float* min_dist, const float* max_dist, const uint8_t* mp_desc, float th, int* best_idx,
                             int* best_dist);
+/* SearchInNeighbors' shape (src/LocalMapping.cpp:388-466): one key frame's map points go into each of its ~20 neighbours, so the same positions /
+ * normals / descriptors would travel 20 times.  Here they are uploaded ONCE as sets: set s = map points set_off[s] .. set_off[s + 1] of pos / normal /
+ * min_dist / max_dist / mp_desc; job j searches key frame slot job_slot[j] with set job_set[j].  skip (may be NULL), best_idx, best_dist are per
+ * ENTRY: job after job, a job's entries in the order of its set.  Results as cms_kfstore_fuse_search's. */
+int cms_kfstore_fuse_search_sets(cms_kfstore* st, int nsets, const int* set_off, const float* pos, const float* normal, const float* min_dist,
+                                 const float* max_dist, const uint8_t* mp_desc, int njobs, const int* job_slot, const int* job_set, const uint8_t* skip,
+                                 float th, int* best_idx, int* best_dist);
 int cms_kfstore_create_new_map_points(cms_kfstore* st, int njobs, const int* cur_slot, const int* neigh_off, const int* neigh_slot,
                                       int check_orientation, int cap_per_job, int* n_new, int* out_neigh, int* out_idx1, int* out_idx2,
                                       float* out_x3d);

@@ -1220,6 +1220,16 @@ def test_kfstore_fuse_search_matches_oracle():
     for j in range(4):
         assert np.array_equal(got[j][0], want[j][0]) and np.array_equal(got[j][1], want[j][1]), j
     assert sum((w[0] >= 0).sum() for w in want[:3]) > 900
+    # the same searches with the map points uploaded once per SET (cms_kfstore_fuse_search_sets: SearchInNeighbors sends one key frame's map points
+    # to all of its neighbours): job 3 re-uses job 1's set, one more job sends set 0 to key frame 2 with nothing skipped
+    sets = [jobs[j][1] for j in range(3)]
+    sjobs = [(1, 0, jobs[0][1]["skip"]), (2, 1, jobs[1][1]["skip"]), (3, 2, jobs[2][1]["skip"]), (1, 1, jobs[3][1]["skip"]), (2, 0, None)]
+    got_s = store.fuse_search_sets(sets, sjobs, th=3.0)
+    for j in range(4):
+        assert np.array_equal(got_s[j][0], want[j][0]) and np.array_equal(got_s[j][1], want[j][1]), ("sets", j)
+    pr0 = prs[0]
+    w5 = orc.fuse_search(ocam, oks[1][0], np.zeros(len(pr0["pos"]), np.uint8), pr0["pos"], pr0["normal"], pr0["min_dist"], pr0["max_dist"], pr0["desc"], 3.0, sf, inv_s2)
+    assert np.array_equal(got_s[4][0], w5[0]) and np.array_equal(got_s[4][1], w5[1])
     with pytest.raises(api.CmsError):
         store.fuse_search([(0, jobs[0][1])])                    # empty slot
     store.close(); ctx.close()
