@@ -380,13 +380,6 @@ __device__ long long ba_rm_clk[16];
 #else
 #define BA_RM_STAMP(i) do { } while (0)
 #endif
-// reciprocal for the LINEARISATION's arithmetic (3x3 factors; never the residual): hardware estimate + two Newton steps (<= 1 ulp) instead of the IEEE
-// division sequence (v_div_scale x 2, v_rcp, ~7 fused multiply-adds, v_div_fmas, v_div_fixup: a dozen instructions each, three per chunk)
-__device__ __forceinline__ double ba_rcp_nr(double d) {
-  double x = __builtin_amdgcn_rcp(d);
-  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
-  return __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
-}
 // a double of quad lane P (P = 0 .. 3) in every lane of the quad: two DPP moves, no LDS
 template <int P> __device__ __forceinline__ double ba_quad_bcast(double v) {
   const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), P * 0x55, 0xF, 0xF, true);
@@ -572,22 +565,11 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     {
       // the key frame's own block and gradient: summed in registers until the run ends
       int cidx = 0;
-#ifdef BA_RM_FAST
-      double Jw[12];                                               // ow Jp once: two fused multiply-adds per entry of the block instead of a product, a fused multiply-add and another
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Jw[i] = owf * Jp[i];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int q = r; q < 6; ++q) hp[cidx++] += Jw[r] * Jp[q] + Jw[6 + r] * Jp[6 + q];
-      }
-#else
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
 #pragma unroll
         for (int q = r; q < 6; ++q) hp[cidx++] += owf * (Jp[r] * Jp[q] + Jp[6 + r] * Jp[6 + q]);
       }
-#endif
       const double of0 = s_ >= 0 ? o0 : 0.0, of1 = s_ >= 0 ? o1 : 0.0;
 #pragma unroll
       for (int r = 0; r < 6; ++r) hp[21 + r] += Jp[r] * of0 + Jp[6 + r] * of1;
@@ -603,15 +585,8 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     // Other point sizes: through the rows.
     double sum[9];
     if (k_run == 4) {
-#ifdef BA_RM_FAST
-      // butterfly: (v0 + v1) + (v2 + v3) in every lane of the quad -- the same bits in all four (additions commute), four DPP moves and two
-      // additions per value instead of eight and three
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { const double s1 = hl[i] + ba_quad_perm<0xB1>(hl[i]); sum[i] = s1 + ba_quad_perm<0x4E>(s1); }
-#else
 #pragma unroll
       for (int i = 0; i < 9; ++i) sum[i] = ((ba_quad_bcast<0>(hl[i]) + ba_quad_bcast<1>(hl[i])) + ba_quad_bcast<2>(hl[i])) + ba_quad_bcast<3>(hl[i]);
-#endif
     } else if (k_run == 2) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) sum[i] = ba_quad_perm<0xA0>(hl[i]) + ba_quad_perm<0xF5>(hl[i]);      // lanes {0, 0, 2, 2} + lanes {1, 1, 3, 3}
@@ -648,19 +623,13 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
       // A = Hll + lambda I = L D L^T (unit lower L); every lane of the point computes the same factors (a lane without an edge: of the identity)
       const double dead = live ? 0.0 : 1.0;
       const double a00 = sum[0] + lambda + dead, a10 = sum[1], a11 = sum[3] + lambda + dead, a20 = sum[2], a21 = sum[4], a22 = sum[5] + lambda + dead;
-#ifdef BA_RM_FAST
-#define BA_RM_RCP(x) ba_rcp_nr(x)
-#else
-#define BA_RM_RCP(x) (1.0 / (x))
-#endif
-      const double i0 = BA_RM_RCP(a00);
+      const double i0 = 1.0 / a00;
       const double l10 = a10 * i0, l20 = a20 * i0;
       const double d1 = a11 - l10 * a10;
-      const double i1 = BA_RM_RCP(d1);
+      const double i1 = 1.0 / d1;
       const double l21 = (a21 - l20 * a10) * i1;
       const double d2 = a22 - l20 * a20 - l21 * (l21 * d1);
-      const double i2 = BA_RM_RCP(d2);
-#undef BA_RM_RCP
+      const double i2 = 1.0 / d2;
       if (live && a == 0) {                                        // the point's slot: D^-1 | y = L^-1 bl
         const double y0 = sum[6], y1 = sum[7] - l10 * y0, y2 = sum[8] - l20 * y0 - l21 * y1;
         double2* pp = reinterpret_cast<double2*>(slots + (size_t)jpt * 6);
