@@ -567,6 +567,12 @@ def main():
             Ow = np.ascontiguousarray(np.stack([k["Ow"] for k in S["kfs"][:20]]), np.float32)
             per_w.append(dict(keep=(sl, R, t, Ow), args=(20, api._p(sl), api._p(R), api._p(t), api._p(Ow))))
         upd_prep.append(per_w)
+    upd_all = []                                                  # a whole step's windows of a group in one call (what the queue usually holds)
+    for gi in range(n_grp):
+        ks = [q["keep"] for q in upd_prep[gi]]
+        sl = np.ascontiguousarray(np.concatenate([k_[0] for k_ in ks])); R = np.ascontiguousarray(np.concatenate([k_[1] for k_ in ks]))
+        t = np.ascontiguousarray(np.concatenate([k_[2] for k_ in ks])); Ow = np.ascontiguousarray(np.concatenate([k_[3] for k_ in ks]))
+        upd_all.append(dict(keep=(sl, R, t, Ow), n=len(ks), args=(len(sl), api._p(sl), api._p(R), api._p(t), api._p(Ow))))
     map_acc = {"fuse_ms": 0.0, "fuse_n": 0, "fused": 0, "put_ms": 0.0, "put_n": 0, "upd_ms": 0.0, "upd_n": 0}
     def fuse_group(gi):
         t0_ = time.perf_counter()
@@ -581,6 +587,14 @@ def main():
         local BA's result before it takes the next key frame"""
         wb_queue[gi].append(wi)
     def apply_write_backs(gi):
+        if len(wb_queue[gi]) >= upd_all[gi]["n"] and sorted(list(wb_queue[gi])[:upd_all[gi]["n"]]) == list(range(upd_all[gi]["n"])):
+            for _ in range(upd_all[gi]["n"]):                      # every window of the previous step was read back: their 16 x 20 poses in one call
+                wb_queue[gi].popleft()
+            t0_ = time.perf_counter()
+            rc = L_.cms_kfstore_update_poses(tri_store[gi].h, *upd_all[gi]["args"])
+            if rc < 0:
+                raise RuntimeError("cms_kfstore_update_poses: %s" % L_.cms_last_error().decode())
+            map_acc["upd_ms"] += 1e3 * (time.perf_counter() - t0_); map_acc["upd_n"] += upd_all[gi]["n"]
         while wb_queue[gi]:
             wi = wb_queue[gi].popleft()
             t0_ = time.perf_counter()
