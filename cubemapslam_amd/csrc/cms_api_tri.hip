@@ -331,6 +331,7 @@ struct cms_kfstore {
   struct PutCall { hipEvent_t ev = nullptr; ~PutCall() { if (ev) (void)hipEventDestroy(ev); } };
   int* h_ff = nullptr; size_t ff_stride = 0; std::vector<std::shared_ptr<PutCall>> ff_call;
   void* h_items = nullptr; int items_gen = 0; std::shared_ptr<PutCall> items_call[2];      // the batch's descriptors: two pinned arrays, used alternately
+  unsigned upd_call = 0; hipEvent_t upd_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool upd_ev_set[4] = {false, false, false, false};
   float* h_upd = nullptr; std::vector<uint8_t> upd_par;      // two 16-float blocks per SLOT, used alternately: a block is rewritten only by the SECOND later update
                                                              // of the same slot, long after the kernel of the first has read it (no event, no wait)
 };
@@ -344,6 +345,7 @@ extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
   if (st->h_ff) (void)hipHostFree(st->h_ff);
   if (st->h_items) (void)hipHostFree(st->h_items);
   if (st->h_upd) (void)hipHostFree(st->h_upd);
+  for (hipEvent_t e : st->upd_ev) if (e) (void)hipEventDestroy(e);
   delete st;
 }
 
@@ -546,11 +548,11 @@ extern "C" int cms_kfstore_put_from_frame(cms_kfstore* st, int slot, cms_ctx* sr
 
 // the poses of n resident key frames after a local BA (Optimizer.cpp:419-431 writes them back; LocalMapping's next CreateNewMapPoints reads them):
 // one kernel, the values read from a pinned block, no synchronisation -- cms_kfstore_update per key frame is a copy and a stream wait each
-struct CmsKfUpdSlots { int n; int slot[62]; };      // (by value in the kernel arguments: nothing of a call lives in memory another call could overwrite)
-extern "C" __global__ void __launch_bounds__(64) k_kf_update_poses(CmsTriKF* kf, const float* upd, CmsKfUpdSlots sl) {
+// (the call's slot list travels in a pinned ring of four lists: a list is rewritten four calls later)
+extern "C" __global__ void __launch_bounds__(64) k_kf_update_poses(CmsTriKF* kf, const float* upd, const int* __restrict__ list, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= sl.n) return;
-  const int slot = sl.slot[i] & 0x3FFFFFFF, par = (sl.slot[i] >> 30) & 1;
+  if (i >= n) return;
+  const int slot = list[i] & 0x3FFFFFFF, par = (list[i] >> 30) & 1;
   const float* u = upd + 16 * (2 * (size_t)slot + par);
   CmsTriKF& d = kf[slot];
   for (int j = 0; j < 9; ++j) d.Rcw[j] = u[j];
@@ -562,26 +564,29 @@ extern "C" int cms_kfstore_update_poses(cms_kfstore* st, int n, const int* slots
   if (n == 0) return CMS_OK;
   cms_ctx* c = st->c;
   HIPCHK(hipSetDevice(c->device));
-  if (!st->h_upd) {
-    HIPCHK(hipHostMalloc((void**)&st->h_upd, (size_t)st->maxkf * 32 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+  if (!st->h_upd) {      // two 16-float blocks per slot, then four slot lists of maxkf ints
+    HIPCHK(hipHostMalloc((void**)&st->h_upd, (size_t)st->maxkf * (32 * sizeof(float) + 4 * sizeof(int)), hipHostMallocMapped | hipHostMallocCoherent));
     st->upd_par.assign((size_t)st->maxkf, 0);
   }
-  for (int i0 = 0; i0 < n; i0 += 62) {
-    CmsKfUpdSlots sl;
-    sl.n = std::min(62, n - i0);
-    for (int i = 0; i < sl.n; ++i) {
-      const int slot = slots[i0 + i];
-      const size_t k = (size_t)(i0 + i);
-      const int par = (st->upd_par[(size_t)slot] ^= 1);
-      float* u = st->h_upd + 16 * (2 * (size_t)slot + par);
-      std::memcpy(u, Rcw + 9 * k, 36); std::memcpy(u + 9, tcw + 3 * k, 12); std::memcpy(u + 12, Ow + 3 * k, 12);
-      CmsTriKF& d = st->h_kf[(size_t)slot];
-      std::memcpy(d.Rcw, Rcw + 9 * k, 36); std::memcpy(d.tcw, tcw + 3 * k, 12); std::memcpy(d.Ow, Ow + 3 * k, 12);
-      sl.slot[i] = slot | (par << 30);
-    }
-    hipLaunchKernelGGL(k_kf_update_poses, dim3(1), dim3(64), 0, c->stream, st->d_kf, (const float*)st->h_upd, sl);
+  const unsigned ring = st->upd_call++ & 3;
+  if (!st->upd_ev[ring]) HIPCHK(hipEventCreateWithFlags(&st->upd_ev[ring], hipEventDisableTiming));
+  // the call before the last one must be through (it usually is, long since): then every pose block written up to it has been read -- this call
+  // writes each slot's OTHER block than the slot's last update did -- and so has the slot list this call is about to reuse
+  if (st->upd_ev_set[(ring + 2) & 3]) HIPCHK(hipEventSynchronize(st->upd_ev[(ring + 2) & 3]));
+  int* list = reinterpret_cast<int*>(st->h_upd + (size_t)st->maxkf * 32) + (size_t)ring * st->maxkf;
+  for (int i = 0; i < n; ++i) {
+    const int slot = slots[i];
+    const int par = (st->upd_par[(size_t)slot] ^= 1);
+    float* u = st->h_upd + 16 * (2 * (size_t)slot + par);
+    std::memcpy(u, Rcw + 9 * (size_t)i, 36); std::memcpy(u + 9, tcw + 3 * (size_t)i, 12); std::memcpy(u + 12, Ow + 3 * (size_t)i, 12);
+    CmsTriKF& d = st->h_kf[(size_t)slot];
+    std::memcpy(d.Rcw, Rcw + 9 * (size_t)i, 36); std::memcpy(d.tcw, tcw + 3 * (size_t)i, 12); std::memcpy(d.Ow, Ow + 3 * (size_t)i, 12);
+    list[i] = slot | (par << 30);
   }
+  hipLaunchKernelGGL(k_kf_update_poses, dim3((n + 63) / 64), dim3(64), 0, c->stream, st->d_kf, (const float*)st->h_upd, (const int*)list, n);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(st->upd_ev[ring], c->stream));
+  st->upd_ev_set[ring] = true;
   return CMS_OK;
 }
 
