@@ -143,11 +143,13 @@ def host_budget(world, local_rank, window_threads_arg=0, pin=True):
             pinned = True
         except (AttributeError, OSError):
             pass
-    # one pool thread per core of the slice (between 4 and 32): the threads spend a third of their time waiting on the device.  CMS_BA_RELAXED_WAIT=1
-    # (read once by the library) lets those waits sleep instead of spin: ~3 cores less per GPU, but 3-16 % of the throughput on a 16-core box (windows
-    # are ready later, the chain's kernels measure slower) -- an option for hosts short of cores, not a default; with it 1.5 threads per core
+    # pool threads that build, read back and destroy windows: one per TWO cores of the slice since round 5 (between 4 and 16; one per core before).  A
+    # window's set-up is 0.6 ms of CPU now (device-side planner) instead of 2.5, and the threads no longer spin while the set-up waits for its turn
+    # on the device (cms_ba_set_stream's event): eight threads build a step's 32 windows in ~3 ms, sixteen only add waiters on the runtime's locks
+    # (measured 22.9 k against 22.0-22.3 k frames/s with round 4's step).  CMS_BA_RELAXED_WAIT=1 (read once by the library) lets the remaining waits
+    # sleep instead of spin; with it 1.5x the threads
     relaxed = os.environ.get("CMS_BA_RELAXED_WAIT", "") != ""
-    wthreads = window_threads_arg or max(4, min(32, (3 * budget) // 2 if relaxed else budget))
+    wthreads = window_threads_arg or max(4, min(16, (3 * budget) // 4 if relaxed else budget // 2))
     return {"cores_visible": len(cores), "cpu_quota_cores": quota, "local_world_size": local_world, "thread_budget": budget,
             "core_slice": [mine[0], mine[-1]] if mine else None, "pinned": pinned, "window_threads": wthreads, "host_waits": "sleep" if relaxed else "spin"}
 
@@ -289,6 +291,11 @@ def main():
         ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(0x4))
     args = parse_args()
     maybe_spawn(args)
+    # ~25 Python threads drive this process (window pool, window groups, mapping threads, the frame path); every library call releases the interpreter
+    # lock and has to take it again when it returns.  With the default 5-ms switch interval a returning thread can wait milliseconds for a thread that
+    # is merely running Python glue -- on the mapping side's critical path (CreateNewMapPoints -> Fuse -> local BA) that wait was most of the calls'
+    # measured time.  Bench plumbing (a C++ host has no such lock); CMS_BENCH_SWITCH_INTERVAL_US overrides.
+    sys.setswitchinterval(1e-6 * float(os.environ.get("CMS_BENCH_SWITCH_INTERVAL_US", "200")))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
