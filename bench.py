@@ -89,6 +89,7 @@ def parse_args(argv=None):
     ap.add_argument("--optimise-only-steps", type=int, default=10, help="steps of the extra pass that keeps the windows and only resets them between steps "
                     "(round 2's headline, reported as config.optimise_only; 0 = skip)")
     ap.add_argument("--unpipelined-steps", type=int, default=10, help="steps of the loop that waits for every step's own mapping side (config.unpipelined; 0 = skip)")
+    ap.add_argument("--deterministic-steps", type=int, default=6, help="steps of the extra pass with cms_ba_set_deterministic(1) (config.deterministic; 0 = skip)")
     ap.add_argument("--mapping-only-steps", type=int, default=6, help="steps of the mapping side alone (CreateNewMapPoints + local BA, no frame path): config.mapping_only, and the Schur kernel's launch time without the frame path next to it in roofline (0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
@@ -1021,6 +1022,22 @@ def main():
                         "ba_ms_per_step": round(ba_ms_r, 3), "steps": args.random_views_steps, "edges_per_window": int(np.mean([len(p_["e_pose"]) for p_ in rp])),
                         "note": "synth.ba_problem(views='random'): no point shares its set of observing key frames with enough others, every point goes through the edge-major Schur body"}
 
+    # ---- determinism as a product mode (cms_ba_set_deterministic: fixed summation order, bit-identical runs like the reference's single-threaded g2o):
+    # the same steps with every window created under the mode -- pair-owner Schur kernel, the host planner with all work lists
+    deterministic = None
+    if args.deterministic_steps > 0 and n_ba > 0:
+        api.ba_set_deterministic(True)
+        try:
+            warm_keep = args.warmup
+            args.warmup = max(args.warmup, 3)          # (these windows are larger: their slabs enter the pool during the warm-up)
+            dt_d, _, ba_ms_d, _ = timed(False, steps=args.deterministic_steps)
+            args.warmup = warm_keep
+        finally:
+            api.ba_set_deterministic(False)
+        deterministic = {"value": round(total_frames_per_step * args.deterministic_steps / dt_d, 2), "ms_per_step": round(1e3 * dt_d / args.deterministic_steps, 3),
+                         "ba_ms_per_step": round(ba_ms_d, 3), "steps": args.deterministic_steps,
+                         "note": "cms_ba_set_deterministic(1): windows run kb_ba_schur_points (fixed order, bit-identical from run to run) and are planned by the host planner"}
+
     # ---- outside the timed region: one more step with the windows' whole life cycle whose results are kept; iteration counts and outlier
     # counts of ALL its windows, and the estimates of a sample, against the CPU oracle
     ba_check = None
@@ -1347,7 +1364,7 @@ def main():
                                            "note": "every step creates its %d windows from the problems' host arrays (cms_ba_create: host work lists, one pinned upload), optimises "
                                                    "them, reads poses / points / outlier flags back (cms_ba_read) and destroys them; a pool of host threads builds step s + 1's "
                                                    "windows and finishes step s - 1's while step s runs, all inside the timed region" % n_ba},
-                       "ba_worker_ms": worker_break, "mapping_side": mapping_side, "optimise_only": optimise_only, "unpipelined": unpipelined, "mapping_only": mapping_only,
+                       "ba_worker_ms": worker_break, "mapping_side": mapping_side, "deterministic": deterministic, "optimise_only": optimise_only, "unpipelined": unpipelined, "mapping_only": mapping_only,
                        "step_pipelining": ("the mapping side of step s (CreateNewMapPoints + local BA, windows created / read back / destroyed) is waited for at the end of step s + 1: "
                                            "it overlaps the next batch's frame path like LocalMapping overlaps Tracking; all of it inside the timed region") if pipeline_default else "off (CMS_BENCH_NO_PIPELINE)", "ba_views": args.ba_views, "ba_views_random": random_views,
                        "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
