@@ -8,7 +8,7 @@
 # Summaries are then copied into profiles/ by tools/summarise_profiles.py.  Counter passes never carry --stats / trace domains beyond
 # --kernel-trace.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 PB=${PROF_B:-256}          # frames per dispatch of the PMC passes = bench.py's default --batch
 export PROF_B=$PB
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -27,7 +27,7 @@ with open(sys.argv[2], "w") as f:
         w.writerow([r[k].split("(")[0][:40] if k == "Kernel_Name" else r[k] for k in keep])
 PY
 gzip -f $OUT/${TAG}_trace_small.csv
-python $R/tools/step_table.py $OUT/${TAG}_trace_small.csv.gz 6 > $OUT/${TAG}_step_table.md
+python $R/tools/step_table.py $OUT/${TAG}_trace_small.csv.gz 6 $OUT/${TAG}_bench_kernel_stats_timed_steps.csv > $OUT/${TAG}_step_table.md
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ${TAG}_pmc_fetch -- python $R/tools/prof_frames.py $PB 550 3 > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o ${TAG}_pmc_write -- python $R/tools/prof_frames.py $PB 550 3 > $OUT/${TAG}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ${TAG}_pmc_fetch_ba -- python $R/tools/prof_ba_many.py 8 > $OUT/${TAG}_pmc_fetch_ba.log 2>&1

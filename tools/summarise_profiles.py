@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof/<tag>_* (rocprofv3 csv output) into the small, tracked summaries under profiles/."""
 import collections, csv, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 PB = int(os.environ.get("PROF_B", "256"))      # frames per dispatch of the PMC passes (tools/run_profiles.sh)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof"); dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = os.path.join(src, tag + "_bench_kernel_stats.csv")
+stats = os.path.join(src, tag + "_bench_kernel_stats_timed_steps.csv")      # cut to the last six timed steps by tools/step_table.py (rocprofv3's own --stats
+if not os.path.exists(stats):                                                # file covers the whole process: set-up launches, warm-up and pool priming included)
+    stats = os.path.join(src, tag + "_bench_kernel_stats.csv")
 if os.path.exists(stats):
     rows = list(csv.DictReader(open(stats)))
+    cut = stats.endswith("_timed_steps.csv")
     with open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass "
-                "--optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0   (MI355X, 1 GPU; every step creates, "
-                "optimises, reads back and destroys its 32 local-BA windows; only the timed pass's launches are in the trace)\n")
+        f.write("# rocprofv3 --kernel-trace -- python bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass "
+                "--optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0 --deterministic-steps 0   (MI355X, 1 GPU; every step "
+                "inserts its 32 key frames, runs CreateNewMapPoints and SearchInNeighbors' Fuse searches for them, creates, optimises, reads back and destroys its 32 local-BA windows and writes "
+                "their poses back).  %s\n" % ("Statistics of the kernel launches of the LAST SIX TIMED STEPS only (cut from the trace by tools/step_table.py): no set-up, warm-up or pool-priming "
+                "launches" if cut else "rocprofv3's --stats over the WHOLE process: the set-up's launches (key-frame stores, track sets, pool priming) are in the totals and skew the Percentage column"))
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             f.write(",".join([r["Name"].split("(")[0][:60], r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
