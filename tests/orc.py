@@ -42,11 +42,24 @@ def build(force=False):
 _lib = None
 
 
+_lib_lock = __import__("threading").Lock()
+
+
 def lib():
+    """the oracle library with every prototype set; published only once it is complete (bench.py's first use is eight threads at once: a thread that found
+    the handle before its prototypes were set passed a Python float to an untyped function)"""
     global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
-        L = _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is None:
+            _lib = _load()
+    return _lib
+
+
+def _load():
+    if True:
+        L = C.CDLL(build())
         L.orc_orb_create.restype = C.c_void_p
         L.orc_fast_atan2.restype = C.c_float
         L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
@@ -78,7 +91,7 @@ def lib():
         L.orc_orb_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_orb_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_orb_level_distributed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    return _lib
+    return L
 
 
 def _p(a):
