@@ -524,8 +524,10 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
       const double ratio2 = (double)g.lv[l].w / g.lv[l + 1].w;
       const int la = (int)align_up((size_t)ceil(256 * ratio2) + 34, 16);                 // mid rectangle: k_resize's staged width for the tile of level l + 1
       const int ls = (int)align_up((size_t)ceil((la + 2) * ratio) + 34, 16);             // ... and the src rectangle behind it
-      const int arows = (int)ceil(CMS_RZ_ROWS * ratio2) + 7;
-      const int srows = (int)ceil((arows + 1) * ratio) + 7;
+      // rows of mid a tile can need: floor(yb r) - 1 .. ceil((yl + 1) r) + 1 -> CMS_RZ_ROWS r + 4; rows of src behind them likewise (24 and 33 at the
+      // pyramid's 1.2; the kernel's buffers hold CMS_RZ2_AROWS / CMS_RZ2_SROWS)
+      const int arows = (int)ceil(CMS_RZ_ROWS * ratio2) + 4;
+      const int srows = (int)ceil(arows * ratio) + 4;
       if (la <= 512 && ls <= 512 && arows <= CMS_RZ2_AROWS && srows <= CMS_RZ2_SROWS) {
         const CmsLevel& d = g.lv[l + 1];
         CmsResize2 a;
