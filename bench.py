@@ -1111,7 +1111,7 @@ def main():
     # measured HBM traffic / instruction mix of the kernels: committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
     # separate runs, tools/run_profiles.sh), valid for the batch size and geometry they were taken at
     def pmc(name, kname):
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             pj = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
             if os.path.exists(pj):
                 J = json.load(open(pj))

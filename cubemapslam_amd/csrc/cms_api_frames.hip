@@ -514,9 +514,11 @@ static int cms_launch_frames(cms_ctx* c, int B, int from_fisheye) {
     if (c->copy_stream) { HIPCHK(hipEventRecord(c->ev_remap_done, s)); c->remap_recorded = true; }   // the staging buffer is free from here on
   }
   if (c->prof) hipEventRecord(c->ev[1], s);
-  // levels (1, 2), (3, 4), ... two per launch (k_resize2: the intermediate level is never read back); a last odd level, and every level with
-  // CMS_RESIZE_SINGLE=1 (A/B), through k_resize
-  static const bool rz_single = getenv("CMS_RESIZE_SINGLE") != nullptr;
+  // One launch per level (k_resize).  CMS_RESIZE_FUSED=1: levels (1, 2), (3, 4), (5, 6) two per launch (k_resize2: the intermediate level is computed in LDS
+  // and never read back) -- bit-identical, and measured 2.7x SLOWER as written (2.42 against 0.89 ms per 256 frames for the pyramid): the resize is bound by its
+  // per-pixel integer arithmetic and LDS byte reads, not by HBM, so the saved read buys nothing and the second stage's irregular rectangle costs.  Kept as an
+  // experiment behind the switch.
+  static const bool rz_single = getenv("CMS_RESIZE_FUSED") == nullptr;
   for (int l = 1; l < L; ++l) {
     dim3 block(64, 4);
     const double ratio = (double)g.lv[l - 1].w / g.lv[l].w;

@@ -186,7 +186,10 @@ k_resize(uint8_t* __restrict__ pyr, size_t pyr_bytes, CmsLevel src, CmsLevel dst
 // stores the part of it that it OWNS (rectangles of neighbouring workgroups overlap by a few pixels: the boundaries between them are the left /
 // top edges of the rectangles, which ascend with the tile index), and computes its tile of level l + 1 from the LDS copy.  Same integer
 // arithmetic per pixel as k_resize (cv::resize INTER_LINEAR, 11-bit coefficients): bit-identical levels; about 10 % of level l is computed twice
-// (the overlaps); level l is never read back.  Levels (1, 2), (3, 4), (5, 6) go through this kernel, level 7 through k_resize.
+// (the overlaps); level l is never read back.  With CMS_RESIZE_FUSED=1 levels (1, 2), (3, 4), (5, 6) go through this kernel, level 7 through k_resize.
+// NOT the default: measured 2.42 against 0.89 ms per 256 frames for the whole pyramid (round 5) -- the pyramid is bound by per-pixel integer work and LDS
+// byte reads (~0.5 ms of vector issue), not by the bytes of the intermediate level, and this kernel's second stage (an irregular rectangle, tables through LDS,
+// 30 KB of LDS per workgroup) runs that work less efficiently.  Kept as a documented experiment; its index logic is what the CPU replay verified.
 //   src = level l - 1, mid = level l, dst = level l + 1; tab?1 = mid's tables (from src), tab?2 = dst's tables (from mid)
 //   ls = LDS row stride of the staged src rectangle, la = of the mid rectangle (both multiples of 16); lo? / hi?: the ratios w(l-1) / w(l) and
 //   w(l) / w(l+1) rounded down / up to 16 fractional bits

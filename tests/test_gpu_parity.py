@@ -1462,6 +1462,18 @@ def test_describe_in_spatial_order_is_bit_identical():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_two_pyramid_levels_per_launch_is_bit_identical():
+    """CMS_RESIZE_FUSED=1 computes levels (1, 2), (3, 4), (5, 6) two per launch (k_resize2: the intermediate level in LDS, stored by its owner workgroup, never
+    read back).  Not the default (measured slower: the pyramid is bound by per-pixel integer work, not bytes) but kept as an experiment: the extraction parity
+    tests -- every pyramid level compared pixel by pixel, three face sizes, zero corners skipped or not -- run again in a child process with the switch set."""
+    import os, subprocess, sys
+    env = dict(os.environ); env["CMS_RESIZE_FUSED"] = "1"
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "(extract or lut or front_camera or reference_masks) and not spatial and not two_pyramid"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_ba_optimize_many_ragged_windows_edge_major_path():
     """Windows whose points have very different numbers of observations (1 .. 12: up to six pairing steps per chunk, points straddling
     the 16-lane groups the chunk composition balances, chunks closed by a point that does not fit), two fixed key frames, key frames

@@ -7,9 +7,9 @@
 #   planners               bench step with the device-side planner / the host planner, twice each
 #   mapping                bench step with LocalMapping's whole sequence / CMS_BENCH_MAPPING_MINIMAL=1, twice each, + config.mapping_side of the last run
 #   knobs <tag> [ENV=..]   one bench run under the given environment (e.g. CMS_BA_SET_STREAM_WAIT=1, CMS_BENCH_MAP_PRIORITY=high, CMS_BENCH_BA_PRIORITY=high,
-#                          CMS_BA_RELAXED_WAIT=1, CMS_BENCH_SWITCH_INTERVAL_US=5000, CMS_RESIZE_SINGLE=1); further args go to bench.py (--window-threads 8, --ba-groups 3)
+#                          CMS_BA_RELAXED_WAIT=1, CMS_BENCH_SWITCH_INTERVAL_US=5000, CMS_RESIZE_FUSED=1); further args go to bench.py (--window-threads 8, --ba-groups 3)
 #   steptrace <tag> [ENV=..]  bench.py under rocprofv3 --kernel-trace --stats: in-step average duration of every kernel
-#   frames                 the frame path alone: two pyramid levels per launch against CMS_RESIZE_SINGLE=1
+#   frames                 the frame path alone: one pyramid level per launch (default) against CMS_RESIZE_FUSED=1 (two levels per launch)
 #   ba16 [libs]            tools/prof_ba_many.py 16 track diff 3 (the Schur kernel alone) per library variant (default | ab_NAME from tools/ab_build.sh)
 # (profiles/r05_experiments.txt collects the outputs DESIGN.md quotes)
 set -u
@@ -56,8 +56,8 @@ PY
     rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv ;;
   frames)
     for i in 1 2; do
-      echo "two levels per launch: $(timeout 300 python tools/prof_frames.py 256 550 5 2>&1 | tail -1)" | tee -a $O/frames.txt
-      echo "one level per launch:  $(CMS_RESIZE_SINGLE=1 timeout 300 python tools/prof_frames.py 256 550 5 2>&1 | tail -1)" | tee -a $O/frames.txt
+      echo "two levels per launch: $(CMS_RESIZE_FUSED=1 timeout 300 python tools/prof_frames.py 256 550 5 2>&1 | tail -1)" | tee -a $O/frames.txt
+      echo "one level per launch:  $(timeout 300 python tools/prof_frames.py 256 550 5 2>&1 | tail -1)" | tee -a $O/frames.txt
     done ;;
   ba16) shift; for v in ${@:-default}; do echo "$v: $(CMS_HIP_LIB=$(libpath $v) timeout 300 python tools/prof_ba_many.py 16 track diff 3 2>&1 | grep 'lock-step' | cut -c1-200)" | tee -a $O/ba16.txt; done ;;
   *) echo "unknown case $1"; exit 2 ;;
