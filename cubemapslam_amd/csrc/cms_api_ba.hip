@@ -110,7 +110,7 @@ struct cms_ba {
   int prof_kernel = 0; std::vector<hipEvent_t> prof_ev; double prof_ms = 0; long prof_launches = 0;
   bool fast_plan = false;    // planned by ba_plan_fast (cms_api_ba_plan.hip): the permutations and the per-edge arrays exist on the device only
   int* d_raw_pose = nullptr; int* d_raw_point = nullptr; int8_t* d_raw_face = nullptr; int* d_prank = nullptr; int* d_cpo = nullptr; int* d_cedge = nullptr;
-  uint8_t* d_pcopy = nullptr; uint8_t* d_lo_copy = nullptr; uint64_t* d_run_sig = nullptr; double* d_rb_pts = nullptr; uint8_t* d_rb_flags = nullptr;
+  uint8_t* d_pcopy = nullptr; uint8_t* d_lo_copy = nullptr; uint64_t* d_run_sig = nullptr; int* d_iperm = nullptr;
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
   hipEvent_t ev_setup = nullptr;      // cms_ba_set_stream: marks the end of the window's set-up on the stream it was created on
@@ -1410,7 +1410,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     up(zero_off.data(), (K + 1) * sizeof(int), &b->d_pose_off);
     BA_TRY(ba_alloc(b, &b->d_e_pose, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_point, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_e_face, (size_t)E));
     BA_TRY(ba_alloc(b, &b->d_perm, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_pose_edges, 1));
-    BA_TRY(ba_alloc(b, &b->d_rb_pts, 3 * (size_t)P)); BA_TRY(ba_alloc(b, &b->d_rb_flags, (size_t)E));
+    BA_TRY(ba_alloc(b, &b->d_iperm, (size_t)E));
   } else {
     up(s_pose.data(), E * sizeof(int), &b->d_e_pose); up(s_point.data(), E * sizeof(int), &b->d_e_point);
     up(s_face.data(), E, &b->d_e_face); up(pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off);
@@ -1465,7 +1465,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     x.e_pose = b->d_raw_pose; x.e_point = b->d_raw_point; x.e_face = b->d_raw_face; x.cedge = fp.grouped ? nullptr : b->d_cedge; x.cpo = b->d_cpo;
     x.prank = b->d_prank; x.pinv = b->d_pinv; x.pt_off = b->d_pt_off; x.pcopy = b->d_pcopy; x.lo_copy = b->d_lo_copy; x.e_lo0 = fp.pt_off[fp.P_rm]; x.pose_slot = b->d_pose_slot;
     x.raw_obs = b->d_raw_obs; x.raw_inv = b->d_raw_inv; x.raw_pts = b->d_raw_pts; x.poses0 = b->d_poses0;
-    x.perm = b->d_perm; x.s_pose = b->d_e_pose; x.s_point = b->d_e_point; x.s_face = b->d_e_face; x.info = b->d_se_info;
+    x.perm = b->d_perm; x.iperm = b->d_iperm; x.s_pose = b->d_e_pose; x.s_point = b->d_e_point; x.s_face = b->d_e_face; x.info = b->d_se_info;
     x.e_obs = b->d_e_obs; x.e_inv = b->d_e_inv; x.pts0 = b->d_pts0; x.poses = b->d_poses[0]; x.pts = b->d_pts[0]; x.level = b->d_level; x.err = b->d_err; x.flags = b->d_flags;
     x.gsum = b->d_se_partial; x.n_gsum = b->se.npairs2 * 42; x.gsum_bp = b->d_se_bp_partial; x.n_gsum_bp = b->np * 6;
     x.ce0 = b->d_se_chunk_e0; x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl;
@@ -1579,16 +1579,17 @@ extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* ou
     temp = true;
   }
   hipError_t re = hipSuccess;
-  const double* src_pts = b->d_pts[b->cur]; const uint8_t* src_flags = b->d_flags;
-  if (b->fast_plan && (points || outlier_flags)) {      // the permutations live on the device: points and flags are put into the caller's order there
-    hipLaunchKernelGGL(k_ba_unpermute, dim3(std::min((std::max(b->E, b->P) + 255) / 256, 512)), dim3(256), 0, rs, b->P, b->E, (const int*)b->d_pinv, (const int*)b->d_perm,
-                       (const double*)b->d_pts[b->cur], (const uint8_t*)b->d_flags, points ? b->d_rb_pts : nullptr, outlier_flags ? b->d_rb_flags : nullptr);
+  if (b->fast_plan) {      // the permutations live on the device: one kernel gathers everything in the caller's order straight into the pinned block
+    hipLaunchKernelGGL(k_ba_results_to_host, dim3(std::min((std::max(b->E / 4, 3 * b->P) + 255) / 256, 512)), dim3(256), 0, rs, b->K, b->P, b->E, (const int*)b->d_prank,
+                       (const int*)b->d_iperm, (const double*)b->d_poses[b->cur], (const double*)b->d_pts[b->cur], (const uint8_t*)b->d_flags,
+                       poses ? reinterpret_cast<double*>(h + o_pose) : nullptr, points ? reinterpret_cast<double*>(h + o_pts) : nullptr,
+                       outlier_flags ? reinterpret_cast<uint8_t*>(h + o_flags) : nullptr);
     re = hipGetLastError();
-    src_pts = b->d_rb_pts; src_flags = b->d_rb_flags;
+  } else {
+    if (poses && re == hipSuccess) re = hipMemcpyAsync(h + o_pose, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost, rs);
+    if (points && re == hipSuccess) re = hipMemcpyAsync(h + o_pts, b->d_pts[b->cur], 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, rs);
+    if (outlier_flags && re == hipSuccess) re = hipMemcpyAsync(h + o_flags, b->d_flags, b->E, hipMemcpyDeviceToHost, rs);
   }
-  if (poses && re == hipSuccess) re = hipMemcpyAsync(h + o_pose, b->d_poses[b->cur], 7 * (size_t)b->K * sizeof(double), hipMemcpyDeviceToHost, rs);
-  if (points && re == hipSuccess) re = hipMemcpyAsync(h + o_pts, src_pts, 3 * (size_t)b->P * sizeof(double), hipMemcpyDeviceToHost, rs);
-  if (outlier_flags && re == hipSuccess) re = hipMemcpyAsync(h + o_flags, src_flags, b->E, hipMemcpyDeviceToHost, rs);
   if (re == hipSuccess) re = ba_wait_stream(rs);
   if (temp) ba_stream_give(b->device, rs);
   HIPCHK(re);

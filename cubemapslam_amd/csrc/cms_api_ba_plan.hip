@@ -92,7 +92,7 @@ struct BaExpand {
   const uint8_t* lo_copy; int e_lo0;                                // ... and per left-over observation (sorted position - e_lo0): the copy the host's matching chose
   const int* pose_slot;
   const double* raw_obs; const double* raw_inv; const double* raw_pts; const double* poses0;
-  int* perm; int* s_pose; int* s_point; int8_t* s_face; uint32_t* info;
+  int* perm; int* iperm; int* s_pose; int* s_point; int8_t* s_face; uint32_t* info;      // iperm (may be NULL): caller's edge -> internal position, for the read-back
   double* e_obs; double* e_inv; double* pts0; double* poses; double* pts; uint8_t* level; double* err; uint8_t* flags;
   double* gsum; int n_gsum; double* gsum_bp; int n_gsum_bp;
   // tables
@@ -115,6 +115,7 @@ __host__ __device__ inline void ba_expand_edge_at(const BaExpand& x, int i) {
   const int p = x.prank[q], pos = x.pt_off[p] + a;
   const int face = x.e_face[e];
   x.perm[pos] = e; x.s_pose[pos] = k; x.s_point[pos] = p; x.s_face[pos] = (int8_t)face;
+  if (x.iperm) x.iperm[e] = pos;
   const uint32_t copy = x.pcopy[p] == 0xFF ? (uint32_t)x.lo_copy[pos - x.e_lo0] : (uint32_t)x.pcopy[p];
   x.info[pos] = (uint32_t)a | ((uint32_t)n << 5) | ((uint32_t)(x.pose_slot[k] + 1) << 10) | ((uint32_t)face << 16) | ((uint32_t)k << 19) | (copy << 27);
   if (x.e_obs) {
@@ -146,19 +147,25 @@ extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges(BaExpand x) 
   for (int i = t0; i < x.n_gsum; i += gs) x.gsum[i] = 0.0;
   for (int i = t0; i < x.n_gsum_bp; i += gs) x.gsum_bp[i] = 0.0;
 }
-// results back into the caller's order on the device (cms_ba_read of a window whose permutations only the device holds)
+// cms_ba_read of a window whose permutations only the device holds: one kernel GATHERS poses, points and outlier flags in the caller's order and stores
+// them straight into the window's pinned host block (coalesced stores over PCIe) -- no copy commands at all.  (A first version un-permuted into device
+// buffers and copied those: three copies behind a kernel on the same stream, which the runtime then does with blit kernels, ~100 more launches per bench
+// step at ~70 us each inside the step.)
 extern "C" __global__ void __launch_bounds__(256)
-k_ba_unpermute(int P, int E, const int* __restrict__ pinv, const int* __restrict__ perm, const double* __restrict__ pts, const uint8_t* __restrict__ flags,
-               double* __restrict__ out_pts, uint8_t* __restrict__ out_flags) {
+k_ba_results_to_host(int K, int P, int E, const int* __restrict__ prank, const int* __restrict__ iperm, const double* __restrict__ poses, const double* __restrict__ pts,
+                     const uint8_t* __restrict__ flags, double* __restrict__ out_poses, double* __restrict__ out_pts, uint8_t* __restrict__ out_flags) {
   const int gs = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (out_poses)
+    for (int i = t0; i < 7 * K; i += gs) out_poses[i] = poses[i];
   if (out_pts)
-    for (int i = t0; i < P; i += gs) {
-      const int q = pinv[i];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) out_pts[3 * (size_t)q + j] = pts[3 * (size_t)i + j];
-    }
+    for (int i = t0; i < 3 * P; i += gs) { const int q = i / 3, j = i - 3 * q; out_pts[i] = pts[3 * (size_t)prank[q] + j]; }
   if (out_flags)
-    for (int i = t0; i < E; i += gs) out_flags[perm[i]] = flags[i];
+    for (int i4 = t0; 4 * i4 < E; i4 += gs) {                      // four flags per thread: dword stores
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int e = 4 * i4 + j; if (e < E) w |= (uint32_t)flags[iperm[e]] << (8 * j); }
+      reinterpret_cast<uint32_t*>(out_flags)[i4] = w;
+    }
 }
 
 // ---- host side: everything of the plan that is decided per POINT
@@ -416,7 +423,7 @@ extern "C" int cms_ba_debug_plan_fast(int K, const uint8_t* fixed, int P, int E,
   x.K = K; x.P = P; x.E = E; x.np = b->np;
   x.e_pose = e_pose; x.e_point = e_point; x.e_face = face.data(); x.cedge = fp.grouped ? nullptr : fp.cedge.data(); x.cpo = fp.cpo.data();
   x.prank = fp.prank.data(); x.pinv = fp.pinv.data(); x.pt_off = fp.pt_off.data(); x.pcopy = fp.pcopy.data(); x.pose_slot = fp.pose_slot.data();
-  x.perm = perm_out; x.s_pose = s_pose.data(); x.s_point = s_point.data(); x.s_face = s_face.data(); x.info = info_out;
+  x.perm = perm_out; x.iperm = nullptr; x.s_pose = s_pose.data(); x.s_point = s_point.data(); x.s_face = s_face.data(); x.info = info_out;
   x.ce0 = fp.ce0.data(); x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = fp.run_sig.data(); x.n_runs = fp.n_runs; x.run_mf = run_mf.data(); x.run_fl = run_fl.data();
   x.lo_copy = fp.lo_copy.data(); x.e_lo0 = fp.pt_off[fp.P_rm];
   for (int i = 0; i < E; ++i) ba_expand_edge_at(x, i);

@@ -715,7 +715,7 @@ extern "C" int cms_fuse_search(cms_ctx* c, int b, const float* pose15, int nmp, 
     HIPCHK(hipStreamSynchronize(s));
     if (tot > cap) { cap = tot + 64; continue; }
     CmsFuseScanArgs sa;
-    sa.cap = 0; sa.src = nullptr;
+    sa.cap = 0; sa.src = nullptr; sa.row_slot = nullptr; sa.maxf = 0;
     sa.n = nmp; sa.qx = (const float*)(p + o_qx); sa.qy = (const float*)(p + o_qy); sa.level = (const int*)(p + o_lvl); sa.mp_desc = (const uint4*)(p + o_desc);
     sa.cand_off = (const int*)(p + o_off); sa.cand_idx = (const int*)(p + o_idx); sa.kp = (const CmsKeyPoint*)c->d_kps; sa.t_desc = (const uint4*)c->d_desc;
     for (int l = 0; l < 16; ++l) sa.inv_sigma2[l] = l < c->g.nlevels ? c->inv_sigma2[l] : 0.0f;
@@ -818,11 +818,6 @@ k_fuse_expand_jobs(int nmp, int njobs, const int* __restrict__ mp_off, const int
   mp_job[i] = lo; mp_slot[i] = job_slot[lo];
   if (mp_src) mp_src[i] = job_set0[lo] + (i - mp_off[lo]);         // jobs over shared sets of map points: entry -> the set's map point
 }
-extern "C" __global__ void __launch_bounds__(256)
-k_fuse_store_rows_to_index(int nmp, const int* __restrict__ mp_slot, int maxf, int* __restrict__ best_idx) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nmp && best_idx[i] >= 0) best_idx[i] -= mp_slot[i] * maxf;      // store row -> key point index of its key frame
-}
 // job_set0 == NULL: every job brings its own map points (entry i of the concatenated arrays IS map point i; npts = entries).  Otherwise the jobs
 // refer to SETS of map points uploaded once (job j's entries are the points job_set0[j] .. of the npts-long arrays): SearchInNeighbors sends one key
 // frame's map points to each of its ~20 neighbours, and 20 copies of the same positions / normals / descriptors were 15 of the 16 MB a call uploaded.
@@ -856,6 +851,13 @@ static int kfstore_fuse_core(cms_kfstore* st, int njobs, const int* job_slot, co
                o_pos = take(3 * p4), o_nrm = take(3 * p4), o_min = take(p4), o_max = take(p4), o_desc = take((size_t)npts * 32), o_qx = take(n4), o_qy = take(n4), o_qr = take(n4),
                o_qmin = take(n4), o_qmax = take(n4), o_lvl = take(n4), o_cnt = take(n4), o_off = take(n4 + 4), o_tot = take(16), o_bi = take(n4), o_bd = take(n4);
   const size_t fixed = o;
+  bool direct = false;
+  {
+    hipPointerAttribute_t a1, a2;
+    if (hipPointerGetAttributes(&a1, best_idx) == hipSuccess && hipPointerGetAttributes(&a2, best_dist) == hipSuccess)
+      direct = a1.type == hipMemoryTypeHost && a2.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();                                  // (a pageable pointer: not an error, just the copies)
+  }
   int cap = 64 * nmp + 1024;
   for (int attempt = 0; attempt < 2; ++attempt) {
     int rc = cms_scratch(c, fixed + al((size_t)cap * 4));
@@ -905,18 +907,21 @@ static int kfstore_fuse_core(cms_kfstore* st, int njobs, const int* job_slot, co
     // The scan is enqueued right behind the windows: the total is looked at together with the results (ONE synchronisation per call; the fill pass
     // never writes beyond `cap`, and a call whose lists did not fit is simply repeated with room for them)
     CmsFuseScanArgs sa;
-    sa.cap = cap; sa.src = src_dev;
+    sa.cap = cap; sa.src = src_dev; sa.row_slot = (const int*)(p + o_slot); sa.maxf = st->maxf;
     sa.n = nmp; sa.qx = fa.qx; sa.qy = fa.qy; sa.level = fa.level; sa.mp_desc = (const uint4*)(p + o_desc);
     sa.cand_off = (const int*)(p + o_off); sa.cand_idx = (const int*)(p + o_idx); sa.kp = (const CmsKeyPoint*)st->d_kp; sa.t_desc = (const uint4*)st->d_desc;
     for (int l = 0; l < 16; ++l) sa.inv_sigma2[l] = l < c->g.nlevels ? c->inv_sigma2[l] : 0.0f;
-    sa.best_idx = (int*)(p + o_bi); sa.best_dist = (int*)(p + o_bd);
-    hipLaunchKernelGGL(k_fuse_scan, dim3((nmp * 8 + 255) / 256), dim3(256), 0, s, sa);
-    hipLaunchKernelGGL(k_fuse_store_rows_to_index, dim3((nmp + 255) / 256), dim3(256), 0, s, nmp, (const int*)(p + o_slot), st->maxf, (int*)(p + o_bi));
+    // result arrays in pinned (device-visible) host memory: the kernels store there themselves -- copies queued behind kernels of the same stream are
+    // blit kernels of the runtime, two more dependent launches that wait for a slot on a busy chip
+    sa.best_idx = direct ? best_idx : (int*)(p + o_bi); sa.best_dist = direct ? best_dist : (int*)(p + o_bd);
+    hipLaunchKernelGGL(k_fuse_scan, dim3((nmp * 8 + 255) / 256), dim3(256), 0, s, sa);      // (stores the key-point index inside the job's key frame: row - slot x maxf)
     HIPCHK(hipGetLastError());
     int tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, p + o_tot, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(best_idx, p + o_bi, n4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(best_dist, p + o_bd, n4, hipMemcpyDeviceToHost, s));
+    if (!direct) {
+      HIPCHK(hipMemcpyAsync(best_idx, p + o_bi, n4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(best_dist, p + o_bd, n4, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipStreamSynchronize(s));
     if (tot > cap) { cap = tot + 64; continue; }
     return CMS_OK;

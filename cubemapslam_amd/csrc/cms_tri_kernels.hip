@@ -540,6 +540,7 @@ struct CmsFuseScanArgs {
   const CmsKeyPoint* kp; const uint4* t_desc; float inv_sigma2[16]; int* best_idx; int* best_dist;
   int cap;                      // entries of cand_idx that exist (0: all of them): a scan enqueued before the host has seen the total never reads beyond them
   const int* src;               // NULL, or per entry the map point whose descriptor it scans with (see CmsFuseArgs::src)
+  const int* row_slot; int maxf; // NULL, or per entry the store slot its candidates' rows belong to: the result is then the key-point index inside that key frame (row - slot x maxf)
 };
 extern "C" __global__ void __launch_bounds__(256) k_fuse_scan(CmsFuseScanArgs a) {
   const int n = a.n;
@@ -574,7 +575,7 @@ extern "C" __global__ void __launch_bounds__(256) k_fuse_scan(CmsFuseScanArgs a)
   if (live && gl == 0) {
     const int d = key == 0xFFFFFFFFu ? 256 : (int)(key >> 20);
     const bool hit = d <= 50;                        // TH_LOW
-    best_idx[i] = hit ? cand_idx[c0 + (int)(key & 0xFFFFFu)] : -1;
+    best_idx[i] = hit ? cand_idx[c0 + (int)(key & 0xFFFFFu)] - (a.row_slot ? a.row_slot[i] * a.maxf : 0) : -1;
     best_dist[i] = hit ? d : 256;
   }
 }

@@ -42,7 +42,7 @@ print("GPU busy (at least one kernel in flight) %.2f ms per step = %.0f %% of th
                                       sum(v[1] for v in agg.values()) / nst / 1e6))
 print()
 groups = [("local BA: Levenberg rounds", ("kb_ba_lin_schur", "kb_ba_trial_", "kb_ba_reduce2", "kb_ba_schur_edges_reduce")),
-          ("local BA: per stage / per window", ("kb_ba_first_pass", "k_copy16", "kb_ba_lin", "kb_ba_maxdiag", "kb_ba_errors", "kb_ba_reduce", "kb_ba_classify", "kb_ba_lm_load", "kb_ba_counts", "k_ba_reset", "k_ba_gather", "k_ba_expand", "k_ba_unpermute")),
+          ("local BA: per stage / per window", ("kb_ba_first_pass", "k_copy16", "kb_ba_lin", "kb_ba_maxdiag", "kb_ba_errors", "kb_ba_reduce", "kb_ba_classify", "kb_ba_lm_load", "kb_ba_counts", "k_ba_reset", "k_ba_gather", "k_ba_expand", "k_ba_unpermute", "k_ba_results")),
           ("CreateNewMapPoints", ("k_tri_",)),
           ("key-frame insertion, SearchInNeighbors (Fuse), pose write-back", ("k_kf_", "k_fuse_")),
           ("frame path: remap + ORB extraction", ("k_remap", "k_resize", "k_fast_cells", "k_quadtree", "k_cull", "k_describe")),
