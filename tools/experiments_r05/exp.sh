@@ -9,6 +9,7 @@
 #   knobs <tag> [ENV=..]   one bench run under the given environment (e.g. CMS_BA_SET_STREAM_WAIT=1, CMS_BENCH_MAP_PRIORITY=high, CMS_BENCH_BA_PRIORITY=high,
 #                          CMS_BA_RELAXED_WAIT=1, CMS_BENCH_SWITCH_INTERVAL_US=5000, CMS_RESIZE_FUSED=1); further args go to bench.py (--window-threads 8, --ba-groups 3)
 #   steptrace <tag> [ENV=..]  bench.py under rocprofv3 --kernel-trace --stats: in-step average duration of every kernel
+#   steptable <tag>        bench.py under rocprofv3 --kernel-trace -> tools/step_table.py (per-step launches, summed and average durations)
 #   frames                 the frame path alone: one pyramid level per launch (default) against CMS_RESIZE_FUSED=1 (two levels per launch)
 #   ba16 [libs]            tools/prof_ba_many.py 16 track diff 3 (the Schur kernel alone) per library variant (default | ab_NAME from tools/ab_build.sh)
 # (profiles/r05_experiments.txt collects the outputs DESIGN.md quotes)
@@ -54,6 +55,20 @@ for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:40]:
     print("%-34s calls %6s  avg %9.1f us  max %9.1f  total %8.2f ms" % (r["Name"].split("(")[0][:34], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MaxNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
     rm -f $OUT/*_kernel_trace.csv $OUT/*_agent_info.csv ;;
+  steptable)              # per-step chip-time table of the bench step as it is (tools/step_table.py) -> gpurun_out/r05/step_table_<tag>.md
+    shift; TAG=${1:-now}; R=$PWD; OUT=$R/$O/st_$TAG; rm -rf $OUT; mkdir -p $OUT
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0 --deterministic-steps 0 > $OUT/bench.json 2> $OUT/bench.err)
+    python - "$OUT/t_kernel_trace.csv" "$OUT/trace_small.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+keep = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Queue_Id", "Stream_Id"]
+with open(sys.argv[2], "w") as f:
+    w = csv.writer(f); w.writerow(keep)
+    for r in rows:
+        w.writerow([r[k].split("(")[0][:40] if k == "Kernel_Name" else r[k] for k in keep])
+PY
+    gzip -f $OUT/trace_small.csv; rm -f $OUT/t_kernel_trace.csv $OUT/t_agent_info.csv
+    python tools/step_table.py $OUT/trace_small.csv.gz 6 > $O/step_table_$TAG.md; head -60 $O/step_table_$TAG.md | cut -c1-150 ;;
   frames)
     for i in 1 2; do
       echo "two levels per launch: $(CMS_RESIZE_FUSED=1 timeout 300 python tools/prof_frames.py 256 550 5 2>&1 | tail -1)" | tee -a $O/frames.txt
