@@ -409,6 +409,11 @@ extern "C" int cms_ba_debug_rm_clocks(long long* out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(ba_rm_clk), 16 * sizeof(long long)) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
 }
 #endif
+#ifdef BA_S3_CLK
+extern "C" int cms_ba_debug_s3_clocks(long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(ba_s3_clk), 16 * sizeof(long long)) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
+}
+#endif
 extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
   if (!b || !out8) return CMS_ERR_ARG;
   return hipMemcpy(out8, b->d_scal + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
@@ -696,7 +701,7 @@ static void ba_plan_sizes(cms_ba* b, int K, int P, int E, int np) {
   b->blk_lds = ((size_t)36 * (np * (np + 1) / 2) + 72 * (size_t)np + 2 * (size_t)n + 8) * sizeof(double);
   b->solve_blk = np >= 1 && np * (np + 1) / 2 <= 384 && b->blk_lds <= BA_LDS_CEILING;
   b->blk3_lds = ((size_t)BA_S3_STRIDE * (np * (np - 1) / 2) + 36 * (size_t)np + 2 * (size_t)BA_S3_STRIDE * np + 36 + 3 * (size_t)n + 8) * sizeof(double);
-  b->solve_blk3 = b->solve_blk && 3 * (np * (np + 1) / 2) <= 1024 && b->blk3_lds <= BA_LDS_CEILING;
+  b->solve_blk3 = b->solve_blk && ba_s3_threads(np) <= 1024 && 6 * np <= 60 * BA_S3_NY && b->blk3_lds <= BA_LDS_CEILING;      // (np <= 25)
 }
 // LDS of the edge-major / run-major Schur kernels without the per-wavefront part: the copy of the reduced system + the key frames' rotations
 static size_t ba_se_fixed_lds(int K, int np) {

@@ -409,7 +409,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // trial solve: three lanes per 6x6 block where every window allows it (CMS_BA_SOLVE1=1: one lane per block, the single-window kernel's scheme)
   const bool use_s3 = gm.use_s3;
   int s3_threads = 64; size_t lds3 = 0;
-  for (int w = 0; w < n; ++w) { s3_threads = std::max(s3_threads, (3 * (bas[w]->np * (bas[w]->np + 1) / 2) + 63) / 64 * 64); lds3 = std::max(lds3, bas[w]->blk3_lds); }
+  for (int w = 0; w < n; ++w) { s3_threads = std::max(s3_threads, ba_s3_threads(bas[w]->np)); lds3 = std::max(lds3, bas[w]->blk3_lds); }
   int max_seR = 0, max_np2 = 0, max_Rt = 0; size_t se_lds = 0, te_lds = 0, rm_lds = 0;
   const int se_waves = gm.se_waves;
   bool any_runs = false;

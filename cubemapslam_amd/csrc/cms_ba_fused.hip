@@ -76,7 +76,9 @@ __device__ __forceinline__ void ba_trial_pose_update(BaDevG d, const double* ybu
     if (theta < 0.00001) {
       for (int i = 0; i < 9; ++i) { R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
     } else {
-      const double sa = sin(theta) / theta, sb = (1 - cos(theta)) / (theta * theta), scc = (theta - sin(theta)) / (theta * theta * theta);
+      double sn, cs;
+      sincos(theta, &sn, &cs);
+      const double sa = sn / theta, sb = (1 - cs) / (theta * theta), scc = (theta - sn) / (theta * theta * theta);
       for (int i = 0; i < 9; ++i) {
         const double Id = ((i & 3) == 0 ? 1.0 : 0.0);
         R[i] = Id + sa * Om[i] + sb * Om2[i];
@@ -304,7 +306,28 @@ __device__ __forceinline__ void ba_trial_solve_body(int BX, int GX, BaDevG d, co
 // update is 72 FMAs per lane, the panel solve 30; the strictly serial part (the 6x6 LDL^T of the next diagonal block) still runs in one
 // lane, as a look-ahead behind that lane's own trailing update.  Panels are stored row major, 38 doubles per block (304 B: the three lanes
 // of a block read the same L block -- a broadcast -- and neighbouring blocks fall on different banks).
+// Round 5 (cycle stamps of thread 0, tools/prof_s3_clk.py, 19 free key frames: 103.7 k cycles = 43 us before, 95.8 k after):
+//   * 21 blocks per wavefront (lane 63 idle): a diagonal block's three lanes share a wavefront, so its gather + factorisation follow its own
+//     trailing update without a workgroup barrier -- two barriers per panel step instead of three; the wavefront runs at s_setprio 3 meanwhile.
+//     (The hoped-for overlap of the factorisation with the OTHER wavefronts' trailing updates is small: a wavefront's own trailing update takes
+//     ~1 200 cycles -- 24 16-byte LDS reads with bank conflicts -- whether or not the others run, and the factorisation's 1 260 come behind it.)
+//   * the back substitution keeps the right-hand side in registers of wavefront 0 (v_readlane + uniform 6x6 solves, operands requested ahead):
+//     17.1 k -> 14.4 k cycles;
+//   * R_to_quat without dynamic indexing (it had put the rotation and the quaternion of the pose update into scratch memory).
+// Per panel step now: panels ~1 200, trailing update + next diagonal block ~2 400 cycles.
 #define BA_S3_STRIDE 38
+#define BA_S3_BPW 21          /* blocks (of three lanes) per wavefront */
+#define BA_S3_NY 3            /* registers of the back substitution's right-hand side, sixty entries each: 6 np <= 180 (np <= 25, see solve_blk3) */
+// threads of the solve kernel for np free key frames: whole wavefronts of BA_S3_BPW blocks
+static inline int ba_s3_threads(int np) { return (np * (np + 1) / 2 + BA_S3_BPW - 1) / BA_S3_BPW * 64; }
+#ifdef BA_S3_CLK
+// developer instrumentation (tools/ab_build.sh s3clk -DBA_S3_CLK): where the solve kernel's time goes, phase by phase (thread 0 of window 0);
+// read with cms_ba_debug_s3_clocks
+__device__ long long ba_s3_clk[16];
+#define BA_S3_STAMP(i) do { if (s3_on) { const long long now_ = (long long)__builtin_readcyclecounter(); s3_acc[i] += now_ - s3_last; s3_last = now_; } } while (0)
+#else
+#define BA_S3_STAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
@@ -326,6 +349,11 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
   double* ybuf = dstage + 36;
   double* idg = ybuf + n;
   double* bps = idg + n;
+#ifdef BA_S3_CLK
+  const bool s3_on = threadIdx.x == 0 && blockIdx.z == 0;
+  long long s3_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long s3_last = (long long)__builtin_readcyclecounter();
+#endif
   if (partial) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const int s1 = i / 6, c = i - 6 * s1;
@@ -337,10 +365,14 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
     }
   }
   __shared__ int bad;
-  const int tid = threadIdx.x;
-  const int blk = tid / 3, rp = tid - 3 * blk;
+  // lane <-> block: 21 blocks of three lanes per wavefront, lane 63 idle -- the three lanes of a block (of a DIAGONAL block in particular) never
+  // sit in two wavefronts, so a diagonal block is gathered and factored inside its wavefront, without a workgroup barrier (below)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bw = (lane * 43) >> 7, rp = lane - 3 * bw;                  // lane / 3, lane % 3 (lane < 64)
+  const int blk = BA_S3_BPW * wave + bw;
   int I = 0, K = 0;
-  const bool have = blk < nblk;
+  const bool have = lane < 3 * BA_S3_BPW && blk < nblk;
   if (have) {
     int off = 0;
     while (off + (nb - K) <= blk) { off += nb - K; ++K; }
@@ -363,17 +395,18 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
     double yb[2] = {0, 0};
     if (partial) {
       // dense pair enumeration (se_pob): slice r holds this pair's 42 sums at (r NP2 + pr) 42; two slices' loads are in flight together
-      // (the kernel is compiled for up to 1024 threads, 128 registers: four slices spilled)
+      // (the kernel is compiled for up to 1024 threads, 128 registers: four slices spilled).  Rows r0, r0 + 1 of the block are columns r0, r0 + 1
+      // of the stored (transposed) block: one 16-byte access per stored row
 #pragma unroll 2
       for (int r = 0; r < n_slices; ++r) {
         double* cs = partial + ((size_t)r * NP2 + pr) * 42;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { a[q] -= cs[6 * q + r0]; a[6 + q] -= cs[6 * q + r0 + 1]; }
-        if (I == K) { yb[0] += cs[36 + r0]; yb[1] += cs[36 + r0 + 1]; }
+        for (int q = 0; q < 6; ++q) { const double2 v = *reinterpret_cast<const double2*>(cs + 6 * q + r0); a[q] -= v.x; a[6 + q] -= v.y; }
+        if (I == K) { const double2 v = *reinterpret_cast<const double2*>(cs + 36 + r0); yb[0] += v.x; yb[1] += v.y; }
         if (consume) {
 #pragma unroll
-          for (int q = 0; q < 6; ++q) { cs[6 * q + r0] = 0.0; cs[6 * q + r0 + 1] = 0.0; }
-          if (I == K) { cs[36 + r0] = 0.0; cs[36 + r0 + 1] = 0.0; }
+          for (int q = 0; q < 6; ++q) *reinterpret_cast<double2*>(cs + 6 * q + r0) = make_double2(0.0, 0.0);
+          if (I == K) *reinterpret_cast<double2*>(cs + 36 + r0) = make_double2(0.0, 0.0);
         }
       }
     } else if (pr >= 0) {
@@ -390,22 +423,27 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
       ybuf[6 * I + r0 + 1] = (lumped ? 0.0 : bp[6 * I + r0 + 1]) - yb[1];
     }
   }
-  // a diagonal block is gathered in LDS by its three lanes and factored by one (ba_factor_diag works on a full 6x6); the lanes of a block may
-  // sit in two wavefronts (3 does not divide 64), so block barriers order the staging against the read
-  if (have && I == 0 && K == 0) {
+  // ordering of LDS accesses between the lanes of ONE wavefront (its LDS operations complete in order; the fences pin the compiler's order)
+#define BA_S3_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+  // a diagonal block is gathered in LDS by its three lanes and factored by the first of them (ba_factor_diag works on a full 6x6): all inside
+  // the block's wavefront.  Block (0, 0): wavefront 0, lanes 0 .. 2 -- it also needs every lane's ybuf entries of block 0, which are its own
+  if (wave == 0) {
+    if (have && I == 0 && K == 0) {
 #pragma unroll
-    for (int q = 0; q < 12; ++q) dstage[6 * r0 + q] = a[q];
+      for (int q = 0; q < 12; ++q) dstage[6 * r0 + q] = a[q];
+    }
+    BA_S3_WAVE_SYNC();
+    if (tid == 0) {
+      double f[36];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) f[q] = dstage[q];
+      ba_factor_diag(f, 0, Ldg, ybuf, idg, &bad);
+    }
   }
   __syncthreads();
-  if (tid == 0) {
-    double f[36];
-#pragma unroll
-    for (int q = 0; q < 36; ++q) f[q] = dstage[q];
-    ba_factor_diag(f, 0, Ldg, ybuf, idg, &bad);
-  }
-  __syncthreads();
+  BA_S3_STAMP(0);                                  // assembly (the Schur kernel's sums read, zeros put back) + first diagonal block
   for (int J = 0; J < nb && !bad; ++J) {
-    const int m = nb - J - 1;
     double* Wp = Wbuf + (size_t)(J & 1) * BA_S3_STRIDE * nb;
     double* Lpan = Lp + (size_t)BA_S3_STRIDE * (J * nb - J * (J + 1) / 2);
     if (have && K == J && I > J) {                   // panel rows: W = A L_JJ^-T, L = W D_J^-1, y_I -= L z_J (this lane's two rows)
@@ -444,7 +482,12 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
       ybuf[6 * I + r0] = yi[0]; ybuf[6 * I + r0 + 1] = yi[1];
     }
     __syncthreads();
+    BA_S3_STAMP(2);                                // panels
     const bool next_diag = have && I == J + 1 && K == J + 1;
+    // the wavefront that holds block (J + 1, J + 1) has the step's serial chain behind its trailing update: it goes first on its SIMD
+    const int blkd = (J + 1) * nb - (J + 1) * J / 2, wd = blkd / BA_S3_BPW;
+    const bool crit = J + 1 < nb && wave == wd;
+    if (crit) __builtin_amdgcn_s_setprio(3);
     if (have && K > J) {                             // trailing update of this lane's two rows: A_IK -= W_IJ L_KJ^T
       const int iw = I - J - 1, ik = K - J - 1;
       double wv[12], lk[36];
@@ -468,50 +511,101 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
         for (int q = 0; q < 12; ++q) dstage[6 * r0 + q] = a[q];
       }
     }
-    __syncthreads();
-    if (J + 1 < nb && tid == 3 * ((J + 1) * nb - (J + 1) * J / 2)) {      // first lane of block (J + 1, J + 1): look-ahead factorisation
-      double f[36];
+    // look-ahead factorisation of block (J + 1, J + 1) by the first of its lanes, inside its wavefront: no barrier in front of it, and the other
+    // wavefronts' trailing updates (the phase is bound by LDS bandwidth) run beside its serial chain
+    if (crit) {
+      BA_S3_WAVE_SYNC();
+      if (lane == 3 * (blkd - BA_S3_BPW * wd)) {
+        double f[36];
 #pragma unroll
-      for (int q = 0; q < 36; ++q) f[q] = dstage[q];
-      ba_factor_diag(f, J + 1, Ldg + 36 * (size_t)(J + 1), ybuf, idg, &bad);
+        for (int q = 0; q < 36; ++q) f[q] = dstage[q];
+        ba_factor_diag(f, J + 1, Ldg + 36 * (size_t)(J + 1), ybuf, idg, &bad);
+      }
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
+    BA_S3_STAMP(3);                                // trailing updates + next diagonal block
   }
   const bool isbad = bad != 0;
-  if (!isbad && tid < 64) {
-    for (int i = tid; i < n; i += 64) ybuf[i] *= idg[i];
-    __builtin_amdgcn_wave_barrier();
-    for (int J = nb - 1; J >= 0; --J) {
+  // back substitution L^T x = D^-1 y by wavefront 0, the right-hand side in REGISTERS: entry o = 60 g + lane of register g (ten block rows per
+  // register, lanes 60 .. 63 idle: a block row never straddles two registers).  Per block row J the six unknowns come out of their lanes with
+  // v_readlane, every lane runs the 6x6 triangular solve on them (uniform values; the farthest unknown first: five dependent steps, not
+  // fifteen), lane 0 stores the solution, and every lane subtracts L_{J,Kq}^T x_J from its entries above.  The L operands do not depend on x: a
+  // step's are requested at its top (the diagonal factor one step ahead), from addresses that are valid for every lane -- no predicated loads.
+  // (Through ybuf in LDS it was 900 cycles per block row: three dependent round trips.)
+  if (!isbad && wave == 0) {
+    const int ln = min(lane, 59);
+    double y[BA_S3_NY];
+    const double* Lo[BA_S3_NY];
+#pragma unroll
+    for (int g = 0; g < BA_S3_NY; ++g) {
+      const int o = 60 * g + ln;
+      y[g] = o < n ? ybuf[o] * idg[o] : 0.0;
+      const int Kq = o / 6, c = o - 6 * Kq;
+      // L_{J,Kq}[r][c]: block J - Kq - 1 of the panel of column Kq, row major -> Lo + J stride + 6 r
+      Lo[g] = Lp + (ptrdiff_t)BA_S3_STRIDE * (Kq * nb - Kq * (Kq + 1) / 2 - Kq - 1) + c;
+    }
+    const double* Lsafe = Lp - BA_S3_STRIDE;         // + J stride: block (J, 0), there for every J >= 1
+    double nld[15];
+    auto fetch = [&](int J) {                        // the diagonal factor of block row J
       const double* Ld = Ldg + 36 * (size_t)J;
-      double xj[6];
 #pragma unroll
-      for (int r = 5; r >= 0; --r) {
-        xj[r] = ybuf[6 * J + r];
+      for (int q = 1; q < 6; ++q)
 #pragma unroll
-        for (int q = r + 1; q < 6; ++q) xj[r] -= Ld[6 * q + r] * xj[q];
+        for (int r = 0; r < q; ++r) nld[q * (q - 1) / 2 + r] = Ld[6 * q + r];
+    };
+    fetch(nb - 1);
+#pragma unroll
+    for (int g = BA_S3_NY - 1; g >= 0; --g) {
+      for (int J = min(nb, 10 * (g + 1)) - 1; J >= 10 * g; --J) {
+        double ld[15], u[BA_S3_NY][6];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) ld[i] = nld[i];
+        bool upd[BA_S3_NY];
+#pragma unroll
+        for (int h = 0; h <= g; ++h) {
+          upd[h] = lane < 60 && 60 * h + lane < 6 * J;
+          const double* src = (upd[h] ? Lo[h] : Lsafe) + (ptrdiff_t)BA_S3_STRIDE * max(J, 1);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) u[h][r] = src[6 * r];
+        }
+        if (J > 0) fetch(J - 1);
+        double xj[6];
+        const int sl = 6 * (J - 10 * g);             // (uniform)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const int lo_ = __builtin_amdgcn_readlane(__double2loint(y[g]), sl + r), hi_ = __builtin_amdgcn_readlane(__double2hiint(y[g]), sl + r);
+          xj[r] = __hiloint2double(hi_, lo_);
+        }
+#pragma unroll
+        for (int r = 4; r >= 0; --r)
+#pragma unroll
+          for (int q = 5; q > r; --q) xj[r] = __builtin_fma(-ld[q * (q - 1) / 2 + r], xj[q], xj[r]);
+        if (lane == 0) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) ybuf[6 * J + r] = xj[r];
+        }
+#pragma unroll
+        for (int h = 0; h <= g; ++h) {
+          double v = y[h];
+#pragma unroll
+          for (int r = 0; r < 6; ++r) v = __builtin_fma(-u[h][r], xj[r], v);
+          y[h] = upd[h] ? v : y[h];
+        }
       }
-      __builtin_amdgcn_wave_barrier();
-      if (tid == 0) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) ybuf[6 * J + r] = xj[r];
-      }
-      for (int o = tid; o < 6 * J; o += 64) {
-        const int Kq = o / 6, c = o - 6 * Kq;
-        // L_{J,Kq}: block i = J - Kq - 1 of the panel of column Kq, row major
-        const double* Lq = Lp + (size_t)BA_S3_STRIDE * (Kq * nb - Kq * (Kq + 1) / 2) + (size_t)(J - Kq - 1) * BA_S3_STRIDE;
-        double v = ybuf[o];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) v -= Lq[6 * r + c] * xj[r];
-        ybuf[o] = v;
-      }
-      __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
+  BA_S3_STAMP(5);                                  // back substitution
   if (isbad) for (int i = tid; i < n; i += blockDim.x) ybuf[i] = 0.0;
   __syncthreads();
   for (int i = tid; i < n; i += blockDim.x) xp_out[i] = ybuf[i];
   ba_trial_pose_update(d, ybuf, partial ? bps : bp, lambda, poses, poses_new, scal, isbad);      // (bps was complete before the first barrier above)
+  BA_S3_STAMP(6);                                  // pose update
+#ifdef BA_S3_CLK
+  if (s3_on) { for (int i = 0; i < 10; ++i) ba_s3_clk[i] = s3_acc[i]; ba_s3_clk[10] = nb; }
+#endif
+#undef BA_S3_WAVE_SYNC
 }
 
 // per point: x_l = Dinv (b_l - sum B^T x_p), X_new = X + x_l, gain-denominator partial; then residuals + robust chi2 of the

@@ -656,15 +656,23 @@ __device__ __forceinline__ void R_to_quat(const double* m, double* q) {  // Eige
     q[3] = 0.5 * t; t = 0.5 / t;
     q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
   } else {
+    // largest diagonal entry i, then j = i + 1, k = i + 2 (mod 3) -- the three cases written out: indexing m and q with i put both into scratch memory
     int i = 0;
     if (m[4] > m[0]) i = 1;
-    if (m[8] > m[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
-    q[i] = 0.5 * t; t = 0.5 / t;
-    q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
-    q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-    q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    if (m[8] > (i ? m[4] : m[0])) i = 2;
+    if (i == 0) {
+      t = sqrt(m[0] - m[4] - m[8] + 1.0);
+      q[0] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+    } else if (i == 1) {
+      t = sqrt(m[4] - m[8] - m[0] + 1.0);
+      q[1] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+    } else {
+      t = sqrt(m[8] - m[0] - m[4] + 1.0);
+      q[2] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+    }
   }
 }
 __device__ __forceinline__ void normalize_rot(double* q) {
