@@ -791,9 +791,18 @@ def main():
                 map_acc["put_ms"] += 1e3 * (time.perf_counter() - t_put); map_acc["put_n"] += 1
         if step_trace is not None:
             step_trace.append(("tracking enqueued", time.perf_counter()))
+        frame_poses = None
+        if part != "ba":
+            # the step's frames are THROUGH when their key points, matches and optimised poses are on the host side of the boundary: wait for the frame
+            # path and fetch the poses, every step (Tracking hands a pose back per frame).  (From the middle of round 4 to the middle of round 5 these
+            # two calls sat under the developer trace's condition by an editing mistake: the frame path was only waited for at the end of the timed
+            # region and the multi-GPU gather below had no poses to send.  All of the step's GPU work was inside the timed region either way --
+            # barrier() synchronises the device -- but the per-step wait and the pose fetch were not.  Measured with the calls back in place: the same
+            # frames/s within the run-to-run spread (the step is bound by the window groups' chain, the frame path's host thread has slack);
+            # tests/test_bench_step_cpu.py guards the structure, DESIGN.md section 4 has the numbers.)
             ctx.sync()
-        if step_trace is not None:
-            step_trace.append(("ctx.sync returned", time.perf_counter()))
+            if step_trace is not None:
+                step_trace.append(("ctx.sync returned", time.perf_counter()))
             _, frame_poses, _, _ = po.fetch()
         if life.get("deferred") is not None:
             submit_windows(life.pop("deferred"))
