@@ -50,10 +50,13 @@ import time
 
 import numpy as np
 
-# The frame path and every local-BA window group run on their own HIP stream; the ROCm runtime multiplexes streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4), which serialises the BA groups behind each other.  Must be set before the
-# HIP runtime initialises (measured: 4 -> 8 queues = +28 % frames/s with 4 concurrent windows).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The frame path, every local-BA window group, the mapping contexts and the window pool run on their own HIP streams; the ROCm runtime multiplexes
+# streams onto GPU_MAX_HW_QUEUES hardware queues (its default: 4).  Must be set before the HIP runtime initialises.  Round 1 (every window a stream of its
+# own, four concurrent windows): 8 queues = +28 % frames/s over 4.  Round 5 (two window groups on long-lived streams, set-ups on pool streams, the mapping
+# side's calls): measured again -- 2 / 3 / 4 / 6 / 8 / 16 / 24 queues = 18.6 / 19.2 / 20.2-21.6 / 18.9-19.7 / 19.7-20.4 / 19.8-20.2 / 14.8-16.4 k frames/s
+# (profiles/r05_experiments.txt): with fewer queues the frame path's kernels queue behind each other instead of competing with the Levenberg chain for
+# compute units (extractor inside the step 0.35-0.36 of its byte roofline against 0.31-0.32), with two or three the chains themselves serialise.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -308,13 +311,22 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # developer smoke test of the N > 1 control flow on a box with ONE GPU (CMS_BENCH_SHARED_GPU_GLOO=1): every rank drives device 0 and the
+    # collectives run over gloo on host tensors.  Not a measurement (the ranks share the chip) -- it exists because the multi-rank branches cannot
+    # otherwise run before the driver's scaling bench does.
+    shared_gpu_debug = os.environ.get("CMS_BENCH_SHARED_GPU_GLOO", "") != "" and world > 1
+    if shared_gpu_debug:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu_debug:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: RCCL sees %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
     from cubemapslam_amd import api, build, synth
@@ -344,6 +356,7 @@ def main():
         scaling = "weak"
     B = len(my_streams) * fps
     dev = torch.device("cuda", local_rank)
+    coll_dev = torch.device("cpu") if shared_gpu_debug else dev       # where the collectives' tensors live (RCCL: the GPU)
     # The frame path's queue runs at LOW dispatch priority (CMS_FRAME_STREAM_PRIORITY, read by cms_ctx_create): its kernels are few and
     # chip-filling, the mapping side's are a long chain of short dependent launches -- when both have workgroups ready the chain goes first.
     # Measured 13.9-14.1 against 14.6-15.5 ms per step (tools/experiments_r03/r03_run14.sh; "high" does the same: what counts is that the queue classes
@@ -822,7 +835,7 @@ def main():
             collect(ths, keep)
         if part != "ba" and (world > 1 or args.force_gather):   # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only)
             recs = [cdist.make_records(my_streams[s], i * fps + np.arange(fps), frame_poses[s * fps:(s + 1) * fps]) for s in range(len(my_streams))]
-            traj = cdist.gather_trajectory(np.concatenate(recs, 0), device=dev, dst=0)
+            traj = cdist.gather_trajectory(np.concatenate(recs, 0), device=coll_dev, dst=0)
             if traj is not None:
                 last["traj"] = traj
 
@@ -898,7 +911,7 @@ def main():
         if streaming:
             ctx.upload_wait()
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         for k in stage:
@@ -1353,6 +1366,7 @@ def main():
             "value": round(total_frames_per_step * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8 (extract/match), f64 (BA)", "data": "synthetic",
+            **({"developer_smoke_test": "CMS_BENCH_SHARED_GPU_GLOO: all ranks on ONE GPU, collectives over gloo -- control flow only, NOT a measurement"} if shared_gpu_debug else {}),
             "config": {"workload": "%s synthetic streams, %dx%d fisheye, face=%d (%dx%d cross), nFeatures %d; per step and GPU %d frames (%d streams x %d consecutive frames; two "
                                    "batches alternate): remap+ORB extract, frame grids, frame-to-frame SearchByProjection (projection + GetFeaturesInArea windows + greedy Hamming match + "
                                    "rotation histogram: %d map points, %d candidate pairs), local-map search (isInFrustum + SearchByProjection, %d map points, %d candidate pairs), "
