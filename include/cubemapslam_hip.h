@@ -436,7 +436,9 @@ int cms_pose_optimize_batch(cms_pose* p, int nf, const int* edge_off, const doub
                             const int8_t* face, double fx, double fy, double cx, double cy, double* poses7, uint8_t* outlier,
                             int* n_inliers, cms_pose_stats* stats);
 /* the same in three steps, for callers that keep the problem resident: upload once, launch (asynchronous, restarts from the
- * uploaded poses every time), fetch (synchronises) */
+ * uploaded poses every time; the results' copies into the handle's pinned block are enqueued right behind the kernel), fetch (waits for
+ * those copies -- nothing is enqueued at fetch time, so a caller that launches early and fetches late does not wait for a slot on a busy
+ * device -- and hands the results out; may be called again for the same launch) */
 int cms_pose_upload(cms_pose* p, int nf, const int* edge_off, const double* Xw, const double* obs_uv, const double* inv_sigma2,
                     const int8_t* face, double fx, double fy, double cx, double cy, const double* poses7);
 int cms_pose_launch(cms_pose* p);
