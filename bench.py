@@ -290,11 +290,20 @@ class TrackSet:
 def main():
     # developer knob: every hipStreamSynchronize / hipEventSynchronize of this process blocks instead of spinning (hipDeviceScheduleBlockingSync);
     # must be set before the first HIP call of the process
-    if os.environ.get("CMS_BENCH_BLOCKING_SYNC", "") != "":
-        import ctypes
-        ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(0x4))
     args = parse_args()
     maybe_spawn(args)
+    # A rank with few host cores (8 ranks on a node whose container has a 16-core quota: two each) cannot afford the runtime's spinning waits: with
+    # <= 4 cores the process blocks in its synchronisations and the library's window threads sleep between stream queries (CMS_BA_RELAXED_WAIT).
+    # Measured on one GPU with the process confined by taskset: 2 cores 12.5 k -> 13.2-13.8 k frames/s, 4 cores 17.7 k -> 19.1 k; with cores to spare
+    # the spinning waits stay (sleeping costs 3-16 % there, round 4).  Both switches must be thrown before the first HIP call of the process.
+    early_budget = host_budget(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")), pin=False)["thread_budget"]
+    few_cores = early_budget <= 4 and os.environ.get("CMS_BENCH_SPIN_ANYWAY", "") == ""
+    if few_cores:
+        os.environ.setdefault("CMS_BA_RELAXED_WAIT", "1")
+    blocking_sync = os.environ.get("CMS_BENCH_BLOCKING_SYNC", "") != "" or few_cores
+    if blocking_sync:
+        import ctypes
+        ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(0x4))
     # ~25 Python threads drive this process (window pool, window groups, mapping threads, the frame path); every library call releases the interpreter
     # lock and has to take it again when it returns.  With the default 5-ms switch interval a returning thread can wait milliseconds for a thread that
     # is merely running Python glue -- on the mapping side's critical path (CreateNewMapPoints -> Fuse -> local BA) that wait was most of the calls'
@@ -389,6 +398,7 @@ def main():
         p["poses"] = np.ascontiguousarray(p["poses"], np.float64); p["points"] = np.ascontiguousarray(p["points"], np.float64)
         p["e_obs"] = np.ascontiguousarray(p["e_obs"], np.float64)
     host = host_budget(world, local_rank, args.window_threads)      # the ranks of a node split its usable cores (and are pinned to their slice)
+    host["blocking_sync"] = bool(blocking_sync)
     n_wthreads = host["window_threads"]
     wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
     group_stream = []           # one long-lived stream per window group (filled below): CreateNewMapPoints and the group's BA rounds

@@ -129,8 +129,9 @@ def test_ranks_of_a_node_get_disjoint_host_thread_budgets():
     assert sum(h["thread_budget"] for h in hosts) <= ncores
     (a0, a1), (b0, b1) = hosts[0]["core_slice"], hosts[1]["core_slice"]
     assert a1 < b0 or b1 < a0, hosts                                   # the slices do not overlap
-    # a pool thread per core (1.5 with sleeping host waits, CMS_BA_RELAXED_WAIT=1: not set here)
-    assert all(4 <= h["window_threads"] <= max(4, h["thread_budget"]) and h["host_waits"] == "spin" for h in hosts)
+    # a pool thread per two cores; a rank with <= 4 cores switches to sleeping / blocking host waits by itself (bench.py main()), the others spin
+    assert all(4 <= h["window_threads"] <= max(4, h["thread_budget"]) for h in hosts)
+    assert all(h["host_waits"] == ("sleep" if h["thread_budget"] <= 4 else "spin") for h in hosts), hosts
     # a single rank keeps the whole affinity mask and is not pinned
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=120)
     h = _json_records(one.stdout)[0]["host"]
