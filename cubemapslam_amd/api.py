@@ -793,6 +793,17 @@ def ba_plan_fast(fixed, n_points, e_pose, e_point):
                 n_rm=n_rm, n_runs=nruns, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), usable=bool(cnt[7]))
 
 
+def ba_run_fg(fixed, n_points, e_pose, e_point, fast=False):
+    """Host-only: the tables of the opt-in one-wavefront run workgroups (cms_ba_debug_run_fg); None when the planner does not take the window."""
+    fixed = np.ascontiguousarray(fixed, np.uint8); e_pose = np.ascontiguousarray(e_pose, np.int32); e_point = np.ascontiguousarray(e_point, np.int32)
+    P, E = int(n_points), len(e_pose)
+    fg = np.zeros((P, 64, 24), np.uint32); cut = np.zeros((2, 1025), np.int32); cnt = np.zeros(4, np.int32)
+    _chk(lib().cms_ba_debug_run_fg(len(fixed), _p(fixed), P, E, _p(e_pose), _p(e_point), 1 if fast else 0, _p(fg), _p(cut), _p(cnt)), "cms_ba_debug_run_fg")
+    if cnt[0] < 0:
+        return None
+    return dict(run_fg=fg[:int(cnt[0])].copy(), rm_cut=cut, n_runs=int(cnt[0]), n_rm=int(cnt[1]), n_rmA=int(cnt[2]), np=int(cnt[3]))
+
+
 def ba_set_deterministic(on):
     """cms_ba_set_deterministic: windows created afterwards run the fixed-order (bit-repeatable) kernels, like the reference's single-threaded g2o."""
     _chk(lib().cms_ba_set_deterministic(1 if on else 0), "cms_ba_set_deterministic")

@@ -23,6 +23,7 @@ struct BaKnobs {
   bool global_sum;
   int lookahead, compose_segments, dup, run_min_chunks, rm_weight, se_waves_cap, em_cost_a, em_cost_b, te_chunks, run_min_pct; bool unified;
   char stream_priority;
+  bool run_wg; int rw_waves_cu0, rw_waves_cu1;
 };
 static const BaKnobs& ba_knobs() {
   static const BaKnobs k = [] {
@@ -56,6 +57,11 @@ static const BaKnobs& ba_knobs() {
     q.em_cost_a = num("CMS_BA_EM_COST_A", 40); q.em_cost_b = num("CMS_BA_EM_COST_B", 30);      // cost of a left-over chunk: a + b x (edges of its largest point / 2), units of ba_rm_chunk_cost
     q.te_chunks = std::max(1, std::min(16, num("CMS_BA_TE_CHUNKS", 2)));      // chunks per wavefront of kb_ba_trial_edges
     q.se_waves_cap = num("CMS_BA_SE_WAVES", 0);          // developer A/B: fewer wavefronts per Schur workgroup (how much of the kernel is latency?)
+    // CMS_BA_RUN_WG=1: the runs through one-wavefront workgroups that add to the global copy (cms_ba_schur_runwg.hip), the left-over chunks through
+    // kb_ba_lin_schur_edges behind them -- round 6's re-decomposition of kb_ba_lin_schur_runs, parity-green and SLOWER (the kernel is bound
+    // by FP64 issue, not by latency; 160 us against 90 for 16 windows): an opt-in experiment.  Units per launch = wavefronts per CU x CUs / windows
+    q.run_wg = on("CMS_BA_RUN_WG");
+    q.rw_waves_cu0 = std::max(1, std::min(32, num("CMS_BA_RW_WAVES0", 12))); q.rw_waves_cu1 = std::max(1, std::min(32, num("CMS_BA_RW_WAVES1", 8)));
     const char* pr = getenv("CMS_BA_STREAM_PRIORITY");
     q.stream_priority = pr ? pr[0] : 0;
     return q;
@@ -63,6 +69,8 @@ static const BaKnobs& ba_knobs() {
   return k;
 }
 
+static thread_local bool ba_force_rw_tables = false;      // cms_ba_debug_run_fg: build the one-wavefront workgroups' tables whatever the knob says
+static inline bool ba_want_rw_tables() { return ba_knobs().run_wg || ba_force_rw_tables; }
 struct BaBlock { void* p; size_t bytes; };      // a device slab / pinned block of the per-device pool (below)
 struct cms_ba {
   int device = 0;
@@ -95,6 +103,7 @@ struct cms_ba {
   BaSe se = {};
   int* d_se_chunk_e0 = nullptr; uint32_t* d_se_info = nullptr; double* d_se_partial = nullptr; double* d_se_bp_partial = nullptr; double* d_se_sum = nullptr; int* d_se_pob = nullptr; int* d_se_chunk_off = nullptr;
   int* d_se_lone = nullptr; int4* d_rm_chunk = nullptr; uint2* d_run_lane = nullptr; uint32_t* d_run_mf = nullptr; uint32_t* d_run_fl = nullptr; uint32_t* d_rm_cost = nullptr;
+  uint32_t* d_run_fg = nullptr; int* d_rm_cut = nullptr;      // one-wavefront workgroups (cms_ba_schur_runwg.hip)
   size_t se_lds_fixed = 0; int se_waves = 0;      // LDS of the edge-major kernel without the per-wavefront part; wavefronts per workgroup that fit
   size_t rm_lds = 0; int n_runs = 0, rm_points = 0;   // run-major part (cms_ba_schur_runs.hip): LDS it needs (0: the window has no runs), runs, points inside runs
   char* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned block the window's uploads went through; cms_ba_read's read-back reuses it
@@ -133,7 +142,7 @@ static int ba_lds_attrs_once(int device) {
   std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || done[device]) return CMS_OK;
   const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)kb_ba_lin_schur_edges,
-                       (const void*)kb_ba_lin_schur_runs, (const void*)kb_ba_lin_schur_runs_valu, (const void*)kb_ba_trial_solve3r, (const void*)k_ba_trial_solve,
+                       (const void*)kb_ba_lin_schur_runs, (const void*)kb_ba_lin_schur_runs_valu, (const void*)kb_ba_lin_schur_run_wg0, (const void*)kb_ba_lin_schur_run_wg1, (const void*)kb_ba_trial_solve3r, (const void*)k_ba_trial_solve,
                        (const void*)kb_ba_trial_solve, (const void*)kb_ba_trial_solve3, (const void*)k_ba_solve_r192};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);
@@ -404,6 +413,11 @@ extern "C" int cms_ba_profile_get(cms_ba* b, double* total_ms, long* launches) {
   *total_ms = b->prof_ms; *launches = b->prof_launches;
   return CMS_OK;
 }
+#ifdef BA_RW_TS
+extern "C" int cms_ba_debug_rw_ts(long long* out) {      // 2 classes x 4096 units x (start, end)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_rw_ts), sizeof(long long) * 2 * 2 * 4096) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
+}
+#endif
 #ifdef BA_RM_CLK
 extern "C" int cms_ba_debug_rm_clocks(long long* out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(ba_rm_clk), 16 * sizeof(long long)) == hipSuccess ? CMS_OK : CMS_ERR_HIP;
@@ -670,10 +684,18 @@ extern "C" int cms_ba_debug_compose(int K, const uint8_t* fixed, int P, int E, c
 // by CMS_BA_RM_WEIGHT (cost of a run chunk in percent of an edge-major one: 100 -> 102.5 us, 60 -> 95.0, 50 -> 95.2, 40 -> 101.7: with 14 + 2
 // workgroups the two edge-major ones were the launch's long pole; a left-over chunk costs about 1.8 run chunks when eight wavefronts of a
 // workgroup all add to LDS, less next to run-major wavefronts).
-static void ba_se_split(BaSe& se, int Rtotal) {
+static void ba_se_split(BaSe& se, int Rtotal, bool run_wg = false) {
   const int n_se = se.nchunks - se.n_rm;
   Rtotal = std::max(2, std::min(Rtotal, BA_SE_RANGES));
   int R_rm = 0, R_se = 0;
+  if (run_wg && se.n_rm > 0) {
+    // the runs have their own launches (cms_ba_schur_runwg.hip); the edge-major kernel's workgroups take the left-over chunks, about one per wavefront
+    se.R_rm = 0;
+    se.R = n_se > 0 ? std::max(1, std::min(Rtotal, (n_se + BA_SE_THREADS / 64 - 1) / (BA_SE_THREADS / 64))) : 0;
+    se.cpw = se.R > 0 ? (n_se + se.R - 1) / se.R : 1;
+    if (se.R > 0) se.R = (n_se + se.cpw - 1) / se.cpw;
+    return;
+  }
   if (se.n_rm > 0 && n_se > 0 && ba_knobs().unified && !ba_knobs().rm_valu) {
     // the run-major body's workgroups take the left-over chunks too (a wavefront's range is cut by cost over all chunks): se.R = 0 tells it so
     se.cpw = 1; se.R = 0; se.R_rm = std::min(Rtotal, (se.nchunks + BA_SE_THREADS / 64 - 1) / (BA_SE_THREADS / 64));
@@ -718,7 +740,9 @@ struct BaPlan {
   std::vector<uint32_t> info;
   std::vector<int4> rm_chunk;
   std::vector<uint2> run_lane;
-  std::vector<uint32_t> run_mf, run_fl, rm_cost;
+  std::vector<uint32_t> run_mf, run_fl, rm_cost, run_fg;
+  std::vector<int> rm_cut;
+  int n_rmA = 0;
   bool se_built = false;
 };
 template <class Tick>
@@ -731,7 +755,8 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   std::vector<uint32_t>& info = pl.info;
   std::vector<int4>& rm_chunk = pl.rm_chunk;
   std::vector<uint2>& run_lane = pl.run_lane;
-  std::vector<uint32_t>&run_mf = pl.run_mf, &run_fl = pl.run_fl, &rm_cost = pl.rm_cost;
+  std::vector<uint32_t>&run_mf = pl.run_mf, &run_fl = pl.run_fl, &rm_cost = pl.rm_cost, &run_fg = pl.run_fg;
+  std::vector<int>& rm_cut = pl.rm_cut;
   bool& se_built = pl.se_built;
   struct InFlight { InFlight() { ba_plans_in_flight.fetch_add(1); } ~InFlight() { ba_plans_in_flight.fetch_sub(1); } } in_flight;
   const BaKnobs& kn = ba_knobs();
@@ -772,7 +797,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   const size_t rm_lds = se_fixed_lds + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF * sizeof(double);
   const bool rm_ok = se_ok && kn.runs && !kn.no_fused && !kn.want_all_lists && !b->deterministic && !kn.solve1 && !kn.trial_points && b->solve_blk3 && rm_lds <= BA_LDS_CEILING &&
                      BA_SE_THREADS == 128 * BA_RM_PAIRS;
-  struct Run { int k, first, npts, chunks, m; };              // first: a member point (its key frames are the signature)
+  struct Run { int k, first, npts, chunks, m, kf; };          // first: a member point (its key frames are the signature)
   std::vector<Run> runs;
   BA_TLV(int, rm_points); rm_points.clear();                  // caller ids, run after run
   BA_TLV(int, left); left.clear();                            // caller ids of the left-over points, caller's order
@@ -831,7 +856,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
       const int q = gfirst[g], k = cpo[q + 1] - cpo[q];
       int kf = 0;
       for (int i = cpo[q]; i < cpo[q + 1]; ++i) kf += pose_slot[e_pose[cpe[i]]] >= 0;
-      if (k < 1 || kf < 1 || kf * (kf + 1) / 2 > 64 || (!kn.rm_valu && 6 * kf + 1 > 48)) continue;      // (lane tables of the vector variant / three MFMA tiles a side)
+      if (k < 1 || k > 9 || kf < 1 || kf * (kf + 1) / 2 > 64 || (!kn.rm_valu && 6 * kf + 1 > 48)) continue;      // (k <= 9: the one-wavefront workgroups' own-block tasks, cms_ba_schur_runwg.hip)      // (lane tables of the vector variant / three MFMA tiles a side)
       const int m = std::min(64 / k, BA_RM_PTS);
       if (gcount[g] * 100 < kn.run_min_chunks * m * kn.run_min_pct) continue;      // at least that many FULL chunks (x run_min_pct / 100): a run pays for one set of LDS additions
       const int full = gcount[g] / m, tail = gcount[g] - full * m;
@@ -839,8 +864,9 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
       if (full == 0 && !keep_tail) continue;
       run_of_group[g] = (int)runs.size();
       take[g] = full * m + (keep_tail ? tail : 0);
-      runs.push_back({k, q, take[g], full + (keep_tail ? 1 : 0), m});
+      runs.push_back({k, q, take[g], full + (keep_tail ? 1 : 0), m, kf});
     }
+    ba_rw_order_runs(runs, run_of_group, [](const Run& r) { return r.kf; });      // signatures with two tile rows first (cms_ba_schur_runwg.hip)
     rm_run_pt0.assign(runs.size() + 1, 0);
     for (size_t r = 0; r < runs.size(); ++r) rm_run_pt0[r + 1] = rm_run_pt0[r] + runs[r].npts;
     rm_points.assign(rm_run_pt0.back(), 0);
@@ -930,7 +956,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   tick("csr");
   // ---- work lists of the edge-major / run-major Schur kernels: chunks of whole points with <= 64 edges (one wavefront each), the per-edge
   // words, the runs' chunk descriptors and consumer-lane tables, the dense enumeration of the pose pairs s1 <= s2 for the solve kernel
-  ce0.clear(); pob.clear(); ident.clear(); lone.clear(); info.clear(); rm_chunk.clear(); run_lane.clear(); run_mf.clear(); run_fl.clear(); rm_cost.clear();
+  ce0.clear(); pob.clear(); ident.clear(); lone.clear(); info.clear(); rm_chunk.clear(); run_lane.clear(); run_mf.clear(); run_fl.clear(); rm_cost.clear(); run_fg.clear(); rm_cut.clear(); pl.n_rmA = 0;
   se_built = false;
   if (se_ok) {
     bool ok = true;
@@ -1036,12 +1062,31 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
         for (int e = ce0[c]; e < ce0[c + 1]; ++e) kmax = std::max(kmax, (int)((info[e] >> 5) & 31));
         rm_cost[(size_t)c + 1] = rm_cost[c] + (uint32_t)(kn.em_cost_a + kn.em_cost_b * (kmax / 2));
       }
+      // ... and for the one-wavefront workgroups (cms_ba_schur_runwg.hip): the accumulators' offsets into the global copy, the cut points of the two classes
+      if (ba_want_rw_tables()) run_fg.assign(std::max<size_t>(runs.size(), 1) * 64 * 24, BA_RW_NONE);
+      for (size_t r = 0; r < runs.size() && ba_want_rw_tables(); ++r) {
+        const int q = runs[r].first;
+        BaRunSig rs; rs.kf = 0; rs.fpos8 = 0; rs.fslot8 = 0;
+        for (int i = cpo[q]; i < cpo[q + 1]; ++i) { const int sl = pose_slot[e_pose[cpe[i]]]; if (sl >= 0) rs.push(i - cpo[q], sl); }
+        for (int l = 0; l < 64; ++l)
+          for (int i = 0; i < 24; ++i) run_fg[(r * 64 + l) * 24 + i] = ba_run_fg_word(rs, np, l, i);
+      }
+      {
+        int n_rmA = 0;
+        while (n_rmA < n_rm && ba_rw_class(runs[rm_chunk_run[n_rmA]].kf) == 0) ++n_rmA;
+        pl.n_rmA = n_rmA;
+        if (ba_want_rw_tables()) {
+          rm_cut.assign(2 * (BA_RW_CUTS + 1), 0);
+          ba_rw_make_cuts(rm_cost, 0, n_rmA, rm_cut.data());
+          ba_rw_make_cuts(rm_cost, n_rmA, n_rm, rm_cut.data() + (BA_RW_CUTS + 1));
+        }
+      }
       if (run_fl.empty()) run_fl.assign(12, 0xFFFFFFFFu);
       if (run_mf.empty()) run_mf.assign(64, BA_RM_MF_NONE);
       if (run_lane.empty()) run_lane.push_back(make_uint2(0u, 0u));
       if (rm_chunk.empty()) rm_chunk.push_back(make_int4(0, 0, -1, 0));
       BaSe& se = b->se;
-      se.nchunks = nchunks; se.n_rm = n_rm; se.npairs2 = NP2;
+      se.nchunks = nchunks; se.n_rm = n_rm; se.n_rmA = pl.n_rmA; se.npairs2 = NP2;
       se.cpw_t = (BA_TE_THREADS / 64) * kn.te_chunks;             // the trial kernel: te_chunks chunks per wavefront (its workgroups stage the key frames' rotations first)
       se.Rt = (nchunks + se.cpw_t - 1) / se.cpw_t;
       se.nlone = (int)lone.size();
@@ -1199,9 +1244,11 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     up(fp.ident.data(), fp.ident.size() * sizeof(int), &b->d_se_chunk_off); up(fp.lone.data(), fp.lone.size() * sizeof(int), &b->d_se_lone);
     up(fp.rm_chunk.data(), fp.rm_chunk.size() * sizeof(int4), &b->d_rm_chunk); up(fp.rm_cost.data(), fp.rm_cost.size() * sizeof(uint32_t), &b->d_rm_cost);
     up(fp.run_sig.data(), fp.run_sig.size() * sizeof(uint64_t), &b->d_run_sig);
+    up(fp.rm_cut.data(), fp.rm_cut.size() * sizeof(int), &b->d_rm_cut);
     // what the expansion kernels write: the per-edge words and the runs' tables (run_lane: the vector variant's table, never read on this path)
     BA_TRY(ba_alloc(b, &b->d_se_info, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_run_mf, (size_t)std::max(fp.n_runs, 1) * 64));
     BA_TRY(ba_alloc(b, &b->d_run_fl, (size_t)std::max(fp.n_runs, 1) * 64 * 12)); BA_TRY(ba_alloc(b, &b->d_run_lane, 1));
+    if (ba_want_rw_tables()) BA_TRY(ba_alloc(b, &b->d_run_fg, (size_t)std::max(fp.n_runs, 1) * 64 * 24));
   } else if (se_built) {
     up(pl.ce0.data(), pl.ce0.size() * sizeof(int), &b->d_se_chunk_e0); up(pl.info.data(), pl.info.size() * sizeof(uint32_t), &b->d_se_info);
     up(pl.pob.data(), pl.pob.size() * sizeof(int), &b->d_se_pob); up(pl.ident.data(), pl.ident.size() * sizeof(int), &b->d_se_chunk_off);
@@ -1209,6 +1256,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     up(pl.rm_chunk.data(), pl.rm_chunk.size() * sizeof(int4), &b->d_rm_chunk); up(pl.run_lane.data(), pl.run_lane.size() * sizeof(uint2), &b->d_run_lane);
     up(pl.run_mf.data(), pl.run_mf.size() * sizeof(uint32_t), &b->d_run_mf); up(pl.run_fl.data(), pl.run_fl.size() * sizeof(uint32_t), &b->d_run_fl);
     up(pl.rm_cost.data(), pl.rm_cost.size() * sizeof(uint32_t), &b->d_rm_cost);
+    up(pl.run_fg.data(), pl.run_fg.size() * sizeof(uint32_t), &b->d_run_fg); up(pl.rm_cut.data(), pl.rm_cut.size() * sizeof(int), &b->d_rm_cut);
   }
   tick("se");
   // A window that has the edge-major work list runs through the grouped driver with the edge-major kernels (cms_ba_optimize_many also puts
@@ -1460,7 +1508,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy;
   if (se_built) {
     BaSe& se = b->se;
-    se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane; se.run_mf = b->d_run_mf; se.run_fl = b->d_run_fl; se.rm_cost = b->d_rm_cost;
+    se.chunk_e0 = b->d_se_chunk_e0; se.e_info = b->d_se_info; se.lone = b->d_se_lone; se.rm_chunk = b->d_rm_chunk; se.run_lane = b->d_run_lane; se.run_mf = b->d_run_mf; se.run_fl = b->d_run_fl; se.rm_cost = b->d_rm_cost; se.run_fg = b->d_run_fg; se.rm_cut = b->d_rm_cut;
   }
   tick("uploads");
   b->cur = 0;
@@ -1473,7 +1521,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     x.perm = b->d_perm; x.iperm = b->d_iperm; x.s_pose = b->d_e_pose; x.s_point = b->d_e_point; x.s_face = b->d_e_face; x.info = b->d_se_info;
     x.e_obs = b->d_e_obs; x.e_inv = b->d_e_inv; x.pts0 = b->d_pts0; x.poses = b->d_poses[0]; x.pts = b->d_pts[0]; x.level = b->d_level; x.err = b->d_err; x.flags = b->d_flags;
     x.gsum = b->d_se_partial; x.n_gsum = b->se.npairs2 * 42; x.gsum_bp = b->d_se_bp_partial; x.n_gsum_bp = b->np * 6;
-    x.ce0 = b->d_se_chunk_e0; x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl;
+    x.ce0 = b->d_se_chunk_e0; x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl; x.run_fg = b->d_run_fg;
     hipLaunchKernelGGL(k_ba_expand_edges, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, x);      // (+ the runs' tables)
   } else
   hipLaunchKernelGGL(k_ba_gather, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, K, P, E, (const int*)b->d_perm, (const int*)b->d_pinv,

@@ -206,18 +206,19 @@ static bool ba_use_te(cms_ba** bas, int n) {
 // Workgroups (ranges of chunks) per window for the edge-major Schur kernel of a GROUP: one workgroup fills a CU (148 KB of LDS), so the launch
 // should have at most as many workgroups as the chip has CUs -- 11 windows x 32 ranges = 352 workgroups run as one full round plus a round
 // at 37 %.  Windows keep the 32 ranges their buffers are sized for as the upper limit.
-static int ba_group_ranges(cms_ba** bas, int n) {
+static int ba_device_cus(int dev) {
   static std::mutex mu;
   static int cus_of[64] = {0};                  // compute units per device (a process may drive several)
-  const int dev = bas[0]->device;
   int cus = 256;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (dev >= 0 && dev < 64) {
-      if (cus_of[dev] == 0) { hipDeviceProp_t pr; cus_of[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-      cus = cus_of[dev];
-    }
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev >= 0 && dev < 64) {
+    if (cus_of[dev] == 0) { hipDeviceProp_t pr; cus_of[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    cus = cus_of[dev];
   }
+  return cus;
+}
+static int ba_group_ranges(cms_ba** bas, int n) {
+  const int cus = ba_device_cus(bas[0]->device);
   int R = BA_SE_RANGES;
   if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, cus / n));
   return R;
@@ -225,7 +226,7 @@ static int ba_group_ranges(cms_ba** bas, int n) {
 // Which kernels a group's rounds are made of: decided ONCE per group from the windows' lists and the knobs (ba_upload_items and the stage
 // driver both use it).  fused: the Schur kernel linearises itself (edge-major kernels + three-lane solve); rm: windows with signature runs
 // send them through the run-major body (needs the fused path and full 512-thread workgroups)
-struct BaGroupMode { bool use_se, use_te, use_s3, fused, rm, gsum; int se_waves; };
+struct BaGroupMode { bool use_se, use_te, use_s3, fused, rm, gsum, run_wg; int se_waves; };
 static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
   BaGroupMode m;
   m.use_se = ba_use_se(bas, n); m.use_te = ba_use_te(bas, n);
@@ -243,6 +244,8 @@ static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
   // one global copy of the reduced system per window, added to by all its workgroups (not with the A/B knobs that want the slices or launch a
   // kernel of the round twice)
   m.gsum = m.fused && ba_knobs().global_sum && !ba_knobs().separate_reduce && ba_knobs().dup == 0;
+  // the runs through one-wavefront workgroups (cms_ba_schur_runwg.hip): they add to the global copy, so they need it; the MFMA body only
+  m.run_wg = m.rm && m.gsum && ba_knobs().run_wg && !ba_knobs().rm_valu;
   return m;
 }
 static int ba_upload_items(cms_ba** bas, int n) {
@@ -275,7 +278,7 @@ static int ba_upload_items(cms_ba** bas, int n) {
       // workgroups of this window in the group's Schur launch: one workgroup fills a CU, so the group shares the chip's CUs; a window's share
       // is split between its run chunks and its left-over chunks (without the run-major body the edge-major one takes every chunk)
       if (!gm.rm) it.se.n_rm = 0;
-      ba_se_split(it.se, ba_group_ranges(bas, n));
+      ba_se_split(it.se, ba_group_ranges(bas, n), gm.run_wg);
     }
     it.se.gsum = (use_se && gm.gsum) ? 1 : 0;
     b->grp_se = it.se;
@@ -412,9 +415,10 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   for (int w = 0; w < n; ++w) { s3_threads = std::max(s3_threads, ba_s3_threads(bas[w]->np)); lds3 = std::max(lds3, bas[w]->blk3_lds); }
   int max_seR = 0, max_np2 = 0, max_Rt = 0; size_t se_lds = 0, te_lds = 0, rm_lds = 0;
   const int se_waves = gm.se_waves;
-  bool any_runs = false;
+  bool any_runs = false, any_rw0 = false, any_rw1 = false;
   for (int w = 0; w < n; ++w) {
     const BaSe& gs = bas[w]->grp_se;             // this group's split of the window (ba_upload_items)
+    if (gm.run_wg) { any_rw0 = any_rw0 || gs.n_rmA > 0; any_rw1 = any_rw1 || gs.n_rm > gs.n_rmA; }
     max_seR = std::max(max_seR, gs.R_rm + gs.R); max_np2 = std::max(max_np2, gs.npairs2); se_lds = std::max(se_lds, bas[w]->se_lds_fixed);
     any_runs = any_runs || gs.R_rm > 0;
     if (gs.R_rm > 0) rm_lds = std::max(rm_lds, bas[w]->rm_lds);
@@ -430,6 +434,10 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   se_lds += (size_t)se_waves * ((size_t)64 * 18 * sizeof(double) + 64 * sizeof(int));      // the group runs with the wavefront count its largest window allows
   se_lds = std::max(se_lds, rm_lds);                                                        // (the run-major body's chunk buffers, when a window has runs)
   const int se_threads = 64 * se_waves;
+  // one-wavefront workgroups: units per window so that the launch fills the chip's wavefront slots about once
+  const size_t rw_lds = ba_rw_lds(std::max(max_K, 1));
+  const int rw_units0 = std::max(8, std::min(BA_RW_CUTS, ba_device_cus(bas[0]->device) * ba_knobs().rw_waves_cu0 / std::max(n, 1)));
+  const int rw_units1 = std::max(8, std::min(BA_RW_CUTS, ba_device_cus(bas[0]->device) * ba_knobs().rw_waves_cu1 / std::max(n, 1)));
   // linearisation inside the Schur kernel (cms_ba_schur_edges.hip, FUSED): needs the edge-major kernels and the three-lane solve
   const bool fused = gm.fused;
   // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
@@ -478,6 +486,12 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         if (fused && any_runs && ba_knobs().rm_valu) {
           hipLaunchKernelGGL(kb_ba_lin_schur_runs_valu, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
           if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_runs_valu, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        } else if (fused && gm.run_wg && (any_rw0 || any_rw1)) {
+          // the runs: one wavefront per workgroup, as many units per window as fill the chip once (class 1 first: its units are the longer ones);
+          // then the left-over chunks, edge-major
+          if (any_rw1) hipLaunchKernelGGL(kb_ba_lin_schur_run_wg1, dim3(rw_units1, 1, n), dim3(64), rw_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL, rw_units1);
+          if (any_rw0) hipLaunchKernelGGL(kb_ba_lin_schur_run_wg0, dim3(rw_units0, 1, n), dim3(64), rw_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL, rw_units0);
+          if (max_seR > 0) hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         } else if (fused && any_runs) {
           hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
           if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);

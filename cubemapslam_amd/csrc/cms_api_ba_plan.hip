@@ -26,25 +26,7 @@
 // the windows both can plan, the two give byte-identical device arrays (tests/test_gpu_parity.py::test_ba_device_plan_equals_host_plan).
 #include <stdint.h>
 
-// the free key frames of a signature (a 64-bit set of key frames), in ascending key-frame order: position of the observation within its point
-// (points' observations are sorted by key frame) and free-pose slot; at most eight are kept (signatures of runs have <= 7).  Packed (8 bits
-// each): indexable arrays would live in scratch memory on the device.
-struct BaRunSig {
-  int kf; unsigned long long fpos8, fslot8;
-  __host__ __device__ int fpos(int a) const { return (int)((fpos8 >> (8 * a)) & 0xFFu); }
-  __host__ __device__ int fslot(int a) const { return (int)((fslot8 >> (8 * a)) & 0xFFu); }
-};
-__host__ __device__ inline void ba_run_decode(uint64_t sig, const int* pose_slot, BaRunSig& rs) {
-  rs.kf = 0; rs.fpos8 = 0; rs.fslot8 = 0;
-  int pos = 0;
-  while (sig) {
-    const int k = __builtin_ctzll(sig);
-    sig &= sig - 1;
-    const int s = pose_slot[k];
-    if (s >= 0) { if (rs.kf < 8) { rs.fpos8 |= (unsigned long long)pos << (8 * rs.kf); rs.fslot8 |= (unsigned long long)s << (8 * rs.kf); } ++rs.kf; }
-    ++pos;
-  }
-}
+// (BaRunSig / ba_run_decode: cms_ba_schur_runwg.hip)
 // run_mf[run * 64 + i] (cms_ba_schur_runs.hip): rows / columns of the signature's stacked matrix, the slots, the count
 __host__ __device__ inline uint32_t ba_run_mf_word(const BaRunSig& rs, int i) {
   if (i < 48) {
@@ -97,7 +79,7 @@ struct BaExpand {
   double* gsum; int n_gsum; double* gsum_bp; int n_gsum_bp;
   // tables
   const int* ce0; int n_rm, nchunks;                                // chunk first edges; chunks [n_rm, nchunks) are the left-over ones
-  const uint64_t* run_sig; int n_runs; uint32_t* run_mf; uint32_t* run_fl;
+  const uint64_t* run_sig; int n_runs; uint32_t* run_mf; uint32_t* run_fl; uint32_t* run_fg;
 };
 
 // one observation (position i of the caller's grouped order) / one table entry: the kernels' bodies, callable on the host too (cms_ba_debug_plan_fast
@@ -132,6 +114,8 @@ __host__ __device__ inline void ba_expand_table_at(const BaExpand& x, int u) {
   ba_run_decode(x.run_sig[r], x.pose_slot, rs);
   x.run_mf[(size_t)r * 64 + l] = ba_run_mf_word(rs, l);
   for (int w = 0; w < 12; ++w) x.run_fl[((size_t)r * 64 + l) * 12 + w] = ba_run_fl_word(rs, x.np, l, w);
+  if (x.run_fg)
+    for (int i = 0; i < 24; ++i) x.run_fg[((size_t)r * 64 + l) * 24 + i] = ba_run_fg_word(rs, x.np, l, i);
 }
 
 extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges(BaExpand x) {
@@ -175,8 +159,9 @@ struct BaFastPlan {
   std::vector<uint64_t> sig, run_sig;
   std::vector<int4> rm_chunk;
   std::vector<uint32_t> rm_cost;
+  std::vector<int> rm_cut;
   bool grouped = true;
-  int n_rm = 0, n_runs = 0, P_rm = 0, nchunks = 0;
+  int n_rm = 0, n_rmA = 0, n_runs = 0, P_rm = 0, nchunks = 0;
 };
 
 // the knobs under which the fast plan's windows run exactly the kernels it prepares for (anything else: ba_plan)
@@ -264,7 +249,7 @@ static int ba_plan_fast(cms_ba* b, BaFastPlan& fp, int K, const uint8_t* fixed, 
   for (int g = 0; g < ng; ++g) {
     const int q = gfirst[g], k = cnt[q];
     const int kf = __builtin_popcountll(sig[q] & free_mask);
-    if (k < 1 || kf < 1 || kf * (kf + 1) / 2 > 64 || 6 * kf + 1 > 48) continue;
+    if (k < 1 || k > 9 || kf < 1 || kf * (kf + 1) / 2 > 64 || 6 * kf + 1 > 48) continue;
     const int m = std::min(64 / k, BA_RM_PTS);
     if (gcount[g] < m) continue;                                    // at least one full chunk (run_min_chunks 1, run_min_pct 100: the defaults this path requires)
     const int full = gcount[g] / m, tail = gcount[g] - full * m;
@@ -273,6 +258,7 @@ static int ba_plan_fast(cms_ba* b, BaFastPlan& fp, int K, const uint8_t* fixed, 
     take[g] = full * m + (keep_tail ? tail : 0);
     runs.push_back({k, q, take[g], full + (keep_tail ? 1 : 0), m, kf});
   }
+  ba_rw_order_runs(runs, run_of_group, [](const Run& r) { return r.kf; });      // signatures with two tile rows first (cms_ba_schur_runwg.hip)
   std::vector<int> run_pt0(runs.size() + 1, 0);
   for (size_t r = 0; r < runs.size(); ++r) run_pt0[r + 1] = run_pt0[r] + runs[r].npts;
   const int P_rm = run_pt0.back(), PL = P - P_rm;
@@ -300,6 +286,8 @@ static int ba_plan_fast(cms_ba* b, BaFastPlan& fp, int K, const uint8_t* fixed, 
   for (size_t r = 0; r < runs.size(); ++r)
     for (int c = 0; c < runs[r].chunks; ++c) { chunk_pt0.push_back(run_pt0[r] + c * runs[r].m); rm_chunk_run.push_back((int)r); }
   const int n_rm = (int)rm_chunk_run.size();
+  int n_rmA = 0;
+  while (n_rmA < n_rm && ba_rw_class(runs[rm_chunk_run[n_rmA]].kf) == 0) ++n_rmA;
   {
     const int nseg = std::max(1, std::min(8, PL / 512));
     for (int t = 0; t < nseg; ++t) {
@@ -381,9 +369,15 @@ static int ba_plan_fast(cms_ba* b, BaFastPlan& fp, int K, const uint8_t* fixed, 
   for (int i = 0; i <= NP2; ++i) fp.ident[i] = i;
   fp.run_sig.resize(std::max<size_t>(runs.size(), 1), 0);
   for (size_t r = 0; r < runs.size(); ++r) fp.run_sig[r] = sig[runs[r].first];
-  fp.n_rm = n_rm; fp.n_runs = (int)runs.size(); fp.P_rm = P_rm; fp.nchunks = nchunks;
+  fp.n_rm = n_rm; fp.n_rmA = n_rmA; fp.n_runs = (int)runs.size(); fp.P_rm = P_rm; fp.nchunks = nchunks;
+  fp.rm_cut.clear();
+  if (ba_want_rw_tables()) {
+    fp.rm_cut.assign(2 * (BA_RW_CUTS + 1), 0);
+    ba_rw_make_cuts(fp.rm_cost, 0, n_rmA, fp.rm_cut.data());
+    ba_rw_make_cuts(fp.rm_cost, n_rmA, n_rm, fp.rm_cut.data() + (BA_RW_CUTS + 1));
+  }
   BaSe& se = b->se;
-  se.nchunks = nchunks; se.n_rm = n_rm; se.npairs2 = NP2;
+  se.nchunks = nchunks; se.n_rm = n_rm; se.n_rmA = n_rmA; se.npairs2 = NP2;
   se.cpw_t = (BA_TE_THREADS / 64) * kn.te_chunks;
   se.Rt = (nchunks + se.cpw_t - 1) / se.cpw_t;
   se.nlone = (int)fp.lone.size();
@@ -434,6 +428,42 @@ extern "C" int cms_ba_debug_plan_fast(int K, const uint8_t* fixed, int P, int E,
   if (run_mf_out && fp.n_runs > 0) memcpy(run_mf_out, run_mf.data(), (size_t)fp.n_runs * 64 * sizeof(uint32_t));
   if (run_fl_out && fp.n_runs > 0) memcpy(run_fl_out, run_fl.data(), (size_t)fp.n_runs * 64 * 12 * sizeof(uint32_t));
   counts[0] = fp.nchunks; counts[1] = fp.n_rm; counts[2] = fp.n_runs; counts[3] = b->np; counts[4] = fp.P_rm; counts[5] = b->se.R_rm; counts[6] = b->se.R; counts[7] = 1;
+  delete b;
+  return CMS_OK;
+}
+
+// developer / test entry, host only: the tables of the one-wavefront run workgroups (cms_ba_schur_runwg.hip) as either planner makes them.
+// run_fg: runs x 64 x 24 words, rm_cut: 2 x 1025, counts[4] = runs, run chunks, class-0 run chunks, free key frames; fast != 0: the device-side
+// planner's host part + the expansion kernel's body on the host (counts[0] = -1 when it does not take the window)
+extern "C" int cms_ba_debug_run_fg(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int fast, uint32_t* run_fg_out, int* rm_cut_out, int* counts) {
+  if (K < 1 || P < 1 || E < 1 || !fixed || !e_pose || !e_point || !run_fg_out || !rm_cut_out || !counts) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_run_fg: bad argument");
+  for (int e = 0; e < E; ++e)
+    if (e_pose[e] < 0 || e_pose[e] >= K || e_point[e] < 0 || e_point[e] >= P) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_run_fg: index out of range");
+  struct Force { Force() { ba_force_rw_tables = true; } ~Force() { ba_force_rw_tables = false; } } force;
+  cms_ba* b = new cms_ba;
+  b->K = K; b->P = P; b->E = E;
+  for (int i = 0; i < 4; ++i) counts[i] = 0;
+  if (fast) {
+    BaFastPlan fp;
+    std::vector<int8_t> face(E, 0);
+    const int rc = ba_plan_fast(b, fp, K, fixed, P, E, e_pose, e_point, face.data(), [](const char*) {});
+    if (rc <= 0) { delete b; counts[0] = -1; return rc < 0 ? cms_fail(CMS_ERR_ARG, "cms_ba_debug_run_fg: index out of range") : CMS_OK; }
+    for (int r = 0; r < fp.n_runs; ++r) {
+      BaRunSig rs;
+      ba_run_decode(fp.run_sig[r], fp.pose_slot.data(), rs);
+      for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 24; ++i) run_fg_out[((size_t)r * 64 + l) * 24 + i] = ba_run_fg_word(rs, b->np, l, i);
+    }
+    memcpy(rm_cut_out, fp.rm_cut.data(), fp.rm_cut.size() * sizeof(int));
+    counts[0] = fp.n_runs; counts[1] = fp.n_rm; counts[2] = fp.n_rmA; counts[3] = b->np;
+  } else {
+    BaPlan pl;
+    ba_plan(b, pl, K, fixed, P, E, e_pose, e_point, nullptr, nullptr, nullptr, [](const char*) {});
+    if (!pl.se_built) { delete b; counts[0] = -1; return CMS_OK; }
+    if (b->n_runs > 0) memcpy(run_fg_out, pl.run_fg.data(), (size_t)b->n_runs * 64 * 24 * sizeof(uint32_t));
+    if (!pl.rm_cut.empty()) memcpy(rm_cut_out, pl.rm_cut.data(), pl.rm_cut.size() * sizeof(int));
+    counts[0] = b->n_runs; counts[1] = b->se.n_rm; counts[2] = pl.n_rmA; counts[3] = b->np;
+  }
   delete b;
   return CMS_OK;
 }

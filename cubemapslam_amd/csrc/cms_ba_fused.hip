@@ -400,8 +400,18 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
 #pragma unroll 2
       for (int r = 0; r < n_slices; ++r) {
         double* cs = partial + ((size_t)r * NP2 + pr) * 42;
+        if (I == K && consume) {
+          // a diagonal pair of the ONE global copy: only its upper triangle is complete (the one-wavefront run workgroups add nothing else,
+          // cms_ba_schur_runwg.hip; the edge-major write-out adds both): element (r, q) is stored[min][max]
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { const double2 v = *reinterpret_cast<const double2*>(cs + 6 * q + r0); a[q] -= v.x; a[6 + q] -= v.y; }
+          for (int q = 0; q < 6; ++q) {
+            a[q] -= cs[6 * min(q, r0) + max(q, r0)];
+            a[6 + q] -= cs[6 * min(q, r0 + 1) + max(q, r0 + 1)];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { const double2 v = *reinterpret_cast<const double2*>(cs + 6 * q + r0); a[q] -= v.x; a[6 + q] -= v.y; }
+        }
         if (I == K) { const double2 v = *reinterpret_cast<const double2*>(cs + 36 + r0); yb[0] += v.x; yb[1] += v.y; }
         if (consume) {
 #pragma unroll

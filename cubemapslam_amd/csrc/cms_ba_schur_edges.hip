@@ -55,6 +55,10 @@ struct BaSe {                      // device view of the edge-major work list (c
   const uint32_t* run_mf;         // runs x 64: rows / columns of a signature's stacked matrix for the MFMA variant (cms_ba_schur_runs.hip, BA_RM_MF_*)
   const uint32_t* run_fl;         // runs x 64 x 12: per lane, where its 24 MFMA accumulators are added (two 16-bit LDS offsets per word)
   const uint32_t* rm_cost;        // n_rm + 1: running sum of the run chunks' estimated cost (ba_rm_chunk_cost): the wavefronts' ranges are cut by cost, not by count
+  // one-wavefront workgroups (cms_ba_schur_runwg.hip): the runs are ordered by class (signatures with two tile rows first), chunks [0, n_rmA) are class 0
+  const uint32_t* run_fg;         // runs x 64 x 24: per lane and MFMA accumulator its offset into `partial` (doubles; 0xFFFFFFFF: nowhere)
+  const int* rm_cut;              // 2 x 1025: per class, the chunk at which i / 1024 of the class's estimated cost is reached
+  int n_rmA;
   int Rt, cpw_t;                  // the same chunks cut into more, shorter ranges for the edge-major trial kernel (no LDS copy of the system to amortise)
   int npairs2;                    // np (np + 1) / 2: pose pairs s1 <= s2 enumerated densely, row by row
   const int* chunk_e0;            // nchunks + 1: first edge of every chunk (whole points, <= 64 edges)
@@ -70,6 +74,7 @@ struct BaSe {                      // device view of the edge-major work list (c
 struct BaSeG {                     // BaSe with global-memory pointer types (see BaDevG, cms_ba_kernels.hip): what the device bodies take
   int R, nchunks, cpw, n_rm, R_rm;
   const BA_AS1 int4* rm_chunk; const BA_AS1 uint2* run_lane; const BA_AS1 uint32_t* run_mf; const BA_AS1 uint32_t* run_fl; const BA_AS1 uint32_t* rm_cost;
+  const BA_AS1 uint32_t* run_fg; const BA_AS1 int* rm_cut; int n_rmA;
   int Rt, cpw_t, npairs2;
   const BA_AS1 int* chunk_e0; const BA_AS1 uint32_t* e_info;
   BA_AS1 double* partial; BA_AS1 double* bp_partial;
@@ -78,7 +83,7 @@ struct BaSeG {                     // BaSe with global-memory pointer types (see
   __device__ __forceinline__ BaSeG() {}
   __device__ __forceinline__ BaSeG(const BaSe& s)
       : R(s.R), nchunks(s.nchunks), cpw(s.cpw), n_rm(s.n_rm), R_rm(s.R_rm), rm_chunk(ba_g(s.rm_chunk)), run_lane(ba_g(s.run_lane)), run_mf(ba_g(s.run_mf)),
-        run_fl(ba_g(s.run_fl)), rm_cost(ba_g(s.rm_cost)), Rt(s.Rt), cpw_t(s.cpw_t), npairs2(s.npairs2), chunk_e0(ba_g(s.chunk_e0)), e_info(ba_g(s.e_info)), partial(ba_g(s.partial)),
+        run_fl(ba_g(s.run_fl)), rm_cost(ba_g(s.rm_cost)), run_fg(ba_g(s.run_fg)), rm_cut(ba_g(s.rm_cut)), n_rmA(s.n_rmA), Rt(s.Rt), cpw_t(s.cpw_t), npairs2(s.npairs2), chunk_e0(ba_g(s.chunk_e0)), e_info(ba_g(s.e_info)), partial(ba_g(s.partial)),
         bp_partial(ba_g(s.bp_partial)), lone(ba_g(s.lone)), nlone(s.nlone), gsum(s.gsum) {}
 };
 

@@ -217,6 +217,12 @@ int cms_ba_debug_fetch_plan(cms_ba* ba, int* pinv, int* perm, uint32_t* info, in
  * (run_lane excepted); counts[7] = 0 when the window is not one the device-side planner takes (cms_ba_create then uses the host planner). */
 int cms_ba_debug_plan_fast(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int* pinv, int* perm, uint32_t* info,
                            int* chunk_pt0, int* rm_chunk, int* counts, uint32_t* run_mf, uint32_t* run_fl);
+/* developer / test aid, host only: the tables of the opt-in one-wavefront run workgroups (CMS_BA_RUN_WG=1, cubemapslam_amd/csrc/cms_ba_schur_runwg.hip:
+ * round 6's re-decomposition of the Schur kernel, block_solver.hpp:367-437) as either planner makes them (fast != 0: the device-side planner's host
+ * part).  run_fg: 64 x 24 words per run (per lane and MFMA accumulator its offset into the window's global copy of the reduced system, 0xFFFFFFFF: none),
+ * rm_cut: 2 x 1025 cut points (per class of signature), counts[4] = runs (-1: the planner does not take the window), run chunks, class-0 run chunks,
+ * free key frames. */
+int cms_ba_debug_run_fg(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int fast, uint32_t* run_fg, int* rm_cut, int* counts);
 void cms_ba_destroy(cms_ba* ba);
 /* Device slabs and pinned blocks of destroyed windows wait in a per-device pool for the next window (CMS_BA_POOL_MB bounds the device part, default
  * 16384; the pool is also emptied and the allocation retried when hipMalloc fails).  cms_ba_pool_trim hands everything cached for `device` back

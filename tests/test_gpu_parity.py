@@ -1241,7 +1241,7 @@ def test_kfstore_fuse_search_matches_oracle():
 @pytest.mark.parametrize("knob", ["CMS_BA_NO_FUSED_LIN", "CMS_BA_DETERMINISTIC", "CMS_BA_NO_PERMUTE", "CMS_BA_NO_RUNS", "CMS_BA_RUNS_AS_EDGES",
                                   "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU", "CMS_BA_SOLVE_REDUCE_MAX=1000",
                                   "CMS_BA_SPLIT_WORKGROUPS", "CMS_BA_SEPARATE_REDUCE2", "CMS_BA_SEPARATE_FIRST_PASS", "CMS_BA_TE_CHUNKS=1", "CMS_BA_TE_CHUNKS=5",
-                                  "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT", "CMS_BA_HOST_PLAN", "CMS_BA_LEFTOVER_LOOKAHEAD=4"])
+                                  "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT", "CMS_BA_HOST_PLAN", "CMS_BA_LEFTOVER_LOOKAHEAD=4", "CMS_BA_RUN_WG"])
 def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     """The grouped local-BA driver has several Schur paths -- signature runs multiplied in MFMA tiles + edge-major left-overs, linearisation
     fused (default); the runs' products on the vector ALU by producer / consumer wavefront pairs (CMS_BA_RM_VALU); every point edge-major
@@ -1252,7 +1252,9 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     Round 4's alternatives: separate workgroups for run chunks and left-over chunks instead of cost-balanced ranges over both
     (CMS_BA_SPLIT_WORKGROUPS), kb_ba_reduce2 / the four first-iteration launches instead of their folded forms (CMS_BA_SEPARATE_REDUCE2,
     CMS_BA_SEPARATE_FIRST_PASS), one or five chunks per wavefront of the trial kernel, the window descriptions through a copy engine, sleeping host waits.
-    Round 5: the host planner for every window instead of the device-side one (CMS_BA_HOST_PLAN), and round 4's look-ahead for the left-over points.  The
+    Round 5: the host planner for every window instead of the device-side one (CMS_BA_HOST_PLAN), and round 4's look-ahead for the left-over points.
+    Round 6: the runs through one-wavefront workgroups that add straight to the window's global copy of the reduced system, the left-over chunks through
+    kb_ba_lin_schur_edges behind them (CMS_BA_RUN_WG: cms_ba_schur_runwg.hip -- the re-decomposition round 5's verdict asked for; slower, kept opt-in).  The
     knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""
     import os, subprocess, sys
     env = dict(os.environ)
