@@ -786,8 +786,8 @@ def main():
             ctx.process(B, True)        # (streaming: waits on the device for the copy enqueued during the previous step)
         if step_trace is not None:
             step_trace.append(("frame path enqueued", time.perf_counter()))
-            if streaming:
-                ctx.upload_async(sets[(i + 1) % 2].pinned.array)   # next step's frames travel under this step's kernels
+        if streaming:
+            ctx.upload_async(sets[(i + 1) % 2].pinned.array)   # next step's frames travel under this step's kernels
         if part != "frames":
             if serial and part != "ba":
                 # extraction and the local-BA chain each fill the chip; side by side they only slow each other down.  The mapping side of the

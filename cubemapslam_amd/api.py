@@ -580,6 +580,27 @@ class KeyframeStore:
         _chk(L.cms_kfstore_put_from_frame(self.h, slot, src_ctx.h, b, n, _p(R), _p(t), _p(Ow), float(kf["median_depth"]), _p(mp), len(nid), _p(nid), _p(noff), _p(nfeat)),
              "cms_kfstore_put_from_frame")
 
+    def put_from_frames(self, src_ctx, items):
+        """cms_kfstore_put_from_frames: several key frames of src_ctx's last batch in ONE call (one kernel); items = [(slot, b, n, kf), ...] with kf as in
+        put_from_frame.  All items are checked before anything is touched: on an error the store is unchanged."""
+        class KfFromFrame(C.Structure):      # cms_kf_from_frame (include/cubemapslam_hip.h)
+            _fields_ = [("slot", C.c_int), ("b", C.c_int), ("n", C.c_int), ("Rcw", C.c_void_p), ("tcw", C.c_void_p), ("Ow", C.c_void_p), ("median_depth", C.c_float),
+                        ("mp", C.c_void_p), ("nnodes", C.c_int), ("node_id", C.c_void_p), ("node_off", C.c_void_p), ("node_feat", C.c_void_p)]
+        arr = (KfFromFrame * len(items))()
+        keep = []
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        i32 = lambda a: None if a is None else np.ascontiguousarray(a, np.int32)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        for q, (slot, b, n, kf) in zip(arr, items):
+            R, t, Ow = f32(np.asarray(kf["R"]).reshape(9)), f32(kf["t"]), f32(kf["Ow"])
+            mp, nid, noff, nfeat = i32(kf.get("mp")), i32(kf["node_id"]), i32(kf["node_off"]), i32(kf["node_feat"])
+            keep.append((R, t, Ow, mp, nid, noff, nfeat))
+            q.slot = slot; q.b = b; q.n = n; q.Rcw = ptr(R); q.tcw = ptr(t); q.Ow = ptr(Ow); q.median_depth = float(kf["median_depth"]); q.mp = ptr(mp)
+            q.nnodes = len(nid); q.node_id = ptr(nid); q.node_off = ptr(noff); q.node_feat = ptr(nfeat)
+        L = lib()
+        L.cms_kfstore_put_from_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _chk(L.cms_kfstore_put_from_frames(self.h, src_ctx.h, len(items), arr), "cms_kfstore_put_from_frames")
+
     def debug_fetch(self, slot, max_features=16384, max_nodes=16384):
         """cms_kfstore_debug_fetch: the slot's device contents as a dict"""
         hdr = np.zeros(21, np.uint32); misc = np.zeros(2, np.int32)

@@ -390,9 +390,13 @@ extern "C" int cms_ba_set_stream(cms_ba* b, void* hip_stream) {
   // steps ahead of its optimisation, and a wait inserted now would hold up whatever the group's stream is running in the meantime.
   static const bool host_wait = getenv("CMS_BA_SET_STREAM_WAIT") != nullptr;
   if (host_wait || !b->async_pending || (hipStream_t)hip_stream == b->stream) {
+    if (b->setup_wait_pending) { HIPCHK(hipEventSynchronize(b->ev_setup)); b->setup_wait_pending = false; }      // (an earlier hand-over's set-up, never waited for)
     HIPCHK(ba_wait_stream(b->stream));
     b->async_pending = false;
   } else {
+    // a second hand-over before the window was ever used on the first new stream: that stream never waited for the set-up, so an event recorded
+    // on it now would mark nothing -- put the pending wait into it first, then record behind it
+    if (b->setup_wait_pending) HIPCHK(ba_order_behind_setup(b));
     if (!b->ev_setup) b->ev_setup = ba_event_take(b->device);
     if (!b->ev_setup) return cms_fail(CMS_ERR_HIP, "cms_ba_set_stream: no event");
     HIPCHK(hipEventRecord(b->ev_setup, b->stream));

@@ -642,10 +642,16 @@ static int ba_optimize_group(cms_ba** bas, int n, int its_robust, int its_final,
     snprintf(buf, sizeof(buf), " %s %.3f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
     t_log += buf;
   };
+  // a window handed to its stream by cms_ba_set_stream: the stream waits for the window's set-up (the host does not) -- whichever driver runs the
+  // group.  (Until round 6 only the batched branch did this: windows that cannot batch -- more free key frames than the blocked solve takes --
+  // started their kernels on the new stream with nothing ordering them behind the upload and the set-up kernel on the old one.)
+  for (int w = 0; w < n; ++w) { HIPCHK(hipSetDevice(bas[w]->device)); HIPCHK(ba_order_behind_setup(bas[w])); }
+  if (!batched)
+    for (int w = 0; w < n; ++w)      // the one-window drivers enqueue on the window's own stream and synchronise it: nothing else may still be pending there
+      if (bas[w]->async_pending) { HIPCHK(ba_wait_stream(bas[w]->stream)); bas[w]->async_pending = false; }
   if (batched) {
     HIPCHK(hipSetDevice(bas[0]->device));
     for (int w = 0; w < n; ++w) {     // pending uploads / resets on the windows' streams
-      HIPCHK(ba_order_behind_setup(bas[w]));      // (a window handed to this stream by cms_ba_set_stream: the stream waits for its set-up, the host does not)
       // a window on a stream of its own: the group's stream (bas[0]'s) must not start before that window's pending work is through -- the host waits.
       // A window that already sits on the group's stream is ordered by the stream itself.
       if (bas[w]->async_pending && bas[w]->stream != bas[0]->stream) { HIPCHK(ba_wait_stream(bas[w]->stream)); bas[w]->async_pending = false; }

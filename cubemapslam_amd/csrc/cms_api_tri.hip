@@ -332,6 +332,9 @@ struct cms_kfstore {
   int* h_ff = nullptr; size_t ff_stride = 0; std::vector<std::shared_ptr<PutCall>> ff_call;
   void* h_items = nullptr; int items_gen = 0; std::shared_ptr<PutCall> items_call[2];      // the batch's descriptors: two pinned arrays, used alternately
   unsigned upd_call = 0; hipEvent_t upd_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool upd_ev_set[4] = {false, false, false, false};
+  // slots that work enqueued on the store's stream reads or writes (pose updates, CreateNewMapPoints, the Fuse searches) since the slot was last
+  // filled: cms_kfstore_put_from_frames copies on the FRAME context's stream, so before it overwrites such a slot that stream waits for the store's
+  std::vector<uint8_t> busy; hipEvent_t order_ev = nullptr;
   float* h_upd = nullptr; std::vector<uint8_t> upd_par;      // two 16-float blocks per SLOT, used alternately: a block is rewritten only by the SECOND later update
                                                              // of the same slot, long after the kernel of the first has read it (no event, no wait)
 };
@@ -346,6 +349,7 @@ extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
   if (st->h_items) (void)hipHostFree(st->h_items);
   if (st->h_upd) (void)hipHostFree(st->h_upd);
   for (hipEvent_t e : st->upd_ev) if (e) (void)hipEventDestroy(e);
+  if (st->order_ev) (void)hipEventDestroy(st->order_ev);
   delete st;
 }
 
@@ -372,7 +376,7 @@ extern "C" int cms_kfstore_create(cms_kfstore** out, cms_ctx* c, int max_keyfram
   KF_ALLOC(st->d_nvalid, K * sizeof(int));
   KF_ALLOC(st->d_kp_cnt, K * sizeof(int));
 #undef KF_ALLOC
-  st->h_kf.assign(K, CmsTriKF{}); st->h_median.assign(K, 1.0f); st->used.assign(K, 0);
+  st->h_kf.assign(K, CmsTriKF{}); st->h_median.assign(K, 1.0f); st->used.assign(K, 0); st->busy.assign(K, 0);
   *out = st;
   return CMS_OK;
 }
@@ -461,9 +465,9 @@ static int kfstore_ff_reserve(cms_kfstore* st) {
   st->ff_call.assign((size_t)st->maxkf, nullptr);
   return CMS_OK;
 }
-// validation + the slot's pinned block + the descriptor of one key frame (no launch)
-static int kf_put_prepare(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow, float median_depth,
-                          const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat, CmsKfFromFrame& a) {
+// validation of one key frame of a cms_kfstore_put_from_frames call: touches nothing
+static int kf_put_check(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow,
+                        const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat) {
   if (slot < 0 || slot >= st->maxkf || b < 0 || b >= src->max_batch || n < 0 || nnodes < 0 || !Rcw || !tcw || !Ow ||
       (nnodes > 0 && (!node_id || !node_off || !node_feat)))
     return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: bad argument");
@@ -480,6 +484,14 @@ static int kf_put_prepare(cms_kfstore* st, int slot, cms_ctx* src, int b, int n,
   }
   const int nfeat = nnodes > 0 ? node_off[nnodes] : 0;
   if (nfeat > st->maxf) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: FeatureVector lists more features than the slot holds");
+  (void)c; (void)mp;
+  return CMS_OK;
+}
+// ... then the slot's pinned block and the descriptor (no launch; the store's host-side record of the slot is committed by the caller once the
+// kernel is in the stream)
+static int kf_put_fill(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, const float* Rcw, const float* tcw, const float* Ow,
+                       const int* mp, int nnodes, const int* node_id, const int* node_off, const int* node_feat, CmsKfFromFrame& a) {
+  const int nfeat = nnodes > 0 ? node_off[nnodes] : 0;
   if (st->ff_call[(size_t)slot]) { HIPCHK(hipEventSynchronize(st->ff_call[(size_t)slot]->ev)); st->ff_call[(size_t)slot].reset(); }      // (the call that last read this block: long through)
   int* h = st->h_ff + (size_t)slot * st->ff_stride;
   int* h_mp = h; int* h_fn = h + st->maxf; int* h_nfeat = h + 2 * (size_t)st->maxf; int* h_nid = h + 3 * (size_t)st->maxf; int* h_noff = h_nid + st->maxn;
@@ -501,8 +513,6 @@ static int kf_put_prepare(cms_kfstore* st, int slot, cms_ctx* src, int b, int n,
   a.o_mp = st->d_mp + f0; a.o_fn = st->d_fn + f0; a.o_nid = st->d_nid + n0; a.o_noff = st->d_noff + o0; a.o_nfeat = st->d_nfeat + f0; a.o_kf = st->d_kf + slot;
   a.h_mp = mp ? h_mp : nullptr; a.h_fn = h_fn; a.h_nid = h_nid; a.h_noff = h_noff; a.h_nfeat = h_nfeat;
   a.n = n; a.nnodes = nnodes; a.nfeat = nfeat;
-  st->h_kf[(size_t)slot] = d; st->h_median[(size_t)slot] = median_depth; st->used[(size_t)slot] = 1;
-  (void)c;
   return CMS_OK;
 }
 // several key frames of one batch in one call (a process that tracks many camera streams per GPU inserts one key frame per stream and step): ONE
@@ -514,27 +524,56 @@ extern "C" int cms_kfstore_put_from_frames(cms_kfstore* st, cms_ctx* src, int n_
   if (src->device != c->device || src->g.F != c->g.F || src->g.W != c->g.W) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frame: the frame context and the store must share device and cubemap geometry");
   HIPCHK(hipSetDevice(c->device));
   { const int rc = kfstore_ff_reserve(st); if (rc) return rc; }
+  // every item is checked before anything is touched: a bad item (or a slot named twice: the second would overwrite the first one's pinned block
+  // with no event between them) leaves the store as it was
+  {
+    std::vector<uint8_t> seen((size_t)st->maxkf, 0);
+    for (int i = 0; i < n_items; ++i) {
+      const cms_kf_from_frame& q = items[i];
+      const int rc = kf_put_check(st, q.slot, src, q.b, q.n, q.Rcw, q.tcw, q.Ow, q.mp, q.nnodes, q.node_id, q.node_off, q.node_feat);
+      if (rc) return rc;
+      if (seen[(size_t)q.slot]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put_from_frames: a slot is named twice");
+      seen[(size_t)q.slot] = 1;
+    }
+  }
   const int gen = (st->items_gen ^= 1);
   if (st->items_call[gen]) { HIPCHK(hipEventSynchronize(st->items_call[gen]->ev)); st->items_call[gen].reset(); }      // (two calls ago)
   CmsKfFromFrame* h_items = reinterpret_cast<CmsKfFromFrame*>(st->h_items) + (size_t)gen * st->maxkf;
   int max_n = 0;
   for (int i = 0; i < n_items; ++i) {
     const cms_kf_from_frame& q = items[i];
-    const int rc = kf_put_prepare(st, q.slot, src, q.b, q.n, q.Rcw, q.tcw, q.Ow, q.median_depth, q.mp, q.nnodes, q.node_id, q.node_off, q.node_feat, h_items[i]);
-    if (rc) return rc;
+    const int rc = kf_put_fill(st, q.slot, src, q.b, q.n, q.Rcw, q.tcw, q.Ow, q.mp, q.nnodes, q.node_id, q.node_off, q.node_feat, h_items[i]);
+    if (rc) return rc;      // (only a failing event wait: nothing of the store's record has changed yet)
     max_n = std::max(max_n, q.n);
   }
   // The copy runs on the FRAME context's stream: right behind the work that produced the frames, and in front of whatever the caller enqueues there
   // next (the next batch overwrites the frame buffers) -- the KeyFrame constructor's copy happens on the Tracking thread in the reference too
   // (Tracking.cpp:1015-1017, KeyFrame.cpp:29-55).  The store's stream then waits for it on the device.
   hipStream_t s = src->stream;
+  // ... but work already queued on the STORE's stream may still read or write a slot this call refills (an asynchronous pose update landing after
+  // the new record, a search still reading the old key points): then the frame stream waits for the store's stream first.  Slots that nothing on
+  // the store's stream referred to since they were last filled -- the usual case: a new key frame goes to a fresh slot -- cost no wait.
+  {
+    bool wait = false;
+    for (int i = 0; i < n_items; ++i) wait = wait || (st->busy[(size_t)items[i].slot] != 0);
+    if (wait && c->stream != s) {
+      if (!st->order_ev) HIPCHK(hipEventCreateWithFlags(&st->order_ev, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(st->order_ev, c->stream));
+      HIPCHK(hipStreamWaitEvent(s, st->order_ev, 0));
+      std::fill(st->busy.begin(), st->busy.end(), 0);      // (everything queued on the store's stream so far is in front of the copy now)
+    }
+  }
   hipLaunchKernelGGL(k_kf_put_from_frame, dim3(std::max(1, std::min(32, (6 * max_n + 255) / 256)), n_items), dim3(256), 0, s, (const CmsKfFromFrame*)h_items);
   HIPCHK(hipGetLastError());
   auto call = std::make_shared<cms_kfstore::PutCall>();
   HIPCHK(hipEventCreateWithFlags(&call->ev, hipEventDisableTiming));
   HIPCHK(hipEventRecord(call->ev, s));
   if (c->stream != s) HIPCHK(hipStreamWaitEvent(c->stream, call->ev, 0));
-  for (int i = 0; i < n_items; ++i) st->ff_call[(size_t)items[i].slot] = call;
+  for (int i = 0; i < n_items; ++i) {      // the kernel is in the stream: commit the store's record of the slots
+    const cms_kf_from_frame& q = items[i];
+    st->ff_call[(size_t)q.slot] = call;
+    st->h_kf[(size_t)q.slot] = h_items[i].kf; st->h_median[(size_t)q.slot] = q.median_depth; st->used[(size_t)q.slot] = 1;
+  }
   st->items_call[gen] = call;
   return CMS_OK;
 }
@@ -582,6 +621,7 @@ extern "C" int cms_kfstore_update_poses(cms_kfstore* st, int n, const int* slots
     CmsTriKF& d = st->h_kf[(size_t)slot];
     std::memcpy(d.Rcw, Rcw + 9 * (size_t)i, 36); std::memcpy(d.tcw, tcw + 3 * (size_t)i, 12); std::memcpy(d.Ow, Ow + 3 * (size_t)i, 12);
     list[i] = slot | (par << 30);
+    st->busy[(size_t)slot] = 1;      // (asynchronous: a later cms_kfstore_put_from_frames into this slot orders itself behind this kernel)
   }
   hipLaunchKernelGGL(k_kf_update_poses, dim3((n + 63) / 64), dim3(64), 0, c->stream, st->d_kf, (const float*)st->h_upd, (const int*)list, n);
   HIPCHK(hipGetLastError());

@@ -55,6 +55,11 @@ def test_step_waits_for_the_frame_path_and_fetches_the_poses_unconditionally():
         # the only condition allowed around them is the developer split of the step into its halves
         for c in free:
             assert all(t in ('part != "ba"', "part != 'ba'") for t in c[1]), (name, c[1])
+    # the streaming pass's upload of the NEXT step's frames: conditioned on `streaming` alone (it sat under the step-trace switch until round 6 -- the
+    # default run's with_input_streaming figure then contained one upload, not one per step)
+    ups = [c for c in calls if c[0] == "ctx.upload_async"]
+    assert ups, "ctx.upload_async is not called in step()"
+    assert any(c[1] == ["streaming"] for c in ups), ups
     # the gather of the trajectory uses what the fetch returned
     src = ast.unparse(steps[0])
     assert "frame_poses" in src and src.index("po.fetch") < src.index("cdist.gather_trajectory")

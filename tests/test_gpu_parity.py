@@ -1193,6 +1193,71 @@ def test_kfstore_put_from_frame_equals_put():
     sA.close(); sB.close(); cg.close(); ctx.close()
 
 
+def test_kfstore_put_from_frames_is_all_or_nothing_and_orders_itself_behind_pose_updates():
+    """A batch of key frames in one cms_kfstore_put_from_frames call (LocalMapping::ProcessNewKeyFrame for several camera streams, LocalMapping.cpp:52-117):
+    a bad item or a slot named twice must leave the store untouched (earlier items used to be committed before a later one failed), and a put
+    into a slot whose asynchronous pose update (cms_kfstore_update_poses, Optimizer.cpp:419-431) may still be queued on the store's stream must
+    land AFTER it: the copy runs on the frame context's stream, which then waits for the store's."""
+    F = 550
+    camd, ocam, _ = _cfg("lafida", F, 2000)
+    ctx = api.Context(camd, nfeatures=2000, max_batch=2)
+    ctx.set_mask(synth.cubemap_valid_mask(camd))
+    ctx.upload(np.stack([synth.texture(camd["Ih"], camd["Iw"], s_) for s_ in (81, 82)])); ctx.process(2, True); ctx.area_grid(2); ctx.sync()
+    cg = api.Context(camd, nfeatures=2000, max_batch=1)
+    st = api.KeyframeStore(cg, max_keyframes=4, max_features=2048, max_nodes=512)
+    kfs = []
+    for b in range(2):
+        k, d = ctx.fetch(b)
+        n = len(k)
+        node = (d[:, 0].astype(np.int32)) % 200
+        order = np.lexsort((np.arange(n), node))
+        ids, starts = np.unique(node[order], return_index=True)
+        pr = synth.local_map_problem(F, k["x"], k["y"], k["octave"], d, seed=300 + b)
+        kfs.append((n, dict(mp=np.full(n, -1, np.int32), R=pr["pose15"][:9], t=pr["pose15"][9:12], Ow=pr["pose15"][12:], node_id=ids.astype(np.int32),
+                            node_off=np.concatenate([starts, [n]]).astype(np.int32), node_feat=order.astype(np.int32), median_depth=2.0)))
+    with pytest.raises(api.CmsError):
+        st.put_from_frames(ctx, [(0, 0, kfs[0][0], kfs[0][1]), (0, 1, kfs[1][0], kfs[1][1])])      # slot 0 twice
+    with pytest.raises(api.CmsError):
+        st.put_from_frames(ctx, [(1, 0, kfs[0][0], kfs[0][1]), (2, 7, kfs[1][0], kfs[1][1])])      # second item: no such frame
+    for slot in (0, 1, 2):
+        with pytest.raises(api.CmsError):
+            st.debug_fetch(slot)                                     # nothing was committed: the slots are still empty
+    st.put_from_frames(ctx, [(1, 0, kfs[0][0], kfs[0][1]), (2, 1, kfs[1][0], kfs[1][1])])
+    h1 = st.debug_fetch(1)["header"].copy()
+    assert st.debug_fetch(1)["kp_cnt"] == kfs[0][0] and st.debug_fetch(2)["kp_cnt"] == kfs[1][0]
+    # a pose update of slot 1 (asynchronous), then the slot is refilled from the frame: the slot must end up with the PUT's pose, every time
+    for rep in range(20):
+        R2 = np.full((1, 9), float(rep + 1), np.float32); t2 = np.full((1, 3), -1.0, np.float32)
+        st.update_poses([1], R2, t2, -t2)
+        st.put_from_frames(ctx, [(1, 0, kfs[0][0], kfs[0][1])])
+        assert np.array_equal(st.debug_fetch(1)["header"], h1), rep
+    st.close(); cg.close(); ctx.close()
+
+
+def test_ba_window_handed_to_another_stream_is_ordered_behind_its_set_up():
+    """cms_ba_set_stream right after cms_ba_create: the new stream waits for the window's upload and set-up kernel on the device, on every driver --
+    the grouped one (windows the blocked solve takes) and the one-window driver (more than 27 free key frames: what a reference-sized local BA with
+    a long co-visibility list looks like, Optimizer.cpp:246-357) -- and after a second hand-over before the first use."""
+    camd = synth.camera("lafida", 550)
+    c1 = api.Context(camd, nfeatures=500, max_batch=1); c2 = api.Context(camd, nfeatures=500, max_batch=1)
+    for K, P, seed in ((40, 2500, 4), (12, 3000, 3)):
+        prob = synth.ba_problem(K=K, P=P, obs_per_point=5 if K == 40 else 4, F=550, seed=seed, views="random" if K == 40 else "track")
+        w = orc.ba_run(prob)
+        for hops in (1, 2):
+            for rep in range(3):
+                ba = api.BundleAdjuster(prob)
+                ba.set_stream(c1.stream)
+                if hops == 2:
+                    ba.set_stream(c2.stream)
+                _, stats = api.ba_optimize_many([ba], (5, 10))
+                poses, pts, flags = ba.read()
+                ba.close()
+                assert list(stats[0].iterations_done) == list(w["stats"].iterations_done), (K, hops, rep)
+                assert np.array_equal(flags, w["outliers"]), (K, hops, rep)
+                _ba_updates_close_or_cascade(prob, poses, pts, w, tag="K %d hops %d" % (K, hops))
+    c1.close(); c2.close()
+
+
 def test_kfstore_fuse_search_matches_oracle():
     """SearchInNeighbors' Fuse calls on resident key frames: three key frames in a store, four jobs (one slot used twice) in one call"""
     import test_area_emu as te
