@@ -95,6 +95,8 @@ def parse_args(argv=None):
     ap.add_argument("--deterministic-steps", type=int, default=6, help="steps of the extra pass with cms_ba_set_deterministic(1) (config.deterministic; 0 = skip)")
     ap.add_argument("--mapping-only-steps", type=int, default=6, help="steps of the mapping side alone (CreateNewMapPoints + local BA, no frame path): config.mapping_only, and the Schur kernel's launch time without the frame path next to it in roofline (0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
+    ap.add_argument("--confined-steps", type=int, default=8, help="steps of the two child runs of the same step with the process confined to 2 and to 4 host cores "
+                    "(config.host.confined_2_cores / _4_cores: what a rank gets when eight of them share a 16-core box; rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
     return ap.parse_args(argv)
 
@@ -291,6 +293,8 @@ def main():
     # developer knob: every hipStreamSynchronize / hipEventSynchronize of this process blocks instead of spinning (hipDeviceScheduleBlockingSync);
     # must be set before the first HIP call of the process
     args = parse_args()
+    if os.environ.get("CMS_BENCH_AFFINITY", "") and hasattr(os, "sched_setaffinity"):      # a confined child leg (see confined_leg): before any thread exists
+        os.sched_setaffinity(0, {int(c) for c in os.environ["CMS_BENCH_AFFINITY"].split(",")})
     maybe_spawn(args)
     # A rank with few host cores (8 ranks on a node whose container has a 16-core quota: two each) cannot afford the runtime's spinning waits: with
     # <= 4 cores the process blocks in its synchronisations and the library's window threads sleep between stream queries (CMS_BA_RELAXED_WAIT).
@@ -411,6 +415,36 @@ def main():
         cpu_acc["create"] += time.thread_time() - c1; cpu_acc["n"] += 1
         return ba, 1e3 * (time.perf_counter() - t1)        # streams on 8 hardware queues: the two groups' chains and CreateNewMapPoints queued behind each other)
     own_streams = os.environ.get("CMS_BENCH_WINDOW_STREAMS", "") != ""      # developer knob: the old behaviour
+    # Round 6: a window GROUP's set-up and read-back are one library call each (cms_ba_create_many: host parts on a few threads of the call, one expansion
+    # launch per eight windows; cms_ba_read_many: one gather launch), and the group's 16 x 20 poses go back to the store in one cms_kfstore_update_poses
+    # -- 2 x 3 pool tasks and ~8 small launches per step instead of 32 + 32 tasks and ~92 launches.  CMS_BENCH_PER_WINDOW_CALLS=1: round 5's calls (A/B)
+    per_window_calls = os.environ.get("CMS_BENCH_PER_WINDOW_CALLS", "") != ""
+    per_window_create = per_window_calls or os.environ.get("CMS_BENCH_PER_WINDOW_CREATE", "") != ""      # (each half on its own, A/B)
+    per_window_finish = per_window_calls or os.environ.get("CMS_BENCH_PER_WINDOW_FINISH", "") != ""
+    win_arrays = {}
+    def make_group(j, gi, ids):
+        t1 = time.perf_counter(); c1 = time.thread_time()
+        mine = [prob_sets[j][w] for w in ids]
+        key = tuple(id(p_) for p_ in mine)         # (the random-views pass swaps the problem sets: the descriptions belong to the problem OBJECTS)
+        if key not in win_arrays:
+            win_arrays[key] = (api.ba_window_array(mine), mine)
+        grp = api.ba_create_many(mine, device=local_rank, threads=max(1, n_wthreads // max(1, n_grp)), windows=win_arrays[key][0])
+        if not own_streams:
+            for ba in grp:
+                ba.set_stream(group_stream[gi])
+        cpu_acc["create"] += time.thread_time() - c1; cpu_acc["n"] += len(grp)
+        ms = 1e3 * (time.perf_counter() - t1) / max(len(grp), 1)
+        return [(ba, ms) for ba in grp]
+    def finish_group(grp, gi):
+        c1 = time.thread_time()
+        outs = api.ba_read_many(grp)
+        if life.get("mapping_full"):
+            for wi in range(len(grp)):
+                write_back(gi, wi)
+        for ba in grp:
+            ba.close()
+        cpu_acc["finish"] += time.thread_time() - c1
+        return outs
     def finish_window(ba, gw=None):
         c1 = time.thread_time()
         out = ba.read()             # poses, points, outlier flags -> host arrays (Optimizer.cpp:419-450)
@@ -659,7 +693,10 @@ def main():
         step ran (futs); here they are optimised, then handed back to the pool to be read back and destroyed.  Returns (elapsed ms, new map
         points, per-window stats, futures of the read-backs, the windows' creation times)"""
         t_ba0 = time.perf_counter()
-        made = [f.result() for f in futs]
+        made = []
+        for f in futs:
+            r_ = f.result()
+            made.extend(r_ if isinstance(r_, list) else [r_])
         t_w = time.perf_counter()
         grp = [m[0] for m in made]
         grp[0].profile_kernel(3)          # HIP events around the Schur kernel of every round (the BA chain's largest kernel)
@@ -678,7 +715,7 @@ def main():
             res = tri_store[gi].create_new_map_points(tri_jobs[gi], copy=False)
         ms, nl = grp[0].profile_get()
         schur_acc["ms"] += ms; schur_acc["n"] += nl
-        outs = [wpool.submit(finish_window, ba, (gi, wi)) for wi, ba in enumerate(grp)]
+        outs = [wpool.submit(finish_window, ba, (gi, wi)) for wi, ba in enumerate(grp)] if per_window_finish else [wpool.submit(finish_group, grp, gi)]
         if step_trace is not None:
             step_trace.append(("worker %d" % gi, t_ba0, t_w, t_t, t_o, time.perf_counter()))
         for k_, v_ in (("wait_for_windows", t_w - t_ba0), ("create_new_map_points", t_t - t_w), ("optimize_many", t_o - t_t), ("hand_over", time.perf_counter() - t_o)):
@@ -705,7 +742,10 @@ def main():
 
     def submit_windows(j):
         """the pool starts building the n_ba windows of problem set j; returned per group"""
-        life["queue"].append((j, [[wpool.submit(make_window_at, 1e-3 * spread_ms * w / max(n_ba, 1), prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]))
+        if per_window_create:
+            life["queue"].append((j, [[wpool.submit(make_window_at, 1e-3 * spread_ms * w / max(n_ba, 1), prob_sets[j][w], gi) for w in ids] for gi, ids in enumerate(group_ids)]))
+        else:
+            life["queue"].append((j, [[wpool.submit(make_group, j, gi, ids)] for gi, ids in enumerate(group_ids)]))
 
     # developer knob: hand the next set of windows to the pool only after the step's frame path has been waited for (the pool's uploads and
     # gather / reset kernels then stay off the extraction kernels -- and land on the Levenberg rounds instead: 14.8-15.4 against 14.4-14.7 ms)
@@ -756,7 +796,7 @@ def main():
                     step_trace.append(("earlier read-backs waited for", time.perf_counter()))
                 life["reads"] = [f for r in res for f in r[3]]
                 if keep:
-                    last["ba_out"] = [[f.result() for f in r[3]] for r in res]
+                    last["ba_out"] = [[o_ for f in r[3] for o_ in (f.result() if isinstance(f.result(), list) else [f.result()])] for r in res]
                 for r in res:
                     acc["create_ms"] += sum(r[4]); acc["create_n"] += len(r[4])
 
@@ -863,7 +903,9 @@ def main():
         while life["queue"]:
             for futs in life["queue"].popleft()[1]:
                 for f in futs:
-                    f.result()[0].close()
+                    r_ = f.result()
+                    for m_ in (r_ if isinstance(r_, list) else [r_]):
+                        m_[0].close()
 
     step_times = [] if os.environ.get("CMS_BENCH_STEP_TIMES", "") != "" else None      # developer knob: host wall time of every timed step (stderr)
     def timed(streaming, lifecycle=True, steps=None, only="", pipeline=None, mapping_full=None):
@@ -1222,6 +1264,8 @@ def main():
                    "windows_per_launch": wpl,
                    "signature_runs": {"runs_per_window": round(float(np.mean([r[0] for r in run_stats])), 1), "points_in_runs": round(float(np.mean([r[1] for r in run_stats])), 3),
                                       "run_chunks_of_all_chunks": "%d / %d" % (int(np.mean([r[2] for r in run_stats])), int(np.mean([r[3] for r in run_stats])))},
+                   "traffic_note": "PMC counters (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE) of an 8-window launch of tools/prof_ba_many.py, "
+                                   "scaled to this run's %d windows per launch" % wpl,
                    "note": "HIP events on each window group's stream around the kernel of every round, inside the timed region; the groups' launches overlap each "
                            "other and the frame path, so ms_per_step is summed kernel time"}
     if roof_ba and mapping_only is not None and mapping_only["schur_launches"] > 0:
@@ -1357,6 +1401,37 @@ def main():
         except Exception as ex:      # the driver is a report line, not the metric
             closed["cpp_driver"] = {"error": str(ex)[:200]}
 
+    # ---- the same step with the whole process confined to 2 and to 4 host cores (child processes; the parent is idle meanwhile): the driver's box gives
+    # 8 ranks a 16-core quota, two cores each -- SCALE_rNN cannot be measured on a one-GPU lease, this is the part of it that can
+    def confined_leg(ncores):
+        try:
+            cores = sorted(os.sched_getaffinity(0))[:ncores]
+        except AttributeError:
+            return None
+        if len(cores) < ncores:
+            return None
+        env = dict(os.environ); env["CMS_BENCH_AFFINITY"] = ",".join(str(c) for c in cores)
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.confined_steps), "--warmup", "3", "--cpu-frames", "0", "--no-streaming-pass", "--verify-windows", "0",
+               "--extract-only-steps", "0", "--random-views-steps", "0", "--optimise-only-steps", "0", "--unpipelined-steps", "0", "--deterministic-steps", "0",
+               "--mapping-only-steps", "0", "--closed-loop-frames", "0", "--confined-steps", "0", "--camera", args.camera, "--batch", str(args.batch), "--ba-every", str(args.ba_every)]
+        t0_ = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            return {"cores": ncores, "state": "timed out"}
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"cores": ncores, "state": "failed (rc %d)" % r.returncode, "stderr_tail": r.stderr[-300:]}
+        j = json.loads(lines[-1])
+        h = j["config"].get("host") or {}
+        return {"cores": ncores, "core_list": cores, "value": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "host_cores_used": h.get("host_cores_used"),
+                "host_waits": h.get("host_waits"), "window_threads": h.get("window_threads"), "child_wall_s": round(time.perf_counter() - t0_, 1)}
+    if rank == 0 and world == 1 and args.confined_steps > 0 and n_ba > 0:
+        torch.cuda.synchronize()
+        host["confined_2_cores"] = confined_leg(2)
+        host["confined_4_cores"] = confined_leg(4)
+        host["confined_note"] = ("child processes of this bench.py with sched_setaffinity to the first 2 / 4 cores of the parent's affinity mask (CMS_BENCH_AFFINITY), same step, "
+                                 "no extra passes; the parent holds its device memory but launches nothing meanwhile")
     if rank == 0 and args.save_trajectory and last["traj"] is not None:
         # rank 0's assembled trajectory of the last step in the reference's TUM format (System.cpp:238-268)
         tr = last["traj"]

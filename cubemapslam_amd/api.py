@@ -714,6 +714,14 @@ class BundleAdjuster:
                                  _p(prob["e_invsig2"]), _p(prob["e_face"]), prob["fx"], prob["fy"], prob["cx"], prob["cy"]),
              "cms_ba_create")
 
+    @classmethod
+    def from_handle(cls, prob, handle):
+        self = cls.__new__(cls)
+        self.prob = prob
+        self.K, self.P, self.E = len(prob["poses"]), len(prob["points"]), len(prob["e_pose"])
+        self.h = C.c_void_p(handle)
+        return self
+
     def reset(self):
         _chk(lib().cms_ba_reset(self.h), "cms_ba_reset")
 
@@ -823,6 +831,51 @@ def ba_run_fg(fixed, n_points, e_pose, e_point, fast=False):
     if cnt[0] < 0:
         return None
     return dict(run_fg=fg[:int(cnt[0])].copy(), rm_cut=cut, n_runs=int(cnt[0]), n_rm=int(cnt[1]), n_rmA=int(cnt[2]), np=int(cnt[3]))
+
+
+class BaWindow(C.Structure):      # cms_ba_window (include/cubemapslam_hip.h)
+    _fields_ = [("K", C.c_int), ("poses", C.c_void_p), ("fixed", C.c_void_p), ("P", C.c_int), ("points", C.c_void_p), ("E", C.c_int), ("e_pose", C.c_void_p),
+                ("e_point", C.c_void_p), ("e_obs", C.c_void_p), ("e_invsig2", C.c_void_p), ("e_face", C.c_void_p), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double)]
+
+
+def ba_window_array(probs):
+    """(array of cms_ba_window, the numpy arrays it points into) for cms_ba_create_many; the problems' arrays must stay alive while the call runs"""
+    arr = (BaWindow * len(probs))()
+    keep = []
+    for q, p in zip(arr, probs):
+        a = [np.ascontiguousarray(p["poses"], np.float64), np.ascontiguousarray(p["fixed"], np.uint8), np.ascontiguousarray(p["points"], np.float64),
+             np.ascontiguousarray(p["e_pose"], np.int32), np.ascontiguousarray(p["e_point"], np.int32), np.ascontiguousarray(p["e_obs"], np.float64),
+             np.ascontiguousarray(p["e_invsig2"], np.float64), np.ascontiguousarray(p["e_face"], np.int8)]
+        keep.append(a)
+        q.K = len(a[0]); q.poses = a[0].ctypes.data; q.fixed = a[1].ctypes.data; q.P = len(a[2]); q.points = a[2].ctypes.data; q.E = len(a[3])
+        q.e_pose = a[3].ctypes.data; q.e_point = a[4].ctypes.data; q.e_obs = a[5].ctypes.data; q.e_invsig2 = a[6].ctypes.data; q.e_face = a[7].ctypes.data
+        q.fx = p["fx"]; q.fy = p["fy"]; q.cx = p["cx"]; q.cy = p["cy"]
+    return arr, keep
+
+
+def ba_create_many(probs, device=0, threads=4, windows=None):
+    """cms_ba_create_many: the windows of a group in one call (host parts on `threads` threads, one set-up launch per eight device-planned windows).
+    windows: a prepared ba_window_array(probs) (bench.py builds it once per problem set)."""
+    n = len(probs)
+    arr, keep = windows if windows is not None else ba_window_array(probs)
+    handles = (C.c_void_p * n)()
+    L = lib()
+    L.cms_ba_create_many.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    _chk(L.cms_ba_create_many(handles, n, device, arr, threads), "cms_ba_create_many")
+    return [BundleAdjuster.from_handle(p, handles[i]) for i, p in enumerate(probs)]
+
+
+def ba_read_many(bas):
+    """cms_ba_read_many: [(poses, points, outlier flags)] of optimised windows, one gather launch per sixteen device-planned windows"""
+    n = len(bas)
+    outs = [(np.zeros((b.K, 7)), np.zeros((b.P, 3)), np.zeros(b.E, np.uint8)) for b in bas]
+    handles = (C.c_void_p * n)(*[b.h for b in bas])
+    pp = (C.c_void_p * n)(*[o[0].ctypes.data for o in outs]); pq = (C.c_void_p * n)(*[o[1].ctypes.data for o in outs]); pf = (C.c_void_p * n)(*[o[2].ctypes.data for o in outs])
+    L = lib()
+    L.cms_ba_read_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    _chk(L.cms_ba_read_many(handles, n, pp, pq, pf), "cms_ba_read_many")
+    return outs
 
 
 def ba_set_deterministic(on):

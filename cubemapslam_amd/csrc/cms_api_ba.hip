@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <atomic>
 #include <cmath>
 #include <mutex>
@@ -69,6 +72,8 @@ static const BaKnobs& ba_knobs() {
   return k;
 }
 
+struct BaExpand;
+static thread_local BaExpand* ba_tl_defer_expand = nullptr;      // cms_ba_create_many: where cms_ba_create leaves the description of a device-planned window's expansion instead of launching it
 static thread_local bool ba_force_rw_tables = false;      // cms_ba_debug_run_fg: build the one-wavefront workgroups' tables whatever the knob says
 static inline bool ba_want_rw_tables() { return ba_knobs().run_wg || ba_force_rw_tables; }
 struct BaBlock { void* p; size_t bytes; };      // a device slab / pinned block of the per-device pool (below)
@@ -1526,7 +1531,8 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     x.e_obs = b->d_e_obs; x.e_inv = b->d_e_inv; x.pts0 = b->d_pts0; x.poses = b->d_poses[0]; x.pts = b->d_pts[0]; x.level = b->d_level; x.err = b->d_err; x.flags = b->d_flags;
     x.gsum = b->d_se_partial; x.n_gsum = b->se.npairs2 * 42; x.gsum_bp = b->d_se_bp_partial; x.n_gsum_bp = b->np * 6;
     x.ce0 = b->d_se_chunk_e0; x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl; x.run_fg = b->d_run_fg;
-    hipLaunchKernelGGL(k_ba_expand_edges, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, x);      // (+ the runs' tables)
+    if (ba_tl_defer_expand) { *ba_tl_defer_expand = x; ba_tl_defer_expand = nullptr; }      // cms_ba_create_many launches the group's expansions together
+    else hipLaunchKernelGGL(k_ba_expand_edges, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, x);      // (+ the runs' tables)
   } else
   hipLaunchKernelGGL(k_ba_gather, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, K, P, E, (const int*)b->d_perm, (const int*)b->d_pinv,
                      (const double*)b->d_raw_obs, (const double*)b->d_raw_inv, (const double*)b->d_raw_pts, b->d_e_obs, b->d_e_inv, b->d_pts0,
@@ -1661,6 +1667,165 @@ extern "C" int cms_ba_read(cms_ba* b, double* poses, double* points, uint8_t* ou
   else if (outlier_flags) {
     const uint8_t* f = reinterpret_cast<const uint8_t*>(h + o_flags);
     for (int i = 0; i < b->E; ++i) outlier_flags[b->perm[i]] = f[i];
+  }
+  return CMS_OK;
+}
+
+// ---- a window GROUP's set-up and read-back as one call each (round 6): what LocalMapping threads of many camera streams on one GPU do per step
+// (Optimizer.cpp:246-357 assembles one window; :419-450 writes one back).  The host parts of the n windows run on up to `threads` threads of the
+// call, the device parts of all device-planned windows are ONE launch per eight windows instead of one per window.
+static_assert(sizeof(BaExpandBatch) <= 4096 && sizeof(BaReadBatch) <= 4096, "the batches travel as kernel arguments");
+// standing host threads for the windows' host parts: threads that live for one call each would take the HIP runtime's per-thread state (and this
+// file's thread-local plan buffers) up and down sixteen times per step -- and the runtime's tear-down of short-lived threads corrupted the heap
+// under bench.py's load (glibc: double free, within a few steps)
+struct BaWorkers {
+  std::mutex mu; std::condition_variable cv;
+  std::deque<std::function<void()>> jobs;
+  int nthreads = 0;
+  void ensure(int n) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (; nthreads < std::min(n, 16); ++nthreads)
+      std::thread([this]() {
+        for (;;) {
+          std::function<void()> job;
+          { std::unique_lock<std::mutex> lk2(mu); cv.wait(lk2, [this]() { return !jobs.empty(); }); job = std::move(jobs.front()); jobs.pop_front(); }
+          job();
+        }
+      }).detach();
+  }
+  void post(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(f)); } cv.notify_one(); }
+};
+static BaWorkers& ba_workers() { static BaWorkers* w = new BaWorkers; return *w; }      // never destroyed: its threads wait for work until the process ends
+extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_window* w, int threads) {
+  if (!out || n < 0 || (n > 0 && !w)) return cms_fail(CMS_ERR_ARG, "cms_ba_create_many: bad argument");
+  for (int i = 0; i < n; ++i) out[i] = nullptr;
+  if (n == 0) return CMS_OK;
+  std::vector<BaExpand> xs((size_t)n);
+  std::vector<char> deferred((size_t)n, 0);
+  std::vector<int> rcs((size_t)n, CMS_OK);
+  std::vector<std::string> errs((size_t)n);
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      memset(&xs[(size_t)i], 0, sizeof(BaExpand));
+      ba_tl_defer_expand = &xs[(size_t)i];
+      rcs[(size_t)i] = cms_ba_create(&out[i], device, w[i].K, w[i].poses, w[i].fixed, w[i].P, w[i].points, w[i].E, w[i].e_pose, w[i].e_point, w[i].e_obs, w[i].e_invsig2,
+                                     w[i].e_face, w[i].fx, w[i].fy, w[i].cx, w[i].cy);
+      deferred[(size_t)i] = ba_tl_defer_expand == nullptr && rcs[(size_t)i] == CMS_OK;      // (taken: a device-planned window; a host-planned one launched its own set-up kernel)
+      ba_tl_defer_expand = nullptr;
+      if (rcs[(size_t)i] != CMS_OK) errs[(size_t)i] = cms_last_error();
+    }
+  };
+  {
+    const int T = std::max(1, std::min(threads > 0 ? threads : 4, n));
+    std::mutex dmu; std::condition_variable dcv; int running = T - 1;
+    if (T > 1) ba_workers().ensure(T - 1);
+    for (int t = 1; t < T; ++t)
+      ba_workers().post([&]() { work(); std::lock_guard<std::mutex> lk(dmu); if (--running == 0) dcv.notify_one(); });
+    work();
+    std::unique_lock<std::mutex> lk(dmu);
+    dcv.wait(lk, [&]() { return running == 0; });
+  }
+  auto fail_all = [&](int rc, const char* msg) {
+    for (int i = 0; i < n; ++i) if (out[i]) { cms_ba_destroy(out[i]); out[i] = nullptr; }
+    return cms_fail(rc, msg);
+  };
+  for (int i = 0; i < n; ++i) if (rcs[(size_t)i] != CMS_OK) return fail_all(rcs[(size_t)i], errs[(size_t)i].c_str());
+  // ---- the deferred expansions: batches of eight on the first window's stream, behind every window's upload; the other windows' streams then wait for it
+  std::vector<int> D;
+  for (int i = 0; i < n; ++i) if (deferred[(size_t)i]) D.push_back(i);
+  if (D.empty()) return CMS_OK;
+  if (hipSetDevice(device) != hipSuccess) return fail_all(CMS_ERR_HIP, "cms_ba_create_many: hipSetDevice");
+  for (size_t b0 = 0; b0 < D.size(); b0 += BA_EXPAND_BATCH) {
+    const int nb = (int)std::min<size_t>(BA_EXPAND_BATCH, D.size() - b0);
+    cms_ba* lead = out[D[b0]];
+    hipEvent_t ev = ba_event_take(device);
+    if (!ev) return fail_all(CMS_ERR_HIP, "cms_ba_create_many: no event");
+    BaExpandBatch batch;
+    int maxEP = 1;
+    hipError_t re = hipSuccess;
+    for (int k = 0; k < nb; ++k) {
+      cms_ba* b = out[D[b0 + k]];
+      batch.x[k] = xs[(size_t)D[b0 + k]];
+      maxEP = std::max(maxEP, std::max(b->E, b->P));
+      if (k > 0 && b->stream != lead->stream && re == hipSuccess) {      // the lead's stream waits for this window's upload
+        re = hipEventRecord(ev, b->stream);
+        if (re == hipSuccess) re = hipStreamWaitEvent(lead->stream, ev, 0);
+      }
+    }
+    for (int k = nb; k < BA_EXPAND_BATCH; ++k) batch.x[k] = batch.x[0];
+    if (re == hipSuccess) {
+      hipLaunchKernelGGL(k_ba_expand_edges_many, dim3(std::min((maxEP + 255) / 256, 1024), nb), dim3(256), 0, lead->stream, batch);
+      re = hipGetLastError();
+    }
+    if (re == hipSuccess && nb > 1) re = hipEventRecord(ev, lead->stream);
+    for (int k = 1; k < nb && re == hipSuccess; ++k) {
+      cms_ba* b = out[D[b0 + k]];
+      if (b->stream != lead->stream) re = hipStreamWaitEvent(b->stream, ev, 0);      // ... and whatever this window's stream does next comes behind the expansion
+    }
+    ba_event_give(device, ev);      // (a wait that is already enqueued keeps the record it saw)
+    if (re != hipSuccess) return fail_all(CMS_ERR_HIP, "cms_ba_create_many: launch failed");
+  }
+  return CMS_OK;
+}
+
+// poses / points / outlier flags of n optimised windows (any of the three arrays, or single entries of them, may be NULL): the device-planned windows'
+// results are gathered in the caller's order by ONE kernel per sixteen windows straight into their pinned blocks, one stream, one wait
+extern "C" int cms_ba_read_many(cms_ba** bas, int n, double** poses, double** points, uint8_t** outlier_flags) {
+  if (n < 0 || (n > 0 && !bas)) return cms_fail(CMS_ERR_ARG, "cms_ba_read_many: bad argument");
+  for (int i = 0; i < n; ++i) if (!bas[i]) return cms_fail(CMS_ERR_ARG, "cms_ba_read_many: null window");
+  std::vector<int> F;      // windows the batched kernel takes: device-planned, results complete (nothing pending on a stream of their own), one device
+  for (int i = 0; i < n; ++i) {
+    cms_ba* b = bas[i];
+    const size_t o_pts = ((size_t)7 * b->K * 8 + 255) & ~(size_t)255, o_flags = o_pts + (((size_t)3 * b->P * 8 + 255) & ~(size_t)255);
+    const bool ok = b->fast_plan && b->device == bas[0]->device && b->h_stage && b->h_stage_bytes >= o_flags + (size_t)b->E && !b->setup_wait_pending &&
+                    !(b->own_stream && b->async_pending);
+    if (ok) F.push_back(i);
+    else {
+      const int rc = cms_ba_read(b, poses ? poses[i] : nullptr, points ? points[i] : nullptr, outlier_flags ? outlier_flags[i] : nullptr);
+      if (rc) return rc;
+    }
+  }
+  if (F.empty()) return CMS_OK;
+  const int device = bas[F[0]]->device;
+  HIPCHK(hipSetDevice(device));
+  // windows on a shared stream with work of their group still pending there are ordered by that stream; everything else reads on a pooled stream
+  hipStream_t rs = nullptr; bool temp = false;
+  for (int i : F) if (bas[i]->async_pending) rs = bas[i]->stream;
+  if (rs) { for (int i : F) if (bas[i]->async_pending && bas[i]->stream != rs) HIPCHK(ba_wait_stream(bas[i]->stream)); }
+  else { rs = ba_stream_take(device); if (!rs) HIPCHK(hipStreamCreateWithFlags(&rs, hipStreamNonBlocking)); temp = true; }
+  hipError_t re = hipSuccess;
+  for (size_t b0 = 0; b0 < F.size() && re == hipSuccess; b0 += BA_READ_BATCH) {
+    const int nb = (int)std::min<size_t>(BA_READ_BATCH, F.size() - b0);
+    BaReadBatch batch;
+    int work = 1;
+    for (int k = 0; k < nb; ++k) {
+      const int i = F[b0 + k];
+      cms_ba* b = bas[i];
+      const size_t o_pts = ((size_t)7 * b->K * 8 + 255) & ~(size_t)255, o_flags = o_pts + (((size_t)3 * b->P * 8 + 255) & ~(size_t)255);
+      BaReadJob& q = batch.j[k];
+      q.K = b->K; q.P = b->P; q.E = b->E; q.prank = b->d_prank; q.iperm = b->d_iperm; q.poses = b->d_poses[b->cur]; q.pts = b->d_pts[b->cur]; q.flags = b->d_flags;
+      q.out_poses = (poses && poses[i]) ? reinterpret_cast<double*>(b->h_stage) : nullptr;
+      q.out_pts = (points && points[i]) ? reinterpret_cast<double*>(b->h_stage + o_pts) : nullptr;
+      q.out_flags = (outlier_flags && outlier_flags[i]) ? reinterpret_cast<uint8_t*>(b->h_stage + o_flags) : nullptr;
+      work = std::max(work, std::max(b->E / 4, 3 * b->P));
+    }
+    for (int k = nb; k < BA_READ_BATCH; ++k) batch.j[k] = batch.j[0];
+    hipLaunchKernelGGL(k_ba_results_to_host_many, dim3(std::min((work + 255) / 256, 256), nb), dim3(256), 0, rs, batch);
+    re = hipGetLastError();
+  }
+  if (re == hipSuccess) re = ba_wait_stream(rs);
+  if (temp) ba_stream_give(device, rs);
+  HIPCHK(re);
+  for (int i : F) {
+    cms_ba* b = bas[i];
+    const size_t o_pts = ((size_t)7 * b->K * 8 + 255) & ~(size_t)255, o_flags = o_pts + (((size_t)3 * b->P * 8 + 255) & ~(size_t)255);
+    b->async_pending = false;
+    if (poses && poses[i]) memcpy(poses[i], b->h_stage, 7 * (size_t)b->K * sizeof(double));
+    if (points && points[i]) memcpy(points[i], b->h_stage + o_pts, 3 * (size_t)b->P * sizeof(double));
+    if (outlier_flags && outlier_flags[i]) memcpy(outlier_flags[i], b->h_stage + o_flags, (size_t)b->E);
   }
   return CMS_OK;
 }

@@ -118,8 +118,19 @@ __host__ __device__ inline void ba_expand_table_at(const BaExpand& x, int u) {
     for (int i = 0; i < 24; ++i) x.run_fg[((size_t)r * 64 + l) * 24 + i] = ba_run_fg_word(rs, x.np, l, i);
 }
 
+// the windows of ONE cms_ba_create_many call expanded by one launch: blockIdx.y = window (a window group's sixteen set-ups were sixteen launches of
+// ~19 us each that waited up to 1.8 ms for a queue slot behind the Levenberg rounds inside bench.py's step).  Eight descriptions fit the 4 KB of
+// kernel arguments; a larger group is two launches
+#define BA_EXPAND_BATCH 8
+struct BaExpandBatch { BaExpand x[BA_EXPAND_BATCH]; };
+__device__ __forceinline__ void ba_expand_body(const BaExpand& x, int t0, int gs);
+extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges_many(BaExpandBatch b) {
+  ba_expand_body(b.x[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges(BaExpand x) {
-  const int gs = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  ba_expand_body(x, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+__device__ __forceinline__ void ba_expand_body(const BaExpand& x, int t0, int gs) {
   for (int i = t0; i < x.E; i += gs) ba_expand_edge_at(x, i);
   for (int u = t0; u < 64 * x.n_runs; u += gs) ba_expand_table_at(x, u);
   for (int i = t0; i < x.P; i += gs) {
@@ -149,6 +160,26 @@ k_ba_results_to_host(int K, int P, int E, const int* __restrict__ prank, const i
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const int e = 4 * i4 + j; if (e < E) w |= (uint32_t)flags[iperm[e]] << (8 * j); }
       reinterpret_cast<uint32_t*>(out_flags)[i4] = w;
+    }
+}
+
+// ... and the read-back of several windows in one launch (cms_ba_read_many): blockIdx.y = window
+struct BaReadJob { int K, P, E; const int* prank; const int* iperm; const double* poses; const double* pts; const uint8_t* flags; double* out_poses; double* out_pts; uint8_t* out_flags; };
+#define BA_READ_BATCH 16
+struct BaReadBatch { BaReadJob j[BA_READ_BATCH]; };
+extern "C" __global__ void __launch_bounds__(256) k_ba_results_to_host_many(BaReadBatch b) {
+  const BaReadJob& q = b.j[blockIdx.y];
+  const int gs = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q.out_poses)
+    for (int i = t0; i < 7 * q.K; i += gs) q.out_poses[i] = q.poses[i];
+  if (q.out_pts)
+    for (int i = t0; i < 3 * q.P; i += gs) { const int p = i / 3, j = i - 3 * p; q.out_pts[i] = q.pts[3 * (size_t)q.prank[p] + j]; }
+  if (q.out_flags)
+    for (int i4 = t0; 4 * i4 < q.E; i4 += gs) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int e = 4 * i4 + j; if (e < q.E) w |= (uint32_t)q.flags[q.iperm[e]] << (8 * j); }
+      reinterpret_cast<uint32_t*>(q.out_flags)[i4] = w;
     }
 }
 

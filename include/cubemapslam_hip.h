@@ -167,6 +167,19 @@ typedef struct {
 int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const uint8_t* fixed, int P, const double* points,
                   int E, const int* e_pose, const int* e_point, const double* e_obs, const double* e_invsig2,
                   const int8_t* e_face, double fx, double fy, double cx, double cy);
+/* The set-up of a window GROUP in one call (round 6): n windows as an array of descriptions (cms_ba_create's arguments).  The host parts run on up to
+ * `threads` threads of the call (0: four), the set-up kernels of all device-planned windows are one launch per eight windows instead of one each --
+ * a process that tracks many camera streams per GPU creates a group's sixteen windows per step (what Optimizer::LocalBundleAdjustment assembles once
+ * per key frame, Optimizer.cpp:246-357).  On any error every window of the call is destroyed and out[] is all NULL.  The windows are independent
+ * afterwards (cms_ba_set_stream, cms_ba_optimize_many, cms_ba_read / cms_ba_read_many, cms_ba_destroy each). */
+typedef struct cms_ba_window {
+  int K; const double* poses; const uint8_t* fixed; int P; const double* points; int E; const int* e_pose; const int* e_point;
+  const double* e_obs; const double* e_invsig2; const int8_t* e_face; double fx, fy, cx, cy;
+} cms_ba_window;
+int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_window* windows, int threads);
+/* ... and the read-back of n optimised windows (Optimizer.cpp:419-450): poses[i] / points[i] / outlier_flags[i] as cms_ba_read's (the arrays of
+ * pointers, or single entries, may be NULL); one gather kernel per sixteen device-planned windows, one wait. */
+int cms_ba_read_many(cms_ba** bas, int n, double** poses, double** points, uint8_t** outlier_flags);
 int cms_ba_reset(cms_ba* ba);  /* restore the initial estimate on the device (benchmark loops) */
 int cms_ba_optimize(cms_ba* ba, int its_robust, int its_final, const volatile uint8_t* stop, cms_ba_stats* stats);
 /* n independent windows (e.g. the LocalMapping threads of n camera streams) advanced in lock-step by ONE host thread, each on

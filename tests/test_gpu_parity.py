@@ -1370,6 +1370,42 @@ def test_ba_device_plan_equals_host_plan(shuffle):
     ba.close()
 
 
+def test_ba_create_many_and_read_many_equal_the_single_window_calls():
+    """A window group's set-up and read-back as one call each (cms_ba_create_many: host parts on several threads, ONE expansion launch per eight
+    device-planned windows; cms_ba_read_many: one gather launch): the device arrays of every window must be byte-identical to those of the same window
+    created on its own -- four tracked windows (device-planned, one of them with shuffled edges) and one window with random views (the host planner's,
+    which sets itself up) in the same call --, the group optimises to the oracle's results, and the batched read-back returns what cms_ba_read returns.
+    (What one Optimizer::LocalBundleAdjustment call assembles and writes back: Optimizer.cpp:246-357, 419-450.)"""
+    probs = [synth.ba_problem(K=20, P=6000 + 500 * i, obs_per_point=4, F=550, seed=70 + i, views="track") for i in range(4)]
+    o = np.random.default_rng(5).permutation(len(probs[2]["e_pose"]))
+    probs[2] = dict(probs[2], **{k: np.ascontiguousarray(probs[2][k][o]) for k in ("e_pose", "e_point", "e_obs", "e_invsig2", "e_face")})
+    probs.append(synth.ba_problem(K=12, P=2500, obs_per_point=4, F=550, seed=75, views="random"))
+    many = api.ba_create_many(probs, threads=3)
+    keys = ("pinv", "perm", "info", "pt_off", "e_pose", "e_point", "e_face", "chunk_e0", "rm_chunk", "rm_cost", "run_mf", "run_fl")
+    for i, p in enumerate(probs):
+        one = api.BundleAdjuster(p)
+        a, b = many[i].fetch_plan(), one.fetch_plan()
+        assert a["device_planned"] == b["device_planned"] == (i < 4), i
+        for k in keys:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (i, k)
+        one.close()
+    # the four device-planned windows as a group (one kind per cms_ba_optimize_many group), the host-planned one on its own
+    _, stats = api.ba_optimize_many(many[:4], (5, 10))
+    _, st4 = many[4].optimize()
+    stats = list(stats) + [st4]
+    outs = api.ba_read_many(many)
+    for i, p in enumerate(probs):
+        poses, pts, flags = many[i].read()
+        assert np.array_equal(outs[i][0], poses) and np.array_equal(outs[i][1], pts) and np.array_equal(outs[i][2], flags), i
+        _check_window(i, many[i], p, stats[i], tag="create_many")
+    for b in many:
+        b.close()
+    # an error in one window leaves nothing behind
+    bad = dict(probs[1]); bad["e_pose"] = probs[1]["e_pose"].copy(); bad["e_pose"][7] = 99
+    with pytest.raises(api.CmsError):
+        api.ba_create_many([probs[0], bad, probs[3]], threads=2)
+
+
 def _check_window(i, ba, p, st, w=None, tag="window"):
     poses, pts, flags = ba.read()
     w = w or orc.ba_run(p)

@@ -2,7 +2,7 @@
 # developer helper (run on the GPU box through gpurun): bench.py with the given extra args, one line of key numbers
 # usage: tools/gb.sh <tag> [bench args...]       env is inherited (A/B knobs)
 tag=$1; shift
-python bench.py --steps 20 --warmup 5 --cpu-frames 0 --no-streaming-pass --verify-windows 0 --optimise-only-steps 0 --closed-loop-frames 0 "$@" > gpurun_out/gb_$tag.log 2>&1
+python bench.py --steps 20 --warmup 5 --cpu-frames 0 --no-streaming-pass --verify-windows 0 --optimise-only-steps 0 --closed-loop-frames 0 --confined-steps 0 "$@" > gpurun_out/gb_$tag.log 2>&1
 python - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]

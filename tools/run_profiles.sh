@@ -15,7 +15,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0 --deterministic-steps 0 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python $R/bench.py --steps 10 --warmup 2 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0 --deterministic-steps 0 --confined-steps 0 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 # the same trace, condensed to (kernel, start, end, queue, stream): input of tools/step_table.py (per-step chip-time table)
 python - "$OUT/${TAG}_bench_kernel_trace.csv" "$OUT/${TAG}_trace_small.csv" <<'PY'
 import csv, sys
