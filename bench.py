@@ -1414,6 +1414,9 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.confined_steps), "--warmup", "3", "--cpu-frames", "0", "--no-streaming-pass", "--verify-windows", "0",
                "--extract-only-steps", "0", "--random-views-steps", "0", "--optimise-only-steps", "0", "--unpipelined-steps", "0", "--deterministic-steps", "0",
                "--mapping-only-steps", "0", "--closed-loop-frames", "0", "--confined-steps", "0", "--camera", args.camera, "--batch", str(args.batch), "--ba-every", str(args.ba_every)]
+        import shutil
+        if shutil.which("taskset"):      # the whole child process from its first instruction on (threads that exist before main() runs keep their own mask otherwise)
+            cmd = ["taskset", "-c", env["CMS_BENCH_AFFINITY"]] + cmd
         t0_ = time.perf_counter()
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)

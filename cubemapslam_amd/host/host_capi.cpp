@@ -265,6 +265,43 @@ extern "C" int hm_create_new_map_points(int nkf, const int* feat_off, const cms_
     }
     return n;)
 }
+// ORBMatcher::Fuse through the mirror (ORBMatcher.cpp:1127-1244): the key frame as flat arrays (n key points, descriptors, the map-point slot per key
+// point: in / out), M map points (position, normal, distance range, descriptor, id), skip[M] (pMP->isBad() / IsInKeyFrame, may be NULL).  fused[M] = the
+// key point every map point is fused with or -1; mp_slots receives the ADDITIONS (AddMapPoint for a free key point, in list order); for a key point
+// that already holds a point the caller decides the Replace by Observations() like the reference does.  Returns nFused.
+extern "C" int hm_fuse(int n, const cms_keypoint* kps, const uint8_t* desc, long* mp_slots, float* Tcw, int M, const float* pos, const float* normal,
+                       const float* min_dist, const float* max_dist, const uint8_t* mp_desc, const long* mp_id, const uint8_t* skip, float th, int* fused) {
+  HM_TRY(
+    KeyFrameView v;
+    v.mnId = 0; v.mvKeys.resize(n); v.mvpMapPoints.assign(mp_slots, mp_slots + n);
+    v.mDescriptors.create(n > 0 ? n : 1, 32, cv::CV_8U);
+    for (int i = 0; i < n; ++i) {
+      v.mvKeys[i].pt = cv::Point2f(kps[i].x, kps[i].y); v.mvKeys[i].angle = kps[i].angle; v.mvKeys[i].octave = kps[i].octave;
+      v.mvKeys[i].size = kps[i].size; v.mvKeys[i].response = kps[i].response;
+      std::memcpy(v.mDescriptors.ptr<uint8_t>(i), desc + 32 * (size_t)i, 32);
+    }
+    v.Tcw = cv::Mat(4, 4, cv::CV_32F, Tcw, 16);
+    std::vector<MapPointView> mps(M);
+    std::vector<float> store(6 * (size_t)std::max(M, 1));
+    std::vector<uint8_t> dstore(32 * (size_t)std::max(M, 1));
+    for (int i = 0; i < M; ++i) {
+      for (int c = 0; c < 3; ++c) { store[6 * (size_t)i + c] = pos[3 * (size_t)i + c]; store[6 * (size_t)i + 3 + c] = normal[3 * (size_t)i + c]; }
+      std::memcpy(&dstore[32 * (size_t)i], mp_desc + 32 * (size_t)i, 32);
+      mps[i].mnId = mp_id[i];
+      mps[i].mWorldPos = cv::Mat(3, 1, cv::CV_32F, &store[6 * (size_t)i], 4);
+      mps[i].mNormalVector = cv::Mat(3, 1, cv::CV_32F, &store[6 * (size_t)i + 3], 4);
+      mps[i].mfMinDistance = min_dist[i]; mps[i].mfMaxDistance = max_dist[i];
+      mps[i].mDescriptor = cv::Mat(1, 32, cv::CV_8U, &dstore[32 * (size_t)i], 32);
+    }
+    std::vector<uint8_t> sk;
+    if (skip) sk.assign(skip, skip + M);
+    std::vector<int> f;
+    ORBMatcher matcher;
+    const int nf = matcher.Fuse(v, mps, sk, th, f);
+    for (int i = 0; i < M; ++i) fused[i] = f[i];
+    for (int i = 0; i < n; ++i) mp_slots[i] = v.mvpMapPoints[i];
+    return nf;)
+}
 // local BA through the Optimizer mirror.  Tcw: K x 16 float (row major 4x4), Xw: P x 3 float, observations flat.
 extern "C" int hm_local_ba(int K, float* Tcw, const long* kf_id, const uint8_t* kf_fixed, const float* inv_sigma2, int nlevels, int P,
                            float* Xw, int nobs, const int* obs_kf, const int* obs_mp, const cms_keypoint* obs_kp, const float* obs_ray,

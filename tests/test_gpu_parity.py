@@ -315,7 +315,9 @@ def _ba_updates_close_or_cascade(prob, poses, pts, w, tol=1e-4, tag=""):
     return float(r_prod.max()), True
 
 
-def _ba_compare(prob, tol=1e-4):
+def _ba_compare(prob, tol=1e-4, count_cascade=None):
+    """count_cascade: a list; the window is then held to the cascade-aware bar (_ba_updates_close_or_cascade) and whether it cascaded is appended --
+    a window known to cascade at float-rounding level is COUNTED by its test, not replaced by a tamer seed"""
     g = api.ba_run(prob)
     w = orc.ba_run(prob)
     assert g["rc"] == 0 and w["rc"] == 0
@@ -323,7 +325,11 @@ def _ba_compare(prob, tol=1e-4):
     assert list(gs.iterations_done) == list(ws.iterations_done), (list(gs.iterations_done), list(ws.iterations_done))
     for i in range(2):
         assert abs(gs.chi2_final[i] - ws.chi2_final[i]) <= 1e-6 * abs(ws.chi2_final[i])
-    _ba_updates_close(prob, g["poses"], g["points"], w, tol)
+    if count_cascade is None:
+        _ba_updates_close(prob, g["poses"], g["points"], w, tol)
+    else:
+        worst, cascaded = _ba_updates_close_or_cascade(prob, g["poses"], g["points"], w, tol, tag="K %d P %d" % (len(prob["poses"]), len(prob["points"])))
+        count_cascade.append((cascaded, worst))
     assert np.array_equal(g["outliers"], w["outliers"])
     return g, w
 
@@ -343,7 +349,14 @@ def test_ba_run_larger_windows_all_solver_paths():
     (global-memory fallback)."""
     _ba_compare(synth.ba_problem(K=25, P=1500, obs_per_point=5, F=550, seed=3))
     # the three-lane solve's limits: 25 free key frames (16 wavefronts of 21 blocks, 150 unknowns = the back substitution's third register) and one
-    _ba_compare(synth.ba_problem(K=26, P=1500, obs_per_point=5, F=550, seed=16))     # (seed 6 is one of the windows whose points cascade at rounding level, DESIGN.md section 2: 16 of 1500 points at 2e-4, with round 4's solve kernel as well)
+    _ba_compare(synth.ba_problem(K=26, P=1500, obs_per_point=5, F=550, seed=16))
+    # ... and seed 6 of the same shape: one of the windows whose POINTS cascade at float-rounding level between product and oracle (DESIGN.md section 2:
+    # 16 of 1500 points at 2e-4 with every solve kernel since round 4).  It is held to the cascade-aware bar -- key frames within 1e-4 per block as
+    # always, points no worse than the oracle against itself under a 1e-12 m perturbation -- and COUNTED here, not avoided
+    counted = []
+    _ba_compare(synth.ba_problem(K=26, P=1500, obs_per_point=5, F=550, seed=6), count_cascade=counted)
+    assert len(counted) == 1, "the K = 26, seed 6 window was not checked"
+    print("K = 26, seed 6: %s, worst relative point-update error %.3g (counted, not excused)" % ("CASCADED at float-rounding level" if counted[0][0] else "within 1e-4", counted[0][1]))
     _ba_compare(synth.ba_problem(K=2, P=120, obs_per_point=2, F=550, seed=7))
     _ba_compare(synth.ba_problem(K=30, P=2000, obs_per_point=5, F=550, seed=5))
     _ba_compare(synth.ba_problem(K=40, P=2500, obs_per_point=6, F=550, seed=4))
