@@ -253,4 +253,201 @@ void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
     mps[i]->UpdateNormalAndDepth();
   }
 }
+
+// ------------------------------------------------------------------------------------------------ LocalMapping on resident key frames
+namespace {
+struct StoreBook { std::map<KeyFrame*, int> slot; std::vector<int> free_slots; int max_features = 0; };
+std::map<cms_kfstore*, StoreBook> g_books;
+std::mutex g_books_mutex;
+StoreBook& book(cms_kfstore* st) { std::lock_guard<std::mutex> lk(g_books_mutex); return g_books[st]; }
+int slot_of(StoreBook& b, KeyFrame* k) { const auto it = b.slot.find(k); return it == b.slot.end() ? -1 : it->second; }
+void pose_floats(KeyFrame* k, float* R9, float* t3, float* O3) {
+  const cv::Mat R = k->GetRotation(), t = k->GetTranslation(), O = k->GetCameraCenter();
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R9[3 * r + c] = R.at<float>(r, c); t3[r] = t.at<float>(r); O3[r] = O.at<float>(r); }
+}
+// the map-point slot per key point as the device holds it: >= 0 where the key point holds a point that is not bad (the id only has to be >= 0)
+void mp_slots(KeyFrame* k, std::vector<int>& mp) {
+  const std::vector<MapPoint*> v = k->GetMapPointMatches();
+  mp.assign(v.size(), -1);
+  for (size_t i = 0; i < v.size(); ++i) if (v[i] && !v[i]->isBad()) mp[i] = (int)(v[i]->mnId & 0x3FFFFFFF);
+}
+// a map point as the Fuse search reads it (ORBMatcher.cpp:1140-1175)
+void push_point(MapPoint* p, std::vector<float>& pos, std::vector<float>& nrm, std::vector<float>& dmin, std::vector<float>& dmax, std::vector<uint8_t>& desc) {
+  const cv::Mat x = p->GetWorldPos(), n = p->GetNormal(), d = p->GetDescriptor();
+  for (int k = 0; k < 3; ++k) { pos.push_back(x.at<float>(k)); nrm.push_back(n.at<float>(k)); }
+  dmin.push_back(p->GetMinDistanceInvariance()); dmax.push_back(p->GetMaxDistanceInvariance());      // (the store's context runs in distance-bounds mode 1, see CreateContext)
+  desc.insert(desc.end(), d.data, d.data + 32);
+}
+}  // namespace
+
+cms_kfstore* CreateKeyFrameStore(cms_ctx* mappingCtx, int maxKeyFrames, int maxFeatures) {
+  cms_kfstore* st = nullptr;
+  check(cms_kfstore_create(&st, mappingCtx, maxKeyFrames, maxFeatures, 4096), "cms_kfstore_create");
+  StoreBook& b = book(st);
+  b.max_features = maxFeatures;
+  for (int s = maxKeyFrames - 1; s >= 0; --s) b.free_slots.push_back(s);
+  return st;
+}
+
+int ProcessNewKeyFrame(cms_kfstore* store, cms_ctx* frameCtx, KeyFrame* pKF) {
+  StoreBook& b = book(store);
+  int slot = slot_of(b, pKF);
+  if (slot < 0) {
+    if (b.free_slots.empty()) throw std::runtime_error("Hip::ProcessNewKeyFrame: the key-frame store is full");
+    slot = b.free_slots.back(); b.free_slots.pop_back(); b.slot[pKF] = slot;
+  }
+  // mFeatVec (KeyFrame::ComputeBoW, LocalMapping.cpp:62): node id -> feature indices, std::map order
+  std::vector<int> node_id, node_off(1, 0), node_feat, mp;
+  for (const auto& nf : pKF->mFeatVec) {
+    node_id.push_back((int)nf.first);
+    for (unsigned f : nf.second) node_feat.push_back((int)f);
+    node_off.push_back((int)node_feat.size());
+  }
+  mp_slots(pKF, mp);
+  float R[9], t[3], O[3];
+  pose_floats(pKF, R, t, O);
+  check(cms_kfstore_put_from_frame(store, slot, frameCtx, 0, pKF->N, R, t, O, pKF->ComputeSceneMedianDepth(2), mp.data(), (int)node_id.size(), node_id.data(),
+                                   node_off.data(), node_feat.data()), "cms_kfstore_put_from_frame");
+  return slot;
+}
+
+void ReleaseKeyFrame(cms_kfstore* store, KeyFrame* pKF) {
+  StoreBook& b = book(store);
+  const auto it = b.slot.find(pKF);
+  if (it == b.slot.end()) return;
+  b.free_slots.push_back(it->second);
+  b.slot.erase(it);
+}
+
+int CreateNewMapPoints(cms_kfstore* store, KeyFrame* pCurrentKF, Map* pMap, std::vector<MapPoint*>& newPoints) {
+  StoreBook& b = book(store);
+  const int cur = slot_of(b, pCurrentKF);
+  if (cur < 0) throw std::runtime_error("Hip::CreateNewMapPoints: the current key frame is not resident (Hip::ProcessNewKeyFrame first)");
+  std::vector<KeyFrame*> neigh;                                    // GetBestCovisibilityKeyFrames(20), the resident ones, in covisibility order
+  std::vector<int> neigh_slot;
+  for (KeyFrame* k : pCurrentKF->GetBestCovisibilityKeyFrames(20)) {
+    const int s = slot_of(b, k);
+    if (s < 0 || k->isBad()) continue;
+    // poses, median depths and map-point slots may have changed since the key frame entered the store (local BA, Fuse, culling)
+    float R[9], t[3], O[3]; std::vector<int> mp;
+    pose_floats(k, R, t, O); mp_slots(k, mp);
+    const float md = k->ComputeSceneMedianDepth(2);
+    check(cms_kfstore_update(store, s, R, t, O, &md, mp.data()), "cms_kfstore_update");
+    neigh.push_back(k); neigh_slot.push_back(s);
+  }
+  {
+    float R[9], t[3], O[3]; std::vector<int> mp;
+    pose_floats(pCurrentKF, R, t, O); mp_slots(pCurrentKF, mp);
+    check(cms_kfstore_update(store, cur, R, t, O, nullptr, mp.data()), "cms_kfstore_update");
+  }
+  if (neigh.empty()) return 0;
+  const int cap = pCurrentKF->N;
+  const int neigh_off[2] = {0, (int)neigh.size()};
+  int n_new = 0;
+  std::vector<int> o_neigh(cap), o_idx1(cap), o_idx2(cap);
+  std::vector<float> o_x((size_t)cap * 3);
+  check(cms_kfstore_create_new_map_points(store, 1, &cur, neigh_off, neigh_slot.data(), 0, cap, &n_new, o_neigh.data(), o_idx1.data(), o_idx2.data(), o_x.data()),
+        "cms_kfstore_create_new_map_points");
+  for (int i = 0; i < n_new; ++i) {                                // LocalMapping.cpp:359-381, in the reference's creation order
+    KeyFrame* pKF2 = neigh[o_neigh[i]];
+    cv::Mat x3D(3, 1, CV_32F);
+    for (int k = 0; k < 3; ++k) x3D.at<float>(k) = o_x[(size_t)i * 3 + k];
+    MapPoint* pMP = new MapPoint(x3D, pCurrentKF, pMap);
+    pMP->AddObservation(pCurrentKF, o_idx1[i]);
+    pMP->AddObservation(pKF2, o_idx2[i]);
+    pCurrentKF->AddMapPoint(pMP, o_idx1[i]);
+    pKF2->AddMapPoint(pMP, o_idx2[i]);
+    pMP->ComputeDistinctiveDescriptors();
+    pMP->UpdateNormalAndDepth();
+    pMap->AddMapPoint(pMP);
+    newPoints.push_back(pMP);
+  }
+  return n_new;
+}
+
+void SearchInNeighbors(cms_kfstore* store, KeyFrame* pCurrentKF) {
+  StoreBook& b = book(store);
+  const int cur = slot_of(b, pCurrentKF);
+  if (cur < 0) throw std::runtime_error("Hip::SearchInNeighbors: the current key frame is not resident");
+  // ---- target key frames: neighbours and second neighbours (LocalMapping.cpp:391-412), the resident ones
+  std::vector<KeyFrame*> targets;
+  for (KeyFrame* k : pCurrentKF->GetBestCovisibilityKeyFrames(20)) {
+    if (k->isBad() || k->mnFuseTargetForKF == pCurrentKF->mnId) continue;
+    targets.push_back(k);
+    k->mnFuseTargetForKF = pCurrentKF->mnId;
+    for (KeyFrame* k2 : k->GetBestCovisibilityKeyFrames(5)) {
+      if (k2->isBad() || k2->mnFuseTargetForKF == pCurrentKF->mnId || k2->mnId == pCurrentKF->mnId) continue;
+      targets.push_back(k2);
+    }
+  }
+  std::vector<KeyFrame*> tk;
+  for (KeyFrame* k : targets) if (slot_of(b, k) >= 0) tk.push_back(k);
+  if (tk.empty()) return;
+  // ---- set 0: the current key frame's map points (into every target); set 1: the targets' map points, first appearance (into the current key frame)
+  std::vector<MapPoint*> set0, set1;
+  for (MapPoint* p : pCurrentKF->GetMapPointMatches()) if (p) set0.push_back(p);            // (ORBMatcher::Fuse skips null / bad points itself: the skip flags below)
+  for (KeyFrame* k : tk)
+    for (MapPoint* p : k->GetMapPointMatches()) {
+      if (!p || p->isBad() || p->mnFuseCandidateForKF == pCurrentKF->mnId) continue;        // LocalMapping.cpp:432-447
+      p->mnFuseCandidateForKF = pCurrentKF->mnId;
+      set1.push_back(p);
+    }
+  std::vector<float> pos, nrm, dmin, dmax;
+  std::vector<uint8_t> desc;
+  for (MapPoint* p : set0) push_point(p, pos, nrm, dmin, dmax, desc);
+  for (MapPoint* p : set1) push_point(p, pos, nrm, dmin, dmax, desc);
+  const int set_off[3] = {0, (int)set0.size(), (int)(set0.size() + set1.size())};
+  // ---- jobs: set 0 into every target, set 1 into the current key frame; an entry is skipped like ORBMatcher.cpp:1143-1147 skips it
+  std::vector<int> job_slot, job_set;
+  std::vector<uint8_t> skip;
+  for (KeyFrame* k : tk) {
+    job_slot.push_back(slot_of(b, k)); job_set.push_back(0);
+    for (MapPoint* p : set0) skip.push_back((p->isBad() || p->IsInKeyFrame(k)) ? 1 : 0);
+  }
+  job_slot.push_back(cur); job_set.push_back(1);
+  for (MapPoint* p : set1) skip.push_back((p->isBad() || p->IsInKeyFrame(pCurrentKF)) ? 1 : 0);
+  // the searched key frames' map-point slots as they are NOW (the search only needs the key points; the decisions below read the live objects)
+  std::vector<int> best_idx(skip.size()), best_dist(skip.size());
+  check(cms_kfstore_fuse_search_sets(store, 2, set_off, pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(), (int)job_slot.size(), job_slot.data(),
+                                     job_set.data(), skip.data(), 3.0f, best_idx.data(), best_dist.data()), "cms_kfstore_fuse_search_sets");
+  // ---- the decisions, job after job and point after point in the reference's order (ORBMatcher.cpp:1213-1236).  A point that an earlier job of this
+  // call added to / replaced in a later job's key frame is re-checked here exactly like the reference's sequential Fuse calls would see it
+  size_t e = 0;
+  for (size_t j = 0; j < job_slot.size(); ++j) {
+    KeyFrame* pKF = j < tk.size() ? tk[j] : pCurrentKF;
+    const std::vector<MapPoint*>& pts = j < tk.size() ? set0 : set1;
+    for (size_t i = 0; i < pts.size(); ++i, ++e) {
+      MapPoint* pMP = pts[i];
+      if (best_idx[e] < 0 || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+      MapPoint* pMPinKF = pKF->GetMapPoint(best_idx[e]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) {
+          if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+          else pMPinKF->Replace(pMP);
+        }
+      } else {
+        pMP->AddObservation(pKF, best_idx[e]);
+        pKF->AddMapPoint(pMP, best_idx[e]);
+      }
+    }
+  }
+  // ---- update points and connections (LocalMapping.cpp:449-465)
+  for (MapPoint* p : pCurrentKF->GetMapPointMatches())
+    if (p && !p->isBad()) { p->ComputeDistinctiveDescriptors(); p->UpdateNormalAndDepth(); }
+  pCurrentKF->UpdateConnections();
+}
+
+void UpdateKeyFramePoses(cms_kfstore* store, const std::vector<KeyFrame*>& vpKFs) {
+  StoreBook& b = book(store);
+  std::vector<int> slots;
+  std::vector<float> R, t, O;
+  for (KeyFrame* k : vpKFs) {
+    const int s = slot_of(b, k);
+    if (s < 0) continue;
+    float r9[9], t3[3], o3[3];
+    pose_floats(k, r9, t3, o3);
+    slots.push_back(s); R.insert(R.end(), r9, r9 + 9); t.insert(t.end(), t3, t3 + 3); O.insert(O.end(), o3, o3 + 3);
+  }
+  if (!slots.empty()) check(cms_kfstore_update_poses(store, (int)slots.size(), slots.data(), R.data(), t.data(), O.data()), "cms_kfstore_update_poses");
+}
 }  // namespace Hip

@@ -36,5 +36,25 @@ int SearchLocalPoints(cms_ctx* ctx, Frame& F, const std::vector<MapPoint*>& vpMa
 int PoseOptimization(Frame* pFrame);
 // Optimizer::LocalBundleAdjustment (Optimizer.cpp:192-451)
 void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap);
+
+// ---- LocalMapping's per-key-frame sequence on key frames RESIDENT on the device (cms_kfstore_*).  The store maps KeyFrame* -> slot; a key frame enters
+// it once (ProcessNewKeyFrame), its pose and map-point slots are refreshed where the reference changes them, and it leaves with ReleaseKeyFrame
+// (KeyFrame::SetBadFlag / the end of the map).
+cms_kfstore* CreateKeyFrameStore(cms_ctx* mappingCtx, int maxKeyFrames, int maxFeatures);
+// LocalMapping::ProcessNewKeyFrame's device half (LocalMapping.cpp:52-117; the KeyFrame constructor's copy of the frame, KeyFrame.cpp:29-55): the frame
+// `frameCtx` extracted last (slot 0 of its batch, FrameGrid already called) becomes pKF's resident copy -- key points, descriptors, key rays and grid
+// device to device, mFeatVec (pKF->ComputeBoW() must have run) and the map-point slots from the host.  Returns the slot.
+int ProcessNewKeyFrame(cms_kfstore* store, cms_ctx* frameCtx, KeyFrame* pKF);
+void ReleaseKeyFrame(cms_kfstore* store, KeyFrame* pKF);
+// the body of LocalMapping::CreateNewMapPoints (LocalMapping.cpp:209-386) for mpCurrentKeyFrame and its GetBestCovisibilityKeyFrames(20): the search,
+// triangulation and every test on the device, the MapPoint bookkeeping (:359-381) here; newPoints receives what the reference pushes to
+// mlpRecentAddedMapPoints.  Returns nnew.
+int CreateNewMapPoints(cms_kfstore* store, KeyFrame* pCurrentKF, Map* pMap, std::vector<MapPoint*>& newPoints);
+// the body of LocalMapping::SearchInNeighbors (LocalMapping.cpp:388-466): both Fuse directions as ONE device call (every set of map points uploaded
+// once), then ORBMatcher::Fuse's Replace / AddObservation decisions in the reference's order (ORBMatcher.cpp:1213-1236) and the update of the
+// current key frame's points and connections (:449-465)
+void SearchInNeighbors(cms_kfstore* store, KeyFrame* pCurrentKF);
+// after Optimizer::LocalBundleAdjustment's write-back (Optimizer.cpp:419-431): the resident copies of the local key frames get their new poses
+void UpdateKeyFramePoses(cms_kfstore* store, const std::vector<KeyFrame*>& vpKFs);
 }  // namespace Hip
 #endif

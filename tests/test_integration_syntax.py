@@ -32,12 +32,13 @@ def test_bridge_and_extractor_header_parse_against_the_reference_headers(tmp_pat
 
 def test_the_check_sees_both_files(tmp_path):
     """a misspelt C-ABI call in either file must fail the check (i.e. both files are really parsed, with their function bodies)"""
-    for fname, old, new in (("OrbExtractorHip.h", "cms_extract(ctx,", "cms_extrakt(ctx,"), ("CubemapHipBridge.cpp", "cms_area_grid(ctx, 1)", "cms_area_grid(ctx)")):
-        d = tmp_path / ("broken_" + fname.split(".")[0])
+    for fname, old, new in (("OrbExtractorHip.h", "cms_extract(ctx,", "cms_extrakt(ctx,"), ("CubemapHipBridge.cpp", "cms_area_grid(ctx, 1)", "cms_area_grid(ctx)"),
+                           ("CubemapHipBridge.cpp", "cms_kfstore_fuse_search_sets(store, 2, set_off,", "cms_kfstore_fuse_search_sets(store, set_off,")):      # (round 6: LocalMapping's bindings)
+        d = tmp_path / ("broken_%s_%d" % (fname.split(".")[0], abs(hash(old)) % 10000))
         shutil.copytree(os.path.join(ROOT, "integration"), d)
         src = (d / fname).read_text()
         assert old in src
         (d / fname).write_text(src.replace(old, new, 1))
-        sub = tmp_path / ("t_" + fname.split(".")[0]); sub.mkdir()
+        sub = tmp_path / ("t_%s_%d" % (fname.split(".")[0], abs(hash(old)) % 10000)); sub.mkdir()
         r = _syntax_check(sub, str(d))
         assert r.returncode != 0 and "error" in r.stderr, fname
