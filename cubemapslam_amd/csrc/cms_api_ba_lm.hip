@@ -220,7 +220,11 @@ static int ba_device_cus(int dev) {
 static int ba_group_ranges(cms_ba** bas, int n) {
   const int cus = ba_device_cus(bas[0]->device);
   int R = BA_SE_RANGES;
-  if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, cus / n));
+  // CMS_BA_RESERVE_CUS=k: the group's Schur launch leaves k compute units free.  A Schur workgroup fills its CU (158 KB of LDS, 8 x 256 registers):
+  // while a launch of 256 of them runs nothing else does -- the other window group's solve and trial kernels (16 workgroups; latency bound) and the frame
+  // path wait for it to drain.  With a few CUs left over they run NEXT to it instead of behind it
+  static const int reserve = [] { const char* v = getenv("CMS_BA_RESERVE_CUS"); return v ? std::max(0, atoi(v)) : 0; }();
+  if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, std::max(n, cus - reserve) / n));
   return R;
 }
 // Which kernels a group's rounds are made of: decided ONCE per group from the windows' lists and the knobs (ba_upload_items and the stage

@@ -49,15 +49,18 @@ void CamModelGeneral::GetPosInFace(double& u, double& v, double uCubemap, double
 static std::mutex g_ctx_mutex;
 static cms_ctx* g_ctx = nullptr;
 static cms_orb_params g_ctx_orb{};
+static cms_camera g_ctx_cam{};      // the camera the shared context was built for (SetCamParams zero-fills the record first: comparable byte for byte)
 cms_ctx* SharedContext(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) {
   std::lock_guard<std::mutex> lock(g_ctx_mutex);
   cms_orb_params orb{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
-  if (g_ctx && std::memcmp(&orb, &g_ctx_orb, sizeof(orb)) == 0) return g_ctx;
   if (!CamModelGeneral::GetCamera()->configured()) throw std::runtime_error("CamModelGeneral::SetCamParams was not called");
+  // the context belongs to (camera, extractor parameters): a process that configures the camera singleton again (another sequence, another face
+  // size) gets a new one -- until round 6 only the extractor parameters were compared, and the mirror kept searching with the OLD camera's LUT and grid
+  if (g_ctx && std::memcmp(&orb, &g_ctx_orb, sizeof(orb)) == 0 && std::memcmp(&g_ctx_cam, &CamModelGeneral::GetCamera()->params(), sizeof(cms_camera)) == 0) return g_ctx;
   if (g_ctx) { cms_ctx_destroy(g_ctx); g_ctx = nullptr; }
   const int rc = cms_ctx_create(&g_ctx, 0, &CamModelGeneral::GetCamera()->params(), &orb, 1);
   if (rc != CMS_OK) throw std::runtime_error(std::string("cms_ctx_create: ") + cms_last_error());
-  g_ctx_orb = orb;
+  g_ctx_orb = orb; g_ctx_cam = CamModelGeneral::GetCamera()->params();
   return g_ctx;
 }
 
