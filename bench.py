@@ -652,7 +652,7 @@ def main():
         local BA's result before it takes the next key frame"""
         wb_queue[gi].append(wi)
     def apply_write_backs(gi):
-        if len(wb_queue[gi]) >= upd_all[gi]["n"] and sorted(list(wb_queue[gi])[:upd_all[gi]["n"]]) == list(range(upd_all[gi]["n"])):
+        while len(wb_queue[gi]) >= upd_all[gi]["n"] and sorted(list(wb_queue[gi])[:upd_all[gi]["n"]]) == list(range(upd_all[gi]["n"])):
             for _ in range(upd_all[gi]["n"]):                      # every window of the previous step was read back: their 16 x 20 poses in one call
                 wb_queue[gi].popleft()
             t0_ = time.perf_counter()
