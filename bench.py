@@ -986,11 +986,161 @@ def main():
             except (OSError, ValueError):
                 pass
         return out
+    # ---- the same step loop WITHOUT the interpreter: cubemapslam_amd/host/batch_driver.cpp makes the very calls step() makes, in the same order and with the same
+    # pipelining, from C++ threads (one frame thread; a mapping, a local-BA, a builder and a finisher thread per window group).  Everything it touches is what
+    # this file prepared above.  It is the headline's driver when libcubemapslam_host.so has it (CMS_BENCH_PY_DRIVER=1: the Python loop); the Python loop's
+    # figure is reported next to it (config.python_step_loop), and every other pass of this file still runs the Python loop.
+    cpp = None
+    if os.environ.get("CMS_BENCH_PY_DRIVER", "") == "" and not part and not tri_inline and not own_streams and not per_window_create and not per_window_finish:
+        try:
+            from cubemapslam_amd import build as _build
+            HL = C_.CDLL(_build.HOST_LIB)
+            HL.cbd_create.restype = C_.c_void_p; HL.cbd_last_error.restype = C_.c_char_p
+            cpp = HL if hasattr(HL, "cbd_steps") else None
+        except (OSError, AttributeError):
+            cpp = None
+    if cpp is not None:
+        VP = C_.c_void_p
+        class CbdFrameSet(C_.Structure):
+            _fields_ = [("d_frames", VP), ("nq", C_.c_int), ("d_mm_frame", VP), ("d_mm_pose", VP), ("d_mm_valid", VP), ("d_mm_xw", VP), ("d_mm_oct", VP), ("d_mm_q", VP * 5),
+                        ("d_cnt", VP), ("d_off", VP), ("d_idx", VP), ("cand_cap", C_.c_int), ("d_tot", VP),
+                        ("d_mm_mpoff", VP), ("d_mm_desc", VP), ("d_mm_pd", VP), ("d_mm_match", VP), ("d_mm_ang", VP), ("d_mm_n", VP),
+                        ("n_mp", C_.c_int), ("d_lm_frame", VP), ("d_lm_pose", VP), ("d_lm_in", VP * 4), ("d_lm_vis", VP), ("d_lm_f", VP * 4), ("d_lm_i", VP * 5),
+                        ("d_lm_off", VP), ("d_lm_idx", VP), ("lm_cap", C_.c_int), ("d_lm_tot", VP), ("d_lm_mpoff", VP), ("d_lm_desc", VP), ("d_lm_pd", VP),
+                        ("d_kpmp", VP), ("d_kpmp0", VP), ("kpmp_bytes", C_.c_size_t), ("put_items", VP * 8), ("put_n", C_.c_int * 8)]
+        class CbdGroup(C_.Structure):
+            _fields_ = [("store", VP), ("ba_stream", VP),
+                        ("njobs", C_.c_int), ("cur_slot", VP), ("neigh_off", VP), ("neigh_slot", VP), ("cap", C_.c_int), ("n_new", VP), ("o_neigh", VP), ("o_idx1", VP), ("o_idx2", VP), ("o_x3d", VP),
+                        ("nsets", C_.c_int), ("set_off", VP), ("pos", VP), ("normal", VP), ("min_d", VP), ("max_d", VP), ("desc", VP),
+                        ("nfjobs", C_.c_int), ("job_slot", VP), ("job_set", VP), ("skip", VP), ("th", C_.c_float), ("best_idx", VP), ("best_dist", VP),
+                        ("n_upd", C_.c_int), ("upd_slots", VP), ("upd_R", VP), ("upd_t", VP), ("upd_Ow", VP),
+                        ("nwin", C_.c_int), ("windows", VP * 2)]
+        STEP_DONE = C_.CFUNCTYPE(None, VP, C_.c_int, C_.POINTER(C_.c_double), C_.c_int)
+        class CbdPlan(C_.Structure):
+            _fields_ = [("ctx", VP), ("po", VP), ("B", C_.c_int), ("device", C_.c_int), ("ngroups", C_.c_int), ("create_threads", C_.c_int), ("mapping_full", C_.c_int),
+                        ("ahead", C_.c_int), ("n_pose_edges", C_.c_int), ("groups", CbdGroup * 8), ("sets", CbdFrameSet * 2), ("step_done", STEP_DONE), ("user", VP)]
+        class CbdStats(C_.Structure):
+            _fields_ = [("ba_ms_sum", C_.c_double), ("ba_jobs", C_.c_long), ("schur_ms", C_.c_double), ("schur_launches", C_.c_long), ("create_ms_sum", C_.c_double),
+                        ("create_windows", C_.c_long), ("tri_ms_sum", C_.c_double), ("fuse_ms_sum", C_.c_double), ("put_ms_sum", C_.c_double), ("upd_ms_sum", C_.c_double),
+                        ("tri_calls", C_.c_long), ("fuse_calls", C_.c_long), ("put_calls", C_.c_long), ("upd_calls", C_.c_long),
+                        ("wait_windows_ms", C_.c_double), ("wait_tri_ms", C_.c_double), ("optimize_ms", C_.c_double),
+                        ("new_map_points_last_step", C_.c_long), ("fused_last_call", C_.c_long), ("stage_ms", C_.c_float * 7), ("steps", C_.c_long)]
+        ptr = lambda t: int(t.data_ptr())
+        cpp_keep = []
+        def make_plan(mapping_full):
+            P_ = CbdPlan()
+            P_.ctx = ctx.h.value; P_.po = po.h.value; P_.B = B; P_.device = local_rank; P_.ngroups = n_grp; P_.create_threads = max(1, n_wthreads // max(1, n_grp))
+            P_.mapping_full = 1 if mapping_full else 0; P_.ahead = ahead; P_.n_pose_edges = int(po.off[-1])
+            for j, S in enumerate(sets):
+                Q = P_.sets[j]
+                Q.d_frames = ptr(S.d_frames); Q.nq = S.nq; Q.d_mm_frame = ptr(S.d_mm_frame); Q.d_mm_pose = ptr(S.d_mm_pose); Q.d_mm_valid = ptr(S.d_mm_valid)
+                Q.d_mm_xw = ptr(S.d_mm_xw); Q.d_mm_oct = ptr(S.d_mm_oct)
+                for k_, t_ in enumerate(S.d_mm_q):
+                    Q.d_mm_q[k_] = ptr(t_)
+                Q.d_cnt = ptr(S.d_cnt); Q.d_off = ptr(S.d_off); Q.d_idx = ptr(S.d_idx); Q.cand_cap = S.cand_cap; Q.d_tot = ptr(S.d_tot)
+                Q.d_mm_mpoff = ptr(S.d_mm_mpoff); Q.d_mm_desc = ptr(S.d_mm_desc); Q.d_mm_pd = ptr(S.d_mm_pd); Q.d_mm_match = ptr(S.d_mm_match); Q.d_mm_ang = ptr(S.d_mm_ang); Q.d_mm_n = ptr(S.d_mm_n)
+                Q.n_mp = S.n_mp; Q.d_lm_frame = ptr(S.d_lm_frame); Q.d_lm_pose = ptr(S.d_lm_pose)
+                for k_, t_ in enumerate(S.d_lm_in):
+                    Q.d_lm_in[k_] = ptr(t_)
+                Q.d_lm_vis = ptr(S.d_lm_vis)
+                for k_, t_ in enumerate(S.d_lm_f):
+                    Q.d_lm_f[k_] = ptr(t_)
+                for k_, t_ in enumerate(S.d_lm_i):
+                    Q.d_lm_i[k_] = ptr(t_)
+                Q.d_lm_off = ptr(S.d_lm_off); Q.d_lm_idx = ptr(S.d_lm_idx); Q.lm_cap = S.lm_cap; Q.d_lm_tot = ptr(S.d_lm_tot); Q.d_lm_mpoff = ptr(S.d_lm_mpoff)
+                Q.d_lm_desc = ptr(S.d_lm_desc); Q.d_lm_pd = ptr(S.d_lm_pd)
+                Q.d_kpmp = ptr(S.d_kpmp); Q.d_kpmp0 = ptr(S.d_kpmp0); Q.kpmp_bytes = S.d_kpmp.numel() * S.d_kpmp.element_size()
+                for gi in range(n_grp):
+                    Q.put_items[gi] = C_.cast(put_items[j][gi], VP); Q.put_n[gi] = len(group_ids[gi])
+            for gi in range(n_grp):
+                G = P_.groups[gi]
+                st_ = tri_store[gi]
+                st_.create_new_map_points(tri_jobs[gi], copy=False)          # (sizes the job arrays and output buffers the wrapper keeps: st_._cnmp)
+                key_, arrs_, _ = st_._cnmp
+                cur_, off_, neigh_, n_new_, on_, o1_, o2_, ox_ = arrs_
+                G.store = st_.h.value; G.ba_stream = int(group_stream[gi])
+                G.njobs = len(tri_jobs[gi]); G.cur_slot = cur_.ctypes.data; G.neigh_off = off_.ctypes.data; G.neigh_slot = neigh_.ctypes.data; G.cap = key_[0]
+                G.n_new = n_new_.ctypes.data; G.o_neigh = on_.ctypes.data; G.o_idx1 = o1_.ctypes.data; G.o_idx2 = o2_.ctypes.data; G.o_x3d = ox_.ctypes.data
+                fa = fuse_prep[gi]["args"]
+                val = lambda a_: a_.value if hasattr(a_, "value") else a_
+                G.nsets = fa[0]; G.set_off = val(fa[1]); G.pos = val(fa[2]); G.normal = val(fa[3]); G.min_d = val(fa[4]); G.max_d = val(fa[5]); G.desc = val(fa[6])
+                G.nfjobs = fa[7]; G.job_slot = val(fa[8]); G.job_set = val(fa[9]); G.skip = val(fa[10]); G.th = 3.0; G.best_idx = val(fa[12]); G.best_dist = val(fa[13])
+                ua = upd_all[gi]["args"]
+                G.n_upd = ua[0]; G.upd_slots = val(ua[1]); G.upd_R = val(ua[2]); G.upd_t = val(ua[3]); G.upd_Ow = val(ua[4])
+                G.nwin = len(group_ids[gi])
+                for j in range(2):
+                    wa = api.ba_window_array([prob_sets[j][w] for w in group_ids[gi]])
+                    cpp_keep.append(wa)
+                    G.windows[j] = C_.cast(wa[0], VP)
+            return P_
+        def step_done_py(user, step_i, poses_ptr, nframes):
+            # trajectory assembly on rank 0 over RCCL (72 B / frame, latency only), like step() does it
+            frame_poses = np.ctypeslib.as_array(poses_ptr, shape=(nframes, 7)).copy()
+            recs = [cdist.make_records(my_streams[s_], step_i * fps + np.arange(fps), frame_poses[s_ * fps:(s_ + 1) * fps]) for s_ in range(len(my_streams))]
+            traj = cdist.gather_trajectory(np.concatenate(recs, 0), device=coll_dev, dst=0)
+            if traj is not None:
+                last["traj"] = traj
+        step_done_c = STEP_DONE(step_done_py)
+        def timed_cpp(steps=None, mapping_full=True):
+            steps = args.steps if steps is None else steps
+            P_ = make_plan(mapping_full)
+            if world > 1 or args.force_gather:
+                P_.step_done = step_done_c
+            h_ = cpp.cbd_create(C_.byref(P_), int(po.off[-1]))
+            if not h_:
+                raise RuntimeError("cbd_create: %s" % cpp.cbd_last_error().decode())
+            h_ = VP(h_)
+            def ck(rc, what):
+                if rc != 0:
+                    raise RuntimeError("%s: %s" % (what, cpp.cbd_last_error().decode()))
+            try:
+                ck(cpp.cbd_begin(h_), "cbd_begin")
+                ck(cpp.cbd_steps(h_, 0, args.warmup), "cbd_steps")
+                ck(cpp.cbd_collect_inflight(h_), "cbd_collect_inflight")      # (the warm-up's last mapping side ends before the clock starts)
+                barrier()
+                cpp.cbd_stats_get(h_, None, 1)
+                gc.collect(); gc.disable()
+                t0 = time.perf_counter()
+                ck(cpp.cbd_steps(h_, args.warmup, steps), "cbd_steps")
+                ck(cpp.cbd_collect_inflight(h_), "cbd_collect_inflight")      # the last step's mapping side (pipelined steps)
+                ck(cpp.cbd_finish(h_), "cbd_finish")                          # the last read-backs and their pose write-backs
+                barrier()
+                dt_ = time.perf_counter() - t0
+                gc.enable()
+                ck(cpp.cbd_drain(h_), "cbd_drain")
+                st_ = CbdStats()
+                cpp.cbd_stats_get(h_, C_.byref(st_), 0)
+            finally:
+                gc.enable()
+                cpp.cbd_destroy(h_)
+            if world > 1:
+                tt = torch.tensor([dt_], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_ = float(tt.item())
+            return dt_, st_
     cpu0 = thread_cpu() if os.environ.get("CMS_BENCH_THREAD_CPU", "") != "" else None
     ctx.profile(True)
+    python_loop = None
     cpu_t0 = time.process_time()
-    dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
+    if cpp is not None:
+        dt, cst = timed_cpp()
+        names7 = ("remap", "pyramid", "fast", "octree", "cull", "describe", "total")
+        stage_ms = {k_: cst.stage_ms[i_] / max(cst.steps, 1) for i_, k_ in enumerate(names7)}
+        ba_ms_per_step = cst.ba_ms_sum / max(cst.ba_jobs, 1)
+        schur_prof = [(cst.schur_ms, cst.schur_launches)]
+        life["mapping_full"] = True; life["on"] = True
+        map_acc.update(put_ms=cst.put_ms_sum, put_n=cst.put_calls, fuse_ms=cst.fuse_ms_sum, fuse_n=cst.fuse_calls, upd_ms=cst.upd_ms_sum, upd_n=max(cst.upd_calls, 1) * upd_all[0]["n"],
+                       fused=int(sum((fq["best_idx"] >= 0).sum() for fq in fuse_prep[-1:])))
+        acc["create_ms"] = cst.create_ms_sum; acc["create_n"] = cst.create_windows
+        worker_ms.clear()
+        worker_ms.update(n=max(cst.ba_jobs, 1), wait_for_windows=cst.wait_windows_ms, create_new_map_points=cst.wait_tri_ms, optimize_many=cst.optimize_ms,
+                         create_new_map_points_library_call=cst.tri_ms_sum)
+        last["tri_new"] = int(cst.new_map_points_last_step)
+    else:
+        dt, stage_ms, ba_ms_per_step, schur_prof = timed(False)
     host["host_cores_used"] = round((time.process_time() - cpu_t0) / max(dt, 1e-9), 2)      # CPU seconds of this process per second of the timed pass (warm-up included in both)
+    host["step_driver"] = ("c++ (cubemapslam_amd/host/batch_driver.cpp: the step's C-ABI calls from C++ threads, no interpreter in the loop)" if cpp is not None
+                           else "python (bench.py's own loop; ~25 threads)")
     host_all = [host]
     if world > 1:
         host_all = [None] * world
@@ -1028,6 +1178,13 @@ def main():
                             "the step, CreateNewMapPoints' geometry stays consistent.  `minimal` = the same steps with CreateNewMapPoints + local BA only (round 4's step)"}
     create_ms_in_step = acc["create_ms"] / max(acc["create_n"], 1)
     worker_break = {k_: round(v_ / max(worker_ms.get("n", 1), 1), 3) for k_, v_ in worker_ms.items() if k_ != "n"}      # per window group and step
+    if cpp is not None and rank == 0 and world == 1 and os.environ.get("CMS_BENCH_NO_PY_LOOP", "") == "":
+        n_py = min(args.steps, 10)
+        c0_ = time.process_time()
+        dt_p, _, ba_ms_p, _ = timed(False, steps=n_py)
+        python_loop = {"value": round(total_frames_per_step * n_py / dt_p, 2), "ms_per_step": round(1e3 * dt_p / n_py, 3), "ba_ms_per_step": round(ba_ms_p, 3), "steps": n_py,
+                       "host_cores_used": round((time.process_time() - c0_) / max(dt_p, 1e-9), 2),
+                       "note": "the same step through bench.py's own Python loop (the driver of rounds 1-5): same calls, same pipelining, ~25 interpreter threads"}
     if part:
         if rank == 0:
             print(json.dumps({"developer_part": part, "ms_per_step": round(1e3 * dt / args.steps, 3), "config": {"ba_ms_per_step": round(ba_ms_per_step, 3), "ba_window_setup": {"ms_per_window_inside_the_step": round(create_ms_in_step, 2)}, "ba_worker_ms": worker_break, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}}))
@@ -1479,7 +1636,7 @@ def main():
                        "step_pipelining": ("the mapping side of step s (CreateNewMapPoints + local BA, windows created / read back / destroyed) is waited for at the end of step s + 1: "
                                            "it overlaps the next batch's frame path like LocalMapping overlaps Tracking; all of it inside the timed region") if pipeline_default else "off (CMS_BENCH_NO_PIPELINE)", "ba_views": args.ba_views, "ba_views_random": random_views,
                        "ba_ms_per_step": round(ba_ms_per_step, 3), "new_map_points_per_step": last["tri_new"],
-                       "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed},
+                       "ba_check": ba_check, "one_local_ba_call": ba_call, "with_input_streaming": streamed, "single_stream_closed_loop": closed, "python_step_loop": python_loop},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

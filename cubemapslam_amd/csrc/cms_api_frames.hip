@@ -463,6 +463,15 @@ extern "C" int cms_frames_upload_device(cms_ctx* c, const void* d_src, int B) {
   HIPCHK(hipMemcpyAsync(c->d_fish, d_src, c->fish_pitch * (size_t)B, hipMemcpyDeviceToDevice, c->stream));
   return CMS_OK;
 }
+// a device-to-device copy on the frame path's stream: what a host keeps between its own device-resident arrays and the calls above and below (e.g. the
+// per-key-point map-point slots of a batch, reset before every tracking pass: Frame::Frame starts with mvpMapPoints all NULL, Frame.cpp:99-102)
+extern "C" int cms_stream_copy_device(cms_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
+  if (!c || (bytes > 0 && (!d_dst || !d_src))) return cms_fail(CMS_ERR_ARG, "cms_stream_copy_device: bad argument");
+  if (bytes == 0) return CMS_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return CMS_OK;
+}
 extern "C" int cms_frames_upload_wait(cms_ctx* c) {
   if (!c) return cms_fail(CMS_ERR_ARG, "null ctx");
   HIPCHK(hipSetDevice(c->device));

@@ -113,6 +113,9 @@ int cms_frames_upload_wait(cms_ctx* ctx);
  * extraction of ctx's last cms_frames_process; the first call only arms the event (takes effect from the next process call on) */
 int cms_stream_wait_extracted(cms_ctx* ctx, void* hip_stream);
 int cms_frames_upload_device(cms_ctx* ctx, const void* d_src, int B);   /* device -> staging copy, [B][Ih][fisheye_stride], async on the ctx stream */
+/* device -> device copy on the ctx stream, asynchronous: e.g. resetting the per-key-point map-point slots of a resident batch before a tracking pass
+ * (Frame::Frame leaves mvpMapPoints all NULL, src/Frame.cpp:99-102) without leaving the frame path's queue */
+int cms_stream_copy_device(cms_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int cms_host_alloc(void** out, size_t bytes);   /* pinned host memory for cms_frames_upload_async */
 void cms_host_free(void* p);
 int cms_frames_process(cms_ctx* ctx, int B, int from_fisheye);
