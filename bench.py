@@ -63,6 +63,38 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def cbd_types():
+    """ctypes descriptions of cubemapslam_amd/host/batch_driver.cpp's plan structures (cbd_frame_set, cbd_group, cbd_plan, cbd_stats); bench.py checks their sizes
+    against the library's own (cbd_sizes) before it uses them, tests/test_batch_driver_cpu.py does it without a GPU"""
+    import ctypes as C_
+    VP = C_.c_void_p
+    class CbdFrameSet(C_.Structure):
+        _fields_ = [("d_frames", VP), ("nq", C_.c_int), ("d_mm_frame", VP), ("d_mm_pose", VP), ("d_mm_valid", VP), ("d_mm_xw", VP), ("d_mm_oct", VP), ("d_mm_q", VP * 5),
+                    ("d_cnt", VP), ("d_off", VP), ("d_idx", VP), ("cand_cap", C_.c_int), ("d_tot", VP),
+                    ("d_mm_mpoff", VP), ("d_mm_desc", VP), ("d_mm_pd", VP), ("d_mm_match", VP), ("d_mm_ang", VP), ("d_mm_n", VP),
+                    ("n_mp", C_.c_int), ("d_lm_frame", VP), ("d_lm_pose", VP), ("d_lm_in", VP * 4), ("d_lm_vis", VP), ("d_lm_f", VP * 4), ("d_lm_i", VP * 5),
+                    ("d_lm_off", VP), ("d_lm_idx", VP), ("lm_cap", C_.c_int), ("d_lm_tot", VP), ("d_lm_mpoff", VP), ("d_lm_desc", VP), ("d_lm_pd", VP),
+                    ("d_kpmp", VP), ("d_kpmp0", VP), ("kpmp_bytes", C_.c_size_t), ("put_items", VP * 8), ("put_n", C_.c_int * 8)]
+    class CbdGroup(C_.Structure):
+        _fields_ = [("store", VP), ("ba_stream", VP),
+                    ("njobs", C_.c_int), ("cur_slot", VP), ("neigh_off", VP), ("neigh_slot", VP), ("cap", C_.c_int), ("n_new", VP), ("o_neigh", VP), ("o_idx1", VP), ("o_idx2", VP), ("o_x3d", VP),
+                    ("nsets", C_.c_int), ("set_off", VP), ("pos", VP), ("normal", VP), ("min_d", VP), ("max_d", VP), ("desc", VP),
+                    ("nfjobs", C_.c_int), ("job_slot", VP), ("job_set", VP), ("skip", VP), ("th", C_.c_float), ("best_idx", VP), ("best_dist", VP),
+                    ("n_upd", C_.c_int), ("upd_slots", VP), ("upd_R", VP), ("upd_t", VP), ("upd_Ow", VP),
+                    ("nwin", C_.c_int), ("windows", VP * 2)]
+    STEP_DONE = C_.CFUNCTYPE(None, VP, C_.c_int, C_.POINTER(C_.c_double), C_.c_int)
+    class CbdPlan(C_.Structure):
+        _fields_ = [("ctx", VP), ("po", VP), ("B", C_.c_int), ("device", C_.c_int), ("ngroups", C_.c_int), ("create_threads", C_.c_int), ("mapping_full", C_.c_int),
+                    ("ahead", C_.c_int), ("n_pose_edges", C_.c_int), ("groups", CbdGroup * 8), ("sets", CbdFrameSet * 2), ("step_done", STEP_DONE), ("user", VP)]
+    class CbdStats(C_.Structure):
+        _fields_ = [("ba_ms_sum", C_.c_double), ("ba_jobs", C_.c_long), ("schur_ms", C_.c_double), ("schur_launches", C_.c_long), ("create_ms_sum", C_.c_double),
+                    ("create_windows", C_.c_long), ("tri_ms_sum", C_.c_double), ("fuse_ms_sum", C_.c_double), ("put_ms_sum", C_.c_double), ("upd_ms_sum", C_.c_double),
+                    ("tri_calls", C_.c_long), ("fuse_calls", C_.c_long), ("put_calls", C_.c_long), ("upd_calls", C_.c_long),
+                    ("wait_windows_ms", C_.c_double), ("wait_tri_ms", C_.c_double), ("optimize_ms", C_.c_double),
+                    ("new_map_points_last_step", C_.c_long), ("fused_last_call", C_.c_long), ("stage_ms", C_.c_float * 7), ("steps", C_.c_long)]
+    return VP, CbdFrameSet, CbdGroup, STEP_DONE, CbdPlan, CbdStats
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +127,7 @@ def parse_args(argv=None):
     ap.add_argument("--deterministic-steps", type=int, default=6, help="steps of the extra pass with cms_ba_set_deterministic(1) (config.deterministic; 0 = skip)")
     ap.add_argument("--mapping-only-steps", type=int, default=6, help="steps of the mapping side alone (CreateNewMapPoints + local BA, no frame path): config.mapping_only, and the Schur kernel's launch time without the frame path next to it in roofline (0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
-    ap.add_argument("--confined-steps", type=int, default=8, help="steps of the two child runs of the same step with the process confined to 2 and to 4 host cores "
+    ap.add_argument("--confined-steps", type=int, default=12, help="steps of the two child runs of the same step with the process confined to 2 and to 4 host cores "
                     "(config.host.confined_2_cores / _4_cores: what a rank gets when eight of them share a 16-core box; rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
     return ap.parse_args(argv)
@@ -401,6 +433,13 @@ def main():
     for p in all_probs:        # contiguous arrays of the C-ABI's types once, so that a window's creation is nothing but the cms_ba_create call
         p["poses"] = np.ascontiguousarray(p["poses"], np.float64); p["points"] = np.ascontiguousarray(p["points"], np.float64)
         p["e_obs"] = np.ascontiguousarray(p["e_obs"], np.float64)
+    # the windows' observation-sized arrays in pinned host memory (cms_ba_window.flags = CMS_BA_INPUTS_PINNED): cms_ba_create_many then copies them to the device from
+    # where they lie instead of through a staging memcpy -- a host assembles a window's observations (Optimizer.cpp:246-357) into buffers of its choice.
+    # CMS_BENCH_PAGEABLE_WINDOWS=1: ordinary arrays, staged by the library (rounds 1-5)
+    if os.environ.get("CMS_BENCH_PAGEABLE_WINDOWS", "") == "":
+        all_probs = [api.pin_problem(p) for p in all_probs]
+        prob_sets = [all_probs[:n_ba], all_probs[n_ba:]]
+        probs = prob_sets[0]
     host = host_budget(world, local_rank, args.window_threads)      # the ranks of a node split its usable cores (and are pinned to their slice)
     host["blocking_sync"] = bool(blocking_sync)
     n_wthreads = host["window_threads"]
@@ -1000,31 +1039,11 @@ def main():
         except (OSError, AttributeError):
             cpp = None
     if cpp is not None:
-        VP = C_.c_void_p
-        class CbdFrameSet(C_.Structure):
-            _fields_ = [("d_frames", VP), ("nq", C_.c_int), ("d_mm_frame", VP), ("d_mm_pose", VP), ("d_mm_valid", VP), ("d_mm_xw", VP), ("d_mm_oct", VP), ("d_mm_q", VP * 5),
-                        ("d_cnt", VP), ("d_off", VP), ("d_idx", VP), ("cand_cap", C_.c_int), ("d_tot", VP),
-                        ("d_mm_mpoff", VP), ("d_mm_desc", VP), ("d_mm_pd", VP), ("d_mm_match", VP), ("d_mm_ang", VP), ("d_mm_n", VP),
-                        ("n_mp", C_.c_int), ("d_lm_frame", VP), ("d_lm_pose", VP), ("d_lm_in", VP * 4), ("d_lm_vis", VP), ("d_lm_f", VP * 4), ("d_lm_i", VP * 5),
-                        ("d_lm_off", VP), ("d_lm_idx", VP), ("lm_cap", C_.c_int), ("d_lm_tot", VP), ("d_lm_mpoff", VP), ("d_lm_desc", VP), ("d_lm_pd", VP),
-                        ("d_kpmp", VP), ("d_kpmp0", VP), ("kpmp_bytes", C_.c_size_t), ("put_items", VP * 8), ("put_n", C_.c_int * 8)]
-        class CbdGroup(C_.Structure):
-            _fields_ = [("store", VP), ("ba_stream", VP),
-                        ("njobs", C_.c_int), ("cur_slot", VP), ("neigh_off", VP), ("neigh_slot", VP), ("cap", C_.c_int), ("n_new", VP), ("o_neigh", VP), ("o_idx1", VP), ("o_idx2", VP), ("o_x3d", VP),
-                        ("nsets", C_.c_int), ("set_off", VP), ("pos", VP), ("normal", VP), ("min_d", VP), ("max_d", VP), ("desc", VP),
-                        ("nfjobs", C_.c_int), ("job_slot", VP), ("job_set", VP), ("skip", VP), ("th", C_.c_float), ("best_idx", VP), ("best_dist", VP),
-                        ("n_upd", C_.c_int), ("upd_slots", VP), ("upd_R", VP), ("upd_t", VP), ("upd_Ow", VP),
-                        ("nwin", C_.c_int), ("windows", VP * 2)]
-        STEP_DONE = C_.CFUNCTYPE(None, VP, C_.c_int, C_.POINTER(C_.c_double), C_.c_int)
-        class CbdPlan(C_.Structure):
-            _fields_ = [("ctx", VP), ("po", VP), ("B", C_.c_int), ("device", C_.c_int), ("ngroups", C_.c_int), ("create_threads", C_.c_int), ("mapping_full", C_.c_int),
-                        ("ahead", C_.c_int), ("n_pose_edges", C_.c_int), ("groups", CbdGroup * 8), ("sets", CbdFrameSet * 2), ("step_done", STEP_DONE), ("user", VP)]
-        class CbdStats(C_.Structure):
-            _fields_ = [("ba_ms_sum", C_.c_double), ("ba_jobs", C_.c_long), ("schur_ms", C_.c_double), ("schur_launches", C_.c_long), ("create_ms_sum", C_.c_double),
-                        ("create_windows", C_.c_long), ("tri_ms_sum", C_.c_double), ("fuse_ms_sum", C_.c_double), ("put_ms_sum", C_.c_double), ("upd_ms_sum", C_.c_double),
-                        ("tri_calls", C_.c_long), ("fuse_calls", C_.c_long), ("put_calls", C_.c_long), ("upd_calls", C_.c_long),
-                        ("wait_windows_ms", C_.c_double), ("wait_tri_ms", C_.c_double), ("optimize_ms", C_.c_double),
-                        ("new_map_points_last_step", C_.c_long), ("fused_last_call", C_.c_long), ("stage_ms", C_.c_float * 7), ("steps", C_.c_long)]
+        VP, CbdFrameSet, CbdGroup, STEP_DONE, CbdPlan, CbdStats = cbd_types()
+        sz_ = (C_.c_int * 4)()
+        cpp.cbd_sizes(sz_)
+        if list(sz_) != [C_.sizeof(CbdFrameSet), C_.sizeof(CbdGroup), C_.sizeof(CbdPlan), C_.sizeof(CbdStats)]:
+            raise RuntimeError("bench.py's descriptions of the batch driver's structures do not match libcubemapslam_host.so: %s" % list(sz_))
         ptr = lambda t: int(t.data_ptr())
         cpp_keep = []
         def make_plan(mapping_full):
@@ -1108,6 +1127,8 @@ def main():
                 dt_ = time.perf_counter() - t0
                 gc.enable()
                 ck(cpp.cbd_drain(h_), "cbd_drain")
+                if cpu0 is not None:
+                    life["cpp_thread_cpu"] = thread_cpu()      # (the driver's threads end with the handle: their CPU seconds are read while they still exist)
                 st_ = CbdStats()
                 cpp.cbd_stats_get(h_, C_.byref(st_), 0)
             finally:
@@ -1146,7 +1167,7 @@ def main():
         host_all = [None] * world
         dist.all_gather_object(host_all, host)
     if cpu0 is not None:
-        cpu1 = thread_cpu()
+        cpu1 = life.pop("cpp_thread_cpu", None) or thread_cpu()
         use = sorted(((cpu1[k] - cpu0.get(k, 0.0), k) for k in cpu1), reverse=True)
         tot = sum(u for u, _ in use)
         print("window threads: cms_ba_create %.2f ms CPU per window, read + destroy %.2f ms CPU per window (%d windows since start)" % (

@@ -836,7 +836,20 @@ def ba_run_fg(fixed, n_points, e_pose, e_point, fast=False):
 class BaWindow(C.Structure):      # cms_ba_window (include/cubemapslam_hip.h)
     _fields_ = [("K", C.c_int), ("poses", C.c_void_p), ("fixed", C.c_void_p), ("P", C.c_int), ("points", C.c_void_p), ("E", C.c_int), ("e_pose", C.c_void_p),
                 ("e_point", C.c_void_p), ("e_obs", C.c_void_p), ("e_invsig2", C.c_void_p), ("e_face", C.c_void_p), ("fx", C.c_double), ("fy", C.c_double),
-                ("cx", C.c_double), ("cy", C.c_double)]
+                ("cx", C.c_double), ("cy", C.c_double), ("flags", C.c_int)]
+
+
+def pin_problem(prob):
+    """a copy of a BA problem whose observation-sized arrays lie in pinned host memory (cms_host_alloc), for cms_ba_window.flags = CMS_BA_INPUTS_PINNED;
+    the PinnedArray objects travel with the dict and keep the memory alive"""
+    q = dict(prob); keep = []
+    for key, dt in (("points", np.float64), ("e_pose", np.int32), ("e_point", np.int32), ("e_obs", np.float64), ("e_invsig2", np.float64), ("e_face", np.int8)):
+        a = np.ascontiguousarray(prob[key], dt)
+        pa = PinnedArray((max(a.nbytes, 16),))
+        v = pa.array[:a.nbytes].view(dt).reshape(a.shape); v[...] = a
+        q[key] = v; keep.append(pa)
+    q["_pinned"] = keep
+    return q
 
 
 def ba_window_array(probs):
@@ -851,6 +864,7 @@ def ba_window_array(probs):
         q.K = len(a[0]); q.poses = a[0].ctypes.data; q.fixed = a[1].ctypes.data; q.P = len(a[2]); q.points = a[2].ctypes.data; q.E = len(a[3])
         q.e_pose = a[3].ctypes.data; q.e_point = a[4].ctypes.data; q.e_obs = a[5].ctypes.data; q.e_invsig2 = a[6].ctypes.data; q.e_face = a[7].ctypes.data
         q.fx = p["fx"]; q.fy = p["fy"]; q.cx = p["cx"]; q.cy = p["cy"]
+        q.flags = 1 if p.get("_pinned") else 0      # CMS_BA_INPUTS_PINNED: pin_problem() made the arrays
     return arr, keep
 
 

@@ -15,6 +15,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <pthread.h>
 #include <unordered_map>
 
 // Every A/B switch of the local-BA host code, read ONCE (first use) so that the choices made when a window is built (which work lists exist)
@@ -74,6 +75,7 @@ static const BaKnobs& ba_knobs() {
 
 struct BaExpand;
 static thread_local BaExpand* ba_tl_defer_expand = nullptr;      // cms_ba_create_many: where cms_ba_create leaves the description of a device-planned window's expansion instead of launching it
+static thread_local bool ba_tl_inputs_pinned = false;      // cms_ba_create_many, CMS_BA_INPUTS_PINNED: the caller's arrays are pinned and stay alive -- they are copied from where they lie
 static thread_local bool ba_force_rw_tables = false;      // cms_ba_debug_run_fg: build the one-wavefront workgroups' tables whatever the knob says
 static inline bool ba_want_rw_tables() { return ba_knobs().run_wg || ba_force_rw_tables; }
 struct BaBlock { void* p; size_t bytes; };      // a device slab / pinned block of the per-device pool (below)
@@ -1241,9 +1243,13 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   const int np = b->np, n = 6 * np;
   // ---- everything the window uploads goes through ONE pinned block and ONE asynchronous copy on the window's stream (a dozen synchronous
   // hipMemcpy calls from pageable memory were 0.3 ms of a 2 ms set-up and serialised the host threads that build windows side by side)
-  struct Up { const void* src; size_t bytes; void** dst; };
+  struct Up { const void* src; size_t bytes; void** dst; bool direct; };
   std::vector<Up> ups;
-  auto up = [&](const void* src, size_t bytes, auto** dst) { ups.push_back({src, bytes, reinterpret_cast<void**>(dst)}); };
+  auto up = [&](const void* src, size_t bytes, auto** dst) { ups.push_back({src, bytes, reinterpret_cast<void**>(dst), false}); };
+  // one of the CALLER's arrays: with CMS_BA_INPUTS_PINNED it is not staged (a memcpy of ~3 MB per 80 k-observation window: as much host time as the
+  // whole plan) but copied asynchronously from the caller's pinned memory
+  const bool inputs_pinned = ba_tl_inputs_pinned;
+  auto up_in = [&](const void* src, size_t bytes, auto** dst) { ups.push_back({src, bytes, reinterpret_cast<void**>(dst), inputs_pinned && bytes >= 4096}); };
   if (se_built) {
     const int NP2 = np * (np + 1) / 2;
     BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)BA_SE_RANGES * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)BA_SE_RANGES * np * 6));
@@ -1460,12 +1466,12 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   // random cache lines per point over arrays no other window shares: 1.2 of cms_ba_create's 2.8 ms alone and 2.0-2.7 of ~5 ms when 32 host
   // threads build windows side by side (memory bound) -- the part a host inside a CPU quota could least afford.
   up(fixed, K, &b->d_fixed); up(pose_slot.data(), K * sizeof(int), &b->d_pose_slot);
-  up(e_obs, 2 * (size_t)E * sizeof(double), &b->d_raw_obs); up(e_invsig2, E * sizeof(double), &b->d_raw_inv);
-  up(p0.data(), 7 * (size_t)K * sizeof(double), &b->d_poses0); up(points, 3 * (size_t)P * sizeof(double), &b->d_raw_pts);
+  up_in(e_obs, 2 * (size_t)E * sizeof(double), &b->d_raw_obs); up_in(e_invsig2, E * sizeof(double), &b->d_raw_inv);
+  up(p0.data(), 7 * (size_t)K * sizeof(double), &b->d_poses0); up_in(points, 3 * (size_t)P * sizeof(double), &b->d_raw_pts);
   std::vector<int> zero_off;
   if (fast) {
     // the caller's index arrays as they are; sorted edge arrays, per-edge words and the edge permutation are written by k_ba_expand_edges
-    up(e_pose, E * sizeof(int), &b->d_raw_pose); up(e_point, E * sizeof(int), &b->d_raw_point); up(e_face, E, &b->d_raw_face);
+    up_in(e_pose, E * sizeof(int), &b->d_raw_pose); up_in(e_point, E * sizeof(int), &b->d_raw_point); up_in(e_face, E, &b->d_raw_face);
     up(fp.pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off); up(fp.prank.data(), P * sizeof(int), &b->d_prank); up(fp.pinv.data(), P * sizeof(int), &b->d_pinv);
     up(fp.cpo.data(), (P + 1) * sizeof(int), &b->d_cpo); up(fp.pcopy.data(), P, &b->d_pcopy); up(fp.lo_copy.data(), fp.lo_copy.size(), &b->d_lo_copy);
     if (!fp.grouped) up(fp.cedge.data(), E * sizeof(int), &b->d_cedge);
@@ -1497,19 +1503,23 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   tick("alloc");
   // ---- the one staging block and the one copy
   {
-    size_t total = 0;
+    size_t total = 0, staged = 0;
     std::vector<size_t> offs(ups.size());
-    for (size_t i = 0; i < ups.size(); ++i) { offs[i] = total; total += (ups[i].bytes + 255) & ~(size_t)255; }
-    // (the read-back of cms_ba_read reuses the block: poses, points, flags)
-    total = std::max(total, ((size_t)7 * K * 8 + 255 + (size_t)3 * P * 8 + 255 + (size_t)E + 255));
+    for (size_t i = 0; i < ups.size(); ++i) if (!ups[i].direct) { offs[i] = total; total += (ups[i].bytes + 255) & ~(size_t)255; }
+    staged = total;                                               // the staged entries first (one copy), the caller's pinned arrays behind them (one copy each)
+    for (size_t i = 0; i < ups.size(); ++i) if (ups[i].direct) { offs[i] = total; total += (ups[i].bytes + 255) & ~(size_t)255; }
+    // (the read-back of cms_ba_read reuses the pinned block: poses, points, flags)
+    const size_t rd_bytes = (size_t)7 * K * 8 + 255 + (size_t)3 * P * 8 + 255 + (size_t)E + 255;
     char* dev = nullptr;
-    BA_TRY(ba_alloc(b, &dev, total));
-    BA_HIP(ba_stage_take(device, total, (void**)&b->h_stage, &b->h_stage_bytes));
+    BA_TRY(ba_alloc(b, &dev, std::max(total, (size_t)256)));
+    BA_HIP(ba_stage_take(device, std::max(staged, rd_bytes), (void**)&b->h_stage, &b->h_stage_bytes));
     for (size_t i = 0; i < ups.size(); ++i) {
-      if (ups[i].bytes) memcpy(b->h_stage + offs[i], ups[i].src, ups[i].bytes);
+      if (ups[i].bytes && !ups[i].direct) memcpy(b->h_stage + offs[i], ups[i].src, ups[i].bytes);
       *ups[i].dst = dev + offs[i];
     }
-    BA_HIP(hipMemcpyAsync(dev, b->h_stage, total, hipMemcpyHostToDevice, b->stream));
+    if (staged) BA_HIP(hipMemcpyAsync(dev, b->h_stage, staged, hipMemcpyHostToDevice, b->stream));
+    for (size_t i = 0; i < ups.size(); ++i)
+      if (ups[i].direct && ups[i].bytes) BA_HIP(hipMemcpyAsync(dev + offs[i], ups[i].src, ups[i].bytes, hipMemcpyHostToDevice, b->stream));
     b->async_pending = true;
   }
   BaDev& d = b->d;
@@ -1688,6 +1698,7 @@ struct BaWorkers {
     std::lock_guard<std::mutex> lk(mu);
     for (; nthreads < std::min(n, 16); ++nthreads)
       std::thread([this]() {
+        pthread_setname_np(pthread_self(), "cms-ba-plan");
         for (;;) {
           std::function<void()> job;
           { std::unique_lock<std::mutex> lk2(mu); cv.wait(lk2, [this]() { return !jobs.empty(); }); job = std::move(jobs.front()); jobs.pop_front(); }
@@ -1713,10 +1724,11 @@ extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_
       if (i >= n) break;
       memset(&xs[(size_t)i], 0, sizeof(BaExpand));
       ba_tl_defer_expand = &xs[(size_t)i];
+      ba_tl_inputs_pinned = (w[i].flags & CMS_BA_INPUTS_PINNED) != 0;
       rcs[(size_t)i] = cms_ba_create(&out[i], device, w[i].K, w[i].poses, w[i].fixed, w[i].P, w[i].points, w[i].E, w[i].e_pose, w[i].e_point, w[i].e_obs, w[i].e_invsig2,
                                      w[i].e_face, w[i].fx, w[i].fy, w[i].cx, w[i].cy);
       deferred[(size_t)i] = ba_tl_defer_expand == nullptr && rcs[(size_t)i] == CMS_OK;      // (taken: a device-planned window; a host-planned one launched its own set-up kernel)
-      ba_tl_defer_expand = nullptr;
+      ba_tl_defer_expand = nullptr; ba_tl_inputs_pinned = false;
       if (rcs[(size_t)i] != CMS_OK) errs[(size_t)i] = cms_last_error();
     }
   };

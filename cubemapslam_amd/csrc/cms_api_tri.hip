@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -335,10 +336,16 @@ struct cms_kfstore {
   // slots that work enqueued on the store's stream reads or writes (pose updates, CreateNewMapPoints, the Fuse searches) since the slot was last
   // filled: cms_kfstore_put_from_frames copies on the FRAME context's stream, so before it overwrites such a slot that stream waits for the store's
   std::vector<uint8_t> busy; hipEvent_t order_ev = nullptr;
+  // copies of cms_kfstore_put_from_frames that the store's stream has not been told to wait for yet: the put runs on the FRAME thread, and a call that
+  // touches the store's stream from there (hipStreamWaitEvent) queues inside the runtime behind the mapping thread's synchronous calls on that stream
+  // (measured: 2.8 ms per put call of 16 key frames, the length of a CreateNewMapPoints / Fuse call).  The wait is inserted by the store's next own
+  // operation instead (kfstore_order_behind_puts)
+  std::mutex put_mu; std::vector<std::shared_ptr<PutCall>> pending_puts;
   float* h_upd = nullptr; std::vector<uint8_t> upd_par;      // two 16-float blocks per SLOT, used alternately: a block is rewritten only by the SECOND later update
                                                              // of the same slot, long after the kernel of the first has read it (no event, no wait)
 };
 
+static hipError_t kfstore_order_behind_puts(cms_kfstore* st);
 extern "C" void cms_kfstore_destroy(cms_kfstore* st) {
   if (!st) return;
   if (st->c) (void)hipSetDevice(st->c->device);
@@ -389,6 +396,7 @@ extern "C" int cms_kfstore_put(cms_kfstore* st, int slot, const cms_keyframe* kf
   if (kf->n > st->maxf || kf->nnodes > st->maxn) return cms_fail(CMS_ERR_ARG, "cms_kfstore_put: key frame larger than the store's slots");
   cms_ctx* c = st->c;
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(kfstore_order_behind_puts(st));
   hipStream_t s = c->stream;
   const size_t f0 = (size_t)slot * st->maxf, n0 = (size_t)slot * st->maxn, o0 = (size_t)slot * (st->maxn + 1);
   CmsTriKF d;
@@ -457,6 +465,13 @@ extern "C" __global__ void __launch_bounds__(256) k_kf_put_from_frame(const CmsK
   for (int i = t0; i < a.nfeat; i += gs) a.o_nfeat[i] = a.h_nfeat[i];
   if (t0 == 0) { *a.o_nvalid = *a.nvalid; *a.o_kp_cnt = n; *a.o_kf = a.kf; }
 }
+// first thing every operation on the store's stream does: the stream waits (on the device) for the frame-to-store copies enqueued since the last one
+static hipError_t kfstore_order_behind_puts(cms_kfstore* st) {
+  std::vector<std::shared_ptr<cms_kfstore::PutCall>> w;
+  { std::lock_guard<std::mutex> lk(st->put_mu); w.swap(st->pending_puts); }
+  for (auto& c : w) { const hipError_t e = hipStreamWaitEvent(st->c->stream, c->ev, 0); if (e != hipSuccess) return e; }
+  return hipSuccess;
+}
 static int kfstore_ff_reserve(cms_kfstore* st) {
   if (st->h_ff) return CMS_OK;
   st->ff_stride = ((size_t)3 * st->maxf + 2 * (size_t)st->maxn + 1 + 63) & ~(size_t)63;      // ints per slot: mp | feat_node | node_feat | node_id | node_off
@@ -496,9 +511,15 @@ static int kf_put_fill(cms_kfstore* st, int slot, cms_ctx* src, int b, int n, co
   int* h = st->h_ff + (size_t)slot * st->ff_stride;
   int* h_mp = h; int* h_fn = h + st->maxf; int* h_nfeat = h + 2 * (size_t)st->maxf; int* h_nid = h + 3 * (size_t)st->maxf; int* h_noff = h_nid + st->maxn;
   if (mp && n > 0) std::memcpy(h_mp, mp, 4 * (size_t)n);
-  for (int i = 0; i < n; ++i) h_fn[i] = -1;
-  for (int e = 0; e < nnodes; ++e)
-    for (int q = node_off[e]; q < node_off[e + 1]; ++q) h_fn[node_feat[q]] = e;
+  {
+    // feature -> node: scattered writes, made in ordinary memory and copied in one piece (the block is uncached, device-coherent host memory: 1 650
+    // scattered 4-byte stores into it cost ~170 us per key frame, 5.6 ms of the frame thread per bench step)
+    static thread_local std::vector<int> fn;
+    fn.assign((size_t)std::max(n, 1), -1);
+    for (int e = 0; e < nnodes; ++e)
+      for (int q = node_off[e]; q < node_off[e + 1]; ++q) fn[(size_t)node_feat[q]] = e;
+    if (n > 0) std::memcpy(h_fn, fn.data(), 4 * (size_t)n);
+  }
   if (nnodes > 0) { std::memcpy(h_nid, node_id, 4 * (size_t)nnodes); std::memcpy(h_noff, node_off, 4 * ((size_t)nnodes + 1)); std::memcpy(h_nfeat, node_feat, 4 * (size_t)nfeat); }
   const size_t f0 = (size_t)slot * st->maxf, n0 = (size_t)slot * st->maxn, o0 = (size_t)slot * (st->maxn + 1);
   std::memset(&a, 0, sizeof(a));
@@ -568,7 +589,7 @@ extern "C" int cms_kfstore_put_from_frames(cms_kfstore* st, cms_ctx* src, int n_
   auto call = std::make_shared<cms_kfstore::PutCall>();
   HIPCHK(hipEventCreateWithFlags(&call->ev, hipEventDisableTiming));
   HIPCHK(hipEventRecord(call->ev, s));
-  if (c->stream != s) HIPCHK(hipStreamWaitEvent(c->stream, call->ev, 0));
+  if (c->stream != s) { std::lock_guard<std::mutex> lk(st->put_mu); st->pending_puts.push_back(call); }      // (the store's stream waits for it at its next own operation)
   for (int i = 0; i < n_items; ++i) {      // the kernel is in the stream: commit the store's record of the slots
     const cms_kf_from_frame& q = items[i];
     st->ff_call[(size_t)q.slot] = call;
@@ -603,6 +624,7 @@ extern "C" int cms_kfstore_update_poses(cms_kfstore* st, int n, const int* slots
   if (n == 0) return CMS_OK;
   cms_ctx* c = st->c;
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(kfstore_order_behind_puts(st));
   if (!st->h_upd) {      // two 16-float blocks per slot, then four slot lists of maxkf ints
     HIPCHK(hipHostMalloc((void**)&st->h_upd, (size_t)st->maxkf * (32 * sizeof(float) + 4 * sizeof(int)), hipHostMallocMapped | hipHostMallocCoherent));
     st->upd_par.assign((size_t)st->maxkf, 0);
@@ -638,6 +660,7 @@ extern "C" int cms_kfstore_debug_fetch(cms_kfstore* st, int slot, cms_keypoint* 
   if (!st || slot < 0 || slot >= st->maxkf || !st->used[(size_t)slot]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_debug_fetch: bad slot");
   cms_ctx* c = st->c;
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(kfstore_order_behind_puts(st));
   HIPCHK(hipStreamSynchronize(c->stream));
   CmsTriKF d;
   HIPCHK(hipMemcpy(&d, st->d_kf + slot, sizeof(d), hipMemcpyDeviceToHost));
@@ -662,6 +685,7 @@ extern "C" int cms_kfstore_update(cms_kfstore* st, int slot, const float* Rcw, c
   if (!st || slot < 0 || slot >= st->maxkf || !st->used[(size_t)slot]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_update: bad slot");
   cms_ctx* c = st->c;
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(kfstore_order_behind_puts(st));
   CmsTriKF& d = st->h_kf[(size_t)slot];
   if (Rcw) std::memcpy(d.Rcw, Rcw, sizeof(d.Rcw));
   if (tcw) std::memcpy(d.tcw, tcw, sizeof(d.tcw));
@@ -689,6 +713,7 @@ extern "C" int cms_kfstore_create_new_map_points(cms_kfstore* st, int njobs, con
   for (int q = 0; q < nneigh; ++q)
     if (neigh_slot[q] < 0 || neigh_slot[q] >= st->maxkf || !st->used[(size_t)neigh_slot[q]]) return cms_fail(CMS_ERR_ARG, "cms_kfstore_create_new_map_points: empty slot");
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(kfstore_order_behind_puts(st));
   const size_t need = tri_work_bytes(njobs, nneigh, st->maxf, cap_per_job);
   if (need > st->work_bytes) {
     if (st->d_work) HIPCHK(hipFree(st->d_work));
@@ -881,6 +906,7 @@ static int kfstore_fuse_core(cms_kfstore* st, int njobs, const int* job_slot, co
     memcpy(&pose[15 * (size_t)j], k.Rcw, 36); memcpy(&pose[15 * (size_t)j + 9], k.tcw, 12); memcpy(&pose[15 * (size_t)j + 12], k.Ow, 12);
   }
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(kfstore_order_behind_puts(st));
   hipStream_t s = c->stream;
   if (!job_set0) npts = nmp;
   const size_t n4 = (size_t)nmp * 4, j4 = (size_t)njobs * 4, p4 = (size_t)npts * 4;

@@ -30,6 +30,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <pthread.h>
 #include <vector>
 
 #include "cubemapslam_hip.h"
@@ -89,7 +90,7 @@ namespace {
 // one worker thread executing jobs in order
 class Worker {
  public:
-  Worker() : th_([this]() { run(); }) {}
+  explicit Worker(const std::string& name) : th_([this, name]() { pthread_setname_np(pthread_self(), name.substr(0, 15).c_str()); run(); }) {}
   ~Worker() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
     cv_.notify_one();
@@ -304,7 +305,9 @@ cbd* cbd_create(const cbd_plan* plan, int max_pose_edges) {
   d->p = *plan;
   std::memset(&d->st, 0, sizeof(d->st));
   for (int g = 0; g < plan->ngroups; ++g) {
-    d->mapping.emplace_back(new Worker); d->ba.emplace_back(new Worker); d->builder.emplace_back(new Worker); d->finisher.emplace_back(new Worker);
+    const std::string gs = std::to_string(g);
+    d->mapping.emplace_back(new Worker("cbd-map" + gs)); d->ba.emplace_back(new Worker("cbd-ba" + gs)); d->builder.emplace_back(new Worker("cbd-build" + gs));
+    d->finisher.emplace_back(new Worker("cbd-finish" + gs));
     d->wb_pending[g] = 0;
     size_t np = 0, nq = 0, nf = 0;
     for (int i = 0; i < plan->groups[g].nwin; ++i) {
@@ -340,6 +343,8 @@ int cbd_drain(cbd* d) {
     }
     return 0;)
 }
+// sizes of the plan structures as this library was compiled with them (the caller's descriptions must match: bench.py checks)
+void cbd_sizes(int* out4) { out4[0] = (int)sizeof(cbd_frame_set); out4[1] = (int)sizeof(cbd_group); out4[2] = (int)sizeof(cbd_plan); out4[3] = (int)sizeof(cbd_stats); }
 void cbd_stats_get(cbd* d, cbd_stats* out, int reset) {
   std::lock_guard<std::mutex> lk(d->stats_mu);
   if (out) *out = d->st;

@@ -1,0 +1,39 @@
+"""bench.py's step through the C++ batch driver (cubemapslam_amd/host/batch_driver.cpp) and through its own Python loop: the same calls in the same order.
+Both must run, the windows of the step that bench.py verifies must agree with the oracle under either driver (iteration counts, outlier flags, estimates:
+config.ba_check), and the two figures must be of the same order -- a driver that skipped work would be much faster, one that serialised it much slower."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra):
+    env = dict(os.environ); env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "64", "--cpu-frames", "0", "--no-streaming-pass", "--verify-windows", "4",
+           "--optimise-only-steps", "0", "--closed-loop-frames", "0", "--confined-steps", "0", "--extract-only-steps", "0", "--random-views-steps", "0",
+           "--mapping-only-steps", "0", "--unpipelined-steps", "0", "--deterministic-steps", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-1000:]
+    return json.loads(lines[-1])
+
+
+def test_cpp_driver_and_python_loop_run_the_same_step():
+    a = _run({})
+    b = _run({"CMS_BENCH_PY_DRIVER": "1"})
+    assert a["config"]["host"]["step_driver"].startswith("c++") and b["config"]["host"]["step_driver"].startswith("python")
+    for j in (a, b):
+        chk = j["config"]["ba_check"]
+        n_ba = j["config"]["ba_windows_per_step"]
+        assert chk["windows_with_iterations_and_outlier_flags_equal_to_the_oracle"] == n_ba, chk
+        assert chk["worst_relative_update_error"] <= 1e-4 or chk["windows_with_a_float_rounding_cascade"], chk
+        assert j["roofline"]["launches_per_step"] > 10 and j["config"]["new_map_points_per_step"] > 0
+    assert a["config"]["python_step_loop"] is not None
+    ratio = a["value"] / b["value"]
+    assert 0.6 < ratio < 1.7, (a["value"], b["value"])

@@ -1393,6 +1393,8 @@ def test_ba_create_many_and_read_many_equal_the_single_window_calls():
     o = np.random.default_rng(5).permutation(len(probs[2]["e_pose"]))
     probs[2] = dict(probs[2], **{k: np.ascontiguousarray(probs[2][k][o]) for k in ("e_pose", "e_point", "e_obs", "e_invsig2", "e_face")})
     probs.append(synth.ba_problem(K=12, P=2500, obs_per_point=4, F=550, seed=75, views="random"))
+    probs[1] = api.pin_problem(probs[1])            # CMS_BA_INPUTS_PINNED: this window's arrays are copied to the device from the caller's pinned memory, unstaged
+    probs[4] = api.pin_problem(probs[4])            # (... and a host-planned window with the flag)
     many = api.ba_create_many(probs, threads=3)
     keys = ("pinv", "perm", "info", "pt_off", "e_pose", "e_point", "e_face", "chunk_e0", "rm_chunk", "rm_cost", "run_mf", "run_fl")
     for i, p in enumerate(probs):
