@@ -417,6 +417,12 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   const bool use_s3 = gm.use_s3;
   int s3_threads = 64; size_t lds3 = 0;
   for (int w = 0; w < n; ++w) { s3_threads = std::max(s3_threads, ba_s3_threads(bas[w]->np)); lds3 = std::max(lds3, bas[w]->blk3_lds); }
+  {
+    // CMS_BA_SOLVE_LDS_KB=k: the solve kernel asks for k KB of LDS whatever it needs -- with ~150 it has its compute unit to itself as far as LDS-using kernels
+    // go (developer A/B: how much of its 2-3x longer duration inside bench.py's step is other kernels' wavefronts on the same CU?)
+    static const int solve_kb = [] { const char* v = getenv("CMS_BA_SOLVE_LDS_KB"); return v ? atoi(v) : 0; }();
+    if (solve_kb > 0) lds3 = std::max(lds3, std::min((size_t)solve_kb * 1024, (size_t)BA_LDS_CEILING));
+  }
   int max_seR = 0, max_np2 = 0, max_Rt = 0; size_t se_lds = 0, te_lds = 0, rm_lds = 0;
   const int se_waves = gm.se_waves;
   bool any_runs = false, any_rw0 = false, any_rw1 = false;
