@@ -442,6 +442,15 @@ def main():
         probs = prob_sets[0]
     host = host_budget(world, local_rank, args.window_threads)      # the ranks of a node split its usable cores (and are pinned to their slice)
     host["blocking_sync"] = bool(blocking_sync)
+    # A rank short of cores lets the device plan its windows (cms_ba_window.flags |= CMS_BA_PLAN_ON_DEVICE: k_ba_plan_many, byte-identical device arrays): the plans are
+    # half of a two-core rank's CPU time per step.  With cores to spare the host's plan stays: its windows become ready spread over the step and the Levenberg rounds
+    # overlap the frame path better (profiles/r06_bench_runs.txt).  CMS_BENCH_PLAN_ON_DEVICE=1 / 0 overrides.
+    pod_env = os.environ.get("CMS_BENCH_PLAN_ON_DEVICE", "")
+    plan_on_device = (pod_env == "1") if pod_env in ("0", "1") else host["thread_budget"] <= 2
+    host["window_plans"] = "device (k_ba_plan_many)" if plan_on_device else "host threads"
+    if plan_on_device:
+        for p in all_probs:
+            p["_plan_on_device"] = True
     n_wthreads = host["window_threads"]
     wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
     group_stream = []           # one long-lived stream per window group (filled below): CreateNewMapPoints and the group's BA rounds

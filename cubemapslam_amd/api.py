@@ -748,7 +748,7 @@ class BundleAdjuster:
                                        _p(out["e_face"]), _p(out["chunk_e0"]), _p(out["rm_chunk"]), _p(out["rm_cost"]), _p(out["run_mf"]), _p(out["run_fl"]), _p(cnt)),
              "cms_ba_debug_fetch_plan")
         nch, n_rm, nr = int(cnt[0]), int(cnt[1]), int(cnt[2])
-        out.update(n_chunks=nch, n_rm=n_rm, n_runs=nr, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), device_planned=bool(cnt[7]))
+        out.update(n_chunks=nch, n_rm=n_rm, n_runs=nr, np=int(cnt[3]), rm_points=int(cnt[4]), R_rm=int(cnt[5]), R=int(cnt[6]), device_planned=bool(cnt[7]), plan_kernel=int(cnt[7]) == 2)
         out["chunk_e0"] = out["chunk_e0"][:nch + 1].copy(); out["rm_chunk"] = out["rm_chunk"][:n_rm].copy(); out["rm_cost"] = out["rm_cost"][:nch + 1].copy()
         out["run_mf"] = out["run_mf"][:nr].copy(); out["run_fl"] = out["run_fl"][:nr].copy()
         return out
@@ -864,7 +864,7 @@ def ba_window_array(probs):
         q.K = len(a[0]); q.poses = a[0].ctypes.data; q.fixed = a[1].ctypes.data; q.P = len(a[2]); q.points = a[2].ctypes.data; q.E = len(a[3])
         q.e_pose = a[3].ctypes.data; q.e_point = a[4].ctypes.data; q.e_obs = a[5].ctypes.data; q.e_invsig2 = a[6].ctypes.data; q.e_face = a[7].ctypes.data
         q.fx = p["fx"]; q.fy = p["fy"]; q.cx = p["cx"]; q.cy = p["cy"]
-        q.flags = 1 if p.get("_pinned") else 0      # CMS_BA_INPUTS_PINNED: pin_problem() made the arrays
+        q.flags = (1 if p.get("_pinned") else 0) | (2 if p.get("_plan_on_device") else 0)      # CMS_BA_INPUTS_PINNED: pin_problem() made the arrays; CMS_BA_PLAN_ON_DEVICE
     return arr, keep
 
 

@@ -75,6 +75,9 @@ static const BaKnobs& ba_knobs() {
 
 struct BaExpand;
 static thread_local BaExpand* ba_tl_defer_expand = nullptr;      // cms_ba_create_many: where cms_ba_create leaves the description of a device-planned window's expansion instead of launching it
+struct BaDevPlan;
+static thread_local BaDevPlan* ba_tl_dev_plan = nullptr;      // cms_ba_create_many, CMS_BA_PLAN_ON_DEVICE: where cms_ba_create leaves the description of the window's plan kernel (taken: set to nullptr)
+static thread_local hipStream_t ba_tl_setup_stream = nullptr;      // cms_ba_create_many: the stream the calling thread's windows of this call are set up on (ba_setup_stream_take)
 static thread_local bool ba_tl_inputs_pinned = false;      // cms_ba_create_many, CMS_BA_INPUTS_PINNED: the caller's arrays are pinned and stay alive -- they are copied from where they lie
 static thread_local bool ba_force_rw_tables = false;      // cms_ba_debug_run_fg: build the one-wavefront workgroups' tables whatever the knob says
 static inline bool ba_want_rw_tables() { return ba_knobs().run_wg || ba_force_rw_tables; }
@@ -127,6 +130,9 @@ struct cms_ba {
   bool fast_plan = false;    // planned by ba_plan_fast (cms_api_ba_plan.hip): the permutations and the per-edge arrays exist on the device only
   int* d_raw_pose = nullptr; int* d_raw_point = nullptr; int8_t* d_raw_face = nullptr; int* d_prank = nullptr; int* d_cpo = nullptr; int* d_cedge = nullptr;
   uint8_t* d_pcopy = nullptr; uint8_t* d_lo_copy = nullptr; uint64_t* d_run_sig = nullptr; int* d_iperm = nullptr;
+  bool dev_plan = false;     // ... and planned by k_ba_plan_many (cms_api_ba_devplan.hip): the host learns the counts from h_plan_counts once the kernel is through
+  int* d_plan_counts = nullptr; int* h_plan_counts = nullptr; size_t h_plan_counts_bytes = 0;
+  long long* d_plan_clk = nullptr;      // developer: CMS_BA_DP_CLK=1
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
   hipEvent_t ev_setup = nullptr;      // cms_ba_set_stream: marks the end of the window's set-up on the stream it was created on
@@ -199,6 +205,23 @@ static void ba_stream_give(int device, hipStream_t s) {
     if (device >= 0 && device < 64 && pl.idle[device].size() < 256 && (q == hipSuccess || q == hipErrorNotReady)) { pl.idle[device].push_back(s); return; }
   }
   hipStreamDestroy(s);
+}
+// set-up streams of cms_ba_create_many: a pool of their own -- such a stream never becomes a window's own stream, windows only reference it (own_stream = false)
+// until cms_ba_set_stream moves them, so it may be handed to the next call while earlier windows still point at it.  Never destroyed (no HIP calls at exit).
+static BaStreamPool& ba_setup_stream_pool() { static BaStreamPool* p = new BaStreamPool; return *p; }
+static hipStream_t ba_setup_stream_take(int device) {
+  BaStreamPool& pl = ba_setup_stream_pool();
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (device >= 0 && device < 64 && !pl.idle[device].empty()) { hipStream_t s = pl.idle[device].back(); pl.idle[device].pop_back(); return s; }
+  }
+  hipStream_t s = nullptr;
+  return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
+}
+static void ba_setup_stream_give(int device, hipStream_t s) {
+  BaStreamPool& pl = ba_setup_stream_pool();
+  std::lock_guard<std::mutex> lk(pl.mu);
+  if (device >= 0 && device < 64) pl.idle[device].push_back(s);
 }
 // events for such hand-overs, pooled like the streams
 struct BaEventPool { std::mutex mu; std::vector<hipEvent_t> idle[64]; };
@@ -343,7 +366,8 @@ template <class T> static int ba_alloc(cms_ba* b, T** p, size_t n) {
   const size_t need = (((n > 0 ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
   if (b->slabs.empty() || b->slab_off + need > b->slabs.back().bytes) {
     const size_t kk = (size_t)std::min(b->K, 26);       // (the edge-major partial sums exist for up to 25 free key frames)
-    const size_t first = (size_t)b->E * 176 + (size_t)b->P * 416 + kk * kk * 22000 + ((size_t)1 << 20);
+    const size_t first = (size_t)b->E * 176 + (size_t)b->P * 416 + kk * kk * 22000 + ((size_t)1 << 20) +
+                         (b->dev_plan ? (size_t)b->E * 8 + (size_t)b->P * 96 + ((size_t)5 << 20) : 0);      // (the plan kernel's scratch and its tables sized by bounds)
     size_t want = std::max(need, b->slabs.empty() ? first : (size_t)4 << 20);
     void* sp = nullptr; size_t got = 0;
     hipError_t e = ba_dev_take(b->device, want, &sp, &got);
@@ -368,6 +392,7 @@ extern "C" void cms_ba_destroy(cms_ba* b) {
   if (b->async_pending && b->grp_stream && b->grp_stream != b->stream) (void)ba_wait_stream(b->grp_stream);
   for (const BaBlock& sl : b->slabs) ba_dev_give(b->device, sl.p, sl.bytes);
   if (b->h_pin) ba_pin_give(b->device, b->h_pin, b->h_pin_bytes);
+  if (b->h_plan_counts) ba_pin_give(b->device, b->h_plan_counts, b->h_plan_counts_bytes);
   if (b->h_stage) ba_stage_give(b->device, b->h_stage, b->h_stage_bytes);
   if (b->grp_items_host) ba_pin_give(b->device, b->grp_items_host, b->grp_pin_bytes[0]);
   if (b->grp_scal_host) ba_pin_give(b->device, b->grp_scal_host, b->grp_pin_bytes[1]);
@@ -1151,6 +1176,7 @@ extern "C" int cms_ba_debug_plan(int K, const uint8_t* fixed, int P, int E, cons
 }
 
 #include "cms_api_ba_plan.hip"
+#include "cms_api_ba_devplan.hip"
 
 // edge i of the internal order is the caller's edge perm[i], point i the caller's point pinv[i]: measurements, informations and initial positions
 // into that order (cms_ba_create uploads the caller's arrays untouched) -- and, in the same launch, what k_ba_reset does for a window that
@@ -1209,6 +1235,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     int lo = 0, hi = 0;
     if (ba_knobs().stream_priority == 'l' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
       BA_HIP(hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, lo));
+    else if (ba_tl_setup_stream) { b->stream = ba_tl_setup_stream; b->own_stream = false; }
     else {
       b->stream = ba_stream_take(device);
       if (!b->stream) BA_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
@@ -1223,7 +1250,13 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   BaFastPlan& fp = tl_fp;
   // the device-side planner for the windows it takes (cms_api_ba_plan.hip: one pass over the observations on the host, the rest per point);
   // it validates the indices in that pass.  Everything else: the host plan, after the validation loop
-  const int fast_rc = ba_tl_force_host_plan ? 0 : ba_plan_fast(b, fp, K, fixed, P, E, e_pose, e_point, e_face, tick);
+  // ... or, inside a cms_ba_create_many call with CMS_BA_PLAN_ON_DEVICE, the plan kernel (cms_api_ba_devplan.hip): the host only checks what does not need
+  // the observations, the kernel validates the indices and says so in its status word
+  BaDevPlan* const dplan = ba_tl_force_host_plan ? nullptr : ba_tl_dev_plan;
+  unsigned long long dp_free_mask = 0;
+  const bool devp = dplan && ba_dev_plan_prepare(b, K, fixed, P, E, pl.pose_slot, dp_free_mask);
+  b->dev_plan = devp;
+  const int fast_rc = devp ? 1 : ba_tl_force_host_plan ? 0 : ba_plan_fast(b, fp, K, fixed, P, E, e_pose, e_point, e_face, tick);
   const bool fast = fast_rc > 0;
   bool bad_index = fast_rc < 0;
   if (!fast && !bad_index)
@@ -1234,7 +1267,8 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     return cms_fail(CMS_ERR_ARG, "cms_ba_create: edge index / face out of range (unknown-face edges must be culled by the caller)");
   }
   b->fast_plan = fast;
-  if (fast) pl.pose_slot = fp.pose_slot;
+  if (devp) {}
+  else if (fast) pl.pose_slot = fp.pose_slot;
   else ba_plan(b, pl, K, fixed, P, E, e_pose, e_point, e_obs, e_invsig2, e_face, tick);
   std::vector<int>&pose_slot = pl.pose_slot, &prank = pl.prank, &s_pose = pl.s_pose, &s_point = pl.s_point, &pt_off = pl.pt_off, &pose_off = pl.pose_off, &pose_edges = pl.pose_edges;
   std::vector<double>&s_obs = pl.s_obs, &s_inv = pl.s_inv;
@@ -1256,7 +1290,20 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
     BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42));
     b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial;
   }
-  if (fast) {
+  const int dp_run_cap = devp ? std::min(BA_DP_RUN_CAP + 1, P / 7 + 1) : 0, dp_chunk_cap = devp ? E / 28 + dp_run_cap + 16 : 0;
+  if (devp) {
+    // what the plan kernel writes (sized by bounds: a chunk holds >= 28 observations or is the last of its run / segment) and the two tables that follow from np alone
+    const int NP2 = np * (np + 1) / 2;
+    fp.pob.assign((size_t)NP2, 0); fp.ident.resize((size_t)NP2 + 1);
+    for (int I = 0; I < np; ++I)
+      for (int Kc = 0; Kc <= I; ++Kc) fp.pob[(size_t)I * (I + 1) / 2 + Kc] = Kc * np - (Kc * (Kc - 1)) / 2 + (I - Kc);
+    for (int i = 0; i <= NP2; ++i) fp.ident[i] = i;
+    up(fp.pob.data(), fp.pob.size() * sizeof(int), &b->d_se_pob); up(fp.ident.data(), fp.ident.size() * sizeof(int), &b->d_se_chunk_off);
+    BA_TRY(ba_alloc(b, &b->d_se_chunk_e0, (size_t)dp_chunk_cap + 1)); BA_TRY(ba_alloc(b, &b->d_se_lone, (size_t)P)); BA_TRY(ba_alloc(b, &b->d_rm_chunk, (size_t)dp_chunk_cap));
+    BA_TRY(ba_alloc(b, &b->d_rm_cost, (size_t)dp_chunk_cap + 1)); BA_TRY(ba_alloc(b, &b->d_run_sig, (size_t)dp_run_cap)); BA_TRY(ba_alloc(b, &b->d_rm_cut, 1));
+    BA_TRY(ba_alloc(b, &b->d_se_info, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_run_mf, (size_t)dp_run_cap * 64));
+    BA_TRY(ba_alloc(b, &b->d_run_fl, (size_t)dp_run_cap * 64 * 12)); BA_TRY(ba_alloc(b, &b->d_run_lane, 1));
+  } else if (fast) {
     up(fp.ce0.data(), fp.ce0.size() * sizeof(int), &b->d_se_chunk_e0); up(fp.pob.data(), fp.pob.size() * sizeof(int), &b->d_se_pob);
     up(fp.ident.data(), fp.ident.size() * sizeof(int), &b->d_se_chunk_off); up(fp.lone.data(), fp.lone.size() * sizeof(int), &b->d_se_lone);
     up(fp.rm_chunk.data(), fp.rm_chunk.size() * sizeof(int4), &b->d_rm_chunk); up(fp.rm_cost.data(), fp.rm_cost.size() * sizeof(uint32_t), &b->d_rm_cost);
@@ -1472,9 +1519,17 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   if (fast) {
     // the caller's index arrays as they are; sorted edge arrays, per-edge words and the edge permutation are written by k_ba_expand_edges
     up_in(e_pose, E * sizeof(int), &b->d_raw_pose); up_in(e_point, E * sizeof(int), &b->d_raw_point); up_in(e_face, E, &b->d_raw_face);
+    if (devp) {
+      BA_TRY(ba_alloc(b, &b->d_pt_off, (size_t)P + 1)); BA_TRY(ba_alloc(b, &b->d_prank, (size_t)P)); BA_TRY(ba_alloc(b, &b->d_pinv, (size_t)P));
+      BA_TRY(ba_alloc(b, &b->d_cpo, (size_t)P + 1)); BA_TRY(ba_alloc(b, &b->d_pcopy, (size_t)P)); BA_TRY(ba_alloc(b, &b->d_lo_copy, (size_t)E));
+      BA_TRY(ba_alloc(b, &b->d_cedge, (size_t)E)); BA_TRY(ba_alloc(b, &b->d_plan_counts, BA_DP_COUNTS));
+      BA_HIP(ba_pin_take(device, BA_DP_COUNTS * sizeof(int), (void**)&b->h_plan_counts, &b->h_plan_counts_bytes));
+      b->h_plan_counts[0] = 0;
+    } else {
     up(fp.pt_off.data(), (P + 1) * sizeof(int), &b->d_pt_off); up(fp.prank.data(), P * sizeof(int), &b->d_prank); up(fp.pinv.data(), P * sizeof(int), &b->d_pinv);
     up(fp.cpo.data(), (P + 1) * sizeof(int), &b->d_cpo); up(fp.pcopy.data(), P, &b->d_pcopy); up(fp.lo_copy.data(), fp.lo_copy.size(), &b->d_lo_copy);
     if (!fp.grouped) up(fp.cedge.data(), E * sizeof(int), &b->d_cedge);
+    }
     // (the per-key-frame edge lists serve kb_ba_lin, which a group of such windows never launches: an empty CSR)
     zero_off.assign(K + 1, 0);
     up(zero_off.data(), (K + 1) * sizeof(int), &b->d_pose_off);
@@ -1536,13 +1591,31 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   if (fast) {
     BaExpand x;
     x.K = K; x.P = P; x.E = E; x.np = np;
-    x.e_pose = b->d_raw_pose; x.e_point = b->d_raw_point; x.e_face = b->d_raw_face; x.cedge = fp.grouped ? nullptr : b->d_cedge; x.cpo = b->d_cpo;
-    x.prank = b->d_prank; x.pinv = b->d_pinv; x.pt_off = b->d_pt_off; x.pcopy = b->d_pcopy; x.lo_copy = b->d_lo_copy; x.e_lo0 = fp.pt_off[fp.P_rm]; x.pose_slot = b->d_pose_slot;
+    x.e_pose = b->d_raw_pose; x.e_point = b->d_raw_point; x.e_face = b->d_raw_face; x.cedge = devp ? b->d_cedge : fp.grouped ? nullptr : b->d_cedge; x.cpo = b->d_cpo;
+    x.prank = b->d_prank; x.pinv = b->d_pinv; x.pt_off = b->d_pt_off; x.pcopy = b->d_pcopy; x.lo_copy = b->d_lo_copy; x.e_lo0 = devp ? 0 : fp.pt_off[fp.P_rm]; x.pose_slot = b->d_pose_slot;
+    x.dcounts = devp ? b->d_plan_counts : nullptr;             // (a window planned on the device: the counts below and `grouped` are read from there)
     x.raw_obs = b->d_raw_obs; x.raw_inv = b->d_raw_inv; x.raw_pts = b->d_raw_pts; x.poses0 = b->d_poses0;
     x.perm = b->d_perm; x.iperm = b->d_iperm; x.s_pose = b->d_e_pose; x.s_point = b->d_e_point; x.s_face = b->d_e_face; x.info = b->d_se_info;
     x.e_obs = b->d_e_obs; x.e_inv = b->d_e_inv; x.pts0 = b->d_pts0; x.poses = b->d_poses[0]; x.pts = b->d_pts[0]; x.level = b->d_level; x.err = b->d_err; x.flags = b->d_flags;
     x.gsum = b->d_se_partial; x.n_gsum = b->se.npairs2 * 42; x.gsum_bp = b->d_se_bp_partial; x.n_gsum_bp = b->np * 6;
-    x.ce0 = b->d_se_chunk_e0; x.n_rm = fp.n_rm; x.nchunks = fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl; x.run_fg = b->d_run_fg;
+    x.ce0 = b->d_se_chunk_e0; x.n_rm = devp ? 0 : fp.n_rm; x.nchunks = devp ? 0 : fp.nchunks; x.run_sig = b->d_run_sig; x.n_runs = devp ? 0 : fp.n_runs; x.run_mf = b->d_run_mf; x.run_fl = b->d_run_fl; x.run_fg = b->d_run_fg;
+    if (devp) {
+      // scratch of the plan kernel + its description; cms_ba_create_many launches it in front of the expansion
+      BaDevPlan dp;
+      memset(&dp, 0, sizeof(dp));
+      dp.K = K; dp.P = P; dp.E = E; dp.np = np; dp.chunk_cap = dp_chunk_cap; dp.em_cost_a = kn.em_cost_a; dp.em_cost_b = kn.em_cost_b; dp.free_mask = dp_free_mask;
+      dp.e_pose = b->d_raw_pose; dp.e_point = b->d_raw_point; dp.e_face = b->d_raw_face; dp.pose_slot = b->d_pose_slot;
+      BA_TRY(ba_alloc(b, &dp.cnt, (size_t)P)); BA_TRY(ba_alloc(b, &dp.sig, (size_t)P)); BA_TRY(ba_alloc(b, &dp.sig_i, (size_t)P)); BA_TRY(ba_alloc(b, &dp.hkey, (size_t)BA_DP_HCAP));
+      BA_TRY(ba_alloc(b, &dp.gslot, (size_t)P)); BA_TRY(ba_alloc(b, &dp.ord, (size_t)P)); BA_TRY(ba_alloc(b, &dp.scan, (size_t)P + 1)); BA_TRY(ba_alloc(b, &dp.cnt_i, (size_t)P));
+      BA_TRY(ba_alloc(b, &dp.seg_tmp, (size_t)P)); BA_TRY(ba_alloc(b, &dp.run_tab, (size_t)(BA_DP_RUN_CAP + 1) * 8)); BA_TRY(ba_alloc(b, &dp.chunk_pt0, (size_t)dp_chunk_cap + 1));
+      BA_TRY(ba_alloc(b, &dp.chunk_run, (size_t)dp_chunk_cap + 1));
+      dp.cpo = b->d_cpo; dp.cedge = b->d_cedge; dp.prank = b->d_prank; dp.pinv = b->d_pinv; dp.pt_off = b->d_pt_off; dp.pcopy = b->d_pcopy; dp.lo_copy = b->d_lo_copy;
+      dp.ce0 = b->d_se_chunk_e0; dp.rm_chunk = b->d_rm_chunk; dp.rm_cost = b->d_rm_cost; dp.run_sig = reinterpret_cast<unsigned long long*>(b->d_run_sig); dp.lone = b->d_se_lone;
+      dp.counts = b->d_plan_counts; dp.h_counts = b->h_plan_counts;
+      static const bool dp_clk = getenv("CMS_BA_DP_CLK") != nullptr;
+      if (dp_clk) { BA_TRY(ba_alloc(b, &b->d_plan_clk, 16)); dp.clk = b->d_plan_clk; }
+      *dplan = dp; ba_tl_dev_plan = nullptr;
+    }
     if (ba_tl_defer_expand) { *ba_tl_defer_expand = x; ba_tl_defer_expand = nullptr; }      // cms_ba_create_many launches the group's expansions together
     else hipLaunchKernelGGL(k_ba_expand_edges, dim3(std::min((std::max(E, P) + 255) / 256, 1024)), dim3(256), 0, b->stream, x);      // (+ the runs' tables)
   } else
@@ -1562,7 +1635,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
 // developer / test entry: the plan arrays AS THE DEVICE HOLDS THEM (after the window's set-up has run), whichever planner made them -- for the
 // comparison of the device-side planner with cms_ba_debug_plan.  Sizes: pinv P, perm E, info E, pt_off P + 1, e_pose / e_point E, e_face E,
 // chunk_e0 chunks + 1 (<= P + 2), rm_chunk 4 ints per run chunk, rm_cost chunks + 1, run_mf 64 / run_fl 768 words per run; any pointer may be NULL.
-// counts[8] = chunks, run chunks, runs, free key frames, points inside runs, R_rm, R, 1 if the device-side planner made the window.
+// counts[8] = chunks, run chunks, runs, free key frames, points inside runs, R_rm, R, 1 if the device-side planner made the window (2: all of it in the plan kernel).
 extern "C" int cms_ba_debug_fetch_plan(cms_ba* b, int* pinv, int* perm, uint32_t* info, int* pt_off, int* e_pose, int* e_point, int8_t* e_face, int* chunk_e0,
                                        int* rm_chunk, uint32_t* rm_cost, uint32_t* run_mf, uint32_t* run_fl, int* counts) {
   if (!b || !counts) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_fetch_plan: bad argument");
@@ -1571,7 +1644,7 @@ extern "C" int cms_ba_debug_fetch_plan(cms_ba* b, int* pinv, int* perm, uint32_t
   HIPCHK(hipStreamSynchronize(b->stream));
   b->async_pending = false;
   const int nch = b->se.nchunks, n_rm = b->se.n_rm, nr = b->n_runs;
-  counts[0] = nch; counts[1] = n_rm; counts[2] = nr; counts[3] = b->np; counts[4] = b->rm_points; counts[5] = b->se.R_rm; counts[6] = b->se.R; counts[7] = b->fast_plan ? 1 : 0;
+  counts[0] = nch; counts[1] = n_rm; counts[2] = nr; counts[3] = b->np; counts[4] = b->rm_points; counts[5] = b->se.R_rm; counts[6] = b->se.R; counts[7] = b->dev_plan ? 2 : b->fast_plan ? 1 : 0;
   auto dl = [&](void* dst, const void* src, size_t bytes) -> int {
     if (!dst || !src || bytes == 0) return CMS_OK;
     return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? CMS_OK : cms_fail(CMS_ERR_HIP, "cms_ba_debug_fetch_plan: copy");
@@ -1714,21 +1787,36 @@ extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_
   for (int i = 0; i < n; ++i) out[i] = nullptr;
   if (n == 0) return CMS_OK;
   std::vector<BaExpand> xs((size_t)n);
+  std::vector<BaDevPlan> dps((size_t)n);
+  static const bool dev_plan_all = getenv("CMS_BA_DEV_PLAN") != nullptr;      // A/B: every window of every call, whatever its flags say
   std::vector<char> deferred((size_t)n, 0);
   std::vector<int> rcs((size_t)n, CMS_OK);
   std::vector<std::string> errs((size_t)n);
   std::atomic<int> next(0);
+  // The windows a thread of this call builds are set up on ONE stream (uploads, the plan kernel, the expansion), taken from a small pool of set-up streams:
+  // every window on a pooled stream of its own spread a group's ~100 upload commands over all hardware queues, in front of whatever the frame path and the
+  // Levenberg rounds had there -- measured on bench.py's step (profiles/r06_bench_runs.txt): 21.2 -> 22.4 k frames/s with four host cores, and what makes the
+  // plan kernel pay (17.3 -> 20.5 k with two).  A window keeps the stream until cms_ba_set_stream moves it.  CMS_BA_SETUP_OWN_STREAMS=1: as before (A/B).
+  static const bool shared_stream = getenv("CMS_BA_SETUP_OWN_STREAMS") == nullptr;
+  std::mutex ss_mu; std::vector<hipStream_t> ss_taken;
   auto work = [&]() {
+    if (shared_stream && hipSetDevice(device) == hipSuccess) {
+      hipStream_t st = ba_setup_stream_take(device);
+      ba_tl_setup_stream = st;
+      if (st) { std::lock_guard<std::mutex> lk(ss_mu); ss_taken.push_back(st); }
+    }
+    struct Reset { ~Reset() { ba_tl_setup_stream = nullptr; } } reset_;
     for (;;) {
       const int i = next.fetch_add(1);
       if (i >= n) break;
       memset(&xs[(size_t)i], 0, sizeof(BaExpand));
       ba_tl_defer_expand = &xs[(size_t)i];
+      ba_tl_dev_plan = (dev_plan_all || (w[i].flags & CMS_BA_PLAN_ON_DEVICE) != 0) ? &dps[(size_t)i] : nullptr;
       ba_tl_inputs_pinned = (w[i].flags & CMS_BA_INPUTS_PINNED) != 0;
       rcs[(size_t)i] = cms_ba_create(&out[i], device, w[i].K, w[i].poses, w[i].fixed, w[i].P, w[i].points, w[i].E, w[i].e_pose, w[i].e_point, w[i].e_obs, w[i].e_invsig2,
                                      w[i].e_face, w[i].fx, w[i].fy, w[i].cx, w[i].cy);
       deferred[(size_t)i] = ba_tl_defer_expand == nullptr && rcs[(size_t)i] == CMS_OK;      // (taken: a device-planned window; a host-planned one launched its own set-up kernel)
-      ba_tl_defer_expand = nullptr; ba_tl_inputs_pinned = false;
+      ba_tl_defer_expand = nullptr; ba_tl_inputs_pinned = false; ba_tl_dev_plan = nullptr;
       if (rcs[(size_t)i] != CMS_OK) errs[(size_t)i] = cms_last_error();
     }
   };
@@ -1742,6 +1830,7 @@ extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_
     std::unique_lock<std::mutex> lk(dmu);
     dcv.wait(lk, [&]() { return running == 0; });
   }
+  struct GiveBack { std::vector<hipStream_t>& v; int dev; ~GiveBack() { for (hipStream_t st : v) ba_setup_stream_give(dev, st); } } give_back_{ss_taken, device};      // (with work queued: the next call's set-ups line up behind it)
   auto fail_all = [&](int rc, const char* msg) {
     for (int i = 0; i < n; ++i) if (out[i]) { cms_ba_destroy(out[i]); out[i] = nullptr; }
     return cms_fail(rc, msg);
@@ -1752,6 +1841,8 @@ extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_
   for (int i = 0; i < n; ++i) if (deferred[(size_t)i]) D.push_back(i);
   if (D.empty()) return CMS_OK;
   if (hipSetDevice(device) != hipSuccess) return fail_all(CMS_ERR_HIP, "cms_ba_create_many: hipSetDevice");
+  static_assert(BA_DP_BATCH == BA_EXPAND_BATCH, "a batch of expansions has one batch of plans in front of it");
+  std::vector<hipStream_t> plan_streams;
   for (size_t b0 = 0; b0 < D.size(); b0 += BA_EXPAND_BATCH) {
     const int nb = (int)std::min<size_t>(BA_EXPAND_BATCH, D.size() - b0);
     cms_ba* lead = out[D[b0]];
@@ -1770,6 +1861,20 @@ extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_
       }
     }
     for (int k = nb; k < BA_EXPAND_BATCH; ++k) batch.x[k] = batch.x[0];
+    {
+      // the windows of the batch whose plan the device makes: one workgroup each, in front of the expansion
+      BaDevPlanBatch pb;
+      int nd = 0;
+      for (int k = 0; k < nb; ++k) if (out[D[b0 + k]]->dev_plan) pb.x[nd++] = dps[(size_t)D[b0 + k]];
+      for (int k = nd; k < BA_DP_BATCH && nd > 0; ++k) pb.x[k] = pb.x[0];
+      if (nd > 0 && re == hipSuccess) {
+        re = ba_dev_plan_attr_once(device);
+        if (re == hipSuccess) hipLaunchKernelGGL(k_ba_plan_many, dim3(nd), dim3(BA_DP_THREADS), BA_DP_LDS, lead->stream, pb);
+        if (re == hipSuccess) re = hipGetLastError();
+        if (re == hipSuccess) { hipLaunchKernelGGL(k_ba_match_copies_many, dim3(BA_DP_MATCH_BLOCKS, nd), dim3(64), 0, lead->stream, pb); re = hipGetLastError(); }
+        plan_streams.push_back(lead->stream);
+      }
+    }
     if (re == hipSuccess) {
       hipLaunchKernelGGL(k_ba_expand_edges_many, dim3(std::min((maxEP + 255) / 256, 1024), nb), dim3(256), 0, lead->stream, batch);
       re = hipGetLastError();
@@ -1781,6 +1886,22 @@ extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_
     }
     ba_event_give(device, ev);      // (a wait that is already enqueued keeps the record it saw)
     if (re != hipSuccess) return fail_all(CMS_ERR_HIP, "cms_ba_create_many: launch failed");
+  }
+  // ---- windows planned on the device: the counts that size their launches are on the host once the plan kernels are through.  A window the kernel
+  // gave up on (a point seen twice by a key frame, no runs, ...) is built again with the host's planners; an index out of range fails the call
+  for (hipStream_t ps : plan_streams) if (ba_wait_stream(ps) != hipSuccess) return fail_all(CMS_ERR_HIP, "cms_ba_create_many: the plan kernel failed");
+  for (int i : D) {
+    cms_ba* b = out[i];
+    if (!b->dev_plan) continue;
+    const int prc = ba_dev_plan_finish(b);
+    if (prc == 1) continue;
+    if (prc < 0) return fail_all(CMS_ERR_ARG, "cms_ba_create: edge index / face out of range (unknown-face edges must be culled by the caller)");
+    cms_ba_destroy(b); out[i] = nullptr;
+    ba_tl_inputs_pinned = (w[i].flags & CMS_BA_INPUTS_PINNED) != 0;
+    const int rc = cms_ba_create(&out[i], device, w[i].K, w[i].poses, w[i].fixed, w[i].P, w[i].points, w[i].E, w[i].e_pose, w[i].e_point, w[i].e_obs, w[i].e_invsig2,
+                                 w[i].e_face, w[i].fx, w[i].fy, w[i].cx, w[i].cy);
+    ba_tl_inputs_pinned = false;
+    if (rc != CMS_OK) { const std::string msg = cms_last_error(); return fail_all(rc, msg.c_str()); }
   }
   return CMS_OK;
 }

@@ -80,6 +80,7 @@ struct BaExpand {
   // tables
   const int* ce0; int n_rm, nchunks;                                // chunk first edges; chunks [n_rm, nchunks) are the left-over ones
   const uint64_t* run_sig; int n_runs; uint32_t* run_mf; uint32_t* run_fl; uint32_t* run_fg;
+  const int* dcounts;                                               // non-NULL: the plan was made by k_ba_plan_many (cms_api_ba_devplan.hip) and n_rm, nchunks, n_runs, e_lo0, "grouped" are there
 };
 
 // one observation (position i of the caller's grouped order) / one table entry: the kernels' bodies, callable on the host too (cms_ba_debug_plan_fast
@@ -123,6 +124,7 @@ __host__ __device__ inline void ba_expand_table_at(const BaExpand& x, int u) {
 // kernel arguments; a larger group is two launches
 #define BA_EXPAND_BATCH 8
 struct BaExpandBatch { BaExpand x[BA_EXPAND_BATCH]; };
+static_assert(sizeof(BaExpandBatch) <= 4096, "k_ba_expand_edges_many: the batch must fit the kernel arguments");
 __device__ __forceinline__ void ba_expand_body(const BaExpand& x, int t0, int gs);
 extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges_many(BaExpandBatch b) {
   ba_expand_body(b.x[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
@@ -130,7 +132,13 @@ extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges_many(BaExpan
 extern "C" __global__ void __launch_bounds__(256) k_ba_expand_edges(BaExpand x) {
   ba_expand_body(x, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
-__device__ __forceinline__ void ba_expand_body(const BaExpand& x, int t0, int gs) {
+__device__ __forceinline__ void ba_expand_body(const BaExpand& xin, int t0, int gs) {
+  BaExpand x = xin;
+  if (x.dcounts) {                                                  // (BA_DP_COUNTS: status, chunks, run chunks, class-0 run chunks, runs, points inside runs, lone points, grouped, first left-over edge)
+    if (x.dcounts[0] != 1) return;                                  // the plan kernel gave the window up: the host plans it again
+    x.nchunks = x.dcounts[1]; x.n_rm = x.dcounts[2]; x.n_runs = x.dcounts[4]; x.e_lo0 = x.dcounts[8];
+    if (x.dcounts[7]) x.cedge = nullptr;
+  }
   for (int i = t0; i < x.E; i += gs) ba_expand_edge_at(x, i);
   for (int u = t0; u < 64 * x.n_runs; u += gs) ba_expand_table_at(x, u);
   for (int i = t0; i < x.P; i += gs) {

@@ -178,13 +178,20 @@ int cms_ba_create(cms_ba** out, int device, int K, const double* poses, const ui
 typedef struct cms_ba_window {
   int K; const double* poses; const uint8_t* fixed; int P; const double* points; int E; const int* e_pose; const int* e_point;
   const double* e_obs; const double* e_invsig2; const int8_t* e_face; double fx, fy, cx, cy;
-  int flags;      /* CMS_BA_INPUTS_PINNED or 0 */
+  int flags;      /* CMS_BA_INPUTS_PINNED | CMS_BA_PLAN_ON_DEVICE, or 0 */
 } cms_ba_window;
 /* flags: the window's observation-sized arrays (points, e_pose, e_point, e_obs, e_invsig2, e_face) lie in pinned host memory (cms_host_alloc, or registered with
  * the HIP runtime) and stay unchanged and alive until the window's first cms_ba_optimize* / cms_ba_read has returned or the window is destroyed: they are then
  * copied to the device from where they lie, asynchronously, instead of through the window's staging block -- a host that assembles a window's observations
  * (Optimizer.cpp:246-357) straight into pinned buffers saves one 3 MB memcpy per 80 k-observation window, as much host time as the window's whole plan. */
 #define CMS_BA_INPUTS_PINNED 1
+/* flags: the window's whole plan (signature groups, runs, internal point order, chunks, the left-over observations' diagonal copies) is made by a kernel
+ * (k_ba_plan_many, one workgroup per window, launched per eight windows in front of their expansion) instead of by the calling threads; the call then waits
+ * for those kernels (40 bytes of counts per window come back).  Same device arrays, byte for byte.  Worth it for a host short of cores -- the plan is
+ * ~0.4 ms of a host thread per 80 k-observation window, half of what a two-core rank spends per step of bench.py; with cores to spare the host plan overlaps
+ * the GPU better (bench.py sets the flag when its rank has at most two cores).  Windows the kernel does not take (a point seen twice by a key frame, no
+ * signature runs, more than 64 key frames, deterministic mode) fall back to the host planners inside the call; an index out of range fails the call as ever. */
+#define CMS_BA_PLAN_ON_DEVICE 2
 int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_window* windows, int threads);
 /* ... and the read-back of n optimised windows (Optimizer.cpp:419-450): poses[i] / points[i] / outlier_flags[i] as cms_ba_read's (the arrays of
  * pointers, or single entries, may be NULL); one gather kernel per sixteen device-planned windows, one wait. */

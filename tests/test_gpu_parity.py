@@ -1383,6 +1383,53 @@ def test_ba_device_plan_equals_host_plan(shuffle):
     ba.close()
 
 
+def test_ba_plan_kernel_equals_the_host_plan():
+    """CMS_BA_PLAN_ON_DEVICE: the WHOLE plan of a window by k_ba_plan_many (cms_api_ba_devplan.hip: one workgroup per window -- signature groups by open
+    addressing, the runs' order by prefix sums, a point's ordinal inside its group by wavefront matching + one ordered walk over the tiles, greedy packing of
+    the left-over points, the matching of their diagonal copies without recursion).  The device arrays must be byte-identical to those of the same window
+    created on its own (the host's planner): tracked windows of three sizes, one with its edges shuffled (not grouped by point), one with points nobody
+    observes, one larger than a batch of eight; windows the kernel gives up on -- random views (mostly left-over points), a point seen twice by a key frame --
+    come back planned by the host inside the same call; the group optimises to the oracle's results; an index out of range fails the call."""
+    probs = [synth.ba_problem(K=20, P=5000 + 700 * i, obs_per_point=4, F=550, seed=170 + i, views="track") for i in range(9)]
+    probs[0] = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=64, views="track")
+    o = np.random.default_rng(5).permutation(len(probs[2]["e_pose"]))
+    probs[2] = dict(probs[2], **{k: np.ascontiguousarray(probs[2][k][o]) for k in ("e_pose", "e_point", "e_obs", "e_invsig2", "e_face")})
+    # three points nobody observes: their observations go to the next point's key frames ... simply dropped
+    p3 = probs[3]; keep = ~np.isin(p3["e_point"], [5, 6, 1000])
+    probs[3] = dict(p3, **{k: np.ascontiguousarray(p3[k][keep]) for k in ("e_pose", "e_point", "e_obs", "e_invsig2", "e_face")})
+    probs.append(synth.ba_problem(K=12, P=2500, obs_per_point=4, F=550, seed=75, views="random"))        # [9]: the kernel gives it up
+    dup = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in probs[4].items()}               # [10]: a point seen twice by a key frame
+    dup["e_pose"][1] = dup["e_pose"][0] if dup["e_point"][1] == dup["e_point"][0] else dup["e_pose"][1]
+    assert dup["e_point"][1] == dup["e_point"][0]
+    probs.append(dup)
+    probs[1] = api.pin_problem(probs[1])
+    probs = [dict(p, _plan_on_device=True) for p in probs]
+    many = api.ba_create_many(probs, threads=3)
+    keys = ("pinv", "perm", "info", "pt_off", "e_pose", "e_point", "e_face", "chunk_e0", "rm_chunk", "rm_cost", "run_mf", "run_fl")
+    for i, p in enumerate(probs):
+        one = api.BundleAdjuster(p)
+        a, b = many[i].fetch_plan(), one.fetch_plan()
+        assert a["plan_kernel"] == (i < 9), (i, a["plan_kernel"])
+        assert a["device_planned"] == b["device_planned"], i
+        for k in ("n_chunks", "n_rm", "n_runs", "np", "rm_points", "R_rm", "R"):
+            assert a[k] == b[k], (i, k, a[k], b[k])
+        for k in keys:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (i, k)
+        one.close()
+    _, stats = api.ba_optimize_many(many[:9], (5, 10))
+    for i in range(9):
+        _check_window(i, many[i], probs[i], stats[i], tag="plan kernel")
+    for i in (9, 10):
+        _, st = many[i].optimize()
+        if i == 9:
+            _check_window(i, many[i], probs[i], st, tag="plan kernel (fallback)")
+    for b in many:
+        b.close()
+    bad = dict(probs[1]); bad["e_pose"] = probs[1]["e_pose"].copy(); bad["e_pose"][7] = 99
+    with pytest.raises(api.CmsError):
+        api.ba_create_many([probs[0], bad, probs[3]], threads=2)
+
+
 def test_ba_create_many_and_read_many_equal_the_single_window_calls():
     """A window group's set-up and read-back as one call each (cms_ba_create_many: host parts on several threads, ONE expansion launch per eight
     device-planned windows; cms_ba_read_many: one gather launch): the device arrays of every window must be byte-identical to those of the same window
