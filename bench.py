@@ -452,6 +452,11 @@ def main():
         for p in all_probs:
             p["_plan_on_device"] = True
     n_wthreads = host["window_threads"]
+    # threads of one cms_ba_create_many call (a group's 16 windows): every one of them sets its windows up on a stream of its own, and set-up streams compete with
+    # the frame path and the Levenberg rounds for the hardware queues -- ONE thread per group keeps up (16 plans of ~0.35 ms per ~11.5-ms step) and measured best
+    # (profiles/r06_bench_runs.txt: 1 / 2 / 3 / 4 threads per group = 23.0 / 22.2 / 22.1 / 21.7 k frames/s).  CMS_BENCH_CREATE_THREADS overrides.
+    create_threads = max(1, int(os.environ.get("CMS_BENCH_CREATE_THREADS", "1")))
+    host["create_threads_per_group"] = create_threads
     wpool = ThreadPoolExecutor(max_workers=n_wthreads)        # builds, reads back and destroys windows next to the running step
     group_stream = []           # one long-lived stream per window group (filled below): CreateNewMapPoints and the group's BA rounds
     cpu_acc = {"create": 0.0, "finish": 0.0, "n": 0}      # thread CPU seconds (developer knob CMS_BENCH_THREAD_CPU)
@@ -476,7 +481,7 @@ def main():
         key = tuple(id(p_) for p_ in mine)         # (the random-views pass swaps the problem sets: the descriptions belong to the problem OBJECTS)
         if key not in win_arrays:
             win_arrays[key] = (api.ba_window_array(mine), mine)
-        grp = api.ba_create_many(mine, device=local_rank, threads=max(1, n_wthreads // max(1, n_grp)), windows=win_arrays[key][0])
+        grp = api.ba_create_many(mine, device=local_rank, threads=create_threads, windows=win_arrays[key][0])
         if not own_streams:
             for ba in grp:
                 ba.set_stream(group_stream[gi])
@@ -1057,7 +1062,7 @@ def main():
         cpp_keep = []
         def make_plan(mapping_full):
             P_ = CbdPlan()
-            P_.ctx = ctx.h.value; P_.po = po.h.value; P_.B = B; P_.device = local_rank; P_.ngroups = n_grp; P_.create_threads = max(1, n_wthreads // max(1, n_grp))
+            P_.ctx = ctx.h.value; P_.po = po.h.value; P_.B = B; P_.device = local_rank; P_.ngroups = n_grp; P_.create_threads = create_threads
             P_.mapping_full = 1 if mapping_full else 0; P_.ahead = ahead; P_.n_pose_edges = int(po.off[-1])
             for j, S in enumerate(sets):
                 Q = P_.sets[j]
