@@ -449,8 +449,10 @@ def main():
     plan_on_device = (pod_env == "1") if pod_env in ("0", "1") else host["thread_budget"] <= 2
     host["window_plans"] = "device (k_ba_plan_many)" if plan_on_device else "host threads"
     if plan_on_device:
-        for p in all_probs:
-            p["_plan_on_device"] = True
+        frac = float(os.environ.get("CMS_BENCH_PLAN_ON_DEVICE_FRACTION", "1"))      # developer knob: only this share of the windows (the flag is per window)
+        for i, p in enumerate(all_probs):
+            if (i % 8) < round(8 * frac):
+                p["_plan_on_device"] = True
     n_wthreads = host["window_threads"]
     # threads of one cms_ba_create_many call (a group's 16 windows): every one of them sets its windows up on a stream of its own, and set-up streams compete with
     # the frame path and the Levenberg rounds for the hardware queues -- ONE thread per group keeps up (16 plans of ~0.35 ms per ~11.5-ms step) and measured best
