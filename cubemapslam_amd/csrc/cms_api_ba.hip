@@ -216,6 +216,11 @@ static hipStream_t ba_setup_stream_take(int device) {
     if (device >= 0 && device < 64 && !pl.idle[device].empty()) { hipStream_t s = pl.idle[device].back(); pl.idle[device].pop_back(); return s; }
   }
   hipStream_t s = nullptr;
+  // CMS_BA_SETUP_PRIORITY=low / high: the set-up streams in another priority class than the frame path's and the groups' (A/B)
+  static const char* pr = getenv("CMS_BA_SETUP_PRIORITY");
+  int lo = 0, hi = 0;
+  if (pr && (pr[0] == 'l' || pr[0] == 'h') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+    return hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr[0] == 'l' ? lo : hi) == hipSuccess ? s : nullptr;
   return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
 }
 static void ba_setup_stream_give(int device, hipStream_t s) {
@@ -1871,7 +1876,13 @@ extern "C" int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_
         re = ba_dev_plan_attr_once(device);
         if (re == hipSuccess) hipLaunchKernelGGL(k_ba_plan_many, dim3(nd), dim3(BA_DP_THREADS), BA_DP_LDS, lead->stream, pb);
         if (re == hipSuccess) re = hipGetLastError();
-        if (re == hipSuccess) { hipLaunchKernelGGL(k_ba_match_copies_many, dim3(BA_DP_MATCH_BLOCKS, nd), dim3(64), 0, lead->stream, pb); re = hipGetLastError(); }
+        if (re == hipSuccess) {
+          static const int m_lanes = getenv("CMS_BA_MATCH_LANES") ? atoi(getenv("CMS_BA_MATCH_LANES")) : 16;        // A/B: matchings per wavefront
+          static const int m_blocks = getenv("CMS_BA_MATCH_BLOCKS") ? atoi(getenv("CMS_BA_MATCH_BLOCKS")) : BA_DP_MATCH_BLOCKS;
+          for (int k = 0; k < BA_DP_BATCH; ++k) pb.x[k].pad_ = m_lanes;
+          hipLaunchKernelGGL(k_ba_match_copies_many, dim3(m_blocks, nd), dim3(64), 0, lead->stream, pb);
+          re = hipGetLastError();
+        }
         plan_streams.push_back(lead->stream);
       }
     }

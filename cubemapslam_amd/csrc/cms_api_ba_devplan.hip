@@ -545,8 +545,9 @@ extern "C" __global__ void __launch_bounds__(64) k_ba_match_copies_many(BaDevPla
   __shared__ int s_pslot[64];
   s_pslot[threadIdx.x] = (int)threadIdx.x < x.K ? x.pose_slot[threadIdx.x] : -1;
   __syncthreads();
-  if (threadIdx.x >= 16) return;
-  for (int u = blockIdx.x * 16 + threadIdx.x; u < 4 * (nchunks - n_rm); u += 16 * gridDim.x) {
+  const int lanes = x.pad_ > 0 ? x.pad_ : 16;                       // matchings per wavefront
+  if ((int)threadIdx.x >= lanes) return;
+  for (int u = blockIdx.x * lanes + threadIdx.x; u < 4 * (nchunks - n_rm); u += lanes * gridDim.x) {
     const int c = n_rm + (u >> 2), g = u & 3;
     const int p0 = x.chunk_pt0[c], pn = x.chunk_pt0[c + 1], e0 = x.ce0[c], ne = x.ce0[c + 1] - e0;
     if (16 * g >= ne) continue;

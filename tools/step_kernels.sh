@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; tag=$1; shift
 cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/sk_$tag
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sk_$tag -o t -- python $R/bench.py --steps ${STEPS:-10} --warmup 3 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0 --deterministic-steps 0 --confined-steps 0 > $R/gpurun_out/sk_$tag.json 2> $R/gpurun_out/sk_$tag.err
+env "$@" CMS_BENCH_NO_PY_LOOP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sk_$tag -o t -- python $R/bench.py --steps ${STEPS:-10} --warmup 3 --cpu-frames 0 --closed-loop-frames 0 --no-streaming-pass --optimise-only-steps 0 --verify-windows 0 --extract-only-steps 0 --random-views-steps 0 --mapping-only-steps 0 --unpipelined-steps 0 --deterministic-steps 0 --confined-steps 0 > $R/gpurun_out/sk_$tag.json 2> $R/gpurun_out/sk_$tag.err
 python - $R/gpurun_out/sk_$tag/t_kernel_stats.csv $R/gpurun_out/sk_$tag.json $tag <<'PY'
 import csv, sys, json
 rows = {r["Name"]: r for r in csv.DictReader(open(sys.argv[1]))}
