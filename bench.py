@@ -483,7 +483,8 @@ def main():
         key = tuple(id(p_) for p_ in mine)         # (the random-views pass swaps the problem sets: the descriptions belong to the problem OBJECTS)
         if key not in win_arrays:
             win_arrays[key] = (api.ba_window_array(mine), mine)
-        grp = api.ba_create_many(mine, device=local_rank, threads=create_threads, windows=win_arrays[key][0])
+        grp = api.ba_create_many(mine, device=local_rank, threads=create_threads if not api.ba_get_deterministic() else max(1, n_wthreads // max(1, n_grp)),
+                                 windows=win_arrays[key][0])      # (deterministic windows: the host's full plan, 4 ms each -- the window threads' share)
         if not own_streams:
             for ba in grp:
                 ba.set_stream(group_stream[gi])
