@@ -95,10 +95,10 @@ template <class F> __device__ __forceinline__ int ba_dp_exscan(int n, F&& val, i
 // Lane i's candidate banks are (slot_i + r np) mod 16 for its copies r = 0..3 (BA_SE_DSTRIDE = 33 = 1 mod 16), so a lane is the low four bits of its free-pose
 // slot; owners, choices, the path's frames and the banks' loads are nibbles / bytes of 64-bit words (private arrays of a GPU thread live in memory).
 static_assert((BA_SE_DSTRIDE & 15) == 1 && BA_SE_DCOPIES == 4, "ba_dp_match: the banks of a lane's copies");
-__device__ __forceinline__ int ba_dp_nib(unsigned long long w, int i) { return (int)((w >> (4 * i)) & 15ull); }
-__device__ __forceinline__ void ba_dp_set_nib(unsigned long long& w, int i, int v) { w = (w & ~(15ull << (4 * i))) | ((unsigned long long)(v & 15) << (4 * i)); }
+__host__ __device__ __forceinline__ int ba_dp_nib(unsigned long long w, int i) { return (int)((w >> (4 * i)) & 15ull); }
+__host__ __device__ __forceinline__ void ba_dp_set_nib(unsigned long long& w, int i, int v) { w = (w & ~(15ull << (4 * i))) | ((unsigned long long)(v & 15) << (4 * i)); }
 // slots: nibble i = slot of lane i mod 16; returns the choices (nibble i = copy of lane i)
-__device__ inline unsigned long long ba_dp_match(int n, unsigned long long slots, int np) {
+__host__ __device__ inline unsigned long long ba_dp_match(int n, unsigned long long slots, int np) {
   unsigned long long owner = 0, choice = 0, load_lo = 0, load_hi = 0;      // owner nibbles (valid where `owned` has the bank's bit), choice nibbles, loads as bytes (banks 0-7 | 8-15)
   unsigned owned = 0, chosen = 0;
   auto bank = [&](int i, int r) { return (ba_dp_nib(slots, i) + r * np) & 15; };
@@ -634,4 +634,24 @@ static hipError_t ba_dev_plan_attr_once(int device) {
   const hipError_t e = hipFuncSetAttribute((const void*)k_ba_plan_many, hipFuncAttributeMaxDynamicSharedMemorySize, BA_DP_LDS);
   if (e == hipSuccess) done[device] = true;
   return e;
+}
+
+// developer / test entry, host only (no device needed): one group's matching by the plan path's register-only search (which = 1) or by the host planners'
+// BaDiagMatch (which = 0).  slots[n]: the lanes' free-pose slots (n <= 16), np: free key frames; choice_out[n]: the copy every lane got
+extern "C" int cms_ba_debug_match(int which, int n, const int* slots, int np, int* choice_out) {
+  if (n < 0 || n > 16 || np < 1 || !slots || !choice_out) return cms_fail(CMS_ERR_ARG, "cms_ba_debug_match: bad argument");
+  if (which) {
+    unsigned long long w = 0;
+    for (int i = 0; i < n; ++i) ba_dp_set_nib(w, i, slots[i]);
+    const unsigned long long c = ba_dp_match(n, w, np);
+    for (int i = 0; i < n; ++i) choice_out[i] = ba_dp_nib(c, i);
+  } else {
+    BaDiagMatch m;
+    m.n = n;
+    for (int i = 0; i < n; ++i)
+      for (int r = 0; r < BA_SE_DCOPIES; ++r) m.bank[i][r] = (uint8_t)((BA_SE_DSTRIDE * (r * np + slots[i])) & 15);
+    m.run();
+    for (int i = 0; i < n; ++i) choice_out[i] = m.choice[i];
+  }
+  return CMS_OK;
 }

@@ -252,6 +252,9 @@ int cms_ba_debug_plan_fast(int K, const uint8_t* fixed, int P, int E, const int*
  * rm_cut: 2 x 1025 cut points (per class of signature), counts[4] = runs (-1: the planner does not take the window), run chunks, class-0 run chunks,
  * free key frames. */
 int cms_ba_debug_run_fg(int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, int fast, uint32_t* run_fg, int* rm_cut, int* counts);
+/* developer / test entry, host only: the matching lanes -> copies of one group of 16 left-over observations (which = 0: the host planners' search, 1: the plan
+ * kernel's register-only form of it -- the two must agree, tests/test_ba_plan_kernel_cpu.py); slots[n] = the lanes' free-pose slots, n <= 16 */
+int cms_ba_debug_match(int which, int n, const int* slots, int np, int* choice_out);
 void cms_ba_destroy(cms_ba* ba);
 /* Device slabs and pinned blocks of destroyed windows wait in a per-device pool for the next window (CMS_BA_POOL_MB bounds the device part, default
  * 16384; the pool is also emptied and the allocation retried when hipMalloc fails).  cms_ba_pool_trim hands everything cached for `device` back
