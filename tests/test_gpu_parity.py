@@ -1430,6 +1430,38 @@ def test_ba_plan_kernel_equals_the_host_plan():
         api.ba_create_many([probs[0], bad, probs[3]], threads=2)
 
 
+def test_ba_plan_kernel_on_small_and_odd_windows():
+    """CMS_BA_PLAN_ON_DEVICE on windows at the edges of what the kernel takes: a few points only (less than one tile of 64), one free key frame, 26 key frames
+    (25 free: the largest the fused solve takes), 40 key frames (the kernel's tables hold them, the solve path does not: the host declines before the kernel runs),
+    every point observed by every key frame (one signature).  Whoever plans a window -- the kernel or, after it gave up, the host -- the device arrays equal those
+    of the window created on its own, and the windows optimise to the oracle's results."""
+    probs = [synth.ba_problem(K=5, P=40, obs_per_point=3, F=550, seed=300, views="track"),
+             synth.ba_problem(K=3, P=700, obs_per_point=3, F=550, seed=301, views="track"),
+             synth.ba_problem(K=26, P=1500, obs_per_point=4, F=550, seed=16, views="track"),
+             synth.ba_problem(K=40, P=1500, obs_per_point=4, F=550, seed=303, views="track"),
+             synth.ba_problem(K=6, P=900, obs_per_point=6, F=550, seed=304, views="track")]
+    probs[1]["fixed"][:] = 1; probs[1]["fixed"][2] = 0          # one free key frame
+    probs = [dict(p, _plan_on_device=True) for p in probs]
+    many = api.ba_create_many(probs, threads=2)
+    keys = ("pinv", "perm", "info", "pt_off", "e_pose", "e_point", "e_face", "chunk_e0", "rm_chunk", "rm_cost", "run_mf", "run_fl")
+    planned_by_kernel = 0
+    for i, p in enumerate(probs):
+        one = api.BundleAdjuster(p)
+        a, b = many[i].fetch_plan(), one.fetch_plan()
+        planned_by_kernel += bool(a["plan_kernel"])
+        assert a["device_planned"] == b["device_planned"], i
+        for k in ("n_chunks", "n_rm", "n_runs", "np", "rm_points", "R_rm", "R"):
+            assert a[k] == b[k], (i, k, a[k], b[k])
+        for k in keys:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (i, k)
+        one.close()
+    assert planned_by_kernel >= 1          # (the small ones have no signature runs worth a chunk: the kernel says so and the host plans them)
+    for i, b in enumerate(many):
+        _, st = b.optimize()
+        _check_window(i, b, probs[i], st, tag="plan kernel (small / odd)")
+        b.close()
+
+
 def test_ba_create_many_and_read_many_equal_the_single_window_calls():
     """A window group's set-up and read-back as one call each (cms_ba_create_many: host parts on several threads, ONE expansion launch per eight
     device-planned windows; cms_ba_read_many: one gather launch): the device arrays of every window must be byte-identical to those of the same window
