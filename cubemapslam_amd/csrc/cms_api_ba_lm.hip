@@ -225,6 +225,9 @@ static int ba_group_ranges(cms_ba** bas, int n) {
   // path wait for it to drain.  With a few CUs left over they run NEXT to it instead of behind it
   static const int reserve = [] { const char* v = getenv("CMS_BA_RESERVE_CUS"); return v ? std::max(0, atoi(v)) : 0; }();
   if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, std::max(n, cus - reserve) / n));
+  // CMS_BA_RANGES_PER_WINDOW=k: k workgroups per window whatever the chip has (A/B: shorter workgroups let the other group's small kernels in sooner)
+  static const int per_window = [] { const char* v = getenv("CMS_BA_RANGES_PER_WINDOW"); return v ? atoi(v) : 0; }();
+  if (per_window > 0) R = std::max(2, std::min(BA_SE_RANGES, per_window));
   return R;
 }
 // Which kernels a group's rounds are made of: decided ONCE per group from the windows' lists and the knobs (ba_upload_items and the stage
