@@ -1343,6 +1343,22 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("knob", ["CMS_BA_DEV_PLAN", "CMS_BA_SETUP_OWN_STREAMS", "CMS_BA_SETUP_PRIORITY=low", "CMS_BA_NO_DEV_PLAN"])
+def test_ba_window_group_calls_under_their_switches(knob):
+    """cms_ba_create_many's switches, read once per process: every window of every call planned by the plan kernel whatever its flags say (CMS_BA_DEV_PLAN),
+    every window set up on a pooled stream of its own as before round 6 instead of one set-up stream per building thread (CMS_BA_SETUP_OWN_STREAMS), the
+    set-up streams in the low-priority class, the plan kernel switched off (CMS_BA_NO_DEV_PLAN: the flag is ignored, the host plans).  The group-call tests and
+    the C++ step driver's test run again in a child process with the switch set."""
+    import os, subprocess, sys
+    env = dict(os.environ)
+    env[knob.split("=")[0]] = knob.split("=")[1] if "=" in knob else "1"
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "create_many_and_read_many" + ("" if knob == "CMS_BA_NO_DEV_PLAN" else " or small_and_odd or plan_kernel_equals")      # (those two assert that the kernel planned)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_batch_driver.py"), "-q", "-x", "-m", "gpu",
+                        "-k", sel + " or cpp_driver"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("shuffle", [False, True])
 def test_ba_device_plan_equals_host_plan(shuffle):
     """cms_ba_create plans a tracked window with one host pass over the observations + per-point work and lets kernels write the observation-sized
