@@ -127,7 +127,7 @@ def parse_args(argv=None):
     ap.add_argument("--deterministic-steps", type=int, default=6, help="steps of the extra pass with cms_ba_set_deterministic(1) (config.deterministic; 0 = skip)")
     ap.add_argument("--mapping-only-steps", type=int, default=6, help="steps of the mapping side alone (CreateNewMapPoints + local BA, no frame path): config.mapping_only, and the Schur kernel's launch time without the frame path next to it in roofline (0 = skip)")
     ap.add_argument("--closed-loop-frames", type=int, default=24, help="frames of the single-stream closed-loop run reported next to the batch figure (rank 0, N = 1; 0 = skip)")
-    ap.add_argument("--confined-steps", type=int, default=12, help="steps of the two child runs of the same step with the process confined to 2 and to 4 host cores "
+    ap.add_argument("--confined-steps", type=int, default=40, help="steps of the two child runs of the same step with the process confined to 2 and to 4 host cores "
                     "(config.host.confined_2_cores / _4_cores: what a rank gets when eight of them share a 16-core box; rank 0, N = 1; 0 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true", help="no GPU work: every rank reports its rendezvous (gloo) and exits")
     return ap.parse_args(argv)
@@ -1600,11 +1600,13 @@ def main():
     # 8 ranks a 16-core quota, two cores each -- SCALE_rNN cannot be measured on a one-GPU lease, this is the part of it that can
     def confined_leg(ncores):
         try:
-            cores = sorted(os.sched_getaffinity(0))[:ncores]
+            mask = sorted(os.sched_getaffinity(0))
         except AttributeError:
             return None
-        if len(cores) < ncores:
+        if len(mask) < ncores:
             return None
+        lo = max(0, min(len(mask) - ncores, len(mask) // 2))      # from the middle of the mask: the first cores of a box are where its interrupts and other tenants' spill-over land
+        cores = mask[lo:lo + ncores]
         env = dict(os.environ); env["CMS_BENCH_AFFINITY"] = ",".join(str(c) for c in cores)
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.confined_steps), "--warmup", "3", "--cpu-frames", "0", "--no-streaming-pass", "--verify-windows", "0",
                "--extract-only-steps", "0", "--random-views-steps", "0", "--optimise-only-steps", "0", "--unpipelined-steps", "0", "--deterministic-steps", "0",
@@ -1628,7 +1630,7 @@ def main():
         torch.cuda.synchronize()
         host["confined_2_cores"] = confined_leg(2)
         host["confined_4_cores"] = confined_leg(4)
-        host["confined_note"] = ("child processes of this bench.py with sched_setaffinity to the first 2 / 4 cores of the parent's affinity mask (CMS_BENCH_AFFINITY), same step, "
+        host["confined_note"] = ("child processes of this bench.py with sched_setaffinity to 2 / 4 cores from the middle of the parent's affinity mask (CMS_BENCH_AFFINITY), same step, "
                                  "no extra passes; the parent holds its device memory but launches nothing meanwhile")
     if rank == 0 and args.save_trajectory and last["traj"] is not None:
         # rank 0's assembled trajectory of the last step in the reference's TUM format (System.cpp:238-268)
