@@ -195,6 +195,13 @@ def host_budget(world, local_rank, window_threads_arg=0, pin=True):
             "core_slice": [mine[0], mine[-1]] if mine else None, "pinned": pinned, "window_threads": wthreads, "host_waits": "sleep" if relaxed else "spin"}
 
 
+def plans_on_device(thread_budget, env=None):
+    """Does this rank let k_ba_plan_many plan its local-BA windows (cms_ba_window.flags |= CMS_BA_PLAN_ON_DEVICE)?  With at most two host cores (eight ranks on a
+    16-core box): yes -- the plans are half of such a rank's CPU time per step; with more the host's plan overlaps the GPU better.  CMS_BENCH_PLAN_ON_DEVICE=1 / 0 overrides."""
+    v = (os.environ if env is None else env).get("CMS_BENCH_PLAN_ON_DEVICE", "")
+    return (v == "1") if v in ("0", "1") else thread_budget <= 2
+
+
 def launcher_selftest(args, rank, world, local_rank):
     import torch
     import torch.distributed as dist
@@ -448,8 +455,7 @@ def main():
     # A rank short of cores lets the device plan its windows (cms_ba_window.flags |= CMS_BA_PLAN_ON_DEVICE: k_ba_plan_many, byte-identical device arrays): the plans are
     # half of a two-core rank's CPU time per step.  With cores to spare the host's plan stays: its windows become ready spread over the step and the Levenberg rounds
     # overlap the frame path better (profiles/r06_bench_runs.txt).  CMS_BENCH_PLAN_ON_DEVICE=1 / 0 overrides.
-    pod_env = os.environ.get("CMS_BENCH_PLAN_ON_DEVICE", "")
-    plan_on_device = (pod_env == "1") if pod_env in ("0", "1") else host["thread_budget"] <= 2
+    plan_on_device = plans_on_device(host["thread_budget"])
     host["window_plans"] = "device (k_ba_plan_many)" if plan_on_device else "host threads"
     if plan_on_device:
         frac = float(os.environ.get("CMS_BENCH_PLAN_ON_DEVICE_FRACTION", "1"))      # developer knob: only this share of the windows (the flag is per window)

@@ -139,3 +139,18 @@ def test_ranks_of_a_node_get_disjoint_host_thread_budgets():
     # --window-threads overrides the pool size, not the budget
     two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-selftest", "--window-threads", "5"], env=env, capture_output=True, text=True, timeout=120)
     assert _json_records(two.stdout)[0]["host"]["window_threads"] == 5
+
+
+def test_a_rank_short_of_cores_plans_its_windows_on_the_device():
+    """bench.py's policy for cms_ba_window.flags: eight ranks under a 16-core quota get two cores each and let the plan kernel make their windows' work lists;
+    a rank with three or more cores keeps the host's plan; the environment overrides either way."""
+    import bench
+    assert bench.plans_on_device(2, env={}) and bench.plans_on_device(1, env={})
+    assert not bench.plans_on_device(3, env={}) and not bench.plans_on_device(16, env={})
+    assert bench.plans_on_device(16, env={"CMS_BENCH_PLAN_ON_DEVICE": "1"}) and not bench.plans_on_device(2, env={"CMS_BENCH_PLAN_ON_DEVICE": "0"})
+    os.environ["LOCAL_WORLD_SIZE"] = "8"
+    try:
+        hb = bench.host_budget(8, 3, pin=False)
+    finally:
+        del os.environ["LOCAL_WORLD_SIZE"]
+    assert bench.plans_on_device(hb["thread_budget"], env={}) == (hb["thread_budget"] <= 2)
