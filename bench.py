@@ -56,6 +56,11 @@ import numpy as np
 # side's calls): measured again -- 2 / 3 / 4 / 6 / 8 / 16 / 24 queues = 18.6 / 19.2 / 20.2-21.6 / 18.9-19.7 / 19.7-20.4 / 19.8-20.2 / 14.8-16.4 k frames/s
 # (profiles/r05_experiments.txt): with fewer queues the frame path's kernels queue behind each other instead of competing with the Levenberg chain for
 # compute units (extractor inside the step 0.35-0.36 of its byte roofline against 0.31-0.32), with two or three the chains themselves serialise.
+# Round 6: WHICH streams share a queue is what counts (the runtime hands its queues to new streams in a fixed cycle; tools/stream_queues.py on a profiled run): with four, one
+# window group's rounds share a queue with a set-up stream -- harmless while the host plans (short uploads), but a rank that plans on the device (<= 2 cores) has its
+# plan kernels there, in front of that group's rounds: 1-ms gaps inside the rounds, 20.2 k frames/s; with six the set-up streams sit with the pose optimiser's / alone:
+# 21.4 k (three runs each, 2 cores).  With cores to spare four stays best (23.0 against 22.0 / 22.6 / 21.9 / 22.5 k with 5 / 6 / 10 / 12).  main() picks once the budget is known.
+_HWQ_FROM_USER = "GPU_MAX_HW_QUEUES" in os.environ
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -343,6 +348,8 @@ def main():
     # Measured on one GPU with the process confined by taskset: 2 cores 12.5 k -> 13.2-13.8 k frames/s, 4 cores 17.7 k -> 19.1 k; with cores to spare
     # the spinning waits stay (sleeping costs 3-16 % there, round 4).  Both switches must be thrown before the first HIP call of the process.
     early_budget = host_budget(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")), pin=False)["thread_budget"]
+    if not _HWQ_FROM_USER:
+        os.environ["GPU_MAX_HW_QUEUES"] = "6" if plans_on_device(early_budget) else "4"      # (see the top of this file; before the first HIP call)
     few_cores = early_budget <= 4 and os.environ.get("CMS_BENCH_SPIN_ANYWAY", "") == ""
     if few_cores:
         os.environ.setdefault("CMS_BA_RELAXED_WAIT", "1")
@@ -452,6 +459,7 @@ def main():
         probs = prob_sets[0]
     host = host_budget(world, local_rank, args.window_threads)      # the ranks of a node split its usable cores (and are pinned to their slice)
     host["blocking_sync"] = bool(blocking_sync)
+    host["gpu_max_hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
     # A rank short of cores lets the device plan its windows (cms_ba_window.flags |= CMS_BA_PLAN_ON_DEVICE: k_ba_plan_many, byte-identical device arrays): the plans are
     # half of a two-core rank's CPU time per step.  With cores to spare the host's plan stays: its windows become ready spread over the step and the Levenberg rounds
     # overlap the frame path better (profiles/r06_bench_runs.txt).  CMS_BENCH_PLAN_ON_DEVICE=1 / 0 overrides.
