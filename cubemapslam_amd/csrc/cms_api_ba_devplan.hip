@@ -4,18 +4,21 @@
 // runs, internal point order, chunks, the matching of the left-over observations' diagonal copies): 32 windows per 12-ms step of bench.py are half
 // of what a rank confined to two host cores can do at all (profiles/r06_bench_runs.txt: 16.8 k frames/s there, 19.7 k with the plans taken from a cache).
 // k_ba_plan_many does all of it with ONE workgroup of 1024 threads per window (blockIdx.x = window of a cms_ba_create_many call) and gives, byte for
-// byte, the arrays ba_plan_fast + the staging copy would have put on the device (tests/test_gpu_parity.py::test_ba_device_planner_kernel_equals_the_host_plan):
+// byte, the arrays ba_plan_fast + the staging copy would have put on the device (tests/test_gpu_parity.py::test_ba_plan_kernel_equals_the_host_plan):
 //
-//   pass      per observation: validation, atomicAdd / atomicOr into its point's count and key-frame set; "grouped" = the caller's points never decrease
-//   groups    open addressing on the 64-bit key-frame set (atomicCAS), per group its first point (atomicMin) and its size -> which groups are runs;
-//             the run order of the host (first appearance, class 0 before class 1) is a prefix sum over the points that are a run group's first
-//   order     a point's ordinal inside its group in the caller's order (the host's `seen` counter): per tile of 64 points the wavefront matches equal
-//             groups (ballot / readlane) and lists (run, count) once per group; ONE wavefront then walks the tiles in order and turns counts into
-//             bases; ordinal = base + rank inside the tile.  Left-over points keep the caller's order (a prefix sum over "not inside a run")
+//   pass      per observation: validation; "grouped" = the caller's points never decrease; where a point's observations begin and end.  Then a thread per
+//             point ORs its observations' key frames into the point's 64-bit set (grouped order: no atomics; otherwise an atomic OR per observation)
+//   groups    open addressing on the set (a slot is read before it is claimed with atomicCAS), per slot the group's size and first point in LDS -> which
+//             groups are runs; the run order of the host (first appearance inside a class, class 0 first) is the rank of a run's first point among the candidates'
+//   order     a point's ordinal inside its run in the caller's order (the host's `seen` counter): in a tile of 64 points the lanes of the same run find each
+//             other with one ballot per bit of the run's number; a wavefront walks a contiguous segment of tiles and keeps 16-bit per-run counters for it in
+//             LDS; a prefix over the 16 segments makes them bases.  Left-over points keep the caller's order (a prefix sum over "not inside a run")
 //   chunks    run chunks by binary search in the runs' chunk offsets; the left-over points are packed greedily by one thread per segment (<= 8
-//             segments, the same cut as the host's), counts of the left-over points in LDS
-//   tables    CSR offsets, chunk first edges, run chunk descriptors, the running chunk cost, per (left-over chunk, 16 lanes) the matching lanes -> LDS
-//             banks (BaDiagMatch, here without recursion), the points nobody observes
+//             segments, the same cut as the host's), their counts in LDS
+//   tables    CSR offsets, chunk first edges, run chunk descriptors, the running chunk cost, the points nobody observes
+// ... and k_ba_match_copies_many behind it: per (left-over chunk, 16 lanes) the matching lanes -> LDS banks (BaDiagMatch without recursion, state in nibbles).
+// Every loop reads a batch of values before it works on them -- a thread's iteration is otherwise one memory round trip -- and nothing is per-observation
+// atomic: the first version (serial probes, an atomic per observation, one round trip per iteration) took 2.4 ms per batch of eight windows, this one 0.36.
 //
 // What the host still needs -- the counts that size the Levenberg launches -- comes back through 40 bytes of pinned memory per window; the expansion
 // kernel (k_ba_expand_edges_many) reads the same counts from device memory, so it is enqueued right behind this kernel without a host round trip.
@@ -28,7 +31,7 @@
 #define BA_DP_HCAP 8192               /* slots of the signature table (counts and first points in LDS): more than 4096 different key-frame sets -> the host plans */
 #define BA_DP_LCNT_CAP 32768          /* left-over points at most (their observation counts sit in LDS for the greedy packing) */
 #define BA_DP_COUNTS 10               /* status, chunks, run chunks, class-0 run chunks, runs, points inside runs, lone points, grouped, first left-over edge */
-#define BA_DP_LDS (2 * BA_DP_HCAP * 4 + 3 * 1024 * 4 + 1024)      /* (tables + 104 small words) */      /* dynamic LDS of the kernel, bytes */
+#define BA_DP_LDS (2 * BA_DP_HCAP * 4 + 3 * 1024 * 4 + 1024)      /* dynamic LDS of the kernel, bytes: the two slot tables, three run tables, 104 small words */
 
 struct BaDevPlan {
   int K, P, E, np, chunk_cap, em_cost_a, em_cost_b, pad_;
