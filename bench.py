@@ -207,6 +207,41 @@ def plans_on_device(thread_budget, env=None):
     return (v == "1") if v in ("0", "1") else thread_budget <= 2
 
 
+# ---- the same step with the whole process confined to 2 and to 4 host cores (child processes, run before the parent touches the GPU): the driver's box gives
+# 8 ranks a 16-core quota, two cores each -- SCALE_rNN cannot be measured on a one-GPU lease, this is the part of it that can
+def confined_leg(args, ncores):
+    try:
+        mask = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if len(mask) < ncores:
+        return None
+    lo = max(0, min(len(mask) - ncores, len(mask) // 2))      # from the middle of the mask: the first cores of a box are where its interrupts and other tenants' spill-over land
+    cores = mask[lo:lo + ncores]
+    env = dict(os.environ); env["CMS_BENCH_AFFINITY"] = ",".join(str(c) for c in cores)
+    if not _HWQ_FROM_USER:
+        env.pop("GPU_MAX_HW_QUEUES", None)      # (this process's default, not the user's wish: the child picks its own from ITS core budget)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.confined_steps), "--warmup", "3", "--cpu-frames", "0", "--no-streaming-pass", "--verify-windows", "0",
+           "--extract-only-steps", "0", "--random-views-steps", "0", "--optimise-only-steps", "0", "--unpipelined-steps", "0", "--deterministic-steps", "0",
+           "--mapping-only-steps", "0", "--closed-loop-frames", "0", "--confined-steps", "0", "--camera", args.camera, "--batch", str(args.batch), "--ba-every", str(args.ba_every)]
+    import shutil
+    if shutil.which("taskset"):      # the whole child process from its first instruction on (threads that exist before main() runs keep their own mask otherwise)
+        cmd = ["taskset", "-c", env["CMS_BENCH_AFFINITY"]] + cmd
+    t0_ = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"cores": ncores, "state": "timed out"}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"cores": ncores, "state": "failed (rc %d)" % r.returncode, "stderr_tail": r.stderr[-300:]}
+    j = json.loads(lines[-1])
+    h = j["config"].get("host") or {}
+    return {"cores": ncores, "core_list": cores, "value": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "host_cores_used": h.get("host_cores_used"),
+            "host_waits": h.get("host_waits"), "window_threads": h.get("window_threads"), "window_plans": h.get("window_plans"), "gpu_max_hw_queues": h.get("gpu_max_hw_queues"),
+            "child_wall_s": round(time.perf_counter() - t0_, 1)}
+
+
 def launcher_selftest(args, rank, world, local_rank):
     import torch
     import torch.distributed as dist
@@ -343,6 +378,15 @@ def main():
     if os.environ.get("CMS_BENCH_AFFINITY", "") and hasattr(os, "sched_setaffinity"):      # a confined child leg (see confined_leg): before any thread exists
         os.sched_setaffinity(0, {int(c) for c in os.environ["CMS_BENCH_AFFINITY"].split(",")})
     maybe_spawn(args)
+    # The confined child legs run FIRST, while this process has not touched the GPU yet: an idle parent's context (its hardware queues, its memory) on the same
+    # GPU cost a two-core child ~6 % (19.0-19.7 k frames/s inside a default run against 21.3 k for the same command on its own, profiles/r06_bench_runs.txt)
+    early_confined = {}
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and args.confined_steps > 0 and args.batch // max(args.ba_every, 1) > 0
+            and os.environ.get("CMS_BENCH_AFFINITY", "") == "" and not args.launcher_selftest):
+        early_confined["confined_2_cores"] = confined_leg(args, 2)
+        early_confined["confined_4_cores"] = confined_leg(args, 4)
+        early_confined["confined_note"] = ("child processes of this bench.py with sched_setaffinity to 2 / 4 cores from the middle of the parent's affinity mask (CMS_BENCH_AFFINITY), same step, "
+                                           "no extra passes; they run before the parent's first HIP call, alone on the GPU")
     # A rank with few host cores (8 ranks on a node whose container has a 16-core quota: two each) cannot afford the runtime's spinning waits: with
     # <= 4 cores the process blocks in its synchronisations and the library's window threads sleep between stream queries (CMS_BA_RELAXED_WAIT).
     # Measured on one GPU with the process confined by taskset: 2 cores 12.5 k -> 13.2-13.8 k frames/s, 4 cores 17.7 k -> 19.1 k; with cores to spare
@@ -1613,42 +1657,9 @@ def main():
         except Exception as ex:      # the driver is a report line, not the metric
             closed["cpp_driver"] = {"error": str(ex)[:200]}
 
-    # ---- the same step with the whole process confined to 2 and to 4 host cores (child processes; the parent is idle meanwhile): the driver's box gives
-    # 8 ranks a 16-core quota, two cores each -- SCALE_rNN cannot be measured on a one-GPU lease, this is the part of it that can
-    def confined_leg(ncores):
-        try:
-            mask = sorted(os.sched_getaffinity(0))
-        except AttributeError:
-            return None
-        if len(mask) < ncores:
-            return None
-        lo = max(0, min(len(mask) - ncores, len(mask) // 2))      # from the middle of the mask: the first cores of a box are where its interrupts and other tenants' spill-over land
-        cores = mask[lo:lo + ncores]
-        env = dict(os.environ); env["CMS_BENCH_AFFINITY"] = ",".join(str(c) for c in cores)
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.confined_steps), "--warmup", "3", "--cpu-frames", "0", "--no-streaming-pass", "--verify-windows", "0",
-               "--extract-only-steps", "0", "--random-views-steps", "0", "--optimise-only-steps", "0", "--unpipelined-steps", "0", "--deterministic-steps", "0",
-               "--mapping-only-steps", "0", "--closed-loop-frames", "0", "--confined-steps", "0", "--camera", args.camera, "--batch", str(args.batch), "--ba-every", str(args.ba_every)]
-        import shutil
-        if shutil.which("taskset"):      # the whole child process from its first instruction on (threads that exist before main() runs keep their own mask otherwise)
-            cmd = ["taskset", "-c", env["CMS_BENCH_AFFINITY"]] + cmd
-        t0_ = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
-        except subprocess.TimeoutExpired:
-            return {"cores": ncores, "state": "timed out"}
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode != 0 or not lines:
-            return {"cores": ncores, "state": "failed (rc %d)" % r.returncode, "stderr_tail": r.stderr[-300:]}
-        j = json.loads(lines[-1])
-        h = j["config"].get("host") or {}
-        return {"cores": ncores, "core_list": cores, "value": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "host_cores_used": h.get("host_cores_used"),
-                "host_waits": h.get("host_waits"), "window_threads": h.get("window_threads"), "child_wall_s": round(time.perf_counter() - t0_, 1)}
-    if rank == 0 and world == 1 and args.confined_steps > 0 and n_ba > 0:
-        torch.cuda.synchronize()
-        host["confined_2_cores"] = confined_leg(2)
-        host["confined_4_cores"] = confined_leg(4)
-        host["confined_note"] = ("child processes of this bench.py with sched_setaffinity to 2 / 4 cores from the middle of the parent's affinity mask (CMS_BENCH_AFFINITY), same step, "
-                                 "no extra passes; the parent holds its device memory but launches nothing meanwhile")
+    # ---- the same step with the whole process confined to 2 and to 4 host cores: measured by child processes BEFORE this process touched the GPU (main()'s beginning)
+    if early_confined:
+        host.update(early_confined)
     if rank == 0 and args.save_trajectory and last["traj"] is not None:
         # rank 0's assembled trajectory of the last step in the reference's TUM format (System.cpp:238-268)
         tr = last["traj"]
