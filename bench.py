@@ -152,6 +152,8 @@ def maybe_spawn(args):
         return
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not _HWQ_FROM_USER:
+        env.pop("GPU_MAX_HW_QUEUES", None)      # (this process's default, not the user's wish: every rank picks its own from ITS core budget)
     env["CMS_BENCH_SPAWNED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
