@@ -546,8 +546,9 @@ def main():
         key = tuple(id(p_) for p_ in mine)         # (the random-views pass swaps the problem sets: the descriptions belong to the problem OBJECTS)
         if key not in win_arrays:
             win_arrays[key] = (api.ba_window_array(mine), mine)
-        grp = api.ba_create_many(mine, device=local_rank, threads=create_threads if not api.ba_get_deterministic() else max(1, n_wthreads // max(1, n_grp)),
-                                 windows=win_arrays[key][0])      # (deterministic windows: the host's full plan, 4 ms each -- the window threads' share)
+        det_points = api.ba_get_deterministic() and os.environ.get("CMS_BA_DET_POINTS", "") != ""      # (round 5's deterministic windows: the host's full plan, 4 ms each -- the window threads' share)
+        grp = api.ba_create_many(mine, device=local_rank, threads=create_threads if not det_points else max(1, n_wthreads // max(1, n_grp)),
+                                 windows=win_arrays[key][0])
         if not own_streams:
             for ba in grp:
                 ba.set_stream(group_stream[gi])
@@ -1355,7 +1356,8 @@ def main():
                         "note": "synth.ba_problem(views='random'): no point shares its set of observing key frames with enough others, every point goes through the edge-major Schur body"}
 
     # ---- determinism as a product mode (cms_ba_set_deterministic: fixed summation order, bit-identical runs like the reference's single-threaded g2o):
-    # the same steps with every window created under the mode -- pair-owner Schur kernel, the host planner with all work lists
+    # the same steps with every window created under the mode -- since round 6 the fused chain with its LDS additions in a fixed order and slices instead
+    # of the global copy (kb_ba_lin_schur_runs_det), planned like any other window; CMS_BA_DET_POINTS=1: rounds 3-5's pair-owner kernel on the host's full plan
     deterministic = None
     if args.deterministic_steps > 0 and n_ba > 0:
         api.ba_set_deterministic(True)
@@ -1368,7 +1370,12 @@ def main():
             api.ba_set_deterministic(False)
         deterministic = {"value": round(total_frames_per_step * args.deterministic_steps / dt_d, 2), "ms_per_step": round(1e3 * dt_d / args.deterministic_steps, 3),
                          "ba_ms_per_step": round(ba_ms_d, 3), "steps": args.deterministic_steps,
-                         "note": "cms_ba_set_deterministic(1): windows run kb_ba_schur_points (fixed order, bit-identical from run to run) and are planned by the host planner"}
+                         "of_python_step_loop": (round(total_frames_per_step * args.deterministic_steps / dt_d / python_loop["value"], 3) if python_loop else None),      # (this pass runs the Python loop too)
+                         "note": ("cms_ba_set_deterministic(1): the fused chain with the Schur kernel's LDS additions in a fixed order (kb_ba_lin_schur_runs_det: keys from the plan's "
+                                  "estimated chunk costs), workgroup slices added by the solve kernel in slice order instead of global FP64 atomics, 16 workgroups per window whatever the "
+                                  "group, kb_ba_first_pass adding the key frames' diagonal sums in chunk and slice order; planned like default windows -- bit-identical from run to run"
+                                  if os.environ.get("CMS_BA_DET_POINTS", "") == "" else
+                                  "CMS_BA_DET_POINTS: windows run kb_ba_schur_points (pair-owner kernel) and are planned by the host planner with every work list (rounds 3-5)")}
 
     # ---- outside the timed region: one more step with the windows' whole life cycle whose results are kept; iteration counts and outlier
     # counts of ALL its windows, and the estimates of a sample, against the CPU oracle

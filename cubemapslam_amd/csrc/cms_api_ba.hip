@@ -21,7 +21,7 @@
 // Every A/B switch of the local-BA host code, read ONCE (first use) so that the choices made when a window is built (which work lists exist)
 // and the choices made when it is optimised (which kernels run) can never disagree.  Tests that flip a switch use a child process.
 struct BaKnobs {
-  bool deterministic, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
+  bool deterministic, det_points, host_lm, single_host_lm, schur_chunks, schur_points, all_lists, want_all_lists;
   bool no_fused, solve1, trial_points, fixed_ranges, no_permute, create_timing, compose_timing, runs, runs_as_edges, separate_reduce, separate_reduce2, separate_first_pass, rm_valu;
   int solve_reduce_max, leftover_lookahead;
   bool global_sum;
@@ -37,7 +37,10 @@ static const BaKnobs& ba_knobs() {
     q.deterministic = on("CMS_BA_DETERMINISTIC"); q.host_lm = on("CMS_BA_HOST_LM"); q.single_host_lm = on("CMS_BA_SINGLE_HOST_LM");
     q.schur_chunks = on("CMS_BA_SCHUR_CHUNKS"); q.schur_points = on("CMS_BA_SCHUR_POINTS"); q.all_lists = on("CMS_BA_ALL_LISTS");
     // the pair-owner / tuple-chunk kernels' work lists and the stored 6x3 blocks: only built when a switch selects those kernels
-    q.want_all_lists = q.deterministic || q.host_lm || q.single_host_lm || q.schur_chunks || q.schur_points || q.all_lists;
+    // CMS_BA_DET_POINTS=1: deterministic windows on the pair-owner kernel with the host plan and every work list (rounds 3-5's deterministic path; the
+    // default since round 6 is the fused chain with its LDS additions in a fixed order, kb_ba_lin_schur_runs_det / _edges_det)
+    q.det_points = on("CMS_BA_DET_POINTS");
+    q.want_all_lists = (q.deterministic && q.det_points) || q.host_lm || q.single_host_lm || q.schur_chunks || q.schur_points || q.all_lists;
     q.no_fused = on("CMS_BA_NO_FUSED_LIN"); q.solve1 = on("CMS_BA_SOLVE1"); q.trial_points = on("CMS_BA_TRIAL_POINTS");
     q.fixed_ranges = on("CMS_BA_FIXED_RANGES"); q.no_permute = on("CMS_BA_NO_PERMUTE");
     q.create_timing = on("CMS_BA_CREATE_TIMING"); q.compose_timing = on("CMS_BA_COMPOSE_TIMING");
@@ -134,7 +137,9 @@ struct cms_ba {
   int* d_plan_counts = nullptr; int* h_plan_counts = nullptr; size_t h_plan_counts_bytes = 0;
   long long* d_plan_clk = nullptr;      // developer: CMS_BA_DP_CLK=1
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
-  bool deterministic = false;   // created under cms_ba_set_deterministic(1): all work lists, the pair-owner Schur kernel
+  bool deterministic = false;   // created under cms_ba_set_deterministic(1): sums in a fixed order, bit-identical from run to run
+  bool det_points = false;      // ... through the pair-owner Schur kernel on all work lists (CMS_BA_DET_POINTS, or a window the fused chain cannot take);
+                                // otherwise through the fused chain's fixed-order kernels (kb_ba_lin_schur_runs_det / kb_ba_lin_schur_edges_det, slices)
   hipEvent_t ev_setup = nullptr;      // cms_ba_set_stream: marks the end of the window's set-up on the stream it was created on
   bool setup_wait_pending = false;    // ... and b->stream has not been told to wait for it yet (ba_order_behind_setup, at the window's first use there)
   hipStream_t grp_stream = nullptr;   // the stream of the group whose rounds may still be in flight for this window (ba_optimize_group; cleared at its successful end)
@@ -155,7 +160,7 @@ static int ba_lds_attrs_once(int device) {
   std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || done[device]) return CMS_OK;
   const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)kb_ba_lin_schur_edges,
-                       (const void*)kb_ba_lin_schur_runs, (const void*)kb_ba_lin_schur_runs_valu, (const void*)kb_ba_lin_schur_run_wg0, (const void*)kb_ba_lin_schur_run_wg1, (const void*)kb_ba_trial_solve3r, (const void*)k_ba_trial_solve,
+                       (const void*)kb_ba_lin_schur_runs, (const void*)kb_ba_lin_schur_runs_det, (const void*)kb_ba_lin_schur_edges_det, (const void*)kb_ba_lin_schur_runs_valu, (const void*)kb_ba_lin_schur_run_wg0, (const void*)kb_ba_lin_schur_run_wg1, (const void*)kb_ba_trial_solve3r, (const void*)k_ba_trial_solve,
                        (const void*)kb_ba_trial_solve, (const void*)kb_ba_trial_solve3, (const void*)k_ba_solve_r192};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);
@@ -836,7 +841,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
   // edge-major kernel.  Runs need the fused path (linearisation inside the Schur kernel: three-lane solve, edge-major trial kernel) and the
   // LDS for four producer / consumer pairs.
   const size_t rm_lds = se_fixed_lds + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF * sizeof(double);
-  const bool rm_ok = se_ok && kn.runs && !kn.no_fused && !kn.want_all_lists && !b->deterministic && !kn.solve1 && !kn.trial_points && b->solve_blk3 && rm_lds <= BA_LDS_CEILING &&
+  const bool rm_ok = se_ok && kn.runs && !kn.no_fused && !kn.want_all_lists && !b->det_points && !kn.solve1 && !kn.trial_points && b->solve_blk3 && rm_lds <= BA_LDS_CEILING &&
                      BA_SE_THREADS == 128 * BA_RM_PAIRS;
   struct Run { int k, first, npts, chunks, m, kf; };          // first: a member point (its key frames are the signature)
   std::vector<Run> runs;
@@ -944,7 +949,7 @@ static void ba_plan(cms_ba* b, BaPlan& pl, int K, const uint8_t* fixed, int P, i
     for (int i = 0; i < PL; ++i) loc[left[i]] = i;
     // (a deterministic window runs the pair-owner kernel on its own work lists: the look-ahead composition -- 3.6 of its 6.8 ms of planning -- would place
     // points for LDS bank classes of a kernel the window never runs; it keeps the caller's order)
-    if (PL == P) ba_compose_chunks(K, fixed, P, E, e_pose, e_point, (kn.no_permute || b->deterministic) ? 1 : kn.lookahead, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
+    if (PL == P) ba_compose_chunks(K, fixed, P, E, e_pose, e_point, (kn.no_permute || b->det_points) ? 1 : kn.lookahead, prankL, pinvL, chunk_pt0L, cp_offL, cp_poseL, cp_rankL);
     else {
       ep.reserve(E); ept.reserve(E);
       for (int e = 0; e < E; ++e) if (loc[e_point[e]] >= 0) { ep.push_back(e_pose[e]); ept.push_back(loc[e_point[e]]); }
@@ -1221,6 +1226,16 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   cms_ba* b = new cms_ba;
   b->device = device; b->K = K; b->P = P; b->E = E;
   b->deterministic = ba_det_mode().load() != 0;
+  if (b->deterministic) {
+    // which deterministic path: the fused chain in fixed order needs what the fused chain needs (three-lane solve: <= 25 free key frames; none of the
+    // switches that take a kernel of the chain away); everything else keeps the pair-owner kernel on its own work lists
+    const BaKnobs& k0 = ba_knobs();
+    int np0 = 0;
+    for (int k = 0; k < K; ++k) np0 += fixed[k] ? 0 : 1;
+    ba_plan_sizes(b, K, P, E, np0);
+    b->det_points = k0.det_points || !b->solve_blk3 || k0.no_fused || k0.solve1 || k0.trial_points || k0.rm_valu || k0.run_wg || k0.host_lm || k0.single_host_lm ||
+                    k0.want_all_lists || k0.separate_reduce2 || k0.dup != 0;
+  }
 #define BA_TRY(x) do { int _rc = (x); if (_rc) { cms_ba_destroy(b); return _rc; } } while (0)
 #define BA_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cms_ba_destroy(b); return cms_fail(CMS_ERR_HIP, #x, _e); } } while (0)
   // CMS_BA_CREATE_TIMING=1: where the host side of a window's set-up goes (stderr, one line per window)
@@ -1291,7 +1306,9 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   auto up_in = [&](const void* src, size_t bytes, auto** dst) { ups.push_back({src, bytes, reinterpret_cast<void**>(dst), inputs_pinned && bytes >= 4096}); };
   if (se_built) {
     const int NP2 = np * (np + 1) / 2;
-    BA_TRY(ba_alloc(b, &b->d_se_partial, (size_t)BA_SE_RANGES * NP2 * 42)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)BA_SE_RANGES * np * 6));
+    // (a deterministic window's first pass parks its workgroups' diagonal sums in `partial` before the first Schur launch: Rt <= P / 8 + 2 slices of 6 np)
+    const size_t se_partial_n = std::max((size_t)BA_SE_RANGES * NP2 * 42, b->deterministic ? ((size_t)P / 8 + 4) * 6 * (size_t)np : (size_t)0);
+    BA_TRY(ba_alloc(b, &b->d_se_partial, se_partial_n)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)BA_SE_RANGES * np * 6));
     BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42));
     b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial;
   }
@@ -1332,7 +1349,7 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   // it into a group of its own kind): the pair-owner and tuple-chunk kernels' work lists (co-visibility tuples: ~10 per point, 2.4 ms of
   // host time at 80 k edges) and the stored 6x3 blocks (144 B per edge) are then never touched and are not built.  The A/B switches that
   // select those kernels bring them back.
-  b->se_only = fast || (se_built && b->solve_blk && !kn.want_all_lists && !b->deterministic);
+  b->se_only = fast || (se_built && b->solve_blk && !kn.want_all_lists && !b->det_points);
   if (!b->se_only) BA_TRY(ba_alloc(b, &b->d_Hpl, 18 * (size_t)E));
   // co-visibility tuples: for every point, every ordered pair of its edges whose free-pose slots satisfy s1 <= s2
   if (!b->se_only) {

@@ -589,7 +589,7 @@ extern "C" __global__ void __launch_bounds__(64) k_ba_match_copies_many(BaDevPla
 static bool ba_dev_plan_prepare(cms_ba* b, int K, const uint8_t* fixed, int P, int E, std::vector<int>& pose_slot, unsigned long long& free_mask) {
   const BaKnobs& kn = ba_knobs();
   static const bool off = getenv("CMS_BA_NO_DEV_PLAN") != nullptr;
-  if (off || K > 64 || b->deterministic || !ba_fast_plan_allowed(kn) || ba_want_rw_tables() || P > 65535) return false;      // (ordinals and segment counters are 16-bit)
+  if (off || K > 64 || b->det_points || !ba_fast_plan_allowed(kn) || ba_want_rw_tables() || P > 65535) return false;      // (ordinals and segment counters are 16-bit)
   pose_slot.assign(K, -1);
   int np = 0;
   free_mask = 0;

@@ -194,7 +194,7 @@ static bool ba_all_sp(cms_ba** bas, int n) {
 // per-point path is available too (the two share the block-free linearisation); CMS_BA_DETERMINISTIC=1 keeps the pair-owner kernel
 static bool ba_use_se(cms_ba** bas, int n) {
   if (ba_knobs().host_lm) return false;   // (the host-driven A/B driver only knows the pair-owner kernel)
-  for (int w = 0; w < n; ++w) if (bas[w]->se.nchunks <= 0 || bas[w]->deterministic) return false;      // (deterministic windows: the pair-owner kernel)
+  for (int w = 0; w < n; ++w) if (bas[w]->se.nchunks <= 0 || bas[w]->det_points) return false;      // (det_points: deterministic windows on the pair-owner kernel)
   return true;
 }
 // ... and the edge-major trial kernel when, in addition, every point of every window has an observation
@@ -217,6 +217,7 @@ static int ba_device_cus(int dev) {
   }
   return cus;
 }
+#define BA_DET_RANGES 16
 static int ba_group_ranges(cms_ba** bas, int n) {
   const int cus = ba_device_cus(bas[0]->device);
   int R = BA_SE_RANGES;
@@ -225,6 +226,9 @@ static int ba_group_ranges(cms_ba** bas, int n) {
   // path wait for it to drain.  With a few CUs left over they run NEXT to it instead of behind it
   static const int reserve = [] { const char* v = getenv("CMS_BA_RESERVE_CUS"); return v ? std::max(0, atoi(v)) : 0; }();
   if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, std::max(n, cus - reserve) / n));
+  // deterministic windows: how a window's chunks are cut into workgroups decides which sums meet in which order, so the cut must not depend on
+  // the company the window is optimised in -- always BA_DET_RANGES workgroups (16 windows x 16 = the chip once; the solve kernel adds the slices)
+  if (n > 0 && bas[0]->deterministic && !bas[0]->det_points) return BA_DET_RANGES;
   // CMS_BA_RANGES_PER_WINDOW=k: k workgroups per window whatever the chip has (A/B: shorter workgroups let the other group's small kernels in sooner)
   static const int per_window = [] { const char* v = getenv("CMS_BA_RANGES_PER_WINDOW"); return v ? atoi(v) : 0; }();
   if (per_window > 0) R = std::max(2, std::min(BA_SE_RANGES, per_window));
@@ -233,7 +237,7 @@ static int ba_group_ranges(cms_ba** bas, int n) {
 // Which kernels a group's rounds are made of: decided ONCE per group from the windows' lists and the knobs (ba_upload_items and the stage
 // driver both use it).  fused: the Schur kernel linearises itself (edge-major kernels + three-lane solve); rm: windows with signature runs
 // send them through the run-major body (needs the fused path and full 512-thread workgroups)
-struct BaGroupMode { bool use_se, use_te, use_s3, fused, rm, gsum, run_wg; int se_waves; };
+struct BaGroupMode { bool use_se, use_te, use_s3, fused, rm, gsum, run_wg, det; int se_waves; };
 static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
   BaGroupMode m;
   m.use_se = ba_use_se(bas, n); m.use_te = ba_use_te(bas, n);
@@ -250,9 +254,12 @@ static BaGroupMode ba_group_mode(cms_ba** bas, int n) {
   if (ba_knobs().se_waves_cap > 0 && !ba_knobs().rm_valu) m.se_waves = std::max(1, std::min(m.se_waves, ba_knobs().se_waves_cap));      // (the MFMA body takes any count)
   // one global copy of the reduced system per window, added to by all its workgroups (not with the A/B knobs that want the slices or launch a
   // kernel of the round twice)
-  m.gsum = m.fused && ba_knobs().global_sum && !ba_knobs().separate_reduce && ba_knobs().dup == 0;
+  // deterministic windows (fused chain, fixed order): cms_ba_optimize_many forms groups of one kind, so either all windows are or none is
+  m.det = m.fused && n > 0 && bas[0]->deterministic && !bas[0]->det_points;
+  for (int w = 0; w < n; ++w) if ((bas[w]->deterministic && !bas[w]->det_points) != m.det) m.det = false;
+  m.gsum = m.fused && ba_knobs().global_sum && !ba_knobs().separate_reduce && ba_knobs().dup == 0 && !m.det;      // (global FP64 atomics have no order)
   // the runs through one-wavefront workgroups (cms_ba_schur_runwg.hip): they add to the global copy, so they need it; the MFMA body only
-  m.run_wg = m.rm && m.gsum && ba_knobs().run_wg && !ba_knobs().rm_valu;
+  m.run_wg = m.rm && m.gsum && ba_knobs().run_wg && !ba_knobs().rm_valu && !m.det;
   return m;
 }
 static int ba_upload_items(cms_ba** bas, int n) {
@@ -288,6 +295,7 @@ static int ba_upload_items(cms_ba** bas, int n) {
       ba_se_split(it.se, ba_group_ranges(bas, n), gm.run_wg);
     }
     it.se.gsum = (use_se && gm.gsum) ? 1 : 0;
+    it.se.det = gm.det ? 1 : 0;
     b->grp_se = it.se;
     if (use_se && b->d_se_partial) {
       // the global copy of the reduced system (slice 0) must be zero when the first round of a gsum group adds to it; the consuming solve kernel
@@ -456,6 +464,7 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
   const bool solve_reduces = fused && (gm.gsum || (!ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max));
   dyn.fused_lin = fused ? 1 : 0;
+  // (deterministic windows, se.det: kb_ba_first_pass adds the key frames' diagonal sums -- lambda starts from their maximum -- in chunk and slice order)
   const bool first_pass = fused && use_te && first_round && !ba_knobs().separate_first_pass;      // (a stage's windows all start at it == 0)
   // the trial kernel sums its own partial sums and decides the trial (kb_ba_trial_edges) -- not with CMS_BA_DUP: the deciding kernel is not
   // idempotent (its last workgroup advances the Levenberg state and counts the round), a duplicated launch would evaluate a different state
@@ -505,6 +514,9 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
           if (any_rw1) hipLaunchKernelGGL(kb_ba_lin_schur_run_wg1, dim3(rw_units1, 1, n), dim3(64), rw_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL, rw_units1);
           if (any_rw0) hipLaunchKernelGGL(kb_ba_lin_schur_run_wg0, dim3(rw_units0, 1, n), dim3(64), rw_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL, rw_units0);
           if (max_seR > 0) hipLaunchKernelGGL(kb_ba_lin_schur_edges, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+        } else if (fused && gm.det) {      // additions in a fixed order, slices instead of the global copy
+          if (any_runs) hipLaunchKernelGGL(kb_ba_lin_schur_runs_det, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+          else hipLaunchKernelGGL(kb_ba_lin_schur_edges_det, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         } else if (fused && any_runs) {
           hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
           if (dup == 3) hipLaunchKernelGGL(kb_ba_lin_schur_runs, dim3(max_seR, 1, n), dim3(se_threads), se_lds, s, ditems, dyn, (int)BA_PHASE_TRIAL);
@@ -625,7 +637,14 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
   if (!bas || n < 1) return cms_fail(CMS_ERR_ARG, "cms_ba_optimize_many: bad argument");
   for (int w = 0; w < n; ++w) if (!bas[w]) return cms_fail(CMS_ERR_ARG, "null ba");
   // (device-planned windows among themselves: their groups always run the fused kernels, which is all they carry lists for)
-  auto kind = [&](int w) { return bas[w]->device * 8 + (bas[w]->fast_plan ? 4 : 0) + (bas[w]->se.nchunks > 0 ? 2 : 0) + (bas[w]->deterministic ? 1 : 0); };
+  // (a deterministic window's sums must not depend on its company: windows that would change the group's kernels -- fewer wavefronts per workgroup,
+  // no signature runs -- form groups of their own)
+  auto kind = [&](int w) {
+    const cms_ba* b = bas[w];
+    int k = b->device * 8 + (b->fast_plan ? 4 : 0) + (b->se.nchunks > 0 ? 2 : 0) + (b->deterministic ? 1 : 0);
+    if (b->deterministic) k += 1024 * (1 + (b->det_points ? 1 : 0) + 2 * (b->rm_lds > 0 ? 1 : 0) + 4 * std::max(0, std::min(15, b->se_waves)));
+    return k;
+  };
   bool one = n <= BA_MAX_GROUP;
   for (int w = 1; w < n && one; ++w) one = kind(w) == kind(0);
   if (one) return ba_optimize_group(bas, n, its_robust, its_final, stop, stats);

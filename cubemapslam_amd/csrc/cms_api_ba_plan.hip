@@ -215,7 +215,7 @@ static bool ba_fast_plan_allowed(const BaKnobs& kn) {
 template <class Tick>
 static int ba_plan_fast(cms_ba* b, BaFastPlan& fp, int K, const uint8_t* fixed, int P, int E, const int* e_pose, const int* e_point, const int8_t* e_face, Tick&& tick) {
   const BaKnobs& kn = ba_knobs();
-  if (K > 64 || b->deterministic || !ba_fast_plan_allowed(kn)) return 0;
+  if (K > 64 || b->det_points || !ba_fast_plan_allowed(kn)) return 0;
   // ---- the one pass over the observations: validation, observations per point, key-frame set per point, observations per key frame
   std::vector<int>&cnt = fp.cnt, &cpo = fp.cpo; std::vector<uint64_t>& sig = fp.sig;
   cnt.assign(P, 0); sig.assign(P, 0); fp.pose_cnt.assign(K, 0);

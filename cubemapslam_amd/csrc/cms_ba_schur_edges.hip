@@ -69,6 +69,8 @@ struct BaSe {                      // device view of the edge-major work list (c
   const int* lone; int nlone;     // points without any observation (in no chunk): the trial kernel copies their position
   int gsum;                       // 1: the workgroups ADD their LDS copies to slice 0 of partial / bp_partial (global_atomic_add_f64) instead of writing a slice
                                   // each; the solve kernel reads that one slice and puts the zeros back (kb_ba_trial_solve3r)
+  int det;                        // 1: a deterministic window in a fixed-order group (kb_ba_first_pass sums the key frames' diagonals in chunk and slice order)
+  int pad_[3];                    // (sizeof(BaItem) stays a multiple of 16: the items travel as 16-byte words)
 };
 
 struct BaSeG {                     // BaSe with global-memory pointer types (see BaDevG, cms_ba_kernels.hip): what the device bodies take
@@ -79,12 +81,12 @@ struct BaSeG {                     // BaSe with global-memory pointer types (see
   const BA_AS1 int* chunk_e0; const BA_AS1 uint32_t* e_info;
   BA_AS1 double* partial; BA_AS1 double* bp_partial;
   const BA_AS1 int* lone; int nlone;
-  int gsum;
+  int gsum, det;
   __device__ __forceinline__ BaSeG() {}
   __device__ __forceinline__ BaSeG(const BaSe& s)
       : R(s.R), nchunks(s.nchunks), cpw(s.cpw), n_rm(s.n_rm), R_rm(s.R_rm), rm_chunk(ba_g(s.rm_chunk)), run_lane(ba_g(s.run_lane)), run_mf(ba_g(s.run_mf)),
         run_fl(ba_g(s.run_fl)), rm_cost(ba_g(s.rm_cost)), run_fg(ba_g(s.run_fg)), rm_cut(ba_g(s.rm_cut)), n_rmA(s.n_rmA), Rt(s.Rt), cpw_t(s.cpw_t), npairs2(s.npairs2), chunk_e0(ba_g(s.chunk_e0)), e_info(ba_g(s.e_info)), partial(ba_g(s.partial)),
-        bp_partial(ba_g(s.bp_partial)), lone(ba_g(s.lone)), nlone(s.nlone), gsum(s.gsum) {}
+        bp_partial(ba_g(s.bp_partial)), lone(ba_g(s.lone)), nlone(s.nlone), gsum(s.gsum), det(s.det) {}
 };
 
 __device__ __forceinline__ int ba_se_pair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 - 1)) >> 1) + (s2 - s1); }   // s1 <= s2, dense (with diagonal)
@@ -114,16 +116,47 @@ __device__ __forceinline__ void ba_se_cam_point(const double* Rt, const double* 
 // S_aa - Hpp_aa, its right-hand side  s_a - bp_a; bp alone goes to six more slots: the gain ratio needs it).  From the second iteration
 // of a stage on no other kernel linearises: kb_ba_lin + kb_ba_maxdiag drop out of the round (25 + 7 us of ~165 for eight windows), and a
 // rejected trial merely repeats arithmetic this kernel had to do anyway (it rebuilt the Jacobians from the estimate before, too).
+// ---- FIXED-ORDER additions (deterministic windows: cms_ba_set_deterministic, the kernels kb_ba_lin_schur_runs_det / kb_ba_lin_schur_edges_det).
+// The only thing that makes the sums of this kernel family differ in their last bits from run to run is the ORDER in which the wavefronts of a
+// workgroup add to the workgroup's LDS copy (the workgroups' copies go out as slices that the solve kernel adds in slice order, every wavefront's
+// chunks are a fixed range, and inside a wavefront the instruction order is the program's).  The deterministic kernels give every set of additions
+// a KEY that follows from the window's plan alone -- t = the estimated cost of the wavefront's chunks up to and including the one the additions
+// belong to (run-major body and its left-over chunks), or the chunk's index (edge-major body) -- and perform the sets in ascending (t, wavefront)
+// order: L[w] (LDS) holds a lower bound of wavefront w's next key, published at the start of every chunk once its previous additions are through
+// (lgkmcnt(0)); a wavefront adds when every other wavefront's bound lies above its key.  Nobody waits unless the others are BEHIND it in
+// estimated time, so the wavefronts still overlap their vector / matrix phases; the wavefront with the smallest pending key can always go (no
+// deadlock: there is no workgroup barrier between the first publication and the last).
+#define BA_DET_DONE 0xFFFFFFFFu
+#define BA_AS3 __attribute__((address_space(3)))
+typedef volatile BA_AS3 uint32_t* ba_det_ptr;                      // (an LDS pointer by type: a volatile generic pointer is accessed with flat instructions)
+__device__ __forceinline__ void ba_det_publish(ba_det_ptr L, int wave, uint32_t t) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's LDS additions so far have been performed
+  if ((threadIdx.x & 63) == 0) L[wave] = t == BA_DET_DONE ? BA_DET_DONE : ((t << 3) | (uint32_t)wave);
+}
+__device__ __forceinline__ void ba_det_wait(ba_det_ptr L, int wave, int nw, uint32_t t) {
+  const uint32_t key = (t << 3) | (uint32_t)wave;
+  const int lane = threadIdx.x & 63;
+  for (;;) {
+    const uint32_t v = lane < nw ? L[lane] : BA_DET_DONE;
+    if (__ballot(lane != wave && v <= key) == 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+
 template <bool FUSED> __device__ __forceinline__ void ba_se_writeout(int slice, int np, int NP2, const double* S, const double* Dg, const BaSeG& se);
 // The chunks [c_begin, c_end) in steps of c_step, worked on by ONE wavefront: its 64 rows and row slots in LDS, the workgroup's copy (S, Dg) of the
 // reduced system and the key frames' rotations / translations (prt) are the caller's -- the edge-major body below (a wavefront takes every nw-th
 // chunk of the workgroup's range) and the run-major body (cms_ba_schur_runs.hip: a wavefront's share of the left-over chunks behind its run chunks).
-template <bool FUSED>
+// DET (fixed-order additions, see above): 0 no order; 1 key = chunk index - det_base; 2 key = se.rm_cost[chunk + 1] - det_base
+template <bool FUSED, int DET = 0>
 __device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c1, const int c_step, const BaDevG& d, const BaSeG& se, double* __restrict__ Hll,
                                                   double* __restrict__ bl, const double lambda, const double* __restrict__ pts, const int robust, const double delta,
-                                                  double* S, double* Dg, double* myrows, int* myslot, const double* prt) {
+                                                  double* S, double* Dg, double* myrows, int* myslot, const double* prt,
+                                                  ba_det_ptr detL = nullptr, const uint32_t det_base = 0) {
 #pragma clang fp contract(fast)
   const int lane = threadIdx.x & 63;
+  const int det_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), det_nw = (int)(blockDim.x >> 6);
   const int np = d.np;
   // The loop is software pipelined over a wave's chunks: the per-edge words of chunk c + nw are requested before chunk c is worked on,
   // its per-point operands (position, Hll, bl) right after chunk c's rows are published -- the atomics section hides their latency.
@@ -156,6 +189,11 @@ __device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c
   load1(c_begin);
   load2();
   for (int c = c_begin; c < c1; c += c_step) {
+    uint32_t det_t = 0;
+    if (DET) {
+      det_t = DET == 1 ? (uint32_t)c - det_base : se.rm_cost[c + 1] - det_base;
+      ba_det_publish(detL, det_wave, det_t);
+    }
     const uint32_t info = n_info;
     double ow = (FUSED && n_lvl != 0) ? 0.0 : n_ow;
     const int pnt = n_p, eid = n_e;
@@ -271,6 +309,7 @@ __device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     load2();                     // next chunk's per-point operands travel while this chunk's products are added
+    if (DET) ba_det_wait(detL, det_wave, det_nw, det_t);      // this chunk's additions: behind those of every smaller key
     // ---- diagonal tuple (a, a): W D^-1 W^T (upper triangle) and the right-hand side W D^-1 y, into this edge's copy of the diagonal blocks
     if (slot >= 0) {
       double* base = Dg + ((size_t)(info >> 27) * np + slot) * BA_SE_DSTRIDE;
@@ -332,11 +371,14 @@ __device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c
   }
 }
 
-template <bool FUSED>
+template <bool FUSED, bool DET = false>
 __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                     const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
   extern __shared__ __align__(16) double se_lds[];
+  __shared__ uint32_t det_L_[8];                                  // DET: the wavefronts' key bounds (ba_det_publish / ba_det_wait)
+  const ba_det_ptr det_L = (ba_det_ptr)det_L_;
   const int tid = threadIdx.x, wave = tid >> 6, nw = blockDim.x >> 6;
+  if (DET && tid < 8) det_L_[tid] = 0u;
   const int np = d.np, NP2 = se.npairs2, NPO = NP2 - np;
   double* S = se_lds;                                              // NPO x 37: off-diagonal pairs s1 < s2
   double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);               // 4 x np x 33: copies of the diagonal blocks (upper triangle | rhs | bp)
@@ -354,6 +396,10 @@ __device__ __forceinline__ void ba_schur_edges_body(int BX, BaDevG d, BaSeG se, 
   }
   __syncthreads();
   const int c0 = se.n_rm + BX * se.cpw, c1 = min(se.nchunks, c0 + se.cpw);      // (the chunks in front of n_rm belong to the run-major body)
+  if (DET) {      // additions in chunk order, whatever the number of wavefronts
+    ba_se_wave_chunks<FUSED, 1>(c0 + wave, c1, nw, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, rows + (size_t)wave * 64 * 18, rslot + wave * 64, prt, det_L, (uint32_t)c0);
+    ba_det_publish(det_L, __builtin_amdgcn_readfirstlane(wave), BA_DET_DONE);
+  } else
   ba_se_wave_chunks<FUSED>(c0 + wave, c1, nw, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, rows + (size_t)wave * 64 * 18, rslot + wave * 64, prt);
   __syncthreads();
   ba_se_writeout<FUSED>(se.R_rm + BX, np, NP2, S, Dg, se);
@@ -370,7 +416,11 @@ __device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaS
 #pragma clang fp contract(fast)
   extern __shared__ __align__(16) double te_lds[];     // K x 12 (rotation | translation) | np x 6 (diagonal sums of the free key frames)
   __shared__ double sh[16];
+  __shared__ uint32_t det_L_[8];                        // se.det: the key frames' sums are added in chunk order (ba_det_publish / ba_det_wait) ...
+  const ba_det_ptr det_L = (ba_det_ptr)det_L_;
+  const bool det = se.det != 0;                         // ... and handed over as this workgroup's slice, which the window's last workgroup adds in slice order
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  if (tid < 8) det_L_[tid] = 0u;
   double* prc = te_lds;
   double* pd = prc + (size_t)d.K * 12;
   for (int k = tid; k < d.K; k += blockDim.x) {
@@ -387,11 +437,13 @@ __device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaS
   double chi = 0, mx = 0;
   const int c0 = BX * se.cpw_t, c1 = min(se.nchunks, c0 + se.cpw_t);
   for (int c = c0 + wave; c < c1; c += nw) {
+    if (det) ba_det_publish(det_L, __builtin_amdgcn_readfirstlane(wave), (uint32_t)(c - c0));
     const int e0 = se.chunk_e0[c], e1 = se.chunk_e0[c + 1];
     const int e = e0 + lane;
     const bool have = e < e1;
     int a = 0, k = 1;
     double dl[3] = {0, 0, 0};
+    double dp[6] = {0, 0, 0, 0, 0, 0}; int dps = -1;
     if (have) {
       const uint32_t info = se.e_info[e];
       const int p = d.e_point[e];
@@ -416,12 +468,18 @@ __device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaS
         const double ow = w * einv;
         edge_jac_face(d, face, Xc, R, Jp, Jl);
         if (s >= 0) {
+          dps = s;
 #pragma unroll
-          for (int i = 0; i < 6; ++i) unsafeAtomicAdd(pd + 6 * s + i, ow * (Jp[i] * Jp[i] + Jp[6 + i] * Jp[6 + i]));
+          for (int i = 0; i < 6; ++i) dp[i] = ow * (Jp[i] * Jp[i] + Jp[6 + i] * Jp[6 + i]);
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) dl[j] = ow * (Jl[j] * Jl[j] + Jl[3 + j] * Jl[3 + j]);
       }
+    }
+    if (det) ba_det_wait(det_L, __builtin_amdgcn_readfirstlane(wave), nw, (uint32_t)(c - c0));      // (all lanes are back together here)
+    if (dps >= 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) unsafeAtomicAdd(pd + 6 * dps + i, dp[i]);
     }
     // the point's first lane adds its lanes' shares in edge order
     int kmax = k;
@@ -435,6 +493,7 @@ __device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaS
     }
     if (head) mx = fmax(mx, fmax(sl[0], fmax(sl[1], sl[2])));
   }
+  if (det) ba_det_publish(det_L, __builtin_amdgcn_readfirstlane(wave), BA_DET_DONE);
   const double s1 = block_sum(chi, sh);
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
   __syncthreads();
@@ -445,6 +504,11 @@ __device__ __forceinline__ void ba_first_pass_body(int BX, int GX, BaDevG d, BaS
   for (int i = tid; i < 6 * d.np; i += blockDim.x) {           // (up to 62 free key frames: more entries than threads)
     const double v = pd[i];
     // (a non-finite sum stays out, like the fmax of the kernel this one replaced dropped NaNs: lambda's start must not be poisoned by one degenerate edge)
+    if (det) {      // this workgroup's slice (parked in `partial` of the Schur kernel, which has not run yet): the last workgroup adds the slices in order
+      const unsigned long long o = __hip_atomic_exchange(reinterpret_cast<BA_AS1 unsigned long long*>(se.partial) + ((size_t)BX * 6 * d.np + i),
+                                                         (unsigned long long)__double_as_longlong(isfinite(v) ? v : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" :: "v"(o) : "memory");
+    } else
     if (v != 0.0 && isfinite(v)) { const double o = atomicAdd(pose_diag + i, v); asm volatile("" :: "v"(o) : "memory"); }
   }
   if (tid == 0) {

@@ -392,6 +392,9 @@ template <int PERM> __device__ __forceinline__ double ba_quad_perm(double v) {
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), PERM, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+// DET: the additions to the LDS copy in a fixed order (deterministic windows; ba_det_publish / ba_det_wait in cms_ba_schur_edges.hip): the key of a
+// chunk's additions is the estimated cost of the wavefront's chunks up to and including that chunk
+template <bool DET = false>
 __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG se, double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                         const double* __restrict__ poses, const double* __restrict__ pts, int robust, double delta) {
 #pragma clang fp contract(fast)
@@ -415,6 +418,9 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   double* Dg = S + ((NPO * BA_SE_SSTRIDE + 1) & ~1);
   double* bufs = Dg + (size_t)BA_SE_DCOPIES * np * BA_SE_DSTRIDE;  // one chunk buffer per wavefront
   double* prt = bufs + (size_t)BA_RM_PAIRS * 2 * BA_RM_BUF;        // (eight buffers: the same LDS budget as the vector variant's 4 x 2)
+  __shared__ uint32_t det_L_[8];                                   // DET: the wavefronts' key bounds
+  const ba_det_ptr det_L = (ba_det_ptr)det_L_;
+  if (DET && tid < 8) det_L_[tid] = 0u;
   for (int i = tid; i < (int)(prt - S); i += blockDim.x) S[i] = 0.0;      // the chunk buffers too: whatever the matrix phase reads must be finite
   for (int k = tid; k < d.K; k += blockDim.x) {
     double R[9];
@@ -451,6 +457,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     return __builtin_amdgcn_readfirstlane(lo);
   };
   int cb, ce, eb, ee;                                              // run chunks [cb, ce), left-over chunks [eb, ee)
+  uint32_t det_cost0 = 0;                                          // DET: the running cost in front of the wavefront's first chunk
   {
     const unsigned long long total_cost = se.rm_cost[n_all];
     int b0 = gw == 0 ? 0 : first_at((total_cost * (unsigned long long)gw + total_waves - 1) / total_waves);
@@ -458,6 +465,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     b0 = min(b0, n_all); b1 = max(min(b1, n_all), b0);
     cb = min(b0, se.n_rm); ce = min(b1, se.n_rm);
     eb = max(b0, se.n_rm); ee = max(b1, se.n_rm);
+    if (DET) det_cost0 = se.rm_cost[b0];
   }
   const int li = lane & 15, lk = lane >> 4;
 
@@ -524,8 +532,15 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   long long clk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long clk_last = (long long)__builtin_readcyclecounter();
 #endif
+  uint32_t det_cn = DET && cb < ce ? (uint32_t)se.rm_cost[cb + 1] : 0u;      // running cost behind the chunk about to be worked on (requested a chunk ahead)
   for (int c = cb; c < ce; ++c) {
     BA_RM_STAMP(0);                                                // loop overhead / previous flush tail
+    uint32_t det_t = 0; bool det_waited = false;
+    if (DET) {
+      det_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(det_cn - det_cost0));
+      ba_det_publish(det_L, wave, det_t);                          // "my next additions have at least this key" (the previous ones are through)
+      if (c + 1 < ce) det_cn = se.rm_cost[c + 2];
+    }
     const int4 desc = d_cur;
     const int ne = desc.y & 255, k_run = (desc.y >> 8) & 255, m = desc.y >> 16;
     const uint32_t info = n_info;
@@ -765,6 +780,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
 #pragma unroll
           for (int u = 0; u < 3; ++u) { dd[u] += 192u; ad[0][u] += st[0]; ad[1][u] += st[1]; ad[2][u] += st[2]; }
         }
+        if (DET) { ba_det_wait(det_L, wave, nw, det_t); det_waited = true; }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
@@ -792,6 +808,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     BA_RM_STAMP(7);                                                // matrix phase
     // ---------------------------------------------------------------- end of the run (or of this wavefront's range): one set of LDS additions
     if (d_cur.z != desc.z) {
+      if (DET && !det_waited) ba_det_wait(det_L, wave, nw, det_t);
       if (hp_slot >= 0) {
         double* base = Dg + ((size_t)(jpt & (BA_SE_DCOPIES - 1)) * np + hp_slot) * BA_SE_DSTRIDE;
 #pragma unroll
@@ -826,6 +843,10 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   }
 #endif
   // ---- the wavefront's left-over chunks (se.R == 0 only): the edge-major chunk loop on this wavefront's buffer (64 rows of 18 doubles, then the row slots)
+  if (DET) {
+    if (eb < ee) ba_se_wave_chunks<true, 2>(eb, ee, 1, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt, det_L, det_cost0);
+    ba_det_publish(det_L, wave, BA_DET_DONE);                      // (also the wavefronts without a chunk)
+  } else
   if (eb < ee) ba_se_wave_chunks<true>(eb, ee, 1, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt);
   __syncthreads();
   ba_se_writeout<true>(BX, np, NP2, S, Dg, se);

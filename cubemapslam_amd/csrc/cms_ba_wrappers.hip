@@ -290,6 +290,17 @@ extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_runs
   if ((int)blockIdx.x < it.se.R_rm) ba_schur_runs_mfma_body(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
   else ba_schur_edges_body<true>((int)blockIdx.x - it.se.R_rm, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
 }
+// ... and the two with their LDS additions in a fixed order (deterministic windows, cms_ba_set_deterministic: bit-identical sums from run to run; the
+// workgroups store slices, se.gsum = 0, which the solve kernel adds in slice order)
+extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_runs_det(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.R_rm + it.se.R)
+  if ((int)blockIdx.x < it.se.R_rm) ba_schur_runs_mfma_body<true>(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
+  else ba_schur_edges_body<true, true>((int)blockIdx.x - it.se.R_rm, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
+}
+extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_edges_det(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, it.se.R)
+  ba_schur_edges_body<true, true>(blockIdx.x, it.d, it.se, it.Hll, it.bl, ba_lambda, it.poses[cur], it.pts[cur], dyn.robust, dyn.delta);
+}
 // ... the same with the runs' products on the vector ALU (producer / consumer wavefront pairs; CMS_BA_RM_VALU=1, A/B)
 extern "C" __global__ void __launch_bounds__(BA_SE_THREADS) kb_ba_lin_schur_runs_valu(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.se.R_rm + it.se.R)
@@ -414,6 +425,14 @@ extern "C" __global__ void __launch_bounds__(BA_TE_THREADS) kb_ba_first_pass(con
   const double chi = block_sum(v, sh2);
   double m = 0;
   double* pose_diag = it.Hpp;
+  if (it.se.det) {      // a deterministic window: the workgroups' slices of the diagonal sums, added in slice order
+    for (int i = threadIdx.x; i < 6 * it.d.np; i += blockDim.x) {
+      double sum = 0.0;
+      for (int r = 0; r < n; ++r)
+        sum += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<BA_AS1 unsigned long long*>(it.se.partial) + ((size_t)r * 6 * it.d.np + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      m = fmax(m, fabs(sum));
+    }
+  } else
   for (int i = threadIdx.x; i < 6 * it.d.np; i += blockDim.x)       // (read and put back to zero for the next stage)
     m = fmax(m, fabs(__longlong_as_double((long long)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(pose_diag + i), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
   if (threadIdx.x == 0) m = fmax(m, __longlong_as_double((long long)atomicExch(pt_max, 0ull)));

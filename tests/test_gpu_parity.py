@@ -597,6 +597,45 @@ def test_ba_deterministic_mode_is_bit_repeatable_and_matches_the_oracle(views):
     det.close(); dflt.close()
 
 
+def test_ba_deterministic_windows_repeat_twenty_times_whatever_their_company():
+    """The deterministic mode's contract on the windows bench.py optimises (K = 20, 80 k observations, tracked views -- signature runs through
+    kb_ba_lin_schur_runs_det -- and random views -- every point through kb_ba_lin_schur_edges_det): TWENTY runs of a window give the same bits
+    (poses, points, outlier flags); a window gives those bits again when it is optimised in one cms_ba_optimize_many call with other deterministic
+    windows (how a window's chunks are cut into workgroups does not depend on the group: BA_DET_RANGES), when its group call creates it
+    (cms_ba_create_many, the plan kernel included) and whatever order the group lists its windows in; iteration counts and flags are the oracle's."""
+    probs = [synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=77, views="track"),
+             synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=78, views="random"),
+             synth.ba_problem(K=12, P=6000, obs_per_point=4, F=550, seed=91, views="track"),
+             synth.ba_problem(K=20, P=9000, obs_per_point=5, F=550, seed=79, views="track")]
+    api.ba_set_deterministic(True)
+    try:
+        alone = [api.ba_run(p) for p in probs]
+        for i in (0, 1):
+            for r in range(19):
+                g = api.ba_run(probs[i])
+                assert np.array_equal(g["poses"], alone[i]["poses"]) and np.array_equal(g["points"], alone[i]["points"]) and \
+                    np.array_equal(g["outliers"], alone[i]["outliers"]), (i, r)
+        for order in ((0, 1, 2, 3), (3, 0, 2, 1), (2, 2, 0)):
+            bas = [api.BundleAdjuster(probs[i]) for i in order]
+            api.ba_optimize_many(bas, (5, 10))
+            for i, ba in zip(order, bas):
+                o = ba.read()
+                assert np.array_equal(o[0], alone[i]["poses"]) and np.array_equal(o[1], alone[i]["points"]), (order, i)
+                ba.close()
+        grp = api.ba_create_many([dict(probs[i], _plan_on_device=True) for i in (0, 3, 0)])
+        api.ba_optimize_many(list(grp), (5, 10))
+        for i, o in zip((0, 3, 0), api.ba_read_many(grp)):
+            assert np.array_equal(o[0], alone[i]["poses"]) and np.array_equal(o[1], alone[i]["points"]), i
+        for ba in grp:
+            ba.close()
+    finally:
+        api.ba_set_deterministic(False)
+    for p, g in zip(probs[:2], alone[:2]):
+        w = orc.ba_run(p)
+        assert list(g["stats"].iterations_done) == list(w["stats"].iterations_done) and np.array_equal(g["outliers"], w["outliers"])
+        _ba_updates_close_or_cascade(p, g["poses"], g["points"], w, tag="deterministic K=20")
+
+
 def test_c_abi_error_paths():
     """the C-ABI reports misuse with a status code and a message instead of crashing or silently truncating"""
     import ctypes as C
@@ -1319,12 +1358,16 @@ def test_kfstore_fuse_search_matches_oracle():
 @pytest.mark.parametrize("knob", ["CMS_BA_NO_FUSED_LIN", "CMS_BA_DETERMINISTIC", "CMS_BA_NO_PERMUTE", "CMS_BA_NO_RUNS", "CMS_BA_RUNS_AS_EDGES",
                                   "CMS_BA_SEPARATE_REDUCE", "CMS_BA_RM_VALU", "CMS_BA_SOLVE_REDUCE_MAX=1000",
                                   "CMS_BA_SPLIT_WORKGROUPS", "CMS_BA_SEPARATE_REDUCE2", "CMS_BA_SEPARATE_FIRST_PASS", "CMS_BA_TE_CHUNKS=1", "CMS_BA_TE_CHUNKS=5",
-                                  "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT", "CMS_BA_HOST_PLAN", "CMS_BA_LEFTOVER_LOOKAHEAD=4", "CMS_BA_RUN_WG"])
+                                  "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT", "CMS_BA_HOST_PLAN", "CMS_BA_LEFTOVER_LOOKAHEAD=4", "CMS_BA_RUN_WG",
+                                  "CMS_BA_DETERMINISTIC+CMS_BA_DET_POINTS", "CMS_BA_DETERMINISTIC+CMS_BA_NO_RUNS", "CMS_BA_DETERMINISTIC+CMS_BA_SPLIT_WORKGROUPS",
+                                  "CMS_BA_DETERMINISTIC+CMS_BA_HOST_PLAN"])
 def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     """The grouped local-BA driver has several Schur paths -- signature runs multiplied in MFMA tiles + edge-major left-overs, linearisation
     fused (default); the runs' products on the vector ALU by producer / consumer wavefront pairs (CMS_BA_RM_VALU); every point edge-major
     (CMS_BA_NO_RUNS), also with the run order kept (CMS_BA_RUNS_AS_EDGES); the edge-major kernel behind
-    kb_ba_lin (CMS_BA_NO_FUSED_LIN); the deterministic pair-owner kernel (CMS_BA_DETERMINISTIC) -- a host-side chunk composition that can be
+    kb_ba_lin (CMS_BA_NO_FUSED_LIN); deterministic windows (CMS_BA_DETERMINISTIC: since round 6 the fused chain with its LDS additions in a fixed order,
+    kb_ba_lin_schur_runs_det / _edges_det and slices; with CMS_BA_DET_POINTS the pair-owner kernel of rounds 3-5; also without runs, with separate
+    workgroups for the left-over chunks, with the host's plan) -- a host-side chunk composition that can be
     switched off (CMS_BA_NO_PERMUTE), and the range sum either inside the solve kernel (the default for groups whose windows have at most 24
     range slices each, i.e. 11 or more windows per group; CMS_BA_SOLVE_REDUCE_MAX=1000: always) or as its own launch (CMS_BA_SEPARATE_REDUCE).
     Round 4's alternatives: separate workgroups for run chunks and left-over chunks instead of cost-balanced ranges over both
@@ -1336,7 +1379,8 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""
     import os, subprocess, sys
     env = dict(os.environ)
-    env[knob.split("=")[0]] = knob.split("=")[1] if "=" in knob else "1"
+    for kn in knob.split("+"):
+        env[kn.split("=")[0]] = kn.split("=")[1] if "=" in kn else "1"
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
                         "config4_size_eight or stop_flag_raised or mixed_sizes or tracked_windows"], env=env, capture_output=True, text=True, timeout=900)
