@@ -148,7 +148,8 @@ template <bool FUSED> __device__ __forceinline__ void ba_se_writeout(int slice, 
 // The chunks [c_begin, c_end) in steps of c_step, worked on by ONE wavefront: its 64 rows and row slots in LDS, the workgroup's copy (S, Dg) of the
 // reduced system and the key frames' rotations / translations (prt) are the caller's -- the edge-major body below (a wavefront takes every nw-th
 // chunk of the workgroup's range) and the run-major body (cms_ba_schur_runs.hip: a wavefront's share of the left-over chunks behind its run chunks).
-// DET (fixed-order additions, see above): 0 no order; 1 key = chunk index - det_base; 2 key = se.rm_cost[chunk + 1] - det_base
+// DET (fixed-order additions, see above): 0 no order; 1 key = chunk index - det_base; 2 key = se.rm_cost[chunk + 1] - det_base; 3 key = det_base + the
+// estimated cost of the chunks this call has worked on so far (a strided share of the chunks: the run-major body's deterministic variant)
 template <bool FUSED, int DET = 0>
 __device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c1, const int c_step, const BaDevG& d, const BaSeG& se, double* __restrict__ Hll,
                                                   double* __restrict__ bl, const double lambda, const double* __restrict__ pts, const int robust, const double delta,
@@ -188,10 +189,12 @@ __device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c
   };
   load1(c_begin);
   load2();
+  uint32_t det_acc = det_base;
   for (int c = c_begin; c < c1; c += c_step) {
     uint32_t det_t = 0;
     if (DET) {
-      det_t = DET == 1 ? (uint32_t)c - det_base : se.rm_cost[c + 1] - det_base;
+      if (DET == 3) det_acc += se.rm_cost[c + 1] - se.rm_cost[c];
+      det_t = DET == 1 ? (uint32_t)c - det_base : DET == 2 ? se.rm_cost[c + 1] - det_base : det_acc;
       ba_det_publish(detL, det_wave, det_t);
     }
     const uint32_t info = n_info;
@@ -309,7 +312,11 @@ __device__ __forceinline__ void ba_se_wave_chunks(const int c_begin, const int c
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     load2();                     // next chunk's per-point operands travel while this chunk's products are added
+#if defined(BA_DET_NO_WAIT_LEFT)      /* developer A/B (tools/ab_build.sh): what the order costs -- results are then NOT repeatable */
+    if (DET == 1) ba_det_wait(detL, det_wave, det_nw, det_t);
+#else
     if (DET) ba_det_wait(detL, det_wave, det_nw, det_t);      // this chunk's additions: behind those of every smaller key
+#endif
     // ---- diagonal tuple (a, a): W D^-1 W^T (upper triangle) and the right-hand side W D^-1 y, into this edge's copy of the diagonal blocks
     if (slot >= 0) {
       double* base = Dg + ((size_t)(info >> 27) * np + slot) * BA_SE_DSTRIDE;

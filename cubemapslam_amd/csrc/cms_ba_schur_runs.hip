@@ -440,7 +440,12 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   // range reaches behind n_rm hands that part to the edge-major body's chunk loop (below the run loop): the split between the two kinds of
   // chunk then has the granularity of a wavefront, not of a workgroup (2 or 3 of a window's 16, the long pole of the launch either way).
   // first chunk whose running sum reaches the wavefront's share: a 64-wide search, two rounds for up to 4095 chunks
-  const int n_all = se.R == 0 ? se.nchunks : se.n_rm;
+  // DET: the cut by cost covers the run chunks only and every wavefront takes a STRIDED share of the left-over chunks behind its runs (chunk n_rm + its
+  // index, + the window's wavefront count, ...).  The left-over chunks sit at the end of the chunk list: cut by cost they are the whole range of the
+  // window's last workgroups, whose eight wavefronts then add every chunk's ~100 products per lane one after the other -- 175 us per launch instead of 90
+  // (16 windows, profiles/r06_det_experiment.txt); spread over all workgroups each wavefront has one or two of them
+  const bool det_strided = DET && se.R == 0;
+  const int n_all = (se.R == 0 && !det_strided) ? se.nchunks : se.n_rm;
   auto first_at = [&](unsigned long long target) {
     int lo = 0, span = n_all + 1;                                  // answer in [lo, lo + span): rm_cost[n_all] >= any target
     while (span > 1) {
@@ -780,7 +785,9 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
 #pragma unroll
           for (int u = 0; u < 3; ++u) { dd[u] += 192u; ad[0][u] += st[0]; ad[1][u] += st[1]; ad[2][u] += st[2]; }
         }
+#ifndef BA_DET_NO_WAIT_RUNS
         if (DET) { ba_det_wait(det_L, wave, nw, det_t); det_waited = true; }
+#endif
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
@@ -808,7 +815,9 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     BA_RM_STAMP(7);                                                // matrix phase
     // ---------------------------------------------------------------- end of the run (or of this wavefront's range): one set of LDS additions
     if (d_cur.z != desc.z) {
+#ifndef BA_DET_NO_WAIT_RUNS
       if (DET && !det_waited) ba_det_wait(det_L, wave, nw, det_t);
+#endif
       if (hp_slot >= 0) {
         double* base = Dg + ((size_t)(jpt & (BA_SE_DCOPIES - 1)) * np + hp_slot) * BA_SE_DSTRIDE;
 #pragma unroll
@@ -844,6 +853,10 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
 #endif
   // ---- the wavefront's left-over chunks (se.R == 0 only): the edge-major chunk loop on this wavefront's buffer (64 rows of 18 doubles, then the row slots)
   if (DET) {
+    if (det_strided)
+      ba_se_wave_chunks<true, 3>(se.n_rm + (int)gw, se.nchunks, (int)total_waves, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt,
+                                 det_L, cb < ce ? (uint32_t)se.rm_cost[ce] - det_cost0 : 0u);
+    else
     if (eb < ee) ba_se_wave_chunks<true, 2>(eb, ee, 1, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt, det_L, det_cost0);
     ba_det_publish(det_L, wave, BA_DET_DONE);                      // (also the wavefronts without a chunk)
   } else
