@@ -296,6 +296,10 @@ static int ba_upload_items(cms_ba** bas, int n) {
     }
     it.se.gsum = (use_se && gm.gsum) ? 1 : 0;
     it.se.det = gm.det ? 1 : 0;
+    // the run-major body's wavefronts take the left-over chunks strided (one or two each, behind their runs) instead of cut by cost (the whole range of the
+    // window's last workgroups: 145 chunks' ds_add_f64 on two or three CUs' LDS pipes).  Found while ordering the deterministic kernel's additions:
+    // 94 -> 84-87 us per 16-window launch alone, +1.9 % frames/s in bench.py's step (three A/B pairs, profiles/r06_det_experiment.txt).  CMS_BA_LEFT_BY_COST=1: round 4's cut
+    { static const bool left_by_cost = getenv("CMS_BA_LEFT_BY_COST") != nullptr; it.se.strided = left_by_cost ? 0 : 1; }
     b->grp_se = it.se;
     if (use_se && b->d_se_partial) {
       // the global copy of the reduced system (slice 0) must be zero when the first round of a gsum group adds to it; the consuming solve kernel

@@ -70,7 +70,8 @@ struct BaSe {                      // device view of the edge-major work list (c
   int gsum;                       // 1: the workgroups ADD their LDS copies to slice 0 of partial / bp_partial (global_atomic_add_f64) instead of writing a slice
                                   // each; the solve kernel reads that one slice and puts the zeros back (kb_ba_trial_solve3r)
   int det;                        // 1: a deterministic window in a fixed-order group (kb_ba_first_pass sums the key frames' diagonals in chunk and slice order)
-  int pad_[3];                    // (sizeof(BaItem) stays a multiple of 16: the items travel as 16-byte words)
+  int strided;                    // 1: the run-major body's wavefronts take the left-over chunks strided (chunk n_rm + wavefront, + wavefronts, ...) instead of cut by cost
+  int pad_[2];                    // (sizeof(BaItem) stays a multiple of 16: the items travel as 16-byte words)
 };
 
 struct BaSeG {                     // BaSe with global-memory pointer types (see BaDevG, cms_ba_kernels.hip): what the device bodies take
@@ -81,12 +82,12 @@ struct BaSeG {                     // BaSe with global-memory pointer types (see
   const BA_AS1 int* chunk_e0; const BA_AS1 uint32_t* e_info;
   BA_AS1 double* partial; BA_AS1 double* bp_partial;
   const BA_AS1 int* lone; int nlone;
-  int gsum, det;
+  int gsum, det, strided;
   __device__ __forceinline__ BaSeG() {}
   __device__ __forceinline__ BaSeG(const BaSe& s)
       : R(s.R), nchunks(s.nchunks), cpw(s.cpw), n_rm(s.n_rm), R_rm(s.R_rm), rm_chunk(ba_g(s.rm_chunk)), run_lane(ba_g(s.run_lane)), run_mf(ba_g(s.run_mf)),
         run_fl(ba_g(s.run_fl)), rm_cost(ba_g(s.rm_cost)), run_fg(ba_g(s.run_fg)), rm_cut(ba_g(s.rm_cut)), n_rmA(s.n_rmA), Rt(s.Rt), cpw_t(s.cpw_t), npairs2(s.npairs2), chunk_e0(ba_g(s.chunk_e0)), e_info(ba_g(s.e_info)), partial(ba_g(s.partial)),
-        bp_partial(ba_g(s.bp_partial)), lone(ba_g(s.lone)), nlone(s.nlone), gsum(s.gsum), det(s.det) {}
+        bp_partial(ba_g(s.bp_partial)), lone(ba_g(s.lone)), nlone(s.nlone), gsum(s.gsum), det(s.det), strided(s.strided) {}
 };
 
 __device__ __forceinline__ int ba_se_pair(int np, int s1, int s2) { return s1 * np - ((s1 * (s1 - 1)) >> 1) + (s2 - s1); }   // s1 <= s2, dense (with diagonal)

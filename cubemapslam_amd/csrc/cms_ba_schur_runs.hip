@@ -444,7 +444,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   // index, + the window's wavefront count, ...).  The left-over chunks sit at the end of the chunk list: cut by cost they are the whole range of the
   // window's last workgroups, whose eight wavefronts then add every chunk's ~100 products per lane one after the other -- 175 us per launch instead of 90
   // (16 windows, profiles/r06_det_experiment.txt); spread over all workgroups each wavefront has one or two of them
-  const bool det_strided = DET && se.R == 0;
+  const bool det_strided = (DET || se.strided != 0) && se.R == 0;      // (se.strided: the same distribution for the default kernel -- the default since round 6; CMS_BA_LEFT_BY_COST=1 restores the cut by cost)
   const int n_all = (se.R == 0 && !det_strided) ? se.nchunks : se.n_rm;
   auto first_at = [&](unsigned long long target) {
     int lo = 0, span = n_all + 1;                                  // answer in [lo, lo + span): rm_cost[n_all] >= any target
@@ -859,8 +859,10 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     else
     if (eb < ee) ba_se_wave_chunks<true, 2>(eb, ee, 1, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt, det_L, det_cost0);
     ba_det_publish(det_L, wave, BA_DET_DONE);                      // (also the wavefronts without a chunk)
-  } else
-  if (eb < ee) ba_se_wave_chunks<true>(eb, ee, 1, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt);
+  } else {
+    const int lb = det_strided ? se.n_rm + (int)gw : eb, le = det_strided ? se.nchunks : ee, ls = det_strided ? (int)total_waves : 1;
+    if (lb < le) ba_se_wave_chunks<true>(lb, le, ls, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt);
+  }
   __syncthreads();
   ba_se_writeout<true>(BX, np, NP2, S, Dg, se);
 }

@@ -190,7 +190,7 @@ typedef struct cms_ba_window {
  * for those kernels (40 bytes of counts per window come back).  Same device arrays, byte for byte.  Worth it for a host short of cores -- the plan is
  * ~0.4 ms of a host thread per 80 k-observation window, half of what a two-core rank spends per step of bench.py; with cores to spare the host plan overlaps
  * the GPU better (bench.py sets the flag when its rank has at most two cores).  Windows the kernel does not take (a point seen twice by a key frame, no
- * signature runs, more than 64 key frames, deterministic mode) fall back to the host planners inside the call; an index out of range fails the call as ever. */
+ * signature runs, more than 64 key frames, CMS_BA_DET_POINTS windows) fall back to the host planners inside the call; an index out of range fails the call as ever. */
 #define CMS_BA_PLAN_ON_DEVICE 2
 int cms_ba_create_many(cms_ba** out, int n, int device, const cms_ba_window* windows, int threads);
 /* ... and the read-back of n optimised windows (Optimizer.cpp:419-450): poses[i] / points[i] / outlier_flags[i] as cms_ba_read's (the arrays of
@@ -262,10 +262,15 @@ void cms_ba_destroy(cms_ba* ba);
 int cms_ba_pool_trim(int device, size_t* released);
 /* Determinism as a product mode.  The reference optimises with a single-threaded g2o (ThirdParty/g2o/config.h:4: no OpenMP), so two runs on
  * the same window give the same bits.  The default device path adds with FP64 atomics (order varies from run to run: last bits differ, see
- * DESIGN.md section 2); cms_ba_set_deterministic(1) makes every window created AFTERWARDS run the fixed-order kernels (pair-owner Schur kernel,
- * kb_ba_schur_points: bit-identical runs, slower).  The choice is taken at cms_ba_create and travels with the window; windows of both kinds may
- * be passed to one cms_ba_optimize_many call (they run as separate groups).  Process-wide; the environment variable CMS_BA_DETERMINISTIC=1 gives
- * the initial value.  cms_ba_get_deterministic returns the current setting. */
+ * DESIGN.md section 2); cms_ba_set_deterministic(1) makes every window created AFTERWARDS add in a fixed order: the same kernels as the default
+ * path with the Schur kernel's LDS additions performed in an order that follows from the window's plan alone (kb_ba_lin_schur_runs_det /
+ * kb_ba_lin_schur_edges_det), the workgroups' sums kept as slices that the solve kernel adds in slice order instead of one global copy, and a cut
+ * into workgroups that does not depend on the other windows of the call.  Same input, same bits: run after run, alone or in any group of a
+ * cms_ba_optimize_many call, created by cms_ba_create or cms_ba_create_many (plan kernel included); bench.py's step runs at 0.83 of the default with
+ * it (config.deterministic).  Windows the fused chain cannot take (more than 25 free key frames, a point seen twice by a key frame) run rounds 3-5's
+ * pair-owner kernel (kb_ba_schur_points, CMS_BA_DET_POINTS=1 selects it for all) -- deterministic as well.  The choice is taken at cms_ba_create and
+ * travels with the window; windows of both kinds may be passed to one cms_ba_optimize_many call (they run as separate groups).  Process-wide; the
+ * environment variable CMS_BA_DETERMINISTIC=1 gives the initial value.  cms_ba_get_deterministic returns the current setting. */
 int cms_ba_set_deterministic(int on);
 int cms_ba_get_deterministic(void);
 /* one-shot convenience: create + optimize + read + destroy */
