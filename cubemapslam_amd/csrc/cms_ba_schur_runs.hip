@@ -473,7 +473,17 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     if (DET) det_cost0 = se.rm_cost[b0];
   }
   const int li = lane & 15, lk = lane >> 4;
+  // BA_RM_LEFT_FIRST (developer A/B, tools/ab_build.sh): the odd wavefronts of a workgroup work through their strided left-over chunks BEFORE their runs, so that
+  // a workgroup's eight wavefronts do not all reach the edge-major additions (~100 ds_add_f64 per lane and chunk) at the same moment, the end of the launch
+#ifndef BA_RM_LEFT_FIRST
+#define BA_RM_LEFT_FIRST 0
+#endif
+  const bool left_first = BA_RM_LEFT_FIRST && det_strided && (wave & 1);
+  uint32_t det_left_total = 0;                                     // DET: estimated cost of this wavefront's left-over chunks (the offset of its run keys when they come first)
+  if (DET && left_first)
+    for (int c = se.n_rm + (int)gw; c < se.nchunks; c += (int)total_waves) det_left_total += se.rm_cost[c + 1] - se.rm_cost[c];
 
+  auto run_phase = [&](const uint32_t det_toff) {
   double hp[27];
 #pragma unroll
   for (int i = 0; i < 27; ++i) hp[i] = 0.0;
@@ -542,7 +552,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     BA_RM_STAMP(0);                                                // loop overhead / previous flush tail
     uint32_t det_t = 0; bool det_waited = false;
     if (DET) {
-      det_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(det_cn - det_cost0));
+      det_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(det_toff + det_cn - det_cost0));
       ba_det_publish(det_L, wave, det_t);                          // "my next additions have at least this key" (the previous ones are through)
       if (c + 1 < ce) det_cn = se.rm_cost[c + 2];
     }
@@ -851,18 +861,32 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
     ba_rm_clk[12] = ce - cb;
   }
 #endif
+  };
   // ---- the wavefront's left-over chunks (se.R == 0 only): the edge-major chunk loop on this wavefront's buffer (64 rows of 18 doubles, then the row slots)
+  auto left_phase = [&](const uint32_t det_toff) {
   if (DET) {
     if (det_strided)
       ba_se_wave_chunks<true, 3>(se.n_rm + (int)gw, se.nchunks, (int)total_waves, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt,
-                                 det_L, cb < ce ? (uint32_t)se.rm_cost[ce] - det_cost0 : 0u);
+                                 det_L, det_toff);
     else
     if (eb < ee) ba_se_wave_chunks<true, 2>(eb, ee, 1, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt, det_L, det_cost0);
-    ba_det_publish(det_L, wave, BA_DET_DONE);                      // (also the wavefronts without a chunk)
   } else {
     const int lb = det_strided ? se.n_rm + (int)gw : eb, le = det_strided ? se.nchunks : ee, ls = det_strided ? (int)total_waves : 1;
     if (lb < le) ba_se_wave_chunks<true>(lb, le, ls, d, se, Hll, bl, lambda, pts, robust, delta, S, Dg, slots, reinterpret_cast<int*>(slots + 64 * 18), prt);
   }
+  };
+  const uint32_t det_run_total = (DET && cb < ce) ? (uint32_t)se.rm_cost[ce] - det_cost0 : 0u;
+#if BA_RM_LEFT_FIRST
+#pragma nounroll
+  for (int ph = 0; ph < 2; ++ph) {
+    if ((ph == 0) == left_first) left_phase(left_first ? 0u : det_run_total);
+    else run_phase(left_first ? det_left_total : 0u);
+  }
+#else
+  run_phase(0u);
+  left_phase(det_run_total);
+#endif
+  if (DET) ba_det_publish(det_L, wave, BA_DET_DONE);               // (also the wavefronts without a chunk)
   __syncthreads();
   ba_se_writeout<true>(BX, np, NP2, S, Dg, se);
 }
