@@ -478,7 +478,7 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
 #ifndef BA_RM_LEFT_FIRST
 #define BA_RM_LEFT_FIRST 0
 #endif
-  const bool left_first = BA_RM_LEFT_FIRST && det_strided && (wave & 1);
+  const bool left_first = BA_RM_LEFT_FIRST && det_strided && (BA_RM_LEFT_FIRST == 2 || (BA_RM_LEFT_FIRST == 3 && DET) || (wave & 1));      // 2: every wavefront; 3: every wavefront of the deterministic kernel
   uint32_t det_left_total = 0;                                     // DET: estimated cost of this wavefront's left-over chunks (the offset of its run keys when they come first)
   if (DET && left_first)
     for (int c = se.n_rm + (int)gw; c < se.nchunks; c += (int)total_waves) det_left_total += se.rm_cost[c + 1] - se.rm_cost[c];
