@@ -368,6 +368,9 @@ __device__ __forceinline__ void ba_schur_runs_body(int BX, BaDevG d, BaSeG se, d
 __host__ __device__ constexpr uint32_t ba_rm_chunk_cost(int k_run, int kf, int m) {
   return 45u + (uint32_t)((kf <= 2 ? 1 : kf <= 5 ? 3 : 6) * 3 * ((m + 3) >> 2)) + ((k_run == 2 || k_run == 4) ? 0u : 5u);
 }
+#ifndef BA_RM_BALANCE_LEFT
+#define BA_RM_BALANCE_LEFT 1      /* 0: A/B -- the run chunks in equal shares of the RUNS' cost, whatever left-over chunks a wavefront has on top */
+#endif
 #define BA_RM_MF_NONE 0xFFFFu
 #define BA_RM_MF_RHS 0xFFFEu
 typedef double ba_v4d __attribute__((ext_vector_type(4)));
@@ -465,8 +468,22 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   uint32_t det_cost0 = 0;                                          // DET: the running cost in front of the wavefront's first chunk
   {
     const unsigned long long total_cost = se.rm_cost[n_all];
-    int b0 = gw == 0 ? 0 : first_at((total_cost * (unsigned long long)gw + total_waves - 1) / total_waves);
-    int b1 = gw + 1 >= total_waves ? n_all : first_at((total_cost * (unsigned long long)(gw + 1) + total_waves - 1) / total_waves);
+    // strided left-over chunks: wavefront g has (n_left / W) or (n_left / W) + 1 of them (the first n_left % W wavefronts one more) -- its share of the RUN chunks is what
+    // is left of an equal share of the window's whole cost: wavefronts 0 .. 16 of a tracked configs[3] window have two left-over chunks (~100 cost units each next to
+    // ~600 of runs), i.e. the window's first two workgroups ran 14 % over the mean.  Plain proportional shares of the runs when the left-over chunks dominate (the
+    // targets must ascend: every run chunk belongs to exactly one wavefront)
+    const int n_left = se.nchunks - se.n_rm;
+    const unsigned long long total_all = det_strided ? (unsigned long long)se.rm_cost[se.nchunks] : total_cost, left_total = total_all - total_cost;
+    const long long l_base = n_left / total_waves, l_rem = n_left % total_waves;
+    const bool balanced = BA_RM_BALANCE_LEFT && det_strided && n_left > 0 && (left_total * (unsigned long long)(l_base + 1)) / (unsigned long long)n_left + 2 <= total_all / (unsigned long long)total_waves;
+    auto target = [&](long long g) -> unsigned long long {
+      if (!balanced) return (total_cost * (unsigned long long)g + total_waves - 1) / total_waves;
+      const unsigned long long t = (total_all * (unsigned long long)g + total_waves - 1) / total_waves;
+      const unsigned long long l = left_total * (unsigned long long)(g * l_base + (g < l_rem ? g : l_rem)) / (unsigned long long)n_left;      // the left-over chunks of the wavefronts in front of g
+      return t > l ? (t - l < total_cost ? t - l : total_cost) : 0ull;
+    };
+    int b0 = gw == 0 ? 0 : first_at(target(gw));
+    int b1 = gw + 1 >= total_waves ? n_all : first_at(target(gw + 1));
     b0 = min(b0, n_all); b1 = max(min(b1, n_all), b0);
     cb = min(b0, se.n_rm); ce = min(b1, se.n_rm);
     eb = max(b0, se.n_rm); ee = max(b1, se.n_rm);

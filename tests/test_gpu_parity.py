@@ -636,6 +636,29 @@ def test_ba_deterministic_windows_repeat_twenty_times_whatever_their_company():
         _ba_updates_close_or_cascade(p, g["poses"], g["points"], w, tag="deterministic K=20")
 
 
+def test_ba_deterministic_mode_on_windows_of_every_solver_path():
+    """Deterministic windows the fixed-order fused chain does not take fall back to deterministic kernels of their own -- 27 and 29 free key frames (no
+    three-lane solve: the pair-owner kernel on the host's full plan), 39 (register-tiled scalar solve) -- and small or odd windows (two key frames, a
+    single free one, 25 free = the three-lane solve's limit, fewer wavefronts per workgroup) run the fixed-order kernels: three runs give the same bits,
+    iteration counts and flags are the oracle's, the estimates pass the default path's bar."""
+    shapes = [dict(K=2, P=120, obs_per_point=2, seed=7), dict(K=3, P=300, obs_per_point=3, seed=8), dict(K=26, P=1500, obs_per_point=5, seed=16),
+              dict(K=28, P=1500, obs_per_point=5, seed=3), dict(K=30, P=2000, obs_per_point=5, seed=5), dict(K=40, P=2500, obs_per_point=6, seed=4),
+              dict(K=23, P=4000, obs_per_point=4, seed=31, views="track"), dict(K=25, P=5000, obs_per_point=4, seed=32, views="track")]
+    for sh in shapes:
+        prob = synth.ba_problem(F=550, **sh)
+        api.ba_set_deterministic(True)
+        try:
+            runs = [api.ba_run(prob) for _ in range(3)]
+        finally:
+            api.ba_set_deterministic(False)
+        for g in runs[1:]:
+            assert np.array_equal(g["poses"], runs[0]["poses"]) and np.array_equal(g["points"], runs[0]["points"]) and np.array_equal(g["outliers"], runs[0]["outliers"]), sh
+        w = orc.ba_run(prob)
+        g = runs[0]
+        assert list(g["stats"].iterations_done) == list(w["stats"].iterations_done) and np.array_equal(g["outliers"], w["outliers"]), sh
+        _ba_updates_close_or_cascade(prob, g["poses"], g["points"], w, tag="deterministic %r" % (sh,))
+
+
 def test_c_abi_error_paths():
     """the C-ABI reports misuse with a status code and a message instead of crashing or silently truncating"""
     import ctypes as C
