@@ -187,6 +187,9 @@ int PoseOptimization(Frame* pFrame) {
   return n_in;                                                     // nInitialCorrespondences - nBad
 }
 
+void SetDeterministic(bool on) { cms_ba_set_deterministic(on ? 1 : 0); }
+bool GetDeterministic() { return cms_ba_get_deterministic() != 0; }
+
 void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
   CamModelGeneral* cam = CamModelGeneral::GetCamera();
   // ---- the window: local key frames, the map points they see, fixed key frames that see those (Optimizer.cpp:194-245)

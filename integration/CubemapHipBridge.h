@@ -36,6 +36,11 @@ int SearchLocalPoints(cms_ctx* ctx, Frame& F, const std::vector<MapPoint*>& vpMa
 int PoseOptimization(Frame* pFrame);
 // Optimizer::LocalBundleAdjustment (Optimizer.cpp:192-451)
 void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap);
+// The reference's g2o is single-threaded (ThirdParty/g2o/config.h:4): the same window gives the same bits every time.  SetDeterministic(true) makes every
+// LocalBundleAdjustment call from then on add in a fixed order on the device (cms_ba_set_deterministic: 0.83 of the default throughput); the default adds with
+// FP64 atomics and its last bits vary from run to run (DESIGN.md section 2 says what it guarantees).
+void SetDeterministic(bool on);
+bool GetDeterministic();
 
 // ---- LocalMapping's per-key-frame sequence on key frames RESIDENT on the device (cms_kfstore_*).  The store maps KeyFrame* -> slot; a key frame enters
 // it once (ProcessNewKeyFrame), its pose and map-point slots are refreshed where the reference changes them, and it leaves with ReleaseKeyFrame
