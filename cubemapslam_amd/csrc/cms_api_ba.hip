@@ -1306,8 +1306,10 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   auto up_in = [&](const void* src, size_t bytes, auto** dst) { ups.push_back({src, bytes, reinterpret_cast<void**>(dst), inputs_pinned && bytes >= 4096}); };
   if (se_built) {
     const int NP2 = np * (np + 1) / 2;
-    // (a deterministic window's first pass parks its workgroups' diagonal sums in `partial` before the first Schur launch: Rt <= P / 8 + 2 slices of 6 np)
-    const size_t se_partial_n = std::max((size_t)BA_SE_RANGES * NP2 * 42, b->deterministic ? ((size_t)P / 8 + 4) * 6 * (size_t)np : (size_t)0);
+    // (a deterministic window's first pass parks its workgroups' diagonal sums in `partial` before the first Schur launch: Rt slices of 6 np, and Rt =
+    // chunks / cpw_t rounded up <= P / cpw_t + 2 -- a chunk holds at least one point)
+    const size_t cpw_t_min = (size_t)(BA_TE_THREADS / 64) * (size_t)std::max(1, kn.te_chunks);
+    const size_t se_partial_n = std::max((size_t)BA_SE_RANGES * NP2 * 42, b->deterministic ? ((size_t)P / cpw_t_min + 4) * 6 * (size_t)np : (size_t)0);
     BA_TRY(ba_alloc(b, &b->d_se_partial, se_partial_n)); BA_TRY(ba_alloc(b, &b->d_se_bp_partial, (size_t)BA_SE_RANGES * np * 6));
     BA_TRY(ba_alloc(b, &b->d_se_sum, (size_t)NP2 * 42));
     b->se.partial = b->d_se_partial; b->se.bp_partial = b->d_se_bp_partial;
