@@ -1365,12 +1365,18 @@ def main():
             warm_keep = args.warmup
             args.warmup = max(args.warmup, 3)          # (these windows are larger: their slabs enter the pool during the warm-up)
             dt_d, _, ba_ms_d, _ = timed(False, steps=args.deterministic_steps)
+            dt_dc = None
+            if cpp is not None and world == 1 and os.environ.get("CMS_BA_DET_POINTS", "") == "":      # ... and through the headline's C++ step driver (the mode is the process's: its windows are deterministic too)
+                dt_dc, _ = timed_cpp(steps=args.deterministic_steps)
             args.warmup = warm_keep
         finally:
             api.ba_set_deterministic(False)
         deterministic = {"value": round(total_frames_per_step * args.deterministic_steps / dt_d, 2), "ms_per_step": round(1e3 * dt_d / args.deterministic_steps, 3),
                          "ba_ms_per_step": round(ba_ms_d, 3), "steps": args.deterministic_steps,
                          "of_python_step_loop": (round(total_frames_per_step * args.deterministic_steps / dt_d / python_loop["value"], 3) if python_loop else None),      # (this pass runs the Python loop too)
+                         "step_driver": ({"value": round(total_frames_per_step * args.deterministic_steps / dt_dc, 2), "ms_per_step": round(1e3 * dt_dc / args.deterministic_steps, 3),
+                                          "of_value": round(total_frames_per_step * args.deterministic_steps / dt_dc / (total_frames_per_step * args.steps / dt), 3),
+                                          "note": "the same deterministic steps through the C++ step driver, like `value`"} if dt_dc else None),
                          "note": ("cms_ba_set_deterministic(1): the fused chain with the Schur kernel's LDS additions in a fixed order (kb_ba_lin_schur_runs_det: keys from the plan's "
                                   "estimated chunk costs), workgroup slices added by the solve kernel in slice order instead of global FP64 atomics, 16 workgroups per window whatever the "
                                   "group, kb_ba_first_pass adding the key frames' diagonal sums in chunk and slice order; planned like default windows -- bit-identical from run to run"
