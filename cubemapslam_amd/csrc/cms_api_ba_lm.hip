@@ -468,6 +468,12 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
   // the range slices summed by the solve kernel's assembly (kb_ba_trial_solve3r) instead of by a launch of their own
   const bool solve_reduces = fused && (gm.gsum || (!ba_knobs().separate_reduce && max_seR <= ba_knobs().solve_reduce_max));
   dyn.fused_lin = fused ? 1 : 0;
+  {
+    // slices (deterministic windows, CMS_BA_NO_GLOBAL_SUM): the solve kernel adds them into LDS with all its threads first, where the LDS allows it (<= 21 free key frames)
+    static const bool no_presum = getenv("CMS_BA_NO_SOLVE_PRESUM") != nullptr;      // developer A/B
+    const size_t need = lds3 + (size_t)max_np2 * 42 * sizeof(double);
+    if (use_s3 && solve_reduces && !gm.gsum && !no_presum && need <= BA_LDS_CEILING) { dyn.solve_presum = 1; lds3 = need; }
+  }
   // (deterministic windows, se.det: kb_ba_first_pass adds the key frames' diagonal sums -- lambda starts from their maximum -- in chunk and slice order)
   const bool first_pass = fused && use_te && first_round && !ba_knobs().separate_first_pass;      // (a stage's windows all start at it == 0)
   // the trial kernel sums its own partial sums and decides the trial (kb_ba_trial_edges) -- not with CMS_BA_DUP: the deciding kernel is not

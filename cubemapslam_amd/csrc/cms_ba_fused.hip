@@ -332,13 +332,16 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
                  const int* __restrict__ pair_of_block, const int* __restrict__ pair_chunk_off,
                  const double* __restrict__ chunk_sum, const double* __restrict__ poses, double* __restrict__ poses_new,
                  double* __restrict__ xp_out, double* __restrict__ scal, bool lumped = false, double* partial = nullptr,
-                 double* bp_partial = nullptr, int n_slices = 0, int NP2 = 0, bool consume = false) {
+                 double* bp_partial = nullptr, int n_slices = 0, int NP2 = 0, bool consume = false, bool presum = false) {
   // lumped: the diagonal blocks of chunk_sum hold S - Hpp and s - bp already (fused linearisation, cms_ba_schur_edges.hip); bp is only
   // read for the gain ratio
   // partial != nullptr (implies lumped): the Schur kernel's range slices [n_slices][NP2][42] are summed here, in slice order, instead of by
   // kb_ba_schur_edges_reduce -- one launch less per round; bp (sum of the slices of bp_partial) is formed in LDS and stored for later readers
   // consume (n_slices == 1): the Schur kernel's workgroups ADDED their copies to the one slice (BaSe::gsum); every element is read by exactly
   // one thread here, which puts the zero back for the next round's additions
+  // presum (slices, not consume; the launch carries NP2 x 42 more doubles of LDS): ALL threads first add the slices element by element, in slice order, into
+  // LDS -- coalesced loads, many in flight -- and the assembly reads the sums there.  The assembly's own loop walks the slices behind two loads in flight per
+  // thread: 66 instead of 42 us for the 16 slices of a deterministic window (profiles/r06_det_experiment.txt)
   extern __shared__ __align__(16) double sm[];
   const int nb = d.np, n = 6 * nb, nblk = nb * (nb + 1) / 2;
   // LDS (doubles): L panels [nb (nb - 1) / 2][38] | diagonal factors [nb][36] | W double buffer [2][nb][38] | diag staging [36] | y [n] | 1/D [n] | bp [n]
@@ -349,6 +352,18 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
   double* ybuf = dstage + 36;
   double* idg = ybuf + n;
   double* bps = idg + n;
+  double* ssum = bps + n;                          // presum: the slices' sums, NP2 x 42
+  const bool presummed = partial && presum && !consume && n_slices > 1;
+  if (presummed) {
+    const int tot = NP2 * 42;
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+      double v = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < n_slices; ++r) v += partial[(size_t)r * tot + i];
+      ssum[i] = v;
+    }
+    __syncthreads();
+  }
 #ifdef BA_S3_CLK
   const bool s3_on = threadIdx.x == 0 && blockIdx.z == 0;
   long long s3_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -393,7 +408,12 @@ __device__ __forceinline__ void ba_trial_solve3_body(BaDevG d, const double* __r
     }
     const int pr = pair_of_block[I * (I + 1) / 2 + K];
     double yb[2] = {0, 0};
-    if (partial) {
+    if (presummed) {
+      const double* cs = ssum + (size_t)pr * 42;      // (LDS)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { const double2 v = *reinterpret_cast<const double2*>(cs + 6 * q + r0); a[q] -= v.x; a[6 + q] -= v.y; }
+      if (I == K) { const double2 v = *reinterpret_cast<const double2*>(cs + 36 + r0); yb[0] += v.x; yb[1] += v.y; }
+    } else if (partial) {
       // dense pair enumeration (se_pob): slice r holds this pair's 42 sums at (r NP2 + pr) 42; two slices' loads are in flight together
       // (the kernel is compiled for up to 1024 threads, 128 registers: four slices spilled).  Rows r0, r0 + 1 of the block are columns r0, r0 + 1
       // of the stored (transposed) block: one 16-byte access per stored row

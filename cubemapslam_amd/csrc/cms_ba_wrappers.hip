@@ -75,6 +75,7 @@ struct BaDyn {
   double delta, chi2_th;
   int dev_lm, fold_finish;                           // 1: phase / cur / lambda / first_iter come from BaItem::lm instead of the arrays above
   int fused_lin, fold_reduce;                        // fused_lin 1: kb_ba_schur_edges linearises itself (cms_ba_schur_edges.hip): no ITER phase after a stage's first iteration
+  int solve_presum, pad_;                            // kb_ba_trial_solve3r: the slices summed into LDS by all threads first (the launch carries the LDS for it)
 };
 enum { BA_PHASE_IDLE = 0, BA_PHASE_ITER = 1, BA_PHASE_TRIAL = 2, BA_PHASE_CLASSIFY = 3 };
 
@@ -342,7 +343,7 @@ extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3(const BaIt
 extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3r(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
   ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal,
-                       true, (double*)it.se.partial, (double*)it.se.bp_partial, it.se.gsum ? 1 : it.se.R_rm + it.se.R, it.se.npairs2, it.se.gsum != 0);
+                       true, (double*)it.se.partial, (double*)it.se.bp_partial, it.se.gsum ? 1 : it.se.R_rm + it.se.R, it.se.npairs2, it.se.gsum != 0, dyn.solve_presum != 0);
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
