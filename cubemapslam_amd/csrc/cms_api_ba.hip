@@ -160,7 +160,7 @@ static int ba_lds_attrs_once(int device) {
   std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || done[device]) return CMS_OK;
   const void* fns[] = {(const void*)k_ba_schur_points, (const void*)kb_ba_schur_points, (const void*)kb_ba_schur_edges, (const void*)kb_ba_lin_schur_edges,
-                       (const void*)kb_ba_lin_schur_runs, (const void*)kb_ba_lin_schur_runs_det, (const void*)kb_ba_lin_schur_edges_det, (const void*)kb_ba_lin_schur_runs_valu, (const void*)kb_ba_lin_schur_run_wg0, (const void*)kb_ba_lin_schur_run_wg1, (const void*)kb_ba_trial_solve3r, (const void*)k_ba_trial_solve,
+                       (const void*)kb_ba_lin_schur_runs, (const void*)kb_ba_lin_schur_runs_det, (const void*)kb_ba_lin_schur_edges_det, (const void*)kb_ba_lin_schur_runs_valu, (const void*)kb_ba_lin_schur_run_wg0, (const void*)kb_ba_lin_schur_run_wg1, (const void*)kb_ba_trial_solve3r, (const void*)kb_ba_trial_solve3rp, (const void*)k_ba_trial_solve,
                        (const void*)kb_ba_trial_solve, (const void*)kb_ba_trial_solve3, (const void*)k_ba_solve_r192};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_CEILING);

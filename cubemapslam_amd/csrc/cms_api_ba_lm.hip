@@ -554,7 +554,9 @@ static int ba_optimize_stage_batched_dev(cms_ba** bas, int n, std::vector<BaLm>&
         hipLaunchKernelGGL(kb_ba_schur_chunks, dim3(max_chunks, 1, n), dim3(256), 0, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       }
       bracket(5, 0);
-      if (use_s3 && solve_reduces) {
+      if (use_s3 && solve_reduces && dyn.solve_presum) {
+        hipLaunchKernelGGL(kb_ba_trial_solve3rp, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
+      } else if (use_s3 && solve_reduces) {
         hipLaunchKernelGGL(kb_ba_trial_solve3r, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
         if (dup == 5) hipLaunchKernelGGL(kb_ba_trial_solve3r, dim3(1, 1, n), dim3(s3_threads), lds3, s, ditems, dyn, (int)BA_PHASE_TRIAL);
       } else if (use_s3) {

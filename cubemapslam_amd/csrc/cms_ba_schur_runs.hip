@@ -495,7 +495,9 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
 #ifndef BA_RM_LEFT_FIRST
 #define BA_RM_LEFT_FIRST 0
 #endif
-  const bool left_first = BA_RM_LEFT_FIRST && det_strided && (BA_RM_LEFT_FIRST == 2 || (BA_RM_LEFT_FIRST == 3 && DET) || (wave & 1));      // 2: every wavefront; 3: every wavefront of the deterministic kernel
+  // The deterministic kernel does this for its odd wavefronts (-2 % per 16-window call: half as many wavefronts queue for their turn at either end of the range); for the
+  // default kernel it measured neutral to slower (profiles/r06_det_experiment.txt, item 6)
+  const bool left_first = (BA_RM_LEFT_FIRST || DET) && det_strided && (BA_RM_LEFT_FIRST == 2 || (wave & 1));      // (2: every wavefront)
   uint32_t det_left_total = 0;                                     // DET: estimated cost of this wavefront's left-over chunks (the offset of its run keys when they come first)
   if (DET && left_first)
     for (int c = se.n_rm + (int)gw; c < se.nchunks; c += (int)total_waves) det_left_total += se.rm_cost[c + 1] - se.rm_cost[c];
@@ -893,16 +895,16 @@ __device__ __forceinline__ void ba_schur_runs_mfma_body(int BX, BaDevG d, BaSeG 
   }
   };
   const uint32_t det_run_total = (DET && cb < ce) ? (uint32_t)se.rm_cost[ce] - det_cost0 : 0u;
-#if BA_RM_LEFT_FIRST
+  if (BA_RM_LEFT_FIRST || DET) {
 #pragma nounroll
-  for (int ph = 0; ph < 2; ++ph) {
-    if ((ph == 0) == left_first) left_phase(left_first ? 0u : det_run_total);
-    else run_phase(left_first ? det_left_total : 0u);
+    for (int ph = 0; ph < 2; ++ph) {
+      if ((ph == 0) == left_first) left_phase(left_first ? 0u : det_run_total);
+      else run_phase(left_first ? det_left_total : 0u);
+    }
+  } else {
+    run_phase(0u);
+    left_phase(det_run_total);
   }
-#else
-  run_phase(0u);
-  left_phase(det_run_total);
-#endif
   if (DET) ba_det_publish(det_L, wave, BA_DET_DONE);               // (also the wavefronts without a chunk)
   __syncthreads();
   ba_se_writeout<true>(BX, np, NP2, S, Dg, se);

@@ -343,7 +343,14 @@ extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3(const BaIt
 extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3r(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, 1)
   ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal,
-                       true, (double*)it.se.partial, (double*)it.se.bp_partial, it.se.gsum ? 1 : it.se.R_rm + it.se.R, it.se.npairs2, it.se.gsum != 0, dyn.solve_presum != 0);
+                       true, (double*)it.se.partial, (double*)it.se.bp_partial, it.se.gsum ? 1 : it.se.R_rm + it.se.R, it.se.npairs2, it.se.gsum != 0, false);
+}
+// ... for groups whose windows keep slices (deterministic windows, CMS_BA_NO_GLOBAL_SUM): all threads add the slices into LDS first (a kernel of its own: the
+// extra phase cost the default kernel 96 B of scratch when it was a run-time switch)
+extern "C" __global__ void __launch_bounds__(1024) kb_ba_trial_solve3rp(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
+  BA_ITEM(phase, 1)
+  ba_trial_solve3_body(it.d, it.Hpp, it.bp, ba_lambda, it.pair_of_block, it.pair_chunk_off, it.chunk_sum, it.poses[cur], it.poses[nxt], it.x, it.scal,
+                       true, (double*)it.se.partial, (double*)it.se.bp_partial, it.se.R_rm + it.se.R, it.se.npairs2, false, true);
 }
 extern "C" __global__ void __launch_bounds__(128) kb_ba_trial_points(const BaItem* __restrict__ items, BaDyn dyn, int phase) {
   BA_ITEM(phase, it.nblk_p)
