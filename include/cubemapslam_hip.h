@@ -266,7 +266,7 @@ int cms_ba_pool_trim(int device, size_t* released);
  * path with the Schur kernel's LDS additions performed in an order that follows from the window's plan alone (kb_ba_lin_schur_runs_det /
  * kb_ba_lin_schur_edges_det), the workgroups' sums kept as slices that the solve kernel adds in slice order instead of one global copy, and a cut
  * into workgroups that does not depend on the other windows of the call.  Same input, same bits: run after run, alone or in any group of a
- * cms_ba_optimize_many call, created by cms_ba_create or cms_ba_create_many (plan kernel included); bench.py's step runs at 0.83 of the default with
+ * cms_ba_optimize_many call, created by cms_ba_create or cms_ba_create_many (plan kernel included); bench.py's step runs at 0.84-0.87 of the default with
  * it (config.deterministic).  Windows the fused chain cannot take (more than 25 free key frames, a point seen twice by a key frame) run rounds 3-5's
  * pair-owner kernel (kb_ba_schur_points, CMS_BA_DET_POINTS=1 selects it for all) -- deterministic as well.  The choice is taken at cms_ba_create and
  * travels with the window; windows of both kinds may be passed to one cms_ba_optimize_many call (they run as separate groups).  Process-wide; the

@@ -37,7 +37,7 @@ int PoseOptimization(Frame* pFrame);
 // Optimizer::LocalBundleAdjustment (Optimizer.cpp:192-451)
 void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap);
 // The reference's g2o is single-threaded (ThirdParty/g2o/config.h:4): the same window gives the same bits every time.  SetDeterministic(true) makes every
-// LocalBundleAdjustment call from then on add in a fixed order on the device (cms_ba_set_deterministic: 0.83 of the default throughput); the default adds with
+// LocalBundleAdjustment call from then on add in a fixed order on the device (cms_ba_set_deterministic: 0.84-0.87 of the default throughput); the default adds with
 // FP64 atomics and its last bits vary from run to run (DESIGN.md section 2 says what it guarantees).
 void SetDeterministic(bool on);
 bool GetDeterministic();
