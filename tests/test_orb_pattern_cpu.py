@@ -1,0 +1,41 @@
+"""The rBRIEF test pattern (a10: steered BRIEF) is reference-held DATA: 256 x 4 integers in src/ORBExtractor.cpp:121-379 (`bit_pattern_31_`), committed here as
+generated tables for the product (cubemapslam_amd/csrc/orb_pattern.inc) and the oracle (oracle/orc_pattern.inc) by tools/gen_orb_pattern.py.  Both tables must be
+the same 1024 numbers, their digest must be the one recorded when they were generated, and -- in the build container, where /root/reference exists -- they must
+be the reference's numbers as its source holds them today."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIGEST = "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+
+
+def _table(path):
+    txt = open(path).read()
+    body = txt[txt.index("{") + 1:txt.rindex("}")]
+    v = np.array([int(x) for x in re.findall(r"-?\d+", body)], np.int64)
+    assert v.size == 1024, (path, v.size)
+    return v
+
+
+def test_product_and_oracle_hold_the_same_pattern_and_its_digest_is_the_recorded_one():
+    a = _table(os.path.join(ROOT, "cubemapslam_amd", "csrc", "orb_pattern.inc"))
+    b = _table(os.path.join(ROOT, "oracle", "orc_pattern.inc"))
+    assert np.array_equal(a, b)
+    assert np.abs(a).max() <= 15                       # every test point lies inside the 31 x 31 patch
+    assert hashlib.sha256(a.astype(np.int8).tobytes()).hexdigest() == DIGEST
+
+
+def test_pattern_equals_the_reference_source_where_it_is_present():
+    ref = "/root/reference/src/ORBExtractor.cpp"
+    if not os.path.exists(ref):
+        pytest.skip("no reference checkout on this machine (the GPU box): the digest test pins the table")
+    src = open(ref).read()
+    i = src.index("bit_pattern_31_")
+    body = re.sub(r"/\*.*?\*/", "", src[src.index("=", i):src.index("};", i)], flags=re.S)
+    nums = np.array([int(x) for x in re.findall(r"-?\d+", body)], np.int64)
+    assert nums.size == 1024
+    assert np.array_equal(nums, _table(os.path.join(ROOT, "cubemapslam_amd", "csrc", "orb_pattern.inc")))
