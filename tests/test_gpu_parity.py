@@ -1383,7 +1383,7 @@ def test_kfstore_fuse_search_matches_oracle():
                                   "CMS_BA_SPLIT_WORKGROUPS", "CMS_BA_SEPARATE_REDUCE2", "CMS_BA_SEPARATE_FIRST_PASS", "CMS_BA_TE_CHUNKS=1", "CMS_BA_TE_CHUNKS=5",
                                   "CMS_BA_ITEMS_COPY_ENGINE", "CMS_BA_RELAXED_WAIT", "CMS_BA_HOST_PLAN", "CMS_BA_LEFTOVER_LOOKAHEAD=4", "CMS_BA_RUN_WG",
                                   "CMS_BA_DETERMINISTIC+CMS_BA_DET_POINTS", "CMS_BA_DETERMINISTIC+CMS_BA_NO_RUNS", "CMS_BA_DETERMINISTIC+CMS_BA_SPLIT_WORKGROUPS",
-                                  "CMS_BA_DETERMINISTIC+CMS_BA_HOST_PLAN", "CMS_BA_LEFT_BY_COST"])
+                                  "CMS_BA_DETERMINISTIC+CMS_BA_HOST_PLAN", "CMS_BA_LEFT_BY_COST", "CMS_BA_DETERMINISTIC+CMS_BA_NO_SOLVE_PRESUM", "CMS_BA_NO_GLOBAL_SUM"])
 def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     """The grouped local-BA driver has several Schur paths -- signature runs multiplied in MFMA tiles + edge-major left-overs, linearisation
     fused (default); the runs' products on the vector ALU by producer / consumer wavefront pairs (CMS_BA_RM_VALU); every point edge-major
@@ -1400,7 +1400,8 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     Round 6: the runs through one-wavefront workgroups that add straight to the window's global copy of the reduced system, the left-over chunks through
     kb_ba_lin_schur_edges behind them (CMS_BA_RUN_WG: cms_ba_schur_runwg.hip -- the re-decomposition round 5's verdict asked for; slower, kept opt-in).  The
     Second half of round 6: the left-over chunks cut by cost into the ranges of the window's last wavefronts (CMS_BA_LEFT_BY_COST: round 4's cut) instead of
-    strided over all wavefronts.  The knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""
+    strided over all wavefronts; windows that keep slices (deterministic ones, or every window under CMS_BA_NO_GLOBAL_SUM) with the solve kernel's assembly walking the
+    slices itself (CMS_BA_NO_SOLVE_PRESUM) instead of kb_ba_trial_solve3rp's pre-sum into LDS.  The knobs are read once per process: the config-4 parity tests run again in a child process with the knob set."""
     import os, subprocess, sys
     env = dict(os.environ)
     for kn in knob.split("+"):
