@@ -137,10 +137,20 @@ __device__ __forceinline__ void ba_det_publish(ba_det_ptr L, int wave, uint32_t 
 __device__ __forceinline__ void ba_det_wait(ba_det_ptr L, int wave, int nw, uint32_t t) {
   const uint32_t key = (t << 3) | (uint32_t)wave;
   const int lane = threadIdx.x & 63;
+  // (the wait is bounded by the lifetime of the workgroup's slowest wavefront, a few hundred microseconds.  Should the protocol ever be broken -- a key sequence
+  // that does not ascend, a wavefront that leaves without publishing BA_DET_DONE -- the kernel must not spin for ever on somebody's GPU: after ~2^32 shader
+  // clocks, seconds, it traps; the launch fails and the call returns an error)
+  uint32_t polls = 0;
+  long long t0 = 0;
   for (;;) {
     const uint32_t v = lane < nw ? L[lane] : BA_DET_DONE;
     if (__ballot(lane != wave && v <= key) == 0) break;
     __builtin_amdgcn_s_sleep(1);
+    if ((++polls & 0xFFFu) == 0u) {
+      const long long now = (long long)__builtin_readcyclecounter();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > (1ll << 32)) __builtin_trap();
+    }
   }
   asm volatile("" ::: "memory");
 }
