@@ -475,6 +475,14 @@ def main():
     fprio = "" if fprio == "normal" else fprio
     if fprio:
         os.environ["CMS_FRAME_STREAM_PRIORITY"] = fprio
+    # CMS_BENCH_CU_SPLIT=n (developer experiment): the frame path's streams (this context, the pose optimiser) confined to n compute units, the window groups'
+    # streams to the other 256 - n (hipExtStreamCreateWithCUMask through CMS_CTX_CU_MASK; bit i of the mask = compute unit i of the runtime's enumeration)
+    cu_split = int(os.environ.get("CMS_BENCH_CU_SPLIT", "0") or 0)
+    def cu_mask_env(lo, hi):
+        bits = sum(1 << i for i in range(lo, hi))
+        return ",".join("%08x" % ((bits >> (32 * j)) & 0xFFFFFFFF) for j in range(8))
+    if 0 < cu_split < 256:
+        os.environ["CMS_CTX_CU_MASK"] = cu_mask_env(0, cu_split)
     ctx = api.Context(camd, nfeatures=nfeat, max_batch=B, device=local_rank)
     if fprio:
         del os.environ["CMS_FRAME_STREAM_PRIORITY"]
@@ -584,6 +592,7 @@ def main():
     # one problem per frame, ~600 matched map points with 10 % mismatches, resident on the device, one launch per step
     pose_probs = [synth.pose_problem(N=args.pose_edges, F=F, seed=1000 * rank + b, outlier_frac=0.1) for b in range(B)]
     po = api.PoseOptimizer(B, sum(len(p["Xw"]) for p in pose_probs), device=local_rank)
+    os.environ.pop("CMS_CTX_CU_MASK", None)
     po.upload(pose_probs)
 
     # the windows are split into `--ba-groups` groups, each advanced in lock-step by its own host thread on its own stream
@@ -610,7 +619,10 @@ def main():
         mprio = os.environ.get("CMS_BENCH_MAP_PRIORITY", "")       # developer knob: the same for the mapping side's queues (one per window group)
         if mprio:
             os.environ["CMS_FRAME_STREAM_PRIORITY"] = mprio
+        if 0 < cu_split < 256:
+            os.environ["CMS_CTX_CU_MASK"] = cu_mask_env(cu_split, 256)
         cg = api.Context(camd, nfeatures=nfeat, max_batch=1, device=local_rank)
+        os.environ.pop("CMS_CTX_CU_MASK", None)
         if mprio:
             del os.environ["CMS_FRAME_STREAM_PRIORITY"]
         # one more slot per window: where the key frame made from this step's frame lands (cms_kfstore_put_from_frame, see mapping_side below)

@@ -14,6 +14,25 @@
 #include "cms_types.h"
 #include "orb_pattern.inc"
 
+// CMS_CTX_CU_MASK=w0,w1,...,w7 (hex words, bit i of word j = compute unit 32 j + i of the runtime's enumeration): streams created while it is set
+// (cms_ctx_create, cms_pose_create) are confined to those compute units (hipExtStreamCreateWithCUMask).  A developer experiment: the frame path and the
+// local-BA rounds on disjoint parts of the chip instead of time-sharing whole CUs; bench.py sets it around the contexts it creates
+// when CMS_BENCH_CU_SPLIT=n asks for the frame path on n CUs.  Read at every call, not once.
+static bool cms_cu_mask_from_env(uint32_t* words, int* n_words) {
+  const char* v = getenv("CMS_CTX_CU_MASK");
+  if (!v || !*v) return false;
+  int n = 0;
+  while (*v && n < 8) {
+    char* end = nullptr;
+    words[n++] = (uint32_t)strtoul(v, &end, 16);
+    if (end == v) return false;
+    v = *end == ',' ? end + 1 : end;
+    if (*end && *end != ',') return false;
+  }
+  *n_words = n;
+  return n > 0;
+}
+
 static thread_local std::string g_cms_err;
 static int cms_fail(int code, const char* what, hipError_t e = hipSuccess) {
   char buf[512];
@@ -267,6 +286,10 @@ extern "C" int cms_ctx_create(cms_ctx** out, int device, const cms_camera* cam, 
   {
     const char* pr = getenv("CMS_FRAME_STREAM_PRIORITY");
     int lo = 0, hi = 0;
+    uint32_t cu_mask[8]; int cu_words = 0;
+    if (cms_cu_mask_from_env(cu_mask, &cu_words))      // developer A/B (CMS_CTX_CU_MASK, read at every call): the context's stream confined to a set of compute units
+      e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)cu_words, cu_mask);
+    else
     if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
       e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo);
     else

@@ -42,7 +42,12 @@ extern "C" int cms_pose_create(cms_pose** out, int device, int max_frames, int m
   cms_pose* p = new cms_pose();
   p->device = device; p->cap_f = max_frames; p->cap_e = max_edges;
 #define PALLOC(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { cms_pose_free(p); return cms_fail(CMS_ERR_HIP, "hipMalloc " #ptr); } } while (0)
-  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { cms_pose_free(p); return cms_fail(CMS_ERR_HIP, "hipStreamCreate"); }
+  {
+    uint32_t cu_mask[8]; int cu_words = 0;      // (developer A/B, see cms_cu_mask_from_env)
+    const hipError_t se = cms_cu_mask_from_env(cu_mask, &cu_words) ? hipExtStreamCreateWithCUMask(&p->stream, (uint32_t)cu_words, cu_mask)
+                                                                   : hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { cms_pose_free(p); return cms_fail(CMS_ERR_HIP, "hipStreamCreate"); }
+  }
   PALLOC(p->d_off, ((size_t)max_frames + 1) * sizeof(int));
   PALLOC(p->d_Xw, (size_t)max_edges * 3 * sizeof(double)); PALLOC(p->d_obs, (size_t)max_edges * 2 * sizeof(double));
   PALLOC(p->d_inv, (size_t)max_edges * sizeof(double)); PALLOC(p->d_face, (size_t)max_edges);
