@@ -621,6 +621,9 @@ def main():
             os.environ["CMS_FRAME_STREAM_PRIORITY"] = mprio
         if 0 < cu_split < 256:
             os.environ["CMS_CTX_CU_MASK"] = cu_mask_env(cu_split, 256)
+        elif os.environ.get("CMS_BENCH_CU_GROUPS", "") != "":      # developer experiment: every window group on its own share of the chip, the frame path everywhere
+            per = 256 // max(1, n_grp)
+            os.environ["CMS_CTX_CU_MASK"] = cu_mask_env(gi * per, (gi + 1) * per)
         cg = api.Context(camd, nfeatures=nfeat, max_batch=1, device=local_rank)
         os.environ.pop("CMS_CTX_CU_MASK", None)
         if mprio:
