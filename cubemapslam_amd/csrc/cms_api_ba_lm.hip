@@ -228,7 +228,10 @@ static int ba_group_ranges(cms_ba** bas, int n) {
   if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, std::max(n, cus - reserve) / n));
   // deterministic windows: how a window's chunks are cut into workgroups decides which sums meet in which order, so the cut must not depend on
   // the company the window is optimised in -- always BA_DET_RANGES workgroups (16 windows x 16 = the chip once; the solve kernel adds the slices)
-  if (n > 0 && bas[0]->deterministic && !bas[0]->det_points) return BA_DET_RANGES;
+  if (n > 0 && bas[0]->deterministic && !bas[0]->det_points) {
+    static const int det_ranges = [] { const char* v = getenv("CMS_BA_DET_RANGES"); return v ? std::max(2, std::min(BA_SE_RANGES, atoi(v))) : BA_DET_RANGES; }();      // (developer A/B; the bits depend on it)
+    return det_ranges;
+  }
   // CMS_BA_RANGES_PER_WINDOW=k: k workgroups per window whatever the chip has (A/B: shorter workgroups let the other group's small kernels in sooner)
   static const int per_window = [] { const char* v = getenv("CMS_BA_RANGES_PER_WINDOW"); return v ? atoi(v) : 0; }();
   if (per_window > 0) R = std::max(2, std::min(BA_SE_RANGES, per_window));
