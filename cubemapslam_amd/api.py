@@ -894,7 +894,7 @@ def ba_read_many(bas):
 
 def ba_set_deterministic(on):
     """cms_ba_set_deterministic: windows created afterwards run the fixed-order (bit-repeatable) kernels, like the reference's single-threaded g2o."""
-    _chk(lib().cms_ba_set_deterministic(1 if on else 0), "cms_ba_set_deterministic")
+    _chk(lib().cms_ba_set_deterministic(int(on) if not isinstance(on, bool) else (1 if on else 0)), "cms_ba_set_deterministic")      # (an integer >= 2: workgroups per window)
 
 
 def ba_get_deterministic():

@@ -138,6 +138,7 @@ struct cms_ba {
   long long* d_plan_clk = nullptr;      // developer: CMS_BA_DP_CLK=1
   bool se_only = false;      // only the edge-major work list was built (see cms_ba_create)
   bool deterministic = false;   // created under cms_ba_set_deterministic(1): sums in a fixed order, bit-identical from run to run
+  int det_ranges = 0;           // ... cut into this many workgroups whatever the group (fixed at creation: the bits depend on it)
   bool det_points = false;      // ... through the pair-owner Schur kernel on all work lists (CMS_BA_DET_POINTS, or a window the fused chain cannot take);
                                 // otherwise through the fused chain's fixed-order kernels (kb_ba_lin_schur_runs_det / kb_ba_lin_schur_edges_det, slices)
   hipEvent_t ev_setup = nullptr;      // cms_ba_set_stream: marks the end of the window's set-up on the stream it was created on
@@ -483,7 +484,8 @@ extern "C" int cms_ba_debug_clocks(cms_ba* b, long long* out8) {
 // created while it is on carry the pair-owner kernel's work lists and run kb_ba_schur_points -- fixed summation order, bit-identical runs, like the
 // reference's single-threaded g2o (ThirdParty/g2o/config.h:4).  The choice is taken when a window is CREATED and travels with it.
 static std::atomic<int>& ba_det_mode() { static std::atomic<int> m{ba_knobs().deterministic ? 1 : 0}; return m; }
-extern "C" int cms_ba_set_deterministic(int on) { ba_det_mode().store(on ? 1 : 0); return CMS_OK; }
+// (on >= 2: the number of workgroups such windows are cut into -- see the header; 1: the default count)
+extern "C" int cms_ba_set_deterministic(int on) { ba_det_mode().store(on < 0 ? 1 : std::min(on, (int)BA_SE_RANGES)); return CMS_OK; }
 extern "C" int cms_ba_get_deterministic(void) { return ba_det_mode().load(); }
 static thread_local bool ba_tl_force_host_plan = false;      // cms_ba_linearize: the host plan for the window this thread creates next
 static std::atomic<int> ba_plans_in_flight{0};      // windows being planned right now (cms_ba_create / cms_ba_debug_plan calls of all host threads)
@@ -1225,8 +1227,11 @@ extern "C" int cms_ba_create(cms_ba** out, int device, int K, const double* pose
   HIPCHK(hipSetDevice(device));
   cms_ba* b = new cms_ba;
   b->device = device; b->K = K; b->P = P; b->E = E;
-  b->deterministic = ba_det_mode().load() != 0;
+  const int det_mode_now = ba_det_mode().load();
+  b->deterministic = det_mode_now != 0;
   if (b->deterministic) {
+    static const int det_ranges_dflt = [] { const char* v = getenv("CMS_BA_DET_RANGES"); return v ? std::max(2, std::min((int)BA_SE_RANGES, atoi(v))) : 16; }();
+    b->det_ranges = det_mode_now >= 2 ? det_mode_now : det_ranges_dflt;
     // which deterministic path: the fused chain in fixed order needs what the fused chain needs (three-lane solve: <= 25 free key frames; none of the
     // switches that take a kernel of the chain away); everything else keeps the pair-owner kernel on its own work lists
     const BaKnobs& k0 = ba_knobs();

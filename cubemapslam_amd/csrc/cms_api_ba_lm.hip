@@ -217,7 +217,6 @@ static int ba_device_cus(int dev) {
   }
   return cus;
 }
-#define BA_DET_RANGES 16
 static int ba_group_ranges(cms_ba** bas, int n) {
   const int cus = ba_device_cus(bas[0]->device);
   int R = BA_SE_RANGES;
@@ -227,11 +226,8 @@ static int ba_group_ranges(cms_ba** bas, int n) {
   static const int reserve = [] { const char* v = getenv("CMS_BA_RESERVE_CUS"); return v ? std::max(0, atoi(v)) : 0; }();
   if (!ba_knobs().fixed_ranges && n > 0) R = std::max(4, std::min(BA_SE_RANGES, std::max(n, cus - reserve) / n));
   // deterministic windows: how a window's chunks are cut into workgroups decides which sums meet in which order, so the cut must not depend on
-  // the company the window is optimised in -- always BA_DET_RANGES workgroups (16 windows x 16 = the chip once; the solve kernel adds the slices)
-  if (n > 0 && bas[0]->deterministic && !bas[0]->det_points) {
-    static const int det_ranges = [] { const char* v = getenv("CMS_BA_DET_RANGES"); return v ? std::max(2, std::min(BA_SE_RANGES, atoi(v))) : BA_DET_RANGES; }();      // (developer A/B; the bits depend on it)
-    return det_ranges;
-  }
+  // the company the window is optimised in -- always the count fixed at its creation (default 16: 16 windows x 16 = the chip once; the solve kernel adds the slices)
+  if (n > 0 && bas[0]->deterministic && !bas[0]->det_points) return std::max(2, bas[0]->det_ranges);      // (fixed when the window was created; a group's windows share it: `kind`)
   // CMS_BA_RANGES_PER_WINDOW=k: k workgroups per window whatever the chip has (A/B: shorter workgroups let the other group's small kernels in sooner)
   static const int per_window = [] { const char* v = getenv("CMS_BA_RANGES_PER_WINDOW"); return v ? atoi(v) : 0; }();
   if (per_window > 0) R = std::max(2, std::min(BA_SE_RANGES, per_window));
@@ -657,7 +653,7 @@ extern "C" int cms_ba_optimize_many(cms_ba** bas, int n, int its_robust, int its
   auto kind = [&](int w) {
     const cms_ba* b = bas[w];
     int k = b->device * 8 + (b->fast_plan ? 4 : 0) + (b->se.nchunks > 0 ? 2 : 0) + (b->deterministic ? 1 : 0);
-    if (b->deterministic) k += 1024 * (1 + (b->det_points ? 1 : 0) + 2 * (b->rm_lds > 0 ? 1 : 0) + 4 * std::max(0, std::min(15, b->se_waves)));
+    if (b->deterministic) k += 1024 * (1 + (b->det_points ? 1 : 0) + 2 * (b->rm_lds > 0 ? 1 : 0) + 4 * std::max(0, std::min(15, b->se_waves)) + 64 * b->det_ranges);
     return k;
   };
   bool one = n <= BA_MAX_GROUP;

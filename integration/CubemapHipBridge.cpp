@@ -187,7 +187,7 @@ int PoseOptimization(Frame* pFrame) {
   return n_in;                                                     // nInitialCorrespondences - nBad
 }
 
-void SetDeterministic(bool on) { cms_ba_set_deterministic(on ? 1 : 0); }
+void SetDeterministic(bool on) { cms_ba_set_deterministic(on ? 64 : 0); }      // (64 workgroups per window: this bridge optimises one window per call)
 bool GetDeterministic() { return cms_ba_get_deterministic() != 0; }
 
 void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {

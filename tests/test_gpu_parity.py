@@ -636,6 +636,34 @@ def test_ba_deterministic_windows_repeat_twenty_times_whatever_their_company():
         _ba_updates_close_or_cascade(p, g["poses"], g["points"], w, tag="deterministic K=20")
 
 
+def test_ba_deterministic_mode_with_a_workgroup_count_of_the_callers_choice():
+    """cms_ba_set_deterministic(n >= 2): windows created afterwards are cut into n workgroups (a host that optimises one window per call passes 64, the bridge does).
+    The count belongs to the window: three runs give the same bits; windows of two counts in ONE cms_ba_optimize_many call run as groups of their own and each
+    gives the bits it gives alone; iteration counts and flags are the oracle's."""
+    prob = synth.ba_problem(K=20, P=22150, obs_per_point=4, F=550, seed=77, views="track")
+    try:
+        api.ba_set_deterministic(64)
+        assert api.ba_get_deterministic()
+        runs64 = [api.ba_run(prob) for _ in range(3)]
+        w64 = api.BundleAdjuster(prob)
+        api.ba_set_deterministic(True)
+        run16 = api.ba_run(prob)
+        w16 = api.BundleAdjuster(prob)
+    finally:
+        api.ba_set_deterministic(False)
+    for g in runs64[1:]:
+        assert np.array_equal(g["poses"], runs64[0]["poses"]) and np.array_equal(g["points"], runs64[0]["points"]) and np.array_equal(g["outliers"], runs64[0]["outliers"])
+    api.ba_optimize_many([w16, w64], (5, 10))
+    o16, o64 = w16.read(), w64.read()
+    assert np.array_equal(o64[0], runs64[0]["poses"]) and np.array_equal(o64[1], runs64[0]["points"])
+    assert np.array_equal(o16[0], run16["poses"]) and np.array_equal(o16[1], run16["points"])
+    w16.close(); w64.close()
+    w = orc.ba_run(prob)
+    for g in (runs64[0], run16):
+        assert list(g["stats"].iterations_done) == list(w["stats"].iterations_done) and np.array_equal(g["outliers"], w["outliers"])
+        _ba_updates_close_or_cascade(prob, g["poses"], g["points"], w, tag="deterministic, chosen workgroup count")
+
+
 def test_ba_deterministic_mode_on_windows_of_every_solver_path():
     """Deterministic windows the fixed-order fused chain does not take fall back to deterministic kernels of their own -- 27 and 29 free key frames (no
     three-lane solve: the pair-owner kernel on the host's full plan), 39 (register-tiled scalar solve) -- and small or odd windows (two key frames, a
