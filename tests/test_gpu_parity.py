@@ -1440,17 +1440,20 @@ def test_ba_alternative_schur_paths_pass_the_same_parity_tests(knob):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("knob", ["CMS_BA_DEV_PLAN", "CMS_BA_SETUP_OWN_STREAMS", "CMS_BA_SETUP_PRIORITY=low", "CMS_BA_NO_DEV_PLAN"])
+@pytest.mark.parametrize("knob", ["CMS_BA_DEV_PLAN", "CMS_BA_SETUP_OWN_STREAMS", "CMS_BA_SETUP_PRIORITY=low", "CMS_BA_NO_DEV_PLAN", "CMS_BA_DETERMINISTIC"])
 def test_ba_window_group_calls_under_their_switches(knob):
     """cms_ba_create_many's switches, read once per process: every window of every call planned by the plan kernel whatever its flags say (CMS_BA_DEV_PLAN),
     every window set up on a pooled stream of its own as before round 6 instead of one set-up stream per building thread (CMS_BA_SETUP_OWN_STREAMS), the
     set-up streams in the low-priority class, the plan kernel switched off (CMS_BA_NO_DEV_PLAN: the flag is ignored, the host plans).  The group-call tests and
-    the C++ step driver's test run again in a child process with the switch set."""
+    the C++ step driver's test run again in a child process with the switch set.  CMS_BA_DETERMINISTIC: the same calls with every window deterministic (the group calls
+    and the C++ step driver create fixed-order windows then; the plan kernel plans them like any other)."""
     import os, subprocess, sys
     env = dict(os.environ)
     env[knob.split("=")[0]] = knob.split("=")[1] if "=" in knob else "1"
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "create_many_and_read_many" + ("" if knob == "CMS_BA_NO_DEV_PLAN" else " or small_and_odd or plan_kernel_equals")      # (those two assert that the kernel planned)
+    sel = "create_many_and_read_many" + ("" if knob in ("CMS_BA_NO_DEV_PLAN", "CMS_BA_DETERMINISTIC") else " or small_and_odd or plan_kernel_equals")      # (those two assert that the kernel planned;
+    # under CMS_BA_DETERMINISTIC the K = 40 window of small_and_odd runs the pair-owner kernel on another point order and lands 1.1e-4 from the oracle on six pose blocks -- the
+    # rounding-level sensitivity of DESIGN.md section 2, which that test's strict bar does not allow for: test_ba_deterministic_mode_on_windows_of_every_solver_path holds such windows to the cascade-aware one)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_batch_driver.py"), "-q", "-x", "-m", "gpu",
                         "-k", sel + " or cpp_driver"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
